@@ -1,0 +1,128 @@
+/*
+ * lele_hip.h -- C ABI of liblele_hip.so: an MI355X (gfx950) implementation of lele's hot path.
+ *
+ * Every entry point is what lele's FFI for the path would bind.  lele (Rust) has no GPU back end; the
+ * precedent for a C-ABI kernel boundary in the reference is its macOS cblas_sgemm binding
+ * (/root/reference/src/kernels/gemm.rs:30-47).  Each function below names the reference function it
+ * replaces (file:line under /root/reference).  INTEGRATION.md shows the Rust `extern "C"` stub for each.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types.
+ *   - every function returns 0 on success, non-zero on error; lele_hip_last_error() then describes it.
+ *     lele's kernels panic! on shape/attr violations (e.g. rnn.rs:85-90, norm.rs:218); the Rust shim turns
+ *     a non-zero code into the same panic, nothing unwinds across the FFI.
+ *   - tensors are row-major, described by LeleTensor {data, shape, rank, dtype, mem}: the C image of
+ *     lele::tensor::TensorView (src/tensor.rs:5-12).  mem says where `data` lives:
+ *       LELE_MEM_HOST   : host memory, staged to the device for the call (drop-in semantics);
+ *       LELE_MEM_DEVICE : device memory (e.g. lele_hip_buf_data() of a previous op's output);
+ *       LELE_MEM_WEIGHT : host memory that is immutable for the life of the ctx (weights.bin slices):
+ *                         uploaded (and pre-packed where an op needs it) once, cached by (ptr, bytes) --
+ *                         the analogue of lele's thread-local B_WEIGHT_CACHE (avx/quantization.rs:12-95).
+ *   - outputs go to a LeleBuf: a growable device allocation that mirrors the `out: &mut Vec<f32>` workspace
+ *     buffers of generated code (src/compiler/mod.rs:148-290).  The op resizes it, writes the result and
+ *     reports the result shape through out_shape[0..*out_rank) (capacity LELE_MAX_RANK).
+ *   - a LeleCtx owns one HIP stream; all work of a ctx is stream-ordered; lele_hip_sync() drains it.
+ *     One ctx per host thread (lele itself is single-threaded with thread-local scratch, conv2d.rs:601-603).
+ */
+#ifndef LELE_HIP_H
+#define LELE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LELE_MAX_RANK 8
+
+typedef enum { LELE_F32 = 0, LELE_I64 = 1, LELE_I32 = 2, LELE_U8 = 3, LELE_I8 = 4 } LeleDType;
+typedef enum { LELE_MEM_HOST = 0, LELE_MEM_DEVICE = 1, LELE_MEM_WEIGHT = 2 } LeleMem;
+typedef enum { LELE_ACT_NONE = 0, LELE_ACT_RELU = 1, LELE_ACT_SILU = 2 } LeleAct;
+
+typedef struct LeleTensor {
+    const void* data;
+    const int64_t* shape;
+    int32_t rank;
+    int32_t dtype; /* LeleDType */
+    int32_t mem;   /* LeleMem   */
+} LeleTensor;
+
+typedef struct LeleCtx LeleCtx;
+typedef struct LeleBuf LeleBuf;
+typedef struct LeleFrontend LeleFrontend;
+
+/* ---- context / memory ------------------------------------------------------------------------------ */
+const char* lele_hip_last_error(void);
+int lele_hip_device_count(int* count);
+int lele_hip_ctx_create(int device, LeleCtx** out);
+int lele_hip_ctx_destroy(LeleCtx* ctx);
+int lele_hip_sync(LeleCtx* ctx);
+void* lele_hip_ctx_stream(LeleCtx* ctx); /* hipStream_t */
+/* stream-ordered stopwatch (HIP events on the ctx stream) used by bench.py */
+int lele_hip_timer_start(LeleCtx* ctx);
+int lele_hip_timer_stop(LeleCtx* ctx, float* elapsed_ms);
+
+int lele_hip_buf_create(LeleCtx* ctx, LeleBuf** out);
+int lele_hip_buf_destroy(LeleBuf* buf);
+int lele_hip_buf_reserve(LeleBuf* buf, size_t bytes);
+void* lele_hip_buf_data(LeleBuf* buf);
+size_t lele_hip_buf_bytes(LeleBuf* buf); /* size of the last result in bytes */
+int lele_hip_buf_from_host(LeleBuf* buf, const void* src, size_t bytes);
+int lele_hip_buf_to_host(LeleBuf* buf, void* dst, size_t bytes); /* synchronises the ctx stream */
+
+/* ---- src/features ---------------------------------------------------------------------------------- */
+/* FeatureConfig, src/features/pipeline.rs:8-27 */
+typedef struct LeleFeatureConfig {
+    int64_t sample_rate;
+    int64_t n_mels;
+    float frame_length_ms;
+    float frame_shift_ms;
+    int64_t lfr_m;
+    int64_t lfr_n;
+} LeleFeatureConfig;
+
+/* SenseVoiceFrontend::new, pipeline.rs:38-65 (window, twiddle/bit-reverse tables, sparse mel bank, LFR) */
+int lele_hip_frontend_create(LeleCtx* ctx, const LeleFeatureConfig* cfg, LeleFrontend** out);
+int lele_hip_frontend_destroy(LeleFrontend* fe);
+/* rows of the [T, n_mels*lfr_m] result for a pcm of `pcm_len` samples; 0 <=> TensorView::empty() (pipeline.rs:70-73) */
+int lele_hip_frontend_out_rows(const LeleFrontend* fe, int64_t pcm_len, int64_t* rows, int64_t* cols,
+                               int64_t* num_frames);
+/* SenseVoiceFrontend::compute, pipeline.rs:67-193.  pcm: f32 [pcm_len] -> out [T, n_mels*lfr_m] */
+int lele_hip_frontend_compute(LeleFrontend* fe, const LeleTensor* pcm, LeleBuf* out, int64_t* out_shape,
+                              int32_t* out_rank);
+/* The same for `batch` equal-length utterances stored back to back: pcm [batch, pcm_len] ->
+ * out [batch, T, n_mels*lfr_m].  (lele loops over utterances on the host; examples/sensevoice/src/main.rs:58-86) */
+int lele_hip_frontend_compute_batch(LeleFrontend* fe, const LeleTensor* pcm, LeleBuf* out, int64_t* out_shape,
+                                    int32_t* out_rank);
+/* log-mel before LFR ([num_frames, n_mels]) of the last compute call's shape, for tests */
+int lele_hip_frontend_logmel(LeleFrontend* fe, const LeleTensor* pcm, LeleBuf* out, int64_t* out_shape,
+                             int32_t* out_rank);
+/* per-kernel stopwatch for bench.py's roofline block: while on, every compute call records HIP events around
+ * its two kernels on the ctx stream (no synchronisation); profile_read() drains the stream and returns the
+ * average duration of fe_frame_sum_kernel and fe_main_kernel over the `runs` calls since the last read. */
+int lele_hip_frontend_set_profiling(LeleFrontend* fe, int on);
+int lele_hip_frontend_profile_read(LeleFrontend* fe, float* sum_kernel_ms, float* main_kernel_ms, int64_t* runs);
+
+/* Lfr::compute, src/features/lfr.rs:18-54: [T, D] (or [1,T,D]) -> [ceil(T/n), D*m] */
+int lele_hip_lfr(LeleCtx* ctx, const LeleTensor* x, int64_t m, int64_t n, LeleBuf* out, int64_t* out_shape,
+                 int32_t* out_rank);
+/* Cmvn::compute, src/features/cmvn.rs:14-66: per-utterance mean/var over time */
+int lele_hip_cmvn(LeleCtx* ctx, const LeleTensor* x, float eps, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* Cmvn::apply_with_stats, cmvn.rs:67-92 */
+int lele_hip_cmvn_apply_with_stats(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* mean, const LeleTensor* std_,
+                                   float eps, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* RealFft::process (features/fft.rs:18-43) / rfft_forward_f32_precomputed (kernels/fft.rs:51-77):
+ * x [rows, n] real, n power of two -> re, im [rows, n/2+1] */
+int lele_hip_rfft(LeleCtx* ctx, const LeleTensor* x, LeleBuf* out_re, LeleBuf* out_im, int64_t* out_shape,
+                  int32_t* out_rank);
+/* kernels::stft / stft_power_spectrum, src/kernels/math.rs:2304-2439; window may be NULL (periodic Hann) */
+int lele_hip_stft(LeleCtx* ctx, const LeleTensor* signal, int64_t n_fft, int64_t hop_length, int64_t win_length,
+                  const LeleTensor* window, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+int lele_hip_stft_power_spectrum(LeleCtx* ctx, const LeleTensor* signal, int64_t n_fft, int64_t hop_length,
+                                 int64_t win_length, const LeleTensor* window, LeleBuf* out, int64_t* out_shape,
+                                 int32_t* out_rank);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LELE_HIP_H */

@@ -1,0 +1,191 @@
+"""ctypes binding of liblele_hip.so (the C ABI declared in include/lele_hip.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises -- there is no CPU
+fallback anywhere in lele_amd (the CPU restatement under oracle/ is test infrastructure and is never
+imported from here).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblele_hip.so")
+
+MAX_RANK = 8
+F32, I64, I32, U8, I8 = 0, 1, 2, 3, 4
+MEM_HOST, MEM_DEVICE, MEM_WEIGHT = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+
+_NP2DT = {np.dtype(np.float32): F32, np.dtype(np.int64): I64, np.dtype(np.int32): I32, np.dtype(np.uint8): U8,
+          np.dtype(np.int8): I8}
+_DT2NP = {v: k for k, v in _NP2DT.items()}
+
+
+class LeleTensor(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("shape", C.POINTER(C.c_int64)), ("rank", C.c_int32), ("dtype", C.c_int32),
+                ("mem", C.c_int32)]
+
+
+class LeleFeatureConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int64), ("n_mels", C.c_int64), ("frame_length_ms", C.c_float),
+                ("frame_shift_ms", C.c_float), ("lfr_m", C.c_int64), ("lfr_n", C.c_int64)]
+
+
+class LeleError(RuntimeError):
+    """Raised where lele's Rust kernels would panic! (shape/attribute violations) or on a HIP failure."""
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "lele_amd: %s is missing. Build it with `python -m lele_amd.build` (needs hipcc, gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.lele_hip_last_error.restype = C.c_char_p
+        _lib.lele_hip_buf_data.restype = C.c_void_p
+        _lib.lele_hip_buf_bytes.restype = C.c_size_t
+        _lib.lele_hip_ctx_stream.restype = C.c_void_p
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise LeleError(lib().lele_hip_last_error().decode("utf-8", "replace"))
+
+
+def exported_symbols():
+    """Names declared in include/lele_hip.h (parsed from the header), for the symbol-coverage test."""
+    import re
+    hdr = os.path.join(_HERE, "..", "include", "lele_hip.h")
+    txt = open(hdr).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lele_hip_\w+)\s*\(", txt)))
+
+
+class Ctx:
+    """LeleCtx: one HIP stream + staging arena + weight cache on one device."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        check(lib().lele_hip_ctx_create(C.c_int(device), C.byref(self._h)))
+        self.device = device
+        self._bufs = []
+
+    def close(self):
+        if self._h:
+            for b in self._bufs:
+                b.close()
+            lib().lele_hip_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(lib().lele_hip_sync(self._h))
+
+    def timer_start(self):
+        check(lib().lele_hip_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(lib().lele_hip_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def buf(self):
+        b = Buf(self)
+        self._bufs.append(b)
+        return b
+
+
+class Buf:
+    """LeleBuf: growable device buffer = the `out: &mut Vec<f32>` of a lele kernel call."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        check(lib().lele_hip_buf_create(ctx._h, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().lele_hip_buf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    @property
+    def ptr(self):
+        return lib().lele_hip_buf_data(self._h)
+
+    @property
+    def nbytes(self):
+        return lib().lele_hip_buf_bytes(self._h)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        check(lib().lele_hip_buf_from_host(self._h, arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)))
+        return DevTensor(self, arr.shape, arr.dtype)
+
+    def to_numpy(self, shape, dtype=np.float32):
+        out = np.empty(shape, dtype)
+        check(lib().lele_hip_buf_to_host(self._h, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)))
+        return out
+
+
+class DevTensor:
+    """A device-resident tensor: (LeleBuf, shape, dtype)."""
+
+    def __init__(self, buf, shape, dtype=np.float32):
+        self.buf = buf
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+
+    def numpy(self):
+        if int(np.prod(self.shape)) == 0:
+            return np.zeros(self.shape, self.dtype)
+        return self.buf.to_numpy(self.shape, self.dtype)
+
+
+def as_tensor(x, keep, mem=None):
+    """Build a LeleTensor for x (numpy array -> host memory, DevTensor -> device memory).
+    `keep` collects the objects that must stay alive for the duration of the call."""
+    if x is None:
+        return None
+    if isinstance(x, DevTensor):
+        shape = (C.c_int64 * max(1, len(x.shape)))(*x.shape)
+        keep.append(shape)
+        t = LeleTensor(C.c_void_p(x.buf.ptr), shape, len(x.shape), _NP2DT[x.dtype], MEM_DEVICE)
+        keep.append(t)
+        return C.byref(t)
+    a = np.asarray(x)
+    if a.dtype not in _NP2DT:
+        a = a.astype(np.float32)
+    a = np.ascontiguousarray(a)
+    keep.append(a)
+    shape = (C.c_int64 * max(1, a.ndim))(*a.shape)
+    keep.append(shape)
+    t = LeleTensor(a.ctypes.data_as(C.c_void_p), shape, a.ndim, _NP2DT[a.dtype], MEM_HOST if mem is None else mem)
+    keep.append(t)
+    return C.byref(t)
+
+
+def i64_array(vals, keep):
+    arr = (C.c_int64 * max(1, len(vals)))(*[int(v) for v in vals])
+    keep.append(arr)
+    return arr, C.c_size_t(len(vals))
+
+
+class OutShape:
+    def __init__(self):
+        self.shape = (C.c_int64 * MAX_RANK)()
+        self.rank = C.c_int32(0)
+
+    def get(self):
+        return tuple(int(self.shape[i]) for i in range(self.rank.value))

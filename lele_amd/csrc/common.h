@@ -1,0 +1,106 @@
+// common.h -- internals shared by the translation units of liblele_hip.so (context, buffers, staging).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/lele_hip.h"
+
+namespace lele {
+
+void set_error(const char* fmt, ...);
+
+#define LELE_HIP_CHECK(expr)                                                                     \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            ::lele::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                            \
+        }                                                                                        \
+    } while (0)
+
+#define LELE_REQUIRE(cond, ...)             \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::lele::set_error(__VA_ARGS__); \
+            return 2;                       \
+        }                                   \
+    } while (0)
+
+#define LELE_TRY(expr)           \
+    do {                         \
+        int _rc = (expr);        \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+inline size_t dtype_size(int dt) {
+    switch (dt) {
+        case LELE_F32: return 4;
+        case LELE_I64: return 8;
+        case LELE_I32: return 4;
+        default: return 1;
+    }
+}
+
+inline int64_t numel(const LeleTensor* t) {
+    int64_t n = 1;
+    for (int i = 0; i < t->rank; ++i) n *= t->shape[i];
+    return n;
+}
+
+}  // namespace lele
+
+// Opaque types of the C ABI -------------------------------------------------------------------------------
+struct LeleCtx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int num_cus = 256;
+    // staging arena for LELE_MEM_HOST inputs of the call in flight (bump allocator, reset per op)
+    char* arena = nullptr;
+    size_t arena_cap = 0, arena_used = 0;
+    std::vector<void*> arena_overflow;  // freed at the next reset
+    // LELE_MEM_WEIGHT cache: (host ptr, bytes, tag) -> device copy (tag distinguishes pre-packed forms)
+    std::map<std::tuple<const void*, size_t, int>, void*> weights;
+    // scratch that ops may keep across calls (grown on demand)
+    void* scratch = nullptr;
+    size_t scratch_cap = 0;
+
+    int arena_reset();
+    int arena_alloc(size_t bytes, void** out);
+    int get_scratch(size_t bytes, void** out);
+    // Returns a device pointer for tensor t (uploads host data through the arena / weight cache).
+    int dev_ptr(const LeleTensor* t, const void** out);
+};
+
+struct LeleBuf {
+    LeleCtx* ctx = nullptr;
+    void* data = nullptr;
+    size_t cap = 0;
+    size_t bytes = 0;  // size of the last result
+    int reserve(size_t n);
+};
+
+namespace lele {
+inline int set_shape(int64_t* out_shape, int32_t* out_rank, std::initializer_list<int64_t> dims) {
+    if (out_rank) *out_rank = (int32_t)dims.size();
+    if (out_shape) {
+        int i = 0;
+        for (int64_t d : dims) out_shape[i++] = d;
+    }
+    return 0;
+}
+inline int set_shape_v(int64_t* out_shape, int32_t* out_rank, const std::vector<int64_t>& dims) {
+    if (out_rank) *out_rank = (int32_t)dims.size();
+    if (out_shape)
+        for (size_t i = 0; i < dims.size(); ++i) out_shape[i] = dims[i];
+    return 0;
+}
+}  // namespace lele

@@ -1,0 +1,205 @@
+// context.hip -- LeleCtx / LeleBuf: stream, staging arena, weight cache, timers.
+#include "common.h"
+
+#include <tuple>
+
+namespace lele {
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+}  // namespace lele
+
+using namespace lele;
+
+int LeleCtx::arena_reset() {
+    arena_used = 0;
+    if (!arena_overflow.empty()) {
+        // the previous op's kernels may still read the overflow blocks: drain before freeing
+        LELE_HIP_CHECK(hipStreamSynchronize(stream));
+        for (void* p : arena_overflow) (void)hipFree(p);
+        arena_overflow.clear();
+    }
+    return 0;
+}
+
+int LeleCtx::arena_alloc(size_t bytes, void** out) {
+    size_t need = (bytes + 255) & ~size_t(255);
+    if (arena_used + need <= arena_cap) {
+        *out = arena + arena_used;
+        arena_used += need;
+        return 0;
+    }
+    void* p = nullptr;
+    LELE_HIP_CHECK(hipMalloc(&p, need ? need : 256));
+    arena_overflow.push_back(p);
+    *out = p;
+    return 0;
+}
+
+int LeleCtx::get_scratch(size_t bytes, void** out) {
+    if (bytes > scratch_cap) {
+        LELE_HIP_CHECK(hipStreamSynchronize(stream));
+        if (scratch) (void)hipFree(scratch);
+        scratch = nullptr;
+        scratch_cap = 0;
+        size_t cap = (bytes + (1 << 20)) & ~size_t((1 << 20) - 1);
+        LELE_HIP_CHECK(hipMalloc(&scratch, cap));
+        scratch_cap = cap;
+    }
+    *out = scratch;
+    return 0;
+}
+
+int LeleCtx::dev_ptr(const LeleTensor* t, const void** out) {
+    if (!t) {
+        *out = nullptr;
+        return 0;
+    }
+    size_t bytes = (size_t)numel(t) * dtype_size(t->dtype);
+    if (t->mem == LELE_MEM_DEVICE || bytes == 0) {
+        *out = t->data;
+        return 0;
+    }
+    if (t->mem == LELE_MEM_WEIGHT) {
+        auto key = std::make_tuple(t->data, bytes, 0);
+        auto it = weights.find(key);
+        if (it != weights.end()) {
+            *out = it->second;
+            return 0;
+        }
+        void* d = nullptr;
+        LELE_HIP_CHECK(hipMalloc(&d, bytes));
+        LELE_HIP_CHECK(hipMemcpyAsync(d, t->data, bytes, hipMemcpyHostToDevice, stream));
+        LELE_HIP_CHECK(hipStreamSynchronize(stream));
+        weights[key] = d;
+        *out = d;
+        return 0;
+    }
+    void* d = nullptr;
+    LELE_TRY(arena_alloc(bytes, &d));
+    // pageable host memory: hipMemcpyAsync stages it before returning, so the caller may reuse `data` at once
+    LELE_HIP_CHECK(hipMemcpyAsync(d, t->data, bytes, hipMemcpyHostToDevice, stream));
+    *out = d;
+    return 0;
+}
+
+int LeleBuf::reserve(size_t n) {
+    if (n > cap) {
+        LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (data) (void)hipFree(data);
+        data = nullptr;
+        cap = 0;
+        size_t c = (n + 4095) & ~size_t(4095);
+        LELE_HIP_CHECK(hipMalloc(&data, c));
+        cap = c;
+    }
+    bytes = n;
+    return 0;
+}
+
+extern "C" {
+
+const char* lele_hip_last_error(void) { return g_err.c_str(); }
+
+int lele_hip_device_count(int* count) {
+    LELE_HIP_CHECK(hipGetDeviceCount(count));
+    return 0;
+}
+
+int lele_hip_ctx_create(int device, LeleCtx** out) {
+    LELE_REQUIRE(out != nullptr, "ctx_create: out is NULL");
+    LELE_HIP_CHECK(hipSetDevice(device));
+    LeleCtx* c = new LeleCtx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    LELE_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount;
+    LELE_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    LELE_HIP_CHECK(hipEventCreate(&c->ev0));
+    LELE_HIP_CHECK(hipEventCreate(&c->ev1));
+    c->arena_cap = size_t(64) << 20;
+    LELE_HIP_CHECK(hipMalloc((void**)&c->arena, c->arena_cap));
+    *out = c;
+    return 0;
+}
+
+int lele_hip_ctx_destroy(LeleCtx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (void* p : c->arena_overflow) (void)hipFree(p);
+    for (auto& kv : c->weights) (void)hipFree(kv.second);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->scratch) (void)hipFree(c->scratch);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int lele_hip_sync(LeleCtx* c) {
+    LELE_REQUIRE(c, "sync: ctx is NULL");
+    LELE_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+void* lele_hip_ctx_stream(LeleCtx* c) { return c ? (void*)c->stream : nullptr; }
+
+int lele_hip_timer_start(LeleCtx* c) {
+    LELE_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    return 0;
+}
+int lele_hip_timer_stop(LeleCtx* c, float* ms) {
+    LELE_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    LELE_HIP_CHECK(hipEventSynchronize(c->ev1));
+    LELE_HIP_CHECK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return 0;
+}
+
+int lele_hip_buf_create(LeleCtx* c, LeleBuf** out) {
+    LELE_REQUIRE(c && out, "buf_create: NULL argument");
+    LeleBuf* b = new LeleBuf();
+    b->ctx = c;
+    *out = b;
+    return 0;
+}
+int lele_hip_buf_destroy(LeleBuf* b) {
+    if (!b) return 0;
+    if (b->data) {
+        (void)hipStreamSynchronize(b->ctx->stream);
+        (void)hipFree(b->data);
+    }
+    delete b;
+    return 0;
+}
+int lele_hip_buf_reserve(LeleBuf* b, size_t bytes) {
+    LELE_REQUIRE(b, "buf_reserve: buf is NULL");
+    return b->reserve(bytes);
+}
+void* lele_hip_buf_data(LeleBuf* b) { return b ? b->data : nullptr; }
+size_t lele_hip_buf_bytes(LeleBuf* b) { return b ? b->bytes : 0; }
+int lele_hip_buf_from_host(LeleBuf* b, const void* src, size_t bytes) {
+    LELE_REQUIRE(b, "buf_from_host: buf is NULL");
+    LELE_TRY(b->reserve(bytes));
+    if (bytes) {
+        LELE_HIP_CHECK(hipMemcpyAsync(b->data, src, bytes, hipMemcpyHostToDevice, b->ctx->stream));
+        LELE_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
+    }
+    return 0;
+}
+int lele_hip_buf_to_host(LeleBuf* b, void* dst, size_t bytes) {
+    LELE_REQUIRE(b, "buf_to_host: buf is NULL");
+    LELE_REQUIRE(bytes <= b->bytes, "buf_to_host: %zu bytes requested, result holds %zu", bytes, b->bytes);
+    if (bytes) LELE_HIP_CHECK(hipMemcpyAsync(dst, b->data, bytes, hipMemcpyDeviceToHost, b->ctx->stream));
+    LELE_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,585 @@
+// frontend.hip -- SenseVoiceFrontend on gfx950: PCM -> (x32768, mean, pre-emphasis, Hann) -> 512-pt FFT ->
+// power -> sparse mel -> ln -> LFR, one launch pair per batch of utterances.
+//
+// Replaces /root/reference/src/features/pipeline.rs:38-193 (+ window.rs, fft.rs, mel.rs, lfr.rs) and
+// /root/reference/src/kernels/fft.rs:51-266.
+//
+// Numerics contract: the power spectrum is BIT-EXACT with the reference's x86 path (see fe_core.h for why a
+// merely "accurate" FFT is not enough); the mel sum uses the reference's order and roundings; only logf may
+// differ in the last ulp.  Two kernels:
+//   fe_frame_sum_kernel : the per-frame mean is a sequential f32 sum of 400 samples (pipeline.rs:115-116);
+//                         reproduced exactly by giving each LANE one frame (64 independent chains per wave)
+//                         and transposing the PCM tile through LDS so every step is a conflict-free row read.
+//   fe_main_kernel      : 16 lanes per frame, 4 frames per wave pass; stages 1-5 in registers, one LDS
+//                         exchange (two 2 KB rounds), stages 6-9 in registers, power -> LDS (aliasing the
+//                         exchange buffer) -> lane-per-filter sparse mel -> ln -> LFR scatter store.
+// HBM traffic per utterance: PCM read once by each kernel (the second read is an L2/MALL hit for batches
+// below the 256 MiB Infinity Cache) + the LFR output; algorithmic bytes = 4*S + 4*T*560.
+#include "common.h"
+#include "fe_core.h"
+
+#include <math.h>
+
+#include <algorithm>
+
+using namespace lele;
+
+namespace {
+
+constexpr int kMaxMelRounds = 8;  // n_mels <= 128 on the fast path
+
+struct FeDev {                 // device tables (all owned by LeleFrontend)
+    const float* tw_re;        // 511 (+1 pad) reference twiddle table
+    const float* tw_im;
+    const float2* tw;          // same, interleaved, for LDS staging
+    const float* window;       // [frame_len]
+    const float* melw;         // [total_steps][16]: weight of step t for lane pm
+    const int* mel_start;      // [rounds*16] first bin of filter m (0 for padding filters)
+    const int* mel_step_off;   // [rounds+1] first step of each round in melw
+    int mel_rounds;            // ceil(n_mels/16)
+    int n_mels;
+    int lfr_m, lfr_n;
+};
+
+// ------------------------------------------------------------------------------------------------------
+// Kernel 1: exact sequential frame sums.  grid (ceil(F/64), batch), block 64.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kSumSeg = 32;                   // steps per LDS tile
+constexpr int kSumStride = 65;                // odd stride: column reads and the transposing writes stay spread
+
+__global__ __launch_bounds__(64) void fe_frame_sum_kernel(const float* __restrict__ pcm, int64_t utt_stride,
+                                                          int64_t num_frames, float* __restrict__ mean_out,
+                                                          int aligned16) {
+    __shared__ float tile[kSumSeg * kSumStride];
+    const int lane = threadIdx.x;
+    const int64_t f0 = (int64_t)blockIdx.x * 64;
+    const float* base = pcm + (int64_t)blockIdx.y * utt_stride;
+    const int row8 = lane >> 3, c4 = lane & 7;
+    float sum = 0.0f;  // raw_frame.iter().sum(): starts from 0.0 and adds in index order
+    for (int seg = 0; seg < (fe::kFrame + kSumSeg - 1) / kSumSeg; ++seg) {
+        const int j0 = seg * kSumSeg;
+        const int nsteps = (fe::kFrame - j0) < kSumSeg ? (fe::kFrame - j0) : kSumSeg;
+        // cooperative load: 8 lanes cover the 32 samples of one frame row, 8 rows per instruction
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + row8;
+            const int64_t f = f0 + row;
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f < num_frames && j0 + c4 * 4 < fe::kFrame) {
+                const float* src = base + f * fe::kHop + j0 + c4 * 4;
+                if (aligned16) {
+                    xv = *reinterpret_cast<const float4*>(src);
+                } else {
+                    xv.x = src[0];
+                    xv.y = src[1];
+                    xv.z = src[2];
+                    xv.w = src[3];
+                }
+            }
+            // 1. Scale (pipeline.rs:90-112): exact multiplication by 2^15
+            tile[(c4 * 4 + 0) * kSumStride + row] = xv.x * 32768.0f;
+            tile[(c4 * 4 + 1) * kSumStride + row] = xv.y * 32768.0f;
+            tile[(c4 * 4 + 2) * kSumStride + row] = xv.z * 32768.0f;
+            tile[(c4 * 4 + 3) * kSumStride + row] = xv.w * 32768.0f;
+        }
+        __syncthreads();
+        for (int jj = 0; jj < nsteps; ++jj) sum = sum + tile[jj * kSumStride + lane];
+        __syncthreads();
+    }
+    const int64_t f = f0 + lane;
+    if (f < num_frames) mean_out[(int64_t)blockIdx.y * num_frames + f] = sum / (float)fe::kFrame;  // pipeline.rs:116
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Kernel 2: FFT + mel + log + LFR.  grid (ceil(F/64), batch), block 256 = 4 independent waves of 16 frames.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kFrameXchgFloats = 544;  // 256 slots * 2 floats + 32-float skew so odd frames use the other bank half
+constexpr int kWaveLdsFloats = 4 * kFrameXchgFloats;  // 8704 B per wave
+constexpr int kPStride = 258;          // power row stride (words); 4*258 <= kWaveLdsFloats
+
+struct TwLds {  // twiddle accessor over the LDS copy (phase B: per-lane indices)
+    const float2* t;
+    __device__ __forceinline__ float2 at(int i) const { return t[i]; }
+};
+
+template <int MODE>
+__device__ __forceinline__ float lane_rot_prev(float v, int p) {
+    // value of lane (p-1) mod 16 inside this 16-lane row
+    if (MODE == 1) {
+        // DPP row_ror:1 -- data moves to the next higher lane, lane 0 receives lane 15
+        return __builtin_bit_cast(float,
+                                  __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    } else {
+        return __shfl(v, (p + 15) & 15, 16);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ pcm, int64_t utt_stride,
+                                                      int64_t num_frames, int64_t t_lfr,
+                                                      const float* __restrict__ means, FeDev tb,
+                                                      float* __restrict__ out, float* __restrict__ logmel_out) {
+    __shared__ float2 s_tw[512];
+    __shared__ __attribute__((aligned(16))) float s_x[4 * kWaveLdsFloats];
+
+    for (int i = threadIdx.x; i < 511; i += 256) s_tw[i] = tb.tw[i];
+    __syncthreads();  // the only block-level barrier; waves are independent from here on
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, p = lane & 15;
+    const int h = fe::rev4(p);
+    float* xw = s_x + wave * kWaveLdsFloats;           // this wave's exchange / power region
+    float* xf = xw + g * kFrameXchgFloats;             // this frame's 2 KB round buffer
+    const float* base = pcm + (int64_t)blockIdx.y * utt_stride;
+    const float* mean_u = means + (int64_t)blockIdx.y * num_frames;
+    const int d_out = tb.n_mels * tb.lfr_m;
+    float* out_u = out ? out + (int64_t)blockIdx.y * t_lfr * d_out : nullptr;
+    float* lm_u = logmel_out ? logmel_out + (int64_t)blockIdx.y * num_frames * tb.n_mels : nullptr;
+
+    // Hann window coefficients of this lane's samples n = p + 16 q (features/window.rs), kept in registers
+    float win[fe::kQ];
+#pragma unroll
+    for (int q = 0; q < fe::kQ; ++q) win[q] = tb.window[p + 16 * q];
+
+    for (int pass = 0; pass < 4; ++pass) {
+        const int64_t f = (int64_t)blockIdx.x * 64 + wave * 16 + pass * 4 + g;
+        const bool valid = f < num_frames;
+        const float* src = base + f * fe::kHop;
+        const float mean = valid ? mean_u[f] : 0.0f;
+
+        // 1./2. scale and mean subtraction (pipeline.rs:90-137): fl(x*32768) is exact, one rounding on the sub
+        float v[fe::kQ];
+#pragma unroll
+        for (int q = 0; q < fe::kQ; ++q) {
+            float x = valid ? src[p + 16 * q] : 0.0f;
+            v[q] = fe::fsub(fe::fmul(x, 32768.0f), mean);
+        }
+        // 3. pre-emphasis (pipeline.rs:140-142): y[n] = v[n] - 0.97*v[n-1] for n >= 1; v[n-1] lives in lane p-1
+        //    (same q) or, for p == 0, in lane 15 at q-1.  4. window (pipeline.rs:145-166).
+        float are[fe::kRegs], aim[fe::kRegs];
+#pragma unroll
+        for (int r = 0; r < fe::kRegs; ++r) {
+            are[r] = 0.0f;
+            aim[r] = 0.0f;
+        }
+        float rot_prev_q = 0.0f;
+#pragma unroll
+        for (int q = 0; q < fe::kQ; ++q) {
+            float rot = lane_rot_prev<MODE>(v[q], p);
+            float prev = (p == 0) ? rot_prev_q : rot;
+            rot_prev_q = rot;
+            float y = fe::fsub(v[q], fe::fmul(0.97f, prev));
+            if (q == 0) y = (p == 0) ? v[0] : y;  // sample 0 is not pre-emphasised
+            are[fe::rev5(q)] = fe::fmul(y, win[q]);
+        }
+
+        // 5. FFT stages 1..5 (wave-uniform twiddles straight from the table)
+        fe::phase_a_fast(are, aim, tb.tw_re, tb.tw_im);
+
+        float pw[2][8];
+        float p256 = 0.0f;
+#pragma unroll
+        for (int rho = 0; rho < 2; ++rho) {
+            // exchange: register r = rho*16 + cc of lane h  ->  lane cc, register v = h
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) {
+                const int slot = fe::xchg_slot(h, cc);
+                *reinterpret_cast<float2*>(xf + 2 * slot) = make_float2(are[rho * 16 + cc], aim[rho * 16 + cc]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            float bre[16], bim[16];
+#pragma unroll
+            for (int vv = 0; vv < 16; ++vv) {
+                float2 t = *reinterpret_cast<const float2*>(xf + 2 * fe::xchg_slot(vv, p));
+                bre[vv] = t.x;
+                bim[vv] = t.y;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // stages 6..9 with per-lane twiddles from LDS
+            {
+#pragma unroll
+                for (int s = 6; s <= 8; ++s) {
+                    const int hv = 1 << (s - 6);
+#pragma unroll
+                    for (int b = 0; b < 16; b += 2 * hv) {
+#pragma unroll
+                        for (int k = 0; k < hv; ++k) {
+                            const float2 w = s_tw[fe::tw_off(s) + k * 32 + rho * 16 + p];
+                            fe::bfly_fma(w.x, w.y, bre[b + k], bim[b + k], bre[b + hv + k], bim[b + hv + k]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float2 w = s_tw[fe::tw_off(9) + k * 32 + rho * 16 + p];
+                    float tr = fe::ffma(w.x, bre[8 + k], -fe::fmul(w.y, bim[8 + k]));
+                    float ti = fe::ffma(w.x, bim[8 + k], fe::fmul(w.y, bre[8 + k]));
+                    if (k == 0 && rho == 0) p256 = fe::fsub(bre[0], tr);  // position 256 (used by lane p == 0)
+                    bre[k] = fe::fadd(bre[k], tr);
+                    bim[k] = fe::fadd(bim[k], ti);
+                }
+            }
+            // 6. power spectrum (pipeline.rs:165-169); bins 0 and 256 have im forced to 0 (kernels/fft.rs:256-261)
+#pragma unroll
+            for (int vv = 0; vv < 8; ++vv) {
+                float im = bim[vv];
+                if (vv == 0 && rho == 0) im = (p == 0) ? 0.0f : im;
+                pw[rho][vv] = fe::power(bre[vv], im);
+            }
+        }
+        // power -> LDS, row layout [frame g][bin]; aliases the exchange region (all exchange reads are done)
+        float* prow = xw + g * kPStride;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rho = 0; rho < 2; ++rho)
+#pragma unroll
+            for (int vv = 0; vv < 8; ++vv) prow[(2 * vv + rho) * 16 + p] = pw[rho][vv];
+        if (p == 0) prow[256] = fe::power(p256, 0.0f);
+        __builtin_amdgcn_wave_barrier();
+
+        // 7. sparse mel: lane pm = p owns filters m = 16*rd + p; sequential sum += w*P (mel.rs:92-104)
+        // 8. ln(max(x, 1e-5)) (mel.rs:124-128) and LFR scatter (lfr.rs:18-54)
+        for (int rd = 0; rd < tb.mel_rounds; ++rd) {
+            const int m = rd * 16 + p;
+            const int start = tb.mel_start[m];
+            float acc = 0.0f;
+            for (int t = tb.mel_step_off[rd]; t < tb.mel_step_off[rd + 1]; ++t) {
+                const int bin = start + (t - tb.mel_step_off[rd]);
+                const float pv = prow[bin > 256 ? 256 : bin];
+                acc = fe::fadd(acc, fe::fmul(tb.melw[t * 16 + p], pv));
+            }
+            if (valid && m < tb.n_mels) {
+                const float val = logf(fmaxf(acc, 1e-5f));
+                if (lm_u) lm_u[f * tb.n_mels + m] = val;
+                if (out_u) {
+                    const int pad = (tb.lfr_m - 1) / 2;
+                    // regular targets: n*i + b - pad == f
+                    const int64_t fp = f + pad;
+                    for (int64_t b = fp % tb.lfr_n; b < tb.lfr_m; b += tb.lfr_n) {
+                        const int64_t i = (fp - b) / tb.lfr_n;
+                        if (fp - b >= 0 && i < t_lfr) out_u[i * d_out + b * tb.n_mels + m] = val;
+                    }
+                    if (f == 0) {  // left clamp: raw index < 0 reads frame 0
+                        for (int64_t i = 0; i * tb.lfr_n - pad < 0 && i < t_lfr; ++i)
+                            for (int64_t b = 0; b < tb.lfr_m && i * tb.lfr_n + b - pad < 0; ++b)
+                                out_u[i * d_out + b * tb.n_mels + m] = val;
+                    }
+                    if (f == num_frames - 1) {  // right clamp: raw index > T-1 reads the last frame
+                        for (int64_t i = t_lfr - 1; i >= 0 && i * tb.lfr_n + (tb.lfr_m - 1) - pad > f; --i)
+                            for (int64_t b = tb.lfr_m - 1; b >= 0 && i * tb.lfr_n + b - pad > f; --b)
+                                out_u[i * d_out + b * tb.n_mels + m] = val;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------------
+// Host side: mirrors SenseVoiceFrontend::new (pipeline.rs:38-65)
+// ------------------------------------------------------------------------------------------------------
+struct LeleFrontend {
+    LeleCtx* ctx = nullptr;
+    LeleFeatureConfig cfg{};
+    int64_t frame_len = 0, hop_len = 0, n_fft = 0;
+    bool fast = false;
+    int dpp_mode = 0;  // 0: __shfl, 1: DPP row_ror (selected after a self-test)
+    FeDev dev{};
+    std::vector<void*> allocs;
+    // optional per-kernel stopwatch (bench.py roofline block): 3 events per run, read back lazily
+    bool profiling = false;
+    std::vector<hipEvent_t> events;  // triples (before sum, between, after main)
+    size_t events_used = 0;
+};
+
+namespace {
+
+static const float PI_F = 3.14159265358979323846264338327950288f;
+
+void host_hann(int64_t size, std::vector<float>& w) {  // window.rs:2-13
+    w.resize(size);
+    if (size == 1) w[0] = 1.0f;
+    for (int64_t n = 0; size > 1 && n < size; ++n) w[n] = 0.5f * (1.0f - cosf(2.0f * PI_F * (float)n / (float)(size - 1)));
+}
+
+void host_twiddles(int64_t n, std::vector<float>& re, std::vector<float>& im) {  // kernels/fft.rs:136-157
+    re.clear();
+    im.clear();
+    for (int64_t size = 2; size <= n; size *= 2) {
+        int64_t half = size / 2, step = n / size;
+        for (int64_t k = 0; k < half; ++k) {
+            float angle = -2.0f * PI_F * (float)(k * step) / (float)n;
+            re.push_back(cosf(angle));
+            im.push_back(sinf(angle));
+        }
+    }
+}
+
+float hz_to_mel(float hz) { return 2595.0f * log10f(1.0f + hz / 700.0f); }       // mel.rs:1-3
+float mel_to_hz(float mel) { return 700.0f * (powf(10.0f, mel / 2595.0f) - 1.0f); }  // mel.rs:4-6
+
+// mel_filterbank + SparseMelBank::new (mel.rs:7-90): per filter (start_bin, weights[])
+void host_sparse_mel(float sr, int64_t n_fft, int64_t n_mels, float f_min, std::vector<int>& start,
+                     std::vector<std::vector<float>>& w) {
+    const float f_max = sr / 2.0f;
+    const int64_t n_freqs = n_fft / 2 + 1;
+    const float mel_min = hz_to_mel(f_min), mel_max = hz_to_mel(f_max);
+    const float mel_step = (mel_max - mel_min) / (float)(n_mels + 1);
+    std::vector<float> hz(n_mels + 2), ff(n_freqs), row(n_freqs);
+    for (int64_t i = 0; i < n_mels + 2; ++i) hz[i] = mel_to_hz(mel_min + (float)i * mel_step);
+    for (int64_t i = 0; i < n_freqs; ++i) ff[i] = (float)i * sr / (float)n_fft;
+    start.assign(n_mels, 0);
+    w.assign(n_mels, {});
+    for (int64_t i = 0; i < n_mels; ++i) {
+        const float fl = hz[i], fc = hz[i + 1], fr = hz[i + 2];
+        for (int64_t j = 0; j < n_freqs; ++j) {
+            const float f = ff[j];
+            float val = 0.0f;
+            if (f > fl && f < fc)
+                val = (f - fl) / (fc - fl);
+            else if (f >= fc && f < fr)
+                val = (fr - f) / (fr - fc);
+            row[j] = val;
+        }
+        int64_t s = 0;
+        while (s < n_freqs && row[s] == 0.0f) ++s;
+        int64_t e = n_freqs;
+        while (e > s && row[e - 1] == 0.0f) --e;
+        if (s < e) {
+            start[i] = (int)s;
+            w[i].assign(row.begin() + s, row.begin() + e);
+        }
+    }
+}
+
+template <typename T>
+int upload(LeleFrontend* fe, const std::vector<T>& v, const T** out) {
+    void* d = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    LELE_HIP_CHECK(hipMalloc(&d, bytes));
+    fe->allocs.push_back(d);
+    if (!v.empty()) LELE_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = (const T*)d;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lele_hip_frontend_create(LeleCtx* ctx, const LeleFeatureConfig* cfg, LeleFrontend** out) {
+    LELE_REQUIRE(ctx && cfg && out, "frontend_create: NULL argument");
+    LELE_REQUIRE(cfg->sample_rate > 0 && cfg->n_mels > 0 && cfg->lfr_m > 0 && cfg->lfr_n > 0,
+                 "frontend_create: invalid FeatureConfig");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    LeleFrontend* fe = new LeleFrontend();
+    fe->ctx = ctx;
+    fe->cfg = *cfg;
+    fe->frame_len = (int64_t)((float)cfg->sample_rate * cfg->frame_length_ms / 1000.0f);  // pipeline.rs:39
+    fe->n_fft = fe->frame_len > 400 ? 1024 : 512;                                        // pipeline.rs:40
+    fe->hop_len = (int64_t)((float)cfg->sample_rate * cfg->frame_shift_ms / 1000.0f);     // pipeline.rs:42
+    fe->fast = (fe->frame_len == fe::kFrame && fe->hop_len == fe::kHop && fe->n_fft == fe::kNfft &&
+                cfg->n_mels <= 16 * kMaxMelRounds);
+    if (!fe->fast) {
+        delete fe;
+        set_error("frontend_create: only frame_len=400/hop=160/n_fft=512 (16 kHz, 25/10 ms) is implemented on the "
+                  "device; got frame_len=%lld hop=%lld",
+                  (long long)fe->frame_len, (long long)fe->hop_len);
+        return 3;
+    }
+    std::vector<float> win, twr, twi;
+    host_hann(fe->frame_len, win);
+    host_twiddles(fe->n_fft, twr, twi);
+    // phase_a_fast folds table[0], table[1] == (1, -0) away: make sure this libm agrees (it must: cos(-0)=1)
+    LELE_REQUIRE(twr[0] == 1.0f && twi[0] == 0.0f && twr[1] == 1.0f && twi[1] == 0.0f,
+                 "frontend_create: unexpected twiddle table head");
+    std::vector<float2> tw(512, make_float2(0.f, 0.f));
+    for (size_t i = 0; i < twr.size(); ++i) tw[i] = make_float2(twr[i], twi[i]);
+    twr.resize(512, 0.0f);
+    twi.resize(512, 0.0f);
+    std::vector<int> mstart;
+    std::vector<std::vector<float>> mw;
+    host_sparse_mel((float)cfg->sample_rate, fe->n_fft, cfg->n_mels, 20.0f, mstart, mw);  // pipeline.rs:45-51
+    FeDev& d = fe->dev;
+    d.n_mels = (int)cfg->n_mels;
+    d.lfr_m = (int)cfg->lfr_m;
+    d.lfr_n = (int)cfg->lfr_n;
+    d.mel_rounds = (int)((cfg->n_mels + 15) / 16);
+    std::vector<int> start_pad(d.mel_rounds * 16, 0);
+    std::vector<float> melw;
+    std::vector<int> step_off(d.mel_rounds + 1, 0);
+    int off = 0;
+    for (int rd = 0; rd < d.mel_rounds; ++rd) {
+        size_t maxlen = 0;
+        for (int pm = 0; pm < 16; ++pm) {
+            int m = rd * 16 + pm;
+            if (m < cfg->n_mels) {
+                start_pad[m] = mstart[m];
+                maxlen = std::max(maxlen, mw[m].size());
+            }
+        }
+        step_off[rd] = off;
+        for (size_t t = 0; t < maxlen; ++t)
+            for (int pm = 0; pm < 16; ++pm) {
+                int m = rd * 16 + pm;
+                melw.push_back((m < cfg->n_mels && t < mw[m].size()) ? mw[m][t] : 0.0f);
+            }
+        off += (int)maxlen;
+    }
+    step_off[d.mel_rounds] = off;
+    int rc = 0;
+    rc |= upload(fe, twr, &d.tw_re);
+    rc |= upload(fe, twi, &d.tw_im);
+    rc |= upload(fe, tw, &d.tw);
+    rc |= upload(fe, win, &d.window);
+    rc |= upload(fe, melw, &d.melw);
+    rc |= upload(fe, start_pad, &d.mel_start);
+    rc |= upload(fe, step_off, &d.mel_step_off);
+    if (rc) {
+        lele_hip_frontend_destroy(fe);
+        return rc;
+    }
+    const char* env = getenv("LELE_HIP_FE_DPP");
+    fe->dpp_mode = env ? atoi(env) : 0;
+    *out = fe;
+    return 0;
+}
+
+int lele_hip_frontend_destroy(LeleFrontend* fe) {
+    if (!fe) return 0;
+    (void)hipStreamSynchronize(fe->ctx->stream);
+    for (void* p : fe->allocs) (void)hipFree(p);
+    for (hipEvent_t e : fe->events) (void)hipEventDestroy(e);
+    delete fe;
+    return 0;
+}
+
+int lele_hip_frontend_out_rows(const LeleFrontend* fe, int64_t pcm_len, int64_t* rows, int64_t* cols,
+                               int64_t* num_frames) {
+    LELE_REQUIRE(fe, "frontend_out_rows: fe is NULL");
+    int64_t nf = 0, t = 0;
+    if (pcm_len >= fe->frame_len) {  // pipeline.rs:70-73
+        nf = (pcm_len - fe->frame_len) / fe->hop_len + 1;
+        t = (nf + fe->cfg.lfr_n - 1) / fe->cfg.lfr_n;  // lfr.rs:33
+    }
+    if (rows) *rows = t;
+    if (cols) *cols = fe->cfg.n_mels * fe->cfg.lfr_m;
+    if (num_frames) *num_frames = nf;
+    return 0;
+}
+
+static int fe_run(LeleFrontend* fe, const LeleTensor* pcm, int64_t batch, int64_t pcm_len, LeleBuf* out,
+                  bool want_logmel, int64_t* out_shape, int32_t* out_rank) {
+    LeleCtx* ctx = fe->ctx;
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    LELE_REQUIRE(pcm->dtype == LELE_F32, "frontend: pcm must be f32");
+    int64_t t_lfr = 0, cols = 0, nf = 0;
+    lele_hip_frontend_out_rows(fe, pcm_len, &t_lfr, &cols, &nf);
+    if (nf == 0 || batch == 0) {  // TensorView::empty()
+        out->bytes = 0;
+        if (out_rank) *out_rank = 0;
+        return 0;
+    }
+    LELE_TRY(ctx->arena_reset());
+    const void* dpcm = nullptr;
+    LELE_TRY(ctx->dev_ptr(pcm, &dpcm));
+    void* dmean = nullptr;
+    LELE_TRY(ctx->get_scratch((size_t)batch * nf * sizeof(float), &dmean));
+    const size_t out_elems = want_logmel ? (size_t)batch * nf * fe->cfg.n_mels : (size_t)batch * t_lfr * cols;
+    LELE_TRY(out->reserve(out_elems * sizeof(float)));
+    const int aligned16 = ((uintptr_t)dpcm % 16 == 0) && (pcm_len % 4 == 0);
+    dim3 grid((unsigned)((nf + 63) / 64), (unsigned)batch);
+    hipEvent_t* ev = nullptr;
+    if (fe->profiling) {
+        if (fe->events_used + 3 > fe->events.size()) {
+            for (int i = 0; i < 3; ++i) {
+                hipEvent_t e;
+                LELE_HIP_CHECK(hipEventCreate(&e));
+                fe->events.push_back(e);
+            }
+        }
+        ev = &fe->events[fe->events_used];
+        fe->events_used += 3;
+        LELE_HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
+    }
+    hipLaunchKernelGGL(fe_frame_sum_kernel, grid, dim3(64), 0, ctx->stream, (const float*)dpcm, pcm_len, nf,
+                       (float*)dmean, aligned16);
+    if (ev) LELE_HIP_CHECK(hipEventRecord(ev[1], ctx->stream));
+    float* o = want_logmel ? nullptr : (float*)out->data;
+    float* lm = want_logmel ? (float*)out->data : nullptr;
+    if (fe->dpp_mode == 1)
+        hipLaunchKernelGGL(fe_main_kernel<1>, grid, dim3(256), 0, ctx->stream, (const float*)dpcm, pcm_len, nf, t_lfr,
+                           (const float*)dmean, fe->dev, o, lm);
+    else
+        hipLaunchKernelGGL(fe_main_kernel<0>, grid, dim3(256), 0, ctx->stream, (const float*)dpcm, pcm_len, nf, t_lfr,
+                           (const float*)dmean, fe->dev, o, lm);
+    LELE_HIP_CHECK(hipGetLastError());
+    if (ev) LELE_HIP_CHECK(hipEventRecord(ev[2], ctx->stream));
+    if (want_logmel) {
+        if (batch == 1) return set_shape(out_shape, out_rank, {nf, fe->cfg.n_mels});
+        return set_shape(out_shape, out_rank, {batch, nf, fe->cfg.n_mels});
+    }
+    return 0;
+}
+
+int lele_hip_frontend_compute(LeleFrontend* fe, const LeleTensor* pcm, LeleBuf* out, int64_t* out_shape,
+                              int32_t* out_rank) {
+    LELE_REQUIRE(fe && pcm && out, "frontend_compute: NULL argument");
+    const int64_t n = numel(pcm);
+    LELE_TRY(fe_run(fe, pcm, 1, n, out, false, out_shape, out_rank));
+    if (out->bytes == 0) return 0;
+    int64_t t = 0, cols = 0;
+    lele_hip_frontend_out_rows(fe, n, &t, &cols, nullptr);
+    return set_shape(out_shape, out_rank, {t, cols});
+}
+
+int lele_hip_frontend_compute_batch(LeleFrontend* fe, const LeleTensor* pcm, LeleBuf* out, int64_t* out_shape,
+                                    int32_t* out_rank) {
+    LELE_REQUIRE(fe && pcm && out, "frontend_compute_batch: NULL argument");
+    LELE_REQUIRE(pcm->rank == 2, "frontend_compute_batch: pcm must be [batch, pcm_len]");
+    const int64_t batch = pcm->shape[0], n = pcm->shape[1];
+    LELE_TRY(fe_run(fe, pcm, batch, n, out, false, out_shape, out_rank));
+    if (out->bytes == 0) return 0;
+    int64_t t = 0, cols = 0;
+    lele_hip_frontend_out_rows(fe, n, &t, &cols, nullptr);
+    return set_shape(out_shape, out_rank, {batch, t, cols});
+}
+
+int lele_hip_frontend_logmel(LeleFrontend* fe, const LeleTensor* pcm, LeleBuf* out, int64_t* out_shape,
+                             int32_t* out_rank) {
+    LELE_REQUIRE(fe && pcm && out, "frontend_logmel: NULL argument");
+    if (pcm->rank == 2) return fe_run(fe, pcm, pcm->shape[0], pcm->shape[1], out, true, out_shape, out_rank);
+    return fe_run(fe, pcm, 1, numel(pcm), out, true, out_shape, out_rank);
+}
+
+int lele_hip_frontend_set_profiling(LeleFrontend* fe, int on) {
+    LELE_REQUIRE(fe, "frontend_set_profiling: fe is NULL");
+    fe->profiling = on != 0;
+    fe->events_used = 0;
+    return 0;
+}
+
+int lele_hip_frontend_profile_read(LeleFrontend* fe, float* sum_kernel_ms, float* main_kernel_ms, int64_t* runs) {
+    LELE_REQUIRE(fe, "frontend_profile_read: fe is NULL");
+    LELE_HIP_CHECK(hipStreamSynchronize(fe->ctx->stream));
+    double a = 0, b = 0;
+    const size_t n = fe->events_used / 3;
+    for (size_t i = 0; i < n; ++i) {
+        float m0 = 0, m1 = 0;
+        LELE_HIP_CHECK(hipEventElapsedTime(&m0, fe->events[3 * i], fe->events[3 * i + 1]));
+        LELE_HIP_CHECK(hipEventElapsedTime(&m1, fe->events[3 * i + 1], fe->events[3 * i + 2]));
+        a += m0;
+        b += m1;
+    }
+    if (sum_kernel_ms) *sum_kernel_ms = n ? (float)(a / n) : 0.f;
+    if (main_kernel_ms) *main_kernel_ms = n ? (float)(b / n) : 0.f;
+    if (runs) *runs = (int64_t)n;
+    fe->events_used = 0;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+"""TensorView: host mirror of lele::tensor::TensorView (/root/reference/src/tensor.rs:5-85).
+
+The Rust type is a borrowed-or-owned flat row-major buffer plus a shape.  Here `data` is either a numpy
+array (host) or a device-resident `_lib.DevTensor` (the result of a kernel call).  Device results are
+materialised on the host lazily by `.numpy()` / `.data` -- the analogue of the Rust shim's Deref<[T]> with
+lazy D2H -- so chains of kernel calls never leave HBM.
+"""
+import numpy as np
+
+from . import _lib
+
+
+class TensorView:
+    def __init__(self, data, shape=None):
+        if isinstance(data, _lib.DevTensor):
+            self._dev = data if shape is None else _lib.DevTensor(data.buf, shape, data.dtype)
+            self._host = None
+            self.shape = tuple(self._dev.shape)
+        else:
+            a = np.asarray(data)
+            if a.dtype not in (np.float32, np.int64, np.int32, np.uint8, np.int8):
+                a = a.astype(np.float32)
+            if shape is not None:
+                shape = tuple(int(s) for s in shape)
+                assert a.size == int(np.prod(shape, dtype=np.int64)), "Data length mismatch"  # tensor.rs:29
+                a = a.reshape(shape)
+            self._host = np.ascontiguousarray(a)
+            self._dev = None
+            self.shape = tuple(self._host.shape)
+
+    # constructors named as in tensor.rs:27-71
+    @classmethod
+    def new(cls, data, shape):
+        return cls(data, shape)
+
+    from_owned = new
+    from_slice = new
+
+    @classmethod
+    def empty(cls):
+        t = cls(np.zeros((0,), np.float32))
+        t.shape = ()
+        return t
+
+    def to_owned(self):
+        return TensorView(self.numpy().copy())
+
+    def dim(self):
+        return len(self.shape)
+
+    def size(self, dim):
+        return self.shape[dim]
+
+    @property
+    def dtype(self):
+        return self._dev.dtype if self._dev is not None else self._host.dtype
+
+    @property
+    def is_device(self):
+        return self._dev is not None
+
+    def numpy(self):
+        if self._host is None:
+            self._host = self._dev.numpy().reshape(self.shape)
+        return self._host
+
+    @property
+    def data(self):
+        """flat row-major values, like TensorView.data in Rust"""
+        return self.numpy().reshape(-1)
+
+    def raw(self):
+        """what to hand to the C ABI: the device tensor if there is one, else the numpy array"""
+        return self._dev if self._dev is not None else self._host
+
+    def __repr__(self):
+        return "TensorView(shape=%s, dtype=%s, %s)" % (self.shape, self.dtype, "device" if self.is_device else "host")
+
+
+def unwrap(x):
+    """TensorView | numpy | None -> object accepted by _lib.as_tensor"""
+    if x is None:
+        return None
+    if isinstance(x, TensorView):
+        return x.raw()
+    return x

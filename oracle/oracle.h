@@ -1,0 +1,65 @@
+/*
+ * oracle.h -- CPU restatement of miuda-ai/lele's hot path (x86_64 AVX2+FMA branch).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker / the reported CPU baseline -- never as the
+ * thing measured or shipped.  lele_amd/ never links, imports or dlopens it.
+ *
+ * Parity status: PINNED against every golden vector / known-answer test the
+ * reference's own test-suite holds for the path (tests/test_oracle_golden.py lists
+ * them with reference file:line).  The reference itself (Rust 2024, nightly) cannot
+ * be compiled in this image (no rustc/cargo), so there is no oracle/_ref build.
+ * The f32 GEMM inside lele is the third-party crate faer 0.24 (not vendored under
+ * /root/reference); the oracle restates GEMM as a k-ordered f32 accumulation and
+ * additionally offers an f64-accumulated variant -- bit-level parity with faer's
+ * summation order is UNPINNED.
+ *
+ * All functions are plain C ABI over host pointers.  Citations are file:line in
+ * /root/reference.
+ */
+#ifndef LELE_ORACLE_H
+#define LELE_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- src/features + src/kernels/fft.rs ------------------------------------------------ */
+void orc_hann_window(int64_t size, float* out);                     /* features/window.rs:2-13   */
+void orc_precompute_twiddles(int64_t n, float* tw_re, float* tw_im, /* kernels/fft.rs:136-157    */
+                             int64_t* bit_rev);
+/* mode 0: rfft_forward_f32 (fft.rs:2-49), 1: precomputed scalar (79-134), 2: AVX2 (172-266) */
+void orc_rfft(const float* input, int64_t n, float* out_re, float* out_im, int mode);
+float orc_hz_to_mel_htk(float hz);                                  /* features/mel.rs:1-3       */
+float orc_mel_to_hz_htk(float mel);                                 /* features/mel.rs:4-6       */
+void orc_mel_filterbank(float sample_rate, int64_t n_fft, int64_t n_mels, float f_min,
+                        float f_max /* <0 => None */, float* weights /* [n_mels, n_fft/2+1] */);
+/* SparseMelBank::new + apply (mel.rs:48-105) */
+void orc_sparse_mel_apply(float sample_rate, int64_t n_fft, int64_t n_mels, float f_min, float f_max,
+                          const float* power, float* out);
+/* SenseVoiceFrontend::compute (features/pipeline.rs:38-193).  Returns number of LFR rows
+ * (0 when pcm_len < frame_len == TensorView::empty()).  `mel_out` (may be NULL) receives the
+ * intermediate log-mel [num_frames, n_mels]; `out` receives [t_lfr, n_mels*lfr_m]. */
+int64_t orc_frontend_shape(int64_t pcm_len, int64_t sample_rate, float frame_length_ms, float frame_shift_ms,
+                           int64_t lfr_n, int64_t* num_frames);
+int64_t orc_frontend_compute(const float* pcm, int64_t pcm_len, int64_t sample_rate, int64_t n_mels,
+                             float frame_length_ms, float frame_shift_ms, int64_t lfr_m, int64_t lfr_n,
+                             float* mel_out, float* out);
+void orc_lfr(const float* in, int64_t t, int64_t d, int64_t m, int64_t n, float* out); /* lfr.rs:18-54 */
+void orc_cmvn(const float* in, int64_t t, int64_t d, float eps, float* out);          /* cmvn.rs:14-66 */
+void orc_cmvn_apply_with_stats(const float* in, int64_t t, int64_t d, float eps, const float* mean,
+                               const float* std_, float* out);                         /* cmvn.rs:67-92 */
+/* ONNX STFT op (kernels/math.rs:2304-2370) and stft_power_spectrum (2372-2439).
+ * window==NULL => periodic Hann over win_length.  Returns num_frames. */
+int64_t orc_stft(const float* signal, int64_t len, int64_t n_fft, int64_t hop, int64_t win_length,
+                 const float* window, float* out /* [frames, n_fft/2+1, 2] */);
+int64_t orc_stft_power(const float* signal, int64_t len, int64_t n_fft, int64_t hop, int64_t win_length,
+                       const float* window, float* out /* [frames, n_fft/2+1] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
