@@ -37,6 +37,7 @@ struct FeDev {                 // device tables (all owned by LeleFrontend)
     const int* mel_start;      // [rounds*16] first bin of filter m (0 for padding filters)
     const int* mel_step_off;   // [rounds+1] first step of each round in melw
     int mel_rounds;            // ceil(n_mels/16)
+    int mel_steps;             // total steps (rows of melw)
     int n_mels;
     int lfr_m, lfr_n;
 };
@@ -44,47 +45,72 @@ struct FeDev {                 // device tables (all owned by LeleFrontend)
 // ------------------------------------------------------------------------------------------------------
 // Kernel 1: exact sequential frame sums.  grid (ceil(F/64), batch), block 64.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kSumSeg = 32;                   // steps per LDS tile
-constexpr int kSumStride = 65;                // odd stride: column reads and the transposing writes stay spread
+constexpr int kSumRows = 66;     // hop-sized rows covered by 64 consecutive frames (64 + 2 of overlap, 400 = 2.5 hops)
+constexpr int kSumPitch = 164;   // floats per row (656 B, 16-B aligned): lane l reads row l(+1,+2) with ds_read_b128
+                                 // at word 164*l = 36*l (mod 64) -> a 16-lane group covers all 64 banks exactly once
 
 __global__ __launch_bounds__(64) void fe_frame_sum_kernel(const float* __restrict__ pcm, int64_t utt_stride,
-                                                          int64_t num_frames, float* __restrict__ mean_out,
-                                                          int aligned16) {
-    __shared__ float tile[kSumSeg * kSumStride];
+                                                          int64_t pcm_len, int64_t num_frames,
+                                                          float* __restrict__ mean_out, int aligned16) {
+    // The 64 frames of this block span one contiguous run of samples; it is read from HBM exactly once
+    // (linear, coalesced float4) and laid out as [hop row][offset in hop]: frame i = rows i, i+1 and half of i+2.
+    __shared__ __attribute__((aligned(16))) float tile[kSumRows * kSumPitch];
     const int lane = threadIdx.x;
     const int64_t f0 = (int64_t)blockIdx.x * 64;
     const float* base = pcm + (int64_t)blockIdx.y * utt_stride;
-    const int row8 = lane >> 3, c4 = lane & 7;
-    float sum = 0.0f;  // raw_frame.iter().sum(): starts from 0.0 and adds in index order
-    for (int seg = 0; seg < (fe::kFrame + kSumSeg - 1) / kSumSeg; ++seg) {
-        const int j0 = seg * kSumSeg;
-        const int nsteps = (fe::kFrame - j0) < kSumSeg ? (fe::kFrame - j0) : kSumSeg;
-        // cooperative load: 8 lanes cover the 32 samples of one frame row, 8 rows per instruction
+    const int64_t s0 = f0 * fe::kHop;  // first sample of the run
+    constexpr int kVecPerRow = fe::kHop / 4;
+    constexpr int kVecs = kSumRows * kVecPerRow;
+    constexpr int kIters = (kVecs + 63) / 64;  // 42 float4 per lane
+    constexpr int kBatch = 14;                  // loads kept in flight together (56 VGPRs)
+    static_assert(kIters % kBatch == 0, "batching");
+    for (int b0 = 0; b0 < kIters; b0 += kBatch) {
+        float4 st[kBatch];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + row8;
-            const int64_t f = f0 + row;
-            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < num_frames && j0 + c4 * 4 < fe::kFrame) {
-                const float* src = base + f * fe::kHop + j0 + c4 * 4;
-                if (aligned16) {
-                    xv = *reinterpret_cast<const float4*>(src);
-                } else {
-                    xv.x = src[0];
-                    xv.y = src[1];
-                    xv.z = src[2];
-                    xv.w = src[3];
-                }
+        for (int u = 0; u < kBatch; ++u) {
+            const int idx = (b0 + u) * 64 + lane;
+            int64_t s = s0 + 4 * (int64_t)idx;
+            // clamp instead of branching so that every load of the batch is issued before the first wait; lanes
+            // that would read past the utterance only ever feed frames >= num_frames, whose sums are discarded
+            if (s + 3 >= pcm_len) s = aligned16 ? ((pcm_len - 4) & ~int64_t(3)) : (pcm_len - 4);
+            if (s < 0) s = 0;
+            const float* src = base + s;
+            if (aligned16) {
+                st[u] = *reinterpret_cast<const float4*>(src);
+            } else {
+                st[u] = make_float4(src[0], src[1], src[2], src[3]);
             }
-            // 1. Scale (pipeline.rs:90-112): exact multiplication by 2^15
-            tile[(c4 * 4 + 0) * kSumStride + row] = xv.x * 32768.0f;
-            tile[(c4 * 4 + 1) * kSumStride + row] = xv.y * 32768.0f;
-            tile[(c4 * 4 + 2) * kSumStride + row] = xv.z * 32768.0f;
-            tile[(c4 * 4 + 3) * kSumStride + row] = xv.w * 32768.0f;
         }
-        __syncthreads();
-        for (int jj = 0; jj < nsteps; ++jj) sum = sum + tile[jj * kSumStride + lane];
-        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int idx = (b0 + u) * 64 + lane;
+            if (idx < kVecs) {
+                float4 xv = st[u];
+                // 1. Scale (pipeline.rs:90-112): exact multiplication by 2^15
+                xv.x *= 32768.0f;
+                xv.y *= 32768.0f;
+                xv.z *= 32768.0f;
+                xv.w *= 32768.0f;
+                const int row = idx / kVecPerRow, c = idx - row * kVecPerRow;
+                *reinterpret_cast<float4*>(&tile[row * kSumPitch + 4 * c]) = xv;
+            }
+        }
+    }
+    __syncthreads();
+    // 2. raw_frame.iter().sum() (pipeline.rs:115): one lane per frame, 400 adds in index order
+    float sum = 0.0f;
+#pragma unroll
+    for (int seg = 0; seg < 3; ++seg) {
+        const float* rowp = &tile[(lane + seg) * kSumPitch];
+        const int nvec = seg < 2 ? kVecPerRow : (fe::kFrame - 2 * fe::kHop) / 4;
+#pragma unroll 10
+        for (int k = 0; k < nvec; ++k) {
+            const float4 r = *reinterpret_cast<const float4*>(rowp + 4 * k);
+            sum = sum + r.x;
+            sum = sum + r.y;
+            sum = sum + r.z;
+            sum = sum + r.w;
+        }
     }
     const int64_t f = f0 + lane;
     if (f < num_frames) mean_out[(int64_t)blockIdx.y * num_frames + f] = sum / (float)fe::kFrame;  // pipeline.rs:116
@@ -93,7 +119,7 @@ __global__ __launch_bounds__(64) void fe_frame_sum_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------------
 // Kernel 2: FFT + mel + log + LFR.  grid (ceil(F/64), batch), block 256 = 4 independent waves of 16 frames.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kFrameXchgFloats = 544;  // 256 slots * 2 floats + 32-float skew so odd frames use the other bank half
+constexpr int kFrameXchgFloats = 2 * 16 * fe::kXchgPitch;  // 544 floats = 2176 B: odd frames start 32 banks later
 constexpr int kWaveLdsFloats = 4 * kFrameXchgFloats;  // 8704 B per wave
 constexpr int kPStride = 258;          // power row stride (words); 4*258 <= kWaveLdsFloats
 
@@ -114,15 +140,27 @@ __device__ __forceinline__ float lane_rot_prev(float v, int p) {
     }
 }
 
-template <int MODE>
+// STDMEL: the mel bank has the round structure of the default config (80 mels @16 kHz/512: 5 rounds of
+// 3,4,6,10,17 steps, no filter reaching past bin 256) -- verified on the host -- so the lane-per-filter dot
+// products are fully unrolled with immediate LDS offsets; otherwise the table-driven loop is used.
+constexpr int kStdMelLen[5] = {3, 4, 6, 10, 17};
+constexpr int kStdMelOff[6] = {0, 3, 7, 13, 23, 40};
+
+template <int MODE, bool STDMEL>
 __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ pcm, int64_t utt_stride,
                                                       int64_t num_frames, int64_t t_lfr,
                                                       const float* __restrict__ means, FeDev tb,
                                                       float* __restrict__ out, float* __restrict__ logmel_out) {
     __shared__ float2 s_tw[512];
     __shared__ __attribute__((aligned(16))) float s_x[4 * kWaveLdsFloats];
+    __shared__ int s_mstart[16 * kMaxMelRounds];
+    __shared__ int s_moff[kMaxMelRounds + 1];
+    extern __shared__ float s_melw[];  // [mel_steps][16]
 
     for (int i = threadIdx.x; i < 511; i += 256) s_tw[i] = tb.tw[i];
+    for (int i = threadIdx.x; i < tb.mel_steps * 16; i += 256) s_melw[i] = tb.melw[i];
+    if (threadIdx.x < tb.mel_rounds * 16) s_mstart[threadIdx.x] = tb.mel_start[threadIdx.x];
+    if (threadIdx.x <= tb.mel_rounds) s_moff[threadIdx.x] = tb.mel_step_off[threadIdx.x];
     __syncthreads();  // the only block-level barrier; waves are independent from here on
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -141,27 +179,35 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
 #pragma unroll
     for (int q = 0; q < fe::kQ; ++q) win[q] = tb.window[p + 16 * q];
 
+    // raw PCM of the next pass is fetched while the current pass computes (software prefetch): the loads are
+    // unconditional (clamped to frame 0 for the tail) so that all 25 are in flight together.
+    float xr[fe::kQ];
+    float mean_next;
+    auto issue_loads = [&](int pass) {
+        const int64_t f = (int64_t)blockIdx.x * 64 + wave * 16 + pass * 4 + g;
+        const int64_t fc = f < num_frames ? f : 0;
+        const float* src = base + fc * fe::kHop + p;
+        mean_next = mean_u[fc];
+#pragma unroll
+        for (int q = 0; q < fe::kQ; ++q) xr[q] = src[16 * q];
+    };
+    issue_loads(0);
+
     for (int pass = 0; pass < 4; ++pass) {
         const int64_t f = (int64_t)blockIdx.x * 64 + wave * 16 + pass * 4 + g;
         const bool valid = f < num_frames;
-        const float* src = base + f * fe::kHop;
-        const float mean = valid ? mean_u[f] : 0.0f;
+        const float mean = mean_next;
 
         // 1./2. scale and mean subtraction (pipeline.rs:90-137): fl(x*32768) is exact, one rounding on the sub
         float v[fe::kQ];
 #pragma unroll
-        for (int q = 0; q < fe::kQ; ++q) {
-            float x = valid ? src[p + 16 * q] : 0.0f;
-            v[q] = fe::fsub(fe::fmul(x, 32768.0f), mean);
-        }
+        for (int q = 0; q < fe::kQ; ++q) v[q] = fe::fsub(fe::fmul(xr[q], 32768.0f), mean);
+        if (pass + 1 < 4) issue_loads(pass + 1);
         // 3. pre-emphasis (pipeline.rs:140-142): y[n] = v[n] - 0.97*v[n-1] for n >= 1; v[n-1] lives in lane p-1
         //    (same q) or, for p == 0, in lane 15 at q-1.  4. window (pipeline.rs:145-166).
-        float are[fe::kRegs], aim[fe::kRegs];
+        float xin[fe::kRegs];
 #pragma unroll
-        for (int r = 0; r < fe::kRegs; ++r) {
-            are[r] = 0.0f;
-            aim[r] = 0.0f;
-        }
+        for (int r = 0; r < fe::kRegs; ++r) xin[r] = 0.0f;
         float rot_prev_q = 0.0f;
 #pragma unroll
         for (int q = 0; q < fe::kQ; ++q) {
@@ -170,11 +216,12 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
             rot_prev_q = rot;
             float y = fe::fsub(v[q], fe::fmul(0.97f, prev));
             if (q == 0) y = (p == 0) ? v[0] : y;  // sample 0 is not pre-emphasised
-            are[fe::rev5(q)] = fe::fmul(y, win[q]);
+            xin[fe::rev5(q)] = fe::fmul(y, win[q]);
         }
 
         // 5. FFT stages 1..5 (wave-uniform twiddles straight from the table)
-        fe::phase_a_fast(are, aim, tb.tw_re, tb.tw_im);
+        fe::cf a[fe::kRegs];
+        fe::phase_a_fast(xin, a, tb.tw_re, tb.tw_im);
 
         float pw[2][8];
         float p256 = 0.0f;
@@ -185,47 +232,26 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc) {
                 const int slot = fe::xchg_slot(h, cc);
-                *reinterpret_cast<float2*>(xf + 2 * slot) = make_float2(are[rho * 16 + cc], aim[rho * 16 + cc]);
+                *reinterpret_cast<float2*>(xf + 2 * slot) = make_float2(a[rho * 16 + cc].x, a[rho * 16 + cc].y);
             }
             __builtin_amdgcn_wave_barrier();
-            float bre[16], bim[16];
+            fe::cf bq[16];
 #pragma unroll
             for (int vv = 0; vv < 16; ++vv) {
-                float2 t = *reinterpret_cast<const float2*>(xf + 2 * fe::xchg_slot(vv, p));
-                bre[vv] = t.x;
-                bim[vv] = t.y;
+                const float2 t = *reinterpret_cast<const float2*>(xf + 2 * fe::xchg_slot(vv, p));
+                bq[vv] = fe::cmk(t.x, t.y);
             }
             __builtin_amdgcn_wave_barrier();
             // stages 6..9 with per-lane twiddles from LDS
-            {
-#pragma unroll
-                for (int s = 6; s <= 8; ++s) {
-                    const int hv = 1 << (s - 6);
-#pragma unroll
-                    for (int b = 0; b < 16; b += 2 * hv) {
-#pragma unroll
-                        for (int k = 0; k < hv; ++k) {
-                            const float2 w = s_tw[fe::tw_off(s) + k * 32 + rho * 16 + p];
-                            fe::bfly_fma(w.x, w.y, bre[b + k], bim[b + k], bre[b + hv + k], bim[b + hv + k]);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float2 w = s_tw[fe::tw_off(9) + k * 32 + rho * 16 + p];
-                    float tr = fe::ffma(w.x, bre[8 + k], -fe::fmul(w.y, bim[8 + k]));
-                    float ti = fe::ffma(w.x, bim[8 + k], fe::fmul(w.y, bre[8 + k]));
-                    if (k == 0 && rho == 0) p256 = fe::fsub(bre[0], tr);  // position 256 (used by lane p == 0)
-                    bre[k] = fe::fadd(bre[k], tr);
-                    bim[k] = fe::fadd(bim[k], ti);
-                }
-            }
+            float re256 = 0.0f;
+            fe::phase_b(bq, p, rho, [&](int i) { const float2 w = s_tw[i]; return fe::cmk(w.x, w.y); }, &re256);
+            if (rho == 0) p256 = re256;  // position 256 (used by lane p == 0)
             // 6. power spectrum (pipeline.rs:165-169); bins 0 and 256 have im forced to 0 (kernels/fft.rs:256-261)
 #pragma unroll
             for (int vv = 0; vv < 8; ++vv) {
-                float im = bim[vv];
-                if (vv == 0 && rho == 0) im = (p == 0) ? 0.0f : im;
-                pw[rho][vv] = fe::power(bre[vv], im);
+                fe::cf z = bq[vv];
+                if (vv == 0 && rho == 0) z = fe::cmk(z.x, (p == 0) ? 0.0f : z.y);
+                pw[rho][vv] = fe::power(z);
             }
         }
         // power -> LDS, row layout [frame g][bin]; aliases the exchange region (all exchange reads are done)
@@ -238,38 +264,67 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
         if (p == 0) prow[256] = fe::power(p256, 0.0f);
         __builtin_amdgcn_wave_barrier();
 
+        // LFR targets of this frame (lfr.rs:36-52): rows i, blocks b with n*i + b - pad == f.  Computed once per
+        // frame in 32-bit arithmetic; the clamped first/last frames are handled in the rare branches below.
+        const int fi = (int)f, nfr = (int)num_frames, tl = (int)t_lfr;
+        const int pad = (tb.lfr_m - 1) / 2;
+        const int fp = fi + pad;
+        const int b_first = fp % tb.lfr_n, i_first = fp / tb.lfr_n;
+
         // 7. sparse mel: lane pm = p owns filters m = 16*rd + p; sequential sum += w*P (mel.rs:92-104)
         // 8. ln(max(x, 1e-5)) (mel.rs:124-128) and LFR scatter (lfr.rs:18-54)
-        for (int rd = 0; rd < tb.mel_rounds; ++rd) {
+        float vals[STDMEL ? 5 : kMaxMelRounds];
+#pragma unroll
+        for (int rd = 0; rd < (STDMEL ? 5 : kMaxMelRounds); ++rd) {
+            vals[rd] = 0.0f;
+            if (!STDMEL && rd >= tb.mel_rounds) continue;
             const int m = rd * 16 + p;
-            const int start = tb.mel_start[m];
+            const int start = s_mstart[m];
+            const float* pp = prow + start;
             float acc = 0.0f;
-            for (int t = tb.mel_step_off[rd]; t < tb.mel_step_off[rd + 1]; ++t) {
-                const int bin = start + (t - tb.mel_step_off[rd]);
-                const float pv = prow[bin > 256 ? 256 : bin];
-                acc = fe::fadd(acc, fe::fmul(tb.melw[t * 16 + p], pv));
+            if (STDMEL) {
+                const float* wp = tb.melw + kStdMelOff[rd < 5 ? rd : 0] * 16 + p;  // L1-resident table, coalesced
+                float w[17];
+#pragma unroll
+                for (int t = 0; t < 17; ++t)
+                    if (t < kStdMelLen[rd < 5 ? rd : 0]) w[t] = wp[t * 16];
+#pragma unroll
+                for (int t = 0; t < 17; ++t)
+                    if (t < kStdMelLen[rd < 5 ? rd : 0]) acc = fe::fadd(acc, fe::fmul(w[t], pp[t]));
+            } else {
+                const int t0 = s_moff[rd], t1 = s_moff[rd + 1];
+                const float* wp = s_melw + t0 * 16 + p;
+                const int lim = 256 - start;
+#pragma unroll 4
+                for (int t = 0; t < t1 - t0; ++t) {
+                    const float pv = pp[t < lim ? t : lim];
+                    acc = fe::fadd(acc, fe::fmul(wp[t * 16], pv));
+                }
             }
-            if (valid && m < tb.n_mels) {
-                const float val = logf(fmaxf(acc, 1e-5f));
-                if (lm_u) lm_u[f * tb.n_mels + m] = val;
-                if (out_u) {
-                    const int pad = (tb.lfr_m - 1) / 2;
-                    // regular targets: n*i + b - pad == f
-                    const int64_t fp = f + pad;
-                    for (int64_t b = fp % tb.lfr_n; b < tb.lfr_m; b += tb.lfr_n) {
-                        const int64_t i = (fp - b) / tb.lfr_n;
-                        if (fp - b >= 0 && i < t_lfr) out_u[i * d_out + b * tb.n_mels + m] = val;
-                    }
-                    if (f == 0) {  // left clamp: raw index < 0 reads frame 0
-                        for (int64_t i = 0; i * tb.lfr_n - pad < 0 && i < t_lfr; ++i)
-                            for (int64_t b = 0; b < tb.lfr_m && i * tb.lfr_n + b - pad < 0; ++b)
-                                out_u[i * d_out + b * tb.n_mels + m] = val;
-                    }
-                    if (f == num_frames - 1) {  // right clamp: raw index > T-1 reads the last frame
-                        for (int64_t i = t_lfr - 1; i >= 0 && i * tb.lfr_n + (tb.lfr_m - 1) - pad > f; --i)
-                            for (int64_t b = tb.lfr_m - 1; b >= 0 && i * tb.lfr_n + b - pad > f; --b)
-                                out_u[i * d_out + b * tb.n_mels + m] = val;
-                    }
+            vals[rd] = __logf(fmaxf(acc, 1e-5f));  // v_log_f32 * ln2 (<= 2 ulp), input >= 1e-5
+        }
+        // store: log-mel row (test hook) and/or the LFR scatter; lane p writes mels p, p+16, ... of each target
+        if (valid) {
+            constexpr int kR = STDMEL ? 5 : kMaxMelRounds;
+            auto put = [&](float* dst) {
+#pragma unroll
+                for (int rd = 0; rd < kR; ++rd)
+                    if (rd * 16 + p < tb.n_mels) dst[rd * 16] = vals[rd];
+            };
+            if (lm_u) put(lm_u + (int64_t)fi * tb.n_mels + p);
+            if (out_u) {
+                int i = i_first;
+                for (int b = b_first; b < tb.lfr_m && i >= 0; b += tb.lfr_n, --i)
+                    if (i < tl) put(out_u + i * d_out + b * tb.n_mels + p);
+                if (fi == 0) {  // left clamp: raw index < 0 reads frame 0
+                    for (int i2 = 0; i2 * tb.lfr_n - pad < 0 && i2 < tl; ++i2)
+                        for (int b = 0; b < tb.lfr_m && i2 * tb.lfr_n + b - pad < 0; ++b)
+                            put(out_u + i2 * d_out + b * tb.n_mels + p);
+                }
+                if (fi == nfr - 1) {  // right clamp: raw index > T-1 reads the last frame
+                    for (int i2 = tl - 1; i2 >= 0 && i2 * tb.lfr_n + (tb.lfr_m - 1) - pad > fi; --i2)
+                        for (int b = tb.lfr_m - 1; b >= 0 && i2 * tb.lfr_n + b - pad > fi; --b)
+                            put(out_u + i2 * d_out + b * tb.n_mels + p);
                 }
             }
         }
@@ -287,6 +342,7 @@ struct LeleFrontend {
     LeleFeatureConfig cfg{};
     int64_t frame_len = 0, hop_len = 0, n_fft = 0;
     bool fast = false;
+    bool std_mel = false;  // mel bank has the default round structure (fully unrolled kernel variant)
     int dpp_mode = 0;  // 0: __shfl, 1: DPP row_ror (selected after a self-test)
     FeDev dev{};
     std::vector<void*> allocs;
@@ -431,6 +487,14 @@ int lele_hip_frontend_create(LeleCtx* ctx, const LeleFeatureConfig* cfg, LeleFro
         off += (int)maxlen;
     }
     step_off[d.mel_rounds] = off;
+    d.mel_steps = off;
+    fe->std_mel = (d.mel_rounds == 5 && cfg->n_mels == 80);
+    for (int rd = 0; fe->std_mel && rd < 5; ++rd) {
+        if (step_off[rd] != kStdMelOff[rd] || step_off[rd + 1] != kStdMelOff[rd + 1]) fe->std_mel = false;
+        for (int pm = 0; pm < 16; ++pm)
+            if (start_pad[rd * 16 + pm] + kStdMelLen[rd] - 1 > 256) fe->std_mel = false;
+    }
+    if (getenv("LELE_HIP_FE_GENERIC_MEL")) fe->std_mel = false;
     int rc = 0;
     rc |= upload(fe, twr, &d.tw_re);
     rc |= upload(fe, twi, &d.tw_im);
@@ -444,7 +508,7 @@ int lele_hip_frontend_create(LeleCtx* ctx, const LeleFeatureConfig* cfg, LeleFro
         return rc;
     }
     const char* env = getenv("LELE_HIP_FE_DPP");
-    fe->dpp_mode = env ? atoi(env) : 0;
+    fe->dpp_mode = env ? atoi(env) : 1;  // 1: DPP row_ror (default), 0: __shfl (ds_bpermute)
     *out = fe;
     return 0;
 }
@@ -506,17 +570,21 @@ static int fe_run(LeleFrontend* fe, const LeleTensor* pcm, int64_t batch, int64_
         fe->events_used += 3;
         LELE_HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
     }
-    hipLaunchKernelGGL(fe_frame_sum_kernel, grid, dim3(64), 0, ctx->stream, (const float*)dpcm, pcm_len, nf,
+    hipLaunchKernelGGL(fe_frame_sum_kernel, grid, dim3(64), 0, ctx->stream, (const float*)dpcm, pcm_len, pcm_len, nf,
                        (float*)dmean, aligned16);
     if (ev) LELE_HIP_CHECK(hipEventRecord(ev[1], ctx->stream));
+    const size_t mel_lds = (size_t)fe->dev.mel_steps * 16 * sizeof(float);
     float* o = want_logmel ? nullptr : (float*)out->data;
     float* lm = want_logmel ? (float*)out->data : nullptr;
-    if (fe->dpp_mode == 1)
-        hipLaunchKernelGGL(fe_main_kernel<1>, grid, dim3(256), 0, ctx->stream, (const float*)dpcm, pcm_len, nf, t_lfr,
-                           (const float*)dmean, fe->dev, o, lm);
-    else
-        hipLaunchKernelGGL(fe_main_kernel<0>, grid, dim3(256), 0, ctx->stream, (const float*)dpcm, pcm_len, nf, t_lfr,
-                           (const float*)dmean, fe->dev, o, lm);
+#define FE_LAUNCH(MODE, STD)                                                                                     \
+    hipLaunchKernelGGL((fe_main_kernel<MODE, STD>), grid, dim3(256), mel_lds, ctx->stream, (const float*)dpcm, \
+                       pcm_len, nf, t_lfr, (const float*)dmean, fe->dev, o, lm)
+    if (fe->dpp_mode == 1) {
+        if (fe->std_mel) FE_LAUNCH(1, true); else FE_LAUNCH(1, false);
+    } else {
+        if (fe->std_mel) FE_LAUNCH(0, true); else FE_LAUNCH(0, false);
+    }
+#undef FE_LAUNCH
     LELE_HIP_CHECK(hipGetLastError());
     if (ev) LELE_HIP_CHECK(hipEventRecord(ev[2], ctx->stream));
     if (want_logmel) {

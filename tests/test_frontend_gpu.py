@@ -87,9 +87,10 @@ def test_full_size_30s_config2(fe, orc):
     assert np.array_equal(a[1:], b)
 
 
-def test_dpp_variant_is_identical(ctx, fe):
+def test_shfl_variant_is_identical(ctx, fe):
+    # default = DPP row_ror for the pre-emphasis neighbour; LELE_HIP_FE_DPP=0 selects the __shfl formulation
     from lele_amd.features import SenseVoiceFrontend
-    os.environ["LELE_HIP_FE_DPP"] = "1"
+    os.environ["LELE_HIP_FE_DPP"] = "0"
     try:
         fe2 = SenseVoiceFrontend(ctx=ctx)
     finally:
