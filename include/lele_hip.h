@@ -122,6 +122,35 @@ int lele_hip_stft_power_spectrum(LeleCtx* ctx, const LeleTensor* signal, int64_t
                                  int64_t win_length, const LeleTensor* window, LeleBuf* out, int64_t* out_shape,
                                  int32_t* out_rank);
 
+/* ---- src/kernels/gemm.rs ---------------------------------------------------------------------------- */
+/* matmul, gemm.rs:112-222: [..,M,K] x [..,K,N]; B may be un-batched (batch_b == 1) else batches must match */
+int lele_hip_matmul(LeleCtx* ctx, const LeleTensor* a, const LeleTensor* b, LeleBuf* out, int64_t* out_shape,
+                    int32_t* out_rank);
+/* matmul_fused_add, gemm.rs:223-432: bias.len()==N -> per-column bias, else out[i] += bias[i % len] */
+int lele_hip_matmul_fused_add(LeleCtx* ctx, const LeleTensor* a, const LeleTensor* b, const LeleTensor* bias,
+                              LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* gemm, gemm.rs:433-535: 2-D, out[M,N] = alpha*op(A)*op(B) + beta*C (C broadcast: full / [N] / [M] / scalar / modulo) */
+int lele_hip_gemm(LeleCtx* ctx, const LeleTensor* a, const LeleTensor* b, const LeleTensor* c_or_null, float alpha,
+                  float beta, int trans_a, int trans_b, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+
+/* ---- src/kernels/quantization.rs --------------------------------------------------------------------- */
+/* fused_quantized_linear, quantization.rs:77-169: DynamicQuantizeLinear (one range PER BATCH SLICE) + MatMulInteger
+ * + scale + bias [+ ReLU].  weight_int8: u8 values carried as f32 [K,N]; weight_scale [1] or [N]; weight_zero [1];
+ * bias [N] or empty/NULL.  Bit-exact with the reference's x86 path. */
+int lele_hip_fused_quantized_linear(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8,
+                                    const LeleTensor* weight_scale, const LeleTensor* weight_zero,
+                                    const LeleTensor* bias_or_null, int apply_relu, LeleBuf* out, int64_t* out_shape,
+                                    int32_t* out_rank);
+/* dynamic_quantize_linear, quantization.rs:1628-1657: y (u8 values as f32, shape of x), scale [1], zero_point [1] */
+int lele_hip_dynamic_quantize_linear(LeleCtx* ctx, const LeleTensor* x, LeleBuf* out_y, LeleBuf* out_scale,
+                                     LeleBuf* out_zp, int64_t* out_shape, int32_t* out_rank);
+/* mat_mul_integer / _with_bias / _with_scale_bias / _with_scale_bias_relu, quantization.rs:8-72, 927-992:
+ * a, b hold u8 values as f32; zero points [1], scale [1] or [N], bias [N] -- each may be NULL */
+int lele_hip_mat_mul_integer_with_scale_bias(LeleCtx* ctx, const LeleTensor* a, const LeleTensor* b,
+                                             const LeleTensor* a_zero_point, const LeleTensor* b_zero_point,
+                                             const LeleTensor* scale, const LeleTensor* bias, int apply_relu,
+                                             LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,220 @@
+// gemm_core.h -- f32-input MFMA GEMM core for gfx950 (v_mfma_f32_32x32x2_f32: exact f32, k-ordered FMA chain).
+//
+// One kernel template serves every op that lele routes through faer's f32 matmul on x86
+// (/root/reference/src/kernels/gemm.rs:196,315,527; conv1d.rs:1086,1259; conv2d.rs:358,686; rnn.rs:134-149):
+// the operands are supplied by LOADER functors (row-major, column-major, implicit im2col ...) and the result is
+// consumed by an EPILOGUE functor (plain store, alpha/beta*C, bias + ReLU/SiLU into NCHW ...).
+//
+// Tiling: block tile BM x BN, K step 16, WM x WN waves, each wave owns (BM/WM) x (BN/WN) as 32x32 MFMA tiles.
+// Both operand tiles live in LDS as [row][16 k + 4 pad] (pitch 20 floats = 80 B, so the two ds_read_b128 a lane
+// issues per 32-row tile are 16-B aligned and a 16-lane group touches 16 distinct 16-B slots: 5*row mod 16).
+// Lane l feeds MFMA step s (0..7) with k = 8*(l>>5) + s of the current K tile for BOTH operands, i.e. the
+// K index is permuted identically on A and B -- a reordering of the exact f32 sum, nothing else.
+// Global -> register -> LDS with the next tile's loads in flight during the MFMAs (double-buffered LDS,
+// one __syncthreads per K tile).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gemm {
+
+constexpr int BK = 16;
+constexpr int PITCH = 20;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------- loaders
+// element(row, k) = p[batch*bs + row*ld + k]   (k contiguous in memory)
+struct LoadRowK {
+    const float* p;
+    int64_t bs;  // batch stride (0 = broadcast)
+    int64_t ld;
+    int rows, K;
+    int vec;  // 1 when float4 loads are legal (base and ld 16-B aligned)
+    static constexpr bool kRowFast = false;
+    __device__ __forceinline__ float4 get4(int b, int row, int k) const {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row >= rows) return v;
+        const float* q = p + (int64_t)b * bs + (int64_t)row * ld + k;
+        if (vec && k + 3 < K) return *reinterpret_cast<const float4*>(q);
+        if (k + 0 < K) v.x = q[0];
+        if (k + 1 < K) v.y = q[1];
+        if (k + 2 < K) v.z = q[2];
+        if (k + 3 < K) v.w = q[3];
+        return v;
+    }
+};
+// element(row, k) = p[batch*bs + k*ld + row]   (row contiguous in memory: B of a plain matmul, A of transA)
+struct LoadKRow {
+    const float* p;
+    int64_t bs;
+    int64_t ld;
+    int rows, K;
+    static constexpr bool kRowFast = true;
+    __device__ __forceinline__ float4 get4(int b, int row, int k) const {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row >= rows) return v;
+        const float* q = p + (int64_t)b * bs + (int64_t)k * ld + row;
+        if (k + 0 < K) v.x = q[0];
+        if (k + 1 < K) v.y = q[ld];
+        if (k + 2 < K) v.z = q[2 * ld];
+        if (k + 3 < K) v.w = q[3 * ld];
+        return v;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- epilogues
+enum CMode { C_NONE = 0, C_FULL = 1, C_ROWVEC = 2 /* [N] */, C_COLVEC = 3 /* [M] */, C_SCALAR = 4, C_MODULO = 5 };
+
+// out[b][row][col] = alpha*acc + beta*C[...]  (matmul, matmul_fused_add, gemm)
+struct EpiAffine {
+    float* out;
+    int64_t bs;  // batch stride of out
+    int M, N;
+    float alpha, beta;
+    const float* c;
+    int cmode;
+    int64_t clen;
+    __device__ __forceinline__ void operator()(int b, int row, int col, float acc) const {
+        if (row >= M || col >= N) return;
+        float pre = 0.0f;
+        switch (cmode) {
+            case C_FULL: pre = c[(int64_t)row * N + col] * beta; break;
+            case C_ROWVEC: pre = c[col] * beta; break;
+            case C_COLVEC: pre = c[row] * beta; break;
+            case C_SCALAR: pre = c[0] * beta; break;
+            case C_MODULO: pre = c[((int64_t)b * bs + (int64_t)row * N + col) % clen] * beta; break;
+            default: break;
+        }
+        out[(int64_t)b * bs + (int64_t)row * N + col] = __builtin_fmaf(alpha, acc, pre);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- kernel
+template <int BM, int BN, int WM, int WN, class AL, class BL, class EPI>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(AL al, BL bl, EPI epi, int M, int N, int K) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TMT = BM / WM / 32, TNT = BN / WN / 32;  // 32x32 MFMA tiles per wave
+    constexpr int ASLOTS = (BM * 4 + NT - 1) / NT, BSLOTS = (BN * 4 + NT - 1) / NT;  // float4 staging slots per thread
+    __shared__ __attribute__((aligned(16))) float As[2][BM * PITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, batch = blockIdx.z;
+    const int hv = lane >> 5, l31 = lane & 31;
+
+    float4 ra[ASLOTS], rb[BSLOTS];
+    auto slot_rc = [](int s, int rows, bool rowfast, int& row, int& kq) {
+        if (rowfast) {
+            row = s % rows;
+            kq = s / rows;
+        } else {
+            kq = s & 3;
+            row = s >> 2;
+        }
+    };
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < ASLOTS; ++i) {
+            int row, kq;
+            slot_rc(tid + i * NT, BM, AL::kRowFast, row, kq);
+            if (tid + i * NT < BM * 4) ra[i] = al.get4(batch, m0 + row, k0 + 4 * kq);
+        }
+#pragma unroll
+        for (int i = 0; i < BSLOTS; ++i) {
+            int row, kq;
+            slot_rc(tid + i * NT, BN, BL::kRowFast, row, kq);
+            if (tid + i * NT < BN * 4) rb[i] = bl.get4(batch, n0 + row, k0 + 4 * kq);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < ASLOTS; ++i) {
+            int row, kq;
+            slot_rc(tid + i * NT, BM, AL::kRowFast, row, kq);
+            if (tid + i * NT < BM * 4) *reinterpret_cast<float4*>(&As[buf][row * PITCH + 4 * kq]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BSLOTS; ++i) {
+            int row, kq;
+            slot_rc(tid + i * NT, BN, BL::kRowFast, row, kq);
+            if (tid + i * NT < BN * 4) *reinterpret_cast<float4*>(&Bs[buf][row * PITCH + 4 * kq]) = rb[i];
+        }
+    };
+
+    f32x16 acc[TMT][TNT];
+#pragma unroll
+    for (int i = 0; i < TMT; ++i)
+#pragma unroll
+        for (int j = 0; j < TNT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = (K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);  // in flight during the MFMAs below
+        float a[TMT][8], b[TNT][8];
+#pragma unroll
+        for (int i = 0; i < TMT; ++i) {
+            const float* src = &As[cur][(wm * TMT * 32 + i * 32 + l31) * PITCH + 8 * hv];
+            const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+            a[i][0] = v0.x; a[i][1] = v0.y; a[i][2] = v0.z; a[i][3] = v0.w;
+            a[i][4] = v1.x; a[i][5] = v1.y; a[i][6] = v1.z; a[i][7] = v1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) {
+            const float* src = &Bs[cur][(wn * TNT * 32 + j * 32 + l31) * PITCH + 8 * hv];
+            const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+            b[j][0] = v0.x; b[j][1] = v0.y; b[j][2] = v0.z; b[j][3] = v0.w;
+            b[j][4] = v1.x; b[j][5] = v1.y; b[j][6] = v1.z; b[j][7] = v1.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int i = 0; i < TMT; ++i)
+#pragma unroll
+                for (int j = 0; j < TNT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TMT; ++i)
+#pragma unroll
+        for (int j = 0; j < TNT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TMT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv;
+                const int col = n0 + wn * TNT * 32 + j * 32 + l31;
+                epi(batch, row, col, acc[i][j][r]);
+            }
+}
+
+// Launch with a tile chosen from the problem size: big tiles when they still fill 256 CUs, else 64x64 / 32x128.
+template <class AL, class BL, class EPI>
+inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int batch,
+                   int num_cus) {
+    if (M <= 0 || N <= 0 || batch <= 0) return;
+    auto blocks = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
+    if (M <= 32) {
+        dim3 grid((N + 127) / 128, (M + 31) / 32, batch);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<32, 128, 1, 4, AL, BL, EPI>), grid, dim3(256), 0, st, al, bl, epi, M, N,
+                           K);
+    } else if (blocks(128, 128) >= 2 * (int64_t)num_cus) {
+        dim3 grid((N + 127) / 128, (M + 127) / 128, batch);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<128, 128, 2, 2, AL, BL, EPI>), grid, dim3(256), 0, st, al, bl, epi, M,
+                           N, K);
+    } else {
+        dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<64, 64, 2, 2, AL, BL, EPI>), grid, dim3(256), 0, st, al, bl, epi, M, N,
+                           K);
+    }
+}
+
+}  // namespace gemm

@@ -1,0 +1,566 @@
+// quant.hip -- lele's dynamic-quantised u8 linear path on gfx950 (i8 MFMA, v_mfma_i32_32x32x32_i8).
+//
+//   lele_hip_fused_quantized_linear     <- /root/reference/src/kernels/quantization.rs:77-169 (x86 branch) +
+//                                          src/kernels/avx/quantization.rs:102-417 (DynQuant + u8 GEMM + epilogue)
+//   lele_hip_dynamic_quantize_linear    <- quantization.rs:1628-1657 + avx/quantization.rs:832-927
+//   lele_hip_mat_mul_integer_with_scale_bias (zero points, scale, bias, ReLU all optional)
+//                                       <- quantization.rs:8-72, 927-992 + avx/quantization.rs:642-830
+//
+// Bit-exact with the reference: the integer part is exact, every rounding step is reproduced
+// (round-half-even(fma(x,1/scale,zp)) in the 8-wide body, f32::round(x*inv+zp) in the per-row scalar tail; epilogue
+// (float)acc * (dyn_scale*w_scale[j]) then + bias then max(.,0), mul and add NOT fused).
+//
+// Pipeline per call (all on the ctx stream):
+//   1. qminmax_kernel + qparams_kernel : min/max of each batch slice -> {scale, zp, 1/scale}   (one range per slice!)
+//   2. qrows_kernel                    : f32 rows -> i8 (q - 128) rows padded to 16, + exact i32 row sums
+//   3. igemm_kernel                    : sum (q-128)(w-128) on the matrix cores; zero-point algebra + f32 epilogue
+// Weights (f32-encoded u8 [K,N], as lele's TensorView::from_bytes_u8 carries them) are transposed once to i8
+// [N, Kpad] (w - 128) with column sums and cached per (pointer, bytes) -- the analogue of B_WEIGHT_CACHE
+// (avx/quantization.rs:12-95).
+#include "common.h"
+
+#include <math.h>
+
+using namespace lele;
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+struct QParams {  // per batch slice
+    float scale, zp, inv_scale;
+    int zp_i;
+};
+
+// ------------------------------------------------------------------------------------------ 1. range
+__global__ __launch_bounds__(256) void qminmax_kernel(const float* __restrict__ x, int64_t slice_len,
+                                                      float* __restrict__ partial /*[slices][blocks][2]*/) {
+    const float* p = x + (int64_t)blockIdx.y * slice_len;
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slice_len; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = p[i];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    __shared__ float smn[4], smx[4];
+    if ((threadIdx.x & 63) == 0) {
+        smn[threadIdx.x >> 6] = mn;
+        smx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            mn = smn[w] < mn ? smn[w] : mn;
+            mx = smx[w] > mx ? smx[w] : mx;
+        }
+        float* o = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+        o[0] = mn;
+        o[1] = mx;
+    }
+}
+
+__global__ void qparams_kernel(const float* __restrict__ partial, int nblocks, QParams* __restrict__ prm,
+                               float* __restrict__ scale_out, float* __restrict__ zp_out) {
+    const int s = blockIdx.x;
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+    for (int i = threadIdx.x; i < nblocks; i += 64) {
+        const float a = partial[((int64_t)s * nblocks + i) * 2], b = partial[((int64_t)s * nblocks + i) * 2 + 1];
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if (threadIdx.x == 0) {  // avx/quantization.rs:134-140
+        const float adjusted_max = mx > 0.0f ? mx : 0.0f;
+        const float adjusted_min = mn < 0.0f ? mn : 0.0f;
+        float range = adjusted_max - adjusted_min;
+        if (!(range > 1e-5f)) range = 1e-5f;
+        const float scale = range / 255.0f;
+        float z = roundf(-adjusted_min / scale);  // f32::round (half away from zero)
+        z = z < 0.0f ? 0.0f : (z > 255.0f ? 255.0f : z);
+        QParams q;
+        q.scale = scale;
+        q.zp = z;
+        q.inv_scale = 1.0f / scale;
+        q.zp_i = (int)z;
+        prm[s] = q;
+        if (scale_out) scale_out[s] = scale;
+        if (zp_out) zp_out[s] = z;
+    }
+}
+
+__device__ __forceinline__ float quant_one(float v, const QParams& q, bool simd_body) {
+    float r = simd_body ? rintf(__builtin_fmaf(v, q.inv_scale, q.zp))  // _mm256_fmadd_ps + round-to-nearest-even
+                        : roundf(v * q.inv_scale + q.zp);               // scalar remainder: two roundings, half away
+    return r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
+}
+
+// ------------------------------------------------------------------------------------------ 2. rows -> i8
+// MODE 0: dynamic quantisation with prm[row / m] (fused linear: SIMD body = first k&~7 elements of EACH ROW)
+// MODE 1: the input already holds u8 values as f32 (mat_mul_integer): q = sat_u8(round-nearest-even(x))
+// One wave per row; writes q-128 as i8 into [rows][kp] (zero padded = contributes 0) and the exact sum of (q-128).
+template <int MODE>
+__global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x, int64_t rows, int k, int kp, int m,
+                                                    const QParams* __restrict__ prm, int8_t* __restrict__ aq,
+                                                    int* __restrict__ row_sums) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    QParams q;
+    if (MODE == 0) q = prm[row / m];
+    const float* xr = x + row * k;
+    int8_t* dst = aq + row * kp;
+    const int simd_k = k & ~7;
+    int sum = 0;
+    for (int c = lane * 4; c < kp; c += 256) {
+        int packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kk = c + e;
+            int v = 0;
+            if (kk < k) {
+                float qf;
+                if (MODE == 0)
+                    qf = quant_one(xr[kk], q, kk < simd_k);
+                else {
+                    const float r = rintf(xr[kk]);
+                    qf = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
+                }
+                v = (int)qf - 128;
+                sum += v;
+            }
+            packed |= (v & 0xff) << (8 * e);
+        }
+        *reinterpret_cast<int*>(dst + c) = packed;
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) row_sums[row] = sum;
+}
+
+// unfused DynamicQuantizeLinear: y (u8 values as f32), body = first len&~7 elements of the FLAT tensor
+__global__ void dq_apply_kernel(const float* __restrict__ x, int64_t len, const QParams* __restrict__ prm,
+                                float* __restrict__ y) {
+    const QParams q = prm[0];
+    const int64_t simd_end = (len / 8) * 8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = quant_one(x[i], q, i < simd_end);
+}
+
+// ------------------------------------------------------------------------------------------ weights -> i8 [N][Kp]
+__global__ void wpack_kernel(const float* __restrict__ w /*[K][N]*/, int k, int n, int kp, int8_t* __restrict__ wt,
+                             int* __restrict__ col_sums) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;  // coalesced over n
+    if (j >= n) return;
+    int sum = 0;
+    for (int kk = 0; kk < kp; ++kk) {
+        int v = 0;
+        if (kk < k) {
+            const float r = rintf(w[(int64_t)kk * n + j]);  // cvtps + saturating packs (transpose_b_from_f32_avx2)
+            const int u = r < 0.0f ? 0 : (r > 255.0f ? 255 : (int)r);
+            v = u - 128;  // == u8 ^ 0x80 read as i8
+            sum += v;
+        }
+        wt[(int64_t)j * kp + kk] = (int8_t)v;
+    }
+    col_sums[j] = sum;
+}
+
+// ------------------------------------------------------------------------------------------ 3. i8 GEMM
+// C[row][col] = sum_k A'[row][k] * B'[col][k]   (A' = q-128, B' = w-128, both [rows][kp] with k contiguous)
+// Tile BM x BN, K step 64 bytes; LDS rows of 64 B + 16 B pad (same bank argument as the f32 core: 5*row mod 16).
+// Lane l feeds the two MFMA steps of a K tile with bytes [32*(l>>5), +16) and [32*(l>>5)+16, +16) of its row, for A
+// and B alike, so the hardware's internal k order is irrelevant (it pairs like with like).
+struct IgemmEpi {
+    float* out;
+    int64_t rows, n;
+    int m;  // rows per batch slice
+    int k;
+    const int* row_sums;  // sum_k (q-128) per row
+    const int* col_sums;  // sum_k (w-128) per column
+    const QParams* prm;   // per slice (dynamic) or NULL
+    int zp_a_fixed, zp_b;
+    const float* wscale;  // may be NULL
+    int wscale_len;
+    const float* bias;  // may be NULL
+    int relu;
+    __device__ __forceinline__ void operator()(int64_t row, int col, int acc) const {
+        if (row >= rows || col >= n) return;
+        int zp_a = zp_a_fixed;
+        float dyn_scale = 1.0f;
+        if (prm) {
+            const QParams q = prm[row / m];
+            zp_a = q.zp_i;
+            dyn_scale = q.scale;
+        }
+        // sum (q - zp_a)(w - zp_b) with q = q'+128, w = w'+128  (exact in i32, as the reference's wrapping algebra)
+        const int ca = 128 - zp_a, cb = 128 - zp_b;
+        const int total = acc + cb * row_sums[row] + ca * col_sums[col] + k * ca * cb;
+        float vf = (float)total;  // _mm256_cvtepi32_ps
+        if (wscale) {
+            const float ws = wscale_len <= 1 ? wscale[0] : wscale[col];
+            vf = vf * (prm ? dyn_scale * ws : ws);  // combined_scale[j] = dyn_scale * weight_scale[j], then mul
+        }
+        if (bias) vf = vf + bias[col];
+        if (relu) vf = vf > 0.0f ? vf : 0.0f;
+        out[row * n + col] = vf;
+    }
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const int8_t* __restrict__ a, const int8_t* __restrict__ b,
+                                                            int64_t rows, int n, int kp, int64_t b_batch_stride,
+                                                            int m_per_batch, IgemmEpi epi) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int PITCH = 80;  // bytes
+    constexpr int TMT = BM / WM / 32, TNT = BN / WN / 32;
+    constexpr int ASLOTS = (BM * 4 + NT - 1) / NT, BSLOTS = (BN * 4 + NT - 1) / NT;  // 16-B chunks per thread
+    __shared__ __attribute__((aligned(16))) char As[2][BM * PITCH];
+    __shared__ __attribute__((aligned(16))) char Bs[2][BN * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int64_t m0 = (int64_t)blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int hv = lane >> 5, l31 = lane & 31;
+    // un-batched weights: b_batch_stride == 0; batched B (mat_mul_integer with batch_b > 1): slice = row block / m
+    const int8_t* bb = b + (b_batch_stride ? (m0 / m_per_batch) * b_batch_stride : 0);
+
+    v4i ra[ASLOTS], rb[BSLOTS];
+    const v4i zero4 = {0, 0, 0, 0};
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < ASLOTS; ++i) {
+            const int s = tid + i * NT, row = s >> 2, kq = s & 3;
+            if (s < BM * 4) {
+                const int64_t r = m0 + row;
+                const int kb = k0 + 16 * kq;
+                ra[i] = (r < rows && kb < kp) ? *reinterpret_cast<const v4i*>(a + r * kp + kb) : zero4;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BSLOTS; ++i) {
+            const int s = tid + i * NT, row = s >> 2, kq = s & 3;
+            if (s < BN * 4) {
+                const int c = n0 + row;
+                const int kb = k0 + 16 * kq;
+                rb[i] = (c < n && kb < kp) ? *reinterpret_cast<const v4i*>(bb + (int64_t)c * kp + kb) : zero4;
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < ASLOTS; ++i) {
+            const int s = tid + i * NT;
+            if (s < BM * 4) *reinterpret_cast<v4i*>(&As[buf][(s >> 2) * PITCH + 16 * (s & 3)]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BSLOTS; ++i) {
+            const int s = tid + i * NT;
+            if (s < BN * 4) *reinterpret_cast<v4i*>(&Bs[buf][(s >> 2) * PITCH + 16 * (s & 3)]) = rb[i];
+        }
+    };
+    v16i acc[TMT][TNT];
+#pragma unroll
+    for (int i = 0; i < TMT; ++i)
+#pragma unroll
+        for (int j = 0; j < TNT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    const int nk = (kp + 63) / 64;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * 64);
+        v4i fa[TMT][2], fb[TNT][2];
+#pragma unroll
+        for (int i = 0; i < TMT; ++i) {
+            const char* src = &As[cur][(wm * TMT * 32 + i * 32 + l31) * PITCH + 32 * hv];
+            fa[i][0] = *reinterpret_cast<const v4i*>(src);
+            fa[i][1] = *reinterpret_cast<const v4i*>(src + 16);
+        }
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) {
+            const char* src = &Bs[cur][(wn * TNT * 32 + j * 32 + l31) * PITCH + 32 * hv];
+            fb[j][0] = *reinterpret_cast<const v4i*>(src);
+            fb[j][1] = *reinterpret_cast<const v4i*>(src + 16);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < TMT; ++i)
+#pragma unroll
+                for (int j = 0; j < TNT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+        if (kt + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TMT; ++i)
+#pragma unroll
+        for (int j = 0; j < TNT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * TMT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv;
+                const int col = n0 + wn * TNT * 32 + j * 32 + l31;
+                epi(row, col, acc[i][j][r]);
+            }
+}
+
+// ------------------------------------------------------------------------------------------ host helpers
+struct PackedW {
+    int8_t* wt;
+    int* col_sums;
+};
+
+int get_packed_weights(LeleCtx* ctx, const LeleTensor* w, const float* dw, int64_t nbatch, int k, int n, int kp,
+                       PackedW* out, bool cacheable) {
+    // cache key: the caller's pointer (host pointer for LELE_MEM_WEIGHT, device pointer otherwise) + size
+    auto key_w = std::make_tuple((const void*)w->data, (size_t)numel(w) * 4, 201);
+    auto key_s = std::make_tuple((const void*)w->data, (size_t)numel(w) * 4, 202);
+    if (cacheable) {
+        auto it = ctx->weights.find(key_w);
+        if (it != ctx->weights.end()) {
+            out->wt = (int8_t*)it->second;
+            out->col_sums = (int*)ctx->weights[key_s];
+            return 0;
+        }
+    }
+    void *dwt = nullptr, *dcs = nullptr;
+    if (cacheable) {
+        LELE_HIP_CHECK(hipMalloc(&dwt, (size_t)nbatch * n * kp));
+        LELE_HIP_CHECK(hipMalloc(&dcs, (size_t)nbatch * n * 4));
+        ctx->weights[key_w] = dwt;
+        ctx->weights[key_s] = dcs;
+    } else {
+        LELE_TRY(ctx->arena_alloc((size_t)nbatch * n * kp, &dwt));
+        LELE_TRY(ctx->arena_alloc((size_t)nbatch * n * 4, &dcs));
+    }
+    for (int64_t b = 0; b < nbatch; ++b)
+        hipLaunchKernelGGL(wpack_kernel, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, dw + b * (int64_t)k * n, k, n,
+                           kp, (int8_t*)dwt + b * (int64_t)n * kp, (int*)dcs + b * n);
+    LELE_HIP_CHECK(hipGetLastError());
+    out->wt = (int8_t*)dwt;
+    out->col_sums = (int*)dcs;
+    return 0;
+}
+
+int launch_range(LeleCtx* ctx, const float* dx, int64_t slices, int64_t slice_len, QParams* prm, float* scale_out,
+                 float* zp_out) {
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(256, (slice_len + 4095) / 4096));
+    void* partial = nullptr;
+    LELE_TRY(ctx->arena_alloc((size_t)slices * nblk * 8, &partial));
+    hipLaunchKernelGGL(qminmax_kernel, dim3(nblk, (unsigned)slices), dim3(256), 0, ctx->stream, dx, slice_len,
+                       (float*)partial);
+    hipLaunchKernelGGL(qparams_kernel, dim3((unsigned)slices), dim3(64), 0, ctx->stream, (const float*)partial, nblk,
+                       prm, scale_out, zp_out);
+    LELE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows, int n, int kp, int64_t b_stride,
+                 int m_per_batch, const IgemmEpi& epi) {
+    if (rows == 0 || n == 0) return 0;
+    const int64_t b128 = ((rows + 127) / 128) * ((n + 127) / 128);
+    // batched B needs every block to stay inside one batch slice: tiles never straddle slices when BM divides m,
+    // otherwise fall back to one launch per slice (handled by the caller passing rows == m)
+    if (b128 >= 2 * ctx->num_cus) {
+        dim3 grid((n + 127) / 128, (unsigned)((rows + 127) / 128));
+        hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, ctx->stream, aq, wt, rows, n, kp, b_stride,
+                           m_per_batch, epi);
+    } else if (rows <= 32) {
+        dim3 grid((n + 127) / 128, (unsigned)((rows + 31) / 32));
+        hipLaunchKernelGGL((igemm_kernel<32, 128, 1, 4>), grid, dim3(256), 0, ctx->stream, aq, wt, rows, n, kp, b_stride,
+                           m_per_batch, epi);
+    } else {
+        dim3 grid((n + 63) / 64, (unsigned)((rows + 63) / 64));
+        hipLaunchKernelGGL((igemm_kernel<64, 64, 2, 2>), grid, dim3(256), 0, ctx->stream, aq, wt, rows, n, kp, b_stride,
+                           m_per_batch, epi);
+    }
+    LELE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lele_hip_fused_quantized_linear(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8,
+                                    const LeleTensor* weight_scale, const LeleTensor* weight_zero,
+                                    const LeleTensor* bias, int apply_relu, LeleBuf* out, int64_t* out_shape,
+                                    int32_t* out_rank) {
+    LELE_REQUIRE(ctx && input && weight_int8 && weight_scale && out, "fused_quantized_linear: NULL argument");
+    LELE_REQUIRE(input->rank >= 2 && weight_int8->rank >= 2, "fused_quantized_linear: rank >= 2 required");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t m = input->shape[input->rank - 2], k = input->shape[input->rank - 1];
+    const int64_t kw = weight_int8->shape[weight_int8->rank - 2], n = weight_int8->shape[weight_int8->rank - 1];
+    LELE_REQUIRE(k == kw, "fused_quantized_linear: K mismatch (%lld vs %lld)", (long long)k, (long long)kw);
+    int64_t batch = 1;
+    for (int i = 0; i + 2 < input->rank; ++i) batch *= input->shape[i];
+    const int64_t ws_len = numel(weight_scale);
+    LELE_REQUIRE(ws_len >= 1, "fused_quantized_linear: empty weight_scale");
+    LELE_REQUIRE(ws_len <= 1 || ws_len >= n, "fused_quantized_linear: weight_scale has %lld entries for N=%lld",
+                 (long long)ws_len, (long long)n);
+    const int64_t blen = bias ? numel(bias) : 0;
+    LELE_REQUIRE(blen == 0 || blen >= n, "fused_quantized_linear: bias has %lld entries for N=%lld", (long long)blen,
+                 (long long)n);
+    std::vector<int64_t> shp(input->shape, input->shape + input->rank - 1);
+    shp.push_back(n);
+    const int64_t rows = batch * m;
+    LELE_TRY(out->reserve((size_t)rows * n * 4));
+    if (rows == 0 || n == 0) return set_shape_v(out_shape, out_rank, shp);
+    LELE_TRY(ctx->arena_reset());
+    const void *dx = nullptr, *dw = nullptr, *dws = nullptr, *db = nullptr;
+    LELE_TRY(ctx->dev_ptr(input, &dx));
+    LELE_TRY(ctx->dev_ptr(weight_scale, &dws));
+    if (blen) LELE_TRY(ctx->dev_ptr(bias, &db));
+    // weight_zero.data.first() as i32 (quantization.rs:100); fetched on the host: it is a scalar attribute
+    float wz = 0.0f;
+    if (weight_zero && numel(weight_zero) > 0) {
+        if (weight_zero->mem == LELE_MEM_DEVICE) {
+            LELE_HIP_CHECK(hipMemcpyAsync(&wz, weight_zero->data, 4, hipMemcpyDeviceToHost, ctx->stream));
+            LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        } else {
+            wz = *(const float*)weight_zero->data;
+        }
+    }
+    const int kp = (int)((k + 15) & ~int64_t(15));
+    PackedW pw;
+    {
+        const bool cacheable = weight_int8->mem == LELE_MEM_WEIGHT;  // only declared-immutable weights are cached
+        auto key_w = std::make_tuple((const void*)weight_int8->data, (size_t)numel(weight_int8) * 4, 201);
+        if (cacheable && ctx->weights.count(key_w)) {
+            LELE_TRY(get_packed_weights(ctx, weight_int8, nullptr, 1, (int)k, (int)n, kp, &pw, true));
+        } else {
+            LELE_TRY(ctx->dev_ptr(weight_int8, &dw));
+            LELE_TRY(get_packed_weights(ctx, weight_int8, (const float*)dw, 1, (int)k, (int)n, kp, &pw, cacheable));
+        }
+    }
+    void *prm = nullptr, *aq = nullptr, *rs = nullptr;
+    LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm));
+    LELE_TRY(ctx->arena_alloc((size_t)rows * kp, &aq));
+    LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));
+    LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr));
+    hipLaunchKernelGGL(qrows_kernel<0>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
+                       rows, (int)k, kp, (int)m, (const QParams*)prm, (int8_t*)aq, (int*)rs);
+    IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, (const int*)rs, pw.col_sums, (const QParams*)prm, 0,
+                 (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu};
+    LELE_TRY(launch_igemm(ctx, (const int8_t*)aq, pw.wt, rows, (int)n, kp, 0, (int)m, epi));
+    return set_shape_v(out_shape, out_rank, shp);
+}
+
+int lele_hip_dynamic_quantize_linear(LeleCtx* ctx, const LeleTensor* x, LeleBuf* out_y, LeleBuf* out_scale,
+                                     LeleBuf* out_zp, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && out_y && out_scale && out_zp, "dynamic_quantize_linear: NULL argument");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t len = numel(x);
+    std::vector<int64_t> shp(x->shape, x->shape + x->rank);
+    LELE_TRY(out_y->reserve((size_t)len * 4));
+    LELE_TRY(out_scale->reserve(4));
+    LELE_TRY(out_zp->reserve(4));
+    if (len == 0) {  // avx/quantization.rs:845-851: scale 1.0, zero point 0.0
+        const float one = 1.0f, zero = 0.0f;
+        LELE_HIP_CHECK(hipMemcpyAsync(out_scale->data, &one, 4, hipMemcpyHostToDevice, ctx->stream));
+        LELE_HIP_CHECK(hipMemcpyAsync(out_zp->data, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+        LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return set_shape_v(out_shape, out_rank, shp);
+    }
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    void* prm = nullptr;
+    LELE_TRY(ctx->arena_alloc(sizeof(QParams), &prm));
+    LELE_TRY(launch_range(ctx, (const float*)dx, 1, len, (QParams*)prm, (float*)out_scale->data, (float*)out_zp->data));
+    const int blocks = (int)std::min<int64_t>((len + 255) / 256, 2048);
+    hipLaunchKernelGGL(dq_apply_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)dx, len,
+                       (const QParams*)prm, (float*)out_y->data);
+    LELE_HIP_CHECK(hipGetLastError());
+    return set_shape_v(out_shape, out_rank, shp);
+}
+
+int lele_hip_mat_mul_integer_with_scale_bias(LeleCtx* ctx, const LeleTensor* a, const LeleTensor* b,
+                                             const LeleTensor* a_zero_point, const LeleTensor* b_zero_point,
+                                             const LeleTensor* scale, const LeleTensor* bias, int apply_relu,
+                                             LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && a && b && out, "mat_mul_integer: NULL argument");
+    LELE_REQUIRE(a->rank >= 2 && b->rank >= 2, "mat_mul_integer: rank >= 2 required");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t m = a->shape[a->rank - 2], k = a->shape[a->rank - 1];
+    const int64_t kb = b->shape[b->rank - 2], n = b->shape[b->rank - 1];
+    LELE_REQUIRE(k == kb, "mat_mul_integer: K mismatch (%lld vs %lld)", (long long)k, (long long)kb);
+    int64_t batch_a = 1, batch_b = 1;
+    for (int i = 0; i + 2 < a->rank; ++i) batch_a *= a->shape[i];
+    for (int i = 0; i + 2 < b->rank; ++i) batch_b *= b->shape[i];
+    LELE_REQUIRE(batch_a == batch_b || batch_a == 1 || batch_b == 1, "mat_mul_integer: batch %lld vs %lld",
+                 (long long)batch_a, (long long)batch_b);
+    const int64_t fb = std::max(batch_a, batch_b);
+    std::vector<int64_t> shp;
+    if (batch_a >= batch_b)
+        shp.assign(a->shape, a->shape + a->rank - 2);
+    else
+        shp.assign(b->shape, b->shape + b->rank - 2);
+    shp.push_back(m);
+    shp.push_back(n);
+    LELE_TRY(out->reserve((size_t)fb * m * n * 4));
+    if (fb * m * n == 0) return set_shape_v(out_shape, out_rank, shp);
+    auto first_as_int = [&](const LeleTensor* t, int* v) -> int {  // `.data.first().map(|&v| v as i32).unwrap_or(0)`
+        *v = 0;
+        if (!t || numel(t) == 0) return 0;
+        float f = 0.0f;
+        if (t->mem == LELE_MEM_DEVICE) {
+            LELE_HIP_CHECK(hipMemcpyAsync(&f, t->data, 4, hipMemcpyDeviceToHost, ctx->stream));
+            LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        } else {
+            f = *(const float*)t->data;
+        }
+        *v = (int)f;
+        return 0;
+    };
+    int zp_a = 0, zp_b = 0;
+    LELE_TRY(first_as_int(a_zero_point, &zp_a));
+    LELE_TRY(first_as_int(b_zero_point, &zp_b));
+    const int64_t slen = scale ? numel(scale) : 0, blen = bias ? numel(bias) : 0;
+    LELE_REQUIRE(!scale || slen == 1 || slen >= n, "mat_mul_integer: scale has %lld entries for N=%lld",
+                 (long long)slen, (long long)n);
+    LELE_REQUIRE(!bias || blen >= n, "mat_mul_integer: bias has %lld entries for N=%lld", (long long)blen, (long long)n);
+    LELE_TRY(ctx->arena_reset());
+    const void *da = nullptr, *db = nullptr, *ds = nullptr, *dbi = nullptr;
+    LELE_TRY(ctx->dev_ptr(a, &da));
+    LELE_TRY(ctx->dev_ptr(b, &db));
+    if (scale) LELE_TRY(ctx->dev_ptr(scale, &ds));
+    if (bias) LELE_TRY(ctx->dev_ptr(bias, &dbi));
+    const int kp = (int)((k + 15) & ~int64_t(15));
+    PackedW pw;
+    LELE_TRY(get_packed_weights(ctx, b, (const float*)db, batch_b, (int)k, (int)n, kp, &pw,
+                                b->mem == LELE_MEM_WEIGHT));
+    const int64_t rows_a = batch_a * m;
+    void *aq = nullptr, *rs = nullptr;
+    LELE_TRY(ctx->arena_alloc((size_t)rows_a * kp, &aq));
+    LELE_TRY(ctx->arena_alloc((size_t)rows_a * 4, &rs));
+    hipLaunchKernelGGL(qrows_kernel<1>, dim3((unsigned)((rows_a + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)da,
+                       rows_a, (int)k, kp, (int)m, (const QParams*)nullptr, (int8_t*)aq, (int*)rs);
+    // one launch per batch slice unless everything is un-batched on the B side (then all rows share the weights)
+    const int64_t launches = (batch_b == 1 && batch_a >= 1) ? 1 : fb;
+    for (int64_t bi = 0; bi < launches; ++bi) {
+        const int64_t rows = launches == 1 ? rows_a : m;
+        const int8_t* aptr = (const int8_t*)aq + (launches == 1 || batch_a == 1 ? 0 : bi * m * kp);
+        const int* rsp = (const int*)rs + (launches == 1 || batch_a == 1 ? 0 : bi * m);
+        IgemmEpi epi{(float*)out->data + (launches == 1 ? 0 : bi * m * n), rows, n, (int)m, (int)k, rsp,
+                     pw.col_sums + (batch_b == 1 ? 0 : bi * n), nullptr, zp_a, zp_b, (const float*)ds, (int)slen,
+                     (const float*)dbi, apply_relu};
+        LELE_TRY(launch_igemm(ctx, aptr, pw.wt + (batch_b == 1 ? 0 : bi * n * kp), rows, (int)n, kp, 0, (int)m, epi));
+    }
+    return set_shape_v(out_shape, out_rank, shp);
+}
+
+}  // extern "C"

@@ -32,3 +32,95 @@ def stft_power_spectrum(input, n_fft, hop_length, win_length, window=None, out=N
         ctx._h, _lib.as_tensor(unwrap(input), keep), C.c_int64(n_fft), C.c_int64(hop_length), C.c_int64(win_length),
         _lib.as_tensor(unwrap(window), keep), out._h, sh.shape, C.byref(sh.rank)))
     return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
+
+
+def _call(fn, tensors, extra=(), out=None, ctx=None, dtype=np.float32):
+    """generic C-ABI call: fn(ctx, *tensors, *extra, out, out_shape, out_rank) -> TensorView"""
+    return _op(ctx, fn, tensors, list(extra), out, dtype)
+
+
+def matmul(a, b, out=None, ctx=None):  # gemm.rs:112
+    return _call(_lib.lib().lele_hip_matmul, [a, b], (), out, ctx)
+
+
+def matmul_fused_add(a, b, bias, out=None, ctx=None):  # gemm.rs:223
+    return _call(_lib.lib().lele_hip_matmul_fused_add, [a, b, bias], (), out, ctx)
+
+
+def gemm(a, b, c=None, alpha=1.0, beta=1.0, trans_a=False, trans_b=False, out=None, ctx=None):  # gemm.rs:433
+    ctx = _ctx(ctx)
+    keep = []
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_gemm(ctx._h, _lib.as_tensor(unwrap(a), keep), _lib.as_tensor(unwrap(b), keep),
+                                        _lib.as_tensor(unwrap(c), keep), C.c_float(alpha), C.c_float(beta),
+                                        C.c_int(int(trans_a)), C.c_int(int(trans_b)), out._h, sh.shape,
+                                        C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
+
+
+def _mem_weight(x):
+    """mark a host array as an immutable weight (LELE_MEM_WEIGHT): uploaded / pre-packed once per ctx"""
+    return Weight(x)
+
+
+class Weight:
+    """A host array that is immutable for the life of the ctx (a weights.bin slice)."""
+
+    def __init__(self, arr):
+        self.arr = np.ascontiguousarray(np.asarray(arr, dtype=np.float32) if np.asarray(arr).dtype not in
+                                        (np.float32, np.int64, np.int32, np.uint8, np.int8) else arr)
+
+
+def _t(x, keep):
+    if isinstance(x, Weight):
+        return _lib.as_tensor(x.arr, keep, _lib.MEM_WEIGHT)
+    return _lib.as_tensor(unwrap(x), keep)
+
+
+def fused_quantized_linear(input, weight_int8, weight_scale, weight_zero, bias, apply_relu=False, out=None,
+                           ctx=None):  # quantization.rs:77
+    ctx = _ctx(ctx)
+    keep = []
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_fused_quantized_linear(
+        ctx._h, _t(input, keep), _t(weight_int8, keep), _t(weight_scale, keep), _t(weight_zero, keep), _t(bias, keep),
+        C.c_int(int(apply_relu)), out._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
+
+
+def dynamic_quantize_linear(x, ctx=None):  # quantization.rs:1628 -> (y, scale, zero_point)
+    ctx = _ctx(ctx)
+    keep = []
+    oy, os_, oz = ctx.buf(), ctx.buf(), ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_dynamic_quantize_linear(ctx._h, _t(x, keep), oy._h, os_._h, oz._h, sh.shape,
+                                                           C.byref(sh.rank)))
+    return (TensorView(_lib.DevTensor(oy, sh.get(), np.float32)), TensorView(_lib.DevTensor(os_, (1,), np.float32)),
+            TensorView(_lib.DevTensor(oz, (1,), np.float32)))
+
+
+def mat_mul_integer_with_scale_bias(a, b, a_zero_point=None, b_zero_point=None, scale=None, bias=None,
+                                    apply_relu=False, out=None, ctx=None):  # quantization.rs:31, 927
+    ctx = _ctx(ctx)
+    keep = []
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_mat_mul_integer_with_scale_bias(
+        ctx._h, _t(a, keep), _t(b, keep), _t(a_zero_point, keep), _t(b_zero_point, keep), _t(scale, keep),
+        _t(bias, keep), C.c_int(int(apply_relu)), out._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
+
+
+def mat_mul_integer(a, b, a_zero_point=None, b_zero_point=None, out=None, ctx=None):  # quantization.rs:8
+    return mat_mul_integer_with_scale_bias(a, b, a_zero_point, b_zero_point, None, None, False, out, ctx)
+
+
+def mat_mul_integer_with_bias(a, b, a_zero_point=None, b_zero_point=None, bias=None, out=None, ctx=None):
+    return mat_mul_integer_with_scale_bias(a, b, a_zero_point, b_zero_point, None, bias, False, out, ctx)
+
+
+def mat_mul_integer_with_scale_bias_relu(a, b, a_zero_point=None, b_zero_point=None, scale=None, bias=None, out=None,
+                                         ctx=None):
+    return mat_mul_integer_with_scale_bias(a, b, a_zero_point, b_zero_point, scale, bias, True, out, ctx)

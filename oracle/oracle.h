@@ -59,6 +59,24 @@ int64_t orc_stft(const float* signal, int64_t len, int64_t n_fft, int64_t hop, i
 int64_t orc_stft_power(const float* signal, int64_t len, int64_t n_fft, int64_t hop, int64_t win_length,
                        const float* window, float* out /* [frames, n_fft/2+1] */);
 
+/* ---- src/kernels/gemm.rs ---------------------------------------------------------------------------- */
+/* acc32 = 0: float64-accumulated inner product (the tolerance reference); 1: k-ordered f32 FMA chain */
+void orc_matmul(const float* a, const float* b, int64_t batch_a, int64_t batch_b, int64_t m, int64_t k, int64_t n,
+                float* out, int acc32);                                              /* gemm.rs:112-222 */
+void orc_matmul_fused_add(const float* a, const float* b, const float* bias, int64_t bias_len, int64_t batch_a,
+                          int64_t batch_b, int64_t m, int64_t k, int64_t n, float* out, int acc32); /* 223-432 */
+void orc_gemm(const float* a, const float* b, const float* c, int64_t c_len, float alpha, float beta, int trans_a,
+              int trans_b, int64_t m, int64_t k, int64_t n, float* out, int acc32); /* gemm.rs:433-535 */
+
+/* ---- src/kernels/quantization.rs (+ avx/quantization.rs) --------------------------------------------- */
+void orc_dynamic_quantize_linear(const float* x, int64_t len, float* y, float* scale, float* zp);
+void orc_fused_quantized_linear(const float* input, int64_t batch, int64_t m, int64_t k, int64_t n,
+                                const float* weight, const float* weight_scale, int64_t weight_scale_len,
+                                float weight_zero, const float* bias, int relu, float* out);
+void orc_mat_mul_integer(const float* a, const float* b, int64_t batch_a, int64_t batch_b, int64_t m, int64_t k,
+                         int64_t n, float zp_a, float zp_b, const float* scale, int64_t scale_len, const float* bias,
+                         int relu, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -168,3 +168,89 @@ def stft_power(signal, n_fft, hop, win_length, window=None):
     lib().orc_stft_power(_p(s), i64(s.shape[0]), i64(n_fft), i64(hop), i64(win_length),
                          _p(w) if w is not None else None, _p(out))
     return out
+
+
+# ---------------------------------------------------------------- gemm
+def _batch_dims(shape):
+    b = 1
+    for d in shape[:-2]:
+        b *= d
+    return b
+
+
+def matmul(a, b, acc32=False):
+    a, b = _f32(a), _f32(b)
+    m, k = a.shape[-2:]
+    k2, n = b.shape[-2:]
+    assert k == k2, "MatMul K dim mismatch"
+    ba, bb = _batch_dims(a.shape), _batch_dims(b.shape)
+    assert bb == 1 or bb == ba, "MatMul broadcast not fully supported yet"
+    lead = a.shape[:-2] if ba >= bb else b.shape[:-2]
+    out = np.empty(tuple(lead) + (m, n), np.float32)
+    lib().orc_matmul(_p(a), _p(b), i64(ba), i64(bb), i64(m), i64(k), i64(n), _p(out), C.c_int(int(acc32)))
+    return out
+
+
+def matmul_fused_add(a, b, bias, acc32=False):
+    a, b, bias = _f32(a), _f32(b), _f32(bias)
+    m, k = a.shape[-2:]
+    n = b.shape[-1]
+    ba, bb = max(_batch_dims(a.shape), 1), max(_batch_dims(b.shape), 1)
+    lead = a.shape[:-2] if ba >= bb else b.shape[:-2]
+    out = np.empty(tuple(lead) + (m, n), np.float32)
+    lib().orc_matmul_fused_add(_p(a), _p(b), _p(bias), i64(bias.size), i64(ba), i64(bb), i64(m), i64(k), i64(n),
+                               _p(out), C.c_int(int(acc32)))
+    return out
+
+
+def gemm(a, b, c=None, alpha=1.0, beta=1.0, trans_a=False, trans_b=False, acc32=False):
+    a, b = _f32(a), _f32(b)
+    m = a.shape[-1] if trans_a else a.shape[-2]
+    k = a.shape[-2] if trans_a else a.shape[-1]
+    n = b.shape[-2] if trans_b else b.shape[-1]
+    out = np.empty((m, n), np.float32)
+    cc = _f32(c) if c is not None else None
+    lib().orc_gemm(_p(a), _p(b), _p(cc) if cc is not None else None, i64(cc.size if cc is not None else 0), f(alpha),
+                   f(beta), C.c_int(int(trans_a)), C.c_int(int(trans_b)), i64(m), i64(k), i64(n), _p(out),
+                   C.c_int(int(acc32)))
+    return out
+
+
+# ---------------------------------------------------------------- quantization
+def dynamic_quantize_linear(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    s, z = C.c_float(), C.c_float()
+    lib().orc_dynamic_quantize_linear(_p(x), i64(x.size), _p(y), C.byref(s), C.byref(z))
+    return y, np.array([s.value], np.float32), np.array([z.value], np.float32)
+
+
+def fused_quantized_linear(x, weight, weight_scale, weight_zero, bias, relu=False):
+    x, weight, weight_scale = _f32(x), _f32(weight), _f32(weight_scale).reshape(-1)
+    m, k = x.shape[-2:]
+    n = weight.shape[-1]
+    batch = _batch_dims(x.shape)
+    wz = float(np.asarray(weight_zero).reshape(-1)[0]) if np.asarray(weight_zero).size else 0.0
+    b = _f32(bias).reshape(-1) if bias is not None and np.asarray(bias).size else None
+    out = np.empty(x.shape[:-1] + (n,), np.float32)
+    lib().orc_fused_quantized_linear(_p(x), i64(batch), i64(m), i64(k), i64(n), _p(weight), _p(weight_scale),
+                                     i64(weight_scale.size), f(wz), _p(b) if b is not None else None,
+                                     C.c_int(int(relu)), _p(out))
+    return out
+
+
+def mat_mul_integer(a, b, a_zero_point=None, b_zero_point=None, scale=None, bias=None, relu=False):
+    a, b = _f32(a), _f32(b)
+    m, k = a.shape[-2:]
+    n = b.shape[-1]
+    ba, bb = _batch_dims(a.shape), _batch_dims(b.shape)
+    lead = a.shape[:-2] if ba >= bb else b.shape[:-2]
+    out = np.empty(tuple(lead) + (m, n), np.float32)
+    za = float(np.asarray(a_zero_point).reshape(-1)[0]) if a_zero_point is not None else 0.0
+    zb = float(np.asarray(b_zero_point).reshape(-1)[0]) if b_zero_point is not None else 0.0
+    sc = _f32(scale).reshape(-1) if scale is not None else None
+    bi = _f32(bias).reshape(-1) if bias is not None else None
+    lib().orc_mat_mul_integer(_p(a), _p(b), i64(ba), i64(bb), i64(m), i64(k), i64(n), f(za), f(zb),
+                              _p(sc) if sc is not None else None, i64(sc.size if sc is not None else 0),
+                              _p(bi) if bi is not None else None, C.c_int(int(relu)), _p(out))
+    return out

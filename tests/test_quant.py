@@ -1,0 +1,149 @@
+"""Dynamic-quantised u8 linear path: oracle pinned on the reference's KATs (CPU); device BIT-EXACT vs oracle (GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+K = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kats.json")))
+
+
+def _arr(k, name):
+    return np.array(k[name], np.float32).reshape(k[name + "_shape"])
+
+
+def _sweep_inputs(m, k, n):
+    a = ((np.arange(m * k, dtype=np.int64) * 7 + 13) % 256).astype(np.float32).reshape(m, k)
+    b = ((np.arange(k * n, dtype=np.int64) * 11 + 3) % 256).astype(np.float32).reshape(k, n)
+    return a, b
+
+
+def test_oracle_kats(orc):
+    for name in ("mat_mul_integer_zero_points", "mat_mul_integer_no_zp"):
+        k = K[name]
+        r = orc.mat_mul_integer(_arr(k, "a"), _arr(k, "b"), [k["zp_a"]], [k["zp_b"]])
+        assert np.abs(r.ravel() - np.array(k["expected"])).max() < k["tol"]
+    k = K["mat_mul_integer_per_channel_scale"]
+    r = orc.mat_mul_integer(_arr(k, "a"), _arr(k, "b"), None, None, k["scale"])
+    assert r.shape == (1, 2) and np.abs(r.ravel() - np.array(k["expected"])).max() < k["tol"]
+    k = K["dynamic_quantize_accuracy"]
+    x = _arr(k, "x")
+    y, s, z = orc.dynamic_quantize_linear(x)
+    assert np.abs((y - z[0]) * s[0] - x).max() < s[0] + 0.1  # kernel_accuracy.rs:239-244
+
+
+def test_oracle_int8_shape_sweep(orc):
+    k = K["int8_shape_sweep"]
+    for m, kk, n in k["shapes"]:
+        if m * kk * n > 3_000_000:  # keep the CPU suite fast; the big shapes run in the GPU test below
+            continue
+        a, b = _sweep_inputs(m, kk, n)
+        ref = (a.astype(np.float64) - k["zp_a"]) @ (b.astype(np.float64) - k["zp_b"])  # ref_mat_mul_integer
+        got = orc.mat_mul_integer(a, b, [k["zp_a"]], [k["zp_b"]])
+        assert np.array_equal(got, ref.astype(np.float32)), (m, kk, n)
+
+
+def test_oracle_fused_matches_unfused_composition(orc):
+    # fused == dynamic_quantize_linear + mat_mul_integer(scale = dyn*w_scale, bias) when the batch is one slice and
+    # K is a multiple of 8 (no scalar-tail rounding difference), cf. SURVEY.md section 7 defect (v)/(vi)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 9, 32)).astype(np.float32)
+    w = np.clip(np.round(128 + 32 * rng.standard_normal((32, 24))), 0, 255).astype(np.float32)
+    ws = (np.abs(rng.standard_normal(24)) * 0.01 + 0.002).astype(np.float32)
+    bias = (rng.standard_normal(24) * 0.02).astype(np.float32)
+    fused = orc.fused_quantized_linear(x, w, ws, [128.0], bias, relu=True)
+    y, s, z = orc.dynamic_quantize_linear(x)
+    comp = orc.mat_mul_integer(y, w, z, [128.0], (s[0] * ws).astype(np.float32), bias, relu=True)
+    assert np.array_equal(fused, comp)
+
+
+def _weights(rng, k, n):
+    w = np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32)
+    ws = (np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32)
+    bias = (rng.standard_normal(n) * 0.02).astype(np.float32)
+    return w, ws, bias
+
+
+@pytest.mark.gpu
+def test_device_kats(ctx):
+    from lele_amd import kernels as Kk
+    for name in ("mat_mul_integer_zero_points", "mat_mul_integer_no_zp"):
+        k = K[name]
+        r = Kk.mat_mul_integer(_arr(k, "a"), _arr(k, "b"), [k["zp_a"]], [k["zp_b"]], ctx=ctx)
+        assert r.shape == (2, 2) and np.abs(r.data - np.array(k["expected"])).max() < k["tol"]
+    k = K["mat_mul_integer_per_channel_scale"]
+    r = Kk.mat_mul_integer_with_scale_bias(_arr(k, "a"), _arr(k, "b"), None, None, np.array(k["scale"], np.float32),
+                                           None, ctx=ctx)
+    assert np.abs(r.data - np.array(k["expected"])).max() < k["tol"]
+
+
+@pytest.mark.gpu
+def test_device_int8_shape_sweep_exact(ctx):
+    from lele_amd import kernels as Kk
+    k = K["int8_shape_sweep"]
+    for m, kk, n in k["shapes"]:
+        a, b = _sweep_inputs(m, kk, n)
+        ref = ((a.astype(np.float64) - k["zp_a"]) @ (b.astype(np.float64) - k["zp_b"])).astype(np.float32)
+        got = Kk.mat_mul_integer(a, b, [k["zp_a"]], [k["zp_b"]], ctx=ctx)
+        assert got.shape == (m, n) and np.array_equal(got.numpy(), ref), (m, kk, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 93, 560, 1536), (1, 93, 512, 512), (1, 93, 512, 2048), (1, 93, 2048, 512),
+                                   (3, 17, 64, 40), (2, 5, 37, 19), (1, 1, 8, 1), (1, 504, 512, 1536), (4, 171, 512, 512),
+                                   (1, 33, 100, 130)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_device_fused_quantized_linear_bit_exact(ctx, orc, shape, relu):
+    from lele_amd import kernels as Kk
+    b, m, k, n = shape
+    rng = np.random.default_rng(b * 1000 + m + k + n)
+    x = (rng.standard_normal((b, m, k)) * rng.uniform(0.5, 3.0, (b, 1, 1))).astype(np.float32)  # a range per slice
+    w, ws, bias = _weights(rng, k, n)
+    ref = orc.fused_quantized_linear(x, w, ws, [128.0], bias, relu)
+    got = Kk.fused_quantized_linear(x, w, ws, np.array([128.0], np.float32), bias, relu, ctx=ctx)
+    assert got.shape == ref.shape and np.array_equal(got.numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_device_fused_variants(ctx, orc):
+    from lele_amd import kernels as Kk
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 7, 48)).astype(np.float32)
+    w, ws, bias = _weights(rng, 48, 20)
+    # scalar weight scale, empty bias, non-default weight zero point, weights declared immutable (cached pre-pack)
+    for wsc, bb, wz in ((ws[:1], bias, 128.0), (ws, np.zeros((0,), np.float32), 131.0), (ws, None, 0.0)):
+        ref = orc.fused_quantized_linear(x, w, wsc, [wz], bb)
+        wq = Kk.Weight(w)
+        for _ in range(2):  # second call hits the weight cache
+            got = Kk.fused_quantized_linear(x, wq, wsc, np.array([wz], np.float32), bb, ctx=ctx)
+            assert np.array_equal(got.numpy(), ref)
+    # all-zero and constant inputs (range clamps to 1e-5)
+    for xx in (np.zeros((1, 4, 48), np.float32), np.full((1, 4, 48), 0.25, np.float32)):
+        assert np.array_equal(Kk.fused_quantized_linear(xx, w, ws, [128.0], bias, ctx=ctx).numpy(),
+                              orc.fused_quantized_linear(xx, w, ws, [128.0], bias))
+
+
+@pytest.mark.gpu
+def test_device_dynamic_quantize_and_unfused_chain_bit_exact(ctx, orc):
+    from lele_amd import kernels as Kk
+    rng = np.random.default_rng(4)
+    for shape in ((2, 4), (3, 5, 7), (1, 93, 512), (13,)):
+        x = (rng.standard_normal(shape) * 2 + 0.3).astype(np.float32)
+        y, s, z = Kk.dynamic_quantize_linear(x, ctx=ctx)
+        ry, rs, rz = orc.dynamic_quantize_linear(x)
+        assert y.shape == x.shape and np.array_equal(y.numpy(), ry)
+        assert np.array_equal(s.numpy(), rs) and np.array_equal(z.numpy(), rz)
+    x = rng.standard_normal((2, 9, 40)).astype(np.float32)
+    w, ws, bias = _weights(rng, 40, 24)
+    y, s, z = Kk.dynamic_quantize_linear(x, ctx=ctx)  # device-resident chain: no host round trip for y / z
+    comb = (orc.dynamic_quantize_linear(x)[1][0] * ws).astype(np.float32)
+    got = Kk.mat_mul_integer_with_scale_bias_relu(y, w, z, np.array([128.0], np.float32), comb, bias, ctx=ctx)
+    ry, rs, rz = orc.dynamic_quantize_linear(x)
+    assert np.array_equal(got.numpy(), orc.mat_mul_integer(ry, w, rz, [128.0], comb, bias, relu=True))
+    # batched B (batch_b == batch_a) and broadcast A
+    a = rng.integers(0, 256, (3, 6, 20)).astype(np.float32)
+    bq = rng.integers(0, 256, (3, 20, 10)).astype(np.float32)
+    assert np.array_equal(Kk.mat_mul_integer(a, bq, [3.0], [250.0], ctx=ctx).numpy(),
+                          orc.mat_mul_integer(a, bq, [3.0], [250.0]))
+    assert np.array_equal(Kk.mat_mul_integer(a[:1], bq, [3.0], [250.0], ctx=ctx).numpy(),
+                          orc.mat_mul_integer(a[:1], bq, [3.0], [250.0]))
