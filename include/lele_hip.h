@@ -151,6 +151,44 @@ int lele_hip_mat_mul_integer_with_scale_bias(LeleCtx* ctx, const LeleTensor* a, 
                                              const LeleTensor* scale, const LeleTensor* bias, int apply_relu,
                                              LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
 
+/* ---- src/kernels/math.rs: activations and element-wise ops ---------------------------------------------- */
+/* Unary f32 ops.  LeleUnaryOp names the lele kernel it replaces (math.rs file:line in eltwise.hip). */
+typedef enum {
+    LELE_U_EXP = 0, LELE_U_SIGMOID = 1, LELE_U_TANH = 2, LELE_U_SILU = 3, LELE_U_ERF = 4, LELE_U_GELU = 5,
+    LELE_U_FAST_GELU = 6, LELE_U_RELU = 7, LELE_U_SQRT = 8, LELE_U_LOG = 9, LELE_U_SIN = 10, LELE_U_COS = 11,
+    LELE_U_NEG = 12, LELE_U_RECIPROCAL = 13, LELE_U_SOFTPLUS = 14, LELE_U_NOT = 15, LELE_U_ABS = 16,
+    LELE_U_FLOOR = 17, LELE_U_CEIL = 18
+} LeleUnaryOp;
+int lele_hip_unary(LeleCtx* ctx, int op, const LeleTensor* x, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* Binary ops with numpy-style broadcasting (math.rs:69-264): add, sub, mul, div work on f32 and i64 */
+typedef enum {
+    LELE_B_ADD = 0, LELE_B_SUB = 1, LELE_B_MUL = 2, LELE_B_DIV = 3, LELE_B_POW = 4, LELE_B_MAX = 5, LELE_B_MIN = 6,
+    LELE_B_EQUAL = 7, LELE_B_LESS = 8, LELE_B_GREATER = 9, LELE_B_PRELU = 10, LELE_B_MOD = 11, LELE_B_AND = 12,
+    LELE_B_OR = 13
+} LeleBinaryOp;
+int lele_hip_binary(LeleCtx* ctx, int op, const LeleTensor* a, const LeleTensor* b, LeleBuf* out, int64_t* out_shape,
+                    int32_t* out_rank);
+/* where_op, manipulation.rs:1215: out = cond != 0 ? x : y */
+int lele_hip_where(LeleCtx* ctx, const LeleTensor* cond, const LeleTensor* x, const LeleTensor* y, LeleBuf* out,
+                   int64_t* out_shape, int32_t* out_rank);
+/* clip, math.rs:1984-2010 */
+int lele_hip_clip(LeleCtx* ctx, const LeleTensor* x, int has_min, float min_v, int has_max, float max_v, LeleBuf* out,
+                  int64_t* out_shape, int32_t* out_rank);
+/* reduce_sum / reduce_mean / reduce_max / reduce_l2 (/ min), math.rs:1527-1920 */
+typedef enum { LELE_R_SUM = 0, LELE_R_MEAN = 1, LELE_R_MAX = 2, LELE_R_L2 = 3, LELE_R_MIN = 4 } LeleReduceOp;
+int lele_hip_reduce(LeleCtx* ctx, int op, const LeleTensor* x, const int64_t* axes, size_t naxes, int keepdims,
+                    LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* ---- src/kernels/norm.rs --------------------------------------------------------------------------------- */
+int lele_hip_layer_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, const LeleTensor* bias,
+                        int32_t axis, float epsilon, LeleBuf* out, int64_t* out_shape, int32_t* out_rank); /* norm.rs:226 */
+int lele_hip_rms_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* weight, int32_t axis, float epsilon,
+                      LeleBuf* out, int64_t* out_shape, int32_t* out_rank);                                /* norm.rs:420 */
+int lele_hip_softmax(LeleCtx* ctx, const LeleTensor* x, int32_t axis, LeleBuf* out, int64_t* out_shape,
+                     int32_t* out_rank);                                                                    /* norm.rs:8 */
+int lele_hip_batch_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, const LeleTensor* bias,
+                        const LeleTensor* mean, const LeleTensor* var, float epsilon, LeleBuf* out, int64_t* out_shape,
+                        int32_t* out_rank);                                                                  /* norm.rs:313 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,637 @@
+// eltwise.hip -- activations, element-wise broadcast ops, reductions and the normalisation kernels.
+//
+// Unary (src/kernels/math.rs:893-1104, 1280-1479, 2084-2153 -> src/kernels/avx/math.rs:11-603):
+//   lele's x86 kernels run an 8-wide AVX2 body (degree-6 polynomial exp with hi/lo ln2 split, A&S erf, ...) over the
+//   first len&~7 elements and call libm for the scalar tail.  The device applies THE SAME polynomial, with the same
+//   FMA placement, to exactly those elements (bit-exact), and the accurate device libm to the tail elements.
+// Binary broadcast / compare / where / clip / prelu (math.rs:69-264, 414-836, 838, 1106, 1163-1278, 1481, 1922-2031):
+//   one IEEE operation per element, numpy-style broadcasting -> bit-exact.
+// Reductions (math.rs:1527-1920): every output element accumulates its inputs in row-major input order, as the
+//   reference's coordinate walk does -> bit-exact.
+// LayerNorm / Softmax / RMSNorm / BatchNorm (norm.rs:8-506 -> avx/norm.rs:10-345): the reference's 4x8-lane
+//   accumulators, merge order, 8-wide remainder, horizontal sum and scalar tail are reproduced by giving 32 lanes the
+//   roles of the 32 SIMD accumulator slots, so the statistics -- and therefore the outputs -- are bit-exact.
+#include "common.h"
+
+#include <math.h>
+
+using namespace lele;
+
+namespace {
+
+__device__ __forceinline__ float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// avx2_exp_ps, avx/math.rs:11-63
+__device__ __forceinline__ float exp_poly(float x) {
+    x = fmaxf(x, -87.33654f);
+    x = fminf(x, 88.72284f);
+    const float fx = rintf(x * 1.44269504088896341f);  // _mm256_round_ps(nearest-even)
+    x = fmaf_(-fx, 0.693359375f, x);                    // _mm256_fnmadd_ps(fx, ln2_hi, x)
+    x = fmaf_(-fx, -2.12194440e-4f, x);
+    float y = fmaf_(0.000198712018891638893f, x, 0.00139712726883569741f);
+    y = fmaf_(y, x, 0.00833345670066840443f);
+    y = fmaf_(y, x, 0.0416657844442129135f);
+    y = fmaf_(y, x, 0.166666671633720398f);
+    y = fmaf_(y, x, 0.5f);
+    y = fmaf_(y, x, 1.0f);
+    y = fmaf_(y, x, 1.0f);
+    const int e = ((int)fx + 127) << 23;  // cvtps_epi32(fx) is exact: fx is integral
+    return y * __int_as_float(e);
+}
+__device__ __forceinline__ float sigmoid_poly(float x) { return 1.0f / (1.0f + exp_poly(-x)); }  // avx/math.rs:66-76
+__device__ __forceinline__ float tanh_poly(float x) {                                            // avx/math.rs:79-97
+    const float e = exp_poly(-x * 2.0f);
+    const float r = (1.0f - e) / (1.0f + e);
+    return copysignf(fabsf(r), x);
+}
+__device__ __forceinline__ float erf_poly(float x) {  // avx/math.rs:112-145
+    const float ax = fabsf(x);
+    const float t = 1.0f / fmaf_(0.3275911f, ax, 1.0f);
+    float poly = fmaf_(1.061405429f, t, -1.453152027f);
+    poly = fmaf_(poly, t, 1.421413741f);
+    poly = fmaf_(poly, t, -0.284496736f);
+    poly = fmaf_(poly, t, 0.254829592f);
+    const float ev = exp_poly(-(ax * ax));
+    const float r = fmaf_(-(poly * t), ev, 1.0f);  // _mm256_fnmadd_ps(poly*t, exp, one)
+    return __int_as_float(__float_as_int(r) | (__float_as_int(x) & 0x80000000));
+}
+
+enum UnaryOp {
+    U_EXP = 0, U_SIGMOID = 1, U_TANH = 2, U_SILU = 3, U_ERF = 4, U_GELU = 5, U_FAST_GELU = 6, U_RELU = 7, U_SQRT = 8,
+    U_LOG = 9, U_SIN = 10, U_COS = 11, U_NEG = 12, U_RECIPROCAL = 13, U_SOFTPLUS = 14, U_NOT = 15, U_ABS = 16,
+    U_FLOOR = 17, U_CEIL = 18
+};
+
+__device__ __forceinline__ float unary_apply(int op, float x, bool body) {
+    switch (op) {
+        case U_EXP: return body ? exp_poly(x) : expf(x);
+        case U_SIGMOID: return body ? sigmoid_poly(x) : 1.0f / (1.0f + expf(-x));
+        case U_TANH: return body ? tanh_poly(x) : tanhf(x);
+        case U_SILU: return body ? x * sigmoid_poly(x) : x / (1.0f + expf(-x));
+        case U_ERF: return body ? erf_poly(x) : erff(x);
+        case U_GELU:
+            return body ? (x * 0.5f) * (1.0f + erf_poly(x * 0.7071067811865475f))
+                        : x * 0.5f * (1.0f + erff(x * 0.7071067811865475f));
+        case U_FAST_GELU: {
+            if (body) {
+                const float x3 = (x * x) * x;
+                const float inner = 0.7978845608028654f * fmaf_(0.044715f, x3, x);
+                return (x * 0.5f) * (1.0f + tanh_poly(inner));
+            }
+            const float inner = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+            return 0.5f * x * (1.0f + tanhf(inner));
+        }
+        case U_RELU: return x > 0.0f ? x : 0.0f;
+        case U_SQRT: return sqrtf(x);
+        case U_LOG: return logf(x);
+        case U_SIN: return sinf(x);
+        case U_COS: return cosf(x);
+        case U_NEG: return -x;
+        case U_RECIPROCAL: return 1.0f / x;
+        case U_SOFTPLUS: return x > 20.0f ? x : logf(1.0f + expf(x));  // math.rs:1046-1056
+        case U_NOT: return x == 0.0f ? 1.0f : 0.0f;                     // math.rs:1508-1525
+        case U_ABS: return fabsf(x);
+        case U_FLOOR: return floorf(x);
+        case U_CEIL: return ceilf(x);
+    }
+    return x;
+}
+
+__global__ void unary_kernel(int op, const float* __restrict__ x, float* __restrict__ y, int64_t len) {
+    const int64_t body_end = len & ~int64_t(7);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = unary_apply(op, x[i], i < body_end);
+}
+
+// ------------------------------------------------------------------------------------------ binary broadcast
+enum BinaryOp {
+    B_ADD = 0, B_SUB = 1, B_MUL = 2, B_DIV = 3, B_POW = 4, B_MAX = 5, B_MIN = 6, B_EQUAL = 7, B_LESS = 8,
+    B_GREATER = 9, B_PRELU = 10, B_MOD = 11, B_AND = 12, B_OR = 13
+};
+
+struct Bcast {
+    int rank;
+    int64_t oshape[LELE_MAX_RANK];
+    int64_t astride[LELE_MAX_RANK];  // 0 on broadcast dimensions
+    int64_t bstride[LELE_MAX_RANK];
+    int64_t cstride[LELE_MAX_RANK];  // third operand (where_op)
+};
+
+template <typename T>
+__device__ __forceinline__ T binary_apply(int op, T a, T b);
+template <>
+__device__ __forceinline__ float binary_apply<float>(int op, float a, float b) {
+    switch (op) {
+        case B_ADD: return a + b;
+        case B_SUB: return a - b;
+        case B_MUL: return a * b;
+        case B_DIV: return a / b;
+        case B_POW: return powf(a, b);
+        case B_MAX: return fmaxf(a, b);
+        case B_MIN: return fminf(a, b);
+        case B_EQUAL: return a == b ? 1.0f : 0.0f;
+        case B_LESS: return a < b ? 1.0f : 0.0f;
+        case B_GREATER: return a > b ? 1.0f : 0.0f;
+        case B_PRELU: return a < 0.0f ? a * b : a;                        // math.rs:2012-2031
+        case B_MOD: return b == 0.0f ? 0.0f : a - b * floorf(a / b);      // math.rs:1163-1192
+        case B_AND: return (a != 0.0f && b != 0.0f) ? 1.0f : 0.0f;
+        case B_OR: return (a != 0.0f || b != 0.0f) ? 1.0f : 0.0f;
+    }
+    return a;
+}
+template <>
+__device__ __forceinline__ int64_t binary_apply<int64_t>(int op, int64_t a, int64_t b) {
+    switch (op) {
+        case B_ADD: return a + b;
+        case B_SUB: return a - b;
+        case B_MUL: return a * b;
+        case B_DIV: return b == 0 ? 0 : a / b;
+        case B_MAX: return a > b ? a : b;
+        case B_MIN: return a < b ? a : b;
+        case B_EQUAL: return a == b ? 1 : 0;
+        case B_LESS: return a < b ? 1 : 0;
+        case B_GREATER: return a > b ? 1 : 0;
+        case B_MOD: return b == 0 ? 0 : a % b;
+    }
+    return a;
+}
+
+template <typename T>
+__global__ void binary_kernel(int op, const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out,
+                              int64_t numel, Bcast bc, int same) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t ia = i, ib = i;
+        if (!same) {
+            ia = 0;
+            ib = 0;
+            int64_t rem = i;
+            for (int d = bc.rank - 1; d >= 0; --d) {
+                const int64_t c = rem % bc.oshape[d];
+                rem /= bc.oshape[d];
+                ia += c * bc.astride[d];
+                ib += c * bc.bstride[d];
+            }
+        }
+        out[i] = binary_apply<T>(op, a[ia], b[ib]);
+    }
+}
+
+// where_op (manipulation.rs:1215-): out = cond != 0 ? x : y, three-way broadcast
+__global__ void where_kernel(const float* __restrict__ cnd, const float* __restrict__ x, const float* __restrict__ y,
+                             float* __restrict__ out, int64_t numel, Bcast bc) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t ic = 0, ix = 0, iy = 0, rem = i;
+        for (int d = bc.rank - 1; d >= 0; --d) {
+            const int64_t c = rem % bc.oshape[d];
+            rem /= bc.oshape[d];
+            ic += c * bc.cstride[d];
+            ix += c * bc.astride[d];
+            iy += c * bc.bstride[d];
+        }
+        out[i] = cnd[ic] != 0.0f ? x[ix] : y[iy];
+    }
+}
+
+__global__ void clip_kernel(const float* __restrict__ x, float lo, float hi, float* __restrict__ y, int64_t len) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+        float v = x[i];
+        v = v < lo ? lo : v;  // f32::clamp
+        v = v > hi ? hi : v;
+        y[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ reductions
+enum ReduceOp { R_SUM = 0, R_MEAN = 1, R_MAX = 2, R_L2 = 3, R_MIN = 4 };
+struct ReduceDesc {
+    int rank_keep, rank_red;
+    int64_t keep_shape[LELE_MAX_RANK], keep_stride[LELE_MAX_RANK];  // input strides of kept dims
+    int64_t red_shape[LELE_MAX_RANK], red_stride[LELE_MAX_RANK];    // input strides of reduced dims (row-major order)
+    int64_t red_count;
+};
+// one thread per output element; reduced elements visited in row-major input order (math.rs:1580-1597)
+__global__ void reduce_kernel(int op, const float* __restrict__ x, float* __restrict__ out, int64_t out_numel,
+                              ReduceDesc rd) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= out_numel) return;
+    int64_t base = 0, rem = o;
+    for (int d = rd.rank_keep - 1; d >= 0; --d) {
+        base += (rem % rd.keep_shape[d]) * rd.keep_stride[d];
+        rem /= rd.keep_shape[d];
+    }
+    float acc = (op == R_MAX) ? -INFINITY : (op == R_MIN ? INFINITY : 0.0f);
+    for (int64_t r = 0; r < rd.red_count; ++r) {
+        int64_t off = base, rr = r;
+        for (int d = rd.rank_red - 1; d >= 0; --d) {
+            off += (rr % rd.red_shape[d]) * rd.red_stride[d];
+            rr /= rd.red_shape[d];
+        }
+        const float v = x[off];
+        if (op == R_MAX)
+            acc = v > acc ? v : acc;
+        else if (op == R_MIN)
+            acc = v < acc ? v : acc;
+        else if (op == R_L2)
+            acc = acc + v * v;
+        else
+            acc = acc + v;
+    }
+    if (op == R_MEAN) acc = acc * (1.0f / (float)rd.red_count);  // math.rs:1602-1605
+    if (op == R_L2) acc = sqrtf(acc);
+    out[o] = acc;
+}
+
+// ------------------------------------------------------------------------------------------ row statistics
+// 32 lanes play the 4x8 accumulator slots of the AVX2 code: slot l = 8*u + i accumulates elements j = 32c + l.
+// Returns (in every lane of the 32-lane group) hsum( (s0+s1)+(s2+s3) [+ 8-wide remainder chunks] ) + scalar tail.
+template <bool SQUARE, bool PLAIN, class F>
+__device__ __forceinline__ void row_sums(const F& elem, int64_t n, int l, float* out_sum, float* out_sq) {
+    float s = 0.0f, q = 0.0f;
+    int64_t j = 0;
+    for (; j + 32 <= n; j += 32) {
+        const float v = elem(j + l);
+        if (PLAIN) s = s + v;
+        if (SQUARE) q = fmaf_(v, v, q);
+    }
+    // merge (acc0+acc1) + (acc2+acc3): slot i of the result lives in lanes 0..7
+    float s01 = s + __shfl_down(s, 8, 32), q01 = q + __shfl_down(q, 8, 32);
+    float sv = s01 + __shfl_down(s01, 16, 32), qv = q01 + __shfl_down(q01, 16, 32);
+    for (; j + 8 <= n; j += 8) {  // remaining 8-wide chunks go to the merged vector
+        if (l < 8) {
+            const float v = elem(j + l);
+            if (PLAIN) sv = sv + v;
+            if (SQUARE) qv = fmaf_(v, v, qv);
+        }
+    }
+    // horizontal: (i)+(i+4), then (i)+(i+2), then [0]+[1]
+    sv = sv + __shfl_down(sv, 4, 32);
+    qv = qv + __shfl_down(qv, 4, 32);
+    sv = sv + __shfl_down(sv, 2, 32);
+    qv = qv + __shfl_down(qv, 2, 32);
+    sv = sv + __shfl_down(sv, 1, 32);
+    qv = qv + __shfl_down(qv, 1, 32);
+    for (; j < n; ++j) {  // scalar tail (lane 0 carries the result)
+        const float v = elem(j);
+        if (PLAIN) sv = sv + v;
+        if (SQUARE) qv = qv + v * v;
+    }
+    *out_sum = __shfl(sv, 0, 32);
+    *out_sq = __shfl(qv, 0, 32);
+}
+
+// layer_norm_x86, avx/norm.rs:10-133.  8 rows per 256-thread block (one 32-lane group per row).
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ b, float* __restrict__ y,
+                                                         int64_t norm, int64_t outer, float eps) {
+    const int l = threadIdx.x & 31;
+    const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= outer) return;
+    const float* in = x + row * norm;
+    float* out = y + row * norm;
+    float sum, sumsq;
+    row_sums<true, true>([&](int64_t j) { return in[j]; }, norm, l, &sum, &sumsq);
+    const float inv_n = 1.0f / (float)norm;
+    const float mean = sum * inv_n;
+    const float var = sumsq * inv_n - mean * mean;
+    const float inv_std = 1.0f / sqrtf(var + eps);
+    const int64_t body = norm & ~int64_t(7);
+    for (int64_t j = l; j < norm; j += 32) {
+        const float t = (in[j] - mean) * inv_std;
+        out[j] = j < body ? fmaf_(t, g[j], b[j]) : t * g[j] + b[j];
+    }
+}
+
+// rms_norm_x86, avx/norm.rs:236-307
+__global__ __launch_bounds__(256) void rms_norm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       float* __restrict__ y, int64_t norm, int64_t outer, float eps) {
+    const int l = threadIdx.x & 31;
+    const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= outer) return;
+    const float* in = x + row * norm;
+    float* out = y + row * norm;
+    float dummy, sumsq;
+    row_sums<true, false>([&](int64_t j) { return in[j]; }, norm, l, &dummy, &sumsq);
+    const float inv_n = 1.0f / (float)norm;
+    const float rms_inv = 1.0f / sqrtf(sumsq * inv_n + eps);
+    const int64_t body = norm & ~int64_t(7);
+    for (int64_t j = l; j < norm; j += 32)
+        out[j] = j < body ? in[j] * (w[j] * rms_inv) : in[j] * rms_inv * w[j];  // body: eff_w = weight*rms_inv
+}
+
+// softmax over a contiguous last axis, avx/norm.rs:139-229
+__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t len,
+                                                      int64_t outer) {
+    const int l = threadIdx.x & 31;
+    const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= outer) return;
+    const float* src = x + row * len;
+    float* dst = y + row * len;
+    float m = -3.40282347e+38f;  // f32::MIN seeds; max is order-independent
+    for (int64_t j = l; j < len; j += 32) m = fmaxf(m, src[j]);
+    for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+    const int64_t body = len & ~int64_t(7);
+    // exp(x - max): polynomial in the SIMD body, libm in the tail; summed in the AVX accumulator order.  The values
+    // are recomputed (deterministically) wherever another lane's element is needed, so no cross-lane memory traffic.
+    auto ev = [&](int64_t j) { return j < body ? exp_poly(src[j] - m) : expf(src[j] - m); };
+    float sum, dummy;
+    row_sums<false, true>(ev, len, l, &sum, &dummy);
+    const float inv_sum = 1.0f / sum;
+    for (int64_t j = l; j < len; j += 32) dst[j] = ev(j) * inv_sum;
+}
+
+// batch_norm (norm.rs:313-418): per (outer, channel) slice out = fma(x, scale_val, bias_val) in the 8-wide body
+__global__ void batch_norm_kernel(const float* __restrict__ x, const float* __restrict__ s, const float* __restrict__ b,
+                                  const float* __restrict__ m, const float* __restrict__ v, float eps, int64_t c,
+                                  int64_t inner, int64_t numel, float* __restrict__ y) {
+    const int64_t body = inner & ~int64_t(7);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = i % inner, ch = (i / inner) % c;
+        const float scale_val = s[ch] / sqrtf(v[ch] + eps);
+        const float bias_val = b[ch] - m[ch] * scale_val;
+        y[i] = k < body ? fmaf_(x[i], scale_val, bias_val) : x[i] * scale_val + bias_val;
+    }
+}
+
+inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)); }
+
+// numpy-style broadcast of up to three operands (utils.rs:103-132)
+int make_bcast(const LeleTensor* const* ops, int nops, Bcast* bc, std::vector<int64_t>* oshape, const char* who) {
+    int rank = 0;
+    for (int i = 0; i < nops; ++i) rank = std::max(rank, (int)ops[i]->rank);
+    LELE_REQUIRE(rank <= LELE_MAX_RANK, "%s: rank %d exceeds %d", who, rank, LELE_MAX_RANK);
+    oshape->assign(rank, 1);
+    for (int d = 0; d < rank; ++d)
+        for (int i = 0; i < nops; ++i) {
+            const int od = d - (rank - ops[i]->rank);
+            const int64_t dim = od < 0 ? 1 : ops[i]->shape[od];
+            if (dim != 1) {
+                LELE_REQUIRE((*oshape)[d] == 1 || (*oshape)[d] == dim, "Shapes not broadcastable");  // math.rs:80-85
+                (*oshape)[d] = dim;
+            }
+        }
+    for (int d = 0; d < rank; ++d) {
+        const int od = d - (rank - ops[0]->rank);
+        if (od >= 0 && ops[0]->shape[od] == 0) (*oshape)[d] = 0;
+    }
+    bc->rank = rank;
+    int64_t* strides[3] = {bc->astride, bc->bstride, bc->cstride};
+    for (int i = 0; i < nops; ++i) {
+        int64_t st = 1;
+        for (int d = rank - 1; d >= 0; --d) {
+            const int od = d - (rank - ops[i]->rank);
+            const int64_t dim = od < 0 ? 1 : ops[i]->shape[od];
+            strides[i][d] = dim == 1 ? 0 : st;
+            st *= dim;
+        }
+    }
+    for (int d = 0; d < rank; ++d) bc->oshape[d] = (*oshape)[d];
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lele_hip_unary(LeleCtx* ctx, int op, const LeleTensor* x, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && out, "unary: NULL argument");
+    LELE_REQUIRE(op >= 0 && op <= U_CEIL, "unary: unknown op %d", op);
+    LELE_REQUIRE(x->dtype == LELE_F32, "unary: f32 input required");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t len = numel(x);
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(out->reserve((size_t)len * 4));
+    if (len) {
+        hipLaunchKernelGGL(unary_kernel, dim3(grid_for(len)), dim3(256), 0, ctx->stream, op, (const float*)dx,
+                           (float*)out->data, len);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(x->shape, x->shape + x->rank));
+}
+
+int lele_hip_binary(LeleCtx* ctx, int op, const LeleTensor* a, const LeleTensor* b, LeleBuf* out, int64_t* out_shape,
+                    int32_t* out_rank) {
+    LELE_REQUIRE(ctx && a && b && out, "binary: NULL argument");
+    LELE_REQUIRE(op >= 0 && op <= B_OR, "binary: unknown op %d", op);
+    LELE_REQUIRE(a->dtype == b->dtype && (a->dtype == LELE_F32 || a->dtype == LELE_I64),
+                 "binary: operands must both be f32 or both i64");
+    LELE_REQUIRE(a->dtype == LELE_F32 || (op != B_POW && op != B_PRELU && op != B_AND && op != B_OR),
+                 "binary: op %d is f32-only", op);
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    Bcast bc;
+    std::vector<int64_t> oshape;
+    const LeleTensor* ops[2] = {a, b};
+    LELE_TRY(make_bcast(ops, 2, &bc, &oshape, "binary"));
+    int64_t n = 1;
+    for (int64_t d : oshape) n *= d;
+    const size_t es = dtype_size(a->dtype);
+    LELE_TRY(ctx->arena_reset());
+    const void *da = nullptr, *db = nullptr;
+    LELE_TRY(ctx->dev_ptr(a, &da));
+    LELE_TRY(ctx->dev_ptr(b, &db));
+    LELE_TRY(out->reserve((size_t)n * es));
+    if (n) {
+        const int same = (numel(a) == n && numel(b) == n) ? 1 : 0;
+        if (a->dtype == LELE_F32)
+            hipLaunchKernelGGL(binary_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, op, (const float*)da,
+                               (const float*)db, (float*)out->data, n, bc, same);
+        else
+            hipLaunchKernelGGL(binary_kernel<int64_t>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, op,
+                               (const int64_t*)da, (const int64_t*)db, (int64_t*)out->data, n, bc, same);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, oshape);
+}
+
+int lele_hip_where(LeleCtx* ctx, const LeleTensor* cond, const LeleTensor* x, const LeleTensor* y, LeleBuf* out,
+                   int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && cond && x && y && out, "where_op: NULL argument");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    Bcast bc;
+    std::vector<int64_t> oshape;
+    const LeleTensor* ops[3] = {x, y, cond};
+    LELE_TRY(make_bcast(ops, 3, &bc, &oshape, "where_op"));
+    int64_t n = 1;
+    for (int64_t d : oshape) n *= d;
+    LELE_TRY(ctx->arena_reset());
+    const void *dc = nullptr, *dx = nullptr, *dy = nullptr;
+    LELE_TRY(ctx->dev_ptr(cond, &dc));
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(ctx->dev_ptr(y, &dy));
+    LELE_TRY(out->reserve((size_t)n * 4));
+    if (n) {
+        hipLaunchKernelGGL(where_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const float*)dc,
+                           (const float*)dx, (const float*)dy, (float*)out->data, n, bc);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, oshape);
+}
+
+int lele_hip_clip(LeleCtx* ctx, const LeleTensor* x, int has_min, float min_v, int has_max, float max_v, LeleBuf* out,
+                  int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && out, "clip: NULL argument");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t len = numel(x);
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(out->reserve((size_t)len * 4));
+    if (len) {
+        hipLaunchKernelGGL(clip_kernel, dim3(grid_for(len)), dim3(256), 0, ctx->stream, (const float*)dx,
+                           has_min ? min_v : -3.40282347e+38f, has_max ? max_v : 3.40282347e+38f, (float*)out->data,
+                           len);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(x->shape, x->shape + x->rank));
+}
+
+int lele_hip_reduce(LeleCtx* ctx, int op, const LeleTensor* x, const int64_t* axes, size_t naxes, int keepdims,
+                    LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && out, "reduce: NULL argument");
+    LELE_REQUIRE(op >= 0 && op <= R_MIN, "reduce: unknown op %d", op);
+    LELE_REQUIRE(x->rank <= LELE_MAX_RANK, "reduce: rank too large");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int dims = x->rank;
+    std::vector<bool> mask(dims, false);
+    for (size_t i = 0; i < naxes; ++i) {  // math.rs:1534-1551
+        int64_t ax = axes[i] < 0 ? dims + axes[i] : axes[i];
+        LELE_REQUIRE(ax >= 0 && ax < dims, "reduce: axis %lld out of range", (long long)axes[i]);
+        mask[ax] = true;
+    }
+    if (naxes == 0)
+        for (int d = 0; d < dims; ++d) mask[d] = true;  // ONNX default: reduce all
+    std::vector<int64_t> istr(dims, 1);
+    for (int d = dims - 2; d >= 0; --d) istr[d] = istr[d + 1] * x->shape[d + 1];
+    ReduceDesc rd{};
+    std::vector<int64_t> oshape;
+    rd.red_count = 1;
+    for (int d = 0; d < dims; ++d) {
+        if (mask[d]) {
+            rd.red_shape[rd.rank_red] = x->shape[d];
+            rd.red_stride[rd.rank_red++] = istr[d];
+            rd.red_count *= x->shape[d];
+            if (keepdims) oshape.push_back(1);
+        } else {
+            rd.keep_shape[rd.rank_keep] = x->shape[d];
+            rd.keep_stride[rd.rank_keep++] = istr[d];
+            oshape.push_back(x->shape[d]);
+        }
+    }
+    int64_t on = 1;
+    for (int64_t d : oshape) on *= d;
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(out->reserve((size_t)on * 4));
+    if (on) {
+        hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((on + 63) / 64)), dim3(64), 0, ctx->stream, op,
+                           (const float*)dx, (float*)out->data, on, rd);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, oshape);
+}
+
+int lele_hip_layer_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, const LeleTensor* bias,
+                        int32_t axis, float epsilon, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && scale && bias && out, "layer_norm: NULL argument");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int nd = x->rank;
+    const int ax = axis < 0 ? nd + axis : axis;  // norm.rs:234-235
+    LELE_REQUIRE(ax >= 0 && ax <= nd, "layer_norm: axis %d out of range", axis);
+    int64_t outer = 1, norm = 1;
+    for (int d = 0; d < ax; ++d) outer *= x->shape[d];
+    for (int d = ax; d < nd; ++d) norm *= x->shape[d];
+    LELE_REQUIRE(numel(scale) >= norm && numel(bias) >= norm, "layer_norm: scale/bias shorter than the normalised size");
+    LELE_TRY(ctx->arena_reset());
+    const void *dx = nullptr, *dg = nullptr, *db = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(ctx->dev_ptr(scale, &dg));
+    LELE_TRY(ctx->dev_ptr(bias, &db));
+    LELE_TRY(out->reserve((size_t)outer * norm * 4));
+    if (outer * norm) {
+        hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)((outer + 7) / 8)), dim3(256), 0, ctx->stream,
+                           (const float*)dx, (const float*)dg, (const float*)db, (float*)out->data, norm, outer, epsilon);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(x->shape, x->shape + x->rank));
+}
+
+int lele_hip_rms_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* weight, int32_t axis, float epsilon,
+                      LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && weight && out, "rms_norm: NULL argument");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int nd = x->rank;
+    const int ax = axis < 0 ? nd + axis : axis;
+    LELE_REQUIRE(ax >= 0 && ax <= nd, "rms_norm: axis %d out of range", axis);
+    int64_t outer = 1, norm = 1;
+    for (int d = 0; d < ax; ++d) outer *= x->shape[d];
+    for (int d = ax; d < nd; ++d) norm *= x->shape[d];
+    LELE_REQUIRE(numel(weight) >= norm, "rms_norm: weight shorter than the normalised size");
+    LELE_TRY(ctx->arena_reset());
+    const void *dx = nullptr, *dw = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(ctx->dev_ptr(weight, &dw));
+    LELE_TRY(out->reserve((size_t)outer * norm * 4));
+    if (outer * norm) {
+        hipLaunchKernelGGL(rms_norm_kernel, dim3((unsigned)((outer + 7) / 8)), dim3(256), 0, ctx->stream,
+                           (const float*)dx, (const float*)dw, (float*)out->data, norm, outer, epsilon);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(x->shape, x->shape + x->rank));
+}
+
+int lele_hip_softmax(LeleCtx* ctx, const LeleTensor* x, int32_t axis, LeleBuf* out, int64_t* out_shape,
+                     int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && out, "softmax: NULL argument");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int nd = x->rank;
+    const int ax = axis < 0 ? nd + axis : axis;
+    LELE_REQUIRE(ax >= 0 && ax < nd, "softmax: axis %d out of range", axis);  // norm.rs:15
+    int64_t inner = 1, outer = 1;
+    for (int d = ax + 1; d < nd; ++d) inner *= x->shape[d];
+    for (int d = 0; d < ax; ++d) outer *= x->shape[d];
+    LELE_REQUIRE(inner == 1, "Softmax only supported on last dimension for now");  // norm.rs:218
+    const int64_t len = x->shape[ax];
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(out->reserve((size_t)outer * len * 4));
+    if (outer * len) {
+        hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((outer + 7) / 8)), dim3(256), 0, ctx->stream,
+                           (const float*)dx, (float*)out->data, len, outer);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(x->shape, x->shape + x->rank));
+}
+
+int lele_hip_batch_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, const LeleTensor* bias,
+                        const LeleTensor* mean, const LeleTensor* var, float epsilon, LeleBuf* out, int64_t* out_shape,
+                        int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && scale && bias && mean && var && out, "batch_norm: NULL argument");
+    LELE_REQUIRE(x->rank >= 1, "batch_norm: rank >= 1 required");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t c = x->rank > 1 ? x->shape[1] : x->shape[0];  // norm.rs:370
+    int64_t inner = 1;
+    for (int d = 2; d < x->rank; ++d) inner *= x->shape[d];
+    const int64_t n = numel(x);
+    LELE_REQUIRE(numel(scale) >= c && numel(bias) >= c && numel(mean) >= c && numel(var) >= c,
+                 "batch_norm: per-channel parameters shorter than C");
+    LELE_TRY(ctx->arena_reset());
+    const void *dx, *ds, *db, *dm, *dv;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(ctx->dev_ptr(scale, &ds));
+    LELE_TRY(ctx->dev_ptr(bias, &db));
+    LELE_TRY(ctx->dev_ptr(mean, &dm));
+    LELE_TRY(ctx->dev_ptr(var, &dv));
+    LELE_TRY(out->reserve((size_t)n * 4));
+    if (n) {
+        hipLaunchKernelGGL(batch_norm_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const float*)dx,
+                           (const float*)ds, (const float*)db, (const float*)dm, (const float*)dv, epsilon, c, inner, n,
+                           (float*)out->data);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(x->shape, x->shape + x->rank));
+}
+
+}  // extern "C"

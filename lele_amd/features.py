@@ -80,10 +80,10 @@ class SenseVoiceFrontend:
         return self._call(_lib.lib().lele_hip_frontend_logmel, pcm, out)
 
 
-def _op(ctx, fn, tensors, extra, out=None, dtype=np.float32):
+def _op(ctx, fn, tensors, extra, out=None, dtype=np.float32, prefix=()):
     ctx = _ctx(ctx)
     keep = []
-    args = [ctx._h]
+    args = [ctx._h] + list(prefix)
     for t in tensors:
         args.append(_lib.as_tensor(unwrap(t), keep))
     args.extend(extra)

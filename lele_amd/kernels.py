@@ -124,3 +124,87 @@ def mat_mul_integer_with_bias(a, b, a_zero_point=None, b_zero_point=None, bias=N
 def mat_mul_integer_with_scale_bias_relu(a, b, a_zero_point=None, b_zero_point=None, scale=None, bias=None, out=None,
                                          ctx=None):
     return mat_mul_integer_with_scale_bias(a, b, a_zero_point, b_zero_point, scale, bias, True, out, ctx)
+
+
+# ------------------------------------------------------------------------------------------- element-wise
+_UNARY = {"exp": 0, "sigmoid": 1, "tanh_kernel": 2, "silu": 3, "erf": 4, "gelu": 5, "fast_gelu": 6, "relu": 7,
+          "sqrt": 8, "log": 9, "sin": 10, "cos": 11, "neg": 12, "reciprocal": 13, "softplus": 14, "not_": 15,
+          "abs": 16, "floor": 17, "ceil": 18}
+_BINARY = {"add": 0, "sub": 1, "mul": 2, "div": 3, "pow": 4, "max": 5, "min": 6, "equal": 7, "less": 8, "greater": 9,
+           "prelu": 10, "mod_f32": 11, "and_": 12, "or_": 13}
+
+
+def _make_unary(name, op):
+    def fn(input, out=None, ctx=None):
+        return _op(ctx, _lib.lib().lele_hip_unary, [input], [], out, prefix=[C.c_int(op)])
+    fn.__name__ = name
+    fn.__doc__ = "lele::kernels::%s (src/kernels/math.rs)" % name.rstrip("_")
+    return fn
+
+
+def _make_binary(name, op):
+    def fn(a, b, out=None, ctx=None):
+        dt = np.int64 if (np.asarray(unwrap(a)).dtype == np.int64 if not isinstance(unwrap(a), _lib.DevTensor)
+                          else unwrap(a).dtype == np.int64) else np.float32
+        return _op(ctx, _lib.lib().lele_hip_binary, [a, b], [], out, dt, prefix=[C.c_int(op)])
+    fn.__name__ = name
+    fn.__doc__ = "lele::kernels::%s (src/kernels/math.rs), numpy-style broadcast" % name.rstrip("_")
+    return fn
+
+
+for _n, _o in _UNARY.items():
+    globals()[_n] = _make_unary(_n, _o)
+for _n, _o in _BINARY.items():
+    globals()[_n] = _make_binary(_n, _o)
+tanh = tanh_kernel  # noqa: F821
+
+
+def where_op(cond, x, y, out=None, ctx=None):  # manipulation.rs:1215
+    return _op(ctx, _lib.lib().lele_hip_where, [cond, x, y], [], out)
+
+
+def clip(input, min=None, max=None, out=None, ctx=None):  # math.rs:1984: min/max are 1-element tensors or None
+    lo = None if min is None else float(np.asarray(unwrap(min) if not isinstance(unwrap(min), _lib.DevTensor)
+                                                   else TensorView(unwrap(min)).numpy()).reshape(-1)[0])
+    hi = None if max is None else float(np.asarray(unwrap(max) if not isinstance(unwrap(max), _lib.DevTensor)
+                                                   else TensorView(unwrap(max)).numpy()).reshape(-1)[0])
+    return _op(ctx, _lib.lib().lele_hip_clip, [input],
+               [C.c_int(lo is not None), C.c_float(lo or 0.0), C.c_int(hi is not None), C.c_float(hi or 0.0)], out)
+
+
+def _reduce(op, input, axes, keepdims, out, ctx):
+    keep = []
+    arr, n = _lib.i64_array(list(axes), keep)
+    return _op(ctx, _lib.lib().lele_hip_reduce, [input], [arr, n, C.c_int(int(keepdims))], out, prefix=[C.c_int(op)])
+
+
+def reduce_sum(input, axes, keepdims=True, out=None, ctx=None):  # math.rs:1611
+    return _reduce(0, input, axes, keepdims, out, ctx)
+
+
+def reduce_mean(input, axes, keepdims=True, out=None, ctx=None):  # math.rs:1527
+    return _reduce(1, input, axes, keepdims, out, ctx)
+
+
+def reduce_max(input, axes, keepdims=True, out=None, ctx=None):  # math.rs:1688
+    return _reduce(2, input, axes, keepdims, out, ctx)
+
+
+def reduce_l2(input, axes, keepdims=True, out=None, ctx=None):  # math.rs:1771
+    return _reduce(3, input, axes, keepdims, out, ctx)
+
+
+def layer_norm(input, scale, bias, axis, epsilon, out=None, ctx=None):  # norm.rs:226
+    return _op(ctx, _lib.lib().lele_hip_layer_norm, [input, scale, bias], [C.c_int32(axis), C.c_float(epsilon)], out)
+
+
+def rms_norm(input, weight, axis, epsilon, out=None, ctx=None):  # norm.rs:420
+    return _op(ctx, _lib.lib().lele_hip_rms_norm, [input, weight], [C.c_int32(axis), C.c_float(epsilon)], out)
+
+
+def softmax(input, axis, out=None, ctx=None):  # norm.rs:8
+    return _op(ctx, _lib.lib().lele_hip_softmax, [input], [C.c_int32(axis)], out)
+
+
+def batch_norm(input, scale, bias, mean, var, epsilon, out=None, ctx=None):  # norm.rs:313
+    return _op(ctx, _lib.lib().lele_hip_batch_norm, [input, scale, bias, mean, var], [C.c_float(epsilon)], out)

@@ -77,6 +77,17 @@ void orc_mat_mul_integer(const float* a, const float* b, int64_t batch_a, int64_
                          int64_t n, float zp_a, float zp_b, const float* scale, int64_t scale_len, const float* bias,
                          int relu, float* out);
 
+/* ---- src/kernels/avx/math.rs, avx/norm.rs, norm.rs ---------------------------------------------------- */
+/* op: 0 exp 1 sigmoid 2 tanh 3 silu 4 erf 5 gelu 6 fast_gelu 7 relu 8 sqrt (8-wide SIMD body + libm scalar tail) */
+void orc_unary_simd(int op, const float* in, float* out, int64_t len);
+void orc_layer_norm(const float* input, const float* scale, const float* bias, float* output, int64_t norm_size,
+                    int64_t outer_size, float epsilon);
+void orc_softmax_lastdim(const float* input, float* output, int64_t outer, int64_t len);
+void orc_rms_norm(const float* input, const float* weight, float* output, int64_t norm_size, int64_t outer_size,
+                  float epsilon);
+void orc_batch_norm(const float* src, const float* scale, const float* bias, const float* mean, const float* var,
+                    float epsilon, int64_t outer, int64_t c, int64_t inner, float* out);
+
 #ifdef __cplusplus
 }
 #endif

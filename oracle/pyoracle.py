@@ -254,3 +254,56 @@ def mat_mul_integer(a, b, a_zero_point=None, b_zero_point=None, scale=None, bias
                               _p(sc) if sc is not None else None, i64(sc.size if sc is not None else 0),
                               _p(bi) if bi is not None else None, C.c_int(int(relu)), _p(out))
     return out
+
+
+# ---------------------------------------------------------------- activations / normalisation (SIMD restatement)
+UNARY_SIMD = {"exp": 0, "sigmoid": 1, "tanh": 2, "silu": 3, "erf": 4, "gelu": 5, "fast_gelu": 6, "relu": 7, "sqrt": 8}
+
+
+def unary(name, x):
+    x = _f32(x)
+    out = np.empty_like(x)
+    lib().orc_unary_simd(C.c_int(UNARY_SIMD[name]), _p(x), _p(out), i64(x.size))
+    return out
+
+
+def layer_norm(x, scale, bias, axis=-1, eps=1e-5):
+    x, scale, bias = _f32(x), _f32(scale), _f32(bias)
+    axis = axis + x.ndim if axis < 0 else axis
+    outer = int(np.prod(x.shape[:axis], dtype=np.int64))
+    norm = int(np.prod(x.shape[axis:], dtype=np.int64))
+    out = np.empty_like(x)
+    lib().orc_layer_norm(_p(x), _p(scale), _p(bias), _p(out), i64(norm), i64(outer), f(eps))
+    return out
+
+
+def softmax(x, axis=-1):
+    x = _f32(x)
+    axis = axis + x.ndim if axis < 0 else axis
+    assert axis == x.ndim - 1 or int(np.prod(x.shape[axis + 1:])) == 1, "Softmax only supported on last dimension"
+    n = x.shape[axis]
+    out = np.empty_like(x)
+    lib().orc_softmax_lastdim(_p(x), _p(out), i64(x.size // max(n, 1)), i64(n))
+    return out
+
+
+def rms_norm(x, weight, axis=-1, eps=1e-5):
+    x, weight = _f32(x), _f32(weight)
+    axis = axis + x.ndim if axis < 0 else axis
+    outer = int(np.prod(x.shape[:axis], dtype=np.int64))
+    norm = int(np.prod(x.shape[axis:], dtype=np.int64))
+    out = np.empty_like(x)
+    lib().orc_rms_norm(_p(x), _p(weight), _p(out), i64(norm), i64(outer), f(eps))
+    return out
+
+
+def batch_norm(x, scale, bias, mean, var, eps=1e-5):
+    x = _f32(x)
+    shape = x.shape
+    c = shape[1] if len(shape) > 1 else shape[0]
+    outer = shape[0]
+    inner = int(np.prod(shape[2:], dtype=np.int64)) if len(shape) > 2 else 1
+    out = np.empty_like(x)
+    lib().orc_batch_norm(_p(x), _p(_f32(scale)), _p(_f32(bias)), _p(_f32(mean)), _p(_f32(var)), f(eps), i64(outer),
+                         i64(c), i64(inner), _p(out))
+    return out
