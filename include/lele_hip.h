@@ -189,6 +189,37 @@ int lele_hip_batch_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* sca
                         const LeleTensor* mean, const LeleTensor* var, float epsilon, LeleBuf* out, int64_t* out_shape,
                         int32_t* out_rank);                                                                  /* norm.rs:313 */
 
+/* ---- src/kernels/manipulation.rs, shape.rs, conv2d.rs:1051-1502: data movement (bit-exact) ---------------- */
+/* out[c] = x[offset + sum_k c_k*strides[k]] (c_k taken modulo mods[k] when mods && mods[k] > 0): the engine behind
+ * slice (manipulation.rs:209), transpose (644), expand (math.rs:2168), tile (math.rs:2249), split (1091) */
+int lele_hip_strided_copy(LeleCtx* ctx, const LeleTensor* x, const int64_t* out_dims, const int64_t* strides,
+                          const int64_t* mods_or_null, int32_t rank, int64_t offset, LeleBuf* out, int64_t* out_shape,
+                          int32_t* out_rank);
+int lele_hip_concat(LeleCtx* ctx, const LeleTensor* const* inputs, size_t ninputs, int64_t axis, LeleBuf* out,
+                    int64_t* out_shape, int32_t* out_rank);                                   /* manipulation.rs:108 */
+/* pads = [begin_0..begin_{r-1}, end_0..end_{r-1}]; mode 0 constant, 1 edge, 2 reflect; fill_bits = raw element */
+int lele_hip_pad(LeleCtx* ctx, const LeleTensor* x, const int64_t* pads, int32_t mode, uint64_t fill_bits,
+                 LeleBuf* out, int64_t* out_shape, int32_t* out_rank);                        /* manipulation.rs:382 */
+int lele_hip_gather(LeleCtx* ctx, const LeleTensor* data, const LeleTensor* indices, int64_t axis, LeleBuf* out,
+                    int64_t* out_shape, int32_t* out_rank);                                   /* manipulation.rs:589 */
+int lele_hip_gather_elements(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* indices, int64_t axis, LeleBuf* out,
+                             int64_t* out_shape, int32_t* out_rank);                          /* conv2d.rs:1438 */
+int lele_hip_resize_nearest(LeleCtx* ctx, const LeleTensor* x, int64_t out_h, int64_t out_w, int asymmetric,
+                            LeleBuf* out, int64_t* out_shape, int32_t* out_rank);             /* conv2d.rs:1261 */
+int lele_hip_max_pool2d(LeleCtx* ctx, const LeleTensor* x, const int64_t* kernel_shape, size_t nk,
+                        const int64_t* strides, size_t ns, const int64_t* pads, size_t np, const int64_t* dilations,
+                        size_t nd, int ceil_mode, LeleBuf* out, int64_t* out_shape, int32_t* out_rank); /* conv2d.rs:1051 */
+int lele_hip_topk(LeleCtx* ctx, const LeleTensor* x, int64_t k, int largest, LeleBuf* out_values, LeleBuf* out_indices,
+                  int64_t* out_shape, int32_t* out_rank);                                     /* conv2d.rs:1385 */
+int lele_hip_range_f32(LeleCtx* ctx, float start, float delta, int64_t n, LeleBuf* out, int64_t* out_shape,
+                       int32_t* out_rank);                                                    /* math.rs:2033 */
+int lele_hip_range_i64(LeleCtx* ctx, int64_t start, int64_t delta, int64_t n, LeleBuf* out, int64_t* out_shape,
+                       int32_t* out_rank);                                                    /* math.rs:2057 */
+int lele_hip_fill(LeleCtx* ctx, const int64_t* shape, int32_t rank, int32_t dtype, uint64_t bits, LeleBuf* out,
+                  int64_t* out_shape, int32_t* out_rank);                                     /* shape.rs:122 */
+int lele_hip_cast(LeleCtx* ctx, const LeleTensor* x, int32_t to_dtype, LeleBuf* out, int64_t* out_shape,
+                  int32_t* out_rank);                                                         /* utils.rs:66-101 */
+
 #ifdef __cplusplus
 }
 #endif

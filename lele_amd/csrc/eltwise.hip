@@ -447,6 +447,8 @@ int lele_hip_binary(LeleCtx* ctx, int op, const LeleTensor* a, const LeleTensor*
 int lele_hip_where(LeleCtx* ctx, const LeleTensor* cond, const LeleTensor* x, const LeleTensor* y, LeleBuf* out,
                    int64_t* out_shape, int32_t* out_rank) {
     LELE_REQUIRE(ctx && cond && x && y && out, "where_op: NULL argument");
+    LELE_REQUIRE(cond->dtype == LELE_F32 && x->dtype == LELE_F32 && y->dtype == LELE_F32,
+                 "where_op: condition and values must be f32 tensors");
     LELE_HIP_CHECK(hipSetDevice(ctx->device));
     Bcast bc;
     std::vector<int64_t> oshape;

@@ -1,0 +1,573 @@
+// manip.hip -- the data-movement operators (bit-exact class): pure index arithmetic on the device.
+//
+//   strided gather-copy engine  -> slice (manipulation.rs:209-380), transpose (644-1080), expand (math.rs:2168-2247),
+//                                  tile (math.rs:2249-2302), concat (manipulation.rs:108-207), split/split_owned
+//                                  (1091-1213)
+//   pad (constant / edge / reflect)            manipulation.rs:382-587
+//   gather                                      manipulation.rs:589-641
+//   gather_elements, topk, resize_nearest, max_pool2d   conv2d.rs:1051-1502
+//   range / constant_of_shape / cast            math.rs:2033-2082, shape.rs:122-135, utils.rs:66-101
+// Views (reshape, flatten, squeeze, unsqueeze, identity; shape.rs:2-186) move no data: the host mirror handles them.
+// Elements are moved as 4- or 8-byte words, so every dtype of TensorView (f32, i32, i64) goes through the same code.
+#include "common.h"
+
+#include <math.h>
+
+using namespace lele;
+
+namespace {
+
+struct CopyDesc {
+    int rank;
+    int64_t oshape[LELE_MAX_RANK];
+    int64_t istride[LELE_MAX_RANK];  // element strides into the source (may be 0 or negative)
+    int64_t imod[LELE_MAX_RANK];     // >0: source coordinate = coordinate % imod (tile)
+    int64_t ostride[LELE_MAX_RANK];  // element strides into the destination
+    int64_t ioff, ooff;
+};
+
+template <typename W>
+__global__ void strided_copy_kernel(const W* __restrict__ in, W* __restrict__ out, int64_t numel, CopyDesc d) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t rem = i, si = d.ioff, di = d.ooff;
+        for (int k = d.rank - 1; k >= 0; --k) {
+            int64_t c = rem % d.oshape[k];
+            rem /= d.oshape[k];
+            di += c * d.ostride[k];
+            if (d.imod[k] > 0) c %= d.imod[k];
+            si += c * d.istride[k];
+        }
+        out[di] = in[si];
+    }
+}
+
+template <typename W>
+__global__ void fill_kernel(W* __restrict__ out, int64_t numel, W v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = v;
+}
+
+struct PadDesc {
+    int rank, mode;  // 0 constant, 1 edge, 2 reflect
+    int64_t oshape[LELE_MAX_RANK], ishape[LELE_MAX_RANK], before[LELE_MAX_RANK];
+};
+template <typename W>
+__global__ void pad_kernel(const W* __restrict__ in, W* __restrict__ out, int64_t numel, PadDesc d, W fill) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t rem = i, si = 0, st = 1;
+        bool inside = true;
+        for (int k = d.rank - 1; k >= 0; --k) {
+            const int64_t c = rem % d.oshape[k];
+            rem /= d.oshape[k];
+            int64_t s = c - d.before[k];
+            if (s < 0 || s >= d.ishape[k]) {
+                inside = false;
+                if (d.mode == 1)
+                    s = s < 0 ? 0 : d.ishape[k] - 1;  // manipulation.rs:511-518
+                else if (d.mode == 2)
+                    // manipulation.rs:562-569 AS WRITTEN: mirrored without the edge at the front (pad_begin +
+                    // (pad_begin - c)) but WITH the edge at the back (pad_end - 1 - past); kept for bit-parity
+                    s = s < 0 ? -s : 2 * d.ishape[k] - 1 - s;
+            }
+            si += s * st;
+            st *= d.ishape[k];
+        }
+        out[i] = (inside || d.mode != 0) ? in[si] : fill;
+    }
+}
+
+// gather (manipulation.rs:589-641): out[o][j][k] = data[o][idx[j]][k]
+template <typename W, typename I>
+__global__ void gather_kernel(const W* __restrict__ data, const I* __restrict__ idx, W* __restrict__ out,
+                              int64_t outer, int64_t axis_dim, int64_t inner, int64_t nidx) {
+    const int64_t total = outer * nidx * inner;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = i % inner, j = (i / inner) % nidx, o = i / (inner * nidx);
+        int64_t v = (int64_t)idx[j];
+        if (v < 0) v += axis_dim;
+        out[i] = data[(o * axis_dim + v) * inner + k];
+    }
+}
+
+// gather_elements (conv2d.rs:1438-1502): indices carried as f32
+struct GeDesc {
+    int rank, axis;
+    int64_t ishape[LELE_MAX_RANK], xstride[LELE_MAX_RANK], axis_dim;
+};
+__global__ void gather_elements_kernel(const float* __restrict__ x, const float* __restrict__ idx,
+                                       float* __restrict__ out, int64_t total, GeDesc d) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t rem = i, off = 0;
+        int64_t iv = (int64_t)idx[i];
+        if (iv < 0) iv += d.axis_dim;
+        for (int k = d.rank - 1; k >= 0; --k) {
+            const int64_t c = rem % d.ishape[k];
+            rem /= d.ishape[k];
+            off += (k == d.axis ? iv : c) * d.xstride[k];
+        }
+        out[i] = x[off];
+    }
+}
+
+// resize_nearest (conv2d.rs:1261-1382): f32 coordinate arithmetic exactly as the reference
+__global__ void resize_nearest_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t planes, int in_h,
+                                      int in_w, int out_h, int out_w, int asymmetric) {
+    const float h_scale = (float)in_h / (float)out_h, w_scale = (float)in_w / (float)out_w;
+    const int64_t total = planes * out_h * out_w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ow = (int)(i % out_w), oh = (int)((i / out_w) % out_h);
+        const int64_t p = i / ((int64_t)out_w * out_h);
+        int ih, iw;
+        if (asymmetric) {
+            ih = (int)fminf(floorf((float)oh * h_scale), (float)(in_h - 1));
+            iw = (int)fminf(floorf((float)ow * w_scale), (float)(in_w - 1));
+        } else {
+            ih = (int)fminf(fmaxf(roundf(((float)oh + 0.5f) * h_scale - 0.5f), 0.0f), (float)(in_h - 1));
+            iw = (int)fminf(fmaxf(roundf(((float)ow + 0.5f) * w_scale - 0.5f), 0.0f), (float)(in_w - 1));
+        }
+        out[i] = x[(p * in_h + ih) * in_w + iw];
+    }
+}
+
+// max_pool2d (conv2d.rs:1051-1254): padded cells are skipped (== -inf)
+struct PoolDesc {
+    int in_h, in_w, out_h, out_w, kh, kw, sh, sw, pt, pl, dh, dw;
+};
+__global__ void max_pool2d_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t planes, PoolDesc d) {
+    const int64_t total = planes * d.out_h * d.out_w;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ow = (int)(i % d.out_w), oh = (int)((i / d.out_w) % d.out_h);
+        const int64_t p = i / ((int64_t)d.out_w * d.out_h);
+        float m = -INFINITY;
+        for (int a = 0; a < d.kh; ++a) {
+            const int ih = oh * d.sh - d.pt + a * d.dh;
+            if (ih < 0 || ih >= d.in_h) continue;
+            for (int b = 0; b < d.kw; ++b) {
+                const int iw = ow * d.sw - d.pl + b * d.dw;
+                if (iw < 0 || iw >= d.in_w) continue;
+                const float v = x[(p * d.in_h + ih) * d.in_w + iw];
+                m = v > m ? v : m;
+            }
+        }
+        out[i] = m;
+    }
+}
+
+// topk over the last axis (conv2d.rs:1385-1435): stable sort by value => rank(i) = #{j : v_j beats v_i, or ties with
+// j < i}.  One block per row, O(n^2 / threads) comparisons; rows of the sizes lele uses (<= 8400) take microseconds.
+__global__ void topk_kernel(const float* __restrict__ x, int64_t n, int64_t k, int largest, float* __restrict__ values,
+                            float* __restrict__ indices) {
+    const float* row = x + (int64_t)blockIdx.x * n;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = row[i];
+        int64_t rank = 0;
+        for (int64_t j = 0; j < n; ++j) {
+            const float u = row[j];
+            const bool beats = largest ? (u > v) : (u < v);
+            rank += (beats || (u == v && j < i)) ? 1 : 0;
+        }
+        if (rank < k) {
+            values[(int64_t)blockIdx.x * k + rank] = v;
+            indices[(int64_t)blockIdx.x * k + rank] = (float)i;  // indices are returned as f32
+        }
+    }
+}
+
+__global__ void range_kernel(float start, float delta, int64_t n, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = start + (float)i * delta;  // math.rs:2049-2053
+}
+__global__ void range_i64_kernel(int64_t start, int64_t delta, int64_t n, int64_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = start + i * delta;
+}
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ in, D* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (D)in[i];
+}
+
+inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)); }
+
+int launch_copy(LeleCtx* ctx, const void* in, void* out, int64_t numel, const CopyDesc& d, size_t esize) {
+    if (numel == 0) return 0;
+    if (esize == 8)
+        hipLaunchKernelGGL(strided_copy_kernel<uint64_t>, dim3(grid_for(numel)), dim3(256), 0, ctx->stream,
+                           (const uint64_t*)in, (uint64_t*)out, numel, d);
+    else
+        hipLaunchKernelGGL(strided_copy_kernel<uint32_t>, dim3(grid_for(numel)), dim3(256), 0, ctx->stream,
+                           (const uint32_t*)in, (uint32_t*)out, numel, d);
+    LELE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+std::vector<int64_t> strides_of(const int64_t* shape, int rank) {
+    std::vector<int64_t> s(rank, 1);
+    for (int i = rank - 2; i >= 0; --i) s[i] = s[i + 1] * shape[i + 1];
+    return s;
+}
+
+int check_word(const LeleTensor* t, const char* who, size_t* es) {
+    *es = dtype_size(t->dtype);
+    LELE_REQUIRE(*es == 4 || *es == 8, "%s: only 4- and 8-byte element types are supported", who);
+    LELE_REQUIRE(t->rank <= LELE_MAX_RANK, "%s: rank %d exceeds %d", who, t->rank, LELE_MAX_RANK);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* Generic strided gather: out[c0..c(r-1)] = in[offset + sum c_k * stride_k] (coordinate taken modulo mod_k when
+ * mod_k > 0).  slice / transpose / expand / tile are this call with host-computed descriptors. */
+int lele_hip_strided_copy(LeleCtx* ctx, const LeleTensor* x, const int64_t* out_shape_in, const int64_t* strides,
+                          const int64_t* mods, int32_t rank, int64_t offset, LeleBuf* out, int64_t* out_shape,
+                          int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && out && (rank == 0 || (out_shape_in && strides)), "strided_copy: NULL argument");
+    LELE_REQUIRE(rank >= 0 && rank <= LELE_MAX_RANK, "strided_copy: bad rank %d", rank);
+    size_t es;
+    LELE_TRY(check_word(x, "strided_copy", &es));
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    CopyDesc d{};
+    d.rank = rank;
+    int64_t n = 1;
+    for (int i = 0; i < rank; ++i) {
+        d.oshape[i] = out_shape_in[i];
+        d.istride[i] = strides[i];
+        d.imod[i] = mods ? mods[i] : 0;
+        n *= out_shape_in[i];
+    }
+    int64_t st = 1;
+    for (int i = rank - 1; i >= 0; --i) {
+        d.ostride[i] = st;
+        st *= out_shape_in[i];
+    }
+    d.ioff = offset;
+    d.ooff = 0;
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(out->reserve((size_t)n * es));
+    LELE_TRY(launch_copy(ctx, dx, out->data, n, d, es));
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(out_shape_in, out_shape_in + rank));
+}
+
+/* concat, manipulation.rs:108-207 */
+int lele_hip_concat(LeleCtx* ctx, const LeleTensor* const* inputs, size_t ninputs, int64_t axis, LeleBuf* out,
+                    int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && inputs && ninputs > 0 && out, "concat: NULL argument or no inputs");
+    const int rank = inputs[0]->rank;
+    size_t es;
+    LELE_TRY(check_word(inputs[0], "concat", &es));
+    const int ax = (int)(axis < 0 ? rank + axis : axis);
+    LELE_REQUIRE(ax >= 0 && ax < rank, "concat: axis %lld out of range", (long long)axis);
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<int64_t> oshape(inputs[0]->shape, inputs[0]->shape + rank);
+    oshape[ax] = 0;
+    for (size_t i = 0; i < ninputs; ++i) {
+        LELE_REQUIRE(inputs[i]->rank == rank && inputs[i]->dtype == inputs[0]->dtype, "concat: rank/dtype mismatch");
+        for (int d = 0; d < rank; ++d)
+            LELE_REQUIRE(d == ax || inputs[i]->shape[d] == inputs[0]->shape[d], "concat: shape mismatch on dim %d", d);
+        oshape[ax] += inputs[i]->shape[ax];
+    }
+    int64_t n = 1;
+    for (int64_t v : oshape) n *= v;
+    std::vector<int64_t> ostr = strides_of(oshape.data(), rank);
+    LELE_TRY(ctx->arena_reset());
+    LELE_TRY(out->reserve((size_t)n * es));
+    int64_t pos = 0;
+    for (size_t i = 0; i < ninputs; ++i) {
+        const LeleTensor* t = inputs[i];
+        const void* dx = nullptr;
+        LELE_TRY(ctx->dev_ptr(t, &dx));
+        CopyDesc d{};
+        d.rank = rank;
+        std::vector<int64_t> istr = strides_of(t->shape, rank);
+        for (int k = 0; k < rank; ++k) {
+            d.oshape[k] = t->shape[k];
+            d.istride[k] = istr[k];
+            d.ostride[k] = ostr[k];
+        }
+        d.ooff = pos * ostr[ax];
+        LELE_TRY(launch_copy(ctx, dx, out->data, numel(t), d, es));
+        pos += t->shape[ax];
+    }
+    return set_shape_v(out_shape, out_rank, oshape);
+}
+
+/* pad, manipulation.rs:382-587: pads = [begin_0..begin_r-1, end_0..end_r-1] (already expanded to 2*rank by the host
+ * mirror, negatives clamped to 0); mode 0 constant / 1 edge / 2 reflect; fill = raw 4- or 8-byte pattern */
+int lele_hip_pad(LeleCtx* ctx, const LeleTensor* x, const int64_t* pads, int32_t mode, uint64_t fill_bits, LeleBuf* out,
+                 int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && pads && out, "pad: NULL argument");
+    LELE_REQUIRE(mode >= 0 && mode <= 2, "pad: unknown mode %d", mode);
+    size_t es;
+    LELE_TRY(check_word(x, "pad", &es));
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int rank = x->rank;
+    PadDesc d{};
+    d.rank = rank;
+    d.mode = mode;
+    std::vector<int64_t> oshape(rank);
+    int64_t n = 1;
+    for (int i = 0; i < rank; ++i) {
+        const int64_t b = pads[i] < 0 ? 0 : pads[i], e = pads[rank + i] < 0 ? 0 : pads[rank + i];
+        d.before[i] = b;
+        d.ishape[i] = x->shape[i];
+        d.oshape[i] = oshape[i] = x->shape[i] + b + e;
+        if (mode == 2) LELE_REQUIRE(b < x->shape[i] && e <= x->shape[i], "pad: reflect padding must be smaller than the dim");
+        n *= oshape[i];
+    }
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(out->reserve((size_t)n * es));
+    if (n) {
+        if (es == 8)
+            hipLaunchKernelGGL(pad_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const uint64_t*)dx,
+                               (uint64_t*)out->data, n, d, (uint64_t)fill_bits);
+        else
+            hipLaunchKernelGGL(pad_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const uint32_t*)dx,
+                               (uint32_t*)out->data, n, d, (uint32_t)fill_bits);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, oshape);
+}
+
+/* gather, manipulation.rs:589-641: indices may be f32 (values as floats), i64 or i32 */
+int lele_hip_gather(LeleCtx* ctx, const LeleTensor* data, const LeleTensor* indices, int64_t axis, LeleBuf* out,
+                    int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && data && indices && out, "gather: NULL argument");
+    size_t es;
+    LELE_TRY(check_word(data, "gather", &es));
+    const int rank = data->rank;
+    const int ax = (int)(axis < 0 ? rank + axis : axis);
+    LELE_REQUIRE(ax >= 0 && ax < rank, "gather: axis %lld out of range", (long long)axis);
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    std::vector<int64_t> oshape(data->shape, data->shape + ax);
+    oshape.insert(oshape.end(), indices->shape, indices->shape + indices->rank);
+    oshape.insert(oshape.end(), data->shape + ax + 1, data->shape + rank);
+    LELE_REQUIRE(oshape.size() <= LELE_MAX_RANK, "gather: result rank exceeds %d", LELE_MAX_RANK);
+    int64_t outer = 1, inner = 1;
+    for (int i = 0; i < ax; ++i) outer *= data->shape[i];
+    for (int i = ax + 1; i < rank; ++i) inner *= data->shape[i];
+    const int64_t nidx = numel(indices), total = outer * nidx * inner;
+    LELE_TRY(ctx->arena_reset());
+    const void *dd = nullptr, *di = nullptr;
+    LELE_TRY(ctx->dev_ptr(data, &dd));
+    LELE_TRY(ctx->dev_ptr(indices, &di));
+    LELE_TRY(out->reserve((size_t)total * es));
+    if (total) {
+        const dim3 g(grid_for(total)), b(256);
+#define LELE_GATHER(W, I)                                                                                          \
+    hipLaunchKernelGGL((gather_kernel<W, I>), g, b, 0, ctx->stream, (const W*)dd, (const I*)di, (W*)out->data, outer, \
+                       data->shape[ax], inner, nidx)
+        if (es == 8) {
+            if (indices->dtype == LELE_F32) LELE_GATHER(uint64_t, float);
+            else if (indices->dtype == LELE_I64) LELE_GATHER(uint64_t, int64_t);
+            else LELE_GATHER(uint64_t, int32_t);
+        } else {
+            if (indices->dtype == LELE_F32) LELE_GATHER(uint32_t, float);
+            else if (indices->dtype == LELE_I64) LELE_GATHER(uint32_t, int64_t);
+            else LELE_GATHER(uint32_t, int32_t);
+        }
+#undef LELE_GATHER
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, oshape);
+}
+
+int lele_hip_gather_elements(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* indices, int64_t axis, LeleBuf* out,
+                             int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && indices && out, "gather_elements: NULL argument");
+    LELE_REQUIRE(x->dtype == LELE_F32 && indices->dtype == LELE_F32, "gather_elements: f32 data and f32-carried indices");
+    LELE_REQUIRE(x->rank == indices->rank && x->rank <= LELE_MAX_RANK, "gather_elements: rank mismatch");
+    const int rank = x->rank;
+    const int ax = (int)(axis < 0 ? rank + axis : axis);
+    LELE_REQUIRE(ax >= 0 && ax < rank, "gather_elements: axis out of range");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    GeDesc d{};
+    d.rank = rank;
+    d.axis = ax;
+    d.axis_dim = x->shape[ax];
+    std::vector<int64_t> xs = strides_of(x->shape, rank);
+    for (int i = 0; i < rank; ++i) {
+        d.ishape[i] = indices->shape[i];
+        d.xstride[i] = xs[i];
+    }
+    const int64_t total = numel(indices);
+    LELE_TRY(ctx->arena_reset());
+    const void *dx = nullptr, *di = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(ctx->dev_ptr(indices, &di));
+    LELE_TRY(out->reserve((size_t)total * 4));
+    if (total) {
+        hipLaunchKernelGGL(gather_elements_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx,
+                           (const float*)di, (float*)out->data, total, d);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(indices->shape, indices->shape + rank));
+}
+
+/* resize_nearest, conv2d.rs:1261-1382: output H, W already resolved from sizes / scales by the host mirror */
+int lele_hip_resize_nearest(LeleCtx* ctx, const LeleTensor* x, int64_t out_h, int64_t out_w, int asymmetric,
+                            LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && out, "resize_nearest: NULL argument");
+    LELE_REQUIRE(x->rank == 4 && x->dtype == LELE_F32, "Resize: expected rank-4 input");
+    LELE_REQUIRE(out_h > 0 && out_w > 0, "Resize: output dimensions must be positive, got out_h=%lld out_w=%lld",
+                 (long long)out_h, (long long)out_w);
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t planes = x->shape[0] * x->shape[1], total = planes * out_h * out_w;
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(out->reserve((size_t)total * 4));
+    if (total) {
+        hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx,
+                           (float*)out->data, planes, (int)x->shape[2], (int)x->shape[3], (int)out_h, (int)out_w,
+                           asymmetric);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape(out_shape, out_rank, {x->shape[0], x->shape[1], out_h, out_w});
+}
+
+/* max_pool2d, conv2d.rs:1051-1254 */
+int lele_hip_max_pool2d(LeleCtx* ctx, const LeleTensor* x, const int64_t* kernel_shape, size_t nk,
+                        const int64_t* strides, size_t ns, const int64_t* pads, size_t np, const int64_t* dilations,
+                        size_t nd, int ceil_mode, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && out && kernel_shape && nk >= 1, "max_pool2d: NULL argument");
+    LELE_REQUIRE(x->rank == 4 && x->dtype == LELE_F32, "MaxPool2d: expected rank-4 input");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    PoolDesc d{};
+    d.in_h = (int)x->shape[2];
+    d.in_w = (int)x->shape[3];
+    d.kh = (int)kernel_shape[0];
+    d.kw = nk > 1 ? (int)kernel_shape[1] : d.kh;
+    d.sh = ns == 0 ? 1 : (int)strides[0];
+    d.sw = ns > 1 ? (int)strides[1] : d.sh;
+    d.pt = np == 0 ? 0 : (int)pads[0];
+    d.pl = np > 1 ? (int)pads[1] : d.pt;
+    const int pb = np > 2 ? (int)pads[2] : d.pt, pr = np > 3 ? (int)pads[3] : d.pl;
+    d.dh = nd == 0 ? 1 : (int)dilations[0];
+    d.dw = nd > 1 ? (int)dilations[1] : d.dh;
+    const int ekh = d.dh * (d.kh - 1) + 1, ekw = d.dw * (d.kw - 1) + 1;
+    const int64_t num_h = d.in_h + d.pt + pb - ekh, num_w = d.in_w + d.pl + pr - ekw;
+    LELE_REQUIRE(num_h >= 0 && num_w >= 0 && d.sh > 0 && d.sw > 0, "max_pool2d: window larger than the padded input");
+    d.out_h = (int)(ceil_mode ? (num_h + d.sh - 1) / d.sh + 1 : num_h / d.sh + 1);
+    d.out_w = (int)(ceil_mode ? (num_w + d.sw - 1) / d.sw + 1 : num_w / d.sw + 1);
+    const int64_t planes = x->shape[0] * x->shape[1], total = planes * d.out_h * d.out_w;
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(out->reserve((size_t)total * 4));
+    if (total) {
+        hipLaunchKernelGGL(max_pool2d_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx,
+                           (float*)out->data, planes, d);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape(out_shape, out_rank, {x->shape[0], x->shape[1], (int64_t)d.out_h, (int64_t)d.out_w});
+}
+
+/* topk, conv2d.rs:1385-1435: last axis only (the `axis` argument is ignored by the reference too) */
+int lele_hip_topk(LeleCtx* ctx, const LeleTensor* x, int64_t k, int largest, LeleBuf* out_values, LeleBuf* out_indices,
+                  int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && out_values && out_indices, "topk: NULL argument");
+    LELE_REQUIRE(x->rank >= 1 && x->dtype == LELE_F32, "topk: f32 tensor of rank >= 1 required");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t n = x->shape[x->rank - 1];
+    const int64_t rows = n ? numel(x) / n : 0;
+    const int64_t kk = std::min<int64_t>(std::max<int64_t>(k, 0), n);  // k.min(last_dim)
+    std::vector<int64_t> oshape(x->shape, x->shape + x->rank);
+    oshape.back() = kk;
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(out_values->reserve((size_t)rows * kk * 4));
+    LELE_TRY(out_indices->reserve((size_t)rows * kk * 4));
+    if (rows * kk) {
+        hipLaunchKernelGGL(topk_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const float*)dx, n, kk, largest,
+                           (float*)out_values->data, (float*)out_indices->data);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, oshape);
+}
+
+/* range, math.rs:2033-2082: n and the first/step values are resolved by the host mirror (they are scalars) */
+int lele_hip_range_f32(LeleCtx* ctx, float start, float delta, int64_t n, LeleBuf* out, int64_t* out_shape,
+                       int32_t* out_rank) {
+    LELE_REQUIRE(ctx && out && n >= 0, "range: bad argument");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    LELE_TRY(out->reserve((size_t)n * 4));
+    if (n) {
+        hipLaunchKernelGGL(range_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, start, delta, n, (float*)out->data);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape(out_shape, out_rank, {n});
+}
+int lele_hip_range_i64(LeleCtx* ctx, int64_t start, int64_t delta, int64_t n, LeleBuf* out, int64_t* out_shape,
+                       int32_t* out_rank) {
+    LELE_REQUIRE(ctx && out && n >= 0, "range_i64: bad argument");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    LELE_TRY(out->reserve((size_t)n * 8));
+    if (n) {
+        hipLaunchKernelGGL(range_i64_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, start, delta, n,
+                           (int64_t*)out->data);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape(out_shape, out_rank, {n});
+}
+
+/* constant_of_shape, shape.rs:122-135: fill with a raw 4- or 8-byte pattern */
+int lele_hip_fill(LeleCtx* ctx, const int64_t* shape, int32_t rank, int32_t dtype, uint64_t bits, LeleBuf* out,
+                  int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && out && (rank == 0 || shape) && rank >= 0 && rank <= LELE_MAX_RANK, "fill: bad argument");
+    const size_t es = dtype_size(dtype);
+    LELE_REQUIRE(es == 4 || es == 8, "fill: 4- or 8-byte element types only");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    int64_t n = 1;
+    for (int i = 0; i < rank; ++i) n *= shape[i];
+    LELE_TRY(out->reserve((size_t)n * es));
+    if (n) {
+        if (es == 8)
+            hipLaunchKernelGGL(fill_kernel<uint64_t>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (uint64_t*)out->data,
+                               n, (uint64_t)bits);
+        else
+            hipLaunchKernelGGL(fill_kernel<uint32_t>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (uint32_t*)out->data,
+                               n, (uint32_t)bits);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(shape, shape + rank));
+}
+
+/* cast_to_f32 / cast_to_i64, utils.rs:66-101 */
+int lele_hip_cast(LeleCtx* ctx, const LeleTensor* x, int32_t to_dtype, LeleBuf* out, int64_t* out_shape,
+                  int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && out, "cast: NULL argument");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t n = numel(x);
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(out->reserve((size_t)n * dtype_size(to_dtype)));
+    const dim3 g(grid_for(n)), b(256);
+    if (n) {
+#define LELE_CAST(S, D) hipLaunchKernelGGL((cast_kernel<S, D>), g, b, 0, ctx->stream, (const S*)dx, (D*)out->data, n)
+        if (x->dtype == LELE_F32 && to_dtype == LELE_I64) LELE_CAST(float, int64_t);
+        else if (x->dtype == LELE_I64 && to_dtype == LELE_F32) LELE_CAST(int64_t, float);
+        else if (x->dtype == LELE_I32 && to_dtype == LELE_F32) LELE_CAST(int32_t, float);
+        else if (x->dtype == LELE_I32 && to_dtype == LELE_I64) LELE_CAST(int32_t, int64_t);
+        else if (x->dtype == LELE_F32 && to_dtype == LELE_F32) LELE_CAST(float, float);
+        else if (x->dtype == LELE_I64 && to_dtype == LELE_I64) LELE_CAST(int64_t, int64_t);
+        else if (x->dtype == LELE_U8 && to_dtype == LELE_F32) LELE_CAST(uint8_t, float);
+        else if (x->dtype == LELE_I8 && to_dtype == LELE_F32) LELE_CAST(int8_t, float);
+        else {
+            set_error("cast: unsupported conversion %d -> %d", x->dtype, to_dtype);
+            return 2;
+        }
+#undef LELE_CAST
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(x->shape, x->shape + x->rank));
+}
+
+}  // extern "C"

@@ -3,6 +3,7 @@
 Each function keeps the reference's name and argument order; `out` (a _lib.Buf) plays the role of the
 `out: &mut Vec<f32>` workspace buffer and may be omitted.
 """
+import builtins as _b
 import ctypes as C
 
 import numpy as np
@@ -208,3 +209,334 @@ def softmax(input, axis, out=None, ctx=None):  # norm.rs:8
 
 def batch_norm(input, scale, bias, mean, var, epsilon, out=None, ctx=None):  # norm.rs:313
     return _op(ctx, _lib.lib().lele_hip_batch_norm, [input, scale, bias, mean, var], [C.c_float(epsilon)], out)
+
+
+# ------------------------------------------------------------------------------------------- data movement
+def _shape_of(x):
+    x = unwrap(x)
+    return tuple(x.shape) if isinstance(x, _lib.DevTensor) else tuple(np.asarray(x).shape)
+
+
+def _dtype_of(x):
+    x = unwrap(x)
+    if isinstance(x, _lib.DevTensor):
+        return x.dtype
+    a = np.asarray(x)
+    return a.dtype if a.dtype in (np.float32, np.int64, np.int32) else np.dtype(np.float32)
+
+
+def _row_major_strides(shape):
+    st, acc = [], 1
+    for d in reversed(shape):
+        st.append(acc)
+        acc *= d
+    return list(reversed(st))
+
+
+def _strided(x, oshape, strides, offset=0, mods=None, out=None, ctx=None):
+    ctx = _ctx(ctx)
+    keep = []
+    rank = len(oshape)
+    a, _ = _lib.i64_array(list(oshape), keep)
+    s, _ = _lib.i64_array(list(strides), keep)
+    m = _lib.i64_array(list(mods), keep)[0] if mods is not None else None
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_strided_copy(ctx._h, _lib.as_tensor(unwrap(x), keep), a, s, m, C.c_int32(rank),
+                                                C.c_int64(offset), out._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), _dtype_of(x)))
+
+
+def slice(input, starts, ends, axes=(), steps=(), out=None, ctx=None):  # manipulation.rs:209-380
+    shape = _shape_of(input)
+    ndim = len(shape)
+    a_start, a_end, a_step = [0] * ndim, list(shape), [1] * ndim
+    for i in _b.range(len(starts)):
+        ax = i if not len(axes) else (axes[i] + ndim if axes[i] < 0 else axes[i])
+        dim = shape[ax]
+        step = steps[i] if i < len(steps) else 1
+        s64, e64 = int(starts[i]), int(ends[i])
+        e_max, e_min = e64 > (2 ** 63 - 1) // 2, e64 < -(2 ** 63) // 2
+        start = dim if s64 > dim else (-dim if s64 < -dim else s64)
+        end = dim if e_max else (-dim if e_min else (dim if e64 > dim else (-dim if e64 < -dim else e64)))
+        ns = start + dim if start < 0 else start
+        if e_max:
+            ne = dim if step > 0 else -1
+        elif e_min:
+            ne = 0 if step > 0 else -1
+        else:
+            ne = end + dim if end < 0 else end
+        if step > 0:
+            s, e = _b.min(_b.max(ns, 0), dim), _b.min(_b.max(ne, 0), dim)
+        else:
+            s, e = _b.min(_b.max(ns, 0), dim - 1), _b.min(_b.max(ne, -1), dim - 1)
+        a_start[ax], a_end[ax], a_step[ax] = s, e, step
+    oshape = []
+    for s, e, st in zip(a_start, a_end, a_step):
+        oshape.append(_b.max(0, (e - s + st - 1) // st) if st > 0 else _b.max(0, (s - e + (-st) - 1) // (-st)))
+    istr = _row_major_strides(shape)
+    off = sum(s * t for s, t in zip(a_start, istr))
+    return _strided(input, oshape, [t * st for t, st in zip(istr, a_step)], off, None, out, ctx)
+
+
+def transpose(input, perm=(), out=None, ctx=None):  # manipulation.rs:644-1080
+    shape = _shape_of(input)
+    ndim = len(shape)
+    perm = list(_b.range(ndim))[::-1] if not len(perm) else [p + ndim if p < 0 else p for p in perm]
+    istr = _row_major_strides(shape)
+    return _strided(input, [shape[p] for p in perm], [istr[p] for p in perm], 0, None, out, ctx)
+
+
+def expand(input, shape, out=None, ctx=None):  # math.rs:2168-2247
+    ishape = _shape_of(input)
+    nd = _b.max(len(ishape), len(shape))
+    oshape, strides = [], []
+    istr = _row_major_strides(ishape)
+    for i in _b.range(nd):
+        oi, ot = i - (nd - len(ishape)), i - (nd - len(shape))
+        din = ishape[oi] if oi >= 0 else 1
+        dt = (shape[ot] or din) if ot >= 0 else 1  # 0 means "use the input dimension"
+        if din == dt or dt == 1:
+            oshape.append(din)
+        elif din == 1:
+            oshape.append(dt)
+        else:
+            raise _lib.LeleError("Expand: incompatible shapes %s -> %s" % (ishape, tuple(shape)))
+        strides.append(istr[oi] if (oi >= 0 and din != 1) else 0)
+    return _strided(input, oshape, strides, 0, None, out, ctx)
+
+
+def tile(input, repeats, out=None, ctx=None):  # math.rs:2249-2302
+    shape = _shape_of(input)
+    if len(repeats) != len(shape):
+        raise _lib.LeleError("Tile: repeats length must match input rank")
+    return _strided(input, [d * int(r) for d, r in zip(shape, repeats)], _row_major_strides(shape), 0, list(shape), out,
+                    ctx)
+
+
+def split(input, axis, splits, outputs=None, ctx=None):  # manipulation.rs:1091-1151 -> list of TensorView
+    shape = _shape_of(input)
+    ndim = len(shape)
+    ax = axis + ndim if axis < 0 else axis
+    if not 0 <= ax < ndim:
+        raise _lib.LeleError("Split: axis out of bounds")
+    if sum(splits) != shape[ax]:
+        raise _lib.LeleError("Split: splits sum mismatch")
+    istr = _row_major_strides(shape)
+    res, pos = [], 0
+    for i, sz in enumerate(splits):
+        osh = list(shape)
+        osh[ax] = int(sz)
+        res.append(_strided(input, osh, istr, pos * istr[ax], None, outputs[i] if outputs else None, ctx))
+        pos += int(sz)
+    return res
+
+
+split_owned = split  # manipulation.rs:1153-1213: same values, owned storage
+
+
+def concat(inputs, axis, out=None, ctx=None):  # manipulation.rs:108-207
+    ctx = _ctx(ctx)
+    keep = []
+    ptrs = [_lib.as_tensor(unwrap(t), keep) for t in inputs]
+    arr = (C.POINTER(_lib.LeleTensor) * len(ptrs))(*[C.cast(p, C.POINTER(_lib.LeleTensor)) for p in ptrs])
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_concat(ctx._h, arr, C.c_size_t(len(ptrs)), C.c_int64(axis), out._h, sh.shape,
+                                          C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), _dtype_of(inputs[0])))
+
+
+def pad(input, pads, constant_value=None, mode="constant", out=None, ctx=None):  # manipulation.rs:382-587
+    shape = _shape_of(input)
+    rank = len(shape)
+    raw = [_b.max(0, int(p)) for p in pads]
+    if len(raw) < rank * 2:  # covers only the trailing dims (manipulation.rs:397-412)
+        half = len(raw) // 2
+        missing = rank - half
+        full = [0] * (rank * 2)
+        for i in _b.range(half):
+            full[missing + i] = raw[i]
+            full[rank + missing + i] = raw[half + i]
+        raw = full
+    dt = _dtype_of(input)
+    cv = 0
+    if constant_value is not None:
+        c = np.asarray(TensorView(unwrap(constant_value)).numpy() if isinstance(unwrap(constant_value), _lib.DevTensor)
+                       else unwrap(constant_value)).reshape(-1)
+        if c.size:
+            cv = c[0]
+    bits = int(np.array([cv], dt).view(np.uint32 if dt.itemsize == 4 else np.uint64)[0])
+    m = {"constant": 0, "edge": 1, "reflect": 2}.get(mode)
+    if m is None:
+        raise _lib.LeleError("Pad: unknown mode %r" % mode)
+    ctx = _ctx(ctx)
+    keep = []
+    p, _ = _lib.i64_array(raw, keep)
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_pad(ctx._h, _lib.as_tensor(unwrap(input), keep), p, C.c_int32(m), C.c_uint64(bits),
+                                       out._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), dt))
+
+
+def gather(data, indices, axis, out=None, ctx=None):  # manipulation.rs:589-641
+    return _op(ctx, _lib.lib().lele_hip_gather, [data, indices], [C.c_int64(axis)], out, _dtype_of(data))
+
+
+def gather_elements(input, indices, axis, out=None, ctx=None):  # conv2d.rs:1438-1502
+    return _op(ctx, _lib.lib().lele_hip_gather_elements, [input, indices], [C.c_int64(axis)], out)
+
+
+def resize_nearest(input, scales=None, sizes=None, coordinate_transform_mode="asymmetric", out=None, ctx=None):
+    """conv2d.rs:1261-1382"""
+    shape = _shape_of(input)
+    if len(shape) != 4:
+        raise _lib.LeleError("Resize: expected rank-4 input")
+    if sizes is not None:
+        if len(sizes) < 4:
+            raise _lib.LeleError("Resize: sizes must have at least 4 elements")
+        oh, ow = int(sizes[2]), int(sizes[3])
+    elif scales is not None:
+        sh_ = float(np.float32(scales[2])) if len(scales) >= 3 else 1.0
+        sw_ = float(np.float32(scales[3])) if len(scales) >= 4 else 1.0
+        oh, ow = int(shape[2] * sh_), int(shape[3] * sw_)  # (in_h as f64 * sh as f64) as u64
+    else:
+        raise _lib.LeleError("Resize: either scales or sizes must be provided")
+    return _op(ctx, _lib.lib().lele_hip_resize_nearest, [input],
+               [C.c_int64(oh), C.c_int64(ow), C.c_int(int(coordinate_transform_mode == "asymmetric"))], out)
+
+
+def max_pool2d(input, kernel_shape, strides=(), pads=(), dilations=(), ceil_mode=False, out=None, ctx=None):
+    """conv2d.rs:1051-1254"""
+    keep = []
+    args = []
+    for v in (kernel_shape, strides, pads, dilations):
+        a, n = _lib.i64_array(list(v), keep)
+        args += [a, n]
+    return _op(ctx, _lib.lib().lele_hip_max_pool2d, [input], args + [C.c_int(int(ceil_mode))], out)
+
+
+def topk(input, k, axis=-1, largest=True, sorted=True, ctx=None):  # conv2d.rs:1385-1435 -> (values, indices)
+    ctx = _ctx(ctx)
+    keep = []
+    ov, oi = ctx.buf(), ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_topk(ctx._h, _lib.as_tensor(unwrap(input), keep), C.c_int64(int(k)),
+                                        C.c_int(int(largest)), ov._h, oi._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(ov, sh.get(), np.float32)), TensorView(_lib.DevTensor(oi, sh.get(), np.float32))
+
+
+def _first(x, default):
+    a = np.asarray(TensorView(unwrap(x)).numpy() if isinstance(unwrap(x), _lib.DevTensor) else unwrap(x)).reshape(-1)
+    return a[0] if a.size else default
+
+
+def range(start, limit, delta, out=None, ctx=None):  # math.rs:2033-2055 (f32)
+    s, l, d = (np.float32(_first(v, dflt)) for v, dflt in ((start, 0.0), (limit, 0.0), (delta, 1.0)))
+    n = int(_b.max(np.ceil(np.float32(np.float32(l - s) / d)), 0.0)) if d != 0 else 0
+    ctx = _ctx(ctx)
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_range_f32(ctx._h, C.c_float(float(s)), C.c_float(float(d)), C.c_int64(n), out._h,
+                                             sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
+
+
+def constant_of_shape(input, value, dtype=np.float32, out=None, ctx=None):  # shape.rs:122-135
+    shape = [int(v) for v in np.asarray(TensorView(unwrap(input)).numpy() if isinstance(unwrap(input), _lib.DevTensor)
+                                        else unwrap(input)).reshape(-1)]
+    dt = np.dtype(dtype)
+    bits = int(np.array([value], dt).view(np.uint32 if dt.itemsize == 4 else np.uint64)[0])
+    ctx = _ctx(ctx)
+    keep = []
+    a, _ = _lib.i64_array(shape, keep)
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_fill(ctx._h, a, C.c_int32(len(shape)), C.c_int32(_lib._NP2DT[dt]), C.c_uint64(bits),
+                                        out._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), dt))
+
+
+def cast_to_f32(input, out=None, ctx=None):  # utils.rs:66-83
+    return _op(ctx, _lib.lib().lele_hip_cast, [input], [C.c_int32(_lib.F32)], out, np.float32)
+
+
+def cast_to_i64(input, out=None, ctx=None):  # utils.rs:84-101
+    return _op(ctx, _lib.lib().lele_hip_cast, [input], [C.c_int32(_lib.I64)], out, np.int64)
+
+
+# views: no data movement (shape.rs:2-186)
+def _view(input, shape):
+    x = unwrap(input)
+    return TensorView(x, shape) if isinstance(x, _lib.DevTensor) else TensorView(np.asarray(x), shape)
+
+
+def _try_reshape(ishape, target, total):
+    new, known, infer = [], 1, None
+    for i, d in enumerate(target):
+        if d == -1:
+            if infer is not None:
+                return None
+            infer = i
+        elif d == 0:
+            if i >= len(ishape):
+                return None
+            new.append(ishape[i])
+            known *= ishape[i]
+        else:
+            new.append(int(d))
+            known *= int(d)
+    if infer is not None:
+        if known == 0 or total % known:
+            return None
+        new.insert(infer, total // known)
+    return new if int(np.prod(new, dtype=np.int64)) == total else None
+
+
+def reshape(input, target_shape_raw):  # shape.rs:2-52 (three strategies)
+    ishape = _shape_of(input)
+    total = int(np.prod(ishape, dtype=np.int64))
+    tgt = [int(v) for v in target_shape_raw]
+    r = _try_reshape(ishape, tgt, total) or _try_reshape(ishape, [-1 if d == 0 else d for d in tgt], total)
+    if r is None and len(tgt) > len(ishape) > 0:
+        col = [tgt[0] if tgt[0] > 0 else -1, -1] + [d if d > 0 else -1 for d in tgt[len(tgt) - (len(ishape) - 1):]]
+        r = _try_reshape(ishape, col, total)
+    if r is None:
+        raise _lib.LeleError("Reshape: element count mismatch (input=%s target=%s)" % (list(ishape), tgt))
+    return _view(input, r)
+
+
+def flatten(input, axis):  # shape.rs:105-121
+    s = _shape_of(input)
+    ax = axis + len(s) if axis < 0 else axis
+    return _view(input, [int(np.prod(s[:ax], dtype=np.int64)), int(np.prod(s[ax:], dtype=np.int64))])
+
+
+def unsqueeze(input, axes):  # shape.rs:136-156
+    s = list(_shape_of(input))
+    rank = len(s) + len(axes)
+    for a in sorted(axes):
+        idx = a + rank if a < 0 else a
+        s.insert(idx, 1) if idx <= len(s) else s.append(1)
+    return _view(input, s)
+
+
+def squeeze(input, axes=None):  # shape.rs:157-185
+    s = _shape_of(input)
+    if axes is None:
+        return _view(input, [d for d in s if d != 1])
+    ax = {a + len(s) if a < 0 else a for a in axes}
+    return _view(input, [d for i, d in enumerate(s) if not (d == 1 and i in ax)])
+
+
+def identity(input):  # shape.rs:186
+    return _view(input, _shape_of(input))
+
+
+def shape(input):  # shape.rs:100-104 -> i64 [rank]
+    return TensorView(np.array(_shape_of(input), np.int64))
+
+
+def size(input):  # shape.rs:95-99 -> i64 scalar
+    return TensorView(np.array(int(np.prod(_shape_of(input), dtype=np.int64)), np.int64).reshape(()))

@@ -24,9 +24,10 @@ class TensorView:
                 shape = tuple(int(s) for s in shape)
                 assert a.size == int(np.prod(shape, dtype=np.int64)), "Data length mismatch"  # tensor.rs:29
                 a = a.reshape(shape)
+            lshape = tuple(a.shape)  # np.ascontiguousarray promotes 0-d to 1-d: keep the logical shape ourselves
             self._host = np.ascontiguousarray(a)
             self._dev = None
-            self.shape = tuple(self._host.shape)
+            self.shape = lshape
 
     # constructors named as in tensor.rs:27-71
     @classmethod
@@ -61,8 +62,8 @@ class TensorView:
 
     def numpy(self):
         if self._host is None:
-            self._host = self._dev.numpy().reshape(self.shape)
-        return self._host
+            self._host = self._dev.numpy()
+        return self._host.reshape(self.shape)
 
     @property
     def data(self):

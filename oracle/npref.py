@@ -109,3 +109,107 @@ def reduce(op, x, axes, keepdims):
         out = acc
     oshape = [1 if d in ax else x.shape[d] for d in range(dims)] if keepdims else [x.shape[d] for d in keep]
     return out.astype(np.float32).reshape(oshape)
+
+
+# ---- data movement (bit-exact): manipulation.rs, shape.rs, conv2d.rs:1051-1502, math.rs:2033-2302 ----------------
+def slice_(x, starts, ends, axes=(), steps=()):  # manipulation.rs:209-380 == numpy slicing with ONNX clamping
+    x = np.asarray(x)
+    idx = [slice(None)] * x.ndim
+    for i in range(len(starts)):
+        ax = i if not len(axes) else axes[i] % x.ndim
+        st = steps[i] if i < len(steps) else 1
+        s, e = int(starts[i]), int(ends[i])
+        e = None if (e > (2 ** 62) or e < -(2 ** 62)) else e
+        if e is not None and st < 0 and e < -x.shape[ax]:
+            e = None
+        idx[ax] = slice(s, e, st)
+    return x[tuple(idx)]
+
+
+def pad(x, pads, value=0, mode="constant"):
+    x = np.asarray(x)
+    r = x.ndim
+    raw = [max(0, int(p)) for p in pads]
+    if len(raw) < 2 * r:
+        half = len(raw) // 2
+        full = [0] * (2 * r)
+        for i in range(half):
+            full[r - half + i] = raw[i]
+            full[2 * r - half + i] = raw[half + i]
+        raw = full
+    if mode == "constant":
+        return np.pad(x, [(raw[i], raw[r + i]) for i in range(r)], constant_values=value)
+    if mode == "edge":
+        return np.pad(x, [(raw[i], raw[r + i]) for i in range(r)], mode="edge")
+    # reflect AS IMPLEMENTED by the reference (manipulation.rs:562-569): no edge repeat in front, edge repeated behind
+    out = x
+    for d in range(r):
+        n = out.shape[d]
+        src = [(-(c - raw[d])) if c < raw[d] else ((2 * n - 1 - (c - raw[d])) if c - raw[d] >= n else c - raw[d])
+               for c in range(n + raw[d] + raw[r + d])]
+        out = np.take(out, src, axis=d)
+    return out
+
+
+def gather(data, indices, axis):
+    return np.take(np.asarray(data), np.asarray(indices).astype(np.int64), axis=axis)
+
+
+def gather_elements(x, idx, axis):
+    x = np.asarray(x)
+    i = np.asarray(idx).astype(np.int64)
+    i = np.where(i < 0, i + x.shape[axis], i)
+    return np.take_along_axis(x, i, axis=axis)
+
+
+def resize_nearest(x, out_h, out_w, asymmetric=True):  # conv2d.rs:1348-1377, f32 coordinate arithmetic
+    x = np.asarray(x, np.float32)
+    in_h, in_w = x.shape[2:]
+    hs, ws = np.float32(in_h) / np.float32(out_h), np.float32(in_w) / np.float32(out_w)
+
+    def rnd(v):  # f32::round, half away from zero
+        return np.sign(v) * np.floor(np.abs(v) + np.float32(0.5))
+
+    def idx(n_out, scale, n_in):
+        o = np.arange(n_out, dtype=np.float32)
+        if asymmetric:
+            v = np.minimum(np.floor((o * scale).astype(np.float32)), np.float32(n_in - 1))
+        else:
+            t = ((o + np.float32(0.5)).astype(np.float32) * scale).astype(np.float32) - np.float32(0.5)
+            v = np.minimum(np.maximum(rnd(t.astype(np.float32)), 0), np.float32(n_in - 1))
+        return v.astype(np.int64)
+
+    return x[:, :, idx(out_h, hs, in_h)][:, :, :, idx(out_w, ws, in_w)]
+
+
+def max_pool2d(x, kernel, strides=(), pads=(), dilations=(), ceil_mode=False):  # conv2d.rs:1051-1254
+    x = np.asarray(x, np.float32)
+    n, c, ih, iw = x.shape
+    kh = kernel[0]
+    kw = kernel[1] if len(kernel) > 1 else kh
+    sh = strides[0] if len(strides) else 1
+    sw = strides[1] if len(strides) > 1 else sh
+    pt = pads[0] if len(pads) else 0
+    pl = pads[1] if len(pads) > 1 else pt
+    pb = pads[2] if len(pads) > 2 else pt
+    pr = pads[3] if len(pads) > 3 else pl
+    dh = dilations[0] if len(dilations) else 1
+    dw = dilations[1] if len(dilations) > 1 else dh
+    ekh, ekw = dh * (kh - 1) + 1, dw * (kw - 1) + 1
+    nh, nw = ih + pt + pb - ekh, iw + pl + pr - ekw
+    oh = (nh + sh - 1) // sh + 1 if ceil_mode else nh // sh + 1
+    ow = (nw + sw - 1) // sw + 1 if ceil_mode else nw // sw + 1
+    xp = np.full((n, c, ih + pt + pb + sh * 2 + ekh, iw + pl + pr + sw * 2 + ekw), -np.inf, np.float32)
+    xp[:, :, pt:pt + ih, pl:pl + iw] = x
+    out = np.full((n, c, oh, ow), -np.inf, np.float32)
+    for a in range(kh):
+        for b in range(kw):
+            out = np.maximum(out, xp[:, :, a * dh:a * dh + oh * sh:sh, b * dw:b * dw + ow * sw:sw])
+    return out
+
+
+def topk(x, k, largest=True):  # conv2d.rs:1385-1435: stable sort, indices as f32
+    x = np.asarray(x, np.float32)
+    k = min(k, x.shape[-1])
+    order = np.argsort(-x if largest else x, axis=-1, kind="stable")[..., :k]
+    return np.take_along_axis(x, order, -1), order.astype(np.float32)
