@@ -213,6 +213,8 @@ def batch_norm(input, scale, bias, mean, var, epsilon, out=None, ctx=None):  # n
 
 # ------------------------------------------------------------------------------------------- data movement
 def _shape_of(x):
+    if isinstance(x, TensorView):
+        return tuple(x.shape)
     x = unwrap(x)
     return tuple(x.shape) if isinstance(x, _lib.DevTensor) else tuple(np.asarray(x).shape)
 

@@ -72,7 +72,9 @@ class TensorView:
 
     def raw(self):
         """what to hand to the C ABI: the device tensor if there is one, else the numpy array"""
-        return self._dev if self._dev is not None else self._host
+        if self._dev is not None:
+            return self._dev
+        return self._host.reshape(self.shape) if self.shape != () else self._host.reshape(())
 
     def __repr__(self):
         return "TensorView(shape=%s, dtype=%s, %s)" % (self.shape, self.dtype, "device" if self.is_device else "host")
