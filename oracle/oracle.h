@@ -88,6 +88,19 @@ void orc_rms_norm(const float* input, const float* weight, float* output, int64_
 void orc_batch_norm(const float* src, const float* scale, const float* bias, const float* mean, const float* var,
                     float epsilon, int64_t outer, int64_t c, int64_t inner, float* out);
 
+/* ---- src/kernels/rnn.rs, conv2d.rs, conv1d.rs ----------------------------------------------------------- */
+void orc_lstm(const float* x, int64_t seq_len, int64_t input_size, int64_t hidden, const float* w, const float* r,
+              const float* bias, const float* h0, const float* c0, float* out_y, float* out_h, float* out_c);
+void orc_gru(const float* x, int64_t seq_len, int64_t input_size, int64_t hidden, const float* w, const float* r,
+             const float* bias, const float* h0, float* out_y, float* out_h);
+/* act: 0 none, 1 relu, 2 silu; conv1d is the H == 1 case */
+void orc_conv2d(const float* x, const float* w, const float* bias, int64_t n, int64_t c, int64_t ih, int64_t iw,
+                int64_t oc, int64_t kh, int64_t kw, int64_t group, int64_t pt, int64_t pl, int64_t pb, int64_t pr,
+                int64_t sh, int64_t sw, int64_t dh, int64_t dw, int act, float* out);
+void orc_conv_transpose2d(const float* x, const float* w, const float* bias, int64_t n, int64_t c, int64_t ih,
+                          int64_t iw, int64_t oc, int64_t kh, int64_t kw, int64_t pt, int64_t pl, int64_t pb, int64_t pr,
+                          int64_t sh, int64_t sw, int64_t dh, int64_t dw, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -307,3 +307,104 @@ def batch_norm(x, scale, bias, mean, var, eps=1e-5):
     lib().orc_batch_norm(_p(x), _p(_f32(scale)), _p(_f32(bias)), _p(_f32(mean)), _p(_f32(var)), f(eps), i64(outer),
                          i64(c), i64(inner), _p(out))
     return out
+
+
+# ---------------------------------------------------------------- rnn / conv
+def lstm(x, w, r, bias=None, h0=None, c0=None):
+    x, w, r = _f32(x), _f32(w), _f32(r)
+    t, b, i = x.shape
+    assert w.shape[0] == 1 and b == 1, "LSTM: Only num_directions=1 / batch_size=1 supported"
+    h = w.shape[1] // 4
+    y, oh, oc = np.empty((t, 1, 1, h), np.float32), np.empty((1, 1, h), np.float32), np.empty((1, 1, h), np.float32)
+    bb = _f32(bias).reshape(-1) if bias is not None else None
+    hh = _f32(h0).reshape(-1) if h0 is not None else None
+    cc = _f32(c0).reshape(-1) if c0 is not None else None
+    lib().orc_lstm(_p(x), i64(t), i64(i), i64(h), _p(w), _p(r), _p(bb) if bb is not None else None,
+                   _p(hh) if hh is not None else None, _p(cc) if cc is not None else None, _p(y), _p(oh), _p(oc))
+    return y, oh, oc
+
+
+def gru(x, w, r, bias=None, h0=None):
+    x, w, r = _f32(x), _f32(w), _f32(r)
+    t, b, i = x.shape
+    assert w.shape[0] == 1 and b == 1
+    h = w.shape[1] // 3
+    y, oh = np.empty((t, 1, 1, h), np.float32), np.empty((1, 1, h), np.float32)
+    bb = _f32(bias).reshape(-1) if bias is not None else None
+    hh = _f32(h0).reshape(-1) if h0 is not None else None
+    lib().orc_gru(_p(x), i64(t), i64(i), i64(h), _p(w), _p(r), _p(bb) if bb is not None else None,
+                  _p(hh) if hh is not None else None, _p(y), _p(oh))
+    return y, oh
+
+
+def _attr2(v, default):
+    v = list(v)
+    if len(v) >= 2:
+        return int(v[0]), int(v[1])
+    if len(v) == 1:
+        return int(v[0]), int(v[0])
+    return default, default
+
+
+def _pads4(p):  # conv2d.rs:246-273: [top, left, bottom, right]; 2 values = symmetric
+    p = list(p)
+    if len(p) >= 4:
+        return int(p[0]), int(p[1]), int(p[2]), int(p[3])
+    if len(p) >= 2:
+        return int(p[0]), int(p[1]), int(p[0]), int(p[1])
+    return 0, 0, 0, 0
+
+
+ACT = {None: 0, "none": 0, "relu": 1, "silu": 2}
+
+
+def conv2d(x, w, bias=None, dilations=(), group=1, pads=(), strides=(), act=None):
+    x, w = _f32(x), _f32(w)
+    n, c, ih, iw = x.shape
+    oc, _, kh, kw = w.shape
+    dh, dw = _attr2(dilations, 1)
+    sh, sw = _attr2(strides, 1)
+    pt, pl, pb, pr = _pads4(pads)
+    oh = (ih + pt + pb - dh * (kh - 1) - 1) // sh + 1
+    ow = (iw + pl + pr - dw * (kw - 1) - 1) // sw + 1
+    out = np.empty((n, oc, oh, ow), np.float32)
+    b = _f32(bias) if bias is not None else None
+    lib().orc_conv2d(_p(x), _p(w), _p(b) if b is not None else None, i64(n), i64(c), i64(ih), i64(iw), i64(oc), i64(kh),
+                     i64(kw), i64(group), i64(pt), i64(pl), i64(pb), i64(pr), i64(sh), i64(sw), i64(dh), i64(dw),
+                     C.c_int(ACT[act]), _p(out))
+    return out
+
+
+def conv1d(x, w, bias=None, dilations=(), group=1, pads=(), strides=(), relu=False):
+    """conv1d_fused, conv1d.rs:853-1464: NCL; pads = [left, right]"""
+    x, w = _f32(x), _f32(w)
+    p = list(pads)
+    pl, pr = (int(p[0]), int(p[1])) if len(p) >= 2 else ((int(p[0]), int(p[0])) if len(p) == 1 else (0, 0))
+    d = int(list(dilations)[0]) if len(list(dilations)) else 1
+    s = int(list(strides)[0]) if len(list(strides)) else 1
+    y = conv2d(x[:, :, None, :], w[:, :, None, :], bias, [1, d], group, [0, pl, 0, pr], [1, s], "relu" if relu else None)
+    return y[:, :, 0, :]
+
+
+def conv_transpose(x, w, bias=None, dilations=(), group=1, pads=(), strides=()):
+    assert group == 1, "ConvTranspose: group > 1 not supported yet"
+    x, w = _f32(x), _f32(w)
+    n, c, ih, iw = x.shape
+    _, oc, kh, kw = w.shape
+    st, dl, pd = list(strides), list(dilations), list(pads)
+    sh = int(st[0]) if len(st) > 0 else 1
+    sw = int(st[1]) if len(st) > 1 else 1
+    dh = int(dl[0]) if len(dl) > 0 else 1
+    dw = int(dl[1]) if len(dl) > 1 else 1
+    pt = int(pd[0]) if len(pd) > 0 else 0
+    pl = int(pd[1]) if len(pd) > 1 else 0
+    pb = int(pd[2]) if len(pd) > 2 else pt
+    pr = int(pd[3]) if len(pd) > 3 else pl
+    oh = (ih - 1) * sh - (pt + pb) + dh * (kh - 1) + 1
+    ow = (iw - 1) * sw - (pl + pr) + dw * (kw - 1) + 1
+    out = np.empty((n, oc, oh, ow), np.float32)
+    b = _f32(bias) if bias is not None else None
+    lib().orc_conv_transpose2d(_p(x), _p(w), _p(b) if b is not None else None, i64(n), i64(c), i64(ih), i64(iw), i64(oc),
+                               i64(kh), i64(kw), i64(pt), i64(pl), i64(pb), i64(pr), i64(sh), i64(sw), i64(dh), i64(dw),
+                               _p(out))
+    return out

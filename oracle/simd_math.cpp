@@ -262,3 +262,172 @@ extern "C" void orc_batch_norm(const float* src, const float* s, const float* b,
             for (; k < inner; ++k) o[k] = p[k] * scale_val + bias_val;
         }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// LSTM / GRU (batch 1, one direction), /root/reference/src/kernels/rnn.rs:15-432.  The two GEMVs per step go through
+// faer in the reference (summation order unpinned): here they are float64-accumulated dot products rounded once.
+// The gate arithmetic is the reference's AVX2 code (poly sigmoid / tanh in the 8-wide body, libm in the tail).
+static inline float dot64(const float* a, const float* b, int64_t n) {
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) s += (double)a[i] * (double)b[i];
+    return (float)s;
+}
+static inline float sigmoid_scalar(float x) { return 1.0f / (1.0f + expf(-x)); }  // activations.rs:1-3
+
+extern "C" void orc_lstm(const float* x, int64_t seq_len, int64_t input_size, int64_t hidden, const float* w,
+                         const float* r, const float* bias /*[8H] or NULL*/, const float* h0, const float* c0,
+                         float* out_y /*[T,H]*/, float* out_h, float* out_c) {
+    const int64_t H = hidden, G = 4 * hidden;
+    for (int64_t k = 0; k < H; ++k) {
+        out_h[k] = h0 ? h0[k] : 0.0f;
+        out_c[k] = c0 ? c0[k] : 0.0f;
+    }
+    float* gates = new float[G];
+    for (int64_t t = 0; t < seq_len; ++t) {
+        const float* xt = x + t * input_size;
+        for (int64_t g = 0; g < G; ++g) {
+            float wc = dot64(w + g * input_size, xt, input_size), rc = dot64(r + g * H, out_h, H);
+            float bw = bias ? bias[g] : 0.0f, br = bias ? bias[G + g] : 0.0f;
+            gates[g] = wc + rc + bw + br;  // rnn.rs:152-154 (left-associated f32 adds)
+        }
+        int64_t k = 0;
+        for (; k + 8 <= H; k += 8) {  // lstm_gates_avx2, rnn.rs:15-65; gate order i, o, f, c
+            __m256 ig = sigmoid_ps(_mm256_loadu_ps(gates + k)), og = sigmoid_ps(_mm256_loadu_ps(gates + H + k));
+            __m256 fg = sigmoid_ps(_mm256_loadu_ps(gates + 2 * H + k)), cg = tanh_ps(_mm256_loadu_ps(gates + 3 * H + k));
+            __m256 ct = _mm256_fmadd_ps(fg, _mm256_loadu_ps(out_c + k), _mm256_mul_ps(ig, cg));
+            __m256 ht = _mm256_mul_ps(og, tanh_ps(ct));
+            _mm256_storeu_ps(out_c + k, ct);
+            _mm256_storeu_ps(out_h + k, ht);
+            _mm256_storeu_ps(out_y + t * H + k, ht);
+        }
+        for (; k < H; ++k) {
+            float ig = sigmoid_scalar(gates[k]), og = sigmoid_scalar(gates[H + k]), fg = sigmoid_scalar(gates[2 * H + k]);
+            float cg = tanhf(gates[3 * H + k]);
+            float ct = fg * out_c[k] + ig * cg;
+            float ht = og * tanhf(ct);
+            out_c[k] = ct;
+            out_h[k] = ht;
+            out_y[t * H + k] = ht;
+        }
+    }
+    delete[] gates;
+}
+
+extern "C" void orc_gru(const float* x, int64_t seq_len, int64_t input_size, int64_t hidden, const float* w,
+                        const float* r, const float* bias /*[6H] or NULL*/, const float* h0, float* out_y,
+                        float* out_h) {
+    // x86 always evaluates the linear_before_reset=1 form (rnn.rs:311-316, 393-407), like the reference's own
+    // ref_gru_step oracle (tests/regression_kernels.rs:602-633)
+    const int64_t H = hidden, G = 3 * hidden;
+    for (int64_t k = 0; k < H; ++k) out_h[k] = h0 ? h0[k] : 0.0f;
+    float *wc = new float[G], *rc = new float[G], *hn = new float[H];
+    const __m256 one = _mm256_set1_ps(1.0f);
+    for (int64_t t = 0; t < seq_len; ++t) {
+        const float* xt = x + t * input_size;
+        for (int64_t g = 0; g < G; ++g) {
+            wc[g] = dot64(w + g * input_size, xt, input_size);
+            rc[g] = dot64(r + g * H, out_h, H);
+        }
+        const float* bw = bias;
+        const float* br = bias ? bias + G : nullptr;
+        auto B = [&](const float* b, int64_t i) { return b ? b[i] : 0.0f; };
+        int64_t k = 0;
+        for (; k + 8 <= H; k += 8) {  // gru_gate_fusion_avx2, rnn.rs:359-432
+            float tmp[8];
+            auto ld = [&](const float* p, int64_t off, bool isb) {
+                for (int e = 0; e < 8; ++e) tmp[e] = isb ? B(p, off + e) : p[off + e];
+                return _mm256_loadu_ps(tmp);
+            };
+            __m256 z = sigmoid_ps(_mm256_add_ps(_mm256_add_ps(ld(wc, k, false), ld(rc, k, false)),
+                                                _mm256_add_ps(ld(bw, k, true), ld(br, k, true))));
+            __m256 rg = sigmoid_ps(_mm256_add_ps(_mm256_add_ps(ld(wc, H + k, false), ld(rc, H + k, false)),
+                                                 _mm256_add_ps(ld(bw, H + k, true), ld(br, H + k, true))));
+            __m256 whx = _mm256_add_ps(ld(wc, 2 * H + k, false), ld(bw, 2 * H + k, true));
+            __m256 rrh = _mm256_mul_ps(rg, _mm256_add_ps(ld(rc, 2 * H + k, false), ld(br, 2 * H + k, true)));
+            __m256 hg = tanh_ps(_mm256_add_ps(whx, rrh));
+            __m256 ht = _mm256_fmadd_ps(_mm256_sub_ps(one, z), hg, _mm256_mul_ps(z, _mm256_loadu_ps(out_h + k)));
+            _mm256_storeu_ps(hn + k, ht);
+        }
+        for (; k < H; ++k) {
+            float z = sigmoid_scalar(wc[k] + rc[k] + B(bw, k) + B(br, k));
+            float rg = sigmoid_scalar(wc[H + k] + rc[H + k] + B(bw, H + k) + B(br, H + k));
+            float hg = tanhf((wc[2 * H + k] + B(bw, 2 * H + k)) + rg * (rc[2 * H + k] + B(br, 2 * H + k)));
+            hn[k] = (1.0f - z) * hg + z * out_h[k];
+        }
+        for (int64_t i = 0; i < H; ++i) {
+            out_h[i] = hn[i];
+            out_y[t * H + i] = hn[i];
+        }
+    }
+    delete[] wc;
+    delete[] rc;
+    delete[] hn;
+}
+
+// Convolutions: ONNX semantics (= the reference's in-test oracle ref_conv2d, tests/regression_kernels.rs:23-69),
+// float64-accumulated, then the x86 epilogue per (n, oc) plane: + bias, then ReLU / SiLU with the polynomial in the
+// 8-wide body and libm in the tail (bias_{silu,relu,add}_inplace, avx/math.rs:344-529; conv2d.rs:373-396).
+extern "C" void orc_conv2d(const float* x, const float* w, const float* bias, int64_t n, int64_t c, int64_t ih,
+                           int64_t iw, int64_t oc, int64_t kh, int64_t kw, int64_t group, int64_t pt, int64_t pl,
+                           int64_t pb, int64_t pr, int64_t sh, int64_t sw, int64_t dh, int64_t dw, int act, float* out) {
+    const int64_t oh = (ih + pt + pb - dh * (kh - 1) - 1) / sh + 1, ow = (iw + pl + pr - dw * (kw - 1) - 1) / sw + 1;
+    const int64_t icg = c / group, ocg = oc / group, plane = oh * ow;
+    for (int64_t b = 0; b < n; ++b)
+        for (int64_t o = 0; o < oc; ++o) {
+            const int64_t g = o / ocg;
+            float* op = out + (b * oc + o) * plane;
+            for (int64_t y = 0; y < oh; ++y)
+                for (int64_t xx = 0; xx < ow; ++xx) {
+                    double acc = 0.0;
+                    for (int64_t ci = 0; ci < icg; ++ci)
+                        for (int64_t a = 0; a < kh; ++a) {
+                            const int64_t iy = y * sh - pt + a * dh;
+                            if (iy < 0 || iy >= ih) continue;
+                            for (int64_t bb = 0; bb < kw; ++bb) {
+                                const int64_t ix = xx * sw - pl + bb * dw;
+                                if (ix < 0 || ix >= iw) continue;
+                                acc += (double)x[((b * c + g * icg + ci) * ih + iy) * iw + ix] *
+                                       (double)w[((o * icg + ci) * kh + a) * kw + bb];
+                            }
+                        }
+                    float v = (float)acc;
+                    if (bias) v = v + bias[o];
+                    op[y * ow + xx] = v;
+                }
+            if (act == 1)
+                for (int64_t i = 0; i < plane; ++i) op[i] = op[i] > 0.0f ? op[i] : 0.0f;
+            else if (act == 2)
+                orc_unary_simd(3, op, op, plane);  // silu: polynomial body over plane&~7, libm tail
+        }
+}
+
+extern "C" void orc_conv_transpose2d(const float* x, const float* w /*[C,OC,kh,kw]*/, const float* bias, int64_t n,
+                                     int64_t c, int64_t ih, int64_t iw, int64_t oc, int64_t kh, int64_t kw, int64_t pt,
+                                     int64_t pl, int64_t pb, int64_t pr, int64_t sh, int64_t sw, int64_t dh, int64_t dw,
+                                     float* out) {  // conv2d.rs:2952-3128 (group 1, no output_padding)
+    const int64_t oh = (ih - 1) * sh - (pt + pb) + dh * (kh - 1) + 1, ow = (iw - 1) * sw - (pl + pr) + dw * (kw - 1) + 1;
+    for (int64_t b = 0; b < n; ++b)
+        for (int64_t o = 0; o < oc; ++o)
+            for (int64_t y = 0; y < oh; ++y)
+                for (int64_t xx = 0; xx < ow; ++xx) {
+                    double acc = 0.0;
+                    for (int64_t a = 0; a < kh; ++a) {
+                        const int64_t ty = y + pt - a * dh;
+                        if (ty < 0 || ty % sh) continue;
+                        const int64_t iy = ty / sh;
+                        if (iy >= ih) continue;
+                        for (int64_t bb = 0; bb < kw; ++bb) {
+                            const int64_t tx = xx + pl - bb * dw;
+                            if (tx < 0 || tx % sw) continue;
+                            const int64_t ix = tx / sw;
+                            if (ix >= iw) continue;
+                            for (int64_t ci = 0; ci < c; ++ci)
+                                acc += (double)x[((b * c + ci) * ih + iy) * iw + ix] *
+                                       (double)w[((ci * oc + o) * kh + a) * kw + bb];
+                        }
+                    }
+                    float v = (float)acc;
+                    if (bias) v = v + bias[o];
+                    out[((b * oc + o) * oh + y) * ow + xx] = v;
+                }
+}
