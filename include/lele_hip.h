@@ -220,6 +220,33 @@ int lele_hip_fill(LeleCtx* ctx, const int64_t* shape, int32_t rank, int32_t dtyp
 int lele_hip_cast(LeleCtx* ctx, const LeleTensor* x, int32_t to_dtype, LeleBuf* out, int64_t* out_shape,
                   int32_t* out_rank);                                                         /* utils.rs:66-101 */
 
+/* ---- src/kernels/conv2d.rs, conv1d.rs: convolutions (implicit GEMM on the f32 MFMA core) ------------------- */
+/* conv2d (conv2d.rs:107), conv2d_fused (conv2d.rs:420: act = LELE_ACT_RELU), conv2d_silu (conv2d.rs:437:
+ * act = LELE_ACT_SILU).  x [N,C,H,W], w [C_out,C_in/g,kH,kW], bias [C_out] or NULL.  dilations / strides hold 0, 1 or 2
+ * values (one value is used for both axes), pads holds 0, 2 ([ph, pw]) or 4 ([top, left, bottom, right]) values. */
+int lele_hip_conv2d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,
+                    const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
+                    const int64_t* strides, size_t nstr, int act, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* conv1d (conv1d.rs:837) / conv1d_fused (conv1d.rs:1464: relu != 0).  x [N,C,L], w [C_out,C_in/g,K], pads [left,right] */
+int lele_hip_conv1d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,
+                    const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
+                    const int64_t* strides, size_t nstr, int relu, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* conv_transpose (conv2d.rs:2952): x [N,C,H,W], w [C_in,C_out,kH,kW], group must be 1 (error otherwise, as upstream) */
+int lele_hip_conv_transpose(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,
+                            const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
+                            const int64_t* strides, size_t nstr, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+
+/* ---- src/kernels/rnn.rs: LSTM / GRU (batch 1, one direction; anything else is an error, as upstream panics) ---- */
+/* lstm (rnn.rs:67): x [T,1,I], w [1,4H,I], r [1,4H,H], bias [1,8H] or NULL; gate order i,o,f,c.
+ * out_y [T,1,1,H] (shape written to y_shape), out_h / out_c hold [1,1,H]. sequence_lens is ignored (as upstream). */
+int lele_hip_lstm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* r, const LeleTensor* bias,
+                  const LeleTensor* sequence_lens, const LeleTensor* initial_h, const LeleTensor* initial_c,
+                  LeleBuf* out_y, LeleBuf* out_h, LeleBuf* out_c, int64_t* y_shape, int32_t* y_rank);
+/* gru (rnn.rs:246): w [1,3H,I], r [1,3H,H], bias [1,6H] or NULL; gate order z,r,h */
+int lele_hip_gru(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* r, const LeleTensor* bias,
+                 const LeleTensor* initial_h, int linear_before_reset, LeleBuf* out_y, LeleBuf* out_h, int64_t* y_shape,
+                 int32_t* y_rank);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@
 // libm form for the tail (avx/math.rs:344-365).
 #include "common.h"
 #include "gemm_core.h"
+#include "simd_math.h"
 
 #include <math.h>
 
@@ -23,22 +24,6 @@ using namespace lele;
 
 namespace {
 
-__device__ __forceinline__ float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ float exp_poly(float x) {  // avx2_exp_ps, avx/math.rs:11-63 (same code as eltwise.hip)
-    x = fmaxf(x, -87.33654f);
-    x = fminf(x, 88.72284f);
-    const float fx = rintf(x * 1.44269504088896341f);
-    x = fmaf_(-fx, 0.693359375f, x);
-    x = fmaf_(-fx, -2.12194440e-4f, x);
-    float y = fmaf_(0.000198712018891638893f, x, 0.00139712726883569741f);
-    y = fmaf_(y, x, 0.00833345670066840443f);
-    y = fmaf_(y, x, 0.0416657844442129135f);
-    y = fmaf_(y, x, 0.166666671633720398f);
-    y = fmaf_(y, x, 0.5f);
-    y = fmaf_(y, x, 1.0f);
-    y = fmaf_(y, x, 1.0f);
-    return y * __int_as_float(((int)fx + 127) << 23);
-}
 __device__ __forceinline__ float apply_act(float v, int act, bool body) {
     if (act == LELE_ACT_RELU) return v > 0.0f ? v : 0.0f;
     if (act == LELE_ACT_SILU) return body ? v * (1.0f / (1.0f + exp_poly(-v))) : v / (1.0f + expf(-v));
@@ -261,15 +246,16 @@ int lele_hip_conv1d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, cons
                     const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
                     const int64_t* strides, size_t nstr, int relu, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
     LELE_REQUIRE(ctx && x && w && out, "conv1d: NULL argument");
-    LELE_REQUIRE(x->rank == 3 && w->rank == 3, "conv1d: expected input [N,C,L] and weight [C_out,C_in/g,K]");
+    LELE_REQUIRE(x->rank == 3 || x->rank == 2, "Conv1d: Unsupported input rank %d", x->rank);  // conv1d.rs:867-873
+    LELE_REQUIRE(w->rank == 3, "conv1d: expected weight [C_out,C_in/g,K]");
     LELE_REQUIRE(x->dtype == LELE_F32 && w->dtype == LELE_F32, "conv1d: f32 tensors required");
     LELE_REQUIRE(group >= 1, "conv1d: group must be >= 1");
     LELE_HIP_CHECK(hipSetDevice(ctx->device));
     ConvGeom g{};
     g.n = (int)x->shape[0];
-    g.c = (int)x->shape[1];
+    g.c = x->rank == 3 ? (int)x->shape[1] : 1;  // [N, L] is a single channel
     g.ih = 1;
-    g.iw = (int)x->shape[2];
+    g.iw = (int)x->shape[x->rank - 1];
     g.oc = (int)w->shape[0];
     g.kh = 1;
     g.kw = (int)w->shape[2];
@@ -282,7 +268,7 @@ int lele_hip_conv1d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, cons
     g.dw = ndil ? (int)dilations[0] : 1;
     g.sh = 1;
     g.sw = nstr ? (int)strides[0] : 1;
-    const int pl = npads >= 1 ? (int)pads[0] : 0, pr = npads >= 2 ? (int)pads[1] : pl;
+    const int pl = npads >= 1 ? (int)pads[0] : 0, pr = npads >= 2 ? (int)pads[1] : 0;  // conv1d.rs:886-887
     g.pt = 0;
     g.pl = pl;
     const int64_t nw = (int64_t)g.iw + pl + pr - (int64_t)g.dw * (g.kw - 1) - 1;  // conv1d.rs:888-889

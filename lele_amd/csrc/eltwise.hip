@@ -13,48 +13,13 @@
 //   roles of the 32 SIMD accumulator slots, so the statistics -- and therefore the outputs -- are bit-exact.
 #include "common.h"
 
+#include "simd_math.h"
+
 #include <math.h>
 
 using namespace lele;
 
 namespace {
-
-__device__ __forceinline__ float fmaf_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-
-// avx2_exp_ps, avx/math.rs:11-63
-__device__ __forceinline__ float exp_poly(float x) {
-    x = fmaxf(x, -87.33654f);
-    x = fminf(x, 88.72284f);
-    const float fx = rintf(x * 1.44269504088896341f);  // _mm256_round_ps(nearest-even)
-    x = fmaf_(-fx, 0.693359375f, x);                    // _mm256_fnmadd_ps(fx, ln2_hi, x)
-    x = fmaf_(-fx, -2.12194440e-4f, x);
-    float y = fmaf_(0.000198712018891638893f, x, 0.00139712726883569741f);
-    y = fmaf_(y, x, 0.00833345670066840443f);
-    y = fmaf_(y, x, 0.0416657844442129135f);
-    y = fmaf_(y, x, 0.166666671633720398f);
-    y = fmaf_(y, x, 0.5f);
-    y = fmaf_(y, x, 1.0f);
-    y = fmaf_(y, x, 1.0f);
-    const int e = ((int)fx + 127) << 23;  // cvtps_epi32(fx) is exact: fx is integral
-    return y * __int_as_float(e);
-}
-__device__ __forceinline__ float sigmoid_poly(float x) { return 1.0f / (1.0f + exp_poly(-x)); }  // avx/math.rs:66-76
-__device__ __forceinline__ float tanh_poly(float x) {                                            // avx/math.rs:79-97
-    const float e = exp_poly(-x * 2.0f);
-    const float r = (1.0f - e) / (1.0f + e);
-    return copysignf(fabsf(r), x);
-}
-__device__ __forceinline__ float erf_poly(float x) {  // avx/math.rs:112-145
-    const float ax = fabsf(x);
-    const float t = 1.0f / fmaf_(0.3275911f, ax, 1.0f);
-    float poly = fmaf_(1.061405429f, t, -1.453152027f);
-    poly = fmaf_(poly, t, 1.421413741f);
-    poly = fmaf_(poly, t, -0.284496736f);
-    poly = fmaf_(poly, t, 0.254829592f);
-    const float ev = exp_poly(-(ax * ax));
-    const float r = fmaf_(-(poly * t), ev, 1.0f);  // _mm256_fnmadd_ps(poly*t, exp, one)
-    return __int_as_float(__float_as_int(r) | (__float_as_int(x) & 0x80000000));
-}
 
 enum UnaryOp {
     U_EXP = 0, U_SIGMOID = 1, U_TANH = 2, U_SILU = 3, U_ERF = 4, U_GELU = 5, U_FAST_GELU = 6, U_RELU = 7, U_SQRT = 8,

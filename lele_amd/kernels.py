@@ -467,6 +467,74 @@ def cast_to_f32(input, out=None, ctx=None):  # utils.rs:66-83
 def cast_to_i64(input, out=None, ctx=None):  # utils.rs:84-101
     return _op(ctx, _lib.lib().lele_hip_cast, [input], [C.c_int32(_lib.I64)], out, np.int64)
 
+# ------------------------------------------------------------------------------------------------- conv / rnn
+def _conv(fn, input, weights, bias, dilations, group, pads, strides, tail, out, ctx):
+    keep = []
+    args = []
+    d, n = _lib.i64_array(list(dilations), keep)
+    args += [d, n, C.c_int64(int(group))]
+    for v in (pads, strides):
+        a, n = _lib.i64_array(list(v), keep)
+        args += [a, n]
+    return _op(ctx, fn, [input, weights, bias], args + list(tail), out)
+
+
+def conv2d(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), out=None, ctx=None):  # conv2d.rs:107
+    return _conv(_lib.lib().lele_hip_conv2d, input, weights, bias, dilations, group, pads, strides, [C.c_int(0)], out, ctx)
+
+
+def conv2d_fused(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), relu=False, out=None, ctx=None):
+    """conv2d.rs:155"""
+    return _conv(_lib.lib().lele_hip_conv2d, input, weights, bias, dilations, group, pads, strides,
+                 [C.c_int(1 if relu else 0)], out, ctx)
+
+
+def conv2d_silu(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), out=None, ctx=None):  # conv2d.rs:124
+    return _conv(_lib.lib().lele_hip_conv2d, input, weights, bias, dilations, group, pads, strides, [C.c_int(2)], out, ctx)
+
+
+def conv1d(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), out=None, ctx=None):  # conv1d.rs:837
+    return _conv(_lib.lib().lele_hip_conv1d, input, weights, bias, dilations, group, pads, strides, [C.c_int(0)], out, ctx)
+
+
+def conv1d_fused(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), relu=False, out=None, ctx=None):
+    """conv1d.rs:853"""
+    return _conv(_lib.lib().lele_hip_conv1d, input, weights, bias, dilations, group, pads, strides,
+                 [C.c_int(int(bool(relu)))], out, ctx)
+
+
+def conv_transpose(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), out=None, ctx=None):
+    """conv2d.rs:2952"""
+    return _conv(_lib.lib().lele_hip_conv_transpose, input, weights, bias, dilations, group, pads, strides, [], out, ctx)
+
+
+def lstm(input, w, r, bias=None, sequence_lens=None, initial_h=None, initial_c=None, ctx=None):
+    """rnn.rs:67 -> (Y [T,1,1,H], H_n [1,1,H], C_n [1,1,H])"""
+    ctx = _ctx(ctx)
+    keep = []
+    oy, oh, oc = ctx.buf(), ctx.buf(), ctx.buf()
+    sh = _lib.OutShape()
+    t = [_lib.as_tensor(unwrap(v), keep) for v in (input, w, r, bias, sequence_lens, initial_h, initial_c)]
+    _lib.check(_lib.lib().lele_hip_lstm(ctx._h, *t, oy._h, oh._h, oc._h, sh.shape, C.byref(sh.rank)))
+    ys = sh.get()
+    hs = (1, 1, ys[-1])
+    return (TensorView(_lib.DevTensor(oy, ys, np.float32)), TensorView(_lib.DevTensor(oh, hs, np.float32)),
+            TensorView(_lib.DevTensor(oc, hs, np.float32)))
+
+
+def gru(input, w, r, bias=None, initial_h=None, linear_before_reset=False, ctx=None):
+    """rnn.rs:246 -> (Y [T,1,1,H], H_n [1,1,H])"""
+    ctx = _ctx(ctx)
+    keep = []
+    oy, oh = ctx.buf(), ctx.buf()
+    sh = _lib.OutShape()
+    t = [_lib.as_tensor(unwrap(v), keep) for v in (input, w, r, bias, initial_h)]
+    _lib.check(_lib.lib().lele_hip_gru(ctx._h, *t, C.c_int(int(bool(linear_before_reset))), oy._h, oh._h, sh.shape,
+                                       C.byref(sh.rank)))
+    ys = sh.get()
+    return TensorView(_lib.DevTensor(oy, ys, np.float32)), TensorView(_lib.DevTensor(oh, (1, 1, ys[-1]), np.float32))
+
+
 
 # views: no data movement (shape.rs:2-186)
 def _view(input, shape):

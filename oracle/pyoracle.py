@@ -379,7 +379,9 @@ def conv1d(x, w, bias=None, dilations=(), group=1, pads=(), strides=(), relu=Fal
     """conv1d_fused, conv1d.rs:853-1464: NCL; pads = [left, right]"""
     x, w = _f32(x), _f32(w)
     p = list(pads)
-    pl, pr = (int(p[0]), int(p[1])) if len(p) >= 2 else ((int(p[0]), int(p[0])) if len(p) == 1 else (0, 0))
+    pl, pr = (int(p[0]), int(p[1])) if len(p) >= 2 else ((int(p[0]), 0) if len(p) == 1 else (0, 0))  # conv1d.rs:886-887
+    if x.ndim == 2:  # [N, L] is one channel, conv1d.rs:869
+        x = x[:, None, :]
     d = int(list(dilations)[0]) if len(list(dilations)) else 1
     s = int(list(strides)[0]) if len(list(strides)) else 1
     y = conv2d(x[:, :, None, :], w[:, :, None, :], bias, [1, d], group, [0, pl, 0, pr], [1, s], "relu" if relu else None)

@@ -1,0 +1,337 @@
+"""Conv1d / Conv2d / ConvTranspose / LSTM / GRU.
+
+CPU: the oracle is pinned on the reference's own test cases -- the conv1d unit tests (src/kernels/conv1d.rs:1621-1674),
+the ref_conv2d / ref_gru_step cases of tests/regression_kernels.rs:75-252, 602-737 (same generated inputs, same
+tolerances) -- and cross-checked against torch's CPU operators.  GPU: the HIP operators against the oracle through the
+C ABI at the 1e-4 relative bar BASELINE.json states for f32 kernels.
+"""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+
+RTOL = 1e-4
+
+
+def _close(got, want, tol=RTOL, what=""):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = max(1.0, float(np.abs(want).max())) if want.size else 1.0
+    err = float(np.abs(got - want).max()) if want.size else 0.0
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
+
+
+def _seq(n, mul, add, mod=None):
+    i = np.arange(n, dtype=np.int64)
+    if mod:
+        i = i % mod
+    return (i.astype(np.float32) * np.float32(mul) + np.float32(add)).astype(np.float32)
+
+
+def _ref_conv2d(x, w, b, stride, pad, group, relu):
+    """plain-loop restatement of the in-test oracle ref_conv2d (tests/regression_kernels.rs:23-69), float64"""
+    n, c, ih, iw = x.shape
+    oc, icg, kh, kw = w.shape
+    oh = (ih + 2 * pad - kh) // stride + 1
+    ow = (iw + 2 * pad - kw) // stride + 1
+    xp = np.zeros((n, c, ih + 2 * pad, iw + 2 * pad), np.float64)
+    xp[:, :, pad:pad + ih, pad:pad + iw] = x
+    out = np.zeros((n, oc, oh, ow), np.float64)
+    ocg = oc // group
+    for o in range(oc):
+        g = o // ocg
+        for y in range(oh):
+            for xx in range(ow):
+                win = xp[:, g * icg:(g + 1) * icg, y * stride:y * stride + kh, xx * stride:xx * stride + kw]
+                out[:, o, y, xx] = (win * w[o].astype(np.float64)).sum(axis=(1, 2, 3))
+        if b is not None:
+            out[:, o] += b[o]
+    return np.maximum(out, 0.0) if relu else out
+
+
+CONV_KATS = [
+    # (name, n, ic, oc, ih, iw, k, stride, pad, group, x(mul,add,mod), w(mul,add,mod), bias, relu, tol)
+    ("3x3_s1_p1", 1, 2, 3, 8, 8, 3, 1, 1, 1, (0.1, -2.0, None), (0.05, -1.0, None), lambda oc: _seq(oc, 0.01, 0), True, 1e-3),
+    ("3x3_s1_no_bias", 1, 1, 2, 6, 6, 3, 1, 1, 1, (0.3, -1.0, None), (0.2, -0.5, None), None, False, 1e-3),
+    ("3x3_s2", 1, 3, 4, 16, 16, 3, 2, 1, 1, (0.01, -1.0, None), (0.03, 0.0, None),
+     lambda oc: np.full(oc, 0.1, np.float32), True, 1e-3),
+    ("1x1", 1, 16, 8, 4, 4, 1, 1, 0, 1, (0.1, 0.0, None), (0.01, 0.0, None), lambda oc: _seq(oc, 0.001, 0), True, 1e-3),
+    ("pw_after_dw", 1, 32, 64, 4, 4, 1, 1, 0, 1, (0.05, 0.0, None), (0.02, -0.5, None), lambda oc: _seq(oc, 0.001, 0),
+     True, 1e-2),
+    # depthwise cases (regression_kernels.rs:133-210); upstream only asserts shape/finiteness there (its 4-channel
+    # depthwise path is known-divergent, see the TODO at :165) -- the ONNX definition is the oracle here
+    ("dw_4ch", 1, 4, 4, 10, 10, 3, 1, 1, 4, (0.2, -3.0, None), (0.1, -0.5, None), None, False, 1e-3),
+    ("dw_64ch", 1, 64, 64, 8, 8, 3, 1, 1, 64, (0.07, -1.0, 97), (0.05, -0.3, 31), None, False, 1e-3),
+    ("dw_128ch", 1, 128, 128, 6, 6, 3, 1, 1, 128, (0.03, 0.0, 73), (0.1, -0.5, 19), None, False, 1e-3),
+]
+
+
+def _kat_tensors(kat):
+    name, n, ic, oc, ih, iw, k, stride, pad, group, xs, ws, bias, relu, tol = kat
+    x = _seq(n * ic * ih * iw, *xs).reshape(n, ic, ih, iw)
+    w = _seq(oc * (ic // group) * k * k, *ws).reshape(oc, ic // group, k, k)
+    b = bias(oc) if bias else None
+    return x, w, b
+
+
+@pytest.mark.parametrize("kat", CONV_KATS, ids=[k[0] for k in CONV_KATS])
+def test_oracle_conv2d_reference_cases(kat):
+    name, n, ic, oc, ih, iw, k, stride, pad, group, xs, ws, bias, relu, tol = kat
+    x, w, b = _kat_tensors(kat)
+    want = _ref_conv2d(x, w, b, stride, pad, group, relu)
+    got = O.conv2d(x, w, b, [1, 1], group, [pad] * 4, [stride, stride], "relu" if relu else None)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= tol  # assert_close of the reference is absolute, regression_kernels.rs:5-21
+
+
+def test_oracle_conv1d_reference_unit_tests():
+    # conv1d.rs:1621-1631 grouped, 1632-1643 simple, 1645-1674 k3 with padding
+    y = O.conv1d(np.ones((1, 2, 3), np.float32), np.ones((2, 1, 1), np.float32), None, [1], 2, [0, 0], [1])
+    assert y.shape == (1, 2, 3) and np.array_equal(y.ravel(), np.ones(6))
+    y = O.conv1d(np.array([1, 2, 3], np.float32).reshape(1, 1, 3), np.ones((1, 1, 2), np.float32), None, [1], 1, [0, 0], [1])
+    assert y.shape == (1, 1, 2) and np.array_equal(y.ravel(), [3, 5])
+    y = O.conv1d(np.arange(10, dtype=np.float32).reshape(1, 1, 10), np.ones((1, 1, 3), np.float32), None, [1], 1, [1, 1], [1])
+    assert y.shape == (1, 1, 10) and (y[0, 0, 0], y[0, 0, 1], y[0, 0, 5], y[0, 0, 9]) == (1.0, 3.0, 15.0, 17.0)
+
+
+def test_oracle_conv_vs_torch():
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 6, 11, 9)).astype(np.float32)
+    w = rng.standard_normal((8, 3, 3, 2)).astype(np.float32)
+    b = rng.standard_normal(8).astype(np.float32)
+    want = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), stride=(2, 1), padding=(1, 2),
+                    dilation=(1, 2), groups=2).numpy()
+    _close(O.conv2d(x, w, b, [1, 2], 2, [1, 2, 1, 2], [2, 1]), want, 1e-5, "conv2d")
+    _close(O.conv2d(x, w, b, [1, 2], 2, [1, 2, 1, 2], [2, 1], "silu"), F.silu(torch.from_numpy(want)).numpy(), 1e-5, "silu")
+    wt = rng.standard_normal((6, 4, 3, 3)).astype(np.float32)
+    bt = rng.standard_normal(4).astype(np.float32)
+    want = F.conv_transpose2d(torch.from_numpy(x), torch.from_numpy(wt), torch.from_numpy(bt), stride=2, padding=1).numpy()
+    _close(O.conv_transpose(x, wt, bt, [1, 1], 1, [1, 1, 1, 1], [2, 2]), want, 1e-5, "conv_transpose")
+    x1 = rng.standard_normal((2, 4, 50)).astype(np.float32)
+    w1 = rng.standard_normal((6, 2, 5)).astype(np.float32)
+    want = F.conv1d(torch.from_numpy(x1), torch.from_numpy(w1), None, stride=2, padding=2, dilation=2, groups=2).numpy()
+    _close(O.conv1d(x1, w1, None, [2], 2, [2, 2], [2]), want, 1e-5, "conv1d")
+
+
+def _ref_gru(x, w, r, bw, br, hs):
+    """plain restatement of ref_gru_step (tests/regression_kernels.rs:602-633), float64 sigmoid/tanh"""
+    h = np.zeros(hs)
+    ys = []
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    for xt in x:
+        wc, rc = w.astype(np.float64) @ xt, r.astype(np.float64) @ h
+        z = sig(wc[:hs] + rc[:hs] + bw[:hs] + br[:hs])
+        rg = sig(wc[hs:2 * hs] + rc[hs:2 * hs] + bw[hs:2 * hs] + br[hs:2 * hs])
+        hg = np.tanh(wc[2 * hs:] + bw[2 * hs:] + rg * (rc[2 * hs:] + br[2 * hs:]))
+        h = (1.0 - z) * hg + z * h
+        ys.append(h.copy())
+    return np.array(ys), h
+
+
+GRU_KATS = [
+    # (name, T, I, H, x, w(mul,add), r(mul,add), bias, lbr, tol)   regression_kernels.rs:635-737
+    ("single_step", 1, 4, 8, np.array([0.1, 0.2, -0.1, 0.3], np.float32), (0.01, -0.1), (0.02, -0.2),
+     lambda n: _seq(n, 0.005, -0.05), False, 1e-4),
+    ("multi_step", 5, 3, 6, ((np.arange(15) * 7 + 3) % 20).astype(np.float32) * np.float32(0.1) - np.float32(0.5),
+     (0.03, -0.2), (0.01, -0.1), lambda n: np.full(n, 0.1, np.float32), False, 1e-3),
+    ("linear_before_reset", 3, 4, 8, _seq(12, 0.15, -0.3), (0.01, 0.0), (0.02, -0.1),
+     lambda n: np.full(n, 0.05, np.float32), True, 1e-3),
+    ("no_bias", 2, 3, 4, np.array([0.5, -0.3, 0.1, -0.2, 0.4, 0.6], np.float32), (0.05, 0.0), (0.03, 0.0), None, False, 1e-4),
+]
+
+
+def _gru_tensors(kat):
+    name, T, I, H, x, ws, rs, bias, lbr, tol = kat
+    x = np.asarray(x, np.float32).reshape(T, 1, I)
+    w = _seq(3 * H * I, *ws).reshape(1, 3 * H, I)
+    r = _seq(3 * H * H, *rs).reshape(1, 3 * H, H)
+    b = bias(6 * H).reshape(1, 6 * H) if bias else None
+    return x, w, r, b
+
+
+@pytest.mark.parametrize("kat", GRU_KATS, ids=[k[0] for k in GRU_KATS])
+def test_oracle_gru_reference_cases(kat):
+    name, T, I, H, _, _, _, _, lbr, tol = kat
+    x, w, r, b = _gru_tensors(kat)
+    bw = b[0, :3 * H] if b is not None else np.zeros(3 * H)
+    br = b[0, 3 * H:] if b is not None else np.zeros(3 * H)
+    yref, href = _ref_gru(x[:, 0, :], w[0], r[0], bw, br, H)
+    y, h = O.gru(x, w, r, b)
+    assert y.shape == (T, 1, 1, H) and h.shape == (1, 1, H)
+    assert np.abs(y.reshape(T, H) - yref).max() <= tol and np.abs(h.ravel() - href).max() <= tol
+
+
+def test_oracle_rnn_vs_torch():
+    import torch
+    rng = np.random.default_rng(3)
+    T, I, H = 7, 12, 20  # H = 20: two 8-wide polynomial blocks + a 4-element libm tail
+    x = rng.standard_normal((T, 1, I)).astype(np.float32)
+    h0 = rng.standard_normal((1, 1, H)).astype(np.float32) * 0.3
+    c0 = rng.standard_normal((1, 1, H)).astype(np.float32) * 0.3
+    # LSTM: lele's gate order is i, o, f, c (ONNX); torch's is i, f, g(c), o
+    w = rng.standard_normal((1, 4 * H, I)).astype(np.float32) * 0.3
+    r = rng.standard_normal((1, 4 * H, H)).astype(np.float32) * 0.3
+    b = rng.standard_normal((1, 8 * H)).astype(np.float32) * 0.3
+    perm = np.concatenate([np.arange(0, H), np.arange(2 * H, 3 * H), np.arange(3 * H, 4 * H), np.arange(H, 2 * H)])
+    m = torch.nn.LSTM(I, H)
+    with torch.no_grad():
+        m.weight_ih_l0.copy_(torch.from_numpy(w[0][perm]))
+        m.weight_hh_l0.copy_(torch.from_numpy(r[0][perm]))
+        m.bias_ih_l0.copy_(torch.from_numpy(b[0, :4 * H][perm]))
+        m.bias_hh_l0.copy_(torch.from_numpy(b[0, 4 * H:][perm]))
+        ty, (th, tc) = m(torch.from_numpy(x), (torch.from_numpy(h0), torch.from_numpy(c0)))
+    y, h, c = O.lstm(x, w, r, b, h0, c0)
+    _close(y.reshape(T, H), ty.numpy().reshape(T, H), 1e-5, "lstm y")
+    _close(h.ravel(), th.numpy().ravel(), 1e-5, "lstm h")
+    _close(c.ravel(), tc.numpy().ravel(), 1e-5, "lstm c")
+    # GRU: lele z, r, h; torch r, z, n (and torch is the linear_before_reset = 1 form)
+    w = rng.standard_normal((1, 3 * H, I)).astype(np.float32) * 0.3
+    r = rng.standard_normal((1, 3 * H, H)).astype(np.float32) * 0.3
+    b = rng.standard_normal((1, 6 * H)).astype(np.float32) * 0.3
+    perm = np.concatenate([np.arange(H, 2 * H), np.arange(0, H), np.arange(2 * H, 3 * H)])
+    m = torch.nn.GRU(I, H)
+    with torch.no_grad():
+        m.weight_ih_l0.copy_(torch.from_numpy(w[0][perm]))
+        m.weight_hh_l0.copy_(torch.from_numpy(r[0][perm]))
+        m.bias_ih_l0.copy_(torch.from_numpy(b[0, :3 * H][perm]))
+        m.bias_hh_l0.copy_(torch.from_numpy(b[0, 3 * H:][perm]))
+        ty, th = m(torch.from_numpy(x), torch.from_numpy(h0))
+    y, h = O.gru(x, w, r, b, h0)
+    _close(y.reshape(T, H), ty.numpy().reshape(T, H), 1e-5, "gru y")
+    _close(h.ravel(), th.numpy().ravel(), 1e-5, "gru h")
+
+
+# --------------------------------------------------------------------------------------------------- device
+@pytest.mark.gpu
+@pytest.mark.parametrize("kat", CONV_KATS, ids=[k[0] for k in CONV_KATS])
+def test_device_conv2d_reference_cases(ctx, kat):
+    from lele_amd import kernels as K
+    name, n, ic, oc, ih, iw, k, stride, pad, group, xs, ws, bias, relu, tol = kat
+    x, w, b = _kat_tensors(kat)
+    got = K.conv2d_fused(x, w, b, [1, 1], group, [pad] * 4, [stride, stride], relu, ctx=ctx).numpy()
+    want = O.conv2d(x, w, b, [1, 1], group, [pad] * 4, [stride, stride], "relu" if relu else None)
+    _close(got, want, RTOL, name)
+
+
+CONV_SHAPES = [
+    # n, c, h, w, oc, kh, kw, group, pads, strides, dilations, act
+    (1, 3, 64, 64, 16, 3, 3, 1, [1, 1, 1, 1], [2, 2], [1, 1], "silu"),       # yolo stem shape class
+    (2, 32, 40, 40, 64, 3, 3, 1, [1, 1, 1, 1], [1, 1], [1, 1], "silu"),
+    (1, 64, 20, 20, 64, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "relu"),
+    (1, 16, 33, 29, 24, 5, 3, 2, [2, 1, 0, 3], [2, 1], [1, 2], None),         # ragged everything
+    (1, 128, 17, 17, 128, 3, 3, 128, [1, 1, 1, 1], [1, 1], [1, 1], "silu"),   # depthwise + activation
+    (3, 8, 9, 9, 16, 3, 3, 8, [1, 1], [1], [1], "relu"),                       # channel multiplier 2, short attr forms
+    (1, 4, 7, 5, 6, 7, 5, 1, [], [], [], None),                                # kernel == input -> 1x1 output
+    (1, 96, 12, 12, 200, 3, 3, 1, [1, 1, 1, 1], [1, 1], [1, 1], None),         # OC > 128 tile, K = 864
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", CONV_SHAPES, ids=[str(i) for i in range(len(CONV_SHAPES))])
+def test_device_conv2d_vs_oracle(ctx, shape):
+    from lele_amd import kernels as K
+    n, c, h, w_, oc, kh, kw, g, pads, strides, dil, act = shape
+    rng = np.random.default_rng(hash(shape[:8]) & 0xffff)
+    x = rng.standard_normal((n, c, h, w_)).astype(np.float32)
+    w = (rng.standard_normal((oc, c // g, kh, kw)) * 0.2).astype(np.float32)
+    b = rng.standard_normal(oc).astype(np.float32)
+    fn = {"silu": K.conv2d_silu, "relu": lambda *a, **k: K.conv2d_fused(*a, relu=True, **k), None: K.conv2d}[act]
+    got = fn(x, w, b, dil, g, pads, strides, ctx=ctx).numpy()
+    _close(got, O.conv2d(x, w, b, dil, g, pads, strides, act), RTOL, str(shape))
+    got = fn(x, w, None, dil, g, pads, strides, ctx=ctx).numpy()
+    _close(got, O.conv2d(x, w, None, dil, g, pads, strides, act), RTOL, str(shape) + " no bias")
+
+
+@pytest.mark.gpu
+def test_device_conv1d(ctx):
+    from lele_amd import kernels as K
+    y = K.conv1d(np.ones((1, 2, 3), np.float32), np.ones((2, 1, 1), np.float32), None, [1], 2, [0, 0], [1], ctx=ctx)
+    assert y.shape == (1, 2, 3) and np.array_equal(y.numpy().ravel(), np.ones(6))
+    y = K.conv1d(np.arange(10, dtype=np.float32).reshape(1, 1, 10), np.ones((1, 1, 3), np.float32), None, [1], 1, [1, 1],
+                 [1], ctx=ctx).numpy()
+    assert y.shape == (1, 1, 10) and (y[0, 0, 0], y[0, 0, 1], y[0, 0, 5], y[0, 0, 9]) == (1.0, 3.0, 15.0, 17.0)
+    rng = np.random.default_rng(8)
+    cases = [
+        ((1, 1, 4000), (258, 1, 256), 1, [], [128], [], False),      # STFT-as-conv of the VAD model (conv1d.rs:899)
+        ((2, 64, 301), (128, 64, 3), 1, [1, 1], [2], [1], True),
+        ((1, 80, 500), (80, 1, 5), 80, [2, 2], [1], [1], False),     # depthwise 1-D
+        ((1, 16, 77), (32, 4, 7), 4, [9, 3], [3], [2], True),
+        ((3, 200), (4, 1, 9), 1, [4], [1], [1], False),              # rank-2 input, single pad value (right pad 0)
+    ]
+    for xs, ws, g, pads, strides, dil, relu in cases:
+        x = rng.standard_normal(xs).astype(np.float32)
+        w = (rng.standard_normal(ws) * 0.2).astype(np.float32)
+        b = rng.standard_normal(ws[0]).astype(np.float32)
+        got = K.conv1d_fused(x, w, b, dil, g, pads, strides, relu, ctx=ctx).numpy()
+        _close(got, O.conv1d(x, w, b, dil, g, pads, strides, relu), RTOL, str((xs, ws)))
+
+
+@pytest.mark.gpu
+def test_device_conv_transpose(ctx):
+    import lele_amd
+    from lele_amd import kernels as K
+    rng = np.random.default_rng(9)
+    for xs, ws, pads, strides, dil in [((1, 8, 10, 10), (8, 4, 2, 2), [], [2, 2], []),
+                                       ((2, 6, 7, 9), (6, 5, 3, 3), [1, 1, 1, 1], [2, 2], [1, 1]),
+                                       ((1, 3, 5, 6), (3, 7, 4, 3), [1, 0, 2, 1], [3, 2], [2, 1]),
+                                       ((1, 16, 20, 20), (16, 16, 3, 3), [1, 1, 1, 1], [1, 1], [1, 1])]:
+        x = rng.standard_normal(xs).astype(np.float32)
+        w = (rng.standard_normal(ws) * 0.2).astype(np.float32)
+        b = rng.standard_normal(ws[1]).astype(np.float32)
+        got = K.conv_transpose(x, w, b, dil, 1, pads, strides, ctx=ctx).numpy()
+        _close(got, O.conv_transpose(x, w, b, dil, 1, pads, strides), RTOL, str((xs, ws)))
+    with pytest.raises(lele_amd.LeleError, match="group > 1 not supported"):
+        K.conv_transpose(np.zeros((1, 4, 3, 3), np.float32), np.zeros((4, 2, 2, 2), np.float32), None, [], 2, [], [], ctx=ctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kat", GRU_KATS, ids=[k[0] for k in GRU_KATS])
+def test_device_gru_reference_cases(ctx, kat):
+    from lele_amd import kernels as K
+    name, T, I, H, _, _, _, _, lbr, tol = kat
+    x, w, r, b = _gru_tensors(kat)
+    y, h = K.gru(x, w, r, b, None, lbr, ctx=ctx)
+    yo, ho = O.gru(x, w, r, b)
+    assert y.shape == (T, 1, 1, H) and h.shape == (1, 1, H)
+    _close(y.numpy(), yo, RTOL, name + " y")
+    _close(h.numpy(), ho, RTOL, name + " h")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,I,H", [(1, 128, 128), (50, 64, 128), (9, 13, 20), (4, 300, 517), (3, 7, 1)])
+def test_device_lstm_gru_vs_oracle(ctx, T, I, H):
+    import lele_amd
+    from lele_amd import kernels as K
+    rng = np.random.default_rng(T * 1000 + H)
+    x = rng.standard_normal((T, 1, I)).astype(np.float32)
+    sc = np.float32(1.0 / np.sqrt(max(I, H)))
+    h0 = (rng.standard_normal((1, 1, H)) * 0.5).astype(np.float32)
+    c0 = (rng.standard_normal((1, 1, H)) * 0.5).astype(np.float32)
+    w = (rng.standard_normal((1, 4 * H, I)) * sc).astype(np.float32)
+    r = (rng.standard_normal((1, 4 * H, H)) * sc).astype(np.float32)
+    b = (rng.standard_normal((1, 8 * H)) * 0.2).astype(np.float32)
+    for bias, hh, cc in ((b, h0, c0), (None, None, None)):
+        y, h, c = K.lstm(x, w, r, bias, None, hh, cc, ctx=ctx)
+        yo, ho, co = O.lstm(x, w, r, bias, hh, cc)
+        assert y.shape == (T, 1, 1, H) and h.shape == (1, 1, H) and c.shape == (1, 1, H)
+        _close(y.numpy(), yo, RTOL, "lstm y")
+        _close(h.numpy(), ho, RTOL, "lstm h")
+        _close(c.numpy(), co, RTOL, "lstm c")
+    w, r, b = w[:, :3 * H], r[:, :3 * H], b[:, :6 * H]
+    for bias, hh in ((b, h0), (None, None)):
+        y, h = K.gru(x, w, r, bias, hh, False, ctx=ctx)
+        yo, ho = O.gru(x, w, r, bias, hh)
+        _close(y.numpy(), yo, RTOL, "gru y")
+        _close(h.numpy(), ho, RTOL, "gru h")
+    with pytest.raises(lele_amd.LeleError, match="Only batch_size=1 supported"):
+        K.lstm(np.zeros((2, 2, I), np.float32), w_pad(w, 4 * H, I), r_pad(r, 4 * H, H), ctx=ctx)
+
+
+def w_pad(w, g, i):
+    return np.zeros((1, g, i), np.float32)
+
+
+def r_pad(r, g, h):
+    return np.zeros((1, g, h), np.float32)
