@@ -153,11 +153,23 @@ class DevTensor:
         return self.buf.to_numpy(self.shape, self.dtype)
 
 
+class Weight:
+    """A host array that is immutable for the life of the ctx (a weights.bin slice): passed as LELE_MEM_WEIGHT, so
+    the library uploads / pre-packs it once per ctx and caches the device copy by (pointer, bytes)."""
+
+    def __init__(self, arr):
+        a = np.asarray(arr)
+        self.arr = np.ascontiguousarray(a if a.dtype in _NP2DT else a.astype(np.float32))
+        self.shape = self.arr.shape
+
+
 def as_tensor(x, keep, mem=None):
-    """Build a LeleTensor for x (numpy array -> host memory, DevTensor -> device memory).
+    """Build a LeleTensor for x (numpy array -> host memory, DevTensor -> device memory, Weight -> cached weight).
     `keep` collects the objects that must stay alive for the duration of the call."""
     if x is None:
         return None
+    if isinstance(x, Weight):
+        x, mem = x.arr, MEM_WEIGHT
     if isinstance(x, DevTensor):
         shape = (C.c_int64 * max(1, len(x.shape)))(*x.shape)
         keep.append(shape)

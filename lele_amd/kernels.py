@@ -65,17 +65,10 @@ def _mem_weight(x):
     return Weight(x)
 
 
-class Weight:
-    """A host array that is immutable for the life of the ctx (a weights.bin slice)."""
-
-    def __init__(self, arr):
-        self.arr = np.ascontiguousarray(np.asarray(arr, dtype=np.float32) if np.asarray(arr).dtype not in
-                                        (np.float32, np.int64, np.int32, np.uint8, np.int8) else arr)
+Weight = _lib.Weight
 
 
 def _t(x, keep):
-    if isinstance(x, Weight):
-        return _lib.as_tensor(x.arr, keep, _lib.MEM_WEIGHT)
     return _lib.as_tensor(unwrap(x), keep)
 
 
