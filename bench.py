@@ -39,6 +39,28 @@ def synth_batch(batch, n, seed0):
     return out
 
 
+def shard_range(total, rank, world):
+    """static block partition of the global batch; rank r owns utterances [lo, hi)"""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def rank_seed_base(rank, total, world):
+    """utterance i of the global batch is synthesised from seed i, whichever rank owns it"""
+    return shard_range(total, rank, world)[0]
+
+
+def max_over_ranks(wall, dist, device):
+    """the job's time is the slowest rank's time: one MAX all-reduce (the only collective besides the barriers)"""
+    if dist is None:
+        return wall
+    import torch
+    tt = torch.tensor([wall], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
 def cpu_baseline(n, budget_s=12.0):
     """the oracle (kind "port"), 1 thread, on utterances of the same shape until ~budget_s of CPU work"""
     from oracle import pyoracle as O
@@ -87,7 +109,9 @@ def main():
     n = SAMPLE_RATE * SECONDS
     t_lfr, cols, nf = fe.out_rows(n)
     bytes_per_utt = 4 * n + 4 * t_lfr * cols  # PCM read once + LFR written once
-    pcm = ctx.buf().upload(synth_batch(args.batch, n, 1000 * rank))  # resident in HBM before the timed region
+    # weak scaling: the global batch is world * batch utterances; this rank synthesises and keeps its own shard
+    lo, hi = shard_range(world * args.batch, rank, world)
+    pcm = ctx.buf().upload(synth_batch(hi - lo, n, rank_seed_base(rank, world * args.batch, world)))  # resident in HBM
     out = ctx.buf()
 
     def barrier():
@@ -109,11 +133,7 @@ def main():
     wall = time.perf_counter() - t0
     sum_ms, main_ms, runs = fe.profile_read()
     fe.set_profiling(False)
-    if dist is not None:
-        import torch
-        tt = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
+    wall = max_over_ranks(wall, dist, "cuda")
 
     if rank == 0:
         total_bytes = world * args.batch * bytes_per_utt * args.steps

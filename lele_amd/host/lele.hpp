@@ -1,0 +1,669 @@
+// lele.hpp -- header-only C++ mirror of lele's host-side interface over the C ABI of include/lele_hip.h.
+//
+// lele's host code is Rust (`lele::tensor::TensorView`, `lele::kernels::*`, `lele::features::*`); Rust is not
+// available in this image, so this header is the compiled stand-in for the Rust shim of INTEGRATION.md: the same
+// names, the same argument order and meaning, the same "panic on misuse" behaviour (here: lele::Error carrying
+// lele_hip_last_error()), with `Vec<f32>` workspace slots replaced by lele::Buffer (a LeleBuf in HBM).
+//   namespace lele            TensorView (src/tensor.rs:5-71), Ctx, Buffer, Error
+//   namespace lele::kernels   one function per reference kernel (file:line in include/lele_hip.h)
+//   namespace lele::features  FeatureConfig, SenseVoiceFrontend, Cmvn, Lfr (src/features/*.rs)
+// Results stay on the device; TensorView::to_vec<T>() is the lazy D2H (the analogue of `.data` access in Rust).
+#pragma once
+#include "lele_hip.h"
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace lele {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+inline void check(int rc) {
+    if (rc != 0) throw Error(lele_hip_last_error());
+}
+
+// One HIP stream + staging arena + weight cache: the per-thread state of a lele model instance (SURVEY 8b "Threading").
+class Ctx {
+   public:
+    explicit Ctx(int device = 0) { check(lele_hip_ctx_create(device, &h_)); }
+    ~Ctx() {
+        if (h_) lele_hip_ctx_destroy(h_);
+    }
+    Ctx(const Ctx&) = delete;
+    Ctx& operator=(const Ctx&) = delete;
+    LeleCtx* raw() const { return h_; }
+    void sync() const { check(lele_hip_sync(h_)); }
+    static Ctx& current() {  // thread-local default, like lele's thread-local scratch and caches
+        static thread_local Ctx ctx(0);
+        return ctx;
+    }
+
+   private:
+    LeleCtx* h_ = nullptr;
+};
+
+// A workspace slot: the device-side counterpart of `ws.buf_k: Vec<f32>` (compiler/mod.rs:148-290).
+class Buffer {
+   public:
+    explicit Buffer(Ctx& ctx = Ctx::current()) { check(lele_hip_buf_create(ctx.raw(), &h_)); }
+    ~Buffer() {
+        if (h_) lele_hip_buf_destroy(h_);
+    }
+    Buffer(const Buffer&) = delete;
+    Buffer& operator=(const Buffer&) = delete;
+    LeleBuf* raw() const { return h_; }
+    void* data() const { return lele_hip_buf_data(h_); }
+    void upload(const void* src, size_t bytes) { check(lele_hip_buf_from_host(h_, src, bytes)); }
+    void download(void* dst, size_t bytes) const { check(lele_hip_buf_to_host(h_, dst, bytes)); }
+
+   private:
+    LeleBuf* h_ = nullptr;
+};
+
+template <class T>
+struct dtype_of;
+template <>
+struct dtype_of<float> {
+    static constexpr int value = LELE_F32;
+};
+template <>
+struct dtype_of<int64_t> {
+    static constexpr int value = LELE_I64;
+};
+template <>
+struct dtype_of<int32_t> {
+    static constexpr int value = LELE_I32;
+};
+template <>
+struct dtype_of<uint8_t> {
+    static constexpr int value = LELE_U8;
+};
+template <>
+struct dtype_of<int8_t> {
+    static constexpr int value = LELE_I8;
+};
+
+// Borrowed view: host memory (from_slice), an immutable weight (weight -> cached on the device) or a device result.
+class TensorView {
+   public:
+    std::vector<int64_t> shape;
+    TensorView() = default;  // TensorView::empty()
+    template <class T>
+    static TensorView from_slice(const T* data, std::vector<int64_t> shape) {  // tensor.rs:52-61
+        return TensorView(data, std::move(shape), dtype_of<T>::value, LELE_MEM_HOST);
+    }
+    template <class T>
+    static TensorView weight(const T* data, std::vector<int64_t> shape) {  // Model::weight_f32, tensor.rs:131-147
+        return TensorView(data, std::move(shape), dtype_of<T>::value, LELE_MEM_WEIGHT);
+    }
+    static TensorView from_device(const Buffer& buf, std::vector<int64_t> shape, int dtype = LELE_F32) {
+        TensorView t(buf.data(), std::move(shape), dtype, LELE_MEM_DEVICE);
+        t.buf_ = &buf;
+        return t;
+    }
+    int64_t size() const {
+        int64_t n = 1;
+        for (int64_t d : shape) n *= d;
+        return n;
+    }
+    size_t dim() const { return shape.size(); }
+    int dtype() const { return dtype_; }
+    bool is_empty() const { return data_ == nullptr; }
+    TensorView with_shape(std::vector<int64_t> s) const {  // view ops share the data (shape.rs:2-13)
+        TensorView t = *this;
+        t.shape = std::move(s);
+        return t;
+    }
+    LeleTensor c() const { return LeleTensor{data_, shape.data(), (int32_t)shape.size(), dtype_, mem_}; }
+    template <class T>
+    std::vector<T> to_vec() const {  // `.data` in Rust: host copy (D2H for device results)
+        if (dtype_of<T>::value != dtype_) throw Error("TensorView::to_vec: dtype mismatch");
+        std::vector<T> v((size_t)size());
+        if (v.empty()) return v;
+        if (mem_ == LELE_MEM_DEVICE) {
+            if (!buf_) throw Error("TensorView::to_vec: device view without a buffer");
+            buf_->download(v.data(), v.size() * sizeof(T));
+        } else {
+            std::memcpy(v.data(), data_, v.size() * sizeof(T));
+        }
+        return v;
+    }
+
+   private:
+    TensorView(const void* d, std::vector<int64_t> s, int dt, int mem) : shape(std::move(s)), data_(d), dtype_(dt), mem_(mem) {}
+    const void* data_ = nullptr;
+    int dtype_ = LELE_F32;
+    int mem_ = LELE_MEM_HOST;
+    const Buffer* buf_ = nullptr;
+};
+
+namespace detail {
+struct Shape {
+    int64_t dims[8] = {0};
+    int32_t rank = 0;
+    std::vector<int64_t> vec() const { return std::vector<int64_t>(dims, dims + rank); }
+};
+struct Opt {  // Option<&TensorView>
+    LeleTensor t;
+    const LeleTensor* p = nullptr;
+    explicit Opt(const TensorView* v) {
+        if (v) {
+            t = v->c();
+            p = &t;
+        }
+    }
+};
+inline std::vector<int64_t> row_major_strides(const std::vector<int64_t>& shape) {
+    std::vector<int64_t> st(shape.size(), 1);
+    for (int i = (int)shape.size() - 2; i >= 0; --i) st[i] = st[i + 1] * shape[i + 1];
+    return st;
+}
+inline LeleCtx* ctx() { return Ctx::current().raw(); }
+}  // namespace detail
+
+namespace kernels {
+using detail::ctx;
+using detail::Opt;
+using detail::Shape;
+
+#define LELE_RET(out, dt) return TensorView::from_device(out, sh.vec(), dt)
+
+// ---- gemm.rs
+inline TensorView matmul(const TensorView& a, const TensorView& b, Buffer& out) {
+    Shape sh;
+    LeleTensor ta = a.c(), tb = b.c();
+    check(lele_hip_matmul(ctx(), &ta, &tb, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView matmul_fused_add(const TensorView& a, const TensorView& b, const TensorView& bias, Buffer& out) {
+    Shape sh;
+    LeleTensor ta = a.c(), tb = b.c(), tc = bias.c();
+    check(lele_hip_matmul_fused_add(ctx(), &ta, &tb, &tc, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView gemm(const TensorView& a, const TensorView& b, const TensorView* c, float alpha, float beta, bool trans_a,
+                       bool trans_b, Buffer& out) {
+    Shape sh;
+    LeleTensor ta = a.c(), tb = b.c();
+    Opt oc(c);
+    check(lele_hip_gemm(ctx(), &ta, &tb, oc.p, alpha, beta, trans_a, trans_b, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+
+// ---- conv2d.rs / conv1d.rs
+inline TensorView conv2d_activation(const TensorView& x, const TensorView& w, const TensorView* bias,
+                                    const std::vector<int64_t>& dilations, int64_t group, const std::vector<int64_t>& pads,
+                                    const std::vector<int64_t>& strides, int act, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c(), tw = w.c();
+    Opt ob(bias);
+    check(lele_hip_conv2d(ctx(), &tx, &tw, ob.p, dilations.data(), dilations.size(), group, pads.data(), pads.size(),
+                          strides.data(), strides.size(), act, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView conv2d(const TensorView& x, const TensorView& w, const TensorView* bias, const std::vector<int64_t>& dilations,
+                         int64_t group, const std::vector<int64_t>& pads, const std::vector<int64_t>& strides, Buffer& out) {
+    return conv2d_activation(x, w, bias, dilations, group, pads, strides, LELE_ACT_NONE, out);
+}
+inline TensorView conv2d_fused(const TensorView& x, const TensorView& w, const TensorView* bias,
+                               const std::vector<int64_t>& dilations, int64_t group, const std::vector<int64_t>& pads,
+                               const std::vector<int64_t>& strides, bool relu, Buffer& out) {
+    return conv2d_activation(x, w, bias, dilations, group, pads, strides, relu ? LELE_ACT_RELU : LELE_ACT_NONE, out);
+}
+inline TensorView conv2d_silu(const TensorView& x, const TensorView& w, const TensorView* bias,
+                              const std::vector<int64_t>& dilations, int64_t group, const std::vector<int64_t>& pads,
+                              const std::vector<int64_t>& strides, Buffer& out) {
+    return conv2d_activation(x, w, bias, dilations, group, pads, strides, LELE_ACT_SILU, out);
+}
+inline TensorView conv1d_fused(const TensorView& x, const TensorView& w, const TensorView* bias,
+                               const std::vector<int64_t>& dilations, int64_t group, const std::vector<int64_t>& pads,
+                               const std::vector<int64_t>& strides, bool relu, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c(), tw = w.c();
+    Opt ob(bias);
+    check(lele_hip_conv1d(ctx(), &tx, &tw, ob.p, dilations.data(), dilations.size(), group, pads.data(), pads.size(),
+                          strides.data(), strides.size(), relu, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView conv1d(const TensorView& x, const TensorView& w, const TensorView* bias, const std::vector<int64_t>& dilations,
+                         int64_t group, const std::vector<int64_t>& pads, const std::vector<int64_t>& strides, Buffer& out) {
+    return conv1d_fused(x, w, bias, dilations, group, pads, strides, false, out);
+}
+inline TensorView conv_transpose(const TensorView& x, const TensorView& w, const TensorView* bias,
+                                 const std::vector<int64_t>& dilations, int64_t group, const std::vector<int64_t>& pads,
+                                 const std::vector<int64_t>& strides, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c(), tw = w.c();
+    Opt ob(bias);
+    check(lele_hip_conv_transpose(ctx(), &tx, &tw, ob.p, dilations.data(), dilations.size(), group, pads.data(), pads.size(),
+                                  strides.data(), strides.size(), out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+
+// ---- rnn.rs
+struct LstmOut {
+    TensorView y, h, c;
+};
+inline LstmOut lstm(const TensorView& x, const TensorView& w, const TensorView& r, const TensorView* bias,
+                    const TensorView* sequence_lens, const TensorView* initial_h, const TensorView* initial_c, Buffer& out_y,
+                    Buffer& out_h, Buffer& out_c) {
+    Shape sh;
+    LeleTensor tx = x.c(), tw = w.c(), tr = r.c();
+    Opt ob(bias), os(sequence_lens), oh(initial_h), oc(initial_c);
+    check(lele_hip_lstm(ctx(), &tx, &tw, &tr, ob.p, os.p, oh.p, oc.p, out_y.raw(), out_h.raw(), out_c.raw(), sh.dims, &sh.rank));
+    const std::vector<int64_t> ys = sh.vec(), hs = {1, 1, ys.back()};
+    return {TensorView::from_device(out_y, ys), TensorView::from_device(out_h, hs), TensorView::from_device(out_c, hs)};
+}
+struct GruOut {
+    TensorView y, h;
+};
+inline GruOut gru(const TensorView& x, const TensorView& w, const TensorView& r, const TensorView* bias,
+                  const TensorView* initial_h, bool linear_before_reset, Buffer& out_y, Buffer& out_h) {
+    Shape sh;
+    LeleTensor tx = x.c(), tw = w.c(), tr = r.c();
+    Opt ob(bias), oh(initial_h);
+    check(lele_hip_gru(ctx(), &tx, &tw, &tr, ob.p, oh.p, linear_before_reset, out_y.raw(), out_h.raw(), sh.dims, &sh.rank));
+    const std::vector<int64_t> ys = sh.vec();
+    return {TensorView::from_device(out_y, ys), TensorView::from_device(out_h, {1, 1, ys.back()})};
+}
+
+// ---- quantization.rs
+inline TensorView fused_quantized_linear(const TensorView& input, const TensorView& weight_int8, const TensorView& weight_scale,
+                                         const TensorView& weight_zero, const TensorView* bias, bool apply_relu, Buffer& out) {
+    Shape sh;
+    LeleTensor a = input.c(), b = weight_int8.c(), s = weight_scale.c(), z = weight_zero.c();
+    Opt ob(bias);
+    check(lele_hip_fused_quantized_linear(ctx(), &a, &b, &s, &z, ob.p, apply_relu, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+struct DqlOut {
+    TensorView y, scale, zero_point;
+};
+inline DqlOut dynamic_quantize_linear(const TensorView& x, Buffer& out_y, Buffer& out_scale, Buffer& out_zp) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    check(lele_hip_dynamic_quantize_linear(ctx(), &tx, out_y.raw(), out_scale.raw(), out_zp.raw(), sh.dims, &sh.rank));
+    return {TensorView::from_device(out_y, sh.vec()), TensorView::from_device(out_scale, {1}),
+            TensorView::from_device(out_zp, {1})};
+}
+inline TensorView mat_mul_integer_with_scale_bias(const TensorView& a, const TensorView& b, const TensorView* a_zero_point,
+                                                  const TensorView* b_zero_point, const TensorView* scale, const TensorView* bias,
+                                                  bool relu, Buffer& out) {
+    Shape sh;
+    LeleTensor ta = a.c(), tb = b.c();
+    Opt za(a_zero_point), zb(b_zero_point), sc(scale), bi(bias);
+    check(lele_hip_mat_mul_integer_with_scale_bias(ctx(), &ta, &tb, za.p, zb.p, sc.p, bi.p, relu, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView mat_mul_integer(const TensorView& a, const TensorView& b, const TensorView* a_zero_point,
+                                  const TensorView* b_zero_point, Buffer& out) {
+    return mat_mul_integer_with_scale_bias(a, b, a_zero_point, b_zero_point, nullptr, nullptr, false, out);
+}
+
+// ---- math.rs: activations, element-wise, reductions
+inline TensorView unary(int op, const TensorView& x, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    check(lele_hip_unary(ctx(), op, &tx, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+#define LELE_UNARY(name, OP) \
+    inline TensorView name(const TensorView& x, Buffer& out) { return unary(OP, x, out); }
+LELE_UNARY(exp, LELE_U_EXP)
+LELE_UNARY(sigmoid, LELE_U_SIGMOID)
+LELE_UNARY(tanh_kernel, LELE_U_TANH)
+LELE_UNARY(silu, LELE_U_SILU)
+LELE_UNARY(erf, LELE_U_ERF)
+LELE_UNARY(gelu, LELE_U_GELU)
+LELE_UNARY(fast_gelu, LELE_U_FAST_GELU)
+LELE_UNARY(relu, LELE_U_RELU)
+LELE_UNARY(sqrt, LELE_U_SQRT)
+LELE_UNARY(log, LELE_U_LOG)
+LELE_UNARY(sin, LELE_U_SIN)
+LELE_UNARY(cos, LELE_U_COS)
+LELE_UNARY(neg, LELE_U_NEG)
+LELE_UNARY(reciprocal, LELE_U_RECIPROCAL)
+LELE_UNARY(softplus, LELE_U_SOFTPLUS)
+LELE_UNARY(not_, LELE_U_NOT)
+LELE_UNARY(abs, LELE_U_ABS)
+LELE_UNARY(floor, LELE_U_FLOOR)
+LELE_UNARY(ceil, LELE_U_CEIL)
+#undef LELE_UNARY
+inline TensorView binary(int op, const TensorView& a, const TensorView& b, Buffer& out) {
+    Shape sh;
+    LeleTensor ta = a.c(), tb = b.c();
+    check(lele_hip_binary(ctx(), op, &ta, &tb, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, a.dtype() == LELE_I64 ? LELE_I64 : LELE_F32);
+}
+#define LELE_BINARY(name, OP) \
+    inline TensorView name(const TensorView& a, const TensorView& b, Buffer& out) { return binary(OP, a, b, out); }
+LELE_BINARY(add, LELE_B_ADD)
+LELE_BINARY(sub, LELE_B_SUB)
+LELE_BINARY(mul, LELE_B_MUL)
+LELE_BINARY(div, LELE_B_DIV)
+LELE_BINARY(pow, LELE_B_POW)
+LELE_BINARY(max, LELE_B_MAX)
+LELE_BINARY(min, LELE_B_MIN)
+LELE_BINARY(equal, LELE_B_EQUAL)
+LELE_BINARY(less, LELE_B_LESS)
+LELE_BINARY(greater, LELE_B_GREATER)
+LELE_BINARY(prelu, LELE_B_PRELU)
+LELE_BINARY(and_, LELE_B_AND)
+LELE_BINARY(or_, LELE_B_OR)
+#undef LELE_BINARY
+inline TensorView where_op(const TensorView& cond, const TensorView& x, const TensorView& y, Buffer& out) {
+    Shape sh;
+    LeleTensor tc = cond.c(), tx = x.c(), ty = y.c();
+    check(lele_hip_where(ctx(), &tc, &tx, &ty, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView clip(const TensorView& x, const float* min_v, const float* max_v, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    check(lele_hip_clip(ctx(), &tx, min_v != nullptr, min_v ? *min_v : 0.0f, max_v != nullptr, max_v ? *max_v : 0.0f, out.raw(),
+                        sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView reduce(int op, const TensorView& x, const std::vector<int64_t>& axes, bool keepdims, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    check(lele_hip_reduce(ctx(), op, &tx, axes.data(), axes.size(), keepdims, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView reduce_sum(const TensorView& x, const std::vector<int64_t>& axes, bool keepdims, Buffer& out) {
+    return reduce(LELE_R_SUM, x, axes, keepdims, out);
+}
+inline TensorView reduce_mean(const TensorView& x, const std::vector<int64_t>& axes, bool keepdims, Buffer& out) {
+    return reduce(LELE_R_MEAN, x, axes, keepdims, out);
+}
+inline TensorView reduce_max(const TensorView& x, const std::vector<int64_t>& axes, bool keepdims, Buffer& out) {
+    return reduce(LELE_R_MAX, x, axes, keepdims, out);
+}
+inline TensorView reduce_l2(const TensorView& x, const std::vector<int64_t>& axes, bool keepdims, Buffer& out) {
+    return reduce(LELE_R_L2, x, axes, keepdims, out);
+}
+
+// ---- norm.rs
+inline TensorView layer_norm(const TensorView& x, const TensorView& scale, const TensorView& bias, int64_t axis, float epsilon,
+                             Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c(), ts = scale.c(), tb = bias.c();
+    check(lele_hip_layer_norm(ctx(), &tx, &ts, &tb, (int32_t)axis, epsilon, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView rms_norm(const TensorView& x, const TensorView& weight, int64_t axis, float epsilon, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c(), tw = weight.c();
+    check(lele_hip_rms_norm(ctx(), &tx, &tw, (int32_t)axis, epsilon, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView softmax(const TensorView& x, int64_t axis, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    check(lele_hip_softmax(ctx(), &tx, (int32_t)axis, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView batch_norm(const TensorView& x, const TensorView& scale, const TensorView& bias, const TensorView& mean,
+                             const TensorView& var, float epsilon, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c(), ts = scale.c(), tb = bias.c(), tm = mean.c(), tv = var.c();
+    check(lele_hip_batch_norm(ctx(), &tx, &ts, &tb, &tm, &tv, epsilon, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+
+// ---- manipulation.rs / shape.rs / conv2d.rs:1051-1502: data movement
+inline TensorView strided(const TensorView& x, const std::vector<int64_t>& oshape, const std::vector<int64_t>& strides,
+                          int64_t offset, const std::vector<int64_t>* mods, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    check(lele_hip_strided_copy(ctx(), &tx, oshape.data(), strides.data(), mods ? mods->data() : nullptr, (int32_t)oshape.size(),
+                                offset, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, x.dtype());
+}
+inline TensorView transpose(const TensorView& x, std::vector<int64_t> perm, Buffer& out) {  // manipulation.rs:644
+    const int64_t nd = (int64_t)x.dim();
+    if (perm.empty())
+        for (int64_t i = nd - 1; i >= 0; --i) perm.push_back(i);
+    const auto istr = detail::row_major_strides(x.shape);
+    std::vector<int64_t> osh, ost;
+    for (int64_t p : perm) {
+        if (p < 0) p += nd;
+        osh.push_back(x.shape[(size_t)p]);
+        ost.push_back(istr[(size_t)p]);
+    }
+    return strided(x, osh, ost, 0, nullptr, out);
+}
+inline TensorView slice(const TensorView& x, const std::vector<int64_t>& starts, const std::vector<int64_t>& ends,
+                        const std::vector<int64_t>& axes, const std::vector<int64_t>& steps, Buffer& out) {  // :209-380
+    const int64_t nd = (int64_t)x.dim();
+    std::vector<int64_t> a_start((size_t)nd, 0), a_end = x.shape, a_step((size_t)nd, 1);
+    for (size_t i = 0; i < starts.size(); ++i) {
+        int64_t ax = axes.empty() ? (int64_t)i : (axes[i] < 0 ? axes[i] + nd : axes[i]);
+        const int64_t dim = x.shape[(size_t)ax], step = i < steps.size() ? steps[i] : 1;
+        const int64_t s64 = starts[i], e64 = ends[i];
+        const bool e_max = e64 > INT64_MAX / 2, e_min = e64 < INT64_MIN / 2;
+        const int64_t start = s64 > dim ? dim : (s64 < -dim ? -dim : s64);
+        const int64_t end = e_max ? dim : (e_min ? -dim : (e64 > dim ? dim : (e64 < -dim ? -dim : e64)));
+        const int64_t ns = start < 0 ? start + dim : start;
+        const int64_t ne = e_max ? (step > 0 ? dim : -1) : e_min ? (step > 0 ? 0 : -1) : (end < 0 ? end + dim : end);
+        if (step > 0) {
+            a_start[(size_t)ax] = std::min(std::max<int64_t>(ns, 0), dim);
+            a_end[(size_t)ax] = std::min(std::max<int64_t>(ne, 0), dim);
+        } else {
+            a_start[(size_t)ax] = std::min(std::max<int64_t>(ns, 0), dim - 1);
+            a_end[(size_t)ax] = std::min(std::max<int64_t>(ne, -1), dim - 1);
+        }
+        a_step[(size_t)ax] = step;
+    }
+    const auto istr = detail::row_major_strides(x.shape);
+    std::vector<int64_t> osh, ost;
+    int64_t off = 0;
+    for (size_t d = 0; d < (size_t)nd; ++d) {
+        const int64_t s = a_start[d], e = a_end[d], st = a_step[d];
+        osh.push_back(st > 0 ? std::max<int64_t>(0, (e - s + st - 1) / st) : std::max<int64_t>(0, (s - e + (-st) - 1) / (-st)));
+        ost.push_back(istr[d] * st);
+        off += s * istr[d];
+    }
+    return strided(x, osh, ost, off, nullptr, out);
+}
+inline TensorView expand(const TensorView& x, const std::vector<int64_t>& shape, Buffer& out) {  // math.rs:2168
+    const size_t nd = std::max(x.dim(), shape.size());
+    const auto istr = detail::row_major_strides(x.shape);
+    std::vector<int64_t> osh, ost;
+    for (size_t i = 0; i < nd; ++i) {
+        const int64_t oi = (int64_t)i - (int64_t)(nd - x.dim()), ot = (int64_t)i - (int64_t)(nd - shape.size());
+        const int64_t din = oi >= 0 ? x.shape[(size_t)oi] : 1;
+        const int64_t dt = ot >= 0 ? (shape[(size_t)ot] ? shape[(size_t)ot] : din) : 1;
+        if (din == dt || dt == 1)
+            osh.push_back(din);
+        else if (din == 1)
+            osh.push_back(dt);
+        else
+            throw Error("Expand: incompatible shapes");
+        ost.push_back((oi >= 0 && din != 1) ? istr[(size_t)oi] : 0);
+    }
+    return strided(x, osh, ost, 0, nullptr, out);
+}
+inline TensorView tile(const TensorView& x, const std::vector<int64_t>& repeats, Buffer& out) {  // math.rs:2249
+    if (repeats.size() != x.dim()) throw Error("Tile: repeats length must match input rank");
+    std::vector<int64_t> osh;
+    for (size_t i = 0; i < x.dim(); ++i) osh.push_back(x.shape[i] * repeats[i]);
+    return strided(x, osh, detail::row_major_strides(x.shape), 0, &x.shape, out);
+}
+inline std::vector<TensorView> split(const TensorView& x, int64_t axis, const std::vector<int64_t>& splits,
+                                     std::vector<Buffer*>& outputs) {  // manipulation.rs:1091
+    const int64_t nd = (int64_t)x.dim(), ax = axis < 0 ? axis + nd : axis;
+    if (ax < 0 || ax >= nd) throw Error("Split: axis out of bounds");
+    int64_t total = 0;
+    for (int64_t s : splits) total += s;
+    if (total != x.shape[(size_t)ax]) throw Error("Split: splits sum mismatch");
+    const auto istr = detail::row_major_strides(x.shape);
+    std::vector<TensorView> res;
+    int64_t pos = 0;
+    for (size_t i = 0; i < splits.size(); ++i) {
+        std::vector<int64_t> osh = x.shape;
+        osh[(size_t)ax] = splits[i];
+        res.push_back(strided(x, osh, istr, pos * istr[(size_t)ax], nullptr, *outputs[i]));
+        pos += splits[i];
+    }
+    return res;
+}
+inline TensorView concat(const std::vector<const TensorView*>& inputs, int64_t axis, Buffer& out) {  // manipulation.rs:108
+    Shape sh;
+    std::vector<LeleTensor> ts;
+    for (const TensorView* t : inputs) ts.push_back(t->c());
+    std::vector<const LeleTensor*> ps;
+    for (const LeleTensor& t : ts) ps.push_back(&t);
+    check(lele_hip_concat(ctx(), ps.data(), ps.size(), axis, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, inputs.empty() ? LELE_F32 : inputs[0]->dtype());
+}
+inline TensorView gather(const TensorView& data, const TensorView& indices, int64_t axis, Buffer& out) {
+    Shape sh;
+    LeleTensor td = data.c(), ti = indices.c();
+    check(lele_hip_gather(ctx(), &td, &ti, axis, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, data.dtype());
+}
+inline TensorView gather_elements(const TensorView& x, const TensorView& indices, int64_t axis, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c(), ti = indices.c();
+    check(lele_hip_gather_elements(ctx(), &tx, &ti, axis, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView max_pool2d(const TensorView& x, const std::vector<int64_t>& kernel_shape, const std::vector<int64_t>& strides,
+                             const std::vector<int64_t>& pads, const std::vector<int64_t>& dilations, bool ceil_mode, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    check(lele_hip_max_pool2d(ctx(), &tx, kernel_shape.data(), kernel_shape.size(), strides.data(), strides.size(), pads.data(),
+                              pads.size(), dilations.data(), dilations.size(), ceil_mode, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView resize_nearest(const TensorView& x, int64_t out_h, int64_t out_w, bool asymmetric, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    check(lele_hip_resize_nearest(ctx(), &tx, out_h, out_w, asymmetric, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+struct TopkOut {
+    TensorView values, indices;
+};
+inline TopkOut topk(const TensorView& x, int64_t k, bool largest, Buffer& out_values, Buffer& out_indices) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    check(lele_hip_topk(ctx(), &tx, k, largest, out_values.raw(), out_indices.raw(), sh.dims, &sh.rank));
+    return {TensorView::from_device(out_values, sh.vec()), TensorView::from_device(out_indices, sh.vec())};
+}
+inline TensorView cast_to_f32(const TensorView& x, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    check(lele_hip_cast(ctx(), &tx, LELE_F32, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView cast_to_i64(const TensorView& x, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    check(lele_hip_cast(ctx(), &tx, LELE_I64, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_I64);
+}
+// view operators: shape bookkeeping only (shape.rs:2-52, 105-185)
+inline TensorView reshape(const TensorView& x, const std::vector<int64_t>& target) {
+    const int64_t total = x.size();
+    std::vector<int64_t> s;
+    int64_t known = 1;
+    int infer = -1;
+    for (size_t i = 0; i < target.size(); ++i) {
+        int64_t d = target[i];
+        if (d == 0 && i < x.dim()) d = x.shape[i];  // 0 copies the input dimension
+        if (d == -1) {
+            infer = (int)i;
+            d = 1;
+        } else {
+            known *= d;
+        }
+        s.push_back(d);
+    }
+    if (infer >= 0) s[(size_t)infer] = known ? total / known : 0;
+    int64_t n = 1;
+    for (int64_t d : s) n *= d;
+    if (n != total) throw Error("Reshape: element count mismatch");
+    return x.with_shape(s);
+}
+inline TensorView flatten(const TensorView& x, int64_t axis) {
+    const int64_t nd = (int64_t)x.dim(), ax = axis < 0 ? axis + nd : axis;
+    int64_t a = 1, b = 1;
+    for (int64_t i = 0; i < nd; ++i) (i < ax ? a : b) *= x.shape[(size_t)i];
+    return x.with_shape({a, b});
+}
+inline TensorView identity(const TensorView& x) { return x; }
+
+#undef LELE_RET
+}  // namespace kernels
+
+namespace features {
+using detail::Shape;
+
+struct FeatureConfig {  // src/features/pipeline.rs:8-36 (Default)
+    int64_t sample_rate = 16000;
+    int64_t n_mels = 80;
+    float frame_length_ms = 25.0f;
+    float frame_shift_ms = 10.0f;
+    int64_t lfr_m = 7;
+    int64_t lfr_n = 6;
+};
+
+class SenseVoiceFrontend {  // pipeline.rs:29-193
+   public:
+    explicit SenseVoiceFrontend(const FeatureConfig& cfg = FeatureConfig(), Ctx& ctx = Ctx::current()) {
+        LeleFeatureConfig c{cfg.sample_rate, cfg.n_mels, cfg.frame_length_ms, cfg.frame_shift_ms, cfg.lfr_m, cfg.lfr_n};
+        check(lele_hip_frontend_create(ctx.raw(), &c, &h_));
+    }
+    ~SenseVoiceFrontend() {
+        if (h_) lele_hip_frontend_destroy(h_);
+    }
+    SenseVoiceFrontend(const SenseVoiceFrontend&) = delete;
+    SenseVoiceFrontend& operator=(const SenseVoiceFrontend&) = delete;
+    // pcm: f32 [len] -> [T, n_mels*lfr_m]; an empty TensorView when len < frame length (pipeline.rs:70-73)
+    TensorView compute(const TensorView& pcm, Buffer& out) const {
+        Shape sh;
+        LeleTensor t = pcm.c();
+        check(lele_hip_frontend_compute(h_, &t, out.raw(), sh.dims, &sh.rank));
+        if (sh.rank == 0 || sh.dims[0] == 0) return TensorView();
+        return TensorView::from_device(out, sh.vec());
+    }
+    TensorView compute_batch(const TensorView& pcm, Buffer& out) const {
+        Shape sh;
+        LeleTensor t = pcm.c();
+        check(lele_hip_frontend_compute_batch(h_, &t, out.raw(), sh.dims, &sh.rank));
+        return TensorView::from_device(out, sh.vec());
+    }
+
+   private:
+    LeleFrontend* h_ = nullptr;
+};
+
+struct Cmvn {  // cmvn.rs
+    float eps = 1e-5f;
+    TensorView compute(const TensorView& x, Buffer& out) const {
+        Shape sh;
+        LeleTensor t = x.c();
+        check(lele_hip_cmvn(detail::ctx(), &t, eps, out.raw(), sh.dims, &sh.rank));
+        return TensorView::from_device(out, sh.vec());
+    }
+};
+struct Lfr {  // lfr.rs
+    int64_t m = 7, n = 6;
+    TensorView compute(const TensorView& x, Buffer& out) const {
+        Shape sh;
+        LeleTensor t = x.c();
+        check(lele_hip_lfr(detail::ctx(), &t, m, n, out.raw(), sh.dims, &sh.rank));
+        return TensorView::from_device(out, sh.vec());
+    }
+};
+}  // namespace features
+
+}  // namespace lele
