@@ -1,6 +1,6 @@
 // host_demo.cpp -- exercises lele_amd/host/lele.hpp (the C++ mirror of lele's Rust host interface) end to end.
 //   host_demo probe                      : no GPU needed; checks that creating a context without a device fails loudly
-//   host_demo run <pcm.f32> <out.f32>    : SenseVoiceFrontend -> Cmvn on the PCM file, writes [T,560] f32; also runs
+//   host_demo run <pcm.f32> <out.f32> [<feats.f32>] : SenseVoiceFrontend -> Cmvn on the PCM file, writes [T,560] f32; also runs
 //                                          the reference's matmul / layer_norm / transpose known-answer cases
 // Driven by tests/test_host_cpp.py, which compares the output file with the oracle.
 #include "lele.hpp"
@@ -75,6 +75,11 @@ int main(int argc, char** argv) {
         Buffer feats, normed;
         TensorView f = fe.compute(TensorView::from_slice(pcm.data(), {(int64_t)pcm.size()}), feats);
         if (f.is_empty()) return fail("front-end returned an empty tensor");
+        if (argc > 4) {  // the intermediate [T,560] features, so the test can check each stage against the oracle
+            const std::vector<float> fv = f.to_vec<float>();
+            std::ofstream ff(argv[4], std::ios::binary);
+            ff.write(reinterpret_cast<const char*>(fv.data()), (std::streamsize)(fv.size() * 4));
+        }
         TensorView n = lele::features::Cmvn().compute(f, normed);
         const std::vector<float> out = n.to_vec<float>();
         std::ofstream of(argv[3], std::ios::binary);

@@ -35,11 +35,14 @@ def test_host_cpp_builds_and_fails_loudly_without_device():
 def test_host_cpp_frontend_cmvn_matches_oracle(tmp_path, orc):
     exe = _build()
     pcm = synth_pcm(16000 * 3, seed=4)
-    pin, pout = tmp_path / "pcm.f32", tmp_path / "out.f32"
+    pin, pout, pfeat = tmp_path / "pcm.f32", tmp_path / "out.f32", tmp_path / "feats.f32"
     pcm.astype(np.float32).tofile(pin)
-    r = subprocess.run([exe, "run", str(pin), str(pout)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, "run", str(pin), str(pout), str(pfeat)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
-    want = orc.cmvn(orc.frontend_compute(pcm))
+    want = orc.frontend_compute(pcm)
+    feats = np.fromfile(pfeat, np.float32).reshape(want.shape)
+    # front-end: bit-exact up to the mel sums, ln within 2 ulp -> 1e-6 relative (the contract bar is 1e-4)
+    np.testing.assert_allclose(feats, want, rtol=1e-6, atol=2e-6)
+    # CMVN is bit-exact on identical input (sequential per-dim sums as cmvn.rs:14-66)
     got = np.fromfile(pout, np.float32).reshape(want.shape)
-    # front-end is bit-exact up to ln (<= 2 ulp); CMVN divides by the per-dim std: 1e-4 relative bar, written here
-    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    assert np.array_equal(got, orc.cmvn(feats))
