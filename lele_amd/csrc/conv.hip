@@ -89,11 +89,14 @@ struct ConvEpi {
     const float* bias;
     ConvGeom g;
     int act;
-    __device__ __forceinline__ void operator()(int b, int row, int col, float acc) const {
+    __device__ __forceinline__ float load(int b, int row, int col) const {  // clamped coordinates, unconditional
+        return bias ? bias[(b % g.group) * g.ocg + row] : 0.0f;
+    }
+    __device__ __forceinline__ void store(int b, int row, int col, float acc, float pre) const {
         if (row >= g.ocg || col >= g.plane) return;
         const int img = b / g.group, o = (b % g.group) * g.ocg + row;
         float v = acc;
-        if (bias) v = v + bias[o];
+        if (bias) v = v + pre;
         out[((int64_t)img * g.oc + o) * g.plane + col] = apply_act(v, act, col < (g.plane & ~7));
     }
 };

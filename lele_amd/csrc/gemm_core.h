@@ -66,6 +66,11 @@ struct LoadKRow {
 // ---------------------------------------------------------------------------------------------- epilogues
 enum CMode { C_NONE = 0, C_FULL = 1, C_ROWVEC = 2 /* [N] */, C_COLVEC = 3 /* [M] */, C_SCALAR = 4, C_MODULO = 5 };
 
+// Epilogue protocol: `load(b, row, col)` fetches whatever the element needs from memory (C, bias ...) and is called
+// with CLAMPED in-range coordinates, unconditionally, for all 16 accumulators of an MFMA tile before any of them is
+// stored -- so the loads are issued back to back.  (A load behind a per-lane bounds branch compiles to a serialised
+// branch + s_waitcnt per element: 64 dependent round trips per thread.)  `store(b, row, col, acc, pre)` does the
+// bounds check and the arithmetic.
 // out[b][row][col] = alpha*acc + beta*C[...]  (matmul, matmul_fused_add, gemm)
 struct EpiAffine {
     float* out;
@@ -75,18 +80,21 @@ struct EpiAffine {
     const float* c;
     int cmode;
     int64_t clen;
-    __device__ __forceinline__ void operator()(int b, int row, int col, float acc) const {
-        if (row >= M || col >= N) return;
-        float pre = 0.0f;
+    __device__ __forceinline__ float load(int b, int row, int col) const {
+        if (cmode == C_NONE) return 0.0f;  // uniform branch (kernel argument)
+        int64_t idx;
         switch (cmode) {
-            case C_FULL: pre = c[(int64_t)row * N + col] * beta; break;
-            case C_ROWVEC: pre = c[col] * beta; break;
-            case C_COLVEC: pre = c[row] * beta; break;
-            case C_SCALAR: pre = c[0] * beta; break;
-            case C_MODULO: pre = c[((int64_t)b * bs + (int64_t)row * N + col) % clen] * beta; break;
-            default: break;
+            case C_FULL: idx = (int64_t)row * N + col; break;
+            case C_ROWVEC: idx = col; break;
+            case C_COLVEC: idx = row; break;
+            case C_SCALAR: idx = 0; break;
+            default: idx = ((int64_t)b * bs + (int64_t)row * N + col) % clen; break;
         }
-        out[(int64_t)b * bs + (int64_t)row * N + col] = __builtin_fmaf(alpha, acc, pre);
+        return c[idx];
+    }
+    __device__ __forceinline__ void store(int b, int row, int col, float acc, float pre) const {
+        if (row >= M || col >= N) return;
+        out[(int64_t)b * bs + (int64_t)row * N + col] = __builtin_fmaf(alpha, acc, cmode == C_NONE ? 0.0f : pre * beta);
     }
 };
 
@@ -187,13 +195,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(AL al, BL bl
 #pragma unroll
     for (int i = 0; i < TMT; ++i)
 #pragma unroll
-        for (int j = 0; j < TNT; ++j)
+        for (int j = 0; j < TNT; ++j) {
+            const int col = n0 + wn * TNT * 32 + j * 32 + l31;
+            const int colc = col < N ? col : N - 1;
+            const int rbase = m0 + wm * TMT * 32 + i * 32 + 4 * hv;
+            float pre[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * TMT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv;
-                const int col = n0 + wn * TNT * 32 + j * 32 + l31;
-                epi(batch, row, col, acc[i][j][r]);
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                pre[r] = epi.load(batch, row < M ? row : M - 1, colc);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) epi.store(batch, rbase + (r & 3) + 8 * (r >> 2), col, acc[i][j][r], pre[r]);
+        }
 }
 
 // Launch with a tile chosen from the problem size: big tiles when they still fill 256 CUs, else 64x64 / 32x128.

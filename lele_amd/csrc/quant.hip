@@ -21,6 +21,8 @@
 
 #include <math.h>
 
+#include <algorithm>
+
 using namespace lele;
 
 namespace {
@@ -38,11 +40,24 @@ __global__ __launch_bounds__(256) void qminmax_kernel(const float* __restrict__ 
                                                       float* __restrict__ partial /*[slices][blocks][2]*/) {
     const float* p = x + (int64_t)blockIdx.y * slice_len;
     float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < slice_len; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = p[i];
+    auto upd = [&](float v) {
         mn = v < mn ? v : mn;
         mx = v > mx ? v : mx;
+    };
+    // scalar head up to the first 16-byte boundary, float4 body, scalar tail (min/max are order-independent: exact)
+    const int64_t head = std::min<int64_t>(slice_len, (int64_t)((4 - (((uintptr_t)p >> 2) & 3)) & 3));
+    const int64_t nvec = (slice_len - head) / 4;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = (int64_t)gridDim.x * blockDim.x;
+    if (gtid < head) upd(p[gtid]);
+    const float4* pv = reinterpret_cast<const float4*>(p + head);
+    for (int64_t i = gtid; i < nvec; i += gstride) {
+        const float4 v = pv[i];
+        upd(v.x);
+        upd(v.y);
+        upd(v.z);
+        upd(v.w);
     }
+    for (int64_t i = head + nvec * 4 + gtid; i < slice_len; i += gstride) upd(p[i]);
     for (int off = 32; off > 0; off >>= 1) {
         const float a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
         mn = a < mn ? a : mn;
@@ -192,26 +207,45 @@ struct IgemmEpi {
     int wscale_len;
     const float* bias;  // may be NULL
     int relu;
-    __device__ __forceinline__ void operator()(int64_t row, int col, int acc) const {
-        if (row >= rows || col >= n) return;
+    // Everything that depends only on the row (slice parameters, row-sum term, output row pointer) or only on the
+    // column (column sum, weight scale, bias) is computed once per row / column of a thread's tile, not per element.
+    struct RowCtx {
+        int ca, rterm;
+        float dyn_scale;
+        float* orow;
+    };
+    struct ColCtx {
+        int colsum;
+        float ws, bias;
+    };
+    __device__ __forceinline__ RowCtx row_ctx(int64_t row) const {
         int zp_a = zp_a_fixed;
-        float dyn_scale = 1.0f;
+        float ds = 1.0f;
         if (prm) {
-            const QParams q = prm[row / m];
+            const QParams q = prm[rows == m ? 0u : (unsigned)row / (unsigned)m];
             zp_a = q.zp_i;
-            dyn_scale = q.scale;
+            ds = q.scale;
         }
         // sum (q - zp_a)(w - zp_b) with q = q'+128, w = w'+128  (exact in i32, as the reference's wrapping algebra)
         const int ca = 128 - zp_a, cb = 128 - zp_b;
-        const int total = acc + cb * row_sums[row] + ca * col_sums[col] + k * ca * cb;
+        return RowCtx{ca, cb * row_sums[row] + k * ca * cb, ds, out + row * n};
+    }
+    __device__ __forceinline__ ColCtx col_ctx(int col) const {
+        ColCtx c{0, 1.0f, 0.0f};
+        col = col < n ? col : (int)n - 1;  // clamped: loads stay unconditional, out-of-range columns are never stored
+        c.colsum = col_sums[col];
+        if (wscale) c.ws = wscale_len <= 1 ? wscale[0] : wscale[col];
+        if (bias) c.bias = bias[col];
+        return c;
+    }
+    __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, int col, int acc) const {
+        const int total = acc + r.rterm + r.ca * c.colsum;
         float vf = (float)total;  // _mm256_cvtepi32_ps
-        if (wscale) {
-            const float ws = wscale_len <= 1 ? wscale[0] : wscale[col];
-            vf = vf * (prm ? dyn_scale * ws : ws);  // combined_scale[j] = dyn_scale * weight_scale[j], then mul
-        }
-        if (bias) vf = vf + bias[col];
+        // combined_scale[j] = dyn_scale * weight_scale[j], then one mul (dyn_scale is 1.0 when there is no dynamic range)
+        if (wscale) vf = vf * (r.dyn_scale * c.ws);
+        if (bias) vf = vf + c.bias;
         if (relu) vf = vf > 0.0f ? vf : 0.0f;
-        out[row * n + col] = vf;
+        r.orow[col] = vf;
     }
 };
 
@@ -225,9 +259,20 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const int8_t* __rest
     constexpr int ASLOTS = (BM * 4 + NT - 1) / NT, BSLOTS = (BN * 4 + NT - 1) / NT;  // 16-B chunks per thread
     __shared__ __attribute__((aligned(16))) char As[2][BM * PITCH];
     __shared__ __attribute__((aligned(16))) char Bs[2][BN * PITCH];
+    __shared__ int s_ca[BM], s_rterm[BM];
+    __shared__ float s_ds[BM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int64_t m0 = (int64_t)blockIdx.y * BM;
+    // per-row epilogue terms: fetched once per block up front (clamped, unconditional -- their latency hides behind
+    // the K loop) instead of per element behind a bounds branch, which serialises one global load per row
+    for (int t = tid; t < BM; t += NT) {
+        const int64_t r = m0 + t < rows ? m0 + t : rows - 1;
+        const IgemmEpi::RowCtx rc = epi.row_ctx(r);
+        s_ca[t] = rc.ca;
+        s_rterm[t] = rc.rterm;
+        s_ds[t] = rc.dyn_scale;
+    }
     const int n0 = blockIdx.x * BN;
     const int hv = lane >> 5, l31 = lane & 31;
     // un-batched weights: b_batch_stride == 0; batched B (mat_mul_integer with batch_b > 1): slice = row block / m
@@ -305,16 +350,25 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const int8_t* __rest
         if (kt + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
     }
+    IgemmEpi::ColCtx cc[TNT];
+    int cols[TNT];
+#pragma unroll
+    for (int j = 0; j < TNT; ++j) {
+        cols[j] = n0 + wn * TNT * 32 + j * 32 + l31;
+        cc[j] = epi.col_ctx(cols[j]);
+    }
 #pragma unroll
     for (int i = 0; i < TMT; ++i)
 #pragma unroll
-        for (int j = 0; j < TNT; ++j)
+        for (int r = 0; r < 16; ++r) {
+            const int lr = wm * TMT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv;
+            const int64_t row = m0 + lr;
+            if (row >= rows) continue;
+            const IgemmEpi::RowCtx rc{s_ca[lr], s_rterm[lr], s_ds[lr], epi.out + row * epi.n};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * TMT * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv;
-                const int col = n0 + wn * TNT * 32 + j * 32 + l31;
-                epi(row, col, acc[i][j][r]);
-            }
+            for (int j = 0; j < TNT; ++j)
+                if (cols[j] < n) epi.store(rc, cc[j], cols[j], acc[i][j][r]);
+        }
 }
 
 // ------------------------------------------------------------------------------------------ host helpers
@@ -357,7 +411,9 @@ int get_packed_weights(LeleCtx* ctx, const LeleTensor* w, const float* dw, int64
 
 int launch_range(LeleCtx* ctx, const float* dx, int64_t slices, int64_t slice_len, QParams* prm, float* scale_out,
                  float* zp_out) {
-    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(256, (slice_len + 4095) / 4096));
+    // enough blocks to fill 256 CUs x 4 even for one slice; every thread then streams >= 4 float4
+    const int64_t want = (slice_len + 4095) / 4096;
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, 1024 / slices), want));
     void* partial = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)slices * nblk * 8, &partial));
     hipLaunchKernelGGL(qminmax_kernel, dim3(nblk, (unsigned)slices), dim3(256), 0, ctx->stream, dx, slice_len,
@@ -371,6 +427,7 @@ int launch_range(LeleCtx* ctx, const float* dx, int64_t slices, int64_t slice_le
 int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows, int n, int kp, int64_t b_stride,
                  int m_per_batch, const IgemmEpi& epi) {
     if (rows == 0 || n == 0) return 0;
+    LELE_REQUIRE(rows < (int64_t(1) << 31), "quantized GEMM: more than 2^31 rows");
     const int64_t b128 = ((rows + 127) / 128) * ((n + 127) / 128);
     // batched B needs every block to stay inside one batch slice: tiles never straddle slices when BM divides m,
     // otherwise fall back to one launch per slice (handled by the caller passing rows == m)
