@@ -5,10 +5,10 @@
 // the operands are supplied by LOADER functors (row-major, column-major, implicit im2col ...) and the result is
 // consumed by an EPILOGUE functor (plain store, alpha/beta*C, bias + ReLU/SiLU into NCHW ...).
 //
-// Tiling: block tile BM x BN, K step 16, WM x WN waves, each wave owns (BM/WM) x (BN/WN) as 32x32 MFMA tiles.
-// Both operand tiles live in LDS as [row][16 k + 4 pad] (pitch 20 floats = 80 B, so the two ds_read_b128 a lane
+// Tiling: block tile BM x BN, K step BK (16 or 32), WM x WN waves, each wave owns (BM/WM) x (BN/WN) as 32x32 MFMA tiles.
+// Both operand tiles live in LDS as [row][BK k + 4 pad] (pitch 20 / 36 floats, so the two ds_read_b128 a lane
 // issues per 32-row tile are 16-B aligned and a 16-lane group touches 16 distinct 16-B slots: 5*row mod 16).
-// Lane l feeds MFMA step s (0..7) with k = 8*(l>>5) + s of the current K tile for BOTH operands, i.e. the
+// Lane l feeds MFMA step s (0..7) of sub-step u with k = 16*u + 8*(l>>5) + s of the K tile for BOTH operands, i.e. the
 // K index is permuted identically on A and B -- a reordering of the exact f32 sum, nothing else.
 // Global -> register -> LDS with the next tile's loads in flight during the MFMAs (double-buffered LDS,
 // one __syncthreads per K tile).
@@ -18,8 +18,8 @@
 
 namespace gemm {
 
-constexpr int BK = 16;
-constexpr int PITCH = 20;
+// K depth of one LDS tile is a template parameter (16 or 32 floats); rows are padded by 4 floats (pitch 20 / 36), both
+// of which keep 16-B alignment and give the 16 lanes of a ds_read_b128 group 16 distinct 16-B bank slots.
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -99,13 +99,16 @@ struct EpiAffine {
 };
 
 // ---------------------------------------------------------------------------------------------- kernel
-template <int BM, int BN, int WM, int WN, class AL, class BL, class EPI>
+template <int BM, int BN, int WM, int WN, int BK, class AL, class BL, class EPI>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(AL al, BL bl, EPI epi, int M, int N, int K) {
     constexpr int NT = WM * WN * 64;
+    constexpr int PITCH = BK + 4;
+    constexpr int KQ = BK / 4;                              // float4 chunks per tile row
     constexpr int TMT = BM / WM / 32, TNT = BN / WN / 32;  // 32x32 MFMA tiles per wave
-    constexpr int ASLOTS = (BM * 4 + NT - 1) / NT, BSLOTS = (BN * 4 + NT - 1) / NT;  // float4 staging slots per thread
-    __shared__ __attribute__((aligned(16))) float As[2][BM * PITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * PITCH];
+    constexpr int ASLOTS = (BM * KQ + NT - 1) / NT, BSLOTS = (BN * KQ + NT - 1) / NT;  // float4 staging slots per thread
+    extern __shared__ __attribute__((aligned(16))) float gemm_lds[];  // As[2][BM*PITCH] then Bs[2][BN*PITCH]
+    float(*As)[BM * PITCH] = reinterpret_cast<float(*)[BM * PITCH]>(gemm_lds);
+    float(*Bs)[BN * PITCH] = reinterpret_cast<float(*)[BN * PITCH]>(gemm_lds + 2 * BM * PITCH);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -118,8 +121,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(AL al, BL bl
             row = s % rows;
             kq = s / rows;
         } else {
-            kq = s & 3;
-            row = s >> 2;
+            kq = s % KQ;
+            row = s / KQ;
         }
     };
     auto gload = [&](int k0) {
@@ -127,13 +130,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(AL al, BL bl
         for (int i = 0; i < ASLOTS; ++i) {
             int row, kq;
             slot_rc(tid + i * NT, BM, AL::kRowFast, row, kq);
-            if (tid + i * NT < BM * 4) ra[i] = al.get4(batch, m0 + row, k0 + 4 * kq);
+            if (tid + i * NT < BM * KQ) ra[i] = al.get4(batch, m0 + row, k0 + 4 * kq);
         }
 #pragma unroll
         for (int i = 0; i < BSLOTS; ++i) {
             int row, kq;
             slot_rc(tid + i * NT, BN, BL::kRowFast, row, kq);
-            if (tid + i * NT < BN * 4) rb[i] = bl.get4(batch, n0 + row, k0 + 4 * kq);
+            if (tid + i * NT < BN * KQ) rb[i] = bl.get4(batch, n0 + row, k0 + 4 * kq);
         }
     };
     auto lstore = [&](int buf) {
@@ -141,13 +144,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(AL al, BL bl
         for (int i = 0; i < ASLOTS; ++i) {
             int row, kq;
             slot_rc(tid + i * NT, BM, AL::kRowFast, row, kq);
-            if (tid + i * NT < BM * 4) *reinterpret_cast<float4*>(&As[buf][row * PITCH + 4 * kq]) = ra[i];
+            if (tid + i * NT < BM * KQ) *reinterpret_cast<float4*>(&As[buf][row * PITCH + 4 * kq]) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < BSLOTS; ++i) {
             int row, kq;
             slot_rc(tid + i * NT, BN, BL::kRowFast, row, kq);
-            if (tid + i * NT < BN * 4) *reinterpret_cast<float4*>(&Bs[buf][row * PITCH + 4 * kq]) = rb[i];
+            if (tid + i * NT < BN * KQ) *reinterpret_cast<float4*>(&Bs[buf][row * PITCH + 4 * kq]) = rb[i];
         }
     };
 
@@ -166,28 +169,31 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(AL al, BL bl
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) gload((kt + 1) * BK);  // in flight during the MFMAs below
-        float a[TMT][8], b[TNT][8];
 #pragma unroll
-        for (int i = 0; i < TMT; ++i) {
-            const float* src = &As[cur][(wm * TMT * 32 + i * 32 + l31) * PITCH + 8 * hv];
-            const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
-            a[i][0] = v0.x; a[i][1] = v0.y; a[i][2] = v0.z; a[i][3] = v0.w;
-            a[i][4] = v1.x; a[i][5] = v1.y; a[i][6] = v1.z; a[i][7] = v1.w;
+        for (int sub = 0; sub < BK / 16; ++sub) {  // 16 k per sub-step: fragment registers are reused
+            float a[TMT][8], b[TNT][8];
+#pragma unroll
+            for (int i = 0; i < TMT; ++i) {
+                const float* src = &As[cur][(wm * TMT * 32 + i * 32 + l31) * PITCH + sub * 16 + 8 * hv];
+                const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+                a[i][0] = v0.x; a[i][1] = v0.y; a[i][2] = v0.z; a[i][3] = v0.w;
+                a[i][4] = v1.x; a[i][5] = v1.y; a[i][6] = v1.z; a[i][7] = v1.w;
+            }
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) {
+                const float* src = &Bs[cur][(wn * TNT * 32 + j * 32 + l31) * PITCH + sub * 16 + 8 * hv];
+                const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+                b[j][0] = v0.x; b[j][1] = v0.y; b[j][2] = v0.z; b[j][3] = v0.w;
+                b[j][4] = v1.x; b[j][5] = v1.y; b[j][6] = v1.z; b[j][7] = v1.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int i = 0; i < TMT; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < TNT; ++j) {
-            const float* src = &Bs[cur][(wn * TNT * 32 + j * 32 + l31) * PITCH + 8 * hv];
-            const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
-            b[j][0] = v0.x; b[j][1] = v0.y; b[j][2] = v0.z; b[j][3] = v0.w;
-            b[j][4] = v1.x; b[j][5] = v1.y; b[j][6] = v1.z; b[j][7] = v1.w;
-        }
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int i = 0; i < TMT; ++i)
-#pragma unroll
-                for (int j = 0; j < TNT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         if (kt + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
     }
@@ -210,25 +216,33 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_f32_mfma_kernel(AL al, BL bl
         }
 }
 
+template <int BM, int BN, int WM, int WN, int BK, class AL, class BL, class EPI>
+inline void launch_tile(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int batch) {
+    constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    auto kern = gemm_f32_mfma_kernel<BM, BN, WM, WN, BK, AL, BL, EPI>;
+    if (lds > 64 * 1024) {  // above the default per-block limit: opt in once per instantiation
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            done = true;
+        }
+    }
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+    hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, al, bl, epi, M, N, K);
+}
+
 // Launch with a tile chosen from the problem size: big tiles when they still fill 256 CUs, else 64x64 / 32x128.
 template <class AL, class BL, class EPI>
 inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int batch,
                    int num_cus) {
     if (M <= 0 || N <= 0 || batch <= 0) return;
     auto blocks = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
-    if (M <= 32) {
-        dim3 grid((N + 127) / 128, (M + 31) / 32, batch);
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<32, 128, 1, 4, AL, BL, EPI>), grid, dim3(256), 0, st, al, bl, epi, M, N,
-                           K);
-    } else if (blocks(128, 128) >= 2 * (int64_t)num_cus) {
-        dim3 grid((N + 127) / 128, (M + 127) / 128, batch);
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<128, 128, 2, 2, AL, BL, EPI>), grid, dim3(256), 0, st, al, bl, epi, M,
-                           N, K);
-    } else {
-        dim3 grid((N + 63) / 64, (M + 63) / 64, batch);
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<64, 64, 2, 2, AL, BL, EPI>), grid, dim3(256), 0, st, al, bl, epi, M, N,
-                           K);
-    }
+    if (M <= 32)
+        launch_tile<32, 128, 1, 4, 16>(st, al, bl, epi, M, N, K, batch);
+    else if (blocks(128, 128) >= 2 * (int64_t)num_cus)
+        launch_tile<128, 128, 2, 2, 32>(st, al, bl, epi, M, N, K, batch);
+    else
+        launch_tile<64, 64, 2, 2, 16>(st, al, bl, epi, M, N, K, batch);
 }
 
 }  // namespace gemm

@@ -23,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="", help="comma-separated section names: matmul,quant,conv,conv1d,eltwise,rnn,misc")
     args = ap.parse_args()
     import lele_amd
     from lele_amd import kernels as K
@@ -64,98 +65,109 @@ def main():
         print(json.dumps(r), flush=True)
 
     it = 5 if args.quick else 20
+    nb = 8 if args.quick else 64
+    only = [t for t in args.only.split(",") if t]
+
+    def want(name):
+        return not only or name in only
 
     # ---- f32 MatMul (a6/a7): SenseVoice attention shapes, bench shapes of benches/kernels.rs:310-315, one large square
-    for b, m, k, n in [(4, 504, 128, 504), (4, 504, 504, 128), (1, 504, 512, 2048), (1, 512, 512, 512),
-                       (2, 400, 32, 400), (1, 4096, 4096, 4096)]:
-        a, bb = dev(f32(b, m, k)), dev(f32(b, k, n))
-        ms = timeit(lambda o: K.matmul(a, bb, out=o, ctx=ctx), it)
-        record("matmul", [b, m, k, n], ms, 2.0 * b * m * k * n, 4.0 * b * (m * k + k * n + m * n), "mfma_f32")
-    a, bb, bias = dev(f32(504, 512)), dev(f32(512, 2048)), dev(f32(2048))
-    ms = timeit(lambda o: K.matmul_fused_add(a, bb, bias, out=o, ctx=ctx), it)
-    record("matmul_fused_add", [504, 512, 2048], ms, 2.0 * 504 * 512 * 2048, 4.0 * (504 * 512 + 512 * 2048 + 504 * 2048),
-           "mfma_f32")
+    if want('matmul'):
+        for b, m, k, n in [(4, 504, 128, 504), (4, 504, 504, 128), (1, 504, 512, 2048), (1, 512, 512, 512),
+                           (2, 400, 32, 400), (1, 4096, 4096, 4096)]:
+            a, bb = dev(f32(b, m, k)), dev(f32(b, k, n))
+            ms = timeit(lambda o: K.matmul(a, bb, out=o, ctx=ctx), it)
+            record("matmul", [b, m, k, n], ms, 2.0 * b * m * k * n, 4.0 * b * (m * k + k * n + m * n), "mfma_f32")
+        a, bb, bias = dev(f32(504, 512)), dev(f32(512, 2048)), dev(f32(2048))
+        ms = timeit(lambda o: K.matmul_fused_add(a, bb, bias, out=o, ctx=ctx), it)
+        record("matmul_fused_add", [504, 512, 2048], ms, 2.0 * 504 * 512 * 2048, 4.0 * (504 * 512 + 512 * 2048 + 504 * 2048),
+               "mfma_f32")
 
     # ---- quantized linear (a17): SenseVoice encoder shapes at M = 504 tokens
-    for m, k, n in [(504, 560, 1536), (504, 512, 1536), (504, 512, 512), (504, 512, 2048), (504, 2048, 512),
-                    (504, 512, 25055), (8064, 512, 2048)]:
-        x = dev(f32(1, m, k))
-        w = Weight(np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32))
-        ws = Weight((np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32))
-        wz = Weight(np.array([128.0], np.float32))
-        bs = Weight(f32(n, scale=0.02))
-        ms = timeit(lambda o: K.fused_quantized_linear(x, w, ws, wz, bs, False, out=o, ctx=ctx), it)
-        record("fused_quantized_linear", [m, k, n], ms, 2.0 * m * k * n, 4.0 * m * k + k * n + 8.0 * n + 4.0 * m * n,
-               "mfma_i8", "dynamic quantisation of the activations included")
+    if want('quant'):
+        for m, k, n in [(504, 560, 1536), (504, 512, 1536), (504, 512, 512), (504, 512, 2048), (504, 2048, 512),
+                        (504, 512, 25055), (8064, 512, 2048)]:
+            x = dev(f32(1, m, k))
+            w = Weight(np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32))
+            ws = Weight((np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32))
+            wz = Weight(np.array([128.0], np.float32))
+            bs = Weight(f32(n, scale=0.02))
+            ms = timeit(lambda o: K.fused_quantized_linear(x, w, ws, wz, bs, False, out=o, ctx=ctx), it)
+            record("fused_quantized_linear", [m, k, n], ms, 2.0 * m * k * n, 4.0 * m * k + k * n + 8.0 * n + 4.0 * m * n,
+                   "mfma_i8", "dynamic quantisation of the activations included")
 
     # ---- Conv2d (a9): Yolo26n-seg shapes at batch 64 (C5), conv_transpose (a10)
-    nb = 8 if args.quick else 64
-    for c, h, oc, k, s, g, act in [(64, 160, 64, 3, 1, 1, "silu"), (3, 640, 16, 3, 2, 1, "silu"), (128, 80, 128, 1, 1, 1, "silu"),
-                                   (256, 20, 256, 3, 1, 1, "silu"), (128, 40, 128, 3, 1, 128, None)]:
-        x = dev(f32(nb, c, h, h))
-        w = Weight(f32(oc, c // g, k, k, scale=0.1))
-        bs = Weight(f32(oc))
-        p = k // 2
-        fn = K.conv2d_silu if act == "silu" else K.conv2d
-        ms = timeit(lambda o: fn(x, w, bs, [1, 1], g, [p, p, p, p], [s, s], out=o, ctx=ctx), max(3, it // 4))
-        oh = (h + 2 * p - k) // s + 1
-        fl = 2.0 * nb * oc * (c // g) * k * k * oh * oh
-        by = 4.0 * nb * (c * h * h + oc * oh * oh)
-        record("conv2d" + ("_silu" if act else ""), [nb, c, h, h, oc, k, s, g], ms, fl, by, "hbm" if g > 1 else "mfma_f32")
-    x = dev(f32(nb, 64, 80, 80))
-    w = Weight(f32(64, 64, 2, 2, scale=0.1))
-    ms = timeit(lambda o: K.conv_transpose(x, w, None, [1, 1], 1, [0, 0, 0, 0], [2, 2], out=o, ctx=ctx), 3)
-    record("conv_transpose", [nb, 64, 80, 80, 64, 2, 2], ms, 2.0 * nb * 64 * 64 * 4 * 80 * 80,
-           4.0 * nb * 64 * (80 * 80 + 160 * 160), "mfma_f32", "direct gather kernel (not on MFMA yet)")
+    if want('conv'):
+        for c, h, oc, k, s, g, act in [(64, 160, 64, 3, 1, 1, "silu"), (3, 640, 16, 3, 2, 1, "silu"), (128, 80, 128, 1, 1, 1, "silu"),
+                                       (256, 20, 256, 3, 1, 1, "silu"), (128, 40, 128, 3, 1, 128, None)]:
+            x = dev(f32(nb, c, h, h))
+            w = Weight(f32(oc, c // g, k, k, scale=0.1))
+            bs = Weight(f32(oc))
+            p = k // 2
+            fn = K.conv2d_silu if act == "silu" else K.conv2d
+            ms = timeit(lambda o: fn(x, w, bs, [1, 1], g, [p, p, p, p], [s, s], out=o, ctx=ctx), max(3, it // 4))
+            oh = (h + 2 * p - k) // s + 1
+            fl = 2.0 * nb * oc * (c // g) * k * k * oh * oh
+            by = 4.0 * nb * (c * h * h + oc * oh * oh)
+            record("conv2d" + ("_silu" if act else ""), [nb, c, h, h, oc, k, s, g], ms, fl, by, "hbm" if g > 1 else "mfma_f32")
+        x = dev(f32(nb, 64, 80, 80))
+        w = Weight(f32(64, 64, 2, 2, scale=0.1))
+        ms = timeit(lambda o: K.conv_transpose(x, w, None, [1, 1], 1, [0, 0, 0, 0], [2, 2], out=o, ctx=ctx), 3)
+        record("conv_transpose", [nb, 64, 80, 80, 64, 2, 2], ms, 2.0 * nb * 64 * 64 * 4 * 80 * 80,
+               4.0 * nb * 64 * (80 * 80 + 160 * 160), "mfma_f32", "direct gather kernel (not on MFMA yet)")
 
     # ---- Conv1d (a8): FSMN depthwise k=11 and the Silero STFT-as-conv
-    x, w = dev(f32(1, 512, 514)), Weight(f32(512, 1, 11))
-    ms = timeit(lambda o: K.conv1d(x, w, None, [1], 512, [0, 0], [1], out=o, ctx=ctx), it)
-    record("conv1d_depthwise", [1, 512, 514, 11], ms, 2.0 * 512 * 504 * 11, 4.0 * 512 * (514 + 504), "hbm")
-    x, w = dev(f32(1, 1, 640)), Weight(f32(258, 1, 256))
-    ms = timeit(lambda o: K.conv1d(x, w, None, [1], 1, [0, 0], [128], out=o, ctx=ctx), it)
-    record("conv1d_stft", [1, 1, 640, 258, 256], ms, 2.0 * 258 * 256 * 4, 0, "latency", "Silero chunk; launch-latency bound")
+    if want('conv1d'):
+        x, w = dev(f32(1, 512, 514)), Weight(f32(512, 1, 11))
+        ms = timeit(lambda o: K.conv1d(x, w, None, [1], 512, [0, 0], [1], out=o, ctx=ctx), it)
+        record("conv1d_depthwise", [1, 512, 514, 11], ms, 2.0 * 512 * 504 * 11, 4.0 * 512 * (514 + 504), "hbm")
+        x, w = dev(f32(1, 1, 640)), Weight(f32(258, 1, 256))
+        ms = timeit(lambda o: K.conv1d(x, w, None, [1], 1, [0, 0], [128], out=o, ctx=ctx), it)
+        record("conv1d_stft", [1, 1, 640, 258, 256], ms, 2.0 * 258 * 256 * 4, 0, "latency", "Silero chunk; launch-latency bound")
 
     # ---- normalisation / activations / data movement (a13-a16, a19): HBM-bound
-    x, gmm, bta = dev(f32(1, 504, 512)), dev(f32(512)), dev(f32(512))
-    ms = timeit(lambda o: K.layer_norm(x, gmm, bta, -1, 1e-5, out=o, ctx=ctx), it)
-    record("layer_norm", [1, 504, 512], ms, 0, 8.0 * 504 * 512, "hbm", "1 MB problem: launch-latency dominated")
-    x, gmm, bta = dev(f32(64, 504, 512)), dev(f32(512)), dev(f32(512))
-    ms = timeit(lambda o: K.layer_norm(x, gmm, bta, -1, 1e-5, out=o, ctx=ctx), it)
-    record("layer_norm", [64, 504, 512], ms, 0, 8.0 * 64 * 504 * 512, "hbm")
-    x = dev(f32(1, 4, 504, 504))
-    ms = timeit(lambda o: K.softmax(x, -1, out=o, ctx=ctx), it)
-    record("softmax", [1, 4, 504, 504], ms, 0, 8.0 * 4 * 504 * 504, "hbm")
-    x = dev(f32(64, 4, 504, 504))
-    ms = timeit(lambda o: K.softmax(x, -1, out=o, ctx=ctx), it)
-    record("softmax", [64, 4, 504, 504], ms, 0, 8.0 * 64 * 4 * 504 * 504, "hbm")
-    x = dev(f32(nb, 16, 320, 320))
-    ms = timeit(lambda o: K.silu(x, out=o, ctx=ctx), it)
-    record("silu", [nb, 16, 320, 320], ms, 0, 8.0 * nb * 16 * 320 * 320, "hbm")
-    y = dev(f32(nb, 16, 320, 320))
-    ms = timeit(lambda o: K.add(x, y, out=o, ctx=ctx), it)
-    record("add", [nb, 16, 320, 320], ms, 0, 12.0 * nb * 16 * 320 * 320, "hbm")
-    x = dev(f32(64, 504, 4, 128))
-    ms = timeit(lambda o: K.transpose(x, [0, 2, 1, 3], out=o, ctx=ctx), it)
-    record("transpose_0213", [64, 504, 4, 128], ms, 0, 8.0 * 64 * 504 * 512, "hbm")
-    x = dev(f32(nb, 128, 20, 20))
-    ms = timeit(lambda o: K.max_pool2d(x, [5, 5], [1, 1], [2, 2, 2, 2], out=o, ctx=ctx), it)
-    record("max_pool2d_5x5", [nb, 128, 20, 20], ms, 0, 8.0 * nb * 128 * 400, "hbm")
+    if want('eltwise'):
+        x, gmm, bta = dev(f32(1, 504, 512)), dev(f32(512)), dev(f32(512))
+        ms = timeit(lambda o: K.layer_norm(x, gmm, bta, -1, 1e-5, out=o, ctx=ctx), it)
+        record("layer_norm", [1, 504, 512], ms, 0, 8.0 * 504 * 512, "hbm", "1 MB problem: launch-latency dominated")
+        x, gmm, bta = dev(f32(64, 504, 512)), dev(f32(512)), dev(f32(512))
+        ms = timeit(lambda o: K.layer_norm(x, gmm, bta, -1, 1e-5, out=o, ctx=ctx), it)
+        record("layer_norm", [64, 504, 512], ms, 0, 8.0 * 64 * 504 * 512, "hbm")
+        x = dev(f32(1, 4, 504, 504))
+        ms = timeit(lambda o: K.softmax(x, -1, out=o, ctx=ctx), it)
+        record("softmax", [1, 4, 504, 504], ms, 0, 8.0 * 4 * 504 * 504, "hbm")
+        x = dev(f32(64, 4, 504, 504))
+        ms = timeit(lambda o: K.softmax(x, -1, out=o, ctx=ctx), it)
+        record("softmax", [64, 4, 504, 504], ms, 0, 8.0 * 64 * 4 * 504 * 504, "hbm")
+        x = dev(f32(nb, 16, 320, 320))
+        ms = timeit(lambda o: K.silu(x, out=o, ctx=ctx), it)
+        record("silu", [nb, 16, 320, 320], ms, 0, 8.0 * nb * 16 * 320 * 320, "hbm")
+        y = dev(f32(nb, 16, 320, 320))
+        ms = timeit(lambda o: K.add(x, y, out=o, ctx=ctx), it)
+        record("add", [nb, 16, 320, 320], ms, 0, 12.0 * nb * 16 * 320 * 320, "hbm")
+        x = dev(f32(64, 504, 4, 128))
+        ms = timeit(lambda o: K.transpose(x, [0, 2, 1, 3], out=o, ctx=ctx), it)
+        record("transpose_0213", [64, 504, 4, 128], ms, 0, 8.0 * 64 * 504 * 512, "hbm")
+        x = dev(f32(nb, 128, 20, 20))
+        ms = timeit(lambda o: K.max_pool2d(x, [5, 5], [1, 1], [2, 2, 2, 2], out=o, ctx=ctx), it)
+        record("max_pool2d_5x5", [nb, 128, 20, 20], ms, 0, 8.0 * nb * 128 * 400, "hbm")
 
     # ---- LSTM / GRU (a11/a12): latency-bound, microseconds per step
-    for T in (1, 175):
-        x, w, r, b = dev(f32(T, 1, 128)), Weight(f32(1, 512, 128, scale=0.1)), Weight(f32(1, 512, 128, scale=0.1)), Weight(f32(1, 1024))
-        out3 = [None]
+    if want('rnn'):
+        for T in (1, 175):
+            x, w, r, b = dev(f32(T, 1, 128)), Weight(f32(1, 512, 128, scale=0.1)), Weight(f32(1, 512, 128, scale=0.1)), Weight(f32(1, 1024))
+            out3 = [None]
 
-        def run(_o):
-            out3[0] = K.lstm(x, w, r, b, None, None, None, ctx=ctx)
-        ms = timeit(run, it)
-        record("lstm_H128", [T, 1, 128], ms, 0, 0, "latency", "%.2f us per step" % (ms * 1e3 / T))
+            def run(_o):
+                out3[0] = K.lstm(x, w, r, b, None, None, None, ctx=ctx)
+            ms = timeit(run, it)
+            record("lstm_H128", [T, 1, 128], ms, 0, 0, "latency", "%.2f us per step" % (ms * 1e3 / T))
 
     # ---- front-end pieces outside the fused kernel: cmvn, stft
-    x = dev(f32(500, 560))
-    ms = timeit(lambda o: lele_amd.features.Cmvn(ctx=ctx).compute(x, out=o), it)
-    record("cmvn", [500, 560], ms, 0, 8.0 * 500 * 560, "hbm", "single utterance: launch-latency dominated")
+    if want('misc'):
+        x = dev(f32(500, 560))
+        ms = timeit(lambda o: lele_amd.features.Cmvn(ctx=ctx).compute(x, out=o), it)
+        record("cmvn", [500, 560], ms, 0, 8.0 * 500 * 560, "hbm", "single utterance: launch-latency dominated")
 
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
