@@ -34,6 +34,24 @@ struct ConvGeom {
     int n, c, ih, iw, oc, kh, kw, group, icg, ocg, pt, pl, sh, sw, dh, dw, oh, ow, K, plane;
 };
 
+// exact n / d for the small non-negative values of this file via one mulhi (m = floor(2^32/d) + 1 is exact while
+// n * d < 2^32, which the host checks; otherwise use_magic is 0 and a real division is used)
+struct FastDiv {
+    unsigned m, d;
+    int use_magic;
+    __device__ __forceinline__ int div(int n) const { return use_magic ? (int)__umulhi((unsigned)n, m) : n / (int)d; }
+};
+inline FastDiv make_fastdiv(int d, int64_t max_n) {
+    FastDiv f;
+    f.d = (unsigned)d;
+    f.m = (unsigned)((uint64_t(1) << 32) / (unsigned)d + 1);
+    f.use_magic = d > 1 && max_n * d < (int64_t(1) << 32);
+    if (d == 1) {  // n / 1: the magic would overflow
+        f.use_magic = 0;
+    }
+    return f;
+}
+
 // A operand: weights [OC][ICg*kh*kw] row-major; GEMM batch b = img*G + g selects the group's rows
 struct ConvWLoad {
     const float* w;
@@ -41,49 +59,90 @@ struct ConvWLoad {
     int vec;
     static constexpr bool kRowFast = false;
     __device__ __forceinline__ float4 get4(int b, int row, int k) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row >= g.ocg) return v;
-        const float* q = w + ((int64_t)((b % g.group) * g.ocg + row)) * g.K + k;
-        if (vec && k + 3 < g.K) return *reinterpret_cast<const float4*>(q);
-        if (k + 0 < g.K) v.x = q[0];
-        if (k + 1 < g.K) v.y = q[1];
-        if (k + 2 < g.K) v.z = q[2];
-        if (k + 3 < g.K) v.w = q[3];
-        return v;
+        const bool rin = row < g.ocg;
+        const float* q = w + ((int64_t)((b % g.group) * g.ocg + (rin ? row : g.ocg - 1))) * g.K;
+        float4 v;
+        if (vec && k + 3 < g.K) {
+            v = *reinterpret_cast<const float4*>(q + k);
+        } else {
+            const int last = g.K - 1;
+            const float e0 = q[k + 0 < g.K ? k + 0 : last], e1 = q[k + 1 < g.K ? k + 1 : last];
+            const float e2 = q[k + 2 < g.K ? k + 2 : last], e3 = q[k + 3 < g.K ? k + 3 : last];
+            v = make_float4(k + 0 < g.K ? e0 : 0.f, k + 1 < g.K ? e1 : 0.f, k + 2 < g.K ? e2 : 0.f, k + 3 < g.K ? e3 : 0.f);
+        }
+        return rin ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 };
-// B operand: element(position p, k) = x[img][g*ICg + ic][oh*sh - pt + a*dh][ow*sw - pl + bb*dw] (0 outside)
+// B operand: element(position p, k) = x[img][g*ICg + ic][oh*sh - pt + a*dh][ow*sw - pl + bb*dw] (0 outside).
+// Index arithmetic only (mulhi divisions); the four loads are unconditional on clamped addresses.
 struct ConvXLoad {
     const float* x;
     ConvGeom g;
+    FastDiv d_ow, d_khw, d_kw;
     static constexpr bool kRowFast = true;  // consecutive threads -> consecutive output positions (coalesced along W)
     __device__ __forceinline__ float4 get4(int b, int row, int k) const {
-        float r[4] = {0.f, 0.f, 0.f, 0.f};
-        if (row < g.plane) {
-            const int img = b / g.group, grp = b % g.group;
-            const int oy = row / g.ow, ox = row - oy * g.ow;
-            const int khw = g.kh * g.kw;
-            int ic = k / khw, rem = k - ic * khw;
-            int a = rem / g.kw, bb = rem - a * g.kw;
-            const float* base = x + ((int64_t)img * g.c + grp * g.icg) * g.ih * g.iw;
+        const bool rin = row < g.plane;
+        const int rowc = rin ? row : g.plane - 1;
+        const int img = b / g.group, grp = b - img * g.group;
+        const int oy = d_ow.div(rowc), ox = rowc - oy * g.ow;
+        const int kc = k < g.K ? k : g.K - 1;
+        int ic = d_khw.div(kc), rem = kc - ic * (g.kh * g.kw);
+        int a = d_kw.div(rem), bb = rem - a * g.kw;
+        const float* base = x + ((int64_t)img * g.c + grp * g.icg) * g.ih * g.iw;
+        const int iy0 = oy * g.sh - g.pt, ix0 = ox * g.sw - g.pl;
+        int idx[4];
+        bool ok[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (k + e < g.K) {
-                    const int iy = oy * g.sh - g.pt + a * g.dh, ix = ox * g.sw - g.pl + bb * g.dw;
-                    if (iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw) r[e] = base[((int64_t)ic * g.ih + iy) * g.iw + ix];
-                }
-                if (++bb == g.kw) {
-                    bb = 0;
-                    if (++a == g.kh) {
-                        a = 0;
-                        ++ic;
-                    }
+        for (int e = 0; e < 4; ++e) {
+            const int iy = iy0 + a * g.dh, ix = ix0 + bb * g.dw;
+            ok[e] = rin && k + e < g.K && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+            idx[e] = ok[e] ? (ic * g.ih + iy) * g.iw + ix : 0;
+            if (++bb == g.kw) {
+                bb = 0;
+                if (++a == g.kh) {
+                    a = 0;
+                    ++ic;
                 }
             }
         }
-        return make_float4(r[0], r[1], r[2], r[3]);
+        const float e0 = base[idx[0]], e1 = base[idx[1]], e2 = base[idx[2]], e3 = base[idx[3]];
+        return make_float4(ok[0] ? e0 : 0.f, ok[1] ? e1 : 0.f, ok[2] ? e2 : 0.f, ok[3] ? e3 : 0.f);
     }
 };
+// Tap-major variant (IC/g % 4 == 0): the GEMM K index is (tap, ic) instead of lele's (ic, tap) -- a permutation of the
+// exact f32 sum -- so the 4 consecutive k of a chunk are 4 input channels at ONE tap: one bounds test and one base
+// index per chunk, four loads at the constant stride ih*iw.  The weights are re-laid out once to [OC][tap][ic]
+// (cached for LELE_MEM_WEIGHT tensors).
+struct ConvXLoadTap {
+    const float* x;
+    ConvGeom g;
+    FastDiv d_ow, d_icg, d_kw;
+    static constexpr bool kRowFast = true;
+    __device__ __forceinline__ float4 get4(int b, int row, int k) const {
+        const bool rin = row < g.plane;
+        const int rowc = rin ? row : g.plane - 1;
+        const int img = b / g.group, grp = b - img * g.group;
+        const int oy = d_ow.div(rowc), ox = rowc - oy * g.ow;
+        const int kc = k < g.K ? k : g.K - 4;  // K % 4 == 0 here, so a chunk is entirely in or out of range
+        const int tap = d_icg.div(kc), ic = kc - tap * g.icg;
+        const int a = d_kw.div(tap), bb = tap - a * g.kw;
+        const int iy = oy * g.sh - g.pt + a * g.dh, ix = ox * g.sw - g.pl + bb * g.dw;
+        const bool ok = rin && k < g.K && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+        const int hw = g.ih * g.iw;
+        const float* q = x + ((int64_t)img * g.c + grp * g.icg) * hw + (ok ? ic * hw + iy * g.iw + ix : 0);
+        const float e0 = q[0], e1 = q[hw], e2 = q[2 * hw], e3 = q[3 * hw];
+        return ok ? make_float4(e0, e1, e2, e3) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+};
+__global__ void conv_wperm_kernel(const float* __restrict__ w, float* __restrict__ wt, int oc, int icg, int khw) {
+    const int64_t total = (int64_t)oc * icg * khw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ic = (int)(i % icg), tap = (int)((i / icg) % khw);
+        const int64_t o = i / ((int64_t)icg * khw);
+        wt[i] = w[(o * icg + ic) * khw + tap];
+    }
+}
+
 struct ConvEpi {
     float* out;
     const float* bias;
@@ -167,7 +226,8 @@ inline int64_t attr(const int64_t* v, size_t n, size_t i, int64_t dflt) {
     return dflt;
 }
 
-int run_conv2d(LeleCtx* ctx, const float* dx, const float* dw, const float* db, ConvGeom g, int act, float* out) {
+int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float* dw, const float* db, ConvGeom g, int act,
+               float* out) {
     if ((int64_t)g.n * g.oc * g.plane == 0) return 0;
     if (g.icg == 1 && g.ocg == 1) {
         const int64_t total = (int64_t)g.n * g.oc * g.plane;
@@ -175,9 +235,40 @@ int run_conv2d(LeleCtx* ctx, const float* dx, const float* dw, const float* db, 
                            act);
     } else {
         ConvWLoad al{dw, g, (int)((((uintptr_t)dw & 15) == 0) && g.K % 4 == 0)};
-        ConvXLoad bl{dx, g};
         ConvEpi epi{out, db, g, act};
-        gemm::launch(ctx->stream, al, bl, epi, g.ocg, g.plane, g.K, g.n * g.group, ctx->num_cus);
+        const int64_t img_elems = (int64_t)g.icg * g.ih * g.iw;
+        LELE_REQUIRE(img_elems < (int64_t(1) << 31), "conv2d: one image group exceeds 2^31 elements");
+        if (g.kh == 1 && g.kw == 1 && g.sh == 1 && g.sw == 1 && g.pt == 0 && g.pl == 0 && g.oh == g.ih && g.ow == g.iw) {
+            // pointwise: B[p][k] = x[img][grp*ICg + k][p] is a plain column-major operand; batch b = img*G + grp
+            gemm::LoadKRow bl{dx, img_elems, (int64_t)g.plane, g.plane, g.K};
+            gemm::launch(ctx->stream, al, bl, epi, g.ocg, g.plane, g.K, g.n * g.group, ctx->num_cus);
+        } else if (g.icg % 4 == 0) {
+            // tap-major K: weights permuted to [OC][tap][ic] once (cached when the caller declared them immutable)
+            const int khw = g.kh * g.kw;
+            const size_t wbytes = (size_t)g.oc * g.K * 4;
+            void* dwt = nullptr;
+            const bool cacheable = wt->mem == LELE_MEM_WEIGHT;
+            auto key = std::make_tuple((const void*)wt->data, wbytes, 301);
+            auto it = cacheable ? ctx->weights.find(key) : ctx->weights.end();
+            if (it != ctx->weights.end()) {
+                dwt = it->second;
+            } else {
+                if (cacheable) {
+                    LELE_HIP_CHECK(hipMalloc(&dwt, wbytes));
+                    ctx->weights[key] = dwt;
+                } else {
+                    LELE_TRY(ctx->arena_alloc(wbytes, &dwt));
+                }
+                hipLaunchKernelGGL(conv_wperm_kernel, dim3(grid_for((int64_t)g.oc * g.K)), dim3(256), 0, ctx->stream, dw,
+                                   (float*)dwt, g.oc, g.icg, khw);
+            }
+            ConvWLoad alt{(const float*)dwt, g, 1};  // hipMalloc / arena chunks are 16-B aligned and K % 4 == 0
+            ConvXLoadTap bl{dx, g, make_fastdiv(g.ow, g.plane), make_fastdiv(g.icg, g.K), make_fastdiv(g.kw, khw)};
+            gemm::launch(ctx->stream, alt, bl, epi, g.ocg, g.plane, g.K, g.n * g.group, ctx->num_cus);
+        } else {
+            ConvXLoad bl{dx, g, make_fastdiv(g.ow, g.plane), make_fastdiv(g.kh * g.kw, g.K), make_fastdiv(g.kw, g.kh * g.kw)};
+            gemm::launch(ctx->stream, al, bl, epi, g.ocg, g.plane, g.K, g.n * g.group, ctx->num_cus);
+        }
     }
     LELE_HIP_CHECK(hipGetLastError());
     return 0;
@@ -241,7 +332,7 @@ int lele_hip_conv2d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, cons
     LELE_TRY(ctx->dev_ptr(w, &dwp));
     if (bias) LELE_TRY(ctx->dev_ptr(bias, &db));
     LELE_TRY(out->reserve((size_t)g.n * g.oc * g.plane * 4));
-    LELE_TRY(run_conv2d(ctx, (const float*)dx, (const float*)dwp, (const float*)db, g, act, (float*)out->data));
+    LELE_TRY(run_conv2d(ctx, w, (const float*)dx, (const float*)dwp, (const float*)db, g, act, (float*)out->data));
     return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, (int64_t)g.oh, (int64_t)g.ow});
 }
 
@@ -287,7 +378,7 @@ int lele_hip_conv1d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, cons
     LELE_TRY(ctx->dev_ptr(w, &dwp));
     if (bias) LELE_TRY(ctx->dev_ptr(bias, &db));
     LELE_TRY(out->reserve((size_t)g.n * g.oc * g.plane * 4));
-    LELE_TRY(run_conv2d(ctx, (const float*)dx, (const float*)dwp, (const float*)db, g, relu ? LELE_ACT_RELU : LELE_ACT_NONE,
+    LELE_TRY(run_conv2d(ctx, w, (const float*)dx, (const float*)dwp, (const float*)db, g, relu ? LELE_ACT_RELU : LELE_ACT_NONE,
                         (float*)out->data));
     return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, (int64_t)g.ow});
 }

@@ -24,6 +24,8 @@ namespace gemm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------- loaders
+// Loaders never put a global load behind a per-lane branch (that serialises one memory round trip per element):
+// coordinates are clamped into range, the load is unconditional, and out-of-range elements are zeroed by a select.
 // element(row, k) = p[batch*bs + row*ld + k]   (k contiguous in memory)
 struct LoadRowK {
     const float* p;
@@ -33,15 +35,18 @@ struct LoadRowK {
     int vec;  // 1 when float4 loads are legal (base and ld 16-B aligned)
     static constexpr bool kRowFast = false;
     __device__ __forceinline__ float4 get4(int b, int row, int k) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row >= rows) return v;
-        const float* q = p + (int64_t)b * bs + (int64_t)row * ld + k;
-        if (vec && k + 3 < K) return *reinterpret_cast<const float4*>(q);
-        if (k + 0 < K) v.x = q[0];
-        if (k + 1 < K) v.y = q[1];
-        if (k + 2 < K) v.z = q[2];
-        if (k + 3 < K) v.w = q[3];
-        return v;
+        const bool rin = row < rows;
+        const float* q = p + (int64_t)b * bs + (int64_t)(rin ? row : rows - 1) * ld;
+        float4 v;
+        if (vec && k + 3 < K) {  // whole chunk in range (always, except in the last K tile)
+            v = *reinterpret_cast<const float4*>(q + k);
+        } else {
+            const int last = K - 1;
+            const float e0 = q[k + 0 < K ? k + 0 : last], e1 = q[k + 1 < K ? k + 1 : last];
+            const float e2 = q[k + 2 < K ? k + 2 : last], e3 = q[k + 3 < K ? k + 3 : last];
+            v = make_float4(k + 0 < K ? e0 : 0.f, k + 1 < K ? e1 : 0.f, k + 2 < K ? e2 : 0.f, k + 3 < K ? e3 : 0.f);
+        }
+        return rin ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 };
 // element(row, k) = p[batch*bs + k*ld + row]   (row contiguous in memory: B of a plain matmul, A of transA)
@@ -52,14 +57,13 @@ struct LoadKRow {
     int rows, K;
     static constexpr bool kRowFast = true;
     __device__ __forceinline__ float4 get4(int b, int row, int k) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row >= rows) return v;
-        const float* q = p + (int64_t)b * bs + (int64_t)k * ld + row;
-        if (k + 0 < K) v.x = q[0];
-        if (k + 1 < K) v.y = q[ld];
-        if (k + 2 < K) v.z = q[2 * ld];
-        if (k + 3 < K) v.w = q[3 * ld];
-        return v;
+        const bool rin = row < rows;
+        const float* q = p + (int64_t)b * bs + (rin ? row : rows - 1);
+        const int last = K - 1;
+        const float e0 = q[(int64_t)(k + 0 < K ? k + 0 : last) * ld], e1 = q[(int64_t)(k + 1 < K ? k + 1 : last) * ld];
+        const float e2 = q[(int64_t)(k + 2 < K ? k + 2 : last) * ld], e3 = q[(int64_t)(k + 3 < K ? k + 3 : last) * ld];
+        return make_float4(rin && k + 0 < K ? e0 : 0.f, rin && k + 1 < K ? e1 : 0.f, rin && k + 2 < K ? e2 : 0.f,
+                           rin && k + 3 < K ? e3 : 0.f);
     }
 };
 
@@ -239,6 +243,8 @@ inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, i
     auto blocks = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
     if (M <= 32)
         launch_tile<32, 128, 1, 4, 16>(st, al, bl, epi, M, N, K, batch);
+    else if (M <= 64 && blocks(64, 256) >= 2 * (int64_t)num_cus)  // few rows (e.g. 64 output channels), many columns
+        launch_tile<64, 256, 1, 4, 16>(st, al, bl, epi, M, N, K, batch);
     else if (blocks(128, 128) >= 2 * (int64_t)num_cus)
         launch_tile<128, 128, 2, 2, 32>(st, al, bl, epi, M, N, K, batch);
     else
