@@ -146,13 +146,20 @@ __device__ __forceinline__ float lane_rot_prev(float v, int p) {
 constexpr int kStdMelLen[5] = {3, 4, 6, 10, 17};
 constexpr int kStdMelOff[6] = {0, 3, 7, 13, 23, 40};
 
-template <int MODE, bool STDMEL>
+// FUSED: the block first stages its run of PCM (64 frames = 10 480 samples, read from HBM once) into an LDS tile that
+// aliases the exchange region, wave 0 computes the 64 exact sequential frame sums from it (as fe_frame_sum_kernel
+// does), and the per-pass sample loads below then hit L2 -- no separate sum kernel, no second HBM read of the PCM.
+template <int MODE, bool STDMEL, bool FUSED>
 __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ pcm, int64_t utt_stride,
                                                       int64_t num_frames, int64_t t_lfr,
                                                       const float* __restrict__ means, FeDev tb,
-                                                      float* __restrict__ out, float* __restrict__ logmel_out) {
+                                                      float* __restrict__ out, float* __restrict__ logmel_out,
+                                                      int aligned16) {
+    constexpr int kXFloats = FUSED ? (kSumRows * kSumPitch > 4 * kWaveLdsFloats ? kSumRows * kSumPitch : 4 * kWaveLdsFloats)
+                                   : 4 * kWaveLdsFloats;
     __shared__ float2 s_tw[512];
-    __shared__ __attribute__((aligned(16))) float s_x[4 * kWaveLdsFloats];
+    __shared__ __attribute__((aligned(16))) float s_x[kXFloats];
+    __shared__ float s_mean[64];
     __shared__ int s_mstart[16 * kMaxMelRounds];
     __shared__ int s_moff[kMaxMelRounds + 1];
     extern __shared__ float s_melw[];  // [mel_steps][16]
@@ -161,10 +168,46 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
     for (int i = threadIdx.x; i < tb.mel_steps * 16; i += 256) s_melw[i] = tb.melw[i];
     if (threadIdx.x < tb.mel_rounds * 16) s_mstart[threadIdx.x] = tb.mel_start[threadIdx.x];
     if (threadIdx.x <= tb.mel_rounds) s_moff[threadIdx.x] = tb.mel_step_off[threadIdx.x];
-    __syncthreads();  // the only block-level barrier; waves are independent from here on
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, p = lane & 15;
+    if (FUSED) {
+        // stage the run [64*blockIdx.x*hop, +66 hops) as [hop row][offset] (x32768, exact) -- same layout and bank
+        // argument as fe_frame_sum_kernel, 256 threads, all loads of a thread issued before the first use
+        const float* ubase = pcm + (int64_t)blockIdx.y * utt_stride;
+        const int64_t s0 = (int64_t)blockIdx.x * 64 * fe::kHop;
+        constexpr int kVecPerRow = fe::kHop / 4;
+        constexpr int kVecs = kSumRows * kVecPerRow;
+        constexpr int kIters = (kVecs + 255) / 256;
+        float4 st[kIters];
+#pragma unroll
+        for (int u = 0; u < kIters; ++u) {
+            const int idx = u * 256 + (int)threadIdx.x;
+            int64_t sidx = s0 + 4 * (int64_t)idx;
+            if (sidx + 3 >= utt_stride) sidx = aligned16 ? ((utt_stride - 4) & ~int64_t(3)) : (utt_stride - 4);
+            if (sidx < 0) sidx = 0;
+            const float* src = ubase + sidx;
+            if (aligned16)
+                st[u] = *reinterpret_cast<const float4*>(src);
+            else
+                st[u] = make_float4(src[0], src[1], src[2], src[3]);
+        }
+#pragma unroll
+        for (int u = 0; u < kIters; ++u) {
+            const int idx = u * 256 + (int)threadIdx.x;
+            if (idx < kVecs) {
+                float4 xv = st[u];
+                xv.x *= 32768.0f;
+                xv.y *= 32768.0f;
+                xv.z *= 32768.0f;
+                xv.w *= 32768.0f;
+                const int row = idx / kVecPerRow, c = idx - row * kVecPerRow;
+                *reinterpret_cast<float4*>(&s_x[row * kSumPitch + 4 * c]) = xv;
+            }
+        }
+        __syncthreads();
+    }
+    // window coefficients and the first pass's samples are requested before the sums / barrier below, so that their
+    // latency overlaps the 400-step add chain of wave 0
     const int h = fe::rev4(p);
     float* xw = s_x + wave * kWaveLdsFloats;           // this wave's exchange / power region
     float* xf = xw + g * kFrameXchgFloats;             // this frame's 2 KB round buffer
@@ -182,21 +225,42 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
     // raw PCM of the next pass is fetched while the current pass computes (software prefetch): the loads are
     // unconditional (clamped to frame 0 for the tail) so that all 25 are in flight together.
     float xr[fe::kQ];
-    float mean_next;
+    float mean_next = 0.0f;
     auto issue_loads = [&](int pass) {
         const int64_t f = (int64_t)blockIdx.x * 64 + wave * 16 + pass * 4 + g;
         const int64_t fc = f < num_frames ? f : 0;
         const float* src = base + fc * fe::kHop + p;
-        mean_next = mean_u[fc];
+        if (!FUSED) mean_next = mean_u[fc];
 #pragma unroll
         for (int q = 0; q < fe::kQ; ++q) xr[q] = src[16 * q];
     };
     issue_loads(0);
+    if (FUSED) {
+        constexpr int kVecPerRow = fe::kHop / 4;
+        if (wave == 0) {  // raw_frame.iter().sum() (pipeline.rs:115): one lane per frame, 400 adds in index order
+            float sum = 0.0f;
+#pragma unroll
+            for (int seg = 0; seg < 3; ++seg) {
+                const float* rowp = &s_x[(lane + seg) * kSumPitch];
+                const int nvec = seg < 2 ? kVecPerRow : (fe::kFrame - 2 * fe::kHop) / 4;
+#pragma unroll 10
+                for (int k = 0; k < nvec; ++k) {
+                    const float4 r = *reinterpret_cast<const float4*>(rowp + 4 * k);
+                    sum = sum + r.x;
+                    sum = sum + r.y;
+                    sum = sum + r.z;
+                    sum = sum + r.w;
+                }
+            }
+            s_mean[lane] = sum / (float)fe::kFrame;  // pipeline.rs:116
+        }
+    }
+    __syncthreads();  // tables (and, when FUSED, the means) are in LDS; the PCM tile may now be overwritten
 
     for (int pass = 0; pass < 4; ++pass) {
         const int64_t f = (int64_t)blockIdx.x * 64 + wave * 16 + pass * 4 + g;
         const bool valid = f < num_frames;
-        const float mean = mean_next;
+        const float mean = FUSED ? s_mean[wave * 16 + pass * 4 + g] : mean_next;
 
         // 1./2. scale and mean subtraction (pipeline.rs:90-137): fl(x*32768) is exact, one rounding on the sub
         float v[fe::kQ];
@@ -344,6 +408,7 @@ struct LeleFrontend {
     bool fast = false;
     bool std_mel = false;  // mel bank has the default round structure (fully unrolled kernel variant)
     int dpp_mode = 0;  // 0: __shfl, 1: DPP row_ror (selected after a self-test)
+    bool fused = true;  // frame sums computed inside fe_main_kernel (LELE_HIP_FE_FUSED=0 selects the two-kernel form)
     FeDev dev{};
     std::vector<void*> allocs;
     // optional per-kernel stopwatch (bench.py roofline block): 3 events per run, read back lazily
@@ -509,6 +574,8 @@ int lele_hip_frontend_create(LeleCtx* ctx, const LeleFeatureConfig* cfg, LeleFro
     }
     const char* env = getenv("LELE_HIP_FE_DPP");
     fe->dpp_mode = env ? atoi(env) : 1;  // 1: DPP row_ror (default), 0: __shfl (ds_bpermute)
+    const char* envf = getenv("LELE_HIP_FE_FUSED");
+    fe->fused = envf ? atoi(envf) != 0 : true;
     *out = fe;
     return 0;
 }
@@ -570,20 +637,29 @@ static int fe_run(LeleFrontend* fe, const LeleTensor* pcm, int64_t batch, int64_
         fe->events_used += 3;
         LELE_HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
     }
-    hipLaunchKernelGGL(fe_frame_sum_kernel, grid, dim3(64), 0, ctx->stream, (const float*)dpcm, pcm_len, pcm_len, nf,
-                       (float*)dmean, aligned16);
+    if (!fe->fused)
+        hipLaunchKernelGGL(fe_frame_sum_kernel, grid, dim3(64), 0, ctx->stream, (const float*)dpcm, pcm_len, pcm_len, nf,
+                           (float*)dmean, aligned16);
     if (ev) LELE_HIP_CHECK(hipEventRecord(ev[1], ctx->stream));
     const size_t mel_lds = (size_t)fe->dev.mel_steps * 16 * sizeof(float);
     float* o = want_logmel ? nullptr : (float*)out->data;
     float* lm = want_logmel ? (float*)out->data : nullptr;
-#define FE_LAUNCH(MODE, STD)                                                                                     \
-    hipLaunchKernelGGL((fe_main_kernel<MODE, STD>), grid, dim3(256), mel_lds, ctx->stream, (const float*)dpcm, \
-                       pcm_len, nf, t_lfr, (const float*)dmean, fe->dev, o, lm)
+#define FE_LAUNCH(MODE, STD, FUS)                                                                                     \
+    hipLaunchKernelGGL((fe_main_kernel<MODE, STD, FUS>), grid, dim3(256), mel_lds, ctx->stream, (const float*)dpcm, \
+                       pcm_len, nf, t_lfr, (const float*)dmean, fe->dev, o, lm, aligned16)
+#define FE_LAUNCH2(MODE, STD) \
+    do {                      \
+        if (fe->fused)        \
+            FE_LAUNCH(MODE, STD, true); \
+        else                  \
+            FE_LAUNCH(MODE, STD, false); \
+    } while (0)
     if (fe->dpp_mode == 1) {
-        if (fe->std_mel) FE_LAUNCH(1, true); else FE_LAUNCH(1, false);
+        if (fe->std_mel) FE_LAUNCH2(1, true); else FE_LAUNCH2(1, false);
     } else {
-        if (fe->std_mel) FE_LAUNCH(0, true); else FE_LAUNCH(0, false);
+        if (fe->std_mel) FE_LAUNCH2(0, true); else FE_LAUNCH2(0, false);
     }
+#undef FE_LAUNCH2
 #undef FE_LAUNCH
     LELE_HIP_CHECK(hipGetLastError());
     if (ev) LELE_HIP_CHECK(hipEventRecord(ev[2], ctx->stream));

@@ -41,6 +41,8 @@ def main():
                 pmc.setdefault(short, {})[c + "_KiB_avg"] = sum(v) / len(v)
                 pmc[short]["launches_" + c] = len(v)
     for k, d in pmc.items():
+        if "FETCH_SIZE_KiB_avg" not in d or "WRITE_SIZE_KiB_avg" not in d:
+            continue
         d["read_bytes_corrected"] = int(d["FETCH_SIZE_KiB_avg"] * 1024 * 2)  # gfx950: FETCH_SIZE is half of wide reads
         d["write_bytes"] = int(d["WRITE_SIZE_KiB_avg"] * 1024)
         d["hbm_bytes_per_launch"] = d["read_bytes_corrected"] + d["write_bytes"]
