@@ -249,16 +249,18 @@ struct IgemmEpi {
     }
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BKB /* bytes of K per LDS tile: 64 or 128 */>
 __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const int8_t* __restrict__ a, const int8_t* __restrict__ b,
                                                             int64_t rows, int n, int kp, int64_t b_batch_stride,
                                                             int m_per_batch, IgemmEpi epi) {
     constexpr int NT = WM * WN * 64;
-    constexpr int PITCH = 80;  // bytes
+    constexpr int PITCH = BKB + 16;  // bytes (80 / 144: 16-B aligned rows, 16 distinct bank slots per 16-lane group)
+    constexpr int CQ = BKB / 16;     // 16-B chunks per tile row
     constexpr int TMT = BM / WM / 32, TNT = BN / WN / 32;
-    constexpr int ASLOTS = (BM * 4 + NT - 1) / NT, BSLOTS = (BN * 4 + NT - 1) / NT;  // 16-B chunks per thread
-    __shared__ __attribute__((aligned(16))) char As[2][BM * PITCH];
-    __shared__ __attribute__((aligned(16))) char Bs[2][BN * PITCH];
+    constexpr int ASLOTS = (BM * CQ + NT - 1) / NT, BSLOTS = (BN * CQ + NT - 1) / NT;  // 16-B chunks per thread
+    extern __shared__ __attribute__((aligned(16))) char igemm_lds[];  // As[2][BM*PITCH] then Bs[2][BN*PITCH]
+    char(*As)[BM * PITCH] = reinterpret_cast<char(*)[BM * PITCH]>(igemm_lds);
+    char(*Bs)[BN * PITCH] = reinterpret_cast<char(*)[BN * PITCH]>(igemm_lds + 2 * BM * PITCH);
     __shared__ int s_ca[BM], s_rterm[BM];
     __shared__ float s_ds[BM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -283,8 +285,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const int8_t* __rest
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < ASLOTS; ++i) {
-            const int s = tid + i * NT, row = s >> 2, kq = s & 3;
-            if (s < BM * 4) {
+            const int s = tid + i * NT, row = s / CQ, kq = s % CQ;
+            if (s < BM * CQ) {
                 const int64_t r = m0 + row;
                 const int kb = k0 + 16 * kq;
                 ra[i] = (r < rows && kb < kp) ? *reinterpret_cast<const v4i*>(a + r * kp + kb) : zero4;
@@ -292,8 +294,8 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const int8_t* __rest
         }
 #pragma unroll
         for (int i = 0; i < BSLOTS; ++i) {
-            const int s = tid + i * NT, row = s >> 2, kq = s & 3;
-            if (s < BN * 4) {
+            const int s = tid + i * NT, row = s / CQ, kq = s % CQ;
+            if (s < BN * CQ) {
                 const int c = n0 + row;
                 const int kb = k0 + 16 * kq;
                 rb[i] = (c < n && kb < kp) ? *reinterpret_cast<const v4i*>(bb + (int64_t)c * kp + kb) : zero4;
@@ -304,12 +306,12 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const int8_t* __rest
 #pragma unroll
         for (int i = 0; i < ASLOTS; ++i) {
             const int s = tid + i * NT;
-            if (s < BM * 4) *reinterpret_cast<v4i*>(&As[buf][(s >> 2) * PITCH + 16 * (s & 3)]) = ra[i];
+            if (s < BM * CQ) *reinterpret_cast<v4i*>(&As[buf][(s / CQ) * PITCH + 16 * (s % CQ)]) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < BSLOTS; ++i) {
             const int s = tid + i * NT;
-            if (s < BN * 4) *reinterpret_cast<v4i*>(&Bs[buf][(s >> 2) * PITCH + 16 * (s & 3)]) = rb[i];
+            if (s < BN * CQ) *reinterpret_cast<v4i*>(&Bs[buf][(s / CQ) * PITCH + 16 * (s % CQ)]) = rb[i];
         }
     };
     v16i acc[TMT][TNT];
@@ -320,33 +322,36 @@ __global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const int8_t* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
-    const int nk = (kp + 63) / 64;
+    const int nk = (kp + BKB - 1) / BKB;
     gload(0);
     lstore(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * 64);
-        v4i fa[TMT][2], fb[TNT][2];
+        if (kt + 1 < nk) gload((kt + 1) * BKB);
 #pragma unroll
-        for (int i = 0; i < TMT; ++i) {
-            const char* src = &As[cur][(wm * TMT * 32 + i * 32 + l31) * PITCH + 32 * hv];
-            fa[i][0] = *reinterpret_cast<const v4i*>(src);
-            fa[i][1] = *reinterpret_cast<const v4i*>(src + 16);
+        for (int sub = 0; sub < BKB / 64; ++sub) {  // 64 bytes of K per sub-step (two MFMA steps)
+            v4i fa[TMT][2], fb[TNT][2];
+#pragma unroll
+            for (int i = 0; i < TMT; ++i) {
+                const char* src = &As[cur][(wm * TMT * 32 + i * 32 + l31) * PITCH + sub * 64 + 32 * hv];
+                fa[i][0] = *reinterpret_cast<const v4i*>(src);
+                fa[i][1] = *reinterpret_cast<const v4i*>(src + 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TNT; ++j) {
+                const char* src = &Bs[cur][(wn * TNT * 32 + j * 32 + l31) * PITCH + sub * 64 + 32 * hv];
+                fb[j][0] = *reinterpret_cast<const v4i*>(src);
+                fb[j][1] = *reinterpret_cast<const v4i*>(src + 16);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int i = 0; i < TMT; ++i)
+#pragma unroll
+                    for (int j = 0; j < TNT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < TNT; ++j) {
-            const char* src = &Bs[cur][(wn * TNT * 32 + j * 32 + l31) * PITCH + 32 * hv];
-            fb[j][0] = *reinterpret_cast<const v4i*>(src);
-            fb[j][1] = *reinterpret_cast<const v4i*>(src + 16);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int i = 0; i < TMT; ++i)
-#pragma unroll
-                for (int j = 0; j < TNT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
         if (kt + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
     }
@@ -431,19 +436,30 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
     const int64_t b128 = ((rows + 127) / 128) * ((n + 127) / 128);
     // batched B needs every block to stay inside one batch slice: tiles never straddle slices when BM divides m,
     // otherwise fall back to one launch per slice (handled by the caller passing rows == m)
+#define IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BKB_)                                                                            \
+    do {                                                                                                                  \
+        constexpr size_t lds = (size_t)2 * ((BM_) + (BN_)) * ((BKB_) + 16);                                               \
+        auto kern = igemm_kernel<BM_, BN_, WM_, WN_, BKB_>;                                                               \
+        if (lds > 64 * 1024) {                                                                                            \
+            static bool done = false;                                                                                     \
+            if (!done) {                                                                                                  \
+                LELE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+                done = true;                                                                                              \
+            }                                                                                                             \
+        }                                                                                                                 \
+        dim3 grid((n + (BN_)-1) / (BN_), (unsigned)((rows + (BM_)-1) / (BM_)));                                           \
+        hipLaunchKernelGGL(kern, grid, dim3((WM_) * (WN_) * 64), lds, ctx->stream, aq, wt, rows, n, kp, b_stride,          \
+                           m_per_batch, epi);                                                                             \
+    } while (0)
     if (b128 >= 2 * ctx->num_cus) {
-        dim3 grid((n + 127) / 128, (unsigned)((rows + 127) / 128));
-        hipLaunchKernelGGL((igemm_kernel<128, 128, 2, 2>), grid, dim3(256), 0, ctx->stream, aq, wt, rows, n, kp, b_stride,
-                           m_per_batch, epi);
+        IGEMM_LAUNCH(128, 128, 2, 2, 128);
     } else if (rows <= 32) {
-        dim3 grid((n + 127) / 128, (unsigned)((rows + 31) / 32));
-        hipLaunchKernelGGL((igemm_kernel<32, 128, 1, 4>), grid, dim3(256), 0, ctx->stream, aq, wt, rows, n, kp, b_stride,
-                           m_per_batch, epi);
+        IGEMM_LAUNCH(32, 128, 1, 4, 64);
     } else {
-        dim3 grid((n + 63) / 64, (unsigned)((rows + 63) / 64));
-        hipLaunchKernelGGL((igemm_kernel<64, 64, 2, 2>), grid, dim3(256), 0, ctx->stream, aq, wt, rows, n, kp, b_stride,
-                           m_per_batch, epi);
+        IGEMM_LAUNCH(64, 64, 2, 2, 64);
     }
+#undef IGEMM_LAUNCH
     LELE_HIP_CHECK(hipGetLastError());
     return 0;
 }
