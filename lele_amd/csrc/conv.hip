@@ -19,6 +19,7 @@
 #include "simd_math.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 using namespace lele;
 
@@ -216,6 +217,46 @@ __global__ void conv_transpose_kernel(const float* __restrict__ x, const float* 
         }
         if (bias) acc = acc + bias[o];
         out[i] = acc;
+    }
+}
+
+// conv_transpose as one implicit GEMM per output phase (oy mod sh, ox mod sw): within a phase the contributing taps
+// are a fixed arithmetic progression a = a0 + t*sa (b likewise) and the input row is iy = j + off_a0 - t*da, i.e. a
+// stride-1 convolution with "dilation" -da over the phase's sub-grid.  The k2/s2 upsampling of the YOLO neck is four
+// 1x1 convolutions.  Weights are gathered once per phase into [OC][K_phase] (tap-major when C % 4 == 0).
+struct ConvTEpi {
+    float* out;
+    const float* bias;
+    FastDiv d_ni;
+    int oc, oh, ow, py, px, sh, sw, ni, plane;
+    __device__ __forceinline__ float load(int b, int row, int col) const { return bias ? bias[row] : 0.0f; }
+    __device__ __forceinline__ void store(int b, int row, int col, float acc, float pre) const {
+        if (row >= oc || col >= plane) return;
+        const int j = d_ni.div(col), i = col - j * ni;
+        float v = acc;
+        if (bias) v = v + pre;
+        out[(((int64_t)b * oc + row) * oh + (py + sh * j)) * ow + (px + sw * i)] = v;
+    }
+};
+__global__ void convt_wphase_kernel(const float* __restrict__ w, float* __restrict__ wt, int c, int oc, int kh, int kw,
+                                    int a0, int sa, int na, int b0, int sb, int nb, int tap_major) {
+    const int ntap = na * nb;
+    const int64_t total = (int64_t)oc * c * ntap;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kk = (int)(i % ((int64_t)c * ntap));
+        const int o = (int)(i / ((int64_t)c * ntap));
+        const int tap = tap_major ? kk / c : kk % ntap, ci = tap_major ? kk % c : kk / ntap;
+        const int a = a0 + (tap / nb) * sa, b = b0 + (tap % nb) * sb;
+        wt[i] = w[(((int64_t)ci * oc + o) * kh + a) * kw + b];
+    }
+}
+__global__ void convt_fill_phase_kernel(float* __restrict__ out, const float* __restrict__ bias, int n, int oc, int oh,
+                                        int ow, int py, int px, int sh, int sw, int nj, int ni) {
+    const int64_t total = (int64_t)n * oc * nj * ni;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t % ni), j = (int)((t / ni) % nj);
+        const int64_t no = t / ((int64_t)ni * nj);
+        out[(no * oh + (py + sh * j)) * ow + (px + sw * i)] = bias ? bias[no % oc] : 0.0f;
     }
 }
 
@@ -421,11 +462,94 @@ int lele_hip_conv_transpose(LeleCtx* ctx, const LeleTensor* x, const LeleTensor*
     if (bias) LELE_TRY(ctx->dev_ptr(bias, &db));
     const int64_t total = (int64_t)g.n * g.oc * oh * ow;
     LELE_TRY(out->reserve((size_t)total * 4));
-    if (total) {
+    if (total == 0) return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, oh, ow});
+    if (getenv("LELE_HIP_CONVT_GATHER")) {  // reference gather kernel, kept for A/B checks
         hipLaunchKernelGGL(conv_transpose_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx,
                            (const float*)dwp, (const float*)db, (float*)out->data, g);
         LELE_HIP_CHECK(hipGetLastError());
+        return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, oh, ow});
     }
+    // per-phase weights: one buffer holding every phase's [OC][K_phase] block (each tap belongs to exactly one phase)
+    const size_t wbytes = (size_t)g.c * g.oc * g.kh * g.kw * 4;
+    const int tap_major = g.c % 4 == 0;
+    void* dwt = nullptr;
+    const bool cacheable = w->mem == LELE_MEM_WEIGHT;
+    // the phase structure depends on stride / dilation / pad-begin, so they are part of the cache tag
+    const int tag = 400 + ((g.sh * 31 + g.sw) * 31 + g.dh) * 31 + g.dw + 7919 * (g.pt * 64 + g.pl);
+    auto key = std::make_tuple((const void*)w->data, wbytes, tag);
+    auto it = cacheable ? ctx->weights.find(key) : ctx->weights.end();
+    const bool have_w = it != ctx->weights.end();
+    if (have_w) {
+        dwt = it->second;
+    } else if (cacheable) {
+        LELE_HIP_CHECK(hipMalloc(&dwt, std::max<size_t>(wbytes, 16)));
+        ctx->weights[key] = dwt;
+    } else {
+        LELE_TRY(ctx->arena_alloc(std::max<size_t>(wbytes, 16), &dwt));
+    }
+    auto mod = [](int v, int m) { return ((v % m) + m) % m; };
+    size_t woff = 0;
+    for (int py = 0; py < g.sh; ++py)
+        for (int px = 0; px < g.sw; ++px) {
+            const int nj = py < g.oh ? (g.oh - py + g.sh - 1) / g.sh : 0, ni = px < g.ow ? (g.ow - px + g.sw - 1) / g.sw : 0;
+            int a0 = -1, sa = 1, na = 0, b0 = -1, sb = 1, nb = 0;
+            for (int a = 0; a < g.kh; ++a)
+                if (mod(py + g.pt - a * g.dh, g.sh) == 0) {
+                    if (na == 0) a0 = a;
+                    if (na == 1) sa = a - a0;
+                    ++na;
+                }
+            for (int b = 0; b < g.kw; ++b)
+                if (mod(px + g.pl - b * g.dw, g.sw) == 0) {
+                    if (nb == 0) b0 = b;
+                    if (nb == 1) sb = b - b0;
+                    ++nb;
+                }
+            const int kp = g.c * na * nb;
+            float* wph = (float*)dwt + woff;
+            woff += (size_t)g.oc * kp;
+            if (nj == 0 || ni == 0) continue;
+            if (kp == 0) {  // no tap reaches this phase: bias only
+                hipLaunchKernelGGL(convt_fill_phase_kernel, dim3(grid_for((int64_t)g.n * g.oc * nj * ni)), dim3(256), 0,
+                                   ctx->stream, (float*)out->data, (const float*)db, g.n, g.oc, g.oh, g.ow, py, px, g.sh,
+                                   g.sw, nj, ni);
+                continue;
+            }
+            if (!have_w)
+                hipLaunchKernelGGL(convt_wphase_kernel, dim3(grid_for((int64_t)g.oc * kp)), dim3(256), 0, ctx->stream,
+                                   (const float*)dwp, wph, g.c, g.oc, g.kh, g.kw, a0, sa, na, b0, sb, nb, tap_major);
+            ConvGeom q{};
+            q.n = g.n;
+            q.c = g.c;
+            q.ih = g.ih;
+            q.iw = g.iw;
+            q.oc = g.oc;
+            q.kh = na;
+            q.kw = nb;
+            q.group = 1;
+            q.icg = g.c;
+            q.ocg = g.oc;
+            q.sh = q.sw = 1;
+            q.pt = -((py + g.pt - a0 * g.dh) / g.sh);  // iy = j - pt + t*dh with dh = -(sa*dh/sh)
+            q.pl = -((px + g.pl - b0 * g.dw) / g.sw);
+            q.dh = -(sa * g.dh / g.sh);
+            q.dw = -(sb * g.dw / g.sw);
+            q.oh = nj;
+            q.ow = ni;
+            q.K = kp;
+            q.plane = nj * ni;
+            ConvWLoad al{wph, q, (int)((((uintptr_t)wph & 15) == 0) && kp % 4 == 0)};
+            ConvTEpi epi{(float*)out->data, (const float*)db, make_fastdiv(ni, q.plane), g.oc, g.oh, g.ow, py, px, g.sh, g.sw, ni,
+                         q.plane};
+            if (tap_major) {
+                ConvXLoadTap bl{(const float*)dx, q, make_fastdiv(ni, q.plane), make_fastdiv(g.c, kp), make_fastdiv(nb, na * nb)};
+                gemm::launch(ctx->stream, al, bl, epi, g.oc, q.plane, kp, g.n, ctx->num_cus);
+            } else {
+                ConvXLoad bl{(const float*)dx, q, make_fastdiv(ni, q.plane), make_fastdiv(na * nb, kp), make_fastdiv(nb, na * nb)};
+                gemm::launch(ctx->stream, al, bl, epi, g.oc, q.plane, kp, g.n, ctx->num_cus);
+            }
+        }
+    LELE_HIP_CHECK(hipGetLastError());
     return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, oh, ow});
 }
 

@@ -276,7 +276,10 @@ def test_device_conv_transpose(ctx):
     for xs, ws, pads, strides, dil in [((1, 8, 10, 10), (8, 4, 2, 2), [], [2, 2], []),
                                        ((2, 6, 7, 9), (6, 5, 3, 3), [1, 1, 1, 1], [2, 2], [1, 1]),
                                        ((1, 3, 5, 6), (3, 7, 4, 3), [1, 0, 2, 1], [3, 2], [2, 1]),
-                                       ((1, 16, 20, 20), (16, 16, 3, 3), [1, 1, 1, 1], [1, 1], [1, 1])]:
+                                       ((1, 16, 20, 20), (16, 16, 3, 3), [1, 1, 1, 1], [1, 1], [1, 1]),
+                                       ((1, 4, 5, 5), (4, 3, 1, 1), [], [2, 2], []),          # stride > kernel: bias-only phases
+                                       ((2, 64, 12, 12), (64, 40, 2, 2), [], [2, 2], []),     # the YOLO neck upsampling shape class
+                                       ((1, 5, 6, 7), (5, 6, 3, 5), [0, 2, 1, 0], [2, 3], [3, 2])]:
         x = rng.standard_normal(xs).astype(np.float32)
         w = (rng.standard_normal(ws) * 0.2).astype(np.float32)
         b = rng.standard_normal(ws[1]).astype(np.float32)
