@@ -67,6 +67,20 @@ __global__ void unary_kernel(int op, const float* __restrict__ x, float* __restr
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = unary_apply(op, x[i], i < body_end);
 }
+// 16-byte variant (both pointers 16-B aligned): a float4 never straddles the 8-aligned body/tail boundary
+__global__ void unary_vec4_kernel(int op, const float* __restrict__ x, float* __restrict__ y, int64_t len) {
+    const int64_t body_end = len & ~int64_t(7), nvec = len >> 2;
+    const float4* xv = reinterpret_cast<const float4*>(x);
+    float4* yv = reinterpret_cast<float4*>(y);
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = gtid; i < nvec; i += gstride) {
+        const float4 v = xv[i];
+        const bool body = 4 * i < body_end;
+        yv[i] = make_float4(unary_apply(op, v.x, body), unary_apply(op, v.y, body), unary_apply(op, v.z, body),
+                            unary_apply(op, v.w, body));
+    }
+    for (int64_t i = 4 * nvec + gtid; i < len; i += gstride) y[i] = unary_apply(op, x[i], i < body_end);
+}
 
 // ------------------------------------------------------------------------------------------ binary broadcast
 enum BinaryOp {
@@ -368,8 +382,12 @@ int lele_hip_unary(LeleCtx* ctx, int op, const LeleTensor* x, LeleBuf* out, int6
     LELE_TRY(ctx->dev_ptr(x, &dx));
     LELE_TRY(out->reserve((size_t)len * 4));
     if (len) {
-        hipLaunchKernelGGL(unary_kernel, dim3(grid_for(len)), dim3(256), 0, ctx->stream, op, (const float*)dx,
-                           (float*)out->data, len);
+        if ((((uintptr_t)dx | (uintptr_t)out->data) & 15) == 0)
+            hipLaunchKernelGGL(unary_vec4_kernel, dim3(grid_for((len + 3) / 4)), dim3(256), 0, ctx->stream, op,
+                               (const float*)dx, (float*)out->data, len);
+        else
+            hipLaunchKernelGGL(unary_kernel, dim3(grid_for(len)), dim3(256), 0, ctx->stream, op, (const float*)dx,
+                               (float*)out->data, len);
         LELE_HIP_CHECK(hipGetLastError());
     }
     return set_shape_v(out_shape, out_rank, std::vector<int64_t>(x->shape, x->shape + x->rank));

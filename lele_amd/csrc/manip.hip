@@ -26,16 +26,18 @@ struct CopyDesc {
     int64_t ioff, ooff;
 };
 
-template <typename W>
+// I = int32_t when every index fits (the common case: 32-bit div/mod), int64_t otherwise
+template <typename W, typename I>
 __global__ void strided_copy_kernel(const W* __restrict__ in, W* __restrict__ out, int64_t numel, CopyDesc d) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t rem = i, si = d.ioff, di = d.ooff;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < numel; i0 += (int64_t)gridDim.x * blockDim.x) {
+        I rem = (I)i0, si = (I)d.ioff, di = (I)d.ooff;
         for (int k = d.rank - 1; k >= 0; --k) {
-            int64_t c = rem % d.oshape[k];
-            rem /= d.oshape[k];
-            di += c * d.ostride[k];
-            if (d.imod[k] > 0) c %= d.imod[k];
-            si += c * d.istride[k];
+            const I sh = (I)d.oshape[k];
+            I c = rem % sh;
+            rem /= sh;
+            di += c * (I)d.ostride[k];
+            if (d.imod[k] > 0) c %= (I)d.imod[k];
+            si += c * (I)d.istride[k];
         }
         out[di] = in[si];
     }
@@ -187,16 +189,78 @@ __global__ void cast_kernel(const S* __restrict__ in, D* __restrict__ out, int64
         out[i] = (D)in[i];
 }
 
-inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096)); }
+inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 8192)); }
 
-int launch_copy(LeleCtx* ctx, const void* in, void* out, int64_t numel, const CopyDesc& d, size_t esize) {
+struct Word16 {
+    uint32_t a, b, c, d;
+};
+
+// Canonicalise the descriptor before launching: drop unit dims, merge dims that are contiguous on both sides, move
+// 16-byte words when the innermost dim allows it, and index in 32 bits when everything fits.
+int launch_copy(LeleCtx* ctx, const void* in, void* out, int64_t numel, const CopyDesc& d0, size_t esize) {
     if (numel == 0) return 0;
-    if (esize == 8)
-        hipLaunchKernelGGL(strided_copy_kernel<uint64_t>, dim3(grid_for(numel)), dim3(256), 0, ctx->stream,
-                           (const uint64_t*)in, (uint64_t*)out, numel, d);
-    else
-        hipLaunchKernelGGL(strided_copy_kernel<uint32_t>, dim3(grid_for(numel)), dim3(256), 0, ctx->stream,
-                           (const uint32_t*)in, (uint32_t*)out, numel, d);
+    CopyDesc d{};
+    d.ioff = d0.ioff;
+    d.ooff = d0.ooff;
+    int r = 0;
+    for (int k = 0; k < d0.rank; ++k) {
+        if (d0.oshape[k] == 1) continue;
+        d.oshape[r] = d0.oshape[k];
+        d.istride[r] = d0.istride[k];
+        d.ostride[r] = d0.ostride[k];
+        d.imod[r] = d0.imod[k];
+        ++r;
+    }
+    for (int k = r - 2; k >= 0; --k) {  // merge k with k+1
+        if (d.imod[k] == 0 && d.imod[k + 1] == 0 && d.istride[k] == d.istride[k + 1] * d.oshape[k + 1] &&
+            d.ostride[k] == d.ostride[k + 1] * d.oshape[k + 1]) {
+            d.oshape[k] *= d.oshape[k + 1];
+            d.istride[k] = d.istride[k + 1];
+            d.ostride[k] = d.ostride[k + 1];
+            for (int j = k + 1; j + 1 < r; ++j) {
+                d.oshape[j] = d.oshape[j + 1];
+                d.istride[j] = d.istride[j + 1];
+                d.ostride[j] = d.ostride[j + 1];
+                d.imod[j] = d.imod[j + 1];
+            }
+            --r;
+        }
+    }
+    d.rank = r;
+    // 16-byte words
+    const int64_t v = (int64_t)(16 / esize);
+    bool vec = r >= 1 && d.istride[r - 1] == 1 && d.ostride[r - 1] == 1 && d.imod[r - 1] == 0 && d.oshape[r - 1] % v == 0 &&
+               d.ioff % v == 0 && d.ooff % v == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0;
+    for (int k = 0; vec && k + 1 < r; ++k)
+        vec = d.istride[k] % v == 0 && d.ostride[k] % v == 0;
+    if (vec) {
+        d.oshape[r - 1] /= v;
+        d.ioff /= v;
+        d.ooff /= v;
+        for (int k = 0; k + 1 < r; ++k) {
+            d.istride[k] /= v;
+            d.ostride[k] /= v;
+        }
+        numel /= v;
+    }
+    // 32-bit indexing when every reachable offset fits
+    int64_t imax = d.ioff < 0 ? -d.ioff : d.ioff, omax = d.ooff < 0 ? -d.ooff : d.ooff;
+    for (int k = 0; k < r; ++k) {
+        imax += (d.oshape[k] - 1) * (d.istride[k] < 0 ? -d.istride[k] : d.istride[k]);
+        omax += (d.oshape[k] - 1) * (d.ostride[k] < 0 ? -d.ostride[k] : d.ostride[k]);
+    }
+    const bool i32 = numel < (int64_t(1) << 31) && imax < (int64_t(1) << 31) && omax < (int64_t(1) << 31);
+    const dim3 grid(grid_for(numel)), block(256);
+#define LELE_COPY(W, I) \
+    hipLaunchKernelGGL((strided_copy_kernel<W, I>), grid, block, 0, ctx->stream, (const W*)in, (W*)out, numel, d)
+    if (vec) {
+        if (i32) LELE_COPY(Word16, int32_t); else LELE_COPY(Word16, int64_t);
+    } else if (esize == 8) {
+        if (i32) LELE_COPY(uint64_t, int32_t); else LELE_COPY(uint64_t, int64_t);
+    } else {
+        if (i32) LELE_COPY(uint32_t, int32_t); else LELE_COPY(uint32_t, int64_t);
+    }
+#undef LELE_COPY
     LELE_HIP_CHECK(hipGetLastError());
     return 0;
 }
