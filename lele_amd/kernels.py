@@ -206,7 +206,7 @@ def batch_norm(input, scale, bias, mean, var, epsilon, out=None, ctx=None):  # n
 
 # ------------------------------------------------------------------------------------------- data movement
 def _shape_of(x):
-    if isinstance(x, TensorView):
+    if isinstance(x, (TensorView, _lib.Weight)):
         return tuple(x.shape)
     x = unwrap(x)
     return tuple(x.shape) if isinstance(x, _lib.DevTensor) else tuple(np.asarray(x).shape)
@@ -214,6 +214,8 @@ def _shape_of(x):
 
 def _dtype_of(x):
     x = unwrap(x)
+    if isinstance(x, _lib.Weight):
+        return x.arr.dtype
     if isinstance(x, _lib.DevTensor):
         return x.dtype
     a = np.asarray(x)
