@@ -50,6 +50,7 @@ typedef struct LeleTensor {
 typedef struct LeleCtx LeleCtx;
 typedef struct LeleBuf LeleBuf;
 typedef struct LeleFrontend LeleFrontend;
+typedef struct LeleGraph LeleGraph;
 
 /* ---- context / memory ------------------------------------------------------------------------------ */
 const char* lele_hip_last_error(void);
@@ -58,6 +59,17 @@ int lele_hip_ctx_create(int device, LeleCtx** out);
 int lele_hip_ctx_destroy(LeleCtx* ctx);
 int lele_hip_sync(LeleCtx* ctx);
 void* lele_hip_ctx_stream(LeleCtx* ctx); /* hipStream_t */
+/* hipGraph capture of an op sequence.  lele's generated forward() is a fixed sequence of kernel calls per input shape
+ * (src/compiler/mod.rs:1291-1303); at SenseVoice's token counts every call is launch-latency bound, so the sequence is
+ * recorded once and replayed as ONE graph launch.  Between begin and end every lele_hip_* op on this ctx is recorded
+ * instead of executed; ops must not allocate, grow a LeleBuf, synchronise, or take LELE_MEM_HOST inputs while
+ * capturing (they return an error) -- run the sequence once eagerly first, with the same buffers and shapes.  Replays
+ * read and write the same device buffers as the recorded calls. */
+int lele_hip_graph_begin(LeleCtx* ctx);
+int lele_hip_graph_end(LeleCtx* ctx, LeleGraph** out);
+int lele_hip_graph_abort(LeleCtx* ctx);
+int lele_hip_graph_launch(LeleGraph* graph);
+int lele_hip_graph_destroy(LeleGraph* graph);
 /* stream-ordered stopwatch (HIP events on the ctx stream) used by bench.py */
 int lele_hip_timer_start(LeleCtx* ctx);
 int lele_hip_timer_stop(LeleCtx* ctx, float* elapsed_ms);

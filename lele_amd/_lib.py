@@ -101,6 +101,21 @@ class Ctx:
         check(lib().lele_hip_timer_stop(self._h, C.byref(ms)))
         return ms.value
 
+    def graph_begin(self):
+        """start recording every op issued on this ctx into a hipGraph (see include/lele_hip.h)"""
+        check(lib().lele_hip_graph_begin(self._h))
+
+    def graph_end(self):
+        h = C.c_void_p()
+        rc = lib().lele_hip_graph_end(self._h, C.byref(h))
+        if rc != 0:
+            lib().lele_hip_graph_abort(self._h)
+        check(rc)
+        return Graph(self, h)
+
+    def graph_abort(self):
+        lib().lele_hip_graph_abort(self._h)
+
     def buf(self):
         b = Buf(self)
         self._bufs.append(b)
@@ -137,6 +152,27 @@ class Buf:
         out = np.empty(shape, dtype)
         check(lib().lele_hip_buf_to_host(self._h, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)))
         return out
+
+
+class Graph:
+    """A captured op sequence; launch() replays it on the ctx stream with one hipGraphLaunch."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self._h = ctx, h
+
+    def launch(self):
+        check(lib().lele_hip_graph_launch(self._h))
+
+    def close(self):
+        if self._h:
+            lib().lele_hip_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DevTensor:

@@ -72,12 +72,20 @@ struct LeleCtx {
     // scratch that ops may keep across calls (grown on demand)
     void* scratch = nullptr;
     size_t scratch_cap = 0;
+    // true between lele_hip_graph_begin / _end: every launch on `stream` is being recorded into a hipGraph, so nothing
+    // may allocate, free, synchronise or touch pageable host memory (the guards return an error instead)
+    bool capturing = false;
 
     int arena_reset();
     int arena_alloc(size_t bytes, void** out);
     int get_scratch(size_t bytes, void** out);
     // Returns a device pointer for tensor t (uploads host data through the arena / weight cache).
     int dev_ptr(const LeleTensor* t, const void** out);
+};
+
+struct LeleGraph {
+    LeleCtx* ctx = nullptr;
+    hipGraphExec_t exec = nullptr;
 };
 
 struct LeleBuf {

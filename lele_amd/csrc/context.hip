@@ -20,6 +20,7 @@ using namespace lele;
 int LeleCtx::arena_reset() {
     arena_used = 0;
     if (!arena_overflow.empty()) {
+        LELE_REQUIRE(!capturing, "graph capture: the staging arena overflowed in the op before capture began; sync first");
         // the previous op's kernels may still read the overflow blocks: drain before freeing
         LELE_HIP_CHECK(hipStreamSynchronize(stream));
         for (void* p : arena_overflow) (void)hipFree(p);
@@ -35,6 +36,7 @@ int LeleCtx::arena_alloc(size_t bytes, void** out) {
         arena_used += need;
         return 0;
     }
+    LELE_REQUIRE(!capturing, "graph capture: an op needs %zu bytes of scratch beyond the %zu-byte arena", need, arena_cap);
     void* p = nullptr;
     LELE_HIP_CHECK(hipMalloc(&p, need ? need : 256));
     arena_overflow.push_back(p);
@@ -44,6 +46,7 @@ int LeleCtx::arena_alloc(size_t bytes, void** out) {
 
 int LeleCtx::get_scratch(size_t bytes, void** out) {
     if (bytes > scratch_cap) {
+        LELE_REQUIRE(!capturing, "graph capture: scratch would grow; run the sequence once before capturing it");
         LELE_HIP_CHECK(hipStreamSynchronize(stream));
         if (scratch) (void)hipFree(scratch);
         scratch = nullptr;
@@ -73,6 +76,7 @@ int LeleCtx::dev_ptr(const LeleTensor* t, const void** out) {
             *out = it->second;
             return 0;
         }
+        LELE_REQUIRE(!capturing, "graph capture: weight %p is not cached yet; run the sequence once before capturing it", t->data);
         void* d = nullptr;
         LELE_HIP_CHECK(hipMalloc(&d, bytes));
         LELE_HIP_CHECK(hipMemcpyAsync(d, t->data, bytes, hipMemcpyHostToDevice, stream));
@@ -81,6 +85,7 @@ int LeleCtx::dev_ptr(const LeleTensor* t, const void** out) {
         *out = d;
         return 0;
     }
+    LELE_REQUIRE(!capturing, "graph capture: LELE_MEM_HOST inputs cannot be captured; pass device tensors or weights");
     void* d = nullptr;
     LELE_TRY(arena_alloc(bytes, &d));
     // pageable host memory: hipMemcpyAsync stages it before returning, so the caller may reuse `data` at once
@@ -91,6 +96,7 @@ int LeleCtx::dev_ptr(const LeleTensor* t, const void** out) {
 
 int LeleBuf::reserve(size_t n) {
     if (n > cap) {
+        LELE_REQUIRE(!ctx->capturing, "graph capture: an output buffer would grow; run the sequence once before capturing it");
         LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (data) (void)hipFree(data);
         data = nullptr;
@@ -146,11 +152,63 @@ int lele_hip_ctx_destroy(LeleCtx* c) {
 
 int lele_hip_sync(LeleCtx* c) {
     LELE_REQUIRE(c, "sync: ctx is NULL");
+    LELE_REQUIRE(!c->capturing, "sync: not allowed while a graph is being captured");
     LELE_HIP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
 void* lele_hip_ctx_stream(LeleCtx* c) { return c ? (void*)c->stream : nullptr; }
+
+/* ---- hipGraph capture of an op sequence -------------------------------------------------------------------------- */
+int lele_hip_graph_begin(LeleCtx* c) {
+    LELE_REQUIRE(c, "graph_begin: ctx is NULL");
+    LELE_REQUIRE(!c->capturing, "graph_begin: a capture is already in progress");
+    LELE_HIP_CHECK(hipSetDevice(c->device));
+    LELE_TRY(c->arena_reset());  // frees any overflow blocks now, while synchronising is still legal
+    LELE_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    c->capturing = true;
+    return 0;
+}
+int lele_hip_graph_end(LeleCtx* c, LeleGraph** out) {
+    LELE_REQUIRE(c && out, "graph_end: NULL argument");
+    LELE_REQUIRE(c->capturing, "graph_end: no capture in progress");
+    c->capturing = false;
+    hipGraph_t g = nullptr;
+    LELE_HIP_CHECK(hipStreamEndCapture(c->stream, &g));
+    LELE_REQUIRE(g != nullptr, "graph_end: the capture was invalidated (an op allocated or synchronised)");
+    hipGraphExec_t e = nullptr;
+    hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    LELE_HIP_CHECK(rc);
+    LeleGraph* lg = new LeleGraph();
+    lg->ctx = c;
+    lg->exec = e;
+    *out = lg;
+    return 0;
+}
+int lele_hip_graph_abort(LeleCtx* c) {  // leave capture mode after a failed op, discarding what was recorded
+    LELE_REQUIRE(c, "graph_abort: ctx is NULL");
+    if (!c->capturing) return 0;
+    c->capturing = false;
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(c->stream, &g);
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    return 0;
+}
+int lele_hip_graph_launch(LeleGraph* g) {
+    LELE_REQUIRE(g && g->exec, "graph_launch: graph is NULL");
+    LELE_REQUIRE(!g->ctx->capturing, "graph_launch: not allowed while capturing");
+    LELE_HIP_CHECK(hipGraphLaunch(g->exec, g->ctx->stream));
+    return 0;
+}
+int lele_hip_graph_destroy(LeleGraph* g) {
+    if (!g) return 0;
+    (void)hipStreamSynchronize(g->ctx->stream);
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    delete g;
+    return 0;
+}
 
 int lele_hip_timer_start(LeleCtx* c) {
     LELE_HIP_CHECK(hipEventRecord(c->ev0, c->stream));

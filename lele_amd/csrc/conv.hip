@@ -295,6 +295,7 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
                 dwt = it->second;
             } else {
                 if (cacheable) {
+                    LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
                     LELE_HIP_CHECK(hipMalloc(&dwt, wbytes));
                     ctx->weights[key] = dwt;
                 } else {
@@ -482,6 +483,7 @@ int lele_hip_conv_transpose(LeleCtx* ctx, const LeleTensor* x, const LeleTensor*
     if (have_w) {
         dwt = it->second;
     } else if (cacheable) {
+        LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
         LELE_HIP_CHECK(hipMalloc(&dwt, std::max<size_t>(wbytes, 16)));
         ctx->weights[key] = dwt;
     } else {

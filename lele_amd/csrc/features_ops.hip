@@ -153,9 +153,13 @@ int get_fft_tables(LeleCtx* ctx, int64_t n, FftTables* out) {
         re.push_back(0.f);
         im.push_back(0.f);
         void *dre = nullptr, *dim = nullptr;
+        LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
         LELE_HIP_CHECK(hipMalloc(&dre, re.size() * 4));
+        LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
         LELE_HIP_CHECK(hipMalloc(&dim, im.size() * 4));
+        LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
         LELE_HIP_CHECK(hipMemcpy(dre, re.data(), re.size() * 4, hipMemcpyHostToDevice));
+        LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
         LELE_HIP_CHECK(hipMemcpy(dim, im.data(), im.size() * 4, hipMemcpyHostToDevice));
         ctx->weights[key_re] = dre;
         ctx->weights[key_im] = dim;
@@ -217,6 +221,7 @@ int stft_common(LeleCtx* ctx, const LeleTensor* signal, int64_t n_fft, int64_t h
         void* d = nullptr;
         LELE_TRY(ctx->arena_alloc(win_length * 4, &d));
         LELE_HIP_CHECK(hipMemcpyAsync(d, w.data(), win_length * 4, hipMemcpyHostToDevice, ctx->stream));
+        LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
         LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));  // w is a local
         dwin = (const float*)d;
     }

@@ -397,7 +397,9 @@ int get_packed_weights(LeleCtx* ctx, const LeleTensor* w, const float* dw, int64
     }
     void *dwt = nullptr, *dcs = nullptr;
     if (cacheable) {
+        LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
         LELE_HIP_CHECK(hipMalloc(&dwt, (size_t)nbatch * n * kp));
+        LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
         LELE_HIP_CHECK(hipMalloc(&dcs, (size_t)nbatch * n * 4));
         ctx->weights[key_w] = dwt;
         ctx->weights[key_s] = dcs;
@@ -502,6 +504,7 @@ int lele_hip_fused_quantized_linear(LeleCtx* ctx, const LeleTensor* input, const
     if (weight_zero && numel(weight_zero) > 0) {
         if (weight_zero->mem == LELE_MEM_DEVICE) {
             LELE_HIP_CHECK(hipMemcpyAsync(&wz, weight_zero->data, 4, hipMemcpyDeviceToHost, ctx->stream));
+            LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
             LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         } else {
             wz = *(const float*)weight_zero->data;
@@ -545,6 +548,7 @@ int lele_hip_dynamic_quantize_linear(LeleCtx* ctx, const LeleTensor* x, LeleBuf*
         const float one = 1.0f, zero = 0.0f;
         LELE_HIP_CHECK(hipMemcpyAsync(out_scale->data, &one, 4, hipMemcpyHostToDevice, ctx->stream));
         LELE_HIP_CHECK(hipMemcpyAsync(out_zp->data, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+        LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
         LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         return set_shape_v(out_shape, out_rank, shp);
     }
@@ -592,6 +596,7 @@ int lele_hip_mat_mul_integer_with_scale_bias(LeleCtx* ctx, const LeleTensor* a, 
         float f = 0.0f;
         if (t->mem == LELE_MEM_DEVICE) {
             LELE_HIP_CHECK(hipMemcpyAsync(&f, t->data, 4, hipMemcpyDeviceToHost, ctx->stream));
+            LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
             LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         } else {
             f = *(const float*)t->data;

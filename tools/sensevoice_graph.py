@@ -164,12 +164,28 @@ def main():
             logits = enc.forward(frontend())
             ctx.sync()
             t_all.append(time.perf_counter() - t0)
+        # the same call sequence recorded once and replayed as one hipGraph launch (lele_hip_graph_*)
+        t_graph = []
+        ctx.sync()
+        ctx.graph_begin()
+        logits = enc.forward(feats)
+        graph = ctx.graph_end()
+        graph.launch()
+        ctx.sync()
+        for _ in range(args.runs):
+            ctx.sync()
+            t0 = time.perf_counter()
+            graph.launch()
+            ctx.sync()
+            t_graph.append(time.perf_counter() - t0)
         audio = batch * seconds
         lg = logits.numpy()
         rec = {"config": name, "batch": batch, "seconds_per_utterance": seconds, "layers": args.layers,
                "tokens": int(lg.shape[1]), "logits_shape": list(lg.shape), "finite": bool(np.isfinite(lg).all()),
                "model_ms": round(1e3 * float(np.mean(t_model)), 3), "frontend_plus_model_ms": round(1e3 * float(np.mean(t_all)), 3),
                "rtf_model": round(float(np.mean(t_model)) / audio, 6), "rtf_total": round(float(np.mean(t_all)) / audio, 6),
+               "model_graph_ms": round(1e3 * float(np.mean(t_graph)), 3),
+               "rtf_model_graph": round(float(np.mean(t_graph)) / audio, 6),
                "note": "assumed topology, synthetic weights, every node a separate C-ABI call issued from Python"}
         print(json.dumps(rec), flush=True)
         results.append(rec)
