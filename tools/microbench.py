@@ -114,7 +114,7 @@ def main():
         w = Weight(f32(64, 64, 2, 2, scale=0.1))
         ms = timeit(lambda o: K.conv_transpose(x, w, None, [1, 1], 1, [0, 0, 0, 0], [2, 2], out=o, ctx=ctx), 3)
         record("conv_transpose", [nb, 64, 80, 80, 64, 2, 2], ms, 2.0 * nb * 64 * 64 * 4 * 80 * 80,
-               4.0 * nb * 64 * (80 * 80 + 160 * 160), "mfma_f32", "direct gather kernel (not on MFMA yet)")
+               4.0 * nb * 64 * (80 * 80 + 160 * 160), "mfma_f32", "one implicit GEMM per output phase")
 
     # ---- Conv1d (a8): FSMN depthwise k=11 and the Silero STFT-as-conv
     if want('conv1d'):

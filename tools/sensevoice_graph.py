@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--runs", type=int, default=10)
     ap.add_argument("--out", default=None)
     ap.add_argument("--configs", default="c3,c4")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph leg (rocprofv3 cannot trace captures)")
     args = ap.parse_args()
     import lele_amd
     from lele_amd import kernels as K
@@ -165,14 +166,15 @@ def main():
             ctx.sync()
             t_all.append(time.perf_counter() - t0)
         # the same call sequence recorded once and replayed as one hipGraph launch (lele_hip_graph_*)
-        t_graph = []
+        t_graph = [float("nan")] if args.no_graph else []
         ctx.sync()
-        ctx.graph_begin()
-        logits = enc.forward(feats)
-        graph = ctx.graph_end()
-        graph.launch()
-        ctx.sync()
-        for _ in range(args.runs):
+        if not args.no_graph:
+            ctx.graph_begin()
+            logits = enc.forward(feats)
+            graph = ctx.graph_end()
+            graph.launch()
+            ctx.sync()
+        for _ in range(0 if args.no_graph else args.runs):
             ctx.sync()
             t0 = time.perf_counter()
             graph.launch()
