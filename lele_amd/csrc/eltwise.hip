@@ -258,6 +258,120 @@ __device__ __forceinline__ void row_sums(const F& elem, int64_t n, int l, float*
     *out_sq = __shfl(qv, 0, 32);
 }
 
+// Register-resident form of row_sums for rows of at most 32*NT elements: lane l holds v[c] = row[32c + l].  The same
+// additions in the same order as row_sums (so the same bits); elements another lane owns (the 8-wide remainder chunks
+// and the scalar tail) arrive by __shfl instead of a second trip to memory.
+template <int NT, bool SQUARE, bool PLAIN>
+__device__ __forceinline__ void row_sums_reg(const float (&v)[NT], int n, int l, float* out_sum, float* out_sq) {
+    float s = 0.0f, q = 0.0f;
+    const int nfull = n >> 5;
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+        if (c < nfull) {
+            if (PLAIN) s = s + v[c];
+            if (SQUARE) q = fmaf_(v[c], v[c], q);
+        }
+    float s01 = s + __shfl_down(s, 8, 32), q01 = q + __shfl_down(q, 8, 32);
+    float sv = s01 + __shfl_down(s01, 16, 32), qv = q01 + __shfl_down(q01, 16, 32);
+    float last = 0.0f;  // the partially filled register row v[nfull]
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+        if (c == nfull) last = v[c];
+    const int rem = n - 32 * nfull, nch = rem >> 3;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        if (r < nch) {
+            const float got = __shfl(last, 8 * r + (l & 7), 32);
+            if (l < 8) {
+                if (PLAIN) sv = sv + got;
+                if (SQUARE) qv = fmaf_(got, got, qv);
+            }
+        }
+    sv = sv + __shfl_down(sv, 4, 32);
+    qv = qv + __shfl_down(qv, 4, 32);
+    sv = sv + __shfl_down(sv, 2, 32);
+    qv = qv + __shfl_down(qv, 2, 32);
+    sv = sv + __shfl_down(sv, 1, 32);
+    qv = qv + __shfl_down(qv, 1, 32);
+#pragma unroll
+    for (int t = 0; t < 7; ++t)
+        if (t < (rem & 7)) {
+            const float got = __shfl(last, 8 * nch + t, 32);
+            if (PLAIN) sv = sv + got;
+            if (SQUARE) qv = qv + got * got;
+        }
+    *out_sum = __shfl(sv, 0, 32);
+    *out_sq = __shfl(qv, 0, 32);
+}
+
+// One trip to memory per element: the row lives in registers between the statistics and the output pass.
+// RPB rows per block (32 lanes each); NT = ceil(norm / 32) rounded up to the instantiated sizes.
+template <int NT>
+__global__ void layer_norm_reg_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                      const float* __restrict__ b, float* __restrict__ y, int norm, int64_t outer,
+                                      float eps) {
+    const int l = threadIdx.x & 31;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    if (row >= outer) return;
+    const float* in = x + row * norm;
+    float* out = y + row * norm;
+    float v[NT], gg[NT], bb[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int j = 32 * c + l, jc = j < norm ? j : norm - 1;  // clamped, unconditional: all loads in flight together
+        v[c] = in[jc];
+        gg[c] = g[jc];
+        bb[c] = b[jc];
+    }
+    float sum, sumsq;
+    row_sums_reg<NT, true, true>(v, norm, l, &sum, &sumsq);
+    const float inv_n = 1.0f / (float)norm;
+    const float mean = sum * inv_n;
+    const float var = sumsq * inv_n - mean * mean;
+    const float inv_std = 1.0f / sqrtf(var + eps);
+    const int body = norm & ~7;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int j = 32 * c + l;
+        if (j < norm) {
+            const float t = (v[c] - mean) * inv_std;
+            out[j] = j < body ? fmaf_(t, gg[c], bb[c]) : t * gg[c] + bb[c];
+        }
+    }
+}
+
+template <int NT>
+__global__ void softmax_reg_kernel(const float* __restrict__ x, float* __restrict__ y, int len, int64_t outer) {
+    const int l = threadIdx.x & 31;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
+    if (row >= outer) return;
+    const float* src = x + row * len;
+    float* dst = y + row * len;
+    float v[NT];
+    float m = -3.40282347e+38f;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int j = 32 * c + l;
+        v[c] = src[j < len ? j : len - 1];
+        if (j < len) m = fmaxf(m, v[c]);
+    }
+    for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+    const int body = len & ~7;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int j = 32 * c + l;
+        v[c] = j < body ? exp_poly(v[c] - m) : expf(v[c] - m);  // computed once, reused for the sum and the output
+    }
+    float sum, dummy;
+    row_sums_reg<NT, false, true>(v, len, l, &sum, &dummy);
+    const float inv_sum = 1.0f / sum;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        const int j = 32 * c + l;
+        if (j < len) dst[j] = v[c] * inv_sum;
+    }
+}
+
 // layer_norm_x86, avx/norm.rs:10-133.  8 rows per 256-thread block (one 32-lane group per row).
 __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                          const float* __restrict__ b, float* __restrict__ y,
@@ -535,6 +649,19 @@ int lele_hip_layer_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* sca
     LELE_TRY(ctx->dev_ptr(bias, &db));
     LELE_TRY(out->reserve((size_t)outer * norm * 4));
     if (outer * norm) {
+        // rows that fit 32 registers per lane take the single-pass kernel; few rows -> fewer rows per block (more CUs)
+        const int rpb = outer >= 4096 ? 8 : (outer >= 1024 ? 4 : 2);
+        const dim3 rgrid((unsigned)((outer + rpb - 1) / rpb)), rblock(32 * rpb);
+        if (norm <= 256)
+            hipLaunchKernelGGL(layer_norm_reg_kernel<8>, rgrid, rblock, 0, ctx->stream, (const float*)dx, (const float*)dg,
+                               (const float*)db, (float*)out->data, (int)norm, outer, epsilon);
+        else if (norm <= 512)
+            hipLaunchKernelGGL(layer_norm_reg_kernel<16>, rgrid, rblock, 0, ctx->stream, (const float*)dx, (const float*)dg,
+                               (const float*)db, (float*)out->data, (int)norm, outer, epsilon);
+        else if (norm <= 1024)
+            hipLaunchKernelGGL(layer_norm_reg_kernel<32>, rgrid, rblock, 0, ctx->stream, (const float*)dx, (const float*)dg,
+                               (const float*)db, (float*)out->data, (int)norm, outer, epsilon);
+        else
         hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)((outer + 7) / 8)), dim3(256), 0, ctx->stream,
                            (const float*)dx, (const float*)dg, (const float*)db, (float*)out->data, norm, outer, epsilon);
         LELE_HIP_CHECK(hipGetLastError());
@@ -583,6 +710,18 @@ int lele_hip_softmax(LeleCtx* ctx, const LeleTensor* x, int32_t axis, LeleBuf* o
     LELE_TRY(ctx->dev_ptr(x, &dx));
     LELE_TRY(out->reserve((size_t)outer * len * 4));
     if (outer * len) {
+        const int rpb = outer >= 4096 ? 8 : (outer >= 1024 ? 4 : 2);
+        const dim3 rgrid((unsigned)((outer + rpb - 1) / rpb)), rblock(32 * rpb);
+        if (len <= 256)
+            hipLaunchKernelGGL(softmax_reg_kernel<8>, rgrid, rblock, 0, ctx->stream, (const float*)dx, (float*)out->data,
+                               (int)len, outer);
+        else if (len <= 512)
+            hipLaunchKernelGGL(softmax_reg_kernel<16>, rgrid, rblock, 0, ctx->stream, (const float*)dx, (float*)out->data,
+                               (int)len, outer);
+        else if (len <= 1024)
+            hipLaunchKernelGGL(softmax_reg_kernel<32>, rgrid, rblock, 0, ctx->stream, (const float*)dx, (float*)out->data,
+                               (int)len, outer);
+        else
         hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((outer + 7) / 8)), dim3(256), 0, ctx->stream,
                            (const float*)dx, (float*)out->data, len, outer);
         LELE_HIP_CHECK(hipGetLastError());
