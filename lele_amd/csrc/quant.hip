@@ -18,6 +18,7 @@
 // [N, Kpad] (w - 128) with column sums and cached per (pointer, bytes) -- the analogue of B_WEIGHT_CACHE
 // (avx/quantization.rs:12-95).
 #include "common.h"
+#include "gemm_small.h"
 
 #include <math.h>
 
@@ -80,6 +81,23 @@ __global__ __launch_bounds__(256) void qminmax_kernel(const float* __restrict__ 
     }
 }
 
+// avx/quantization.rs:134-140: range -> {scale, zero point, 1/scale}
+__device__ __forceinline__ QParams make_qparams(float mn, float mx) {
+    const float adjusted_max = mx > 0.0f ? mx : 0.0f;
+    const float adjusted_min = mn < 0.0f ? mn : 0.0f;
+    float range = adjusted_max - adjusted_min;
+    if (!(range > 1e-5f)) range = 1e-5f;
+    const float scale = range / 255.0f;
+    float z = roundf(-adjusted_min / scale);  // f32::round (half away from zero)
+    z = z < 0.0f ? 0.0f : (z > 255.0f ? 255.0f : z);
+    QParams q;
+    q.scale = scale;
+    q.zp = z;
+    q.inv_scale = 1.0f / scale;
+    q.zp_i = (int)z;
+    return q;
+}
+
 __global__ void qparams_kernel(const float* __restrict__ partial, int nblocks, QParams* __restrict__ prm,
                                float* __restrict__ scale_out, float* __restrict__ zp_out) {
     const int s = blockIdx.x;
@@ -94,22 +112,11 @@ __global__ void qparams_kernel(const float* __restrict__ partial, int nblocks, Q
         mn = a < mn ? a : mn;
         mx = b > mx ? b : mx;
     }
-    if (threadIdx.x == 0) {  // avx/quantization.rs:134-140
-        const float adjusted_max = mx > 0.0f ? mx : 0.0f;
-        const float adjusted_min = mn < 0.0f ? mn : 0.0f;
-        float range = adjusted_max - adjusted_min;
-        if (!(range > 1e-5f)) range = 1e-5f;
-        const float scale = range / 255.0f;
-        float z = roundf(-adjusted_min / scale);  // f32::round (half away from zero)
-        z = z < 0.0f ? 0.0f : (z > 255.0f ? 255.0f : z);
-        QParams q;
-        q.scale = scale;
-        q.zp = z;
-        q.inv_scale = 1.0f / scale;
-        q.zp_i = (int)z;
+    if (threadIdx.x == 0) {
+        const QParams q = make_qparams(mn, mx);
         prm[s] = q;
-        if (scale_out) scale_out[s] = scale;
-        if (zp_out) zp_out[s] = z;
+        if (scale_out) scale_out[s] = q.scale;
+        if (zp_out) zp_out[s] = q.zp;
     }
 }
 
@@ -123,15 +130,39 @@ __device__ __forceinline__ float quant_one(float v, const QParams& q, bool simd_
 // MODE 0: dynamic quantisation with prm[row / m] (fused linear: SIMD body = first k&~7 elements of EACH ROW)
 // MODE 1: the input already holds u8 values as f32 (mat_mul_integer): q = sat_u8(round-nearest-even(x))
 // One wave per row; writes q-128 as i8 into [rows][kp] (zero padded = contributes 0) and the exact sum of (q-128).
+// MODE 0 with `partial` != NULL: the slice's {scale, zp} are derived here from the min/max partials (every wave
+// repeats the same few-hundred-element reduction, which is cheaper than a separate launch) and the first row of each
+// slice publishes them to prm[] for the GEMM epilogue.
 template <int MODE>
 __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x, int64_t rows, int k, int kp, int m,
-                                                    const QParams* __restrict__ prm, int8_t* __restrict__ aq,
-                                                    int* __restrict__ row_sums) {
+                                                    QParams* __restrict__ prm, int8_t* __restrict__ aq,
+                                                    int* __restrict__ row_sums, const float* __restrict__ partial,
+                                                    int nblk) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     QParams q;
-    if (MODE == 0) q = prm[row / m];
+    if (MODE == 0) {
+        const int64_t slice = row / m;
+        if (partial) {
+            float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+            const float* pp = partial + slice * nblk * 2;
+            for (int i = lane; i < nblk; i += 64) {
+                const float a = pp[2 * i], b = pp[2 * i + 1];
+                mn = a < mn ? a : mn;
+                mx = b > mx ? b : mx;
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const float a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
+                mn = a < mn ? a : mn;
+                mx = b > mx ? b : mx;
+            }
+            q = make_qparams(mn, mx);
+            if (lane == 0 && row == slice * m) prm[slice] = q;
+        } else {
+            q = prm[slice];
+        }
+    }
     const float* xr = x + row * k;
     int8_t* dst = aq + row * kp;
     const int simd_k = k & ~7;
@@ -416,17 +447,24 @@ int get_packed_weights(LeleCtx* ctx, const LeleTensor* w, const float* dw, int64
     return 0;
 }
 
+// fused != NULL: only the min/max partials are produced (at most 256 per slice); *fused / *fused_nblk receive them and the
+// caller's qrows_kernel<0> turns them into parameters -- one launch fewer on the latency-bound path.
 int launch_range(LeleCtx* ctx, const float* dx, int64_t slices, int64_t slice_len, QParams* prm, float* scale_out,
-                 float* zp_out) {
+                 float* zp_out, const float** fused = nullptr, int* fused_nblk = nullptr) {
     // enough blocks to fill 256 CUs x 4 even for one slice; every thread then streams >= 4 float4
     const int64_t want = (slice_len + 4095) / 4096;
-    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, 1024 / slices), want));
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, (fused ? 256 : 1024) / slices), want));
     void* partial = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)slices * nblk * 8, &partial));
     hipLaunchKernelGGL(qminmax_kernel, dim3(nblk, (unsigned)slices), dim3(256), 0, ctx->stream, dx, slice_len,
                        (float*)partial);
-    hipLaunchKernelGGL(qparams_kernel, dim3((unsigned)slices), dim3(64), 0, ctx->stream, (const float*)partial, nblk,
-                       prm, scale_out, zp_out);
+    if (fused) {
+        *fused = (const float*)partial;
+        *fused_nblk = nblk;
+    } else {
+        hipLaunchKernelGGL(qparams_kernel, dim3((unsigned)slices), dim3(64), 0, ctx->stream, (const float*)partial, nblk,
+                           prm, scale_out, zp_out);
+    }
     LELE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -454,7 +492,13 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
         hipLaunchKernelGGL(kern, grid, dim3((WM_) * (WN_) * 64), lds, ctx->stream, aq, wt, rows, n, kp, b_stride,          \
                            m_per_batch, epi);                                                                             \
     } while (0)
-    if (b128 >= 2 * ctx->num_cus) {
+    const int64_t b64 = ((rows + 63) / 64) * ((n + 63) / 64);
+    if (b64 < 2 * (int64_t)ctx->num_cus) {
+        // small problem (SenseVoice at M = 504): 32x32 tiles, K split over the four waves, operands straight from L2
+        dim3 grid((unsigned)((n + 31) / 32), (unsigned)((rows + 31) / 32));
+        hipLaunchKernelGGL((gemm::igemm_small_kernel<IgemmEpi>), grid, dim3(256), 0, ctx->stream, aq, wt, rows, n, kp, b_stride,
+                           m_per_batch, epi);
+    } else if (b128 >= 2 * ctx->num_cus) {
         IGEMM_LAUNCH(128, 128, 2, 2, 128);
     } else if (rows <= 32) {
         IGEMM_LAUNCH(32, 128, 1, 4, 64);
@@ -526,9 +570,11 @@ int lele_hip_fused_quantized_linear(LeleCtx* ctx, const LeleTensor* input, const
     LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm));
     LELE_TRY(ctx->arena_alloc((size_t)rows * kp, &aq));
     LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));
-    LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr));
+    const float* partial = nullptr;
+    int nblk = 0;
+    LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
     hipLaunchKernelGGL(qrows_kernel<0>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
-                       rows, (int)k, kp, (int)m, (const QParams*)prm, (int8_t*)aq, (int*)rs);
+                       rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk);
     IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, (const int*)rs, pw.col_sums, (const QParams*)prm, 0,
                  (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu};
     LELE_TRY(launch_igemm(ctx, (const int8_t*)aq, pw.wt, rows, (int)n, kp, 0, (int)m, epi));
@@ -626,7 +672,7 @@ int lele_hip_mat_mul_integer_with_scale_bias(LeleCtx* ctx, const LeleTensor* a, 
     LELE_TRY(ctx->arena_alloc((size_t)rows_a * kp, &aq));
     LELE_TRY(ctx->arena_alloc((size_t)rows_a * 4, &rs));
     hipLaunchKernelGGL(qrows_kernel<1>, dim3((unsigned)((rows_a + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)da,
-                       rows_a, (int)k, kp, (int)m, (const QParams*)nullptr, (int8_t*)aq, (int*)rs);
+                       rows_a, (int)k, kp, (int)m, (QParams*)nullptr, (int8_t*)aq, (int*)rs, (const float*)nullptr, 0);
     // one launch per batch slice unless everything is un-batched on the B side (then all rows share the weights)
     const int64_t launches = (batch_b == 1 && batch_a >= 1) ? 1 : fb;
     for (int64_t bi = 0; bi < launches; ++bi) {
