@@ -118,7 +118,8 @@ int lele_hip_frontend_profile_read(LeleFrontend* fe, float* sum_kernel_ms, float
 /* Lfr::compute, src/features/lfr.rs:18-54: [T, D] (or [1,T,D]) -> [ceil(T/n), D*m] */
 int lele_hip_lfr(LeleCtx* ctx, const LeleTensor* x, int64_t m, int64_t n, LeleBuf* out, int64_t* out_shape,
                  int32_t* out_rank);
-/* Cmvn::compute, src/features/cmvn.rs:14-66: per-utterance mean/var over time */
+/* Cmvn::compute, src/features/cmvn.rs:14-66: per-utterance mean/var over time.  [T,D] or [1,T,D] as upstream; extension:
+ * [B,T,D] with B > 1 normalises each of the B utterances with its own statistics in one launch pair */
 int lele_hip_cmvn(LeleCtx* ctx, const LeleTensor* x, float eps, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
 /* Cmvn::apply_with_stats, cmvn.rs:67-92 */
 int lele_hip_cmvn_apply_with_stats(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* mean, const LeleTensor* std_,

@@ -33,22 +33,46 @@ __global__ void lfr_kernel(const float* __restrict__ x, int64_t t, int64_t d, in
 }
 
 // ---------------------------------------------------------------------------------------------- CMVN
-// one thread per feature dimension; coalesced across dimensions, sequential over time (cmvn.rs:28-63)
-__global__ void cmvn_kernel(const float* __restrict__ x, int64_t t, int64_t d, float eps, float* __restrict__ out) {
+// Statistics: one thread per feature dimension, coalesced across dimensions, SEQUENTIAL over time exactly as
+// cmvn.rs:28-50 accumulates (sum and sum of squares in frame order).  The loads of 8 frames are issued together before
+// the 8 dependent adds.  grid.y = utterance.  The normalisation itself is a separate fully parallel pass.
+__global__ void cmvn_moments_kernel(const float* __restrict__ x, int64_t t, int64_t d, float eps,
+                                    float* __restrict__ mean_out, float* __restrict__ sd_out) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= d) return;
+    const float* xu = x + (int64_t)blockIdx.y * t * d + k;
     float sum = 0.0f, sq = 0.0f;
-    for (int64_t ti = 0; ti < t; ++ti) {
-        const float v = x[ti * d + k];
+    int64_t ti = 0;
+    for (; ti + 8 <= t; ti += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xu[(ti + u) * d];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            sum = sum + v[u];
+            sq = sq + v[u] * v[u];  // contraction is off: product rounded, then added
+        }
+    }
+    for (; ti < t; ++ti) {
+        const float v = xu[ti * d];
         sum = sum + v;
-        sq = sq + v * v;  // contraction is off: product rounded, then added
+        sq = sq + v * v;
     }
     const float tf = (float)t;
     const float mean = sum / tf;
     float var = sq / tf - mean * mean;
     var = (var > 0.0f) ? var : 0.0f;  // f32::max(0.0) (NaN -> 0)
-    const float sd = sqrtf(var + eps);
-    for (int64_t ti = 0; ti < t; ++ti) out[ti * d + k] = (x[ti * d + k] - mean) / sd;
+    mean_out[(int64_t)blockIdx.y * d + k] = mean;
+    sd_out[(int64_t)blockIdx.y * d + k] = sqrtf(var + eps);
+}
+__global__ void cmvn_apply_kernel(const float* __restrict__ x, int64_t t, int64_t d, const float* __restrict__ mean,
+                                  const float* __restrict__ sd, float* __restrict__ out) {
+    const int64_t total = t * d, u = blockIdx.y;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = idx % d;
+        out[u * total + idx] = (x[u * total + idx] - mean[u * d + k]) / sd[u * d + k];  // cmvn.rs:58-62
+    }
 }
 
 __global__ void cmvn_stats_kernel(const float* __restrict__ x, int64_t t, int64_t d, float eps,
@@ -284,15 +308,27 @@ int lele_hip_lfr(LeleCtx* ctx, const LeleTensor* x, int64_t m, int64_t n, LeleBu
 int lele_hip_cmvn(LeleCtx* ctx, const LeleTensor* x, float eps, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
     LELE_REQUIRE(ctx && x && out, "cmvn: NULL argument");
     LELE_HIP_CHECK(hipSetDevice(ctx->device));
-    int64_t t, d;
-    LELE_TRY(feature_2d(x, &t, &d, "CMVN"));
+    int64_t t, d, nb = 1;
+    if (x->rank == 3 && x->shape[0] > 1) {  // extension: [B, T, D] = B utterances, each normalised with its own statistics
+        nb = x->shape[0];
+        t = x->shape[1];
+        d = x->shape[2];
+    } else {
+        LELE_TRY(feature_2d(x, &t, &d, "CMVN"));
+    }
     LELE_TRY(ctx->arena_reset());
     const void* dx = nullptr;
     LELE_TRY(ctx->dev_ptr(x, &dx));
-    LELE_TRY(out->reserve((size_t)t * d * 4));
+    LELE_TRY(out->reserve((size_t)nb * t * d * 4));
     if (t > 0 && d > 0) {
-        hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)((d + 63) / 64)), dim3(64), 0, ctx->stream, (const float*)dx, t,
-                           d, eps, (float*)out->data);
+        void *dm = nullptr, *ds = nullptr;
+        LELE_TRY(ctx->arena_alloc((size_t)nb * d * 4, &dm));
+        LELE_TRY(ctx->arena_alloc((size_t)nb * d * 4, &ds));
+        hipLaunchKernelGGL(cmvn_moments_kernel, dim3((unsigned)((d + 63) / 64), (unsigned)nb), dim3(64), 0, ctx->stream,
+                           (const float*)dx, t, d, eps, (float*)dm, (float*)ds);
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((t * d + 255) / 256, 1024));
+        hipLaunchKernelGGL(cmvn_apply_kernel, dim3(blocks, (unsigned)nb), dim3(256), 0, ctx->stream, (const float*)dx, t, d,
+                           (const float*)dm, (const float*)ds, (float*)out->data);
         LELE_HIP_CHECK(hipGetLastError());
     }
     std::vector<int64_t> shp(x->shape, x->shape + x->rank);

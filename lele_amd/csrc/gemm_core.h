@@ -236,22 +236,40 @@ inline void launch_tile(hipStream_t st, const AL& al, const BL& bl, const EPI& e
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, al, bl, epi, M, N, K);
 }
 
-// Launch with a tile chosen from the problem size: big tiles when they still fill 256 CUs, else 64x64 / 32x128.
+// Launch with the tile that wastes the least work: padded-tile efficiency (useful / computed elements) x the tile's
+// intrinsic efficiency (bigger tiles reuse operands better), discounted when there are fewer workgroups than CUs.
 template <class AL, class BL, class EPI>
 inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int batch,
                    int num_cus) {
     if (M <= 0 || N <= 0 || batch <= 0) return;
-    auto blocks = [&](int bm, int bn) { return (int64_t)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * batch; };
-    if (M <= 32)
-        launch_tile<32, 128, 1, 4, 16>(st, al, bl, epi, M, N, K, batch);
-    else if (M <= 64 && blocks(64, 256) >= 2 * (int64_t)num_cus)  // few rows (e.g. 64 output channels), many columns
-        launch_tile<64, 256, 1, 4, 16>(st, al, bl, epi, M, N, K, batch);
-    else if (blocks(128, 128) >= 2 * (int64_t)num_cus)
-        // K tile 16 + a register budget for 3+ waves/SIMD (accumulators stay in arch VGPRs, 128 total -> 4 blocks/CU)
-        // measured best at 4096^3: 103 TFLOP/s vs 92 (K tile 32, 2 blocks/CU) vs 90 (K tile 16, 2 blocks/CU)
-        launch_tile<128, 128, 2, 2, 16, 3>(st, al, bl, epi, M, N, K, batch);
-    else
-        launch_tile<64, 64, 2, 2, 16>(st, al, bl, epi, M, N, K, batch);
+    struct Cand {
+        int bm, bn;
+        double base;
+    };
+    static const Cand cands[4] = {{128, 128, 1.0}, {64, 256, 0.92}, {64, 64, 0.70}, {32, 128, 0.55}};
+    int best = 0;
+    double best_score = -1.0;
+    for (int i = 0; i < 4; ++i) {
+        const double tm = (M + cands[i].bm - 1) / cands[i].bm, tn = (N + cands[i].bn - 1) / cands[i].bn;
+        const double eff = ((double)M * N) / (tm * cands[i].bm * tn * cands[i].bn);
+        const double blocks = tm * tn * batch;
+        const double fill = blocks >= 2.0 * num_cus ? 1.0 : blocks / (2.0 * num_cus);
+        const double score = eff * cands[i].base * fill;
+        if (score > best_score) {
+            best_score = score;
+            best = i;
+        }
+    }
+    switch (best) {
+        case 0:
+            // K tile 16 + a register budget for 3+ waves/SIMD (accumulators stay in arch VGPRs, 128 total -> 4 blocks/CU)
+            // measured best at 4096^3: 103 TFLOP/s vs 92 (K tile 32, 2 blocks/CU) vs 90 (K tile 16, 2 blocks/CU)
+            launch_tile<128, 128, 2, 2, 16, 3>(st, al, bl, epi, M, N, K, batch);
+            break;
+        case 1: launch_tile<64, 256, 1, 4, 16>(st, al, bl, epi, M, N, K, batch); break;
+        case 2: launch_tile<64, 64, 2, 2, 16>(st, al, bl, epi, M, N, K, batch); break;
+        default: launch_tile<32, 128, 1, 4, 16>(st, al, bl, epi, M, N, K, batch); break;
+    }
 }
 
 }  // namespace gemm

@@ -43,6 +43,36 @@ __global__ void strided_copy_kernel(const W* __restrict__ in, W* __restrict__ ou
     }
 }
 
+// Transposing copies: the innermost output dim is strided in the input while some other dim `tj` is contiguous there.
+// A 32x32 tile goes through LDS so that both the reads (along tj) and the writes (along the inner dim) are coalesced.
+// grid.x = tiles along the inner dim, grid.y = tiles along tj, grid.z = all remaining dims flattened.
+template <typename W>
+__global__ __launch_bounds__(256) void transpose_tile_kernel(const W* __restrict__ in, W* __restrict__ out, CopyDesc d, int tj) {
+    __shared__ W tile[32][33];
+    const int r = d.rank, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    int64_t rem = blockIdx.z, si = d.ioff, di = d.ooff;
+    for (int k = r - 2; k >= 0; --k) {
+        if (k == tj) continue;
+        const int64_t c = rem % d.oshape[k];
+        rem /= d.oshape[k];
+        si += c * d.istride[k];
+        di += c * d.ostride[k];
+    }
+    const int64_t j0 = (int64_t)blockIdx.y * 32, i0 = (int64_t)blockIdx.x * 32;
+    const int64_t nj = d.oshape[tj], ni = d.oshape[r - 1];
+    // read: tx runs along tj (input-contiguous), ty (+8 per step) along the inner dim
+    for (int q = ty; q < 32; q += 8) {
+        const int64_t j = j0 + tx, i = i0 + q;
+        if (j < nj && i < ni) tile[q][tx] = in[si + j * d.istride[tj] + i * d.istride[r - 1]];
+    }
+    __syncthreads();
+    // write: tx runs along the inner dim (output-contiguous), ty along tj
+    for (int q = ty; q < 32; q += 8) {
+        const int64_t j = j0 + q, i = i0 + tx;
+        if (j < nj && i < ni) out[di + j * d.ostride[tj] + i * d.ostride[r - 1]] = tile[tx][q];
+    }
+}
+
 template <typename W>
 __global__ void fill_kernel(W* __restrict__ out, int64_t numel, W v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
@@ -250,6 +280,30 @@ int launch_copy(LeleCtx* ctx, const void* in, void* out, int64_t numel, const Co
         omax += (d.oshape[k] - 1) * (d.ostride[k] < 0 ? -d.ostride[k] : d.ostride[k]);
     }
     const bool i32 = numel < (int64_t(1) << 31) && imax < (int64_t(1) << 31) && omax < (int64_t(1) << 31);
+    // transposing copy: inner dim strided in the input, another dim contiguous there -> LDS-tiled kernel
+    if (!vec && r >= 2 && d.ostride[r - 1] == 1 && d.istride[r - 1] != 1 && d.oshape[r - 1] >= 8) {
+        int tj = -1;
+        bool plain = true;
+        for (int k = 0; k < r; ++k) plain = plain && d.imod[k] == 0;
+        for (int k = 0; plain && k + 1 < r; ++k)
+            if (d.istride[k] == 1 && d.oshape[k] >= 8) tj = k;
+        int64_t others = 1;
+        for (int k = 0; k + 1 < r; ++k)
+            if (k != tj) others *= d.oshape[k];
+        if (tj >= 0 && others <= 65535) {
+            const dim3 tgrid((unsigned)((d.oshape[r - 1] + 31) / 32), (unsigned)((d.oshape[tj] + 31) / 32), (unsigned)others);
+            if (tgrid.y <= 65535) {
+                if (esize == 8)
+                    hipLaunchKernelGGL(transpose_tile_kernel<uint64_t>, tgrid, dim3(256), 0, ctx->stream, (const uint64_t*)in,
+                                       (uint64_t*)out, d, tj);
+                else
+                    hipLaunchKernelGGL(transpose_tile_kernel<uint32_t>, tgrid, dim3(256), 0, ctx->stream, (const uint32_t*)in,
+                                       (uint32_t*)out, d, tj);
+                LELE_HIP_CHECK(hipGetLastError());
+                return 0;
+            }
+        }
+    }
     const dim3 grid(grid_for(numel)), block(256);
 #define LELE_COPY(W, I) \
     hipLaunchKernelGGL((strided_copy_kernel<W, I>), grid, block, 0, ctx->stream, (const W*)in, (W*)out, numel, d)

@@ -141,12 +141,8 @@ def main():
 
         def frontend():
             f = fe.compute_batch(pcm, fbuf)                                    # [B, T, 560]
-            if batch == 1:
-                return K.reshape(cmvn.compute(K.reshape(f, list(f.shape[1:])), out=cbufs[0]), [1] + list(f.shape[1:]))
-            parts = K.split(f, 0, [1] * batch, ctx=ctx)                         # CMVN is per utterance (cmvn.rs:14-66)
-            normed = [K.reshape(cmvn.compute(K.reshape(p, list(f.shape[1:])), out=cbufs[i]), [1] + list(f.shape[1:]))
-                      for i, p in enumerate(parts)]
-            return K.concat(normed, 0, ctx=ctx)
+            return cmvn.compute(f, out=cbufs[0]) if batch > 1 else K.reshape(
+                cmvn.compute(K.reshape(f, list(f.shape[1:])), out=cbufs[0]), [1] + list(f.shape[1:]))
 
         feats = frontend()
         for _ in range(2):  # warm-up: uploads and pre-packs every weight once
