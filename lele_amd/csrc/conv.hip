@@ -161,29 +161,38 @@ struct ConvEpi {
     }
 };
 
-// depthwise: one thread per output element, taps in (kh, kw) order, FMA chain in f32
-__global__ void depthwise_conv2d_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                        const float* __restrict__ bias, float* __restrict__ out, ConvGeom g, int act) {
-    const int64_t total = (int64_t)g.n * g.oc * g.plane;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int p = (int)(i % g.plane);
-        const int ch = (int)((i / g.plane) % g.oc);
-        const int64_t img = i / ((int64_t)g.plane * g.oc);
-        const int oy = p / g.ow, ox = p - oy * g.ow;
-        const float* xp = x + (img * g.c + ch) * g.ih * g.iw;
+// depthwise: one thread per output element, taps in (kh, kw) order, FMA chain in f32.  grid.x tiles one (image,
+// channel) plane, grid.y walks the planes: no 64-bit div/mod per element; every tap is an unconditional load from a
+// clamped address followed by a select (a bounds-checked load would serialise one memory round trip per tap).
+__global__ __launch_bounds__(256) void depthwise_conv2d_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                               ConvGeom g, int act) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool pin = p < g.plane;
+    const int pc = pin ? p : g.plane - 1;
+    const int oy = pc / g.ow, ox = pc - oy * g.ow;
+    const int iy0 = oy * g.sh - g.pt, ix0 = ox * g.sw - g.pl;
+    const int planes = g.n * g.oc;
+    for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
+        const int ch = pl % g.oc;
+        const float* xp = x + (int64_t)pl * g.ih * g.iw;  // depthwise: input plane index == output plane index
         const float* wp = w + (int64_t)ch * g.kh * g.kw;
         float acc = 0.0f;
         for (int a = 0; a < g.kh; ++a) {
-            const int iy = oy * g.sh - g.pt + a * g.dh;
-            if (iy < 0 || iy >= g.ih) continue;
+            const int iy = iy0 + a * g.dh;
+            const bool yin = iy >= 0 && iy < g.ih;
+            const int rowoff = (yin ? iy : 0) * g.iw;
+#pragma unroll 4
             for (int b = 0; b < g.kw; ++b) {
-                const int ix = ox * g.sw - g.pl + b * g.dw;
-                if (ix < 0 || ix >= g.iw) continue;
-                acc = fmaf_(xp[iy * g.iw + ix], wp[a * g.kw + b], acc);
+                const int ix = ix0 + b * g.dw;
+                const bool in = yin && ix >= 0 && ix < g.iw;
+                const float xv = xp[rowoff + (in ? ix : 0)];
+                const float wv = wp[a * g.kw + b];
+                acc = in ? fmaf_(xv, wv, acc) : acc;  // skipped taps leave the chain untouched, as the reference's loop does
             }
         }
         if (bias) acc = acc + bias[ch];
-        out[i] = apply_act(acc, act, p < (g.plane & ~7));
+        if (pin) out[(int64_t)pl * g.plane + p] = apply_act(acc, act, p < (g.plane & ~7));
     }
 }
 
@@ -271,9 +280,8 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
                float* out) {
     if ((int64_t)g.n * g.oc * g.plane == 0) return 0;
     if (g.icg == 1 && g.ocg == 1) {
-        const int64_t total = (int64_t)g.n * g.oc * g.plane;
-        hipLaunchKernelGGL(depthwise_conv2d_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dx, dw, db, out, g,
-                           act);
+        const dim3 dgrid((unsigned)((g.plane + 255) / 256), (unsigned)std::min<int64_t>((int64_t)g.n * g.oc, 65535));
+        hipLaunchKernelGGL(depthwise_conv2d_kernel, dgrid, dim3(256), 0, ctx->stream, dx, dw, db, out, g, act);
     } else {
         ConvWLoad al{dw, g, (int)((((uintptr_t)dw & 15) == 0) && g.K % 4 == 0)};
         ConvEpi epi{out, db, g, act};

@@ -166,8 +166,17 @@ __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x,
     const float* xr = x + row * k;
     int8_t* dst = aq + row * kp;
     const int simd_k = k & ~7;
+    const bool vec4 = (k & 3) == 0 && (((uintptr_t)x & 15) == 0);  // every row start is then 16-byte aligned
     int sum = 0;
     for (int c = lane * 4; c < kp; c += 256) {
+        float xv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (vec4 && c + 3 < k) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + c);
+            xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = xr[c + e < k ? c + e : k - 1];
+        }
         int packed = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -176,9 +185,9 @@ __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x,
             if (kk < k) {
                 float qf;
                 if (MODE == 0)
-                    qf = quant_one(xr[kk], q, kk < simd_k);
+                    qf = quant_one(xv[e], q, kk < simd_k);
                 else {
-                    const float r = rintf(xr[kk]);
+                    const float r = rintf(xv[e]);
                     qf = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
                 }
                 v = (int)qf - 128;
@@ -453,7 +462,7 @@ int launch_range(LeleCtx* ctx, const float* dx, int64_t slices, int64_t slice_le
                  float* zp_out, const float** fused = nullptr, int* fused_nblk = nullptr) {
     // enough blocks to fill 256 CUs x 4 even for one slice; every thread then streams >= 4 float4
     const int64_t want = (slice_len + 4095) / 4096;
-    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, (fused ? 256 : 1024) / slices), want));
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(1, 1024 / slices), want));  // <= 1024 partial pairs in total; a fused reader scans its slice's (<= 1024) pairs
     void* partial = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)slices * nblk * 8, &partial));
     hipLaunchKernelGGL(qminmax_kernel, dim3(nblk, (unsigned)slices), dim3(256), 0, ctx->stream, dx, slice_len,
@@ -499,7 +508,12 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
         hipLaunchKernelGGL((gemm::igemm_small_kernel<IgemmEpi>), grid, dim3(256), 0, ctx->stream, aq, wt, rows, n, kp, b_stride,
                            m_per_batch, epi);
     } else if (b128 >= 2 * ctx->num_cus) {
-        IGEMM_LAUNCH(128, 128, 2, 2, 128);
+        // 128-byte K tiles need 74 KB of LDS (2 workgroups/CU); with 64-byte tiles 3 fit.  When the whole grid fits in
+        // one round of 3 per CU but not of 2, the shallower tile avoids a nearly empty second round.
+        if (b128 > 2 * ctx->num_cus && b128 <= 3 * ctx->num_cus)
+            IGEMM_LAUNCH(128, 128, 2, 2, 64);
+        else
+            IGEMM_LAUNCH(128, 128, 2, 2, 128);
     } else if (rows <= 32) {
         IGEMM_LAUNCH(32, 128, 1, 4, 64);
     } else {
