@@ -161,20 +161,19 @@ struct ConvEpi {
     }
 };
 
-// depthwise: one thread per output element, taps in (kh, kw) order, FMA chain in f32.  grid.x tiles one (image,
-// channel) plane, grid.y walks the planes: no 64-bit div/mod per element; every tap is an unconditional load from a
-// clamped address followed by a select (a bounds-checked load would serialise one memory round trip per tap).
+// depthwise: one thread per output element, taps in (kh, kw) order, FMA chain in f32.  32-bit index arithmetic (the
+// host checks the element count), grid-stride over the flattened (plane, position) space so that small planes still
+// give full workgroups; every tap is an unconditional load from a clamped address followed by a select (a
+// bounds-checked load would serialise one memory round trip per tap).
 __global__ __launch_bounds__(256) void depthwise_conv2d_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ out,
-                                                               ConvGeom g, int act) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const bool pin = p < g.plane;
-    const int pc = pin ? p : g.plane - 1;
-    const int oy = pc / g.ow, ox = pc - oy * g.ow;
-    const int iy0 = oy * g.sh - g.pt, ix0 = ox * g.sw - g.pl;
-    const int planes = g.n * g.oc;
-    for (int pl = blockIdx.y; pl < planes; pl += gridDim.y) {
-        const int ch = pl % g.oc;
+                                                               ConvGeom g, int act, unsigned total) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned pl = i / (unsigned)g.plane;
+        const int p = (int)(i - pl * (unsigned)g.plane);
+        const int oy = p / g.ow, ox = p - oy * g.ow;
+        const int iy0 = oy * g.sh - g.pt, ix0 = ox * g.sw - g.pl;
+        const int ch = (int)(pl % (unsigned)g.oc);
         const float* xp = x + (int64_t)pl * g.ih * g.iw;  // depthwise: input plane index == output plane index
         const float* wp = w + (int64_t)ch * g.kh * g.kw;
         float acc = 0.0f;
@@ -192,7 +191,7 @@ __global__ __launch_bounds__(256) void depthwise_conv2d_kernel(const float* __re
             }
         }
         if (bias) acc = acc + bias[ch];
-        if (pin) out[(int64_t)pl * g.plane + p] = apply_act(acc, act, p < (g.plane & ~7));
+        out[i] = apply_act(acc, act, p < (g.plane & ~7));
     }
 }
 
@@ -280,8 +279,10 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
                float* out) {
     if ((int64_t)g.n * g.oc * g.plane == 0) return 0;
     if (g.icg == 1 && g.ocg == 1) {
-        const dim3 dgrid((unsigned)((g.plane + 255) / 256), (unsigned)std::min<int64_t>((int64_t)g.n * g.oc, 65535));
-        hipLaunchKernelGGL(depthwise_conv2d_kernel, dgrid, dim3(256), 0, ctx->stream, dx, dw, db, out, g, act);
+        const int64_t total = (int64_t)g.n * g.oc * g.plane;
+        LELE_REQUIRE(total < (int64_t(1) << 32), "depthwise conv: more than 2^32 output elements");
+        hipLaunchKernelGGL(depthwise_conv2d_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dx, dw, db, out, g, act,
+                           (unsigned)total);
     } else {
         ConvWLoad al{dw, g, (int)((((uintptr_t)dw & 15) == 0) && g.K % 4 == 0)};
         ConvEpi epi{out, db, g, act};
