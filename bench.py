@@ -85,8 +85,8 @@ def cpu_baseline(n, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -98,8 +98,15 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist  # backend "nccl" is RCCL on ROCm
+        # LELE_BENCH_BACKEND=gloo + LELE_BENCH_SHARE_GPU=1 exist only to exercise this N>1 path on a one-GPU box
+        backend = os.environ.get("LELE_BENCH_BACKEND", "nccl")
+        if os.environ.get("LELE_BENCH_SHARE_GPU") == "1":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import lele_amd
     from lele_amd.features import SenseVoiceFrontend
@@ -133,7 +140,7 @@ def main():
     wall = time.perf_counter() - t0
     sum_ms, main_ms, runs = fe.profile_read()
     fe.set_profiling(False)
-    wall = max_over_ranks(wall, dist, "cuda")
+    wall = max_over_ranks(wall, dist, "cuda" if dist is None or dist.get_backend() == "nccl" else "cpu")
 
     if rank == 0:
         total_bytes = world * args.batch * bytes_per_utt * args.steps
