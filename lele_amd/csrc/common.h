@@ -97,6 +97,10 @@ struct LeleBuf {
 };
 
 namespace lele {
+// features_ops.hip: power spectrum |FFT|^2 of `rows` real rows of length n_fft (a power of two <= 4096), bit-exact with the
+// reference's radix-2 network; out_power is [rows, n_fft/2 + 1]
+int fft_rows_power(LeleCtx* ctx, const float* rows_in, int64_t rows, int64_t n_fft, float* out_power);
+
 inline int set_shape(int64_t* out_shape, int32_t* out_rank, std::initializer_list<int64_t> dims) {
     if (out_rank) *out_rank = (int32_t)dims.size();
     if (out_shape) {

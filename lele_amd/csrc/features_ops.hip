@@ -280,6 +280,12 @@ int feature_2d(const LeleTensor* x, int64_t* t, int64_t* d, const char* who) {
 
 }  // namespace
 
+namespace lele {
+int fft_rows_power(LeleCtx* ctx, const float* rows_in, int64_t rows, int64_t n_fft, float* out_power) {
+    return launch_fft(ctx, rows_in, rows, n_fft, n_fft, n_fft, n_fft, n_fft, nullptr, 1, 1, out_power, nullptr);
+}
+}  // namespace lele
+
 extern "C" {
 
 int lele_hip_lfr(LeleCtx* ctx, const LeleTensor* x, int64_t m, int64_t n, LeleBuf* out, int64_t* out_shape,

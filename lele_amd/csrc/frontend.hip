@@ -396,6 +396,63 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Generic path: any FeatureConfig the reference accepts (other sample rates / frame lengths / n_fft = 1024).
+// The same operations in the same order as pipeline.rs:84-187, spread over four simple kernels + the generic
+// radix-2 FFT of features_ops.hip; nothing is fused, it only has to be bit-exact.
+// ------------------------------------------------------------------------------------------------------
+__global__ void fe_generic_mean_kernel(const float* __restrict__ pcm, int64_t num_frames, int frame_len, int hop,
+                                       float* __restrict__ mean) {
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= num_frames) return;
+    const float* src = pcm + f * hop;
+    float sum = 0.0f;
+    for (int j = 0; j < frame_len; ++j) sum = sum + src[j] * 32768.0f;  // raw_frame.iter().sum(), pipeline.rs:115
+    mean[f] = sum / (float)frame_len;
+}
+__global__ void fe_generic_frame_kernel(const float* __restrict__ pcm, const float* __restrict__ mean,
+                                        const float* __restrict__ window, int64_t num_frames, int frame_len, int hop,
+                                        int n_fft, float* __restrict__ frames) {
+    const int64_t total = num_frames * n_fft;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i / n_fft;
+        const int j = (int)(i - f * n_fft);
+        float v = 0.0f;
+        if (j < frame_len) {
+            const float* src = pcm + f * hop;
+            const float m = mean[f];
+            const float cur = fe::fsub(fe::fmul(src[j], 32768.0f), m);
+            float y = cur;
+            if (j >= 1) y = fe::fsub(cur, fe::fmul(0.97f, fe::fsub(fe::fmul(src[j - 1], 32768.0f), m)));  // pipeline.rs:140-142
+            v = fe::fmul(y, window[j]);
+        }
+        frames[i] = v;
+    }
+}
+__global__ void fe_generic_mel_kernel(const float* __restrict__ power, int64_t num_frames, int n_bins, int n_mels,
+                                      const int* __restrict__ mstart, const int* __restrict__ moff,
+                                      const float* __restrict__ mw, float* __restrict__ logmel) {
+    const int64_t total = num_frames * n_mels;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t f = i / n_mels;
+        const int m = (int)(i - f * n_mels);
+        const float* p = power + f * n_bins + mstart[m];
+        float acc = 0.0f;
+        for (int t = moff[m]; t < moff[m + 1]; ++t) acc = fe::fadd(acc, fe::fmul(mw[t], p[t - moff[m]]));  // mel.rs:92-104
+        logmel[i] = __logf(fmaxf(acc, 1e-5f));                                                            // mel.rs:124-128
+    }
+}
+__global__ void fe_generic_lfr_kernel(const float* __restrict__ x, int64_t t, int64_t d, int64_t m, int64_t n,
+                                      int64_t t_lfr, float* __restrict__ out) {  // lfr.rs:18-54
+    const int64_t d_out = d * m, total = t_lfr * d_out, pad = (m - 1) / 2;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = idx / d_out, rem = idx - i * d_out, block = rem / d, k = rem - block * d;
+        int64_t raw = i * n + block - pad;
+        raw = raw < 0 ? 0 : (raw > t - 1 ? t - 1 : raw);
+        out[idx] = x[raw * d + k];
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------
@@ -409,6 +466,11 @@ struct LeleFrontend {
     bool std_mel = false;  // mel bank has the default round structure (fully unrolled kernel variant)
     int dpp_mode = 0;  // 0: __shfl, 1: DPP row_ror (selected after a self-test)
     bool fused = true;  // frame sums computed inside fe_main_kernel (LELE_HIP_FE_FUSED=0 selects the two-kernel form)
+    // generic path tables (configs other than 400/160/512)
+    const float* g_window = nullptr;
+    const int* g_mstart = nullptr;
+    const int* g_moff = nullptr;
+    const float* g_mw = nullptr;
     FeDev dev{};
     std::vector<void*> allocs;
     // optional per-kernel stopwatch (bench.py roofline block): 3 events per run, read back lazily
@@ -506,11 +568,37 @@ int lele_hip_frontend_create(LeleCtx* ctx, const LeleFeatureConfig* cfg, LeleFro
     fe->fast = (fe->frame_len == fe::kFrame && fe->hop_len == fe::kHop && fe->n_fft == fe::kNfft &&
                 cfg->n_mels <= 16 * kMaxMelRounds);
     if (!fe->fast) {
-        delete fe;
-        set_error("frontend_create: only frame_len=400/hop=160/n_fft=512 (16 kHz, 25/10 ms) is implemented on the "
-                  "device; got frame_len=%lld hop=%lld",
-                  (long long)fe->frame_len, (long long)fe->hop_len);
-        return 3;
+        // generic path: window + flat sparse mel bank; the FFT tables live in the ctx (features_ops.hip)
+        if (fe->frame_len < 1 || fe->hop_len < 1 || fe->frame_len > fe->n_fft) {
+            const long long fl = (long long)fe->frame_len, hl = (long long)fe->hop_len, nf = (long long)fe->n_fft;
+            delete fe;
+            // upstream indexes frame_buf[..fft_len] with frame_len (pipeline.rs:145-166) and divides by hop_len (:73)
+            set_error("frontend_create: frame_len=%lld hop_len=%lld do not fit fft_len=%lld (the reference panics here)", fl, hl, nf);
+            return 3;
+        }
+        std::vector<float> gwin;
+        host_hann(fe->frame_len, gwin);
+        std::vector<int> gstart;
+        std::vector<std::vector<float>> gw;
+        host_sparse_mel((float)cfg->sample_rate, fe->n_fft, cfg->n_mels, 20.0f, gstart, gw);  // pipeline.rs:45-51
+        std::vector<int> goff(cfg->n_mels + 1, 0);
+        std::vector<float> gflat;
+        for (int64_t m = 0; m < cfg->n_mels; ++m) {
+            goff[m] = (int)gflat.size();
+            gflat.insert(gflat.end(), gw[m].begin(), gw[m].end());
+        }
+        goff[cfg->n_mels] = (int)gflat.size();
+        int rc = 0;
+        rc |= upload(fe, gwin, &fe->g_window);
+        rc |= upload(fe, gstart, &fe->g_mstart);
+        rc |= upload(fe, goff, &fe->g_moff);
+        rc |= upload(fe, gflat, &fe->g_mw);
+        if (rc) {
+            lele_hip_frontend_destroy(fe);
+            return rc;
+        }
+        *out = fe;
+        return 0;
     }
     std::vector<float> win, twr, twi;
     host_hann(fe->frame_len, win);
@@ -622,6 +710,36 @@ static int fe_run(LeleFrontend* fe, const LeleTensor* pcm, int64_t batch, int64_
     LELE_TRY(ctx->get_scratch((size_t)batch * nf * sizeof(float), &dmean));
     const size_t out_elems = want_logmel ? (size_t)batch * nf * fe->cfg.n_mels : (size_t)batch * t_lfr * cols;
     LELE_TRY(out->reserve(out_elems * sizeof(float)));
+    if (!fe->fast) {
+        // generic path, one utterance at a time (scratch: means [nf], frames [nf, n_fft], power [nf, bins], logmel [nf, mels])
+        const int64_t bins = fe->n_fft / 2 + 1, nm = fe->cfg.n_mels;
+        void *gm = nullptr, *gf = nullptr, *gp = nullptr, *gl = nullptr;
+        LELE_TRY(ctx->arena_alloc((size_t)nf * 4, &gm));
+        LELE_TRY(ctx->arena_alloc((size_t)nf * fe->n_fft * 4, &gf));
+        LELE_TRY(ctx->arena_alloc((size_t)nf * bins * 4, &gp));
+        if (!want_logmel) LELE_TRY(ctx->arena_alloc((size_t)nf * nm * 4, &gl));
+        auto blocks = [](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096))); };
+        for (int64_t u = 0; u < batch; ++u) {
+            const float* up = (const float*)dpcm + u * pcm_len;
+            float* lm = want_logmel ? (float*)out->data + u * nf * nm : (float*)gl;
+            hipLaunchKernelGGL(fe_generic_mean_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, ctx->stream, up, nf,
+                               (int)fe->frame_len, (int)fe->hop_len, (float*)gm);
+            hipLaunchKernelGGL(fe_generic_frame_kernel, blocks(nf * fe->n_fft), dim3(256), 0, ctx->stream, up, (const float*)gm,
+                               fe->g_window, nf, (int)fe->frame_len, (int)fe->hop_len, (int)fe->n_fft, (float*)gf);
+            LELE_TRY(fft_rows_power(ctx, (const float*)gf, nf, fe->n_fft, (float*)gp));
+            hipLaunchKernelGGL(fe_generic_mel_kernel, blocks(nf * nm), dim3(256), 0, ctx->stream, (const float*)gp, nf, (int)bins,
+                               (int)nm, fe->g_mstart, fe->g_moff, fe->g_mw, lm);
+            if (!want_logmel)
+                hipLaunchKernelGGL(fe_generic_lfr_kernel, blocks(t_lfr * cols), dim3(256), 0, ctx->stream, (const float*)lm, nf, nm,
+                                   fe->cfg.lfr_m, fe->cfg.lfr_n, t_lfr, (float*)out->data + u * t_lfr * cols);
+        }
+        LELE_HIP_CHECK(hipGetLastError());
+        if (want_logmel) {
+            if (batch == 1) return set_shape(out_shape, out_rank, {nf, nm});
+            return set_shape(out_shape, out_rank, {batch, nf, nm});
+        }
+        return 0;
+    }
     const int aligned16 = ((uintptr_t)dpcm % 16 == 0) && (pcm_len % 4 == 0);
     dim3 grid((unsigned)((nf + 63) / 64), (unsigned)batch);
     hipEvent_t* ev = nullptr;

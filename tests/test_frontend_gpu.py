@@ -109,11 +109,30 @@ def test_other_lfr_settings(ctx, orc):
         assert got.shape == ref.shape and close(got, ref)
 
 
+@pytest.mark.parametrize("sr,fl,fs,nm", [(8000, 25.0, 10.0, 80), (22050, 25.0, 10.0, 80), (32000, 25.0, 10.0, 64),
+                                         (16000, 20.0, 8.0, 40), (16000, 32.0, 16.0, 80), (40000, 25.0, 10.0, 128)])
+def test_other_feature_configs_take_the_generic_path(ctx, orc, sr, fl, fs, nm):
+    # any FeatureConfig the reference accepts (pipeline.rs:38-65): other framings run the composed bit-exact path
+    from lele_amd.features import FeatureConfig, SenseVoiceFrontend
+    x = synth_pcm(int(sr * 0.9), 5)
+    f2 = SenseVoiceFrontend(FeatureConfig(sample_rate=sr, n_mels=nm, frame_length_ms=fl, frame_shift_ms=fs), ctx=ctx)
+    ref, mel = orc.frontend_compute(x, sample_rate=sr, n_mels=nm, frame_length_ms=fl, frame_shift_ms=fs, return_mel=True)
+    got = f2.compute(x).numpy()
+    assert got.shape == ref.shape and close(got, ref)
+    assert close(f2.logmel(x).numpy(), mel)
+    xs = np.stack([synth_pcm(int(sr * 0.5), s) for s in range(3)])
+    gb = f2.compute_batch(xs).numpy()
+    for i in range(3):
+        assert np.array_equal(gb[i], f2.compute(xs[i]).numpy())
+    assert f2.compute(x[:10]).shape == ()  # shorter than one frame -> TensorView::empty()
+
+
 def test_unsupported_config_fails_loudly(ctx):
     import lele_amd
     from lele_amd.features import FeatureConfig, SenseVoiceFrontend
-    with pytest.raises(lele_amd.LeleError):
-        SenseVoiceFrontend(FeatureConfig(sample_rate=8000), ctx=ctx)
+    # 48 kHz x 25 ms = 1200 samples > fft_len 1024: the reference indexes past frame_buf and panics (pipeline.rs:40,145)
+    with pytest.raises(lele_amd.LeleError, match="do not fit fft_len"):
+        SenseVoiceFrontend(FeatureConfig(sample_rate=48000), ctx=ctx)
 
 
 # ---------------------------------------------------------------------------- small feature operators
