@@ -1,0 +1,103 @@
+"""Size-independent properties at BASELINE.json's full sizes (where an element-by-element oracle comparison would take
+minutes): batch independence, exact scaling by powers of two, identity products, per-slice dynamic quantisation,
+normalisation invariants.  The per-operator oracle comparisons at oracle-friendly sizes live in the other test files."""
+import numpy as np
+import pytest
+
+from conftest import synth_pcm
+
+pytestmark = pytest.mark.gpu
+
+
+def test_frontend_bench_batch_equals_single_utterance_calls(ctx):
+    # bench.py's workload shape: 30 s utterances, batched (64 here to bound the host-side synthesis time)
+    from lele_amd.features import SenseVoiceFrontend
+    fe = SenseVoiceFrontend(ctx=ctx)
+    n, batch = 480000, 64
+    xs = np.stack([synth_pcm(n, s) for s in range(batch)])
+    out = fe.compute_batch(xs).numpy()
+    assert out.shape == (batch, 500, 560) and np.isfinite(out).all()
+    for i in (0, 17, 63):
+        assert np.array_equal(out[i], fe.compute(xs[i]).numpy())
+    # LFR structure (lfr.rs:36-52): block b of row i is log-mel frame 6i + b - 3 -> consecutive rows share 1 of 7 blocks
+    assert np.array_equal(out[:, 1:, 0:80], out[:, :-1, 480:560])
+
+
+def test_matmul_4096_identity_and_power_of_two_scaling(ctx):
+    from lele_amd import kernels as K
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((4096, 4096)).astype(np.float32)
+    da = ctx.buf().upload(a)
+    eye = ctx.buf().upload(np.eye(4096, dtype=np.float32))
+    assert np.array_equal(K.matmul(da, eye, ctx=ctx).numpy(), a)      # products with 0 and 1 are exact
+    assert np.array_equal(K.matmul(eye, da, ctx=ctx).numpy(), a)
+    b = rng.standard_normal((4096, 4096)).astype(np.float32)
+    db, db4 = ctx.buf().upload(b), ctx.buf().upload(b * np.float32(4.0))
+    c = K.matmul(da, db, ctx=ctx).numpy()
+    assert np.array_equal(K.matmul(da, db4, ctx=ctx).numpy(), c * np.float32(4.0))  # scaling by 2^k commutes with rounding
+    # spot-check 64 entries against float64
+    idx = rng.integers(0, 4096, (64, 2))
+    ref = np.array([np.dot(a[i].astype(np.float64), b[:, j].astype(np.float64)) for i, j in idx])
+    got = np.array([c[i, j] for i, j in idx])
+    assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_conv2d_c5_shapes_batch_independent_and_scale_exact(ctx):
+    from lele_amd import kernels as K
+    rng = np.random.default_rng(1)
+    # (N, C, H, OC, k, stride): Yolo26n-seg stem and one 3x3 body convolution at batch 64 (BASELINE configs[4])
+    for n, c, h, oc, k, st in ((64, 3, 640, 16, 3, 2), (64, 64, 160, 64, 3, 1)):
+        x = rng.standard_normal((n, c, h, h)).astype(np.float32)
+        w = (rng.standard_normal((oc, c, k, k)) * 0.1).astype(np.float32)
+        b = rng.standard_normal(oc).astype(np.float32)
+        dx = ctx.buf().upload(x)
+        p = k // 2
+        full = K.conv2d(dx, w, b, [1, 1], 1, [p, p, p, p], [st, st], ctx=ctx).numpy()
+        assert np.isfinite(full).all()
+        for i in (0, n - 1):
+            one = K.conv2d(x[i:i + 1], w, b, [1, 1], 1, [p, p, p, p], [st, st], ctx=ctx).numpy()
+            assert np.array_equal(one[0], full[i])
+        # exact scaling (no bias, no activation): conv(2x) == 2 conv(x)
+        y1 = K.conv2d(x[:2], w, None, [1, 1], 1, [p, p, p, p], [st, st], ctx=ctx).numpy()
+        y2 = K.conv2d(x[:2] * np.float32(2.0), w, None, [1, 1], 1, [p, p, p, p], [st, st], ctx=ctx).numpy()
+        assert np.array_equal(y2, y1 * np.float32(2.0))
+        # interior output pixel against float64 for a few positions
+        oh = full.shape[2]
+        for (i, o, yy, xx) in ((0, 0, oh // 2, oh // 3), (n - 1, oc - 1, oh - 2, 1)):
+            win = x[i, :, yy * st - p:yy * st - p + k, xx * st - p:xx * st - p + k].astype(np.float64)
+            ref = (win * w[o].astype(np.float64)).sum() + b[o]
+            assert abs(full[i, o, yy, xx] - ref) <= 1e-4 * max(1.0, abs(ref))
+
+
+def test_quantized_linear_c4_shape_slices_are_independent(ctx):
+    # SenseVoice C4 shard: 32 utterances x 171 tokens, 512 -> 2048.  The dynamic range is PER BATCH SLICE
+    # (quantization.rs:104-128), so the batched call must equal 32 separate calls bit for bit.
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    rng = np.random.default_rng(2)
+    x = (rng.standard_normal((32, 171, 512)) * rng.uniform(0.5, 4.0, (32, 1, 1))).astype(np.float32)
+    w = Weight(np.clip(np.round(128 + 32 * rng.standard_normal((512, 2048))), 0, 255).astype(np.float32))
+    ws = Weight((np.abs(rng.standard_normal(2048)) * 0.01 + 0.002).astype(np.float32))
+    wz = Weight(np.array([128.0], np.float32))
+    bs = Weight((rng.standard_normal(2048) * 0.02).astype(np.float32))
+    full = K.fused_quantized_linear(ctx.buf().upload(x), w, ws, wz, bs, True, ctx=ctx).numpy()
+    assert full.shape == (32, 171, 2048) and (full >= 0).all()
+    for i in (0, 13, 31):
+        one = K.fused_quantized_linear(x[i:i + 1], w, ws, wz, bs, True, ctx=ctx).numpy()
+        assert np.array_equal(one[0], full[i])
+
+
+def test_softmax_and_layernorm_invariants_at_attention_size(ctx):
+    from lele_amd import kernels as K
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((32, 4, 171, 171)) * 3).astype(np.float32)
+    p = K.softmax(ctx.buf().upload(x), -1, ctx=ctx).numpy()
+    assert (p >= 0).all() and np.abs(p.sum(-1, dtype=np.float64) - 1.0).max() < 1e-5
+    assert np.array_equal(p.argmax(-1), x.argmax(-1))  # monotone
+    h = rng.standard_normal((32, 171, 512)).astype(np.float32)
+    g, b = np.ones(512, np.float32), np.zeros(512, np.float32)
+    y = K.layer_norm(ctx.buf().upload(h), g, b, -1, 1e-5, ctx=ctx).numpy().astype(np.float64)
+    assert np.abs(y.mean(-1)).max() < 1e-5 and np.abs(y.var(-1) - 1.0).max() < 1e-3
+    # idempotence of normalisation with unit scale: LN(LN(x)) == LN(x) up to the eps term
+    y2 = K.layer_norm(y.astype(np.float32), g, b, -1, 1e-5, ctx=ctx).numpy()
+    assert np.abs(y2 - y).max() < 1e-4
