@@ -39,6 +39,15 @@ class Ctx {
     Ctx& operator=(const Ctx&) = delete;
     LeleCtx* raw() const { return h_; }
     void sync() const { check(lele_hip_sync(h_)); }
+    // hipGraph capture of an op sequence (see include/lele_hip.h): begin, issue the ops, end -> Graph; Graph::launch()
+    void graph_begin() const { check(lele_hip_graph_begin(h_)); }
+    LeleGraph* graph_end() const {
+        LeleGraph* g = nullptr;
+        const int rc = lele_hip_graph_end(h_, &g);
+        if (rc != 0) lele_hip_graph_abort(h_);
+        check(rc);
+        return g;
+    }
     static Ctx& current() {  // thread-local default, like lele's thread-local scratch and caches
         static thread_local Ctx ctx(0);
         return ctx;
@@ -46,6 +55,20 @@ class Ctx {
 
    private:
     LeleCtx* h_ = nullptr;
+};
+
+class Graph {  // a captured op sequence; replays on the ctx stream with one hipGraphLaunch
+   public:
+    explicit Graph(LeleGraph* g) : g_(g) {}
+    ~Graph() {
+        if (g_) lele_hip_graph_destroy(g_);
+    }
+    Graph(const Graph&) = delete;
+    Graph& operator=(const Graph&) = delete;
+    void launch() const { check(lele_hip_graph_launch(g_)); }
+
+   private:
+    LeleGraph* g_ = nullptr;
 };
 
 // A workspace slot: the device-side counterpart of `ws.buf_k: Vec<f32>` (compiler/mod.rs:148-290).
