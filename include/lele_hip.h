@@ -260,6 +260,15 @@ int lele_hip_gru(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const L
                  const LeleTensor* initial_h, int linear_before_reset, LeleBuf* out_y, LeleBuf* out_h, int64_t* y_shape,
                  int32_t* y_rank);
 
+/* ---- application-side pre/post-processing ----------------------------------------------------- */
+/* examples/sensevoice/src/audio.rs:52-73: WAV payload bytes -> f32 mono.  16-bit: i16::from_le_bytes / 32768.0;
+ * 8-bit: (b - 128) / 128; stereo: (l + r) / 2.  bytes: U8 [n].  out: f32 [frames] */
+int lele_hip_wav_to_f32(LeleCtx* ctx, const LeleTensor* bytes, int32_t bits_per_sample, int32_t num_channels, LeleBuf* out,
+                        int64_t* out_shape, int32_t* out_rank);
+/* examples/sensevoice/src/tokenizer.rs:50-61: arg-max over the last axis; the LAST of equal maxima wins (Iterator::max_by).
+ * x: f32 [.., V] -> i32 ids [..]; only the ids need to leave the device */
+int lele_hip_argmax_last(LeleCtx* ctx, const LeleTensor* x, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+
 #ifdef __cplusplus
 }
 #endif

@@ -605,3 +605,15 @@ def shape(input):  # shape.rs:100-104 -> i64 [rank]
 
 def size(input):  # shape.rs:95-99 -> i64 scalar
     return TensorView(np.array(int(np.prod(_shape_of(input), dtype=np.int64)), np.int64).reshape(()))
+
+
+# ------------------------------------------------------------------------------------------- app-side pre/post
+def wav_to_f32(payload, bits_per_sample=16, num_channels=1, out=None, ctx=None):
+    """examples/sensevoice/src/audio.rs:52-73: WAV payload bytes (uint8) -> f32 mono samples"""
+    b = np.frombuffer(payload, np.uint8) if isinstance(payload, (bytes, bytearray, memoryview)) else payload
+    return _op(ctx, _lib.lib().lele_hip_wav_to_f32, [b], [C.c_int32(int(bits_per_sample)), C.c_int32(int(num_channels))], out)
+
+
+def argmax_last(input, out=None, ctx=None):
+    """examples/sensevoice/src/tokenizer.rs:50-61: greedy ids, last of equal maxima (Iterator::max_by) -> int32"""
+    return _op(ctx, _lib.lib().lele_hip_argmax_last, [input], [], out, np.int32)

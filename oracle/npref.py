@@ -213,3 +213,24 @@ def topk(x, k, largest=True):  # conv2d.rs:1385-1435: stable sort, indices as f3
     k = min(k, x.shape[-1])
     order = np.argsort(-x if largest else x, axis=-1, kind="stable")[..., :k]
     return np.take_along_axis(x, order, -1), order.astype(np.float32)
+
+
+def wav_to_f32(payload, bits_per_sample=16, num_channels=1):
+    """examples/sensevoice/src/audio.rs:52-73"""
+    b = np.frombuffer(bytes(payload), np.uint8)
+    if bits_per_sample == 16:
+        s = b[:len(b) // 2 * 2].view("<i2").astype(np.float32) / np.float32(32768.0)
+    elif bits_per_sample == 8:
+        s = (b.astype(np.float32) - np.float32(128.0)) / np.float32(128.0)
+    else:
+        raise ValueError("Unsupported bits per sample: %d" % bits_per_sample)
+    if num_channels == 2:
+        s = (s[0::2] + s[1::2]) / np.float32(2.0)
+    return s.astype(np.float32)
+
+
+def argmax_last(x):
+    """tokenizer.rs:50-61: Iterator::max_by keeps the last of equal maxima"""
+    x = np.asarray(x, np.float32)
+    v = x.shape[-1]
+    return (v - 1 - np.argmax(x[..., ::-1], axis=-1)).astype(np.int32)
