@@ -187,21 +187,70 @@ __global__ void max_pool2d_kernel(const float* __restrict__ x, float* __restrict
 
 // topk over the last axis (conv2d.rs:1385-1435): stable sort by value => rank(i) = #{j : v_j beats v_i, or ties with
 // j < i}.  One block per row, O(n^2 / threads) comparisons; rows of the sizes lele uses (<= 8400) take microseconds.
-__global__ void topk_kernel(const float* __restrict__ x, int64_t n, int64_t k, int largest, float* __restrict__ values,
-                            float* __restrict__ indices) {
-    const float* row = x + (int64_t)blockIdx.x * n;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        const float v = row[i];
-        int64_t rank = 0;
-        for (int64_t j = 0; j < n; ++j) {
-            const float u = row[j];
-            const bool beats = largest ? (u > v) : (u < v);
-            rank += (beats || (u == v && j < i)) ? 1 : 0;
-        }
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ x, int64_t n, int64_t k, int largest,
+                                                   float* __restrict__ values, float* __restrict__ indices) {
+    // grid (ceil(n / 256), rows): every thread ranks ONE element by streaming the row through LDS in 2048-element chunks;
+    // a workgroup stops as soon as all of its elements are known to be outside the top k.
+    __shared__ __attribute__((aligned(16))) float chunk[2048];
+    __shared__ int alive;
+    const int64_t rowi = blockIdx.y;
+    const float* row = x + rowi * n;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = i < n;
+    const float v = in ? row[i] : 0.0f;
+    int64_t rank = in ? 0 : k;
+    for (int64_t c0 = 0; c0 < n; c0 += 2048) {
+        __syncthreads();
+        if (threadIdx.x == 0) alive = 0;
+        const int64_t cn = n - c0 < 2048 ? n - c0 : 2048;
+        for (int t = threadIdx.x; t < 2048; t += 256) chunk[t] = t < cn ? row[c0 + t] : __builtin_nanf("");
+        __syncthreads();
         if (rank < k) {
-            values[(int64_t)blockIdx.x * k + rank] = v;
-            indices[(int64_t)blockIdx.x * k + rank] = (float)i;  // indices are returned as f32
+            // four candidates per LDS read; slots past cn hold NaN, which never counts.  A chunk that lies entirely
+            // before element i counts "beats or ties" (ties with a lower index rank first), one entirely after counts
+            // "beats" only; just the chunk containing i needs the per-candidate index test.  256 | 2048, so the case is
+            // uniform across the workgroup.
+            const int before = (int)(i - c0);
+            int add = 0;
+            const float4* c4 = reinterpret_cast<const float4*>(chunk);
+            if (before >= 2048) {
+#pragma unroll 8
+                for (int t = 0; t < 512; ++t) {
+                    const float4 u = c4[t];
+                    if (largest)
+                        add += (int)(u.x >= v) + (int)(u.y >= v) + (int)(u.z >= v) + (int)(u.w >= v);
+                    else
+                        add += (int)(u.x <= v) + (int)(u.y <= v) + (int)(u.z <= v) + (int)(u.w <= v);
+                }
+            } else if (before < 0) {
+#pragma unroll 8
+                for (int t = 0; t < 512; ++t) {
+                    const float4 u = c4[t];
+                    if (largest)
+                        add += (int)(u.x > v) + (int)(u.y > v) + (int)(u.z > v) + (int)(u.w > v);
+                    else
+                        add += (int)(u.x < v) + (int)(u.y < v) + (int)(u.z < v) + (int)(u.w < v);
+                }
+            } else {
+                for (int t = 0; t < 512; ++t) {
+                    const float4 u = c4[t];
+                    const float uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool beats = largest ? (uu[e] > v) : (uu[e] < v);
+                        add += (beats || (uu[e] == v && 4 * t + e < before)) ? 1 : 0;
+                    }
+                }
+            }
+            rank += add;
+            if (rank < k) alive = 1;  // benign race: every writer stores 1
         }
+        __syncthreads();
+        if (!alive) break;
+    }
+    if (in && rank < k) {
+        values[rowi * k + rank] = v;
+        indices[rowi * k + rank] = (float)i;  // indices are returned as f32
     }
 }
 
@@ -603,7 +652,7 @@ int lele_hip_topk(LeleCtx* ctx, const LeleTensor* x, int64_t k, int largest, Lel
     LELE_TRY(out_values->reserve((size_t)rows * kk * 4));
     LELE_TRY(out_indices->reserve((size_t)rows * kk * 4));
     if (rows * kk) {
-        hipLaunchKernelGGL(topk_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const float*)dx, n, kk, largest,
+        hipLaunchKernelGGL(topk_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, (const float*)dx, n, kk, largest,
                            (float*)out_values->data, (float*)out_indices->data);
         LELE_HIP_CHECK(hipGetLastError());
     }

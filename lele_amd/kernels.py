@@ -414,10 +414,11 @@ def max_pool2d(input, kernel_shape, strides=(), pads=(), dilations=(), ceil_mode
     return _op(ctx, _lib.lib().lele_hip_max_pool2d, [input], args + [C.c_int(int(ceil_mode))], out)
 
 
-def topk(input, k, axis=-1, largest=True, sorted=True, ctx=None):  # conv2d.rs:1385-1435 -> (values, indices)
+def topk(input, k, axis=-1, largest=True, sorted=True, out_values=None, out_indices=None, ctx=None):
+    """conv2d.rs:1385-1435 -> (values, indices); the two `&mut Vec` outputs of the reference are out_values / out_indices"""
     ctx = _ctx(ctx)
     keep = []
-    ov, oi = ctx.buf(), ctx.buf()
+    ov, oi = out_values or ctx.buf(), out_indices or ctx.buf()
     sh = _lib.OutShape()
     _lib.check(_lib.lib().lele_hip_topk(ctx._h, _lib.as_tensor(unwrap(input), keep), C.c_int64(int(k)),
                                         C.c_int(int(largest)), ov._h, oi._h, sh.shape, C.byref(sh.rank)))

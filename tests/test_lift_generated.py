@@ -1,0 +1,82 @@
+"""tools/lift_generated.py parses lele's generated statement forms.  The statements below are
+written for this test in the emitters' style (src/compiler/ops/*.rs emit exactly these argument shapes); no file of the
+reference is read or stored."""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+GENERATED_STYLE = """
+pub struct ToyWorkspace {
+    pub buf_0: Vec<f32>,
+    pub buf_1: Vec<f32>,
+}
+impl<'a> Toy<'a> {
+    fn run_chunk_0<'w>(&self, ws: &'w mut ToyWorkspace, images: TensorView<'w, f32>) -> (TensorView<'static, f32>) {
+        let a = lele::kernels::conv2d_silu(&images, &self.weight_f32(0, 432, &[4, 3, 3, 3]), Some(&self.weight_f32(432, 16, &[4])), &[1, 1], 1, &[1, 1, 1, 1], &[2, 2], &mut ws.buf_0);
+        let splits_slice = &[2, 2];
+        let mut split_results = lele::kernels::split_owned(&a, 1, splits_slice);
+        let hi = split_results.swap_remove(1);
+        let lo = split_results.swap_remove(0);
+        let r = lele::kernels::resize_nearest(&hi, Some(&self.weight_f32(448, 16, &[4]).data), None, "asymmetric", &mut ws.buf_1);
+        let v = lele::kernels::reshape(&r, &[1, 2, -1]);
+        let mut buf_tv = Vec::<f32>::new();
+        let mut buf_ti = Vec::<f32>::new();
+        let (tv, ti) = lele::kernels::topk(&v, self.weight_i64(464, 8, &[1]).data[0] as usize, -1, true, true, &mut buf_tv, &mut buf_ti);
+        let c = tv.clone(); // Cast f32->f32 is no-op
+        let output0 = lele::kernels::concat(&[&c, &ti], -1, &mut ws.buf_0);
+        (output0.to_owned())
+    }
+}
+"""
+
+
+def test_lifter_parses_the_emitted_statement_forms(tmp_path):
+    import lift_generated as L
+    p = tmp_path / "toy.rs"
+    p.write_text(GENERATED_STYLE)
+    plan = L.lift(str(p))
+    assert plan["inputs"] == ["images"] and plan["outputs"] == ["output0"] and plan["slots"] == ["buf_0", "buf_1"]
+    ops = [s.get("fn", s["op"]) for s in plan["statements"]]
+    assert ops == ["conv2d_silu", "ints", "split_owned", "swap_remove", "swap_remove", "resize_nearest", "reshape", "newbuf",
+                   "newbuf", "topk", "alias", "concat"]
+    conv = plan["statements"][0]["args"]
+    assert conv[1] == {"weight": ["weight_f32", 0, 432, [4, 3, 3, 3]]} and conv[2] == {"some": {"weight": ["weight_f32", 432, 16, [4]]}}
+    assert conv[-1] == {"slot": "buf_0"} and conv[3] == {"list": [{"int": 1}, {"int": 1}]}
+    rz = plan["statements"][5]["args"]
+    assert rz[1] == {"some": {"weight_list": ["weight_f32", 448, 16, [4]]}} and rz[2] == {"none": True} and rz[3] == {"str": "asymmetric"}
+    tk = plan["statements"][9]
+    assert tk["out"] == ["tv", "ti"] and tk["args"][1] == {"weight_scalar": ["weight_i64", 464, 8, [1]]}
+    assert tk["args"][-2:] == [{"buf": "buf_tv"}, {"buf": "buf_ti"}]
+    assert plan["statements"][-1]["args"][0] == {"refs": ["c", "ti"]}
+    assert sorted(plan["weights"]) == ["0", "432", "448", "464"]
+    w = L.synth_weights(plan, {464: [3], 448: [1.0, 1.0, 2.0, 2.0]})
+    assert w[0].shape == (4, 3, 3, 3) and w[464].dtype.kind == "i" and w[448].tolist() == [1.0, 1.0, 2.0, 2.0]
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_lifted_toy_plan_runs_and_matches_the_oracle_composition(tmp_path, ctx):
+    import numpy as np
+    import lift_generated as L
+    from lele_amd.tensor import TensorView
+    from oracle import npref
+    from oracle import pyoracle as O
+    p = tmp_path / "toy.rs"
+    p.write_text(GENERATED_STYLE)
+    plan = L.lift(str(p))
+    w = L.synth_weights(plan, {464: [3], 448: [1.0, 1.0, 2.0, 2.0]})
+    r = L.Runner(plan, w, ctx)
+    x = np.random.default_rng(0).uniform(0, 1, (1, 3, 8, 8)).astype(np.float32)
+    (out,) = r.run({"images": TensorView(x)})
+    a = O.conv2d(x, w[0], w[432], [1, 1], 1, [1, 1, 1, 1], [2, 2], "silu")          # [1,4,4,4]
+    hi = a[:, 2:4]
+    rz = npref.resize_nearest(hi, 8, 8).reshape(1, 2, -1)
+    tv, ti = npref.topk(rz, 3)
+    want = np.concatenate([tv, ti], -1)
+    got = out.numpy()
+    assert got.shape == want.shape == (1, 2, 6)
+    assert np.array_equal(got[..., 3:], want[..., 3:])                              # indices: exact
+    assert np.abs(got[..., :3] - want[..., :3]).max() <= 1e-4 * max(1.0, np.abs(want).max())

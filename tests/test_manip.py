@@ -137,3 +137,16 @@ def test_device_range_fill_cast(ctx):
     x = np.array([1.7, -2.2, 3.0], np.float32)
     assert np.array_equal(Kk.cast_to_i64(x, ctx=ctx).numpy(), x.astype(np.int64))
     assert np.array_equal(Kk.cast_to_f32(np.array([5, -6], np.int64), ctx=ctx).numpy(), [5.0, -6.0])
+
+
+@pytest.mark.gpu
+def test_device_topk_long_rows_with_ties(ctx):
+    # rows longer than the 2048-element LDS chunk, heavy ties (stable: the lower index ranks first), both directions
+    from lele_amd import kernels as Kk
+    rng = np.random.default_rng(7)
+    for n, k in ((5000, 300), (24000, 300), (2049, 2049), (300, 7)):
+        x = np.round(rng.standard_normal((3, n)) * 3).astype(np.float32)
+        for largest in (True, False):
+            v, i = Kk.topk(x, k, -1, largest, True, ctx=ctx)
+            rv, ri = npref.topk(x, k, largest)
+            assert np.array_equal(v.numpy(), rv) and np.array_equal(i.numpy(), ri.astype(np.float32))

@@ -1,0 +1,460 @@
+#!/usr/bin/env python3
+"""Lift the call sequence out of a lele-GENERATED model source (the `forward` body lele's compiler emits, e.g.
+examples/yolo26n-seg/src/yolo26seg.rs) and run it through this library's operator mirror.
+
+lele compiles an ONNX graph to Rust whose body is one `lele::kernels::<op>(...)` statement per node.  Because
+`lele_amd.kernels` keeps lele's function names and argument order, the statements can be executed as they stand: this
+tool parses each `let X = lele::kernels::fn(args);` into (outputs, fn, argument tree) and interprets it -- nothing about
+the model is written by hand.  It is a drop-in check (every op, attribute form and view helper the generated code uses
+must exist with the same meaning) and it gives whole-model timings.
+
+    lift:  python tools/lift_generated.py lift /path/to/generated.rs -o _lifted/model_plan.json      (needs the source)
+    run :  python tools/lift_generated.py run _lifted/model_plan.json --batch-runs 64                 (needs a GPU)
+
+The plan is a DERIVED, UNTRACKED artifact (like oracle/_ref/): `_lifted/` is git-ignored and never committed; it
+exists so that a plan lifted where the reference tree is mounted can be timed on the GPU box, where it is not.
+Weights: lele's `<model>_weights.bin` is downloaded at build time and is not in the tree, so the run uses synthetic
+weights of the recorded shapes (SURVEY.md section 8(d) recipe); the few integer constants the graph reads from the
+weights file (top-k size, resize target, class count) are taken from `--const offset=value,...` or the defaults below.
+"""
+import argparse
+import json
+import os
+import re
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+# ----------------------------------------------------------------------------------------------- parsing
+class P:
+    """tiny recursive-descent parser for the argument expressions lele's emitters produce"""
+
+    def __init__(self, s):
+        self.s, self.i = s, 0
+
+    def ws(self):
+        while self.i < len(self.s) and self.s[self.i].isspace():
+            self.i += 1
+
+    def eat(self, tok):
+        self.ws()
+        if self.s.startswith(tok, self.i):
+            self.i += len(tok)
+            return True
+        return False
+
+    def expect(self, tok):
+        if not self.eat(tok):
+            raise ValueError("expected %r at ...%s" % (tok, self.s[self.i:self.i + 60]))
+
+    def ident(self):
+        self.ws()
+        m = re.match(r"[A-Za-z_][A-Za-z_0-9]*", self.s[self.i:])
+        if not m:
+            raise ValueError("identifier expected at ...%s" % self.s[self.i:self.i + 60])
+        self.i += m.end()
+        return m.group(0)
+
+    def number(self):
+        self.ws()
+        m = re.match(r"-?\d+(\.\d+)?([eE][-+]?\d+)?(_?f32|_?usize|_?i64)?", self.s[self.i:])
+        if not m:
+            raise ValueError("number expected at ...%s" % self.s[self.i:self.i + 60])
+        self.i += m.end()
+        t = re.sub(r"_?(f32|usize|i64)$", "", m.group(0))
+        return {"float": float(t)} if ("." in t or "e" in t.lower()) else {"int": int(t)}
+
+    def int_list(self):  # after '['
+        vals = []
+        while not self.eat("]"):
+            vals.append(self.expr())
+            self.eat(",")
+        return vals
+
+    def weight(self):  # after 'self.'
+        kind = self.ident()
+        self.expect("(")
+        off = self.number()["int"]
+        self.expect(",")
+        ln = self.number()["int"]
+        self.expect(",")
+        self.expect("&")
+        self.expect("[")
+        shape = [v["int"] for v in self.int_list()]
+        self.expect(")")
+        node = {"weight": [kind, off, ln, shape]}
+        # suffixes:  .data   |   .data[0] as usize   |   .data.iter().map(|&v| v as i64).collect::<Vec<_>>()
+        if self.eat(".data"):
+            if self.eat("[0]"):
+                self.eat(" as usize")
+                self.eat("as usize")
+                return {"weight_scalar": node["weight"]}
+            if self.eat(".iter().map(|&v| v as i64).collect::<Vec<_>>()"):
+                return {"weight_list": node["weight"]}
+            return {"weight_list": node["weight"]}
+        return node
+
+    def expr(self):
+        self.ws()
+        if self.eat("Some("):
+            e = self.expr()
+            self.expect(")")
+            return {"some": e}
+        if self.eat("None"):
+            return {"none": True}
+        if self.eat("true"):
+            return {"bool": True}
+        if self.eat("false"):
+            return {"bool": False}
+        if self.eat('"'):
+            j = self.s.index('"', self.i)
+            v = self.s[self.i:j]
+            self.i = j + 1
+            return {"str": v}
+        if self.eat("&mut ws."):
+            return {"slot": self.ident()}
+        if self.eat("&mut "):
+            return {"buf": self.ident()}
+        if self.eat("&["):
+            vals = self.int_list()
+            if vals and all("ref" in v for v in vals):
+                return {"refs": [v["ref"] for v in vals]}
+            return {"list": vals}
+        if self.eat("&self."):
+            return self.weight()
+        if self.eat("self."):
+            return self.weight()
+        if self.eat("&"):
+            return {"ref": self.ident()}
+        self.ws()
+        if re.match(r"-?\d", self.s[self.i:]):
+            return self.number()
+        return {"ref": self.ident()}  # bare identifier (e.g. splits_slice)
+
+    def args(self):
+        out = []
+        self.ws()
+        while not self.eat(")"):
+            out.append(self.expr())
+            self.eat(",")
+        return out
+
+
+def lift(path):
+    src = open(path).read()
+    m = re.search(r"fn run_chunk_0.*?\{\n(.*?)\n    \}\n", src, re.S)
+    if not m:
+        raise SystemExit("no run_chunk_0 body found in %s" % path)
+    body = m.group(1)
+    inputs = re.findall(r"(\w+): TensorView", re.search(r"fn run_chunk_0<[^>]*>\(([^)]*)\)", src).group(1))
+    stmts, outputs = [], []
+    for line in body.split("\n"):
+        line = line.split("//")[0].strip()
+        if not line:
+            continue
+        mm = re.match(r"let (?:mut )?(\w+) = &\[([-\d, ]*)\];$", line)
+        if mm:
+            stmts.append({"op": "ints", "out": [mm.group(1)], "value": [int(v) for v in mm.group(2).split(",") if v.strip()]})
+            continue
+        mm = re.match(r"let mut (\w+) = Vec::<f32>::new\(\);$", line)
+        if mm:
+            stmts.append({"op": "newbuf", "out": [mm.group(1)]})
+            continue
+        mm = re.match(r"let (\w+) = (\w+)\.swap_remove\((\d+)\);$", line)
+        if mm:
+            stmts.append({"op": "swap_remove", "out": [mm.group(1)], "list": mm.group(2), "index": int(mm.group(3))})
+            continue
+        mm = re.match(r"let (\w+) = (\w+)\.clone\(\);$", line)
+        if mm:
+            stmts.append({"op": "alias", "out": [mm.group(1)], "src": mm.group(2)})
+            continue
+        mm = re.match(r"let (?:mut )?(\(?[\w, ]+\)?) = (?:lele::kernels::|self\.)(\w+)\((.*);$", line)
+        if mm:
+            outs = [o.strip() for o in mm.group(1).strip("()").split(",")]
+            p = P(mm.group(3))
+            stmts.append({"op": "call", "out": outs, "fn": mm.group(2), "args": p.args()})
+            continue
+        mm = re.match(r"\(([\w.() ,]+)\)$", line)
+        if mm:
+            outputs = [o.strip().replace(".to_owned()", "") for o in mm.group(1).split(",")]
+            continue
+        raise SystemExit("cannot parse statement: %s" % line[:200])
+    slots = sorted(set(re.findall(r"pub (buf_\d+): Vec<f32>", src)), key=lambda s: int(s.split("_")[1]))
+    weights = {}
+    def walk(n):
+        if isinstance(n, dict):
+            for k in ("weight", "weight_scalar", "weight_list"):
+                if k in n:
+                    kind, off, ln, shape = n[k]
+                    weights[off] = [kind, ln, shape]
+            for v in n.values():
+                walk(v)
+        elif isinstance(n, list):
+            for v in n:
+                walk(v)
+    walk(stmts)
+    return {"source": os.path.basename(path), "inputs": inputs, "outputs": outputs, "slots": slots, "statements": stmts,
+            "weights": {str(k): v for k, v in sorted(weights.items())}}
+
+
+# ----------------------------------------------------------------------------------------------- execution
+def synth_weights(plan, consts, seed=1234):
+    """one numpy array per weights.bin view: f32 ~ N(0, 1/sqrt(fan_in)), biases small; integer views from `consts`"""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for off, (kind, ln, shape) in plan["weights"].items():
+        off = int(off)
+        if kind == "weight_f32":
+            n = int(np.prod(shape)) if shape else 1
+            if len(shape) >= 2:
+                a = rng.standard_normal(n) / np.sqrt(max(1, int(np.prod(shape[1:]))))
+            else:
+                a = rng.standard_normal(n) * 0.02
+            if off in consts:
+                a = np.asarray(consts[off], np.float64).reshape(-1)
+            out[off] = a.astype(np.float32).reshape(shape)
+        else:  # weight_i64 / weight_i64_f32 / weight_i32...: graph constants, must be supplied
+            if off not in consts:
+                raise SystemExit("integer constant at weights offset %d (shape %s) is needed: pass --const %d=..." % (off, shape, off))
+            a = np.asarray(consts[off]).reshape(shape if shape else ())
+            out[off] = a.astype(np.float32) if kind.endswith("_f32") else a.astype(np.int64)
+    return out
+
+
+def load_weights_bin(plan, path):
+    """decode the views of a real lele `<model>_weights.bin` (raw little-endian tensors at recorded byte offsets,
+    src/compiler/mod.rs:1135-1233): weight_f32 -> f32, weight_i64 -> i64, weight_i64_f32 -> i64 values as f32,
+    weight_i32 / weight_i32_i64 -> i32 (as i64)"""
+    data = open(path, "rb").read()
+    out = {}
+    for off, (kind, ln, shape) in plan["weights"].items():
+        off = int(off)
+        raw = data[off:off + ln]
+        if kind == "weight_f32":
+            a = np.frombuffer(raw, "<f4")
+        elif kind in ("weight_i64", "weight_i64_f32"):
+            a = np.frombuffer(raw, "<i8")
+            a = a.astype(np.float32) if kind.endswith("_f32") else a.astype(np.int64)
+        elif kind in ("weight_i32", "weight_i32_i64"):
+            a = np.frombuffer(raw, "<i4").astype(np.int64)
+        else:
+            raise SystemExit("weights view kind %r is not handled yet" % kind)
+        out[off] = np.array(a).reshape(shape if shape else ())
+    return out
+
+
+class Runner:
+    def __init__(self, plan, weights, ctx):
+        import lele_amd
+        from lele_amd import kernels as K
+        from lele_amd._lib import Weight
+        self.plan, self.K, self.ctx = plan, K, ctx
+        self.W = {off: (Weight(a) if a.dtype != np.int64 else a) for off, a in weights.items()}
+        self.raw = weights
+        self.ws = {s: ctx.buf() for s in plan["slots"]}
+        self.extra = {}
+        self.calls = 0
+        self.profile = None
+        self.stmt_index = 0
+
+    def val(self, n, env):
+        K = self.K
+        if "ref" in n:
+            return env[n["ref"]]
+        if "refs" in n:
+            return [env[r] for r in n["refs"]]
+        if "weight" in n:
+            w = self.W[n["weight"][1]]
+            return w
+        if "weight_scalar" in n:
+            return int(np.asarray(self.raw[n["weight_scalar"][1]]).reshape(-1)[0])
+        if "weight_list" in n:
+            a = np.asarray(self.raw[n["weight_list"][1]]).reshape(-1)
+            return [float(v) for v in a] if a.dtype == np.float32 else [int(v) for v in a]
+        if "some" in n:
+            return self.val(n["some"], env)
+        if "none" in n:
+            return None
+        if "list" in n:
+            return [self.val(v, env) for v in n["list"]]
+        for k in ("int", "float", "bool", "str"):
+            if k in n:
+                return n[k]
+        raise ValueError(n)
+
+    def call(self, f, fn, pos, bufs, key=None):
+        ctx = self.ctx
+        if fn == "split_owned":  # owned results: one persistent device buffer per output of this statement
+            outs = self.extra.setdefault(("split", key), [ctx.buf() for _ in pos[2]])
+            return list(f(pos[0], pos[1], pos[2], outputs=outs, ctx=ctx))
+        if fn == "topk":
+            return f(pos[0], pos[1], pos[2], pos[3], pos[4], out_values=bufs[0], out_indices=bufs[1], ctx=ctx)
+        if fn in ("reshape", "flatten", "unsqueeze", "squeeze", "identity"):
+            return f(*pos)
+        return f(*pos, out=bufs[0], ctx=ctx) if bufs else f(*pos, ctx=ctx)
+
+    def run(self, inputs):
+        K, ctx = self.K, self.ctx
+        env = dict(inputs)
+        for self.stmt_index, st in enumerate(self.plan["statements"]):
+            op = st["op"]
+            if op == "ints":
+                env[st["out"][0]] = st["value"]
+            elif op == "newbuf":
+                self.extra.setdefault(st["out"][0], ctx.buf())
+                env[st["out"][0]] = self.extra[st["out"][0]]
+            elif op == "swap_remove":  # Vec::swap_remove: take element i, move the last element into its place
+                lst = env[st["list"]]
+                i = st["index"]
+                env[st["out"][0]] = lst[i]
+                lst[i] = lst[-1]
+                lst.pop()
+            elif op == "alias":
+                env[st["out"][0]] = env[st["src"]]
+            else:
+                fn, args = st["fn"], st["args"]
+                pos, kw = [], {}
+                bufs = []
+                for a in args:
+                    if "slot" in a:
+                        bufs.append(self.ws[a["slot"]])
+                    elif "buf" in a:
+                        bufs.append(env[a["buf"]])
+                    else:
+                        pos.append(self.val(a, env))
+                f = getattr(K, fn)
+                self.calls += 1
+                try:
+                    t0 = time.perf_counter() if self.profile is not None else 0.0
+                    res = self.call(f, fn, pos, bufs, key=st["out"][0] + str(self.stmt_index))
+                    if self.profile is not None:
+                        ctx.sync()
+                        self.profile[fn] = self.profile.get(fn, 0.0) + time.perf_counter() - t0
+                except Exception as e:  # noqa: BLE001
+                    shp = [getattr(p, "shape", p) if not isinstance(p, list) else [getattr(q, "shape", q) for q in p] for p in pos]
+                    raise RuntimeError("statement %s = %s(...) failed with %s; argument shapes/values: %s" % (st["out"], fn, e, shp))
+                if len(st["out"]) == 1:
+                    env[st["out"][0]] = res
+                else:
+                    for name, r in zip(st["out"], res):
+                        env[name] = r
+                continue
+                if fn == "split_owned":
+                    res = list(f(pos[0], pos[1], pos[2], ctx=ctx))
+                elif fn == "topk":
+                    res = f(pos[0], pos[1], pos[2], pos[3], pos[4], ctx=ctx)
+                elif fn in ("reshape", "flatten", "unsqueeze", "squeeze", "identity"):
+                    res = f(*pos)
+                else:
+                    res = f(*pos, out=bufs[0], ctx=ctx) if bufs else f(*pos, ctx=ctx)
+                if len(st["out"]) == 1:
+                    env[st["out"][0]] = res
+                else:
+                    for name, r in zip(st["out"], res):
+                        env[name] = r
+        return [env[o] for o in self.plan["outputs"]]
+
+
+# YOLO26n-seg integer constants read from weights.bin (inferred from the graph: see --help); offset -> value
+DEFAULT_CONSTS = {
+    5445328: [1.0, 1.0, 2.0, 2.0],   # Resize scales (x2 nearest upsampling in the neck)
+    7762768: [1, 64, 80, 80],        # proto Resize target size (features brought to the 80x80 level before fusion)
+    10993152: [300],                 # TopK k (max detections)
+    10993200: 80,                    # number of classes (flat index -> anchor = idx / 80, class = idx % 80)
+}
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    a = sub.add_parser("lift")
+    a.add_argument("source")
+    a.add_argument("-o", "--out", required=True)
+    b = sub.add_parser("run")
+    b.add_argument("plan")
+    b.add_argument("--input-shape", default="1,3,640,640")
+    b.add_argument("--runs", type=int, default=10)
+    b.add_argument("--batch-runs", type=int, default=64, help="forwards per timed run (lele loops over images on the host)")
+    b.add_argument("--const", default="")
+    b.add_argument("--weights", default=None, help="a real <model>_weights.bin; default: synthetic weights")
+    b.add_argument("--out", default=None)
+    args = ap.parse_args()
+    if args.cmd == "lift":
+        plan = lift(args.source)
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        json.dump(plan, open(args.out, "w"))
+        ops = {}
+        for s in plan["statements"]:
+            if s["op"] == "call":
+                ops[s["fn"]] = ops.get(s["fn"], 0) + 1
+        print(json.dumps({"statements": len(plan["statements"]), "weights_views": len(plan["weights"]), "ops": ops}))
+        return
+    plan = json.load(open(args.plan))
+    consts = dict(DEFAULT_CONSTS)
+    for kv in filter(None, args.const.split(";")):
+        k, v = kv.split("=")
+        consts[int(k)] = json.loads(v)
+    import lele_amd
+    ctx = lele_amd._lib.Ctx(0)
+    r = Runner(plan, load_weights_bin(plan, args.weights) if args.weights else synth_weights(plan, consts), ctx)
+    shape = [int(v) for v in args.input_shape.split(",")]
+    rng = np.random.default_rng(0)
+    x = ctx.buf().upload(rng.uniform(0, 1, shape).astype(np.float32))  # section 8(d): uniform[0,1) images
+    from lele_amd.tensor import TensorView
+    inp = {plan["inputs"][-1]: TensorView(x)}
+    outs = r.run(inp)
+    calls = r.calls
+    shapes = [list(o.shape) for o in outs]
+    finite = all(bool(np.isfinite(o.numpy()).all()) for o in outs)
+    for _ in range(2):
+        r.run(inp)
+    ctx.sync()
+    r.profile = {}
+    r.run(inp)
+    prof = {k: round(1e3 * v, 3) for k, v in sorted(r.profile.items(), key=lambda kv: -kv[1])}
+    r.profile = None
+    eager = []
+    for _ in range(args.runs):
+        ctx.sync()
+        t0 = time.perf_counter()
+        r.run(inp)
+        ctx.sync()
+        eager.append(time.perf_counter() - t0)
+    # the same sequence as one hipGraph, replayed batch_runs times per timed run (one image per forward, as lele does)
+    graph_ms = None
+    try:
+        ctx.sync()
+        ctx.graph_begin()
+        r.run(inp)
+        g = ctx.graph_end()
+        g.launch()
+        ctx.sync()
+        ts = []
+        for _ in range(args.runs):
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.batch_runs):
+                g.launch()
+            ctx.sync()
+            ts.append(time.perf_counter() - t0)
+        graph_ms = 1e3 * float(np.mean(ts)) / args.batch_runs
+    except Exception as e:  # noqa: BLE001
+        ctx.graph_abort()
+        graph_ms = "capture failed: %s" % e
+    rec = {"model": plan["source"], "input_shape": shape, "kernel_calls_per_forward": calls, "output_shapes": shapes,
+           "finite": finite, "eager_ms_per_forward": round(1e3 * float(np.mean(eager)), 3), "graph_ms_per_forward": graph_ms,
+           "images_per_s_graph": (round(1e3 / graph_ms, 1) if isinstance(graph_ms, float) else None),
+           "per_op_ms_synced": prof,
+           "note": "call sequence lifted from lele's generated source, synthetic weights, one image per forward"}
+    print(json.dumps(rec), flush=True)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        json.dump(rec, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
