@@ -49,16 +49,6 @@ int run_matmul(LeleCtx* ctx, const float* da, const float* db, const MmShape& s,
                       (int)(aligned16(da) && s.k % 4 == 0)};
     gemm::LoadKRow bl{db, s.batch_b == 1 ? 0 : s.k * s.n, s.n, (int)s.n, (int)s.k};
     gemm::EpiAffine epi{out, s.m * s.n, (int)s.m, (int)s.n, alpha, beta, c, cmode, clen};
-    const int64_t blocks64 = ((s.m + 63) / 64) * ((s.n + 63) / 64) * s.fb;
-    if (blocks64 < 2 * (int64_t)ctx->num_cus && s.k >= 16) {
-        // too few 64x64 tiles to fill the chip: one workgroup per 32x32 tile, K split over its four waves (gemm_small.h)
-        dim3 grid((unsigned)((s.n + 31) / 32), (unsigned)((s.m + 31) / 32), (unsigned)s.fb);
-        hipLaunchKernelGGL((gemm::gemm_f32_small_kernel<false, gemm::EpiAffine>), grid, dim3(256), 0, ctx->stream, da,
-                           s.batch_a == 1 ? 0 : s.m * s.k, s.k, db, s.batch_b == 1 ? 0 : s.k * s.n, s.n, epi, (int)s.m,
-                           (int)s.n, (int)s.k, (int)(aligned16(da) && s.k % 4 == 0), 0);
-        LELE_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
     gemm::launch(ctx->stream, al, bl, epi, (int)s.m, (int)s.n, (int)s.k, (int)s.fb, ctx->num_cus);
     LELE_HIP_CHECK(hipGetLastError());
     return 0;

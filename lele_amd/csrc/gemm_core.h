@@ -221,6 +221,63 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
         }
 }
 
+// ---------------------------------------------------------------------------------------------- small problems
+// One 256-thread workgroup per 32x32 output tile; its four waves split K four ways.  Every wave feeds its MFMAs straight
+// from global memory through the SAME loader functors (the operands are L2-resident at these sizes): no LDS staging, no
+// barrier in the K loop, all loads of a K step issued back to back.  The four partial tiles meet once in LDS and are
+// added in the fixed order (p0+p1)+(p2+p3): deterministic, a re-association of the exact-product sum (inside 1e-4).
+// Lane (l31, hv) owns k = 16c + 8hv + s of chunk c -- the operand mapping of the tiled kernel.
+template <class AL, class BL, class EPI>
+__global__ __launch_bounds__(256) void gemm_f32_small_kernel(AL al, BL bl, EPI epi, int M, int N, int K) {
+    __shared__ float red[4][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int hv = lane >> 5, l31 = lane & 31;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32, batch = blockIdx.z;
+    const int row = m0 + l31, col = n0 + l31;
+    const int nchunk = (K + 15) / 16, per = (nchunk + 3) / 4;
+    const int c0 = wave * per, c1 = c0 + per < nchunk ? c0 + per : nchunk;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int c = c0; c < c1; c += 2) {  // two 16-k chunks per trip: 4 get4 per operand in flight
+        float4 fa[2][2], fb[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            // a chunk past this wave's range reads k >= K, which every loader returns as zeros
+            const int k0 = c + u < c1 ? (c + u) * 16 + 8 * hv : K;
+            fa[u][0] = al.get4(batch, row, k0);
+            fa[u][1] = al.get4(batch, row, k0 + 4);
+            fb[u][0] = bl.get4(batch, col, k0);
+            fb[u][1] = bl.get4(batch, col, k0 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float a8[8] = {fa[u][0].x, fa[u][0].y, fa[u][0].z, fa[u][0].w, fa[u][1].x, fa[u][1].y, fa[u][1].z, fa[u][1].w};
+            const float b8[8] = {fb[u][0].x, fb[u][0].y, fb[u][0].z, fb[u][0].w, fb[u][1].x, fb[u][1].y, fb[u][1].z, fb[u][1].w};
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a8[s], b8[s], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    // wave w finishes accumulator registers 4w..4w+3 of the tile: row = (r&3) + 8*(r>>2) + 4*hv, col = l31
+    const int colc = col < N ? col : N - 1;
+    float pre[4], tot[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 4 * wave + q;
+        const int orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * hv;
+        pre[q] = epi.load(batch, orow < M ? orow : M - 1, colc);
+        tot[q] = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int r = 4 * wave + q;
+        epi.store(batch, m0 + (r & 3) + 8 * (r >> 2) + 4 * hv, col, tot[q], pre[q]);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int BK, int OCC = 1, class AL, class BL, class EPI>
 inline void launch_tile(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int batch) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
@@ -242,6 +299,12 @@ template <class AL, class BL, class EPI>
 inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int batch,
                    int num_cus) {
     if (M <= 0 || N <= 0 || batch <= 0) return;
+    // too few 64x64 tiles to fill the chip: 32x32 tiles with a 4-way split of K (latency-optimised, see above)
+    if ((int64_t)((M + 63) / 64) * ((N + 63) / 64) * batch < 2 * (int64_t)num_cus && K >= 16) {
+        dim3 grid((N + 31) / 32, (M + 31) / 32, batch);
+        hipLaunchKernelGGL((gemm_f32_small_kernel<AL, BL, EPI>), grid, dim3(256), 0, st, al, bl, epi, M, N, K);
+        return;
+    }
     struct Cand {
         int bm, bn;
         double base;

@@ -54,9 +54,13 @@ def test_conv2d_c5_shapes_batch_independent_and_scale_exact(ctx):
         p = k // 2
         full = K.conv2d(dx, w, b, [1, 1], 1, [p, p, p, p], [st, st], ctx=ctx).numpy()
         assert np.isfinite(full).all()
+        # the same images in a smaller batch: bit-identical while the same tile kernel is chosen (two halves of 32), and
+        # within the 1e-4 bar when a single image is routed to the split-K small-problem kernel (different association)
+        half = K.conv2d(x[n // 2:], w, b, [1, 1], 1, [p, p, p, p], [st, st], ctx=ctx).numpy()
+        assert np.array_equal(half, full[n // 2:])
         for i in (0, n - 1):
             one = K.conv2d(x[i:i + 1], w, b, [1, 1], 1, [p, p, p, p], [st, st], ctx=ctx).numpy()
-            assert np.array_equal(one[0], full[i])
+            assert np.abs(one[0] - full[i]).max() <= 1e-4 * max(1.0, np.abs(full[i]).max())
         # exact scaling (no bias, no activation): conv(2x) == 2 conv(x)
         y1 = K.conv2d(x[:2], w, None, [1, 1], 1, [p, p, p, p], [st, st], ctx=ctx).numpy()
         y2 = K.conv2d(x[:2] * np.float32(2.0), w, None, [1, 1], 1, [p, p, p, p], [st, st], ctx=ctx).numpy()
