@@ -254,6 +254,89 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ x, 
     }
 }
 
+// Long rows (n > 2048): prefilter.  If t0 is the k-th best of the first 2048 elements, anything strictly worse than t0
+// already has k elements ahead of it and cannot be in the top k -- and it can never outrank a survivor either, so the
+// survivors' ranks depend on survivors only.  Three small kernels: threshold, compaction (value + original index, the
+// index keeps the tie-break "lower index first"), rank among the survivors.
+__global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __restrict__ x, int64_t n, int64_t k, int largest,
+                                                             float* __restrict__ t0, int* __restrict__ count) {
+    // grid (8, rows): 2048 sample elements, one per thread, each ranked against the whole sample held in LDS
+    __shared__ __attribute__((aligned(16))) float chunk[2048];
+    const float* row = x + (int64_t)blockIdx.y * n;
+    const int m = (int)(n < 2048 ? n : 2048);
+    for (int t = threadIdx.x; t < 2048; t += 256) chunk[t] = t < m ? row[t] : __builtin_nanf("");
+    __syncthreads();
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= m) return;
+    const float v = chunk[e];
+    int rank = 0;
+    const float4* c4 = reinterpret_cast<const float4*>(chunk);
+#pragma unroll 4
+    for (int t = 0; t < 512; ++t) {
+        const float4 u = c4[t];
+        const float uu[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool beats = largest ? (uu[q] > v) : (uu[q] < v);
+            rank += (beats || (uu[q] == v && 4 * t + q < e)) ? 1 : 0;
+        }
+    }
+    if (rank == k - 1) t0[blockIdx.y] = v;  // exactly one element of the sample has this rank
+}
+__global__ void topk_init_kernel(int64_t rows, int largest, float* __restrict__ t0, int* __restrict__ count) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) {
+        count[r] = 0;
+        t0[r] = largest ? -INFINITY : INFINITY;  // stays when the sample holds fewer than k elements: keep everything
+    }
+}
+__global__ __launch_bounds__(256) void topk_compact_kernel(const float* __restrict__ x, int64_t n, int largest,
+                                                           const float* __restrict__ t0, int* __restrict__ count,
+                                                           float* __restrict__ cv, int* __restrict__ ci) {
+    const int64_t rowi = blockIdx.y, i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[rowi * n + i], t = t0[rowi];
+    const bool keep = largest ? !(v < t) : !(v > t);
+    if (keep) {
+        const int pos = atomicAdd(&count[rowi], 1);
+        cv[rowi * n + pos] = v;
+        ci[rowi * n + pos] = (int)i;
+    }
+}
+__global__ __launch_bounds__(256) void topk_rank_kernel(const float* __restrict__ cv, const int* __restrict__ ci, int64_t n,
+                                                        int64_t k, int largest, const int* __restrict__ count,
+                                                        float* __restrict__ values, float* __restrict__ indices) {
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
+    const int64_t rowi = blockIdx.y;
+    const int m = count[rowi];
+    if ((int64_t)blockIdx.x * 256 >= m) return;  // uniform per workgroup
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const bool in = j < m;
+    const float v = in ? cv[rowi * n + j] : 0.0f;
+    const int vi = in ? ci[rowi * n + j] : 0;
+    int rank = 0;
+    for (int c0 = 0; c0 < m; c0 += 1024) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < 1024; t += 256) {
+            const bool live = c0 + t < m;
+            sv[t] = live ? cv[rowi * n + c0 + t] : __builtin_nanf("");
+            si[t] = live ? ci[rowi * n + c0 + t] : 0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int t = 0; t < 1024; ++t) {
+            const float u = sv[t];
+            const bool beats = largest ? (u > v) : (u < v);
+            rank += (beats || (u == v && si[t] < vi)) ? 1 : 0;
+        }
+    }
+    if (in && rank < k) {
+        values[rowi * k + rank] = v;
+        indices[rowi * k + rank] = (float)vi;
+    }
+}
+
 __global__ void range_kernel(float start, float delta, int64_t n, float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = start + (float)i * delta;  // math.rs:2049-2053
@@ -652,8 +735,25 @@ int lele_hip_topk(LeleCtx* ctx, const LeleTensor* x, int64_t k, int largest, Lel
     LELE_TRY(out_values->reserve((size_t)rows * kk * 4));
     LELE_TRY(out_indices->reserve((size_t)rows * kk * 4));
     if (rows * kk) {
-        hipLaunchKernelGGL(topk_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)rows), dim3(256), 0, ctx->stream, (const float*)dx, n, kk, largest,
-                           (float*)out_values->data, (float*)out_indices->data);
+        const dim3 tgrid((unsigned)((n + 255) / 256), (unsigned)rows);
+        if (n <= 4096 || kk > 1024 || n >= (int64_t(1) << 31)) {
+            hipLaunchKernelGGL(topk_kernel, tgrid, dim3(256), 0, ctx->stream, (const float*)dx, n, kk, largest,
+                               (float*)out_values->data, (float*)out_indices->data);
+        } else {  // prefilter on the first 2048 elements, then rank the survivors only
+            void *t0 = nullptr, *cnt = nullptr, *cv = nullptr, *ci = nullptr;
+            LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &t0));
+            LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &cnt));
+            LELE_TRY(ctx->arena_alloc((size_t)rows * n * 4, &cv));
+            LELE_TRY(ctx->arena_alloc((size_t)rows * n * 4, &ci));
+            hipLaunchKernelGGL(topk_init_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, rows, largest,
+                               (float*)t0, (int*)cnt);
+            hipLaunchKernelGGL(topk_threshold_kernel, dim3(8, (unsigned)rows), dim3(256), 0, ctx->stream, (const float*)dx, n, kk,
+                               largest, (float*)t0, (int*)cnt);
+            hipLaunchKernelGGL(topk_compact_kernel, tgrid, dim3(256), 0, ctx->stream, (const float*)dx, n, largest,
+                               (const float*)t0, (int*)cnt, (float*)cv, (int*)ci);
+            hipLaunchKernelGGL(topk_rank_kernel, tgrid, dim3(256), 0, ctx->stream, (const float*)cv, (const int*)ci, n, kk,
+                               largest, (const int*)cnt, (float*)out_values->data, (float*)out_indices->data);
+        }
         LELE_HIP_CHECK(hipGetLastError());
     }
     return set_shape_v(out_shape, out_rank, oshape);
