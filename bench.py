@@ -39,6 +39,38 @@ def synth_batch(batch, n, seed0):
     return out
 
 
+def cpu_baseline_all_cores(n, budget_s=6.0):
+    """lele's only route to multi-core is one independent instance per core (everything in it is
+    Par::Seq with thread-local scratch), utterances sharded round-robin.  One oracle instance per hardware thread here:
+    ctypes releases the GIL for the duration of the C call, so plain threads run truly in parallel."""
+    import threading
+    from oracle import pyoracle as O
+    O.lib()
+    cores = os.cpu_count() or 1
+    xs = synth_batch(4, n, 20_000)
+    t_lfr, _ = O.frontend_shape(n)
+    done = [0] * cores
+    stop = time.perf_counter() + budget_s
+
+    def work(i):
+        while time.perf_counter() < stop:
+            O.frontend_compute(xs[(i + done[i]) % 4])
+            done[i] += 1
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    el = time.perf_counter() - t0
+    total = sum(done)
+    bytes_per_utt = 4 * n + 4 * t_lfr * 560
+    return {"value": round(total * bytes_per_utt / el / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": "%d x 30 s utterances over %d independent single-threaded oracle instances, %.1f s wall" % (total, cores, el),
+            "rtf": round(el / max(1, total) / (n / SAMPLE_RATE), 7)}
+
+
 def shard_range(total, rank, world):
     """static block partition of the global batch; rank r owns utterances [lo, hi)"""
     base, rem = divmod(total, world)
@@ -176,6 +208,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:  # reported baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(n)
+            line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(n)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
