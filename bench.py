@@ -202,6 +202,14 @@ def main():
                     traffic = rec.get("bytes_per_launch")
             except Exception:
                 traffic = None
+        valu_busy = None
+        pf = os.path.join(ROOT, "profiles", "r01_frontend_pmc_sq.json")
+        if os.path.exists(pf):  # SQ counters of the same kernel (profiles/README.md): the kernel is VALU-bound, not HBM-bound
+            try:
+                c = json.load(open(pf))
+                valu_busy = round(c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 3)
+            except Exception:
+                valu_busy = None
         line = {
             "metric": "STFT+mel GB/s (SenseVoice front-end: PCM -> log-mel -> LFR, algorithmic bytes)",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -218,7 +226,10 @@ def main():
                          "aux_kernel": "none (frame sums are fused into fe_main_kernel; LELE_HIP_FE_FUSED=0 restores "
                                        "the separate fe_frame_sum_kernel)" if sum_ms < 0.02 else "fe_frame_sum_kernel",
                          "aux_kernel_ms": round(sum_ms, 5), "launches": runs,
-                         "algorithmic_bytes_per_launch": args.batch * bytes_per_utt},
+                         "algorithmic_bytes_per_launch": args.batch * bytes_per_utt,
+                         "valu_busy_frac_pmc": valu_busy,
+                         "note": "bit-exact radix-2 FFT replica: ~19 VALU lane-ops per algorithmic byte against a ridge of ~4.9 "
+                                 "-> VALU-bound by construction (DESIGN.md 3.1); traffic is an upper bound (profiles/README.md)"},
         }
         if world == 1 and not args.no_cpu_baseline:  # reported baseline: rank 0 at N=1 only
             line["cpu_baseline"] = cpu_baseline(n)
