@@ -1,0 +1,118 @@
+"""Real speech (the reference's fixtures/zh.wav, BASELINE configs[0] input): front-end parity on real audio and a
+Silero-shaped streaming chain -- STFT-as-conv1d -> magnitude -> conv blocks -> LSTM with state carried over 175 chunks
+of 512 samples (the loop of examples/silero/src/main.rs:151-228; assumed topology, synthetic weights) -- device vs oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import npref
+from oracle import pyoracle as O
+
+WAV = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "zh.wav")
+
+
+def _payload():
+    b = open(WAV, "rb").read()
+    assert b[:4] == b"RIFF" and b[8:12] == b"WAVE"
+    i = b.index(b"data") + 8
+    return b[i:]
+
+
+def test_oracle_on_real_speech_matches_the_shape_lele_states():
+    pcm = npref.wav_to_f32(_payload(), 16, 1)
+    assert pcm.shape == (89472,) and np.abs(pcm).max() <= 1.0
+    feats, mel = O.frontend_compute(pcm, return_mel=True)
+    assert mel.shape == (557, 80) and feats.shape == (93, 560)          # T = 93: src/bin/wasm_bench.rs:734-758
+    assert np.isfinite(feats).all() and mel.min() >= np.float32(np.log(np.float32(1e-5)))  # ln(max(x, 1e-5)) floor
+    n = O.cmvn(feats)
+    assert np.abs(n.mean(0)).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_device_frontend_on_real_speech(ctx):
+    from lele_amd import kernels as K
+    from lele_amd.features import Cmvn, SenseVoiceFrontend
+    payload = _payload()
+    pcm_dev = K.wav_to_f32(payload, 16, 1, ctx=ctx)                      # s16 crosses PCIe, f32 is made on the device
+    pcm = npref.wav_to_f32(payload, 16, 1)
+    assert np.array_equal(pcm_dev.numpy(), pcm)
+    fe = SenseVoiceFrontend(ctx=ctx)
+    want, mel = O.frontend_compute(pcm, return_mel=True)
+    got = fe.compute(pcm_dev).numpy()
+    assert got.shape == (93, 560)
+    # bit-exact up to the mel sums; ln differs by <= 2 ulp of a value of magnitude <= 25
+    assert np.abs(got - want).max() <= 4e-6
+    assert np.abs(fe.logmel(pcm_dev).numpy() - mel).max() <= 4e-6
+    assert np.array_equal(Cmvn(ctx=ctx).compute(got).numpy(), O.cmvn(got))
+
+
+def _silero_like_weights(rng):
+    w = {}
+    w["stft"] = (rng.standard_normal((258, 1, 256)) / 16).astype(np.float32)
+    chans = [(129, 128), (128, 64), (64, 64), (64, 128)]
+    for i, (ci, co) in enumerate(chans):
+        w["c%d" % i] = (rng.standard_normal((co, ci, 3)) / np.sqrt(3 * ci)).astype(np.float32)
+        w["b%d" % i] = (rng.standard_normal(co) * 0.05).astype(np.float32)
+    w["lw"] = (rng.standard_normal((1, 512, 128)) / np.sqrt(128)).astype(np.float32)
+    w["lr"] = (rng.standard_normal((1, 512, 128)) / np.sqrt(128)).astype(np.float32)
+    w["lb"] = (rng.standard_normal((1, 1024)) * 0.05).astype(np.float32)
+    w["out"] = (rng.standard_normal((128, 1)) / np.sqrt(128)).astype(np.float32)
+    return w
+
+
+def _chain(ops, w, chunk, h, c):
+    """one Silero-shaped step; `ops` is either the device mirror or the oracle, same call sequence"""
+    x = ops.pad(chunk.reshape(1, 1, 512), [0, 0, 64, 0, 0, 64], None, "reflect")          # [1,1,640]
+    s = ops.conv1d(x, w["stft"], None, [1], 1, [0, 0], [128])                               # [1,258,4]
+    re, im = ops.slice(s, [0], [129], [1], [1]), ops.slice(s, [129], [258], [1], [1])
+    mag = ops.sqrt(ops.add(ops.mul(re, re), ops.mul(im, im)))                               # [1,129,4]
+    y = mag
+    for i, st in enumerate((1, 2, 2, 1)):
+        y = ops.conv1d_fused(y, w["c%d" % i], w["b%d" % i], [1], 1, [1, 1], [st], True)
+    feat = ops.reduce_mean(y, [2], False)                                                   # [1,128]
+    yy, h2, c2 = ops.lstm(ops.reshape(feat, [1, 1, 128]), w["lw"], w["lr"], w["lb"], None, h, c)
+    p = ops.sigmoid(ops.matmul(ops.reshape(h2, [1, 128]), w["out"]))
+    return p, h2, c2
+
+
+class _OracleOps:
+    pad = staticmethod(lambda x, pads, cv, mode: npref.pad(x, pads, 0.0 if cv is None else cv, mode))
+    conv1d = staticmethod(lambda *a: O.conv1d(*a))
+    conv1d_fused = staticmethod(lambda x, w, b, d, g, p, s, relu: O.conv1d(x, w, b, d, g, p, s, relu))
+    slice = staticmethod(lambda x, st, en, ax, sp: npref.slice_(x, st, en, ax, sp))
+    add = staticmethod(lambda a, b: a + b)
+    mul = staticmethod(lambda a, b: a * b)
+    sqrt = staticmethod(lambda a: np.sqrt(a))
+    reduce_mean = staticmethod(lambda x, axes, keep: npref.reduce("mean", x, axes, keep))
+    reshape = staticmethod(lambda x, shp: np.asarray(x).reshape(shp))
+    matmul = staticmethod(lambda a, b: O.matmul(a, b))
+    sigmoid = staticmethod(lambda a: O.unary("sigmoid", a))
+
+    @staticmethod
+    def lstm(x, w, r, b, sl, h, c):
+        return O.lstm(x, w, r, b, h, c)
+
+
+@pytest.mark.gpu
+def test_silero_shaped_streaming_chain_matches_oracle(ctx):
+    from lele_amd import kernels as K
+
+    class Dev:
+        pass
+    for name in ("pad", "conv1d", "conv1d_fused", "slice", "add", "mul", "sqrt", "reduce_mean", "matmul", "sigmoid", "lstm"):
+        setattr(Dev, name, staticmethod((lambda f: (lambda *a: f(*a, ctx=ctx)))(getattr(K, name))))
+    Dev.reshape = staticmethod(lambda x, shp: K.reshape(x, shp))
+    pcm = npref.wav_to_f32(_payload(), 16, 1)
+    pcm = np.concatenate([pcm, np.zeros(175 * 512 - pcm.size, np.float32)])               # 89 600 = 175 x 512
+    w = _silero_like_weights(np.random.default_rng(11))
+    hd = cd = ho = co = np.zeros((1, 1, 128), np.float32)
+    worst = 0.0
+    for i in range(175):
+        chunk = pcm[i * 512:(i + 1) * 512]
+        pd, hd, cd = _chain(Dev, w, chunk, hd, cd)
+        po, ho, co = _chain(_OracleOps, w, chunk, ho, co)
+        hd_n, cd_n = hd.numpy(), cd.numpy()
+        worst = max(worst, float(np.abs(pd.numpy() - po).max()), float(np.abs(hd_n - ho).max()), float(np.abs(cd_n - co).max()))
+        # keep the two recurrences independent: each carries its own state (no re-synchronisation)
+    assert worst <= 1e-4, worst  # 175 dependent steps: the 1e-4 bar holds on the state itself
