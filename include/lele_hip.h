@@ -260,6 +260,26 @@ int lele_hip_gru(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const L
                  const LeleTensor* initial_h, int linear_before_reset, LeleBuf* out_y, LeleBuf* out_h, int64_t* y_shape,
                  int32_t* y_rank);
 
+/* ---- ConvInteger family, src/kernels/conv2d.rs:1507-2761 ------------------------------------- */
+/* conv_integer (conv2d.rs:2216): x, w hold u8 values as f32; zero points are host scalars ([1] or NULL = 0);
+ * out = f32 conv2d(x - x_zp, w - w_zp) with zero padding, as the x86 path computes it */
+int lele_hip_conv_integer(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* x_zero_point,
+                          const LeleTensor* w_zero_point, const int64_t* dilations, size_t ndil, int64_t group,
+                          const int64_t* pads, size_t npads, const int64_t* strides, size_t nstr, LeleBuf* out,
+                          int64_t* out_shape, int32_t* out_rank);
+/* conv_integer_from_f32 (conv2d.rs:2246; nsrc == 1) and conv_integer_from_f32_multi (conv2d.rs:2420; nsrc > 1, sources
+ * concatenated along C, upstream always 1x1/s1/p0): DynamicQuantizeLinear over ALL sources, then conv_integer.
+ * out_scale receives the quantisation scale ([1] f32, on the device -- upstream returns it as a host float) */
+int lele_hip_conv_integer_from_f32(LeleCtx* ctx, const LeleTensor* const* sources, size_t nsrc, const LeleTensor* w,
+                                   const LeleTensor* w_zero_point, const int64_t* dilations, size_t ndil, int64_t group,
+                                   const int64_t* pads, size_t npads, const int64_t* strides, size_t nstr, LeleBuf* out,
+                                   LeleBuf* out_scale, int64_t* out_shape, int32_t* out_rank);
+/* fused_scale_bias / fused_scale_bias_silu (conv2d.rs:2636-2761): out = data * scale + bias[c] (then x / (1 + exp(-x)));
+ * scale = scale_dev[0] * scale_mul (scale_dev may be NULL: scale = scale_mul) so that the scale produced by
+ * conv_integer_from_f32 never has to visit the host.  Passing the buffer of `data` as `out` is the in-place form. */
+int lele_hip_fused_scale_bias(LeleCtx* ctx, const LeleTensor* data, const LeleTensor* scale_dev_or_null, float scale_mul,
+                              const LeleTensor* bias, int silu, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+
 /* ---- application-side pre/post-processing ----------------------------------------------------- */
 /* examples/sensevoice/src/audio.rs:52-73: WAV payload bytes -> f32 mono.  16-bit: i16::from_le_bytes / 32768.0;
  * 8-bit: (b - 128) / 128; stereo: (l + r) / 2.  bytes: U8 [n].  out: f32 [frames] */

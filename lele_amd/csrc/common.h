@@ -101,6 +101,13 @@ namespace lele {
 // reference's radix-2 network; out_power is [rows, n_fft/2 + 1]
 int fft_rows_power(LeleCtx* ctx, const float* rows_in, int64_t rows, int64_t n_fft, float* out_power);
 
+// quant.hip: dynamic-quantisation parameters of the joint range of several device arrays (16 bytes on the device)
+struct QParamsDev {
+    float scale, zp, inv_scale;
+    int zp_i;
+};
+int quant_params_of(LeleCtx* ctx, const float* const* srcs, const int64_t* lens, int nsrc, void* prm_dev);
+
 inline int set_shape(int64_t* out_shape, int32_t* out_rank, std::initializer_list<int64_t> dims) {
     if (out_rank) *out_rank = (int32_t)dims.size();
     if (out_shape) {

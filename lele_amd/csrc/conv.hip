@@ -19,6 +19,7 @@
 #include "simd_math.h"
 
 #include <math.h>
+#include <string.h>
 #include <stdlib.h>
 
 using namespace lele;
@@ -325,6 +326,122 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
     return 0;
 }
 
+// ---- ConvInteger family (conv2d.rs:1507-2761).  On x86 lele subtracts the zero points in f32 and runs its f32 GEMM
+// (conv2d_with_zero_points, :1507-2000: w - w_zp at :1631-1718, x - x_zp inside im2col_with_zp with padding = 0), so the
+// result is the f32 convolution of the centred operands; here: one centring pass, then the implicit-GEMM convolution.
+__global__ void ci_sub_kernel(const float* __restrict__ x, int64_t n, float zp, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = x[i] - zp;
+}
+// conv_integer_from_f32 (:2246-2418, x86 branch :2388-2394): q = clamp(round(x * inv_scale + zp), 0, 255); the conv sees q - zp.
+// src is [N, src_c, spatial]; it lands in channels [ch_off, ch_off + src_c) of a [N, total_c, spatial] tensor (multi form)
+__global__ void ci_quant_center_kernel(const float* __restrict__ src, int64_t n_img, int64_t src_c, int64_t total_c,
+                                       int64_t ch_off, int64_t spatial, const QParamsDev* __restrict__ prm,
+                                       float* __restrict__ out) {
+    const QParamsDev q = prm[0];
+    const int64_t per_img = src_c * spatial, total = n_img * per_img;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t img = i / per_img, r = i - img * per_img;
+        float v = roundf(src[i] * q.inv_scale + q.zp);  // f32::round: half away from zero; mul then add, not fused
+        v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+        out[(img * total_c + ch_off) * spatial + r] = v - q.zp;
+    }
+}
+__global__ void ci_scale_out_kernel(const QParamsDev* __restrict__ prm, float* __restrict__ scale) { scale[0] = prm[0].scale; }
+// fused_scale_bias / fused_scale_bias_silu (:2636-2761, x86 branches): x = d*scale + bias[c]; silu: x / (1 + exp(-x))
+__global__ void ci_scale_bias_kernel(const float* __restrict__ d, int64_t total, int64_t channels, int64_t spatial,
+                                     const float* __restrict__ scale_dev, float scale_mul, const float* __restrict__ bias,
+                                     int silu, float* __restrict__ out) {
+    const float scale = scale_dev ? scale_dev[0] * scale_mul : scale_mul;  // in_scale * w_scale, as the caller multiplies
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = (i / spatial) % channels;
+        const float x = d[i] * scale + bias[c];
+        out[i] = silu ? x / (1.0f + expf(-x)) : x;
+    }
+}
+
+int conv_geom_from(const LeleTensor* x, const int64_t* xshape, const LeleTensor* w, const int64_t* dilations, size_t ndil,
+                   int64_t group, const int64_t* pads, size_t npads, const int64_t* strides, size_t nstr, ConvGeom* out) {
+    ConvGeom g{};
+    g.n = (int)xshape[0];
+    g.c = (int)xshape[1];
+    g.ih = (int)xshape[2];
+    g.iw = (int)xshape[3];
+    g.oc = (int)w->shape[0];
+    g.kh = (int)w->shape[2];
+    g.kw = (int)w->shape[3];
+    g.group = (int)group;
+    LELE_REQUIRE(group >= 1 && g.c % g.group == 0 && g.oc % g.group == 0, "conv_integer: channels not divisible by group");
+    g.icg = g.c / g.group;
+    g.ocg = g.oc / g.group;
+    LELE_REQUIRE(w->shape[1] == g.icg, "conv_integer: weight C_in/g mismatch");
+    g.dh = (int)attr(dilations, ndil, 0, 1);
+    g.dw = (int)attr(dilations, ndil, 1, 1);
+    g.sh = (int)attr(strides, nstr, 0, 1);
+    g.sw = (int)attr(strides, nstr, 1, 1);
+    int pb, pr;
+    if (npads >= 4) {
+        g.pt = (int)pads[0];
+        g.pl = (int)pads[1];
+        pb = (int)pads[2];
+        pr = (int)pads[3];
+    } else if (npads >= 2) {
+        g.pt = pb = (int)pads[0];
+        g.pl = pr = (int)pads[1];
+    } else {
+        g.pt = g.pl = pb = pr = 0;
+    }
+    const int64_t nh = (int64_t)g.ih + g.pt + pb - (int64_t)g.dh * (g.kh - 1) - 1;
+    const int64_t nw = (int64_t)g.iw + g.pl + pr - (int64_t)g.dw * (g.kw - 1) - 1;
+    LELE_REQUIRE(nh >= 0 && nw >= 0 && g.sh > 0 && g.sw > 0,
+                 "conv2d_with_zero_points: output dimensions must be positive");  // conv2d.rs:1602
+    g.oh = (int)(nh / g.sh + 1);
+    g.ow = (int)(nw / g.sw + 1);
+    g.K = g.icg * g.kh * g.kw;
+    g.plane = g.oh * g.ow;
+    *out = g;
+    return 0;
+}
+
+float host_scalar(const LeleTensor* t) {  // zp.data[0] or 0 (conv2d.rs:2227-2236); zero points are host-side attributes
+    if (!t || numel(t) == 0 || t->mem == LELE_MEM_DEVICE) return 0.0f;
+    return *(const float*)t->data;
+}
+
+// centred weights (w - w_zp), cached for immutable weights
+int centred_weights(LeleCtx* ctx, const LeleTensor* w, float w_zp, const float** out) {
+    const void* dw = nullptr;
+    if (w_zp == 0.0f) {
+        LELE_TRY(ctx->dev_ptr(w, &dw));
+        *out = (const float*)dw;
+        return 0;
+    }
+    const size_t bytes = (size_t)numel(w) * 4;
+    int zbits;
+    memcpy(&zbits, &w_zp, 4);
+    auto key = std::make_tuple((const void*)w->data, bytes, 500 + (zbits & 0x7fffff));
+    const bool cacheable = w->mem == LELE_MEM_WEIGHT;
+    if (cacheable) {
+        auto it = ctx->weights.find(key);
+        if (it != ctx->weights.end()) {
+            *out = (const float*)it->second;
+            return 0;
+        }
+    }
+    LELE_TRY(ctx->dev_ptr(w, &dw));
+    void* adj = nullptr;
+    if (cacheable) {
+        LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
+        LELE_HIP_CHECK(hipMalloc(&adj, std::max<size_t>(bytes, 16)));
+        ctx->weights[key] = adj;
+    } else {
+        LELE_TRY(ctx->arena_alloc(std::max<size_t>(bytes, 16), &adj));
+    }
+    hipLaunchKernelGGL(ci_sub_kernel, dim3(grid_for(numel(w))), dim3(256), 0, ctx->stream, (const float*)dw, numel(w), w_zp,
+                       (float*)adj);
+    *out = (const float*)adj;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -562,6 +679,117 @@ int lele_hip_conv_transpose(LeleCtx* ctx, const LeleTensor* x, const LeleTensor*
         }
     LELE_HIP_CHECK(hipGetLastError());
     return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, oh, ow});
+}
+
+int lele_hip_conv_integer(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* x_zero_point,
+                          const LeleTensor* w_zero_point, const int64_t* dilations, size_t ndil, int64_t group,
+                          const int64_t* pads, size_t npads, const int64_t* strides, size_t nstr, LeleBuf* out,
+                          int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && w && out, "conv_integer: NULL argument");
+    LELE_REQUIRE(x->rank == 4 && w->rank == 4 && x->dtype == LELE_F32 && w->dtype == LELE_F32,
+                 "conv_integer: rank-4 tensors holding u8 values as f32 required");  // conv2d.rs:1522-1523
+    LELE_REQUIRE(!(x_zero_point && x_zero_point->mem == LELE_MEM_DEVICE) && !(w_zero_point && w_zero_point->mem == LELE_MEM_DEVICE),
+                 "conv_integer: zero points are scalar attributes and must be host tensors");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    ConvGeom g;
+    LELE_TRY(conv_geom_from(x, x->shape, w, dilations, ndil, group, pads, npads, strides, nstr, &g));
+    const float x_zp = host_scalar(x_zero_point), w_zp = host_scalar(w_zero_point);
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    const float* dwc = nullptr;
+    LELE_TRY(centred_weights(ctx, w, w_zp, &dwc));
+    const float* xin = (const float*)dx;
+    if (x_zp != 0.0f) {
+        void* xc = nullptr;
+        LELE_TRY(ctx->arena_alloc((size_t)numel(x) * 4, &xc));
+        hipLaunchKernelGGL(ci_sub_kernel, dim3(grid_for(numel(x))), dim3(256), 0, ctx->stream, (const float*)dx, numel(x), x_zp,
+                           (float*)xc);
+        xin = (const float*)xc;
+    }
+    LELE_TRY(out->reserve((size_t)g.n * g.oc * g.plane * 4));
+    LeleTensor wv = *w;
+    wv.mem = LELE_MEM_DEVICE;  // the centred copy is what run_conv2d sees (its own weight cache keys on the pointer below)
+    wv.data = dwc;
+    LELE_TRY(run_conv2d(ctx, &wv, xin, dwc, nullptr, g, LELE_ACT_NONE, (float*)out->data));
+    return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, (int64_t)g.oh, (int64_t)g.ow});
+}
+
+// conv_integer_from_f32 (conv2d.rs:2246) and conv_integer_from_f32_multi (:2420: channel-concatenated sources, 1x1 conv).
+// nsrc == 1 with explicit attributes is the single form; out_scale receives the DynamicQuantizeLinear scale ([1], device).
+int lele_hip_conv_integer_from_f32(LeleCtx* ctx, const LeleTensor* const* sources, size_t nsrc, const LeleTensor* w,
+                                   const LeleTensor* w_zero_point, const int64_t* dilations, size_t ndil, int64_t group,
+                                   const int64_t* pads, size_t npads, const int64_t* strides, size_t nstr, LeleBuf* out,
+                                   LeleBuf* out_scale, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && sources && nsrc >= 1 && w && out && out_scale, "conv_integer_from_f32: NULL argument");
+    LELE_REQUIRE(w->rank == 4 && w->dtype == LELE_F32, "conv_integer_from_f32: rank-4 f32-coded weights required");
+    LELE_REQUIRE(!(w_zero_point && w_zero_point->mem == LELE_MEM_DEVICE), "conv_integer_from_f32: w_zero_point must be a host scalar");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    int64_t total_c = 0;
+    for (size_t i = 0; i < nsrc; ++i) {
+        const LeleTensor* s = sources[i];
+        LELE_REQUIRE(s && s->rank == 4 && s->dtype == LELE_F32, "conv_integer_from_f32: sources must be rank-4 f32");
+        LELE_REQUIRE(s->shape[0] == sources[0]->shape[0] && s->shape[2] == sources[0]->shape[2] && s->shape[3] == sources[0]->shape[3],
+                     "conv_integer_from_f32_multi: sources must share N, H, W");
+        total_c += s->shape[1];
+    }
+    const int64_t xshape[4] = {sources[0]->shape[0], total_c, sources[0]->shape[2], sources[0]->shape[3]};
+    ConvGeom g;
+    LELE_TRY(conv_geom_from(sources[0], xshape, w, dilations, ndil, group, pads, npads, strides, nstr, &g));
+    const float w_zp = host_scalar(w_zero_point);
+    LELE_TRY(ctx->arena_reset());
+    std::vector<const float*> ds(nsrc);
+    std::vector<int64_t> lens(nsrc);
+    for (size_t i = 0; i < nsrc; ++i) {
+        const void* d = nullptr;
+        LELE_TRY(ctx->dev_ptr(sources[i], &d));
+        ds[i] = (const float*)d;
+        lens[i] = numel(sources[i]);
+    }
+    const float* dwc = nullptr;
+    LELE_TRY(centred_weights(ctx, w, w_zp, &dwc));
+    void *prm = nullptr, *xq = nullptr;
+    LELE_TRY(ctx->arena_alloc(sizeof(QParamsDev), &prm));
+    const int64_t spatial = xshape[2] * xshape[3], total = xshape[0] * total_c * spatial;
+    LELE_TRY(ctx->arena_alloc((size_t)std::max<int64_t>(total, 1) * 4, &xq));
+    LELE_TRY(out->reserve((size_t)g.n * g.oc * g.plane * 4));
+    LELE_TRY(out_scale->reserve(4));
+    LELE_TRY(quant_params_of(ctx, ds.data(), lens.data(), (int)nsrc, prm));
+    int64_t ch_off = 0;
+    for (size_t i = 0; i < nsrc; ++i) {
+        if (lens[i])
+            hipLaunchKernelGGL(ci_quant_center_kernel, dim3(grid_for(lens[i])), dim3(256), 0, ctx->stream, ds[i], xshape[0],
+                               sources[i]->shape[1], total_c, ch_off, spatial, (const QParamsDev*)prm, (float*)xq);
+        ch_off += sources[i]->shape[1];
+    }
+    hipLaunchKernelGGL(ci_scale_out_kernel, dim3(1), dim3(1), 0, ctx->stream, (const QParamsDev*)prm, (float*)out_scale->data);
+    LeleTensor wv = *w;
+    wv.mem = LELE_MEM_DEVICE;
+    wv.data = dwc;
+    LELE_TRY(run_conv2d(ctx, &wv, (const float*)xq, dwc, nullptr, g, LELE_ACT_NONE, (float*)out->data));
+    return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, (int64_t)g.oh, (int64_t)g.ow});
+}
+
+int lele_hip_fused_scale_bias(LeleCtx* ctx, const LeleTensor* data, const LeleTensor* scale_dev_or_null, float scale_mul,
+                              const LeleTensor* bias, int silu, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && data && bias && out, "fused_scale_bias: NULL argument");
+    LELE_REQUIRE(data->rank == 4 && data->dtype == LELE_F32, "fused_scale_bias: [N,C,H,W] f32 required");
+    LELE_REQUIRE(numel(bias) >= data->shape[1], "fused_scale_bias: bias shorter than C");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    LELE_TRY(ctx->arena_reset());
+    const void *dd = nullptr, *db = nullptr, *dsc = nullptr;
+    LELE_TRY(ctx->dev_ptr(data, &dd));
+    LELE_TRY(ctx->dev_ptr(bias, &db));
+    if (scale_dev_or_null) LELE_TRY(ctx->dev_ptr(scale_dev_or_null, &dsc));
+    const int64_t total = numel(data);
+    LELE_TRY(out->reserve((size_t)total * 4));
+    if (total) {
+        hipLaunchKernelGGL(ci_scale_bias_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dd, total,
+                           data->shape[1], data->shape[2] * data->shape[3], (const float*)dsc, scale_mul, (const float*)db, silu,
+                           (float*)out->data);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(data->shape, data->shape + 4));
 }
 
 }  // extern "C"

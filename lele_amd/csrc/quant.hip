@@ -526,6 +526,34 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
 
 }  // namespace
 
+namespace lele {
+// {scale, zp, 1/scale, (int)zp} of the joint range of several device arrays (DynamicQuantizeLinear's rule,
+// avx/quantization.rs:134-140 == conv2d.rs:2329-2333); prm_dev receives 16 bytes laid out as QParamsDev (common.h)
+int quant_params_of(LeleCtx* ctx, const float* const* srcs, const int64_t* lens, int nsrc, void* prm_dev) {
+    int64_t total_blocks = 0;
+    std::vector<int> nb(nsrc);
+    for (int i = 0; i < nsrc; ++i) {
+        nb[i] = (int)std::max<int64_t>(1, std::min<int64_t>(256, (lens[i] + 4095) / 4096));
+        total_blocks += nb[i];
+    }
+    void* partial = nullptr;
+    LELE_TRY(ctx->arena_alloc((size_t)total_blocks * 8, &partial));
+    int64_t off = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        if (lens[i] > 0)
+            hipLaunchKernelGGL(qminmax_kernel, dim3(nb[i], 1), dim3(256), 0, ctx->stream, srcs[i], lens[i],
+                               (float*)partial + 2 * off);
+        else
+            nb[i] = 0;
+        off += nb[i];
+    }
+    hipLaunchKernelGGL(qparams_kernel, dim3(1), dim3(64), 0, ctx->stream, (const float*)partial, (int)off, (QParams*)prm_dev,
+                       (float*)nullptr, (float*)nullptr);
+    LELE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+}  // namespace lele
+
 extern "C" {
 
 int lele_hip_fused_quantized_linear(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8,

@@ -618,3 +618,69 @@ def wav_to_f32(payload, bits_per_sample=16, num_channels=1, out=None, ctx=None):
 def argmax_last(input, out=None, ctx=None):
     """examples/sensevoice/src/tokenizer.rs:50-61: greedy ids, last of equal maxima (Iterator::max_by) -> int32"""
     return _op(ctx, _lib.lib().lele_hip_argmax_last, [input], [], out, np.int32)
+
+
+# ------------------------------------------------------------------------------------------- ConvInteger family
+def conv_integer(input, weights, x_zero_point=None, w_zero_point=None, dilations=(), group=1, pads=(), strides=(), out=None,
+                 ctx=None):
+    """conv2d.rs:2216: u8 values carried as f32; zero points are [1] host tensors or None"""
+    keep = []
+    args = []
+    d, n = _lib.i64_array(list(dilations), keep)
+    args += [d, n, C.c_int64(int(group))]
+    for v in (pads, strides):
+        a, n = _lib.i64_array(list(v), keep)
+        args += [a, n]
+    return _op(ctx, _lib.lib().lele_hip_conv_integer, [input, weights, x_zero_point, w_zero_point], args, out)
+
+
+def _conv_integer_from(sources, weights, w_zero_point, dilations, group, pads, strides, out, ctx):
+    ctx = _ctx(ctx)
+    keep = []
+    ptrs = [_lib.as_tensor(unwrap(t), keep) for t in sources]
+    arr = (C.POINTER(_lib.LeleTensor) * len(ptrs))(*[C.cast(p, C.POINTER(_lib.LeleTensor)) for p in ptrs])
+    out = out or ctx.buf()
+    osc = ctx.buf()
+    sh = _lib.OutShape()
+    d, nd = _lib.i64_array(list(dilations), keep)
+    p, npd = _lib.i64_array(list(pads), keep)
+    st, ns = _lib.i64_array(list(strides), keep)
+    _lib.check(_lib.lib().lele_hip_conv_integer_from_f32(
+        ctx._h, arr, C.c_size_t(len(ptrs)), _lib.as_tensor(unwrap(weights), keep), _lib.as_tensor(unwrap(w_zero_point), keep),
+        d, nd, C.c_int64(int(group)), p, npd, st, ns, out._h, osc._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), np.float32)), TensorView(_lib.DevTensor(osc, (1,), np.float32))
+
+
+def conv_integer_from_f32(input, weights, w_zero_point=None, dilations=(), group=1, pads=(), strides=(), out=None, ctx=None):
+    """conv2d.rs:2246 -> (conv output, input scale [1] on the device)"""
+    return _conv_integer_from([input], weights, w_zero_point, dilations, group, pads, strides, out, ctx)
+
+
+def conv_integer_from_f32_multi(sources, weights, w_zero_point=None, out=None, ctx=None):
+    """conv2d.rs:2420: channel-concatenated sources, joint dynamic range, 1x1 convolution"""
+    return _conv_integer_from(list(sources), weights, w_zero_point, [1, 1], 1, [0, 0, 0, 0], [1, 1], out, ctx)
+
+
+def fused_scale_bias(data, scale, bias, silu=False, scale_mul=1.0, out=None, ctx=None):
+    """conv2d.rs:2710 / 2636 (silu=True): data * scale + bias[c]; `scale` is a python float or the [1] device tensor that
+    conv_integer_from_f32 returned (then the effective scale is scale[0] * scale_mul)"""
+    if isinstance(scale, (int, float, np.floating)):
+        sdev, mul = None, float(scale) * float(scale_mul)
+    else:
+        sdev, mul = scale, float(scale_mul)
+    return _fsb(ctx, data, sdev, mul, bias, silu, out)
+
+
+def _fsb(ctx, data, sdev, mul, bias, silu, out):
+    ctx = _ctx(ctx)
+    keep = []
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_fused_scale_bias(ctx._h, _lib.as_tensor(unwrap(data), keep), _lib.as_tensor(unwrap(sdev), keep),
+                                                    C.c_float(mul), _lib.as_tensor(unwrap(bias), keep), C.c_int(int(bool(silu))),
+                                                    out._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
+
+
+def fused_scale_bias_silu(data, scale, bias, scale_mul=1.0, out=None, ctx=None):
+    return fused_scale_bias(data, scale, bias, True, scale_mul, out, ctx)

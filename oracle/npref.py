@@ -234,3 +234,29 @@ def argmax_last(x):
     x = np.asarray(x, np.float32)
     v = x.shape[-1]
     return (v - 1 - np.argmax(x[..., ::-1], axis=-1)).astype(np.int32)
+
+
+# ---- ConvInteger family (conv2d.rs:1507-2761, x86 branches); the convolution itself is pyoracle.conv2d
+def dql_params(xs):
+    """scale, zp of the joint range of the arrays (conv2d.rs:2329-2333), in f32 arithmetic"""
+    mn = np.float32(min(float(np.min(x)) for x in xs if np.size(x)))
+    mx = np.float32(max(float(np.max(x)) for x in xs if np.size(x)))
+    amin, amax = np.float32(min(mn, np.float32(0))), np.float32(max(mx, np.float32(0)))
+    rng = np.float32(max(np.float32(amax - amin), np.float32(1e-5)))
+    scale = np.float32(rng / np.float32(255.0))
+    z = np.float32(-amin) / scale
+    zp = np.float32(np.clip(np.sign(z) * np.floor(np.abs(z) + np.float32(0.5)), 0, 255))  # f32::round: half away from zero
+    return scale, zp
+
+
+def dql_quantize(x, scale, zp):
+    inv = np.float32(1.0) / scale
+    t = (np.asarray(x, np.float32) * inv).astype(np.float32) + zp
+    r = np.sign(t) * np.floor(np.abs(t) + np.float32(0.5))
+    return np.clip(r, 0, 255).astype(np.float32)
+
+
+def fused_scale_bias(data, scale, bias, silu=False):
+    x = (np.asarray(data, np.float32) * np.float32(scale)).astype(np.float32) + np.asarray(bias, np.float32).reshape(1, -1, 1, 1)
+    x = x.astype(np.float32)
+    return (x / (np.float32(1.0) + np.exp(-x).astype(np.float32))).astype(np.float32) if silu else x

@@ -1,0 +1,72 @@
+"""ConvInteger family (conv2d.rs:1507-2761).  On x86 lele centres both operands in f32 and runs
+its f32 GEMM, so the oracle is pyoracle.conv2d on the centred values (+ the numpy DynamicQuantizeLinear of npref)."""
+import numpy as np
+import pytest
+
+from oracle import npref
+from oracle import pyoracle as O
+
+
+def _u8(rng, shape):
+    return rng.integers(0, 256, shape).astype(np.float32)
+
+
+def test_oracle_conv_integer_is_exact_integer_arithmetic():
+    rng = np.random.default_rng(0)
+    x, w = _u8(rng, (1, 3, 6, 6)), _u8(rng, (4, 3, 3, 3))
+    ref = O.conv2d(x - np.float32(120), w - np.float32(128), None, [1, 1], 1, [1, 1, 1, 1], [1, 1])
+    # small K: every partial sum is an integer below 2^24 -> the f32 result is the exact integer convolution
+    xi, wi = x.astype(np.int64) - 120, w.astype(np.int64) - 128
+    xp = np.pad(xi, ((0, 0), (0, 0), (1, 1), (1, 1)))
+    want = np.zeros((1, 4, 6, 6), np.int64)
+    for o in range(4):
+        for y in range(6):
+            for xx in range(6):
+                want[0, o, y, xx] = (xp[0, :, y:y + 3, xx:xx + 3] * wi[o]).sum()
+    assert np.array_equal(ref, want.astype(np.float32))
+    s, z = npref.dql_params([np.array([-1.0, 0.5, 3.0], np.float32)])
+    assert s == np.float32(4.0) / np.float32(255.0) and z == np.float32(64.0)  # round(1 / (4/255)) = round(63.75)
+    assert npref.dql_quantize(np.array([-1.0, 0.0, 3.0], np.float32), s, z).tolist() == [0.0, 64.0, 255.0]
+
+
+@pytest.mark.gpu
+def test_device_conv_integer_family(ctx):
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    rng = np.random.default_rng(1)
+    for (n, c, h, oc, k, st, g) in ((2, 8, 12, 16, 3, 1, 1), (1, 16, 9, 8, 1, 1, 1), (1, 6, 11, 9, 3, 2, 3), (1, 64, 20, 64, 3, 1, 1)):
+        x, w = _u8(rng, (n, c, h, h)), _u8(rng, (oc, c // g, k, k))
+        p = k // 2
+        for xz, wz in ((128.0, 128.0), (0.0, 113.0), (7.0, 0.0), (None, None)):
+            zx = None if xz is None else np.array([xz], np.float32)
+            zw = None if wz is None else np.array([wz], np.float32)
+            got = K.conv_integer(x, Weight(w), zx, zw, [1, 1], g, [p, p, p, p], [st, st], ctx=ctx).numpy()
+            want = O.conv2d(x - np.float32(xz or 0), w - np.float32(wz or 0), None, [1, 1], g, [p, p, p, p], [st, st])
+            assert got.shape == want.shape
+            assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    # from_f32: dynamic quantisation of the activations inside the op
+    xf = (rng.standard_normal((2, 8, 10, 10)) * 3).astype(np.float32)
+    w = _u8(rng, (12, 8, 3, 3))
+    zw = np.array([128.0], np.float32)
+    out, sc = K.conv_integer_from_f32(xf, Weight(w), zw, [1, 1], 1, [1, 1, 1, 1], [1, 1], ctx=ctx)
+    s, z = npref.dql_params([xf])
+    assert sc.numpy()[0] == s
+    want = O.conv2d(npref.dql_quantize(xf, s, z) - z, w - np.float32(128), None, [1, 1], 1, [1, 1, 1, 1], [1, 1])
+    assert np.abs(out.numpy() - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    # multi: joint range over the sources, channel concatenation, 1x1
+    a = (rng.standard_normal((1, 5, 7, 7)) * 2).astype(np.float32)
+    b = (rng.standard_normal((1, 3, 7, 7)) * 6 + 1).astype(np.float32)
+    w1 = _u8(rng, (4, 8, 1, 1))
+    out, sc = K.conv_integer_from_f32_multi([a, b], Weight(w1), zw, ctx=ctx)
+    s, z = npref.dql_params([a, b])
+    assert sc.numpy()[0] == s
+    q = np.concatenate([npref.dql_quantize(a, s, z), npref.dql_quantize(b, s, z)], 1)
+    want = O.conv2d(q - z, w1 - np.float32(128), None, [1, 1], 1, [0, 0, 0, 0], [1, 1])
+    assert np.abs(out.numpy() - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    # fused_scale_bias(_silu): host float scale, and the device scale of conv_integer_from_f32 times a weight scale
+    bias = rng.standard_normal(4).astype(np.float32)
+    got = K.fused_scale_bias(out, sc, bias, scale_mul=0.02, ctx=ctx).numpy()
+    eff = np.float32(s * np.float32(0.02))
+    assert np.array_equal(got, npref.fused_scale_bias(want * 0 + out.numpy(), eff, bias))
+    got = K.fused_scale_bias_silu(out, float(eff), bias, ctx=ctx).numpy()
+    assert np.abs(got - npref.fused_scale_bias(out.numpy(), eff, bias, True)).max() <= 1e-5 * max(1.0, np.abs(got).max())
