@@ -593,6 +593,61 @@ inline TensorView cast_to_i64(const TensorView& x, Buffer& out) {
     check(lele_hip_cast(ctx(), &tx, LELE_I64, out.raw(), sh.dims, &sh.rank));
     LELE_RET(out, LELE_I64);
 }
+// ---- ConvInteger family (conv2d.rs:2216-2761) and the app-side steps (examples/sensevoice/src/{audio,tokenizer}.rs)
+inline TensorView conv_integer(const TensorView& x, const TensorView& w, const TensorView* x_zero_point,
+                               const TensorView* w_zero_point, const std::vector<int64_t>& dilations, int64_t group,
+                               const std::vector<int64_t>& pads, const std::vector<int64_t>& strides, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c(), tw = w.c();
+    Opt zx(x_zero_point), zw(w_zero_point);
+    check(lele_hip_conv_integer(ctx(), &tx, &tw, zx.p, zw.p, dilations.data(), dilations.size(), group, pads.data(), pads.size(),
+                                strides.data(), strides.size(), out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+struct ConvIntOut {
+    TensorView out, scale;  // scale: [1] f32 on the device (upstream returns a host float)
+};
+inline ConvIntOut conv_integer_from_f32_multi(const std::vector<const TensorView*>& sources, const TensorView& w,
+                                              const TensorView* w_zero_point, const std::vector<int64_t>& dilations,
+                                              int64_t group, const std::vector<int64_t>& pads,
+                                              const std::vector<int64_t>& strides, Buffer& out, Buffer& out_scale) {
+    Shape sh;
+    std::vector<LeleTensor> ts;
+    for (const TensorView* t : sources) ts.push_back(t->c());
+    std::vector<const LeleTensor*> ps;
+    for (const LeleTensor& t : ts) ps.push_back(&t);
+    LeleTensor tw = w.c();
+    Opt zw(w_zero_point);
+    check(lele_hip_conv_integer_from_f32(ctx(), ps.data(), ps.size(), &tw, zw.p, dilations.data(), dilations.size(), group,
+                                         pads.data(), pads.size(), strides.data(), strides.size(), out.raw(), out_scale.raw(),
+                                         sh.dims, &sh.rank));
+    return {TensorView::from_device(out, sh.vec()), TensorView::from_device(out_scale, {1})};
+}
+inline ConvIntOut conv_integer_from_f32(const TensorView& x, const TensorView& w, const TensorView* w_zero_point,
+                                        const std::vector<int64_t>& dilations, int64_t group, const std::vector<int64_t>& pads,
+                                        const std::vector<int64_t>& strides, Buffer& out, Buffer& out_scale) {
+    return conv_integer_from_f32_multi({&x}, w, w_zero_point, dilations, group, pads, strides, out, out_scale);
+}
+inline TensorView fused_scale_bias(const TensorView& data, const TensorView* scale_dev, float scale_mul, const TensorView& bias,
+                                   bool silu, Buffer& out) {
+    Shape sh;
+    LeleTensor td = data.c(), tb = bias.c();
+    Opt sc(scale_dev);
+    check(lele_hip_fused_scale_bias(ctx(), &td, sc.p, scale_mul, &tb, silu, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView wav_to_f32(const TensorView& bytes, int bits_per_sample, int num_channels, Buffer& out) {
+    Shape sh;
+    LeleTensor tb = bytes.c();
+    check(lele_hip_wav_to_f32(ctx(), &tb, bits_per_sample, num_channels, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView argmax_last(const TensorView& x, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    check(lele_hip_argmax_last(ctx(), &tx, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_I32);
+}
 // view operators: shape bookkeeping only (shape.rs:2-52, 105-185)
 inline TensorView reshape(const TensorView& x, const std::vector<int64_t>& target) {
     const int64_t total = x.size();
