@@ -289,8 +289,8 @@ struct IgemmEpi {
     }
 };
 
-template <int BM, int BN, int WM, int WN, int BKB /* bytes of K per LDS tile: 64 or 128 */>
-__global__ __launch_bounds__(WM* WN * 64) void igemm_kernel(const int8_t* __restrict__ a, const int8_t* __restrict__ b,
+template <int BM, int BN, int WM, int WN, int BKB /* bytes of K per LDS tile: 64 or 128 */, int OCC = 1>
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC))) void igemm_kernel(const int8_t* __restrict__ a, const int8_t* __restrict__ b,
                                                             int64_t rows, int n, int kp, int64_t b_batch_stride,
                                                             int m_per_batch, IgemmEpi epi) {
     constexpr int NT = WM * WN * 64;
@@ -485,10 +485,10 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
     const int64_t b128 = ((rows + 127) / 128) * ((n + 127) / 128);
     // batched B needs every block to stay inside one batch slice: tiles never straddle slices when BM divides m,
     // otherwise fall back to one launch per slice (handled by the caller passing rows == m)
-#define IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BKB_)                                                                            \
+#define IGEMM_LAUNCH(BM_, BN_, WM_, WN_, BKB_, OCC_)                                                                         \
     do {                                                                                                                  \
         constexpr size_t lds = (size_t)2 * ((BM_) + (BN_)) * ((BKB_) + 16);                                               \
-        auto kern = igemm_kernel<BM_, BN_, WM_, WN_, BKB_>;                                                               \
+        auto kern = igemm_kernel<BM_, BN_, WM_, WN_, BKB_, OCC_>;                                                          \
         if (lds > 64 * 1024) {                                                                                            \
             static bool done = false;                                                                                     \
             if (!done) {                                                                                                  \
@@ -511,13 +511,13 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
         // 128-byte K tiles need 74 KB of LDS (2 workgroups/CU); with 64-byte tiles 3 fit.  When the whole grid fits in
         // one round of 3 per CU but not of 2, the shallower tile avoids a nearly empty second round.
         if (b128 > 2 * ctx->num_cus && b128 <= 3 * ctx->num_cus)
-            IGEMM_LAUNCH(128, 128, 2, 2, 64);
+            IGEMM_LAUNCH(128, 128, 2, 2, 64, 4);
         else
-            IGEMM_LAUNCH(128, 128, 2, 2, 128);
+            IGEMM_LAUNCH(128, 128, 2, 2, 128, 1);
     } else if (rows <= 32) {
-        IGEMM_LAUNCH(32, 128, 1, 4, 64);
+        IGEMM_LAUNCH(32, 128, 1, 4, 64, 1);
     } else {
-        IGEMM_LAUNCH(64, 64, 2, 2, 64);
+        IGEMM_LAUNCH(64, 64, 2, 2, 64, 1);
     }
 #undef IGEMM_LAUNCH
     LELE_HIP_CHECK(hipGetLastError());
