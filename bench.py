@@ -141,7 +141,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("LELE_BENCH_FORCE_DIST") == "1":  # FORCE_DIST: exercise RCCL init + collectives at N=1
         import torch
         import torch.distributed as dist  # backend "nccl" is RCCL on ROCm
         # LELE_BENCH_BACKEND=gloo + LELE_BENCH_SHARE_GPU=1 exist only to exercise this N>1 path on a one-GPU box
