@@ -99,6 +99,23 @@ def test_shfl_variant_is_identical(ctx, fe):
     assert np.array_equal(fe2.compute(x).numpy(), fe.compute(x).numpy())
 
 
+@pytest.mark.parametrize("var", ["LELE_HIP_FE_FUSED", "LELE_HIP_FE_GENERIC_MEL"])
+def test_kernel_variants_are_identical(ctx, fe, var):
+    # LELE_HIP_FE_FUSED=0: separate fe_frame_sum_kernel + unfused main kernel (the first-half-of-round-1 form);
+    # LELE_HIP_FE_GENERIC_MEL=1: table-driven mel loop instead of the unrolled default-bank rounds
+    from lele_amd.features import SenseVoiceFrontend
+    os.environ[var] = "0" if var.endswith("FUSED") else "1"
+    try:
+        fe2 = SenseVoiceFrontend(ctx=ctx)
+    finally:
+        del os.environ[var]
+    xs = np.stack([synth_pcm(40000, s) for s in range(3)])
+    assert np.array_equal(fe2.compute_batch(xs).numpy(), fe.compute_batch(xs).numpy())
+    x = synth_pcm(12345, 2)  # unaligned length: scalar staging loads
+    assert np.array_equal(fe2.compute(x).numpy(), fe.compute(x).numpy())
+    assert np.array_equal(fe2.logmel(x).numpy(), fe.logmel(x).numpy())
+
+
 def test_other_lfr_settings(ctx, orc):
     from lele_amd.features import FeatureConfig, SenseVoiceFrontend
     x = synth_pcm(9000, 4)
