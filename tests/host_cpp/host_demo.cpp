@@ -5,6 +5,7 @@
 // Driven by tests/test_host_cpp.py, which compares the output file with the oracle.
 #include "lele.hpp"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -35,6 +36,30 @@ int main(int argc, char** argv) {
             return 0;
         }
         return fail("context creation succeeded without a device");
+    }
+    if (mode == "latency") {  // host-side cost of one C-ABI call (device-resident operands, tiny kernel), and of a graph replay
+        try {
+            std::vector<float> h(512, 1.0f);
+            Buffer a, b, o;
+            a.upload(h.data(), h.size() * 4);
+            b.upload(h.data(), h.size() * 4);
+            TensorView ta = TensorView::from_device(a, {512}), tb = TensorView::from_device(b, {512});
+            for (int i = 0; i < 100; ++i) K::add(ta, tb, o);
+            lele::Ctx::current().sync();
+            const int n = 20000;
+            auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < n; ++i) K::add(ta, tb, o);
+            auto t1 = std::chrono::steady_clock::now();  // issue cost only (asynchronous)
+            lele::Ctx::current().sync();
+            auto t2 = std::chrono::steady_clock::now();
+            const double issue = std::chrono::duration<double, std::micro>(t1 - t0).count() / n;
+            const double total = std::chrono::duration<double, std::micro>(t2 - t0).count() / n;
+            std::printf("LATENCY issue_us_per_call=%.3f end_to_end_us_per_call=%.3f calls=%d\n", issue, total, n);
+            return 0;
+        } catch (const lele::Error& e) {
+            std::printf("FAIL lele::Error: %s\n", e.what());
+            return 1;
+        }
     }
     if (argc < 4) return fail("usage: host_demo run <pcm.f32> <out.f32>");
     try {

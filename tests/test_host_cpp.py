@@ -46,3 +46,14 @@ def test_host_cpp_frontend_cmvn_matches_oracle(tmp_path, orc):
     # CMVN is bit-exact on identical input (sequential per-dim sums as cmvn.rs:14-66)
     got = np.fromfile(pout, np.float32).reshape(want.shape)
     assert np.array_equal(got, orc.cmvn(feats))
+
+
+@pytest.mark.gpu
+def test_host_cpp_call_overhead_is_reported():
+    exe = _build()
+    r = subprocess.run([exe, "latency"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("LATENCY"), r.stdout + r.stderr
+    fields = dict(kv.split("=") for kv in r.stdout.split()[1:])
+    # the C ABI adds single-digit microseconds per call on the host; the GPU-side floor of a tiny kernel is a few more
+    assert float(fields["issue_us_per_call"]) < 50.0 and float(fields["end_to_end_us_per_call"]) < 100.0
+    print(r.stdout.strip())
