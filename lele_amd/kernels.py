@@ -684,3 +684,51 @@ def _fsb(ctx, data, sdev, mul, bias, silu, out):
 
 def fused_scale_bias_silu(data, scale, bias, scale_mul=1.0, out=None, ctx=None):
     return fused_scale_bias(data, scale, bias, True, scale_mul, out, ctx)
+
+
+# ------------------------------------------------------------------------------------------- i64-result comparisons
+def _is_i64(x):
+    return _dtype_of(x) == np.int64
+
+
+def equal_i64(a, b, out=None, ctx=None):
+    """math.rs:1201: element-wise a == b with numpy broadcasting, result 0/1 as i64 (inputs f32 or i64)"""
+    if _is_i64(a) and _is_i64(b):
+        return equal(a, b, out=out, ctx=ctx)
+    return cast_to_i64(equal(a, b, ctx=ctx), out=out, ctx=ctx)
+
+
+def equal_i64_f32_r(a, b, out=None, ctx=None):
+    """math.rs:1209: both f32 operands are truncated to i64 (`v as i64`) before the comparison"""
+    return equal(cast_to_i64(a, ctx=ctx), cast_to_i64(b, ctx=ctx), out=out, ctx=ctx)
+
+
+def equal_i64_f32_r_i64(a, b, out=None, ctx=None):
+    """math.rs:1219: a is i64, b is f32 truncated to i64"""
+    return equal(a, cast_to_i64(b, ctx=ctx), out=out, ctx=ctx)
+
+
+def equal_i64_f32_lhs(a, b, out=None, ctx=None):
+    """math.rs:1228: a is f32 truncated to i64, b is i64"""
+    return equal(cast_to_i64(a, ctx=ctx), b, out=out, ctx=ctx)
+
+
+def less_i64(a, b, out=None, ctx=None):
+    """math.rs:2161: a < b, result 0/1 as i64"""
+    if _is_i64(a) and _is_i64(b):
+        return less(a, b, out=out, ctx=ctx)
+    return cast_to_i64(less(a, b, ctx=ctx), out=out, ctx=ctx)
+
+
+def min_max(input, ctx=None):
+    """math.rs:56: (min, max) of all elements as python floats (+inf / -inf for an empty tensor)"""
+    shp = _shape_of(input)
+    if int(np.prod(shp)) == 0:
+        return float("inf"), float("-inf")
+    axes = list(_b.range(len(shp)))
+    mn = _reduce(4, input, axes, False, None, ctx).numpy().reshape(-1)[0]
+    mx = _reduce(2, input, axes, False, None, ctx).numpy().reshape(-1)[0]
+    return float(mn), float(mx)
+
+
+add_f32 = add  # math.rs:366: the same-shape f32 fast path of add

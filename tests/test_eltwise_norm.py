@@ -244,3 +244,22 @@ def test_device_norm_kats_axis_and_errors(ctx, orc):
     assert np.array_equal(Kk.batch_norm(x, s, bb, m, v, 1e-5, ctx=ctx).numpy(), orc.batch_norm(x, s, bb, m, v))
     x2 = rng.standard_normal((6, 3)).astype(np.float32)
     assert np.array_equal(Kk.batch_norm(x2, s, bb, m, v, 1e-5, ctx=ctx).numpy(), orc.batch_norm(x2, s, bb, m, v))
+
+
+@pytest.mark.gpu
+def test_i64_result_comparisons_and_min_max(ctx):
+    # math.rs:56, 1201-1235, 2161: the i64-valued comparison variants lele's emitters use for shape arithmetic
+    from lele_amd import kernels as K
+    a = np.array([[1.0, 2.5, -3.0], [4.0, 2.5, 7.9]], np.float32)
+    b = np.array([1.0, 2.0, -3.0], np.float32)
+    r = K.equal_i64(a, b, ctx=ctx).numpy()
+    assert r.dtype == np.int64 and np.array_equal(r, (a == b).astype(np.int64))
+    ai, bi = np.array([[1, 2, 3], [3, 2, 1]], np.int64), np.array([1, 2, 1], np.int64)
+    assert np.array_equal(K.equal_i64(ai, bi, ctx=ctx).numpy(), (ai == bi).astype(np.int64))
+    assert np.array_equal(K.less_i64(ai, bi, ctx=ctx).numpy(), (ai < bi).astype(np.int64))
+    assert np.array_equal(K.less_i64(a, b, ctx=ctx).numpy(), (a < b).astype(np.int64))
+    # `v as i64` truncates toward zero before comparing: 2.5 and 2.0 both become 2
+    assert np.array_equal(K.equal_i64_f32_r(a, b, ctx=ctx).numpy(), (a.astype(np.int64) == b.astype(np.int64)).astype(np.int64))
+    assert np.array_equal(K.equal_i64_f32_r_i64(ai, b, ctx=ctx).numpy(), (ai == b.astype(np.int64)).astype(np.int64))
+    assert np.array_equal(K.equal_i64_f32_lhs(a, bi, ctx=ctx).numpy(), (a.astype(np.int64) == bi).astype(np.int64))
+    assert K.min_max(a, ctx=ctx) == (-3.0, float(np.float32(7.9)))
