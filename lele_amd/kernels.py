@@ -394,6 +394,8 @@ def resize_nearest(input, scales=None, sizes=None, coordinate_transform_mode="as
         if len(sizes) < 4:
             raise _lib.LeleError("Resize: sizes must have at least 4 elements")
         oh, ow = int(sizes[2]), int(sizes[3])
+        if oh <= 0 or ow <= 0:
+            raise _lib.LeleError("Resize: sizes H and W must be positive")  # conv2d.rs:1310-1313
     elif scales is not None:
         sh_ = float(np.float32(scales[2])) if len(scales) >= 3 else 1.0
         sw_ = float(np.float32(scales[3])) if len(scales) >= 4 else 1.0
