@@ -165,20 +165,30 @@ __global__ void resize_nearest_kernel(const float* __restrict__ x, float* __rest
 struct PoolDesc {
     int in_h, in_w, out_h, out_w, kh, kw, sh, sw, pt, pl, dh, dw;
 };
-__global__ void max_pool2d_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t planes, PoolDesc d) {
-    const int64_t total = planes * d.out_h * d.out_w;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ow = (int)(i % d.out_w), oh = (int)((i / d.out_w) % d.out_h);
-        const int64_t p = i / ((int64_t)d.out_w * d.out_h);
+// one thread per output; 32-bit index arithmetic when the tensor allows it; every tap is an unconditional load from a
+// clamped address followed by a select (a bounds-checked load serialises one memory round trip per tap)
+template <typename I>
+__global__ __launch_bounds__(256) void max_pool2d_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t planes,
+                                                         PoolDesc d) {
+    const I plane_out = (I)d.out_h * d.out_w, plane_in = (I)d.in_h * d.in_w;
+    const I total = (I)planes * plane_out;
+    for (I i = (I)blockIdx.x * 256 + threadIdx.x; i < total; i += (I)gridDim.x * 256) {
+        const I p = i / plane_out;
+        const int r = (int)(i - p * plane_out);
+        const int oh = r / d.out_w, ow = r - oh * d.out_w;
+        const float* xp = x + (int64_t)p * plane_in;
+        const int ih0 = oh * d.sh - d.pt, iw0 = ow * d.sw - d.pl;
         float m = -INFINITY;
         for (int a = 0; a < d.kh; ++a) {
-            const int ih = oh * d.sh - d.pt + a * d.dh;
-            if (ih < 0 || ih >= d.in_h) continue;
+            const int ih = ih0 + a * d.dh;
+            const bool hin = ih >= 0 && ih < d.in_h;
+            const int rowoff = (hin ? ih : 0) * d.in_w;
+#pragma unroll 5
             for (int b = 0; b < d.kw; ++b) {
-                const int iw = ow * d.sw - d.pl + b * d.dw;
-                if (iw < 0 || iw >= d.in_w) continue;
-                const float v = x[(p * d.in_h + ih) * d.in_w + iw];
-                m = v > m ? v : m;
+                const int iw = iw0 + b * d.dw;
+                const bool in = hin && iw >= 0 && iw < d.in_w;
+                const float v = xp[rowoff + (in ? iw : 0)];
+                m = (in && v > m) ? v : m;
             }
         }
         out[i] = m;
@@ -711,8 +721,13 @@ int lele_hip_max_pool2d(LeleCtx* ctx, const LeleTensor* x, const int64_t* kernel
     LELE_TRY(ctx->dev_ptr(x, &dx));
     LELE_TRY(out->reserve((size_t)total * 4));
     if (total) {
-        hipLaunchKernelGGL(max_pool2d_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx,
-                           (float*)out->data, planes, d);
+        const int64_t in_total = planes * d.in_h * d.in_w;
+        if (total < (int64_t(1) << 31) && in_total < (int64_t(1) << 31))
+            hipLaunchKernelGGL(max_pool2d_kernel<int32_t>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx,
+                               (float*)out->data, planes, d);
+        else
+            hipLaunchKernelGGL(max_pool2d_kernel<int64_t>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx,
+                               (float*)out->data, planes, d);
         LELE_HIP_CHECK(hipGetLastError());
     }
     return set_shape(out_shape, out_rank, {x->shape[0], x->shape[1], (int64_t)d.out_h, (int64_t)d.out_w});
