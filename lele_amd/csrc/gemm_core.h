@@ -325,11 +325,7 @@ inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, i
         }
     }
     switch (best) {
-        case 0:
-            // K tile 16 + a register budget for 3+ waves/SIMD (accumulators stay in arch VGPRs, 128 total -> 4 blocks/CU)
-            // measured best at 4096^3: 103 TFLOP/s vs 92 (K tile 32, 2 blocks/CU) vs 90 (K tile 16, 2 blocks/CU)
-            launch_tile<128, 128, 2, 2, 16, 3>(st, al, bl, epi, M, N, K, batch);
-            break;
+        case 0: launch_tile<128, 128, 2, 4, 16, 4>(st, al, bl, epi, M, N, K, batch); break;  // 8 waves of 64x32
         case 1: launch_tile<64, 256, 2, 4, 16, 4>(st, al, bl, epi, M, N, K, batch); break;  // 8 waves of 32x64
         case 4: launch_tile<256, 128, 4, 2, 16, 4>(st, al, bl, epi, M, N, K, batch); break;  // 8 waves, 61 KB LDS, 2 per CU
         case 2: launch_tile<64, 64, 2, 2, 16>(st, al, bl, epi, M, N, K, batch); break;
