@@ -511,9 +511,9 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
         // 128-byte K tiles need 74 KB of LDS (2 workgroups/CU); with 64-byte tiles 3 fit.  When the whole grid fits in
         // one round of 3 per CU but not of 2, the shallower tile avoids a nearly empty second round.
         if (b128 > 2 * ctx->num_cus && b128 <= 3 * ctx->num_cus)
-            IGEMM_LAUNCH(128, 128, 2, 2, 64, 4);
+            IGEMM_LAUNCH(128, 128, 2, 4, 64, 4);
         else
-            IGEMM_LAUNCH(128, 128, 2, 2, 128, 1);
+            IGEMM_LAUNCH(128, 128, 2, 4, 128, 1);
     } else if (rows <= 32) {
         IGEMM_LAUNCH(32, 128, 1, 4, 64, 1);
     } else {
