@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
             auto put = [&](float* dst) {
 #pragma unroll
                 for (int rd = 0; rd < kR; ++rd)
-                    if (rd * 16 + p < tb.n_mels) dst[rd * 16] = vals[rd];
+                    if (rd * 16 + p < tb.n_mels) __builtin_nontemporal_store(vals[rd], &dst[rd * 16]);  // streamed: keep L2 for the PCM
             };
             if (lm_u) put(lm_u + (int64_t)fi * tb.n_mels + p);
             if (out_u) {
