@@ -112,18 +112,41 @@ def reduce(op, x, axes, keepdims):
 
 
 # ---- data movement (bit-exact): manipulation.rs, shape.rs, conv2d.rs:1051-1502, math.rs:2033-2302 ----------------
-def slice_(x, starts, ends, axes=(), steps=()):  # manipulation.rs:209-380 == numpy slicing with ONNX clamping
+def slice_(x, starts, ends, axes=(), steps=()):
+    """manipulation.rs:258-380, restated step by step (NOT numpy slicing: an `end` below -dim clamps to -dim and then
+    normalises to 0, so x[-2:-3:-1] on a length-2 axis is empty here, while numpy / ONNX yield one element)"""
     x = np.asarray(x)
-    idx = [slice(None)] * x.ndim
+    nd = x.ndim
+    a_start, a_end, a_step = [0] * nd, list(x.shape), [1] * nd
+    big = 2 ** 63 - 1
     for i in range(len(starts)):
-        ax = i if not len(axes) else axes[i] % x.ndim
-        st = steps[i] if i < len(steps) else 1
-        s, e = int(starts[i]), int(ends[i])
-        e = None if (e > (2 ** 62) or e < -(2 ** 62)) else e
-        if e is not None and st < 0 and e < -x.shape[ax]:
-            e = None
-        idx[ax] = slice(s, e, st)
-    return x[tuple(idx)]
+        ax = i if not len(axes) else (axes[i] + nd if axes[i] < 0 else axes[i])
+        dim = x.shape[ax]
+        step = int(steps[i]) if i < len(steps) else 1
+        s64, e64 = int(starts[i]), int(ends[i])
+        e_max, e_min = e64 > big // 2, e64 < -(2 ** 63) // 2
+        start = dim if s64 > dim else (-dim if s64 < -dim else s64)
+        end = dim if e_max else (-dim if e_min else (dim if e64 > dim else (-dim if e64 < -dim else e64)))
+        ns = start + dim if start < 0 else start
+        if e_max:
+            ne = dim if step > 0 else -1
+        elif e_min:
+            ne = 0 if step > 0 else -1
+        else:
+            ne = end + dim if end < 0 else end
+        if step > 0:
+            s, e = min(max(ns, 0), dim), min(max(ne, 0), dim)
+        else:
+            s, e = min(max(ns, 0), dim - 1), min(max(ne, -1), dim - 1)
+        a_start[ax], a_end[ax], a_step[ax] = s, e, step
+    idx = []
+    for s, e, st in zip(a_start, a_end, a_step):
+        if st > 0:
+            cnt = 0 if s >= e else (e - s + st - 1) // st
+        else:
+            cnt = 0 if s <= e else (s - e + (-st) - 1) // (-st)
+        idx.append(s + st * np.arange(cnt, dtype=np.int64))
+    return x[np.ix_(*idx)] if nd else x
 
 
 def pad(x, pads, value=0, mode="constant"):
