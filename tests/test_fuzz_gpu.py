@@ -127,3 +127,39 @@ def test_fuzz_strided_copies(ctx):
         ax = int(rng.integers(0, rank))
         parts = [x, x[tuple(slice(0, max(1, s // 2)) if d == ax else slice(None) for d, s in enumerate(shape))]]
         assert np.array_equal(K.concat(parts, ax, ctx=ctx).numpy(), np.concatenate(parts, ax)), ("concat", shape, ax)
+
+
+def test_fuzz_broadcast_reduce_norm_pad_gather(ctx):
+    from lele_amd import kernels as K
+    rng = np.random.default_rng(505)
+    for it in range(60):
+        rank = int(rng.integers(1, 5))
+        shape = [int(rng.integers(1, 8)) for _ in range(rank)]
+        a = rng.standard_normal(shape).astype(np.float32)
+        bshape = [s if rng.integers(0, 2) else 1 for s in shape][int(rng.integers(0, rank)):]  # numpy-style broadcast partner
+        b = (rng.standard_normal(bshape) + 2.5).astype(np.float32)
+        for name in ("add", "sub", "mul", "div", "max", "min", "less", "greater", "equal"):
+            got = getattr(K, name)(a, b, ctx=ctx).numpy()
+            assert np.array_equal(got, npref.binary(name, a, b)), (name, shape, bshape)
+        axes = sorted(set(int(v) for v in rng.integers(0, rank, int(rng.integers(1, rank + 1)))))
+        keep = bool(it % 2)
+        for op, fn in (("sum", K.reduce_sum), ("mean", K.reduce_mean), ("max", K.reduce_max), ("l2", K.reduce_l2)):
+            assert np.array_equal(fn(a, axes, keep, ctx=ctx).numpy(), npref.reduce(op, a, axes, keep)), (op, shape, axes, keep)
+        pads = [int(v) for v in rng.integers(0, 3, 2 * rank)]
+        mode = ["constant", "edge", "reflect"][it % 3]
+        if mode == "reflect" and any(p >= s for p, s in zip(pads[:rank], shape)) or any(p >= s for p, s in zip(pads[rank:], shape)):
+            mode = "constant"
+        assert np.array_equal(K.pad(a, pads, np.array([1.5], np.float32), mode, ctx=ctx).numpy(), npref.pad(a, pads, 1.5, mode)), (
+            "pad", shape, pads, mode)
+        ax = int(rng.integers(0, rank))
+        idx = rng.integers(0, shape[ax], (int(rng.integers(1, 5)),)).astype(np.float32)
+        assert np.array_equal(K.gather(a, idx, ax, ctx=ctx).numpy(), npref.gather(a, idx, ax)), ("gather", shape, ax)
+    for it in range(30):
+        outer, n = int(rng.integers(1, 40)), int(rng.choice([1, 7, 8, 31, 32, 33, 80, 171, 255, 256, 257, 504, 512, 600, 1024, 1500]))
+        x = (rng.standard_normal((outer, n)) * 3).astype(np.float32)
+        g, bta = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+        assert np.array_equal(K.layer_norm(x, g, bta, -1, 1e-5, ctx=ctx).numpy(), O.layer_norm(x, g, bta, -1, 1e-5)), ("ln", outer, n)
+        got, want = K.softmax(x, -1, ctx=ctx).numpy(), O.softmax(x, -1)
+        body = n & ~7
+        assert np.array_equal(got[:, :body], want[:, :body]) and np.abs(got - want).max() <= 1e-6, ("softmax", outer, n)
+        assert np.array_equal(K.rms_norm(x, g, -1, 1e-6, ctx=ctx).numpy(), O.rms_norm(x, g, -1, 1e-6)), ("rms", outer, n)
