@@ -196,6 +196,144 @@ __global__ __launch_bounds__(256) void depthwise_conv2d_kernel(const float* __re
     }
 }
 
+// depthwise with unit stride and dilation along the width: one thread produces FOUR consecutive outputs of a row from
+// a sliding window of kw + 3 inputs held in registers, and every weight is fetched once per thread -- (kw + 3) + kw
+// loads per tap row instead of 8 kw.  (The one-output-per-thread kernel above is bound by the rate at which the texture
+// path accepts wave-wide 4-byte loads: 25 us for the [32, 512, 171] k = 11 FSMN convolution.)  Same tap order, same
+// skip-when-out-of-range select, same FMA chain per output: bit-identical results.
+struct DwGeom {  // the scalars the row kernel needs (the full ConvGeom spills SGPRs)
+    int ih, iw, oh, ow, oc, kh, sh, dh, pt, pl, body;
+};
+template <int KW>
+__global__ __launch_bounds__(256) void depthwise_row4_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             DwGeom g, int act, unsigned total, unsigned ngroups) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    const unsigned t = i / ngroups, gq = i - t * ngroups;
+    const unsigned pl = t / (unsigned)g.oh;
+    const int oy = (int)(t - pl * (unsigned)g.oh);
+    const int ox0 = (int)gq * 4, ix0 = ox0 - g.pl, iy0 = oy * g.sh - g.pt;
+    const int ch = (int)(pl % (unsigned)g.oc);
+    const float* xp = x + (int64_t)pl * g.ih * g.iw;
+    const float* wp = w + ch * g.kh * KW;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int a = 0; a < g.kh; ++a) {
+        const int iy = iy0 + a * g.dh;
+        const bool yin = iy >= 0 && iy < g.ih;
+        const float* row = xp + (yin ? iy : 0) * g.iw;
+        float xs[KW + 3], wv[KW];
+#pragma unroll
+        for (int j = 0; j < KW + 3; ++j) {
+            const int ix = ix0 + j;
+            xs[j] = row[min(max(ix, 0), g.iw - 1)];
+        }
+#pragma unroll
+        for (int b = 0; b < KW; ++b) wv[b] = wp[a * KW + b];
+#pragma unroll
+        for (int j = 0; j < KW + 3; ++j) {  // an out-of-range input position is skipped by every output that taps it
+            const int ix = ix0 + j;
+            const bool in = yin && ix >= 0 && ix < g.iw;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = j - q;
+                if (b >= 0 && b < KW) {
+                    // accumulate in tap order per output: output q sees taps b = 0..KW-1 as j = q..q+KW-1 ascends
+                    const float f = fmaf_(xs[j], wv[b], acc[q]);
+                    acc[q] = in ? f : acc[q];
+                }
+            }
+        }
+    }
+    const float bv = bias ? bias[ch] : 0.0f;
+    float* orow = out + ((int64_t)pl * g.oh + oy) * g.ow;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ox = ox0 + q;
+        if (ox < g.ow) {
+            float v = acc[q];
+            if (bias) v = v + bv;
+            orow[ox] = apply_act(v, act, oy * g.ow + ox < g.body);
+        }
+    }
+}
+
+// LDS-staged form of the same computation for planes that fit in LDS: a workgroup copies PB whole input planes
+// (one contiguous run of global memory, 16-byte loads when aligned) into LDS, every thread then slides its window over
+// LDS, results are collected in LDS and leave as one contiguous run.  The row kernel above reads global memory with a
+// 16-byte lane stride, which the vector L1 handles as one access per lane (rocprofv3: 45 cache accesses per load
+// instruction, 16 us for 22 MB); this form issues only fully coalesced global accesses.  Arithmetic is identical.
+__device__ __forceinline__ void dw_copy_run(const float* __restrict__ src, float* __restrict__ dst, unsigned count, bool vec) {
+    if (vec) {  // src and dst 16-byte aligned
+        const unsigned nv = count >> 2;
+        for (unsigned e = threadIdx.x; e < nv; e += 256u)
+            reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(src)[e];
+        for (unsigned e = 4 * nv + threadIdx.x; e < count; e += 256u) dst[e] = src[e];
+    } else {
+        for (unsigned e = threadIdx.x; e < count; e += 256u) dst[e] = src[e];
+    }
+}
+template <int KW>
+__global__ __launch_bounds__(256) void depthwise_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ out,
+                                                            DwGeom g, int act, unsigned planes, unsigned pb, unsigned ngroups) {
+    extern __shared__ __attribute__((aligned(16))) float dw_lds[];
+    const unsigned ihw = (unsigned)(g.ih * g.iw), ohw = (unsigned)(g.oh * g.ow);
+    const unsigned pl0 = blockIdx.x * pb, np = planes - pl0 < pb ? planes - pl0 : pb;
+    float* lin = dw_lds;
+    float* lout = dw_lds + ((pb * ihw + 3u) & ~3u);
+    const float* src = x + (size_t)pl0 * ihw;
+    float* dst = out + (size_t)pl0 * ohw;
+    dw_copy_run(src, lin, np * ihw, (((uintptr_t)src) & 15) == 0);
+    __syncthreads();
+    const unsigned per_plane = (unsigned)g.oh * ngroups, items = np * per_plane;
+    for (unsigned it = threadIdx.x; it < items; it += 256u) {
+        const unsigned p = it / per_plane, r = it - p * per_plane;
+        const int oy = (int)(r / ngroups);
+        const int ox0 = (int)(r - (unsigned)oy * ngroups) * 4, ix0 = ox0 - g.pl, iy0 = oy * g.sh - g.pt;
+        const int ch = (int)((pl0 + p) % (unsigned)g.oc);
+        const float* xp = lin + p * ihw;
+        const float* wp = w + ch * g.kh * KW;
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int a = 0; a < g.kh; ++a) {
+            const int iy = iy0 + a * g.dh;
+            const bool yin = iy >= 0 && iy < g.ih;
+            const float* row = xp + (yin ? iy : 0) * g.iw;
+            float xs[KW + 3], wv[KW];
+#pragma unroll
+            for (int j = 0; j < KW + 3; ++j) xs[j] = row[min(max(ix0 + j, 0), g.iw - 1)];
+#pragma unroll
+            for (int b = 0; b < KW; ++b) wv[b] = wp[a * KW + b];
+#pragma unroll
+            for (int j = 0; j < KW + 3; ++j) {
+                const int ix = ix0 + j;
+                const bool in = yin && ix >= 0 && ix < g.iw;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = j - q;
+                    if (b >= 0 && b < KW) {
+                        const float f = fmaf_(xs[j], wv[b], acc[q]);
+                        acc[q] = in ? f : acc[q];
+                    }
+                }
+            }
+        }
+        const float bv = bias ? bias[ch] : 0.0f;
+        float* orow = lout + p * ohw + (unsigned)oy * (unsigned)g.ow;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ox = ox0 + q;
+            if (ox < g.ow) {
+                float v = acc[q];
+                if (bias) v = v + bv;
+                orow[ox] = apply_act(v, act, oy * g.ow + ox < g.body);
+            }
+        }
+    }
+    __syncthreads();
+    dw_copy_run(lout, dst, np * ohw, (((uintptr_t)dst) & 15) == 0);
+}
+
 // conv_transpose (group 1): gather form of the reference's GEMM + col2im scatter (conv2d.rs:3060-3126)
 struct CtGeom {
     int n, c, ih, iw, oc, kh, kw, pt, pl, sh, sw, dh, dw, oh, ow;
@@ -282,8 +420,42 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
     if (g.icg == 1 && g.ocg == 1) {
         const int64_t total = (int64_t)g.n * g.oc * g.plane;
         LELE_REQUIRE(total < (int64_t(1) << 32), "depthwise conv: more than 2^32 output elements");
-        hipLaunchKernelGGL(depthwise_conv2d_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dx, dw, db, out, g, act,
-                           (unsigned)total);
+        const unsigned ngroups = (unsigned)((g.ow + 3) / 4);
+        const int64_t threads = (int64_t)g.n * g.oc * g.oh * ngroups;
+        const DwGeom dg{g.ih, g.iw, g.oh, g.ow, g.oc, g.kh, g.sh, g.dh, g.pt, g.pl, g.plane & ~7};
+        const dim3 rgrid((unsigned)((threads + 255) / 256));
+#define LELE_DW_ROW(KW) \
+    hipLaunchKernelGGL(depthwise_row4_kernel<KW>, rgrid, dim3(256), 0, ctx->stream, dx, dw, db, out, dg, act, (unsigned)threads, ngroups)
+        const bool row_ok = g.sw == 1 && g.dw == 1 && g.ow >= 8 && threads < (int64_t(1) << 31);
+        // planes per workgroup for the LDS-staged form: input + output planes within 64 KB, enough workgroups to fill the chip
+        const int64_t ihw = (int64_t)g.ih * g.iw, plane_floats = ihw + g.plane + 8, planes = (int64_t)g.n * g.oc;
+        int64_t pb = (16 * 1024 - 8) / plane_floats;
+        while (pb > 1 && (planes + pb - 1) / pb < 4 * (int64_t)ctx->num_cus) pb = (pb + 1) / 2;
+        const bool lds_ok = row_ok && pb >= 1 && (g.kw == 3 || g.kw == 5 || g.kw == 7 || g.kw == 11) && !getenv("LELE_HIP_DW_NO_LDS");
+        if (lds_ok) {
+            const size_t lds = (size_t)((((pb * ihw + 3) & ~int64_t(3)) + pb * g.plane) * 4);
+            const dim3 lgrid((unsigned)((planes + pb - 1) / pb));
+#define LELE_DW_LDS(KW) \
+    hipLaunchKernelGGL(depthwise_lds_kernel<KW>, lgrid, dim3(256), lds, ctx->stream, dx, dw, db, out, dg, act, (unsigned)planes, \
+                       (unsigned)pb, ngroups)
+            if (g.kw == 3) LELE_DW_LDS(3);
+            else if (g.kw == 5) LELE_DW_LDS(5);
+            else if (g.kw == 7) LELE_DW_LDS(7);
+            else LELE_DW_LDS(11);
+#undef LELE_DW_LDS
+        } else if (row_ok && g.kw == 3) {
+            LELE_DW_ROW(3);
+        } else if (row_ok && g.kw == 5) {
+            LELE_DW_ROW(5);
+        } else if (row_ok && g.kw == 7) {
+            LELE_DW_ROW(7);
+        } else if (row_ok && g.kw == 11) {
+            LELE_DW_ROW(11);
+#undef LELE_DW_ROW
+        } else {
+            hipLaunchKernelGGL(depthwise_conv2d_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dx, dw, db, out, g, act,
+                               (unsigned)total);
+        }
     } else {
         ConvWLoad al{dw, g, (int)((((uintptr_t)dw & 15) == 0) && g.K % 4 == 0)};
         ConvEpi epi{out, db, g, act};

@@ -155,6 +155,49 @@ __global__ void binary_kernel(int op, const T* __restrict__ a, const T* __restri
     }
 }
 
+// Fast path for the broadcast patterns generated models actually use (same shape, scalar, bias over the trailing dims,
+// per-channel term over NCHW): element i of the output reads operand[(i / inner) % len] (or operand[i] when `full`), so
+// a float4 chunk needs no per-element index walk.  Host-side conditions (binary_fast_map) guarantee that a 4-chunk
+// never straddles two operand elements (inner % 4 == 0) or is contiguous in the operand (inner == 1, len % 4 == 0).
+// Same binary_apply, element by element: bit-identical to binary_kernel.
+struct OperandMap {
+    unsigned inner, len;
+    int full;
+};
+__device__ __forceinline__ float4 fetch4(const float* __restrict__ p, const OperandMap m, unsigned i) {
+    if (m.full) return *reinterpret_cast<const float4*>(p + i);
+    if (m.len == 1) {
+        const float v = p[0];
+        return make_float4(v, v, v, v);
+    }
+    if (m.inner == 1) return *reinterpret_cast<const float4*>(p + i % m.len);
+    const float v = p[(i / m.inner) % m.len];
+    return make_float4(v, v, v, v);
+}
+__device__ __forceinline__ float fetch1(const float* __restrict__ p, const OperandMap m, unsigned i) {
+    return m.full ? p[i] : p[(i / m.inner) % m.len];
+}
+__global__ __launch_bounds__(256) void binary_fast_kernel(int op, const float* __restrict__ a, const float* __restrict__ b,
+                                                          float* __restrict__ out, unsigned n, OperandMap ma, OperandMap mb) {
+    const unsigned nvec = n >> 2, gtid = blockIdx.x * 256u + threadIdx.x, gstride = gridDim.x * 256u;
+    float4* ov = reinterpret_cast<float4*>(out);
+    unsigned v = gtid;
+    for (; v + gstride < nvec; v += 2 * gstride) {  // two chunks per trip: both operands' loads in flight together
+        const float4 a0 = fetch4(a, ma, 4 * v), b0 = fetch4(b, mb, 4 * v);
+        const float4 a1 = fetch4(a, ma, 4 * (v + gstride)), b1 = fetch4(b, mb, 4 * (v + gstride));
+        ov[v] = make_float4(binary_apply<float>(op, a0.x, b0.x), binary_apply<float>(op, a0.y, b0.y),
+                            binary_apply<float>(op, a0.z, b0.z), binary_apply<float>(op, a0.w, b0.w));
+        ov[v + gstride] = make_float4(binary_apply<float>(op, a1.x, b1.x), binary_apply<float>(op, a1.y, b1.y),
+                                      binary_apply<float>(op, a1.z, b1.z), binary_apply<float>(op, a1.w, b1.w));
+    }
+    if (v < nvec) {
+        const float4 a0 = fetch4(a, ma, 4 * v), b0 = fetch4(b, mb, 4 * v);
+        ov[v] = make_float4(binary_apply<float>(op, a0.x, b0.x), binary_apply<float>(op, a0.y, b0.y),
+                            binary_apply<float>(op, a0.z, b0.z), binary_apply<float>(op, a0.w, b0.w));
+    }
+    for (unsigned i = 4 * nvec + gtid; i < n; i += gstride) out[i] = binary_apply<float>(op, fetch1(a, ma, i), fetch1(b, mb, i));
+}
+
 // where_op (manipulation.rs:1215-): out = cond != 0 ? x : y, three-way broadcast
 __global__ void where_kernel(const float* __restrict__ cnd, const float* __restrict__ x, const float* __restrict__ y,
                              float* __restrict__ out, int64_t numel, Bcast bc) {
@@ -481,6 +524,34 @@ int make_bcast(const LeleTensor* const* ops, int nops, Bcast* bc, std::vector<in
     return 0;
 }
 
+// OperandMap of one operand of a broadcast (strides from make_bcast), or false when the pattern is not a single
+// contiguous run of non-broadcast dimensions / not float4-friendly.
+bool binary_fast_map(const Bcast& bc, const int64_t* stride, const void* ptr, int64_t n, int64_t count, OperandMap* m) {
+    if (((uintptr_t)ptr & 15) != 0) return false;
+    if (count == n) {
+        *m = OperandMap{1u, 1u, 1};
+        return true;
+    }
+    int first = -1, last = -1;
+    for (int d = 0; d < bc.rank; ++d)
+        if (stride[d] != 0 && bc.oshape[d] != 1) {
+            if (first < 0) first = d;
+            last = d;
+        }
+    if (first < 0) {  // a single element
+        *m = OperandMap{1u, 1u, 0};
+        return true;
+    }
+    for (int d = first; d <= last; ++d)
+        if (stride[d] == 0 && bc.oshape[d] != 1) return false;  // a broadcast dimension inside the run
+    int64_t inner = 1, len = 1;
+    for (int d = last + 1; d < bc.rank; ++d) inner *= bc.oshape[d];
+    for (int d = first; d <= last; ++d) len *= bc.oshape[d];
+    if (!(inner % 4 == 0 || (inner == 1 && len % 4 == 0))) return false;
+    *m = OperandMap{(unsigned)inner, (unsigned)len, 0};
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -530,7 +601,12 @@ int lele_hip_binary(LeleCtx* ctx, int op, const LeleTensor* a, const LeleTensor*
     LELE_TRY(out->reserve((size_t)n * es));
     if (n) {
         const int same = (numel(a) == n && numel(b) == n) ? 1 : 0;
-        if (a->dtype == LELE_F32)
+        OperandMap ma, mb;
+        if (a->dtype == LELE_F32 && n < (int64_t(1) << 32) && (((uintptr_t)out->data) & 15) == 0 &&
+            binary_fast_map(bc, bc.astride, da, n, numel(a), &ma) && binary_fast_map(bc, bc.bstride, db, n, numel(b), &mb))
+            hipLaunchKernelGGL(binary_fast_kernel, dim3(grid_for((n + 7) / 8)), dim3(256), 0, ctx->stream, op, (const float*)da,
+                               (const float*)db, (float*)out->data, (unsigned)n, ma, mb);
+        else if (a->dtype == LELE_F32)
             hipLaunchKernelGGL(binary_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ctx->stream, op, (const float*)da,
                                (const float*)db, (float*)out->data, n, bc, same);
         else

@@ -13,6 +13,7 @@
 // Global -> register -> LDS with the next tile's loads in flight during the MFMAs (double-buffered LDS,
 // one __syncthreads per K tile).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -103,6 +104,27 @@ struct EpiAffine {
     }
 };
 
+// ---------------------------------------------------------------------------------------------- tile order
+// The dispatcher is observed to place workgroup b on XCD b % 8 (MI355X_MICROARCH.md, "Workgroup dispatch"; a matter of
+// speed only, never of correctness), and every XCD has its own 4 MiB L2.  In launch order, the tiles that share an
+// A row-panel or a B column-panel would therefore be spread over all eight L2s and each of them would fetch the panel
+// from HBM again (measured on the batched 171x171x128 attention product: 64 % L2 misses, 3x the compulsory traffic).
+// tile_coords() re-labels the workgroups so that every XCD works through one CONTIGUOUS range of logical tiles, and
+// walks that range in patches of up to 8 tile-rows so that the tiles in flight together form a compact 2-D block.
+__device__ __forceinline__ void tile_coords(unsigned& tx, unsigned& ty, unsigned& tz) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, per_batch = gx * gy, total = per_batch * gridDim.z;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned xcd = lin & 7u, base = total >> 3, rem = total & 7u;
+    const unsigned logical = xcd * base + (xcd < rem ? xcd : rem) + (lin >> 3);
+    tz = logical / per_batch;
+    const unsigned l = logical - tz * per_batch;
+    const unsigned width = 8u * gx, group = l / width, first = group * 8u;
+    const unsigned rows = gy - first < 8u ? gy - first : 8u;
+    const unsigned in_group = l - group * width;
+    ty = first + in_group % rows;
+    tx = in_group / rows;
+}
+
 // ---------------------------------------------------------------------------------------------- kernel
 template <int BM, int BN, int WM, int WN, int BK, class AL, class BL, class EPI, int OCC = 1>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC))) void gemm_f32_mfma_kernel(AL al, BL bl, EPI epi, int M, int N, int K) {
@@ -117,7 +139,9 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN, batch = blockIdx.z;
+    unsigned tx, ty, tz;
+    tile_coords(tx, ty, tz);
+    const int m0 = ty * BM, n0 = tx * BN, batch = tz;
     const int hv = lane >> 5, l31 = lane & 31;
 
     float4 ra[ASLOTS], rb[BSLOTS];
@@ -232,7 +256,9 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(AL al, BL bl, EPI e
     __shared__ float red[4][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hv = lane >> 5, l31 = lane & 31;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32, batch = blockIdx.z;
+    unsigned tx, ty, tz;
+    tile_coords(tx, ty, tz);
+    const int m0 = ty * 32, n0 = tx * 32, batch = tz;
     const int row = m0 + l31, col = n0 + l31;
     const int nchunk = (K + 15) / 16, per = (nchunk + 3) / 4;
     const int c0 = wave * per, c1 = c0 + per < nchunk ? c0 + per : nchunk;
@@ -299,6 +325,26 @@ template <class AL, class BL, class EPI>
 inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int batch,
                    int num_cus) {
     if (M <= 0 || N <= 0 || batch <= 0) return;
+    static const int force = getenv("LELE_HIP_GEMM_FORCE") ? atoi(getenv("LELE_HIP_GEMM_FORCE")) : -1;  // A/B experiments
+    if (force >= 0) {
+        switch (force) {
+            case 0: launch_tile<128, 128, 2, 4, 16, 4>(st, al, bl, epi, M, N, K, batch); return;
+            case 1: launch_tile<64, 256, 2, 4, 16, 4>(st, al, bl, epi, M, N, K, batch); return;
+            case 2: launch_tile<64, 64, 2, 2, 16>(st, al, bl, epi, M, N, K, batch); return;
+            case 3: launch_tile<32, 128, 1, 4, 16>(st, al, bl, epi, M, N, K, batch); return;
+            case 4: launch_tile<256, 128, 4, 2, 16, 4>(st, al, bl, epi, M, N, K, batch); return;
+            case 5: {
+                dim3 grid((N + 31) / 32, (M + 31) / 32, batch);
+                hipLaunchKernelGGL((gemm_f32_small_kernel<AL, BL, EPI>), grid, dim3(256), 0, st, al, bl, epi, M, N, K);
+                return;
+            }
+            case 6: launch_tile<64, 64, 2, 2, 32>(st, al, bl, epi, M, N, K, batch); return;
+            case 7: launch_tile<64, 64, 2, 2, 64>(st, al, bl, epi, M, N, K, batch); return;
+            case 8: launch_tile<64, 192, 2, 2, 16>(st, al, bl, epi, M, N, K, batch); return;
+            case 9: launch_tile<64, 64, 2, 2, 16, 4>(st, al, bl, epi, M, N, K, batch); return;
+            default: break;
+        }
+    }
     // too few 64x64 tiles to fill the chip: 32x32 tiles with a 4-way split of K (latency-optimised, see above)
     if ((int64_t)((M + 63) / 64) * ((N + 63) / 64) * batch < 2 * (int64_t)num_cus && K >= 16) {
         dim3 grid((N + 31) / 32, (M + 31) / 32, batch);

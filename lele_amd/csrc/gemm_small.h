@@ -23,8 +23,10 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const int8_t* __restri
     __shared__ int red[4][16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hv = lane >> 5, l31 = lane & 31;
-    const int64_t m0 = (int64_t)blockIdx.y * 32;
-    const int n0 = blockIdx.x * 32;
+    unsigned tx, ty, tz;
+    tile_coords(tx, ty, tz);  // XCD-aware order (gemm_core.h)
+    const int64_t m0 = (int64_t)ty * 32;
+    const int n0 = tx * 32;
     const int64_t row = m0 + l31;
     const int col = n0 + l31;
     const bool rin = row < rows, cin = col < n;

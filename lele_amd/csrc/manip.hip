@@ -44,12 +44,14 @@ __global__ void strided_copy_kernel(const W* __restrict__ in, W* __restrict__ ou
 }
 
 // Transposing copies: the innermost output dim is strided in the input while some other dim `tj` is contiguous there.
-// A 32x32 tile goes through LDS so that both the reads (along tj) and the writes (along the inner dim) are coalesced.
+// A 64x64 tile goes through LDS so that both the reads (along tj) and the writes (along the inner dim) are coalesced
+// 256-byte rows.  Every thread issues its 16 loads back to back from CLAMPED coordinates (a load behind a per-lane bounds
+// branch costs one serialised memory round trip each); only the stores are predicated.
 // grid.x = tiles along the inner dim, grid.y = tiles along tj, grid.z = all remaining dims flattened.
 template <typename W>
 __global__ __launch_bounds__(256) void transpose_tile_kernel(const W* __restrict__ in, W* __restrict__ out, CopyDesc d, int tj) {
-    __shared__ W tile[32][33];
-    const int r = d.rank, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    __shared__ W tile[64][65];
+    const int r = d.rank, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     int64_t rem = blockIdx.z, si = d.ioff, di = d.ooff;
     for (int k = r - 2; k >= 0; --k) {
         if (k == tj) continue;
@@ -58,18 +60,33 @@ __global__ __launch_bounds__(256) void transpose_tile_kernel(const W* __restrict
         si += c * d.istride[k];
         di += c * d.ostride[k];
     }
-    const int64_t j0 = (int64_t)blockIdx.y * 32, i0 = (int64_t)blockIdx.x * 32;
+    const int64_t j0 = (int64_t)blockIdx.y * 64, i0 = (int64_t)blockIdx.x * 64;
     const int64_t nj = d.oshape[tj], ni = d.oshape[r - 1];
-    // read: tx runs along tj (input-contiguous), ty (+8 per step) along the inner dim
-    for (int q = ty; q < 32; q += 8) {
-        const int64_t j = j0 + tx, i = i0 + q;
-        if (j < nj && i < ni) tile[q][tx] = in[si + j * d.istride[tj] + i * d.istride[r - 1]];
+    // read: tx runs along tj (input-contiguous), ty (+4 per step) along the inner dim
+    {
+        const int64_t j = j0 + tx < nj ? j0 + tx : nj - 1;
+        const W* src = in + si + j * d.istride[tj];
+        const int64_t is = d.istride[r - 1];
+        W v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int64_t i = i0 + ty + 4 * u;
+            v[u] = src[(i < ni ? i : ni - 1) * is];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) tile[ty + 4 * u][tx] = v[u];
     }
     __syncthreads();
     // write: tx runs along the inner dim (output-contiguous), ty along tj
-    for (int q = ty; q < 32; q += 8) {
-        const int64_t j = j0 + q, i = i0 + tx;
-        if (j < nj && i < ni) out[di + j * d.ostride[tj] + i * d.ostride[r - 1]] = tile[tx][q];
+    {
+        const int64_t i = i0 + tx;
+        W* dst = out + di + i * d.ostride[r - 1];
+        const int64_t os = d.ostride[tj];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int64_t j = j0 + ty + 4 * u;
+            if (j < nj && i < ni) dst[j * os] = tile[tx][ty + 4 * u];
+        }
     }
 }
 
@@ -433,7 +450,7 @@ int launch_copy(LeleCtx* ctx, const void* in, void* out, int64_t numel, const Co
         for (int k = 0; k + 1 < r; ++k)
             if (k != tj) others *= d.oshape[k];
         if (tj >= 0 && others <= 65535) {
-            const dim3 tgrid((unsigned)((d.oshape[r - 1] + 31) / 32), (unsigned)((d.oshape[tj] + 31) / 32), (unsigned)others);
+            const dim3 tgrid((unsigned)((d.oshape[r - 1] + 63) / 64), (unsigned)((d.oshape[tj] + 63) / 64), (unsigned)others);
             if (tgrid.y <= 65535) {
                 if (esize == 8)
                     hipLaunchKernelGGL(transpose_tile_kernel<uint64_t>, tgrid, dim3(256), 0, ctx->stream, (const uint64_t*)in,

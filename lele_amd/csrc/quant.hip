@@ -305,7 +305,9 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
     __shared__ float s_ds[BM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int64_t m0 = (int64_t)blockIdx.y * BM;
+    unsigned tx, ty, tz;
+    gemm::tile_coords(tx, ty, tz);  // XCD-aware order (gemm_core.h)
+    const int64_t m0 = (int64_t)ty * BM;
     // per-row epilogue terms: fetched once per block up front (clamped, unconditional -- their latency hides behind
     // the K loop) instead of per element behind a bounds branch, which serialises one global load per row
     for (int t = tid; t < BM; t += NT) {
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
         s_rterm[t] = rc.rterm;
         s_ds[t] = rc.dyn_scale;
     }
-    const int n0 = blockIdx.x * BN;
+    const int n0 = tx * BN;
     const int hv = lane >> 5, l31 = lane & 31;
     // un-batched weights: b_batch_stride == 0; batched B (mat_mul_integer with batch_b > 1): slice = row block / m
     const int8_t* bb = b + (b_batch_stride ? (m0 / m_per_batch) * b_batch_stride : 0);

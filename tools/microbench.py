@@ -23,7 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--quick", action="store_true")
-    ap.add_argument("--only", default="", help="comma-separated section names: matmul,quant,conv,conv1d,eltwise,rnn,misc")
+    ap.add_argument("--only", default="", help="comma-separated section names: matmul,quant,conv,conv1d,eltwise,c4,rnn,misc")
     args = ap.parse_args()
     import lele_amd
     from lele_amd import kernels as K
@@ -151,6 +151,50 @@ def main():
         x = dev(f32(nb, 128, 20, 20))
         ms = timeit(lambda o: K.max_pool2d(x, [5, 5], [1, 1], [2, 2, 2, 2], out=o, ctx=ctx), it)
         record("max_pool2d_5x5", [nb, 128, 20, 20], ms, 0, 8.0 * nb * 128 * 400, "hbm")
+
+    # ---- one SenseVoice encoder layer at the batched C4 shapes (32 utterances x 171 tokens = 5472 rows)
+    if want('c4'):
+        B, T, H, DH, D = 32, 171, 4, 128, 512
+        a, bb = dev(f32(B * H, T, DH)), dev(f32(B * H, DH, T))
+        ms = timeit(lambda o: K.matmul(a, bb, out=o, ctx=ctx), it)
+        record("matmul_qk", [B * H, T, DH, T], ms, 2.0 * B * H * T * DH * T, 4.0 * B * H * (2 * T * DH + T * T), "mfma_f32")
+        a, bb = dev(f32(B * H, T, T)), dev(f32(B * H, T, DH))
+        ms = timeit(lambda o: K.matmul(a, bb, out=o, ctx=ctx), it)
+        record("matmul_pv", [B * H, T, T, DH], ms, 2.0 * B * H * T * DH * T, 4.0 * B * H * (2 * T * DH + T * T), "mfma_f32")
+        for m, k, n in [(B * T, 512, 1536), (B * T, 512, 512), (B * T, 512, 2048), (B * T, 2048, 512)]:
+            x = dev(f32(1, m, k))
+            w = Weight(np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32))
+            ws = Weight((np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32))
+            wz = Weight(np.array([128.0], np.float32))
+            bs = Weight(f32(n, scale=0.02))
+            ms = timeit(lambda o: K.fused_quantized_linear(x, w, ws, wz, bs, False, out=o, ctx=ctx), it)
+            record("fused_quantized_linear", [m, k, n], ms, 2.0 * m * k * n, 4.0 * m * k + k * n + 8.0 * n + 4.0 * m * n, "mfma_i8")
+        x, w = dev(f32(B, D, T)), Weight(f32(D, 1, 11))
+        ms = timeit(lambda o: K.conv1d(x, w, None, [1], D, [5, 5], [1], out=o, ctx=ctx), it)
+        record("conv1d_depthwise", [B, D, T, 11], ms, 2.0 * B * D * T * 11, 8.0 * B * D * T, "hbm")
+        x = dev(f32(B, T, D))
+        ms = timeit(lambda o: K.transpose(x, [0, 2, 1], out=o, ctx=ctx), it)
+        record("transpose_021", [B, T, D], ms, 0, 8.0 * B * T * D, "hbm")
+        x4 = dev(f32(B, T, H, DH))
+        ms = timeit(lambda o: K.transpose(x4, [0, 2, 1, 3], out=o, ctx=ctx), it)
+        record("transpose_0213", [B, T, H, DH], ms, 0, 8.0 * B * T * D, "hbm")
+        ms = timeit(lambda o: K.transpose(x4, [0, 2, 3, 1], out=o, ctx=ctx), it)
+        record("transpose_0231", [B, T, H, DH], ms, 0, 8.0 * B * T * D, "hbm")
+        qkv = dev(f32(B, T, 3 * D))
+        outs = [ctx.buf() for _ in range(3)]
+        ms = timeit(lambda o: K.split(qkv, 2, [D, D, D], outputs=outs, ctx=ctx), it)
+        record("split3", [B, T, 3 * D], ms, 0, 8.0 * B * T * 3 * D, "hbm")
+        y = dev(f32(B, T, D))
+        ms = timeit(lambda o: K.add(x, y, out=o, ctx=ctx), it)
+        record("add", [B, T, D], ms, 0, 12.0 * B * T * D, "hbm")
+        sc, one = dev(f32(B, H, T, T)), dev(np.array([0.088], np.float32))
+        ms = timeit(lambda o: K.mul(sc, one, out=o, ctx=ctx), it)
+        record("mul_scalar", [B, H, T, T], ms, 0, 8.0 * B * H * T * T, "hbm")
+        ms = timeit(lambda o: K.softmax(sc, -1, out=o, ctx=ctx), it)
+        record("softmax", [B, H, T, T], ms, 0, 8.0 * B * H * T * T, "hbm")
+        gmm, bta = dev(f32(D)), dev(f32(D))
+        ms = timeit(lambda o: K.layer_norm(x, gmm, bta, -1, 1e-5, out=o, ctx=ctx), it)
+        record("layer_norm", [B, T, D], ms, 0, 8.0 * B * T * D, "hbm")
 
     # ---- LSTM / GRU (a11/a12): latency-bound, microseconds per step
     if want('rnn'):

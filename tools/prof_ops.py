@@ -35,6 +35,10 @@ if what in ("matmul", "all"):
     a, b = dev(rng.standard_normal((4, 504, 128))), dev(rng.standard_normal((4, 128, 504)))
     for _ in range(20):
         K.matmul(a, b, out=out, ctx=ctx)
+if what == "attn":  # batched short-K products of the C4 attention (64x64 tiles)
+    a, b = dev(rng.standard_normal((128, 171, 128))), dev(rng.standard_normal((128, 128, 171)))
+    for _ in range(10):
+        K.matmul(a, b, out=out, ctx=ctx)
 if what in ("conv", "all"):
     x = dev(rng.standard_normal((16, 64, 160, 160)))
     w, bs = Weight(rng.standard_normal((64, 64, 3, 3)).astype(np.float32) * 0.1), Weight(np.zeros(64, np.float32))
