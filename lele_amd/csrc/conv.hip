@@ -55,49 +55,65 @@ inline FastDiv make_fastdiv(int d, int64_t max_n) {
 }
 
 // A operand: weights [OC][ICg*kh*kw] row-major; GEMM batch b = img*G + g selects the group's rows
+// (loader protocol: gemm_core.h -- row() is the k-invariant part, hoisted out of the K loop by the kernel)
 struct ConvWLoad {
     const float* w;
     ConvGeom g;
     int vec;
     static constexpr bool kRowFast = false;
-    __device__ __forceinline__ float4 get4(int b, int row, int k) const {
-        const bool rin = row < g.ocg;
-        const float* q = w + ((int64_t)((b % g.group) * g.ocg + (rin ? row : g.ocg - 1))) * g.K;
+    struct Row {
+        const float* q;
+        bool rin;
+    };
+    __device__ __forceinline__ Row row(int b, int r) const {
+        const bool rin = r < g.ocg;
+        return Row{w + ((int64_t)((b % g.group) * g.ocg + (rin ? r : g.ocg - 1))) * g.K, rin};
+    }
+    __device__ __forceinline__ float4 get4(const Row& r, int k) const {
         float4 v;
         if (vec && k + 3 < g.K) {
-            v = *reinterpret_cast<const float4*>(q + k);
+            v = *reinterpret_cast<const float4*>(r.q + k);
         } else {
             const int last = g.K - 1;
-            const float e0 = q[k + 0 < g.K ? k + 0 : last], e1 = q[k + 1 < g.K ? k + 1 : last];
-            const float e2 = q[k + 2 < g.K ? k + 2 : last], e3 = q[k + 3 < g.K ? k + 3 : last];
+            const float e0 = r.q[k + 0 < g.K ? k + 0 : last], e1 = r.q[k + 1 < g.K ? k + 1 : last];
+            const float e2 = r.q[k + 2 < g.K ? k + 2 : last], e3 = r.q[k + 3 < g.K ? k + 3 : last];
             v = make_float4(k + 0 < g.K ? e0 : 0.f, k + 1 < g.K ? e1 : 0.f, k + 2 < g.K ? e2 : 0.f, k + 3 < g.K ? e3 : 0.f);
         }
-        return rin ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        return r.rin ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    __device__ __forceinline__ float4 get4(int b, int r, int k) const { return get4(row(b, r), k); }
 };
 // B operand: element(position p, k) = x[img][g*ICg + ic][oh*sh - pt + a*dh][ow*sw - pl + bb*dw] (0 outside).
-// Index arithmetic only (mulhi divisions); the four loads are unconditional on clamped addresses.
+// Index arithmetic only (mulhi divisions); the four loads are unconditional on clamped addresses.  The output position
+// -> window origin arithmetic is per row (hoisted); the k -> (ic, a, bb) split is uniform over a wave in the tiled kernel.
+struct ConvXRow {
+    const float* base;  // x + (img, group) offset: uniform over the workgroup
+    int iy0, ix0;
+    bool rin;
+};
 struct ConvXLoad {
     const float* x;
     ConvGeom g;
     FastDiv d_ow, d_khw, d_kw;
     static constexpr bool kRowFast = true;  // consecutive threads -> consecutive output positions (coalesced along W)
-    __device__ __forceinline__ float4 get4(int b, int row, int k) const {
-        const bool rin = row < g.plane;
-        const int rowc = rin ? row : g.plane - 1;
+    typedef ConvXRow Row;
+    __device__ __forceinline__ Row row(int b, int r) const {
+        const bool rin = r < g.plane;
+        const int rowc = rin ? r : g.plane - 1;
         const int img = b / g.group, grp = b - img * g.group;
         const int oy = d_ow.div(rowc), ox = rowc - oy * g.ow;
+        return Row{x + ((int64_t)img * g.c + grp * g.icg) * g.ih * g.iw, oy * g.sh - g.pt, ox * g.sw - g.pl, rin};
+    }
+    __device__ __forceinline__ float4 get4(const Row& r, int k) const {
         const int kc = k < g.K ? k : g.K - 1;
         int ic = d_khw.div(kc), rem = kc - ic * (g.kh * g.kw);
         int a = d_kw.div(rem), bb = rem - a * g.kw;
-        const float* base = x + ((int64_t)img * g.c + grp * g.icg) * g.ih * g.iw;
-        const int iy0 = oy * g.sh - g.pt, ix0 = ox * g.sw - g.pl;
         int idx[4];
         bool ok[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int iy = iy0 + a * g.dh, ix = ix0 + bb * g.dw;
-            ok[e] = rin && k + e < g.K && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+            const int iy = r.iy0 + a * g.dh, ix = r.ix0 + bb * g.dw;
+            ok[e] = r.rin && k + e < g.K && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
             idx[e] = ok[e] ? (ic * g.ih + iy) * g.iw + ix : 0;
             if (++bb == g.kw) {
                 bb = 0;
@@ -107,9 +123,10 @@ struct ConvXLoad {
                 }
             }
         }
-        const float e0 = base[idx[0]], e1 = base[idx[1]], e2 = base[idx[2]], e3 = base[idx[3]];
+        const float e0 = r.base[idx[0]], e1 = r.base[idx[1]], e2 = r.base[idx[2]], e3 = r.base[idx[3]];
         return make_float4(ok[0] ? e0 : 0.f, ok[1] ? e1 : 0.f, ok[2] ? e2 : 0.f, ok[3] ? e3 : 0.f);
     }
+    __device__ __forceinline__ float4 get4(int b, int r, int k) const { return get4(row(b, r), k); }
 };
 // Tap-major variant (IC/g % 4 == 0): the GEMM K index is (tap, ic) instead of lele's (ic, tap) -- a permutation of the
 // exact f32 sum -- so the 4 consecutive k of a chunk are 4 input channels at ONE tap: one bounds test and one base
@@ -120,21 +137,28 @@ struct ConvXLoadTap {
     ConvGeom g;
     FastDiv d_ow, d_icg, d_kw;
     static constexpr bool kRowFast = true;
-    __device__ __forceinline__ float4 get4(int b, int row, int k) const {
-        const bool rin = row < g.plane;
-        const int rowc = rin ? row : g.plane - 1;
+    typedef ConvXRow Row;
+    __device__ __forceinline__ Row row(int b, int r) const {
+        const bool rin = r < g.plane;
+        const int rowc = rin ? r : g.plane - 1;
         const int img = b / g.group, grp = b - img * g.group;
         const int oy = d_ow.div(rowc), ox = rowc - oy * g.ow;
+        return Row{x + ((int64_t)img * g.c + grp * g.icg) * g.ih * g.iw, oy * g.sh - g.pt, ox * g.sw - g.pl, rin};
+    }
+    __device__ __forceinline__ float4 get4(const Row& r, int k) const {
         const int kc = k < g.K ? k : g.K - 4;  // K % 4 == 0 here, so a chunk is entirely in or out of range
         const int tap = d_icg.div(kc), ic = kc - tap * g.icg;
         const int a = d_kw.div(tap), bb = tap - a * g.kw;
-        const int iy = oy * g.sh - g.pt + a * g.dh, ix = ox * g.sw - g.pl + bb * g.dw;
-        const bool ok = rin && k < g.K && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+        const int iy = r.iy0 + a * g.dh, ix = r.ix0 + bb * g.dw;
+        const bool ok = r.rin && k < g.K && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
         const int hw = g.ih * g.iw;
-        const float* q = x + ((int64_t)img * g.c + grp * g.icg) * hw + (ok ? ic * hw + iy * g.iw + ix : 0);
-        const float e0 = q[0], e1 = q[hw], e2 = q[2 * hw], e3 = q[3 * hw];
+        // (base + ic*hw) is uniform when k is; the lane adds its 32-bit position inside the plane
+        const float* q = r.base + (int64_t)ic * hw;
+        const unsigned off = ok ? (unsigned)(iy * g.iw + ix) : 0u;
+        const float e0 = q[off], e1 = (q + hw)[off], e2 = (q + 2 * hw)[off], e3 = (q + 3 * hw)[off];
         return ok ? make_float4(e0, e1, e2, e3) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    __device__ __forceinline__ float4 get4(int b, int r, int k) const { return get4(row(b, r), k); }
 };
 __global__ void conv_wperm_kernel(const float* __restrict__ w, float* __restrict__ wt, int oc, int icg, int khw) {
     const int64_t total = (int64_t)oc * icg * khw;

@@ -28,6 +28,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------------------------- loaders
 // Loaders never put a global load behind a per-lane branch (that serialises one memory round trip per element):
 // coordinates are clamped into range, the load is unconditional, and out-of-range elements are zeroed by a select.
+//
+// Loader protocol: `row(b, r)` does everything that does not depend on k ONCE per staging slot (clamping, the row's
+// address, for convolutions the output position -> input window arithmetic); `get4(Row, k)` is what the K loop pays
+// per step.  In the tiled kernel k is wave-uniform for row-fast loaders (64 consecutive threads share the k chunk), so
+// whatever get4 derives from k alone lands on the scalar unit.  (Measured before the split: 10-12 vector instructions
+// of index arithmetic per MFMA in the K loop; an MFMA 32x32x2 occupies the matrix pipe for 64 cycles = 16 of them.)
 // element(row, k) = p[batch*bs + row*ld + k]   (k contiguous in memory)
 struct LoadRowK {
     const float* p;
@@ -36,20 +42,27 @@ struct LoadRowK {
     int rows, K;
     int vec;  // 1 when float4 loads are legal (base and ld 16-B aligned)
     static constexpr bool kRowFast = false;
-    __device__ __forceinline__ float4 get4(int b, int row, int k) const {
-        const bool rin = row < rows;
-        const float* q = p + (int64_t)b * bs + (int64_t)(rin ? row : rows - 1) * ld;
+    struct Row {
+        const float* q;
+        bool rin;
+    };
+    __device__ __forceinline__ Row row(int b, int r) const {
+        const bool rin = r < rows;
+        return Row{p + (int64_t)b * bs + (int64_t)(rin ? r : rows - 1) * ld, rin};
+    }
+    __device__ __forceinline__ float4 get4(const Row& r, int k) const {
         float4 v;
         if (vec && k + 3 < K) {  // whole chunk in range (always, except in the last K tile)
-            v = *reinterpret_cast<const float4*>(q + k);
+            v = *reinterpret_cast<const float4*>(r.q + k);
         } else {
             const int last = K - 1;
-            const float e0 = q[k + 0 < K ? k + 0 : last], e1 = q[k + 1 < K ? k + 1 : last];
-            const float e2 = q[k + 2 < K ? k + 2 : last], e3 = q[k + 3 < K ? k + 3 : last];
+            const float e0 = r.q[k + 0 < K ? k + 0 : last], e1 = r.q[k + 1 < K ? k + 1 : last];
+            const float e2 = r.q[k + 2 < K ? k + 2 : last], e3 = r.q[k + 3 < K ? k + 3 : last];
             v = make_float4(k + 0 < K ? e0 : 0.f, k + 1 < K ? e1 : 0.f, k + 2 < K ? e2 : 0.f, k + 3 < K ? e3 : 0.f);
         }
-        return rin ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        return r.rin ? v : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    __device__ __forceinline__ float4 get4(int b, int r, int k) const { return get4(row(b, r), k); }
 };
 // element(row, k) = p[batch*bs + k*ld + row]   (row contiguous in memory: B of a plain matmul, A of transA)
 struct LoadKRow {
@@ -58,15 +71,26 @@ struct LoadKRow {
     int64_t ld;
     int rows, K;
     static constexpr bool kRowFast = true;
-    __device__ __forceinline__ float4 get4(int b, int row, int k) const {
-        const bool rin = row < rows;
-        const float* q = p + (int64_t)b * bs + (rin ? row : rows - 1);
-        const int last = K - 1;
-        const float e0 = q[(int64_t)(k + 0 < K ? k + 0 : last) * ld], e1 = q[(int64_t)(k + 1 < K ? k + 1 : last) * ld];
-        const float e2 = q[(int64_t)(k + 2 < K ? k + 2 : last) * ld], e3 = q[(int64_t)(k + 3 < K ? k + 3 : last) * ld];
-        return make_float4(rin && k + 0 < K ? e0 : 0.f, rin && k + 1 < K ? e1 : 0.f, rin && k + 2 < K ? e2 : 0.f,
-                           rin && k + 3 < K ? e3 : 0.f);
+    struct Row {
+        const float* base;  // p + batch offset: uniform over the workgroup
+        unsigned off;       // clamped row
+        bool rin;
+    };
+    __device__ __forceinline__ Row row(int b, int r) const {
+        const bool rin = r < rows;
+        return Row{p + (int64_t)b * bs, (unsigned)(rin ? r : rows - 1), rin};
     }
+    __device__ __forceinline__ float4 get4(const Row& r, int k) const {
+        const int last = K - 1;
+        // (base + k*ld) is scalar arithmetic when k is uniform; the lane contributes only its 32-bit row offset
+        const float e0 = (r.base + (int64_t)(k + 0 < K ? k + 0 : last) * ld)[r.off];
+        const float e1 = (r.base + (int64_t)(k + 1 < K ? k + 1 : last) * ld)[r.off];
+        const float e2 = (r.base + (int64_t)(k + 2 < K ? k + 2 : last) * ld)[r.off];
+        const float e3 = (r.base + (int64_t)(k + 3 < K ? k + 3 : last) * ld)[r.off];
+        return make_float4(r.rin && k + 0 < K ? e0 : 0.f, r.rin && k + 1 < K ? e1 : 0.f, r.rin && k + 2 < K ? e2 : 0.f,
+                           r.rin && k + 3 < K ? e3 : 0.f);
+    }
+    __device__ __forceinline__ float4 get4(int b, int r, int k) const { return get4(row(b, r), k); }
 };
 
 // ---------------------------------------------------------------------------------------------- epilogues
@@ -126,7 +150,7 @@ __device__ __forceinline__ void tile_coords(unsigned& tx, unsigned& ty, unsigned
 }
 
 // ---------------------------------------------------------------------------------------------- kernel
-template <int BM, int BN, int WM, int WN, int BK, class AL, class BL, class EPI, int OCC = 1>
+template <int BM, int BN, int WM, int WN, int BK, class AL, class BL, class EPI, int OCC = 1, int RS = 2>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC))) void gemm_f32_mfma_kernel(AL al, BL bl, EPI epi, int M, int N, int K) {
     constexpr int NT = WM * WN * 64;
     constexpr int PITCH = BK + 4;
@@ -144,43 +168,47 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
     const int m0 = ty * BM, n0 = tx * BN, batch = tz;
     const int hv = lane >> 5, l31 = lane & 31;
 
-    float4 ra[ASLOTS], rb[BSLOTS];
-    auto slot_rc = [](int s, int rows, bool rowfast, int& row, int& kq) {
-        if (rowfast) {
-            row = s % rows;
-            kq = s / rows;
-        } else {
-            kq = s % KQ;
-            row = s / KQ;
-        }
+    float4 ra[RS][ASLOTS], rb[RS][BSLOTS];  // RS = 2 register stages: a tile's loads have two K steps to land
+    // per staging slot, once: the loader's k-invariant row state, the k offset of the slot's chunk (made wave-uniform
+    // where the slot -> (row, chunk) map allows it) and the LDS address the chunk is parked at
+    typename AL::Row arow[ASLOTS];
+    typename BL::Row brow[BSLOTS];
+    int akq[ASLOTS], bkq[BSLOTS], alds[ASLOTS], blds[BSLOTS];
+#pragma unroll
+    for (int i = 0; i < ASLOTS; ++i) {
+        const int s = tid + i * NT;
+        int row = AL::kRowFast ? s % BM : s / KQ, kq = AL::kRowFast ? s / BM : s % KQ;
+        if (AL::kRowFast && BM % 64 == 0) kq = __builtin_amdgcn_readfirstlane(kq);
+        if (s >= BM * KQ) row = 0, kq = 0;
+        arow[i] = al.row(batch, m0 + row);
+        akq[i] = 4 * kq;
+        alds[i] = row * PITCH + 4 * kq;
+    }
+#pragma unroll
+    for (int i = 0; i < BSLOTS; ++i) {
+        const int s = tid + i * NT;
+        int row = BL::kRowFast ? s % BN : s / KQ, kq = BL::kRowFast ? s / BN : s % KQ;
+        if (BL::kRowFast && BN % 64 == 0) kq = __builtin_amdgcn_readfirstlane(kq);
+        if (s >= BN * KQ) row = 0, kq = 0;
+        brow[i] = bl.row(batch, n0 + row);
+        bkq[i] = 4 * kq;
+        blds[i] = row * PITCH + 4 * kq;
+    }
+    auto gload = [&](int k0, int st) {
+#pragma unroll
+        for (int i = 0; i < ASLOTS; ++i)
+            if (tid + i * NT < BM * KQ) ra[st][i] = al.get4(arow[i], k0 + akq[i]);
+#pragma unroll
+        for (int i = 0; i < BSLOTS; ++i)
+            if (tid + i * NT < BN * KQ) rb[st][i] = bl.get4(brow[i], k0 + bkq[i]);
     };
-    auto gload = [&](int k0) {
+    auto lstore = [&](int buf, int st) {
 #pragma unroll
-        for (int i = 0; i < ASLOTS; ++i) {
-            int row, kq;
-            slot_rc(tid + i * NT, BM, AL::kRowFast, row, kq);
-            if (tid + i * NT < BM * KQ) ra[i] = al.get4(batch, m0 + row, k0 + 4 * kq);
-        }
+        for (int i = 0; i < ASLOTS; ++i)
+            if (tid + i * NT < BM * KQ) *reinterpret_cast<float4*>(&As[buf][alds[i]]) = ra[st][i];
 #pragma unroll
-        for (int i = 0; i < BSLOTS; ++i) {
-            int row, kq;
-            slot_rc(tid + i * NT, BN, BL::kRowFast, row, kq);
-            if (tid + i * NT < BN * KQ) rb[i] = bl.get4(batch, n0 + row, k0 + 4 * kq);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < ASLOTS; ++i) {
-            int row, kq;
-            slot_rc(tid + i * NT, BM, AL::kRowFast, row, kq);
-            if (tid + i * NT < BM * KQ) *reinterpret_cast<float4*>(&As[buf][row * PITCH + 4 * kq]) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < BSLOTS; ++i) {
-            int row, kq;
-            slot_rc(tid + i * NT, BN, BL::kRowFast, row, kq);
-            if (tid + i * NT < BN * KQ) *reinterpret_cast<float4*>(&Bs[buf][row * PITCH + 4 * kq]) = rb[i];
-        }
+        for (int i = 0; i < BSLOTS; ++i)
+            if (tid + i * NT < BN * KQ) *reinterpret_cast<float4*>(&Bs[buf][blds[i]]) = rb[st][i];
     };
 
     f32x16 acc[TMT][TNT];
@@ -192,12 +220,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int nk = (K + BK - 1) / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * BK);  // in flight during the MFMAs below
+    auto compute = [&](int cur) {
 #pragma unroll
         for (int sub = 0; sub < BK / 16; ++sub) {  // 16 k per sub-step: fragment registers are reused
             float a[TMT][8], b[TNT][8];
@@ -223,8 +246,35 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
                     for (int j = 0; j < TNT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
+    };
+    if constexpr (RS == 2) {
+        // tile kt is computed from LDS[kt & 1] while tile kt+1 waits in register stage (kt+1) & 1 and tile kt+2 is requested
+        gload(0, 0);
+        if (nk > 1) gload(BK, 1);
+        lstore(0, 0);
         __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            if (kt + 2 < nk) gload((kt + 2) * BK, 0);
+            compute(0);
+            if (kt + 1 < nk) lstore(1, 1);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            if (kt + 3 < nk) gload((kt + 3) * BK, 1);
+            compute(1);
+            if (kt + 2 < nk) lstore(0, 0);
+            __syncthreads();
+        }
+    } else {  // one register stage (the 256x128 tile has no registers to spare): tile kt+1 is in flight during tile kt
+        gload(0, 0);
+        lstore(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) gload((kt + 1) * BK, 0);
+            compute(cur);
+            if (kt + 1 < nk) lstore(cur ^ 1, 0);
+            __syncthreads();
+        }
     }
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -304,10 +354,10 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(AL al, BL bl, EPI e
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int OCC = 1, class AL, class BL, class EPI>
+template <int BM, int BN, int WM, int WN, int BK, int OCC = 1, int RS = 2, class AL, class BL, class EPI>
 inline void launch_tile(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int batch) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-    auto kern = gemm_f32_mfma_kernel<BM, BN, WM, WN, BK, AL, BL, EPI, OCC>;
+    auto kern = gemm_f32_mfma_kernel<BM, BN, WM, WN, BK, AL, BL, EPI, OCC, RS>;
     if (lds > 64 * 1024) {  // above the default per-block limit: opt in once per instantiation
         static bool done = false;
         if (!done) {
@@ -332,16 +382,12 @@ inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, i
             case 1: launch_tile<64, 256, 2, 4, 16, 4>(st, al, bl, epi, M, N, K, batch); return;
             case 2: launch_tile<64, 64, 2, 2, 16>(st, al, bl, epi, M, N, K, batch); return;
             case 3: launch_tile<32, 128, 1, 4, 16>(st, al, bl, epi, M, N, K, batch); return;
-            case 4: launch_tile<256, 128, 4, 2, 16, 4>(st, al, bl, epi, M, N, K, batch); return;
+            case 4: launch_tile<256, 128, 4, 2, 16, 4, 1>(st, al, bl, epi, M, N, K, batch); return;
             case 5: {
                 dim3 grid((N + 31) / 32, (M + 31) / 32, batch);
                 hipLaunchKernelGGL((gemm_f32_small_kernel<AL, BL, EPI>), grid, dim3(256), 0, st, al, bl, epi, M, N, K);
                 return;
             }
-            case 6: launch_tile<64, 64, 2, 2, 32>(st, al, bl, epi, M, N, K, batch); return;
-            case 7: launch_tile<64, 64, 2, 2, 64>(st, al, bl, epi, M, N, K, batch); return;
-            case 8: launch_tile<64, 192, 2, 2, 16>(st, al, bl, epi, M, N, K, batch); return;
-            case 9: launch_tile<64, 64, 2, 2, 16, 4>(st, al, bl, epi, M, N, K, batch); return;
             default: break;
         }
     }
@@ -373,7 +419,7 @@ inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, i
     switch (best) {
         case 0: launch_tile<128, 128, 2, 4, 16, 4>(st, al, bl, epi, M, N, K, batch); break;  // 8 waves of 64x32
         case 1: launch_tile<64, 256, 2, 4, 16, 4>(st, al, bl, epi, M, N, K, batch); break;  // 8 waves of 32x64
-        case 4: launch_tile<256, 128, 4, 2, 16, 4>(st, al, bl, epi, M, N, K, batch); break;  // 8 waves, 61 KB LDS, 2 per CU
+        case 4: launch_tile<256, 128, 4, 2, 16, 4, 1>(st, al, bl, epi, M, N, K, batch); break;  // 8 waves, 61 KB LDS, 2 per CU
         case 2: launch_tile<64, 64, 2, 2, 16>(st, al, bl, epi, M, N, K, batch); break;
         default: launch_tile<32, 128, 1, 4, 16>(st, al, bl, epi, M, N, K, batch); break;
     }
