@@ -289,6 +289,26 @@ int lele_hip_wav_to_f32(LeleCtx* ctx, const LeleTensor* bytes, int32_t bits_per_
  * x: f32 [.., V] -> i32 ids [..]; only the ids need to leave the device */
 int lele_hip_argmax_last(LeleCtx* ctx, const LeleTensor* x, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
 
+/* tokenizer.rs:63-71: the ids the greedy decoder keeps, in frame order -- an id is dropped when it is outside the vocabulary
+ * or its skip flag is set (the host sets skip[0] and skip[id] for every "<|...|>" token once per vocabulary).  No CTC
+ * collapsing (upstream does none).  ids: i32 [.., T]; skip: U8 [V]; out_ids: i32 [.., T] (kept ids first, then -1);
+ * out_counts: i32 [..] */
+int lele_hip_token_filter(LeleCtx* ctx, const LeleTensor* ids, const LeleTensor* skip, LeleBuf* out_ids, LeleBuf* out_counts,
+                          int64_t* out_shape, int32_t* out_rank);
+/* examples/yolo26n-seg/src/image.rs:62-111 (Image::preprocess): PIL-style nearest resize to target x target
+ * (src = min(floor((dst + 0.5) * src_size / target), src_size - 1), f32 arithmetic), HWC u8 -> NCHW f32 / 255.
+ * rgb: U8 [H, W, 3] -> out f32 [1, 3, target, target] */
+int lele_hip_image_preprocess(LeleCtx* ctx, const LeleTensor* rgb, int32_t target, LeleBuf* out, int64_t* out_shape,
+                              int32_t* out_rank);
+/* image.rs:127-265 (postprocess_segmentation).  logits: f32 [1, 300, 38] = box(4, 640-space) + score + class id + 32 mask
+ * coefficients; mask_features: f32 [1, 32, Hm, Wm].  out_dets: f32 [300, 38], the first *out_count rows are the kept
+ * detections in query order (box rescaled and clamped to the image, class id clamped to num_classes - 1);
+ * out_count: i32 [1]; out_mask: U8 [img_height, img_width] (255 where a detection's mask covers the pixel).
+ * The count stays on the device: the call is graph-capturable. */
+int lele_hip_yolo_seg_postprocess(LeleCtx* ctx, const LeleTensor* logits, const LeleTensor* mask_features, int32_t img_width,
+                                  int32_t img_height, float threshold, int32_t num_classes, LeleBuf* out_dets,
+                                  LeleBuf* out_count, LeleBuf* out_mask);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@
 #include "lele_hip.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -647,6 +648,77 @@ inline TensorView argmax_last(const TensorView& x, Buffer& out) {
     LeleTensor tx = x.c();
     check(lele_hip_argmax_last(ctx(), &tx, out.raw(), sh.dims, &sh.rank));
     LELE_RET(out, LELE_I32);
+}
+inline std::pair<TensorView, TensorView> token_filter(const TensorView& ids, const TensorView& skip, Buffer& out_ids,
+                                                      Buffer& out_counts) {  // tokenizer.rs:63-71
+    Shape sh;
+    LeleTensor ti = ids.c(), ts = skip.c();
+    check(lele_hip_token_filter(ctx(), &ti, &ts, out_ids.raw(), out_counts.raw(), sh.dims, &sh.rank));
+    std::vector<int64_t> s(sh.dims, sh.dims + sh.rank), r(sh.dims, sh.dims + (sh.rank > 0 ? sh.rank - 1 : 0));
+    return {TensorView::from_device(out_ids, s, LELE_I32), TensorView::from_device(out_counts, r, LELE_I32)};
+}
+inline TensorView image_preprocess(const TensorView& rgb, int target, Buffer& out) {  // yolo26n-seg image.rs:62-111
+    Shape sh;
+    LeleTensor tr = rgb.c();
+    check(lele_hip_image_preprocess(ctx(), &tr, target, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+struct SegOutputs {
+    TensorView dets, count, mask;  // f32 [300, 38] (first `count` rows valid), i32 [1], u8 [H, W]
+};
+inline SegOutputs yolo_seg_postprocess(const TensorView& logits, const TensorView& mask_features, int img_width, int img_height,
+                                       float threshold, int num_classes, Buffer& dets, Buffer& count, Buffer& mask) {  // image.rs:127-265
+    LeleTensor tl = logits.c(), tm = mask_features.c();
+    check(lele_hip_yolo_seg_postprocess(ctx(), &tl, &tm, img_width, img_height, threshold, num_classes, dets.raw(), count.raw(),
+                                        mask.raw()));
+    return {TensorView::from_device(dets, {300, 38}, LELE_F32), TensorView::from_device(count, {1}, LELE_I32),
+            TensorView::from_device(mask, {img_height, img_width}, LELE_U8)};
+}
+// examples/silero/src/main.rs:151-228: speech segments (sample indices) from per-chunk probabilities; host-only
+struct VadConfig {  // main.rs:18-28
+    float threshold = 0.3f, min_silence_ms = 200.0f, min_speech_ms = 400.0f, speech_pad_ms = 120.0f, merge_gap_ms = 200.0f;
+};
+inline std::vector<std::pair<size_t, size_t>> vad_segments(const std::vector<float>& probs, size_t chunk_size, size_t padded_len,
+                                                           size_t audio_len, uint32_t sample_rate, const VadConfig& cfg = VadConfig()) {
+    auto ms_to_samples = [&](float ms) { return (size_t)std::lround((float)sample_rate * (ms / 1000.0f)); };
+    const size_t min_silence = std::max<size_t>(ms_to_samples(cfg.min_silence_ms), 1);
+    const size_t min_speech = std::max<size_t>(ms_to_samples(cfg.min_speech_ms), 1);
+    const size_t speech_pad = ms_to_samples(cfg.speech_pad_ms), merge_gap = ms_to_samples(cfg.merge_gap_ms);
+    std::vector<std::pair<size_t, size_t>> segs, merged;
+    bool triggered = false;
+    size_t start = 0, silence = 0;
+    for (size_t i = 0; i < probs.size(); ++i) {
+        const size_t offset = i * chunk_size, frame_end = std::min(offset + chunk_size, padded_len);
+        if (probs[i] >= cfg.threshold) {
+            if (!triggered) {
+                triggered = true;
+                start = offset > speech_pad ? offset - speech_pad : 0;
+            }
+            silence = 0;
+        } else if (triggered) {
+            silence += frame_end - offset;
+            if (silence >= min_silence) {
+                const size_t end = std::min(frame_end + speech_pad, audio_len);
+                if (end > start && end - start >= min_speech) segs.emplace_back(start, end);
+                triggered = false;
+                silence = 0;
+            }
+        }
+    }
+    if (triggered && audio_len > start && audio_len - start >= min_speech) segs.emplace_back(start, audio_len);
+    std::stable_sort(segs.begin(), segs.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    for (const auto& seg : segs) {
+        if (!merged.empty()) {
+            auto& last = merged.back();
+            const size_t gap = seg.first > last.second ? seg.first - last.second : 0;
+            if (seg.first <= last.second || gap <= merge_gap) {
+                last.second = std::max(last.second, seg.second);
+                continue;
+            }
+        }
+        merged.push_back(seg);
+    }
+    return merged;
 }
 // view operators: shape bookkeeping only (shape.rs:2-52, 105-185)
 inline TensorView reshape(const TensorView& x, const std::vector<int64_t>& target) {

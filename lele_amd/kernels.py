@@ -622,6 +622,38 @@ def argmax_last(input, out=None, ctx=None):
     return _op(ctx, _lib.lib().lele_hip_argmax_last, [input], [], out, np.int32)
 
 
+def token_filter(ids, skip, out_ids=None, out_counts=None, ctx=None):
+    """tokenizer.rs:63-71: kept ids in frame order (skip[id] set for blank / <|...|> specials) -> (ids padded with -1, counts)"""
+    ctx = _ctx(ctx)
+    keep = []
+    oi, oc = out_ids or ctx.buf(), out_counts or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_token_filter(ctx._h, _lib.as_tensor(unwrap(ids), keep),
+                                                _lib.as_tensor(unwrap(skip), keep),
+                                                oi._h, oc._h, sh.shape, C.byref(sh.rank)))
+    shape = sh.get()
+    return TensorView(_lib.DevTensor(oi, shape, np.int32)), TensorView(_lib.DevTensor(oc, shape[:-1], np.int32))
+
+
+def image_preprocess(rgb, target=640, out=None, ctx=None):
+    """examples/yolo26n-seg/src/image.rs:62-111: u8 [H, W, 3] -> f32 [1, 3, target, target] (nearest resize, / 255)"""
+    return _op(ctx, _lib.lib().lele_hip_image_preprocess, [rgb], [C.c_int32(int(target))], out)
+
+
+def yolo_seg_postprocess(logits, mask_features, img_width, img_height, threshold, num_classes=80, out_dets=None, out_count=None,
+                         out_mask=None, ctx=None):
+    """image.rs:127-265 -> (dets f32 [300, 38] of which the first `count` rows are valid, count i32 [1], mask u8 [H, W])"""
+    ctx = _ctx(ctx)
+    keep = []
+    od, oc, om = out_dets or ctx.buf(), out_count or ctx.buf(), out_mask or ctx.buf()
+    _lib.check(_lib.lib().lele_hip_yolo_seg_postprocess(ctx._h, _lib.as_tensor(unwrap(logits), keep),
+                                                        _lib.as_tensor(unwrap(mask_features), keep), C.c_int32(int(img_width)),
+                                                        C.c_int32(int(img_height)), C.c_float(float(threshold)),
+                                                        C.c_int32(int(num_classes)), od._h, oc._h, om._h))
+    return (TensorView(_lib.DevTensor(od, [300, 38], np.float32)), TensorView(_lib.DevTensor(oc, [1], np.int32)),
+            TensorView(_lib.DevTensor(om, [int(img_height), int(img_width)], np.uint8)))
+
+
 # ------------------------------------------------------------------------------------------- ConvInteger family
 def conv_integer(input, weights, x_zero_point=None, w_zero_point=None, dilations=(), group=1, pads=(), strides=(), out=None,
                  ctx=None):

@@ -101,6 +101,16 @@ void orc_conv_transpose2d(const float* x, const float* w, const float* bias, int
                           int64_t iw, int64_t oc, int64_t kh, int64_t kw, int64_t pt, int64_t pl, int64_t pb, int64_t pr,
                           int64_t sh, int64_t sw, int64_t dh, int64_t dw, float* out);
 
+/* ---- application-side steps (apps.cpp): tokenizer.rs:37-86, yolo26n-seg image.rs:62-265, silero main.rs:151-228 ---- */
+void orc_decode_greedy_ids(const float* logits, int64_t batch, int64_t steps, int64_t vocab, const uint8_t* skip, int64_t skip_len,
+                           int32_t* out, int32_t* counts);
+void orc_image_preprocess(const uint8_t* rgb, int64_t height, int64_t width, int64_t target, float* out);
+int32_t orc_yolo_seg_postprocess(const float* logits, const float* mask_features, int64_t mask_total, int64_t img_width,
+                                 int64_t img_height, float threshold, int64_t num_classes, float* dets, uint8_t* mask_img);
+int64_t orc_vad_segments(const float* probs, int64_t num_probs, int64_t chunk_size, int64_t padded_len, int64_t audio_len,
+                         uint32_t sample_rate, float threshold, float min_silence_ms, float min_speech_ms, float speech_pad_ms,
+                         float merge_gap_ms, int64_t* segments, int64_t max_segments);
+
 #ifdef __cplusplus
 }
 #endif

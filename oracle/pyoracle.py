@@ -410,3 +410,44 @@ def conv_transpose(x, w, bias=None, dilations=(), group=1, pads=(), strides=()):
                                i64(kh), i64(kw), i64(pt), i64(pl), i64(pb), i64(pr), i64(sh), i64(sw), i64(dh), i64(dw),
                                _p(out))
     return out
+
+
+# ---------------------------------------------------------------- application-side steps (apps.cpp)
+def decode_greedy_ids(logits, skip):
+    """tokenizer.rs:50-71 -> (ids [B, T] padded with -1, counts [B])"""
+    logits = _f32(logits)
+    b, t, v = logits.shape
+    skip = np.ascontiguousarray(skip, np.uint8)
+    out, counts = np.empty((b, t), np.int32), np.empty(b, np.int32)
+    lib().orc_decode_greedy_ids(_p(logits), i64(b), i64(t), i64(v), _p(skip), i64(skip.size), _p(out), _p(counts))
+    return out, counts
+
+
+def image_preprocess(rgb, target=640):
+    """yolo26n-seg image.rs:62-111"""
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    out = np.empty((1, 3, target, target), np.float32)
+    lib().orc_image_preprocess(_p(rgb), i64(rgb.shape[0]), i64(rgb.shape[1]), i64(target), _p(out))
+    return out
+
+
+def yolo_seg_postprocess(logits, mask_features, img_width, img_height, threshold, num_classes=80):
+    """yolo26n-seg image.rs:127-265 -> (dets [n, 38], mask u8 [H, W])"""
+    logits, mask_features = _f32(logits), _f32(mask_features)
+    dets, mask = np.zeros((300, 38), np.float32), np.empty((img_height, img_width), np.uint8)
+    lib().orc_yolo_seg_postprocess.restype = C.c_int32
+    n = lib().orc_yolo_seg_postprocess(_p(logits), _p(mask_features), i64(mask_features.size), i64(img_width), i64(img_height),
+                                       f(threshold), i64(num_classes), _p(dets), _p(mask))
+    return dets[:n], mask
+
+
+def vad_segments(probs, chunk_size, padded_len, audio_len, sample_rate=16000, threshold=0.3, min_silence_ms=200.0,
+                 min_speech_ms=400.0, speech_pad_ms=120.0, merge_gap_ms=200.0):
+    """silero main.rs:151-228 (defaults: VadConfig::default, main.rs:18-28) -> list of (start, end) sample indices"""
+    probs = _f32(probs)
+    seg = np.zeros((max(1, probs.size), 2), np.int64)
+    lib().orc_vad_segments.restype = C.c_int64
+    n = lib().orc_vad_segments(_p(probs), i64(probs.size), i64(chunk_size), i64(padded_len), i64(audio_len), C.c_uint32(sample_rate),
+                               f(threshold), f(min_silence_ms), f(min_speech_ms), f(speech_pad_ms), f(merge_gap_ms), _p(seg),
+                               i64(seg.shape[0]))
+    return [(int(a), int(b)) for a, b in seg[:n]]
