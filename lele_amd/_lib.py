@@ -193,10 +193,14 @@ class Weight:
     """A host array that is immutable for the life of the ctx (a weights.bin slice): passed as LELE_MEM_WEIGHT, so
     the library uploads / pre-packs it once per ctx and caches the device copy by (pointer, bytes)."""
 
+    _alive = []  # the contract is "immutable AND alive for the life of the ctx": a collected array's address could be
+                 # handed to a new array of the same size, which the (pointer, bytes) cache would mistake for the old one
+
     def __init__(self, arr):
         a = np.asarray(arr)
         self.arr = np.ascontiguousarray(a if a.dtype in _NP2DT else a.astype(np.float32))
         self.shape = self.arr.shape
+        Weight._alive.append(self.arr)
 
 
 def as_tensor(x, keep, mem=None):

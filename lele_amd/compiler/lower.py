@@ -1,0 +1,532 @@
+"""ONNX graph -> device plan (the compiler back-end).
+
+lele's compiler (src/compiler/mod.rs:311-373) turns an ONNX graph into Rust source: one `lele::kernels::<op>(...)`
+statement per node, fused forms where a pattern of consecutive nodes matches (patterns.rs), output buffers assigned by a
+liveness scan (mod.rs:148-290) and all constants packed into `<model>_weights.bin` (mod.rs:1381-1505).  This module does
+the same job for the device: the product is a PLAN -- the statement list `lele_amd.plan.Runner` executes through the
+C ABI and records into a hipGraph -- plus a weights file in lele's own format (raw little-endian tensors, 16-byte
+aligned, identical contents stored once), so a plan lifted from lele-generated Rust (tools/lift_generated.py) and a
+plan compiled here are interchangeable.
+
+Differences from the Rust emitter, by design:
+  * integer side computations (shapes, axes, slice bounds) are evaluated on the HOST -- at compile time when their
+    operands are constant, otherwise by the runner without touching the device (hostops.py);
+  * a pattern is fused only when its intermediate values have no other consumer (the reference does not check).
+"""
+import numpy as np
+
+from . import hostops
+from . import onnx_pb as pb
+
+KIND_OF_DTYPE = {pb.FLOAT: "weight_f32", pb.UINT8: "weight_u8", pb.INT8: "weight_i8", pb.INT32: "weight_i32",
+                 pb.INT64: "weight_i64", pb.FLOAT16: "weight_f16", pb.DOUBLE: "weight_f64", pb.BOOL: "weight_u8"}
+
+UNARY = {"Relu": "relu", "Sigmoid": "sigmoid", "Tanh": "tanh_kernel", "Exp": "exp", "Log": "log", "Sqrt": "sqrt", "Neg": "neg",
+         "Reciprocal": "reciprocal", "Erf": "erf", "Softplus": "softplus", "Sin": "sin", "Cos": "cos", "Not": "not_",
+         "Abs": "abs", "Floor": "floor", "Ceil": "ceil"}
+BINARY = {"Add": "add", "Sub": "sub", "Mul": "mul", "Div": "div", "Pow": "pow", "Equal": "equal", "Less": "less",
+          "Greater": "greater", "PRelu": "prelu", "Mod": "mod_f32", "And": "and_", "Or": "or_"}
+VIEW_OPS = {"Reshape", "Flatten", "Squeeze", "Unsqueeze", "Identity"}  # share the input's buffer (shape.rs:2-52)
+
+
+class CompileError(Exception):
+    pass
+
+
+def sanitize(name):
+    """src/compiler/mod.rs:1359-1370"""
+    s = name.replace(".", "_").replace("/", "_").replace("-", "_").replace(":", "_")
+    return "_" + s if s[:1].isdigit() else s
+
+
+class WeightPacker:
+    """`<model>_weights.bin`: src/compiler/mod.rs:1381-1505 (align 16, identical byte strings stored once)"""
+
+    def __init__(self):
+        self.blob = bytearray()
+        self.by_content = {}
+
+    def add(self, array, onnx_dtype):
+        a = np.ascontiguousarray(array)
+        raw = a.astype(a.dtype.newbyteorder("<")).tobytes()
+        key = (raw, )  # byte-identical tensors share storage whatever their shape or dtype
+        if key not in self.by_content:
+            pad = (-len(self.blob)) % 16
+            self.blob += b"\0" * pad
+            self.by_content[key] = len(self.blob)
+            self.blob += raw
+        return [KIND_OF_DTYPE[onnx_dtype], self.by_content[key], len(raw), [int(d) for d in a.shape]]
+
+
+def _attrs(node):
+    out = {}
+    for a in node.attribute:
+        if a.t is not None:
+            out[a.name] = a.t.array
+        elif a.ints:
+            out[a.name] = [int(v) for v in a.ints]
+        elif a.floats:
+            out[a.name] = [float(v) for v in a.floats]
+        elif a.s is not None:
+            out[a.name] = a.s.decode()
+        elif a.i is not None:
+            out[a.name] = int(a.i)
+        elif a.f is not None:
+            out[a.name] = float(a.f)
+        elif a.g is not None:
+            raise CompileError("%s: sub-graph attribute %r (control flow) is not supported" % (node.op_type, a.name))
+        else:
+            out[a.name] = []
+    return out
+
+
+class Lowering:
+    def __init__(self, model, name="model"):
+        self.model, self.name = model, name
+        g = model.graph
+        self.consts = {}       # name -> numpy array (initializers, Constant nodes, folded results)
+        self.const_dtype = {}  # name -> ONNX data type of the stored tensor
+        for t in g.initializer:
+            self.consts[t.name], self.const_dtype[t.name] = t.array, t.data_type
+        self.inputs = [v for v in g.input if v.name not in self.consts]
+        self.outputs = [v.name for v in g.output]
+        self.place = {}        # name -> "host" | "dev" for run-time values
+        for v in self.inputs:
+            self.place[v.name] = "host" if v.elem_type in (pb.INT64, pb.INT32, pb.BOOL) else "dev"
+        self.static_shape = {v.name: v.shape for v in self.inputs if v.shape and all(isinstance(d, int) and d > 0 for d in v.shape)}
+        self.packer = WeightPacker()
+        self.weight_cache = {}
+        self.statements = []
+        self.alias = {}        # view output -> the value whose buffer it shares
+
+    # ---------------------------------------------------------------------------------------- constants
+    def add_const(self, name, arr):
+        arr = np.asarray(arr)
+        self.consts[name] = arr
+        if arr.dtype in pb.ONNX_OF:
+            self.const_dtype[name] = pb.ONNX_OF[arr.dtype]
+        else:
+            self.consts[name] = arr.astype(np.int64 if arr.dtype.kind in "iub" else np.float32)
+            self.const_dtype[name] = pb.INT64 if arr.dtype.kind in "iub" else pb.FLOAT
+
+    def fold(self, nodes):
+        """Constant nodes become constants; nodes whose operands are all constant are evaluated now (mod.rs:375-760)"""
+        rest = []
+        for n in nodes:
+            at = _attrs(n)
+            if n.op_type == "Constant":
+                for key in ("value", "value_float", "value_int", "value_ints", "value_floats"):
+                    if key in at:
+                        v = at[key]
+                        arr = v if isinstance(v, np.ndarray) else np.asarray(v, np.int64 if "int" in key else np.float32)
+                        self.add_const(n.output[0], arr)
+                        break
+                else:
+                    raise CompileError("Constant node %r without a supported value attribute" % n.name)
+                continue
+            if n.op_type == "Shape" and n.input[0] in self.static_shape:
+                self.add_const(n.output[0], np.array(self.static_shape[n.input[0]], np.int64))
+                continue
+            ins = [self.consts.get(i) if i else None for i in n.input]
+            if n.input and all(i == "" or i in self.consts for i in n.input):
+                if n.op_type == "ConstantOfShape" and "value" in at:
+                    at = dict(at, value=np.asarray(at["value"]).reshape(-1)[0])
+                res = hostops.evaluate(n.op_type, ins, at)
+                if res is not None:
+                    for o, r in zip(n.output, res):
+                        self.add_const(o, r)
+                    continue
+            rest.append(n)
+        return rest
+
+    def weight(self, name, as_f32=False):
+        """argument node for a constant used as a device tensor"""
+        key = (name, as_f32)
+        if key not in self.weight_cache:
+            arr, dt = self.consts[name], self.const_dtype[name]
+            if as_f32 and dt != pb.FLOAT:  # an integer constant meeting f32 arithmetic: convert once at compile time
+                arr, dt = arr.astype(np.float32), pb.FLOAT
+            self.weight_cache[key] = {"weight": self.packer.add(arr, dt)}
+        return self.weight_cache[key]
+
+    # ---------------------------------------------------------------------------------------- operands
+    def tensor(self, name, as_f32=True):
+        if name in self.consts:
+            return self.weight(name, as_f32)
+        return {"ref": sanitize(name)}
+
+    def opt_tensor(self, node, i):
+        return self.tensor(node.input[i]) if len(node.input) > i and node.input[i] else {"none": 1}
+
+    def ints(self, node, i, attr=None, at=None, default=None):
+        """an integer-list operand: from input i (constant -> literal, run-time host value -> fetched by the runner),
+        else from the attribute, else the default"""
+        if len(node.input) > i and node.input[i]:
+            nm = node.input[i]
+            if nm in self.consts:
+                return {"list": [{"int": int(v)} for v in np.asarray(self.consts[nm]).reshape(-1)]}
+            if self.place.get(nm) != "host":
+                raise CompileError("%s %r: operand %d (%s) must be a host integer value" % (node.op_type, node.name, i, nm))
+            return {"ints": sanitize(nm)}
+        if attr is not None and at is not None and attr in at:
+            return {"list": [{"int": int(v)} for v in at[attr]]}
+        return {"list": [{"int": int(v)} for v in (default or [])]}
+
+    # ---------------------------------------------------------------------------------------- emission
+    def emit(self, outs, fn, args, n_bufs=1, view=False):
+        st = {"op": "call", "out": [sanitize(o) for o in outs], "fn": fn, "args": args, "bufs": 0 if view else n_bufs}
+        self.statements.append(st)
+        for o in outs:
+            self.place[o] = "dev"
+        return st
+
+    def emit_host(self, node, at):
+        ins = []
+        for i in node.input:
+            if not i:
+                ins.append(None)
+            elif i in self.consts:
+                ins.append({"const": np.asarray(self.consts[i]).tolist(), "dtype": "i64" if self.consts[i].dtype.kind in "iub" else "f32"})
+            elif node.op_type in ("Shape", "Size") or self.place.get(i) == "host":
+                ins.append({"ref": sanitize(i)})
+            else:
+                raise CompileError("host op %s %r reads the device value %s" % (node.op_type, node.name, i))
+        at = {k: (np.asarray(v).reshape(-1)[0].item() if isinstance(v, np.ndarray) else v) for k, v in at.items()}
+        self.statements.append({"op": "host", "out": [sanitize(o) for o in node.output], "onnx": node.op_type, "in": ins, "attrs": at})
+        for o in node.output:
+            self.place[o] = "host"
+
+    # ---------------------------------------------------------------------------------------- patterns
+    def uses(self, nodes):
+        cnt = {}
+        for n in nodes:
+            for i in n.input:
+                cnt[i] = cnt.get(i, 0) + 1
+        for o in self.outputs:
+            cnt[o] = cnt.get(o, 0) + 1
+        return cnt
+
+    def match(self, nodes, k, cnt):
+        """patterns.rs: fused forms over CONSECUTIVE nodes -> (nodes consumed, emitter) or None"""
+        def ops(*names):
+            return k + len(names) <= len(nodes) and all(nodes[k + j].op_type == nm for j, nm in enumerate(names))
+
+        def private(*vals):  # every intermediate is read exactly once (by the next node of the pattern)
+            return all(cnt.get(v, 0) == 1 for v in vals)
+
+        n = nodes[k:k + 9]
+        # LayerNorm (patterns.rs:6-119): ReduceMean Sub Pow ReduceMean Add Sqrt Div Mul Add
+        if ops("ReduceMean", "Sub", "Pow", "ReduceMean", "Add", "Sqrt", "Div", "Mul", "Add"):
+            x, mean, sub, pw, var, ade, std, norm, scaled = (n[0].input[0], n[0].output[0], n[1].output[0], n[2].output[0],
+                                                              n[3].output[0], n[4].output[0], n[5].output[0], n[6].output[0], n[7].output[0])
+            ok = (x in n[1].input and mean in n[1].input and n[2].input[0] == sub and n[3].input[0] == pw and n[4].input[0] == var
+                  and n[5].input[0] == ade and n[6].input[:2] == [sub, std] and n[7].input[0] == norm and scaled in n[8].input
+                  and private(mean, pw, var, ade, std, norm, scaled) and cnt.get(sub, 0) == 2)
+            eps_n, scale_n = n[4].input[1], n[7].input[1]
+            bias_n = n[8].input[1] if n[8].input[0] == scaled else n[8].input[0]
+            ax = _attrs(n[0]).get("axes", [-1])
+            if ok and all(v in self.consts for v in (eps_n, scale_n, bias_n)) and ax in ([-1],):
+                eps = float(np.asarray(self.consts[eps_n]).reshape(-1)[0])
+                return 9, lambda: self.emit([n[8].output[0]], "layer_norm", [self.tensor(x), self.weight(scale_n, True), self.weight(bias_n, True),
+                                                                             {"int": -1}, {"float": eps}])
+        # Quantized Linear (+ ReLU) (patterns.rs:121-432): DynamicQuantizeLinear Mul MatMulInteger Cast Mul Add [Relu]
+        if ops("DynamicQuantizeLinear", "Mul", "MatMulInteger", "Cast", "Mul", "Add"):
+            q, s, z = n[0].output[:3]
+            comb, mm, cast, deq = n[1].output[0], n[2].output[0], n[3].output[0], n[4].output[0]
+            ok = (s in n[1].input and n[2].input[0] == q and len(n[2].input) >= 4 and n[2].input[2] == z and n[3].input[0] == mm
+                  and cast in n[4].input and comb in n[4].input and deq in n[5].input and private(q, s, z, comb, mm, cast, deq))
+            ws_n = n[1].input[1] if n[1].input[0] == s else n[1].input[0]
+            bias_n = n[5].input[1] if n[5].input[0] == deq else n[5].input[0]
+            w_n, wz_n = n[2].input[1], n[2].input[3] if len(n[2].input) >= 4 else ""
+            if ok and all(v in self.consts for v in (ws_n, bias_n, w_n, wz_n)):
+                relu = ops("DynamicQuantizeLinear", "Mul", "MatMulInteger", "Cast", "Mul", "Add", "Relu") and \
+                    nodes[k + 6].input[0] == n[5].output[0] and private(n[5].output[0])
+                out = nodes[k + 6].output[0] if relu else n[5].output[0]
+                args = [self.tensor(n[0].input[0]), self.weight(w_n, True), self.weight(ws_n, True), self.weight(wz_n, True),
+                        self.weight(bias_n, True), {"bool": bool(relu)}]
+                return (7 if relu else 6), lambda: self.emit([out], "fused_quantized_linear", args)
+        # Conv + Sigmoid + Mul -> conv2d_silu (patterns.rs:704-840); Conv + Relu (559-703)
+        if ops("Conv", "Sigmoid", "Mul") and len(_attrs(n[0]).get("kernel_shape", [1])) >= 2:
+            c, sg = n[0].output[0], n[1].output[0]
+            if n[1].input[0] == c and sorted(n[2].input) == sorted([c, sg]) and cnt.get(c, 0) == 2 and private(sg):
+                return 3, lambda: self.conv(n[0], "conv2d_silu", n[2].output[0])
+        if ops("Conv", "Relu") and n[1].input[0] == n[0].output[0] and private(n[0].output[0]):
+            return 2, lambda: self.conv(n[0], None, n[1].output[0], relu=True)
+        # Sigmoid + Mul -> silu (patterns.rs:1004-1062)
+        if ops("Sigmoid", "Mul"):
+            x, sg = n[0].input[0], n[0].output[0]
+            if sorted(n[1].input) == sorted([x, sg]) and private(sg) and x not in self.consts:
+                return 2, lambda: self.emit([n[1].output[0]], "silu", [self.tensor(x)])
+        # MatMul + Add(bias) -> matmul_fused_add (patterns.rs:1063-1122); only for a constant 1-D bias
+        if ops("MatMul", "Add") and n[0].output[0] in n[1].input and private(n[0].output[0]):
+            bias_n = n[1].input[1] if n[1].input[0] == n[0].output[0] else n[1].input[0]
+            if bias_n in self.consts and np.asarray(self.consts[bias_n]).ndim == 1 and self.consts[bias_n].dtype.kind == "f":
+                return 2, lambda: self.emit([n[1].output[0]], "matmul_fused_add", [self.tensor(n[0].input[0]), self.tensor(n[0].input[1]),
+                                                                                    self.weight(bias_n, True)])
+        return None
+
+    # ---------------------------------------------------------------------------------------- per-op lowering
+    def conv(self, node, fn, out, relu=False):
+        at = _attrs(node)
+        wname = node.input[1]
+        rank = np.asarray(self.consts[wname]).ndim if wname in self.consts else 3  # ops/nn.rs:46-54: unknown weights -> conv1d
+        geom = [{"list": [{"int": v} for v in at.get("dilations", [])]}, {"int": at.get("group", 1)},
+                {"list": [{"int": v} for v in at.get("pads", [])]}, {"list": [{"int": v} for v in at.get("strides", [])]}]
+        if at.get("auto_pad", "NOTSET") not in ("NOTSET", ""):
+            raise CompileError("Conv %r: auto_pad=%s is not supported (lele reads explicit pads only)" % (node.name, at["auto_pad"]))
+        head = [self.tensor(node.input[0]), self.tensor(wname), self.opt_tensor(node, 2)]
+        if fn is None:
+            base = "conv2d" if rank >= 4 else "conv1d"
+            fn = base + "_fused" if relu else base
+        args = head + geom + ([{"bool": True}] if fn.endswith("_fused") else [])
+        return self.emit([out], fn, args)
+
+    def lower_node(self, node):
+        op, at, I, O = node.op_type, _attrs(node), node.input, node.output
+        T = self.tensor
+        ilist = lambda key, d=None: {"list": [{"int": int(v)} for v in at.get(key, d or [])]}  # noqa: E731
+        if op in UNARY:
+            return self.emit(O, UNARY[op], [T(I[0])])
+        if op in BINARY:
+            return self.emit(O, BINARY[op], [T(I[0]), T(I[1])])
+        if op in ("Max", "Min"):
+            fn, acc = op.lower(), T(I[0])
+            for j, nm in enumerate(I[1:]):
+                last = j == len(I) - 2
+                tmp = O[0] if last else "%s__%s%d" % (O[0], fn, j)
+                self.emit([tmp], fn, [acc, T(nm)])
+                acc = {"ref": sanitize(tmp)}
+            return None
+        if op == "MatMul":
+            return self.emit(O, "matmul", [T(I[0]), T(I[1])])
+        if op == "Gemm":
+            return self.emit(O, "gemm", [T(I[0]), T(I[1]), self.opt_tensor(node, 2), {"float": at.get("alpha", 1.0)},
+                                         {"float": at.get("beta", 1.0)}, {"bool": bool(at.get("transA", 0))}, {"bool": bool(at.get("transB", 0))}])
+        if op == "Conv":
+            return self.conv(node, None, O[0])
+        if op == "ConvTranspose":
+            if at.get("output_padding") and any(at["output_padding"]):
+                raise CompileError("ConvTranspose %r: output_padding is not supported" % node.name)
+            return self.emit(O, "conv_transpose", [T(I[0]), T(I[1]), self.opt_tensor(node, 2), ilist("dilations"), {"int": at.get("group", 1)},
+                                                   ilist("pads"), ilist("strides")])
+        if op == "ConvInteger":
+            return self.emit(O, "conv_integer", [T(I[0]), T(I[1]), self.opt_tensor(node, 2), self.opt_tensor(node, 3), ilist("dilations"),
+                                                 {"int": at.get("group", 1)}, ilist("pads"), ilist("strides")])
+        if op == "MatMulInteger":
+            return self.emit(O, "mat_mul_integer", [T(I[0]), T(I[1]), self.opt_tensor(node, 2), self.opt_tensor(node, 3)])
+        if op == "DynamicQuantizeLinear":
+            return self.emit(O, "dynamic_quantize_linear", [T(I[0])], n_bufs=3)
+        if op == "LSTM":
+            return self.emit([o for o in O] + ["%s__pad%d" % (O[0], j) for j in range(3 - len(O))], "lstm",
+                             [T(I[0]), T(I[1]), T(I[2])] + [self.opt_tensor(node, j) for j in (3, 4, 5, 6)], n_bufs=3)
+        if op == "GRU":
+            return self.emit([o for o in O] + ["%s__pad%d" % (O[0], j) for j in range(2 - len(O))], "gru",
+                             [T(I[0]), T(I[1]), T(I[2]), self.opt_tensor(node, 3), self.opt_tensor(node, 5),
+                              {"bool": bool(at.get("linear_before_reset", 0))}], n_bufs=2)
+        if op == "LayerNormalization":
+            if len(I) < 3 or not I[1] or not I[2]:
+                raise CompileError("LayerNormalization %r: scale and bias are required" % node.name)
+            return self.emit(O[:1], "layer_norm", [T(I[0]), T(I[1]), T(I[2]), {"int": at.get("axis", -1)}, {"float": at.get("epsilon", 1e-5)}])
+        if op == "BatchNormalization":
+            return self.emit(O[:1], "batch_norm", [T(I[j]) for j in range(5)] + [{"float": at.get("epsilon", 1e-5)}])
+        if op == "Softmax":
+            return self.emit(O, "softmax", [T(I[0]), {"int": at.get("axis", -1)}])
+        if op == "MaxPool":
+            return self.emit(O[:1], "max_pool2d", [T(I[0]), ilist("kernel_shape"), ilist("strides"), ilist("pads"), ilist("dilations"),
+                                                   {"bool": bool(at.get("ceil_mode", 0))}])
+        if op == "Resize":
+            mode = at.get("coordinate_transformation_mode", "half_pixel")
+            if at.get("mode", "nearest") != "nearest":
+                raise CompileError("Resize %r: only mode=nearest exists in lele (conv2d.rs:1261)" % node.name)
+            if len(I) > 3 and I[3]:
+                return self.emit(O, "resize_nearest", [T(I[0]), {"none": 1}, {"some": self.ints(node, 3)}, {"str": mode}])
+            sc = I[2]
+            if sc not in self.consts:
+                raise CompileError("Resize %r: run-time scales are not supported" % node.name)
+            return self.emit(O, "resize_nearest", [T(I[0]), {"some": {"list": [{"float": float(v)} for v in np.asarray(self.consts[sc]).reshape(-1)]}},
+                                                   {"none": 1}, {"str": mode}])
+        if op == "Transpose":
+            return self.emit(O, "transpose", [T(I[0]), ilist("perm")])
+        if op == "Reshape":
+            return self.emit(O, "reshape", [T(I[0]), self.ints(node, 1)], view=True)
+        if op == "Flatten":
+            return self.emit(O, "flatten", [T(I[0]), {"int": at.get("axis", 1)}], view=True)
+        if op in ("Unsqueeze", "Squeeze"):
+            return self.emit(O, op.lower(), [T(I[0]), self.ints(node, 1, "axes", at)], view=True)
+        if op == "Identity":
+            return self.emit(O, "identity", [T(I[0])], view=True)
+        if op == "Concat":
+            return self.emit(O, "concat", [{"list": [T(nm) for nm in I]}, {"int": at.get("axis", 0)}])
+        if op == "Where":
+            return self.emit(O, "where_op", [T(I[0]), T(I[1]), T(I[2])])
+        if op in ("Gather", "GatherElements"):
+            return self.emit(O, "gather" if op == "Gather" else "gather_elements", [T(I[0]), T(I[1]), {"int": at.get("axis", 0)}])
+        if op == "Slice":
+            if len(I) == 1:  # opset < 10: attributes
+                return self.emit(O, "slice", [T(I[0]), ilist("starts"), ilist("ends"), ilist("axes"), {"list": []}])
+            return self.emit(O, "slice", [T(I[0]), self.ints(node, 1), self.ints(node, 2), self.ints(node, 3), self.ints(node, 4)])
+        if op == "Expand":
+            return self.emit(O, "expand", [T(I[0]), self.ints(node, 1)])
+        if op == "Tile":
+            return self.emit(O, "tile", [T(I[0]), self.ints(node, 1)])
+        if op == "Split":
+            return self.emit(O, "split", [T(I[0]), {"int": at.get("axis", 0)}, self.ints(node, 1, "split", at, [0] * len(O))], n_bufs=len(O))
+        if op == "Pad":
+            if len(I) > 1 and I[1]:
+                pads = self.ints(node, 1)
+            else:
+                pads = ilist("pads")
+            cv = self.opt_tensor(node, 2) if len(I) > 2 and I[2] else ({"weight": self.packer.add(np.array([at["value"]], np.float32), pb.FLOAT)}
+                                                                       if "value" in at else {"none": 1})
+            return self.emit(O, "pad", [T(I[0]), pads, cv, {"str": at.get("mode", "constant")}])
+        if op in ("ReduceMean", "ReduceSum", "ReduceMax", "ReduceL2"):
+            fn = {"ReduceMean": "reduce_mean", "ReduceSum": "reduce_sum", "ReduceMax": "reduce_max", "ReduceL2": "reduce_l2"}[op]
+            return self.emit(O, fn, [T(I[0]), self.ints(node, 1, "axes", at), {"bool": bool(at.get("keepdims", 1))}])
+        if op == "Clip":
+            def bound(i, key):
+                if len(I) > i and I[i]:
+                    return self.tensor(I[i])
+                return {"weight": self.packer.add(np.array([at[key]], np.float32), pb.FLOAT)} if key in at else {"none": 1}
+            return self.emit(O, "clip", [T(I[0]), bound(1, "min"), bound(2, "max")])
+        if op == "Cast":
+            to = at.get("to", pb.FLOAT)
+            if to in (pb.FLOAT, pb.FLOAT16, pb.DOUBLE):
+                return self.emit(O, "identity", [T(I[0])], view=True)  # f32 -> f32: `clone()` upstream (ops/tensor.rs Cast)
+            if to in (pb.INT64, pb.INT32, pb.BOOL):
+                return self.emit(O, "cast_to_i64", [T(I[0])])
+            raise CompileError("Cast %r: target type %d is not supported" % (node.name, to))
+        if op == "TopK":
+            k = self.ints(node, 1)
+            return self.emit(O, "topk", [T(I[0]), {"first": k}, {"int": at.get("axis", -1)}, {"bool": bool(at.get("largest", 1))},
+                                         {"bool": bool(at.get("sorted", 1))}], n_bufs=2)
+        if op == "ConstantOfShape":
+            val = float(np.asarray(at.get("value", np.float32(0.0))).reshape(-1)[0])
+            return self.emit(O, "constant_of_shape", [self.ints(node, 0), {"float": val}])
+        if op == "STFT":
+            return self.emit(O, "stft", [T(I[0])] + [{"first": self.ints(node, j)} for j in (1,)] + [self.opt_tensor(node, 2)], n_bufs=1)
+        raise CompileError("ONNX operator %s (%r) is not supported by this back-end" % (op, node.name))
+
+    # ---------------------------------------------------------------------------------------- driver
+    def run(self):
+        nodes = self.fold(list(self.model.graph.node))
+        cnt = self.uses(nodes)
+        k = 0
+        while k < len(nodes):
+            n = nodes[k]
+            ins = [i for i in n.input if i]
+            host_ready = all(i in self.consts or self.place.get(i) == "host" for i in ins)
+            if n.op_type in ("Shape", "Size") or (host_ready and n.op_type in HOST_OPS):
+                self.emit_host(n, _attrs(n))
+                k += 1
+                continue
+            m = self.match(nodes, k, cnt)
+            if m:
+                used, emitter = m
+                emitter()
+                k += used
+                continue
+            self.lower_node(n)
+            k += 1
+        for o in self.outputs:
+            if o in self.consts:
+                raise CompileError("graph output %s is a constant" % o)
+        slots = allocate(self.statements, [sanitize(o) for o in self.outputs])
+        plan = {"source": self.name, "format": "lele_amd.plan/2", "inputs": [sanitize(v.name) for v in self.inputs],
+                "input_info": [{"name": sanitize(v.name), "dtype": "i64" if self.place[v.name] == "host" else "f32", "shape": v.shape}
+                               for v in self.inputs],
+                "outputs": [sanitize(o) for o in self.outputs], "slots": slots, "statements": self.statements,
+                "weights": {}}
+        seen = {}
+
+        def walk(n):
+            if isinstance(n, dict):
+                if "weight" in n:
+                    kind, off, ln, shape = n["weight"]
+                    seen["%d:%s:%s" % (off, kind, "x".join(map(str, shape)))] = [kind, off, ln, shape]
+                for v in n.values():
+                    walk(v)
+            elif isinstance(n, list):
+                for v in n:
+                    walk(v)
+        walk(self.statements)
+        plan["weights"] = seen
+        return plan, bytes(self.packer.blob)
+
+
+HOST_OPS = {"Identity", "Shape", "Size", "Unsqueeze", "Squeeze", "Concat", "Gather", "Cast", "Add", "Sub", "Mul", "Div", "Equal", "Less",
+            "Greater", "Max", "Min", "Neg", "Reshape", "Slice", "Range", "ConstantOfShape", "Expand", "Where", "Transpose", "Tile", "Not"}
+
+
+def allocate(statements, outputs):
+    """Workspace slots by liveness (src/compiler/mod.rs:148-290): a value's slot returns to the free heap after its last
+    reader; views extend the life of the buffer they share; a statement never writes a slot it (or one of the five
+    statements before it, which may be fused with it upstream) reads.  Adds "slots" to every device statement in place and
+    returns the slot names."""
+    last_use, owner = {}, {}
+    INF = len(statements) + 1
+
+    def refs(n, acc):
+        if isinstance(n, dict):
+            for key in ("ref", "ints"):
+                if key in n and isinstance(n[key], str):
+                    acc.append(n[key])
+            for v in n.values():
+                refs(v, acc)
+        elif isinstance(n, list):
+            for v in n:
+                refs(v, acc)
+        return acc
+
+    reads = []
+    for i, st in enumerate(statements):
+        r = refs(st.get("args", st.get("in")), [])
+        reads.append(r)
+        for name in r:
+            last_use[name] = i
+        if st["op"] == "call" and st.get("bufs", 1) == 0:  # view: shares its first tensor operand's buffer
+            src = r[0] if r else None
+            owner[st["out"][0]] = owner.get(src, src)
+    for o in outputs:
+        last_use[o] = INF
+    # a buffer lives as long as its longest-lived view
+    for i in range(len(statements) - 1, -1, -1):
+        for o in statements[i]["out"]:
+            root = owner.get(o)
+            if root is not None:
+                last_use[root] = max(last_use.get(root, -1), last_use.get(o, -1))
+    free, active, slot_of, n_slots = [], {}, {}, 0
+    import heapq
+    for i, st in enumerate(statements):
+        for name in [n for n, _s in active.items() if last_use.get(n, -1) < i]:
+            heapq.heappush(free, active.pop(name))
+        if st["op"] != "call" or st.get("bufs", 1) == 0:
+            continue
+        busy = {slot_of[owner.get(r, r)] for j in range(max(0, i - 5), i + 1) for r in reads[j] if owner.get(r, r) in slot_of}
+        st["slots"] = []
+        for b in range(st["bufs"]):
+            deferred, pick = [], None
+            while free:
+                s = heapq.heappop(free)
+                if s in busy:
+                    deferred.append(s)
+                else:
+                    pick = s
+                    break
+            for s in deferred:
+                heapq.heappush(free, s)
+            if pick is None:
+                pick, n_slots = n_slots, n_slots + 1
+            st["slots"].append("buf_%d" % pick)
+            busy.add(pick)
+            name = st["out"][b] if b < len(st["out"]) else None
+            if name is not None:
+                slot_of[name] = pick
+                active[name] = pick
+    return ["buf_%d" % s for s in range(n_slots)]
+
+
+def compile_model(model, name="model"):
+    """ONNX model (bytes, path or onnx_pb.Model) -> (plan dict, weights.bin bytes)"""
+    if not isinstance(model, pb.Model):
+        model = pb.load(model)
+    return Lowering(model, name).run()

@@ -84,10 +84,10 @@ def fused_quantized_linear(input, weight_int8, weight_scale, weight_zero, bias, 
     return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
 
 
-def dynamic_quantize_linear(x, ctx=None):  # quantization.rs:1628 -> (y, scale, zero_point)
+def dynamic_quantize_linear(x, outs=None, ctx=None):  # quantization.rs:1628 -> (y, scale, zero_point); outs = its 3 buffers
     ctx = _ctx(ctx)
     keep = []
-    oy, os_, oz = ctx.buf(), ctx.buf(), ctx.buf()
+    oy, os_, oz = outs if outs else (ctx.buf(), ctx.buf(), ctx.buf())
     sh = _lib.OutShape()
     _lib.check(_lib.lib().lele_hip_dynamic_quantize_linear(ctx._h, _t(x, keep), oy._h, os_._h, oz._h, sh.shape,
                                                            C.byref(sh.rank)))
@@ -506,11 +506,11 @@ def conv_transpose(input, weights, bias=None, dilations=(), group=1, pads=(), st
     return _conv(_lib.lib().lele_hip_conv_transpose, input, weights, bias, dilations, group, pads, strides, [], out, ctx)
 
 
-def lstm(input, w, r, bias=None, sequence_lens=None, initial_h=None, initial_c=None, ctx=None):
-    """rnn.rs:67 -> (Y [T,1,1,H], H_n [1,1,H], C_n [1,1,H])"""
+def lstm(input, w, r, bias=None, sequence_lens=None, initial_h=None, initial_c=None, outs=None, ctx=None):
+    """rnn.rs:67 -> (Y [T,1,1,H], H_n [1,1,H], C_n [1,1,H]); outs = the three `&mut Vec` output buffers of the reference"""
     ctx = _ctx(ctx)
     keep = []
-    oy, oh, oc = ctx.buf(), ctx.buf(), ctx.buf()
+    oy, oh, oc = outs if outs else (ctx.buf(), ctx.buf(), ctx.buf())
     sh = _lib.OutShape()
     t = [_lib.as_tensor(unwrap(v), keep) for v in (input, w, r, bias, sequence_lens, initial_h, initial_c)]
     _lib.check(_lib.lib().lele_hip_lstm(ctx._h, *t, oy._h, oh._h, oc._h, sh.shape, C.byref(sh.rank)))
@@ -520,11 +520,11 @@ def lstm(input, w, r, bias=None, sequence_lens=None, initial_h=None, initial_c=N
             TensorView(_lib.DevTensor(oc, hs, np.float32)))
 
 
-def gru(input, w, r, bias=None, initial_h=None, linear_before_reset=False, ctx=None):
-    """rnn.rs:246 -> (Y [T,1,1,H], H_n [1,1,H])"""
+def gru(input, w, r, bias=None, initial_h=None, linear_before_reset=False, outs=None, ctx=None):
+    """rnn.rs:246 -> (Y [T,1,1,H], H_n [1,1,H]); outs = the two `&mut Vec` output buffers of the reference"""
     ctx = _ctx(ctx)
     keep = []
-    oy, oh = ctx.buf(), ctx.buf()
+    oy, oh = outs if outs else (ctx.buf(), ctx.buf())
     sh = _lib.OutShape()
     t = [_lib.as_tensor(unwrap(v), keep) for v in (input, w, r, bias, initial_h)]
     _lib.check(_lib.lib().lele_hip_gru(ctx._h, *t, C.c_int(int(bool(linear_before_reset))), oy._h, oh._h, sh.shape,

@@ -1,0 +1,184 @@
+"""Plan execution: the statement list produced by `lele_amd.compiler` (from ONNX) or by tools/lift_generated.py (from a
+lele-generated Rust model) run through the operator mirror, one C-ABI call per statement, recordable as a hipGraph.
+
+A plan is JSON: `inputs`, `outputs`, `slots` (workspace buffers, lele's `ws.buf_k`), `weights` (views into a lele
+`<model>_weights.bin`: kind, byte offset, byte length, shape -- src/compiler/mod.rs:1135-1233) and `statements`:
+
+  {"op": "call", "out": [...], "fn": "<lele::kernels name>", "args": [...], "slots": ["buf_3"]}   a kernel call
+  {"op": "host", "out": [...], "onnx": "<op>", "in": [...], "attrs": {...}}                        integer side arithmetic (hostops)
+  {"op": "ints" | "newbuf" | "swap_remove" | "alias", ...}                                       forms lele's emitters produce
+
+Argument nodes: {"ref"}, {"weight"}, {"list"}, {"int"|"float"|"bool"|"str"}, {"none"}, {"some"}, {"slot"}, {"buf"},
+{"ints": name} (a host integer value as a list), {"first": node} (first element of an integer list).
+"""
+import time
+
+import numpy as np
+
+from .compiler import hostops
+
+WEIGHT_DTYPES = {"weight_f32": "<f4", "weight_i64": "<i8", "weight_i64_f32": "<i8", "weight_i32": "<i4", "weight_i32_i64": "<i4",
+                 "weight_i32_f32": "<i4", "weight_u8": "u1", "weight_i8": "i1", "weight_f16": "<f2", "weight_f64": "<f8"}
+
+
+def load_weights_bin(plan, data):
+    """decode the views of a lele `<model>_weights.bin` (path or bytes).  As lele's accessors do (src/compiler/mod.rs:1135-1233),
+    u8 / i8 / f16 / f64 / i32 tensors are handed to the kernels as f32 values, i64 stays i64 unless the view says `_f32`."""
+    if not isinstance(data, (bytes, bytearray, memoryview)):
+        data = open(data, "rb").read()
+    out = {}
+    for key, view in plan["weights"].items():
+        kind, off, ln, shape = view if len(view) == 4 else (view[0], int(key), view[1], view[2])  # lifted plans key by offset
+        if kind not in WEIGHT_DTYPES:
+            raise ValueError("weights view kind %r is not handled" % kind)
+        a = np.frombuffer(data[off:off + ln], WEIGHT_DTYPES[kind])
+        if kind in ("weight_i64", "weight_i32_i64"):
+            a = a.astype(np.int64)
+        elif kind == "weight_i32":
+            a = a.astype(np.int64)
+        else:
+            a = a.astype(np.float32)
+        out[key if len(view) == 4 else int(key)] = np.array(a).reshape(shape if shape else ())
+    return out
+
+
+def weight_key(node):
+    kind, off, _ln, shape = node
+    return "%d:%s:%s" % (off, kind, "x".join(map(str, shape)))
+
+
+class Runner:
+    def __init__(self, plan, weights, ctx):
+        from . import kernels as K
+        from ._lib import Weight
+        self.plan, self.K, self.ctx = plan, K, ctx
+        self.v2 = plan.get("format") == "lele_amd.plan/2"   # compiled plans key weights by (offset, kind, shape); lifted ones by offset
+        self.raw = {(k if self.v2 else int(k)): v for k, v in weights.items()}
+        self.W = {k: (Weight(a) if a.dtype != np.int64 else a) for k, a in self.raw.items()}
+        self.ws = {s: ctx.buf() for s in plan["slots"]}
+        self.extra = {}
+        self.calls = 0
+        self.profile = None
+        self.stmt_index = 0
+
+    def _wkey(self, node):
+        return weight_key(node) if self.v2 else node[1]
+
+    @staticmethod
+    def _host_ints(v):
+        from .tensor import TensorView
+        if isinstance(v, TensorView):
+            v = v.numpy()
+        return [int(x) for x in np.asarray(v).reshape(-1)]
+
+    def val(self, n, env):
+        if "ref" in n:
+            return env[n["ref"]]
+        if "refs" in n:
+            return [env[r] for r in n["refs"]]
+        if "weight" in n:
+            return self.W[self._wkey(n["weight"])]
+        if "weight_scalar" in n:
+            return int(np.asarray(self.raw[self._wkey(n["weight_scalar"])]).reshape(-1)[0])
+        if "weight_list" in n:
+            a = np.asarray(self.raw[self._wkey(n["weight_list"])]).reshape(-1)
+            return [float(v) for v in a] if a.dtype == np.float32 else [int(v) for v in a]
+        if "ints" in n:
+            return self._host_ints(env[n["ints"]])
+        if "first" in n:
+            return self.val(n["first"], env)[0]
+        if "some" in n:
+            return self.val(n["some"], env)
+        if "none" in n:
+            return None
+        if "list" in n:
+            return [self.val(v, env) for v in n["list"]]
+        for k in ("int", "float", "bool", "str"):
+            if k in n:
+                return n[k]
+        raise ValueError(n)
+
+    def call(self, f, fn, pos, bufs, key=None):
+        ctx = self.ctx
+        if fn == "split_owned":  # owned results: one persistent device buffer per output of this statement
+            outs = self.extra.setdefault(("split", key), [ctx.buf() for _ in pos[2]])
+            return list(f(pos[0], pos[1], pos[2], outputs=outs, ctx=ctx))
+        if fn == "split":
+            return list(f(pos[0], pos[1], pos[2], outputs=bufs, ctx=ctx))
+        if fn == "topk":
+            return f(pos[0], pos[1], pos[2], pos[3], pos[4], out_values=bufs[0], out_indices=bufs[1], ctx=ctx)
+        if fn in ("lstm", "gru", "dynamic_quantize_linear"):
+            return f(*pos, outs=bufs, ctx=ctx)
+        if fn in ("reshape", "flatten", "unsqueeze", "squeeze", "identity"):
+            return f(*pos)
+        return f(*pos, out=bufs[0], ctx=ctx) if bufs else f(*pos, ctx=ctx)
+
+    def host(self, st, env):
+        from .tensor import TensorView
+        ins = []
+        for n in st["in"]:
+            if n is None:
+                ins.append(None)
+            elif "const" in n:
+                ins.append(np.asarray(n["const"], np.int64 if n["dtype"] == "i64" else np.float32))
+            else:
+                v = env[n["ref"]]
+                if st["onnx"] in ("Shape", "Size"):  # only the shape is needed: never a device read
+                    v = np.empty([int(d) for d in v.shape], np.uint8) if isinstance(v, TensorView) else np.asarray(v)
+                elif isinstance(v, TensorView):
+                    v = v.numpy()
+                ins.append(np.asarray(v))
+        res = hostops.evaluate(st["onnx"], ins, st["attrs"])
+        if res is None:
+            raise RuntimeError("host statement %s: no host evaluator" % st["onnx"])
+        for name, r in zip(st["out"], res):
+            env[name] = np.asarray(r)
+
+    def run(self, inputs):
+        K, ctx = self.K, self.ctx
+        env = dict(inputs)
+        for self.stmt_index, st in enumerate(self.plan["statements"]):
+            op = st["op"]
+            if op == "ints":
+                env[st["out"][0]] = st["value"]
+            elif op == "newbuf":
+                self.extra.setdefault(st["out"][0], ctx.buf())
+                env[st["out"][0]] = self.extra[st["out"][0]]
+            elif op == "swap_remove":  # Vec::swap_remove: take element i, move the last element into its place
+                lst = env[st["list"]]
+                i = st["index"]
+                env[st["out"][0]] = lst[i]
+                lst[i] = lst[-1]
+                lst.pop()
+            elif op == "alias":
+                env[st["out"][0]] = env[st["src"]]
+            elif op == "host":
+                self.host(st, env)
+            else:
+                fn, args = st["fn"], st["args"]
+                pos = []
+                bufs = [self.ws[s] for s in st.get("slots", [])]
+                for a in args:
+                    if "slot" in a:
+                        bufs.append(self.ws[a["slot"]])
+                    elif "buf" in a:
+                        bufs.append(env[a["buf"]])
+                    else:
+                        pos.append(self.val(a, env))
+                f = getattr(K, fn)
+                self.calls += 1
+                try:
+                    t0 = time.perf_counter() if self.profile is not None else 0.0
+                    res = self.call(f, fn, pos, bufs, key=st["out"][0] + str(self.stmt_index))
+                    if self.profile is not None:
+                        ctx.sync()
+                        self.profile[fn] = self.profile.get(fn, 0.0) + time.perf_counter() - t0
+                except Exception as e:  # noqa: BLE001
+                    shp = [getattr(p, "shape", p) if not isinstance(p, list) else [getattr(q, "shape", q) for q in p] for p in pos]
+                    raise RuntimeError("statement %s = %s(...) failed with %s; argument shapes/values: %s" % (st["out"], fn, e, shp))
+                if len(st["out"]) == 1:
+                    env[st["out"][0]] = res
+                else:
+                    for name, r in zip(st["out"], res):
+                        env[name] = r
+        return [env[o] for o in self.plan["outputs"]]

@@ -1,0 +1,260 @@
+"""ONNX -> device plan compiler (lele_amd/compiler).
+
+CPU: the protobuf reader against its writer AND against torch's exporter output, weights.bin packing (alignment, content
+de-duplication: src/compiler/mod.rs:1381-1505), pattern fusion (patterns.rs), liveness allocation invariants
+(mod.rs:148-290), host shape arithmetic.  GPU: compiled plans run through the C ABI against torch's CPU result (an
+independent second opinion, tolerance 1e-4 relative as for every f32 GEMM-class op) and against the oracle for the
+quantised-linear pattern; hipGraph replay of a compiled plan."""
+import json
+
+import numpy as np
+import pytest
+
+from lele_amd.compiler import CompileError, compile_model, hostops
+from lele_amd.compiler import onnx_pb as pb
+from tests.onnx_util import export
+
+torch = pytest.importorskip("torch")
+
+
+def fns(plan):
+    return [st.get("fn", "host:" + st.get("onnx", "")) for st in plan["statements"]]
+
+
+class Toy(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.c = torch.nn.Conv2d(3, 8, 3, padding=1)
+        self.c2 = torch.nn.Conv2d(8, 8, 1)
+        self.ln = torch.nn.LayerNorm(16)
+        self.fc = torch.nn.Linear(16, 4)
+
+    def forward(self, x):
+        y = self.c(x)
+        y = y * torch.sigmoid(y)
+        y = torch.relu(self.c2(y))
+        y = y.mean(dim=1)
+        y = self.ln(y)
+        y = y.reshape(y.shape[0], -1, 16)
+        return torch.softmax(self.fc(y), -1)
+
+
+def test_protobuf_roundtrip_and_torch_export():
+    g = pb.Graph([pb.Node("Conv", ["x", "w", "b"], ["y"], name="c0", strides=[2, 2], pads=[1, 1, 1, 1], group=1, auto_pad="NOTSET", alpha=0.5),
+                  pb.Node("Constant", [], ["c"], value=np.array([1, -2, 3], np.int64))],
+                 [pb.ValueInfo("x", pb.FLOAT, [1, 3, "h", 640])], [pb.ValueInfo("y", pb.FLOAT, None)],
+                 [pb.Tensor("w", np.arange(24, dtype=np.float32).reshape(2, 3, 2, 2)), pb.Tensor("h", np.array([1, 2], np.float16)),
+                  pb.Tensor("u", np.array([[1, 2], [3, 250]], np.uint8)), pb.Tensor("i", np.array([-(2 ** 62), 7], np.int64))])
+    m = pb.load(pb.Model(g, opset=13).serialize())
+    n = m.graph.node[0]
+    assert (n.op_type, n.input, n.output, n.name) == ("Conv", ["x", "w", "b"], ["y"], "c0") and m.opset == 13
+    assert n.attr("strides").ints == [2, 2] and n.attr("group").i == 1 and n.attr("auto_pad").s == b"NOTSET" and n.attr("alpha").f == 0.5
+    assert m.graph.node[1].attr("value").t.array.tolist() == [1, -2, 3]
+    assert m.graph.input[0].shape == [1, 3, "h", 640] and m.graph.output[0].shape is None
+    got = {t.name: t.array for t in m.graph.initializer}
+    assert got["w"].shape == (2, 3, 2, 2) and got["h"].dtype == np.float16 and got["u"].tolist() == [[1, 2], [3, 250]]
+    assert got["i"].tolist() == [-(2 ** 62), 7]
+    # a real exporter's bytes
+    t = Toy()
+    mm = pb.load(export(t, (torch.randn(2, 3, 16, 16),), opset=13))
+    assert mm.producer == "pytorch" and mm.opset == 13
+    ops = [n.op_type for n in mm.graph.node]
+    assert ops[:3] == ["Conv", "Sigmoid", "Mul"] and "Pow" in ops and ops[-1] == "Softmax"
+    init = {i.name: i.array for i in mm.graph.initializer}
+    assert np.array_equal(init["c.weight"], t.c.weight.detach().numpy()) and np.array_equal(init["ln.bias"], t.ln.bias.detach().numpy())
+    assert mm.graph.input[0].shape == [2, 3, 16, 16]
+
+
+def test_fusion_folding_weights_and_allocation():
+    t = Toy()
+    for opset in (13, 17):
+        plan, blob = compile_model(export(t, (torch.randn(2, 3, 16, 16),), opset=opset), "toy")
+        # Conv+Sigmoid+Mul, Conv+Relu, the 9-node LayerNorm (opset 13) / the op (17), MatMul+Add; Shape/Gather/Concat folded into the reshape
+        assert fns(plan) == ["conv2d_silu", "conv2d_fused", "reduce_mean", "layer_norm", "reshape", "matmul_fused_add", "softmax"], opset
+        rs = [s for s in plan["statements"] if s["fn"] == "reshape"][0]
+        assert [v["int"] for v in rs["args"][1]["list"]] == [2, -1, 16]
+        for kind, off, ln, shape in plan["weights"].values():   # mod.rs:1418-1424: 16-byte aligned views inside the blob
+            assert off % 16 == 0 and off + ln <= len(blob) and kind == "weight_f32" and ln == 4 * int(np.prod(shape))
+        w = {tuple(v[3]): np.frombuffer(blob[v[1]:v[1] + v[2]], "<f4").reshape(v[3]) for v in plan["weights"].values()}
+        assert np.array_equal(w[(8, 3, 3, 3)], t.c.weight.detach().numpy())
+    # identical contents are stored once (mod.rs:1408-1417)
+    a = np.arange(12, dtype=np.float32)
+    g = pb.Graph([pb.Node("Add", ["x", "a"], ["t"]), pb.Node("Mul", ["t", "b"], ["y"])], [pb.ValueInfo("x", pb.FLOAT, [12])],
+                 [pb.ValueInfo("y", pb.FLOAT, [12])], [pb.Tensor("a", a), pb.Tensor("b", a.copy())])
+    plan, blob = compile_model(pb.Model(g).serialize())
+    assert len(blob) == 48 and len({v[1] for v in plan["weights"].values()}) == 1
+    # liveness: a statement never writes a slot it reads, and no slot is reassigned while its value is still needed
+    plan, _ = compile_model(export(t, (torch.randn(2, 3, 16, 16),), opset=17))
+    live, root = {}, {}
+    sts = plan["statements"]
+
+    def refs(n, acc):
+        if isinstance(n, dict):
+            if isinstance(n.get("ref"), str):
+                acc.append(n["ref"])
+            for v in n.values():
+                refs(v, acc)
+        elif isinstance(n, list):
+            for v in n:
+                refs(v, acc)
+        return acc
+    last = {}
+    for i, st in enumerate(sts):
+        for r in refs(st.get("args"), []):
+            last[r] = i
+    for o in plan["outputs"]:
+        last[o] = 10 ** 9
+    for i, st in enumerate(sts):
+        rd = refs(st.get("args"), [])
+        if not st.get("slots"):
+            root[st["out"][0]] = root.get(rd[0], rd[0])
+            continue
+        for name, slot in zip(st["out"], st["slots"]):
+            assert all(live.get(root.get(r, r)) != slot for r in rd), (st["fn"], slot)
+            for other, s in live.items():
+                if s == slot:
+                    users = [v for v in last if root.get(v, v) == other]
+                    assert all(last[v] < i for v in users), (other, slot, i)
+            live[name] = slot
+
+
+def test_quantised_linear_pattern_and_unsupported_ops():
+    rng = np.random.default_rng(0)
+    k, n = 32, 24
+    w = rng.integers(0, 256, (k, n)).astype(np.uint8)
+    init = [pb.Tensor("w", w), pb.Tensor("ws", (rng.random(n) * 0.01 + 0.002).astype(np.float32)), pb.Tensor("wz", np.array(128, np.uint8)),
+            pb.Tensor("b", rng.standard_normal(n).astype(np.float32))]
+    nodes = [pb.Node("DynamicQuantizeLinear", ["x"], ["q", "s", "z"]), pb.Node("Mul", ["s", "ws"], ["cs"]),
+             pb.Node("MatMulInteger", ["q", "w", "z", "wz"], ["mm"]), pb.Node("Cast", ["mm"], ["mmf"], to=1),
+             pb.Node("Mul", ["mmf", "cs"], ["dq"]), pb.Node("Add", ["dq", "b"], ["lin"]), pb.Node("Relu", ["lin"], ["y"])]
+    g = pb.Graph(nodes, [pb.ValueInfo("x", pb.FLOAT, [5, k])], [pb.ValueInfo("y", pb.FLOAT, [5, n])], init)
+    plan, _ = compile_model(pb.Model(g).serialize())
+    assert fns(plan) == ["fused_quantized_linear"] and plan["statements"][0]["args"][-1] == {"bool": True}
+    g.node, g.output = nodes[:6], [pb.ValueInfo("lin", pb.FLOAT, [5, n])]
+    plan, _ = compile_model(pb.Model(g).serialize())
+    assert fns(plan) == ["fused_quantized_linear"] and plan["statements"][0]["args"][-1] == {"bool": False}
+    # an intermediate with a second reader blocks the fusion (the reference does not check this)
+    g.node = nodes[:6] + [pb.Node("Add", ["lin", "dq"], ["y2"])]
+    g.output = [pb.ValueInfo("y2", pb.FLOAT, [5, n])]
+    plan, _ = compile_model(pb.Model(g).serialize())
+    assert "fused_quantized_linear" not in fns(plan) and "dynamic_quantize_linear" in fns(plan) and "mat_mul_integer" in fns(plan)
+    with pytest.raises(CompileError, match="NonMaxSuppression"):
+        compile_model(pb.Model(pb.Graph([pb.Node("NonMaxSuppression", ["x", "x"], ["y"])], [pb.ValueInfo("x", pb.FLOAT, [1])],
+                                        [pb.ValueInfo("y", pb.FLOAT, [1])])).serialize())
+
+
+def test_host_shape_arithmetic():
+    x = np.arange(10)
+    assert hostops.slice_(x, [1], [8], [0], [2]).tolist() == [1, 3, 5, 7]
+    assert hostops.slice_(x, [-1], [-(2 ** 63)], [0], [-1]).tolist() == x[::-1].tolist()
+    assert hostops.slice_(x, [-3], [2 ** 63 - 1]).tolist() == [7, 8, 9]
+    assert hostops.evaluate("Gather", [np.array([4, 5, 6]), np.array(-1)], {}) [0] == 6
+    assert hostops.evaluate("Div", [np.array([7, -7]), np.array([2, 2])], {})[0].tolist() == [3, -3]      # truncating, as Rust
+    assert hostops.evaluate("Unsqueeze", [np.array(5), np.array([0])], {})[0].tolist() == [5]
+    assert hostops.evaluate("Reshape", [np.arange(6).reshape(2, 3), np.array([0, -1])], {})[0].shape == (2, 3)
+    assert hostops.evaluate("Softmax", [x], {}) is None
+
+
+# --------------------------------------------------------------------------------------------------- on the device
+def run_plan(ctx, plan, blob, inputs):
+    from lele_amd.plan import Runner, load_weights_bin
+    plan = json.loads(json.dumps(plan))  # plans are plain JSON
+    r = Runner(plan, load_weights_bin(plan, blob), ctx)
+    return r, r.run(inputs)
+
+
+def close(got, want, tol=1e-4):
+    want = np.asarray(want)
+    return got.shape == want.shape and np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.gpu
+def test_compiled_toy_matches_torch_and_replays_as_graph(ctx):
+    t = Toy()
+    x = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(1))
+    want = t(x).detach().numpy()
+    for opset in (13, 17):
+        plan, blob = compile_model(export(t, (x,), opset=opset))
+        xbuf = ctx.buf()
+        xd = xbuf.upload(x.numpy())
+        from lele_amd.tensor import TensorView
+        r, outs = run_plan(ctx, plan, blob, {"x": TensorView(xd)})
+        assert close(outs[0].numpy(), want), opset
+    # recorded once, replayed: same bits as the eager run
+    eager = outs[0].numpy().copy()
+    ctx.sync()
+    ctx.graph_begin()
+    outs = r.run({"x": TensorView(xd)})
+    g = ctx.graph_end()
+    obuf = r.ws[[st for st in r.plan["statements"] if st["out"] == r.plan["outputs"]][0]["slots"][0]]
+    xbuf.upload(np.zeros((2, 3, 16, 16), np.float32))
+    g.launch()
+    ctx.sync()
+    assert not np.array_equal(obuf.to_numpy(eager.shape), eager)  # different input, same graph
+    xbuf.upload(x.numpy())
+    g.launch()
+    ctx.sync()
+    assert np.array_equal(obuf.to_numpy(eager.shape), eager)
+
+
+class Seq(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.conv = torch.nn.Conv1d(8, 16, 3, padding=1)
+        self.lstm = torch.nn.LSTM(16, 32)
+        self.gru = torch.nn.GRU(32, 16)
+        self.out = torch.nn.Linear(16, 5)
+
+    def forward(self, x):                      # x: [1, 8, T] with T dynamic
+        y = torch.tanh(self.conv(x))           # [1, 16, T]
+        y = y.permute(2, 0, 1)                 # [T, 1, 16]
+        y, _ = self.lstm(y)
+        y, _ = self.gru(y)
+        y = y.reshape(-1, y.shape[-1])[1:]     # drop the first frame: Slice with run-time shape arithmetic
+        z = self.out(y)
+        return torch.cat([z, z * 2.0], dim=0).transpose(0, 1)
+
+
+@pytest.mark.gpu
+def test_compiled_sequence_model_dynamic_length(ctx):
+    from lele_amd.tensor import TensorView
+    s = Seq()
+    data = export(s, (torch.randn(1, 8, 12),), opset=17, dynamic_axes={"x": {2: "t"}})
+    plan, blob = compile_model(data)
+    assert "lstm" in fns(plan) and "gru" in fns(plan) and any(f.startswith("host:") for f in fns(plan))
+    from lele_amd.plan import Runner, load_weights_bin
+    r = Runner(plan, load_weights_bin(plan, blob), ctx)
+    for T in (12, 7, 31):
+        x = torch.randn(1, 8, T, generator=torch.Generator().manual_seed(T))
+        want = s(x).detach().numpy()
+        got = r.run({"x": TensorView(ctx.buf().upload(x.numpy()))})[0].numpy()
+        assert close(got, want), T
+
+
+@pytest.mark.gpu
+def test_compiled_quantised_linear_matches_oracle(ctx):
+    from lele_amd.tensor import TensorView
+    from oracle import pyoracle as O
+    rng = np.random.default_rng(0)
+    m, k, n = 37, 64, 48
+    w = rng.integers(0, 256, (k, n)).astype(np.uint8)
+    ws, b = (rng.random(n) * 0.01 + 0.002).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+    init = [pb.Tensor("w", w), pb.Tensor("ws", ws), pb.Tensor("wz", np.array(128, np.uint8)), pb.Tensor("b", b)]
+    nodes = [pb.Node("DynamicQuantizeLinear", ["x"], ["q", "s", "z"]), pb.Node("Mul", ["s", "ws"], ["cs"]),
+             pb.Node("MatMulInteger", ["q", "w", "z", "wz"], ["mm"]), pb.Node("Cast", ["mm"], ["mmf"], to=1),
+             pb.Node("Mul", ["mmf", "cs"], ["dq"]), pb.Node("Add", ["dq", "b"], ["lin"]), pb.Node("Relu", ["lin"], ["y"])]
+    g = pb.Graph(nodes, [pb.ValueInfo("x", pb.FLOAT, [m, k])], [pb.ValueInfo("y", pb.FLOAT, [m, n])], init)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    want = O.fused_quantized_linear(x, w.astype(np.float32), ws, np.array([128.0], np.float32), b, True)
+    plan, blob = compile_model(pb.Model(g).serialize())
+    _, outs = run_plan(ctx, plan, blob, {"x": TensorView(ctx.buf().upload(x))})
+    assert np.array_equal(outs[0].numpy(), want)       # the fused path is bit-exact with the oracle (test_quant.py)
+    # the same graph with the fusion blocked runs node by node: DynamicQuantizeLinear, MatMulInteger, ... -- same value class
+    g.node = nodes[:6] + [pb.Node("Relu", ["lin"], ["y"]), pb.Node("Identity", ["dq"], ["aux"])]
+    g.output = [pb.ValueInfo("y", pb.FLOAT, [m, n]), pb.ValueInfo("aux", pb.FLOAT, [m, n])]
+    plan, blob = compile_model(pb.Model(g).serialize())
+    assert "fused_quantized_linear" not in fns(plan)
+    _, outs = run_plan(ctx, plan, blob, {"x": TensorView(ctx.buf().upload(x))})
+    assert close(outs[0].numpy(), want, 1e-5)

@@ -225,138 +225,7 @@ def synth_weights(plan, consts, seed=1234):
     return out
 
 
-def load_weights_bin(plan, path):
-    """decode the views of a real lele `<model>_weights.bin` (raw little-endian tensors at recorded byte offsets,
-    src/compiler/mod.rs:1135-1233): weight_f32 -> f32, weight_i64 -> i64, weight_i64_f32 -> i64 values as f32,
-    weight_i32 / weight_i32_i64 -> i32 (as i64)"""
-    data = open(path, "rb").read()
-    out = {}
-    for off, (kind, ln, shape) in plan["weights"].items():
-        off = int(off)
-        raw = data[off:off + ln]
-        if kind == "weight_f32":
-            a = np.frombuffer(raw, "<f4")
-        elif kind in ("weight_i64", "weight_i64_f32"):
-            a = np.frombuffer(raw, "<i8")
-            a = a.astype(np.float32) if kind.endswith("_f32") else a.astype(np.int64)
-        elif kind in ("weight_i32", "weight_i32_i64"):
-            a = np.frombuffer(raw, "<i4").astype(np.int64)
-        else:
-            raise SystemExit("weights view kind %r is not handled yet" % kind)
-        out[off] = np.array(a).reshape(shape if shape else ())
-    return out
-
-
-class Runner:
-    def __init__(self, plan, weights, ctx):
-        import lele_amd
-        from lele_amd import kernels as K
-        from lele_amd._lib import Weight
-        self.plan, self.K, self.ctx = plan, K, ctx
-        self.W = {off: (Weight(a) if a.dtype != np.int64 else a) for off, a in weights.items()}
-        self.raw = weights
-        self.ws = {s: ctx.buf() for s in plan["slots"]}
-        self.extra = {}
-        self.calls = 0
-        self.profile = None
-        self.stmt_index = 0
-
-    def val(self, n, env):
-        K = self.K
-        if "ref" in n:
-            return env[n["ref"]]
-        if "refs" in n:
-            return [env[r] for r in n["refs"]]
-        if "weight" in n:
-            w = self.W[n["weight"][1]]
-            return w
-        if "weight_scalar" in n:
-            return int(np.asarray(self.raw[n["weight_scalar"][1]]).reshape(-1)[0])
-        if "weight_list" in n:
-            a = np.asarray(self.raw[n["weight_list"][1]]).reshape(-1)
-            return [float(v) for v in a] if a.dtype == np.float32 else [int(v) for v in a]
-        if "some" in n:
-            return self.val(n["some"], env)
-        if "none" in n:
-            return None
-        if "list" in n:
-            return [self.val(v, env) for v in n["list"]]
-        for k in ("int", "float", "bool", "str"):
-            if k in n:
-                return n[k]
-        raise ValueError(n)
-
-    def call(self, f, fn, pos, bufs, key=None):
-        ctx = self.ctx
-        if fn == "split_owned":  # owned results: one persistent device buffer per output of this statement
-            outs = self.extra.setdefault(("split", key), [ctx.buf() for _ in pos[2]])
-            return list(f(pos[0], pos[1], pos[2], outputs=outs, ctx=ctx))
-        if fn == "topk":
-            return f(pos[0], pos[1], pos[2], pos[3], pos[4], out_values=bufs[0], out_indices=bufs[1], ctx=ctx)
-        if fn in ("reshape", "flatten", "unsqueeze", "squeeze", "identity"):
-            return f(*pos)
-        return f(*pos, out=bufs[0], ctx=ctx) if bufs else f(*pos, ctx=ctx)
-
-    def run(self, inputs):
-        K, ctx = self.K, self.ctx
-        env = dict(inputs)
-        for self.stmt_index, st in enumerate(self.plan["statements"]):
-            op = st["op"]
-            if op == "ints":
-                env[st["out"][0]] = st["value"]
-            elif op == "newbuf":
-                self.extra.setdefault(st["out"][0], ctx.buf())
-                env[st["out"][0]] = self.extra[st["out"][0]]
-            elif op == "swap_remove":  # Vec::swap_remove: take element i, move the last element into its place
-                lst = env[st["list"]]
-                i = st["index"]
-                env[st["out"][0]] = lst[i]
-                lst[i] = lst[-1]
-                lst.pop()
-            elif op == "alias":
-                env[st["out"][0]] = env[st["src"]]
-            else:
-                fn, args = st["fn"], st["args"]
-                pos, kw = [], {}
-                bufs = []
-                for a in args:
-                    if "slot" in a:
-                        bufs.append(self.ws[a["slot"]])
-                    elif "buf" in a:
-                        bufs.append(env[a["buf"]])
-                    else:
-                        pos.append(self.val(a, env))
-                f = getattr(K, fn)
-                self.calls += 1
-                try:
-                    t0 = time.perf_counter() if self.profile is not None else 0.0
-                    res = self.call(f, fn, pos, bufs, key=st["out"][0] + str(self.stmt_index))
-                    if self.profile is not None:
-                        ctx.sync()
-                        self.profile[fn] = self.profile.get(fn, 0.0) + time.perf_counter() - t0
-                except Exception as e:  # noqa: BLE001
-                    shp = [getattr(p, "shape", p) if not isinstance(p, list) else [getattr(q, "shape", q) for q in p] for p in pos]
-                    raise RuntimeError("statement %s = %s(...) failed with %s; argument shapes/values: %s" % (st["out"], fn, e, shp))
-                if len(st["out"]) == 1:
-                    env[st["out"][0]] = res
-                else:
-                    for name, r in zip(st["out"], res):
-                        env[name] = r
-                continue
-                if fn == "split_owned":
-                    res = list(f(pos[0], pos[1], pos[2], ctx=ctx))
-                elif fn == "topk":
-                    res = f(pos[0], pos[1], pos[2], pos[3], pos[4], ctx=ctx)
-                elif fn in ("reshape", "flatten", "unsqueeze", "squeeze", "identity"):
-                    res = f(*pos)
-                else:
-                    res = f(*pos, out=bufs[0], ctx=ctx) if bufs else f(*pos, ctx=ctx)
-                if len(st["out"]) == 1:
-                    env[st["out"][0]] = res
-                else:
-                    for name, r in zip(st["out"], res):
-                        env[name] = r
-        return [env[o] for o in self.plan["outputs"]]
+from lele_amd.plan import Runner, load_weights_bin  # noqa: E402  (the runner is shared with lele_amd.compiler plans)
 
 
 # YOLO26n-seg integer constants read from weights.bin (inferred from the graph: see --help); offset -> value
