@@ -144,7 +144,9 @@ class Lowering:
         key = (name, as_f32)
         if key not in self.weight_cache:
             arr, dt = self.consts[name], self.const_dtype[name]
-            if as_f32 and dt != pb.FLOAT:  # an integer constant meeting f32 arithmetic: convert once at compile time
+            # an i64 / i32 / f64 constant meeting f32 arithmetic is converted once, here; u8 / i8 / f16 weights stay as they
+            # are in the file and are widened by the loader, as lele's weight_u8 / weight_i8 / weight_f16 accessors do
+            if as_f32 and dt in (pb.INT64, pb.INT32, pb.DOUBLE, pb.BOOL):
                 arr, dt = arr.astype(np.float32), pb.FLOAT
             self.weight_cache[key] = {"weight": self.packer.add(arr, dt)}
         return self.weight_cache[key]
@@ -383,10 +385,12 @@ class Lowering:
             fn = {"ReduceMean": "reduce_mean", "ReduceSum": "reduce_sum", "ReduceMax": "reduce_max", "ReduceL2": "reduce_l2"}[op]
             return self.emit(O, fn, [T(I[0]), self.ints(node, 1, "axes", at), {"bool": bool(at.get("keepdims", 1))}])
         if op == "Clip":
-            def bound(i, key):
+            def bound(i, key):  # lele::kernels::clip reads the bounds on the host (math.rs:1984): pass literals
                 if len(I) > i and I[i]:
+                    if I[i] in self.consts:
+                        return {"array": [float(np.asarray(self.consts[I[i]]).reshape(-1)[0])], "dtype": "f32"}
                     return self.tensor(I[i])
-                return {"weight": self.packer.add(np.array([at[key]], np.float32), pb.FLOAT)} if key in at else {"none": 1}
+                return {"array": [float(at[key])], "dtype": "f32"} if key in at else {"none": 1}
             return self.emit(O, "clip", [T(I[0]), bound(1, "min"), bound(2, "max")])
         if op == "Cast":
             to = at.get("to", pb.FLOAT)
@@ -414,7 +418,9 @@ class Lowering:
         while k < len(nodes):
             n = nodes[k]
             ins = [i for i in n.input if i]
-            host_ready = all(i in self.consts or self.place.get(i) == "host" for i in ins)
+            # integer / tiny-float side arithmetic stays on the host; a float table (an embedding) is device data
+            host_ready = all((i in self.consts and (self.consts[i].dtype.kind in "iub" or self.consts[i].size <= 16))
+                             or self.place.get(i) == "host" for i in ins)
             if n.op_type in ("Shape", "Size") or (host_ready and n.op_type in HOST_OPS):
                 self.emit_host(n, _attrs(n))
                 k += 1

@@ -258,3 +258,80 @@ def test_compiled_quantised_linear_matches_oracle(ctx):
     assert "fused_quantized_linear" not in fns(plan)
     _, outs = run_plan(ctx, plan, blob, {"x": TensorView(ctx.buf().upload(x))})
     assert close(outs[0].numpy(), want, 1e-5)
+
+
+class Vision(torch.nn.Module):
+    """YOLO-flavoured: conv+SiLU stem, split / concat bottleneck, max-pool pyramid, nearest x2 up-sampling, transposed conv"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.stem = torch.nn.Conv2d(3, 16, 3, stride=2, padding=1)
+        self.a = torch.nn.Conv2d(8, 8, 3, padding=1)
+        self.dw = torch.nn.Conv2d(16, 16, 3, padding=1, groups=16)
+        self.bn = torch.nn.BatchNorm2d(16)
+        self.pool = torch.nn.MaxPool2d(5, 1, 2)
+        self.fuse = torch.nn.Conv2d(48, 16, 1)
+        self.up = torch.nn.Upsample(scale_factor=2, mode="nearest")
+        self.ct = torch.nn.ConvTranspose2d(16, 8, 2, stride=2)
+        self.head = torch.nn.Conv2d(8, 4, 1)
+        with torch.no_grad():
+            self.bn.running_mean.uniform_(-0.2, 0.2)
+            self.bn.running_var.uniform_(0.5, 1.5)
+
+    def forward(self, x):
+        y = torch.nn.functional.silu(self.stem(x))
+        p, q = torch.split(y, 8, dim=1)
+        y = torch.cat([p, torch.relu(self.a(q)) + q], dim=1)
+        y = torch.nn.functional.hardtanh(self.bn(self.dw(y)), 0.0, 6.0)
+        y = self.fuse(torch.cat([y, self.pool(y), self.pool(self.pool(y))], dim=1))
+        y = self.up(y)[:, :, 1:-1, ::2]
+        y = torch.nn.functional.pad(y, (1, 1, 0, 2))
+        y = torch.sigmoid(self.head(self.ct(y)))
+        return y, y.mean(dim=(2, 3))
+
+
+class Attention(torch.nn.Module):
+    """SenseVoice-flavoured block: LayerNorm, fused QKV, head split, scaled dot-product attention, GELU feed-forward, embedding"""
+
+    def __init__(self, d=32, heads=4):
+        super().__init__()
+        torch.manual_seed(9)
+        self.d, self.h = d, heads
+        self.emb = torch.nn.Embedding(10, d)
+        self.ln1, self.ln2 = torch.nn.LayerNorm(d), torch.nn.LayerNorm(d)
+        self.qkv, self.proj = torch.nn.Linear(d, 3 * d), torch.nn.Linear(d, d)
+        self.f1, self.f2 = torch.nn.Linear(d, 4 * d), torch.nn.Linear(4 * d, d)
+
+    def forward(self, x, ids):                                       # x: [B, T, d], ids: [B, 2] int64
+        x = torch.cat([self.emb(ids), x], dim=1)
+        b, t, _ = x.shape
+        q, k, v = self.qkv(self.ln1(x)).chunk(3, dim=-1)
+        sp = lambda z: z.reshape(b, t, self.h, self.d // self.h).transpose(1, 2)  # noqa: E731
+        att = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / (self.d // self.h) ** 0.5, dim=-1) @ sp(v)
+        x = x + self.proj(att.transpose(1, 2).reshape(b, t, self.d))
+        x = x + self.f2(torch.nn.functional.gelu(self.f1(self.ln2(x))))
+        return torch.where(x > 0, x, x * 0.1).pow(2.0).sqrt()
+
+
+@pytest.mark.gpu
+def test_compiled_vision_and_attention_blocks(ctx):
+    from lele_amd.tensor import TensorView
+    v = Vision().eval()
+    x = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(2))
+    plan, blob = compile_model(export(v, (x,), opset=13, output_names=("y", "m")))
+    f = fns(plan)
+    for want_fn in ("conv2d_silu", "conv2d_fused", "split", "concat", "max_pool2d", "resize_nearest", "conv_transpose", "slice", "pad", "clip"):
+        assert want_fn in f, (want_fn, f)
+    _, outs = run_plan(ctx, plan, blob, {"x": TensorView(ctx.buf().upload(x.numpy()))})
+    for got, want in zip(outs, v(x)):
+        assert close(got.numpy(), want.detach().numpy()), f
+    a = Attention().eval()
+    xa = torch.randn(2, 9, 32, generator=torch.Generator().manual_seed(4))
+    ids = torch.tensor([[1, 7], [3, 3]])
+    for opset in (13, 17):
+        plan, blob = compile_model(export(a, (xa, ids), opset=opset, input_names=("x", "ids")))
+        f = fns(plan)
+        assert f.count("layer_norm") == 2 and "softmax" in f and "gather" in f and "erf" in f, f
+        _, outs = run_plan(ctx, plan, blob, {"x": TensorView(ctx.buf().upload(xa.numpy())), "ids": ids.numpy()})
+        assert close(outs[0].numpy(), a(xa, ids).detach().numpy()), opset

@@ -37,6 +37,19 @@ class QLinear:
         self.zero = Weight(np.array([128.0], np.float32))
         self.bias = Weight((rng.standard_normal(n) * 0.02).astype(np.float32))
 
+    def onnx(self, g, x, out, relu, tag):
+        """the six-node form ONNX Runtime's dynamic quantisation emits, which lele's compiler fuses (patterns.rs:121-432)"""
+        from lele_amd.compiler import onnx_pb as pb
+        n = lambda s: "%s_%s" % (tag, s)  # noqa: E731
+        g.initializer += [pb.Tensor(n("w"), self.w.arr.astype(np.uint8)), pb.Tensor(n("ws"), self.scale.arr),
+                          pb.Tensor(n("wz"), np.array(int(self.zero.arr[0]), np.uint8)), pb.Tensor(n("b"), self.bias.arr)]
+        lin = n("lin") if relu else out
+        g.node += [pb.Node("DynamicQuantizeLinear", [x], [n("q"), n("s"), n("z")]), pb.Node("Mul", [n("s"), n("ws")], [n("cs")]),
+                   pb.Node("MatMulInteger", [n("q"), n("w"), n("z"), n("wz")], [n("mm")]), pb.Node("Cast", [n("mm")], [n("mmf")], to=1),
+                   pb.Node("Mul", [n("mmf"), n("cs")], [n("dq")]), pb.Node("Add", [n("dq"), n("b")], [lin])]
+        if relu:
+            g.node.append(pb.Node("Relu", [lin], [out]))
+
 
 class Layer:
     def __init__(self, rng, d_in, Weight):
@@ -111,6 +124,51 @@ class Encoder:
         return self.ql(xn, self.ctc, False, 2)
 
 
+def encoder_onnx(enc, batch):
+    """The same assumed topology as an ONNX model (bytes), built from the Encoder's weights: what a SenseVoice export
+    with dynamically quantised linears looks like to lele's compiler.  `lele_amd.compiler` must turn it back into the
+    call sequence of Encoder.forward."""
+    from lele_amd.compiler import onnx_pb as pb
+    g = pb.Graph([], [pb.ValueInfo("feats", pb.FLOAT, [batch, "t", 560])], [pb.ValueInfo("logits", pb.FLOAT, [batch, "t4", VOCAB])])
+    I = g.initializer
+    I += [pb.Tensor("prompt", enc.prompt.arr), pb.Tensor("att_scale", enc.scale.arr), pb.Tensor("shape_heads", np.array([0, 0, HEADS, DH], np.int64)),
+          pb.Tensor("shape_merge", np.array([0, 0, D], np.int64)), pb.Tensor("split_qkv", np.array([D, D, D], np.int64))]
+    if batch > 1:
+        I.append(pb.Tensor("prompt_shape", np.array([batch, 4, 560], np.int64)))
+        g.node.append(pb.Node("Expand", ["prompt", "prompt_shape"], ["prompt_b"]))
+    g.node.append(pb.Node("Concat", ["prompt_b" if batch > 1 else "prompt", "feats"], ["x0"], axis=1))
+    x = "x0"
+    for i, L in enumerate(enc.layers):
+        t = lambda s, i=i: "l%d_%s" % (i, s)  # noqa: E731
+        I += [pb.Tensor(t("ln1_g"), L.ln1[0].arr), pb.Tensor(t("ln1_b"), L.ln1[1].arr), pb.Tensor(t("ln2_g"), L.ln2[0].arr),
+              pb.Tensor(t("ln2_b"), L.ln2[1].arr), pb.Tensor(t("fsmn"), L.fsmn.arr)]
+        g.node.append(pb.Node("LayerNormalization", [x, t("ln1_g"), t("ln1_b")], [t("xn")], axis=-1, epsilon=1e-5))
+        L.qkv.onnx(g, t("xn"), t("qkv"), False, t("qkv"))
+        g.node += [pb.Node("Split", [t("qkv"), "split_qkv"], [t("q"), t("k"), t("v")], axis=2),
+                   pb.Node("Transpose", [t("v")], [t("vt")], perm=[0, 2, 1]),
+                   pb.Node("Conv", [t("vt"), t("fsmn")], [t("memt")], group=D, pads=[FSMN_K // 2, FSMN_K // 2], kernel_shape=[FSMN_K]),
+                   pb.Node("Transpose", [t("memt")], [t("mem0")], perm=[0, 2, 1]), pb.Node("Add", [t("mem0"), t("v")], [t("mem")])]
+        for nm, perm in (("q", [0, 2, 1, 3]), ("k", [0, 2, 3, 1]), ("v", [0, 2, 1, 3])):
+            g.node += [pb.Node("Reshape", [t(nm), "shape_heads"], [t(nm + "r")]), pb.Node("Transpose", [t(nm + "r")], [t(nm + "h")], perm=perm)]
+        g.node += [pb.Node("MatMul", [t("qh"), t("kh")], [t("sc")]), pb.Node("Mul", [t("sc"), "att_scale"], [t("scs")]),
+                   pb.Node("Softmax", [t("scs")], [t("pr")], axis=-1), pb.Node("MatMul", [t("pr"), t("vh")], [t("av")]),
+                   pb.Node("Transpose", [t("av")], [t("avt")], perm=[0, 2, 1, 3]), pb.Node("Reshape", [t("avt"), "shape_merge"], [t("avm")])]
+        L.out.onnx(g, t("avm"), t("att"), False, t("out"))
+        if L.d_in == D:
+            g.node += [pb.Node("Add", [t("att"), t("mem")], [t("am")]), pb.Node("Add", [t("am"), x], [t("x1")])]
+        else:
+            g.node.append(pb.Node("Add", [t("att"), t("mem")], [t("x1")]))
+        g.node.append(pb.Node("LayerNormalization", [t("x1"), t("ln2_g"), t("ln2_b")], [t("x1n")], axis=-1, epsilon=1e-5))
+        L.ffn1.onnx(g, t("x1n"), t("h1"), True, t("ffn1"))
+        L.ffn2.onnx(g, t("h1"), t("h2"), False, t("ffn2"))
+        g.node.append(pb.Node("Add", [t("x1"), t("h2")], [t("x2")]))
+        x = t("x2")
+    I += [pb.Tensor("lnf_g", enc.ln_out[0].arr), pb.Tensor("lnf_b", enc.ln_out[1].arr)]
+    g.node.append(pb.Node("LayerNormalization", [x, "lnf_g", "lnf_b"], ["xf"], axis=-1, epsilon=1e-5))
+    enc.ctc.onnx(g, "xf", "logits", False, "ctc")
+    return pb.Model(g, opset=17).serialize()
+
+
 def synth_pcm(batch, n, seed0=0):
     import bench
     return bench.synth_batch(batch, n, seed0)
@@ -123,6 +181,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--configs", default="c3,c4")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph leg (rocprofv3 cannot trace captures)")
+    ap.add_argument("--via-onnx", action="store_true", help="also build the model as ONNX, compile it with lele_amd.compiler and run the plan")
     args = ap.parse_args()
     import lele_amd
     from lele_amd import kernels as K
@@ -176,6 +235,40 @@ def main():
             graph.launch()
             ctx.sync()
             t_graph.append(time.perf_counter() - t0)
+        onnx_rec = {}
+        if args.via_onnx:  # ONNX bytes -> compiled plan -> the same call sequence; logits must be identical
+            from lele_amd.compiler import compile_model
+            from lele_amd.plan import Runner, load_weights_bin
+            t0 = time.perf_counter()
+            data = encoder_onnx(enc, batch)
+            plan, blob = compile_model(data, "sensevoice_shaped")
+            t_compile = time.perf_counter() - t0
+            r = Runner(plan, load_weights_bin(plan, blob), ctx)
+            want = enc.forward(feats).numpy()
+            got = r.run({"feats": feats})[0]
+            same = bool(np.array_equal(got.numpy(), want))
+            ctx.sync()
+            ctx.graph_begin()
+            r.run({"feats": feats})
+            g2 = ctx.graph_end()
+            g2.launch()
+            ctx.sync()
+            tg = []
+            for _ in range(args.runs):
+                ctx.sync()
+                t0 = time.perf_counter()
+                g2.launch()
+                ctx.sync()
+                tg.append(time.perf_counter() - t0)
+            fn_count = {}
+            for st in plan["statements"]:
+                if st["op"] == "call":
+                    fn_count[st["fn"]] = fn_count.get(st["fn"], 0) + 1
+            onnx_rec = {"onnx_bytes": len(data), "onnx_nodes": sum(1 for _ in __import__("lele_amd.compiler.onnx_pb", fromlist=["x"]).load(data).graph.node),
+                        "plan_statements": len(plan["statements"]), "plan_slots": len(plan["slots"]), "weights_bin_bytes": len(blob),
+                        "compile_s": round(t_compile, 2), "plan_calls": fn_count, "compiled_logits_identical": same,
+                        "compiled_graph_ms": round(1e3 * float(np.mean(tg)), 3)}
+            logits = enc.forward(feats)
         audio = batch * seconds
         lg = logits.numpy()
         rec = {"config": name, "batch": batch, "seconds_per_utterance": seconds, "layers": args.layers,
@@ -185,6 +278,7 @@ def main():
                "model_graph_ms": round(1e3 * float(np.mean(t_graph)), 3),
                "rtf_model_graph": round(float(np.mean(t_graph)) / audio, 6),
                "note": "assumed topology, synthetic weights, every node a separate C-ABI call issued from Python"}
+        rec.update(onnx_rec)
         print(json.dumps(rec), flush=True)
         results.append(rec)
     if args.out:
