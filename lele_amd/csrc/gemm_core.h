@@ -150,7 +150,7 @@ __device__ __forceinline__ void tile_coords(unsigned& tx, unsigned& ty, unsigned
 }
 
 // ---------------------------------------------------------------------------------------------- kernel
-template <int BM, int BN, int WM, int WN, int BK, class AL, class BL, class EPI, int OCC = 1, int RS = 2>
+template <int BM, int BN, int WM, int WN, int BK, class AL, class BL, class EPI, int OCC = 1>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC))) void gemm_f32_mfma_kernel(AL al, BL bl, EPI epi, int M, int N, int K) {
     constexpr int NT = WM * WN * 64;
     constexpr int PITCH = BK + 4;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
     const int m0 = ty * BM, n0 = tx * BN, batch = tz;
     const int hv = lane >> 5, l31 = lane & 31;
 
-    float4 ra[RS][ASLOTS], rb[RS][BSLOTS];  // RS = 2 register stages: a tile's loads have two K steps to land
+    float4 ra[ASLOTS], rb[BSLOTS];
     // per staging slot, once: the loader's k-invariant row state, the k offset of the slot's chunk (made wave-uniform
     // where the slot -> (row, chunk) map allows it) and the LDS address the chunk is parked at
     typename AL::Row arow[ASLOTS];
@@ -194,21 +194,21 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
         bkq[i] = 4 * kq;
         blds[i] = row * PITCH + 4 * kq;
     }
-    auto gload = [&](int k0, int st) {
+    auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < ASLOTS; ++i)
-            if (tid + i * NT < BM * KQ) ra[st][i] = al.get4(arow[i], k0 + akq[i]);
+            if (tid + i * NT < BM * KQ) ra[i] = al.get4(arow[i], k0 + akq[i]);
 #pragma unroll
         for (int i = 0; i < BSLOTS; ++i)
-            if (tid + i * NT < BN * KQ) rb[st][i] = bl.get4(brow[i], k0 + bkq[i]);
+            if (tid + i * NT < BN * KQ) rb[i] = bl.get4(brow[i], k0 + bkq[i]);
     };
-    auto lstore = [&](int buf, int st) {
+    auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < ASLOTS; ++i)
-            if (tid + i * NT < BM * KQ) *reinterpret_cast<float4*>(&As[buf][alds[i]]) = ra[st][i];
+            if (tid + i * NT < BM * KQ) *reinterpret_cast<float4*>(&As[buf][alds[i]]) = ra[i];
 #pragma unroll
         for (int i = 0; i < BSLOTS; ++i)
-            if (tid + i * NT < BN * KQ) *reinterpret_cast<float4*>(&Bs[buf][blds[i]]) = rb[st][i];
+            if (tid + i * NT < BN * KQ) *reinterpret_cast<float4*>(&Bs[buf][blds[i]]) = rb[i];
     };
 
     f32x16 acc[TMT][TNT];
@@ -247,34 +247,17 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
     };
-    if constexpr (RS == 2) {
-        // tile kt is computed from LDS[kt & 1] while tile kt+1 waits in register stage (kt+1) & 1 and tile kt+2 is requested
-        gload(0, 0);
-        if (nk > 1) gload(BK, 1);
-        lstore(0, 0);
+    // tile kt+1 is in flight (global -> registers) during the MFMAs of tile kt.  (A second register stage -- loads two K
+    // steps ahead -- was measured: no gain on long K loops, 3-12 % slower on the short ones.)
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        compute(cur);
+        if (kt + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
-        for (int kt = 0; kt < nk; kt += 2) {
-            if (kt + 2 < nk) gload((kt + 2) * BK, 0);
-            compute(0);
-            if (kt + 1 < nk) lstore(1, 1);
-            __syncthreads();
-            if (kt + 1 >= nk) break;
-            if (kt + 3 < nk) gload((kt + 3) * BK, 1);
-            compute(1);
-            if (kt + 2 < nk) lstore(0, 0);
-            __syncthreads();
-        }
-    } else {  // one register stage (the 256x128 tile has no registers to spare): tile kt+1 is in flight during tile kt
-        gload(0, 0);
-        lstore(0, 0);
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) gload((kt + 1) * BK, 0);
-            compute(cur);
-            if (kt + 1 < nk) lstore(cur ^ 1, 0);
-            __syncthreads();
-        }
     }
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -354,10 +337,10 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(AL al, BL bl, EPI e
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK, int OCC = 1, int RS = 2, class AL, class BL, class EPI>
+template <int BM, int BN, int WM, int WN, int BK, int OCC = 1, class AL, class BL, class EPI>
 inline void launch_tile(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int batch) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-    auto kern = gemm_f32_mfma_kernel<BM, BN, WM, WN, BK, AL, BL, EPI, OCC, RS>;
+    auto kern = gemm_f32_mfma_kernel<BM, BN, WM, WN, BK, AL, BL, EPI, OCC>;
     if (lds > 64 * 1024) {  // above the default per-block limit: opt in once per instantiation
         static bool done = false;
         if (!done) {
@@ -382,7 +365,7 @@ inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, i
             case 1: launch_tile<64, 256, 2, 4, 16, 4>(st, al, bl, epi, M, N, K, batch); return;
             case 2: launch_tile<64, 64, 2, 2, 16>(st, al, bl, epi, M, N, K, batch); return;
             case 3: launch_tile<32, 128, 1, 4, 16>(st, al, bl, epi, M, N, K, batch); return;
-            case 4: launch_tile<256, 128, 4, 2, 16, 4, 1>(st, al, bl, epi, M, N, K, batch); return;
+            case 4: launch_tile<256, 128, 4, 2, 16, 4>(st, al, bl, epi, M, N, K, batch); return;
             case 5: {
                 dim3 grid((N + 31) / 32, (M + 31) / 32, batch);
                 hipLaunchKernelGGL((gemm_f32_small_kernel<AL, BL, EPI>), grid, dim3(256), 0, st, al, bl, epi, M, N, K);
@@ -419,7 +402,7 @@ inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, i
     switch (best) {
         case 0: launch_tile<128, 128, 2, 4, 16, 4>(st, al, bl, epi, M, N, K, batch); break;  // 8 waves of 64x32
         case 1: launch_tile<64, 256, 2, 4, 16, 4>(st, al, bl, epi, M, N, K, batch); break;  // 8 waves of 32x64
-        case 4: launch_tile<256, 128, 4, 2, 16, 4, 1>(st, al, bl, epi, M, N, K, batch); break;  // 8 waves, 61 KB LDS, 2 per CU
+        case 4: launch_tile<256, 128, 4, 2, 16, 4>(st, al, bl, epi, M, N, K, batch); break;  // 8 waves, 61 KB LDS, 2 per CU
         case 2: launch_tile<64, 64, 2, 2, 16>(st, al, bl, epi, M, N, K, batch); break;
         default: launch_tile<32, 128, 1, 4, 16>(st, al, bl, epi, M, N, K, batch); break;
     }
