@@ -61,7 +61,27 @@ def build(force=False, verbose=False):
                 print(out)
     if jobs or force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs)
+    build_runner(force, run)
     return LIB
+
+
+RUNNER = os.path.join(HERE, "lele_run")
+
+
+def build_runner(force=False, run=None):
+    """lele_run: the native plan runner (host/lele_run.cpp + plan_runner.hpp + lele.hpp over the C ABI), plain g++"""
+    host = os.path.join(HERE, "host")
+    deps = [os.path.join(host, f) for f in ("lele_run.cpp", "plan_runner.hpp", "lele.hpp")] + [os.path.join(HERE, "..", "include", "lele_hip.h")]
+    if not force and os.path.exists(RUNNER) and all(os.path.getmtime(d) <= os.path.getmtime(RUNNER) for d in deps) \
+            and os.path.getmtime(LIB) <= os.path.getmtime(RUNNER):
+        return RUNNER
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(HERE, "..", "include"), "-I", host, deps[0], "-L", HERE, "-llele_hip",
+           "-Wl,-rpath,$ORIGIN", "-o", RUNNER]
+    if run is None:
+        subprocess.check_call(cmd)
+    else:
+        run(cmd)
+    return RUNNER
 
 
 if __name__ == "__main__":

@@ -421,6 +421,9 @@ class Lowering:
             # integer / tiny-float side arithmetic stays on the host; a float table (an embedding) is device data
             host_ready = all((i in self.consts and (self.consts[i].dtype.kind in "iub" or self.consts[i].size <= 16))
                              or self.place.get(i) == "host" for i in ins)
+            if n.op_type == "ConstantOfShape":  # a float fill is tensor data (e.g. an RNN's initial state): a device fill
+                v = _attrs(n).get("value")
+                host_ready = host_ready and v is not None and np.asarray(v).dtype.kind in "iub"
             if n.op_type in ("Shape", "Size") or (host_ready and n.op_type in HOST_OPS):
                 self.emit_host(n, _attrs(n))
                 k += 1

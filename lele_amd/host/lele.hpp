@@ -378,6 +378,7 @@ LELE_BINARY(equal, LELE_B_EQUAL)
 LELE_BINARY(less, LELE_B_LESS)
 LELE_BINARY(greater, LELE_B_GREATER)
 LELE_BINARY(prelu, LELE_B_PRELU)
+LELE_BINARY(mod_f32, LELE_B_MOD)
 LELE_BINARY(and_, LELE_B_AND)
 LELE_BINARY(or_, LELE_B_OR)
 #undef LELE_BINARY
@@ -750,6 +751,61 @@ inline TensorView flatten(const TensorView& x, int64_t axis) {
     return x.with_shape({a, b});
 }
 inline TensorView identity(const TensorView& x) { return x; }
+inline TensorView unsqueeze(const TensorView& x, std::vector<int64_t> axes) {  // shape.rs:136-156
+    std::vector<int64_t> s = x.shape;
+    const int64_t rank = (int64_t)s.size() + (int64_t)axes.size();
+    std::sort(axes.begin(), axes.end());
+    for (int64_t a : axes) {
+        const int64_t idx = a < 0 ? a + rank : a;
+        if (idx <= (int64_t)s.size()) s.insert(s.begin() + idx, 1); else s.push_back(1);
+    }
+    return x.with_shape(s);
+}
+inline TensorView squeeze(const TensorView& x, const std::vector<int64_t>* axes) {  // shape.rs:157-185
+    std::vector<int64_t> s;
+    const int64_t nd = (int64_t)x.dim();
+    for (int64_t i = 0; i < nd; ++i) {
+        bool drop = x.shape[(size_t)i] == 1;
+        if (drop && axes) {
+            drop = false;
+            for (int64_t a : *axes) drop = drop || (a < 0 ? a + nd : a) == i;
+        }
+        if (!drop) s.push_back(x.shape[(size_t)i]);
+    }
+    return x.with_shape(s);
+}
+// manipulation.rs:382-587: pads = [begin..., end...] (covering the trailing dims when shorter); mode constant / edge / reflect
+inline TensorView pad(const TensorView& x, const std::vector<int64_t>& pads, const float* constant_value, const std::string& mode,
+                      Buffer& out) {
+    const size_t rank = x.dim();
+    std::vector<int64_t> raw;
+    for (int64_t p : pads) raw.push_back(std::max<int64_t>(0, p));
+    if (raw.size() < rank * 2) {
+        const size_t half = raw.size() / 2, missing = rank - half;
+        std::vector<int64_t> full(rank * 2, 0);
+        for (size_t i = 0; i < half; ++i) {
+            full[missing + i] = raw[i];
+            full[rank + missing + i] = raw[half + i];
+        }
+        raw = full;
+    }
+    const int m = mode == "constant" ? 0 : mode == "edge" ? 1 : mode == "reflect" ? 2 : -1;
+    if (m < 0) throw Error("Pad: unknown mode " + mode);
+    float cv = constant_value ? *constant_value : 0.0f;
+    uint32_t bits;
+    std::memcpy(&bits, &cv, 4);
+    Shape sh;
+    LeleTensor tx = x.c();
+    check(lele_hip_pad(ctx(), &tx, raw.data(), m, bits, out.raw(), sh.dims, &sh.rank));
+    return TensorView::from_device(out, sh.vec(), x.dtype());
+}
+inline TensorView constant_of_shape(const std::vector<int64_t>& shape, float value, Buffer& out) {  // shape.rs:122-135
+    uint32_t bits;
+    std::memcpy(&bits, &value, 4);
+    Shape sh;
+    check(lele_hip_fill(ctx(), shape.data(), (int32_t)shape.size(), LELE_F32, bits, out.raw(), sh.dims, &sh.rank));
+    return TensorView::from_device(out, sh.vec(), LELE_F32);
+}
 
 #undef LELE_RET
 }  // namespace kernels

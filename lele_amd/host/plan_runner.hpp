@@ -1,0 +1,641 @@
+// plan_runner.hpp -- native execution of a compiled plan (lele_amd.compiler output, format "lele_amd.plan/2").
+//
+// The compiled counterpart of lele's generated `forward()`: lele's compiler emits Rust that is then compiled; here the
+// same decisions are data (plan JSON + weights.bin in lele's layout, src/compiler/mod.rs:1381-1505) and this header
+// walks the statement list through the C ABI via lele.hpp -- no Python anywhere on the serving path.  Header-only,
+// C++17, no dependencies beyond lele.hpp.  Mirrors lele_amd/plan.py statement for statement (tests run both on the
+// same plan and compare bits).
+#pragma once
+#include <cctype>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <functional>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "lele.hpp"
+
+namespace lele {
+namespace plan {
+
+// ------------------------------------------------------------------------------------------------ JSON (reader only)
+struct Json {
+    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+    bool b = false, is_int = false;
+    double num = 0.0;
+    int64_t inum = 0;
+    std::string str;
+    std::vector<Json> arr;
+    std::vector<std::pair<std::string, Json>> obj;
+    const Json* find(const std::string& key) const {
+        for (const auto& kv : obj)
+            if (kv.first == key) return &kv.second;
+        return nullptr;
+    }
+    const Json& at(const std::string& key) const {
+        const Json* j = find(key);
+        if (!j) throw Error("plan: missing key '" + key + "'");
+        return *j;
+    }
+    bool has(const std::string& key) const { return find(key) != nullptr; }
+    int64_t as_int() const { return is_int ? inum : (int64_t)num; }
+    double as_num() const { return is_int ? (double)inum : num; }
+};
+
+class JsonParser {
+   public:
+    explicit JsonParser(const std::string& text) : s_(text) {}
+    Json parse() {
+        Json j = value();
+        ws();
+        if (i_ != s_.size()) fail("trailing characters");
+        return j;
+    }
+
+   private:
+    const std::string& s_;
+    size_t i_ = 0;
+    [[noreturn]] void fail(const char* what) const { throw Error(std::string("plan JSON: ") + what + " at byte " + std::to_string(i_)); }
+    void ws() {
+        while (i_ < s_.size() && std::isspace((unsigned char)s_[i_])) ++i_;
+    }
+    Json value() {
+        ws();
+        if (i_ >= s_.size()) fail("unexpected end");
+        const char c = s_[i_];
+        Json j;
+        if (c == '{') {
+            j.kind = Json::Obj;
+            ++i_;
+            ws();
+            if (s_[i_] == '}') return ++i_, j;
+            for (;;) {
+                ws();
+                Json k = string_();
+                ws();
+                if (s_[i_++] != ':') fail("expected ':'");
+                j.obj.emplace_back(k.str, value());
+                ws();
+                if (s_[i_] == ',') { ++i_; continue; }
+                if (s_[i_] == '}') return ++i_, j;
+                fail("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            j.kind = Json::Arr;
+            ++i_;
+            ws();
+            if (s_[i_] == ']') return ++i_, j;
+            for (;;) {
+                j.arr.push_back(value());
+                ws();
+                if (s_[i_] == ',') { ++i_; continue; }
+                if (s_[i_] == ']') return ++i_, j;
+                fail("expected ',' or ']'");
+            }
+        }
+        if (c == '"') return string_();
+        if (s_.compare(i_, 4, "true") == 0) return i_ += 4, j.kind = Json::Bool, j.b = true, j;
+        if (s_.compare(i_, 5, "false") == 0) return i_ += 5, j.kind = Json::Bool, j;
+        if (s_.compare(i_, 4, "null") == 0) return i_ += 4, j;
+        if (s_.compare(i_, 3, "NaN") == 0) return i_ += 3, j.kind = Json::Num, j.num = NAN, j;
+        if (s_.compare(i_, 8, "Infinity") == 0) return i_ += 8, j.kind = Json::Num, j.num = INFINITY, j;
+        if (s_.compare(i_, 9, "-Infinity") == 0) return i_ += 9, j.kind = Json::Num, j.num = -INFINITY, j;
+        // number
+        const size_t b = i_;
+        bool flt = false;
+        if (s_[i_] == '-') ++i_;
+        while (i_ < s_.size() && (std::isdigit((unsigned char)s_[i_]) || s_[i_] == '.' || s_[i_] == 'e' || s_[i_] == 'E' || s_[i_] == '+' || s_[i_] == '-')) {
+            flt = flt || s_[i_] == '.' || s_[i_] == 'e' || s_[i_] == 'E';
+            ++i_;
+        }
+        if (b == i_) fail("unexpected character");
+        const std::string tok = s_.substr(b, i_ - b);
+        j.kind = Json::Num;
+        if (flt) {
+            j.num = std::strtod(tok.c_str(), nullptr);
+        } else {
+            j.is_int = true;
+            j.inum = std::strtoll(tok.c_str(), nullptr, 10);
+            j.num = (double)j.inum;
+        }
+        return j;
+    }
+    Json string_() {
+        if (s_[i_] != '"') fail("expected string");
+        ++i_;
+        Json j;
+        j.kind = Json::Str;
+        while (i_ < s_.size() && s_[i_] != '"') {
+            char c = s_[i_++];
+            if (c == '\\') {
+                const char e = s_[i_++];
+                if (e == 'n') c = '\n';
+                else if (e == 't') c = '\t';
+                else if (e == 'u') {  // plans hold ASCII names; keep the low byte of \uXXXX
+                    c = (char)std::strtol(s_.substr(i_, 4).c_str(), nullptr, 16);
+                    i_ += 4;
+                } else c = e;
+            }
+            j.str.push_back(c);
+        }
+        ++i_;
+        return j;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ values
+// A small host array for the integer / tiny-float side arithmetic (rank <= 1 here: shapes, axes, slice bounds).
+struct HostArr {
+    bool is_int = true;
+    bool scalar = false;  // rank 0
+    std::vector<int64_t> i;
+    std::vector<float> f;
+    size_t size() const { return is_int ? i.size() : f.size(); }
+    double get(size_t k) const { return is_int ? (double)i[k] : (double)f[k]; }
+};
+struct Val {
+    enum Kind { None, Tensor, Host } kind = None;
+    TensorView t;
+    HostArr h;
+    std::shared_ptr<std::vector<char>> keep;  // storage of a host-backed tensor
+};
+
+inline std::vector<int64_t> ints_of(const HostArr& h) {
+    std::vector<int64_t> v;
+    for (size_t k = 0; k < h.size(); ++k) v.push_back(h.is_int ? h.i[k] : (int64_t)h.f[k]);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ host ops (hostops.py)
+inline HostArr host_eval(const std::string& op, const std::vector<const HostArr*>& x, const Json& attrs,
+                         const std::vector<int64_t>* shape_of_first) {
+    auto need = [&](size_t n) {
+        if (x.size() < n) throw Error("host op " + op + ": operand missing");
+    };
+    HostArr r;
+    if (op == "Shape" || op == "Size") {
+        if (!shape_of_first) throw Error("host op " + op + ": no shape");
+        if (op == "Shape") r.i = *shape_of_first;
+        else {
+            int64_t n = 1;
+            for (int64_t d : *shape_of_first) n *= d;
+            r.i = {n};
+            r.scalar = true;
+        }
+        return r;
+    }
+    need(1);
+    const HostArr& a = *x[0];
+    if (op == "Identity") return a;
+    if (op == "Cast") {
+        const int64_t to = attrs.at("to").as_int();
+        r.scalar = a.scalar;
+        if (to == 7 || to == 6 || to == 9) {
+            r.i = ints_of(a);
+        } else {
+            r.is_int = false;
+            for (size_t k = 0; k < a.size(); ++k) r.f.push_back((float)a.get(k));
+        }
+        return r;
+    }
+    if (op == "Unsqueeze" || op == "Squeeze" || op == "Reshape" || op == "Expand" || op == "Transpose") {
+        r = a;  // rank <= 1 arrays: only the scalar / vector distinction can change
+        if (op == "Unsqueeze") r.scalar = false;
+        if (op == "Squeeze" && a.size() == 1) r.scalar = true;
+        if (op == "Reshape" && x.size() > 1 && x[1]) r.scalar = x[1]->size() == 0;
+        if (op == "Expand" && x.size() > 1 && x[1] && x[1]->size() == 1 && a.size() == 1) {
+            const int64_t n = x[1]->i[0];
+            r.scalar = false;
+            if (a.is_int) r.i.assign((size_t)n, a.i[0]); else r.f.assign((size_t)n, a.f[0]);
+        }
+        return r;
+    }
+    if (op == "Concat") {
+        r.is_int = a.is_int;
+        for (const HostArr* p : x) {
+            if (!p) continue;
+            if (p->is_int != r.is_int) throw Error("host Concat: mixed element types");
+            r.i.insert(r.i.end(), p->i.begin(), p->i.end());
+            r.f.insert(r.f.end(), p->f.begin(), p->f.end());
+        }
+        return r;
+    }
+    if (op == "Gather") {
+        need(2);
+        const HostArr& idx = *x[1];
+        r.is_int = a.is_int;
+        r.scalar = idx.scalar;
+        for (size_t k = 0; k < idx.size(); ++k) {
+            int64_t j = idx.i[k];
+            if (j < 0) j += (int64_t)a.size();
+            if (j < 0 || j >= (int64_t)a.size()) throw Error("host Gather: index out of range");
+            if (a.is_int) r.i.push_back(a.i[(size_t)j]); else r.f.push_back(a.f[(size_t)j]);
+        }
+        return r;
+    }
+    if (op == "Slice") {
+        need(3);
+        int64_t st = x[1]->i.at(0), en = x[2]->i.at(0), step = x.size() > 4 && x[4] && x[4]->size() ? x[4]->i[0] : 1;
+        const int64_t d = (int64_t)a.size();
+        if (st < 0) st += d;
+        if (en < 0) en += d;
+        r.is_int = a.is_int;
+        if (step > 0) {
+            st = std::min(std::max<int64_t>(st, 0), d);
+            en = std::min(std::max<int64_t>(en, 0), d);
+            for (int64_t k = st; k < en; k += step) { if (a.is_int) r.i.push_back(a.i[(size_t)k]); else r.f.push_back(a.f[(size_t)k]); }
+        } else {
+            st = std::min(std::max<int64_t>(st, 0), d - 1);
+            en = std::min(std::max<int64_t>(en, -1), d - 1);
+            for (int64_t k = st; k > en; k += step) { if (a.is_int) r.i.push_back(a.i[(size_t)k]); else r.f.push_back(a.f[(size_t)k]); }
+        }
+        return r;
+    }
+    if (op == "Range") {
+        need(3);
+        r.is_int = a.is_int;
+        if (a.is_int) for (int64_t v = a.i[0]; x[2]->i[0] > 0 ? v < x[1]->i[0] : v > x[1]->i[0]; v += x[2]->i[0]) r.i.push_back(v);
+        else for (float v = a.f[0]; x[2]->f[0] > 0 ? v < x[1]->f[0] : v > x[1]->f[0]; v += x[2]->f[0]) r.f.push_back(v);
+        return r;
+    }
+    if (op == "ConstantOfShape") {
+        const std::vector<int64_t> shp = ints_of(a);
+        if (shp.size() > 1) throw Error("host ConstantOfShape: rank > 1 is not supported by the native runner");
+        const double v = attrs.has("value") ? attrs.at("value").as_num() : 0.0;
+        r.is_int = attrs.has("value") && attrs.at("value").is_int;
+        r.scalar = shp.empty();
+        const size_t n = shp.empty() ? 1 : (size_t)shp[0];
+        if (r.is_int) r.i.assign(n, (int64_t)v); else r.f.assign(n, (float)v);
+        return r;
+    }
+    if (op == "Neg" || op == "Not") {
+        r = a;
+        for (auto& v : r.i) v = op == "Neg" ? -v : (v == 0);
+        for (auto& v : r.f) v = op == "Neg" ? -v : (float)(v == 0.0f);
+        return r;
+    }
+    if (op == "Add" || op == "Sub" || op == "Mul" || op == "Div" || op == "Equal" || op == "Less" || op == "Greater" || op == "Max" || op == "Min" || op == "Where") {
+        need(2);
+        const bool where = op == "Where";
+        const HostArr &p = where ? *x[1] : a, &q = where ? *x[2] : *x[1];
+        const size_t n = std::max(std::max(p.size(), q.size()), where ? a.size() : (size_t)0);
+        auto bc = [&](const HostArr& h, size_t k) { return h.get(h.size() == 1 ? 0 : k); };
+        const bool cmp = op == "Equal" || op == "Less" || op == "Greater";
+        r.is_int = cmp || (p.is_int && q.is_int);
+        r.scalar = p.scalar && q.scalar && (!where || a.scalar);
+        for (size_t k = 0; k < n; ++k) {
+            const double u = bc(p, k), v = bc(q, k);
+            double w;
+            if (op == "Add") w = u + v;
+            else if (op == "Sub") w = u - v;
+            else if (op == "Mul") w = u * v;
+            else if (op == "Div") w = r.is_int ? (v == 0 ? 0 : std::trunc(u / v)) : u / v;
+            else if (op == "Equal") w = u == v;
+            else if (op == "Less") w = u < v;
+            else if (op == "Greater") w = u > v;
+            else if (op == "Max") w = std::max(u, v);
+            else if (op == "Min") w = std::min(u, v);
+            else w = bc(a, k) != 0 ? u : v;
+            if (r.is_int) r.i.push_back((int64_t)w); else r.f.push_back((float)w);
+        }
+        return r;
+    }
+    throw Error("host op " + op + " is not supported by the native runner");
+}
+
+// ------------------------------------------------------------------------------------------------ runner
+class Runner {
+   public:
+    Runner(const std::string& plan_json, const std::string& weights_path) {
+        plan_ = JsonParser(plan_json).parse();
+        if (!plan_.has("format") || plan_.at("format").str != "lele_amd.plan/2")
+            throw Error("plan: only compiled plans (format lele_amd.plan/2) are supported by the native runner");
+        std::ifstream f(weights_path, std::ios::binary);
+        if (!f) throw Error("cannot open " + weights_path);
+        blob_.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        for (const auto& kv : plan_.at("weights").obj) load_weight(kv.first, kv.second);
+        for (const Json& s : plan_.at("slots").arr) slots_[s.str] = std::make_unique<Buffer>();
+    }
+    const Json& plan() const { return plan_; }
+    size_t calls() const { return calls_; }
+
+    // inputs by name -> outputs in plan order.  Device inputs must stay alive; i64 inputs are host arrays.
+    std::vector<Val> run(const std::map<std::string, Val>& inputs) {
+        env_.clear();
+        for (const auto& kv : inputs) env_[kv.first] = kv.second;
+        calls_ = 0;
+        for (const Json& st : plan_.at("statements").arr) {
+            const std::string& op = st.at("op").str;
+            if (op == "host") host_stmt(st);
+            else if (op == "call") call_stmt(st);
+            else throw Error("plan: statement kind '" + op + "' is not supported by the native runner");
+        }
+        std::vector<Val> out;
+        for (const Json& o : plan_.at("outputs").arr) out.push_back(env_.at(o.str));
+        return out;
+    }
+
+   private:
+    using TV = TensorView;
+    Json plan_;
+    std::vector<char> blob_;
+    std::unordered_map<std::string, std::unique_ptr<Buffer>> slots_;
+    std::unordered_map<std::string, std::pair<TV, std::shared_ptr<std::vector<char>>>> weights_;
+    std::unordered_map<std::string, Val> env_;
+    size_t calls_ = 0;
+
+    static std::string weight_key(const Json& w) {
+        std::string k = std::to_string(w.arr[1].as_int()) + ":" + w.arr[0].str + ":";
+        for (size_t i = 0; i < w.arr[3].arr.size(); ++i) k += (i ? "x" : "") + std::to_string(w.arr[3].arr[i].as_int());
+        return k;
+    }
+    static float half_to_float(uint16_t h) {
+        const uint32_t sign = (uint32_t)(h & 0x8000) << 16, exp = (h >> 10) & 31, man = h & 1023;
+        uint32_t bits;
+        if (exp == 0) {
+            if (man == 0) bits = sign;
+            else {
+                int e = -1;
+                uint32_t m = man;
+                do { ++e; m <<= 1; } while (!(m & 1024));
+                bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 1023) << 13);
+            }
+        } else if (exp == 31) bits = sign | 0x7F800000u | (man << 13);
+        else bits = sign | ((exp + 112) << 23) | (man << 13);
+        float f;
+        std::memcpy(&f, &bits, 4);
+        return f;
+    }
+    void load_weight(const std::string& key, const Json& w) {  // plan.py load_weights_bin: everything but i64 is handed over as f32
+        const std::string& kind = w.arr[0].str;
+        const size_t off = (size_t)w.arr[1].as_int(), len = (size_t)w.arr[2].as_int();
+        if (off + len > blob_.size()) throw Error("weights.bin is shorter than view " + key);
+        std::vector<int64_t> shape;
+        for (const Json& d : w.arr[3].arr) shape.push_back(d.as_int());
+        const char* p = blob_.data() + off;
+        auto store = std::make_shared<std::vector<char>>();
+        auto as_f32 = [&](size_t n, const std::function<float(size_t)>& get) {
+            store->resize(n * 4);
+            float* d = reinterpret_cast<float*>(store->data());
+            for (size_t k = 0; k < n; ++k) d[k] = get(k);
+            weights_[key] = {TV::weight(d, shape), store};
+        };
+        if (kind == "weight_f32") {
+            store->assign(p, p + len);  // own 4-byte-aligned copy (the blob offset is 16-aligned, but keep it simple and safe)
+            weights_[key] = {TV::weight(reinterpret_cast<const float*>(store->data()), shape), store};
+        } else if (kind == "weight_u8") as_f32(len, [&](size_t k) { return (float)(uint8_t)p[k]; });
+        else if (kind == "weight_i8") as_f32(len, [&](size_t k) { return (float)(int8_t)p[k]; });
+        else if (kind == "weight_f16") as_f32(len / 2, [&](size_t k) { uint16_t h; std::memcpy(&h, p + 2 * k, 2); return half_to_float(h); });
+        else if (kind == "weight_f64") as_f32(len / 8, [&](size_t k) { double v; std::memcpy(&v, p + 8 * k, 8); return (float)v; });
+        else if (kind == "weight_i32") as_f32(len / 4, [&](size_t k) { int32_t v; std::memcpy(&v, p + 4 * k, 4); return (float)v; });
+        else if (kind == "weight_i64") {
+            store->assign(p, p + len);
+            weights_[key] = {TV::weight(reinterpret_cast<const int64_t*>(store->data()), shape), store};
+        } else throw Error("weights view kind '" + kind + "' is not handled");
+    }
+
+    // ---- argument evaluation
+    const Val& ref(const std::string& name) const {
+        auto it = env_.find(name);
+        if (it == env_.end()) throw Error("plan: undefined value '" + name + "'");
+        return it->second;
+    }
+    TV tensor(const Json& n) {
+        if (n.has("ref")) {
+            const Val& v = ref(n.at("ref").str);
+            if (v.kind == Val::Tensor) return v.t;
+            if (v.kind == Val::Host) return host_tensor(v.h);
+            throw Error("plan: value '" + n.at("ref").str + "' is not a tensor");
+        }
+        if (n.has("weight")) return weights_.at(weight_key(n.at("weight"))).first;
+        if (n.has("array")) {
+            HostArr h;
+            h.is_int = n.has("dtype") && n.at("dtype").str == "i64";
+            for (const Json& e : n.at("array").arr) { if (h.is_int) h.i.push_back(e.as_int()); else h.f.push_back((float)e.as_num()); }
+            return host_tensor(h);
+        }
+        throw Error("plan: tensor operand expected");
+    }
+    std::vector<std::shared_ptr<std::vector<char>>> temp_;  // host-backed operands of the current statement
+    TV host_tensor(const HostArr& h) {
+        auto store = std::make_shared<std::vector<char>>();
+        std::vector<int64_t> shape;
+        if (!h.scalar) shape.push_back((int64_t)h.size());
+        temp_.push_back(store);
+        if (h.is_int) {
+            store->resize(h.i.size() * 8);
+            std::memcpy(store->data(), h.i.data(), store->size());
+            return TV::from_slice(reinterpret_cast<const int64_t*>(store->data()), shape);
+        }
+        store->resize(h.f.size() * 4);
+        std::memcpy(store->data(), h.f.data(), store->size());
+        return TV::from_slice(reinterpret_cast<const float*>(store->data()), shape);
+    }
+    bool is_none(const Json& n) const { return n.has("none"); }
+    std::vector<int64_t> ints(const Json& n) {
+        if (n.has("list")) {
+            std::vector<int64_t> v;
+            for (const Json& e : n.at("list").arr) v.push_back(e.at("int").as_int());
+            return v;
+        }
+        if (n.has("ints")) {
+            const Val& v = ref(n.at("ints").str);
+            if (v.kind != Val::Host) throw Error("plan: '" + n.at("ints").str + "' is not a host integer value");
+            return ints_of(v.h);
+        }
+        if (n.has("some")) return ints(n.at("some"));
+        throw Error("plan: integer list expected");
+    }
+    std::vector<float> floats(const Json& n) {
+        const Json& l = n.has("some") ? n.at("some") : n;
+        std::vector<float> v;
+        for (const Json& e : l.at("list").arr) v.push_back((float)(e.has("float") ? e.at("float").as_num() : e.at("int").as_num()));
+        return v;
+    }
+    int64_t integer(const Json& n) { return n.has("first") ? ints(n.at("first")).at(0) : n.at("int").as_int(); }
+    static float number(const Json& n) { return (float)(n.has("float") ? n.at("float").as_num() : n.at("int").as_num()); }
+    static bool boolean(const Json& n) { return n.at("bool").b; }
+
+    void host_stmt(const Json& st) {
+        const std::string& op = st.at("onnx").str;
+        std::vector<HostArr> hold;
+        hold.reserve(st.at("in").arr.size());
+        std::vector<const HostArr*> x;
+        std::vector<int64_t> shape0;
+        bool have_shape = false;
+        for (const Json& n : st.at("in").arr) {
+            if (n.kind == Json::Null) { x.push_back(nullptr); continue; }
+            HostArr h;
+            if (n.has("const")) {
+                const Json& c = n.at("const");
+                h.is_int = n.at("dtype").str == "i64";
+                h.scalar = c.kind != Json::Arr;
+                auto push = [&](const Json& e) { if (h.is_int) h.i.push_back(e.as_int()); else h.f.push_back((float)e.as_num()); };
+                if (c.kind == Json::Arr) for (const Json& e : c.arr) {
+                    if (e.kind == Json::Arr) throw Error("host op " + op + ": rank > 1 constant is not supported by the native runner");
+                    push(e);
+                } else push(c);
+            } else {
+                const Val& v = ref(n.at("ref").str);
+                if (v.kind == Val::Tensor) {
+                    if (op != "Shape" && op != "Size") throw Error("host op " + op + " reads a device tensor");
+                    if (!have_shape) shape0 = v.t.shape, have_shape = true;
+                } else {
+                    h = v.h;
+                    if ((op == "Shape" || op == "Size") && !have_shape) { shape0 = h.scalar ? std::vector<int64_t>{} : std::vector<int64_t>{(int64_t)h.size()}; have_shape = true; }
+                }
+            }
+            hold.push_back(std::move(h));
+            x.push_back(&hold.back());
+        }
+        Val out;
+        out.kind = Val::Host;
+        out.h = host_eval(op, x, st.at("attrs"), have_shape ? &shape0 : nullptr);
+        env_[st.at("out").arr[0].str] = out;
+    }
+
+    void set(const Json& st, size_t k, const TV& t) {
+        Val v;
+        v.kind = Val::Tensor;
+        v.t = t;
+        env_[st.at("out").arr.at(k).str] = v;
+    }
+    Buffer& slot(const Json& st, size_t k) { return *slots_.at(st.at("slots").arr.at(k).str); }
+
+    void call_stmt(const Json& st) {
+        namespace K = kernels;
+        const std::string& fn = st.at("fn").str;
+        const std::vector<Json>& a = st.at("args").arr;
+        temp_.clear();
+        ++calls_;
+        auto opt = [&](const Json& n, TV& hold) -> const TV* { if (is_none(n)) return nullptr; hold = tensor(n); return &hold; };
+        TV h0, h1, h2, h3;
+        // views
+        if (fn == "reshape") return set(st, 0, K::reshape(tensor(a[0]), ints(a[1])));
+        if (fn == "flatten") return set(st, 0, K::flatten(tensor(a[0]), integer(a[1])));
+        if (fn == "unsqueeze") return set(st, 0, K::unsqueeze(tensor(a[0]), ints(a[1])));
+        if (fn == "squeeze") { const auto ax = ints(a[1]); return set(st, 0, K::squeeze(tensor(a[0]), ax.empty() ? nullptr : &ax)); }
+        if (fn == "identity") return set(st, 0, tensor(a[0]));
+        Buffer& o = slot(st, 0);
+        static const std::map<std::string, int> unary = {{"exp", LELE_U_EXP}, {"sigmoid", LELE_U_SIGMOID}, {"tanh_kernel", LELE_U_TANH}, {"silu", LELE_U_SILU},
+            {"erf", LELE_U_ERF}, {"relu", LELE_U_RELU}, {"sqrt", LELE_U_SQRT}, {"log", LELE_U_LOG}, {"sin", LELE_U_SIN}, {"cos", LELE_U_COS}, {"neg", LELE_U_NEG},
+            {"reciprocal", LELE_U_RECIPROCAL}, {"softplus", LELE_U_SOFTPLUS}, {"not_", LELE_U_NOT}, {"abs", LELE_U_ABS}, {"floor", LELE_U_FLOOR}, {"ceil", LELE_U_CEIL}};
+        static const std::map<std::string, int> binary = {{"add", LELE_B_ADD}, {"sub", LELE_B_SUB}, {"mul", LELE_B_MUL}, {"div", LELE_B_DIV}, {"pow", LELE_B_POW},
+            {"max", LELE_B_MAX}, {"min", LELE_B_MIN}, {"equal", LELE_B_EQUAL}, {"less", LELE_B_LESS}, {"greater", LELE_B_GREATER}, {"prelu", LELE_B_PRELU},
+            {"mod_f32", LELE_B_MOD}, {"and_", LELE_B_AND}, {"or_", LELE_B_OR}};
+        if (unary.count(fn)) return set(st, 0, K::unary(unary.at(fn), tensor(a[0]), o));
+        if (binary.count(fn)) return set(st, 0, K::binary(binary.at(fn), tensor(a[0]), tensor(a[1]), o));
+        if (fn == "matmul") return set(st, 0, K::matmul(tensor(a[0]), tensor(a[1]), o));
+        if (fn == "matmul_fused_add") return set(st, 0, K::matmul_fused_add(tensor(a[0]), tensor(a[1]), tensor(a[2]), o));
+        if (fn == "gemm") return set(st, 0, K::gemm(tensor(a[0]), tensor(a[1]), opt(a[2], h0), number(a[3]), number(a[4]), boolean(a[5]), boolean(a[6]), o));
+        if (fn == "conv2d" || fn == "conv1d" || fn == "conv2d_silu" || fn == "conv_transpose")
+            return set(st, 0, (fn == "conv2d" ? K::conv2d : fn == "conv1d" ? K::conv1d : fn == "conv2d_silu" ? K::conv2d_silu : K::conv_transpose)(
+                                  tensor(a[0]), tensor(a[1]), opt(a[2], h0), ints(a[3]), integer(a[4]), ints(a[5]), ints(a[6]), o));
+        if (fn == "conv2d_fused" || fn == "conv1d_fused")
+            return set(st, 0, (fn == "conv2d_fused" ? K::conv2d_fused : K::conv1d_fused)(tensor(a[0]), tensor(a[1]), opt(a[2], h0), ints(a[3]), integer(a[4]),
+                                                                                         ints(a[5]), ints(a[6]), boolean(a[7]), o));
+        if (fn == "conv_integer")
+            return set(st, 0, K::conv_integer(tensor(a[0]), tensor(a[1]), opt(a[2], h0), opt(a[3], h1), ints(a[4]), integer(a[5]), ints(a[6]), ints(a[7]), o));
+        if (fn == "fused_quantized_linear")
+            return set(st, 0, K::fused_quantized_linear(tensor(a[0]), tensor(a[1]), tensor(a[2]), tensor(a[3]), opt(a[4], h0), boolean(a[5]), o));
+        if (fn == "mat_mul_integer") return set(st, 0, K::mat_mul_integer(tensor(a[0]), tensor(a[1]), opt(a[2], h0), opt(a[3], h1), o));
+        if (fn == "dynamic_quantize_linear") {
+            auto r = K::dynamic_quantize_linear(tensor(a[0]), o, slot(st, 1), slot(st, 2));
+            set(st, 0, r.y), set(st, 1, r.scale), set(st, 2, r.zero_point);
+            return;
+        }
+        if (fn == "lstm") {
+            auto r = K::lstm(tensor(a[0]), tensor(a[1]), tensor(a[2]), opt(a[3], h0), opt(a[4], h1), opt(a[5], h2), opt(a[6], h3), o, slot(st, 1), slot(st, 2));
+            set(st, 0, r.y), set(st, 1, r.h), set(st, 2, r.c);
+            return;
+        }
+        if (fn == "gru") {
+            auto r = K::gru(tensor(a[0]), tensor(a[1]), tensor(a[2]), opt(a[3], h0), opt(a[4], h1), boolean(a[5]), o, slot(st, 1));
+            set(st, 0, r.y), set(st, 1, r.h);
+            return;
+        }
+        if (fn == "layer_norm") return set(st, 0, K::layer_norm(tensor(a[0]), tensor(a[1]), tensor(a[2]), integer(a[3]), number(a[4]), o));
+        if (fn == "batch_norm") return set(st, 0, K::batch_norm(tensor(a[0]), tensor(a[1]), tensor(a[2]), tensor(a[3]), tensor(a[4]), number(a[5]), o));
+        if (fn == "softmax") return set(st, 0, K::softmax(tensor(a[0]), integer(a[1]), o));
+        if (fn == "max_pool2d") return set(st, 0, K::max_pool2d(tensor(a[0]), ints(a[1]), ints(a[2]), ints(a[3]), ints(a[4]), boolean(a[5]), o));
+        if (fn == "resize_nearest") {  // kernels.py resize_nearest: sizes win; scales multiply in f64 and truncate (conv2d.rs:1261-1382)
+            const TV x = tensor(a[0]);
+            if (x.dim() != 4) throw Error("Resize: expected rank-4 input");
+            int64_t oh, ow;
+            if (!is_none(a[2])) {
+                const auto sz = ints(a[2]);
+                if (sz.size() < 4) throw Error("Resize: sizes must have at least 4 elements");
+                oh = sz[2], ow = sz[3];
+                if (oh <= 0 || ow <= 0) throw Error("Resize: sizes H and W must be positive");
+            } else if (!is_none(a[1])) {
+                const auto sc = floats(a[1]);
+                const double shh = sc.size() >= 3 ? (double)sc[2] : 1.0, sww = sc.size() >= 4 ? (double)sc[3] : 1.0;
+                oh = (int64_t)((double)x.shape[2] * shh), ow = (int64_t)((double)x.shape[3] * sww);
+            } else throw Error("Resize: either scales or sizes must be provided");
+            return set(st, 0, K::resize_nearest(x, oh, ow, a[3].at("str").str == "asymmetric", o));
+        }
+        if (fn == "transpose") return set(st, 0, K::transpose(tensor(a[0]), ints(a[1]), o));
+        if (fn == "concat") {
+            std::vector<TV> hold;
+            for (const Json& e : a[0].at("list").arr) hold.push_back(tensor(e));
+            std::vector<const TV*> ptrs;
+            for (const TV& t : hold) ptrs.push_back(&t);
+            return set(st, 0, K::concat(ptrs, integer(a[1]), o));
+        }
+        if (fn == "where_op") return set(st, 0, K::where_op(tensor(a[0]), tensor(a[1]), tensor(a[2]), o));
+        if (fn == "gather") return set(st, 0, K::gather(tensor(a[0]), tensor(a[1]), integer(a[2]), o));
+        if (fn == "gather_elements") return set(st, 0, K::gather_elements(tensor(a[0]), tensor(a[1]), integer(a[2]), o));
+        if (fn == "slice") return set(st, 0, K::slice(tensor(a[0]), ints(a[1]), ints(a[2]), ints(a[3]), ints(a[4]), o));
+        if (fn == "expand") return set(st, 0, K::expand(tensor(a[0]), ints(a[1]), o));
+        if (fn == "tile") return set(st, 0, K::tile(tensor(a[0]), ints(a[1]), o));
+        if (fn == "split") {
+            std::vector<Buffer*> outs;
+            for (size_t k = 0; k < st.at("slots").arr.size(); ++k) outs.push_back(&slot(st, k));
+            auto r = K::split(tensor(a[0]), integer(a[1]), ints(a[2]), outs);
+            for (size_t k = 0; k < r.size(); ++k) set(st, k, r[k]);
+            return;
+        }
+        if (fn == "pad") {
+            float cv = 0.0f;
+            const float* pcv = nullptr;
+            if (!is_none(a[2])) {
+                const TV c = tensor(a[2]);
+                const auto v = c.to_vec<float>();
+                if (!v.empty()) cv = v[0], pcv = &cv;
+            }
+            return set(st, 0, K::pad(tensor(a[0]), ints(a[1]), pcv, a[3].at("str").str, o));
+        }
+        if (fn == "reduce_mean" || fn == "reduce_sum" || fn == "reduce_max" || fn == "reduce_l2") {
+            const int op = fn == "reduce_sum" ? 0 : fn == "reduce_mean" ? 1 : fn == "reduce_max" ? 2 : 3;
+            return set(st, 0, K::reduce(op, tensor(a[0]), ints(a[1]), boolean(a[2]), o));
+        }
+        if (fn == "clip") {
+            float lo = 0, hi = 0;
+            const float *plo = nullptr, *phi = nullptr;
+            if (!is_none(a[1])) lo = tensor(a[1]).to_vec<float>().at(0), plo = &lo;
+            if (!is_none(a[2])) hi = tensor(a[2]).to_vec<float>().at(0), phi = &hi;
+            return set(st, 0, K::clip(tensor(a[0]), plo, phi, o));
+        }
+        if (fn == "cast_to_i64") return set(st, 0, K::cast_to_i64(tensor(a[0]), o));
+        if (fn == "topk") {
+            const TV x = tensor(a[0]);
+            const int64_t axis = integer(a[2]);
+            if (axis != -1 && axis != (int64_t)x.dim() - 1) throw Error("TopK: only the last axis is supported (conv2d.rs:1385)");
+            auto r = K::topk(x, integer(a[1]), boolean(a[3]), o, slot(st, 1));
+            set(st, 0, r.values), set(st, 1, r.indices);
+            return;
+        }
+        if (fn == "constant_of_shape") return set(st, 0, K::constant_of_shape(ints(a[0]), number(a[1]), o));
+        throw Error("plan: kernel '" + fn + "' is not supported by the native runner");
+    }
+};
+
+}  // namespace plan
+}  // namespace lele
