@@ -268,6 +268,26 @@ def main():
                         "plan_statements": len(plan["statements"]), "plan_slots": len(plan["slots"]), "weights_bin_bytes": len(blob),
                         "compile_s": round(t_compile, 2), "plan_calls": fn_count, "compiled_logits_identical": same,
                         "compiled_graph_ms": round(1e3 * float(np.mean(tg)), 3)}
+            # the same plan through the native runner (lele_amd/lele_run: C++ over the C ABI, no Python on the serving path)
+            exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lele_amd", "lele_run")
+            if os.path.exists(exe):
+                import subprocess
+                import tempfile
+                with tempfile.TemporaryDirectory() as td:
+                    json.dump(plan, open(os.path.join(td, "m_plan.json"), "w"))
+                    open(os.path.join(td, "m_weights.bin"), "wb").write(blob)
+                    fh = feats.numpy()
+                    fh.tofile(os.path.join(td, "feats.bin"))
+                    out = subprocess.run([exe, os.path.join(td, "m_plan.json"), os.path.join(td, "m_weights.bin"), "--input",
+                                          "feats=%s:f32:%s" % (os.path.join(td, "feats.bin"), ",".join(map(str, fh.shape))), "--out",
+                                          os.path.join(td, "o"), "--runs", str(args.runs), "--graph"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                    if out.returncode == 0:
+                        nrec = json.loads(out.stdout.strip().splitlines()[-1])
+                        native_logits = np.fromfile(os.path.join(td, "o0.bin"), np.float32).reshape(nrec["outputs"][0])
+                        onnx_rec.update({"native_eager_ms": round(nrec["eager_ms"], 3), "native_graph_ms": round(nrec["graph_ms"], 3),
+                                         "native_logits_identical": bool(np.array_equal(native_logits, want))})
+                    else:
+                        onnx_rec["native_error"] = out.stderr.strip()[-300:]
             logits = enc.forward(feats)
         audio = batch * seconds
         lg = logits.numpy()
