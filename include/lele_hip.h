@@ -309,6 +309,19 @@ int lele_hip_yolo_seg_postprocess(LeleCtx* ctx, const LeleTensor* logits, const 
                                   int32_t img_height, float threshold, int32_t num_classes, LeleBuf* out_dets,
                                   LeleBuf* out_count, LeleBuf* out_mask);
 
+/* ---- fused forms beyond the reference's own patterns (emitted by lele_amd.compiler, each bit-identical to the sequence it
+ *      replaces; never required by lele-generated code) ---------------------------------------------------------------- */
+/* softmax(x * scale[0]) over the last axis: `mul` by a one-element tensor followed by `softmax` (norm.rs:8) */
+int lele_hip_softmax_scaled(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, int32_t axis, LeleBuf* out,
+                            int64_t* out_shape, int32_t* out_rank);
+/* (a + b) + c on equal shapes: two consecutive `add`s (math.rs:414) */
+int lele_hip_add3(LeleCtx* ctx, const LeleTensor* a, const LeleTensor* b, const LeleTensor* c, LeleBuf* out, int64_t* out_shape,
+                  int32_t* out_rank);
+/* Transpose(0,2,1) -> depthwise conv1d (group = C, stride 1, dilation 1, conv1d.rs:837) -> Transpose(0,2,1), without the
+ * transposes: x f32 [B, T, C], w [C, 1, K] (K in 3, 5, 7, 11), bias [C] or NULL -> out [B, T + pad_left + pad_right - K + 1, C] */
+int lele_hip_depthwise_conv1d_tlc(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias, int64_t pad_left,
+                                  int64_t pad_right, int relu, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+
 #ifdef __cplusplus
 }
 #endif

@@ -81,8 +81,8 @@ def _attrs(node):
 
 
 class Lowering:
-    def __init__(self, model, name="model"):
-        self.model, self.name = model, name
+    def __init__(self, model, name="model", extra_fusions=True):
+        self.model, self.name, self.extra_fusions = model, name, extra_fusions
         g = model.graph
         self.consts = {}       # name -> numpy array (initializers, Constant nodes, folded results)
         self.const_dtype = {}  # name -> ONNX data type of the stored tensor
@@ -265,6 +265,35 @@ class Lowering:
             if bias_n in self.consts and np.asarray(self.consts[bias_n]).ndim == 1 and self.consts[bias_n].dtype.kind == "f":
                 return 2, lambda: self.emit([n[1].output[0]], "matmul_fused_add", [self.tensor(n[0].input[0]), self.tensor(n[0].input[1]),
                                                                                     self.weight(bias_n, True)])
+        if not self.extra_fusions:
+            return None
+        # ---- fused forms beyond patterns.rs, each bit-identical to the sequence it replaces (include/lele_hip.h) ----
+        # Transpose(0,2,1) -> depthwise Conv1d -> Transpose(0,2,1): an FSMN memory block on a time-major tensor
+        if ops("Transpose", "Conv", "Transpose"):
+            a0, a1, a2 = _attrs(n[0]), _attrs(n[1]), _attrs(n[2])
+            wname = n[1].input[1]
+            w = self.consts.get(wname)
+            bias_ok = len(n[1].input) < 3 or not n[1].input[2] or n[1].input[2] in self.consts
+            if (a0.get("perm") == [0, 2, 1] and a2.get("perm") == [0, 2, 1] and n[1].input[0] == n[0].output[0]
+                    and n[2].input[0] == n[1].output[0] and private(n[0].output[0], n[1].output[0]) and w is not None and w.ndim == 3
+                    and w.shape[1] == 1 and a1.get("group", 1) == w.shape[0] and w.shape[2] in (3, 5, 7, 11) and bias_ok
+                    and all(v == 1 for v in a1.get("strides", [1])) and all(v == 1 for v in a1.get("dilations", [1]))
+                    and a1.get("auto_pad", "NOTSET") in ("NOTSET", "")):
+                pads = a1.get("pads", [])
+                pl, pr = (pads[0] if len(pads) >= 1 else 0), (pads[1] if len(pads) >= 2 else 0)  # conv1d.rs:886-887
+                return 3, lambda: self.emit([n[2].output[0]], "depthwise_conv1d_tlc", [self.tensor(n[0].input[0]), self.tensor(wname), self.opt_tensor(n[1], 2),
+                                                                                        {"int": pl}, {"int": pr}, {"bool": False}])
+        # Mul by a one-element constant -> Softmax over the last axis (attention score scaling)
+        if ops("Mul", "Softmax") and n[1].input[0] == n[0].output[0] and private(n[0].output[0]) and _attrs(n[1]).get("axis", -1) == -1:
+            sc = [i for i in n[0].input if i in self.consts and self.consts[i].size == 1 and self.consts[i].dtype.kind == "f"]
+            xs = [i for i in n[0].input if i not in self.consts]
+            if len(sc) == 1 and len(xs) == 1:
+                return 2, lambda: self.emit([n[1].output[0]], "softmax_scaled", [self.tensor(xs[0]), self.weight(sc[0], True), {"int": -1}])
+        # Add -> Add: (a + b) + c in one pass (two residual connections in a row)
+        if ops("Add", "Add") and n[0].output[0] in n[1].input and private(n[0].output[0]):
+            c = [i for i in n[1].input if i != n[0].output[0]]
+            if len(c) == 1 and not any(i in self.consts for i in list(n[0].input) + c):  # x + y == y + x bit for bit
+                return 2, lambda: self.emit([n[1].output[0]], "add3", [self.tensor(n[0].input[0]), self.tensor(n[0].input[1]), self.tensor(c[0])])
         return None
 
     # ---------------------------------------------------------------------------------------- per-op lowering
@@ -534,8 +563,9 @@ def allocate(statements, outputs):
     return ["buf_%d" % s for s in range(n_slots)]
 
 
-def compile_model(model, name="model"):
-    """ONNX model (bytes, path or onnx_pb.Model) -> (plan dict, weights.bin bytes)"""
+def compile_model(model, name="model", extra_fusions=True):
+    """ONNX model (bytes, path or onnx_pb.Model) -> (plan dict, weights.bin bytes).  extra_fusions=False keeps to the
+    patterns lele's own compiler has (patterns.rs); the extra fused forms are bit-identical to what they replace."""
     if not isinstance(model, pb.Model):
         model = pb.load(model)
-    return Lowering(model, name).run()
+    return Lowering(model, name, extra_fusions).run()

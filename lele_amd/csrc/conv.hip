@@ -358,6 +358,47 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(const float* __restr
     dw_copy_run(lout, dst, np * ohw, (((uintptr_t)dst) & 15) == 0);
 }
 
+// Depthwise 1-D convolution on a TIME-MAJOR tensor x[B][T][C] (channels innermost): what the three-node sequence
+// Transpose(0,2,1) -> Conv(group = C, kernel k) -> Transpose(0,2,1) computes (an FSMN memory block exports that way),
+// without the two transposes.  A lane owns one channel (coalesced 256-byte rows across the wave) and produces TT
+// consecutive time steps from a sliding register window.  Per output: taps in ascending order, out-of-range taps skipped,
+// FMA chain, bias added afterwards -- the arithmetic of the depthwise kernels above, so the result is bit-identical to
+// the unfused sequence.
+template <int KW, int TT>
+__global__ __launch_bounds__(256) void dwconv1d_tlc_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ out, int t_in,
+                                                           int t_out, int c, int pl, int relu, unsigned tiles_t, unsigned total) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    const unsigned ch = i % (unsigned)c, r = i / (unsigned)c;
+    const unsigned tile = r % tiles_t, b = r / tiles_t;
+    const int t0 = (int)tile * TT;
+    const float* xp = x + ((size_t)b * t_in) * c + ch;
+    float xs[KW + TT - 1], wv[KW];
+#pragma unroll
+    for (int j = 0; j < KW + TT - 1; ++j) {
+        const int t = t0 - pl + j;
+        xs[j] = xp[(size_t)min(max(t, 0), t_in - 1) * c];
+    }
+#pragma unroll
+    for (int j = 0; j < KW; ++j) wv[j] = w[ch * KW + j];
+    const float bv = bias ? bias[ch] : 0.0f;
+    float* op = out + ((size_t)b * t_out) * c + ch;
+#pragma unroll
+    for (int q = 0; q < TT; ++q) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KW; ++j) {
+            const int t = t0 + q - pl + j;
+            const float f = fmaf_(xs[q + j], wv[j], acc);
+            acc = (t >= 0 && t < t_in) ? f : acc;
+        }
+        if (bias) acc = acc + bv;
+        if (relu) acc = acc > 0.0f ? acc : 0.0f;
+        if (t0 + q < t_out) op[(size_t)(t0 + q) * c] = acc;
+    }
+}
+
 // conv_transpose (group 1): gather form of the reference's GEMM + col2im scatter (conv2d.rs:3060-3126)
 struct CtGeom {
     int n, c, ih, iw, oc, kh, kw, pt, pl, sh, sw, dh, dw, oh, ow;
@@ -745,6 +786,43 @@ int lele_hip_conv1d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, cons
     LELE_TRY(run_conv2d(ctx, w, (const float*)dx, (const float*)dwp, (const float*)db, g, relu ? LELE_ACT_RELU : LELE_ACT_NONE,
                         (float*)out->data));
     return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, (int64_t)g.ow});
+}
+
+int lele_hip_depthwise_conv1d_tlc(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias, int64_t pad_left,
+                                  int64_t pad_right, int relu, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && w && out, "depthwise_conv1d_tlc: NULL argument");
+    LELE_REQUIRE(x->rank == 3 && w->rank == 3 && x->dtype == LELE_F32 && w->dtype == LELE_F32, "depthwise_conv1d_tlc: x [B,T,C] and w [C,1,K] f32 required");
+    const int64_t bsz = x->shape[0], t_in = x->shape[1], c = x->shape[2], k = w->shape[2];
+    LELE_REQUIRE(w->shape[0] == c && w->shape[1] == 1, "depthwise_conv1d_tlc: weight must be [C, 1, K] (group = C)");
+    LELE_REQUIRE(k == 3 || k == 5 || k == 7 || k == 11, "depthwise_conv1d_tlc: kernel sizes 3, 5, 7, 11 (use transpose + conv1d otherwise)");
+    LELE_REQUIRE(pad_left >= 0 && pad_right >= 0, "depthwise_conv1d_tlc: negative padding");
+    const int64_t t_out = t_in + pad_left + pad_right - (k - 1);
+    LELE_REQUIRE(t_out >= 1 && t_in >= 1, "conv1d: output length must be positive");
+    if (bias) LELE_REQUIRE(numel(bias) >= c, "conv1d: bias shorter than C_out");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    LELE_TRY(ctx->arena_reset());
+    const void *dx = nullptr, *dwp = nullptr, *db = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(ctx->dev_ptr(w, &dwp));
+    if (bias) LELE_TRY(ctx->dev_ptr(bias, &db));
+    LELE_TRY(out->reserve((size_t)(bsz * t_out * c) * 4));
+    constexpr int TT = 8;
+    const int64_t tiles = (t_out + TT - 1) / TT, total = bsz * tiles * c;
+    LELE_REQUIRE(total < (int64_t(1) << 31) && bsz * t_in * c < (int64_t(1) << 40), "depthwise_conv1d_tlc: tensor too large");
+    if (bsz && c) {
+        const dim3 grid((unsigned)((total + 255) / 256));
+#define LELE_TLC(KW)                                                                                                         \
+    hipLaunchKernelGGL((dwconv1d_tlc_kernel<KW, TT>), grid, dim3(256), 0, ctx->stream, (const float*)dx, (const float*)dwp,      \
+                       (const float*)db, (float*)out->data, (int)t_in, (int)t_out, (int)c, (int)pad_left, relu, (unsigned)tiles, \
+                       (unsigned)total)
+        if (k == 3) LELE_TLC(3);
+        else if (k == 5) LELE_TLC(5);
+        else if (k == 7) LELE_TLC(7);
+        else LELE_TLC(11);
+#undef LELE_TLC
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape(out_shape, out_rank, {bsz, t_out, c});
 }
 
 int lele_hip_conv_transpose(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,

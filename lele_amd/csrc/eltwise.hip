@@ -198,6 +198,20 @@ __global__ __launch_bounds__(256) void binary_fast_kernel(int op, const float* _
     for (unsigned i = 4 * nvec + gtid; i < n; i += gstride) out[i] = binary_apply<float>(op, fetch1(a, ma, i), fetch1(b, mb, i));
 }
 
+// (a + b) + c element-wise on equal shapes: the two consecutive residual adds of a transformer block in one pass, same
+// rounding order as two `add` kernels
+__global__ __launch_bounds__(256) void add3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                                   float* __restrict__ out, int64_t n) {
+    const int64_t gtid = (int64_t)blockIdx.x * 256 + threadIdx.x, gstride = (int64_t)gridDim.x * 256;
+    const bool vec = ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)out) & 15) == 0);
+    const int64_t nvec = vec ? n >> 2 : 0;
+    for (int64_t i = gtid; i < nvec; i += gstride) {
+        const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i], z = reinterpret_cast<const float4*>(c)[i];
+        reinterpret_cast<float4*>(out)[i] = make_float4((x.x + y.x) + z.x, (x.y + y.y) + z.y, (x.z + y.z) + z.z, (x.w + y.w) + z.w);
+    }
+    for (int64_t i = 4 * nvec + gtid; i < n; i += gstride) out[i] = (a[i] + b[i]) + c[i];
+}
+
 // where_op (manipulation.rs:1215-): out = cond != 0 ? x : y, three-way broadcast
 __global__ void where_kernel(const float* __restrict__ cnd, const float* __restrict__ x, const float* __restrict__ y,
                              float* __restrict__ out, int64_t numel, Bcast bc) {
@@ -383,19 +397,25 @@ __global__ void layer_norm_reg_kernel(const float* __restrict__ x, const float* 
     }
 }
 
+// `scale` (NULL or one f32 on the device): softmax(x * scale[0]) with the product rounded to f32 first, i.e. exactly what
+// a `mul` kernel followed by this kernel computes (lele_hip_softmax_scaled)
 template <int NT>
-__global__ void softmax_reg_kernel(const float* __restrict__ x, float* __restrict__ y, int len, int64_t outer) {
+__global__ void softmax_reg_kernel(const float* __restrict__ x, float* __restrict__ y, int len, int64_t outer,
+                                   const float* __restrict__ scale) {
     const int l = threadIdx.x & 31;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (row >= outer) return;
     const float* src = x + row * len;
     float* dst = y + row * len;
+    const bool scaled = scale != nullptr;
+    const float sc = scaled ? scale[0] : 1.0f;
     float v[NT];
     float m = -3.40282347e+38f;
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
         const int j = 32 * c + l;
         v[c] = src[j < len ? j : len - 1];
+        if (scaled) v[c] = v[c] * sc;
         if (j < len) m = fmaxf(m, v[c]);
     }
     for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
@@ -456,19 +476,22 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(const float* __restrict__
 
 // softmax over a contiguous last axis, avx/norm.rs:139-229
 __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t len,
-                                                      int64_t outer) {
+                                                      int64_t outer, const float* __restrict__ scale) {
     const int l = threadIdx.x & 31;
     const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
     if (row >= outer) return;
     const float* src = x + row * len;
     float* dst = y + row * len;
+    const bool scaled = scale != nullptr;
+    const float sc = scaled ? scale[0] : 1.0f;
+    auto in = [&](int64_t j) { return scaled ? src[j] * sc : src[j]; };
     float m = -3.40282347e+38f;  // f32::MIN seeds; max is order-independent
-    for (int64_t j = l; j < len; j += 32) m = fmaxf(m, src[j]);
+    for (int64_t j = l; j < len; j += 32) m = fmaxf(m, in(j));
     for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
     const int64_t body = len & ~int64_t(7);
     // exp(x - max): polynomial in the SIMD body, libm in the tail; summed in the AVX accumulator order.  The values
     // are recomputed (deterministically) wherever another lane's element is needed, so no cross-lane memory traffic.
-    auto ev = [&](int64_t j) { return j < body ? exp_poly(src[j] - m) : expf(src[j] - m); };
+    auto ev = [&](int64_t j) { return j < body ? exp_poly(in(j) - m) : expf(in(j) - m); };
     float sum, dummy;
     row_sums<false, true>(ev, len, l, &sum, &dummy);
     const float inv_sum = 1.0f / sum;
@@ -769,9 +792,10 @@ int lele_hip_rms_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* weigh
     return set_shape_v(out_shape, out_rank, std::vector<int64_t>(x->shape, x->shape + x->rank));
 }
 
-int lele_hip_softmax(LeleCtx* ctx, const LeleTensor* x, int32_t axis, LeleBuf* out, int64_t* out_shape,
-                     int32_t* out_rank) {
+static int softmax_impl(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, int32_t axis, LeleBuf* out, int64_t* out_shape,
+                        int32_t* out_rank) {
     LELE_REQUIRE(ctx && x && out, "softmax: NULL argument");
+    LELE_REQUIRE(!scale || (scale->dtype == LELE_F32 && numel(scale) == 1), "softmax_scaled: the scale must be one f32 value");
     LELE_HIP_CHECK(hipSetDevice(ctx->device));
     const int nd = x->rank;
     const int ax = axis < 0 ? nd + axis : axis;
@@ -782,27 +806,71 @@ int lele_hip_softmax(LeleCtx* ctx, const LeleTensor* x, int32_t axis, LeleBuf* o
     LELE_REQUIRE(inner == 1, "Softmax only supported on last dimension for now");  // norm.rs:218
     const int64_t len = x->shape[ax];
     LELE_TRY(ctx->arena_reset());
-    const void* dx = nullptr;
+    const void *dx = nullptr, *dsc = nullptr;
     LELE_TRY(ctx->dev_ptr(x, &dx));
+    if (scale) LELE_TRY(ctx->dev_ptr(scale, &dsc));
     LELE_TRY(out->reserve((size_t)outer * len * 4));
     if (outer * len) {
         const int rpb = outer >= 4096 ? 8 : (outer >= 1024 ? 4 : 2);
         const dim3 rgrid((unsigned)((outer + rpb - 1) / rpb)), rblock(32 * rpb);
         if (len <= 256)
             hipLaunchKernelGGL(softmax_reg_kernel<8>, rgrid, rblock, 0, ctx->stream, (const float*)dx, (float*)out->data,
-                               (int)len, outer);
+                               (int)len, outer, (const float*)dsc);
         else if (len <= 512)
             hipLaunchKernelGGL(softmax_reg_kernel<16>, rgrid, rblock, 0, ctx->stream, (const float*)dx, (float*)out->data,
-                               (int)len, outer);
+                               (int)len, outer, (const float*)dsc);
         else if (len <= 1024)
             hipLaunchKernelGGL(softmax_reg_kernel<32>, rgrid, rblock, 0, ctx->stream, (const float*)dx, (float*)out->data,
-                               (int)len, outer);
+                               (int)len, outer, (const float*)dsc);
         else
-        hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((outer + 7) / 8)), dim3(256), 0, ctx->stream,
-                           (const float*)dx, (float*)out->data, len, outer);
+            hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)((outer + 7) / 8)), dim3(256), 0, ctx->stream,
+                               (const float*)dx, (float*)out->data, len, outer, (const float*)dsc);
         LELE_HIP_CHECK(hipGetLastError());
     }
     return set_shape_v(out_shape, out_rank, std::vector<int64_t>(x->shape, x->shape + x->rank));
+}
+
+int lele_hip_softmax(LeleCtx* ctx, const LeleTensor* x, int32_t axis, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    return softmax_impl(ctx, x, nullptr, axis, out, out_shape, out_rank);
+}
+
+int lele_hip_softmax_scaled(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, int32_t axis, LeleBuf* out,
+                            int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(scale, "softmax_scaled: NULL scale");
+    return softmax_impl(ctx, x, scale, axis, out, out_shape, out_rank);
+}
+
+int lele_hip_add3(LeleCtx* ctx, const LeleTensor* a, const LeleTensor* b, const LeleTensor* c, LeleBuf* out, int64_t* out_shape,
+                  int32_t* out_rank) {
+    LELE_REQUIRE(ctx && a && b && c && out, "add3: NULL argument");
+    LELE_REQUIRE(a->dtype == LELE_F32 && b->dtype == LELE_F32 && c->dtype == LELE_F32, "add3: f32 operands required");
+    bool same = a->rank == b->rank && a->rank == c->rank;
+    for (int d = 0; same && d < a->rank; ++d) same = a->shape[d] == b->shape[d] && a->shape[d] == c->shape[d];
+    if (!same) {  // broadcasting operands: two passes, the second in place (legal when c broadcasts INTO a + b's shape)
+        int64_t sh1[LELE_MAX_RANK];
+        int32_t r1 = 0;
+        LELE_TRY(lele_hip_binary(ctx, B_ADD, a, b, out, sh1, &r1));
+        LeleTensor t{out->data, sh1, r1, LELE_F32, LELE_MEM_DEVICE};
+        LELE_REQUIRE(c->rank <= r1, "add3: the third operand would enlarge the sum of the first two");
+        for (int d = 0; d < c->rank; ++d)
+            LELE_REQUIRE(c->shape[c->rank - 1 - d] == 1 || c->shape[c->rank - 1 - d] == sh1[r1 - 1 - d],
+                         "add3: the third operand would enlarge the sum of the first two");
+        return lele_hip_binary(ctx, B_ADD, &t, c, out, out_shape, out_rank);
+    }
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t n = numel(a);
+    LELE_TRY(ctx->arena_reset());
+    const void *da, *db, *dc;
+    LELE_TRY(ctx->dev_ptr(a, &da));
+    LELE_TRY(ctx->dev_ptr(b, &db));
+    LELE_TRY(ctx->dev_ptr(c, &dc));
+    LELE_TRY(out->reserve((size_t)n * 4));
+    if (n) {
+        hipLaunchKernelGGL(add3_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)da, (const float*)db,
+                           (const float*)dc, (float*)out->data, n);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(a->shape, a->shape + a->rank));
 }
 
 int lele_hip_batch_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, const LeleTensor* bias,

@@ -721,6 +721,27 @@ inline std::vector<std::pair<size_t, size_t>> vad_segments(const std::vector<flo
     }
     return merged;
 }
+// fused forms emitted by lele_amd.compiler (bit-identical to the sequences they replace)
+inline TensorView softmax_scaled(const TensorView& x, const TensorView& scale, int64_t axis, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c(), ts = scale.c();
+    check(lele_hip_softmax_scaled(ctx(), &tx, &ts, (int32_t)axis, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView add3(const TensorView& a, const TensorView& b, const TensorView& c, Buffer& out) {
+    Shape sh;
+    LeleTensor ta = a.c(), tb = b.c(), tc = c.c();
+    check(lele_hip_add3(ctx(), &ta, &tb, &tc, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
+inline TensorView depthwise_conv1d_tlc(const TensorView& x, const TensorView& w, const TensorView* bias, int64_t pad_left,
+                                       int64_t pad_right, bool relu, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c(), tw = w.c();
+    Opt ob(bias);
+    check(lele_hip_depthwise_conv1d_tlc(ctx(), &tx, &tw, ob.p, pad_left, pad_right, relu, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
 // view operators: shape bookkeeping only (shape.rs:2-52, 105-185)
 inline TensorView reshape(const TensorView& x, const std::vector<int64_t>& target) {
     const int64_t total = x.size();

@@ -654,6 +654,23 @@ def yolo_seg_postprocess(logits, mask_features, img_width, img_height, threshold
             TensorView(_lib.DevTensor(om, [int(img_height), int(img_width)], np.uint8)))
 
 
+# ------------------------------------------------------------------------------------------- fused forms (lele_amd.compiler)
+def softmax_scaled(input, scale, axis=-1, out=None, ctx=None):
+    """softmax(input * scale[0]): bit-identical to mul(input, scale) followed by softmax"""
+    return _op(ctx, _lib.lib().lele_hip_softmax_scaled, [input, scale], [C.c_int32(axis)], out)
+
+
+def add3(a, b, c, out=None, ctx=None):
+    """(a + b) + c on equal shapes: bit-identical to add(add(a, b), c)"""
+    return _op(ctx, _lib.lib().lele_hip_add3, [a, b, c], [], out)
+
+
+def depthwise_conv1d_tlc(input, weights, bias=None, pad_left=0, pad_right=0, relu=False, out=None, ctx=None):
+    """transpose(0,2,1) -> depthwise conv1d -> transpose(0,2,1) on a time-major [B, T, C] tensor, without the transposes"""
+    return _op(ctx, _lib.lib().lele_hip_depthwise_conv1d_tlc, [input, weights, bias],
+               [C.c_int64(int(pad_left)), C.c_int64(int(pad_right)), C.c_int(int(bool(relu)))], out)
+
+
 # ------------------------------------------------------------------------------------------- ConvInteger family
 def conv_integer(input, weights, x_zero_point=None, w_zero_point=None, dilations=(), group=1, pads=(), strides=(), out=None,
                  ctx=None):

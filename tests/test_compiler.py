@@ -335,3 +335,47 @@ def test_compiled_vision_and_attention_blocks(ctx):
         assert f.count("layer_norm") == 2 and "softmax" in f and "gather" in f and "erf" in f, f
         _, outs = run_plan(ctx, plan, blob, {"x": TensorView(ctx.buf().upload(xa.numpy())), "ids": ids.numpy()})
         assert close(outs[0].numpy(), a(xa, ids).detach().numpy()), opset
+
+
+@pytest.mark.gpu
+def test_extra_fused_kernels_are_bit_identical_to_their_sequences(ctx):
+    from lele_amd import kernels as K
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal((3, 4, 37, 171)) * 4).astype(np.float32)
+    s = np.array([0.0883883], np.float32)
+    for arr in (x, x[..., :8], x.reshape(3, 4, -1)[..., :600], x.reshape(12, -1)[:, :1500]):
+        arr = np.ascontiguousarray(arr)
+        assert np.array_equal(K.softmax_scaled(arr, s, -1, ctx=ctx).numpy(), K.softmax(K.mul(arr, s, ctx=ctx), -1, ctx=ctx).numpy()), arr.shape
+    a, b, c = (rng.standard_normal((5, 33, 64)).astype(np.float32) for _ in range(3))
+    assert np.array_equal(K.add3(a, b, c, ctx=ctx).numpy(), K.add(K.add(a, b, ctx=ctx), c, ctx=ctx).numpy())
+    assert np.array_equal(K.add3(a, b[:, :1], c[0, 0], ctx=ctx).numpy(), (a + b[:, :1]) + c[0, 0])        # broadcast operands: two passes
+    for k, (pl, pr), bias in ((11, (5, 5), False), (3, (1, 1), True), (5, (0, 4), True), (7, (6, 0), False), (11, (0, 0), True)):
+        xt = rng.standard_normal((3, 29, 48)).astype(np.float32)
+        w = rng.standard_normal((48, 1, k)).astype(np.float32)
+        bv = rng.standard_normal(48).astype(np.float32) if bias else None
+        seq = K.transpose(K.conv1d(K.transpose(xt, [0, 2, 1], ctx=ctx), w, bv, [1], 48, [pl, pr], [1], ctx=ctx), [0, 2, 1], ctx=ctx).numpy()
+        assert np.array_equal(K.depthwise_conv1d_tlc(xt, w, bv, pl, pr, ctx=ctx).numpy(), seq), (k, pl, pr, bias)
+
+
+@pytest.mark.gpu
+def test_extra_fusions_leave_a_sensevoice_shaped_model_bit_identical(ctx):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import sensevoice_graph as S
+    from lele_amd.tensor import TensorView
+    enc = S.Encoder(ctx, layers=3)
+    feats = np.random.default_rng(2).standard_normal((1, 41, 560)).astype(np.float32)
+    data = S.encoder_onnx(enc, 1)
+    plans = {}
+    for extra in (False, True):
+        plan, blob = compile_model(data, extra_fusions=extra)
+        plans[extra] = fns(plan)
+        _, outs = run_plan(ctx, plan, blob, {"feats": TensorView(ctx.buf().upload(feats))})
+        plans[extra, "out"] = outs[0].numpy()
+    assert "softmax_scaled" in plans[True] and "add3" in plans[True] and "depthwise_conv1d_tlc" in plans[True]
+    assert not {"softmax_scaled", "add3", "depthwise_conv1d_tlc"} & set(plans[False])
+    saved = sum(1 for f in plans[False] if not f.startswith("host:")) - sum(1 for f in plans[True] if not f.startswith("host:"))
+    assert saved == 3 * 2 + 3 + 2    # per layer: two transposes, one mul; one add in the layers that have both residuals (2 of 3)
+    assert np.array_equal(plans[True, "out"], plans[False, "out"])
+    assert np.array_equal(plans[True, "out"], enc.forward(TensorView(ctx.buf().upload(feats))).numpy())
