@@ -69,6 +69,8 @@ struct LeleCtx {
     std::vector<void*> arena_overflow;  // freed at the next reset
     // LELE_MEM_WEIGHT cache: (host ptr, bytes, tag) -> device copy (tag distinguishes pre-packed forms)
     std::map<std::tuple<const void*, size_t, int>, void*> weights;
+    // device address -> the LeleBuf that owns it (kept current by LeleBuf::reserve), for the row-statistics side channel
+    std::map<const void*, LeleBuf*> buf_of_data;
     // scratch that ops may keep across calls (grown on demand)
     void* scratch = nullptr;
     size_t scratch_cap = 0;
@@ -93,7 +95,15 @@ struct LeleBuf {
     void* data = nullptr;
     size_t cap = 0;
     size_t bytes = 0;  // size of the last result
+    // Side channel producer -> consumer: {min, max} of every row of the result, written by the kernel that produced it
+    // (LayerNorm) so that a dynamic quantisation reading this buffer next need not scan it again (quant.hip).  Valid only
+    // until the buffer is written again: reserve() -- which every op calls on its output -- clears the flag.
+    float* rowstat = nullptr;  // [rowstat_rows][2] on the device
+    size_t rowstat_cap = 0;    // in rows
+    int64_t rowstat_rows = 0, rowstat_len = 0;
+    bool rowstat_valid = false;
     int reserve(size_t n);
+    int reserve_rowstat(int64_t rows);  // may decline (returns 0 with rowstat == nullptr untouched) while capturing
 };
 
 namespace lele {

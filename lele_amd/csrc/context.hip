@@ -95,17 +95,35 @@ int LeleCtx::dev_ptr(const LeleTensor* t, const void** out) {
 }
 
 int LeleBuf::reserve(size_t n) {
+    rowstat_valid = false;  // the buffer is about to be written
     if (n > cap) {
         LELE_REQUIRE(!ctx->capturing, "graph capture: an output buffer would grow; run the sequence once before capturing it");
         LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (data) (void)hipFree(data);
+        if (data) {
+            ctx->buf_of_data.erase(data);
+            (void)hipFree(data);
+        }
         data = nullptr;
         cap = 0;
         size_t c = (n + 4095) & ~size_t(4095);
         LELE_HIP_CHECK(hipMalloc(&data, c));
         cap = c;
+        ctx->buf_of_data[data] = this;
     }
     bytes = n;
+    return 0;
+}
+
+int LeleBuf::reserve_rowstat(int64_t rows) {
+    if ((size_t)rows <= rowstat_cap) return 0;
+    if (ctx->capturing) return 0;  // no allocation while recording: the producer simply does not publish statistics
+    LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (rowstat) (void)hipFree(rowstat);
+    rowstat = nullptr;
+    rowstat_cap = 0;
+    const size_t c = ((size_t)rows + 511) & ~size_t(511);
+    LELE_HIP_CHECK(hipMalloc((void**)&rowstat, c * 8));
+    rowstat_cap = c;
     return 0;
 }
 
@@ -232,8 +250,10 @@ int lele_hip_buf_destroy(LeleBuf* b) {
     if (!b) return 0;
     if (b->data) {
         (void)hipStreamSynchronize(b->ctx->stream);
+        b->ctx->buf_of_data.erase(b->data);
         (void)hipFree(b->data);
     }
+    if (b->rowstat) (void)hipFree(b->rowstat);
     delete b;
     return 0;
 }

@@ -366,7 +366,7 @@ __device__ __forceinline__ void row_sums_reg(const float (&v)[NT], int n, int l,
 template <int NT>
 __global__ void layer_norm_reg_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                       const float* __restrict__ b, float* __restrict__ y, int norm, int64_t outer,
-                                      float eps) {
+                                      float eps, float* __restrict__ rowstat /* NULL or [outer][2]: min, max of each output row */) {
     const int l = threadIdx.x & 31;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (row >= outer) return;
@@ -387,12 +387,27 @@ __global__ void layer_norm_reg_kernel(const float* __restrict__ x, const float* 
     const float var = sumsq * inv_n - mean * mean;
     const float inv_std = 1.0f / sqrtf(var + eps);
     const int body = norm & ~7;
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
         const int j = 32 * c + l;
         if (j < norm) {
             const float t = (v[c] - mean) * inv_std;
-            out[j] = j < body ? fmaf_(t, gg[c], bb[c]) : t * gg[c] + bb[c];
+            const float o = j < body ? fmaf_(t, gg[c], bb[c]) : t * gg[c] + bb[c];
+            out[j] = o;
+            mn = o < mn ? o : mn;  // the comparisons of qminmax_kernel (quant.hip): min / max are order-independent, exact
+            mx = o > mx ? o : mx;
+        }
+    }
+    if (rowstat) {
+        for (int off = 16; off > 0; off >>= 1) {
+            const float a = __shfl_xor(mn, off, 32), c2 = __shfl_xor(mx, off, 32);
+            mn = a < mn ? a : mn;
+            mx = c2 > mx ? c2 : mx;
+        }
+        if (l == 0) {
+            rowstat[2 * row] = mn;
+            rowstat[2 * row + 1] = mx;
         }
     }
 }
@@ -751,19 +766,30 @@ int lele_hip_layer_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* sca
         // rows that fit 32 registers per lane take the single-pass kernel; few rows -> fewer rows per block (more CUs)
         const int rpb = outer >= 4096 ? 8 : (outer >= 1024 ? 4 : 2);
         const dim3 rgrid((unsigned)((outer + rpb - 1) / rpb)), rblock(32 * rpb);
+        // row statistics for a dynamic quantisation that may read this result next (common.h, LeleBuf::rowstat)
+        float* rs = nullptr;
+        if (norm <= 1024) {
+            LELE_TRY(out->reserve_rowstat(outer));
+            if ((size_t)outer <= out->rowstat_cap) rs = out->rowstat;
+        }
         if (norm <= 256)
             hipLaunchKernelGGL(layer_norm_reg_kernel<8>, rgrid, rblock, 0, ctx->stream, (const float*)dx, (const float*)dg,
-                               (const float*)db, (float*)out->data, (int)norm, outer, epsilon);
+                               (const float*)db, (float*)out->data, (int)norm, outer, epsilon, rs);
         else if (norm <= 512)
             hipLaunchKernelGGL(layer_norm_reg_kernel<16>, rgrid, rblock, 0, ctx->stream, (const float*)dx, (const float*)dg,
-                               (const float*)db, (float*)out->data, (int)norm, outer, epsilon);
+                               (const float*)db, (float*)out->data, (int)norm, outer, epsilon, rs);
         else if (norm <= 1024)
             hipLaunchKernelGGL(layer_norm_reg_kernel<32>, rgrid, rblock, 0, ctx->stream, (const float*)dx, (const float*)dg,
-                               (const float*)db, (float*)out->data, (int)norm, outer, epsilon);
+                               (const float*)db, (float*)out->data, (int)norm, outer, epsilon, rs);
         else
-        hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)((outer + 7) / 8)), dim3(256), 0, ctx->stream,
-                           (const float*)dx, (const float*)dg, (const float*)db, (float*)out->data, norm, outer, epsilon);
+            hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)((outer + 7) / 8)), dim3(256), 0, ctx->stream,
+                               (const float*)dx, (const float*)dg, (const float*)db, (float*)out->data, norm, outer, epsilon);
         LELE_HIP_CHECK(hipGetLastError());
+        if (rs) {
+            out->rowstat_rows = outer;
+            out->rowstat_len = norm;
+            out->rowstat_valid = true;
+        }
     }
     return set_shape_v(out_shape, out_rank, std::vector<int64_t>(x->shape, x->shape + x->rank));
 }

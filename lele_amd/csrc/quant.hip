@@ -616,7 +616,17 @@ int lele_hip_fused_quantized_linear(LeleCtx* ctx, const LeleTensor* input, const
     LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));
     const float* partial = nullptr;
     int nblk = 0;
-    LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
+    // If the producer of this tensor (LayerNorm) left per-row {min, max} next to it, they are the range partials: slice s
+    // owns rows [s*m, (s+1)*m), i.e. m consecutive pairs -- the separate range pass over the activation is skipped.
+    if (input->mem == LELE_MEM_DEVICE && m <= 2048) {
+        auto it = ctx->buf_of_data.find(input->data);
+        if (it != ctx->buf_of_data.end() && it->second->rowstat_valid && it->second->rowstat_rows == rows &&
+            it->second->rowstat_len == k) {
+            partial = it->second->rowstat;
+            nblk = (int)m;
+        }
+    }
+    if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
     hipLaunchKernelGGL(qrows_kernel<0>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
                        rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk);
     IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, (const int*)rs, pw.col_sums, (const QParams*)prm, 0,

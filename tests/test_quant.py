@@ -147,3 +147,31 @@ def test_device_dynamic_quantize_and_unfused_chain_bit_exact(ctx, orc):
                           orc.mat_mul_integer(a, bq, [3.0], [250.0]))
     assert np.array_equal(Kk.mat_mul_integer(a[:1], bq, [3.0], [250.0], ctx=ctx).numpy(),
                           orc.mat_mul_integer(a[:1], bq, [3.0], [250.0]))
+
+
+@pytest.mark.gpu
+def test_layer_norm_row_statistics_feed_the_dynamic_quantisation(ctx):
+    """LayerNorm leaves per-row {min, max} next to its result; a fused_quantized_linear reading that buffer skips its own
+    range pass (quant.hip).  The result must not change by a bit -- against the oracle and against the same call on a copy
+    of the activation (which has no statistics attached) -- and a buffer that was rewritten must not reuse stale ones."""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    from oracle import pyoracle as O
+    rng = np.random.default_rng(77)
+    for b, m, k, n in ((1, 504, 512, 384), (32, 171, 512, 256), (3, 7, 560, 64), (2, 5, 1000, 40)):
+        x = (rng.standard_normal((b, m, k)) * 2).astype(np.float32)
+        g, be = (1 + 0.1 * rng.standard_normal(k)).astype(np.float32), (0.1 * rng.standard_normal(k)).astype(np.float32)
+        w = Weight(np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32))
+        ws, wz, bias = Weight((rng.random(n) * 0.01 + 0.002).astype(np.float32)), Weight(np.array([128.0], np.float32)), Weight(rng.standard_normal(n).astype(np.float32))
+        buf = ctx.buf()
+        xn = K.layer_norm(x, g, be, -1, 1e-5, out=buf, ctx=ctx)
+        got = K.fused_quantized_linear(xn, w, ws, wz, bias, False, ctx=ctx).numpy()
+        xn_host = xn.numpy()
+        assert np.array_equal(xn_host, O.layer_norm(x, g, be, -1, 1e-5))
+        want = O.fused_quantized_linear(xn_host, w.arr, ws.arr, wz.arr, bias.arr, False)
+        assert np.array_equal(got, want), (b, m, k, n)
+        assert np.array_equal(K.fused_quantized_linear(xn_host, w, ws, wz, bias, False, ctx=ctx).numpy(), want)   # no statistics: own range pass
+        # rewrite the same buffer with different data of the same shape: the old statistics must not be used
+        y = K.mul(xn, np.array([3.0], np.float32), out=buf, ctx=ctx)
+        assert np.array_equal(K.fused_quantized_linear(y, w, ws, wz, bias, False, ctx=ctx).numpy(),
+                              O.fused_quantized_linear(xn_host * np.float32(3.0), w.arr, ws.arr, wz.arr, bias.arr, False)), (b, m, k, n)
