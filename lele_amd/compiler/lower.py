@@ -437,12 +437,76 @@ class Lowering:
             return self.emit(O, "constant_of_shape", [self.ints(node, 0), {"float": val}])
         if op == "STFT":
             return self.emit(O, "stft", [T(I[0])] + [{"first": self.ints(node, j)} for j in (1,)] + [self.opt_tensor(node, 2)], n_bufs=1)
+        if op == "_ViewCopy":  # synthesised by push_views
+            return self.emit(O, "view_copy", [T(I[0]), {"chain": node.chain}])
         raise CompileError("ONNX operator %s (%r) is not supported by this back-end" % (op, node.name))
+
+    # ---------------------------------------------------------------------------------------- view chains
+    def push_views(self, nodes, cnt):
+        """Split -> Reshape -> Transpose (the head split of a packed QKV projection): every output that is read only through
+        such a chain becomes ONE strided copy straight from the Split's input (`view_copy`), and the Split shrinks to plain
+        slices of the outputs that are still read directly.  Exact copies throughout, so nothing changes but the number of
+        passes over the data."""
+        consumers = {}
+        for idx, n in enumerate(nodes):
+            for i in n.input:
+                consumers.setdefault(i, []).append(idx)
+        drop, replace = set(), {}
+        for idx, n in enumerate(nodes):
+            if n.op_type != "Split" or n.input[0] in self.consts:
+                continue
+            at = _attrs(n)
+            sizes = self.consts.get(n.input[1]) if len(n.input) > 1 and n.input[1] else at.get("split")
+            if sizes is None:
+                continue
+            sizes = [int(v) for v in np.asarray(sizes).reshape(-1)]
+            if len(sizes) != len(n.output):
+                continue
+            axis, starts = at.get("axis", 0), [int(v) for v in np.cumsum([0] + sizes[:-1])]
+            chained, direct = {}, []
+            for j, o in enumerate(n.output):
+                use = consumers.get(o, [])
+                if len(use) == 1 and cnt.get(o, 0) == 1 and nodes[use[0]].op_type == "Reshape" and nodes[use[0]].input[0] == o \
+                        and nodes[use[0]].input[1] in self.consts:
+                    r = nodes[use[0]]
+                    use2 = consumers.get(r.output[0], [])
+                    if len(use2) == 1 and cnt.get(r.output[0], 0) == 1 and nodes[use2[0]].op_type == "Transpose" and _attrs(nodes[use2[0]]).get("perm"):
+                        t = nodes[use2[0]]
+                        chained[j] = (use[0], use2[0], [["slice", axis, starts[j], sizes[j]],
+                                                       ["reshape", [int(v) for v in np.asarray(self.consts[r.input[1]]).reshape(-1)]],
+                                                       ["transpose", _attrs(t)["perm"]]], t.output[0])
+                        continue
+                direct.append(j)
+            if not chained:
+                continue
+            drop.add(idx)
+            pre = []
+            for j in direct:
+                if cnt.get(n.output[j], 0):
+                    v = pb.Node("_ViewCopy", [n.input[0]], [n.output[j]])
+                    v.chain = [["slice", axis, starts[j], sizes[j]]]
+                    pre.append(v)
+            replace[idx] = pre
+            for j, (ri, ti, chain, out) in chained.items():
+                drop.add(ri)
+                v = pb.Node("_ViewCopy", [n.input[0]], [out])
+                v.chain = chain
+                replace[ti] = [v]
+        out_nodes = []
+        for idx, n in enumerate(nodes):
+            if idx in replace:
+                out_nodes += replace[idx]
+            elif idx not in drop:
+                out_nodes.append(n)
+        return out_nodes
 
     # ---------------------------------------------------------------------------------------- driver
     def run(self):
         nodes = self.fold(list(self.model.graph.node))
         cnt = self.uses(nodes)
+        if self.extra_fusions:
+            nodes = self.push_views(nodes, cnt)
+            cnt = self.uses(nodes)
         k = 0
         while k < len(nodes):
             n = nodes[k]

@@ -310,6 +310,85 @@ inline HostArr host_eval(const std::string& op, const std::vector<const HostArr*
     throw Error("host op " + op + " is not supported by the native runner");
 }
 
+// ------------------------------------------------------------------------------------------------ view chains (kernels.py view_copy)
+inline bool reshape_strides(const std::vector<int64_t>& shape, const std::vector<int64_t>& strides, const std::vector<int64_t>& nw,
+                            std::vector<int64_t>* out) {
+    std::vector<std::pair<int64_t, int64_t>> old;
+    for (size_t i = 0; i < shape.size(); ++i)
+        if (shape[i] != 1) old.emplace_back(shape[i], strides[i]);
+    out->assign(nw.size(), 0);
+    size_t oi = 0, ni = 0;
+    while (ni < nw.size() && oi < old.size()) {
+        if (nw[ni] == 1) { ++ni; continue; }
+        int64_t np = nw[ni], op = old[oi].first;
+        size_t nj = ni + 1, oj = oi + 1;
+        while (np != op) {
+            if (np < op) {
+                if (nj >= nw.size()) return false;
+                np *= nw[nj++];
+            } else {
+                if (oj >= old.size()) return false;
+                op *= old[oj++].first;
+            }
+        }
+        for (size_t k = oi; k + 1 < oj; ++k)
+            if (old[k].second != old[k + 1].first * old[k + 1].second) return false;
+        (*out)[nj - 1] = old[oj - 1].second;
+        for (size_t k = nj - 1; k > ni; --k) (*out)[k - 1] = (*out)[k] * nw[k];
+        ni = nj;
+        oi = oj;
+    }
+    if (oi < old.size()) return false;
+    for (size_t k = ni; k < nw.size(); ++k)
+        if (nw[k] != 1) return false;
+    return true;
+}
+
+inline TensorView view_copy(const TensorView& x, const Json& chain, Buffer& out) {
+    std::vector<int64_t> shape = x.shape, strides = detail::row_major_strides(x.shape);
+    int64_t offset = 0;
+    for (const Json& step : chain.arr) {
+        const std::string& kind = step.arr.at(0).str;
+        const int64_t nd = (int64_t)shape.size();
+        if (kind == "slice") {
+            int64_t axis = step.arr.at(1).as_int();
+            const int64_t start = step.arr.at(2).as_int(), len = step.arr.at(3).as_int();
+            if (axis < 0) axis += nd;
+            if (axis < 0 || axis >= nd || start < 0 || start + len > shape[(size_t)axis]) throw Error("view_copy: slice outside the dimension");
+            offset += start * strides[(size_t)axis];
+            shape[(size_t)axis] = len;
+        } else if (kind == "reshape") {
+            std::vector<int64_t> tgt;
+            for (const Json& d : step.arr.at(1).arr) tgt.push_back(d.as_int());
+            int64_t total = 1, known = 1;
+            for (int64_t d : shape) total *= d;
+            int infer = -1;
+            for (size_t i = 0; i < tgt.size(); ++i) {
+                if (tgt[i] == 0 && i < shape.size()) tgt[i] = shape[i];
+                if (tgt[i] == -1) infer = (int)i; else known *= tgt[i];
+            }
+            if (infer >= 0) tgt[(size_t)infer] = known ? total / known : 0;
+            std::vector<int64_t> st;
+            if (!reshape_strides(shape, strides, tgt, &st)) throw Error("view_copy: this reshape needs a copy");
+            shape = tgt;
+            strides = st;
+        } else if (kind == "transpose") {
+            std::vector<int64_t> ns, nt;
+            for (const Json& p : step.arr.at(1).arr) {
+                int64_t q = p.as_int();
+                if (q < 0) q += nd;
+                ns.push_back(shape.at((size_t)q));
+                nt.push_back(strides.at((size_t)q));
+            }
+            shape = ns;
+            strides = nt;
+        } else {
+            throw Error("view_copy: unknown step " + kind);
+        }
+    }
+    return kernels::strided(x, shape, strides, offset, nullptr, out);
+}
+
 // ------------------------------------------------------------------------------------------------ runner
 class Runner {
    public:
@@ -586,6 +665,7 @@ class Runner {
             return set(st, 0, K::resize_nearest(x, oh, ow, a[3].at("str").str == "asymmetric", o));
         }
         if (fn == "transpose") return set(st, 0, K::transpose(tensor(a[0]), ints(a[1]), o));
+        if (fn == "view_copy") return set(st, 0, view_copy(tensor(a[0]), a[1].at("chain"), o));
         if (fn == "concat") {
             std::vector<TV> hold;
             for (const Json& e : a[0].at("list").arr) hold.push_back(tensor(e));

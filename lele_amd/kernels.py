@@ -654,6 +654,69 @@ def yolo_seg_postprocess(logits, mask_features, img_width, img_height, threshold
             TensorView(_lib.DevTensor(om, [int(img_height), int(img_width)], np.uint8)))
 
 
+def _reshape_strides(shape, strides, new):
+    """strides of `new` over the same memory, or None when the view cannot be reshaped without a copy"""
+    old = [(d, st) for d, st in zip(shape, strides) if d != 1]
+    out = [0] * len(new)
+    oi, ni = 0, 0
+    while ni < len(new) and oi < len(old):
+        if new[ni] == 1:
+            ni += 1
+            continue
+        np_, op, nj, oj = new[ni], old[oi][0], ni + 1, oi + 1
+        while np_ != op:
+            if np_ < op:
+                if nj >= len(new):
+                    return None
+                np_ *= new[nj]
+                nj += 1
+            else:
+                if oj >= len(old):
+                    return None
+                op *= old[oj][0]
+                oj += 1
+        for k in _b.range(oi, oj - 1):                       # the merged old dims must be contiguous among themselves
+            if old[k][1] != old[k + 1][0] * old[k + 1][1]:
+                return None
+        out[nj - 1] = old[oj - 1][1]
+        for k in _b.range(nj - 1, ni, -1):
+            out[k - 1] = out[k] * new[k]
+        ni, oi = nj, oj
+    if oi < len(old) or any(d != 1 for d in new[ni:]):
+        return None
+    return out
+
+
+def view_copy(input, chain, out=None, ctx=None):
+    """One strided copy for a chain of views of `input`: ["slice", axis, start, length], ["reshape", dims] (0 copies the
+    dimension, one -1 is inferred: shape.rs:2-13), ["transpose", perm].  Equal, bit for bit, to running slice / reshape /
+    transpose one after the other (they are exact copies); emitted by lele_amd.compiler for Split -> Reshape -> Transpose."""
+    shape = list(_shape_of(input))
+    strides = _row_major_strides(shape)
+    offset = 0
+    for step in chain:
+        if step[0] == "slice":
+            _, axis, start, length = step
+            axis = axis + len(shape) if axis < 0 else axis
+            if start < 0 or start + length > shape[axis]:
+                raise _lib.LeleError("view_copy: slice [%d, %d) outside dimension %d" % (start, start + length, shape[axis]))
+            offset += start * strides[axis]
+            shape[axis] = length
+        elif step[0] == "reshape":
+            total = int(np.prod(shape)) if shape else 1
+            new = _try_reshape(shape, list(step[1]), total)
+            st = _reshape_strides(shape, strides, new)
+            if st is None:
+                raise _lib.LeleError("view_copy: reshape %s -> %s needs a copy at this point of the chain" % (shape, new))
+            shape, strides = list(new), st
+        elif step[0] == "transpose":
+            perm = [p + len(shape) if p < 0 else p for p in step[1]]
+            shape, strides = [shape[p] for p in perm], [strides[p] for p in perm]
+        else:
+            raise _lib.LeleError("view_copy: unknown step %r" % (step[0],))
+    return _strided(input, shape, strides, offset, None, out, ctx)
+
+
 # ------------------------------------------------------------------------------------------- fused forms (lele_amd.compiler)
 def softmax_scaled(input, scale, axis=-1, out=None, ctx=None):
     """softmax(input * scale[0]): bit-identical to mul(input, scale) followed by softmax"""

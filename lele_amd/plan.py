@@ -10,7 +10,7 @@ A plan is JSON: `inputs`, `outputs`, `slots` (workspace buffers, lele's `ws.buf_
 
 Argument nodes: {"ref"}, {"weight"}, {"list"}, {"int"|"float"|"bool"|"str"}, {"none"}, {"some"}, {"slot"}, {"buf"},
 {"ints": name} (a host integer value as a list), {"first": node} (first element of an integer list),
-{"array": [...], "dtype"} (a literal host tensor).
+{"array": [...], "dtype"} (a literal host tensor), {"chain": [...]} (the view steps of a `view_copy`).
 """
 import time
 
@@ -86,6 +86,8 @@ class Runner:
             return [float(v) for v in a] if a.dtype == np.float32 else [int(v) for v in a]
         if "ints" in n:
             return self._host_ints(env[n["ints"]])
+        if "chain" in n:
+            return n["chain"]
         if "array" in n:
             return np.asarray(n["array"], np.int64 if n.get("dtype") == "i64" else np.float32)
         if "first" in n:

@@ -355,6 +355,13 @@ def test_extra_fused_kernels_are_bit_identical_to_their_sequences(ctx):
         bv = rng.standard_normal(48).astype(np.float32) if bias else None
         seq = K.transpose(K.conv1d(K.transpose(xt, [0, 2, 1], ctx=ctx), w, bv, [1], 48, [pl, pr], [1], ctx=ctx), [0, 2, 1], ctx=ctx).numpy()
         assert np.array_equal(K.depthwise_conv1d_tlc(xt, w, bv, pl, pr, ctx=ctx).numpy(), seq), (k, pl, pr, bias)
+    qkv = rng.standard_normal((3, 41, 1536)).astype(np.float32)
+    for start, perm in ((0, [0, 2, 1, 3]), (512, [0, 2, 3, 1]), (1024, [0, 2, 1, 3])):
+        chain = [["slice", 2, start, 512], ["reshape", [0, 0, 4, 128]], ["transpose", perm]]
+        assert np.array_equal(K.view_copy(qkv, chain, ctx=ctx).numpy(), qkv[:, :, start:start + 512].reshape(3, 41, 4, 128).transpose(perm))
+    assert np.array_equal(K.view_copy(qkv, [["slice", -1, 100, 7]], ctx=ctx).numpy(), qkv[..., 100:107])
+    with pytest.raises(Exception, match="needs a copy"):
+        K.view_copy(qkv, [["transpose", [0, 2, 1]], ["reshape", [-1]]], ctx=ctx)
 
 
 @pytest.mark.gpu
@@ -373,9 +380,12 @@ def test_extra_fusions_leave_a_sensevoice_shaped_model_bit_identical(ctx):
         plans[extra] = fns(plan)
         _, outs = run_plan(ctx, plan, blob, {"feats": TensorView(ctx.buf().upload(feats))})
         plans[extra, "out"] = outs[0].numpy()
-    assert "softmax_scaled" in plans[True] and "add3" in plans[True] and "depthwise_conv1d_tlc" in plans[True]
-    assert not {"softmax_scaled", "add3", "depthwise_conv1d_tlc"} & set(plans[False])
+    assert {"softmax_scaled", "add3", "depthwise_conv1d_tlc", "view_copy"} <= set(plans[True])
+    assert not {"softmax_scaled", "add3", "depthwise_conv1d_tlc", "view_copy"} & set(plans[False])
+    assert plans[True].count("view_copy") == 9 and "split" not in plans[True]   # per layer: q and k heads straight from qkv, one slice for v
     saved = sum(1 for f in plans[False] if not f.startswith("host:")) - sum(1 for f in plans[True] if not f.startswith("host:"))
-    assert saved == 3 * 2 + 3 + 2    # per layer: two transposes, one mul; one add in the layers that have both residuals (2 of 3)
+    # per layer: two transposes (FSMN), one mul, the q / k reshape + transpose pairs' reshapes (2) and split 1 -> 1 slice (0);
+    # one add in the layers that have both residuals (2 of 3)
+    assert saved == 3 * (2 + 1 + 2) + 2
     assert np.array_equal(plans[True, "out"], plans[False, "out"])
     assert np.array_equal(plans[True, "out"], enc.forward(TensorView(ctx.buf().upload(feats))).numpy())
