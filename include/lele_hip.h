@@ -322,6 +322,19 @@ int lele_hip_add3(LeleCtx* ctx, const LeleTensor* a, const LeleTensor* b, const 
 int lele_hip_depthwise_conv1d_tlc(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias, int64_t pad_left,
                                   int64_t pad_right, int relu, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
 
+/* Batched matmul whose operands and result are STRIDED VIEWS (heads inside a packed [B, T, 3*D] projection; the result
+ * stored straight into the [B, T, H, Dh] layout): the same MFMA kernels and tile choice as lele_hip_matmul, so the values
+ * are bit-identical to copying the views out (slice / reshape / transpose) and calling matmul.  Element (bo, bi, r, c) of a
+ * view lives at data[offset + bo*stride_outer + bi*stride_inner + r*stride_row + c*stride_col] (in elements); A is [m, k],
+ * B is [k, n], the result [m, n]; A and B need unit stride along one of their two dimensions, the result along n.
+ * out_dims is the shape reported for `out` (batch_outer*batch_inner*m*n elements). */
+typedef struct LeleMatView {
+    int64_t offset, stride_outer, stride_inner, stride_row, stride_col;
+} LeleMatView;
+int lele_hip_matmul_view(LeleCtx* ctx, const LeleTensor* a, const LeleMatView* a_view, const LeleTensor* b, const LeleMatView* b_view,
+                         int64_t batch_outer, int64_t batch_inner, int64_t m, int64_t k, int64_t n, const LeleMatView* out_view,
+                         const int64_t* out_dims, int32_t out_dims_rank, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+
 #ifdef __cplusplus
 }
 #endif

@@ -437,6 +437,10 @@ class Lowering:
             return self.emit(O, "constant_of_shape", [self.ints(node, 0), {"float": val}])
         if op == "STFT":
             return self.emit(O, "stft", [T(I[0])] + [{"first": self.ints(node, j)} for j in (1,)] + [self.opt_tensor(node, 2)], n_bufs=1)
+        if op == "_MatMulView":  # synthesised by fold_matmul_views
+            opt = lambda v: {"none": 1} if v is None else {"list": [{"int": int(d)} for d in v]}  # noqa: E731
+            return self.emit(O, "matmul_view", [T(I[0]), {"chain": node.a_chain}, T(I[1]), {"chain": node.b_chain}, opt(node.out_perm),
+                                                opt(node.out_reshape)])
         if op == "_ViewCopy":  # synthesised by push_views
             return self.emit(O, "view_copy", [T(I[0]), {"chain": node.chain}])
         raise CompileError("ONNX operator %s (%r) is not supported by this back-end" % (op, node.name))
@@ -498,7 +502,79 @@ class Lowering:
                 out_nodes += replace[idx]
             elif idx not in drop:
                 out_nodes.append(n)
-        return out_nodes
+        return self.fold_matmul_views(out_nodes)
+
+    def fold_matmul_views(self, nodes):
+        """MatMul whose operands are private view copies (head views of a packed projection, a Reshape -> Transpose of a
+        tensor) and/or whose result is only read through Transpose [-> Reshape]: the views go into the GEMM's loaders and
+        store (`matmul_view`) -- same kernels and tiles, so the same bits, without the copies."""
+        cnt = self.uses(nodes)
+        producer, consumers = {}, {}
+        for idx, n in enumerate(nodes):
+            for o in n.output:
+                producer[o] = idx
+            for i in n.input:
+                consumers.setdefault(i, []).append(idx)
+        drop, replace = set(), {}
+
+        def unit_dim_stays_inner(chain, rank_hint=None):
+            # the source's innermost (unit-stride) dimension must end up among the last two logical dimensions
+            pos = None
+            for step in chain:
+                if step[0] == "reshape":
+                    pos = len(step[1]) - 1
+                elif step[0] == "transpose":
+                    perm = step[1]
+                    src = (len(perm) - 1) if pos is None else pos
+                    if src not in [p % len(perm) for p in perm[-2:]]:
+                        return False
+                    pos = [p % len(perm) for p in perm].index(src)
+            return True
+
+        def operand(name):
+            """(source, chain, nodes to drop) for one MatMul operand"""
+            i = producer.get(name)
+            if i is None or cnt.get(name, 0) != 1 or i in drop:
+                return name, [], []
+            n = nodes[i]
+            if n.op_type == "_ViewCopy" and unit_dim_stays_inner(n.chain):
+                return n.input[0], n.chain, [i]
+            if n.op_type == "Transpose" and _attrs(n).get("perm"):
+                perm = _attrs(n)["perm"]
+                j = producer.get(n.input[0])
+                if j is not None and cnt.get(n.input[0], 0) == 1 and nodes[j].op_type == "Reshape" and nodes[j].input[1] in self.consts \
+                        and nodes[j].input[0] not in self.consts:
+                    chain = [["reshape", [int(v) for v in np.asarray(self.consts[nodes[j].input[1]]).reshape(-1)]], ["transpose", perm]]
+                    if unit_dim_stays_inner(chain):
+                        return nodes[j].input[0], chain, [i, j]
+                chain = [["transpose", perm]]
+                if n.input[0] not in self.consts and unit_dim_stays_inner(chain):
+                    return n.input[0], chain, [i]
+            return name, [], []
+
+        for idx, n in enumerate(nodes):
+            if n.op_type != "MatMul" or any(i in self.consts for i in n.input):
+                continue
+            a_src, a_chain, a_drop = operand(n.input[0])
+            b_src, b_chain, b_drop = operand(n.input[1])
+            out, out_perm, out_reshape, o_drop = n.output[0], None, None, []
+            use = consumers.get(out, [])
+            if len(use) == 1 and cnt.get(out, 0) == 1 and nodes[use[0]].op_type == "Transpose":
+                perm = _attrs(nodes[use[0]]).get("perm")
+                if perm and perm[-1] % len(perm) == len(perm) - 1:      # n stays innermost: the store stays row-contiguous
+                    out_perm, o_drop, out = perm, [use[0]], nodes[use[0]].output[0]
+                    use2 = consumers.get(out, [])
+                    if len(use2) == 1 and cnt.get(out, 0) == 1 and nodes[use2[0]].op_type == "Reshape" and nodes[use2[0]].input[1] in self.consts:
+                        out_reshape = [int(v) for v in np.asarray(self.consts[nodes[use2[0]].input[1]]).reshape(-1)]
+                        o_drop.append(use2[0])
+                        out = nodes[use2[0]].output[0]
+            if not a_chain and not b_chain and out_perm is None:
+                continue
+            v = pb.Node("_MatMulView", [a_src, b_src], [out])
+            v.a_chain, v.b_chain, v.out_perm, v.out_reshape = a_chain, b_chain, out_perm, out_reshape
+            replace[idx] = [v]
+            drop.update(a_drop + b_drop + o_drop)
+        return [m for idx, n in enumerate(nodes) for m in (replace.get(idx, [n]) if idx not in drop or idx in replace else [])]
 
     # ---------------------------------------------------------------------------------------- driver
     def run(self):

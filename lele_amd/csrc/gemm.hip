@@ -153,4 +153,55 @@ int lele_hip_gemm(LeleCtx* ctx, const LeleTensor* a, const LeleTensor* b, const 
     return set_shape(out_shape, out_rank, {m, n});
 }
 
+int lele_hip_matmul_view(LeleCtx* ctx, const LeleTensor* a, const LeleMatView* av, const LeleTensor* b, const LeleMatView* bv,
+                         int64_t batch_outer, int64_t batch_inner, int64_t m, int64_t k, int64_t n, const LeleMatView* ov,
+                         const int64_t* out_dims, int32_t out_dims_rank, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && a && av && b && bv && ov && out && out_dims, "matmul_view: NULL argument");
+    LELE_REQUIRE(a->dtype == LELE_F32 && b->dtype == LELE_F32, "matmul_view: operands must be f32");
+    LELE_REQUIRE(batch_outer >= 1 && batch_inner >= 1 && m >= 0 && n >= 0 && k >= 0, "matmul_view: bad dimensions");
+    LELE_REQUIRE(av->stride_col == 1 || av->stride_row == 1, "matmul_view: A must be contiguous along k or along its rows");
+    LELE_REQUIRE(bv->stride_col == 1 || bv->stride_row == 1, "matmul_view: B must be contiguous along n or along k");
+    LELE_REQUIRE(ov->stride_col == 1, "matmul_view: the output must be contiguous along n");
+    const int64_t fb = batch_outer * batch_inner, na = numel(a), nb = numel(b);
+    int64_t total = 1;
+    for (int i = 0; i < out_dims_rank; ++i) total *= out_dims[i];
+    LELE_REQUIRE(total == fb * m * n, "matmul_view: output shape holds %lld elements, the product has %lld", (long long)total,
+                 (long long)(fb * m * n));
+    LELE_REQUIRE(fb < (int64_t(1) << 31) && m < (int64_t(1) << 31) && n < (int64_t(1) << 31) && k < (int64_t(1) << 31), "matmul_view: dimension too large");
+    // the last element each view can touch must lie inside its tensor
+    auto last = [&](const LeleMatView* v, int64_t r, int64_t c) {
+        return v->offset + (batch_outer - 1) * v->stride_outer + (batch_inner - 1) * v->stride_inner + (r - 1) * v->stride_row + (c - 1) * v->stride_col;
+    };
+    if (fb * m * k) LELE_REQUIRE(av->offset >= 0 && last(av, m, k) < na, "matmul_view: the A view leaves its tensor");
+    if (fb * k * n) LELE_REQUIRE(bv->offset >= 0 && last(bv, k, n) < nb, "matmul_view: the B view leaves its tensor");
+    if (total) LELE_REQUIRE(ov->offset >= 0 && last(ov, m, n) < total, "matmul_view: the output view leaves its buffer");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    LELE_TRY(ctx->arena_reset());
+    const void *da = nullptr, *db = nullptr;
+    LELE_TRY(ctx->dev_ptr(a, &da));
+    LELE_TRY(ctx->dev_ptr(b, &db));
+    LELE_TRY(out->reserve((size_t)total * 4));
+    if (total) {
+        const float* pa = (const float*)da + av->offset;
+        const float* pb = (const float*)db + bv->offset;
+        const int bi = (int)batch_inner;
+        gemm::EpiAffine epi{(float*)out->data + ov->offset, ov->stride_outer, (int)m, (int)n, 1.0f, 0.0f, nullptr, gemm::C_NONE, 0,
+                            ov->stride_row, bi, ov->stride_inner};
+        // A(row, k): k-contiguous -> LoadRowK(ld = row stride); row-contiguous -> LoadKRow(ld = k stride).  B likewise on (n, k).
+        gemm::LoadRowK a_rk{pa, av->stride_outer, av->stride_row, (int)m, (int)k,
+                            (int)(aligned16(pa) && av->stride_row % 4 == 0 && av->stride_outer % 4 == 0 && av->stride_inner % 4 == 0), bi, av->stride_inner};
+        gemm::LoadKRow a_kr{pa, av->stride_outer, av->stride_col, (int)m, (int)k, bi, av->stride_inner};
+        gemm::LoadKRow b_kn{pb, bv->stride_outer, bv->stride_row, (int)n, (int)k, bi, bv->stride_inner};
+        gemm::LoadRowK b_nk{pb, bv->stride_outer, bv->stride_col, (int)n, (int)k,
+                            (int)(aligned16(pb) && bv->stride_col % 4 == 0 && bv->stride_outer % 4 == 0 && bv->stride_inner % 4 == 0), bi, bv->stride_inner};
+        const bool a_k = av->stride_col == 1, b_n = bv->stride_col == 1;
+        if (a_k && b_n) gemm::launch(ctx->stream, a_rk, b_kn, epi, (int)m, (int)n, (int)k, (int)fb, ctx->num_cus);
+        else if (a_k && !b_n) gemm::launch(ctx->stream, a_rk, b_nk, epi, (int)m, (int)n, (int)k, (int)fb, ctx->num_cus);
+        else if (!a_k && b_n) gemm::launch(ctx->stream, a_kr, b_kn, epi, (int)m, (int)n, (int)k, (int)fb, ctx->num_cus);
+        else gemm::launch(ctx->stream, a_kr, b_nk, epi, (int)m, (int)n, (int)k, (int)fb, ctx->num_cus);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(out_dims, out_dims + out_dims_rank));
+}
+
 }  // extern "C"

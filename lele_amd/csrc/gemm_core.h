@@ -41,14 +41,20 @@ struct LoadRowK {
     int64_t ld;
     int rows, K;
     int vec;  // 1 when float4 loads are legal (base and ld 16-B aligned)
+    // two-level batch (lele_hip_matmul_view: heads inside a packed tensor): b -> (b / binner) * bs + (b % binner) * bs2
+    int binner = 1;
+    int64_t bs2 = 0;
     static constexpr bool kRowFast = false;
     struct Row {
         const float* q;
         bool rin;
     };
+    __device__ __forceinline__ int64_t boff(int b) const {
+        return binner > 1 ? (int64_t)(b / binner) * bs + (int64_t)(b % binner) * bs2 : (int64_t)b * bs;
+    }
     __device__ __forceinline__ Row row(int b, int r) const {
         const bool rin = r < rows;
-        return Row{p + (int64_t)b * bs + (int64_t)(rin ? r : rows - 1) * ld, rin};
+        return Row{p + boff(b) + (int64_t)(rin ? r : rows - 1) * ld, rin};
     }
     __device__ __forceinline__ float4 get4(const Row& r, int k) const {
         float4 v;
@@ -70,15 +76,20 @@ struct LoadKRow {
     int64_t bs;
     int64_t ld;
     int rows, K;
+    int binner = 1;  // two-level batch, as LoadRowK
+    int64_t bs2 = 0;
     static constexpr bool kRowFast = true;
     struct Row {
         const float* base;  // p + batch offset: uniform over the workgroup
         unsigned off;       // clamped row
         bool rin;
     };
+    __device__ __forceinline__ int64_t boff(int b) const {
+        return binner > 1 ? (int64_t)(b / binner) * bs + (int64_t)(b % binner) * bs2 : (int64_t)b * bs;
+    }
     __device__ __forceinline__ Row row(int b, int r) const {
         const bool rin = r < rows;
-        return Row{p + (int64_t)b * bs, (unsigned)(rin ? r : rows - 1), rin};
+        return Row{p + boff(b), (unsigned)(rin ? r : rows - 1), rin};
     }
     __device__ __forceinline__ float4 get4(const Row& r, int k) const {
         const int last = K - 1;
@@ -110,6 +121,15 @@ struct EpiAffine {
     const float* c;
     int cmode;
     int64_t clen;
+    // strided output (lele_hip_matmul_view: the product stored straight into a transposed layout): row pitch ldo (0 = N),
+    // two-level batch as the loaders.  The C operand is not combined with it.
+    int64_t ldo = 0;
+    int binner = 1;
+    int64_t bs2 = 0;
+    __device__ __forceinline__ int64_t ooff(int b, int row) const {
+        const int64_t bo = binner > 1 ? (int64_t)(b / binner) * bs + (int64_t)(b % binner) * bs2 : (int64_t)b * bs;
+        return bo + (int64_t)row * (ldo ? ldo : (int64_t)N);
+    }
     __device__ __forceinline__ float load(int b, int row, int col) const {
         if (cmode == C_NONE) return 0.0f;  // uniform branch (kernel argument)
         int64_t idx;
@@ -124,7 +144,7 @@ struct EpiAffine {
     }
     __device__ __forceinline__ void store(int b, int row, int col, float acc, float pre) const {
         if (row >= M || col >= N) return;
-        out[(int64_t)b * bs + (int64_t)row * N + col] = __builtin_fmaf(alpha, acc, cmode == C_NONE ? 0.0f : pre * beta);
+        out[ooff(b, row) + col] = __builtin_fmaf(alpha, acc, cmode == C_NONE ? 0.0f : pre * beta);
     }
 };
 

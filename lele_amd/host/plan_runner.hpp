@@ -344,49 +344,111 @@ inline bool reshape_strides(const std::vector<int64_t>& shape, const std::vector
     return true;
 }
 
-inline TensorView view_copy(const TensorView& x, const Json& chain, Buffer& out) {
-    std::vector<int64_t> shape = x.shape, strides = detail::row_major_strides(x.shape);
+struct ViewGeom {
+    std::vector<int64_t> shape, strides;
     int64_t offset = 0;
+};
+inline ViewGeom walk_chain(const std::vector<int64_t>& src_shape, const Json& chain) {
+    ViewGeom g;
+    g.shape = src_shape;
+    g.strides = detail::row_major_strides(src_shape);
     for (const Json& step : chain.arr) {
         const std::string& kind = step.arr.at(0).str;
-        const int64_t nd = (int64_t)shape.size();
+        const int64_t nd = (int64_t)g.shape.size();
         if (kind == "slice") {
             int64_t axis = step.arr.at(1).as_int();
             const int64_t start = step.arr.at(2).as_int(), len = step.arr.at(3).as_int();
             if (axis < 0) axis += nd;
-            if (axis < 0 || axis >= nd || start < 0 || start + len > shape[(size_t)axis]) throw Error("view_copy: slice outside the dimension");
-            offset += start * strides[(size_t)axis];
-            shape[(size_t)axis] = len;
+            if (axis < 0 || axis >= nd || start < 0 || start + len > g.shape[(size_t)axis]) throw Error("view: slice outside the dimension");
+            g.offset += start * g.strides[(size_t)axis];
+            g.shape[(size_t)axis] = len;
         } else if (kind == "reshape") {
             std::vector<int64_t> tgt;
             for (const Json& d : step.arr.at(1).arr) tgt.push_back(d.as_int());
             int64_t total = 1, known = 1;
-            for (int64_t d : shape) total *= d;
+            for (int64_t d : g.shape) total *= d;
             int infer = -1;
             for (size_t i = 0; i < tgt.size(); ++i) {
-                if (tgt[i] == 0 && i < shape.size()) tgt[i] = shape[i];
+                if (tgt[i] == 0 && i < g.shape.size()) tgt[i] = g.shape[i];
                 if (tgt[i] == -1) infer = (int)i; else known *= tgt[i];
             }
             if (infer >= 0) tgt[(size_t)infer] = known ? total / known : 0;
             std::vector<int64_t> st;
-            if (!reshape_strides(shape, strides, tgt, &st)) throw Error("view_copy: this reshape needs a copy");
-            shape = tgt;
-            strides = st;
+            if (!reshape_strides(g.shape, g.strides, tgt, &st)) throw Error("view: this reshape needs a copy");
+            g.shape = tgt;
+            g.strides = st;
         } else if (kind == "transpose") {
             std::vector<int64_t> ns, nt;
             for (const Json& p : step.arr.at(1).arr) {
                 int64_t q = p.as_int();
                 if (q < 0) q += nd;
-                ns.push_back(shape.at((size_t)q));
-                nt.push_back(strides.at((size_t)q));
+                ns.push_back(g.shape.at((size_t)q));
+                nt.push_back(g.strides.at((size_t)q));
             }
-            shape = ns;
-            strides = nt;
+            g.shape = ns;
+            g.strides = nt;
         } else {
-            throw Error("view_copy: unknown step " + kind);
+            throw Error("view: unknown step " + kind);
         }
     }
-    return kernels::strided(x, shape, strides, offset, nullptr, out);
+    return g;
+}
+
+inline TensorView view_copy(const TensorView& x, const Json& chain, Buffer& out) {
+    const ViewGeom g = walk_chain(x.shape, chain);
+    return kernels::strided(x, g.shape, g.strides, g.offset, nullptr, out);
+}
+
+// kernels.py matmul_view: matmul of two views, the product optionally stored transposed (out_perm) and reshaped
+inline TensorView matmul_view(const TensorView& a, const Json& a_chain, const TensorView& b, const Json& b_chain,
+                              const std::vector<int64_t>* out_perm, const std::vector<int64_t>* out_reshape, Buffer& out) {
+    const ViewGeom ga = walk_chain(a.shape, a_chain), gb = walk_chain(b.shape, b_chain);
+    const size_t r = ga.shape.size();
+    if (r != gb.shape.size() || r < 2 || r > 4) throw Error("matmul_view: operand views must have equal rank 2..4");
+    for (size_t i = 0; i + 2 < r; ++i)
+        if (ga.shape[i] != gb.shape[i]) throw Error("matmul_view: batch dimensions differ");
+    const int64_t m = ga.shape[r - 2], k = ga.shape[r - 1], n = gb.shape[r - 1];
+    if (k != gb.shape[r - 2]) throw Error("MatMul K dim mismatch");
+    const int64_t bo = r >= 3 ? ga.shape[0] : 1, bi = r == 4 ? ga.shape[1] : 1;
+    auto view = [&](const std::vector<int64_t>& st, int64_t off) {
+        return LeleMatView{off, r >= 3 ? st[0] : 0, r == 4 ? st[1] : 0, st[r - 2], st[r - 1]};
+    };
+    std::vector<int64_t> logical(ga.shape.begin(), ga.shape.end() - 2);
+    logical.push_back(m);
+    logical.push_back(n);
+    std::vector<int64_t> perm;
+    for (size_t i = 0; i < r; ++i) perm.push_back(out_perm ? ((*out_perm)[i] + (int64_t)r) % (int64_t)r : (int64_t)i);
+    std::vector<int64_t> phys;
+    for (int64_t p : perm) phys.push_back(logical[(size_t)p]);
+    const std::vector<int64_t> pstr = detail::row_major_strides(phys);
+    std::vector<int64_t> lstr(r, 0);
+    for (size_t j = 0; j < r; ++j) lstr[(size_t)perm[j]] = pstr[j];
+    std::vector<int64_t> oshape = phys;
+    if (out_reshape) {
+        Json fake;  // reuse the reshape rule of walk_chain on the contiguous physical shape
+        fake.kind = Json::Arr;
+        Json step, dims, name;
+        step.kind = Json::Arr;
+        dims.kind = Json::Arr;
+        name.kind = Json::Str;
+        name.str = "reshape";
+        for (int64_t d : *out_reshape) {
+            Json e;
+            e.kind = Json::Num;
+            e.is_int = true;
+            e.inum = d;
+            dims.arr.push_back(e);
+        }
+        step.arr = {name, dims};
+        fake.arr.push_back(step);
+        oshape = walk_chain(phys, fake).shape;
+    }
+    const LeleMatView av = view(ga.strides, ga.offset), bv = view(gb.strides, gb.offset), ov = view(lstr, 0);
+    detail::Shape sh;
+    LeleTensor ta = a.c(), tb = b.c();
+    check(lele_hip_matmul_view(detail::ctx(), &ta, &av, &tb, &bv, bo, bi, m, k, n, &ov, oshape.data(), (int32_t)oshape.size(), out.raw(), sh.dims,
+                               &sh.rank));
+    return TensorView::from_device(out, sh.vec(), LELE_F32);
 }
 
 // ------------------------------------------------------------------------------------------------ runner
@@ -666,6 +728,13 @@ class Runner {
         }
         if (fn == "transpose") return set(st, 0, K::transpose(tensor(a[0]), ints(a[1]), o));
         if (fn == "view_copy") return set(st, 0, view_copy(tensor(a[0]), a[1].at("chain"), o));
+        if (fn == "matmul_view") {
+            std::vector<int64_t> perm, resh;
+            if (!is_none(a[4])) perm = ints(a[4]);
+            if (!is_none(a[5])) resh = ints(a[5]);
+            return set(st, 0, matmul_view(tensor(a[0]), a[1].at("chain"), tensor(a[2]), a[3].at("chain"), is_none(a[4]) ? nullptr : &perm,
+                                          is_none(a[5]) ? nullptr : &resh, o));
+        }
         if (fn == "concat") {
             std::vector<TV> hold;
             for (const Json& e : a[0].at("list").arr) hold.push_back(tensor(e));

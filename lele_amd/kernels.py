@@ -687,11 +687,9 @@ def _reshape_strides(shape, strides, new):
     return out
 
 
-def view_copy(input, chain, out=None, ctx=None):
-    """One strided copy for a chain of views of `input`: ["slice", axis, start, length], ["reshape", dims] (0 copies the
-    dimension, one -1 is inferred: shape.rs:2-13), ["transpose", perm].  Equal, bit for bit, to running slice / reshape /
-    transpose one after the other (they are exact copies); emitted by lele_amd.compiler for Split -> Reshape -> Transpose."""
-    shape = list(_shape_of(input))
+def _walk_chain(shape, chain):
+    """(shape, strides, offset) of the view `chain` describes over a contiguous tensor of `shape`"""
+    shape = list(shape)
     strides = _row_major_strides(shape)
     offset = 0
     for step in chain:
@@ -699,22 +697,75 @@ def view_copy(input, chain, out=None, ctx=None):
             _, axis, start, length = step
             axis = axis + len(shape) if axis < 0 else axis
             if start < 0 or start + length > shape[axis]:
-                raise _lib.LeleError("view_copy: slice [%d, %d) outside dimension %d" % (start, start + length, shape[axis]))
+                raise _lib.LeleError("view: slice [%d, %d) outside dimension %d" % (start, start + length, shape[axis]))
             offset += start * strides[axis]
             shape[axis] = length
         elif step[0] == "reshape":
             total = int(np.prod(shape)) if shape else 1
             new = _try_reshape(shape, list(step[1]), total)
-            st = _reshape_strides(shape, strides, new)
+            st = _reshape_strides(shape, strides, new) if new is not None else None
             if st is None:
-                raise _lib.LeleError("view_copy: reshape %s -> %s needs a copy at this point of the chain" % (shape, new))
+                raise _lib.LeleError("view: reshape %s -> %s needs a copy at this point of the chain" % (shape, list(step[1])))
             shape, strides = list(new), st
         elif step[0] == "transpose":
             perm = [p + len(shape) if p < 0 else p for p in step[1]]
             shape, strides = [shape[p] for p in perm], [strides[p] for p in perm]
         else:
-            raise _lib.LeleError("view_copy: unknown step %r" % (step[0],))
+            raise _lib.LeleError("view: unknown step %r" % (step[0],))
+    return shape, strides, offset
+
+
+def view_copy(input, chain, out=None, ctx=None):
+    """One strided copy for a chain of views of `input`: ["slice", axis, start, length], ["reshape", dims] (0 copies the
+    dimension, one -1 is inferred: shape.rs:2-13), ["transpose", perm].  Equal, bit for bit, to running slice / reshape /
+    transpose one after the other (they are exact copies); emitted by lele_amd.compiler for Split -> Reshape -> Transpose."""
+    shape, strides, offset = _walk_chain(_shape_of(input), chain)
     return _strided(input, shape, strides, offset, None, out, ctx)
+
+
+class _MatView(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("stride_outer", C.c_int64), ("stride_inner", C.c_int64), ("stride_row", C.c_int64),
+                ("stride_col", C.c_int64)]
+
+
+def matmul_view(a, a_chain, b, b_chain, out_perm=None, out_reshape=None, out=None, ctx=None):
+    """matmul(view(a), view(b)) with the views never materialised and, optionally, the product stored as
+    transpose(result, out_perm) [then reshaped]: bit-identical to view_copy + matmul + transpose (same kernels, same tiles)."""
+    ash, ast, aoff = _walk_chain(_shape_of(a), a_chain or [])
+    bsh, bst, boff = _walk_chain(_shape_of(b), b_chain or [])
+    if len(ash) != len(bsh) or not 2 <= len(ash) <= 4 or ash[:-2] != bsh[:-2]:
+        raise _lib.LeleError("matmul_view: operand views %s x %s must have equal batch dimensions and rank 2..4" % (ash, bsh))
+    if ash[-1] != bsh[-2]:
+        raise _lib.LeleError("MatMul K dim mismatch: %d vs %d" % (ash[-1], bsh[-2]))
+    m, k, n = ash[-2], ash[-1], bsh[-1]
+    batch = ash[:-2]
+    bo, bi = (batch + [1, 1])[:2] if batch else (1, 1)
+
+    def bstr(st):
+        lead = st[:-2]
+        return (lead[0] if len(lead) >= 1 else 0), (lead[1] if len(lead) == 2 else 0)
+    logical = batch + [m, n]
+    perm = list(out_perm) if out_perm else list(_b.range(len(logical)))
+    phys = [logical[p] for p in perm]
+    pstr = _row_major_strides(phys)
+    lstr = [pstr[perm.index(j)] for j in _b.range(len(logical))]
+    oshape = phys
+    if out_reshape is not None:
+        oshape = _try_reshape(phys, list(out_reshape), int(np.prod(phys)) if phys else 1)
+        if oshape is None:
+            raise _lib.LeleError("matmul_view: cannot reshape %s to %s" % (phys, list(out_reshape)))
+    av = _MatView(aoff, *bstr(ast), ast[-2], ast[-1])
+    bv = _MatView(boff, *bstr(bst), bst[-2], bst[-1])
+    ov = _MatView(0, *bstr(lstr), lstr[-2], lstr[-1])
+    ctx = _ctx(ctx)
+    keep = []
+    out = out or ctx.buf()
+    dims, _ = _lib.i64_array(oshape, keep)
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_matmul_view(ctx._h, _lib.as_tensor(unwrap(a), keep), C.byref(av), _lib.as_tensor(unwrap(b), keep), C.byref(bv),
+                                               C.c_int64(bo), C.c_int64(bi), C.c_int64(m), C.c_int64(k), C.c_int64(n), C.byref(ov), dims,
+                                               C.c_int32(len(oshape)), out._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
 
 
 # ------------------------------------------------------------------------------------------- fused forms (lele_amd.compiler)

@@ -362,6 +362,27 @@ def test_extra_fused_kernels_are_bit_identical_to_their_sequences(ctx):
     assert np.array_equal(K.view_copy(qkv, [["slice", -1, 100, 7]], ctx=ctx).numpy(), qkv[..., 100:107])
     with pytest.raises(Exception, match="needs a copy"):
         K.view_copy(qkv, [["transpose", [0, 2, 1]], ["reshape", [-1]]], ctx=ctx)
+    # matmul on views == copy the views out, matmul, transpose the result: same kernels and tiles, hence the same bits
+    for b_, t_ in ((3, 41), (1, 504), (32, 171), (2, 7)):
+        qkv = rng.standard_normal((b_, t_, 1536)).astype(np.float32)
+        cq = [["slice", 2, 0, 512], ["reshape", [0, 0, 4, 128]], ["transpose", [0, 2, 1, 3]]]
+        ck = [["slice", 2, 512, 512], ["reshape", [0, 0, 4, 128]], ["transpose", [0, 2, 3, 1]]]
+        cv = [["slice", 2, 1024, 512], ["reshape", [0, 0, 4, 128]], ["transpose", [0, 2, 1, 3]]]
+        dq = ctx.buf().upload(qkv)
+        from lele_amd.tensor import TensorView
+        dqv = TensorView(dq)
+        sc_seq = K.matmul(K.view_copy(dqv, cq, ctx=ctx), K.view_copy(dqv, ck, ctx=ctx), ctx=ctx)
+        sc = K.matmul_view(dqv, cq, dqv, ck, ctx=ctx)
+        assert sc.shape == (b_, 4, t_, t_) and np.array_equal(sc.numpy(), sc_seq.numpy()), (b_, t_)
+        pr = K.softmax(sc, -1, ctx=ctx)
+        av_seq = K.reshape(K.transpose(K.matmul(pr, K.view_copy(dqv, cv, ctx=ctx), ctx=ctx), [0, 2, 1, 3], ctx=ctx), [b_, t_, 512])
+        av = K.matmul_view(pr, [], dqv, cv, out_perm=[0, 2, 1, 3], out_reshape=[0, 0, 512], ctx=ctx)
+        assert av.shape == (b_, t_, 512) and np.array_equal(av.numpy(), av_seq.numpy()), (b_, t_)
+    a2, b2 = rng.standard_normal((37, 20)).astype(np.float32), rng.standard_normal((50, 20)).astype(np.float32)
+    assert np.array_equal(K.matmul_view(a2, [], b2, [["transpose", [1, 0]]], ctx=ctx).numpy(), K.gemm(a2, b2, None, 1.0, 0.0, False, True, ctx=ctx).numpy())
+    with pytest.raises(Exception, match="contiguous along"):
+        K.matmul_view(rng.standard_normal((4, 6, 8, 10)).astype(np.float32), [["transpose", [0, 3, 1, 2]]],
+                      rng.standard_normal((4, 10, 8, 5)).astype(np.float32), [], ctx=ctx)
 
 
 @pytest.mark.gpu
@@ -380,12 +401,12 @@ def test_extra_fusions_leave_a_sensevoice_shaped_model_bit_identical(ctx):
         plans[extra] = fns(plan)
         _, outs = run_plan(ctx, plan, blob, {"feats": TensorView(ctx.buf().upload(feats))})
         plans[extra, "out"] = outs[0].numpy()
-    assert {"softmax_scaled", "add3", "depthwise_conv1d_tlc", "view_copy"} <= set(plans[True])
-    assert not {"softmax_scaled", "add3", "depthwise_conv1d_tlc", "view_copy"} & set(plans[False])
-    assert plans[True].count("view_copy") == 9 and "split" not in plans[True]   # per layer: q and k heads straight from qkv, one slice for v
-    saved = sum(1 for f in plans[False] if not f.startswith("host:")) - sum(1 for f in plans[True] if not f.startswith("host:"))
-    # per layer: two transposes (FSMN), one mul, the q / k reshape + transpose pairs' reshapes (2) and split 1 -> 1 slice (0);
-    # one add in the layers that have both residuals (2 of 3)
-    assert saved == 3 * (2 + 1 + 2) + 2
+    extra = {"softmax_scaled", "add3", "depthwise_conv1d_tlc", "view_copy", "matmul_view"}
+    assert extra <= set(plans[True]) and not extra & set(plans[False])
+    # per layer: the q / k / v head views live in the two matmul_views' loaders, the Split is one slice (v, still read directly)
+    assert plans[True].count("view_copy") == 3 and plans[True].count("matmul_view") == 6
+    assert not {"split", "transpose", "reshape", "matmul", "mul"} & set(plans[True])
+    device = lambda fs: sum(1 for f in fs if not f.startswith("host:") and f not in ("reshape", "flatten", "squeeze", "unsqueeze", "identity"))  # noqa: E731
+    assert (device(plans[False]), device(plans[True])) == (68, 45)   # device statements of the 3-layer model (a Split is one statement, three copies)
     assert np.array_equal(plans[True, "out"], plans[False, "out"])
     assert np.array_equal(plans[True, "out"], enc.forward(TensorView(ctx.buf().upload(feats))).numpy())
