@@ -318,10 +318,13 @@ int lele_hip_softmax_scaled(LeleCtx* ctx, const LeleTensor* x, const LeleTensor*
 int lele_hip_add3(LeleCtx* ctx, const LeleTensor* a, const LeleTensor* b, const LeleTensor* c, LeleBuf* out, int64_t* out_shape,
                   int32_t* out_rank);
 /* Transpose(0,2,1) -> depthwise conv1d (group = C, stride 1, dilation 1, conv1d.rs:837) -> Transpose(0,2,1), without the
- * transposes: x f32 [B, T, C], w [C, 1, K] (K in 3, 5, 7, 11), bias [C] or NULL -> out [B, T + pad_left + pad_right - K + 1, C] */
-int lele_hip_depthwise_conv1d_tlc(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias, int64_t pad_left,
-                                  int64_t pad_right, int relu, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
-
+ * transposes.  x f32 [B, T, P]: the C = w.shape[0] channels [x_offset, x_offset + C) of the last dimension are convolved
+ * along T (x_offset = 0 and P = C for a plain [B, T, C] tensor; a non-zero offset reads one part of a packed projection in
+ * place); w [C, 1, K] (K in 3, 5, 7, 11), bias [C] or NULL -> out [B, T + pad_left + pad_right - K + 1, C].
+ * add_input: out += the convolved input itself (the FSMN "memory + input" Add that follows; needs equal lengths). */
+int lele_hip_depthwise_conv1d_tlc(LeleCtx* ctx, const LeleTensor* x, int64_t x_offset, const LeleTensor* w, const LeleTensor* bias,
+                                  int64_t pad_left, int64_t pad_right, int relu, int add_input, LeleBuf* out, int64_t* out_shape,
+                                  int32_t* out_rank);
 /* Batched matmul whose operands and result are STRIDED VIEWS (heads inside a packed [B, T, 3*D] projection; the result
  * stored straight into the [B, T, H, Dh] layout): the same MFMA kernels and tile choice as lele_hip_matmul, so the values
  * are bit-identical to copying the views out (slice / reshape / transpose) and calling matmul.  Element (bo, bi, r, c) of a

@@ -268,21 +268,6 @@ class Lowering:
         if not self.extra_fusions:
             return None
         # ---- fused forms beyond patterns.rs, each bit-identical to the sequence it replaces (include/lele_hip.h) ----
-        # Transpose(0,2,1) -> depthwise Conv1d -> Transpose(0,2,1): an FSMN memory block on a time-major tensor
-        if ops("Transpose", "Conv", "Transpose"):
-            a0, a1, a2 = _attrs(n[0]), _attrs(n[1]), _attrs(n[2])
-            wname = n[1].input[1]
-            w = self.consts.get(wname)
-            bias_ok = len(n[1].input) < 3 or not n[1].input[2] or n[1].input[2] in self.consts
-            if (a0.get("perm") == [0, 2, 1] and a2.get("perm") == [0, 2, 1] and n[1].input[0] == n[0].output[0]
-                    and n[2].input[0] == n[1].output[0] and private(n[0].output[0], n[1].output[0]) and w is not None and w.ndim == 3
-                    and w.shape[1] == 1 and a1.get("group", 1) == w.shape[0] and w.shape[2] in (3, 5, 7, 11) and bias_ok
-                    and all(v == 1 for v in a1.get("strides", [1])) and all(v == 1 for v in a1.get("dilations", [1]))
-                    and a1.get("auto_pad", "NOTSET") in ("NOTSET", "")):
-                pads = a1.get("pads", [])
-                pl, pr = (pads[0] if len(pads) >= 1 else 0), (pads[1] if len(pads) >= 2 else 0)  # conv1d.rs:886-887
-                return 3, lambda: self.emit([n[2].output[0]], "depthwise_conv1d_tlc", [self.tensor(n[0].input[0]), self.tensor(wname), self.opt_tensor(n[1], 2),
-                                                                                        {"int": pl}, {"int": pr}, {"bool": False}])
         # Mul by a one-element constant -> Softmax over the last axis (attention score scaling)
         if ops("Mul", "Softmax") and n[1].input[0] == n[0].output[0] and private(n[0].output[0]) and _attrs(n[1]).get("axis", -1) == -1:
             sc = [i for i in n[0].input if i in self.consts and self.consts[i].size == 1 and self.consts[i].dtype.kind == "f"]
@@ -441,20 +426,69 @@ class Lowering:
             opt = lambda v: {"none": 1} if v is None else {"list": [{"int": int(d)} for d in v]}  # noqa: E731
             return self.emit(O, "matmul_view", [T(I[0]), {"chain": node.a_chain}, T(I[1]), {"chain": node.b_chain}, opt(node.out_perm),
                                                 opt(node.out_reshape)])
+        if op == "_Tlc":  # synthesised by fold_time_major_conv
+            return self.emit(O, "depthwise_conv1d_tlc", [T(I[0]), T(I[1]), self.opt_tensor(node, 2), {"int": node.pl}, {"int": node.pr}, {"bool": False},
+                                                         {"int": node.x_offset}, {"bool": bool(node.add_input)}])
         if op == "_ViewCopy":  # synthesised by push_views
             return self.emit(O, "view_copy", [T(I[0]), {"chain": node.chain}])
         raise CompileError("ONNX operator %s (%r) is not supported by this back-end" % (op, node.name))
 
     # ---------------------------------------------------------------------------------------- view chains
-    def push_views(self, nodes, cnt):
-        """Split -> Reshape -> Transpose (the head split of a packed QKV projection): every output that is read only through
-        such a chain becomes ONE strided copy straight from the Split's input (`view_copy`), and the Split shrinks to plain
-        slices of the outputs that are still read directly.  Exact copies throughout, so nothing changes but the number of
-        passes over the data."""
-        consumers = {}
+    @staticmethod
+    def _links(nodes):
+        producer, consumers = {}, {}
         for idx, n in enumerate(nodes):
+            for o in n.output:
+                producer[o] = idx
             for i in n.input:
                 consumers.setdefault(i, []).append(idx)
+        return producer, consumers
+
+    def fold_time_major_conv(self, nodes):
+        """Transpose(0,2,1) -> depthwise Conv (k in 3, 5, 7, 11; stride 1) -> Transpose(0,2,1) [-> Add with the block's own input]:
+        an FSMN memory block exported channel-major, computed on the time-major tensor it starts from (`depthwise_conv1d_tlc`)."""
+        cnt = self.uses(nodes)
+        producer, consumers = self._links(nodes)
+        drop, replace = set(), {}
+        for idx, c in enumerate(nodes):
+            if c.op_type != "Conv" or c.input[0] not in producer or len(c.input) < 2 or c.input[1] not in self.consts:
+                continue
+            t0 = nodes[producer[c.input[0]]]
+            use = consumers.get(c.output[0], [])
+            if t0.op_type != "Transpose" or len(use) != 1 or nodes[use[0]].op_type != "Transpose":
+                continue
+            t1, a0, a1, a2 = nodes[use[0]], _attrs(t0), _attrs(c), _attrs(nodes[use[0]])
+            w = self.consts[c.input[1]]
+            bias_ok = len(c.input) < 3 or not c.input[2] or c.input[2] in self.consts
+            if not (a0.get("perm") == [0, 2, 1] and a2.get("perm") == [0, 2, 1] and cnt.get(t0.output[0], 0) == 1 and cnt.get(c.output[0], 0) == 1
+                    and w.ndim == 3 and w.shape[1] == 1 and a1.get("group", 1) == w.shape[0] and w.shape[2] in (3, 5, 7, 11) and bias_ok
+                    and all(v == 1 for v in a1.get("strides", [1])) and all(v == 1 for v in a1.get("dilations", [1]))
+                    and a1.get("auto_pad", "NOTSET") in ("NOTSET", "") and t0.input[0] not in self.consts):
+                continue
+            pads = a1.get("pads", [])
+            v = pb.Node("_Tlc", [t0.input[0], c.input[1]] + ([c.input[2]] if len(c.input) > 2 and c.input[2] else []), [t1.output[0]])
+            v.pl, v.pr = (pads[0] if len(pads) >= 1 else 0), (pads[1] if len(pads) >= 2 else 0)  # conv1d.rs:886-887
+            v.x_offset, v.add_input, v.kw = 0, False, int(w.shape[2])
+            # memory + input: Add(block output, block input) -- only when the lengths agree (pl + pr == k - 1)
+            use2 = consumers.get(t1.output[0], [])
+            if len(use2) == 1 and cnt.get(t1.output[0], 0) == 1 and nodes[use2[0]].op_type == "Add" and v.pl + v.pr == v.kw - 1:
+                add = nodes[use2[0]]
+                other = [i for i in add.input if i != t1.output[0]]
+                if other == [t0.input[0]]:
+                    v.add_input, v.output = True, [add.output[0]]
+                    drop.add(use2[0])
+            drop.update((producer[c.input[0]], idx))
+            replace[use[0]] = [v]
+        return [m for idx, n in enumerate(nodes) for m in (replace.get(idx, [n]) if idx not in drop or idx in replace else [])]
+
+    def push_views(self, nodes, cnt):
+        """Split -> Reshape -> Transpose (the head split of a packed QKV projection): every output that is read only through
+        such a chain becomes ONE strided copy straight from the Split's input (`view_copy`), a time-major convolution reads
+        its channel range of the packed tensor in place, and the Split shrinks to plain slices of the outputs that are still
+        read directly.  Exact copies throughout, so nothing changes but the number of passes over the data."""
+        nodes = self.fold_time_major_conv(nodes)
+        cnt = self.uses(nodes)
+        _producer, consumers = self._links(nodes)
         drop, replace = set(), {}
         for idx, n in enumerate(nodes):
             if n.op_type != "Split" or n.input[0] in self.consts:
@@ -467,35 +501,47 @@ class Lowering:
             if len(sizes) != len(n.output):
                 continue
             axis, starts = at.get("axis", 0), [int(v) for v in np.cumsum([0] + sizes[:-1])]
-            chained, direct = {}, []
+            rewrites, direct = [], []
             for j, o in enumerate(n.output):
-                use = consumers.get(o, [])
-                if len(use) == 1 and cnt.get(o, 0) == 1 and nodes[use[0]].op_type == "Reshape" and nodes[use[0]].input[0] == o \
-                        and nodes[use[0]].input[1] in self.consts:
-                    r = nodes[use[0]]
-                    use2 = consumers.get(r.output[0], [])
-                    if len(use2) == 1 and cnt.get(r.output[0], 0) == 1 and nodes[use2[0]].op_type == "Transpose" and _attrs(nodes[use2[0]]).get("perm"):
-                        t = nodes[use2[0]]
-                        chained[j] = (use[0], use2[0], [["slice", axis, starts[j], sizes[j]],
-                                                       ["reshape", [int(v) for v in np.asarray(self.consts[r.input[1]]).reshape(-1)]],
-                                                       ["transpose", _attrs(t)["perm"]]], t.output[0])
+                pending, materialise = [], False
+                for u in consumers.get(o, []):
+                    un = nodes[u]
+                    if un.op_type == "Reshape" and un.input[0] == o and un.input[1] in self.consts:
+                        use2 = consumers.get(un.output[0], [])
+                        if len(use2) == 1 and cnt.get(un.output[0], 0) == 1 and nodes[use2[0]].op_type == "Transpose" and _attrs(nodes[use2[0]]).get("perm"):
+                            t = nodes[use2[0]]
+                            pending.append(("chain", u, use2[0], [["slice", axis, starts[j], sizes[j]],
+                                                                 ["reshape", [int(v) for v in np.asarray(self.consts[un.input[1]]).reshape(-1)]],
+                                                                 ["transpose", _attrs(t)["perm"]]], t.output[0]))
+                            continue
+                    if un.op_type == "_Tlc" and un.input[0] == o and un.x_offset == 0 and axis in (-1, 2) and sizes[j] == int(self.consts[un.input[1]].shape[0]):
+                        pending.append(("tlc", u, starts[j]))
                         continue
-                direct.append(j)
-            if not chained:
+                    materialise = True
+                if cnt.get(o, 0) > len(consumers.get(o, [])):   # also a graph output
+                    materialise = True
+                rewrites += pending
+                if materialise and cnt.get(o, 0):
+                    direct.append(j)
+            if not rewrites:
                 continue
             drop.add(idx)
             pre = []
             for j in direct:
-                if cnt.get(n.output[j], 0):
-                    v = pb.Node("_ViewCopy", [n.input[0]], [n.output[j]])
-                    v.chain = [["slice", axis, starts[j], sizes[j]]]
-                    pre.append(v)
+                v = pb.Node("_ViewCopy", [n.input[0]], [n.output[j]])
+                v.chain = [["slice", axis, starts[j], sizes[j]]]
+                pre.append(v)
             replace[idx] = pre
-            for j, (ri, ti, chain, out) in chained.items():
-                drop.add(ri)
-                v = pb.Node("_ViewCopy", [n.input[0]], [out])
-                v.chain = chain
-                replace[ti] = [v]
+            for rw in rewrites:
+                if rw[0] == "chain":
+                    _, ri, ti, chain, out = rw
+                    drop.add(ri)
+                    v = pb.Node("_ViewCopy", [n.input[0]], [out])
+                    v.chain = chain
+                    replace[ti] = [v]
+                else:
+                    _, ui, start = rw
+                    nodes[ui].input[0], nodes[ui].x_offset = n.input[0], start
         out_nodes = []
         for idx, n in enumerate(nodes):
             if idx in replace:

@@ -367,18 +367,19 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(const float* __restr
 template <int KW, int TT>
 __global__ __launch_bounds__(256) void dwconv1d_tlc_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ out, int t_in,
-                                                           int t_out, int c, int pl, int relu, unsigned tiles_t, unsigned total) {
+                                                           int t_out, int c, int pitch /* elements per time step of x */, int pl,
+                                                           int relu, int add_input, unsigned tiles_t, unsigned total) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= total) return;
     const unsigned ch = i % (unsigned)c, r = i / (unsigned)c;
     const unsigned tile = r % tiles_t, b = r / tiles_t;
     const int t0 = (int)tile * TT;
-    const float* xp = x + ((size_t)b * t_in) * c + ch;
+    const float* xp = x + ((size_t)b * t_in) * pitch + ch;
     float xs[KW + TT - 1], wv[KW];
 #pragma unroll
     for (int j = 0; j < KW + TT - 1; ++j) {
         const int t = t0 - pl + j;
-        xs[j] = xp[(size_t)min(max(t, 0), t_in - 1) * c];
+        xs[j] = xp[(size_t)min(max(t, 0), t_in - 1) * pitch];
     }
 #pragma unroll
     for (int j = 0; j < KW; ++j) wv[j] = w[ch * KW + j];
@@ -395,6 +396,14 @@ __global__ __launch_bounds__(256) void dwconv1d_tlc_kernel(const float* __restri
         }
         if (bias) acc = acc + bv;
         if (relu) acc = acc > 0.0f ? acc : 0.0f;
+        // the FSMN residual (memory + input): x[t0 + q] sits at window index q + pl (the host checks pl <= KW - 1);
+        // a separate unrolled select keeps the index a compile-time constant per (q, pl) pair
+        if (add_input) {
+            float xv = 0.0f;
+#pragma unroll
+            for (int j = 0; j < KW; ++j) xv = (j == pl) ? xs[q + j] : xv;
+            acc = acc + xv;
+        }
         if (t0 + q < t_out) op[(size_t)(t0 + q) * c] = acc;
     }
 }
@@ -788,16 +797,20 @@ int lele_hip_conv1d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, cons
     return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, (int64_t)g.ow});
 }
 
-int lele_hip_depthwise_conv1d_tlc(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias, int64_t pad_left,
-                                  int64_t pad_right, int relu, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+int lele_hip_depthwise_conv1d_tlc(LeleCtx* ctx, const LeleTensor* x, int64_t x_offset, const LeleTensor* w, const LeleTensor* bias,
+                                  int64_t pad_left, int64_t pad_right, int relu, int add_input, LeleBuf* out, int64_t* out_shape,
+                                  int32_t* out_rank) {
     LELE_REQUIRE(ctx && x && w && out, "depthwise_conv1d_tlc: NULL argument");
-    LELE_REQUIRE(x->rank == 3 && w->rank == 3 && x->dtype == LELE_F32 && w->dtype == LELE_F32, "depthwise_conv1d_tlc: x [B,T,C] and w [C,1,K] f32 required");
-    const int64_t bsz = x->shape[0], t_in = x->shape[1], c = x->shape[2], k = w->shape[2];
-    LELE_REQUIRE(w->shape[0] == c && w->shape[1] == 1, "depthwise_conv1d_tlc: weight must be [C, 1, K] (group = C)");
+    LELE_REQUIRE(x->rank == 3 && w->rank == 3 && x->dtype == LELE_F32 && w->dtype == LELE_F32, "depthwise_conv1d_tlc: x [B,T,P] and w [C,1,K] f32 required");
+    const int64_t bsz = x->shape[0], t_in = x->shape[1], pitch = x->shape[2], c = w->shape[0], k = w->shape[2];
+    LELE_REQUIRE(w->shape[1] == 1, "depthwise_conv1d_tlc: weight must be [C, 1, K] (group = C)");
+    LELE_REQUIRE(x_offset >= 0 && x_offset + c <= pitch, "depthwise_conv1d_tlc: channels [%lld, %lld) outside the last dimension (%lld)",
+                 (long long)x_offset, (long long)(x_offset + c), (long long)pitch);
     LELE_REQUIRE(k == 3 || k == 5 || k == 7 || k == 11, "depthwise_conv1d_tlc: kernel sizes 3, 5, 7, 11 (use transpose + conv1d otherwise)");
     LELE_REQUIRE(pad_left >= 0 && pad_right >= 0, "depthwise_conv1d_tlc: negative padding");
     const int64_t t_out = t_in + pad_left + pad_right - (k - 1);
     LELE_REQUIRE(t_out >= 1 && t_in >= 1, "conv1d: output length must be positive");
+    LELE_REQUIRE(!add_input || (t_out == t_in && pad_left <= k - 1), "depthwise_conv1d_tlc: the input can only be added to an output of the same length");
     if (bias) LELE_REQUIRE(numel(bias) >= c, "conv1d: bias shorter than C_out");
     LELE_HIP_CHECK(hipSetDevice(ctx->device));
     LELE_TRY(ctx->arena_reset());
@@ -808,13 +821,13 @@ int lele_hip_depthwise_conv1d_tlc(LeleCtx* ctx, const LeleTensor* x, const LeleT
     LELE_TRY(out->reserve((size_t)(bsz * t_out * c) * 4));
     constexpr int TT = 8;
     const int64_t tiles = (t_out + TT - 1) / TT, total = bsz * tiles * c;
-    LELE_REQUIRE(total < (int64_t(1) << 31) && bsz * t_in * c < (int64_t(1) << 40), "depthwise_conv1d_tlc: tensor too large");
+    LELE_REQUIRE(total < (int64_t(1) << 31) && pitch < (int64_t(1) << 31), "depthwise_conv1d_tlc: tensor too large");
     if (bsz && c) {
         const dim3 grid((unsigned)((total + 255) / 256));
-#define LELE_TLC(KW)                                                                                                         \
-    hipLaunchKernelGGL((dwconv1d_tlc_kernel<KW, TT>), grid, dim3(256), 0, ctx->stream, (const float*)dx, (const float*)dwp,      \
-                       (const float*)db, (float*)out->data, (int)t_in, (int)t_out, (int)c, (int)pad_left, relu, (unsigned)tiles, \
-                       (unsigned)total)
+#define LELE_TLC(KW)                                                                                                            \
+    hipLaunchKernelGGL((dwconv1d_tlc_kernel<KW, TT>), grid, dim3(256), 0, ctx->stream, (const float*)dx + x_offset, (const float*)dwp, \
+                       (const float*)db, (float*)out->data, (int)t_in, (int)t_out, (int)c, (int)pitch, (int)pad_left, relu, add_input,  \
+                       (unsigned)tiles, (unsigned)total)
         if (k == 3) LELE_TLC(3);
         else if (k == 5) LELE_TLC(5);
         else if (k == 7) LELE_TLC(7);

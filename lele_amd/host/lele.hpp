@@ -735,11 +735,11 @@ inline TensorView add3(const TensorView& a, const TensorView& b, const TensorVie
     LELE_RET(out, LELE_F32);
 }
 inline TensorView depthwise_conv1d_tlc(const TensorView& x, const TensorView& w, const TensorView* bias, int64_t pad_left,
-                                       int64_t pad_right, bool relu, Buffer& out) {
+                                       int64_t pad_right, bool relu, int64_t x_offset, bool add_input, Buffer& out) {
     Shape sh;
     LeleTensor tx = x.c(), tw = w.c();
     Opt ob(bias);
-    check(lele_hip_depthwise_conv1d_tlc(ctx(), &tx, &tw, ob.p, pad_left, pad_right, relu, out.raw(), sh.dims, &sh.rank));
+    check(lele_hip_depthwise_conv1d_tlc(ctx(), &tx, x_offset, &tw, ob.p, pad_left, pad_right, relu, add_input, out.raw(), sh.dims, &sh.rank));
     LELE_RET(out, LELE_F32);
 }
 // view operators: shape bookkeeping only (shape.rs:2-52, 105-185)

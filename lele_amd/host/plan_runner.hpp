@@ -708,7 +708,8 @@ class Runner {
         if (fn == "softmax_scaled") return set(st, 0, K::softmax_scaled(tensor(a[0]), tensor(a[1]), integer(a[2]), o));
         if (fn == "add3") return set(st, 0, K::add3(tensor(a[0]), tensor(a[1]), tensor(a[2]), o));
         if (fn == "depthwise_conv1d_tlc")
-            return set(st, 0, K::depthwise_conv1d_tlc(tensor(a[0]), tensor(a[1]), opt(a[2], h0), integer(a[3]), integer(a[4]), boolean(a[5]), o));
+            return set(st, 0, K::depthwise_conv1d_tlc(tensor(a[0]), tensor(a[1]), opt(a[2], h0), integer(a[3]), integer(a[4]), boolean(a[5]), integer(a[6]),
+                                                      boolean(a[7]), o));
         if (fn == "max_pool2d") return set(st, 0, K::max_pool2d(tensor(a[0]), ints(a[1]), ints(a[2]), ints(a[3]), ints(a[4]), boolean(a[5]), o));
         if (fn == "resize_nearest") {  // kernels.py resize_nearest: sizes win; scales multiply in f64 and truncate (conv2d.rs:1261-1382)
             const TV x = tensor(a[0]);

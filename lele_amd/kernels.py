@@ -779,11 +779,18 @@ def add3(a, b, c, out=None, ctx=None):
     return _op(ctx, _lib.lib().lele_hip_add3, [a, b, c], [], out)
 
 
-def depthwise_conv1d_tlc(input, weights, bias=None, pad_left=0, pad_right=0, relu=False, out=None, ctx=None):
-    """transpose(0,2,1) -> depthwise conv1d -> transpose(0,2,1) on a time-major [B, T, C] tensor, without the transposes"""
-    return _op(ctx, _lib.lib().lele_hip_depthwise_conv1d_tlc, [input, weights, bias],
-               [C.c_int64(int(pad_left)), C.c_int64(int(pad_right)), C.c_int(int(bool(relu)))], out)
-
+def depthwise_conv1d_tlc(input, weights, bias=None, pad_left=0, pad_right=0, relu=False, x_offset=0, add_input=False, out=None, ctx=None):
+    """transpose(0,2,1) -> depthwise conv1d -> transpose(0,2,1) on a time-major tensor, without the transposes; reads the
+    channels [x_offset, x_offset + C) of input [B, T, P] in place; add_input adds the convolved input (the FSMN residual)"""
+    ctx = _ctx(ctx)
+    keep = []
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_depthwise_conv1d_tlc(
+        ctx._h, _lib.as_tensor(unwrap(input), keep), C.c_int64(int(x_offset)), _lib.as_tensor(unwrap(weights), keep),
+        _lib.as_tensor(unwrap(bias), keep), C.c_int64(int(pad_left)), C.c_int64(int(pad_right)), C.c_int(int(bool(relu))),
+        C.c_int(int(bool(add_input))), out._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
 
 # ------------------------------------------------------------------------------------------- ConvInteger family
 def conv_integer(input, weights, x_zero_point=None, w_zero_point=None, dilations=(), group=1, pads=(), strides=(), out=None,

@@ -355,6 +355,11 @@ def test_extra_fused_kernels_are_bit_identical_to_their_sequences(ctx):
         bv = rng.standard_normal(48).astype(np.float32) if bias else None
         seq = K.transpose(K.conv1d(K.transpose(xt, [0, 2, 1], ctx=ctx), w, bv, [1], 48, [pl, pr], [1], ctx=ctx), [0, 2, 1], ctx=ctx).numpy()
         assert np.array_equal(K.depthwise_conv1d_tlc(xt, w, bv, pl, pr, ctx=ctx).numpy(), seq), (k, pl, pr, bias)
+        if pl + pr == k - 1:   # the FSMN form: channels read in place from a packed tensor, the block's input added
+            packed = rng.standard_normal((3, 29, 112)).astype(np.float32)
+            packed[:, :, 40:88] = xt
+            got = K.depthwise_conv1d_tlc(packed, w, bv, pl, pr, x_offset=40, add_input=True, ctx=ctx).numpy()
+            assert np.array_equal(got, K.add(seq, xt, ctx=ctx).numpy()), (k, pl, pr, bias)
     qkv = rng.standard_normal((3, 41, 1536)).astype(np.float32)
     for start, perm in ((0, [0, 2, 1, 3]), (512, [0, 2, 3, 1]), (1024, [0, 2, 1, 3])):
         chain = [["slice", 2, start, 512], ["reshape", [0, 0, 4, 128]], ["transpose", perm]]
@@ -401,12 +406,12 @@ def test_extra_fusions_leave_a_sensevoice_shaped_model_bit_identical(ctx):
         plans[extra] = fns(plan)
         _, outs = run_plan(ctx, plan, blob, {"feats": TensorView(ctx.buf().upload(feats))})
         plans[extra, "out"] = outs[0].numpy()
-    extra = {"softmax_scaled", "add3", "depthwise_conv1d_tlc", "view_copy", "matmul_view"}
+    extra = {"softmax_scaled", "add3", "depthwise_conv1d_tlc", "matmul_view"}
     assert extra <= set(plans[True]) and not extra & set(plans[False])
-    # per layer: the q / k / v head views live in the two matmul_views' loaders, the Split is one slice (v, still read directly)
-    assert plans[True].count("view_copy") == 3 and plans[True].count("matmul_view") == 6
-    assert not {"split", "transpose", "reshape", "matmul", "mul"} & set(plans[True])
+    # per layer: the q / k / v head views live in the two matmul_views' loaders, the FSMN convolution reads v in place and adds it
+    assert plans[True].count("matmul_view") == 6 and plans[True].count("depthwise_conv1d_tlc") == 3
+    assert not {"split", "transpose", "reshape", "matmul", "mul", "view_copy"} & set(plans[True])
     device = lambda fs: sum(1 for f in fs if not f.startswith("host:") and f not in ("reshape", "flatten", "squeeze", "unsqueeze", "identity"))  # noqa: E731
-    assert (device(plans[False]), device(plans[True])) == (68, 45)   # device statements of the 3-layer model (a Split is one statement, three copies)
+    assert (device(plans[False]), device(plans[True])) == (68, 39)   # device statements of the 3-layer model (a Split is one statement, three copies)
     assert np.array_equal(plans[True, "out"], plans[False, "out"])
     assert np.array_equal(plans[True, "out"], enc.forward(TensorView(ctx.buf().upload(feats))).numpy())
