@@ -311,6 +311,12 @@ int lele_hip_yolo_seg_postprocess(LeleCtx* ctx, const LeleTensor* logits, const 
 
 /* ---- fused forms beyond the reference's own patterns (emitted by lele_amd.compiler, each bit-identical to the sequence it
  *      replaces; never required by lele-generated code) ---------------------------------------------------------------- */
+/* fused_quantized_linear followed by one or two Adds of same-shape tensors, folded into the GEMM's store:
+ * ((linear(x) + res1) + res2), each sum rounded as the separate `add`s would (res2 may be NULL) */
+int lele_hip_fused_quantized_linear_residual(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8,
+                                             const LeleTensor* weight_scale, const LeleTensor* weight_zero, const LeleTensor* bias,
+                                             int apply_relu, const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out,
+                                             int64_t* out_shape, int32_t* out_rank);
 /* softmax(x * scale[0]) over the last axis: `mul` by a one-element tensor followed by `softmax` (norm.rs:8) */
 int lele_hip_softmax_scaled(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, int32_t axis, LeleBuf* out,
                             int64_t* out_shape, int32_t* out_rank);

@@ -622,6 +622,53 @@ class Lowering:
             drop.update(a_drop + b_drop + o_drop)
         return [m for idx, n in enumerate(nodes) for m in (replace.get(idx, [n]) if idx not in drop or idx in replace else [])]
 
+    def fold_linear_residuals(self):
+        """fused_quantized_linear whose result is read once, by an `add` / `add3` with tensors that already exist: the Adds move
+        into the GEMM's store (`fused_quantized_linear_residual`, ((lin + r1) + r2) in the Adds' own order)."""
+        sts = self.statements
+        outs = {sanitize(o) for o in self.outputs}
+        defined_at, readers = {}, {}
+
+        def refs(n, acc):
+            if isinstance(n, dict):
+                for key in ("ref", "ints"):
+                    if isinstance(n.get(key), str):
+                        acc.append(n[key])
+                for v in n.values():
+                    refs(v, acc)
+            elif isinstance(n, list):
+                for v in n:
+                    refs(v, acc)
+            return acc
+        for i, st in enumerate(sts):
+            for o in st["out"]:
+                defined_at[o] = i
+            for r in refs(st.get("args", st.get("in")), []):
+                readers.setdefault(r, []).append(i)
+        dead = set()
+        for i, st in enumerate(sts):
+            if st.get("fn") != "fused_quantized_linear":
+                continue
+            lin = st["out"][0]
+            rd = readers.get(lin, [])
+            if len(rd) != 1 or lin in outs or rd[0] in dead:
+                continue
+            use = sts[rd[0]]
+            ops = use.get("args", [])
+            if use.get("fn") not in ("add", "add3") or not all(isinstance(a, dict) and "ref" in a for a in ops):
+                continue
+            names = [a["ref"] for a in ops]
+            if names.count(lin) != 1 or (use["fn"] == "add3" and names.index(lin) == 2):
+                continue                      # (r1 + r2) + lin is a different rounding order
+            res = [nm for nm in names if nm != lin]
+            if any(defined_at.get(nm, -1) >= i for nm in res):   # graph inputs are defined "before everything" (-1)
+                continue
+            st["fn"] = "fused_quantized_linear_residual"
+            st["args"] = st["args"] + [{"ref": res[0]}, ({"ref": res[1]} if len(res) > 1 else {"none": 1})]
+            st["out"] = list(use["out"])
+            dead.add(rd[0])
+        self.statements[:] = [st for i, st in enumerate(sts) if i not in dead]
+
     # ---------------------------------------------------------------------------------------- driver
     def run(self):
         nodes = self.fold(list(self.model.graph.node))
@@ -654,6 +701,8 @@ class Lowering:
         for o in self.outputs:
             if o in self.consts:
                 raise CompileError("graph output %s is a constant" % o)
+        if self.extra_fusions:
+            self.fold_linear_residuals()
         slots = allocate(self.statements, [sanitize(o) for o in self.outputs])
         plan = {"source": self.name, "format": "lele_amd.plan/2", "inputs": [sanitize(v.name) for v in self.inputs],
                 "input_info": [{"name": sanitize(v.name), "dtype": "i64" if self.place[v.name] == "host" else "f32", "shape": v.shape}

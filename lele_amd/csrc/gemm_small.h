@@ -56,13 +56,27 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const int8_t* __restri
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
     const typename EPI::ColCtx cc = epi.col_ctx(col);
+    float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (epi.res1) {  // residual operands of the four rows this wave finishes: loaded together, from clamped coordinates
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = 4 * wave + q;
+            const int64_t orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * hv;
+            const int64_t at = (orow < rows ? orow : rows - 1) * (int64_t)n + (cin ? col : n - 1);
+            r1[q] = epi.res1[at];
+            r2[q] = epi.res2 ? epi.res2[at] : 0.0f;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int r = 4 * wave + q;
         const int64_t orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * hv;
         const typename EPI::RowCtx rc = epi.row_ctx(orow < rows ? orow : rows - 1);  // clamped: load unconditionally
         const int tot = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
-        if (orow < rows && cin) epi.store(rc, cc, col, tot);
+        if (orow < rows && cin) {
+            if (epi.res1) epi.store_res(rc, cc, col, tot, r1[q], r2[q]);
+            else epi.store(rc, cc, col, tot);
+        }
     }
 }
 

@@ -247,6 +247,10 @@ struct IgemmEpi {
     int wscale_len;
     const float* bias;  // may be NULL
     int relu;
+    // residual operands [rows][n] added after bias / ReLU, in this order: ((lin + res1) + res2) -- the Add nodes that follow
+    // a projection in a transformer block, folded into its store (lele_hip_fused_quantized_linear_residual)
+    const float* res1 = nullptr;
+    const float* res2 = nullptr;
     // Everything that depends only on the row (slice parameters, row-sum term, output row pointer) or only on the
     // column (column sum, weight scale, bias) is computed once per row / column of a thread's tile, not per element.
     struct RowCtx {
@@ -278,13 +282,20 @@ struct IgemmEpi {
         if (bias) c.bias = bias[col];
         return c;
     }
-    __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, int col, int acc) const {
+    __device__ __forceinline__ float value(const RowCtx& r, const ColCtx& c, int acc) const {
         const int total = acc + r.rterm + r.ca * c.colsum;
         float vf = (float)total;  // _mm256_cvtepi32_ps
         // combined_scale[j] = dyn_scale * weight_scale[j], then one mul (dyn_scale is 1.0 when there is no dynamic range)
         if (wscale) vf = vf * (r.dyn_scale * c.ws);
         if (bias) vf = vf + c.bias;
         if (relu) vf = vf > 0.0f ? vf : 0.0f;
+        return vf;
+    }
+    __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, int col, int acc) const { r.orow[col] = value(r, c, acc); }
+    // with residuals: the caller has loaded them (unconditionally, from clamped coordinates) before any store
+    __device__ __forceinline__ void store_res(const RowCtx& r, const ColCtx& c, int col, int acc, float r1, float r2) const {
+        float vf = value(r, c, acc) + r1;
+        if (res2) vf = vf + r2;
         r.orow[col] = vf;
     }
 };
@@ -403,6 +414,35 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
     for (int j = 0; j < TNT; ++j) {
         cols[j] = n0 + wn * TNT * 32 + j * 32 + l31;
         cc[j] = epi.col_ctx(cols[j]);
+    }
+    if (epi.res1) {  // residual operands: four rows at a time, their loads issued together before the stores
+#pragma unroll
+        for (int i = 0; i < TMT; ++i)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float r1[4][TNT], r2[4][TNT];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t row = m0 + wm * TMT * 32 + i * 32 + q + 8 * g4 + 4 * hv;
+                    const int64_t rowc = row < rows ? row : rows - 1;
+#pragma unroll
+                    for (int j = 0; j < TNT; ++j) {
+                        const int64_t at = rowc * epi.n + (cols[j] < n ? cols[j] : n - 1);
+                        r1[q][j] = epi.res1[at];
+                        r2[q][j] = epi.res2 ? epi.res2[at] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int lr = wm * TMT * 32 + i * 32 + q + 8 * g4 + 4 * hv;
+                    const int64_t row = m0 + lr;
+                    const IgemmEpi::RowCtx rc{s_ca[lr], s_rterm[lr], s_ds[lr], epi.out + (row < rows ? row : 0) * epi.n};
+#pragma unroll
+                    for (int j = 0; j < TNT; ++j)
+                        if (row < rows && cols[j] < n) epi.store_res(rc, cc[j], cols[j], acc[i][j][q + 4 * g4], r1[q][j], r2[q][j]);
+                }
+            }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < TMT; ++i)
@@ -558,10 +598,9 @@ int quant_params_of(LeleCtx* ctx, const float* const* srcs, const int64_t* lens,
 
 extern "C" {
 
-int lele_hip_fused_quantized_linear(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8,
-                                    const LeleTensor* weight_scale, const LeleTensor* weight_zero,
-                                    const LeleTensor* bias, int apply_relu, LeleBuf* out, int64_t* out_shape,
-                                    int32_t* out_rank) {
+static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8, const LeleTensor* weight_scale,
+                    const LeleTensor* weight_zero, const LeleTensor* bias, int apply_relu, const LeleTensor* res1,
+                    const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
     LELE_REQUIRE(ctx && input && weight_int8 && weight_scale && out, "fused_quantized_linear: NULL argument");
     LELE_REQUIRE(input->rank >= 2 && weight_int8->rank >= 2, "fused_quantized_linear: rank >= 2 required");
     LELE_HIP_CHECK(hipSetDevice(ctx->device));
@@ -587,6 +626,9 @@ int lele_hip_fused_quantized_linear(LeleCtx* ctx, const LeleTensor* input, const
     LELE_TRY(ctx->dev_ptr(input, &dx));
     LELE_TRY(ctx->dev_ptr(weight_scale, &dws));
     if (blen) LELE_TRY(ctx->dev_ptr(bias, &db));
+    const void *dr1 = nullptr, *dr2 = nullptr;
+    if (res1) LELE_TRY(ctx->dev_ptr(res1, &dr1));
+    if (res2) LELE_TRY(ctx->dev_ptr(res2, &dr2));
     // weight_zero.data.first() as i32 (quantization.rs:100); fetched on the host: it is a scalar attribute
     float wz = 0.0f;
     if (weight_zero && numel(weight_zero) > 0) {
@@ -630,9 +672,45 @@ int lele_hip_fused_quantized_linear(LeleCtx* ctx, const LeleTensor* input, const
     hipLaunchKernelGGL(qrows_kernel<0>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
                        rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk);
     IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, (const int*)rs, pw.col_sums, (const QParams*)prm, 0,
-                 (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu};
+                 (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
+                 (const float*)dr2};
     LELE_TRY(launch_igemm(ctx, (const int8_t*)aq, pw.wt, rows, (int)n, kp, 0, (int)m, epi));
     return set_shape_v(out_shape, out_rank, shp);
+}
+
+int lele_hip_fused_quantized_linear(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8,
+                                    const LeleTensor* weight_scale, const LeleTensor* weight_zero,
+                                    const LeleTensor* bias, int apply_relu, LeleBuf* out, int64_t* out_shape,
+                                    int32_t* out_rank) {
+    return fql_impl(ctx, input, weight_int8, weight_scale, weight_zero, bias, apply_relu, nullptr, nullptr, out, out_shape, out_rank);
+}
+
+int lele_hip_binary(LeleCtx* ctx, int op, const LeleTensor* a, const LeleTensor* b, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+
+int lele_hip_fused_quantized_linear_residual(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8,
+                                             const LeleTensor* weight_scale, const LeleTensor* weight_zero, const LeleTensor* bias,
+                                             int apply_relu, const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out,
+                                             int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && input && weight_int8 && res1 && out, "fused_quantized_linear_residual: NULL argument");
+    LELE_REQUIRE(res1->dtype == LELE_F32 && (!res2 || res2->dtype == LELE_F32), "fused_quantized_linear_residual: f32 residuals required");
+    int64_t on = weight_int8->shape[weight_int8->rank - 1];
+    for (int i = 0; i + 1 < input->rank; ++i) on *= input->shape[i];
+    if (numel(res1) == on && (!res2 || numel(res2) == on))  // same-shape residuals: folded into the GEMM's store
+        return fql_impl(ctx, input, weight_int8, weight_scale, weight_zero, bias, apply_relu, res1, res2, out, out_shape, out_rank);
+    // broadcasting residuals: the plain linear, then the Adds in place (the residuals must broadcast INTO the result)
+    int64_t sh[LELE_MAX_RANK];
+    int32_t r = 0;
+    LELE_TRY(fql_impl(ctx, input, weight_int8, weight_scale, weight_zero, bias, apply_relu, nullptr, nullptr, out, sh, &r));
+    for (const LeleTensor* res : {res1, res2}) {
+        if (!res) continue;
+        LELE_REQUIRE(res->rank <= r, "fused_quantized_linear_residual: a residual would enlarge the result");
+        for (int d = 0; d < res->rank; ++d)
+            LELE_REQUIRE(res->shape[res->rank - 1 - d] == 1 || res->shape[res->rank - 1 - d] == sh[r - 1 - d],
+                         "fused_quantized_linear_residual: a residual would enlarge the result");
+        LeleTensor t{out->data, sh, r, LELE_F32, LELE_MEM_DEVICE};
+        LELE_TRY(lele_hip_binary(ctx, 0 /* add */, &t, res, out, sh, &r));
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(sh, sh + r));
 }
 
 int lele_hip_dynamic_quantize_linear(LeleCtx* ctx, const LeleTensor* x, LeleBuf* out_y, LeleBuf* out_scale,

@@ -722,6 +722,15 @@ inline std::vector<std::pair<size_t, size_t>> vad_segments(const std::vector<flo
     return merged;
 }
 // fused forms emitted by lele_amd.compiler (bit-identical to the sequences they replace)
+inline TensorView fused_quantized_linear_residual(const TensorView& input, const TensorView& weight_int8, const TensorView& weight_scale,
+                                                  const TensorView& weight_zero, const TensorView* bias, bool apply_relu, const TensorView& res1,
+                                                  const TensorView* res2, Buffer& out) {
+    Shape sh;
+    LeleTensor ti = input.c(), tw = weight_int8.c(), ts = weight_scale.c(), tz = weight_zero.c(), t1 = res1.c();
+    Opt ob(bias), o2(res2);
+    check(lele_hip_fused_quantized_linear_residual(ctx(), &ti, &tw, &ts, &tz, ob.p, apply_relu, &t1, o2.p, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
 inline TensorView softmax_scaled(const TensorView& x, const TensorView& scale, int64_t axis, Buffer& out) {
     Shape sh;
     LeleTensor tx = x.c(), ts = scale.c();

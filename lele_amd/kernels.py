@@ -769,6 +769,18 @@ def matmul_view(a, a_chain, b, b_chain, out_perm=None, out_reshape=None, out=Non
 
 
 # ------------------------------------------------------------------------------------------- fused forms (lele_amd.compiler)
+def fused_quantized_linear_residual(input, weight_int8, weight_scale, weight_zero, bias, apply_relu, res1, res2=None, out=None, ctx=None):
+    """((fused_quantized_linear(...) + res1) + res2): the Adds that follow a projection, folded into its store"""
+    ctx = _ctx(ctx)
+    keep = []
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_fused_quantized_linear_residual(
+        ctx._h, _t(input, keep), _t(weight_int8, keep), _t(weight_scale, keep), _t(weight_zero, keep), _t(bias, keep),
+        C.c_int(int(apply_relu)), _t(res1, keep), _t(res2, keep), out._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
+
+
 def softmax_scaled(input, scale, axis=-1, out=None, ctx=None):
     """softmax(input * scale[0]): bit-identical to mul(input, scale) followed by softmax"""
     return _op(ctx, _lib.lib().lele_hip_softmax_scaled, [input, scale], [C.c_int32(axis)], out)

@@ -175,3 +175,22 @@ def test_layer_norm_row_statistics_feed_the_dynamic_quantisation(ctx):
         y = K.mul(xn, np.array([3.0], np.float32), out=buf, ctx=ctx)
         assert np.array_equal(K.fused_quantized_linear(y, w, ws, wz, bias, False, ctx=ctx).numpy(),
                               O.fused_quantized_linear(xn_host * np.float32(3.0), w.arr, ws.arr, wz.arr, bias.arr, False)), (b, m, k, n)
+
+
+@pytest.mark.gpu
+def test_residual_adds_in_the_linear_epilogue_are_bit_identical(ctx):
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    rng = np.random.default_rng(5)
+    for b, m, k, n, relu in ((1, 504, 512, 512, False), (32, 171, 512, 512, False), (2, 33, 2048, 512, True), (1, 7, 64, 40, False), (3, 200, 512, 1536, False)):
+        x = rng.standard_normal((b, m, k)).astype(np.float32)
+        w = Weight(np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32))
+        ws, wz, bias = Weight((rng.random(n) * 0.01 + 0.002).astype(np.float32)), Weight(np.array([128.0], np.float32)), Weight(rng.standard_normal(n).astype(np.float32))
+        r1, r2 = rng.standard_normal((b, m, n)).astype(np.float32), rng.standard_normal((b, m, n)).astype(np.float32)
+        lin = K.fused_quantized_linear(x, w, ws, wz, bias, relu, ctx=ctx)
+        want1 = K.add(lin, r1, ctx=ctx).numpy()
+        want2 = K.add3(lin, r1, r2, ctx=ctx).numpy()
+        assert np.array_equal(K.fused_quantized_linear_residual(x, w, ws, wz, bias, relu, r1, ctx=ctx).numpy(), want1), (b, m, k, n)
+        assert np.array_equal(K.fused_quantized_linear_residual(x, w, ws, wz, bias, relu, r1, r2, ctx=ctx).numpy(), want2), (b, m, k, n)
+        # a broadcasting residual takes the two-pass route
+        assert np.array_equal(K.fused_quantized_linear_residual(x, w, ws, wz, bias, relu, r1[:, :1], ctx=ctx).numpy(), K.add(lin, r1[:, :1], ctx=ctx).numpy())
