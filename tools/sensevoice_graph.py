@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--configs", default="c3,c4")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph leg (rocprofv3 cannot trace captures)")
     ap.add_argument("--via-onnx", action="store_true", help="also build the model as ONNX, compile it with lele_amd.compiler and run the plan")
+    ap.add_argument("--compiled-only", action="store_true", help="profiling aid: only the compiled plan, eagerly, --runs times (use with rocprofv3)")
     args = ap.parse_args()
     import lele_amd
     from lele_amd import kernels as K
@@ -204,6 +205,16 @@ def main():
                 cmvn.compute(K.reshape(f, list(f.shape[1:])), out=cbufs[0]), [1] + list(f.shape[1:]))
 
         feats = frontend()
+        if args.compiled_only:
+            from lele_amd.compiler import compile_model
+            from lele_amd.plan import Runner, load_weights_bin
+            plan, blob = compile_model(encoder_onnx(enc, batch), "sensevoice_shaped")
+            r = Runner(plan, load_weights_bin(plan, blob), ctx)
+            for _ in range(2 + args.runs):
+                r.run({"feats": feats})
+            ctx.sync()
+            print(json.dumps({"config": name, "compiled_only_forwards": 2 + args.runs, "kernel_calls_per_forward": r.calls // (2 + args.runs)}), flush=True)
+            continue
         for _ in range(2):  # warm-up: uploads and pre-packs every weight once
             logits = enc.forward(feats)
         ctx.sync()
