@@ -161,7 +161,8 @@ struct HostArr {
     double get(size_t k) const { return is_int ? (double)i[k] : (double)f[k]; }
 };
 struct Val {
-    enum Kind { None, Tensor, Host } kind = None;
+    enum Kind { None, Tensor, Host, List } kind = None;
+    std::vector<TensorView> list;  // split_owned results of a lifted plan
     TensorView t;
     HostArr h;
     std::shared_ptr<std::vector<char>> keep;  // storage of a host-backed tensor
@@ -456,8 +457,9 @@ class Runner {
    public:
     Runner(const std::string& plan_json, const std::string& weights_path) {
         plan_ = JsonParser(plan_json).parse();
-        if (!plan_.has("format") || plan_.at("format").str != "lele_amd.plan/2")
-            throw Error("plan: only compiled plans (format lele_amd.plan/2) are supported by the native runner");
+        // "lele_amd.plan/2": compiled from ONNX (lele_amd.compiler); no format tag: lifted from lele-generated Rust
+        // (tools/lift_generated.py) -- weights keyed by byte offset, output buffers named inside the argument lists
+        v2_ = plan_.has("format") && plan_.at("format").str == "lele_amd.plan/2";
         std::ifstream f(weights_path, std::ios::binary);
         if (!f) throw Error("cannot open " + weights_path);
         blob_.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
@@ -472,11 +474,31 @@ class Runner {
         env_.clear();
         for (const auto& kv : inputs) env_[kv.first] = kv.second;
         calls_ = 0;
+        stmt_ = 0;
         for (const Json& st : plan_.at("statements").arr) {
+            ++stmt_;
             const std::string& op = st.at("op").str;
             if (op == "host") host_stmt(st);
             else if (op == "call") call_stmt(st);
-            else throw Error("plan: statement kind '" + op + "' is not supported by the native runner");
+            else if (op == "ints") {   // `let x = &[..];`
+                Val v;
+                v.kind = Val::Host;
+                for (const Json& e : st.at("value").arr) v.h.i.push_back(e.as_int());
+                env_[st.at("out").arr[0].str] = v;
+            } else if (op == "newbuf") {  // `let mut buf_x = Vec::new();` -> a persistent device buffer of that name
+                if (!named_.count(st.at("out").arr[0].str)) named_[st.at("out").arr[0].str] = std::make_unique<Buffer>();
+            } else if (op == "swap_remove") {  // Vec::swap_remove: take element i, the last element takes its place
+                Val& lst = env_.at(st.at("list").str);
+                const size_t i = (size_t)st.at("index").as_int();
+                Val v;
+                v.kind = Val::Tensor;
+                v.t = lst.list.at(i);
+                lst.list[i] = lst.list.back();
+                lst.list.pop_back();
+                env_[st.at("out").arr[0].str] = v;
+            } else if (op == "alias") {
+                env_[st.at("out").arr[0].str] = env_.at(st.at("src").str);
+            } else throw Error("plan: statement kind '" + op + "' is not supported by the native runner");
         }
         std::vector<Val> out;
         for (const Json& o : plan_.at("outputs").arr) out.push_back(env_.at(o.str));
@@ -486,12 +508,15 @@ class Runner {
    private:
     using TV = TensorView;
     Json plan_;
+    bool v2_ = true;
     std::vector<char> blob_;
+    std::unordered_map<std::string, std::unique_ptr<Buffer>> named_;  // `newbuf` buffers and split_owned outputs
     std::unordered_map<std::string, std::unique_ptr<Buffer>> slots_;
     std::unordered_map<std::string, std::pair<TV, std::shared_ptr<std::vector<char>>>> weights_;
     std::unordered_map<std::string, Val> env_;
-    size_t calls_ = 0;
+    size_t calls_ = 0, stmt_ = 0;
 
+    std::string wkey(const Json& w) const { return v2_ ? weight_key(w) : std::to_string(w.arr[1].as_int()); }
     static std::string weight_key(const Json& w) {
         std::string k = std::to_string(w.arr[1].as_int()) + ":" + w.arr[0].str + ":";
         for (size_t i = 0; i < w.arr[3].arr.size(); ++i) k += (i ? "x" : "") + std::to_string(w.arr[3].arr[i].as_int());
@@ -515,11 +540,12 @@ class Runner {
         return f;
     }
     void load_weight(const std::string& key, const Json& w) {  // plan.py load_weights_bin: everything but i64 is handed over as f32
+        const bool four = w.arr.size() == 4;  // compiled: [kind, offset, bytes, shape]; lifted: key = offset, [kind, bytes, shape]
         const std::string& kind = w.arr[0].str;
-        const size_t off = (size_t)w.arr[1].as_int(), len = (size_t)w.arr[2].as_int();
+        const size_t off = four ? (size_t)w.arr[1].as_int() : (size_t)std::stoll(key), len = (size_t)w.arr[four ? 2 : 1].as_int();
         if (off + len > blob_.size()) throw Error("weights.bin is shorter than view " + key);
         std::vector<int64_t> shape;
-        for (const Json& d : w.arr[3].arr) shape.push_back(d.as_int());
+        for (const Json& d : w.arr[four ? 3 : 2].arr) shape.push_back(d.as_int());
         const char* p = blob_.data() + off;
         auto store = std::make_shared<std::vector<char>>();
         auto as_f32 = [&](size_t n, const std::function<float(size_t)>& get) {
@@ -535,8 +561,10 @@ class Runner {
         else if (kind == "weight_i8") as_f32(len, [&](size_t k) { return (float)(int8_t)p[k]; });
         else if (kind == "weight_f16") as_f32(len / 2, [&](size_t k) { uint16_t h; std::memcpy(&h, p + 2 * k, 2); return half_to_float(h); });
         else if (kind == "weight_f64") as_f32(len / 8, [&](size_t k) { double v; std::memcpy(&v, p + 8 * k, 8); return (float)v; });
-        else if (kind == "weight_i32") as_f32(len / 4, [&](size_t k) { int32_t v; std::memcpy(&v, p + 4 * k, 4); return (float)v; });
-        else if (kind == "weight_i64") {
+        else if (kind == "weight_i32" || kind == "weight_i32_f32") as_f32(len / 4, [&](size_t k) { int32_t v; std::memcpy(&v, p + 4 * k, 4); return (float)v; });
+        else if (kind == "weight_i64_f32") as_f32(len / 8, [&](size_t k) { int64_t v; std::memcpy(&v, p + 8 * k, 8); return (float)v; });
+        else if (kind == "weight_i64" || kind == "weight_i32_i64") {
+            if (kind == "weight_i32_i64") throw Error("weights view kind weight_i32_i64 is not handled");
             store->assign(p, p + len);
             weights_[key] = {TV::weight(reinterpret_cast<const int64_t*>(store->data()), shape), store};
         } else throw Error("weights view kind '" + kind + "' is not handled");
@@ -555,7 +583,8 @@ class Runner {
             if (v.kind == Val::Host) return host_tensor(v.h);
             throw Error("plan: value '" + n.at("ref").str + "' is not a tensor");
         }
-        if (n.has("weight")) return weights_.at(weight_key(n.at("weight"))).first;
+        if (n.has("some")) return tensor(n.at("some"));
+        if (n.has("weight")) return weights_.at(wkey(n.at("weight"))).first;
         if (n.has("array")) {
             HostArr h;
             h.is_int = n.has("dtype") && n.at("dtype").str == "i64";
@@ -592,15 +621,31 @@ class Runner {
             return ints_of(v.h);
         }
         if (n.has("some")) return ints(n.at("some"));
+        if (n.has("weight_list") || n.has("weight_scalar")) {
+            const TensorView& w = weights_.at(wkey(n.has("weight_list") ? n.at("weight_list") : n.at("weight_scalar"))).first;
+            std::vector<int64_t> v;
+            if (w.dtype() == LELE_I64) v = w.to_vec<int64_t>();
+            else for (float f : w.to_vec<float>()) v.push_back((int64_t)f);
+            return v;
+        }
+        if (n.has("ref")) {
+            const Val& v = ref(n.at("ref").str);
+            if (v.kind == Val::Host) return ints_of(v.h);
+        }
         throw Error("plan: integer list expected");
     }
     std::vector<float> floats(const Json& n) {
         const Json& l = n.has("some") ? n.at("some") : n;
+        if (l.has("weight_list")) return weights_.at(wkey(l.at("weight_list"))).first.to_vec<float>();
         std::vector<float> v;
         for (const Json& e : l.at("list").arr) v.push_back((float)(e.has("float") ? e.at("float").as_num() : e.at("int").as_num()));
         return v;
     }
-    int64_t integer(const Json& n) { return n.has("first") ? ints(n.at("first")).at(0) : n.at("int").as_int(); }
+    int64_t integer(const Json& n) {
+        if (n.has("first")) return ints(n.at("first")).at(0);
+        if (n.has("weight_scalar")) return ints(n).at(0);
+        return n.at("int").as_int();
+    }
     static float number(const Json& n) { return (float)(n.has("float") ? n.at("float").as_num() : n.at("int").as_num()); }
     static bool boolean(const Json& n) { return n.at("bool").b; }
 
@@ -648,12 +693,25 @@ class Runner {
         v.t = t;
         env_[st.at("out").arr.at(k).str] = v;
     }
-    Buffer& slot(const Json& st, size_t k) { return *slots_.at(st.at("slots").arr.at(k).str); }
+    std::vector<Buffer*> bufs_;  // output buffers of the statement in flight: compiled plans name them in "slots",
+                                 // lifted ones inside the argument list ({"slot"} workspace slots, {"buf"} named buffers)
+    Buffer& slot(const Json&, size_t k) { return *bufs_.at(k); }
 
     void call_stmt(const Json& st) {
         namespace K = kernels;
         const std::string& fn = st.at("fn").str;
-        const std::vector<Json>& a = st.at("args").arr;
+        std::vector<Json> a;
+        bufs_.clear();
+        if (st.has("slots"))
+            for (const Json& sname : st.at("slots").arr) bufs_.push_back(slots_.at(sname.str).get());
+        for (const Json& arg : st.at("args").arr) {
+            if (arg.has("slot")) bufs_.push_back(slots_.at(arg.at("slot").str).get());
+            else if (arg.has("buf")) {
+                auto& b = named_[arg.at("buf").str];
+                if (!b) b = std::make_unique<Buffer>();
+                bufs_.push_back(b.get());
+            } else a.push_back(arg);
+        }
         temp_.clear();
         ++calls_;
         auto opt = [&](const Json& n, TV& hold) -> const TV* { if (is_none(n)) return nullptr; hold = tensor(n); return &hold; };
@@ -664,6 +722,20 @@ class Runner {
         if (fn == "unsqueeze") return set(st, 0, K::unsqueeze(tensor(a[0]), ints(a[1])));
         if (fn == "squeeze") { const auto ax = ints(a[1]); return set(st, 0, K::squeeze(tensor(a[0]), ax.empty() ? nullptr : &ax)); }
         if (fn == "identity") return set(st, 0, tensor(a[0]));
+        if (fn == "split_owned") {  // owned results: one persistent buffer per output of THIS statement
+            const std::vector<int64_t> sizes = ints(a[2]);
+            std::vector<Buffer*> outs;
+            for (size_t k = 0; k < sizes.size(); ++k) {
+                auto& b = named_["split@" + std::to_string(stmt_) + "." + std::to_string(k)];
+                if (!b) b = std::make_unique<Buffer>();
+                outs.push_back(b.get());
+            }
+            Val v;
+            v.kind = Val::List;
+            v.list = K::split(tensor(a[0]), integer(a[1]), sizes, outs);
+            env_[st.at("out").arr[0].str] = v;
+            return;
+        }
         Buffer& o = slot(st, 0);
         static const std::map<std::string, int> unary = {{"exp", LELE_U_EXP}, {"sigmoid", LELE_U_SIGMOID}, {"tanh_kernel", LELE_U_TANH}, {"silu", LELE_U_SILU},
             {"erf", LELE_U_ERF}, {"relu", LELE_U_RELU}, {"sqrt", LELE_U_SQRT}, {"log", LELE_U_LOG}, {"sin", LELE_U_SIN}, {"cos", LELE_U_COS}, {"neg", LELE_U_NEG},
@@ -741,7 +813,8 @@ class Runner {
         }
         if (fn == "concat") {
             std::vector<TV> hold;
-            for (const Json& e : a[0].at("list").arr) hold.push_back(tensor(e));
+            if (a[0].has("refs")) for (const Json& e : a[0].at("refs").arr) hold.push_back(ref(e.str).t);
+            else for (const Json& e : a[0].at("list").arr) hold.push_back(tensor(e));
             std::vector<const TV*> ptrs;
             for (const TV& t : hold) ptrs.push_back(&t);
             return set(st, 0, K::concat(ptrs, integer(a[1]), o));
@@ -753,8 +826,7 @@ class Runner {
         if (fn == "expand") return set(st, 0, K::expand(tensor(a[0]), ints(a[1]), o));
         if (fn == "tile") return set(st, 0, K::tile(tensor(a[0]), ints(a[1]), o));
         if (fn == "split") {
-            std::vector<Buffer*> outs;
-            for (size_t k = 0; k < st.at("slots").arr.size(); ++k) outs.push_back(&slot(st, k));
+            std::vector<Buffer*> outs = bufs_;
             auto r = K::split(tensor(a[0]), integer(a[1]), ints(a[2]), outs);
             for (size_t k = 0; k < r.size(); ++k) set(st, k, r[k]);
             return;

@@ -80,3 +80,15 @@ def test_lifted_toy_plan_runs_and_matches_the_oracle_composition(tmp_path, ctx):
     assert got.shape == want.shape == (1, 2, 6)
     assert np.array_equal(got[..., 3:], want[..., 3:])                              # indices: exact
     assert np.abs(got[..., :3] - want[..., :3]).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    # the same lifted plan through the native runner (C++): identical bits
+    import json
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lele_amd", "lele_run")
+    (tmp_path / "toy_plan.json").write_text(json.dumps(plan))
+    L.write_weights_bin(plan, r.raw, str(tmp_path / "toy_weights.bin"))
+    x.tofile(tmp_path / "x.bin")
+    res = subprocess.run([exe, str(tmp_path / "toy_plan.json"), str(tmp_path / "toy_weights.bin"), "--input",
+                          "images=%s:f32:1,3,8,8" % (tmp_path / "x.bin"), "--out", str(tmp_path / "o")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert res.returncode == 0, res.stderr
+    rec = json.loads(res.stdout.strip().splitlines()[-1])
+    assert rec["outputs"] == [[1, 2, 6]] and np.array_equal(np.fromfile(tmp_path / "o0.bin", np.float32).reshape(1, 2, 6), got)

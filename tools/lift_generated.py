@@ -228,6 +228,19 @@ def synth_weights(plan, consts, seed=1234):
 from lele_amd.plan import Runner, load_weights_bin  # noqa: E402  (the runner is shared with lele_amd.compiler plans)
 
 
+def write_weights_bin(plan, weights, path):
+    """the synthetic weights as a lele `<model>_weights.bin` (every view at its recorded byte offset, in its stored type), so
+    that the native runner (lele_amd/lele_run) reads the very same values"""
+    size = max(int(off) + ln for off, (_kind, ln, _shape) in plan["weights"].items())
+    blob = bytearray(size)
+    for off, (kind, ln, _shape) in plan["weights"].items():
+        a = np.asarray(weights[int(off)])
+        raw = (a.astype("<i8") if kind.startswith("weight_i64") else a.astype("<i4") if kind.startswith("weight_i32") else a.astype("<f4")).tobytes()
+        assert len(raw) == ln, (off, kind, len(raw), ln)
+        blob[int(off):int(off) + ln] = raw
+    open(path, "wb").write(bytes(blob))
+
+
 # YOLO26n-seg integer constants read from weights.bin (inferred from the graph: see --help); offset -> value
 DEFAULT_CONSTS = {
     5445328: [1.0, 1.0, 2.0, 2.0],   # Resize scales (x2 nearest upsampling in the neck)
@@ -251,6 +264,7 @@ def main():
     b.add_argument("--const", default="")
     b.add_argument("--weights", default=None, help="a real <model>_weights.bin; default: synthetic weights")
     b.add_argument("--out", default=None)
+    b.add_argument("--native", action="store_true", help="also run the plan with the native runner (lele_amd/lele_run) and compare")
     args = ap.parse_args()
     if args.cmd == "lift":
         plan = lift(args.source)
@@ -319,6 +333,25 @@ def main():
            "images_per_s_graph": (round(1e3 / graph_ms, 1) if isinstance(graph_ms, float) else None),
            "per_op_ms_synced": prof,
            "note": "call sequence lifted from lele's generated source, synthetic weights, one image per forward"}
+    if args.native:  # the same plan, the same weights, no Python: C++ runner over the C ABI
+        import subprocess
+        import tempfile
+        exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lele_amd", "lele_run")
+        with tempfile.TemporaryDirectory() as td:
+            write_weights_bin(plan, r.raw, os.path.join(td, "w.bin"))
+            xin = x.numpy() if hasattr(x, "numpy") else TensorView(x).numpy()
+            xin.tofile(os.path.join(td, "x.bin"))
+            out = subprocess.run([exe, args.plan, os.path.join(td, "w.bin"), "--input",
+                                  "%s=%s:f32:%s" % (plan["inputs"][-1], os.path.join(td, "x.bin"), ",".join(map(str, shape))), "--out",
+                                  os.path.join(td, "o"), "--runs", str(args.batch_runs), "--graph"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            if out.returncode == 0:
+                nrec = json.loads(out.stdout.strip().splitlines()[-1])
+                same = all(np.array_equal(np.fromfile(os.path.join(td, "o%d.bin" % k), np.float32).reshape(sh_), o.numpy())
+                           for k, (sh_, o) in enumerate(zip(nrec["outputs"], r.run(inp))))
+                rec.update({"native_eager_ms_per_forward": round(nrec["eager_ms"], 3), "native_graph_ms_per_forward": round(nrec["graph_ms"], 3),
+                            "native_outputs_identical": bool(same), "native_kernel_calls": nrec["kernel_calls"]})
+            else:
+                rec["native_error"] = out.stderr.strip()[-400:]
     print(json.dumps(rec), flush=True)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
