@@ -100,7 +100,8 @@ struct LeleBuf {
     // until the buffer is written again: reserve() -- which every op calls on its output -- clears the flag.
     float* rowstat = nullptr;  // [rowstat_rows][2] on the device
     size_t rowstat_cap = 0;    // in rows
-    int64_t rowstat_rows = 0, rowstat_len = 0;
+    int64_t rowstat_rows = 0, rowstat_len = 0;  // ROWS: pairs = rows, len = row length; WHOLE: pairs = blocks, len = element count
+    int rowstat_kind = 0;                       // 0 = one pair per row (LayerNorm); 1 = pairs that together cover the whole tensor
     bool rowstat_valid = false;
     int reserve(size_t n);
     int reserve_rowstat(int64_t rows);  // may decline (returns 0 with rowstat == nullptr untouched) while capturing

@@ -788,6 +788,7 @@ int lele_hip_layer_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* sca
         if (rs) {
             out->rowstat_rows = outer;
             out->rowstat_len = norm;
+            out->rowstat_kind = 0;
             out->rowstat_valid = true;
         }
     }

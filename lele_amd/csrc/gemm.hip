@@ -43,6 +43,21 @@ int mm_shape(const LeleTensor* a, const LeleTensor* b, MmShape* s, const char* w
     return 0;
 }
 
+// the small-problem kernel publishes one {min, max} pair per workgroup next to the result (LeleBuf::rowstat, kind 1)
+float* stat_target(LeleCtx* ctx, LeleBuf* out, int64_t m, int64_t n, int64_t k, int64_t batch, int64_t* count) {
+    *count = gemm::small_kernel_blocks((int)m, (int)n, (int)k, (int)batch, ctx->num_cus);
+    if (*count <= 0 || *count > 4096 || getenv("LELE_HIP_GEMM_FORCE")) return nullptr;
+    if (out->reserve_rowstat(*count) != 0 || (size_t)*count > out->rowstat_cap) return nullptr;
+    return out->rowstat;
+}
+void stat_publish(LeleBuf* out, float* target, int64_t count, int64_t elements) {
+    if (!target) return;
+    out->rowstat_rows = count;
+    out->rowstat_len = elements;
+    out->rowstat_kind = 1;
+    out->rowstat_valid = true;
+}
+
 int run_matmul(LeleCtx* ctx, const float* da, const float* db, const MmShape& s, float* out, float alpha, float beta,
                const float* c, int cmode, int64_t clen) {
     gemm::LoadRowK al{da, s.batch_a == 1 ? 0 : s.m * s.k, s.k, (int)s.m, (int)s.k,
@@ -187,6 +202,8 @@ int lele_hip_matmul_view(LeleCtx* ctx, const LeleTensor* a, const LeleMatView* a
         const int bi = (int)batch_inner;
         gemm::EpiAffine epi{(float*)out->data + ov->offset, ov->stride_outer, (int)m, (int)n, 1.0f, 0.0f, nullptr, gemm::C_NONE, 0,
                             ov->stride_row, bi, ov->stride_inner};
+        int64_t nstat = 0;
+        epi.blockstat = stat_target(ctx, out, m, n, k, fb, &nstat);
         // A(row, k): k-contiguous -> LoadRowK(ld = row stride); row-contiguous -> LoadKRow(ld = k stride).  B likewise on (n, k).
         gemm::LoadRowK a_rk{pa, av->stride_outer, av->stride_row, (int)m, (int)k,
                             (int)(aligned16(pa) && av->stride_row % 4 == 0 && av->stride_outer % 4 == 0 && av->stride_inner % 4 == 0), bi, av->stride_inner};
@@ -200,6 +217,7 @@ int lele_hip_matmul_view(LeleCtx* ctx, const LeleTensor* a, const LeleMatView* a
         else if (!a_k && b_n) gemm::launch(ctx->stream, a_kr, b_kn, epi, (int)m, (int)n, (int)k, (int)fb, ctx->num_cus);
         else gemm::launch(ctx->stream, a_kr, b_nk, epi, (int)m, (int)n, (int)k, (int)fb, ctx->num_cus);
         LELE_HIP_CHECK(hipGetLastError());
+        stat_publish(out, epi.blockstat, nstat, total);
     }
     return set_shape_v(out_shape, out_rank, std::vector<int64_t>(out_dims, out_dims + out_dims_rank));
 }

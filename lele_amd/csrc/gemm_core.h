@@ -16,6 +16,8 @@
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include <utility>
 #include <stdlib.h>
 
 namespace gemm {
@@ -142,11 +144,46 @@ struct EpiAffine {
         }
         return c[idx];
     }
+    // {min, max} of the tile a workgroup stores, one pair per workgroup (small-problem kernel only): a dynamic quantisation
+    // that reads the whole result next reduces these pairs instead of scanning the tensor (common.h, LeleBuf::rowstat)
+    float* blockstat = nullptr;
+    __device__ __forceinline__ float value(float acc, float pre) const {
+        return __builtin_fmaf(alpha, acc, cmode == C_NONE ? 0.0f : pre * beta);
+    }
     __device__ __forceinline__ void store(int b, int row, int col, float acc, float pre) const {
         if (row >= M || col >= N) return;
-        out[ooff(b, row) + col] = __builtin_fmaf(alpha, acc, cmode == C_NONE ? 0.0f : pre * beta);
+        out[ooff(b, row) + col] = value(acc, pre);
     }
 };
+
+// epilogues that can publish per-workgroup {min, max} carry a `blockstat` member
+template <class E, class = void>
+struct has_blockstat : std::false_type {};
+template <class E>
+struct has_blockstat<E, std::void_t<decltype(std::declval<E>().blockstat)>> : std::true_type {};
+
+// min / max of `mn`, `mx` over a 256-thread workgroup -> thread 0 writes the pair (qminmax_kernel's comparisons)
+__device__ __forceinline__ void block_minmax_store(float mn, float mx, float* pair) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const float a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    __shared__ float s_mn[4], s_mx[4];
+    if ((threadIdx.x & 63) == 0) {
+        s_mn[threadIdx.x >> 6] = mn;
+        s_mx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            mn = s_mn[w] < mn ? s_mn[w] : mn;
+            mx = s_mx[w] > mx ? s_mx[w] : mx;
+        }
+        pair[0] = mn;
+        pair[1] = mx;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------- tile order
 // The dispatcher is observed to place workgroup b on XCD b % 8 (MI355X_MICROARCH.md, "Workgroup dispatch"; a matter of
@@ -355,6 +392,22 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(AL al, BL bl, EPI e
         const int r = 4 * wave + q;
         epi.store(batch, m0 + (r & 3) + 8 * (r >> 2) + 4 * hv, col, tot[q], pre[q]);
     }
+    if constexpr (has_blockstat<EPI>::value) {
+        if (epi.blockstat) {  // uniform
+            float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = 4 * wave + q;
+                const int orow = m0 + (r & 3) + 8 * (r >> 2) + 4 * hv;
+                if (orow < M && col < N) {
+                    const float v = epi.value(tot[q], pre[q]);
+                    mn = v < mn ? v : mn;
+                    mx = v > mx ? v : mx;
+                }
+            }
+            block_minmax_store(mn, mx, epi.blockstat + 2 * (size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)));
+        }
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int OCC = 1, class AL, class BL, class EPI>
@@ -374,6 +427,13 @@ inline void launch_tile(hipStream_t st, const AL& al, const BL& bl, const EPI& e
 
 // Launch with the tile that wastes the least work: padded-tile efficiency (useful / computed elements) x the tile's
 // intrinsic efficiency (bigger tiles reuse operands better), discounted when there are fewer workgroups than CUs.
+// true when launch() will take the small-problem kernel (the only one that publishes epi.blockstat): its grid size
+inline int64_t small_kernel_blocks(int M, int N, int K, int batch, int num_cus) {
+    if (M <= 0 || N <= 0 || batch <= 0 || K < 16) return 0;
+    if ((int64_t)((M + 63) / 64) * ((N + 63) / 64) * batch >= 2 * (int64_t)num_cus) return 0;
+    return (int64_t)((N + 31) / 32) * ((M + 31) / 32) * batch;
+}
+
 template <class AL, class BL, class EPI>
 inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int batch,
                    int num_cus) {

@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const int8_t* __restri
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
     const typename EPI::ColCtx cc = epi.col_ctx(col);
+    float smn = 3.40282347e+38f, smx = -3.40282347e+38f;
     float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
     if (epi.res1) {  // residual operands of the four rows this wave finishes: loaded together, from clamped coordinates
 #pragma unroll
@@ -74,10 +75,14 @@ __global__ __launch_bounds__(256) void igemm_small_kernel(const int8_t* __restri
         const typename EPI::RowCtx rc = epi.row_ctx(orow < rows ? orow : rows - 1);  // clamped: load unconditionally
         const int tot = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
         if (orow < rows && cin) {
-            if (epi.res1) epi.store_res(rc, cc, col, tot, r1[q], r2[q]);
-            else epi.store(rc, cc, col, tot);
+            const float v = epi.res1 ? epi.value_res(rc, cc, tot, r1[q], r2[q]) : epi.value(rc, cc, tot);
+            rc.orow[col] = v;
+            smn = v < smn ? v : smn;
+            smx = v > smx ? v : smx;
         }
     }
+    if (epi.blockstat)  // uniform: one {min, max} pair per workgroup for the dynamic quantisation that reads this result next
+        block_minmax_store(smn, smx, epi.blockstat + 2 * (size_t)(blockIdx.x + gridDim.x * blockIdx.y));
 }
 
 }  // namespace gemm

@@ -146,21 +146,27 @@ __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x,
         const int64_t slice = row / m;
         if (partial) {
             float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
-            // {min, max} pairs as 8-byte loads, four per lane in flight (clamped index: a repeated pair changes nothing);
-            // a one-pair-per-trip loop exposed one L2 round trip per 64 pairs -- 4 us for the 504 row pairs of a LayerNorm
+            // {min, max} pairs as 8-byte loads, all of a trip's loads in flight together (clamped index: a repeated pair changes
+            // nothing); a one-pair-per-trip loop exposed one L2 round trip per 64 pairs -- 4 us for the 504 row pairs of a LayerNorm
             const float2* pp = reinterpret_cast<const float2*>(partial) + slice * nblk;
-            for (int i0 = 0; i0 < nblk; i0 += 256) {
-                float2 v[4];
+            auto sweep = [&](int i0, auto unroll) {
+                constexpr int U = decltype(unroll)::value;
+                float2 v[U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < U; ++u) {
                     const int idx = i0 + lane + 64 * u;
                     v[u] = pp[idx < nblk ? idx : nblk - 1];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < U; ++u) {
                     mn = v[u].x < mn ? v[u].x : mn;
                     mx = v[u].y > mx ? v[u].y : mx;
                 }
+            };
+            if (nblk <= 256) {
+                sweep(0, std::integral_constant<int, 4>());
+            } else {  // up to 1024 pairs (a GEMM's per-workgroup pairs, a LayerNorm's rows) per trip: one round trip, not four
+                for (int i0 = 0; i0 < nblk; i0 += 1024) sweep(i0, std::integral_constant<int, 16>());
             }
             for (int off = 32; off > 0; off >>= 1) {
                 const float a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
@@ -261,6 +267,7 @@ struct IgemmEpi {
     // a projection in a transformer block, folded into its store (lele_hip_fused_quantized_linear_residual)
     const float* res1 = nullptr;
     const float* res2 = nullptr;
+    float* blockstat = nullptr;  // small-problem kernel: one {min, max} pair per workgroup (common.h, LeleBuf::rowstat)
     // Everything that depends only on the row (slice parameters, row-sum term, output row pointer) or only on the
     // column (column sum, weight scale, bias) is computed once per row / column of a thread's tile, not per element.
     struct RowCtx {
@@ -303,10 +310,13 @@ struct IgemmEpi {
     }
     __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, int col, int acc) const { r.orow[col] = value(r, c, acc); }
     // with residuals: the caller has loaded them (unconditionally, from clamped coordinates) before any store
-    __device__ __forceinline__ void store_res(const RowCtx& r, const ColCtx& c, int col, int acc, float r1, float r2) const {
+    __device__ __forceinline__ float value_res(const RowCtx& r, const ColCtx& c, int acc, float r1, float r2) const {
         float vf = value(r, c, acc) + r1;
         if (res2) vf = vf + r2;
-        r.orow[col] = vf;
+        return vf;
+    }
+    __device__ __forceinline__ void store_res(const RowCtx& r, const ColCtx& c, int col, int acc, float r1, float r2) const {
+        r.orow[col] = value_res(r, c, acc, r1, r2);
     }
 };
 
@@ -672,10 +682,15 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     // owns rows [s*m, (s+1)*m), i.e. m consecutive pairs -- the separate range pass over the activation is skipped.
     if (input->mem == LELE_MEM_DEVICE && m <= 2048) {
         auto it = ctx->buf_of_data.find(input->data);
-        if (it != ctx->buf_of_data.end() && it->second->rowstat_valid && it->second->rowstat_rows == rows &&
-            it->second->rowstat_len == k) {
-            partial = it->second->rowstat;
-            nblk = (int)m;
+        if (it != ctx->buf_of_data.end() && it->second->rowstat_valid) {
+            const LeleBuf* src = it->second;
+            if (src->rowstat_kind == 0 && src->rowstat_rows == rows && src->rowstat_len == k) {
+                partial = src->rowstat;
+                nblk = (int)m;
+            } else if (src->rowstat_kind == 1 && batch == 1 && src->rowstat_len == rows * k && src->rowstat_rows <= 4096) {
+                partial = src->rowstat;  // per-workgroup pairs of the GEMM that produced the tensor: one slice, all pairs
+                nblk = (int)src->rowstat_rows;
+            }
         }
     }
     if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
@@ -684,7 +699,20 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, (const int*)rs, pw.col_sums, (const QParams*)prm, 0,
                  (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
                  (const float*)dr2};
+    // small-problem kernel: publish one {min, max} pair per workgroup next to the result (for the linear that may follow)
+    const int64_t b64 = ((rows + 63) / 64) * ((n + 63) / 64), nstat = ((rows + 31) / 32) * ((n + 31) / 32);
+    const bool stats = b64 < 2 * (int64_t)ctx->num_cus && nstat <= 4096;
+    if (stats) {
+        LELE_TRY(out->reserve_rowstat(nstat));
+        if ((size_t)nstat <= out->rowstat_cap) epi.blockstat = out->rowstat;
+    }
     LELE_TRY(launch_igemm(ctx, (const int8_t*)aq, pw.wt, rows, (int)n, kp, 0, (int)m, epi));
+    if (epi.blockstat) {
+        out->rowstat_rows = nstat;
+        out->rowstat_len = rows * n;
+        out->rowstat_kind = 1;
+        out->rowstat_valid = true;
+    }
     return set_shape_v(out_shape, out_rank, shp);
 }
 

@@ -194,3 +194,36 @@ def test_residual_adds_in_the_linear_epilogue_are_bit_identical(ctx):
         assert np.array_equal(K.fused_quantized_linear_residual(x, w, ws, wz, bias, relu, r1, r2, ctx=ctx).numpy(), want2), (b, m, k, n)
         # a broadcasting residual takes the two-pass route
         assert np.array_equal(K.fused_quantized_linear_residual(x, w, ws, wz, bias, relu, r1[:, :1], ctx=ctx).numpy(), K.add(lin, r1[:, :1], ctx=ctx).numpy())
+
+
+@pytest.mark.gpu
+def test_gemm_block_statistics_feed_the_next_dynamic_quantisation(ctx):
+    """The small-problem GEMM kernels publish one {min, max} pair per workgroup; a single-slice quantised linear that reads
+    the result next uses them instead of scanning it.  Same bits as the scan (compared with the call on a host copy)."""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    rng = np.random.default_rng(91)
+
+    def qw(k, n):
+        return (Weight(np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32)),
+                Weight((rng.random(n) * 0.01 + 0.002).astype(np.float32)), Weight(np.array([128.0], np.float32)),
+                Weight(rng.standard_normal(n).astype(np.float32)))
+    for t in (504, 93, 7):
+        # ffn1 (ReLU, small-problem i8 kernel) -> ffn2
+        x = rng.standard_normal((1, t, 512)).astype(np.float32)
+        w1, w2 = qw(512, 2048), qw(2048, 512)
+        h = K.fused_quantized_linear(x, *w1, True, ctx=ctx)
+        got = K.fused_quantized_linear(h, *w2, False, ctx=ctx).numpy()
+        assert np.array_equal(got, K.fused_quantized_linear(h.numpy(), *w2, False, ctx=ctx).numpy()), t
+        # P.V stored transposed (small-problem f32 kernel) -> output projection
+        pr = rng.random((1, 4, t, t)).astype(np.float32)
+        qkv = rng.standard_normal((1, t, 1536)).astype(np.float32)
+        cv = [["slice", 2, 1024, 512], ["reshape", [0, 0, 4, 128]], ["transpose", [0, 2, 1, 3]]]
+        av = K.matmul_view(pr, [], qkv, cv, out_perm=[0, 2, 1, 3], out_reshape=[0, 0, 512], ctx=ctx)
+        wo = qw(512, 512)
+        got = K.fused_quantized_linear(av, *wo, False, ctx=ctx).numpy()
+        assert np.array_equal(got, K.fused_quantized_linear(av.numpy(), *wo, False, ctx=ctx).numpy()), t
+    # more than one slice: the pairs do not apply (a tile may straddle two slices) -- the result must still be right
+    x = rng.standard_normal((3, 40, 512)).astype(np.float32)
+    h = K.fused_quantized_linear(x, *w1, True, ctx=ctx)
+    assert np.array_equal(K.fused_quantized_linear(h, *w2, False, ctx=ctx).numpy(), K.fused_quantized_linear(h.numpy(), *w2, False, ctx=ctx).numpy())
