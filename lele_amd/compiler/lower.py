@@ -392,8 +392,11 @@ class Lowering:
                 pads = self.ints(node, 1)
             else:
                 pads = ilist("pads")
-            cv = self.opt_tensor(node, 2) if len(I) > 2 and I[2] else ({"weight": self.packer.add(np.array([at["value"]], np.float32), pb.FLOAT)}
-                                                                       if "value" in at else {"none": 1})
+            if len(I) > 2 and I[2]:  # lele::kernels::pad reads the fill value on the host (manipulation.rs:382): pass a literal
+                cv = ({"array": [float(np.asarray(self.consts[I[2]]).reshape(-1)[0])], "dtype": "f32"} if I[2] in self.consts and self.consts[I[2]].size
+                      else ({"none": 1} if I[2] in self.consts else self.tensor(I[2])))
+            else:
+                cv = {"array": [float(at["value"])], "dtype": "f32"} if "value" in at else {"none": 1}
             return self.emit(O, "pad", [T(I[0]), pads, cv, {"str": at.get("mode", "constant")}])
         if op in ("ReduceMean", "ReduceSum", "ReduceMax", "ReduceL2"):
             fn = {"ReduceMean": "reduce_mean", "ReduceSum": "reduce_sum", "ReduceMax": "reduce_max", "ReduceL2": "reduce_l2"}[op]

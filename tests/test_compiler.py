@@ -415,3 +415,63 @@ def test_extra_fusions_leave_a_sensevoice_shaped_model_bit_identical(ctx):
     assert (device(plans[False]), device(plans[True])) == (68, 33)   # 11 per layer, the Adds inside the out / ffn2 projections   # device statements of the 3-layer model (a Split is one statement, three copies)
     assert np.array_equal(plans[True, "out"], plans[False, "out"])
     assert np.array_equal(plans[True, "out"], enc.forward(TensorView(ctx.buf().upload(feats))).numpy())
+
+
+def misc_ops_model():
+    """hand-built ONNX nodes for the operators the exported models above do not contain -> (model bytes, input, idx, output names)"""
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((2, 3, 8, 8)).astype(np.float32)
+    idx = rng.integers(0, 8, (2, 3, 8, 4)).astype(np.int64)
+    i64 = lambda *v: np.array(v, np.int64)  # noqa: E731
+    init = [pb.Tensor("ax12", i64(1, 2)), pb.Tensor("pads", i64(0, 0, 1, 2, 0, 0, 2, 1)), pb.Tensor("reps", i64(1, 2, 1, 1)),
+            pb.Tensor("k3", i64(3)), pb.Tensor("idx", idx), pb.Tensor("slope", np.array([0.25], np.float32)),
+            pb.Tensor("three", np.array([3.0], np.float32)), pb.Tensor("sizes", i64(2, 3, 12, 16)), pb.Tensor("roi", np.zeros(0, np.float32)),
+            pb.Tensor("scales_none", np.zeros(0, np.float32)), pb.Tensor("two", np.array([2.0], np.float32)),
+            pb.Tensor("eshape", i64(2, 2, 3, 8, 8)), pb.Tensor("lo", np.array(-0.5, np.float32)), pb.Tensor("hi", np.array(0.75, np.float32)),
+            pb.Tensor("starts", i64(1, 7)), pb.Tensor("ends", i64(8, 0)), pb.Tensor("axes", i64(2, 3)), pb.Tensor("steps", i64(2, -3))]
+    nodes = [pb.Node("ReduceSum", ["x", "ax12"], ["rsum"], keepdims=0), pb.Node("ReduceMax", ["x"], ["rmax"], axes=[3], keepdims=1),
+             pb.Node("ReduceL2", ["x"], ["rl2"], axes=[1], keepdims=1), pb.Node("ReduceMean", ["x"], ["rmean"], axes=[0, 2], keepdims=0),
+             pb.Node("Pad", ["x", "pads"], ["padr"], mode="reflect"), pb.Node("Pad", ["x", "pads", "two"], ["padc"], mode="constant"),
+             pb.Node("Tile", ["x", "reps"], ["tiled"]), pb.Node("Expand", ["x", "eshape"], ["expanded"]),
+             pb.Node("TopK", ["x", "k3"], ["tkv", "tki"], axis=-1, largest=1), pb.Node("GatherElements", ["x", "idx"], ["gel"], axis=3),
+             pb.Node("PRelu", ["x", "slope"], ["prelu"]), pb.Node("Mod", ["x", "three"], ["mod"], fmod=0),
+             pb.Node("Softplus", ["x"], ["sp"]), pb.Node("Pow", ["x", "two"], ["sq"]),
+             pb.Node("Resize", ["x", "roi", "scales_none", "sizes"], ["rsz"], mode="nearest", coordinate_transformation_mode="asymmetric",
+                     nearest_mode="floor"),
+             pb.Node("Shape", ["x"], ["shp"]), pb.Node("ConstantOfShape", ["shp"], ["ones"], value=np.array([1.5], np.float32)),
+             pb.Node("Add", ["x", "ones"], ["plus"]), pb.Node("Clip", ["x", "lo", "hi"], ["clipped"]),
+             pb.Node("Slice", ["x", "starts", "ends", "axes", "steps"], ["sliced"]), pb.Node("Max", ["x", "two", "three"], ["mx3"]),
+             pb.Node("Flatten", ["x"], ["flat"], axis=2), pb.Node("Sub", ["flat", "flat"], ["zero"])]
+    outs = ["rsum", "rmax", "rl2", "rmean", "padr", "padc", "tiled", "expanded", "tkv", "tki", "gel", "prelu", "mod", "sp", "sq", "rsz", "plus",
+            "clipped", "sliced", "mx3", "zero"]
+    g = pb.Graph(nodes, [pb.ValueInfo("x", pb.FLOAT, [2, 3, "h", 8])], [pb.ValueInfo(o, pb.FLOAT, None) for o in outs], init)
+    return pb.Model(g, opset=13).serialize(), x, idx, outs
+
+
+@pytest.mark.gpu
+def test_lowering_of_the_remaining_operators_against_numpy(ctx):
+    """every result of misc_ops_model is a graph output and is compared with a numpy statement of the ONNX definition (index /
+    selection ops exactly, arithmetic to 2e-6)"""
+    from lele_amd.tensor import TensorView
+    data, x, idx, outs = misc_ops_model()
+    plan, blob = compile_model(data)
+    _, res = run_plan(ctx, plan, blob, {"x": TensorView(ctx.buf().upload(x))})
+    got = {o: r.numpy() for o, r in zip(outs, res)}
+    order = np.argsort(-x, axis=-1, kind="stable")[..., :3]
+    want = {"rsum": x.sum((1, 2)), "rmax": x.max(3, keepdims=True), "rl2": np.sqrt((x.astype(np.float64) ** 2).sum(1, keepdims=True)),
+            # reflect follows the reference's own index rule at the far edge (manipulation.rs:382-587; oracle npref.pad), not numpy's
+            "rmean": x.mean((0, 2)), "padr": __import__("oracle.npref", fromlist=["pad"]).pad(x, [0, 0, 1, 2, 0, 0, 2, 1], 0.0, "reflect"),
+            "padc": np.pad(x, ((0, 0), (0, 0), (1, 2), (2, 1)), constant_values=2.0), "tiled": np.tile(x, (1, 2, 1, 1)),
+            "expanded": np.broadcast_to(x, (2, 2, 3, 8, 8)), "tkv": np.take_along_axis(x, order, -1), "tki": order.astype(np.float32),
+            "gel": np.take_along_axis(x, idx, 3), "prelu": np.where(x < 0, x * 0.25, x), "mod": x - 3.0 * np.floor(x / 3.0),
+            "sp": np.log1p(np.exp(x.astype(np.float64))), "sq": x.astype(np.float64) ** 2,
+            "rsz": x[:, :, (np.arange(12) * 8 // 12)][:, :, :, (np.arange(16) * 8 // 16)], "plus": x + 1.5, "clipped": np.clip(x, -0.5, 0.75),
+            "sliced": x[:, :, 1:8:2, 7:0:-3], "mx3": np.maximum(np.maximum(x, 2.0), 3.0), "zero": np.zeros((6, 64), np.float32)}
+    exact = {"rmax", "padr", "padc", "tiled", "expanded", "tkv", "tki", "gel", "prelu", "rsz", "plus", "clipped", "sliced", "mx3", "zero"}
+    for o in outs:
+        w = np.asarray(want[o])
+        assert got[o].shape == w.shape, (o, got[o].shape, w.shape)
+        if o in exact:
+            assert np.array_equal(got[o], w.astype(np.float32)), o
+        else:
+            assert np.abs(got[o] - w).max() <= 2e-6 * max(1.0, np.abs(w).max()), (o, np.abs(got[o] - w).max())

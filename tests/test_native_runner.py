@@ -53,9 +53,12 @@ def test_native_runner_matches_python_runner(ctx, tmp_path):
         ("attention", Attention().eval(), {"x": torch.randn(2, 9, 32, generator=g), "ids": torch.tensor([[1, 7], [3, 3]])},
          dict(opset=17, input_names=("x", "ids"))),
     ]
+    from tests.test_compiler import misc_ops_model
+    misc_bytes, misc_x, _idx, _outs = misc_ops_model()
+    cases.append(("misc", misc_bytes, {"x": torch.from_numpy(misc_x)}, {}))
     for name, model, inp, kw in cases:
         example = tuple(torch.randn(1, 8, 12) if name == "seq" else v for v in inp.values())
-        plan, blob = compile_model(export(model, example, **kw), name)
+        plan, blob = compile_model(model if isinstance(model, bytes) else export(model, example, **kw), name)
         feeds = {k: v.numpy() for k, v in inp.items()}
         r = Runner(plan, load_weights_bin(plan, blob), ctx)
         want = [o.numpy() for o in r.run({k: (TensorView(ctx.buf().upload(v)) if v.dtype != np.int64 else v) for k, v in feeds.items()})]
