@@ -182,6 +182,7 @@ def main():
     ap.add_argument("--configs", default="c3,c4")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph leg (rocprofv3 cannot trace captures)")
     ap.add_argument("--via-onnx", action="store_true", help="also build the model as ONNX, compile it with lele_amd.compiler and run the plan")
+    ap.add_argument("--streams", type=int, default=0, help="with --via-onnx: also replay the compiled graph on N contexts (N HIP streams) at once")
     ap.add_argument("--compiled-only", action="store_true", help="profiling aid: only the compiled plan, eagerly, --runs times (use with rocprofv3)")
     args = ap.parse_args()
     import lele_amd
@@ -250,6 +251,7 @@ def main():
         if args.via_onnx:  # ONNX bytes -> compiled plan -> the same call sequence; logits must be identical
             from lele_amd.compiler import compile_model
             from lele_amd.plan import Runner, load_weights_bin
+            from lele_amd.tensor import TensorView as TensorViewOf
             t0 = time.perf_counter()
             data = encoder_onnx(enc, batch)
             plan, blob = compile_model(data, "sensevoice_shaped")
@@ -279,6 +281,34 @@ def main():
                         "plan_statements": len(plan["statements"]), "plan_slots": len(plan["slots"]), "weights_bin_bytes": len(blob),
                         "compile_s": round(t_compile, 2), "plan_calls": fn_count, "compiled_logits_identical": same,
                         "compiled_graph_ms": round(1e3 * float(np.mean(tg)), 3)}
+            if args.streams > 1:  # N independent requests in flight: one ctx (= one stream, one workspace, one graph) each
+                import lele_amd as _la
+                weights = load_weights_bin(plan, blob)
+                ctxs = [ctx] + [_la._lib.Ctx(0) for _ in range(args.streams - 1)]
+                graphs = []
+                fh = feats.numpy()
+                for c in ctxs:
+                    rr = Runner(plan, weights, c)
+                    fx = TensorViewOf(c.buf().upload(fh))
+                    rr.run({"feats": fx})
+                    c.sync()
+                    c.graph_begin()
+                    rr.run({"feats": fx})
+                    graphs.append((c, c.graph_end(), rr, fx))
+                for c, gph, _r, _f in graphs:
+                    gph.launch()
+                for c, *_ in graphs:
+                    c.sync()
+                ts = []
+                for _ in range(args.runs):
+                    t0 = time.perf_counter()
+                    for c, gph, _r, _f in graphs:
+                        gph.launch()
+                    for c, *_ in graphs:
+                        c.sync()
+                    ts.append(time.perf_counter() - t0)
+                onnx_rec.update({"streams": args.streams, "streams_ms_per_round": round(1e3 * float(np.mean(ts)), 3),
+                                 "streams_ms_per_forward": round(1e3 * float(np.mean(ts)) / args.streams, 3)})
             # the same plan through the native runner (lele_amd/lele_run: C++ over the C ABI, no Python on the serving path)
             exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lele_amd", "lele_run")
             if os.path.exists(exe):
