@@ -386,7 +386,10 @@ class Lowering:
         if op == "Tile":
             return self.emit(O, "tile", [T(I[0]), self.ints(node, 1)])
         if op == "Split":
-            return self.emit(O, "split", [T(I[0]), {"int": at.get("axis", 0)}, self.ints(node, 1, "split", at, [0] * len(O))], n_bufs=len(O))
+            if not (len(I) > 1 and I[1]) and "split" not in at:
+                # the Rust emitter writes zeros here (ops/tensor.rs:330-338) and the kernel then panics on the size check
+                raise CompileError("Split %r: no explicit sizes (equal split by output count) -- not supported by lele's split kernel" % node.name)
+            return self.emit(O, "split", [T(I[0]), {"int": at.get("axis", 0)}, self.ints(node, 1, "split", at)], n_bufs=len(O))
         if op == "Pad":
             if len(I) > 1 and I[1]:
                 pads = self.ints(node, 1)
