@@ -133,7 +133,7 @@ __device__ __forceinline__ float quant_one(float v, const QParams& q, bool simd_
 // MODE 0 with `partial` != NULL: the slice's {scale, zp} are derived here from the min/max partials (every wave
 // repeats the same few-hundred-element reduction, which is cheaper than a separate launch) and the first row of each
 // slice publishes them to prm[] for the GEMM epilogue.
-template <int MODE>
+template <int MODE, bool PREFETCH = false>
 __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x, int64_t rows, int k, int kp, int m,
                                                     QParams* __restrict__ prm, int8_t* __restrict__ aq,
                                                     int* __restrict__ row_sums, const float* __restrict__ partial,
@@ -141,6 +141,22 @@ __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x,
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    // PREFETCH (few rows: the launch is latency-bound): the row's elements are requested FIRST (up to 8 x 16 bytes per lane,
+    // K <= 2048), so that they travel while the range partials are fetched and reduced below -- two dependent round trips
+    // become one.  With many rows the streaming loop is better (more waves in flight per SIMD): +3 % on the batched case.
+    constexpr int MAXC = 8;
+    const float* xrow = x + row * k;
+    const bool fast = PREFETCH && (k & 3) == 0 && k >= 4 && (((uintptr_t)x & 15) == 0) && kp <= 256 * MAXC;
+    const int nch = (kp + 255) / 256;
+    float4 pre[MAXC];
+    if (fast) {
+#pragma unroll
+        for (int u = 0; u < MAXC; ++u)
+            if (u < nch) {  // uniform
+                const int c = lane * 4 + 256 * u;
+                pre[u] = *reinterpret_cast<const float4*>(xrow + (c < k ? c : k - 4));
+            }
+    }
     QParams q;
     if (MODE == 0) {
         const int64_t slice = row / m;
@@ -184,6 +200,35 @@ __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x,
     const int simd_k = k & ~7;
     const bool vec4 = (k & 3) == 0 && (((uintptr_t)x & 15) == 0);  // every row start is then 16-byte aligned
     int sum = 0;
+    if (fast) {
+#pragma unroll
+        for (int u = 0; u < MAXC; ++u)
+            if (u < nch) {
+                const int c = lane * 4 + 256 * u;
+                if (c < kp) {
+                    const float xv[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
+                    int packed = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kk = c + e;
+                        int v = 0;
+                        if (kk < k) {
+                            float qf;
+                            if (MODE == 0)
+                                qf = quant_one(xv[e], q, kk < simd_k);
+                            else {
+                                const float r = rintf(xv[e]);
+                                qf = r < 0.0f ? 0.0f : (r > 255.0f ? 255.0f : r);
+                            }
+                            v = (int)qf - 128;
+                            sum += v;
+                        }
+                        packed |= (v & 0xff) << (8 * e);
+                    }
+                    *reinterpret_cast<int*>(dst + c) = packed;
+                }
+            }
+    } else
     for (int c = lane * 4; c < kp; c += 256) {
         float xv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (vec4 && c + 3 < k) {
@@ -694,8 +739,12 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
         }
     }
     if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
-    hipLaunchKernelGGL(qrows_kernel<0>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
-                       rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk);
+    if (rows <= 2048)
+        hipLaunchKernelGGL((qrows_kernel<0, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
+                           rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk);
+    else
+        hipLaunchKernelGGL((qrows_kernel<0, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
+                           rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk);
     IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, (const int*)rs, pw.col_sums, (const QParams*)prm, 0,
                  (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
                  (const float*)dr2};
