@@ -287,28 +287,30 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ x, 
 // index keeps the tie-break "lower index first"), rank among the survivors.
 __global__ __launch_bounds__(256) void topk_threshold_kernel(const float* __restrict__ x, int64_t n, int64_t k, int largest,
                                                              float* __restrict__ t0, int* __restrict__ count) {
-    // grid (8, rows): 2048 sample elements, one per thread, each ranked against the whole sample held in LDS
+    // grid (32, rows): 2048 sample elements, FOUR lanes per element (each scans a quarter of the sample held in LDS; the four
+    // partial ranks meet by shuffle) -- the serial 2048-step scan per element was the longest kernel of the YOLO post-processing
     __shared__ __attribute__((aligned(16))) float chunk[2048];
     const float* row = x + (int64_t)blockIdx.y * n;
     const int m = (int)(n < 2048 ? n : 2048);
     for (int t = threadIdx.x; t < 2048; t += 256) chunk[t] = t < m ? row[t] : __builtin_nanf("");
     __syncthreads();
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= m) return;
-    const float v = chunk[e];
+    const int e = blockIdx.x * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
+    const float v = chunk[e < 2048 ? e : 2047];
     int rank = 0;
-    const float4* c4 = reinterpret_cast<const float4*>(chunk);
+    const float4* c4 = reinterpret_cast<const float4*>(chunk) + 128 * part;
 #pragma unroll 4
-    for (int t = 0; t < 512; ++t) {
+    for (int t = 0; t < 128; ++t) {
         const float4 u = c4[t];
         const float uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool beats = largest ? (uu[q] > v) : (uu[q] < v);
-            rank += (beats || (uu[q] == v && 4 * t + q < e)) ? 1 : 0;
+            rank += (beats || (uu[q] == v && 512 * part + 4 * t + q < e)) ? 1 : 0;
         }
     }
-    if (rank == k - 1) t0[blockIdx.y] = v;  // exactly one element of the sample has this rank
+    rank += __shfl_xor(rank, 1);
+    rank += __shfl_xor(rank, 2);
+    if (part == 0 && e < m && rank == k - 1) t0[blockIdx.y] = v;  // exactly one element of the sample has this rank
 }
 __global__ void topk_init_kernel(int64_t rows, int largest, float* __restrict__ t0, int* __restrict__ count) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -333,12 +335,14 @@ __global__ __launch_bounds__(256) void topk_compact_kernel(const float* __restri
 __global__ __launch_bounds__(256) void topk_rank_kernel(const float* __restrict__ cv, const int* __restrict__ ci, int64_t n,
                                                         int64_t k, int largest, const int* __restrict__ count,
                                                         float* __restrict__ values, float* __restrict__ indices) {
+    // 64 candidates per workgroup, four lanes each: lane `part` ranks its candidate against every fourth survivor of the
+    // LDS chunk, the partial ranks meet by shuffle
     __shared__ float sv[1024];
     __shared__ int si[1024];
     const int64_t rowi = blockIdx.y;
     const int m = count[rowi];
-    if ((int64_t)blockIdx.x * 256 >= m) return;  // uniform per workgroup
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    if ((int64_t)blockIdx.x * 64 >= m) return;  // uniform per workgroup
+    const int j = blockIdx.x * 64 + (threadIdx.x >> 2), part = threadIdx.x & 3;
     const bool in = j < m;
     const float v = in ? cv[rowi * n + j] : 0.0f;
     const int vi = in ? ci[rowi * n + j] : 0;
@@ -352,13 +356,15 @@ __global__ __launch_bounds__(256) void topk_rank_kernel(const float* __restrict_
         }
         __syncthreads();
 #pragma unroll 4
-        for (int t = 0; t < 1024; ++t) {
+        for (int t = part; t < 1024; t += 4) {
             const float u = sv[t];
             const bool beats = largest ? (u > v) : (u < v);
             rank += (beats || (u == v && si[t] < vi)) ? 1 : 0;
         }
     }
-    if (in && rank < k) {
+    rank += __shfl_xor(rank, 1);
+    rank += __shfl_xor(rank, 2);
+    if (in && part == 0 && rank < k) {
         values[rowi * k + rank] = v;
         indices[rowi * k + rank] = (float)vi;
     }
@@ -779,11 +785,12 @@ int lele_hip_topk(LeleCtx* ctx, const LeleTensor* x, int64_t k, int largest, Lel
             LELE_TRY(ctx->arena_alloc((size_t)rows * n * 4, &ci));
             hipLaunchKernelGGL(topk_init_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, rows, largest,
                                (float*)t0, (int*)cnt);
-            hipLaunchKernelGGL(topk_threshold_kernel, dim3(8, (unsigned)rows), dim3(256), 0, ctx->stream, (const float*)dx, n, kk,
+            hipLaunchKernelGGL(topk_threshold_kernel, dim3(32, (unsigned)rows), dim3(256), 0, ctx->stream, (const float*)dx, n, kk,
                                largest, (float*)t0, (int*)cnt);
             hipLaunchKernelGGL(topk_compact_kernel, tgrid, dim3(256), 0, ctx->stream, (const float*)dx, n, largest,
                                (const float*)t0, (int*)cnt, (float*)cv, (int*)ci);
-            hipLaunchKernelGGL(topk_rank_kernel, tgrid, dim3(256), 0, ctx->stream, (const float*)cv, (const int*)ci, n, kk,
+            const dim3 rgrid((unsigned)((n + 63) / 64), (unsigned)rows);
+            hipLaunchKernelGGL(topk_rank_kernel, rgrid, dim3(256), 0, ctx->stream, (const float*)cv, (const int*)ci, n, kk,
                                largest, (const int*)cnt, (float*)out_values->data, (float*)out_indices->data);
         }
         LELE_HIP_CHECK(hipGetLastError());
