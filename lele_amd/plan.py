@@ -48,6 +48,49 @@ def weight_key(node):
     return "%d:%s:%s" % (off, kind, "x".join(map(str, shape)))
 
 
+def fuse_sigmoid_mul(plan, shapes):
+    """Peephole for plans lifted from lele-generated Rust: `s = sigmoid(x)` ... `z = mul(x, s)` (s read nowhere else) becomes
+    `z = silu(x)` in the mul's place and buffer -- lele's own "SiLU" pattern, which its window-based matcher misses when the
+    branches of a block are interleaved (the generated Yolo26n-seg has 39 such pairs).  Only where the element count is a
+    multiple of 8 (`shapes`: value name -> shape, recorded by a first run): there x * sigmoid(x) and silu(x) are the same bits;
+    on a ragged tail the reference's silu divides instead of multiplying by the reciprocal.  Returns a new plan."""
+    sts = plan["statements"]
+
+    def refs(n, acc):
+        if isinstance(n, dict):
+            if isinstance(n.get("ref"), str):
+                acc.append(n["ref"])
+            acc += n.get("refs", [])
+            for v in n.values():
+                refs(v, acc)
+        elif isinstance(n, list):
+            for v in n:
+                refs(v, acc)
+        return acc
+    readers = {}
+    for i, st in enumerate(sts):
+        for r in refs(st.get("args"), []):
+            readers.setdefault(r, []).append(i)
+    drop, replace = set(), {}
+    for i, st in enumerate(sts):
+        if st.get("fn") != "sigmoid" or "ref" not in st["args"][0]:
+            continue
+        x, sg = st["args"][0]["ref"], st["out"][0]
+        rd = readers.get(sg, [])
+        if len(rd) != 1 or sg in plan["outputs"] or int(np.prod(shapes.get(x, [1]))) % 8:
+            continue
+        mul = sts[rd[0]]
+        ops = [a.get("ref") for a in mul.get("args", []) if isinstance(a, dict) and "ref" in a]
+        if mul.get("fn") != "mul" or sorted(ops) != sorted([x, sg]):
+            continue
+        outbuf = [a for a in mul["args"] if "slot" in a or "buf" in a]
+        replace[rd[0]] = dict(mul, fn="silu", args=[{"ref": x}] + outbuf)
+        drop.add(i)
+    new = dict(plan)
+    new["statements"] = [replace.get(i, st) for i, st in enumerate(sts) if i not in drop]
+    return new
+
+
 class Runner:
     def __init__(self, plan, weights, ctx):
         from . import kernels as K
@@ -61,6 +104,7 @@ class Runner:
         self.calls = 0
         self.profile = None
         self.stmt_index = 0
+        self.shapes = None  # set to {} to record the shape of every tensor value of the next run
 
     def _wkey(self, node):
         return weight_key(node) if self.v2 else node[1]
@@ -186,4 +230,8 @@ class Runner:
                 else:
                     for name, r in zip(st["out"], res):
                         env[name] = r
+        if self.shapes is not None:
+            for name, v in env.items():
+                if hasattr(v, "shape"):
+                    self.shapes[name] = [int(d) for d in v.shape]
         return [env[o] for o in self.plan["outputs"]]

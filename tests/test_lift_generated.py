@@ -92,3 +92,20 @@ def test_lifted_toy_plan_runs_and_matches_the_oracle_composition(tmp_path, ctx):
     assert res.returncode == 0, res.stderr
     rec = json.loads(res.stdout.strip().splitlines()[-1])
     assert rec["outputs"] == [[1, 2, 6]] and np.array_equal(np.fromfile(tmp_path / "o0.bin", np.float32).reshape(1, 2, 6), got)
+
+
+def test_sigmoid_mul_peephole_only_where_it_is_bit_identical():
+    from lele_amd.plan import fuse_sigmoid_mul
+    st = [{"op": "call", "out": ["y"], "fn": "conv2d", "args": [{"ref": "images"}, {"slot": "buf_0"}]},
+          {"op": "call", "out": ["s"], "fn": "sigmoid", "args": [{"ref": "y"}, {"slot": "buf_1"}]},
+          {"op": "call", "out": ["t"], "fn": "relu", "args": [{"ref": "images"}, {"slot": "buf_3"}]},
+          {"op": "call", "out": ["z"], "fn": "mul", "args": [{"ref": "y"}, {"ref": "s"}, {"slot": "buf_2"}]},
+          {"op": "call", "out": ["o"], "fn": "add", "args": [{"ref": "z"}, {"ref": "t"}, {"slot": "buf_1"}]}]
+    plan = {"inputs": ["images"], "outputs": ["o"], "slots": ["buf_0", "buf_1", "buf_2", "buf_3"], "statements": st, "weights": {}}
+    fused = fuse_sigmoid_mul(plan, {"y": [1, 4, 4, 4]})
+    assert [s["fn"] for s in fused["statements"]] == ["conv2d", "relu", "silu", "add"]
+    assert fused["statements"][2] == {"op": "call", "out": ["z"], "fn": "silu", "args": [{"ref": "y"}, {"slot": "buf_2"}]}
+    assert len(plan["statements"]) == 5                                                   # the input plan is untouched
+    assert len(fuse_sigmoid_mul(plan, {"y": [1, 3, 3, 3]})["statements"]) == 5          # 27 elements: a ragged tail -> left alone
+    st[4]["args"][1] = {"ref": "s"}                                                       # the sigmoid is read a second time -> left alone
+    assert len(fuse_sigmoid_mul(plan, {"y": [1, 4, 4, 4]})["statements"]) == 5

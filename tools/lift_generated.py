@@ -225,7 +225,7 @@ def synth_weights(plan, consts, seed=1234):
     return out
 
 
-from lele_amd.plan import Runner, load_weights_bin  # noqa: E402  (the runner is shared with lele_amd.compiler plans)
+from lele_amd.plan import Runner, fuse_sigmoid_mul, load_weights_bin  # noqa: E402  (the runner is shared with lele_amd.compiler plans)
 
 
 def write_weights_bin(plan, weights, path):
@@ -264,6 +264,7 @@ def main():
     b.add_argument("--const", default="")
     b.add_argument("--weights", default=None, help="a real <model>_weights.bin; default: synthetic weights")
     b.add_argument("--out", default=None)
+    b.add_argument("--as-lifted", action="store_true", help="run the call sequence exactly as lifted (no sigmoid+mul -> silu peephole)")
     b.add_argument("--native", action="store_true", help="also run the plan with the native runner (lele_amd/lele_run) and compare")
     args = ap.parse_args()
     if args.cmd == "lift":
@@ -289,9 +290,26 @@ def main():
     x = ctx.buf().upload(rng.uniform(0, 1, shape).astype(np.float32))  # section 8(d): uniform[0,1) images
     from lele_amd.tensor import TensorView
     inp = {plan["inputs"][-1]: TensorView(x)}
+    r.shapes = {}
     outs = r.run(inp)
+    shapes, r.shapes = r.shapes, None
     calls = r.calls
-    shapes = [list(o.shape) for o in outs]
+    reference_outputs = [o.numpy().copy() for o in outs]
+    if not args.as_lifted:  # the bit-identical peephole lele's window matcher misses (plan.fuse_sigmoid_mul)
+        fused = fuse_sigmoid_mul(plan, shapes)
+        if len(fused["statements"]) != len(plan["statements"]):
+            r2 = Runner(fused, r.raw, ctx)
+            same = all(np.array_equal(a, b.numpy()) for a, b in zip(reference_outputs, r2.run(inp)))
+            if not same:
+                raise SystemExit("sigmoid+mul -> silu changed the outputs: refusing to use the fused plan")
+            fused_away = len(plan["statements"]) - len(fused["statements"])
+            plan, r = fused, r2
+            calls_fused = calls - fused_away
+        else:
+            fused_away, calls_fused = 0, calls
+    else:
+        fused_away, calls_fused = 0, calls
+    out_shapes = [list(o.shape) for o in outs]
     finite = all(bool(np.isfinite(o.numpy()).all()) for o in outs)
     for _ in range(2):
         r.run(inp)
@@ -328,7 +346,8 @@ def main():
     except Exception as e:  # noqa: BLE001
         ctx.graph_abort()
         graph_ms = "capture failed: %s" % e
-    rec = {"model": plan["source"], "input_shape": shape, "kernel_calls_per_forward": calls, "output_shapes": shapes,
+    rec = {"model": plan["source"], "input_shape": shape, "kernel_calls_per_forward": calls, "kernel_calls_after_silu_peephole": calls_fused,
+           "output_shapes": out_shapes,
            "finite": finite, "eager_ms_per_forward": round(1e3 * float(np.mean(eager)), 3), "graph_ms_per_forward": graph_ms,
            "images_per_s_graph": (round(1e3 / graph_ms, 1) if isinstance(graph_ms, float) else None),
            "per_op_ms_synced": prof,
@@ -339,9 +358,10 @@ def main():
         exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lele_amd", "lele_run")
         with tempfile.TemporaryDirectory() as td:
             write_weights_bin(plan, r.raw, os.path.join(td, "w.bin"))
+            json.dump(plan, open(os.path.join(td, "plan.json"), "w"))   # the plan as executed above (after the peephole)
             xin = x.numpy() if hasattr(x, "numpy") else TensorView(x).numpy()
             xin.tofile(os.path.join(td, "x.bin"))
-            out = subprocess.run([exe, args.plan, os.path.join(td, "w.bin"), "--input",
+            out = subprocess.run([exe, os.path.join(td, "plan.json"), os.path.join(td, "w.bin"), "--input",
                                   "%s=%s:f32:%s" % (plan["inputs"][-1], os.path.join(td, "x.bin"), ",".join(map(str, shape))), "--out",
                                   os.path.join(td, "o"), "--runs", str(args.batch_runs), "--graph"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
             if out.returncode == 0:
