@@ -749,6 +749,8 @@ def allocate(statements, outputs):
             for key in ("ref", "ints"):
                 if key in n and isinstance(n[key], str):
                     acc.append(n[key])
+            if isinstance(n.get("refs"), list):   # lifted plans: a concat's operand list
+                acc += n["refs"]
             for v in n.values():
                 refs(v, acc)
         elif isinstance(n, list):

@@ -91,6 +91,90 @@ def fuse_sigmoid_mul(plan, shapes):
     return new
 
 
+def replan_lifted(plan, shapes):
+    """A plan lifted from lele-generated Rust, re-planned: buffers re-assigned by this library's liveness allocator
+    (lele_amd.compiler.lower.allocate) instead of lele's, which makes statement-level fusions safe that move a result into
+    another statement -- here `conv2d` followed by a private `silu` (itself from fuse_sigmoid_mul) -> `conv2d_silu`, wherever
+    the plane size is a multiple of 8 (then the convolution's SiLU epilogue and the separate kernel are the same bits).
+    `split_owned` + `swap_remove` become one `split` with named outputs.  Returns a format-2 plan (runs in both runners)."""
+    from .compiler.lower import allocate
+    src = plan["statements"]
+    ints = {}                                          # the generated code re-binds the same names: track the latest value
+    out, i = [], 0
+    while i < len(src):
+        st = src[i]
+        op = st["op"]
+        if op == "newbuf" or op == "swap_remove":
+            i += 1
+            continue
+        if op == "alias":
+            out.append({"op": "call", "out": list(st["out"]), "fn": "identity", "args": [{"ref": st["src"]}], "bufs": 0})
+        elif op == "ints":
+            ints[st["out"][0]] = st["value"]
+            out.append(dict(st))
+        elif st.get("fn") == "split_owned":
+            lst = st["out"][0]
+            sizes = ints[st["args"][2]["ref"]]
+            order = list(range(len(sizes)))           # Vec::swap_remove semantics, simulated on the index list
+            names = {}
+            j = i + 1
+            while j < len(src) and order:
+                nx = src[j]
+                if nx["op"] == "swap_remove" and nx["list"] == lst:
+                    k = nx["index"]
+                    names[order[k]] = nx["out"][0]
+                    order[k] = order[-1]
+                    order.pop()
+                elif nx.get("fn") == "split_owned" and nx["out"][0] == lst:
+                    break
+                j += 1
+            outs = [names.get(k, "%s__unused%d_%d" % (lst, i, k)) for k in range(len(sizes))]
+            out.append({"op": "call", "out": outs, "fn": "split", "args": [st["args"][0], st["args"][1], {"list": [{"int": int(v)} for v in sizes]}],
+                        "bufs": len(sizes)})
+        else:
+            args = [a for a in st["args"] if not (isinstance(a, dict) and ("slot" in a or "buf" in a))]
+            nb = len(st["args"]) - len(args)
+            if st["fn"] in ("reshape", "flatten", "unsqueeze", "squeeze", "identity"):
+                nb = 0
+            out.append({"op": "call", "out": list(st["out"]), "fn": st["fn"], "args": args, "bufs": nb})
+        i += 1
+    # conv2d -> private silu  =>  conv2d_silu
+    readers = {}
+
+    def refs(n, acc):
+        if isinstance(n, dict):
+            if isinstance(n.get("ref"), str):
+                acc.append(n["ref"])
+            acc += n.get("refs", [])
+            for v in n.values():
+                refs(v, acc)
+        elif isinstance(n, list):
+            for v in n:
+                refs(v, acc)
+        return acc
+    for k, st in enumerate(out):
+        for r in refs(st.get("args"), []):
+            readers.setdefault(r, []).append(k)
+    dead = set()
+    for k, st in enumerate(out):
+        if st.get("fn") != "conv2d":
+            continue
+        y = st["out"][0]
+        rd = readers.get(y, [])
+        shp = shapes.get(y, [])
+        if len(rd) != 1 or y in plan["outputs"] or len(shp) != 4 or (shp[2] * shp[3]) % 8 or out[rd[0]].get("fn") != "silu":
+            continue
+        st["fn"], st["out"] = "conv2d_silu", list(out[rd[0]]["out"])
+        dead.add(rd[0])
+    out = [st for k, st in enumerate(out) if k not in dead]
+    slots = allocate(out, list(plan["outputs"]))
+    weights = {}
+    for off, (kind, ln, shape) in plan["weights"].items():
+        weights[weight_key([kind, int(off), ln, shape])] = [kind, int(off), ln, shape]
+    return {"source": plan["source"], "format": "lele_amd.plan/2", "inputs": list(plan["inputs"]), "outputs": list(plan["outputs"]),
+            "slots": slots, "statements": out, "weights": weights}
+
+
 class Runner:
     def __init__(self, plan, weights, ctx):
         from . import kernels as K

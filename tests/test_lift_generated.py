@@ -109,3 +109,34 @@ def test_sigmoid_mul_peephole_only_where_it_is_bit_identical():
     assert len(fuse_sigmoid_mul(plan, {"y": [1, 3, 3, 3]})["statements"]) == 5          # 27 elements: a ragged tail -> left alone
     st[4]["args"][1] = {"ref": "s"}                                                       # the sigmoid is read a second time -> left alone
     assert len(fuse_sigmoid_mul(plan, {"y": [1, 4, 4, 4]})["statements"]) == 5
+
+
+def test_replan_lifted_structure():
+    """plan.replan_lifted: lele's slot arguments go, buffers come from the liveness allocator, split_owned + swap_remove
+    become one split with named outputs, and conv2d -> private silu folds only where the plane is a multiple of 8"""
+    from lele_amd.plan import replan_lifted
+    w = ["weight_f32", 0, 64, [4, 4, 1, 1]]
+    st = [{"op": "newbuf", "out": ["buf_9"]},
+          {"op": "call", "out": ["y"], "fn": "conv2d", "args": [{"ref": "images"}, {"weight": w}, {"none": 1}, {"slot": "buf_0"}]},
+          {"op": "call", "out": ["z"], "fn": "silu", "args": [{"ref": "y"}, {"slot": "buf_1"}]},
+          {"op": "ints", "out": ["sizes"], "value": [1, 2, 1]},
+          {"op": "call", "out": ["parts"], "fn": "split_owned", "args": [{"ref": "z"}, {"int": 1}, {"ref": "sizes"}]},
+          {"op": "swap_remove", "out": ["a"], "list": "parts", "index": 0},      # [0,1,2] -> a = part 0, list = [2,1]
+          {"op": "swap_remove", "out": ["c"], "list": "parts", "index": 0},      # c = part 2, list = [1]
+          {"op": "swap_remove", "out": ["b"], "list": "parts", "index": 0},      # b = part 1
+          {"op": "alias", "out": ["b2"], "src": "b"},
+          {"op": "call", "out": ["o"], "fn": "concat", "args": [{"refs": ["a", "b2", "c"]}, {"int": 1}, {"slot": "buf_0"}]}]
+    plan = {"source": "t", "inputs": ["images"], "outputs": ["o"], "slots": ["buf_0", "buf_1", "buf_9"], "statements": st,
+            "weights": {"0": ["weight_f32", 64, [4, 4, 1, 1]]}}
+    re = replan_lifted(plan, {"y": [1, 4, 4, 4]})
+    assert re["format"] == "lele_amd.plan/2" and list(re["weights"]) == ["0:weight_f32:4x4x1x1"]
+    assert [s.get("fn", s["op"]) for s in re["statements"]] == ["conv2d_silu", "ints", "split", "identity", "concat"]
+    conv, _, split, ident, cat = re["statements"]
+    assert conv["out"] == ["z"] and conv["bufs"] == 1 and all("slot" not in a for a in conv["args"])
+    assert split["out"] == ["a", "b", "c"] and split["bufs"] == 3 and split["args"][2] == {"list": [{"int": 1}, {"int": 2}, {"int": 1}]}
+    assert ident == {"op": "call", "out": ["b2"], "fn": "identity", "args": [{"ref": "b"}], "bufs": 0}
+    assert set(conv["slots"] + split["slots"] + cat["slots"]) <= set(re["slots"]) and len(cat["slots"]) == 1
+    live = set(split["slots"])                     # a, b (through its alias) and c are all read by the concat: distinct from its output
+    assert len(live) == 3 and cat["slots"][0] not in live
+    assert [s.get("fn") for s in replan_lifted(plan, {"y": [1, 4, 3, 3]})["statements"]][:2] == ["conv2d", "silu"]     # 9-element planes
+    assert len(plan["statements"]) == 10 and "slot" in plan["statements"][1]["args"][3]                                   # input untouched

@@ -225,19 +225,19 @@ def synth_weights(plan, consts, seed=1234):
     return out
 
 
-from lele_amd.plan import Runner, fuse_sigmoid_mul, load_weights_bin  # noqa: E402  (the runner is shared with lele_amd.compiler plans)
+from lele_amd.plan import Runner, fuse_sigmoid_mul, load_weights_bin, replan_lifted, weight_key  # noqa: E402  (the runner is shared with lele_amd.compiler plans)
 
 
 def write_weights_bin(plan, weights, path):
     """the synthetic weights as a lele `<model>_weights.bin` (every view at its recorded byte offset, in its stored type), so
     that the native runner (lele_amd/lele_run) reads the very same values"""
-    size = max(int(off) + ln for off, (_kind, ln, _shape) in plan["weights"].items())
-    blob = bytearray(size)
-    for off, (kind, ln, _shape) in plan["weights"].items():
-        a = np.asarray(weights[int(off)])
+    views = [(key, v if len(v) == 4 else [v[0], int(key), v[1], v[2]]) for key, v in plan["weights"].items()]   # format 2 / lifted
+    blob = bytearray(max(off + ln for _key, (_kind, off, ln, _shape) in views))
+    for key, (kind, off, ln, _shape) in views:
+        a = np.asarray(weights[key if key in weights else int(key)])
         raw = (a.astype("<i8") if kind.startswith("weight_i64") else a.astype("<i4") if kind.startswith("weight_i32") else a.astype("<f4")).tobytes()
         assert len(raw) == ln, (off, kind, len(raw), ln)
-        blob[int(off):int(off) + ln] = raw
+        blob[off:off + ln] = raw
     open(path, "wb").write(bytes(blob))
 
 
@@ -265,6 +265,8 @@ def main():
     b.add_argument("--weights", default=None, help="a real <model>_weights.bin; default: synthetic weights")
     b.add_argument("--out", default=None)
     b.add_argument("--as-lifted", action="store_true", help="run the call sequence exactly as lifted (no sigmoid+mul -> silu peephole)")
+    b.add_argument("--replan", action="store_true", help="re-assign buffers with this library's liveness allocator and fold conv2d+silu "
+                   "(plan.replan_lifted); kept only if the outputs stay bit-identical")
     b.add_argument("--native", action="store_true", help="also run the plan with the native runner (lele_amd/lele_run) and compare")
     args = ap.parse_args()
     if args.cmd == "lift":
@@ -309,6 +311,14 @@ def main():
             fused_away, calls_fused = 0, calls
     else:
         fused_away, calls_fused = 0, calls
+    calls_replanned = None
+    if args.replan and not args.as_lifted:
+        re = replan_lifted(plan, shapes)
+        raw2 = {weight_key([k, int(off), ln, shp]): r.raw[int(off)] for off, (k, ln, shp) in plan["weights"].items()}
+        r3 = Runner(re, raw2, ctx)
+        if not all(np.array_equal(a, b.numpy()) for a, b in zip(reference_outputs, r3.run(inp))):
+            raise SystemExit("replan_lifted changed the outputs: refusing to use the re-planned graph")
+        plan, r, calls_replanned = re, r3, r3.calls
     out_shapes = [list(o.shape) for o in outs]
     finite = all(bool(np.isfinite(o.numpy()).all()) for o in outs)
     for _ in range(2):
@@ -347,6 +357,7 @@ def main():
         ctx.graph_abort()
         graph_ms = "capture failed: %s" % e
     rec = {"model": plan["source"], "input_shape": shape, "kernel_calls_per_forward": calls, "kernel_calls_after_silu_peephole": calls_fused,
+           "kernel_calls_after_replan": calls_replanned, "buffers": len(plan["slots"]),
            "output_shapes": out_shapes,
            "finite": finite, "eager_ms_per_forward": round(1e3 * float(np.mean(eager)), 3), "graph_ms_per_forward": graph_ms,
            "images_per_s_graph": (round(1e3 / graph_ms, 1) if isinstance(graph_ms, float) else None),
