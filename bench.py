@@ -85,11 +85,7 @@ def cpu_baseline_all_cores(n, budget_s=6.0):
             "rtf": round(el / max(1, total) / (n / SAMPLE_RATE), 7)}
 
 
-def shard_range(total, rank, world):
-    """static block partition of the global batch; rank r owns utterances [lo, hi)"""
-    base, rem = divmod(total, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+from lele_amd.sharded import shard_range  # noqa: E402,F401  SURVEY.md 8(e): static block partition; rank r owns utterances [lo, hi)
 
 
 def rank_seed_base(rank, total, world):

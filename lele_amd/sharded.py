@@ -1,0 +1,68 @@
+"""Utterances across GPUs.
+
+Every utterance (and image) is a complete forward with no cross-item state, so rank r simply owns the block [lo, hi) of the
+global batch and runs the single-GPU path on it.  The one exchange the recogniser has is at the very end: an all-gather of
+the DECODED token ids (i32, a few hundred bytes per utterance -- greedy arg-max and the blank / special-token filter already
+ran on the device, `lele_hip_argmax_last` + `lele_hip_token_filter`), so that every rank (or just rank 0) holds the
+transcripts of the whole batch.  `torch.distributed` is the transport: backend "nccl" is RCCL over xGMI on the GPU box, "gloo"
+in the CPU tests.  Logits never cross a link."""
+import numpy as np
+
+
+def shard_range(total, rank, world):
+    """static block partition of the global batch; rank r owns utterances [lo, hi) (sizes differ by at most one)"""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_ids(ids, counts, rows, width):
+    """[rows, 1 + width] int32: column 0 = number of kept tokens, then the ids, -1 beyond them.  `ids` is the padded
+    [n, W] matrix and `counts` the [n] vector `kernels.token_filter` returns; rows beyond n (ragged last shard) get count -1."""
+    ids, counts = np.asarray(ids, np.int32), np.asarray(counts, np.int32).reshape(-1)
+    if ids.ndim != 2 or ids.shape[0] != counts.shape[0] or ids.shape[0] > rows or ids.shape[1] > width:
+        raise ValueError("pack_ids: ids %s / counts %s do not fit %d rows of width %d" % (ids.shape, counts.shape, rows, width))
+    if counts.size and (counts.min() < 0 or counts.max() > ids.shape[1]):
+        raise ValueError("pack_ids: a count lies outside [0, %d]" % ids.shape[1])
+    out = np.full((rows, 1 + width), -1, np.int32)
+    out[:ids.shape[0], 0] = counts
+    out[:ids.shape[0], 1:1 + ids.shape[1]] = ids
+    return out
+
+
+def unpack_ids(packed):
+    """rows of pack_ids -> list of int32 id arrays (padding rows dropped)"""
+    return [row[1:1 + row[0]].copy() for row in np.asarray(packed) if row[0] >= 0]
+
+
+def all_gather_ids(ids, counts, total, dist=None, device="cpu"):
+    """Token ids of the whole batch, in global utterance order, on every rank.
+
+    ids/counts: this rank's `token_filter` result (host arrays, shard_range(total, rank, world) utterances).  One MAX
+    all-reduce agrees on the row width (shards may have different frame counts), one all-gather moves world x rows x (1+W)
+    int32 -- C4: 32 x 172 x 4 B = 22 KB per GPU, far below any link's latency-bandwidth product, which is why it is a single
+    flat collective and not bucketed."""
+    ids = np.asarray(ids, np.int32)
+    if dist is None:
+        if ids.shape[0] != total:
+            raise ValueError("all_gather_ids: %d utterances given, %d expected" % (ids.shape[0], total))
+        return unpack_ids(pack_ids(ids, counts, total, ids.shape[1]))
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_range(total, rank, world)
+    if ids.shape[0] != hi - lo:
+        raise ValueError("all_gather_ids: rank %d owns %d utterances but was given %d" % (rank, hi - lo, ids.shape[0]))
+    w = torch.tensor([ids.shape[1]], dtype=torch.int64, device=device)
+    dist.all_reduce(w, op=dist.ReduceOp.MAX)
+    width, rows = int(w.item()), -(-total // world)
+    mine = torch.from_numpy(pack_ids(ids, counts, rows, width)).to(device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    out = []
+    for r, p in enumerate(parts):
+        got = unpack_ids(p.cpu().numpy())
+        rlo, rhi = shard_range(total, r, world)
+        if len(got) != rhi - rlo:
+            raise RuntimeError("all_gather_ids: rank %d sent %d utterances, its shard has %d" % (r, len(got), rhi - rlo))
+        out += got
+    return out

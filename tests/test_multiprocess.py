@@ -87,3 +87,68 @@ def test_two_rank_gloo_run_matches_single_process(tmp_path):
         pcm = bench.synth_batch(hi - lo, 16000, bench.rank_seed_base(r, 6, 2))
         for j, p in enumerate(pcm):
             assert got[lo + j] == float(np.float64(O.frontend_compute(p)).sum())
+
+
+GATHER_WORKER = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["LELE_ROOT"])
+import torch.distributed as dist
+from lele_amd.sharded import all_gather_ids, shard_range
+from oracle import pyoracle as O
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+total, vocab = 5, 40
+skip = np.zeros(vocab, np.uint8); skip[[0, 1, 2]] = 1
+lo, hi = shard_range(total, rank, world)
+frames = 9 + 4 * rank                      # shards with different frame counts: the row width has to be agreed on
+logits = np.stack([np.random.default_rng(100 + i).standard_normal((frames, vocab)).astype(np.float32) for i in range(lo, hi)])
+ids, counts = O.decode_greedy_ids(logits, skip)   # stands in for argmax_last + token_filter on the device
+everything = all_gather_ids(ids, counts, total, dist)
+print(json.dumps({"rank": rank, "ids": [[int(v) for v in a] for a in everything]}))
+dist.destroy_process_group()
+'''
+
+
+def test_all_gather_of_decoded_ids_two_ranks_gloo(tmp_path):
+    """the recogniser's only exchange (section 8e): every rank ends up with the token ids of the whole batch, in order"""
+    from lele_amd.sharded import shard_range
+    from oracle import pyoracle as O
+    port = _free_port()
+    script = tmp_path / "gather_worker.py"
+    script.write_text(GATHER_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LELE_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    skip = np.zeros(40, np.uint8)
+    skip[[0, 1, 2]] = 1
+    want = []
+    for r in range(2):
+        lo, hi = shard_range(5, r, 2)
+        for i in range(lo, hi):
+            lg = np.random.default_rng(100 + i).standard_normal((1, 9 + 4 * r, 40)).astype(np.float32)
+            ids, counts = O.decode_greedy_ids(lg, skip)
+            want.append([int(v) for v in ids[0, :counts[0]]])
+    assert any(len(w) > 9 for w in want[3:])          # the wider shard really is wider than the narrow one's row
+    for out, _err in outs:
+        assert json.loads(out.strip().splitlines()[-1])["ids"] == want
+
+
+def test_pack_ids_rejects_what_does_not_fit():
+    import pytest
+    from lele_amd.sharded import all_gather_ids, pack_ids, unpack_ids
+    ids, counts = np.array([[4, 5, -1], [6, -1, -1]], np.int32), np.array([2, 1], np.int32)
+    packed = pack_ids(ids, counts, 3, 4)
+    assert packed.tolist() == [[2, 4, 5, -1, -1], [1, 6, -1, -1, -1], [-1, -1, -1, -1, -1]]
+    assert [a.tolist() for a in unpack_ids(packed)] == [[4, 5], [6]]
+    assert [a.tolist() for a in all_gather_ids(ids, counts, 2)] == [[4, 5], [6]]
+    with pytest.raises(ValueError):
+        pack_ids(ids, counts, 1, 4)
+    with pytest.raises(ValueError):
+        pack_ids(ids, np.array([2, 7], np.int32), 3, 4)
+    with pytest.raises(ValueError):
+        all_gather_ids(ids, counts, 3)
