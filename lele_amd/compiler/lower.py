@@ -74,20 +74,61 @@ def _attrs(node):
         elif a.f is not None:
             out[a.name] = float(a.f)
         elif a.g is not None:
-            raise CompileError("%s: sub-graph attribute %r (control flow) is not supported" % (node.op_type, a.name))
+            out[a.name] = a.g   # control flow: only `If` is lowered (as in lele: ops/control_flow.rs)
         else:
             out[a.name] = []
     return out
 
 
+def captured_names(graph):
+    """outer-scope values a sub-graph reads (its nodes' operands and its outputs, nested sub-graphs included, minus
+    what the sub-graph defines itself), in first-use order"""
+    defined = {t.name for t in graph.initializer} | {v.name for v in graph.input}
+    for n in graph.node:
+        defined.update(o for o in n.output if o)
+    seen, out = set(), []
+
+    def want(name):
+        if name and name not in defined and name not in seen:
+            seen.add(name)
+            out.append(name)
+    for n in graph.node:
+        for i in n.input:
+            want(i)
+        for a in n.attribute:
+            if a.g is not None:
+                for c in captured_names(a.g):
+                    want(c)
+    for v in graph.output:
+        want(v.name)
+    return out
+
+
 class Lowering:
-    def __init__(self, model, name="model", extra_fusions=True):
+    def __init__(self, model, name="model", extra_fusions=True, bind=None, graph=None, parent=None):
+        """bind: {input name: value} -- graph inputs fixed at compile time (they become constants and fold; e.g. Silero's
+        `sr`, whose `If` then inlines the taken branch).  graph/parent: a sub-graph lowered in its parent's scope."""
         self.model, self.name, self.extra_fusions = model, name, extra_fusions
+        if parent is not None:
+            self.consts, self.const_dtype = dict(parent.consts), dict(parent.const_dtype)
+            for t in graph.initializer:
+                self.consts[t.name], self.const_dtype[t.name] = t.array, t.data_type
+            self.inputs, self.outputs = [], [v.name for v in graph.output]
+            self.place, self.static_shape = dict(parent.place), dict(parent.static_shape)
+            self.packer, self.weight_cache = parent.packer, parent.weight_cache
+            self.statements, self.alias = [], {}
+            self.branch_slots, self.if_count = parent.branch_slots, parent.if_count
+            return
+        self.branch_slots, self.if_count = [], [0]   # shared with the sub-graph lowerings: slots private to `If` branches
         g = model.graph
         self.consts = {}       # name -> numpy array (initializers, Constant nodes, folded results)
         self.const_dtype = {}  # name -> ONNX data type of the stored tensor
         for t in g.initializer:
             self.consts[t.name], self.const_dtype[t.name] = t.array, t.data_type
+        for k, v in (bind or {}).items():
+            if k not in {vi.name for vi in g.input}:
+                raise CompileError("bind: %r is not a graph input" % k)
+            self.add_const(k, np.asarray(v))
         self.inputs = [v for v in g.input if v.name not in self.consts]
         self.outputs = [v.name for v in g.output]
         self.place = {}        # name -> "host" | "dev" for run-time values
@@ -126,6 +167,25 @@ class Lowering:
                 continue
             if n.op_type == "Shape" and n.input[0] in self.static_shape:
                 self.add_const(n.output[0], np.array(self.static_shape[n.input[0]], np.int64))
+                continue
+            if n.op_type == "If":
+                if n.input[0] in self.consts:   # the condition is known now: the taken branch is inlined, the other one dropped
+                    g = at["then_branch"] if bool(np.asarray(self.consts[n.input[0]]).reshape(-1)[0] != 0) else at["else_branch"]
+                    for t in g.initializer:
+                        self.consts[t.name], self.const_dtype[t.name] = t.array, t.data_type
+                    rest += self.fold(list(g.node))
+                    for bo, o in zip(g.output, n.output):
+                        if bo.name in self.consts:
+                            self.consts[o], self.const_dtype[o] = self.consts[bo.name], self.const_dtype[bo.name]
+                        else:
+                            rest.append(pb.Node("Identity", [bo.name], [o]))
+                    continue
+                # decided at run time: the values its branches read from this scope become visible operands of the node, so
+                # that fusion privacy, view folding and liveness see those reads
+                extra = [c for g in (at["then_branch"], at["else_branch"]) for c in captured_names(g)]
+                m = pb.Node("If", [n.input[0]] + [c for i, c in enumerate(extra) if c not in extra[:i] and c != n.input[0]], n.output, n.name)
+                m.attribute = n.attribute
+                rest.append(m)
                 continue
             ins = [self.consts.get(i) if i else None for i in n.input]
             if n.input and all(i == "" or i in self.consts for i in n.input):
@@ -676,8 +736,8 @@ class Lowering:
         self.statements[:] = [st for i, st in enumerate(sts) if i not in dead]
 
     # ---------------------------------------------------------------------------------------- driver
-    def run(self):
-        nodes = self.fold(list(self.model.graph.node))
+    def lower_graph(self, graph_nodes):
+        nodes = self.fold(graph_nodes)
         cnt = self.uses(nodes)
         if self.extra_fusions:
             nodes = self.push_views(nodes, cnt)
@@ -685,6 +745,10 @@ class Lowering:
         k = 0
         while k < len(nodes):
             n = nodes[k]
+            if n.op_type == "If":
+                self.lower_if(n)
+                k += 1
+                continue
             ins = [i for i in n.input if i]
             # integer / tiny-float side arithmetic stays on the host; a float table (an embedding) is device data
             host_ready = all((i in self.consts and (self.consts[i].dtype.kind in "iub" or self.consts[i].size <= 16))
@@ -704,16 +768,64 @@ class Lowering:
                 continue
             self.lower_node(n)
             k += 1
+        if self.extra_fusions:
+            self.fold_linear_residuals()
+
+    def lower_if(self, node):
+        """ops/control_flow.rs:18-150: `let (outs) = if cond.data[0] != 0 { then } else { else }` -- the condition is read on
+        the host when the statement runs, the branches are statement lists of their own (own workspace slots), and the
+        results are owned copies (`.to_owned()`): the statement has one output buffer per device result."""
+        at = _attrs(node)
+        self.if_count[0] += 1
+        tag = "if%d" % self.if_count[0]
+        arms, kinds = {}, None
+        for key in ("then", "else"):
+            g = at[key + "_branch"]
+            if len(g.output) != len(node.output):
+                raise CompileError("If %r: the %s branch has %d outputs, the node %d" % (node.name, key, len(g.output), len(node.output)))
+            ch = Lowering(self.model, self.name, self.extra_fusions, graph=g, parent=self)
+            ch.lower_graph(list(g.node))
+            results, k = [], []
+            for o in g.output:
+                if o.name in ch.consts:
+                    arr = np.asarray(ch.consts[o.name])
+                    if arr.dtype.kind in "iub":
+                        results.append({"const": arr.tolist(), "dtype": "i64"})
+                        k.append("host")
+                    else:
+                        results.append(ch.weight(o.name, True))
+                        k.append("dev")
+                else:
+                    results.append({"ref": sanitize(o.name)})
+                    k.append(ch.place.get(o.name, "dev"))
+            if kinds is not None and k != kinds:
+                raise CompileError("If %r: the branches disagree on which results are host values (%s vs %s)" % (node.name, kinds, k))
+            kinds = k
+            inner = allocate(ch.statements, [r["ref"] for r in results if "ref" in r])
+            rename = {s_: "%s%s_%s" % (tag, key[0], s_) for s_ in inner}
+            for st in ch.statements:
+                if "slots" in st:
+                    st["slots"] = [rename[s_] for s_ in st["slots"]]
+            self.branch_slots += [rename[s_] for s_ in inner]
+            arms[key] = {"statements": ch.statements, "results": results}
+        outs = [sanitize(o) for o in node.output]
+        dev_out = [o for o, k in zip(outs, kinds) if k == "dev"]
+        reads = [{"ref": sanitize(i)} for i in node.input if i and i not in self.consts]
+        self.statements.append({"op": "if", "out": outs, "dev_out": dev_out, "kinds": kinds, "bufs": len(dev_out),
+                                "cond": {"ref": sanitize(node.input[0])}, "args": reads, "then": arms["then"], "else": arms["else"]})
+        for o, k in zip(node.output, kinds):
+            self.place[o] = k
+
+    def run(self):
+        self.lower_graph(list(self.model.graph.node))
         for o in self.outputs:
             if o in self.consts:
                 raise CompileError("graph output %s is a constant" % o)
-        if self.extra_fusions:
-            self.fold_linear_residuals()
         slots = allocate(self.statements, [sanitize(o) for o in self.outputs])
         plan = {"source": self.name, "format": "lele_amd.plan/2", "inputs": [sanitize(v.name) for v in self.inputs],
                 "input_info": [{"name": sanitize(v.name), "dtype": "i64" if self.place[v.name] == "host" else "f32", "shape": v.shape}
                                for v in self.inputs],
-                "outputs": [sanitize(o) for o in self.outputs], "slots": slots, "statements": self.statements,
+                "outputs": [sanitize(o) for o in self.outputs], "slots": slots + self.branch_slots, "statements": self.statements,
                 "weights": {}}
         seen = {}
 
@@ -780,7 +892,7 @@ def allocate(statements, outputs):
     for i, st in enumerate(statements):
         for name in [n for n, _s in active.items() if last_use.get(n, -1) < i]:
             heapq.heappush(free, active.pop(name))
-        if st["op"] != "call" or st.get("bufs", 1) == 0:
+        if st["op"] not in ("call", "if") or st.get("bufs", 1) == 0:
             continue
         busy = {slot_of[owner.get(r, r)] for j in range(max(0, i - 5), i + 1) for r in reads[j] if owner.get(r, r) in slot_of}
         st["slots"] = []
@@ -799,16 +911,18 @@ def allocate(statements, outputs):
                 pick, n_slots = n_slots, n_slots + 1
             st["slots"].append("buf_%d" % pick)
             busy.add(pick)
-            name = st["out"][b] if b < len(st["out"]) else None
+            names = st.get("dev_out", st["out"])   # an `if` owns one buffer per DEVICE result
+            name = names[b] if b < len(names) else None
             if name is not None:
                 slot_of[name] = pick
                 active[name] = pick
     return ["buf_%d" % s for s in range(n_slots)]
 
 
-def compile_model(model, name="model", extra_fusions=True):
+def compile_model(model, name="model", extra_fusions=True, bind=None):
     """ONNX model (bytes, path or onnx_pb.Model) -> (plan dict, weights.bin bytes).  extra_fusions=False keeps to the
-    patterns lele's own compiler has (patterns.rs); the extra fused forms are bit-identical to what they replace."""
+    patterns lele's own compiler has (patterns.rs); the extra fused forms are bit-identical to what they replace.
+    bind={input: value} fixes graph inputs at compile time (an `If` on them then inlines the taken branch)."""
     if not isinstance(model, pb.Model):
         model = pb.load(model)
-    return Lowering(model, name, extra_fusions).run()
+    return Lowering(model, name, extra_fusions, bind=bind).run()

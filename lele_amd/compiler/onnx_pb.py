@@ -166,6 +166,8 @@ class Attribute:
             self.t = value
         elif isinstance(value, np.ndarray):
             self.t = Tensor("", value)
+        elif isinstance(value, Graph):
+            self.g = value
         elif isinstance(value, (list, tuple)):
             if value and isinstance(value[0], float):
                 self.floats = list(value)
@@ -208,6 +210,8 @@ class Attribute:
             out += _ld(4, self.s) + _key(20, 0) + _varint(3)
         if self.t is not None:
             out += _ld(5, self.t.serialize()) + _key(20, 0) + _varint(4)
+        if self.g is not None:
+            out += _ld(6, self.g.serialize()) + _key(20, 0) + _varint(5)
         if self.floats:
             out += _ld(7, struct.pack("<%df" % len(self.floats), *self.floats)) + _key(20, 0) + _varint(6)
         if self.ints:

@@ -475,31 +475,7 @@ class Runner {
         for (const auto& kv : inputs) env_[kv.first] = kv.second;
         calls_ = 0;
         stmt_ = 0;
-        for (const Json& st : plan_.at("statements").arr) {
-            ++stmt_;
-            const std::string& op = st.at("op").str;
-            if (op == "host") host_stmt(st);
-            else if (op == "call") call_stmt(st);
-            else if (op == "ints") {   // `let x = &[..];`
-                Val v;
-                v.kind = Val::Host;
-                for (const Json& e : st.at("value").arr) v.h.i.push_back(e.as_int());
-                env_[st.at("out").arr[0].str] = v;
-            } else if (op == "newbuf") {  // `let mut buf_x = Vec::new();` -> a persistent device buffer of that name
-                if (!named_.count(st.at("out").arr[0].str)) named_[st.at("out").arr[0].str] = std::make_unique<Buffer>();
-            } else if (op == "swap_remove") {  // Vec::swap_remove: take element i, the last element takes its place
-                Val& lst = env_.at(st.at("list").str);
-                const size_t i = (size_t)st.at("index").as_int();
-                Val v;
-                v.kind = Val::Tensor;
-                v.t = lst.list.at(i);
-                lst.list[i] = lst.list.back();
-                lst.list.pop_back();
-                env_[st.at("out").arr[0].str] = v;
-            } else if (op == "alias") {
-                env_[st.at("out").arr[0].str] = env_.at(st.at("src").str);
-            } else throw Error("plan: statement kind '" + op + "' is not supported by the native runner");
-        }
+        exec(plan_.at("statements"));
         std::vector<Val> out;
         for (const Json& o : plan_.at("outputs").arr) out.push_back(env_.at(o.str));
         return out;
@@ -648,6 +624,74 @@ class Runner {
     }
     static float number(const Json& n) { return (float)(n.has("float") ? n.at("float").as_num() : n.at("int").as_num()); }
     static bool boolean(const Json& n) { return n.at("bool").b; }
+
+    void exec(const Json& statements) {
+        for (const Json& st : statements.arr) {
+            ++stmt_;
+            const std::string& op = st.at("op").str;
+            if (op == "host") host_stmt(st);
+            else if (op == "if") if_stmt(st);
+            else if (op == "call") call_stmt(st);
+            else if (op == "ints") {   // `let x = &[..];`
+                Val v;
+                v.kind = Val::Host;
+                for (const Json& e : st.at("value").arr) v.h.i.push_back(e.as_int());
+                env_[st.at("out").arr[0].str] = v;
+            } else if (op == "newbuf") {  // `let mut buf_x = Vec::new();` -> a persistent device buffer of that name
+                if (!named_.count(st.at("out").arr[0].str)) named_[st.at("out").arr[0].str] = std::make_unique<Buffer>();
+            } else if (op == "swap_remove") {  // Vec::swap_remove: take element i, the last element takes its place
+                Val& lst = env_.at(st.at("list").str);
+                const size_t i = (size_t)st.at("index").as_int();
+                Val v;
+                v.kind = Val::Tensor;
+                v.t = lst.list.at(i);
+                lst.list[i] = lst.list.back();
+                lst.list.pop_back();
+                env_[st.at("out").arr[0].str] = v;
+            } else if (op == "alias") {
+                env_[st.at("out").arr[0].str] = env_.at(st.at("src").str);
+            } else throw Error("plan: statement kind '" + op + "' is not supported by the native runner");
+        }
+    }
+
+    // `let (outs) = if cond.data[0] != 0 {..} else {..}` (lele: src/compiler/ops/control_flow.rs:18-150).  The condition is
+    // read on the host (a device value is fetched: that waits for the stream and is refused inside a graph capture); the
+    // taken branch's statements run; device results are copied into this statement's buffers (`.to_owned()` upstream).
+    void if_stmt(const Json& st) {
+        const Val& c = ref(st.at("cond").at("ref").str);
+        bool taken = false;
+        if (c.kind == Val::Host) taken = c.h.size() > 0 && (c.h.is_int ? c.h.i[0] != 0 : c.h.f[0] != 0.0f);
+        else if (c.kind == Val::Tensor) {
+            if (c.t.size() > 0) taken = c.t.dtype() == LELE_I64 ? c.t.to_vec<int64_t>()[0] != 0 : c.t.to_vec<float>()[0] != 0.0f;
+        } else throw Error("plan: the condition of an `if` is neither a host value nor a tensor");
+        const Json& arm = st.at(taken ? "then" : "else");
+        exec(arm.at("statements"));
+        size_t k = 0;
+        Json none;
+        none.kind = Json::Arr;
+        for (size_t i = 0; i < st.at("out").arr.size(); ++i) {
+            const Json& res = arm.at("results").arr.at(i);
+            const std::string& name = st.at("out").arr[i].str;
+            if (st.at("kinds").arr.at(i).str == "host") {
+                if (res.has("ref")) { env_[name] = ref(res.at("ref").str); continue; }
+                Val v;
+                v.kind = Val::Host;
+                const Json& cst = res.at("const");
+                v.h.is_int = res.at("dtype").str == "i64";
+                v.h.scalar = cst.kind != Json::Arr;
+                auto push = [&](const Json& e) { if (v.h.is_int) v.h.i.push_back(e.as_int()); else v.h.f.push_back((float)e.as_num()); };
+                if (cst.kind == Json::Arr) for (const Json& e : cst.arr) push(e); else push(cst);
+                env_[name] = v;
+            } else {
+                temp_.clear();
+                ++calls_;
+                Val v;
+                v.kind = Val::Tensor;
+                v.t = view_copy(tensor(res), none, *slots_.at(st.at("slots").arr.at(k++).str));
+                env_[name] = v;
+            }
+        }
+    }
 
     void host_stmt(const Json& st) {
         const std::string& op = st.at("onnx").str;

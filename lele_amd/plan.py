@@ -268,11 +268,43 @@ class Runner:
             env[name] = np.asarray(r)
 
     def run(self, inputs):
-        K, ctx = self.K, self.ctx
         env = dict(inputs)
-        for self.stmt_index, st in enumerate(self.plan["statements"]):
+        self.stmt_index = 0
+        self.exec(self.plan["statements"], env)
+        if self.shapes is not None:
+            for name, v in env.items():
+                if hasattr(v, "shape"):
+                    self.shapes[name] = [int(d) for d in v.shape]
+        return [env[o] for o in self.plan["outputs"]]
+
+    def if_(self, st, env):
+        """`let (outs) = if cond.data[0] != 0 {..} else {..}` (ops/control_flow.rs:18-150): the condition is read on the host --
+        a device value is fetched, which waits for the stream (and cannot happen inside a graph capture, where the library
+        refuses it) -- then the taken branch's statements run and its device results are copied into this statement's
+        buffers, as the generated code's `.to_owned()` does."""
+        from .tensor import TensorView
+        c = self.val(st["cond"], env)
+        c = c.numpy() if isinstance(c, TensorView) else np.asarray(c)
+        arm = st["then"] if c.size and c.reshape(-1)[0] != 0 else st["else"]
+        self.exec(arm["statements"], env)
+        bufs = [self.ws[s] for s in st.get("slots", [])]
+        k = 0
+        for name, res, kind in zip(st["out"], arm["results"], st["kinds"]):
+            if kind == "host":
+                env[name] = np.asarray(res["const"], np.int64 if res.get("dtype") == "i64" else np.float32) if "const" in res else env[res["ref"]]
+            else:
+                self.calls += 1
+                env[name] = self.K.view_copy(self.val(res, env), [], out=bufs[k], ctx=self.ctx)
+                k += 1
+
+    def exec(self, statements, env):
+        K, ctx = self.K, self.ctx
+        for st in statements:
+            self.stmt_index += 1
             op = st["op"]
-            if op == "ints":
+            if op == "if":
+                self.if_(st, env)
+            elif op == "ints":
                 env[st["out"][0]] = st["value"]
             elif op == "newbuf":
                 self.extra.setdefault(st["out"][0], ctx.buf())
@@ -314,8 +346,3 @@ class Runner:
                 else:
                     for name, r in zip(st["out"], res):
                         env[name] = r
-        if self.shapes is not None:
-            for name, v in env.items():
-                if hasattr(v, "shape"):
-                    self.shapes[name] = [int(d) for d in v.shape]
-        return [env[o] for o in self.plan["outputs"]]

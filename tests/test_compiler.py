@@ -12,7 +12,7 @@ import pytest
 
 from lele_amd.compiler import CompileError, compile_model, hostops
 from lele_amd.compiler import onnx_pb as pb
-from tests.onnx_util import export
+from tests.onnx_util import export, splice_if
 
 torch = pytest.importorskip("torch")
 
@@ -475,3 +475,152 @@ def test_lowering_of_the_remaining_operators_against_numpy(ctx):
             assert np.array_equal(got[o], w.astype(np.float32)), o
         else:
             assert np.abs(got[o] - w).max() <= 2e-6 * max(1.0, np.abs(w).max()), (o, np.abs(got[o] - w).max())
+
+
+# --------------------------------------------------------------------------------------------------- control flow: If
+def if_model():
+    """x f32 [2,8], flag i64 [1] -> z.  h = relu(x); if flag == 1 {y = h*w + x; n = 3} else {y = h*sigmoid(h); n = 2};
+    z = tile(y + h, [1, n]).  The branches read h and x from the enclosing scope; n is a host integer result."""
+    w = np.linspace(-1.0, 1.0, 8).astype(np.float32)
+    i64 = lambda *v: np.array(v, np.int64)  # noqa: E731
+    then = pb.Graph([pb.Node("Mul", ["h", "w"], ["t1"]), pb.Node("Add", ["t1", "x"], ["y_then"]), pb.Node("Constant", [], ["n_then"], value=i64(3))],
+                    [], [pb.ValueInfo("y_then", pb.FLOAT, None), pb.ValueInfo("n_then", pb.INT64, None)], [], "then")
+    other = pb.Graph([pb.Node("Sigmoid", ["h"], ["e1"]), pb.Node("Mul", ["h", "e1"], ["y_else"])],
+                     [], [pb.ValueInfo("y_else", pb.FLOAT, None), pb.ValueInfo("n_else", pb.INT64, None)], [pb.Tensor("n_else", i64(2))], "else")
+    nodes = [pb.Node("Relu", ["x"], ["h"]), pb.Node("Equal", ["flag", "one"], ["cond"]),
+             pb.Node("If", ["cond"], ["y", "n"], then_branch=then, else_branch=other),
+             pb.Node("Add", ["y", "h"], ["s"]), pb.Node("Concat", ["one", "n"], ["reps"], axis=0), pb.Node("Tile", ["s", "reps"], ["z"])]
+    g = pb.Graph(nodes, [pb.ValueInfo("x", pb.FLOAT, [2, 8]), pb.ValueInfo("flag", pb.INT64, [1])], [pb.ValueInfo("z", pb.FLOAT, None)],
+                 [pb.Tensor("w", w), pb.Tensor("one", i64(1))])
+    return pb.Model(g, opset=13).serialize(), w
+
+
+def if_reference(x, w, flag):
+    h = np.maximum(x, 0.0)
+    if flag == 1:
+        return np.tile(h * w + x + h, (1, 3))
+    return None   # the SiLU branch goes through the device's polynomial sigmoid: compared with the unfused device ops instead
+
+
+def test_if_lowering_structure_and_static_inlining():
+    data, _w = if_model()
+    m = pb.load(data)
+    assert pb.load(m.serialize()).graph.node[2].attribute[0].g.name == "then"     # graph attributes survive a round trip
+    plan, _blob = compile_model(data)
+    st = [s for s in plan["statements"] if s["op"] == "if"]
+    assert len(st) == 1
+    st = st[0]
+    assert st["out"] == ["y", "n"] and st["kinds"] == ["dev", "host"] and st["dev_out"] == ["y"] and len(st["slots"]) == 1
+    assert st["cond"] == {"ref": "cond"} and {"ref": "h"} in st["args"] and {"ref": "x"} in st["args"]
+    assert [s["fn"] for s in st["then"]["statements"]] == ["mul", "add"] and st["then"]["results"][1] == {"const": [3], "dtype": "i64"}
+    assert [s["fn"] for s in st["else"]["statements"]] == ["silu"] and st["else"]["results"] == [{"ref": "y_else"}, {"const": [2], "dtype": "i64"}]
+    inner = {s for arm in ("then", "else") for t in st[arm]["statements"] for s in t["slots"]}
+    assert inner and inner <= set(plan["slots"]) and not inner & {s for t in plan["statements"] for s in t.get("slots", [])}
+    # h is read inside the branches: its buffer must outlive the `if`, and the `if` must not write into it
+    relu = next(s for s in plan["statements"] if s.get("fn") == "relu")
+    assert relu["slots"][0] not in st["slots"]
+    # the condition known at compile time (the input bound): the taken branch is inlined, no `if` is left
+    for flag, want in ((1, ["relu", "mul", "add", "identity", "add", "tile"]), (0, ["relu", "silu", "identity", "add", "tile"])):
+        p, _ = compile_model(data, bind={"flag": np.array([flag], np.int64)})
+        assert [s.get("fn", s["op"]) for s in p["statements"]] == want and p["inputs"] == ["x"], (flag, fns(p))
+    with pytest.raises(CompileError):
+        compile_model(data, bind={"nope": 1})
+
+
+@pytest.mark.gpu
+def test_if_runs_both_ways_python_and_native(ctx, tmp_path):
+    from lele_amd import kernels as K
+    from lele_amd.tensor import TensorView
+    from tests.test_native_runner import _native
+    data, w = if_model()
+    plan, blob = compile_model(data)
+    x = np.random.default_rng(3).standard_normal((2, 8)).astype(np.float32)
+    xd = TensorView(ctx.buf().upload(x))
+    h = np.maximum(x, 0.0)
+    silu = K.silu(h, ctx=ctx).numpy()
+    want = {1: if_reference(x, w, 1), 0: np.tile(silu + h, (1, 2))}
+    for flag in (1, 0, 1):
+        _r, res = run_plan(ctx, plan, blob, {"x": xd, "flag": np.array([flag], np.int64)})
+        assert np.array_equal(res[0].numpy(), want[flag]), flag
+        d = tmp_path / ("f%d_%d" % (flag, len(list(tmp_path.iterdir()))))
+        d.mkdir()
+        _rec, got = _native(d, plan, blob, {"x": x, "flag": np.array([flag], np.int64)})
+        assert np.array_equal(got[0], want[flag]), flag
+        p2, b2 = compile_model(data, bind={"flag": np.array([flag], np.int64)})     # the statically inlined form: same bits
+        assert np.array_equal(run_plan(ctx, p2, b2, {"x": xd})[1][0].numpy(), want[flag])
+
+
+class VadNet(torch.nn.Module):
+    """Silero-shaped: framing convolution (the STFT basis), magnitude, a small conv encoder, one LSTM step, a sigmoid head"""
+
+    def __init__(self, hop, seed):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.stft = torch.nn.Conv1d(1, 34, 4 * hop, stride=hop, bias=False)
+        self.enc1 = torch.nn.Conv1d(17, 32, 3, padding=1)
+        self.enc2 = torch.nn.Conv1d(32, 24, 3, stride=2, padding=1)
+        self.lstm = torch.nn.LSTM(24, 24)
+        self.head = torch.nn.Conv1d(24, 1, 1)
+
+    def forward(self, x, h0, c0):                 # x [1, N], state [1, 1, 24] each
+        s = self.stft(x.unsqueeze(1))              # [1, 34, F]
+        mag = torch.sqrt(s[:, :17] ** 2 + s[:, 17:] ** 2)
+        y = torch.relu(self.enc2(torch.relu(self.enc1(mag))))     # [1, 24, F/2]
+        y, (hn, cn) = self.lstm(y.permute(2, 0, 1), (h0, c0))      # [F/2, 1, 24]
+        p = torch.sigmoid(self.head(torch.relu(y).permute(1, 2, 0)))
+        return p.mean(dim=2), hn, cn
+
+
+def vad_if_model():
+    nets = VadNet(32, 5).eval(), VadNet(16, 6).eval()         # "16 kHz" and "8 kHz" networks
+    ex = (torch.zeros(1, 512), torch.zeros(1, 1, 24), torch.zeros(1, 1, 24))
+    kw = dict(opset=17, input_names=("x", "h0", "c0"), output_names=("prob", "hn", "cn"))
+    parts = [export(n, ex, **kw) for n in nets]
+    i64 = lambda *v: np.array(v, np.int64)  # noqa: E731
+    data = splice_if(parts[0], parts[1], {"x", "h0", "c0"}, [pb.Node("Equal", ["sr", "sr16k"], ["is16k"])], "is16k",
+                     [pb.ValueInfo("x", pb.FLOAT, [1, 512]), pb.ValueInfo("sr", pb.INT64, [1]), pb.ValueInfo("h0", pb.FLOAT, [1, 1, 24]),
+                      pb.ValueInfo("c0", pb.FLOAT, [1, 1, 24])], [pb.Tensor("sr16k", i64(16000))])
+    return data, nets, parts
+
+
+def test_silero_shaped_if_compiles_both_networks():
+    data, _nets, _parts = vad_if_model()
+    plan, blob = compile_model(data, "vad")
+    st = [s for s in plan["statements"] if s["op"] == "if"]
+    assert len(st) == 1 and st[0]["kinds"] == ["dev", "dev", "dev"] and len(st[0]["slots"]) == 3
+    for arm in ("then", "else"):
+        f = [s["fn"] for s in st[0][arm]["statements"] if s["op"] == "call"]
+        assert f.count("lstm") == 1 and f.count("conv1d_fused") >= 2 and "sigmoid" in f, f
+    assert plan["inputs"] == ["x", "sr", "h0", "c0"] and [i["dtype"] for i in plan["input_info"]] == ["f32", "i64", "f32", "f32"]
+    # both networks' weights are in the one weights.bin
+    assert len(blob) > 4 * sum(p.numel() for p in _nets[0].parameters()) + 4 * sum(p.numel() for p in _nets[1].parameters()) - 4096
+    # sr bound at compile time: only the chosen network is left
+    p16, b16 = compile_model(data, "vad16", bind={"sr": np.array([16000], np.int64)})
+    assert not [s for s in p16["statements"] if s["op"] == "if"] and len(b16) < 0.75 * len(blob)
+
+
+@pytest.mark.gpu
+def test_silero_shaped_if_matches_torch_per_sample_rate(ctx, tmp_path):
+    from lele_amd.tensor import TensorView
+    from tests.test_native_runner import _native
+    data, nets, parts = vad_if_model()
+    plan, blob = compile_model(data, "vad")
+    rng = np.random.default_rng(8)
+    x = (0.3 * rng.standard_normal((1, 512))).astype(np.float32)
+    h0, c0 = (0.1 * rng.standard_normal((2, 1, 1, 24))).astype(np.float32)
+    dev = {k: TensorView(ctx.buf().upload(v)) for k, v in (("x", x), ("h0", h0), ("c0", c0))}
+    for sr, net, part in ((16000, nets[0], parts[0]), (8000, nets[1], parts[1]), (16000, nets[0], parts[0])):
+        with torch.no_grad():
+            want = [t.numpy() for t in net(torch.from_numpy(x), torch.from_numpy(h0), torch.from_numpy(c0))]
+        _r, res = run_plan(ctx, plan, blob, dict(dev, sr=np.array([sr], np.int64)))
+        got = [r.numpy() for r in res]
+        for g, w in zip(got, want):
+            assert close(g, w), (sr, np.abs(g - w).max())
+        # the network compiled on its own (no `If`): the same kernels on the same data, so the same bits
+        p1, b1 = compile_model(part, "one")
+        alone = [r.numpy() for r in run_plan(ctx, p1, b1, dev)[1]]
+        assert all(np.array_equal(a, b) for a, b in zip(got, alone)), sr
+        d = tmp_path / ("sr%d_%d" % (sr, len(list(tmp_path.iterdir()))))
+        d.mkdir()
+        _rec, nat = _native(d, plan, blob, {"x": x, "sr": np.array([sr], np.int64), "h0": h0, "c0": c0})
+        assert all(np.array_equal(a, b) for a, b in zip(nat, got)), sr

@@ -27,6 +27,8 @@ def main():
     a.add_argument("model")
     a.add_argument("-o", "--out", required=True)
     a.add_argument("--name", default=None)
+    a.add_argument("--bind", action="append", default=[], help="input=v[,v...]: fix an integer graph input at compile time, e.g. sr=16000 "
+                   "(an `If` on it then inlines the taken branch)")
     b = sub.add_parser("run")
     b.add_argument("plan")
     b.add_argument("--weights", default=None, help="default: the _weights.bin next to the plan")
@@ -37,7 +39,8 @@ def main():
         from lele_amd.compiler import compile_model
         name = args.name or os.path.splitext(os.path.basename(args.model))[0]
         t0 = time.perf_counter()
-        plan, blob = compile_model(args.model, name)
+        bind = {kv.split("=")[0]: np.array([int(v) for v in kv.split("=")[1].split(",")], np.int64) for kv in args.bind}
+        plan, blob = compile_model(args.model, name, bind=bind or None)
         os.makedirs(args.out, exist_ok=True)
         json.dump(plan, open(os.path.join(args.out, name + "_plan.json"), "w"))
         open(os.path.join(args.out, name + "_weights.bin"), "wb").write(blob)
