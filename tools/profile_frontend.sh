@@ -10,7 +10,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 20 --warmup 3"
+BENCH="python $R/bench.py"   # the default invocation (200 steps after 20 warm-up steps: the clocks have settled)
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- $BENCH > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o bench -- $BENCH --no-cpu-baseline > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.log"
