@@ -1,6 +1,8 @@
 """Randomised shape sweep of the kernels with the most code paths (tile selection, small-problem split-K, tap-major and
 phase-decomposed convolutions, LDS-tiled / vectorised / generic copies, quantised GEMM variants) against the oracle.
-Seeded: every run checks the same cases."""
+Seeded: every run checks the same cases (LELE_FUZZ_SEED=<n> shifts every seed for an extra sweep)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,7 @@ from oracle import pyoracle as O
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-4
+SEED = int(os.environ.get("LELE_FUZZ_SEED", "0"))
 
 
 def _close(got, want, what):
@@ -23,7 +26,7 @@ def _close(got, want, what):
 
 def test_fuzz_matmul_gemm(ctx):
     from lele_amd import kernels as K
-    rng = np.random.default_rng(101)
+    rng = np.random.default_rng(101 + SEED)
     for it in range(60):
         m, k, n = (int(rng.integers(1, 300)) for _ in range(3))
         if it % 7 == 0:
@@ -47,7 +50,7 @@ def test_fuzz_matmul_gemm(ctx):
 
 def test_fuzz_conv2d_conv_transpose(ctx):
     from lele_amd import kernels as K
-    rng = np.random.default_rng(202)
+    rng = np.random.default_rng(202 + SEED)
     for it in range(70):
         g = int(rng.choice([1, 1, 1, 2, 4]))
         icg, ocg = int(rng.choice([1, 3, 4, 8, 12, 16])), int(rng.choice([1, 2, 8, 16, 33]))
@@ -86,7 +89,7 @@ def test_fuzz_conv2d_conv_transpose(ctx):
 
 def test_fuzz_quantized_linear(ctx):
     from lele_amd import kernels as K
-    rng = np.random.default_rng(303)
+    rng = np.random.default_rng(303 + SEED)
     for it in range(40):
         batch = int(rng.choice([1, 1, 2, 3]))
         m, k, n = int(rng.integers(1, 200)), int(rng.integers(1, 300)), int(rng.integers(1, 200))
@@ -105,7 +108,7 @@ def test_fuzz_quantized_linear(ctx):
 
 def test_fuzz_strided_copies(ctx):
     from lele_amd import kernels as K
-    rng = np.random.default_rng(404)
+    rng = np.random.default_rng(404 + SEED)
     for it in range(80):
         rank = int(rng.integers(1, 6))
         shape = [int(rng.integers(1, 9)) for _ in range(rank)]
@@ -131,7 +134,7 @@ def test_fuzz_strided_copies(ctx):
 
 def test_fuzz_broadcast_reduce_norm_pad_gather(ctx):
     from lele_amd import kernels as K
-    rng = np.random.default_rng(505)
+    rng = np.random.default_rng(505 + SEED)
     for it in range(60):
         rank = int(rng.integers(1, 5))
         shape = [int(rng.integers(1, 8)) for _ in range(rank)]

@@ -7,8 +7,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_sv_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+LEGS=${LEGS:-both}   # LEGS=compiled: only the compiled-plan leg
 for C in c3 c4; do
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o $C -- \
+  [ "$LEGS" = compiled ] || timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o $C -- \
       python $R/tools/sensevoice_graph.py --no-graph --configs $C --runs 4 > "$OUT/$C.json" 2> "$OUT/$C.log"
   # the same model compiled from ONNX (lele_amd.compiler, all fused forms), 10 eager forwards
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o ${C}_compiled -- \
