@@ -267,6 +267,7 @@ def main():
     b.add_argument("--as-lifted", action="store_true", help="run the call sequence exactly as lifted (no sigmoid+mul -> silu peephole)")
     b.add_argument("--replan", action="store_true", help="re-assign buffers with this library's liveness allocator and fold conv2d+silu "
                    "(plan.replan_lifted); kept only if the outputs stay bit-identical")
+    b.add_argument("--streams", type=int, default=0, help="also replay the graph on N contexts (N HIP streams, one image each) at once")
     b.add_argument("--native", action="store_true", help="also run the plan with the native runner (lele_amd/lele_run) and compare")
     args = ap.parse_args()
     if args.cmd == "lift":
@@ -363,6 +364,37 @@ def main():
            "images_per_s_graph": (round(1e3 / graph_ms, 1) if isinstance(graph_ms, float) else None),
            "per_op_ms_synced": prof,
            "note": "call sequence lifted from lele's generated source, synthetic weights, one image per forward"}
+    if args.streams > 1 and isinstance(graph_ms, float):
+        # N independent images in flight: one ctx (= one stream, one workspace, one recorded graph) each -- how a server would
+        # keep the device busy with a graph compiled for N = 1 (lele's generated code loops over images on the host)
+        ctxs = [ctx] + [lele_amd._lib.Ctx(0) for _ in range(args.streams - 1)]
+        lanes = []
+        xh = x.numpy() if hasattr(x, "numpy") else TensorView(x).numpy()
+        for c in ctxs:
+            rr = Runner(plan, r.raw, c)
+            feed = {plan["inputs"][-1]: TensorView(c.buf().upload(xh))}
+            first = rr.run(feed)
+            if c is not ctx and not all(np.array_equal(a, b.numpy()) for a, b in zip(reference_outputs, first)):
+                raise SystemExit("a second context computed different outputs")
+            c.sync()
+            c.graph_begin()
+            rr.run(feed)
+            lanes.append((c, c.graph_end(), rr, feed))
+        for c, gph, _r, _f in lanes:
+            gph.launch()
+        for c, *_ in lanes:
+            c.sync()
+        ts = []
+        for _ in range(args.runs):
+            t0 = time.perf_counter()
+            for _ in range(args.batch_runs // args.streams or 1):
+                for c, gph, _r, _f in lanes:
+                    gph.launch()
+            for c, *_ in lanes:
+                c.sync()
+            ts.append(time.perf_counter() - t0)
+        per_image = float(np.mean(ts)) / ((args.batch_runs // args.streams or 1) * args.streams)
+        rec.update({"streams": args.streams, "streams_ms_per_image": round(1e3 * per_image, 4), "images_per_s_streams": round(1.0 / per_image, 1)})
     if args.native:  # the same plan, the same weights, no Python: C++ runner over the C ABI
         import subprocess
         import tempfile
