@@ -320,6 +320,13 @@ int lele_hip_fused_quantized_linear_residual(LeleCtx* ctx, const LeleTensor* inp
 /* softmax(x * scale[0]) over the last axis: `mul` by a one-element tensor followed by `softmax` (norm.rs:8) */
 int lele_hip_softmax_scaled(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, int32_t axis, LeleBuf* out,
                             int64_t* out_shape, int32_t* out_rank);
+/* sqrt(pow(x[.., lo_start:lo_end, ..], exp_lo) + pow(x[.., hi_start:hi_end, ..], exp_hi)) along `axis` (bounds as Slice's: negative
+ * from the end, clamped; the two ranges must be equally long): `slice`, `pow`, `slice`, `pow`, `add`, `sqrt` (manipulation.rs:209,
+ * math.rs:1481, 414, 1460) in one pass -- the magnitude of a spectrum stored as [re | im] channel halves (Silero's
+ * STFT-as-convolution).  exp_lo / exp_hi are one-element host constants. */
+int lele_hip_halves_pow_add_sqrt(LeleCtx* ctx, const LeleTensor* x, int32_t axis, int64_t lo_start, int64_t lo_end, int64_t hi_start,
+                                 int64_t hi_end, const LeleTensor* exp_lo, const LeleTensor* exp_hi, LeleBuf* out, int64_t* out_shape,
+                                 int32_t* out_rank);
 /* (a + b) + c on equal shapes: two consecutive `add`s (math.rs:414) */
 int lele_hip_add3(LeleCtx* ctx, const LeleTensor* a, const LeleTensor* b, const LeleTensor* c, LeleBuf* out, int64_t* out_shape,
                   int32_t* out_rank);

@@ -334,6 +334,28 @@ class Lowering:
             xs = [i for i in n[0].input if i not in self.consts]
             if len(sc) == 1 and len(xs) == 1:
                 return 2, lambda: self.emit([n[1].output[0]], "softmax_scaled", [self.tensor(xs[0]), self.weight(sc[0], True), {"int": -1}])
+        # Slice, Pow, Slice, Pow, Add, Sqrt on two ranges of one axis of the same tensor (the magnitude of a [re | im] spectrum)
+        if ops("Slice", "Pow", "Slice", "Pow", "Add", "Sqrt"):
+            def rng(sl):  # constant single-axis unit-step slice -> (axis, start, end)
+                c = [self.consts.get(i) if i else None for i in sl.input[1:5]] + [None] * 4
+                if c[0] is None or c[1] is None or c[2] is None or not (np.asarray(c[0]).size == np.asarray(c[1]).size == np.asarray(c[2]).size == 1):
+                    return None
+                if c[3] is not None and [int(v) for v in np.asarray(c[3]).reshape(-1)] != [1]:
+                    return None
+                return tuple(int(np.asarray(v).reshape(-1)[0]) for v in (c[2], c[0], c[1]))
+            x, ra, rb = n[0].input[0], rng(n[0]), rng(n[2])
+            e = [[i for i in p.input if i != s_.output[0]] for p, s_ in ((n[1], n[0]), (n[3], n[2]))]
+            ok = (ra and rb and ra[0] == rb[0] and n[2].input[0] == x and x not in self.consts and n[1].input[0] == n[0].output[0]
+                  and n[3].input[0] == n[2].output[0] and sorted(n[4].input) == sorted([n[1].output[0], n[3].output[0]])
+                  and n[5].input[0] == n[4].output[0] and private(n[0].output[0], n[1].output[0], n[2].output[0], n[3].output[0], n[4].output[0])
+                  and all(len(v) == 1 and v[0] in self.consts and self.consts[v[0]].size == 1 for v in e))
+            if ok:
+                first, second = (0, 1) if n[4].input[0] == n[1].output[0] else (1, 0)   # operand order of the Add: a + b == b + a bit for bit
+                r, ex = (ra, rb), (e[0][0], e[1][0])
+                pair = lambda q: {"list": [{"int": q[1]}, {"int": q[2]}]}  # noqa: E731
+                return 6, lambda: self.emit([n[5].output[0]], "halves_pow_add_sqrt",
+                                            [self.tensor(x), {"int": ra[0]}, pair(r[first]), pair(r[second]), self.weight(ex[first], True),
+                                             self.weight(ex[second], True)])
         # Add -> Add: (a + b) + c in one pass (two residual connections in a row)
         if ops("Add", "Add") and n[0].output[0] in n[1].input and private(n[0].output[0]):
             c = [i for i in n[1].input if i != n[0].output[0]]

@@ -198,6 +198,19 @@ __global__ __launch_bounds__(256) void binary_fast_kernel(int op, const float* _
     for (unsigned i = 4 * nvec + gtid; i < n; i += gstride) out[i] = binary_apply<float>(op, fetch1(a, ma, i), fetch1(b, mb, i));
 }
 
+// sqrt(pow(x[.., a0:a0+L, ..], e0) + pow(x[.., b0:b0+L, ..], e1)): the six-node spectrum-magnitude chain Slice, Pow, Slice, Pow,
+// Add, Sqrt in one pass.  Same device functions in the same order as the separate kernels (binary_apply B_POW -> powf with the
+// exponent as a run-time value, B_ADD, unary U_SQRT), so the result is the same bits.  x is [outer, dim, inner].
+__global__ void halves_pow_add_sqrt_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t dim, int64_t a0, int64_t b0, int64_t len,
+                                           int64_t inner, int64_t n, float e0, float e1) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t per = len * inner, o = i / per, r = i - o * per;
+        const float* p = x + o * dim * inner + r;
+        const float a = binary_apply<float>(B_POW, p[a0 * inner], e0), b = binary_apply<float>(B_POW, p[b0 * inner], e1);
+        y[i] = unary_apply(U_SQRT, binary_apply<float>(B_ADD, a, b), true);
+    }
+}
+
 // (a + b) + c element-wise on equal shapes: the two consecutive residual adds of a transformer block in one pass, same
 // rounding order as two `add` kernels
 __global__ __launch_bounds__(256) void add3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
@@ -898,6 +911,43 @@ int lele_hip_add3(LeleCtx* ctx, const LeleTensor* a, const LeleTensor* b, const 
         LELE_HIP_CHECK(hipGetLastError());
     }
     return set_shape_v(out_shape, out_rank, std::vector<int64_t>(a->shape, a->shape + a->rank));
+}
+
+int lele_hip_halves_pow_add_sqrt(LeleCtx* ctx, const LeleTensor* x, int32_t axis, int64_t lo_start, int64_t lo_end, int64_t hi_start,
+                                 int64_t hi_end, const LeleTensor* exp_lo, const LeleTensor* exp_hi, LeleBuf* out, int64_t* out_shape,
+                                 int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && exp_lo && exp_hi && out, "halves_pow_add_sqrt: NULL argument");
+    LELE_REQUIRE(x->dtype == LELE_F32 && exp_lo->dtype == LELE_F32 && exp_hi->dtype == LELE_F32, "halves_pow_add_sqrt: f32 operands required");
+    LELE_REQUIRE(numel(exp_lo) == 1 && numel(exp_hi) == 1, "halves_pow_add_sqrt: the exponents are one-element tensors");
+    LELE_REQUIRE(exp_lo->mem != LELE_MEM_DEVICE && exp_hi->mem != LELE_MEM_DEVICE, "halves_pow_add_sqrt: the exponents are host constants");
+    const int ax = axis < 0 ? axis + x->rank : axis;
+    LELE_REQUIRE(ax >= 0 && ax < x->rank, "halves_pow_add_sqrt: axis %d out of range for rank %d", axis, x->rank);
+    const int64_t dim = x->shape[ax];
+    auto clampi = [dim](int64_t v) {  // Slice with step 1: negative counts from the end, then clamp to [0, dim] (manipulation.rs:240-262)
+        if (v < 0) v += dim;
+        return v < 0 ? 0 : v > dim ? dim : v;
+    };
+    const int64_t a0 = clampi(lo_start), a1 = clampi(lo_end), b0 = clampi(hi_start), b1 = clampi(hi_end);
+    const int64_t len = a1 > a0 ? a1 - a0 : 0;
+    LELE_REQUIRE((b1 > b0 ? b1 - b0 : 0) == len, "halves_pow_add_sqrt: the two ranges [%lld, %lld) and [%lld, %lld) differ in length",
+                 (long long)a0, (long long)a1, (long long)b0, (long long)b1);
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    int64_t outer = 1, inner = 1;
+    for (int d = 0; d < ax; ++d) outer *= x->shape[d];
+    for (int d = ax + 1; d < x->rank; ++d) inner *= x->shape[d];
+    std::vector<int64_t> shp(x->shape, x->shape + x->rank);
+    shp[ax] = len;
+    const int64_t n = outer * len * inner;
+    LELE_TRY(ctx->arena_reset());
+    const void* dx;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(out->reserve((size_t)n * 4));
+    if (n) {
+        hipLaunchKernelGGL(halves_pow_add_sqrt_kernel, dim3(grid_for(n)), dim3(256), 0, ctx->stream, (const float*)dx, (float*)out->data,
+                           dim, a0, b0, len, inner, n, *(const float*)exp_lo->data, *(const float*)exp_hi->data);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, shp);
 }
 
 int lele_hip_batch_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, const LeleTensor* bias,

@@ -743,6 +743,14 @@ inline TensorView add3(const TensorView& a, const TensorView& b, const TensorVie
     check(lele_hip_add3(ctx(), &ta, &tb, &tc, out.raw(), sh.dims, &sh.rank));
     LELE_RET(out, LELE_F32);
 }
+inline TensorView halves_pow_add_sqrt(const TensorView& x, int64_t axis, const std::vector<int64_t>& lo, const std::vector<int64_t>& hi,
+                                      const TensorView& exp_lo, const TensorView& exp_hi, Buffer& out) {
+    if (lo.size() != 2 || hi.size() != 2) throw Error("halves_pow_add_sqrt: lo and hi are [start, end] pairs");
+    Shape sh;
+    LeleTensor tx = x.c(), t0 = exp_lo.c(), t1 = exp_hi.c();
+    check(lele_hip_halves_pow_add_sqrt(ctx(), &tx, (int32_t)axis, lo[0], lo[1], hi[0], hi[1], &t0, &t1, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
 inline TensorView depthwise_conv1d_tlc(const TensorView& x, const TensorView& w, const TensorView* bias, int64_t pad_left,
                                        int64_t pad_right, bool relu, int64_t x_offset, bool add_input, Buffer& out) {
     Shape sh;

@@ -826,6 +826,7 @@ class Runner {
         if (fn == "softmax") return set(st, 0, K::softmax(tensor(a[0]), integer(a[1]), o));
         if (fn == "softmax_scaled") return set(st, 0, K::softmax_scaled(tensor(a[0]), tensor(a[1]), integer(a[2]), o));
         if (fn == "add3") return set(st, 0, K::add3(tensor(a[0]), tensor(a[1]), tensor(a[2]), o));
+        if (fn == "halves_pow_add_sqrt") return set(st, 0, K::halves_pow_add_sqrt(tensor(a[0]), integer(a[1]), ints(a[2]), ints(a[3]), tensor(a[4]), tensor(a[5]), o));
         if (fn == "depthwise_conv1d_tlc")
             return set(st, 0, K::depthwise_conv1d_tlc(tensor(a[0]), tensor(a[1]), opt(a[2], h0), integer(a[3]), integer(a[4]), boolean(a[5]), integer(a[6]),
                                                       boolean(a[7]), o));

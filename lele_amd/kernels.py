@@ -791,6 +791,20 @@ def add3(a, b, c, out=None, ctx=None):
     return _op(ctx, _lib.lib().lele_hip_add3, [a, b, c], [], out)
 
 
+def halves_pow_add_sqrt(input, axis, lo, hi, exp_lo, exp_hi, out=None, ctx=None):
+    """sqrt(pow(x[.., lo[0]:lo[1], ..], exp_lo) + pow(x[.., hi[0]:hi[1], ..], exp_hi)) along axis (Slice's bound rules): bit-identical
+    to sqrt(add(pow(slice(..)), pow(slice(..)))) -- the magnitude of a spectrum stored as [re | im] channel halves"""
+    ctx = _ctx(ctx)
+    keep = []
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_halves_pow_add_sqrt(ctx._h, _lib.as_tensor(unwrap(input), keep), C.c_int32(axis), C.c_int64(lo[0]),
+                                                       C.c_int64(lo[1]), C.c_int64(hi[0]), C.c_int64(hi[1]),
+                                                       _lib.as_tensor(unwrap(exp_lo), keep), _lib.as_tensor(unwrap(exp_hi), keep),
+                                                       out._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
+
+
 def depthwise_conv1d_tlc(input, weights, bias=None, pad_left=0, pad_right=0, relu=False, x_offset=0, add_input=False, out=None, ctx=None):
     """transpose(0,2,1) -> depthwise conv1d -> transpose(0,2,1) on a time-major tensor, without the transposes; reads the
     channels [x_offset, x_offset + C) of input [B, T, P] in place; add_input adds the convolved input (the FSMN residual)"""

@@ -349,6 +349,17 @@ def test_extra_fused_kernels_are_bit_identical_to_their_sequences(ctx):
     a, b, c = (rng.standard_normal((5, 33, 64)).astype(np.float32) for _ in range(3))
     assert np.array_equal(K.add3(a, b, c, ctx=ctx).numpy(), K.add(K.add(a, b, ctx=ctx), c, ctx=ctx).numpy())
     assert np.array_equal(K.add3(a, b[:, :1], c[0, 0], ctx=ctx).numpy(), (a + b[:, :1]) + c[0, 0])        # broadcast operands: two passes
+    # spectrum magnitude: Slice Pow Slice Pow Add Sqrt == halves_pow_add_sqrt (Slice's bound rules: open / negative ends)
+    big = 9223372036854775807
+    for shape, axis, lo, hi, ex in (((2, 258, 7), 1, (0, 129), (129, big), (2.0, 2.0)), ((3, 10, 5, 4), 2, (1, 3), (-2, big), (2.0, 3.0)),
+                                    ((6, 40), -1, (0, 20), (20, 40), (2.0, 2.0)), ((4, 9), 0, (0, 2), (2, 4), (1.5, 2.0))):
+        z = np.abs(rng.standard_normal(shape)).astype(np.float32) * 3
+        e0, e1 = (np.array([v], np.float32) for v in ex)
+        seq = K.sqrt(K.add(getattr(K, "pow")(K.slice(z, [lo[0]], [lo[1]], [axis], [1], ctx=ctx), e0, ctx=ctx),
+                           getattr(K, "pow")(K.slice(z, [hi[0]], [hi[1]], [axis], [1], ctx=ctx), e1, ctx=ctx), ctx=ctx), ctx=ctx).numpy()
+        assert np.array_equal(K.halves_pow_add_sqrt(z, axis, lo, hi, e0, e1, ctx=ctx).numpy(), seq), shape
+    with pytest.raises(Exception):
+        K.halves_pow_add_sqrt(np.ones((2, 9), np.float32), 1, (0, 4), (4, big), np.array([2.0], np.float32), np.array([2.0], np.float32), ctx=ctx)
     for k, (pl, pr), bias in ((11, (5, 5), False), (3, (1, 1), True), (5, (0, 4), True), (7, (6, 0), False), (11, (0, 0), True)):
         xt = rng.standard_normal((3, 29, 48)).astype(np.float32)
         w = rng.standard_normal((48, 1, k)).astype(np.float32)
@@ -591,6 +602,7 @@ def test_silero_shaped_if_compiles_both_networks():
     for arm in ("then", "else"):
         f = [s["fn"] for s in st[0][arm]["statements"] if s["op"] == "call"]
         assert f.count("lstm") == 1 and f.count("conv1d_fused") >= 2 and "sigmoid" in f, f
+        assert f.count("halves_pow_add_sqrt") == 1 and "pow" not in f and "sqrt" not in f, f   # Slice Pow Slice Pow Add Sqrt -> one call
     assert plan["inputs"] == ["x", "sr", "h0", "c0"] and [i["dtype"] for i in plan["input_info"]] == ["f32", "i64", "f32", "f32"]
     # both networks' weights are in the one weights.bin
     assert len(blob) > 4 * sum(p.numel() for p in _nets[0].parameters()) + 4 * sum(p.numel() for p in _nets[1].parameters()) - 4096
@@ -620,6 +632,9 @@ def test_silero_shaped_if_matches_torch_per_sample_rate(ctx, tmp_path):
         p1, b1 = compile_model(part, "one")
         alone = [r.numpy() for r in run_plan(ctx, p1, b1, dev)[1]]
         assert all(np.array_equal(a, b) for a, b in zip(got, alone)), sr
+        p0, b0 = compile_model(part, "plain", extra_fusions=False)          # lele's own patterns only: the fused forms change no bit
+        assert "halves_pow_add_sqrt" not in fns(p0) and "pow" in fns(p0)
+        assert all(np.array_equal(a, r.numpy()) for a, r in zip(got, run_plan(ctx, p0, b0, dev)[1])), sr
         d = tmp_path / ("sr%d_%d" % (sr, len(list(tmp_path.iterdir()))))
         d.mkdir()
         _rec, nat = _native(d, plan, blob, {"x": x, "sr": np.array([sr], np.int64), "h0": h0, "c0": c0})

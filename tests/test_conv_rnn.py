@@ -338,3 +338,37 @@ def w_pad(w, g, i):
 
 def r_pad(r, g, h):
     return np.zeros((1, g, h), np.float32)
+
+
+@pytest.mark.gpu
+def test_device_rnn_state_in_place(ctx):
+    """the final state may be stored where the initial state was read from (out_h / out_c = the buffers of initial_h / initial_c):
+    the kernel takes the initial state into LDS before its first step and stores the final state after the last one.  A
+    streaming caller (Silero, chunk after chunk) keeps the state on the device this way, with no copy in between."""
+    from lele_amd import kernels as K
+    from lele_amd.tensor import TensorView
+    rng = np.random.default_rng(77)
+    T, I, H = 3, 24, 128
+    sc = np.float32(1.0 / np.sqrt(H))
+    w, r = ((rng.standard_normal((1, 4 * H, n)) * sc).astype(np.float32) for n in (I, H))
+    b = (rng.standard_normal((1, 8 * H)) * 0.2).astype(np.float32)
+    xs = [rng.standard_normal((T, 1, I)).astype(np.float32) for _ in range(4)]
+    h = c = np.zeros((1, 1, H), np.float32)
+    want = []
+    for x in xs:                                             # separate state buffers, state round-tripped through the host
+        y, hn, cn = K.lstm(x, w, r, b, None, h, c, ctx=ctx)
+        h, c = hn.numpy().copy(), cn.numpy().copy()
+        want.append((y.numpy().copy(), h, c))
+    hb, cb, yb = ctx.buf(), ctx.buf(), ctx.buf()
+    hv, cv = TensorView(hb.upload(np.zeros((1, 1, H), np.float32))), TensorView(cb.upload(np.zeros((1, 1, H), np.float32)))
+    for x, (yw, hw, cw) in zip(xs, want):                    # in place: initial_h / initial_c and out_h / out_c share buffers
+        y, hn, cn = K.lstm(x, w, r, b, None, hv, cv, outs=[yb, hb, cb], ctx=ctx)
+        assert np.array_equal(y.raw().numpy(), yw) and np.array_equal(hn.raw().numpy(), hw) and np.array_equal(cn.raw().numpy(), cw)
+    w3, r3, b3 = w[:, :3 * H], r[:, :3 * H], b[:, :6 * H]
+    h = np.zeros((1, 1, H), np.float32)
+    hv = TensorView(hb.upload(h))
+    for x in xs:
+        y, hn = K.gru(x, w3, r3, b3, h, False, ctx=ctx)
+        h = hn.numpy().copy()
+        y2, hn2 = K.gru(x, w3, r3, b3, hv, False, outs=[yb, hb], ctx=ctx)
+        assert np.array_equal(y2.raw().numpy(), y.numpy()) and np.array_equal(hn2.raw().numpy(), h)

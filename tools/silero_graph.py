@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=175)
     ap.add_argument("--runs", type=int, default=10)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--streams", type=int, default=0, help="also run N independent audio streams side by side (one context each)")
     ap.add_argument("--bind-sr", action="store_true", help="fix sr = 16000 at compile time: the `If` is inlined, the 8 kHz network dropped")
     args = ap.parse_args()
     import lele_amd
@@ -76,41 +77,62 @@ def main():
     t0 = time.perf_counter()
     plan, blob = compile_model(data, "silero_shaped", bind={"sr": np.array([16000], np.int64)} if args.bind_sr else None)
     t_compile = time.perf_counter() - t0
-    ctx = lele_amd._lib.Ctx(0)
-    runner = Runner(plan, load_weights_bin(plan, blob), ctx)
+    weights = load_weights_bin(plan, blob)
     n = args.chunks * CHUNK
     rng = np.random.default_rng(0)
     t = np.arange(n) / 16000.0
     speech = (np.sin(2 * np.pi * 3 * t) > 0).astype(np.float32)           # bursts, so that the segment logic has something to do
     pcm = (speech * (0.3 * np.sin(2 * np.pi * 220 * t) + 0.05 * rng.uniform(-1, 1, n))).astype(np.float32)
-    audio = TensorView(ctx.buf().upload(np.concatenate([np.zeros(CONTEXT, np.float32), pcm])[None, :]))   # [1, CONTEXT + n]
-    xb, hb, cb = ctx.buf(), ctx.buf(), ctx.buf()
+    padded = np.concatenate([np.zeros(CONTEXT, np.float32), pcm])[None, :]   # [1, CONTEXT + n]
     zeros = np.zeros((1, 1, HID), np.float32)
     sr = np.array([16000], np.int64)
 
-    def reset():
-        return TensorView(hb.upload(zeros)), TensorView(cb.upload(zeros))
+    class Lane:
+        """one audio stream: a context (= HIP stream), the runner's workspace, the recorded per-chunk graph, the LSTM state"""
 
-    h, c = reset()
-    x = K.view_copy(audio, [["slice", 1, 0, CONTEXT + CHUNK]], out=xb, ctx=ctx)
-    feeds = {"x": x, "h0": h, "c0": c} if args.bind_sr else {"x": x, "sr": sr, "h0": h, "c0": c}
-    prob, hn, cn = runner.run(feeds)                     # eager once: uploads and packs the weights
-    calls = runner.calls
-    ctx.sync()
-    ctx.graph_begin()
-    prob, hn, cn = runner.run(feeds)
-    K.view_copy(hn, [], out=hb, ctx=ctx)                 # the state stays on the device: next chunk's h0 / c0
-    K.view_copy(cn, [], out=cb, ctx=ctx)
-    graph = ctx.graph_end()
+        def __init__(self, ctx):
+            self.ctx = ctx
+            self.runner = Runner(plan, weights, ctx)
+            self.audio = TensorView(ctx.buf().upload(padded))
+            self.xb = ctx.buf()
+            x = self.chunk(0)
+            feeds = {"x": x, "h0": TensorView(ctx.buf().upload(zeros)), "c0": TensorView(ctx.buf().upload(zeros))}
+            if not args.bind_sr:
+                feeds["sr"] = sr
+            self.prob, hn, cn = self.runner.run(feeds)        # eager once: uploads and packs the weights, sizes every buffer
+            self.calls = self.runner.calls
+            # The state lives where the network writes it: the next chunk reads h0 / c0 from the buffers hn / cn were stored in
+            # (the LSTM kernel takes its initial state into LDS before the first step and stores the final state after the
+            # last one; tests/test_conv_rnn.py pins that in-place use), so no copy moves it between chunks.
+            self.hbuf, self.cbuf = hn.raw().buf, cn.raw().buf
+            self.feeds = dict(feeds, h0=TensorView(self.hbuf.upload(zeros)), c0=TensorView(self.cbuf.upload(zeros)))
+            self.runner.run(self.feeds)
+            ctx.sync()
+            ctx.graph_begin()
+            self.runner.run(self.feeds)
+            self.graph = ctx.graph_end()
+
+        def chunk(self, i):
+            return K.view_copy(self.audio, [["slice", 1, i * CHUNK, CONTEXT + CHUNK]], out=self.xb, ctx=self.ctx)
+
+        def reset(self):
+            self.hbuf.upload(zeros)
+            self.cbuf.upload(zeros)
+
+        def read_prob(self):   # the device value as it is NOW (a TensorView keeps the first host copy it made): 4-byte D2H + sync
+            return float(self.prob.raw().numpy().reshape(-1)[0])
+
+    ctx = lele_amd._lib.Ctx(0)
+    lane = Lane(ctx)
 
     def stream(read_each):
-        reset()
+        lane.reset()
         probs = []
         for i in range(args.chunks):
-            K.view_copy(audio, [["slice", 1, i * CHUNK, CONTEXT + CHUNK]], out=xb, ctx=ctx)
-            graph.launch()
-            if read_each:   # the device value as it is NOW (a TensorView keeps the first host copy it made): one 4-byte D2H + sync
-                probs.append(float(prob.raw().numpy().reshape(-1)[0]))
+            lane.chunk(i)
+            lane.graph.launch()
+            if read_each:
+                probs.append(lane.read_prob())
         ctx.sync()
         return probs
 
@@ -127,17 +149,38 @@ def main():
         stream(False)
         tb.append(time.perf_counter() - t0)
     # the same chunks eagerly through the runner (no graph): must give the same probabilities
-    reset()
+    lane.reset()
     eager = []
     for i in range(args.chunks):
-        K.view_copy(audio, [["slice", 1, i * CHUNK, CONTEXT + CHUNK]], out=xb, ctx=ctx)
-        p, hn2, cn2 = runner.run(feeds)
-        K.view_copy(hn2, [], out=hb, ctx=ctx)
-        K.view_copy(cn2, [], out=cb, ctx=ctx)
-        eager.append(float(p.numpy().reshape(-1)[0]))
+        lane.chunk(i)
+        p = lane.runner.run(lane.feeds)[0]
+        eager.append(float(p.raw().numpy().reshape(-1)[0]))
+    multi = {}
+    if args.streams > 1:  # independent audio streams side by side, one lane each (Silero parallelises across streams only)
+        lanes = [lane] + [Lane(lele_amd._lib.Ctx(0)) for _ in range(args.streams - 1)]
+
+        def round_():
+            for ln in lanes:
+                ln.reset()
+            for i in range(args.chunks):
+                for ln in lanes:
+                    ln.chunk(i)
+                    ln.graph.launch()
+            for ln in lanes:
+                ln.ctx.sync()
+        round_()
+        tm = []
+        for _ in range(args.runs):
+            t0 = time.perf_counter()
+            round_()
+            tm.append(time.perf_counter() - t0)
+        same = all(ln.read_prob() == lanes[0].read_prob() for ln in lanes)
+        multi = {"streams": args.streams, "streams_us_per_chunk": round(1e6 * float(np.mean(tm)) / (args.chunks * args.streams), 2),
+                 "rtf_streams": round(float(np.mean(tm)) / (args.streams * n / 16000.0), 7), "streams_agree": bool(same)}
+    calls = lane.calls
     seconds = n / 16000.0
     segs = apps.vad_segments(np.asarray(probs, np.float32), CHUNK, n, n)
-    rec = {"config": "c1_silero_shaped", "chunks": args.chunks, "audio_s": round(seconds, 3), "kernel_calls_per_chunk": calls + 3,
+    rec = {"config": "c1_silero_shaped", "chunks": args.chunks, "audio_s": round(seconds, 3), "kernel_calls_per_chunk": calls + 1,
            "compile_s": round(t_compile, 3), "weights_bin_bytes": len(blob), "plan_has_if": any(s["op"] == "if" for s in plan["statements"]),
            "streaming_us_per_chunk": round(1e6 * float(np.mean(ts)) / args.chunks, 2), "rtf_streaming": round(float(np.mean(ts)) / seconds, 7),
            "batched_us_per_chunk": round(1e6 * float(np.mean(tb)) / args.chunks, 2), "rtf_batched": round(float(np.mean(tb)) / seconds, 7),
@@ -145,6 +188,7 @@ def main():
            "graph_vs_eager_max_abs": float(np.abs(np.asarray(probs) - np.asarray(eager)).max()),
            "prob_range": [round(min(probs), 6), round(max(probs), 6)], "segments": len(segs),
            "note": "assumed topology, random weights; per-chunk latency, no roofline claim"}
+    rec.update(multi)
     print(json.dumps(rec), flush=True)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
