@@ -410,6 +410,65 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(AL al, BL bl, EPI e
     }
 }
 
+// ---------------------------------------------------------------------------------------------- thin problems
+// A result with at most 4 columns (THIN_M: at most 4 rows) is a handful of matrix-vector products: streaming chunk-by-chunk
+// models (Silero: convolutions with 1-3 output positions, an LSTM step's W.x) consist of little else, and a 32x32 MFMA tile
+// would be 90 % padding there.  One wave per row of the long side; its 64 lanes split K in float4 chunks read through the
+// SAME loader functors (the long-side operand must be k-contiguous: !kRowFast), FMA into at most 4 accumulators, and meet
+// in a shuffle butterfly -- a fixed order, so the result is deterministic; it is a re-association of the exact-product sum
+// like every other kernel here (inside 1e-4).  No LDS, no barrier, every load of a lane issued before its first use.
+template <bool THIN_M, class AL, class BL, class EPI>
+__global__ __launch_bounds__(256) void gemm_f32_thin_kernel(AL al, BL bl, EPI epi, int M, int N, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int batch = blockIdx.y;
+    const int i = blockIdx.x * 4 + wave;  // row (column when THIN_M) of the long side: uniform over the wave
+    if (i >= (THIN_M ? N : M)) return;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto dot = [](float s, const float4& a, const float4& b) {
+        s = __builtin_fmaf(a.x, b.x, s);
+        s = __builtin_fmaf(a.y, b.y, s);
+        s = __builtin_fmaf(a.z, b.z, s);
+        return __builtin_fmaf(a.w, b.w, s);
+    };
+    if constexpr (THIN_M) {
+        const typename BL::Row lr = bl.row(batch, i);
+        typename AL::Row fr[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) fr[f] = al.row(batch, f);  // rows past M load as zeros (loader protocol)
+        for (int k = 4 * lane; k < K; k += 256) {
+            const float4 l = bl.get4(lr, k);
+            float4 v[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) v[f] = al.get4(fr[f], k);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[f] = dot(acc[f], v[f], l);
+        }
+    } else {
+        const typename AL::Row lr = al.row(batch, i);
+        typename BL::Row fr[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) fr[f] = bl.row(batch, f);
+        for (int k = 4 * lane; k < K; k += 256) {
+            const float4 l = al.get4(lr, k);
+            float4 v[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) v[f] = bl.get4(fr[f], k);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[f] = dot(acc[f], l, v[f]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[f] += __shfl_xor(acc[f], off);
+    const int few = THIN_M ? M : N;
+    if (lane < few) {
+        const float mine = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+        const int row = THIN_M ? lane : i, col = THIN_M ? i : lane;
+        epi.store(batch, row, col, mine, epi.load(batch, row, col));
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int BK, int OCC = 1, class AL, class BL, class EPI>
 inline void launch_tile(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int batch) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
@@ -452,6 +511,20 @@ inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, i
                 return;
             }
             default: break;
+        }
+    }
+    // at most 4 columns (or rows) of output: matrix-vector products, one wave per row of the long side (see above).  A caller
+    // that wants the small-problem kernel's per-workgroup statistics keeps that kernel.
+    bool wants_stats = false;
+    if constexpr (has_blockstat<EPI>::value) wants_stats = epi.blockstat != nullptr;
+    if (!wants_stats && K >= 8 && force < 0) {
+        if (N <= 4 && M >= 8 && !AL::kRowFast) {
+            hipLaunchKernelGGL((gemm_f32_thin_kernel<false, AL, BL, EPI>), dim3((M + 3) / 4, batch), dim3(256), 0, st, al, bl, epi, M, N, K);
+            return;
+        }
+        if (M <= 4 && N >= 8 && !BL::kRowFast) {
+            hipLaunchKernelGGL((gemm_f32_thin_kernel<true, AL, BL, EPI>), dim3((N + 3) / 4, batch), dim3(256), 0, st, al, bl, epi, M, N, K);
+            return;
         }
     }
     // too few 64x64 tiles to fill the chip: 32x32 tiles with a 4-way split of K (latency-optimised, see above)

@@ -372,3 +372,34 @@ def test_device_rnn_state_in_place(ctx):
         h = hn.numpy().copy()
         y2, hn2 = K.gru(x, w3, r3, b3, hv, False, outs=[yb, hb], ctx=ctx)
         assert np.array_equal(y2.raw().numpy(), y.numpy()) and np.array_equal(hn2.raw().numpy(), h)
+
+
+THIN_CONVS = [
+    # Silero-shaped: c_in, c_out, k, stride, pad, length -> 1..4 output positions (the matrix-vector path of gemm_core.h)
+    (1, 258, 256, 128, 0, 576), (129, 128, 3, 1, 1, 3), (128, 64, 3, 2, 1, 3), (64, 64, 3, 2, 1, 2), (64, 128, 3, 1, 1, 1),
+    (128, 1, 1, 1, 0, 1), (7, 13, 5, 1, 2, 4), (24, 40, 3, 1, 0, 3), (16, 9, 4, 3, 0, 13),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", THIN_CONVS, ids=[str(i) for i in range(len(THIN_CONVS))])
+def test_device_thin_convolutions_vs_oracle(ctx, shape):
+    from lele_amd import kernels as K
+    ci, co, k, s, p, n = shape
+    rng = np.random.default_rng(co * 100 + n)
+    for batch, group in ((1, 1), (3, 1)) + (((2, 2),) if ci % 2 == 0 and co % 2 == 0 else ()):
+        x = rng.standard_normal((batch, ci, n)).astype(np.float32)
+        w = (rng.standard_normal((co, ci // group, k)) / np.sqrt(ci * k)).astype(np.float32)
+        b = rng.standard_normal(co).astype(np.float32)
+        for bias, relu in ((b, True), (None, False)):
+            got = K.conv1d_fused(x, w, bias, [1], group, [p, p], [s], relu, ctx=ctx).numpy()
+            want = O.conv1d(x, w, bias, [1], group, [p, p], [s], relu)
+            assert got.shape[-1] <= 4, got.shape
+            _close(got, want, RTOL, "thin conv1d %s batch %d group %d" % (shape, batch, group))
+    # 2-D: a 2x2 (and 1x3) output plane
+    x = rng.standard_normal((2, ci, 4, 5)).astype(np.float32)
+    w = (rng.standard_normal((co, ci, 3, 3)) / np.sqrt(ci * 9)).astype(np.float32)
+    for strides, pads in (([1, 2], [0, 0, 0, 0]), ([2, 2], [0, 1, 0, 0])):
+        got = K.conv2d(x, w, None, [1, 1], 1, pads, strides, ctx=ctx).numpy()
+        assert got.shape[2] * got.shape[3] <= 4, got.shape
+        _close(got, O.conv2d(x, w, None, [1, 1], 1, pads, strides), RTOL, "thin conv2d %s" % (shape,))
