@@ -444,7 +444,12 @@ class Lowering:
             return self.emit(O, "resize_nearest", [T(I[0]), {"some": {"list": [{"float": float(v)} for v in np.asarray(self.consts[sc]).reshape(-1)]}},
                                                    {"none": 1}, {"str": mode}])
         if op == "Transpose":
-            return self.emit(O, "transpose", [T(I[0]), ilist("perm")])
+            st = self.emit(O, "transpose", [T(I[0]), ilist("perm")])
+            # A permutation that only moves size-1 axes changes no byte: the runners then hand the input on as a view instead of
+            # copying it (known only at run time, shapes being dynamic).  allocate() keeps the input's buffer alive as long as
+            # the result for such statements, on top of giving the result a slot of its own.
+            st["may_alias"] = True
+            return st
         if op == "Reshape":
             return self.emit(O, "reshape", [T(I[0]), self.ints(node, 1)], view=True)
         if op == "Flatten":
@@ -875,7 +880,7 @@ def allocate(statements, outputs):
     reader; views extend the life of the buffer they share; a statement never writes a slot it (or one of the five
     statements before it, which may be fused with it upstream) reads.  Adds "slots" to every device statement in place and
     returns the slot names."""
-    last_use, owner = {}, {}
+    last_use, owner, maybe = {}, {}, {}
     INF = len(statements) + 1
 
     def refs(n, acc):
@@ -901,12 +906,16 @@ def allocate(statements, outputs):
         if st["op"] == "call" and st.get("bufs", 1) == 0:  # view: shares its first tensor operand's buffer
             src = r[0] if r else None
             owner[st["out"][0]] = owner.get(src, src)
+        elif st.get("may_alias") and r:                      # may turn out to be a view of its first operand at run time
+            maybe[st["out"][0]] = r[0]
     for o in outputs:
         last_use[o] = INF
     # a buffer lives as long as its longest-lived view
     for i in range(len(statements) - 1, -1, -1):
         for o in statements[i]["out"]:
             root = owner.get(o)
+            if root is None and o in maybe:
+                root = owner.get(maybe[o], maybe[o])
             if root is not None:
                 last_use[root] = max(last_use.get(root, -1), last_use.get(o, -1))
     free, active, slot_of, n_slots = [], {}, {}, 0

@@ -6,6 +6,7 @@
 // C++17, no dependencies beyond lele.hpp.  Mirrors lele_amd/plan.py statement for statement (tests run both on the
 // same plan and compare bits).
 #pragma once
+#include <algorithm>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -847,7 +848,23 @@ class Runner {
             } else throw Error("Resize: either scales or sizes must be provided");
             return set(st, 0, K::resize_nearest(x, oh, ow, a[3].at("str").str == "asymmetric", o));
         }
-        if (fn == "transpose") return set(st, 0, K::transpose(tensor(a[0]), ints(a[1]), o));
+        if (fn == "transpose") {
+            const TV x = tensor(a[0]);
+            std::vector<int64_t> perm = ints(a[1]);
+            if (st.has("may_alias") && perm.size() == x.shape.size()) {   // only size-1 axes move: no byte changes -> a view
+                std::vector<int64_t> kept, shape;
+                for (int64_t& p : perm) {
+                    if (p < 0) p += (int64_t)perm.size();
+                    if (x.shape.at((size_t)p) != 1) kept.push_back(p);
+                    shape.push_back(x.shape.at((size_t)p));
+                }
+                if (std::is_sorted(kept.begin(), kept.end())) {
+                    --calls_;
+                    return set(st, 0, x.with_shape(shape));
+                }
+            }
+            return set(st, 0, K::transpose(x, perm, o));
+        }
         if (fn == "view_copy") return set(st, 0, view_copy(tensor(a[0]), a[1].at("chain"), o));
         if (fn == "matmul_view") {
             std::vector<int64_t> perm, resh;

@@ -231,8 +231,19 @@ class Runner:
                 return n[k]
         raise ValueError(n)
 
-    def call(self, f, fn, pos, bufs, key=None):
+    @staticmethod
+    def moves_only_unit_axes(shape, perm):
+        """a transpose that changes no byte: the axes longer than 1 keep their order"""
+        perm = [p + len(shape) if p < 0 else p for p in perm]
+        kept = [p for p in perm if shape[p] != 1]
+        return len(perm) == len(shape) and kept == sorted(kept)
+
+    def call(self, f, fn, pos, bufs, key=None, may_alias=False):
         ctx = self.ctx
+        if fn == "transpose" and may_alias and self.moves_only_unit_axes(list(pos[0].shape), pos[1]):
+            self.calls -= 1                                  # a view, not a kernel (the plan reserved for both: lower.py, allocate)
+            perm = [p + len(pos[0].shape) if p < 0 else p for p in pos[1]]
+            return self.K.reshape(pos[0], [int(pos[0].shape[p]) for p in perm])
         if fn == "split_owned":  # owned results: one persistent device buffer per output of this statement
             outs = self.extra.setdefault(("split", key), [ctx.buf() for _ in pos[2]])
             return list(f(pos[0], pos[1], pos[2], outputs=outs, ctx=ctx))
@@ -334,7 +345,7 @@ class Runner:
                 self.calls += 1
                 try:
                     t0 = time.perf_counter() if self.profile is not None else 0.0
-                    res = self.call(f, fn, pos, bufs, key=st["out"][0] + str(self.stmt_index))
+                    res = self.call(f, fn, pos, bufs, key=st["out"][0] + str(self.stmt_index), may_alias=bool(st.get("may_alias")))
                     if self.profile is not None:
                         ctx.sync()
                         self.profile[fn] = self.profile.get(fn, 0.0) + time.perf_counter() - t0

@@ -639,3 +639,23 @@ def test_silero_shaped_if_matches_torch_per_sample_rate(ctx, tmp_path):
         d.mkdir()
         _rec, nat = _native(d, plan, blob, {"x": x, "sr": np.array([sr], np.int64), "h0": h0, "c0": c0})
         assert all(np.array_equal(a, b) for a, b in zip(nat, got)), sr
+
+
+def test_transposes_that_may_be_views_keep_their_operand_alive():
+    """a Transpose that only moves size-1 axes is handed on as a view at run time (shapes are dynamic, so the plan cannot know):
+    its statement has a slot of its own AND pins the operand's buffer for as long as the result lives"""
+    from lele_amd.plan import Runner
+    nodes = [pb.Node("Relu", ["x"], ["a"]), pb.Node("Transpose", ["a"], ["t"], perm=[2, 0, 1]), pb.Node("Sigmoid", ["x"], ["b"]),
+             pb.Node("Tanh", ["b"], ["c"]), pb.Node("Exp", ["c"], ["d"]), pb.Node("Neg", ["d"], ["e"]), pb.Node("Abs", ["e"], ["f"]),
+             pb.Node("Floor", ["f"], ["g"]), pb.Node("Ceil", ["g"], ["h"]), pb.Node("Reshape", ["t", "shp"], ["t2"]), pb.Node("Add", ["t2", "h"], ["y"])]
+    g = pb.Graph(nodes, [pb.ValueInfo("x", pb.FLOAT, [1, "c", 1])], [pb.ValueInfo("y", pb.FLOAT, None)], [pb.Tensor("shp", np.array([1, -1, 1], np.int64))])
+    plan, _ = compile_model(pb.Model(g, opset=13).serialize())
+    st = {s["out"][0]: s for s in plan["statements"]}
+    assert st["t"]["may_alias"] and len(st["t"]["slots"]) == 1
+    a_slot = st["a"]["slots"][0]
+    # a's buffer must not be handed to anything between the transpose and the last reader of t (the Add at the end)
+    later = [s for s in plan["statements"][plan["statements"].index(st["t"]):] if s.get("slots")]
+    assert all(a_slot not in s["slots"] for s in later), [(s["out"], s["slots"]) for s in later]
+    assert Runner.moves_only_unit_axes([1, 128, 1], [2, 0, 1]) and Runner.moves_only_unit_axes([1, 1, 7], [1, 2, 0])
+    assert not Runner.moves_only_unit_axes([2, 128, 1], [1, 0, 2]) and Runner.moves_only_unit_axes([5, 1, 6], [0, 2, 1])
+    assert not Runner.moves_only_unit_axes([5, 3, 6], [0, 2, 1])
