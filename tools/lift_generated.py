@@ -267,6 +267,9 @@ def main():
     b.add_argument("--as-lifted", action="store_true", help="run the call sequence exactly as lifted (no sigmoid+mul -> silu peephole)")
     b.add_argument("--replan", action="store_true", help="re-assign buffers with this library's liveness allocator and fold conv2d+silu "
                    "(plan.replan_lifted); kept only if the outputs stay bit-identical")
+    b.add_argument("--e2e", action="store_true", help="also time the whole application step on the device: u8 HWC image -> resize / normalise "
+                   "(image.rs:62-111) -> the graph -> score filter, mask assembly and crop (image.rs:127-265); only the detections and the "
+                   "u8 mask come back")
     b.add_argument("--streams", type=int, default=0, help="also replay the graph on N contexts (N HIP streams, one image each) at once")
     b.add_argument("--native", action="store_true", help="also run the plan with the native runner (lele_amd/lele_run) and compare")
     args = ap.parse_args()
@@ -395,6 +398,37 @@ def main():
             ts.append(time.perf_counter() - t0)
         per_image = float(np.mean(ts)) / ((args.batch_runs // args.streams or 1) * args.streams)
         rec.update({"streams": args.streams, "streams_ms_per_image": round(1e3 * per_image, 4), "images_per_s_streams": round(1.0 / per_image, 1)})
+    if args.e2e and isinstance(graph_ms, float) and shape == [1, 3, 640, 640]:
+        from lele_amd import kernels as K
+        ih, iw = 480, 640
+        img = ctx.buf().upload(rng.integers(0, 256, (ih, iw, 3), dtype=np.uint8))
+        K.image_preprocess(TensorView(img), 640, out=x.buf, ctx=ctx)   # writes the graph's input buffer
+        ctx.sync()
+        res = r.run(inp)
+        db, cb_, mb = ctx.buf(), ctx.buf(), ctx.buf()
+        e2e = {}
+        for tag, thr in (("threshold_0.25", 0.25),):
+
+            def app_step(thr=thr):
+                K.image_preprocess(TensorView(img), 640, out=x.buf, ctx=ctx)
+                g.launch()
+                return K.yolo_seg_postprocess(res[0], res[1], iw, ih, thr, out_dets=db, out_count=cb_, out_mask=mb, ctx=ctx)
+            dets, count, mask = app_step()
+            n_det = int(count.raw().numpy()[0])
+            ts = []
+            for _ in range(args.runs):
+                ctx.sync()
+                t0 = time.perf_counter()
+                for _ in range(args.batch_runs):
+                    dets, count, mask = app_step()
+                mask.raw().numpy()                               # the u8 mask and the detections are what leaves the device
+                ctx.sync()
+                ts.append(time.perf_counter() - t0)
+            e2e[tag] = {"ms_per_image": round(1e3 * float(np.mean(ts)) / args.batch_runs, 4), "detections": n_det}
+        rec.update({"e2e": e2e, "e2e_image": [ih, iw, 3],
+                    "e2e_note": "u8 image -> preprocess -> graph -> postprocess, all on the device; with synthetic weights the boxes are "
+                                "degenerate and none survives the filter (the mask pass still visits every pixel): the path is what is "
+                                "timed, the post-processing's results are pinned by tests/test_app_steps.py"})
     if args.native:  # the same plan, the same weights, no Python: C++ runner over the C ABI
         import subprocess
         import tempfile
