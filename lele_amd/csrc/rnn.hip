@@ -167,7 +167,23 @@ int run_rnn(LeleCtx* ctx, const char* name, const LeleTensor* x, const LeleTenso
     if (c0) LELE_TRY(ctx->dev_ptr(c0, &dc0));
     void *wx = nullptr, *rt = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)std::max<int64_t>(1, T * G) * 4, &wx));
-    LELE_TRY(ctx->arena_alloc((size_t)G * H * 4, &rt));
+    // R transposed: once per weight when the caller declared it immutable (a streaming model calls this for every chunk)
+    const bool r_cacheable = r->mem == LELE_MEM_WEIGHT;
+    const auto r_key = std::make_tuple((const void*)r->data, (size_t)G * H * 4, 601);
+    bool have_rt = false;
+    if (r_cacheable) {
+        auto it = ctx->weights.find(r_key);
+        if (it != ctx->weights.end()) {
+            rt = it->second;
+            have_rt = true;
+        } else {
+            LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
+            LELE_HIP_CHECK(hipMalloc(&rt, (size_t)G * H * 4));
+            ctx->weights[r_key] = rt;
+        }
+    } else {
+        LELE_TRY(ctx->arena_alloc((size_t)G * H * 4, &rt));
+    }
     LELE_TRY(y->reserve((size_t)T * H * 4));
     LELE_TRY(hn->reserve((size_t)H * 4));
     if (MODE == 0) LELE_TRY(cn->reserve((size_t)H * 4));
@@ -177,8 +193,9 @@ int run_rnn(LeleCtx* ctx, const char* name, const LeleTensor* x, const LeleTenso
         gemm::EpiAffine epi{(float*)wx, 0, (int)T, (int)G, 1.0f, 0.0f, nullptr, gemm::C_NONE, 1};
         gemm::launch(ctx->stream, al, bl, epi, (int)T, (int)G, (int)I, 1, ctx->num_cus);
     }
-    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((H + 31) / 32), (unsigned)((G + 31) / 32)), dim3(32, 8), 0,
-                       ctx->stream, (const float*)dr, (float*)rt, (int)G, (int)H);
+    if (!have_rt)
+        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((H + 31) / 32), (unsigned)((G + 31) / 32)), dim3(32, 8), 0,
+                           ctx->stream, (const float*)dr, (float*)rt, (int)G, (int)H);
     static bool attr_set[2] = {false, false};
     if (!attr_set[MODE]) {
         LELE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_kernel<MODE>),
