@@ -659,3 +659,19 @@ def test_transposes_that_may_be_views_keep_their_operand_alive():
     assert Runner.moves_only_unit_axes([1, 128, 1], [2, 0, 1]) and Runner.moves_only_unit_axes([1, 1, 7], [1, 2, 0])
     assert not Runner.moves_only_unit_axes([2, 128, 1], [1, 0, 2]) and Runner.moves_only_unit_axes([5, 1, 6], [0, 2, 1])
     assert not Runner.moves_only_unit_axes([5, 3, 6], [0, 2, 1])
+
+
+def test_silero_tool_model_compiles_to_the_expected_chain():
+    """tools/silero_graph.py (config C1): with sr bound, a chunk is 15 statements of which 12 launch a kernel at run time"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import silero_graph
+    data = silero_graph.build_onnx()
+    plan, blob = compile_model(data, "silero_shaped", bind={"sr": np.array([16000], np.int64)})
+    f = [s["fn"] for s in plan["statements"]]
+    assert f == ["unsqueeze", "conv1d", "halves_pow_add_sqrt", "conv1d_fused", "conv1d_fused", "conv1d_fused", "conv1d_fused", "transpose",
+                 "lstm", "squeeze", "relu", "transpose", "conv1d", "sigmoid", "reduce_mean", "identity", "identity", "identity"], f
+    assert all(s.get("may_alias") for s in plan["statements"] if s["fn"] == "transpose")
+    full, blob2 = compile_model(data, "silero_shaped")
+    assert [s["op"] for s in full["statements"]] == ["host", "if"] and len(blob2) > 1.7 * len(blob)
