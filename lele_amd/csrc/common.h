@@ -74,6 +74,10 @@ struct LeleCtx {
     // scratch that ops may keep across calls (grown on demand)
     void* scratch = nullptr;
     size_t scratch_cap = 0;
+    // page-locked mailbox for small device-to-host reads (a probability, token ids, a count): a copy into pageable memory
+    // goes through the runtime's own staging path and costs several times the latency of one into pinned memory
+    void* mailbox = nullptr;
+    static constexpr size_t kMailboxBytes = 64 * 1024;
     // true between lele_hip_graph_begin / _end: every launch on `stream` is being recorded into a hipGraph, so nothing
     // may allocate, free, synchronise or touch pageable host memory (the guards return an error instead)
     bool capturing = false;

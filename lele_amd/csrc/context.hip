@@ -161,6 +161,7 @@ int lele_hip_ctx_destroy(LeleCtx* c) {
     for (auto& kv : c->weights) (void)hipFree(kv.second);
     if (c->arena) (void)hipFree(c->arena);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->mailbox) (void)hipHostFree(c->mailbox);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->stream);
@@ -275,8 +276,19 @@ int lele_hip_buf_from_host(LeleBuf* b, const void* src, size_t bytes) {
 int lele_hip_buf_to_host(LeleBuf* b, void* dst, size_t bytes) {
     LELE_REQUIRE(b, "buf_to_host: buf is NULL");
     LELE_REQUIRE(bytes <= b->bytes, "buf_to_host: %zu bytes requested, result holds %zu", bytes, b->bytes);
-    if (bytes) LELE_HIP_CHECK(hipMemcpyAsync(dst, b->data, bytes, hipMemcpyDeviceToHost, b->ctx->stream));
-    LELE_HIP_CHECK(hipStreamSynchronize(b->ctx->stream));
+    LeleCtx* c = b->ctx;
+    if (bytes && bytes <= LeleCtx::kMailboxBytes) {   // small read: through the context's page-locked mailbox
+        if (!c->mailbox) {
+            LELE_REQUIRE(!c->capturing, "buf_to_host: not allowed while a graph is being captured");
+            LELE_HIP_CHECK(hipHostMalloc(&c->mailbox, LeleCtx::kMailboxBytes, hipHostMallocDefault));
+        }
+        LELE_HIP_CHECK(hipMemcpyAsync(c->mailbox, b->data, bytes, hipMemcpyDeviceToHost, c->stream));
+        LELE_HIP_CHECK(hipStreamSynchronize(c->stream));
+        memcpy(dst, c->mailbox, bytes);
+        return 0;
+    }
+    if (bytes) LELE_HIP_CHECK(hipMemcpyAsync(dst, b->data, bytes, hipMemcpyDeviceToHost, c->stream));
+    LELE_HIP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
