@@ -78,6 +78,11 @@ int lele_hip_buf_create(LeleCtx* ctx, LeleBuf** out);
 int lele_hip_buf_destroy(LeleBuf* buf);
 int lele_hip_buf_reserve(LeleBuf* buf, size_t bytes);
 void* lele_hip_buf_data(LeleBuf* buf);
+/* Tell the library that the buffer's contents were written behind its back (through lele_hip_buf_data() + the ctx stream: a
+ * hipMemcpy, an RCCL receive, the integrator's own kernel).  Producer-side statistics kept next to the buffer (the {min, max}
+ * row pairs a LayerNorm / linear leaves for the dynamic quantisation that reads the tensor next) are dropped.  Every op of this
+ * library does the equivalent on its own outputs. */
+int lele_hip_buf_mark_dirty(LeleBuf* buf);
 size_t lele_hip_buf_bytes(LeleBuf* buf); /* size of the last result in bytes */
 int lele_hip_buf_from_host(LeleBuf* buf, const void* src, size_t bytes);
 int lele_hip_buf_to_host(LeleBuf* buf, void* dst, size_t bytes); /* synchronises the ctx stream */
@@ -164,6 +169,26 @@ int lele_hip_mat_mul_integer_with_scale_bias(LeleCtx* ctx, const LeleTensor* a, 
                                              const LeleTensor* scale, const LeleTensor* bias, int apply_relu,
                                              LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
 
+/* prepare_weights (quantization.rs:221) / PreparedWeights: a weight matrix given as RAW u8 bytes [K, N] (row-major), packed for
+ * the i8 matrix cores once.  mat_mul_integer_prepared (quantization.rs:699): `a` holds u8 values as f32; zero points are host
+ * scalars (has_* == 0 <=> None).  fused_dq_gemm_prepared (fused_dq_gemm_prepared_x86, quantization.rs:454): dynamic
+ * quantisation per batch slice + prepared GEMM + scale + bias [+ ReLU] -- fused_quantized_linear on a prepared matrix.
+ * mat_mul_integer_u8_weights (quantization.rs:173) is prepare_weights + mat_mul_integer_prepared; the shim keeps the handle. */
+typedef struct LelePrepared LelePrepared;
+int lele_hip_prepare_weights(LeleCtx* ctx, const uint8_t* b_u8, int64_t k, int64_t n, LelePrepared** out);
+int lele_hip_prepared_destroy(LelePrepared* pw);
+int lele_hip_mat_mul_integer_prepared(LeleCtx* ctx, const LeleTensor* a, const LelePrepared* pw, int has_a_zero_point,
+                                      float a_zero_point, int has_b_zero_point, int32_t b_zero_point, const LeleTensor* scale,
+                                      const LeleTensor* bias, int apply_relu, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+int lele_hip_fused_dq_gemm_prepared(LeleCtx* ctx, const LeleTensor* input, const LelePrepared* pw, int has_b_zero_point,
+                                    int32_t b_zero_point, const LeleTensor* weight_scale, const LeleTensor* bias, int apply_relu,
+                                    LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* per-stage stopwatch of fused_quantized_linear for bench.py's roofline block: while on, every EAGER call records HIP events on
+ * the ctx stream between its stages (range pass | row quantisation | i8 GEMM; a stage a call skips reads 0); profile_read()
+ * drains the stream and returns the average duration of each stage over the calls since the last read. */
+int lele_hip_quant_set_profiling(LeleCtx* ctx, int on);
+int lele_hip_quant_profile_read(LeleCtx* ctx, float* range_ms, float* quantise_ms, float* gemm_ms, int64_t* calls);
+
 /* ---- src/kernels/math.rs: activations and element-wise ops ---------------------------------------------- */
 /* Unary f32 ops.  LeleUnaryOp names the lele kernel it replaces (math.rs file:line in eltwise.hip). */
 typedef enum {
@@ -222,6 +247,9 @@ int lele_hip_resize_nearest(LeleCtx* ctx, const LeleTensor* x, int64_t out_h, in
 int lele_hip_max_pool2d(LeleCtx* ctx, const LeleTensor* x, const int64_t* kernel_shape, size_t nk,
                         const int64_t* strides, size_t ns, const int64_t* pads, size_t np, const int64_t* dilations,
                         size_t nd, int ceil_mode, LeleBuf* out, int64_t* out_shape, int32_t* out_rank); /* conv2d.rs:1051 */
+/* adaptive_avg_pool1d, pooling.rs:1-30: x [.., L] -> [.., output_len]; window i = [floor(i*L/O), ceil((i+1)*L/O)) */
+int lele_hip_adaptive_avg_pool1d(LeleCtx* ctx, const LeleTensor* x, int64_t output_len, LeleBuf* out, int64_t* out_shape,
+                                 int32_t* out_rank);
 int lele_hip_topk(LeleCtx* ctx, const LeleTensor* x, int64_t k, int largest, LeleBuf* out_values, LeleBuf* out_indices,
                   int64_t* out_shape, int32_t* out_rank);                                     /* conv2d.rs:1385 */
 int lele_hip_range_f32(LeleCtx* ctx, float start, float delta, int64_t n, LeleBuf* out, int64_t* out_shape,

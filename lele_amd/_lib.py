@@ -76,9 +76,15 @@ class Ctx:
         check(lib().lele_hip_ctx_create(C.c_int(device), C.byref(self._h)))
         self.device = device
         self._bufs = []
+        self._graphs = []  # weak references: ctx_destroy destroys the graphs recorded on it, their wrappers must not do it again
 
     def close(self):
         if self._h:
+            for r in self._graphs:
+                g = r()
+                if g is not None:
+                    g.close()
+            self._graphs = []
             for b in self._bufs:
                 b.close()
             lib().lele_hip_ctx_destroy(self._h)
@@ -111,7 +117,20 @@ class Ctx:
         if rc != 0:
             lib().lele_hip_graph_abort(self._h)
         check(rc)
-        return Graph(self, h)
+        g = Graph(self, h)
+        import weakref
+        self._graphs.append(weakref.ref(g))
+        return g
+
+    def quant_set_profiling(self, on):
+        """per-stage stopwatch of fused_quantized_linear (eager calls only), see include/lele_hip.h"""
+        check(lib().lele_hip_quant_set_profiling(self._h, C.c_int(int(on))))
+
+    def quant_profile_read(self):
+        """-> (range_ms, quantise_ms, gemm_ms, calls): average per call since the last read"""
+        a, b, c, n = C.c_float(), C.c_float(), C.c_float(), C.c_int64()
+        check(lib().lele_hip_quant_profile_read(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return a.value, b.value, c.value, n.value
 
     def graph_abort(self):
         lib().lele_hip_graph_abort(self._h)
@@ -142,6 +161,10 @@ class Buf:
     @property
     def nbytes(self):
         return lib().lele_hip_buf_bytes(self._h)
+
+    def mark_dirty(self):
+        """the contents were written behind the library's back (see lele_hip_buf_mark_dirty)"""
+        check(lib().lele_hip_buf_mark_dirty(self._h))
 
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)

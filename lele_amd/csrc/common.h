@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <map>
+#include <mutex>
+#include <set>
 #include <string>
 #include <utility>
 #include <vector>
@@ -49,6 +51,21 @@ inline size_t dtype_size(int dt) {
     }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: remember the opt-in per (kernel, device),
+// under a lock (one ctx per host thread is the documented threading model, so launches race on this table)
+inline hipError_t ensure_dyn_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({kernel, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({kernel, dev});
+    return e;
+}
+
 inline int64_t numel(const LeleTensor* t) {
     int64_t n = 1;
     for (int i = 0; i < t->rank; ++i) n *= t->shape[i];
@@ -81,7 +98,23 @@ struct LeleCtx {
     // true between lele_hip_graph_begin / _end: every launch on `stream` is being recorded into a hipGraph, so nothing
     // may allocate, free, synchronise or touch pageable host memory (the guards return an error instead)
     bool capturing = false;
+    // Bumped whenever device memory a recorded graph may have baked in is freed (a LeleBuf or the scratch block re-allocated,
+    // arena overflow blocks released): a LeleGraph remembers the value at graph_end and refuses to replay after a change.
+    uint64_t generation = 0;
+    // Sticky device-side error word (page-locked host memory mapped into the device): kernels that meet a data-dependent
+    // violation the reference would panic! on (an out-of-range gather index) clamp the access and set a bit here; the next
+    // lele_hip_sync / buf_to_host reports it as an error.  LELE_DEVERR_* below.
+    unsigned* deverr_host = nullptr;
+    unsigned* deverr_dev = nullptr;
+    std::vector<LeleGraph*> graphs;  // alive graphs recorded on this ctx (destroyed with it)
+    // per-stage stopwatch of the quantised linear (bench.py's roofline block): events recorded between its kernels
+    struct QProf {
+        bool on = false;
+        std::vector<hipEvent_t> ev;  // 4 per call: start, after range, after row quantisation, after GEMM
+        size_t used = 0;
+    } qprof;
 
+    int check_deverr(const char* where);
     int arena_reset();
     int arena_alloc(size_t bytes, void** out);
     int get_scratch(size_t bytes, void** out);
@@ -92,7 +125,10 @@ struct LeleCtx {
 struct LeleGraph {
     LeleCtx* ctx = nullptr;
     hipGraphExec_t exec = nullptr;
+    uint64_t generation = 0;
 };
+
+#define LELE_DEVERR_GATHER_INDEX 1u
 
 struct LeleBuf {
     LeleCtx* ctx = nullptr;
@@ -105,7 +141,9 @@ struct LeleBuf {
     float* rowstat = nullptr;  // [rowstat_rows][2] on the device
     size_t rowstat_cap = 0;    // in rows
     int64_t rowstat_rows = 0, rowstat_len = 0;  // ROWS: pairs = rows, len = row length; WHOLE: pairs = blocks, len = element count
-    int rowstat_kind = 0;                       // 0 = one pair per row (LayerNorm); 1 = pairs that together cover the whole tensor
+    int64_t rowstat_m = 0;                      // kind 2: rows per slice
+    int rowstat_kind = 0;                       // 0 = one pair per row (LayerNorm); 1 = pairs that together cover the whole tensor;
+                                                // 2 = rowstat_rows / slices pairs per slice of rowstat_m rows of length rowstat_len
     bool rowstat_valid = false;
     int reserve(size_t n);
     int reserve_rowstat(int64_t rows);  // may decline (returns 0 with rowstat == nullptr untouched) while capturing

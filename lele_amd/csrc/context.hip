@@ -25,6 +25,18 @@ int LeleCtx::arena_reset() {
         LELE_HIP_CHECK(hipStreamSynchronize(stream));
         for (void* p : arena_overflow) (void)hipFree(p);
         arena_overflow.clear();
+        ++generation;
+    }
+    return 0;
+}
+
+int LeleCtx::check_deverr(const char* where) {
+    if (deverr_host && *deverr_host) {
+        const unsigned bits = *deverr_host;
+        *deverr_host = 0;
+        LELE_REQUIRE(false, "%s: a kernel reported a data-dependent violation earlier on this stream:%s (the access was clamped; "
+                     "lele's bounds-checked indexing panics here, manipulation.rs:626-633)", where,
+                     (bits & LELE_DEVERR_GATHER_INDEX) ? " gather index out of range" : " unknown");
     }
     return 0;
 }
@@ -48,7 +60,10 @@ int LeleCtx::get_scratch(size_t bytes, void** out) {
     if (bytes > scratch_cap) {
         LELE_REQUIRE(!capturing, "graph capture: scratch would grow; run the sequence once before capturing it");
         LELE_HIP_CHECK(hipStreamSynchronize(stream));
-        if (scratch) (void)hipFree(scratch);
+        if (scratch) {
+            (void)hipFree(scratch);
+            ++generation;
+        }
         scratch = nullptr;
         scratch_cap = 0;
         size_t cap = (bytes + (1 << 20)) & ~size_t((1 << 20) - 1);
@@ -102,6 +117,7 @@ int LeleBuf::reserve(size_t n) {
         if (data) {
             ctx->buf_of_data.erase(data);
             (void)hipFree(data);
+            ++ctx->generation;
         }
         data = nullptr;
         cap = 0;
@@ -118,7 +134,10 @@ int LeleBuf::reserve_rowstat(int64_t rows) {
     if ((size_t)rows <= rowstat_cap) return 0;
     if (ctx->capturing) return 0;  // no allocation while recording: the producer simply does not publish statistics
     LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (rowstat) (void)hipFree(rowstat);
+    if (rowstat) {
+        (void)hipFree(rowstat);
+        ++ctx->generation;
+    }
     rowstat = nullptr;
     rowstat_cap = 0;
     const size_t c = ((size_t)rows + 511) & ~size_t(511);
@@ -149,6 +168,9 @@ int lele_hip_ctx_create(int device, LeleCtx** out) {
     LELE_HIP_CHECK(hipEventCreate(&c->ev1));
     c->arena_cap = size_t(64) << 20;
     LELE_HIP_CHECK(hipMalloc((void**)&c->arena, c->arena_cap));
+    LELE_HIP_CHECK(hipHostMalloc((void**)&c->deverr_host, 64, hipHostMallocMapped));
+    *c->deverr_host = 0;
+    LELE_HIP_CHECK(hipHostGetDevicePointer((void**)&c->deverr_dev, c->deverr_host, 0));
     *out = c;
     return 0;
 }
@@ -157,6 +179,9 @@ int lele_hip_ctx_destroy(LeleCtx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    while (!c->graphs.empty()) (void)lele_hip_graph_destroy(c->graphs.back());  // graphs hold raw addresses of this ctx's memory
+    for (hipEvent_t e : c->qprof.ev) (void)hipEventDestroy(e);
+    if (c->deverr_host) (void)hipHostFree(c->deverr_host);
     for (void* p : c->arena_overflow) (void)hipFree(p);
     for (auto& kv : c->weights) (void)hipFree(kv.second);
     if (c->arena) (void)hipFree(c->arena);
@@ -173,7 +198,7 @@ int lele_hip_sync(LeleCtx* c) {
     LELE_REQUIRE(c, "sync: ctx is NULL");
     LELE_REQUIRE(!c->capturing, "sync: not allowed while a graph is being captured");
     LELE_HIP_CHECK(hipStreamSynchronize(c->stream));
-    return 0;
+    return c->check_deverr("sync");
 }
 
 void* lele_hip_ctx_stream(LeleCtx* c) { return c ? (void*)c->stream : nullptr; }
@@ -202,6 +227,8 @@ int lele_hip_graph_end(LeleCtx* c, LeleGraph** out) {
     LeleGraph* lg = new LeleGraph();
     lg->ctx = c;
     lg->exec = e;
+    lg->generation = c->generation;
+    c->graphs.push_back(lg);
     *out = lg;
     return 0;
 }
@@ -218,6 +245,9 @@ int lele_hip_graph_abort(LeleCtx* c) {  // leave capture mode after a failed op,
 int lele_hip_graph_launch(LeleGraph* g) {
     LELE_REQUIRE(g && g->exec, "graph_launch: graph is NULL");
     LELE_REQUIRE(!g->ctx->capturing, "graph_launch: not allowed while capturing");
+    LELE_REQUIRE(g->generation == g->ctx->generation,
+                 "graph_launch: device memory of this ctx was re-allocated after the graph was recorded (a buffer, the scratch "
+                 "block or a row-statistics block grew): the recorded addresses are stale -- record the graph again");
     LELE_HIP_CHECK(hipGraphLaunch(g->exec, g->ctx->stream));
     return 0;
 }
@@ -225,6 +255,12 @@ int lele_hip_graph_destroy(LeleGraph* g) {
     if (!g) return 0;
     (void)hipStreamSynchronize(g->ctx->stream);
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    auto& v = g->ctx->graphs;
+    for (size_t i = 0; i < v.size(); ++i)
+        if (v[i] == g) {
+            v.erase(v.begin() + i);
+            break;
+        }
     delete g;
     return 0;
 }
@@ -253,6 +289,7 @@ int lele_hip_buf_destroy(LeleBuf* b) {
         (void)hipStreamSynchronize(b->ctx->stream);
         b->ctx->buf_of_data.erase(b->data);
         (void)hipFree(b->data);
+        ++b->ctx->generation;
     }
     if (b->rowstat) (void)hipFree(b->rowstat);
     delete b;
@@ -263,6 +300,11 @@ int lele_hip_buf_reserve(LeleBuf* b, size_t bytes) {
     return b->reserve(bytes);
 }
 void* lele_hip_buf_data(LeleBuf* b) { return b ? b->data : nullptr; }
+int lele_hip_buf_mark_dirty(LeleBuf* b) {
+    LELE_REQUIRE(b, "buf_mark_dirty: buf is NULL");
+    b->rowstat_valid = false;
+    return 0;
+}
 size_t lele_hip_buf_bytes(LeleBuf* b) { return b ? b->bytes : 0; }
 int lele_hip_buf_from_host(LeleBuf* b, const void* src, size_t bytes) {
     LELE_REQUIRE(b, "buf_from_host: buf is NULL");
@@ -285,11 +327,11 @@ int lele_hip_buf_to_host(LeleBuf* b, void* dst, size_t bytes) {
         LELE_HIP_CHECK(hipMemcpyAsync(c->mailbox, b->data, bytes, hipMemcpyDeviceToHost, c->stream));
         LELE_HIP_CHECK(hipStreamSynchronize(c->stream));
         memcpy(dst, c->mailbox, bytes);
-        return 0;
+        return c->check_deverr("buf_to_host");
     }
     if (bytes) LELE_HIP_CHECK(hipMemcpyAsync(dst, b->data, bytes, hipMemcpyDeviceToHost, c->stream));
     LELE_HIP_CHECK(hipStreamSynchronize(c->stream));
-    return 0;
+    return c->check_deverr("buf_to_host");
 }
 
 }  // extern "C"

@@ -473,13 +473,8 @@ template <int BM, int BN, int WM, int WN, int BK, int OCC = 1, class AL, class B
 inline void launch_tile(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int batch) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
     auto kern = gemm_f32_mfma_kernel<BM, BN, WM, WN, BK, AL, BL, EPI, OCC>;
-    if (lds > 64 * 1024) {  // above the default per-block limit: opt in once per instantiation
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            done = true;
-        }
-    }
+    if (lds > 64 * 1024)  // above the default per-block limit: opt in once per (instantiation, device)
+        (void)lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds);
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
     hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, st, al, bl, epi, M, N, K);
 }

@@ -128,12 +128,18 @@ __global__ void pad_kernel(const W* __restrict__ in, W* __restrict__ out, int64_
 // gather (manipulation.rs:589-641): out[o][j][k] = data[o][idx[j]][k]
 template <typename W, typename I>
 __global__ void gather_kernel(const W* __restrict__ data, const I* __restrict__ idx, W* __restrict__ out,
-                              int64_t outer, int64_t axis_dim, int64_t inner, int64_t nidx) {
+                              int64_t outer, int64_t axis_dim, int64_t inner, int64_t nidx, unsigned* __restrict__ deverr) {
     const int64_t total = outer * nidx * inner;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t k = i % inner, j = (i / inner) % nidx, o = i / (inner * nidx);
         int64_t v = (int64_t)idx[j];
         if (v < 0) v += axis_dim;
+        // the reference indexes a slice here and panics when out of range (manipulation.rs:626-633): clamp the read and raise
+        // the ctx's sticky error word (host-mapped; reported at the next sync / buf_to_host)
+        if (v < 0 || v >= axis_dim) {
+            *deverr = LELE_DEVERR_GATHER_INDEX;
+            v = v < 0 ? 0 : axis_dim - 1;
+        }
         out[i] = data[(o * axis_dim + v) * inner + k];
     }
 }
@@ -144,17 +150,39 @@ struct GeDesc {
     int64_t ishape[LELE_MAX_RANK], xstride[LELE_MAX_RANK], axis_dim;
 };
 __global__ void gather_elements_kernel(const float* __restrict__ x, const float* __restrict__ idx,
-                                       float* __restrict__ out, int64_t total, GeDesc d) {
+                                       float* __restrict__ out, int64_t total, GeDesc d, unsigned* __restrict__ deverr) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t rem = i, off = 0;
         int64_t iv = (int64_t)idx[i];
         if (iv < 0) iv += d.axis_dim;
+        if (iv < 0 || iv >= d.axis_dim) {  // conv2d.rs:1480-1490 indexes the input slice: a panic upstream
+            *deverr = LELE_DEVERR_GATHER_INDEX;
+            iv = iv < 0 ? 0 : d.axis_dim - 1;
+        }
         for (int k = d.rank - 1; k >= 0; --k) {
             const int64_t c = rem % d.ishape[k];
             rem /= d.ishape[k];
             off += (k == d.axis ? iv : c) * d.xstride[k];
         }
         out[i] = x[off];
+    }
+}
+
+// adaptive_avg_pool1d (pooling.rs:1-30): out[c][i] = sum(in[c][start..end]) / (end - start) with start = floor(i*L/O),
+// end = ceil((i+1)*L/O), both clamped to L; an empty window yields 0.  The window is summed in index order (as upstream).
+__global__ void adaptive_avg_pool1d_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t channels, int64_t in_len,
+                                           int64_t out_len) {
+    const int64_t total = channels * out_len;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t c = t / out_len, i = t - c * out_len;
+        int64_t start = (i * in_len) / out_len, end = ((i + 1) * in_len + out_len - 1) / out_len;
+        start = start < in_len ? start : in_len;
+        end = end < in_len ? end : in_len;
+        const int64_t len = end - start;
+        float sum = 0.0f;
+        const float* p = x + c * in_len;
+        for (int64_t k = start; k < end; ++k) sum = sum + p[k];
+        out[t] = len == 0 ? 0.0f : sum / (float)len;
     }
 }
 
@@ -635,6 +663,15 @@ int lele_hip_gather(LeleCtx* ctx, const LeleTensor* data, const LeleTensor* indi
     for (int i = 0; i < ax; ++i) outer *= data->shape[i];
     for (int i = ax + 1; i < rank; ++i) inner *= data->shape[i];
     const int64_t nidx = numel(indices), total = outer * nidx * inner;
+    if (indices->mem != LELE_MEM_DEVICE && data->shape[ax] > 0) {  // host-visible indices: the reference's panic, before any launch
+        for (int64_t j = 0; j < nidx; ++j) {
+            int64_t v = indices->dtype == LELE_F32 ? (int64_t)((const float*)indices->data)[j]
+                        : indices->dtype == LELE_I64 ? ((const int64_t*)indices->data)[j] : (int64_t)((const int32_t*)indices->data)[j];
+            if (v < 0) v += data->shape[ax];
+            LELE_REQUIRE(v >= 0 && v < data->shape[ax], "gather: index %lld (element %lld) is out of range for axis %d of size %lld",
+                         (long long)v, (long long)j, ax, (long long)data->shape[ax]);
+        }
+    }
     LELE_TRY(ctx->arena_reset());
     const void *dd = nullptr, *di = nullptr;
     LELE_TRY(ctx->dev_ptr(data, &dd));
@@ -644,7 +681,7 @@ int lele_hip_gather(LeleCtx* ctx, const LeleTensor* data, const LeleTensor* indi
         const dim3 g(grid_for(total)), b(256);
 #define LELE_GATHER(W, I)                                                                                          \
     hipLaunchKernelGGL((gather_kernel<W, I>), g, b, 0, ctx->stream, (const W*)dd, (const I*)di, (W*)out->data, outer, \
-                       data->shape[ax], inner, nidx)
+                       data->shape[ax], inner, nidx, ctx->deverr_dev)
         if (es == 8) {
             if (indices->dtype == LELE_F32) LELE_GATHER(uint64_t, float);
             else if (indices->dtype == LELE_I64) LELE_GATHER(uint64_t, int64_t);
@@ -679,6 +716,14 @@ int lele_hip_gather_elements(LeleCtx* ctx, const LeleTensor* x, const LeleTensor
         d.xstride[i] = xs[i];
     }
     const int64_t total = numel(indices);
+    if (indices->mem != LELE_MEM_DEVICE && d.axis_dim > 0) {
+        for (int64_t j = 0; j < total; ++j) {
+            int64_t v = (int64_t)((const float*)indices->data)[j];
+            if (v < 0) v += d.axis_dim;
+            LELE_REQUIRE(v >= 0 && v < d.axis_dim, "gather_elements: index %lld (element %lld) is out of range for axis %d of size %lld",
+                         (long long)v, (long long)j, ax, (long long)d.axis_dim);
+        }
+    }
     LELE_TRY(ctx->arena_reset());
     const void *dx = nullptr, *di = nullptr;
     LELE_TRY(ctx->dev_ptr(x, &dx));
@@ -686,10 +731,36 @@ int lele_hip_gather_elements(LeleCtx* ctx, const LeleTensor* x, const LeleTensor
     LELE_TRY(out->reserve((size_t)total * 4));
     if (total) {
         hipLaunchKernelGGL(gather_elements_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx,
-                           (const float*)di, (float*)out->data, total, d);
+                           (const float*)di, (float*)out->data, total, d, ctx->deverr_dev);
         LELE_HIP_CHECK(hipGetLastError());
     }
     return set_shape_v(out_shape, out_rank, std::vector<int64_t>(indices->shape, indices->shape + rank));
+}
+
+/* adaptive_avg_pool1d, pooling.rs:1-30.  Upstream takes flat slices + (channels, input_len, output_len); here x is
+ * [.., L] (all leading dims are channels) and the result [.., output_len]. */
+int lele_hip_adaptive_avg_pool1d(LeleCtx* ctx, const LeleTensor* x, int64_t output_len, LeleBuf* out, int64_t* out_shape,
+                                 int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && out, "adaptive_avg_pool1d: NULL argument");
+    LELE_REQUIRE(x->dtype == LELE_F32 && x->rank >= 1, "adaptive_avg_pool1d: f32 input of rank >= 1 required");
+    LELE_REQUIRE(output_len >= 0, "adaptive_avg_pool1d: negative output length");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t in_len = x->shape[x->rank - 1];
+    int64_t channels = 1;
+    for (int i = 0; i + 1 < x->rank; ++i) channels *= x->shape[i];
+    std::vector<int64_t> oshape(x->shape, x->shape + x->rank);
+    oshape.back() = output_len;
+    const int64_t total = channels * output_len;
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    LELE_TRY(out->reserve((size_t)total * 4));
+    if (total) {
+        hipLaunchKernelGGL(adaptive_avg_pool1d_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx,
+                           (float*)out->data, channels, in_len, output_len);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, oshape);
 }
 
 /* resize_nearest, conv2d.rs:1261-1382: output H, W already resolved from sizes / scales by the host mirror */

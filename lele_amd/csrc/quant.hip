@@ -21,6 +21,7 @@
 #include "gemm_small.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -523,6 +524,348 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
         }
 }
 
+
+// ------------------------------------------------------------------------------------------ one-pass quantised linear
+// fused_quantized_linear in ONE launch after the range is known (quantization.rs:77-169 -> avx/quantization.rs:225-417):
+// a workgroup owns 32 rows of the activation over ALL of K.  It derives the {scale, zp} of the (one or two) batch slices its
+// rows belong to from the producer's {min, max} pairs, reads its f32 rows from HBM ONCE, quantises them on the way into LDS
+// (rint(fma(x, 1/scale, zp)) body / round(x*inv + zp) tail, exactly as qrows_kernel) while accumulating the exact i32 row
+// sums, and then walks its share of the output columns with v_mfma_i32_32x32x32_i8: A fragments from LDS, W fragments
+// straight from L2 in a FRAGMENT-MAJOR layout (one contiguous 1 KiB block per 32 columns x 32 k: lane l's 16 bytes at
+// offset 16*l), so neither the i8 activation nor its row sums ever exist in HBM and qrows_kernel disappears.  The epilogue
+// is IgemmEpi's (zero-point algebra, (float)acc * (dyn_scale*w_scale[j]), + bias, ReLU, residual adds) and additionally
+// publishes {min, max} of every output row per column group, so that a quantised linear reading THIS result needs no range
+// pass either (ffn1 -> ffn2).  Bit-exact with the three-kernel chain (tests/test_quant.py runs both).
+constexpr int kOpBM = 32;
+
+// weights [K][N] (u8 values as f32) -> fragment-major i8: block (ct, ks) = columns [32ct, +32) x k [32ks, +32), lane l of the
+// block holds column 32ct + (l & 31), k = 32ks + 16(l >> 5) + [0, 16).  One thread per (column, 16-k chunk).
+__global__ void wpack_frag_kernel(const float* __restrict__ w, int k, int n, int ks, int nt, int8_t* __restrict__ wf) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = (int)(t % (nt * 32));          // column (fast: the reads of a wave are one coalesced row segment)
+    const int kc = (int)(t / (nt * 32));         // 16-k chunk
+    if (kc >= ks * 2) return;
+    int packed[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int kk = kc * 16 + e;
+        int v = 0;
+        if (kk < k && j < n) {
+            const float r = rintf(w[(int64_t)kk * n + j]);  // cvtps + saturating packs (transpose_b_from_f32_avx2)
+            const int u = r < 0.0f ? 0 : (r > 255.0f ? 255 : (int)r);
+            v = u - 128;
+        }
+        packed[e >> 2] |= (v & 0xff) << (8 * (e & 3));
+    }
+    const int64_t blk = (int64_t)(j >> 5) * ks + (kc >> 1);
+    const int lane = (j & 31) + 32 * (kc & 1);
+    v4i o = {packed[0], packed[1], packed[2], packed[3]};
+    *reinterpret_cast<v4i*>(wf + (blk * 64 + lane) * 16) = o;
+}
+__global__ void wcolsum_kernel(const float* __restrict__ w, int k, int n, int* __restrict__ col_sums) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    int sum = 0;
+    for (int kk = 0; kk < k; ++kk) {
+        const float r = rintf(w[(int64_t)kk * n + j]);
+        sum += (r < 0.0f ? 0 : (r > 255.0f ? 255 : (int)r)) - 128;
+    }
+    col_sums[j] = sum;
+}
+
+struct OnepassArgs {
+    const float* x;
+    int64_t rows;
+    int k, kp;  // kp = K rounded up to 32
+    int m;      // rows per batch slice
+    const float* partial;  // {min, max} pairs, nblk per slice, slice-major
+    int nblk;
+    const int8_t* wf;
+    int n, nt, ks;   // nt = 32-column tiles, ks = 32-k steps
+    int tpw;         // column tiles per workgroup (blockIdx.x-th group)
+    float* stat_out; // [slices][stat_per_slice][2] or NULL: {min, max} of the result per (slice, row block, column group)
+    int stat_per_slice;
+};
+
+template <bool KSPLIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 4 : 3))) void qlinear_onepass_kernel(OnepassArgs a, IgemmEpi epi) {
+    extern __shared__ __attribute__((aligned(16))) char op_lds[];  // A' tile: [32][kp + 16] bytes
+    __shared__ QParams s_prm[kOpBM];
+    __shared__ int s_ca[kOpBM], s_rterm[kOpBM];
+    __shared__ float s_ds[kOpBM];
+    __shared__ float s_mn[4], s_mx[4];
+    __shared__ float s_stat[4][4];
+    __shared__ int s_red[KSPLIT ? 4 * 16 * 64 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hv = lane >> 5, l31 = lane & 31;
+    const int pitch = a.kp + 16;
+    const int64_t m0 = (int64_t)blockIdx.y * kOpBM;
+    const int rows_here = (int)(a.rows - m0 < kOpBM ? a.rows - m0 : kOpBM);
+
+    // ---- phase 1a: this thread's first loads go out before anything else (8 lanes per row, 16 bytes each: 128-byte runs)
+    const int qrow = tid >> 3, sub = tid & 7;
+    const int64_t grow = m0 + qrow;
+    const bool live = grow < a.rows;
+    const float* xr = a.x + (live ? grow : a.rows - 1) * (int64_t)a.k;
+    const bool vec4 = (a.k & 3) == 0 && (((uintptr_t)a.x & 15) == 0);
+    const int niter = a.kp / 32;
+    constexpr int U = 8;
+    float4 pre[U];
+    auto fetch = [&](int it) -> float4 {
+        const int c = it * 32 + sub * 4;
+        if (vec4) {
+            return *reinterpret_cast<const float4*>(xr + (c + 3 < a.k ? c : a.k - 4));  // clamped: never past the row
+        }
+        float4 v;
+        v.x = xr[c < a.k ? c : a.k - 1];
+        v.y = xr[c + 1 < a.k ? c + 1 : a.k - 1];
+        v.z = xr[c + 2 < a.k ? c + 2 : a.k - 1];
+        v.w = xr[c + 3 < a.k ? c + 3 : a.k - 1];
+        return v;
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u) pre[u] = fetch(u < niter ? u : niter - 1);
+
+    // ---- phase 0: {scale, zp} of the slices this block touches (usually one or two), from the producer's pairs
+    const int64_t sl_lo = m0 / a.m;
+    const int nsl = (int)((m0 + rows_here - 1) / a.m - sl_lo) + 1;
+    for (int s = 0; s < nsl; ++s) {
+        const float2* pp = reinterpret_cast<const float2*>(a.partial) + (sl_lo + s) * (int64_t)a.nblk;
+        float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+        for (int i0 = 0; i0 < a.nblk; i0 += 1024) {
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = i0 + tid + 256 * u;
+                v[u] = pp[idx < a.nblk ? idx : a.nblk - 1];  // clamped: a repeated pair changes nothing
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mn = v[u].x < mn ? v[u].x : mn;
+                mx = v[u].y > mx ? v[u].y : mx;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float p = __shfl_xor(mn, off), q = __shfl_xor(mx, off);
+            mn = p < mn ? p : mn;
+            mx = q > mx ? q : mx;
+        }
+        if (lane == 0) {
+            s_mn[wave] = mn;
+            s_mx[wave] = mx;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) {
+                mn = s_mn[w] < mn ? s_mn[w] : mn;
+                mx = s_mx[w] > mx ? s_mx[w] : mx;
+            }
+            s_prm[s] = make_qparams(mn, mx);
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 1b: quantise the 32 rows into LDS, exact row sums on the way
+    {
+        const QParams q = s_prm[live ? (int)(grow / a.m - sl_lo) : 0];
+        const int simd_k = a.k & ~7;
+        int sum = 0;
+        char* dst = op_lds + qrow * pitch + sub * 4;
+        for (int it0 = 0; it0 < niter; it0 += U) {
+            float4 cur[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = pre[u];
+            if (it0 + U < niter) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) pre[u] = fetch(it0 + U + u < niter ? it0 + U + u : niter - 1);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int it = it0 + u;
+                if (it < niter) {
+                    const int c = it * 32 + sub * 4;
+                    float xv[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+                    int packed = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kk = c + e;
+                        int v = 0;
+                        if (live && kk < a.k) {
+                            v = (int)quant_one(xv[e], q, kk < simd_k) - 128;
+                            sum += v;
+                        }
+                        packed |= (v & 0xff) << (8 * e);
+                    }
+                    *reinterpret_cast<int*>(dst + it * 32) = packed;
+                }
+            }
+        }
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 4);
+        if (sub == 0) {
+            const int ca = 128 - q.zp_i, cb = 128 - epi.zp_b;
+            s_ca[qrow] = ca;
+            s_rterm[qrow] = cb * sum + a.k * ca * cb;
+            s_ds[qrow] = q.scale;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: columns.  This block owns tiles [t_lo, t_hi)
+    const int t_lo = blockIdx.x * a.tpw, t_hi = t_lo + a.tpw < a.nt ? t_lo + a.tpw : a.nt;
+    const char* arow = op_lds + l31 * pitch + 16 * hv;
+    const v4i zero4 = {0, 0, 0, 0};
+    // {min, max} of what this block stores, separately for the (at most two: m >= 32) slices its rows belong to: local rows
+    // below `bnd` are slice sl_lo, the others slice sl_lo + 1
+    const int bnd = (int)((sl_lo + 1) * a.m - m0);
+    float mnA = 3.40282347e+38f, mxA = -3.40282347e+38f, mnB = 3.40282347e+38f, mxB = -3.40282347e+38f;
+    // rows r0..r0+NR-1 (accumulator registers) of tile t: epilogue + statistics
+    auto finish = [&](int t, auto get_acc, int r0, auto nr_c) {
+        constexpr int NR = decltype(nr_c)::value;
+        const int col = t * 32 + l31;
+        const bool cin = col < a.n;
+        const IgemmEpi::ColCtx cc = epi.col_ctx(col);
+#pragma unroll
+        for (int g4 = 0; g4 < NR; g4 += 4) {
+            float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
+            if (epi.res1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = r0 + g4 + q;
+                    const int64_t row = m0 + (r & 3) + 8 * (r >> 2) + 4 * hv;
+                    const int64_t at = (row < a.rows ? row : a.rows - 1) * (int64_t)a.n + (cin ? col : a.n - 1);
+                    r1[q] = epi.res1[at];
+                    r2[q] = epi.res2 ? epi.res2[at] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + g4 + q;
+                const int lr = (r & 3) + 8 * (r >> 2) + 4 * hv;
+                const int64_t row = m0 + lr;
+                const IgemmEpi::RowCtx rc{s_ca[lr], s_rterm[lr], s_ds[lr], epi.out + (row < a.rows ? row : 0) * (int64_t)a.n};
+                const int acc = get_acc(g4 + q);
+                const float v = epi.res1 ? epi.value_res(rc, cc, acc, r1[q], r2[q]) : epi.value(rc, cc, acc);
+                if (row < a.rows && cin) {
+                    rc.orow[col] = v;
+                    if (lr < bnd) {
+                        mnA = v < mnA ? v : mnA;
+                        mxA = v > mxA ? v : mxA;
+                    } else {
+                        mnB = v < mnB ? v : mnB;
+                        mxB = v > mxB ? v : mxB;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: hoisting all 16 rows' loads costs 40 VGPRs and spills
+        }
+    };
+    if (!KSPLIT) {
+        // waves take column tiles two at a time (one A fragment feeds two independent accumulators)
+        for (int t = t_lo + 2 * wave; t < t_hi; t += 8) {
+            const bool two = t + 1 < t_hi;
+            const v4i* w0 = reinterpret_cast<const v4i*>(a.wf) + (int64_t)t * a.ks * 64 + lane;
+            const v4i* w1 = two ? w0 + (int64_t)a.ks * 64 : w0;
+            v16i acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[r] = 0, acc1[r] = 0;
+            for (int s = 0; s < a.ks; s += 4) {
+                v4i fa[4], f0[4], f1[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int su = s + u < a.ks ? s + u : a.ks - 1;
+                    f0[u] = w0[(int64_t)su * 64];
+                    f1[u] = w1[(int64_t)su * 64];
+                    const v4i av = *reinterpret_cast<const v4i*>(arow + su * 32);
+                    fa[u] = s + u < a.ks ? av : zero4;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u], f0[u], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u], f1[u], acc1, 0, 0, 0);
+                }
+            }
+            finish(t, [&](int i) { return acc0[i]; }, 0, std::integral_constant<int, 16>());
+            if (two) finish(t + 1, [&](int i) { return acc1[i]; }, 0, std::integral_constant<int, 16>());
+        }
+    } else {
+        // few tiles per block (single utterance): the four waves split K, partial tiles meet in LDS (exact: i32)
+        const int per = (a.ks + 3) / 4;
+        const int s0 = wave * per, s1 = s0 + per < a.ks ? s0 + per : a.ks;
+        for (int t = t_lo; t < t_hi; ++t) {
+            const v4i* w0 = reinterpret_cast<const v4i*>(a.wf) + (int64_t)t * a.ks * 64 + lane;
+            v16i acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0;
+            for (int s = s0; s < s1; s += 4) {
+                v4i fa[4], f0[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int su = s + u < s1 ? s + u : s1 - 1;
+                    f0[u] = w0[(int64_t)su * 64];
+                    const v4i av = *reinterpret_cast<const v4i*>(arow + su * 32);
+                    fa[u] = s + u < s1 ? av : zero4;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u], f0[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_red[(wave * 16 + r) * 64 + lane] = acc[r];
+            __syncthreads();
+            finish(t, [&](int i) {
+                const int r = 4 * wave + i;
+                return (s_red[(0 * 16 + r) * 64 + lane] + s_red[(1 * 16 + r) * 64 + lane]) +
+                       (s_red[(2 * 16 + r) * 64 + lane] + s_red[(3 * 16 + r) * 64 + lane]);
+            }, 4 * wave, std::integral_constant<int, 4>());
+            __syncthreads();
+        }
+    }
+    if (a.stat_out) {  // uniform.  Slot layout: [slice][block of the slice][column group], a.stat_per_slice pairs per slice
+        for (int off = 32; off > 0; off >>= 1) {
+            const float p0 = __shfl_xor(mnA, off), p1 = __shfl_xor(mxA, off), p2 = __shfl_xor(mnB, off), p3 = __shfl_xor(mxB, off);
+            mnA = p0 < mnA ? p0 : mnA;
+            mxA = p1 > mxA ? p1 : mxA;
+            mnB = p2 < mnB ? p2 : mnB;
+            mxB = p3 > mxB ? p3 : mxB;
+        }
+        if (lane == 0) {
+            s_stat[wave][0] = mnA;
+            s_stat[wave][1] = mxA;
+            s_stat[wave][2] = mnB;
+            s_stat[wave][3] = mxB;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w) {
+                mnA = s_stat[w][0] < mnA ? s_stat[w][0] : mnA;
+                mxA = s_stat[w][1] > mxA ? s_stat[w][1] : mxA;
+                mnB = s_stat[w][2] < mnB ? s_stat[w][2] : mnB;
+                mxB = s_stat[w][3] > mxB ? s_stat[w][3] : mxB;
+            }
+            const int64_t fbA = (sl_lo * a.m) / kOpBM;  // first block of slice sl_lo
+            float* oa = a.stat_out + ((sl_lo * a.stat_per_slice) + ((int64_t)blockIdx.y - fbA) * gridDim.x + blockIdx.x) * 2;
+            oa[0] = mnA;
+            oa[1] = mxA;
+            if (bnd < rows_here) {  // this block also holds the first rows of the next slice: it is that slice's block 0
+                float* ob = a.stat_out + (((sl_lo + 1) * a.stat_per_slice) + blockIdx.x) * 2;
+                ob[0] = mnB;
+                ob[1] = mxB;
+            }
+        }
+        // the block holding the LAST row of slice sl_lo fills the slice's unused slots with the neutral pair
+        if (blockIdx.x == 0 && bnd <= rows_here) {
+            const int64_t fbA = (sl_lo * a.m) / kOpBM;
+            const int used = (int)((int64_t)blockIdx.y - fbA + 1) * (int)gridDim.x;
+            float* base = a.stat_out + sl_lo * a.stat_per_slice * 2;
+            for (int i = used + tid; i < a.stat_per_slice; i += 256) {
+                base[2 * i] = 3.40282347e+38f;
+                base[2 * i + 1] = -3.40282347e+38f;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host helpers
 struct PackedW {
     int8_t* wt;
@@ -563,6 +906,63 @@ int get_packed_weights(LeleCtx* ctx, const LeleTensor* w, const float* dw, int64
     return 0;
 }
 
+
+// fragment-major packed weights for the one-pass kernel (cached like PackedW; tags 203 / 204)
+struct FragW {
+    int8_t* wf;
+    int* col_sums;
+};
+int get_frag_weights(LeleCtx* ctx, const LeleTensor* w, int k, int n, int ks, int nt, FragW* out) {
+    auto key_w = std::make_tuple((const void*)w->data, (size_t)numel(w) * 4, 203);
+    auto key_s = std::make_tuple((const void*)w->data, (size_t)numel(w) * 4, 204);
+    auto it = ctx->weights.find(key_w);
+    if (it != ctx->weights.end()) {
+        out->wf = (int8_t*)it->second;
+        out->col_sums = (int*)ctx->weights[key_s];
+        return 0;
+    }
+    LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
+    const void* dw = nullptr;
+    LELE_TRY(ctx->dev_ptr(w, &dw));  // the f32-encoded matrix (uploaded and cached under tag 0)
+    void *dwf = nullptr, *dcs = nullptr;
+    LELE_HIP_CHECK(hipMalloc(&dwf, (size_t)nt * ks * 1024));
+    LELE_HIP_CHECK(hipMalloc(&dcs, (size_t)n * 4));
+    const int64_t threads = (int64_t)nt * 32 * ks * 2;
+    hipLaunchKernelGGL(wpack_frag_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)dw, k, n, ks,
+                       nt, (int8_t*)dwf);
+    hipLaunchKernelGGL(wcolsum_kernel, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, (const float*)dw, k, n, (int*)dcs);
+    LELE_HIP_CHECK(hipGetLastError());
+    ctx->weights[key_w] = dwf;
+    ctx->weights[key_s] = dcs;
+    out->wf = (int8_t*)dwf;
+    out->col_sums = (int*)dcs;
+    return 0;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// stage stopwatch of the quantised linear (lele_hip_quant_set_profiling): stage = 0 start, 1 after the range pass, 2 after the
+// row quantisation, 3 after the GEMM
+int qprof_mark(LeleCtx* ctx, int stage) {
+    if (!ctx->qprof.on || ctx->capturing) return 0;
+    auto& p = ctx->qprof;
+    if (stage == 0) {
+        if (p.used + 4 > p.ev.size()) {
+            for (int i = 0; i < 4; ++i) {
+                hipEvent_t e;
+                LELE_HIP_CHECK(hipEventCreate(&e));
+                p.ev.push_back(e);
+            }
+        }
+        p.used += 4;
+    }
+    LELE_HIP_CHECK(hipEventRecord(p.ev[p.used - 4 + stage], ctx->stream));
+    return 0;
+}
+
 // fused != NULL: only the min/max partials are produced (at most 256 per slice); *fused / *fused_nblk receive them and the
 // caller's qrows_kernel<0> turns them into parameters -- one launch fewer on the latency-bound path.
 int launch_range(LeleCtx* ctx, const float* dx, int64_t slices, int64_t slice_len, QParams* prm, float* scale_out,
@@ -596,14 +996,7 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
     do {                                                                                                                  \
         constexpr size_t lds = (size_t)2 * ((BM_) + (BN_)) * ((BKB_) + 16);                                               \
         auto kern = igemm_kernel<BM_, BN_, WM_, WN_, BKB_, OCC_>;                                                          \
-        if (lds > 64 * 1024) {                                                                                            \
-            static bool done = false;                                                                                     \
-            if (!done) {                                                                                                  \
-                LELE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                   \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
-                done = true;                                                                                              \
-            }                                                                                                             \
-        }                                                                                                                 \
+        if (lds > 64 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));               \
         dim3 grid((n + (BN_)-1) / (BN_), (unsigned)((rows + (BM_)-1) / (BM_)));                                           \
         hipLaunchKernelGGL(kern, grid, dim3((WM_) * (WN_) * 64), lds, ctx->stream, aq, wt, rows, n, kp, b_stride,          \
                            m_per_batch, epi);                                                                             \
@@ -705,6 +1098,86 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
             wz = *(const float*)weight_zero->data;
         }
     }
+    // the producer's {min, max} pairs, if it left any next to this tensor (LayerNorm: one pair per row; a quantised linear:
+    // one pair per row and column group; a small-problem GEMM: one per workgroup, single slice only): slice s then owns `nblk`
+    // consecutive pairs and the separate range pass over the activation is skipped
+    const float* partial = nullptr;
+    int nblk = 0;
+    if (input->mem == LELE_MEM_DEVICE && m <= 2048) {
+        auto it = ctx->buf_of_data.find(input->data);
+        if (it != ctx->buf_of_data.end() && it->second->rowstat_valid) {
+            const LeleBuf* src = it->second;
+            if (src->rowstat_kind == 0 && src->rowstat_len == k && src->rowstat_rows == rows) {
+                partial = src->rowstat;  // one pair per row
+                nblk = (int)m;
+            } else if (src->rowstat_kind == 2 && src->rowstat_len == k && src->rowstat_m == m && src->rowstat_rows % batch == 0) {
+                partial = src->rowstat;  // a fixed number of pairs per slice of m rows (qlinear_onepass_kernel)
+                nblk = (int)(src->rowstat_rows / batch);
+            } else if (src->rowstat_kind == 1 && batch == 1 && src->rowstat_len == rows * k && src->rowstat_rows <= 4096) {
+                partial = src->rowstat;  // per-workgroup pairs of the GEMM that produced the tensor: one slice, all pairs
+                nblk = (int)src->rowstat_rows;
+            }
+        }
+    }
+    void* prm = nullptr;
+    LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm));
+    LELE_TRY(qprof_mark(ctx, 0));
+    if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
+    LELE_TRY(qprof_mark(ctx, 1));
+
+    // ---- one launch: quantise-on-load i8 GEMM (declared-immutable weights, a tile of 32 x K bytes must fit the LDS)
+    const int kp32 = (int)((k + 31) & ~int64_t(31));
+    const bool onepass = weight_int8->mem == LELE_MEM_WEIGHT && k >= 8 && (size_t)kOpBM * (kp32 + 16) <= 150 * 1024 &&
+                         rows < (int64_t(1) << 31) && env_int("LELE_HIP_QLINEAR_ONEPASS", 1) != 0;
+    if (onepass) {
+        const int ks = kp32 / 32, nt = (int)((n + 31) / 32);
+        FragW fw;
+        LELE_TRY(get_frag_weights(ctx, weight_int8, (int)k, (int)n, ks, nt, &fw));
+        const int64_t row_blocks = (rows + kOpBM - 1) / kOpBM;
+        // enough workgroups to fill the chip a few times over (they are small: 32 x K bytes of LDS), as few column groups as
+        // that allows (every group of a row block repeats the block's quantisation)
+        const int64_t target = env_int("LELE_HIP_ONEPASS_WGS", 3 * ctx->num_cus);
+        int nsplit = (int)std::min<int64_t>(nt, std::max<int64_t>(1, (target + row_blocks - 1) / row_blocks));
+        const int tpw = (nt + nsplit - 1) / nsplit;
+        nsplit = (nt + tpw - 1) / tpw;
+        IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, nullptr, fw.col_sums, nullptr, 0,
+                     (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
+                     (const float*)dr2};
+        OnepassArgs oa{(const float*)dx, rows, (int)k, kp32, (int)m, partial, nblk, fw.wf, (int)n, nt, ks, tpw, nullptr, 0};
+        // statistics for a quantised linear that reads this result next: one pair per (slice, row block, column group); needs
+        // m >= 32 (a block then touches at most two slices)
+        const int64_t per_slice = ((m - 1) / kOpBM + 2) * nsplit, nstat = batch * per_slice;
+        if (m >= kOpBM && per_slice <= 65536 && nstat <= (int64_t(1) << 22)) {
+            LELE_TRY(out->reserve_rowstat(nstat));
+            if ((size_t)nstat <= out->rowstat_cap) {
+                oa.stat_out = out->rowstat;
+                oa.stat_per_slice = (int)per_slice;
+            }
+        }
+        const size_t lds = (size_t)kOpBM * (kp32 + 16);
+        const bool ksplit = tpw < env_int("LELE_HIP_ONEPASS_KSPLIT_BELOW", 4);
+        const dim3 grid((unsigned)nsplit, (unsigned)row_blocks);
+        if (ksplit) {
+            if (lds > 48 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(&qlinear_onepass_kernel<true>), (int)lds));
+            hipLaunchKernelGGL(qlinear_onepass_kernel<true>, grid, dim3(256), lds, ctx->stream, oa, epi);
+        } else {
+            if (lds > 64 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(&qlinear_onepass_kernel<false>), (int)lds));
+            hipLaunchKernelGGL(qlinear_onepass_kernel<false>, grid, dim3(256), lds, ctx->stream, oa, epi);
+        }
+        LELE_HIP_CHECK(hipGetLastError());
+        LELE_TRY(qprof_mark(ctx, 2));
+        LELE_TRY(qprof_mark(ctx, 3));
+        if (oa.stat_out) {
+            out->rowstat_rows = nstat;
+            out->rowstat_len = n;
+            out->rowstat_m = m;
+            out->rowstat_kind = 2;
+            out->rowstat_valid = true;
+        }
+        return set_shape_v(out_shape, out_rank, shp);
+    }
+
+    // ---- three-kernel chain: rows -> i8 (+ row sums) in HBM, then the tiled i8 GEMM
     const int kp = (int)((k + 15) & ~int64_t(15));
     PackedW pw;
     {
@@ -717,34 +1190,16 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
             LELE_TRY(get_packed_weights(ctx, weight_int8, (const float*)dw, 1, (int)k, (int)n, kp, &pw, cacheable));
         }
     }
-    void *prm = nullptr, *aq = nullptr, *rs = nullptr;
-    LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm));
+    void *aq = nullptr, *rs = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)rows * kp, &aq));
     LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));
-    const float* partial = nullptr;
-    int nblk = 0;
-    // If the producer of this tensor (LayerNorm) left per-row {min, max} next to it, they are the range partials: slice s
-    // owns rows [s*m, (s+1)*m), i.e. m consecutive pairs -- the separate range pass over the activation is skipped.
-    if (input->mem == LELE_MEM_DEVICE && m <= 2048) {
-        auto it = ctx->buf_of_data.find(input->data);
-        if (it != ctx->buf_of_data.end() && it->second->rowstat_valid) {
-            const LeleBuf* src = it->second;
-            if (src->rowstat_kind == 0 && src->rowstat_rows == rows && src->rowstat_len == k) {
-                partial = src->rowstat;
-                nblk = (int)m;
-            } else if (src->rowstat_kind == 1 && batch == 1 && src->rowstat_len == rows * k && src->rowstat_rows <= 4096) {
-                partial = src->rowstat;  // per-workgroup pairs of the GEMM that produced the tensor: one slice, all pairs
-                nblk = (int)src->rowstat_rows;
-            }
-        }
-    }
-    if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
     if (rows <= 2048)
         hipLaunchKernelGGL((qrows_kernel<0, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
                            rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk);
     else
         hipLaunchKernelGGL((qrows_kernel<0, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
                            rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk);
+    LELE_TRY(qprof_mark(ctx, 2));
     IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, (const int*)rs, pw.col_sums, (const QParams*)prm, 0,
                  (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
                  (const float*)dr2};
@@ -756,6 +1211,7 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
         if ((size_t)nstat <= out->rowstat_cap) epi.blockstat = out->rowstat;
     }
     LELE_TRY(launch_igemm(ctx, (const int8_t*)aq, pw.wt, rows, (int)n, kp, 0, (int)m, epi));
+    LELE_TRY(qprof_mark(ctx, 3));
     if (epi.blockstat) {
         out->rowstat_rows = nstat;
         out->rowstat_len = rows * n;
@@ -798,6 +1254,98 @@ int lele_hip_fused_quantized_linear_residual(LeleCtx* ctx, const LeleTensor* inp
         LELE_TRY(lele_hip_binary(ctx, 0 /* add */, &t, res, out, sh, &r));
     }
     return set_shape_v(out_shape, out_rank, std::vector<int64_t>(sh, sh + r));
+}
+
+
+/* ---- per-stage stopwatch of fused_quantized_linear (bench.py's roofline block for the model path) ------------------- */
+int lele_hip_quant_set_profiling(LeleCtx* ctx, int on) {
+    LELE_REQUIRE(ctx, "quant_set_profiling: ctx is NULL");
+    ctx->qprof.on = on != 0;
+    ctx->qprof.used = 0;
+    return 0;
+}
+int lele_hip_quant_profile_read(LeleCtx* ctx, float* range_ms, float* quantise_ms, float* gemm_ms, int64_t* calls) {
+    LELE_REQUIRE(ctx && range_ms && quantise_ms && gemm_ms && calls, "quant_profile_read: NULL argument");
+    LELE_REQUIRE(!ctx->capturing, "quant_profile_read: not allowed while a graph is being captured");
+    LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    double t[3] = {0, 0, 0};
+    auto& p = ctx->qprof;
+    const size_t n = p.used / 4;
+    for (size_t i = 0; i < n; ++i)
+        for (int st = 0; st < 3; ++st) {
+            float ms = 0.0f;
+            LELE_HIP_CHECK(hipEventElapsedTime(&ms, p.ev[4 * i + st], p.ev[4 * i + st + 1]));
+            t[st] += ms;
+        }
+    *calls = (int64_t)n;
+    *range_ms = n ? (float)(t[0] / n) : 0.0f;
+    *quantise_ms = n ? (float)(t[1] / n) : 0.0f;
+    *gemm_ms = n ? (float)(t[2] / n) : 0.0f;
+    p.used = 0;
+    return 0;
+}
+
+/* ---- prepared weights: prepare_weights (quantization.rs:221), mat_mul_integer_prepared (699), fused_dq_gemm_prepared_x86
+ *      (454), mat_mul_integer_u8_weights (173).  The handle owns the device copy of the RAW u8 matrix carried as f32 (the
+ *      encoding every other entry point takes) and marks it immutable, so the packed forms are built once and cached. ---- */
+struct LelePrepared {
+    LeleCtx* ctx;
+    std::vector<float> host;  // u8 values as f32 [k, n]: the LELE_MEM_WEIGHT identity of this matrix
+    int64_t k, n;
+    int64_t shape[2];
+};
+int lele_hip_prepare_weights(LeleCtx* ctx, const uint8_t* b_u8, int64_t k, int64_t n, LelePrepared** out) {
+    LELE_REQUIRE(ctx && b_u8 && out, "prepare_weights: NULL argument");
+    LELE_REQUIRE(k > 0 && n > 0, "prepare_weights: empty matrix (k=%lld, n=%lld)", (long long)k, (long long)n);
+    LelePrepared* p = new LelePrepared();
+    p->ctx = ctx;
+    p->k = k;
+    p->n = n;
+    p->shape[0] = k;
+    p->shape[1] = n;
+    p->host.resize((size_t)k * n);
+    for (int64_t i = 0; i < k * n; ++i) p->host[i] = (float)b_u8[i];
+    *out = p;
+    return 0;
+}
+int lele_hip_prepared_destroy(LelePrepared* p) {
+    if (!p) return 0;
+    // the cached device copies stay with the ctx (freed at ctx_destroy); drop the keys so a recycled host address cannot alias
+    LeleCtx* c = p->ctx;
+    (void)hipStreamSynchronize(c->stream);
+    for (int tag : {0, 201, 202, 203, 204}) {
+        auto it = c->weights.find(std::make_tuple((const void*)p->host.data(), p->host.size() * 4, tag));
+        if (it != c->weights.end()) {
+            (void)hipFree(it->second);
+            ++c->generation;
+            c->weights.erase(it);
+        }
+    }
+    delete p;
+    return 0;
+}
+static LeleTensor prepared_tensor(const LelePrepared* p) {
+    return LeleTensor{p->host.data(), p->shape, 2, LELE_F32, LELE_MEM_WEIGHT};
+}
+int lele_hip_mat_mul_integer_prepared(LeleCtx* ctx, const LeleTensor* a, const LelePrepared* pw, int has_a_zero_point,
+                                      float a_zero_point, int has_b_zero_point, int32_t b_zero_point, const LeleTensor* scale,
+                                      const LeleTensor* bias, int apply_relu, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && a && pw && out, "mat_mul_integer_prepared: NULL argument");
+    const LeleTensor b = prepared_tensor(pw);
+    const float za = has_a_zero_point ? a_zero_point : 0.0f, zb = has_b_zero_point ? (float)(b_zero_point & 0xff) : 0.0f;
+    const int64_t one = 1;
+    const LeleTensor tza{&za, &one, 1, LELE_F32, LELE_MEM_HOST}, tzb{&zb, &one, 1, LELE_F32, LELE_MEM_HOST};
+    return lele_hip_mat_mul_integer_with_scale_bias(ctx, a, &b, &tza, &tzb, scale, bias, apply_relu, out, out_shape, out_rank);
+}
+int lele_hip_fused_dq_gemm_prepared(LeleCtx* ctx, const LeleTensor* input, const LelePrepared* pw, int has_b_zero_point,
+                                    int32_t b_zero_point, const LeleTensor* weight_scale, const LeleTensor* bias, int apply_relu,
+                                    LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && input && pw && weight_scale && out, "fused_dq_gemm_prepared: NULL argument");
+    const LeleTensor b = prepared_tensor(pw);
+    const float zb = has_b_zero_point ? (float)(b_zero_point & 0xff) : 0.0f;
+    const int64_t one = 1;
+    const LeleTensor tzb{&zb, &one, 1, LELE_F32, LELE_MEM_HOST};
+    return lele_hip_fused_quantized_linear(ctx, input, &b, weight_scale, &tzb, bias, apply_relu, out, out_shape, out_rank);
 }
 
 int lele_hip_dynamic_quantize_linear(LeleCtx* ctx, const LeleTensor* x, LeleBuf* out_y, LeleBuf* out_scale,

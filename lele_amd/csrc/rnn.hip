@@ -196,12 +196,7 @@ int run_rnn(LeleCtx* ctx, const char* name, const LeleTensor* x, const LeleTenso
     if (!have_rt)
         hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((H + 31) / 32), (unsigned)((G + 31) / 32)), dim3(32, 8), 0,
                            ctx->stream, (const float*)dr, (float*)rt, (int)G, (int)H);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[MODE]) {
-        LELE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&rnn_kernel<MODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[MODE] = true;
-    }
+    LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(&rnn_kernel<MODE>), 160 * 1024));
     hipLaunchKernelGGL(rnn_kernel<MODE>, dim3(1), dim3(kRnnThreads), lds_bytes, ctx->stream, (const float*)wx,
                        (const float*)rt, (const float*)db, (const float*)dh0, (const float*)dc0, (float*)y->data,
                        (float*)hn->data, MODE == 0 ? (float*)cn->data : nullptr, (int)T, (int)H, S);

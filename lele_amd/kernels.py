@@ -84,6 +84,74 @@ def fused_quantized_linear(input, weight_int8, weight_scale, weight_zero, bias, 
     return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
 
 
+class PreparedWeights:
+    """PreparedWeights (quantization.rs:198-215): a u8 weight matrix packed once for the i8 matrix cores"""
+
+    def __init__(self, ctx, h, k, n):
+        self.ctx, self._h, self.k, self.n = ctx, h, k, n
+
+    def close(self):
+        if self._h:
+            _lib.lib().lele_hip_prepared_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prepare_weights(b_data, k, n, ctx=None):  # quantization.rs:221: raw u8 [K, N]
+    ctx = _ctx(ctx)
+    b = np.ascontiguousarray(np.asarray(b_data, np.uint8).reshape(-1))
+    if b.size != k * n:
+        raise _lib.LeleError("prepare_weights: %d bytes given for k=%d, n=%d" % (b.size, k, n))
+    h = C.c_void_p()
+    _lib.check(_lib.lib().lele_hip_prepare_weights(ctx._h, b.ctypes.data_as(C.c_void_p), C.c_int64(k), C.c_int64(n), C.byref(h)))
+    return PreparedWeights(ctx, h, k, n)
+
+
+def mat_mul_integer_prepared(a, pw, a_zero_point=None, b_zero_point=None, scale=None, bias=None, apply_relu=False, out=None,
+                             ctx=None):  # quantization.rs:699; zero points are host scalars (None = Option::None)
+    ctx = _ctx(ctx)
+    keep = []
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_mat_mul_integer_prepared(
+        ctx._h, _t(a, keep), pw._h, C.c_int(a_zero_point is not None), C.c_float(a_zero_point or 0.0),
+        C.c_int(b_zero_point is not None), C.c_int32(int(b_zero_point or 0)), _t(scale, keep), _t(bias, keep),
+        C.c_int(int(apply_relu)), out._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
+
+
+_U8_PREPARED = {}  # (ctx id, data address, bytes) -> PreparedWeights: the shim-side handle cache of mat_mul_integer_u8_weights
+
+
+def mat_mul_integer_u8_weights(a, b_u8_data, b_shape, a_zero_point=None, b_zero_point=None, scale=None, bias=None,
+                               apply_relu=False, out=None, ctx=None):  # quantization.rs:173
+    ctx = _ctx(ctx)
+    b = np.ascontiguousarray(np.asarray(b_u8_data, np.uint8))
+    key = (id(ctx), b.ctypes.data, b.size)
+    pw = _U8_PREPARED.get(key)
+    if pw is None or pw._h is None:
+        pw = _U8_PREPARED[key] = prepare_weights(b, int(b_shape[-2]), int(b_shape[-1]), ctx=ctx)
+        pw._keep = b
+    return mat_mul_integer_prepared(a, pw, a_zero_point, b_zero_point, scale, bias, apply_relu, out, ctx)
+
+
+def fused_dq_gemm_prepared(input, pw, b_zero_point, weight_scale, bias=None, apply_relu=False, out=None, ctx=None):
+    """fused_dq_gemm_prepared_x86, quantization.rs:454"""
+    ctx = _ctx(ctx)
+    keep = []
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_fused_dq_gemm_prepared(
+        ctx._h, _t(input, keep), pw._h, C.c_int(b_zero_point is not None), C.c_int32(int(b_zero_point or 0)),
+        _t(weight_scale, keep), _t(bias, keep), C.c_int(int(apply_relu)), out._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
+
+
 def dynamic_quantize_linear(x, outs=None, ctx=None):  # quantization.rs:1628 -> (y, scale, zero_point); outs = its 3 buffers
     ctx = _ctx(ctx)
     keep = []
@@ -404,6 +472,12 @@ def resize_nearest(input, scales=None, sizes=None, coordinate_transform_mode="as
         raise _lib.LeleError("Resize: either scales or sizes must be provided")
     return _op(ctx, _lib.lib().lele_hip_resize_nearest, [input],
                [C.c_int64(oh), C.c_int64(ow), C.c_int(int(coordinate_transform_mode == "asymmetric"))], out)
+
+
+def adaptive_avg_pool1d(input, output_len, out=None, ctx=None):  # pooling.rs:1
+    """upstream signature is (input: &[f32], output: &mut [f32], channels, input_len, output_len) on flat slices; here the
+    input is [.., L] and the result [.., output_len]"""
+    return _op(ctx, _lib.lib().lele_hip_adaptive_avg_pool1d, [input], [C.c_int64(int(output_len))], out)
 
 
 def max_pool2d(input, kernel_shape, strides=(), pads=(), dilations=(), ceil_mode=False, out=None, ctx=None):

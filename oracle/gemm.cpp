@@ -30,6 +30,10 @@ static inline float dot(const float* a, int64_t sa, const float* b, int64_t sb, 
     return (float)((double)init + (double)alpha * acc);
 }
 
+extern "C" void orc_fast_sgemm_kord(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t m, int64_t k,
+                                    int64_t n, float* c, int64_t ldc);  // fast.cpp: the same k-ordered FMA chains, vectorised
+extern "C" int orc_plain_loops;
+
 extern "C" void orc_matmul(const float* a, const float* b, int64_t batch_a, int64_t batch_b, int64_t m, int64_t k,
                            int64_t n, float* out, int acc32) {
     int64_t fb = batch_a > batch_b ? batch_a : batch_b;  // gemm.rs:131
@@ -37,6 +41,11 @@ extern "C" void orc_matmul(const float* a, const float* b, int64_t batch_a, int6
         const float* A = a + (batch_a == 1 ? 0 : bi * m * k);  // gemm.rs:156-157
         const float* B = b + (batch_b == 1 ? 0 : bi * k * n);
         float* O = out + bi * m * n;
+        if (acc32 && !orc_plain_loops) {  // init 0 + 1.0f * chain == chain exactly (chain + 0.0f keeps every value but -0 -> +0)
+            orc_fast_sgemm_kord(A, k, B, n, m, k, n, O, n);
+            for (int64_t i = 0; i < m * n; ++i) O[i] = 0.0f + 1.0f * O[i];
+            continue;
+        }
         for (int64_t i = 0; i < m; ++i)
             for (int64_t j = 0; j < n; ++j) O[i * n + j] = dot(A + i * k, 1, B + j, n, k, 0.0f, 1.0f, acc32);
     }

@@ -283,3 +283,20 @@ def fused_scale_bias(data, scale, bias, silu=False):
     x = (np.asarray(data, np.float32) * np.float32(scale)).astype(np.float32) + np.asarray(bias, np.float32).reshape(1, -1, 1, 1)
     x = x.astype(np.float32)
     return (x / (np.float32(1.0) + np.exp(-x).astype(np.float32))).astype(np.float32) if silu else x
+
+
+def adaptive_avg_pool1d(x, output_len):  # pooling.rs:1-30 (sequential f32 sum over the window, then / len)
+    x = np.asarray(x, np.float32)
+    L = x.shape[-1]
+    flat = x.reshape(-1, L)
+    out = np.zeros((flat.shape[0], output_len), np.float32)
+    for i in range(output_len):
+        start = min((i * L) // output_len, L)
+        end = min(-(-((i + 1) * L) // output_len), L)
+        if end - start == 0:
+            continue
+        acc = np.zeros(flat.shape[0], np.float32)
+        for k in range(start, end):
+            acc = (acc + flat[:, k]).astype(np.float32)
+        out[:, i] = acc / np.float32(end - start)
+    return out.reshape(x.shape[:-1] + (output_len,))

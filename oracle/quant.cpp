@@ -63,14 +63,31 @@ inline int32_t f32_to_u8(float v) {  // cvtps_epi32 (nearest even) + packs/packu
     return (int32_t)r;
 }
 
+extern "C" void orc_fast_int_gemm(const int32_t* a, const int32_t* b, int64_t m, int64_t k, int64_t n, int32_t zp_a,
+                                  int32_t zp_b, int32_t* acc_out);  // fast.cpp: the reference's vpmaddwd scheme, same integers
+extern "C" {
+int orc_plain_loops = 0;
+}  // tests set this to 1 to run the plain triple loop below instead (cross-check)
+
 // out[i][j] = epilogue( sum_k (a[i][k]-zp_a)*(b[k][j]-zp_b) )
 void int_gemm_epilogue(const int32_t* a, const int32_t* b, int64_t m, int64_t k, int64_t n, int32_t zp_a, int32_t zp_b,
                        const float* scale, int64_t scale_len, const float* bias, int relu, float* out) {
+    std::vector<int32_t> accs;
+    if (!orc_plain_loops && m * n > 0) {
+        accs.resize(m * n);
+        orc_fast_int_gemm(a, b, m, k, n, zp_a, zp_b, accs.data());
+    }
     for (int64_t i = 0; i < m; ++i)
         for (int64_t j = 0; j < n; ++j) {
-            int64_t acc = 0;
-            for (int64_t kk = 0; kk < k; ++kk) acc += (int64_t)(a[i * k + kk] - zp_a) * (int64_t)(b[kk * n + j] - zp_b);
-            float vf = (float)(int32_t)acc;  // _mm256_cvtepi32_ps
+            int32_t total;
+            if (accs.empty()) {
+                int64_t acc = 0;
+                for (int64_t kk = 0; kk < k; ++kk) acc += (int64_t)(a[i * k + kk] - zp_a) * (int64_t)(b[kk * n + j] - zp_b);
+                total = (int32_t)acc;
+            } else {
+                total = accs[i * n + j];
+            }
+            float vf = (float)total;  // _mm256_cvtepi32_ps
             if (scale) vf = vf * (scale_len == 1 ? scale[0] : scale[j]);
             if (bias) vf = vf + bias[j];
             if (relu && !(vf > 0.0f)) vf = 0.0f;  // _mm256_max_ps(vf, 0)

@@ -150,3 +150,40 @@ def test_device_topk_long_rows_with_ties(ctx):
             v, i = Kk.topk(x, k, -1, largest, True, ctx=ctx)
             rv, ri = npref.topk(x, k, largest)
             assert np.array_equal(v.numpy(), rv) and np.array_equal(i.numpy(), ri.astype(np.float32))
+
+
+def test_adaptive_avg_pool1d_oracle():
+    # pooling.rs:1-30: windows [floor(i*L/O), ceil((i+1)*L/O)); equal split, overlapping windows, up-sampling, O = 0
+    x = np.arange(12, dtype=np.float32).reshape(2, 6)
+    assert np.array_equal(npref.adaptive_avg_pool1d(x, 3), [[0.5, 2.5, 4.5], [6.5, 8.5, 10.5]])
+    assert np.array_equal(npref.adaptive_avg_pool1d(x, 6), x)
+    assert np.array_equal(npref.adaptive_avg_pool1d(x[:, :5], 2), [[1.0, 3.0], [7.0, 9.0]])     # [0,3) and [2,5)
+    assert np.array_equal(npref.adaptive_avg_pool1d(x[:, :2], 4), [[0, 0, 1, 1], [6, 6, 7, 7]])  # longer than the input
+    assert npref.adaptive_avg_pool1d(x, 0).shape == (2, 0)
+
+
+@pytest.mark.gpu
+def test_device_adaptive_avg_pool1d_and_gather_bounds(ctx):
+    from lele_amd import kernels as Kk
+    from lele_amd._lib import LeleError
+    rng = np.random.default_rng(8)
+    for shape, o in (((2, 6), 3), ((3, 5, 171), 7), ((4, 1000), 999), ((2, 3), 8), ((1, 64, 93), 1), ((5, 17), 17)):
+        x = rng.standard_normal(shape).astype(np.float32)
+        got = Kk.adaptive_avg_pool1d(x, o, ctx=ctx)
+        assert got.shape == shape[:-1] + (o,) and np.array_equal(got.numpy(), npref.adaptive_avg_pool1d(x, o)), (shape, o)
+    # gather / gather_elements: an out-of-range index is the reference's slice-index panic (manipulation.rs:626-633) --
+    # caught on the host for host-visible indices, reported at the next sync for device-resident ones (read clamped)
+    emb = rng.standard_normal((16, 8)).astype(np.float32)
+    with pytest.raises(LeleError, match="out of range"):
+        Kk.gather(emb, np.array([3, 16], np.int64), 0, ctx=ctx)
+    with pytest.raises(LeleError, match="out of range"):
+        Kk.gather_elements(emb, np.full((16, 8), -17.0, np.float32), 0, ctx=ctx)
+    bad = ctx.buf().upload(np.array([1, 99, -40], np.int64))
+    got = Kk.gather(emb, bad, 0, ctx=ctx)
+    with pytest.raises(LeleError, match="gather index out of range"):
+        ctx.sync()
+    ctx.sync()  # the flag is sticky until reported, then cleared
+    assert np.array_equal(got.numpy()[0], emb[1])  # in-range rows are right, the others were clamped into the table
+    ok = ctx.buf().upload(np.array([1, 15, -16], np.int64))
+    assert np.array_equal(Kk.gather(emb, ok, 0, ctx=ctx).numpy(), emb[[1, 15, 0]])
+    ctx.sync()

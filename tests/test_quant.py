@@ -227,3 +227,110 @@ def test_gemm_block_statistics_feed_the_next_dynamic_quantisation(ctx):
     x = rng.standard_normal((3, 40, 512)).astype(np.float32)
     h = K.fused_quantized_linear(x, *w1, True, ctx=ctx)
     assert np.array_equal(K.fused_quantized_linear(h, *w2, False, ctx=ctx).numpy(), K.fused_quantized_linear(h.numpy(), *w2, False, ctx=ctx).numpy())
+
+
+def _qw(rng, k, n):
+    from lele_amd._lib import Weight
+    return (Weight(np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32)),
+            Weight((np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32)), Weight(np.array([128.0], np.float32)),
+            Weight((rng.standard_normal(n) * 0.02).astype(np.float32)))
+
+
+class _env:
+    """set environment variables for the duration of a block (the library reads its tuning switches per call)"""
+
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 93, 560, 1536), (1, 504, 512, 512), (1, 504, 512, 2048), (1, 504, 2048, 512), (32, 171, 512, 2048),
+                                   (32, 171, 2048, 512), (4, 171, 560, 1536), (3, 17, 64, 40), (2, 40, 37, 19), (1, 1, 8, 1), (1, 33, 100, 130),
+                                   (5, 32, 96, 64), (2, 64, 128, 33), (1, 504, 512, 25055)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_device_onepass_quantized_linear_bit_exact(ctx, orc, shape, relu):
+    """declared-immutable weights take qlinear_onepass_kernel (quantise-on-load i8 GEMM): bit-exact against the oracle, and
+    against the three-kernel chain, in both of its modes (K split over the waves / column tiles per wave) and for several
+    column-group counts"""
+    from lele_amd import kernels as Kk
+    b, m, k, n = shape
+    if relu and n > 4096:
+        pytest.skip("the vocabulary-sized case runs once")
+    rng = np.random.default_rng(b * 1000 + m + k + n)
+    x = (rng.standard_normal((b, m, k)) * rng.uniform(0.5, 3.0, (b, 1, 1))).astype(np.float32)  # a range per slice
+    w = _qw(rng, k, n)
+    ref = orc.fused_quantized_linear(x, w[0].arr, w[1].arr, [128.0], w[3].arr, relu)
+    xd = ctx.buf().upload(x)
+    got = Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx)
+    assert got.shape == ref.shape and np.array_equal(got.numpy(), ref)
+    with _env(LELE_HIP_QLINEAR_ONEPASS=0):
+        assert np.array_equal(Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx).numpy(), ref)
+    for wgs, below in ((1, 0), (64, 0), (100000, 1000), (100000, 0), (700, 4)):
+        with _env(LELE_HIP_ONEPASS_WGS=wgs, LELE_HIP_ONEPASS_KSPLIT_BELOW=below):
+            assert np.array_equal(Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx).numpy(), ref), (wgs, below)
+
+
+@pytest.mark.gpu
+def test_onepass_statistics_feed_the_next_quantised_linear(ctx, orc):
+    """qlinear_onepass_kernel leaves {min, max} per (slice, row block, column group) next to its result; the quantised linear that
+    reads the result next (ffn1 -> ffn2) derives its per-slice range from them instead of scanning the tensor.  Same bits as the
+    oracle on the same input, for slices that straddle row blocks, every grouping, and after the buffer was rewritten."""
+    from lele_amd import kernels as Kk
+    rng = np.random.default_rng(123)
+    for b, m, k, h, n in ((32, 171, 512, 2048, 512), (1, 504, 512, 2048, 512), (3, 40, 64, 96, 40), (2, 32, 64, 64, 64), (5, 100, 128, 70, 33),
+                          (4, 31, 64, 64, 32)):
+        x = (rng.standard_normal((b, m, k)) * rng.uniform(0.5, 3.0, (b, 1, 1))).astype(np.float32)
+        w1, w2 = _qw(rng, k, h), _qw(rng, h, n)
+        hid_ref = orc.fused_quantized_linear(x, w1[0].arr, w1[1].arr, [128.0], w1[3].arr, True)
+        out_ref = orc.fused_quantized_linear(hid_ref, w2[0].arr, w2[1].arr, [128.0], w2[3].arr, False)
+        for wgs in (768, 1, 100000, 300):
+            with _env(LELE_HIP_ONEPASS_WGS=wgs):
+                hbuf = ctx.buf()
+                hid = Kk.fused_quantized_linear(ctx.buf().upload(x), *w1, True, out=hbuf, ctx=ctx)
+                out = Kk.fused_quantized_linear(hid, *w2, False, ctx=ctx)
+                assert np.array_equal(hid.numpy(), hid_ref), (b, m, wgs)
+                assert np.array_equal(out.numpy(), out_ref), (b, m, wgs)
+                # rewrite the buffer with different data of the same shape: the statistics must not survive
+                y = Kk.mul(hid, np.array([0.5], np.float32), out=hbuf, ctx=ctx)
+                assert np.array_equal(Kk.fused_quantized_linear(y, *w2, False, ctx=ctx).numpy(),
+                                      orc.fused_quantized_linear(hid_ref * np.float32(0.5), w2[0].arr, w2[1].arr, [128.0], w2[3].arr, False)), (b, m, wgs)
+        # the three-kernel chain consumes the same statistics
+        with _env(LELE_HIP_QLINEAR_ONEPASS=0):
+            pass
+        hid = Kk.fused_quantized_linear(ctx.buf().upload(x), *w1, True, ctx=ctx)
+        with _env(LELE_HIP_QLINEAR_ONEPASS=0):
+            assert np.array_equal(Kk.fused_quantized_linear(hid, *w2, False, ctx=ctx).numpy(), out_ref), (b, m)
+
+
+@pytest.mark.gpu
+def test_prepared_weight_entry_points(ctx, orc):
+    """prepare_weights / mat_mul_integer_prepared / fused_dq_gemm_prepared / mat_mul_integer_u8_weights
+    (quantization.rs:173, 221, 454, 699) against the oracle's mat_mul_integer / fused_quantized_linear"""
+    from lele_amd import kernels as Kk
+    rng = np.random.default_rng(31)
+    for b, m, k, n in ((1, 93, 512, 512), (2, 9, 37, 19), (3, 171, 512, 96)):
+        wu8 = rng.integers(0, 256, (k, n), dtype=np.uint8)
+        a = rng.integers(0, 256, (b, m, k)).astype(np.float32)
+        ws = (np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32)
+        bias = (rng.standard_normal(n) * 0.02).astype(np.float32)
+        pw = Kk.prepare_weights(wu8, k, n, ctx=ctx)
+        want = orc.mat_mul_integer(a, wu8.astype(np.float32), [3.0], [131.0], ws, bias, relu=True)
+        assert np.array_equal(Kk.mat_mul_integer_prepared(a, pw, 3.0, 131, ws, bias, True, ctx=ctx).numpy(), want)
+        assert np.array_equal(Kk.mat_mul_integer_u8_weights(a, wu8, [k, n], 3.0, 131, ws, bias, True, ctx=ctx).numpy(), want)
+        assert np.array_equal(Kk.mat_mul_integer_prepared(a, pw, None, None, None, None, False, ctx=ctx).numpy(),
+                              orc.mat_mul_integer(a, wu8.astype(np.float32)))
+        x = (rng.standard_normal((b, m, k)) * 2).astype(np.float32)
+        assert np.array_equal(Kk.fused_dq_gemm_prepared(x, pw, 128, ws, bias, False, ctx=ctx).numpy(),
+                              orc.fused_quantized_linear(x, wu8.astype(np.float32), ws, [128.0], bias, False))
+        pw.close()
