@@ -1,20 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- STFT+mel front-end throughput on MI355X (BASELINE.json configs[1], batched).
+"""bench.py -- BASELINE.json's metric on MI355X: "SenseVoiceSmall steady-state RTF @16kHz, 1/2/4/8 MI355X; STFT+mel GB/s".
 
-A "step" = one pass of the hot path (SenseVoiceFrontend: PCM -> log-mel -> LFR) over one batch of
-`--batch` synthetic 30 s / 16 kHz utterances already resident in HBM.  One process per GPU; each rank owns its
-own batch (utterances are independent: weak scaling, no data-path collective).
+    python bench.py [--gpus N] [--steps K] [--warmup W]
 
-Prints ONE JSON line (rank 0):
-  value     = algorithmic GB/s of the whole job = ranks * batch * (4*S + 4*T*560) bytes * steps / wall time
-  roofline  = the dominant kernel (fe_main_kernel) against the 8 TB/s HBM peak, timed with HIP events on the
-              stream it is launched on (lele_hip_frontend_set_profiling)
-  cpu_baseline = the CPU oracle (C++ restatement of lele's x86 AVX2 path, 1 thread = lele's execution model)
-              timed on this host on a bounded sample of the same workload.
+One process per GPU.  With --gpus N > 1 and no WORLD_SIZE in the environment the script SPAWNS its N ranks itself (RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set per child); under `python -m torch.distributed.run` it
+takes the launcher's environment.  It refuses to run when the world size differs from --gpus.  Rank 0 prints ONE JSON line.
+
+Two legs per run, both on synthetic 16 kHz audio that is resident in HBM before anything is timed:
+
+ 1. STFT+mel (BASELINE configs[1], the line's `metric` / `value`): a "step" = one pass of SenseVoiceFrontend (PCM -> log-mel ->
+    LFR) over `--batch` 30 s utterances per GPU.  EXACTLY --steps steps are timed between barrier + device sync fences, MAX
+    over ranks; value = algorithmic GB/s of the whole job.  `roofline` prices the dominant kernel (fe_main_kernel), timed
+    with HIP events on the stream it runs on.
+ 2. SenseVoice-shaped recogniser (BASELINE's headline: steady-state RTF; configs[2] and [3]) -- `sensevoice` object:
+      * every N: one shard of configs[3] per GPU (32 x 10 s utterances): front-end -> CMVN -> 70-layer encoder (compiled
+        plan replayed as one hipGraph) -> greedy decode on the device -> ONE RCCL all-gather of the token ids through the
+        C ABI (lele_hip_comm_*).  Mean of `--sv-steps` steady-state steps, fences as above, MAX over ranks:
+        `rtf_c4` = wall / audio seconds of the WHOLE job, `audio_s_per_s` its inverse (higher is better; scales with N).
+      * N = 1 additionally: configs[2], one 30 s utterance, as lele's harness measures it (examples/sensevoice/src/main.rs:
+        198-237: mean of 10 steady-state forwards / audio seconds): `rtf_model` (encoder graph only) and `rtf_e2e`
+        (front-end + CMVN + encoder + decode + ids on the host).
+    The ONNX file of SenseVoiceSmall is not in the reference tree: the topology is the ASSUMED one of SURVEY.md 8a and the
+    weights are synthetic (8d) -- labelled as such in the line.  The model's dominant kernel (the quantised linear) gets its
+    own roofline fields, and the oracle runs the same layer stack on one host core as the CPU baseline.
+
+`cpu_baseline` (rank 0, N = 1 only): the CPU oracle -- a C++ restatement of lele's x86 AVX2 path, one thread = lele's
+execution model -- on a bounded sample of each leg.  A reported baseline, not the target.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,10 +40,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 SAMPLE_RATE = 16000
 SECONDS = 30
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+I8_PEAK_TOPS = 3944.0   # MI355X_MICROARCH.md: i8 MFMA >= 3944 TOPS measured (16x16x64)
 
 
 def synth_batch(batch, n, seed0):
@@ -39,13 +59,26 @@ def synth_batch(batch, n, seed0):
     return out
 
 
-def cpu_baseline_all_cores(n, budget_s=6.0):
-    """SURVEY.md 8(d)(ii): lele's only route to multi-core is one independent instance per core (everything in it is
-    Par::Seq with thread-local scratch), utterances sharded round-robin.  One forked worker PROCESS per hardware thread,
-    each looping over the oracle's front-end for `budget_s` seconds (separate address spaces: threads of one process
-    serialise on the allocator's mmap traffic and scale only ~6x on 256 cores)."""
-    from oracle import pyoracle as O
-    O.lib()
+from lele_amd.sharded import shard_range  # noqa: E402,F401  SURVEY.md 8(e): static block partition; rank r owns utterances [lo, hi)
+
+
+def rank_seed_base(rank, total, world):
+    """utterance i of the global batch is synthesised from seed i, whichever rank owns it"""
+    return shard_range(total, rank, world)[0]
+
+
+def max_over_ranks(wall, dist, device):
+    """the job's time is the slowest rank's time: one MAX all-reduce (the only collective besides the barriers)"""
+    if dist is None:
+        return wall
+    import torch
+    tt = torch.tensor([wall], dtype=torch.float64, device=device)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
+# ----------------------------------------------------------------------------------------------- CPU baselines (oracle)
+def cpu_quota():
     hw = os.cpu_count() or 1
     cores = hw
     try:  # the container may be granted fewer CPUs than the host has (cgroup v2 cpu.max = "quota period")
@@ -54,6 +87,36 @@ def cpu_baseline_all_cores(n, budget_s=6.0):
             cores = max(1, min(hw, -(-int(q) // int(per))))
     except Exception:
         pass
+    return cores, hw
+
+
+def cpu_baseline_frontend(n, budget_s=8.0):
+    """the oracle (kind "port"), 1 thread, on utterances of the same shape until ~budget_s of CPU work"""
+    from oracle import pyoracle as O
+    O.lib()
+    xs = synth_batch(4, n, 10_000)
+    t_lfr, _ = O.frontend_shape(n)
+    O.frontend_compute(xs[0])  # warm
+    done, t0 = 0, time.perf_counter()
+    while True:
+        O.frontend_compute(xs[done % 4])
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 4096:
+            break
+    bytes_per_utt = 4 * n + 4 * t_lfr * 560
+    return {"value": round(done * bytes_per_utt / el / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "%d x 30 s utterances in %.1f s, oracle (C++ restatement of lele's AVX2 path), 1 thread of %d" % (done, el, os.cpu_count() or 0),
+            "rtf": round(el / (done * n / SAMPLE_RATE), 6)}
+
+
+def cpu_baseline_frontend_all_cores(n, budget_s=5.0):
+    """SURVEY.md 8(d)(ii): lele's only route to multi-core is one independent instance per core (everything in it is
+    Par::Seq with thread-local scratch).  One forked worker PROCESS per granted hardware thread, each looping over the
+    oracle's front-end for `budget_s` seconds."""
+    from oracle import pyoracle as O
+    O.lib()
+    cores, hw = cpu_quota()
     xs = synth_batch(4, n, 20_000)
     t_lfr, _ = O.frontend_shape(n)
     O.frontend_compute(xs[0])  # tables / code warm before the fork
@@ -80,63 +143,226 @@ def cpu_baseline_all_cores(n, budget_s=6.0):
     el = time.perf_counter() - t0
     bytes_per_utt = 4 * n + 4 * t_lfr * 560
     return {"value": round(total * bytes_per_utt / el / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": "%d x 30 s utterances over %d independent single-threaded oracle processes (CPU quota of this "
-                      "container: %d of the host's %d hardware threads), %.1f s wall" % (total, cores, cores, hw, el),
+            "sample": "%d x 30 s utterances, %d single-threaded oracle processes (quota %d of %d hw threads), %.1f s" % (total, cores, cores, hw, el),
             "rtf": round(el / max(1, total) / (n / SAMPLE_RATE), 7)}
 
 
-from lele_amd.sharded import shard_range  # noqa: E402,F401  SURVEY.md 8(e): static block partition; rank r owns utterances [lo, hi)
-
-
-def rank_seed_base(rank, total, world):
-    """utterance i of the global batch is synthesised from seed i, whichever rank owns it"""
-    return shard_range(total, rank, world)[0]
-
-
-def max_over_ranks(wall, dist, device):
-    """the job's time is the slowest rank's time: one MAX all-reduce (the only collective besides the barriers)"""
-    if dist is None:
-        return wall
-    import torch
-    tt = torch.tensor([wall], dtype=torch.float64, device=device)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    return float(tt.item())
-
-
-def cpu_baseline(n, budget_s=12.0):
-    """the oracle (kind "port"), 1 thread, on utterances of the same shape until ~budget_s of CPU work"""
+def cpu_baseline_model(enc_arrays, feats, budget_s=14.0):
+    """lele's execution model for configs[2] on ONE host core: the oracle's restatement of every kernel the generated code
+    would call (oracle/sensevoice_ref.py), layer after layer on one 30 s utterance, until ~budget_s of CPU work; the
+    remaining layers are extrapolated from the per-layer mean (layers 1..69 are identical in shape), the CTC head is timed
+    once.  Integer GEMM = lele's vpmaddwd scheme; the two f32 attention products use the oracle's own AVX2-FMA kernel where
+    lele calls the faer crate (not in the tree)."""
+    from oracle import sensevoice_ref as R
     from oracle import pyoracle as O
-    O.lib()
-    xs = synth_batch(4, n, 10_000)
-    t_lfr, _ = O.frontend_shape(n)
-    O.frontend_compute(xs[0])  # warm
-    done, t0 = 0, time.perf_counter()
-    while True:
-        O.frontend_compute(xs[done % 4])
-        done += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or done >= 4096:
+    x = np.concatenate([enc_arrays["prompt"], feats], axis=1).astype(np.float32)
+    per, t_all = [], time.perf_counter()
+    for L in enc_arrays["layers"]:
+        t0 = time.perf_counter()
+        x = R.layer_forward(x, L)
+        per.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > budget_s:
             break
-    bytes_per_utt = 4 * n + 4 * t_lfr * 560
-    return {"value": round(done * bytes_per_utt / el / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": "%d x 30 s utterances, %.1f s wall, oracle/liboracle.so (C++ restatement of lele's x86 AVX2 "
-                      "path), single thread; host has %d cores" % (done, el, os.cpu_count() or 0),
-            "rtf": round(el / (done * n / SAMPLE_RATE), 6)}
+    t0 = time.perf_counter()
+    xn = O.layer_norm(x, enc_arrays["ln_out"][0], enc_arrays["ln_out"][1], -1, 1e-5)
+    R.qlinear(xn, enc_arrays["ctc"])
+    head = time.perf_counter() - t0
+    nl = len(enc_arrays["layers"])
+    rest = per[1:] if len(per) > 1 else per
+    est = sum(per) + (nl - len(per)) * (sum(rest) / len(rest)) + head
+    audio = feats.shape[0] * SECONDS
+    return {"model_rtf": round(est / audio, 6), "model_ms": round(est * 1e3, 1), "model_cores": 1,
+            "model_sample": "%d of %d layers + CTC head of ONE 30 s utterance timed (%.1f s), rest extrapolated per layer; oracle, 1 thread"
+                            % (len(per), nl, sum(per) + head)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+# ----------------------------------------------------------------------------------------------- the two legs
+def frontend_leg(args, ctx, rank, world, fence, dist, device):
+    from lele_amd.features import SenseVoiceFrontend
+    fe = SenseVoiceFrontend(ctx=ctx)
+    n = SAMPLE_RATE * SECONDS
+    t_lfr, cols, nf = fe.out_rows(n)
+    bytes_per_utt = 4 * n + 4 * t_lfr * cols  # SURVEY.md 8(d): PCM read once + LFR written once
+    # weak scaling: the global batch is world * batch utterances; this rank synthesises and keeps its own shard
+    lo, hi = shard_range(world * args.batch, rank, world)
+    pcm = ctx.buf().upload(synth_batch(hi - lo, n, rank_seed_base(rank, world * args.batch, world)))  # resident in HBM
+    out = ctx.buf()
+    for _ in range(args.warmup):
+        fe.compute_batch(pcm, out)
+    fence()
+    fe.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fe.compute_batch(pcm, out)
+    fence()
+    wall = time.perf_counter() - t0
+    sum_ms, main_ms, runs = fe.profile_read()
+    fe.set_profiling(False)
+    wall = max_over_ranks(wall, dist, device)
+    pcm.buf.close()
+    out.close()
+    return {"wall": wall, "n": n, "t_lfr": t_lfr, "cols": cols, "nf": nf, "bytes_per_utt": bytes_per_utt, "main_ms": main_ms,
+            "sum_ms": sum_ms, "runs": runs}
 
+
+def sensevoice_leg(args, ctx, rank, world, fence, dist, device):
+    import lele_amd
+    from lele_amd import kernels as K
+    from lele_amd.compiler import compile_model
+    from lele_amd.features import Cmvn, SenseVoiceFrontend
+    from lele_amd.plan import Runner, load_weights_bin
+    from lele_amd.sharded import all_gather_ids, all_gather_ids_rccl
+    from sensevoice_graph import VOCAB, Encoder, encoder_arrays, encoder_onnx
+
+    rec = {"topology": "ASSUMED (SURVEY.md 8a): 70 SAN-M layers, d=512, 4x128 heads, FFN 2048, FSMN k=11, int8 linears, CTC 25055; "
+                       "synthetic weights (8d)", "layers": args.layers}
+    fe, cmvn = SenseVoiceFrontend(ctx=ctx), Cmvn(ctx=ctx)
+    enc = Encoder(ctx, args.layers)
+    skip = np.zeros(VOCAB, np.uint8)          # blank + a block of <|...|> specials, as tokenizer.rs:38-48 marks them
+    skip[0] = 1
+    skip[VOCAB - 200:] = 1
+    skip = lele_amd._lib.Weight(skip)
+
+    comm = None
+    if world > 1:  # the C ABI's own RCCL communicator; the 128-byte id travels through the already-initialised process group
+        uid = [lele_amd._lib.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = lele_amd._lib.Comm.from_id(ctx, uid[0], rank, world)
+
+    def build(batch, seconds, seed0):
+        n = SAMPLE_RATE * seconds
+        pcm = ctx.buf().upload(synth_batch(batch, n, seed0))
+        plan, blob = compile_model(encoder_onnx(enc, batch), "sensevoice_shaped")
+        runner = Runner(plan, load_weights_bin(plan, blob), ctx)
+        fbuf, cbuf, abuf, ibuf, nbuf = (ctx.buf() for _ in range(5))
+
+        def features():
+            f = fe.compute_batch(pcm, fbuf)                                    # [B, T, 560]
+            return cmvn.compute(f, out=cbuf)
+
+        feats = features()
+        runner.run({"feats": feats})          # eager once: uploads and packs every weight, sizes every buffer
+        ctx.sync()
+        ctx.graph_begin()
+        logits = runner.run({"feats": feats})[0]
+        graph = ctx.graph_end()
+        graph.launch()
+        ctx.sync()
+
+        def decode():
+            return K.token_filter(K.argmax_last(logits, out=abuf, ctx=ctx), skip, out_ids=ibuf, out_counts=nbuf, ctx=ctx)
+
+        return {"features": features, "graph": graph, "decode": decode, "feats": feats, "logits": logits, "runner": runner,
+                "plan": plan, "audio": batch * seconds}
+
+    # ---- configs[3] shard: per_gpu x 10 s utterances on every rank, ids gathered over RCCL
+    total = args.per_gpu * world
+    lo, hi = shard_range(total, rank, world)
+    c4 = build(hi - lo, 10, lo)
+    gbufs = [ctx.buf() for _ in range(4)]
+
+    def step_c4():
+        c4["features"]()                       # same buffers every step: the graph reads the CMVN output buffer
+        c4["graph"].launch()
+        ids, counts = c4["decode"]()
+        if comm is not None:
+            return all_gather_ids_rccl(ids, counts, total, comm, ctx, gbufs)
+        return all_gather_ids(ids.numpy(), counts.numpy(), total)       # single process: just the D2H copy of the ids
+
+    for _ in range(2):
+        everything = step_c4()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.sv_steps):
+        everything = step_c4()
+    fence()
+    wall = max_over_ranks(time.perf_counter() - t0, dist, device)
+    mine = all_gather_ids(*[a.numpy() for a in c4["decode"]()], hi - lo)
+    agree = all(np.array_equal(a, b) for a, b in zip(everything[lo:hi], mine)) and len(everything) == total
+    fn_count = {}
+    for st in c4["plan"]["statements"]:
+        if st["op"] == "call":
+            fn_count[st["fn"]] = fn_count.get(st["fn"], 0) + 1
+    rec.update({"c4_utterances": total, "c4_utterances_per_gpu": args.per_gpu, "c4_seconds_per_utterance": 10,
+                "c4_ms_per_step": round(1e3 * wall / args.sv_steps, 3), "rtf_c4": round(wall / args.sv_steps / (total * 10), 8),
+                "audio_s_per_s": round(total * 10 * args.sv_steps / wall, 1), "c4_steps": args.sv_steps,
+                "c4_collective": "rccl all-gather of token ids via lele_hip_comm_allgather_i32" if comm else "none (single process)",
+                "c4_gathered_ok": bool(agree), "c4_tokens": int(c4["logits"].shape[1]),
+                "plan_statements": len(c4["plan"]["statements"]), "plan_calls": sum(fn_count.values()),
+                "logits_finite": bool(np.isfinite(c4["logits"].numpy()[0]).all())})
+
+    # ---- the quantised linear (the model's dominant kernel) at the configs[3] shard shape, per-stage HIP events
+    if rank == 0:
+        L = enc.layers[1]
+        x = ctx.buf().upload(np.random.default_rng(5).standard_normal((hi - lo, c4["logits"].shape[1], 512)).astype(np.float32))
+        xn = K.layer_norm(x, L.ln1[0], L.ln1[1], -1, 1e-5, out=ctx.buf(), ctx=ctx)
+        ob = ctx.buf()
+        p = L.ffn1
+        for _ in range(5):
+            K.fused_quantized_linear(xn, p.w, p.scale, p.zero, p.bias, True, out=ob, ctx=ctx)
+        ctx.quant_set_profiling(True)
+        for _ in range(50):
+            K.fused_quantized_linear(xn, p.w, p.scale, p.zero, p.bias, True, out=ob, ctx=ctx)
+        r_ms, q_ms, g_ms, calls = ctx.quant_profile_read()
+        ctx.quant_set_profiling(False)
+        m_rows, kk, nn = (hi - lo) * c4["logits"].shape[1], 512, 2048
+        byts = 4 * m_rows * kk + kk * nn + 8 * nn + 4 * m_rows * nn     # SURVEY.md 8(d): f32 in, u8 weights, scale+bias, f32 out
+        ops = 2 * m_rows * kk * nn
+        op_ms = r_ms + q_ms + g_ms
+        rec["qlinear"] = {"shape": "[%d x %d] x [%d x %d] (ffn1 of one configs[3] shard, input = LayerNorm output)" % (m_rows, kk, kk, nn),
+                          "range_ms": round(r_ms, 5), "quantise_ms": round(q_ms, 5), "gemm_ms": round(g_ms, 5), "op_ms": round(op_ms, 5),
+                          "calls": calls, "algorithmic_bytes": byts, "int_ops": ops,
+                          "hbm_gbs": round(byts / (op_ms * 1e-3) / 1e9, 1) if op_ms > 0 else None,
+                          "tops": round(ops / (op_ms * 1e-3) / 1e12, 1) if op_ms > 0 else None}
+
+    # ---- configs[2]: one 30 s utterance, lele's own protocol (N = 1 only)
+    if world == 1:
+        c3 = build(1, 30, 0)
+        runs = max(10, args.sv_steps)
+        t_model, t_e2e = [], []
+        for _ in range(runs):
+            ctx.sync()
+            t0 = time.perf_counter()
+            c3["graph"].launch()
+            ctx.sync()
+            t_model.append(time.perf_counter() - t0)
+        for _ in range(runs):
+            ctx.sync()
+            t0 = time.perf_counter()
+            c3["features"]()
+            c3["graph"].launch()
+            ids, counts = c3["decode"]()
+            ids.numpy(), counts.numpy()        # the transcript's ids on the host: waits for the stream
+            t_e2e.append(time.perf_counter() - t0)
+        rec.update({"c3_tokens": int(c3["logits"].shape[1]), "c3_runs": runs,
+                    "c3_model_ms": round(1e3 * float(np.mean(t_model)), 3), "c3_e2e_ms": round(1e3 * float(np.mean(t_e2e)), 3),
+                    "rtf_model": round(float(np.mean(t_model)) / 30.0, 7), "rtf_e2e": round(float(np.mean(t_e2e)) / 30.0, 7),
+                    "rtf_target": 0.001})
+        rec["_c3_feats"] = c3["feats"].numpy()
+        rec["_enc"] = enc
+    if comm is not None:
+        comm.close()
+    return rec
+
+
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report n_gpus that is not the number of ranks running"
+                         % (args.gpus, world))
+    if args.dry_run:  # launcher logic only (CPU tests): rendezvous over gloo, the fences and the MAX all-reduce, no GPU work
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+        wall = max_over_ranks(0.001 * (rank + 1), dist, "cpu")
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "dry-run", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "value": wall}), flush=True)
+        dist.destroy_process_group()
+        return
+    dist, device = None, "cpu"
     if world > 1 or os.environ.get("LELE_BENCH_FORCE_DIST") == "1":  # FORCE_DIST: exercise RCCL init + collectives at N=1
         import torch
         import torch.distributed as dist  # backend "nccl" is RCCL on ROCm
@@ -146,94 +372,140 @@ def main():
             local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            device = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
 
     import lele_amd
-    from lele_amd.features import SenseVoiceFrontend
-
     ctx = lele_amd._lib.Ctx(local_rank)
-    fe = SenseVoiceFrontend(ctx=ctx)
-    n = SAMPLE_RATE * SECONDS
-    t_lfr, cols, nf = fe.out_rows(n)
-    bytes_per_utt = 4 * n + 4 * t_lfr * cols  # PCM read once + LFR written once
-    # weak scaling: the global batch is world * batch utterances; this rank synthesises and keeps its own shard
-    lo, hi = shard_range(world * args.batch, rank, world)
-    pcm = ctx.buf().upload(synth_batch(hi - lo, n, rank_seed_base(rank, world * args.batch, world)))  # resident in HBM
-    out = ctx.buf()
 
-    def barrier():
+    def fence():
         ctx.sync()
         if dist is not None:
             import torch
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        fe.compute_batch(pcm, out)
-    barrier()
-    fe.set_profiling(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        fe.compute_batch(pcm, out)
-    ctx.sync()
-    barrier()
-    wall = time.perf_counter() - t0
-    sum_ms, main_ms, runs = fe.profile_read()
-    fe.set_profiling(False)
-    wall = max_over_ranks(wall, dist, "cuda" if dist is None or dist.get_backend() == "nccl" else "cpu")
+    fe = frontend_leg(args, ctx, rank, world, fence, dist, device)
+    sv = None
+    if not args.no_model:
+        sv = sensevoice_leg(args, ctx, rank, world, fence, dist, device)
 
     if rank == 0:
-        total_bytes = world * args.batch * bytes_per_utt * args.steps
+        n, wall = fe["n"], fe["wall"]
+        total_bytes = world * args.batch * fe["bytes_per_utt"] * args.steps
         value = total_bytes / wall / 1e9
         audio_s = world * args.batch * SECONDS * args.steps
-        achieved = args.batch * bytes_per_utt / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "frontend_hbm_traffic.json")
-        if os.path.exists(tf):  # PMC-measured HBM bytes per fe_main_kernel launch at this batch (see profiles/README.md)
+        main_ms = fe["main_ms"]
+        achieved = args.batch * fe["bytes_per_utt"] / (main_ms * 1e-3) / 1e9 if main_ms > 0 else 0.0
+        prof = {}
+        pf = os.path.join(ROOT, "profiles", "frontend_roofline.json")
+        if os.path.exists(pf):  # PMC / microbenchmark constants measured on the box (profiles/README.md): traffic, VALU work and peak
             try:
-                rec = json.load(open(tf))
-                if rec.get("batch") == args.batch:
-                    traffic = rec.get("bytes_per_launch")
+                prof = json.load(open(pf))
             except Exception:
-                traffic = None
-        valu_busy = None
-        pf = os.path.join(ROOT, "profiles", "r01_frontend_pmc_sq.json")
-        if os.path.exists(pf):  # SQ counters of the same kernel (profiles/README.md): the kernel is VALU-bound, not HBM-bound
-            try:
-                c = json.load(open(pf))
-                valu_busy = round(c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 3)
-            except Exception:
-                valu_busy = None
+                prof = {}
+        same_batch = prof.get("batch") == args.batch
+        roof = {"kernel": "fe_main_kernel", "kernel_ms": round(main_ms, 5), "launches": fe["runs"],
+                "algorithmic_bytes_per_launch": args.batch * fe["bytes_per_utt"],
+                "hbm_achieved": round(achieved, 2), "hbm_peak": HBM_PEAK_GBS, "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": prof.get("hbm_bytes_per_launch") if same_batch else None}
+        lane_ops = prof.get("valu_lane_ops_per_launch") if same_batch else None
+        valu_peak = prof.get("valu_peak_lane_ops_per_s")
+        if lane_ops and valu_peak and main_ms > 0:
+            # the governing bound: the bit-exact radix-2 replica needs ~19 VALU lane-ops per algorithmic byte against a ridge of
+            # ~5-10 -> priced against the measured VALU issue ceiling; the HBM fraction stays beside it
+            a = lane_ops / (main_ms * 1e-3)
+            roof.update({"bound": "valu", "achieved": round(a / 1e12, 3), "peak": round(valu_peak / 1e12, 3), "unit": "Tlane-op/s",
+                         "frac": round(a / valu_peak, 4), "valu_lane_ops_per_launch": lane_ops,
+                         "peak_source": prof.get("valu_peak_source")})
+        else:
+            roof.update({"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4)})
         line = {
-            "metric": "STFT+mel GB/s (SenseVoice front-end: PCM -> log-mel -> LFR, algorithmic bytes)",
+            "metric": "STFT+mel GB/s (SenseVoice front-end: PCM -> log-mel -> LFR, algorithmic bytes); SenseVoiceSmall-shaped RTF in `sensevoice`",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: STFT+mel+LFR, 30 s synthetic 16 kHz mono, batch %d "
-                                   "utterances per GPU per step" % args.batch,
-                       "samples_per_utterance": n, "frames": nf, "lfr_rows": t_lfr, "batch_per_gpu": args.batch,
-                       "bytes_per_utterance": bytes_per_utt, "parallelism": "utterance-sharded x%d" % world},
-            "rtf": round(wall / audio_s, 9),
-            "roofline": {"bound": "hbm", "kernel": "fe_main_kernel", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "kernel_ms": round(main_ms, 5),
-                         "aux_kernel": "none (frame sums are fused into fe_main_kernel; LELE_HIP_FE_FUSED=0 restores "
-                                       "the separate fe_frame_sum_kernel)" if sum_ms < 0.02 else "fe_frame_sum_kernel",
-                         "aux_kernel_ms": round(sum_ms, 5), "launches": runs,
-                         "algorithmic_bytes_per_launch": args.batch * bytes_per_utt,
-                         "valu_busy_frac_pmc": valu_busy,
-                         "note": "bit-exact radix-2 FFT replica: ~19 VALU lane-ops per algorithmic byte against a ridge of ~4.9 "
-                                 "-> VALU-bound by construction (DESIGN.md 3.1); traffic is an upper bound (profiles/README.md)"},
+            "config": {"workload": "BASELINE configs[1]: STFT+mel+LFR, 30 s synthetic 16 kHz mono, batch %d utterances per GPU per step; "
+                                   "configs[2]/[3] SenseVoice-shaped recogniser in `sensevoice`" % args.batch,
+                       "samples_per_utterance": n, "frames": fe["nf"], "lfr_rows": fe["t_lfr"], "batch_per_gpu": args.batch,
+                       "bytes_per_utterance": fe["bytes_per_utt"], "parallelism": "utterance-sharded x%d" % world},
+            "rtf_frontend": round(wall / audio_s, 9),
+            "roofline": roof,
         }
+        enc = feats = None
+        if sv is not None:
+            feats, enc = sv.pop("_c3_feats", None), sv.pop("_enc", None)
+            line["sensevoice"] = sv
+            for k in ("rtf_model", "rtf_e2e", "rtf_c4", "audio_s_per_s"):
+                if k in sv:
+                    line[k] = sv[k]
+            q = sv.get("qlinear")
+            if q and q.get("op_ms"):
+                # flat copies inside `roofline`: the model path's dominant kernel, priced against HBM (its bound at K = 512: 57 MB of
+                # f32 traffic = 7 us at 8 TB/s against 2.9 us of i8 MFMA) and, beside it, against the i8 matrix-core peak
+                roof.update({"model_kernel": "fused_quantized_linear " + q["shape"], "model_bound": "hbm", "model_op_ms": q["op_ms"],
+                             "model_achieved": q["hbm_gbs"], "model_peak": HBM_PEAK_GBS, "model_unit": "GB/s",
+                             "model_frac": round(q["hbm_gbs"] / HBM_PEAK_GBS, 4), "model_tops": q["tops"],
+                             "model_mfma_frac": round(q["tops"] / I8_PEAK_TOPS, 4)})
         if world == 1 and not args.no_cpu_baseline:  # reported baseline: rank 0 at N=1 only
-            line["cpu_baseline"] = cpu_baseline(n)
-            line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(n)
+            cb = cpu_baseline_frontend(n)
+            if enc is not None and feats is not None:
+                from sensevoice_graph import encoder_arrays
+                cb.update(cpu_baseline_model(encoder_arrays(enc), feats))
+            line["cpu_baseline"] = cb
+            line["cpu_baseline_all_cores"] = cpu_baseline_frontend_all_cores(n)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn(args, argv):
+    """--gpus N > 1 without a launcher: start the N ranks ourselves (one process per GPU) and pass rank 0's line through"""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    if rc:  # a rank that died takes the job with it: make sure nothing lingers
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=256, help="front-end leg: 30 s utterances per GPU per step")
+    ap.add_argument("--per-gpu", type=int, default=32, help="recogniser leg: 10 s utterances per GPU per step (configs[3]: 256 / 8)")
+    ap.add_argument("--sv-steps", type=int, default=10, help="recogniser leg: timed steady-state steps (lele's harness uses 10)")
+    ap.add_argument("--layers", type=int, default=70)
+    ap.add_argument("--no-model", action="store_true", help="front-end leg only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn(args, sys.argv[1:]))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -337,6 +337,25 @@ int lele_hip_yolo_seg_postprocess(LeleCtx* ctx, const LeleTensor* logits, const 
                                   int32_t img_height, float threshold, int32_t num_classes, LeleBuf* out_dets,
                                   LeleBuf* out_count, LeleBuf* out_mask);
 
+/* ---- multi-GPU: the one exchange step of the utterance-sharded recogniser ------------------------------ */
+/* lele is single-process; its route to several devices is one instance per shard of the utterances (one process per GPU here).
+ * Nothing is exchanged while computing; at the end ONE all-gather of the decoded token ids (i32) over RCCL / xGMI gives every
+ * rank the transcripts of the whole batch.  RCCL is loaded on first use (dlopen): no link-time dependency.
+ * The 128-byte unique id is made by rank 0 (comm_unique_id) and handed to the other ranks by the launcher; comm_init_file does
+ * that through a file (rank 0 writes it atomically, the others poll for up to timeout_ms). */
+typedef struct LeleComm LeleComm;
+int lele_hip_comm_unique_id(uint8_t* id128);
+int lele_hip_comm_init(LeleCtx* ctx, const uint8_t* id128, int rank, int world, LeleComm** out);
+int lele_hip_comm_init_file(LeleCtx* ctx, const char* path, int rank, int world, int timeout_ms, LeleComm** out);
+int lele_hip_comm_rank(const LeleComm* comm, int* rank, int* world);
+/* send: DEVICE i32 tensor of the same element count on every rank -> out [world, count] in rank order, on the ctx stream
+ * (graph-capturable; the result is ordered after everything queued before it, e.g. lele_hip_token_filter) */
+int lele_hip_comm_allgather_i32(LeleComm* comm, const LeleTensor* send, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* MAX over ranks of a host scalar, in place (row width of ragged shards, a wall time in ns); synchronises the ctx stream */
+int lele_hip_comm_allreduce_max_i64(LeleComm* comm, int64_t* value);
+int lele_hip_comm_barrier(LeleComm* comm); /* every rank's ctx stream has drained when any rank returns */
+int lele_hip_comm_destroy(LeleComm* comm);
+
 /* ---- fused forms beyond the reference's own patterns (emitted by lele_amd.compiler, each bit-identical to the sequence it
  *      replaces; never required by lele-generated code) ---------------------------------------------------------------- */
 /* fused_quantized_linear followed by one or two Adds of same-shape tensors, folded into the GEMM's store:

@@ -68,12 +68,31 @@ def exported_symbols():
     return sorted(set(re.findall(r"\b(lele_hip_\w+)\s*\(", txt)))
 
 
+_live_ctxs = []  # weak references; closed at interpreter exit, BEFORE the HIP runtime's own teardown (destroying graphs / events
+                 # after that throws inside the runtime)
+
+
+def _close_all_ctxs():
+    for r in list(_live_ctxs):
+        c = r()
+        if c is not None:
+            try:
+                c.close()
+            except Exception:
+                pass
+
+
 class Ctx:
     """LeleCtx: one HIP stream + staging arena + weight cache on one device."""
 
     def __init__(self, device=0):
         self._h = C.c_void_p()
         check(lib().lele_hip_ctx_create(C.c_int(device), C.byref(self._h)))
+        import atexit
+        import weakref
+        if not _live_ctxs:
+            atexit.register(_close_all_ctxs)
+        _live_ctxs.append(weakref.ref(self))
         self.device = device
         self._bufs = []
         self._graphs = []  # weak references: ctx_destroy destroys the graphs recorded on it, their wrappers must not do it again
@@ -175,6 +194,60 @@ class Buf:
         out = np.empty(shape, dtype)
         check(lib().lele_hip_buf_to_host(self._h, out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)))
         return out
+
+
+class Comm:
+    """LeleComm: this process's membership of an RCCL communicator (one process per GPU), bound to a ctx stream.
+    `Comm.from_file(ctx, path, rank, world)` is the torch-free rendezvous (rank 0 writes the unique id to `path`)."""
+
+    def __init__(self, ctx, h, rank, world):
+        self.ctx, self._h, self.rank, self.world = ctx, h, rank, world
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(lib().lele_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_id(cls, ctx, uid, rank, world):
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        check(lib().lele_hip_comm_init(ctx._h, buf, C.c_int(rank), C.c_int(world), C.byref(h)))
+        return cls(ctx, h, rank, world)
+
+    @classmethod
+    def from_file(cls, ctx, path, rank, world, timeout_ms=120000):
+        h = C.c_void_p()
+        check(lib().lele_hip_comm_init_file(ctx._h, path.encode(), C.c_int(rank), C.c_int(world), C.c_int(timeout_ms), C.byref(h)))
+        return cls(ctx, h, rank, world)
+
+    def allgather_i32(self, send, out=None):
+        """send: device-resident int32 tensor (same size on every rank) -> DevTensor [world, count]"""
+        keep = []
+        out = out or self.ctx.buf()
+        sh = OutShape()
+        check(lib().lele_hip_comm_allgather_i32(self._h, as_tensor(send, keep), out._h, sh.shape, C.byref(sh.rank)))
+        return DevTensor(out, sh.get(), np.int32)
+
+    def allreduce_max(self, value):
+        v = C.c_int64(int(value))
+        check(lib().lele_hip_comm_allreduce_max_i64(self._h, C.byref(v)))
+        return v.value
+
+    def barrier(self):
+        check(lib().lele_hip_comm_barrier(self._h))
+
+    def close(self):
+        if self._h:
+            lib().lele_hip_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Graph:

@@ -60,7 +60,7 @@ def build(force=False, verbose=False):
             if verbose and out.strip():
                 print(out)
     if jobs or force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs)
+        run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-ldl"])
     build_runner(force, run)
     return LIB
 

@@ -1,0 +1,205 @@
+// comm.hip -- the one exchange step of the sharded recogniser, owned by the C ABI.
+//
+// lele itself is single-process; its only route to several devices is "one instance per utterance shard".  Utterances are
+// independent (dynamic quantisation and CMVN are per utterance), so a GPU never needs another GPU's data while it computes.
+// What is exchanged, once, at the very end, is the DECODED token ids (i32, count-prefixed rows; 22 KB per GPU for
+// BASELINE configs[3]) so that every rank holds the transcripts of the whole batch: one RCCL all-gather over xGMI, issued on
+// the ctx stream straight from the device buffer the greedy decoder wrote -- no host round trip, no torch.
+//
+// RCCL is bound at run time (dlopen "librccl.so"): the library itself has no link-time dependency on it, a single-GPU
+// integration never loads it, and a missing RCCL is an error of lele_hip_comm_* only.  One process per GPU; the 128-byte
+// unique id is created by rank 0 and handed to the other ranks by whatever launched them -- lele_hip_comm_init_file does that
+// through a file (rank 0 writes <path>.tmp and renames it; the others poll), which needs neither MPI nor torch.
+#include "common.h"
+
+#include <dlfcn.h>
+#include <errno.h>
+#include <time.h>
+#include <unistd.h>
+
+using namespace lele;
+
+namespace {
+
+struct UniqueId {
+    char internal[128];  // NCCL_UNIQUE_ID_BYTES (rccl.h:40)
+};
+typedef void* Comm;
+// rccl.h:52 ncclSuccess = 0; :448-450 ncclMax = 2; :459-463 ncclInt32 = 2, ncclInt64 = 4
+constexpr int kInt32 = 2, kInt64 = 4, kMax = 2;
+
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+int load_rccl(Rccl** out) {
+    static Rccl r;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!r.handle) {
+        void* h = nullptr;
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        LELE_REQUIRE(h, "comm: librccl.so cannot be loaded (%s)", dlerror());
+#define LELE_SYM(field, sym)                                                         \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, sym));                    \
+    LELE_REQUIRE(r.field, "comm: librccl.so does not export %s", sym)
+        LELE_SYM(GetUniqueId, "ncclGetUniqueId");
+        LELE_SYM(CommInitRank, "ncclCommInitRank");
+        LELE_SYM(CommDestroy, "ncclCommDestroy");
+        LELE_SYM(AllGather, "ncclAllGather");
+        LELE_SYM(AllReduce, "ncclAllReduce");
+        LELE_SYM(GetErrorString, "ncclGetErrorString");
+#undef LELE_SYM
+        r.handle = h;
+    }
+    *out = &r;
+    return 0;
+}
+
+#define LELE_RCCL_CHECK(api, expr)                                                                   \
+    do {                                                                                             \
+        int _rc = (expr);                                                                            \
+        LELE_REQUIRE(_rc == 0, "%s failed: %s (%s:%d)", #expr, (api)->GetErrorString(_rc), __FILE__, __LINE__); \
+    } while (0)
+
+}  // namespace
+
+struct LeleComm {
+    LeleCtx* ctx = nullptr;
+    Rccl* api = nullptr;
+    Comm comm = nullptr;
+    int rank = 0, world = 1;
+    void* scratch = nullptr;  // 64 bytes of device memory for the scalar reductions
+};
+
+extern "C" {
+
+int lele_hip_comm_unique_id(uint8_t* id128) {
+    LELE_REQUIRE(id128, "comm_unique_id: NULL argument");
+    Rccl* api = nullptr;
+    LELE_TRY(load_rccl(&api));
+    UniqueId id;
+    LELE_RCCL_CHECK(api, api->GetUniqueId(&id));
+    memcpy(id128, id.internal, sizeof(id.internal));
+    return 0;
+}
+
+int lele_hip_comm_init(LeleCtx* ctx, const uint8_t* id128, int rank, int world, LeleComm** out) {
+    LELE_REQUIRE(ctx && id128 && out, "comm_init: NULL argument");
+    LELE_REQUIRE(world >= 1 && rank >= 0 && rank < world, "comm_init: rank %d of %d", rank, world);
+    Rccl* api = nullptr;
+    LELE_TRY(load_rccl(&api));
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    UniqueId id;
+    memcpy(id.internal, id128, sizeof(id.internal));
+    LeleComm* c = new LeleComm();
+    c->ctx = ctx;
+    c->api = api;
+    c->rank = rank;
+    c->world = world;
+    int rc = api->CommInitRank(&c->comm, world, id, rank);
+    if (rc != 0) {
+        set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, api->GetErrorString(rc));
+        delete c;
+        return 2;
+    }
+    if (hipMalloc(&c->scratch, 64) != hipSuccess) {
+        set_error("comm_init: hipMalloc failed");
+        (void)api->CommDestroy(c->comm);
+        delete c;
+        return 1;
+    }
+    *out = c;
+    return 0;
+}
+
+int lele_hip_comm_init_file(LeleCtx* ctx, const char* path, int rank, int world, int timeout_ms, LeleComm** out) {
+    LELE_REQUIRE(ctx && path && out, "comm_init_file: NULL argument");
+    uint8_t id[128];
+    if (rank == 0) {
+        LELE_TRY(lele_hip_comm_unique_id(id));
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        LELE_REQUIRE(f, "comm_init_file: cannot write %s (%s)", tmp.c_str(), strerror(errno));
+        const size_t w = fwrite(id, 1, sizeof(id), f);
+        fclose(f);
+        LELE_REQUIRE(w == sizeof(id), "comm_init_file: short write to %s", tmp.c_str());
+        LELE_REQUIRE(rename(tmp.c_str(), path) == 0, "comm_init_file: rename to %s failed (%s)", path, strerror(errno));
+    } else {
+        const int step_ms = 5;
+        int waited = 0;
+        for (;;) {
+            FILE* f = fopen(path, "rb");
+            if (f) {
+                const size_t r = fread(id, 1, sizeof(id), f);
+                fclose(f);
+                if (r == sizeof(id)) break;  // the rename makes the file appear complete; a short read means a foreign file
+            }
+            LELE_REQUIRE(waited < timeout_ms, "comm_init_file: rank %d waited %d ms for %s", rank, timeout_ms, path);
+            struct timespec ts = {0, step_ms * 1000000L};
+            nanosleep(&ts, nullptr);
+            waited += step_ms;
+        }
+    }
+    return lele_hip_comm_init(ctx, id, rank, world, out);
+}
+
+int lele_hip_comm_rank(const LeleComm* c, int* rank, int* world) {
+    LELE_REQUIRE(c && rank && world, "comm_rank: NULL argument");
+    *rank = c->rank;
+    *world = c->world;
+    return 0;
+}
+
+/* every rank contributes `count` i32 values (device memory); out receives [world, count] in rank order, on the ctx stream */
+int lele_hip_comm_allgather_i32(LeleComm* c, const LeleTensor* send, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(c && send && out, "comm_allgather_i32: NULL argument");
+    LELE_REQUIRE(send->dtype == LELE_I32, "comm_allgather_i32: i32 tensor required");
+    LELE_REQUIRE(send->mem == LELE_MEM_DEVICE, "comm_allgather_i32: the send tensor must be device memory (ids stay on the GPU)");
+    LeleCtx* ctx = c->ctx;
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t count = numel(send);
+    LELE_TRY(out->reserve((size_t)c->world * count * 4));
+    if (count) LELE_RCCL_CHECK(c->api, c->api->AllGather(send->data, out->data, (size_t)count, kInt32, c->comm, ctx->stream));
+    return set_shape(out_shape, out_rank, {(int64_t)c->world, count});
+}
+
+/* MAX over ranks of a host scalar (row widths of ragged shards; the bench's wall time in ns): one tiny all-reduce + sync */
+int lele_hip_comm_allreduce_max_i64(LeleComm* c, int64_t* value) {
+    LELE_REQUIRE(c && value, "comm_allreduce_max_i64: NULL argument");
+    LeleCtx* ctx = c->ctx;
+    LELE_REQUIRE(!ctx->capturing, "comm_allreduce_max_i64: not allowed while a graph is being captured");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    LELE_HIP_CHECK(hipMemcpyAsync(c->scratch, value, 8, hipMemcpyHostToDevice, ctx->stream));
+    LELE_RCCL_CHECK(c->api, c->api->AllReduce(c->scratch, (char*)c->scratch + 8, 1, kInt64, kMax, c->comm, ctx->stream));
+    LELE_HIP_CHECK(hipMemcpyAsync(value, (char*)c->scratch + 8, 8, hipMemcpyDeviceToHost, ctx->stream));
+    LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+/* all ranks have finished everything they queued on their ctx streams before any rank returns */
+int lele_hip_comm_barrier(LeleComm* c) {
+    int64_t one = 1;
+    return lele_hip_comm_allreduce_max_i64(c, &one);
+}
+
+int lele_hip_comm_destroy(LeleComm* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) (void)c->api->CommDestroy(c->comm);
+    if (c->scratch) (void)hipFree(c->scratch);
+    delete c;
+    return 0;
+}
+
+}  // extern "C"

@@ -587,8 +587,12 @@ struct OnepassArgs {
     int stat_per_slice;
 };
 
-template <bool KSPLIT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 4 : 3))) void qlinear_onepass_kernel(OnepassArgs a, IgemmEpi epi) {
+// KSPLIT = false: the waves of a block take column tiles two at a time (one A fragment feeds two accumulators), all of K each.
+// KSPLIT = true (few tiles per block: one utterance): the four waves split K, one tile at a time, partial tiles meet in LDS.
+// SETK = k-steps (32 k each) per register set of weight fragments; sets alternate between two register files so that the loads
+// of set i+1 are in flight while the MFMAs of set i issue.  The host guarantees (k-steps per wave) % (2 * SETK) == 0.
+template <bool KSPLIT, int SETK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 3 : 2))) void qlinear_onepass_kernel(OnepassArgs a, IgemmEpi epi) {
     extern __shared__ __attribute__((aligned(16))) char op_lds[];  // A' tile: [32][kp + 16] bytes
     __shared__ QParams s_prm[kOpBM];
     __shared__ int s_ca[kOpBM], s_rterm[kOpBM];
@@ -596,26 +600,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 4 
     __shared__ float s_mn[4], s_mx[4];
     __shared__ float s_stat[4][4];
     __shared__ int s_red[KSPLIT ? 4 * 16 * 64 : 1];
+    constexpr int NTW = KSPLIT ? 1 : 2;  // tiles a wave works on at a time
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hv = lane >> 5, l31 = lane & 31;
     const int pitch = a.kp + 16;
     const int64_t m0 = (int64_t)blockIdx.y * kOpBM;
     const int rows_here = (int)(a.rows - m0 < kOpBM ? a.rows - m0 : kOpBM);
+    const int t_lo = blockIdx.x * a.tpw, t_hi = t_lo + a.tpw < a.nt ? t_lo + a.tpw : a.nt;  // this block's column tiles (>= 1)
+    const v4i zero4 = {0, 0, 0, 0};
+    const v4i* wfv = reinterpret_cast<const v4i*>(a.wf) + lane;  // block (t, s) of the weights: wfv[(t * ks + s) * 64]
+    const int per = a.ks / 4;                                      // K-split: k-steps per wave
+    const int ks0 = KSPLIT ? wave * per : 0, ks1 = KSPLIT ? ks0 + per : a.ks;
+    const int t_first = KSPLIT ? t_lo : t_lo + 2 * wave, tstep = KSPLIT ? 1 : 8;
 
-    // ---- phase 1a: this thread's first loads go out before anything else (8 lanes per row, 16 bytes each: 128-byte runs)
+    // ---- weight fragments: two register files, requested one set ahead.  (tq, sq) = position of the next set to request; past
+    // the wave's last set the position is clamped (a harmless repeated load instead of a branch, so that the hardware's
+    // outstanding-load counter is exact on every path).  The first set does not depend on the activation: it is requested now
+    // and travels during phases 0 and 1.
+    v4i w_a[NTW][SETK], w_b[NTW][SETK];
+    int tq = t_first, sq = ks0;
+    auto req = [&](v4i (&w)[NTW][SETK]) {
+        const int tc = tq < t_hi ? tq : t_hi - 1;
+        const v4i* p0 = wfv + ((int64_t)tc * a.ks + sq) * 64;
+        const v4i* p1 = (NTW == 2 && tc + 1 < t_hi) ? p0 + (int64_t)a.ks * 64 : p0;
+#pragma unroll
+        for (int u = 0; u < SETK; ++u) {
+            w[0][u] = p0[u * 64];
+            if (NTW == 2) w[1][u] = p1[u * 64];
+        }
+        sq += SETK;
+        if (sq >= ks1) {
+            sq = ks0;
+            tq += tstep;
+        }
+    };
+    req(w_a);
+
+    // ---- phase 1a: this thread's first activation loads (8 lanes per row, 16 bytes each: 128-byte runs)
     const int qrow = tid >> 3, sub = tid & 7;
     const int64_t grow = m0 + qrow;
     const bool live = grow < a.rows;
-    const float* xr = a.x + (live ? grow : a.rows - 1) * (int64_t)a.k;
+    const float* xr = a.x + (live ? grow : a.rows - 1) * (int64_t)a.k;  // rows past the end re-read the last row; never stored
     const bool vec4 = (a.k & 3) == 0 && (((uintptr_t)a.x & 15) == 0);
     const int niter = a.kp / 32;
     constexpr int U = 8;
     float4 pre[U];
     auto fetch = [&](int it) -> float4 {
         const int c = it * 32 + sub * 4;
-        if (vec4) {
-            return *reinterpret_cast<const float4*>(xr + (c + 3 < a.k ? c : a.k - 4));  // clamped: never past the row
-        }
+        if (vec4) return *reinterpret_cast<const float4*>(xr + (c + 3 < a.k ? c : a.k - 4));  // clamped: never past the row
         float4 v;
         v.x = xr[c < a.k ? c : a.k - 1];
         v.y = xr[c + 1 < a.k ? c + 1 : a.k - 1];
@@ -665,11 +697,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 4 
         __syncthreads();
     }
 
-    // ---- phase 1b: quantise the 32 rows into LDS, exact row sums on the way
+    // ---- phase 1b: quantise the 32 rows into LDS, exact row sums on the way.  Whole 32-column chunks inside the SIMD body
+    // (k & ~7) take four instructions per element: fma, round-to-nearest-even, v_cvt_pk_u8_f32 (saturates to [0, 255] = the
+    // clamp, and packs), and per four elements one xor 0x80808080 (q - 128 as i8) and one v_sad_u8 (sum of the four q).
     {
         const QParams q = s_prm[live ? (int)(grow / a.m - sl_lo) : 0];
         const int simd_k = a.k & ~7;
-        int sum = 0;
+        const int nfull = simd_k / 32;  // chunks with every column below simd_k
+        unsigned usum = 0;              // sum of q over the fast chunks
+        int ssum = 0;                   // sum of (q - 128) over the ragged chunk
         char* dst = op_lds + qrow * pitch + sub * 4;
         for (int it0 = 0; it0 < niter; it0 += U) {
             float4 cur[U];
@@ -682,17 +718,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 4 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int it = it0 + u;
-                if (it < niter) {
+                if (it < nfull) {  // uniform
+                    unsigned pk = 0;
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(cur[u].x, q.inv_scale, q.zp)), 0, pk);
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(cur[u].y, q.inv_scale, q.zp)), 1, pk);
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(cur[u].z, q.inv_scale, q.zp)), 2, pk);
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(cur[u].w, q.inv_scale, q.zp)), 3, pk);
+                    usum = __builtin_amdgcn_sad_u8(pk, 0u, usum);
+                    *reinterpret_cast<unsigned*>(dst + it * 32) = pk ^ 0x80808080u;
+                } else if (it < niter) {  // the chunk that holds the scalar tail (k % 8 columns) and / or the zero padding
                     const int c = it * 32 + sub * 4;
-                    float xv[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
+                    const float xv[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
                     int packed = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int kk = c + e;
                         int v = 0;
-                        if (live && kk < a.k) {
+                        if (kk < a.k) {
                             v = (int)quant_one(xv[e], q, kk < simd_k) - 128;
-                            sum += v;
+                            ssum += v;
                         }
                         packed |= (v & 0xff) << (8 * e);
                     }
@@ -700,6 +744,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 4 
                 }
             }
         }
+        int sum = (int)usum - 128 * 4 * nfull + ssum;  // every lane of a row did nfull fast chunks of 4 elements
         sum += __shfl_xor(sum, 1);
         sum += __shfl_xor(sum, 2);
         sum += __shfl_xor(sum, 4);
@@ -712,10 +757,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 4 
     }
     __syncthreads();
 
-    // ---- phase 2: columns.  This block owns tiles [t_lo, t_hi)
-    const int t_lo = blockIdx.x * a.tpw, t_hi = t_lo + a.tpw < a.nt ? t_lo + a.tpw : a.nt;
+    // ---- phase 2: columns
     const char* arow = op_lds + l31 * pitch + 16 * hv;
-    const v4i zero4 = {0, 0, 0, 0};
     // {min, max} of what this block stores, separately for the (at most two: m >= 32) slices its rows belong to: local rows
     // below `bnd` are slice sl_lo, the others slice sl_lo + 1
     const int bnd = (int)((sl_lo + 1) * a.m - m0);
@@ -761,57 +804,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 4 
             __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: hoisting all 16 rows' loads costs 40 VGPRs and spills
         }
     };
-    if (!KSPLIT) {
-        // waves take column tiles two at a time (one A fragment feeds two independent accumulators)
-        for (int t = t_lo + 2 * wave; t < t_hi; t += 8) {
-            const bool two = t + 1 < t_hi;
-            const v4i* w0 = reinterpret_cast<const v4i*>(a.wf) + (int64_t)t * a.ks * 64 + lane;
-            const v4i* w1 = two ? w0 + (int64_t)a.ks * 64 : w0;
-            v16i acc0, acc1;
+    // SETK k-steps of MFMAs out of one register set: the A fragments come from LDS (short latency), the W fragments were
+    // requested one set ahead, so the wait before the first MFMA leaves the NEXT set's loads in flight
+    auto mm = [&](const v4i (&w)[NTW][SETK], int s, v16i& acc0, v16i& acc1) {
+        v4i fa[SETK];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc0[r] = 0, acc1[r] = 0;
-            for (int s = 0; s < a.ks; s += 4) {
-                v4i fa[4], f0[4], f1[4];
+        for (int u = 0; u < SETK; ++u) fa[u] = *reinterpret_cast<const v4i*>(arow + (s + u) * 32);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int su = s + u < a.ks ? s + u : a.ks - 1;
-                    f0[u] = w0[(int64_t)su * 64];
-                    f1[u] = w1[(int64_t)su * 64];
-                    const v4i av = *reinterpret_cast<const v4i*>(arow + su * 32);
-                    fa[u] = s + u < a.ks ? av : zero4;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u], f0[u], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u], f1[u], acc1, 0, 0, 0);
-                }
-            }
-            finish(t, [&](int i) { return acc0[i]; }, 0, std::integral_constant<int, 16>());
-            if (two) finish(t + 1, [&](int i) { return acc1[i]; }, 0, std::integral_constant<int, 16>());
+        for (int u = 0; u < SETK; ++u) {
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u], w[0][u], acc0, 0, 0, 0);
+            if (NTW == 2) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u], w[1][u], acc1, 0, 0, 0);
         }
-    } else {
-        // few tiles per block (single utterance): the four waves split K, partial tiles meet in LDS (exact: i32)
-        const int per = (a.ks + 3) / 4;
-        const int s0 = wave * per, s1 = s0 + per < a.ks ? s0 + per : a.ks;
-        for (int t = t_lo; t < t_hi; ++t) {
-            const v4i* w0 = reinterpret_cast<const v4i*>(a.wf) + (int64_t)t * a.ks * 64 + lane;
-            v16i acc;
+    };
+    for (int t = t_first; t < t_hi; t += tstep) {
+        v16i acc0, acc1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0;
-            for (int s = s0; s < s1; s += 4) {
-                v4i fa[4], f0[4];
+        for (int r = 0; r < 16; ++r) acc0[r] = 0, acc1[r] = 0;
+        // sets alternate a, b; the request after this tile's last set is the NEXT tile's first one, so it travels while the
+        // results are stored
+        for (int s = ks0; s < ks1; s += 2 * SETK) {
+            // the scheduling barriers pin "request the next set, THEN issue this set's MFMAs": left alone, the scheduler sinks the
+            // loads next to their uses and waits for each one with the matrix pipe idle
+            req(w_b);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(w_a, s, acc0, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+            req(w_a);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(w_b, s + SETK, acc0, acc1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!KSPLIT) {
+            finish(t, [&](int i) { return acc0[i]; }, 0, std::integral_constant<int, 16>());
+            if (t + 1 < t_hi) finish(t + 1, [&](int i) { return acc1[i]; }, 0, std::integral_constant<int, 16>());
+        } else {
+            // the four waves split K: partial tiles meet in LDS (exact: i32), each wave finishes four accumulator rows
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int su = s + u < s1 ? s + u : s1 - 1;
-                    f0[u] = w0[(int64_t)su * 64];
-                    const v4i av = *reinterpret_cast<const v4i*>(arow + su * 32);
-                    fa[u] = s + u < s1 ? av : zero4;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u], f0[u], acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s_red[(wave * 16 + r) * 64 + lane] = acc[r];
+            for (int r = 0; r < 16; ++r) s_red[(wave * 16 + r) * 64 + lane] = acc0[r];
             __syncthreads();
             finish(t, [&](int i) {
                 const int r = 4 * wave + i;
@@ -1125,18 +1154,20 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
     LELE_TRY(qprof_mark(ctx, 1));
 
-    // ---- one launch: quantise-on-load i8 GEMM (declared-immutable weights, a tile of 32 x K bytes must fit the LDS)
-    const int kp32 = (int)((k + 31) & ~int64_t(31));
-    const bool onepass = weight_int8->mem == LELE_MEM_WEIGHT && k >= 8 && (size_t)kOpBM * (kp32 + 16) <= 150 * 1024 &&
+    // ---- one launch: quantise-on-load i8 GEMM (declared-immutable weights, a tile of 32 x K bytes must fit the LDS).  K is
+    // padded to a multiple of 512 (zero activation bytes x zero weight bytes) so that every wave's k-range splits into an even
+    // number of equal register sets: tiny K would be mostly padding and stays on the three-kernel chain
+    const int kp32 = (int)((k + 511) & ~int64_t(511));
+    const bool onepass = weight_int8->mem == LELE_MEM_WEIGHT && k >= 256 && (size_t)kOpBM * (kp32 + 16) <= 150 * 1024 &&
                          rows < (int64_t(1) << 31) && env_int("LELE_HIP_QLINEAR_ONEPASS", 1) != 0;
     if (onepass) {
         const int ks = kp32 / 32, nt = (int)((n + 31) / 32);
         FragW fw;
         LELE_TRY(get_frag_weights(ctx, weight_int8, (int)k, (int)n, ks, nt, &fw));
         const int64_t row_blocks = (rows + kOpBM - 1) / kOpBM;
-        // enough workgroups to fill the chip a few times over (they are small: 32 x K bytes of LDS), as few column groups as
-        // that allows (every group of a row block repeats the block's quantisation)
-        const int64_t target = env_int("LELE_HIP_ONEPASS_WGS", 3 * ctx->num_cus);
+        // enough workgroups to fill the chip (they are small: 32 x K bytes of LDS, several per CU), as few column groups as that
+        // allows (every group of a row block repeats the block's quantisation)
+        const int64_t target = env_int("LELE_HIP_ONEPASS_WGS", 2 * ctx->num_cus);
         int nsplit = (int)std::min<int64_t>(nt, std::max<int64_t>(1, (target + row_blocks - 1) / row_blocks));
         const int tpw = (nt + nsplit - 1) / nsplit;
         nsplit = (nt + tpw - 1) / tpw;
@@ -1157,15 +1188,23 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
         const size_t lds = (size_t)kOpBM * (kp32 + 16);
         const bool ksplit = tpw < env_int("LELE_HIP_ONEPASS_KSPLIT_BELOW", 4);
         const dim3 grid((unsigned)nsplit, (unsigned)row_blocks);
-        if (ksplit) {
-            if (lds > 48 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(&qlinear_onepass_kernel<true>), (int)lds));
-            hipLaunchKernelGGL(qlinear_onepass_kernel<true>, grid, dim3(256), lds, ctx->stream, oa, epi);
+        LELE_TRY(qprof_mark(ctx, 2));  // no separate row-quantisation stage: the whole kernel is booked as the GEMM stage
+#define LELE_ONEPASS(KS_, SETK_)                                                                                          \
+    do {                                                                                                                \
+        auto kern = qlinear_onepass_kernel<KS_, SETK_>;                                                                  \
+        if (lds + ((KS_) ? 16384 : 0) > 60 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)); \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, oa, epi);                                            \
+    } while (0)
+        if (ksplit) {  // k-steps per wave = ks / 4 (a multiple of 4): the largest set size that divides it into an even count
+            const int per = ks / 4;
+            if (per % 16 == 0) LELE_ONEPASS(true, 8);
+            else if (per % 8 == 0) LELE_ONEPASS(true, 4);
+            else LELE_ONEPASS(true, 2);
         } else {
-            if (lds > 64 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(&qlinear_onepass_kernel<false>), (int)lds));
-            hipLaunchKernelGGL(qlinear_onepass_kernel<false>, grid, dim3(256), lds, ctx->stream, oa, epi);
+            LELE_ONEPASS(false, 4);  // ks is a multiple of 16: an even number of 4-step sets
         }
+#undef LELE_ONEPASS
         LELE_HIP_CHECK(hipGetLastError());
-        LELE_TRY(qprof_mark(ctx, 2));
         LELE_TRY(qprof_mark(ctx, 3));
         if (oa.stat_out) {
             out->rowstat_rows = nstat;

@@ -88,7 +88,9 @@ class PreparedWeights:
     """PreparedWeights (quantization.rs:198-215): a u8 weight matrix packed once for the i8 matrix cores"""
 
     def __init__(self, ctx, h, k, n):
+        import weakref
         self.ctx, self._h, self.k, self.n = ctx, h, k, n
+        ctx._graphs.append(weakref.ref(self))  # closed with the ctx (the handle points into it), like its graphs
 
     def close(self):
         if self._h:

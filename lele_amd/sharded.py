@@ -4,8 +4,14 @@ Every utterance (and image) is a complete forward with no cross-item state, so r
 global batch and runs the single-GPU path on it.  The one exchange the recogniser has is at the very end: an all-gather of
 the DECODED token ids (i32, a few hundred bytes per utterance -- greedy arg-max and the blank / special-token filter already
 ran on the device, `lele_hip_argmax_last` + `lele_hip_token_filter`), so that every rank (or just rank 0) holds the
-transcripts of the whole batch.  `torch.distributed` is the transport: backend "nccl" is RCCL over xGMI on the GPU box, "gloo"
-in the CPU tests.  Logits never cross a link."""
+transcripts of the whole batch.  Logits never cross a link.
+
+Two transports for the same packed rows:
+  * `all_gather_ids_rccl` -- the product path: the C ABI's own communicator (`lele_hip_comm_*`, RCCL over xGMI, no torch).  The
+    ids are packed ON THE DEVICE (count column + ids, -1 padding) and gathered on the ctx stream; only the gathered block is
+    copied to the host, once.
+  * `all_gather_ids` -- the same rows through `torch.distributed` (backend "gloo"), which is how the CPU tests exercise the
+    N > 1 logic without a GPU."""
 import numpy as np
 
 
@@ -64,5 +70,35 @@ def all_gather_ids(ids, counts, total, dist=None, device="cpu"):
         rlo, rhi = shard_range(total, r, world)
         if len(got) != rhi - rlo:
             raise RuntimeError("all_gather_ids: rank %d sent %d utterances, its shard has %d" % (r, len(got), rhi - rlo))
+        out += got
+    return out
+
+
+def all_gather_ids_rccl(ids, counts, total, comm, ctx, bufs=None):
+    """The exchange step on the device.  ids: device int32 [n, W] (kept ids first, -1 after), counts: device int32 [n] -- what
+    `kernels.token_filter` returned on this rank for its `shard_range(total, rank, world)` utterances.  Rows are packed as
+    [count | ids] on the device, padded to ceil(total / world) rows (ragged last shards) and to the widest shard (one MAX
+    all-reduce of a scalar), gathered with ONE `lele_hip_comm_allgather_i32` on the ctx stream, and read back once.
+    `bufs`: optional list of 4 LeleBufs to reuse across steps (no allocation in the steady state)."""
+    from . import kernels as K
+    rank, world = comm.rank, comm.world
+    lo, hi = shard_range(total, rank, world)
+    n, w = ids.shape
+    if n != hi - lo:
+        raise ValueError("all_gather_ids_rccl: rank %d owns %d utterances but was given %d" % (rank, hi - lo, n))
+    b = bufs or [ctx.buf() for _ in range(4)]
+    width = comm.allreduce_max(w) if world > 1 else w
+    rows = -(-total // world)
+    packed = K.concat([K.reshape(counts, [n, 1]), ids], 1, out=b[0], ctx=ctx)                 # [n, 1 + w]
+    if width > w or rows > n:  # -1 fill: count -1 marks a padding row, id -1 a padding column
+        packed = K.pad(packed, [0, 0, rows - n, width - w], np.array([-1], np.int32), "constant", out=b[1], ctx=ctx)
+    flat = K.reshape(packed, [rows * (1 + width)])
+    everything = comm.allgather_i32(flat.raw(), out=b[2]).numpy().reshape(world, rows, 1 + width)  # the one D2H copy
+    out = []
+    for r in range(world):
+        got = unpack_ids(everything[r])
+        rlo, rhi = shard_range(total, r, world)
+        if len(got) != rhi - rlo:
+            raise RuntimeError("all_gather_ids_rccl: rank %d sent %d utterances, its shard has %d" % (r, len(got), rhi - rlo))
         out += got
     return out

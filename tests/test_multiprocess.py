@@ -152,3 +152,24 @@ def test_pack_ids_rejects_what_does_not_fit():
         pack_ids(ids, np.array([2, 7], np.int32), 3, 4)
     with pytest.raises(ValueError):
         all_gather_ids(ids, counts, 3)
+
+
+def test_bench_spawns_its_own_ranks_and_refuses_a_mismatched_world():
+    """`python bench.py --gpus N` with no launcher environment starts N ranks itself and rank 0 prints n_gpus = N; under a
+    launcher whose WORLD_SIZE differs from --gpus it refuses to run (--gpus was parsed and never used).  --dry-run
+    keeps the launcher / rendezvous / fence / MAX-over-ranks logic and skips the GPU work."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    bench_py = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    out = subprocess.run([sys.executable, bench_py, "--gpus", "3", "--steps", "7", "--warmup", "2", "--dry-run"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout          # exactly ONE line, from rank 0
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 3 and rec["steps"] == 7 and rec["warmup"] == 2
+    assert abs(rec["value"] - 0.003) < 1e-9      # MAX over the three ranks' (rank + 1) ms
+    bad = subprocess.run([sys.executable, bench_py, "--gpus", "4", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert bad.returncode != 0 and "refusing" in bad.stderr

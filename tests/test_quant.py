@@ -257,7 +257,8 @@ class _env:
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 93, 560, 1536), (1, 504, 512, 512), (1, 504, 512, 2048), (1, 504, 2048, 512), (32, 171, 512, 2048),
                                    (32, 171, 2048, 512), (4, 171, 560, 1536), (3, 17, 64, 40), (2, 40, 37, 19), (1, 1, 8, 1), (1, 33, 100, 130),
-                                   (5, 32, 96, 64), (2, 64, 128, 33), (1, 504, 512, 25055)])
+                                   (5, 32, 96, 64), (2, 64, 128, 33), (1, 504, 512, 25055), (3, 50, 256, 70), (2, 33, 300, 64),
+                                   (2, 70, 1001, 96), (1, 9, 4096, 32)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_device_onepass_quantized_linear_bit_exact(ctx, orc, shape, relu):
     """declared-immutable weights take qlinear_onepass_kernel (quantise-on-load i8 GEMM): bit-exact against the oracle, and
@@ -288,8 +289,8 @@ def test_onepass_statistics_feed_the_next_quantised_linear(ctx, orc):
     oracle on the same input, for slices that straddle row blocks, every grouping, and after the buffer was rewritten."""
     from lele_amd import kernels as Kk
     rng = np.random.default_rng(123)
-    for b, m, k, h, n in ((32, 171, 512, 2048, 512), (1, 504, 512, 2048, 512), (3, 40, 64, 96, 40), (2, 32, 64, 64, 64), (5, 100, 128, 70, 33),
-                          (4, 31, 64, 64, 32)):
+    for b, m, k, h, n in ((32, 171, 512, 2048, 512), (1, 504, 512, 2048, 512), (3, 40, 256, 288, 40), (2, 32, 256, 256, 64), (5, 100, 512, 270, 33),
+                          (4, 31, 256, 256, 32), (3, 40, 64, 96, 40)):
         x = (rng.standard_normal((b, m, k)) * rng.uniform(0.5, 3.0, (b, 1, 1))).astype(np.float32)
         w1, w2 = _qw(rng, k, h), _qw(rng, h, n)
         hid_ref = orc.fused_quantized_linear(x, w1[0].arr, w1[1].arr, [128.0], w1[3].arr, True)

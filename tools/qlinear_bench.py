@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Per-call time of fused_quantized_linear at the SenseVoice shapes, free of host overhead: 20 calls are recorded into one
+hipGraph and the replay is timed with HIP events on the ctx stream.  Variants are selected through the library's tuning
+environment (read per call): the three-kernel chain vs the one-pass kernel at several workgroup targets.
+
+    gpurun -- 'python tools/qlinear_bench.py --out gpurun_out/qlinear.json'
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--calls", type=int, default=20)
+    args = ap.parse_args()
+    import lele_amd
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    ctx = lele_amd._lib.Ctx(0)
+    rng = np.random.default_rng(0)
+    shapes = [("c4 qkv", 32, 171, 512, 1536, False), ("c4 out", 32, 171, 512, 512, False), ("c4 ffn1", 32, 171, 512, 2048, True),
+              ("c4 ffn2", 32, 171, 2048, 512, False), ("c3 qkv", 1, 504, 512, 1536, False), ("c3 out", 1, 504, 512, 512, False),
+              ("c3 ffn1", 1, 504, 512, 2048, True), ("c3 ffn2", 1, 504, 2048, 512, False)]
+    variants = [("chain", {"LELE_HIP_QLINEAR_ONEPASS": "0"}), ("onepass wgs=256", {"LELE_HIP_ONEPASS_WGS": "256"}),
+                ("onepass wgs=512 (default)", {}), ("onepass wgs=1024", {"LELE_HIP_ONEPASS_WGS": "1024"}),
+                ("onepass wgs=2048", {"LELE_HIP_ONEPASS_WGS": "2048"}),
+                ("onepass wgs=512 no-ksplit", {"LELE_HIP_ONEPASS_KSPLIT_BELOW": "0"})]
+    res = []
+    for name, b, m, k, n, relu in shapes:
+        x = ctx.buf().upload(rng.standard_normal((b, m, k)).astype(np.float32))
+        g, be = Weight(np.ones(k, np.float32)), Weight(np.zeros(k, np.float32))
+        xn = K.layer_norm(x, g, be, -1, 1e-5, out=ctx.buf(), ctx=ctx)     # leaves row statistics, as in the model
+        w = (Weight(np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32)),
+             Weight((np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32)), Weight(np.array([128.0], np.float32)),
+             Weight((rng.standard_normal(n) * 0.02).astype(np.float32)))
+        ob = ctx.buf()
+        row = {"shape": name, "rows": b * m, "k": k, "n": n}
+        ref = None
+        for vname, env in variants:
+            old = {kk: os.environ.get(kk) for kk in env}
+            os.environ.update(env)
+            try:
+                out = K.fused_quantized_linear(xn, *w, relu, out=ob, ctx=ctx)
+                got = out.numpy().copy()
+                if ref is None:
+                    ref = got
+                same = bool(np.array_equal(got, ref))
+                ctx.sync()
+                ctx.graph_begin()
+                for _ in range(args.calls):
+                    K.fused_quantized_linear(xn, *w, relu, out=ob, ctx=ctx)
+                gr = ctx.graph_end()
+                gr.launch()
+                ctx.sync()
+                ctx.timer_start()
+                for _ in range(10):
+                    gr.launch()
+                us = ctx.timer_stop() * 1e3 / (10 * args.calls)
+                gr.close()
+            finally:
+                for kk, v in old.items():
+                    if v is None:
+                        os.environ.pop(kk, None)
+                    else:
+                        os.environ[kk] = v
+            byts = 4 * b * m * k + k * n + 8 * n + 4 * b * m * n
+            row[vname] = {"us": round(us, 2), "same_bits": same, "hbm_gbs": round(byts / us / 1e3, 1),
+                          "tops": round(2 * b * m * k * n / us / 1e6, 1)}
+        print(json.dumps(row), flush=True)
+        res.append(row)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        json.dump(res, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -83,45 +83,79 @@ class Encoder:
     def ql(self, x, p, relu, slot):
         return self.K.fused_quantized_linear(x, p.w, p.scale, p.zero, p.bias, relu, out=self.ws[slot], ctx=self.ctx)
 
-    def forward(self, feats):
-        """feats: [B, T, 560] device tensor (LFR + CMVN output) -> logits [B, T+4, VOCAB]"""
+    def embed(self, feats):
+        """[B, T, 560] -> [B, T+4, 560]: the four prompt embeddings prepended"""
         K, ctx, ws = self.K, self.ctx, self.ws
         b = feats.shape[0]
         prompt = K.expand(self.prompt, [b, 4, 560], out=ws[15], ctx=ctx) if b > 1 else self.prompt
-        x = K.concat([prompt, feats], 1, out=ws[0], ctx=ctx)
-        t = x.shape[1]
-        for i, L in enumerate(self.layers):
-            xin = x
-            xn = K.layer_norm(xin, L.ln1[0], L.ln1[1], -1, 1e-5, out=ws[1], ctx=ctx)
-            qkv = self.ql(xn, L.qkv, False, 2)                                      # [B,T,1536]
-            q, k, v = K.split(qkv, 2, [D, D, D], outputs=[ws[3], ws[4], ws[5]], ctx=ctx)
-            # FSMN memory: depthwise conv over time on v, plus v
-            vt = K.transpose(v, [0, 2, 1], out=ws[6], ctx=ctx)                      # [B,512,T]
-            mem = K.conv1d(vt, L.fsmn, None, [1], D, [FSMN_K // 2, FSMN_K // 2], [1], out=ws[7], ctx=ctx)
-            mem = K.transpose(mem, [0, 2, 1], out=ws[6], ctx=ctx)                   # [B,T,512]
-            mem = K.add(mem, v, out=ws[7], ctx=ctx)
-            # attention
-            qh = K.transpose(K.reshape(q, [b, t, HEADS, DH]), [0, 2, 1, 3], out=ws[8], ctx=ctx)   # [B,4,T,128]
-            kh = K.transpose(K.reshape(k, [b, t, HEADS, DH]), [0, 2, 3, 1], out=ws[9], ctx=ctx)   # [B,4,128,T]
-            vh = K.transpose(K.reshape(v, [b, t, HEADS, DH]), [0, 2, 1, 3], out=ws[10], ctx=ctx)
-            sc = K.matmul(qh, kh, out=ws[3], ctx=ctx)                               # [B,4,T,T]
-            sc = K.mul(sc, self.scale, out=ws[4], ctx=ctx)
-            pr = K.softmax(sc, -1, out=ws[3], ctx=ctx)
-            av = K.matmul(pr, vh, out=ws[4], ctx=ctx)                               # [B,4,T,128]
-            av = K.reshape(K.transpose(av, [0, 2, 1, 3], out=ws[5], ctx=ctx), [b, t, D])
-            att = self.ql(av, L.out, False, 8)
-            slot_x = 11 if i % 2 == 0 else 12
-            if L.d_in == D:
-                att = K.add(att, mem, out=ws[9], ctx=ctx)
-                x = K.add(att, xin, out=ws[slot_x], ctx=ctx)
-            else:  # the first layer changes width (560 -> 512): no residual
-                x = K.add(att, mem, out=ws[slot_x], ctx=ctx)
-            xn = K.layer_norm(x, L.ln2[0], L.ln2[1], -1, 1e-5, out=ws[1], ctx=ctx)
-            h = self.ql(xn, L.ffn1, True, 2)
-            h = self.ql(h, L.ffn2, False, 3)
-            x = K.add(x, h, out=ws[13 if i % 2 == 0 else 14], ctx=ctx)
-        xn = K.layer_norm(x, self.ln_out[0], self.ln_out[1], -1, 1e-5, out=ws[1], ctx=ctx)
+        return K.concat([prompt, feats], 1, out=ws[0], ctx=ctx)
+
+    def layer(self, x, i, taps=None):
+        """one SAN-M layer, one C-ABI call per node (the sequence lele's generated code would issue).  taps: optional dict that
+        receives host copies of the intermediates (tests compare them with the oracle op by op)"""
+        K, ctx, ws, L = self.K, self.ctx, self.ws, self.layers[i]
+        b, t = x.shape[0], x.shape[1]
+        xin = x
+        xn = K.layer_norm(xin, L.ln1[0], L.ln1[1], -1, 1e-5, out=ws[1], ctx=ctx)
+        qkv = self.ql(xn, L.qkv, False, 2)                                      # [B,T,1536]
+        if taps is not None:
+            taps.update(x=xin.numpy(), xn=xn.numpy(), qkv=qkv.numpy())
+        q, k, v = K.split(qkv, 2, [D, D, D], outputs=[ws[3], ws[4], ws[5]], ctx=ctx)
+        # FSMN memory: depthwise conv over time on v, plus v
+        vt = K.transpose(v, [0, 2, 1], out=ws[6], ctx=ctx)                      # [B,512,T]
+        mem = K.conv1d(vt, L.fsmn, None, [1], D, [FSMN_K // 2, FSMN_K // 2], [1], out=ws[7], ctx=ctx)
+        mem = K.transpose(mem, [0, 2, 1], out=ws[6], ctx=ctx)                   # [B,T,512]
+        mem = K.add(mem, v, out=ws[7], ctx=ctx)
+        # attention
+        qh = K.transpose(K.reshape(q, [b, t, HEADS, DH]), [0, 2, 1, 3], out=ws[8], ctx=ctx)   # [B,4,T,128]
+        kh = K.transpose(K.reshape(k, [b, t, HEADS, DH]), [0, 2, 3, 1], out=ws[9], ctx=ctx)   # [B,4,128,T]
+        vh = K.transpose(K.reshape(v, [b, t, HEADS, DH]), [0, 2, 1, 3], out=ws[10], ctx=ctx)
+        sc = K.matmul(qh, kh, out=ws[3], ctx=ctx)                               # [B,4,T,T]
+        if taps is not None:
+            taps.update(mem=mem.numpy(), sc_raw=sc.numpy())
+        sc = K.mul(sc, self.scale, out=ws[4], ctx=ctx)
+        if taps is not None:
+            taps.update(sc=sc.numpy())                                          # ws[4] is reused by the P.V product below
+        pr = K.softmax(sc, -1, out=ws[3], ctx=ctx)
+        av = K.matmul(pr, vh, out=ws[4], ctx=ctx)                               # [B,4,T,128]
+        if taps is not None:
+            taps.update(pr=pr.numpy(), av_heads=av.numpy())
+        av = K.reshape(K.transpose(av, [0, 2, 1, 3], out=ws[5], ctx=ctx), [b, t, D])
+        att = self.ql(av, L.out, False, 8)
+        if taps is not None:
+            taps.update(av=av.numpy(), att=att.numpy())
+        slot_x = 11 if i % 2 == 0 else 12
+        if L.d_in == D:
+            att = K.add(att, mem, out=ws[9], ctx=ctx)
+            x = K.add(att, xin, out=ws[slot_x], ctx=ctx)
+        else:  # the first layer changes width (560 -> 512): no residual
+            x = K.add(att, mem, out=ws[slot_x], ctx=ctx)
+        xn = K.layer_norm(x, L.ln2[0], L.ln2[1], -1, 1e-5, out=ws[1], ctx=ctx)
+        h = self.ql(xn, L.ffn1, True, 2)
+        h2 = self.ql(h, L.ffn2, False, 3)
+        y = K.add(x, h2, out=ws[13 if i % 2 == 0 else 14], ctx=ctx)
+        if taps is not None:
+            taps.update(x1=x.numpy(), xn2=xn.numpy(), h=h.numpy(), h2=h2.numpy(), y=y.numpy())
+        return y
+
+    def head(self, x):
+        xn = self.K.layer_norm(x, self.ln_out[0], self.ln_out[1], -1, 1e-5, out=self.ws[1], ctx=self.ctx)
         return self.ql(xn, self.ctc, False, 2)
+
+    def forward(self, feats, taps=None):
+        """feats: [B, T, 560] device tensor (LFR + CMVN output) -> logits [B, T+4, VOCAB].  taps: {layer index: dict} to fill"""
+        x = self.embed(feats)
+        for i in range(len(self.layers)):
+            x = self.layer(x, i, None if taps is None else taps.get(i))
+        return self.head(x)
+
+
+def encoder_arrays(enc):
+    """the Encoder's weights as plain numpy arrays, in the layout oracle/sensevoice_ref.py consumes"""
+    ql = lambda p: (p.w.arr, p.scale.arr, p.zero.arr, p.bias.arr)  # noqa: E731
+    return {"prompt": enc.prompt.arr, "ln_out": (enc.ln_out[0].arr, enc.ln_out[1].arr), "ctc": ql(enc.ctc),
+            "layers": [{"d_in": L.d_in, "ln1": (L.ln1[0].arr, L.ln1[1].arr), "ln2": (L.ln2[0].arr, L.ln2[1].arr), "qkv": ql(L.qkv),
+                        "out": ql(L.out), "ffn1": ql(L.ffn1), "ffn2": ql(L.ffn2), "fsmn": L.fsmn.arr} for L in enc.layers]}
 
 
 def encoder_onnx(enc, batch):
