@@ -202,11 +202,24 @@ __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x,
     const bool vec4 = (k & 3) == 0 && (((uintptr_t)x & 15) == 0);  // every row start is then 16-byte aligned
     int sum = 0;
     if (fast) {
+        unsigned usum = 0;  // sum of q over the chunks quantised the short way
+        int nfast = 0;
 #pragma unroll
         for (int u = 0; u < MAXC; ++u)
             if (u < nch) {
                 const int c = lane * 4 + 256 * u;
-                if (c < kp) {
+                if (MODE == 0 && c + 3 < simd_k) {
+                    // four elements inside the SIMD body: fma, round-to-nearest-even, v_cvt_pk_u8_f32 (saturates to [0, 255] = the
+                    // clamp, and packs); per four elements one xor 0x80808080 (q - 128 as i8) and one v_sad_u8 (their sum)
+                    unsigned pk = 0;
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(pre[u].x, q.inv_scale, q.zp)), 0, pk);
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(pre[u].y, q.inv_scale, q.zp)), 1, pk);
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(pre[u].z, q.inv_scale, q.zp)), 2, pk);
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(pre[u].w, q.inv_scale, q.zp)), 3, pk);
+                    usum = __builtin_amdgcn_sad_u8(pk, 0u, usum);
+                    nfast += 4;
+                    *reinterpret_cast<unsigned*>(dst + c) = pk ^ 0x80808080u;
+                } else if (c < kp) {
                     const float xv[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
                     int packed = 0;
 #pragma unroll
@@ -229,6 +242,7 @@ __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x,
                     *reinterpret_cast<int*>(dst + c) = packed;
                 }
             }
+        sum += (int)usum - 128 * nfast;
     } else
     for (int c = lane * 4; c < kp; c += 256) {
         float xv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -314,6 +328,7 @@ struct IgemmEpi {
     const float* res1 = nullptr;
     const float* res2 = nullptr;
     float* blockstat = nullptr;  // small-problem kernel: one {min, max} pair per workgroup (common.h, LeleBuf::rowstat)
+    int flags = 0;               // developer A/B switches (LELE_HIP_IGEMM_FLAGS): 1 = column terms after the K loop, 2 = previous epilogue
     // Everything that depends only on the row (slice parameters, row-sum term, output row pointer) or only on the
     // column (column sum, weight scale, bias) is computed once per row / column of a thread's tile, not per element.
     struct RowCtx {
@@ -349,6 +364,16 @@ struct IgemmEpi {
         const int total = acc + r.rterm + r.ca * c.colsum;
         float vf = (float)total;  // _mm256_cvtepi32_ps
         // combined_scale[j] = dyn_scale * weight_scale[j], then one mul (dyn_scale is 1.0 when there is no dynamic range)
+        if (wscale) vf = vf * (r.dyn_scale * c.ws);
+        if (bias) vf = vf + c.bias;
+        if (relu) vf = vf > 0.0f ? vf : 0.0f;
+        return vf;
+    }
+    // the same value with the zero-point product on the 24-bit multiplier (full rate): |128 - zp_a| <= 128 and a column sum of
+    // at most 2^23 (K <= 65536) are exact there
+    __device__ __forceinline__ float value24(const RowCtx& r, const ColCtx& c, int acc) const {
+        const int total = acc + r.rterm + __mul24(r.ca, c.colsum);
+        float vf = (float)total;
         if (wscale) vf = vf * (r.dyn_scale * c.ws);
         if (bias) vf = vf + c.bias;
         if (relu) vf = vf > 0.0f ? vf : 0.0f;
@@ -441,6 +466,17 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
+    // the tiles' column terms (column sum, weight scale, bias): requested before the K loop and pinned there -- fetched after it
+    // every block would wait one full memory round trip with nothing else to do
+    IgemmEpi::ColCtx cc[TNT];
+    int cols[TNT];
+#pragma unroll
+    for (int j = 0; j < TNT; ++j) cols[j] = n0 + wn * TNT * 32 + j * 32 + l31;
+    if (!(epi.flags & 1)) {
+#pragma unroll
+        for (int j = 0; j < TNT; ++j) cc[j] = epi.col_ctx(cols[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     const int nk = (kp + BKB - 1) / BKB;
     gload(0);
     lstore(0);
@@ -474,13 +510,11 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
         if (kt + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
     }
-    IgemmEpi::ColCtx cc[TNT];
-    int cols[TNT];
+    if (epi.flags & 1) {
 #pragma unroll
-    for (int j = 0; j < TNT; ++j) {
-        cols[j] = n0 + wn * TNT * 32 + j * 32 + l31;
-        cc[j] = epi.col_ctx(cols[j]);
+        for (int j = 0; j < TNT; ++j) cc[j] = epi.col_ctx(cols[j]);
     }
+    if (epi.flags & 2) {
     if (epi.res1) {  // residual operands: four rows at a time, their loads issued together before the stores
 #pragma unroll
         for (int i = 0; i < TMT; ++i)
@@ -522,6 +556,55 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
             for (int j = 0; j < TNT; ++j)
                 if (cols[j] < n) epi.store(rc, cc[j], cols[j], acc[i][j][r]);
         }
+        return;
+    }
+    // epilogue: straight-line per tile -- one uniform 64-bit base + 32-bit element offsets, the zero-point product on the 24-bit
+    // multiplier, every residual operand of a tile requested before its first store (loads and stores retire through ONE
+    // in-order counter: a load issued after a store cannot be waited for without waiting for the store)
+    const int rows_here = (int)(rows - m0 < BM ? rows - m0 : BM);
+    float* const obase = epi.out + m0 * (int64_t)n;
+    const unsigned nu = (unsigned)n;
+    auto epilogue = [&](auto nres_c) {
+        constexpr int NRES = decltype(nres_c)::value;
+        const float* const r1base = NRES > 0 ? epi.res1 + m0 * (int64_t)n : nullptr;
+        const float* const r2base = NRES > 1 ? epi.res2 + m0 * (int64_t)n : nullptr;
+#pragma unroll
+        for (int i = 0; i < TMT; ++i) {
+            const int rbase = wm * TMT * 32 + i * 32 + 4 * hv;
+            float r1[NRES > 0 ? 16 : 1][TNT], r2[NRES > 1 ? 16 : 1][TNT];
+            if (NRES > 0) {
+                const int last = rows_here - 1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = rbase + (r & 3) + 8 * (r >> 2);
+                    const unsigned rowoff = (unsigned)(lr < last ? lr : last) * nu;
+#pragma unroll
+                    for (int j = 0; j < TNT; ++j) {
+                        const unsigned at = rowoff + (unsigned)(cols[j] < n ? cols[j] : n - 1);
+                        r1[r][j] = r1base[at];
+                        if (NRES > 1) r2[r][j] = r2base[at];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = rbase + (r & 3) + 8 * (r >> 2);
+                const IgemmEpi::RowCtx rc{s_ca[lr], s_rterm[lr], s_ds[lr], nullptr};
+                const bool rok = lr < rows_here;
+                const unsigned rowoff = (unsigned)lr * nu;
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) {
+                    float v = epi.value24(rc, cc[j], acc[i][j][r]);
+                    if (NRES > 0) v = v + r1[r][j];
+                    if (NRES > 1) v = v + r2[r][j];
+                    if (rok && cols[j] < n) obase[rowoff + (unsigned)cols[j]] = v;
+                }
+            }
+        }
+    };
+    if (!epi.res1) epilogue(std::integral_constant<int, 0>());
+    else if (!epi.res2) epilogue(std::integral_constant<int, 1>());
+    else epilogue(std::integral_constant<int, 2>());
 }
 
 
@@ -536,7 +619,6 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
 // is IgemmEpi's (zero-point algebra, (float)acc * (dyn_scale*w_scale[j]), + bias, ReLU, residual adds) and additionally
 // publishes {min, max} of every output row per column group, so that a quantised linear reading THIS result needs no range
 // pass either (ffn1 -> ffn2).  Bit-exact with the three-kernel chain (tests/test_quant.py runs both).
-constexpr int kOpBM = 32;
 
 // weights [K][N] (u8 values as f32) -> fragment-major i8: block (ct, ks) = columns [32ct, +32) x k [32ks, +32), lane l of the
 // block holds column 32ct + (l & 31), k = 32ks + 16(l >> 5) + [0, 16).  One thread per (column, 16-k chunk).
@@ -576,51 +658,111 @@ __global__ void wcolsum_kernel(const float* __restrict__ w, int k, int n, int* _
 struct OnepassArgs {
     const float* x;
     int64_t rows;
-    int k, kp;  // kp = K rounded up to 32
+    int k, kp;  // kp = K rounded up to 512
     int m;      // rows per batch slice
     const float* partial;  // {min, max} pairs, nblk per slice, slice-major
     int nblk;
     const int8_t* wf;
     int n, nt, ks;   // nt = 32-column tiles, ks = 32-k steps
-    int tpw;         // column tiles per workgroup (blockIdx.x-th group)
+    int tpw;         // column tiles per workgroup
+    int nsplit;      // column groups per row block
+    int row_blocks;
     float* stat_out; // [slices][stat_per_slice][2] or NULL: {min, max} of the result per (slice, row block, column group)
     int stat_per_slice;
+    int dbg;         // developer switch (LELE_HIP_ONEPASS_DEBUG): 1 = skip the quantisation, 2 = skip the MFMA loop, 4 = skip the epilogue
 };
 
-// KSPLIT = false: the waves of a block take column tiles two at a time (one A fragment feeds two accumulators), all of K each.
+// min / max of a slice's `nblk` pairs, by ONE wave (every wave of a block repeats it: cheaper than a barrier pair, and the
+// loads of several slices can be in flight together).  lane = 0..63.
+struct MinMax {
+    float mn, mx;
+};
+template <int NU>
+__device__ __forceinline__ void pairs_issue(const float2* pp, int nblk, int lane, float2 (&v)[NU]) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int idx = lane + 64 * u;
+        v[u] = pp[idx < nblk ? idx : nblk - 1];  // clamped: a repeated pair changes nothing
+    }
+}
+template <int NU>
+__device__ __forceinline__ MinMax pairs_reduce(const float2* pp, int nblk, int lane, const float2 (&v)[NU]) {
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        mn = v[u].x < mn ? v[u].x : mn;
+        mx = v[u].y > mx ? v[u].y : mx;
+    }
+    for (int i = 64 * NU + lane; i < nblk; i += 64) {  // long lists (a LayerNorm's rows of a long utterance)
+        const float2 w = pp[i];
+        mn = w.x < mn ? w.x : mn;
+        mx = w.y > mx ? w.y : mx;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float p = __shfl_xor(mn, off), q = __shfl_xor(mx, off);
+        mn = p < mn ? p : mn;
+        mx = q > mx ? q : mx;
+    }
+    return MinMax{mn, mx};
+}
+
+// KSPLIT = false: the waves of a block take column tiles two at a time, all of K each; a block owns RB x 32 rows, so every
+//   weight fragment feeds RB MFMAs and every activation fragment two (bytes per MFMA and lane: 16 / RB from L2, 8 from LDS).
 // KSPLIT = true (few tiles per block: one utterance): the four waves split K, one tile at a time, partial tiles meet in LDS.
 // SETK = k-steps (32 k each) per register set of weight fragments; sets alternate between two register files so that the loads
 // of set i+1 are in flight while the MFMAs of set i issue.  The host guarantees (k-steps per wave) % (2 * SETK) == 0.
-template <bool KSPLIT, int SETK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 3 : 2))) void qlinear_onepass_kernel(OnepassArgs a, IgemmEpi epi) {
-    extern __shared__ __attribute__((aligned(16))) char op_lds[];  // A' tile: [32][kp + 16] bytes
-    __shared__ QParams s_prm[kOpBM];
-    __shared__ int s_ca[kOpBM], s_rterm[kOpBM];
-    __shared__ float s_ds[kOpBM];
-    __shared__ float s_mn[4], s_mx[4];
+// Grid: 1-D, XCD-aware -- workgroup L runs on XCD L % 8 (MI355X_MICROARCH.md); the column groups of one row block get the
+// same L % 8 and consecutive L / 8, so that the second and later reads of the block's f32 rows hit that XCD's L2.
+template <bool KSPLIT, int SETK, int RB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT || RB == 1 ? 3 : 2))) void qlinear_onepass_kernel(OnepassArgs a, IgemmEpi epi) {
+    constexpr int BM = 32 * RB;
+    constexpr int NTW = KSPLIT ? 1 : 2;  // tiles a wave works on at a time
+    static_assert(!KSPLIT || RB == 1, "K-split mode works on one row block");
+    extern __shared__ __attribute__((aligned(16))) char op_lds[];  // A' tile: [BM][kp + 16] bytes
+    __shared__ int4 s_row[BM];  // per row: {128 - zp_a, (128 - zp_b) * rowsum + K * ca * cb, bits of the dynamic scale, 0}
     __shared__ float s_stat[4][4];
     __shared__ int s_red[KSPLIT ? 4 * 16 * 64 : 1];
-    constexpr int NTW = KSPLIT ? 1 : 2;  // tiles a wave works on at a time
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hv = lane >> 5, l31 = lane & 31;
     const int pitch = a.kp + 16;
-    const int64_t m0 = (int64_t)blockIdx.y * kOpBM;
-    const int rows_here = (int)(a.rows - m0 < kOpBM ? a.rows - m0 : kOpBM);
-    const int t_lo = blockIdx.x * a.tpw, t_hi = t_lo + a.tpw < a.nt ? t_lo + a.tpw : a.nt;  // this block's column tiles (>= 1)
-    const v4i zero4 = {0, 0, 0, 0};
+    // (row block, column group) of this workgroup
+    int rblk, grp;
+    {
+        const unsigned L = blockIdx.x, xcd = L & 7u, j = L >> 3;
+        const unsigned full = (unsigned)a.row_blocks >> 3, rem = (unsigned)a.row_blocks & 7u;
+        // XCD x owns row blocks x, x + 8, ... (full or full + 1 of them); its workgroups j enumerate (block, group) pairs
+        const unsigned mine = full + (xcd < rem ? 1u : 0u);
+        const unsigned rb_local = j / (unsigned)a.nsplit;
+        if (rb_local >= mine) return;  // padding workgroups of the rounded-up grid (uniform: before any barrier)
+        rblk = (int)(rb_local * 8u + xcd);
+        grp = (int)(j - rb_local * (unsigned)a.nsplit);
+    }
+    const int64_t m0 = (int64_t)rblk * BM;
+    const int rows_here = (int)(a.rows - m0 < BM ? a.rows - m0 : BM);
+    const int t_lo = grp * a.tpw, t_hi = t_lo + a.tpw < a.nt ? t_lo + a.tpw : a.nt;  // this block's column tiles (>= 1)
     const v4i* wfv = reinterpret_cast<const v4i*>(a.wf) + lane;  // block (t, s) of the weights: wfv[(t * ks + s) * 64]
     const int per = a.ks / 4;                                      // K-split: k-steps per wave
     const int ks0 = KSPLIT ? wave * per : 0, ks1 = KSPLIT ? ks0 + per : a.ks;
-    const int t_first = KSPLIT ? t_lo : t_lo + 2 * wave, tstep = KSPLIT ? 1 : 8;
+    // work units of the block: tiles (K-split: all four waves on every tile) or tile pairs (taken round-robin by the waves).  The
+    // order is ROTATED by the row block: at any moment the row blocks then write different column ranges.  Left in lockstep, every
+    // block stores the same few 256-byte column strips at the same time, i.e. the whole chip queues on the same L2 / HBM channels
+    // (the row stride N*4 is a multiple of the channel interleave) -- measured 25 us instead of 6 for the 45 MB of ffn1.
+    const int ntile = t_hi - t_lo;
+    const int nunit = KSPLIT ? ntile : (ntile + 1) / 2, ustep = KSPLIT ? 1 : 4, u_first = KSPLIT ? 0 : wave;
+    const int urot = (rblk * 5 + grp) % nunit;
+    auto unit_tile = [&](int u) {
+        const int uu = u + urot;
+        return t_lo + (KSPLIT ? 1 : 2) * (uu < nunit ? uu : uu - nunit);
+    };
 
-    // ---- weight fragments: two register files, requested one set ahead.  (tq, sq) = position of the next set to request; past
+    // ---- weight fragments: two register files, requested one set ahead.  (uq, sq) = position of the next set to request; past
     // the wave's last set the position is clamped (a harmless repeated load instead of a branch, so that the hardware's
     // outstanding-load counter is exact on every path).  The first set does not depend on the activation: it is requested now
     // and travels during phases 0 and 1.
     v4i w_a[NTW][SETK], w_b[NTW][SETK];
-    int tq = t_first, sq = ks0;
+    int uq = u_first, sq = ks0;
     auto req = [&](v4i (&w)[NTW][SETK]) {
-        const int tc = tq < t_hi ? tq : t_hi - 1;
+        const int tc = unit_tile(uq < nunit ? uq : nunit - 1);
         const v4i* p0 = wfv + ((int64_t)tc * a.ks + sq) * 64;
         const v4i* p1 = (NTW == 2 && tc + 1 < t_hi) ? p0 + (int64_t)a.ks * 64 : p0;
 #pragma unroll
@@ -631,22 +773,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 3 
         sq += SETK;
         if (sq >= ks1) {
             sq = ks0;
-            tq += tstep;
+            uq += ustep;
         }
     };
     req(w_a);
 
-    // ---- phase 1a: this thread's first activation loads (8 lanes per row, 16 bytes each: 128-byte runs)
-    const int qrow = tid >> 3, sub = tid & 7;
-    const int64_t grow = m0 + qrow;
-    const bool live = grow < a.rows;
-    const float* xr = a.x + (live ? grow : a.rows - 1) * (int64_t)a.k;  // rows past the end re-read the last row; never stored
+    // ---- phase 0 (loads): the {min, max} pairs of the (at most two, when m >= BM) slices this block's rows belong to
+    const int64_t sl_lo = m0 / a.m;
+    const int nsl = (int)((m0 + rows_here - 1) / a.m - sl_lo) + 1;
+    const float2* pp0 = reinterpret_cast<const float2*>(a.partial) + sl_lo * (int64_t)a.nblk;
+    const float2* pp1 = pp0 + (nsl > 1 ? a.nblk : 0);
+    float2 pv0[4], pv1[4];
+    pairs_issue(pp0, a.nblk, lane, pv0);
+    pairs_issue(pp1, a.nblk, lane, pv1);
+
+    // ---- phase 1a: this thread's first activation loads.  8 lanes per row read 128-byte chunks (32 floats); row r starts at
+    // chunk 2r and wraps, so that the 32 rows of a pass touch 32 different 128-byte columns at a time: with every row on the
+    // same column the row stride (K*4, a multiple of the channel interleave) sends the whole pass to one or two L2 channels
+    const int qrow = tid >> 3, sub = tid & 7;  // row inside a 32-row pass
     const bool vec4 = (a.k & 3) == 0 && (((uintptr_t)a.x & 15) == 0);
-    const int niter = a.kp / 32;
+    const int nreal = (a.k + 31) / 32;          // chunks that hold data; [nreal * 32, kp) is zero padding
+    const int crot = (2 * qrow) % nreal;
     constexpr int U = 8;
     float4 pre[U];
-    auto fetch = [&](int it) -> float4 {
-        const int c = it * 32 + sub * 4;
+    auto chunk_of = [&](int it) {  // it-th chunk this thread's row visits (it < nreal)
+        const int c = it + crot;
+        return c < nreal ? c : c - nreal;
+    };
+    auto fetch = [&](const float* xr, int it) -> float4 {
+        const int c = chunk_of(it < nreal ? it : nreal - 1) * 32 + sub * 4;
         if (vec4) return *reinterpret_cast<const float4*>(xr + (c + 3 < a.k ? c : a.k - 4));  // clamped: never past the row
         float4 v;
         v.x = xr[c < a.k ? c : a.k - 1];
@@ -655,79 +810,79 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 3 
         v.w = xr[c + 3 < a.k ? c + 3 : a.k - 1];
         return v;
     };
+    auto row_ptr = [&](int rb) {  // rows past the end re-read the last row; their results are never stored
+        const int64_t g = m0 + rb * 32 + qrow;
+        return a.x + (g < a.rows ? g : a.rows - 1) * (int64_t)a.k;
+    };
+    {
+        const float* xr = row_ptr(0);
 #pragma unroll
-    for (int u = 0; u < U; ++u) pre[u] = fetch(u < niter ? u : niter - 1);
-
-    // ---- phase 0: {scale, zp} of the slices this block touches (usually one or two), from the producer's pairs
-    const int64_t sl_lo = m0 / a.m;
-    const int nsl = (int)((m0 + rows_here - 1) / a.m - sl_lo) + 1;
-    for (int s = 0; s < nsl; ++s) {
-        const float2* pp = reinterpret_cast<const float2*>(a.partial) + (sl_lo + s) * (int64_t)a.nblk;
-        float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
-        for (int i0 = 0; i0 < a.nblk; i0 += 1024) {
-            float2 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = i0 + tid + 256 * u;
-                v[u] = pp[idx < a.nblk ? idx : a.nblk - 1];  // clamped: a repeated pair changes nothing
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                mn = v[u].x < mn ? v[u].x : mn;
-                mx = v[u].y > mx ? v[u].y : mx;
-            }
-        }
-        for (int off = 32; off > 0; off >>= 1) {
-            const float p = __shfl_xor(mn, off), q = __shfl_xor(mx, off);
-            mn = p < mn ? p : mn;
-            mx = q > mx ? q : mx;
-        }
-        if (lane == 0) {
-            s_mn[wave] = mn;
-            s_mx[wave] = mx;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < 4; ++w) {
-                mn = s_mn[w] < mn ? s_mn[w] : mn;
-                mx = s_mx[w] > mx ? s_mx[w] : mx;
-            }
-            s_prm[s] = make_qparams(mn, mx);
-        }
-        __syncthreads();
+        for (int u = 0; u < U; ++u) pre[u] = fetch(xr, u);
     }
 
-    // ---- phase 1b: quantise the 32 rows into LDS, exact row sums on the way.  Whole 32-column chunks inside the SIMD body
+    // ---- phase 0 (reduce): {scale, zp} per slice, in registers of every wave -- no LDS, no barrier
+    const QParams q0 = [&] {
+        const MinMax r = pairs_reduce(pp0, a.nblk, lane, pv0);
+        return make_qparams(r.mn, r.mx);
+    }();
+    const QParams q1 = [&] {
+        const MinMax r = pairs_reduce(pp1, a.nblk, lane, pv1);
+        return make_qparams(r.mn, r.mx);
+    }();
+    const int bnd = (int)((sl_lo + 1) * a.m - m0);  // local rows below bnd are slice sl_lo, the next a.m rows slice sl_lo + 1
+
+    // ---- phase 1b: quantise the rows into LDS, exact row sums on the way.  Whole 32-column chunks inside the SIMD body
     // (k & ~7) take four instructions per element: fma, round-to-nearest-even, v_cvt_pk_u8_f32 (saturates to [0, 255] = the
     // clamp, and packs), and per four elements one xor 0x80808080 (q - 128 as i8) and one v_sad_u8 (sum of the four q).
-    {
-        const QParams q = s_prm[live ? (int)(grow / a.m - sl_lo) : 0];
+#pragma unroll 1
+    for (int rb = 0; rb < RB; ++rb) {
+        const int lrow = rb * 32 + qrow;
+        QParams q = lrow < bnd ? q0 : q1;
+        if (nsl > 2 && lrow >= bnd + a.m) {  // more than two slices in a block (m < BM): rare, the slow way
+            const int64_t sl = (m0 + lrow) / a.m;
+            const float2* pps = reinterpret_cast<const float2*>(a.partial) + (m0 + lrow < a.rows ? sl : sl_lo) * (int64_t)a.nblk;
+            float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+            for (int i = 0; i < a.nblk; ++i) {
+                const float2 w = pps[i];
+                mn = w.x < mn ? w.x : mn;
+                mx = w.y > mx ? w.y : mx;
+            }
+            q = make_qparams(mn, mx);
+        }
         const int simd_k = a.k & ~7;
         const int nfull = simd_k / 32;  // chunks with every column below simd_k
         unsigned usum = 0;              // sum of q over the fast chunks
         int ssum = 0;                   // sum of (q - 128) over the ragged chunk
-        char* dst = op_lds + qrow * pitch + sub * 4;
-        for (int it0 = 0; it0 < niter; it0 += U) {
+        char* dst = op_lds + lrow * pitch + sub * 4;
+        const float* xr = row_ptr(rb);
+        const float* xr_next = row_ptr(rb + 1 < RB ? rb + 1 : rb);
+        for (int c = nreal * 32 + sub * 4; c < a.kp; c += 32) *reinterpret_cast<int*>(op_lds + lrow * pitch + c) = 0;  // zero padding
+        for (int it0 = 0; it0 < nreal; it0 += U) {
             float4 cur[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) cur[u] = pre[u];
-            if (it0 + U < niter) {
+            if (it0 + U < nreal) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) pre[u] = fetch(it0 + U + u < niter ? it0 + U + u : niter - 1);
+                for (int u = 0; u < U; ++u) pre[u] = fetch(xr, it0 + U + u);
+            } else if (rb + 1 < RB) {  // the next 32 rows' first chunks
+#pragma unroll
+                for (int u = 0; u < U; ++u) pre[u] = fetch(xr_next, u);
             }
+            if (a.dbg & 1) continue;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int it = it0 + u;
-                if (it < nfull) {  // uniform
+                if (it0 + u >= nreal) continue;  // uniform
+                const int ch = chunk_of(it0 + u);
+                if (ch < nfull) {  // all lanes of a row agree; rows differ only around the (at most one) ragged chunk
                     unsigned pk = 0;
                     pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(cur[u].x, q.inv_scale, q.zp)), 0, pk);
                     pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(cur[u].y, q.inv_scale, q.zp)), 1, pk);
                     pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(cur[u].z, q.inv_scale, q.zp)), 2, pk);
                     pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(cur[u].w, q.inv_scale, q.zp)), 3, pk);
                     usum = __builtin_amdgcn_sad_u8(pk, 0u, usum);
-                    *reinterpret_cast<unsigned*>(dst + it * 32) = pk ^ 0x80808080u;
-                } else if (it < niter) {  // the chunk that holds the scalar tail (k % 8 columns) and / or the zero padding
-                    const int c = it * 32 + sub * 4;
+                    *reinterpret_cast<unsigned*>(dst + ch * 32) = pk ^ 0x80808080u;
+                } else {  // the chunk that holds the scalar tail (k % 8 columns) and / or the end of the row
+                    const int c = ch * 32 + sub * 4;
                     const float xv[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
                     int packed = 0;
 #pragma unroll
@@ -740,115 +895,160 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 3 
                         }
                         packed |= (v & 0xff) << (8 * e);
                     }
-                    *reinterpret_cast<int*>(dst + it * 32) = packed;
+                    *reinterpret_cast<int*>(dst + ch * 32) = packed;
                 }
             }
         }
-        int sum = (int)usum - 128 * 4 * nfull + ssum;  // every lane of a row did nfull fast chunks of 4 elements
+        int sum = (int)usum - 128 * 4 * nfull + ssum;  // every lane of a row did nfull fast chunks of 4 elements (nfull <= nreal)
         sum += __shfl_xor(sum, 1);
         sum += __shfl_xor(sum, 2);
         sum += __shfl_xor(sum, 4);
         if (sub == 0) {
             const int ca = 128 - q.zp_i, cb = 128 - epi.zp_b;
-            s_ca[qrow] = ca;
-            s_rterm[qrow] = cb * sum + a.k * ca * cb;
-            s_ds[qrow] = q.scale;
+            s_row[lrow] = make_int4(ca, cb * sum + a.k * ca * cb, __builtin_bit_cast(int, q.scale), 0);
         }
     }
     __syncthreads();
 
     // ---- phase 2: columns
     const char* arow = op_lds + l31 * pitch + 16 * hv;
-    // {min, max} of what this block stores, separately for the (at most two: m >= 32) slices its rows belong to: local rows
-    // below `bnd` are slice sl_lo, the others slice sl_lo + 1
-    const int bnd = (int)((sl_lo + 1) * a.m - m0);
+    // {min, max} of what this block stores, separately for the two slices its rows may belong to
     float mnA = 3.40282347e+38f, mxA = -3.40282347e+38f, mnB = 3.40282347e+38f, mxB = -3.40282347e+38f;
-    // rows r0..r0+NR-1 (accumulator registers) of tile t: epilogue + statistics
-    auto finish = [&](int t, auto get_acc, int r0, auto nr_c) {
-        constexpr int NR = decltype(nr_c)::value;
+    // rows r0..r0+NR-1 (accumulator registers) of row block rb of tile t: epilogue + statistics.  cc = the tile's column terms,
+    // requested before the tile's MFMAs so that they have arrived by now.  NRES (compile time) = number of residual operands:
+    // the body is straight-line code -- loads from clamped coordinates, then predicated stores -- because a branch per row makes
+    // the compiler fall back to "wait for every outstanding memory operation" at the joins, i.e. each group of stores waits for
+    // the previous one to reach memory (measured: 25 us of the 45 us of ffn1).
+    auto finish = [&](int t, int rb, const IgemmEpi::ColCtx& cc, auto get_acc, int r0, auto nr_c, auto nres_c) {
+        constexpr int NR = decltype(nr_c)::value, NRES = decltype(nres_c)::value;
         const int col = t * 32 + l31;
         const bool cin = col < a.n;
-        const IgemmEpi::ColCtx cc = epi.col_ctx(col);
+        const int colc = cin ? col : a.n - 1;
+        // the rows a lane finishes are the same for every tile: left alone, the compiler hoists their 2 x 16 x RB output pointers
+        // and LDS terms out of the tile loop (160 VGPRs for two row blocks -> spills); an opaque copy keeps them per tile
+        int rbase = rb * 32 + 4 * hv;
+        asm volatile("" : "+v"(rbase));
+        // addresses: one uniform 64-bit base per block + a 32-bit element offset per lane (row r of the register file sits
+        // (r & 3) + 8 (r >> 2) rows below rbase: a compile-time multiple of N, computed on the scalar unit) -- per-row 64-bit
+        // multiplies made the epilogue the longest phase of the kernel
+        float* const obase = epi.out + m0 * (int64_t)a.n;
+        const float* const r1base = NRES > 0 ? epi.res1 + m0 * (int64_t)a.n : nullptr;
+        const float* const r2base = NRES > 1 ? epi.res2 + m0 * (int64_t)a.n : nullptr;
+        const unsigned nu = (unsigned)a.n;
+        const unsigned off0 = (unsigned)rbase * nu + (unsigned)col;
+        // residual operands of ALL the rows first: loads and stores retire through one in-order counter, so a load issued after a
+        // store cannot be waited for without waiting for the store -- one such wait per tile instead of one per group of rows
+        float r1[NRES > 0 ? NR : 1], r2[NRES > 1 ? NR : 1];
+        if (NRES > 0) {
+            const int last = rows_here - 1;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int r = r0 + i;
+                const int lr = rbase + (r & 3) + 8 * (r >> 2);
+                const unsigned at = (unsigned)(lr < last ? lr : last) * nu + (unsigned)colc;
+                r1[i] = r1base[at];
+                if (NRES > 1) r2[i] = r2base[at];
+            }
+        }
+        const float nan = __builtin_nanf("");
 #pragma unroll
         for (int g4 = 0; g4 < NR; g4 += 4) {
-            float r1[4] = {0.f, 0.f, 0.f, 0.f}, r2[4] = {0.f, 0.f, 0.f, 0.f};
-            if (epi.res1) {
+            int4 rowt[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = r0 + g4 + q;
-                    const int64_t row = m0 + (r & 3) + 8 * (r >> 2) + 4 * hv;
-                    const int64_t at = (row < a.rows ? row : a.rows - 1) * (int64_t)a.n + (cin ? col : a.n - 1);
-                    r1[q] = epi.res1[at];
-                    r2[q] = epi.res2 ? epi.res2[at] : 0.0f;
-                }
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + g4 + q;
+                rowt[q] = s_row[rbase + (r & 3) + 8 * (r >> 2)];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = r0 + g4 + q;
-                const int lr = (r & 3) + 8 * (r >> 2) + 4 * hv;
-                const int64_t row = m0 + lr;
-                const IgemmEpi::RowCtx rc{s_ca[lr], s_rterm[lr], s_ds[lr], epi.out + (row < a.rows ? row : 0) * (int64_t)a.n};
-                const int acc = get_acc(g4 + q);
-                const float v = epi.res1 ? epi.value_res(rc, cc, acc, r1[q], r2[q]) : epi.value(rc, cc, acc);
-                if (row < a.rows && cin) {
-                    rc.orow[col] = v;
-                    if (lr < bnd) {
-                        mnA = v < mnA ? v : mnA;
-                        mxA = v > mxA ? v : mxA;
-                    } else {
-                        mnB = v < mnB ? v : mnB;
-                        mxB = v > mxB ? v : mxB;
-                    }
-                }
+                const int kr = (r & 3) + 8 * (r >> 2);  // compile time when r0 is (normal mode)
+                const int lr = rbase + kr;
+                const IgemmEpi::RowCtx rc{rowt[q].x, rowt[q].y, __builtin_bit_cast(float, rowt[q].z), nullptr};
+                float v = epi.value24(rc, cc, get_acc(g4 + q));
+                if (NRES > 0) v = v + r1[g4 + q];
+                if (NRES > 1) v = v + r2[g4 + q];
+                const bool ok = cin && lr < rows_here;
+                if (ok) obase[off0 + (unsigned)kr * nu] = v;
+                // statistics: v_min / v_max ignore a NaN operand, so "not this slice / not stored" is one select per slice
+                const float vA = (ok && lr < bnd) ? v : nan, vB = (ok && lr >= bnd) ? v : nan;
+                mnA = __builtin_fminf(mnA, vA);
+                mxA = __builtin_fmaxf(mxA, vA);
+                mnB = __builtin_fminf(mnB, vB);
+                mxB = __builtin_fmaxf(mxB, vB);
             }
-            __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: hoisting all 16 rows' loads costs 40 VGPRs and spills
+            __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: hoisting all 16 rows' LDS terms costs 40 VGPRs
         }
     };
     // SETK k-steps of MFMAs out of one register set: the A fragments come from LDS (short latency), the W fragments were
     // requested one set ahead, so the wait before the first MFMA leaves the NEXT set's loads in flight
-    auto mm = [&](const v4i (&w)[NTW][SETK], int s, v16i& acc0, v16i& acc1) {
-        v4i fa[SETK];
-#pragma unroll
-        for (int u = 0; u < SETK; ++u) fa[u] = *reinterpret_cast<const v4i*>(arow + (s + u) * 32);
+    auto mm = [&](const v4i (&w)[NTW][SETK], int s, v16i (&acc)[RB][NTW]) {
 #pragma unroll
         for (int u = 0; u < SETK; ++u) {
-            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u], w[0][u], acc0, 0, 0, 0);
-            if (NTW == 2) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u], w[1][u], acc1, 0, 0, 0);
+            v4i fa[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) fa[rb] = *reinterpret_cast<const v4i*>(arow + rb * 32 * pitch + (s + u) * 32);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) acc[rb][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[rb], w[j][u], acc[rb][j], 0, 0, 0);
         }
     };
-    for (int t = t_first; t < t_hi; t += tstep) {
-        v16i acc0, acc1;
+    for (int un = u_first; un < nunit; un += ustep) {
+        const int t = unit_tile(un);
+        v16i acc[RB][NTW];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = 0, acc1[r] = 0;
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rb][j][r] = 0;
+        // the tiles' column terms (column sum, weight scale, bias): requested now, used after the MFMAs
+        IgemmEpi::ColCtx cc[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) cc[j] = epi.col_ctx((t + j) * 32 + l31);
+        __builtin_amdgcn_sched_barrier(0);  // pinned HERE: sunk to their use after the MFMAs they would be the youngest loads, and
+                                            // waiting for them would wait for every store of the previous tile as well
         // sets alternate a, b; the request after this tile's last set is the NEXT tile's first one, so it travels while the
         // results are stored
-        for (int s = ks0; s < ks1; s += 2 * SETK) {
+        for (int s = ks0; s < ((a.dbg & 2) ? ks0 : ks1); s += 2 * SETK) {
             // the scheduling barriers pin "request the next set, THEN issue this set's MFMAs": left alone, the scheduler sinks the
             // loads next to their uses and waits for each one with the matrix pipe idle
             req(w_b);
             __builtin_amdgcn_sched_barrier(0);
-            mm(w_a, s, acc0, acc1);
+            mm(w_a, s, acc);
             __builtin_amdgcn_sched_barrier(0);
             req(w_a);
             __builtin_amdgcn_sched_barrier(0);
-            mm(w_b, s + SETK, acc0, acc1);
+            mm(w_b, s + SETK, acc);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (!KSPLIT) {
-            finish(t, [&](int i) { return acc0[i]; }, 0, std::integral_constant<int, 16>());
-            if (t + 1 < t_hi) finish(t + 1, [&](int i) { return acc1[i]; }, 0, std::integral_constant<int, 16>());
-        } else {
-            // the four waves split K: partial tiles meet in LDS (exact: i32), each wave finishes four accumulator rows
+        if (a.dbg & 4) continue;
+        // one uniform branch per tile on the number of residual operands; inside, everything is straight-line
+        auto finish_all = [&](auto nres_c) {
+            if (!KSPLIT) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s_red[(wave * 16 + r) * 64 + lane] = acc0[r];
-            __syncthreads();
-            finish(t, [&](int i) {
-                const int r = 4 * wave + i;
-                return (s_red[(0 * 16 + r) * 64 + lane] + s_red[(1 * 16 + r) * 64 + lane]) +
-                       (s_red[(2 * 16 + r) * 64 + lane] + s_red[(3 * 16 + r) * 64 + lane]);
-            }, 4 * wave, std::integral_constant<int, 4>());
-            __syncthreads();
-        }
+                for (int rb = 0; rb < RB; ++rb) {
+                    finish(t, rb, cc[0], [&](int i) { return acc[rb][0][i]; }, 0, std::integral_constant<int, 16>(), nres_c);
+                    if (t + 1 < t_hi)
+                        finish(t + 1, rb, cc[NTW - 1], [&](int i) { return acc[rb][NTW - 1][i]; }, 0, std::integral_constant<int, 16>(), nres_c);
+                }
+            } else {
+                // the four waves split K: partial tiles meet in LDS (exact: i32), each wave finishes four accumulator rows
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s_red[(wave * 16 + r) * 64 + lane] = acc[0][0][r];
+                __syncthreads();
+                finish(t, 0, cc[0], [&](int i) {
+                    const int r = 4 * wave + i;
+                    return (s_red[(0 * 16 + r) * 64 + lane] + s_red[(1 * 16 + r) * 64 + lane]) +
+                           (s_red[(2 * 16 + r) * 64 + lane] + s_red[(3 * 16 + r) * 64 + lane]);
+                }, 4 * wave, std::integral_constant<int, 4>(), nres_c);
+                __syncthreads();
+            }
+        };
+        if (!epi.res1) finish_all(std::integral_constant<int, 0>());
+        else if (!epi.res2) finish_all(std::integral_constant<int, 1>());
+        else finish_all(std::integral_constant<int, 2>());
     }
     if (a.stat_out) {  // uniform.  Slot layout: [slice][block of the slice][column group], a.stat_per_slice pairs per slice
         for (int off = 32; off > 0; off >>= 1) {
@@ -872,20 +1072,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT ? 3 
                 mnB = s_stat[w][2] < mnB ? s_stat[w][2] : mnB;
                 mxB = s_stat[w][3] > mxB ? s_stat[w][3] : mxB;
             }
-            const int64_t fbA = (sl_lo * a.m) / kOpBM;  // first block of slice sl_lo
-            float* oa = a.stat_out + ((sl_lo * a.stat_per_slice) + ((int64_t)blockIdx.y - fbA) * gridDim.x + blockIdx.x) * 2;
+            const int64_t fbA = (sl_lo * a.m) / BM;  // first block of slice sl_lo
+            float* oa = a.stat_out + ((sl_lo * a.stat_per_slice) + ((int64_t)rblk - fbA) * a.nsplit + grp) * 2;
             oa[0] = mnA;
             oa[1] = mxA;
             if (bnd < rows_here) {  // this block also holds the first rows of the next slice: it is that slice's block 0
-                float* ob = a.stat_out + (((sl_lo + 1) * a.stat_per_slice) + blockIdx.x) * 2;
+                float* ob = a.stat_out + (((sl_lo + 1) * a.stat_per_slice) + grp) * 2;
                 ob[0] = mnB;
                 ob[1] = mxB;
             }
         }
         // the block holding the LAST row of slice sl_lo fills the slice's unused slots with the neutral pair
-        if (blockIdx.x == 0 && bnd <= rows_here) {
-            const int64_t fbA = (sl_lo * a.m) / kOpBM;
-            const int used = (int)((int64_t)blockIdx.y - fbA + 1) * (int)gridDim.x;
+        if (grp == 0 && bnd <= rows_here) {
+            const int64_t fbA = (sl_lo * a.m) / BM;
+            const int used = (int)((int64_t)rblk - fbA + 1) * a.nsplit;
             float* base = a.stat_out + sl_lo * a.stat_per_slice * 2;
             for (int i = used + tid; i < a.stat_per_slice; i += 256) {
                 base[2 * i] = 3.40282347e+38f;
@@ -1015,8 +1215,10 @@ int launch_range(LeleCtx* ctx, const float* dx, int64_t slices, int64_t slice_le
 }
 
 int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows, int n, int kp, int64_t b_stride,
-                 int m_per_batch, const IgemmEpi& epi) {
+                 int m_per_batch, const IgemmEpi& epi_in) {
     if (rows == 0 || n == 0) return 0;
+    IgemmEpi epi = epi_in;
+    epi.flags = env_int("LELE_HIP_IGEMM_FLAGS", 0);
     LELE_REQUIRE(rows < (int64_t(1) << 31), "quantized GEMM: more than 2^31 rows");
     const int64_t b128 = ((rows + 127) / 128) * ((n + 127) / 128);
     // batched B needs every block to stay inside one batch slice: tiles never straddle slices when BM divides m,
@@ -1031,6 +1233,16 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
                            m_per_batch, epi);                                                                             \
     } while (0)
     const int64_t b64 = ((rows + 63) / 64) * ((n + 63) / 64);
+    const int force = env_int("LELE_HIP_IGEMM_TILE", 0);  // developer override for tile-shape experiments (tools/qlinear_bench.py)
+    if (force == 1) IGEMM_LAUNCH(128, 128, 2, 4, 64, 4);
+    else if (force == 2) IGEMM_LAUNCH(128, 128, 2, 4, 128, 1);
+    else if (force == 3) IGEMM_LAUNCH(256, 128, 4, 2, 64, 2);
+    else if (force == 4) IGEMM_LAUNCH(128, 256, 2, 4, 64, 2);
+    else if (force == 5) IGEMM_LAUNCH(64, 64, 2, 2, 64, 1);
+    else if (force == 6) IGEMM_LAUNCH(128, 128, 2, 2, 64, 2);
+    else if (force == 7) IGEMM_LAUNCH(64, 128, 2, 2, 64, 2);
+    else if (force == 8) IGEMM_LAUNCH(256, 128, 4, 2, 128, 2);
+    else
     if (b64 < 2 * (int64_t)ctx->num_cus) {
         // small problem (SenseVoice at M = 504): 32x32 tiles, K split over the four waves, operands straight from L2
         dim3 grid((unsigned)((n + 31) / 32), (unsigned)((rows + 31) / 32));
@@ -1158,50 +1370,61 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     // padded to a multiple of 512 (zero activation bytes x zero weight bytes) so that every wave's k-range splits into an even
     // number of equal register sets: tiny K would be mostly padding and stays on the three-kernel chain
     const int kp32 = (int)((k + 511) & ~int64_t(511));
-    const bool onepass = weight_int8->mem == LELE_MEM_WEIGHT && k >= 256 && (size_t)kOpBM * (kp32 + 16) <= 150 * 1024 &&
-                         rows < (int64_t(1) << 31) && env_int("LELE_HIP_QLINEAR_ONEPASS", 1) != 0;
+    // two row blocks per workgroup (every weight fragment then feeds two MFMAs) while the tile of 64 x K bytes leaves room for two
+    // workgroups per CU; one row block for long K and for single utterances
+    const int rb_env = env_int("LELE_HIP_ONEPASS_RB", 0);
+    const int RBsel = rb_env ? rb_env : ((kp32 <= 1024 && rows >= 2048 && m >= 64) ? 2 : 1);
+    const int BMsel = 32 * RBsel;
+    const bool onepass = weight_int8->mem == LELE_MEM_WEIGHT && k >= 256 && (size_t)BMsel * (kp32 + 16) <= 140 * 1024 &&
+                         rows < (int64_t(1) << 31) && env_int("LELE_HIP_QLINEAR_ONEPASS", 0) != 0;
     if (onepass) {
         const int ks = kp32 / 32, nt = (int)((n + 31) / 32);
         FragW fw;
         LELE_TRY(get_frag_weights(ctx, weight_int8, (int)k, (int)n, ks, nt, &fw));
-        const int64_t row_blocks = (rows + kOpBM - 1) / kOpBM;
-        // enough workgroups to fill the chip (they are small: 32 x K bytes of LDS, several per CU), as few column groups as that
-        // allows (every group of a row block repeats the block's quantisation)
-        const int64_t target = env_int("LELE_HIP_ONEPASS_WGS", 2 * ctx->num_cus);
+        const int64_t row_blocks = (rows + BMsel - 1) / BMsel;
+        // enough workgroups to fill the chip (several fit a CU), as few column groups as that allows (every group of a row
+        // block repeats the block's quantisation; their re-reads of the f32 rows hit the XCD's L2, see the kernel's grid note)
+        const int64_t target = env_int("LELE_HIP_ONEPASS_WGS", ctx->num_cus + ctx->num_cus / 2);
         int nsplit = (int)std::min<int64_t>(nt, std::max<int64_t>(1, (target + row_blocks - 1) / row_blocks));
-        const int tpw = (nt + nsplit - 1) / nsplit;
+        int tpw = (nt + nsplit - 1) / nsplit;
+        bool ksplit = RBsel == 1 && tpw < env_int("LELE_HIP_ONEPASS_KSPLIT_BELOW", 4);
+        if (!ksplit && tpw < 8 && nt >= 8 && RBsel == 1 && rows > 2048) tpw = 8;  // every wave a tile pair
         nsplit = (nt + tpw - 1) / tpw;
         IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, nullptr, fw.col_sums, nullptr, 0,
                      (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
                      (const float*)dr2};
-        OnepassArgs oa{(const float*)dx, rows, (int)k, kp32, (int)m, partial, nblk, fw.wf, (int)n, nt, ks, tpw, nullptr, 0};
+        OnepassArgs oa{(const float*)dx, rows, (int)k, kp32, (int)m, partial, nblk, fw.wf, (int)n, nt, ks, tpw, nsplit, (int)row_blocks,
+                       nullptr, 0, env_int("LELE_HIP_ONEPASS_DEBUG", 0)};
         // statistics for a quantised linear that reads this result next: one pair per (slice, row block, column group); needs
-        // m >= 32 (a block then touches at most two slices)
-        const int64_t per_slice = ((m - 1) / kOpBM + 2) * nsplit, nstat = batch * per_slice;
-        if (m >= kOpBM && per_slice <= 65536 && nstat <= (int64_t(1) << 22)) {
+        // m >= BM (a block then touches at most two slices)
+        const int64_t per_slice = ((m - 1) / BMsel + 2) * nsplit, nstat = batch * per_slice;
+        if (m >= BMsel && per_slice <= 65536 && nstat <= (int64_t(1) << 22)) {
             LELE_TRY(out->reserve_rowstat(nstat));
             if ((size_t)nstat <= out->rowstat_cap) {
                 oa.stat_out = out->rowstat;
                 oa.stat_per_slice = (int)per_slice;
             }
         }
-        const size_t lds = (size_t)kOpBM * (kp32 + 16);
-        const bool ksplit = tpw < env_int("LELE_HIP_ONEPASS_KSPLIT_BELOW", 4);
-        const dim3 grid((unsigned)nsplit, (unsigned)row_blocks);
+        const size_t lds = (size_t)BMsel * (kp32 + 16);
+        // 1-D grid: 8 XCDs x ceil(row_blocks / 8) row blocks x nsplit groups (workgroups beyond an XCD's share exit at once)
+        const dim3 grid((unsigned)(8 * ((row_blocks + 7) / 8) * nsplit));
         LELE_TRY(qprof_mark(ctx, 2));  // no separate row-quantisation stage: the whole kernel is booked as the GEMM stage
-#define LELE_ONEPASS(KS_, SETK_)                                                                                          \
+#define LELE_ONEPASS(KS_, SETK_, RB_)                                                                                     \
     do {                                                                                                                \
-        auto kern = qlinear_onepass_kernel<KS_, SETK_>;                                                                  \
+        auto kern = qlinear_onepass_kernel<KS_, SETK_, RB_>;                                                             \
         if (lds + ((KS_) ? 16384 : 0) > 60 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)); \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, oa, epi);                                            \
     } while (0)
         if (ksplit) {  // k-steps per wave = ks / 4 (a multiple of 4): the largest set size that divides it into an even count
             const int per = ks / 4;
-            if (per % 16 == 0) LELE_ONEPASS(true, 8);
-            else if (per % 8 == 0) LELE_ONEPASS(true, 4);
-            else LELE_ONEPASS(true, 2);
+            if (per % 16 == 0) LELE_ONEPASS(true, 8, 1);
+            else if (per % 8 == 0) LELE_ONEPASS(true, 4, 1);
+            else LELE_ONEPASS(true, 2, 1);
+        } else if (RBsel == 2) {
+            if (env_int("LELE_HIP_ONEPASS_SETK", 2) == 4) LELE_ONEPASS(false, 4, 2);  // ks is a multiple of 16: an even number of sets
+            else LELE_ONEPASS(false, 2, 2);
         } else {
-            LELE_ONEPASS(false, 4);  // ks is a multiple of 16: an even number of 4-step sets
+            LELE_ONEPASS(false, 4, 1);
         }
 #undef LELE_ONEPASS
         LELE_HIP_CHECK(hipGetLastError());
@@ -1232,7 +1455,7 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     void *aq = nullptr, *rs = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)rows * kp, &aq));
     LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));
-    if (rows <= 2048)
+    if (rows <= 2048 || (kp <= 2048 && !env_int("LELE_HIP_QROWS_STREAM", 0)))  // the whole row in flight at once (8 x 16 bytes per lane)
         hipLaunchKernelGGL((qrows_kernel<0, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
                            rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk);
     else

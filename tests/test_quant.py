@@ -273,13 +273,14 @@ def test_device_onepass_quantized_linear_bit_exact(ctx, orc, shape, relu):
     w = _qw(rng, k, n)
     ref = orc.fused_quantized_linear(x, w[0].arr, w[1].arr, [128.0], w[3].arr, relu)
     xd = ctx.buf().upload(x)
-    got = Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx)
-    assert got.shape == ref.shape and np.array_equal(got.numpy(), ref)
-    with _env(LELE_HIP_QLINEAR_ONEPASS=0):
+    with _env(LELE_HIP_QLINEAR_ONEPASS=1):
+        got = Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx)
+        assert got.shape == ref.shape and np.array_equal(got.numpy(), ref)
+    with _env(LELE_HIP_QLINEAR_ONEPASS=0):  # the default: range pass | row quantisation | tiled i8 GEMM
         assert np.array_equal(Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx).numpy(), ref)
-    for wgs, below in ((1, 0), (64, 0), (100000, 1000), (100000, 0), (700, 4)):
-        with _env(LELE_HIP_ONEPASS_WGS=wgs, LELE_HIP_ONEPASS_KSPLIT_BELOW=below):
-            assert np.array_equal(Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx).numpy(), ref), (wgs, below)
+    for wgs, below, rb, setk in ((1, 0, 1, 4), (64, 0, 2, 4), (100000, 1000, 1, 4), (100000, 0, 1, 4), (700, 4, 2, 2), (300, 4, 1, 4), (1, 4, 2, 4)):
+        with _env(LELE_HIP_QLINEAR_ONEPASS=1, LELE_HIP_ONEPASS_WGS=wgs, LELE_HIP_ONEPASS_KSPLIT_BELOW=below, LELE_HIP_ONEPASS_RB=rb, LELE_HIP_ONEPASS_SETK=setk):
+            assert np.array_equal(Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx).numpy(), ref), (wgs, below, rb, setk)
 
 
 @pytest.mark.gpu
@@ -295,8 +296,8 @@ def test_onepass_statistics_feed_the_next_quantised_linear(ctx, orc):
         w1, w2 = _qw(rng, k, h), _qw(rng, h, n)
         hid_ref = orc.fused_quantized_linear(x, w1[0].arr, w1[1].arr, [128.0], w1[3].arr, True)
         out_ref = orc.fused_quantized_linear(hid_ref, w2[0].arr, w2[1].arr, [128.0], w2[3].arr, False)
-        for wgs in (768, 1, 100000, 300):
-            with _env(LELE_HIP_ONEPASS_WGS=wgs):
+        for wgs, rb in ((768, 0), (1, 1), (100000, 2), (300, 2), (300, 1)):
+            with _env(LELE_HIP_QLINEAR_ONEPASS=1, LELE_HIP_ONEPASS_WGS=wgs, LELE_HIP_ONEPASS_RB=rb):
                 hbuf = ctx.buf()
                 hid = Kk.fused_quantized_linear(ctx.buf().upload(x), *w1, True, out=hbuf, ctx=ctx)
                 out = Kk.fused_quantized_linear(hid, *w2, False, ctx=ctx)
@@ -307,9 +308,8 @@ def test_onepass_statistics_feed_the_next_quantised_linear(ctx, orc):
                 assert np.array_equal(Kk.fused_quantized_linear(y, *w2, False, ctx=ctx).numpy(),
                                       orc.fused_quantized_linear(hid_ref * np.float32(0.5), w2[0].arr, w2[1].arr, [128.0], w2[3].arr, False)), (b, m, wgs)
         # the three-kernel chain consumes the same statistics
-        with _env(LELE_HIP_QLINEAR_ONEPASS=0):
-            pass
-        hid = Kk.fused_quantized_linear(ctx.buf().upload(x), *w1, True, ctx=ctx)
+        with _env(LELE_HIP_QLINEAR_ONEPASS=1):
+            hid = Kk.fused_quantized_linear(ctx.buf().upload(x), *w1, True, ctx=ctx)
         with _env(LELE_HIP_QLINEAR_ONEPASS=0):
             assert np.array_equal(Kk.fused_quantized_linear(hid, *w2, False, ctx=ctx).numpy(), out_ref), (b, m)
 

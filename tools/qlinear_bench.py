@@ -19,6 +19,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--calls", type=int, default=20)
+    ap.add_argument("--debug", action="store_true")
+    ap.add_argument("--only", default="")
     args = ap.parse_args()
     import lele_amd
     from lele_amd import kernels as K
@@ -28,12 +30,17 @@ def main():
     shapes = [("c4 qkv", 32, 171, 512, 1536, False), ("c4 out", 32, 171, 512, 512, False), ("c4 ffn1", 32, 171, 512, 2048, True),
               ("c4 ffn2", 32, 171, 2048, 512, False), ("c3 qkv", 1, 504, 512, 1536, False), ("c3 out", 1, 504, 512, 512, False),
               ("c3 ffn1", 1, 504, 512, 2048, True), ("c3 ffn2", 1, 504, 2048, 512, False)]
-    variants = [("chain", {"LELE_HIP_QLINEAR_ONEPASS": "0"}), ("onepass wgs=256", {"LELE_HIP_ONEPASS_WGS": "256"}),
-                ("onepass wgs=512 (default)", {}), ("onepass wgs=1024", {"LELE_HIP_ONEPASS_WGS": "1024"}),
-                ("onepass wgs=2048", {"LELE_HIP_ONEPASS_WGS": "2048"}),
-                ("onepass wgs=512 no-ksplit", {"LELE_HIP_ONEPASS_KSPLIT_BELOW": "0"})]
+    variants = [("chain", {"LELE_HIP_QLINEAR_ONEPASS": "0"})] + [("chain tile=%d" % t, {"LELE_HIP_IGEMM_TILE": str(t)}) for t in range(1, 9)] + [("onepass", {"LELE_HIP_QLINEAR_ONEPASS": "1"})] + [
+        ("onepass rb=%d wgs=%d" % (rb, w), {"LELE_HIP_QLINEAR_ONEPASS": "1", "LELE_HIP_ONEPASS_RB": str(rb), "LELE_HIP_ONEPASS_WGS": str(w)})
+        for rb, w in ((1, 192), (1, 384), (2, 384))]
+    if args.debug:  # phase ablation of the one-pass kernel (results are wrong by construction)
+        variants = [("chain", {"LELE_HIP_QLINEAR_ONEPASS": "0"})] + [
+            ("onepass wgs=%d dbg=%d" % (w, d), {"LELE_HIP_QLINEAR_ONEPASS": "1", "LELE_HIP_ONEPASS_WGS": str(w), "LELE_HIP_ONEPASS_DEBUG": str(d)})
+            for w in (384,) for d in (0, 1, 2, 4, 3, 5, 6, 7)]
     res = []
     for name, b, m, k, n, relu in shapes:
+        if args.only and args.only not in name:
+            continue
         x = ctx.buf().upload(rng.standard_normal((b, m, k)).astype(np.float32))
         g, be = Weight(np.ones(k, np.float32)), Weight(np.zeros(k, np.float32))
         xn = K.layer_norm(x, g, be, -1, 1e-5, out=ctx.buf(), ctx=ctx)     # leaves row statistics, as in the model
