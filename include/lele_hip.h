@@ -398,6 +398,17 @@ int lele_hip_matmul_view(LeleCtx* ctx, const LeleTensor* a, const LeleMatView* a
                          int64_t batch_outer, int64_t batch_inner, int64_t m, int64_t k, int64_t n, const LeleMatView* out_view,
                          const int64_t* out_dims, int32_t out_dims_rank, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
 
+/* softmax(Q K^T * scale) V in one launch: lele_hip_matmul_view(Q view, K^T view) -> lele_hip_softmax_scaled ->
+ * lele_hip_matmul_view(P, V view, out view), with the [.., T, T] score and probability tensors kept on chip.  Views as in
+ * lele_hip_matmul_view: q is [t_q, dh], k is the B operand of the first product, i.e. K TRANSPOSED [dh, t_k], v is [t_k, dh],
+ * the result [t_q, dh].  scale: one f32 value or NULL.  Same arithmetic as the sequence (f32 MFMA with the tiled GEMM's k order,
+ * the row softmax of norm.rs:8), so batched results carry the sequence's bits.  Supported: dh == 128, t_k <= 512, unit stride
+ * along dh for q / k / v / out, 16-byte aligned q / k rows -- anything else returns an error and the caller issues the sequence. */
+int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView* q_view, const LeleTensor* k, const LeleMatView* k_view,
+                            const LeleTensor* v, const LeleMatView* v_view, int64_t batch_outer, int64_t batch_inner, int64_t t_q,
+                            int64_t t_k, int64_t dh, const LeleTensor* scale_or_null, const LeleMatView* out_view,
+                            const int64_t* out_dims, int32_t out_dims_rank, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+
 #ifdef __cplusplus
 }
 #endif

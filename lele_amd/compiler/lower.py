@@ -762,6 +762,65 @@ class Lowering:
             dead.add(rd[0])
         self.statements[:] = [st for i, st in enumerate(sts) if i not in dead]
 
+    def fold_attention(self):
+        """matmul_view(Q view, K^T view) -> softmax_scaled -> matmul_view(P, V view [, out_perm, out_reshape]) with private
+        intermediates becomes ONE `attention_view` statement (lele_hip_attention_view: the score / probability tensors stay on
+        chip).  Shapes are not known here: the run-time form checks the geometry and issues the three calls itself when the
+        kernel does not take it, so the rewrite is always legal."""
+        sts = self.statements
+        outs = {sanitize(o) for o in self.outputs}
+        readers = {}
+
+        def refs(n, acc):
+            if isinstance(n, dict):
+                for key in ("ref", "ints"):
+                    if isinstance(n.get(key), str):
+                        acc.append(n[key])
+                for v in n.values():
+                    refs(v, acc)
+            elif isinstance(n, list):
+                for v in n:
+                    refs(v, acc)
+            return acc
+        for i, st in enumerate(sts):
+            for r in refs(st.get("args", st.get("in")), []):
+                readers.setdefault(r, []).append(i)
+        dead = set()
+        for i, st in enumerate(sts):
+            if st.get("fn") != "matmul_view" or i in dead:
+                continue
+            a = st["args"]
+            if "none" not in a[4] or "none" not in a[5]:
+                continue
+            sc = st["out"][0]
+            rd = readers.get(sc, [])
+            if len(rd) != 1 or sc in outs or sts[rd[0]].get("fn") != "softmax_scaled":
+                continue
+            sm = sts[rd[0]]
+            if sm["args"][0] != {"ref": sc} or sm["args"][2] != {"int": -1}:
+                continue
+            pr = sm["out"][0]
+            rd2 = readers.get(pr, [])
+            if len(rd2) != 1 or pr in outs or sts[rd2[0]].get("fn") != "matmul_view":
+                continue
+            pv = sts[rd2[0]]
+            b = pv["args"]
+            if b[0] != {"ref": pr} or b[1] != {"chain": []} or not (rd[0] < rd2[0]):
+                continue
+            # the V operand must already exist where the first product stands (the fused statement takes its place)
+            st["fn"] = "attention_view"
+            st["args"] = [a[0], a[1], a[2], a[3], b[2], b[3], sm["args"][1], b[4], b[5]]
+            st["out"] = list(pv["out"])
+            moved_ok = True
+            for r in refs([b[2]], []):
+                if any(r in s2["out"] for s2 in sts[i + 1:rd2[0]]):
+                    moved_ok = False
+            if not moved_ok:      # V is produced between the two products: keep the sequence
+                st["fn"], st["args"], st["out"] = "matmul_view", a, [sc]
+                continue
+            dead.update((rd[0], rd2[0]))
+        self.statements[:] = [st for i, st in enumerate(sts) if i not in dead]
+
     # ---------------------------------------------------------------------------------------- driver
     def lower_graph(self, graph_nodes):
         nodes = self.fold(graph_nodes)
@@ -797,6 +856,7 @@ class Lowering:
             k += 1
         if self.extra_fusions:
             self.fold_linear_residuals()
+            self.fold_attention()
 
     def lower_if(self, node):
         """ops/control_flow.rs:18-150: `let (outs) = if cond.data[0] != 0 { then } else { else }` -- the condition is read on

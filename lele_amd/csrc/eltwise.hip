@@ -13,6 +13,7 @@
 //   roles of the 32 SIMD accumulator slots, so the statistics -- and therefore the outputs -- are bit-exact.
 #include "common.h"
 
+#include "norm_core.h"
 #include "simd_math.h"
 
 #include <math.h>
@@ -324,52 +325,6 @@ __device__ __forceinline__ void row_sums(const F& elem, int64_t n, int l, float*
         if (PLAIN) sv = sv + v;
         if (SQUARE) qv = qv + v * v;
     }
-    *out_sum = __shfl(sv, 0, 32);
-    *out_sq = __shfl(qv, 0, 32);
-}
-
-// Register-resident form of row_sums for rows of at most 32*NT elements: lane l holds v[c] = row[32c + l].  The same
-// additions in the same order as row_sums (so the same bits); elements another lane owns (the 8-wide remainder chunks
-// and the scalar tail) arrive by __shfl instead of a second trip to memory.
-template <int NT, bool SQUARE, bool PLAIN>
-__device__ __forceinline__ void row_sums_reg(const float (&v)[NT], int n, int l, float* out_sum, float* out_sq) {
-    float s = 0.0f, q = 0.0f;
-    const int nfull = n >> 5;
-#pragma unroll
-    for (int c = 0; c < NT; ++c)
-        if (c < nfull) {
-            if (PLAIN) s = s + v[c];
-            if (SQUARE) q = fmaf_(v[c], v[c], q);
-        }
-    float s01 = s + __shfl_down(s, 8, 32), q01 = q + __shfl_down(q, 8, 32);
-    float sv = s01 + __shfl_down(s01, 16, 32), qv = q01 + __shfl_down(q01, 16, 32);
-    float last = 0.0f;  // the partially filled register row v[nfull]
-#pragma unroll
-    for (int c = 0; c < NT; ++c)
-        if (c == nfull) last = v[c];
-    const int rem = n - 32 * nfull, nch = rem >> 3;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-        if (r < nch) {
-            const float got = __shfl(last, 8 * r + (l & 7), 32);
-            if (l < 8) {
-                if (PLAIN) sv = sv + got;
-                if (SQUARE) qv = fmaf_(got, got, qv);
-            }
-        }
-    sv = sv + __shfl_down(sv, 4, 32);
-    qv = qv + __shfl_down(qv, 4, 32);
-    sv = sv + __shfl_down(sv, 2, 32);
-    qv = qv + __shfl_down(qv, 2, 32);
-    sv = sv + __shfl_down(sv, 1, 32);
-    qv = qv + __shfl_down(qv, 1, 32);
-#pragma unroll
-    for (int t = 0; t < 7; ++t)
-        if (t < (rem & 7)) {
-            const float got = __shfl(last, 8 * nch + t, 32);
-            if (PLAIN) sv = sv + got;
-            if (SQUARE) qv = qv + got * got;
-        }
     *out_sum = __shfl(sv, 0, 32);
     *out_sq = __shfl(qv, 0, 32);
 }

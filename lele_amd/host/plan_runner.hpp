@@ -453,6 +453,76 @@ inline TensorView matmul_view(const TensorView& a, const Json& a_chain, const Te
     return TensorView::from_device(out, sh.vec(), LELE_F32);
 }
 
+// kernels.py attention_view: softmax(Q K^T * scale) V in one launch when the kernel takes the geometry, else the three calls
+inline TensorView attention_view(const TensorView& q, const Json& q_chain, const TensorView& k, const Json& k_chain, const TensorView& v,
+                                 const Json& v_chain, const TensorView& scale, const std::vector<int64_t>* out_perm,
+                                 const std::vector<int64_t>* out_reshape, Buffer& out, Buffer& tmp0, Buffer& tmp1) {
+    const ViewGeom gq = walk_chain(q.shape, q_chain), gk = walk_chain(k.shape, k_chain), gv = walk_chain(v.shape, v_chain);
+    const size_t r = gq.shape.size();
+    const char* off = getenv("LELE_HIP_ATTENTION_FUSED");
+    bool fused = !(off && off[0] == '0') && r == gk.shape.size() && r == gv.shape.size() && r >= 2 && r <= 4;
+    if (fused) {
+        for (size_t i = 0; i + 2 < r; ++i) fused = fused && gq.shape[i] == gk.shape[i] && gq.shape[i] == gv.shape[i];
+        fused = fused && gq.shape[r - 1] == 128 && gk.shape[r - 2] == 128 && gv.shape[r - 1] == 128 && gk.shape[r - 1] == gv.shape[r - 2] &&
+                gk.shape[r - 1] <= 512 && gq.strides[r - 1] == 1 && gk.strides[r - 2] == 1 && gv.strides[r - 1] == 1 && gq.offset % 4 == 0 &&
+                gk.offset % 4 == 0;
+        for (size_t i = 0; fused && i + 1 < r; ++i) fused = gq.strides[i] % 4 == 0;
+        for (size_t i = 0; fused && i < r; ++i) fused = i == r - 2 || gk.strides[i] % 4 == 0;
+        if (fused && out_perm) fused = (((*out_perm)[r - 1] + (int64_t)r) % (int64_t)r) == (int64_t)r - 1;
+        if (fused) {  // too few workgroups to fill the chip (a single utterance): the sequence's K-split GEMMs are faster
+            int64_t blocks = (gq.shape[r - 2] + 31) / 32;
+            for (size_t i = 0; i + 2 < r; ++i) blocks *= gq.shape[i];
+            const char* mb = getenv("LELE_HIP_ATTENTION_MIN_BLOCKS");
+            fused = blocks >= (mb && *mb ? atoll(mb) : 96);
+        }
+    }
+    if (!fused) {
+        TensorView sc = matmul_view(q, q_chain, k, k_chain, nullptr, nullptr, tmp0);
+        TensorView pr = kernels::softmax_scaled(sc, scale, -1, tmp1);
+        Json none;
+        none.kind = Json::Arr;
+        return matmul_view(pr, none, v, v_chain, out_perm, out_reshape, out);
+    }
+    const int64_t tq = gq.shape[r - 2], dh = gq.shape[r - 1], tk = gk.shape[r - 1];
+    const int64_t bo = r >= 3 ? gq.shape[0] : 1, bi = r == 4 ? gq.shape[1] : 1;
+    auto view = [&](const std::vector<int64_t>& st, int64_t o) { return LeleMatView{o, r >= 3 ? st[0] : 0, r == 4 ? st[1] : 0, st[r - 2], st[r - 1]}; };
+    std::vector<int64_t> logical(gq.shape.begin(), gq.shape.end() - 2);
+    logical.push_back(tq);
+    logical.push_back(dh);
+    std::vector<int64_t> perm;
+    for (size_t i = 0; i < r; ++i) perm.push_back(out_perm ? ((*out_perm)[i] + (int64_t)r) % (int64_t)r : (int64_t)i);
+    std::vector<int64_t> phys;
+    for (int64_t p : perm) phys.push_back(logical[(size_t)p]);
+    const std::vector<int64_t> pstr = detail::row_major_strides(phys);
+    std::vector<int64_t> lstr(r, 0);
+    for (size_t j = 0; j < r; ++j) lstr[(size_t)perm[j]] = pstr[j];
+    std::vector<int64_t> oshape = phys;
+    if (out_reshape) {
+        Json fake, step, dims, name;
+        fake.kind = Json::Arr;
+        step.kind = Json::Arr;
+        dims.kind = Json::Arr;
+        name.kind = Json::Str;
+        name.str = "reshape";
+        for (int64_t d : *out_reshape) {
+            Json e;
+            e.kind = Json::Num;
+            e.is_int = true;
+            e.inum = d;
+            dims.arr.push_back(e);
+        }
+        step.arr = {name, dims};
+        fake.arr.push_back(step);
+        oshape = walk_chain(phys, fake).shape;
+    }
+    const LeleMatView qv = view(gq.strides, gq.offset), kv = view(gk.strides, gk.offset), vv = view(gv.strides, gv.offset), ov = view(lstr, 0);
+    detail::Shape sh;
+    LeleTensor tq_ = q.c(), tk_ = k.c(), tv_ = v.c(), ts_ = scale.c();
+    check(lele_hip_attention_view(detail::ctx(), &tq_, &qv, &tk_, &kv, &tv_, &vv, bo, bi, tq, tk, dh, &ts_, &ov, oshape.data(), (int32_t)oshape.size(),
+                                  out.raw(), sh.dims, &sh.rank));
+    return TensorView::from_device(out, sh.vec(), LELE_F32);
+}
+
 // ------------------------------------------------------------------------------------------------ runner
 class Runner {
    public:
@@ -492,6 +562,7 @@ class Runner {
     std::unordered_map<std::string, std::pair<TV, std::shared_ptr<std::vector<char>>>> weights_;
     std::unordered_map<std::string, Val> env_;
     size_t calls_ = 0, stmt_ = 0;
+    Buffer attn_tmp0_, attn_tmp1_;  // scores / probabilities of an attention_view statement that runs as the three-call sequence
 
     std::string wkey(const Json& w) const { return v2_ ? weight_key(w) : std::to_string(w.arr[1].as_int()); }
     static std::string weight_key(const Json& w) {
@@ -872,6 +943,13 @@ class Runner {
             if (!is_none(a[5])) resh = ints(a[5]);
             return set(st, 0, matmul_view(tensor(a[0]), a[1].at("chain"), tensor(a[2]), a[3].at("chain"), is_none(a[4]) ? nullptr : &perm,
                                           is_none(a[5]) ? nullptr : &resh, o));
+        }
+        if (fn == "attention_view") {
+            std::vector<int64_t> perm, resh;
+            if (!is_none(a[7])) perm = ints(a[7]);
+            if (!is_none(a[8])) resh = ints(a[8]);
+            return set(st, 0, attention_view(tensor(a[0]), a[1].at("chain"), tensor(a[2]), a[3].at("chain"), tensor(a[4]), a[5].at("chain"),
+                                             tensor(a[6]), is_none(a[7]) ? nullptr : &perm, is_none(a[8]) ? nullptr : &resh, o, attn_tmp0_, attn_tmp1_));
         }
         if (fn == "concat") {
             std::vector<TV> hold;

