@@ -1249,12 +1249,10 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
         hipLaunchKernelGGL((gemm::igemm_small_kernel<IgemmEpi>), grid, dim3(256), 0, ctx->stream, aq, wt, rows, n, kp, b_stride,
                            m_per_batch, epi);
     } else if (b128 >= 2 * ctx->num_cus) {
-        // 128-byte K tiles need 74 KB of LDS (2 workgroups/CU); with 64-byte tiles 3 fit.  When the whole grid fits in
-        // one round of 3 per CU but not of 2, the shallower tile avoids a nearly empty second round.
-        if (b128 > 2 * ctx->num_cus && b128 <= 3 * ctx->num_cus)
-            IGEMM_LAUNCH(128, 128, 2, 4, 64, 4);
-        else
-            IGEMM_LAUNCH(128, 128, 2, 4, 128, 1);
+        // 128-byte K tiles (74 KB of LDS, 2 workgroups per CU): half as many barriers and twice the bytes in flight per K step.
+        // Measured on the configs[3] shard shapes (profiles/r02_qlinear_variants.json): 29.3 / 30.0 / 41.1 us for qkv / ffn1 / ffn2
+        // against 32.5 / 32.9 / 48.7 us with 64-byte tiles -- the second, nearly empty round of workgroups costs less than that.
+        IGEMM_LAUNCH(128, 128, 2, 4, 128, 1);
     } else if (rows <= 32) {
         IGEMM_LAUNCH(32, 128, 1, 4, 64, 1);
     } else {
