@@ -30,6 +30,16 @@ int LeleCtx::arena_reset() {
     return 0;
 }
 
+int LeleCtx::tmp_buf(int i, LeleBuf** out) {
+    if (!tmp[i]) {
+        LELE_REQUIRE(!capturing, "graph capture: this op needs a temporary buffer; run the sequence once before capturing it");
+        tmp[i] = new LeleBuf();
+        tmp[i]->ctx = this;
+    }
+    *out = tmp[i];
+    return 0;
+}
+
 int LeleCtx::check_deverr(const char* where) {
     if (deverr_host && *deverr_host) {
         const unsigned bits = *deverr_host;
@@ -181,6 +191,8 @@ int lele_hip_ctx_destroy(LeleCtx* c) {
     (void)hipStreamSynchronize(c->stream);
     while (!c->graphs.empty()) (void)lele_hip_graph_destroy(c->graphs.back());  // graphs hold raw addresses of this ctx's memory
     for (hipEvent_t e : c->qprof.ev) (void)hipEventDestroy(e);
+    for (LeleBuf* t : c->tmp)
+        if (t) (void)lele_hip_buf_destroy(t);
     if (c->deverr_host) (void)hipHostFree(c->deverr_host);
     for (void* p : c->arena_overflow) (void)hipFree(p);
     for (auto& kv : c->weights) (void)hipFree(kv.second);

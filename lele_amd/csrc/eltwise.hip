@@ -841,15 +841,14 @@ int lele_hip_add3(LeleCtx* ctx, const LeleTensor* a, const LeleTensor* b, const 
     LELE_REQUIRE(a->dtype == LELE_F32 && b->dtype == LELE_F32 && c->dtype == LELE_F32, "add3: f32 operands required");
     bool same = a->rank == b->rank && a->rank == c->rank;
     for (int d = 0; same && d < a->rank; ++d) same = a->shape[d] == b->shape[d] && a->shape[d] == c->shape[d];
-    if (!same) {  // broadcasting operands: two passes, the second in place (legal when c broadcasts INTO a + b's shape)
+    if (!same) {  // broadcasting operands: the two `add`s this op stands for, the first into a library-owned temporary (the third
+                  // operand may broadcast OUTWARD, so the second pass cannot run in place)
         int64_t sh1[LELE_MAX_RANK];
         int32_t r1 = 0;
-        LELE_TRY(lele_hip_binary(ctx, B_ADD, a, b, out, sh1, &r1));
-        LeleTensor t{out->data, sh1, r1, LELE_F32, LELE_MEM_DEVICE};
-        LELE_REQUIRE(c->rank <= r1, "add3: the third operand would enlarge the sum of the first two");
-        for (int d = 0; d < c->rank; ++d)
-            LELE_REQUIRE(c->shape[c->rank - 1 - d] == 1 || c->shape[c->rank - 1 - d] == sh1[r1 - 1 - d],
-                         "add3: the third operand would enlarge the sum of the first two");
+        LeleBuf* tmp = nullptr;
+        LELE_TRY(ctx->tmp_buf(0, &tmp));
+        LELE_TRY(lele_hip_binary(ctx, B_ADD, a, b, tmp, sh1, &r1));
+        LeleTensor t{tmp->data, sh1, r1, LELE_F32, LELE_MEM_DEVICE};
         return lele_hip_binary(ctx, B_ADD, &t, c, out, out_shape, out_rank);
     }
     LELE_HIP_CHECK(hipSetDevice(ctx->device));

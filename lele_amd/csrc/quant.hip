@@ -1498,24 +1498,42 @@ int lele_hip_fused_quantized_linear_residual(LeleCtx* ctx, const LeleTensor* inp
     LELE_REQUIRE(res1->dtype == LELE_F32 && (!res2 || res2->dtype == LELE_F32), "fused_quantized_linear_residual: f32 residuals required");
     int64_t on = weight_int8->shape[weight_int8->rank - 1];
     for (int i = 0; i + 1 < input->rank; ++i) on *= input->shape[i];
-    if (numel(res1) == on && (!res2 || numel(res2) == on))  // same-shape residuals: folded into the GEMM's store
+    // same shape as the linear's result (leading unit dimensions aside): folded into the GEMM's store
+    auto same_shape = [&](const LeleTensor* t) {
+        if (numel(t) != on) return false;
+        const int r_lin = input->rank;
+        if (t->rank > r_lin) return false;  // a higher-rank residual changes the result's rank: the generic path
+        for (int d = 0; d < t->rank; ++d) {
+            const int64_t want = d == 0 ? weight_int8->shape[weight_int8->rank - 1] : input->shape[r_lin - 1 - d];
+            if (t->shape[t->rank - 1 - d] != want) return false;
+        }
+        return true;
+    };
+    if (same_shape(res1) && (!res2 || same_shape(res2)))
         return fql_impl(ctx, input, weight_int8, weight_scale, weight_zero, bias, apply_relu, res1, res2, out, out_shape, out_rank);
-    // broadcasting residuals: the plain linear, then the Adds in place (the residuals must broadcast INTO the result)
+    // broadcasting residuals: the node sequence this op stands for -- the plain linear, then one `add` per residual with full
+    // numpy broadcasting (a residual may broadcast OUTWARD: intermediates go to library-owned temporaries, the last sum to `out`)
     int64_t sh[LELE_MAX_RANK];
     int32_t r = 0;
-    LELE_TRY(fql_impl(ctx, input, weight_int8, weight_scale, weight_zero, bias, apply_relu, nullptr, nullptr, out, sh, &r));
-    for (const LeleTensor* res : {res1, res2}) {
-        if (!res) continue;
-        LELE_REQUIRE(res->rank <= r, "fused_quantized_linear_residual: a residual would enlarge the result");
-        for (int d = 0; d < res->rank; ++d)
-            LELE_REQUIRE(res->shape[res->rank - 1 - d] == 1 || res->shape[res->rank - 1 - d] == sh[r - 1 - d],
-                         "fused_quantized_linear_residual: a residual would enlarge the result");
-        LeleTensor t{out->data, sh, r, LELE_F32, LELE_MEM_DEVICE};
-        LELE_TRY(lele_hip_binary(ctx, 0 /* add */, &t, res, out, sh, &r));
+    const int nres = res2 ? 2 : 1;
+    LeleBuf *t0 = nullptr, *t1 = nullptr;
+    LELE_TRY(ctx->tmp_buf(0, &t0));
+    LELE_TRY(ctx->tmp_buf(1, &t1));
+    LELE_TRY(fql_impl(ctx, input, weight_int8, weight_scale, weight_zero, bias, apply_relu, nullptr, nullptr, t0, sh, &r));
+    LeleBuf* cur = t0;
+    for (int i = 0; i < nres; ++i) {
+        const LeleTensor* res = i == 0 ? res1 : res2;
+        LeleBuf* dst = i == nres - 1 ? out : (cur == t0 ? t1 : t0);
+        LeleTensor t{cur->data, sh, r, LELE_F32, LELE_MEM_DEVICE};
+        int64_t sh2[LELE_MAX_RANK];
+        int32_t r2 = 0;
+        LELE_TRY(lele_hip_binary(ctx, 0 /* add */, &t, res, dst, sh2, &r2));
+        for (int d = 0; d < r2; ++d) sh[d] = sh2[d];
+        r = r2;
+        cur = dst;
     }
     return set_shape_v(out_shape, out_rank, std::vector<int64_t>(sh, sh + r));
 }
-
 
 /* ---- per-stage stopwatch of fused_quantized_linear (bench.py's roofline block for the model path) ------------------- */
 int lele_hip_quant_set_profiling(LeleCtx* ctx, int on) {

@@ -396,14 +396,74 @@ inline ViewGeom walk_chain(const std::vector<int64_t>& src_shape, const Json& ch
     return g;
 }
 
-inline TensorView view_copy(const TensorView& x, const Json& chain, Buffer& out) {
-    const ViewGeom g = walk_chain(x.shape, chain);
-    return kernels::strided(x, g.shape, g.strides, g.offset, nullptr, out);
+// the chain run as the operators it stands for (slice, reshape of a contiguous tensor, transpose) with real copies: the fallback
+// when the chain is not ONE strided view of its source -- shapes are not known when a plan is compiled.  `pool` keeps the
+// intermediate buffers alive with the runner.
+inline TensorView materialise_chain(const TensorView& x, const Json& chain, Buffer* out, std::vector<std::unique_ptr<Buffer>>& pool) {
+    TensorView cur = x;
+    for (size_t i = 0; i < chain.arr.size(); ++i) {
+        const Json& step = chain.arr[i];
+        const std::string& kind = step.arr.at(0).str;
+        const bool last = i + 1 == chain.arr.size();
+        auto dst = [&]() -> Buffer& {
+            if (last && out) return *out;
+            pool.push_back(std::make_unique<Buffer>());
+            return *pool.back();
+        };
+        if (kind == "slice") {
+            const int64_t axis = step.arr.at(1).as_int(), start = step.arr.at(2).as_int(), len = step.arr.at(3).as_int();
+            cur = kernels::slice(cur, {start}, {start + len}, {axis}, {1}, dst());
+        } else if (kind == "reshape") {
+            std::vector<int64_t> tgt;
+            for (const Json& d : step.arr.at(1).arr) tgt.push_back(d.as_int());
+            cur = kernels::reshape(cur, tgt);
+        } else if (kind == "transpose") {
+            std::vector<int64_t> perm;
+            for (const Json& d : step.arr.at(1).arr) perm.push_back(d.as_int());
+            cur = kernels::transpose(cur, perm, dst());
+        } else {
+            throw Error("view: unknown step " + kind);
+        }
+    }
+    return cur;
+}
+
+inline TensorView view_copy(const TensorView& x, const Json& chain, Buffer& out, std::vector<std::unique_ptr<Buffer>>* pool = nullptr) {
+    try {
+        const ViewGeom g = walk_chain(x.shape, chain);
+        return kernels::strided(x, g.shape, g.strides, g.offset, nullptr, out);
+    } catch (const Error&) {
+        if (!pool) throw;
+        return materialise_chain(x, chain, &out, *pool);
+    }
 }
 
 // kernels.py matmul_view: matmul of two views, the product optionally stored transposed (out_perm) and reshaped
+inline TensorView matmul_view_direct(const TensorView& a, const Json& a_chain, const TensorView& b, const Json& b_chain,
+                                     const std::vector<int64_t>* out_perm, const std::vector<int64_t>* out_reshape, Buffer& out);
+
+// kernels.py matmul_view.  Geometries the strided GEMM does not take (a view that needs a copy, a rank-2 run-time B against a batched
+// A, ...) run the node sequence the op stands for: materialise the views, `matmul`, transpose / reshape the product.
 inline TensorView matmul_view(const TensorView& a, const Json& a_chain, const TensorView& b, const Json& b_chain,
-                              const std::vector<int64_t>* out_perm, const std::vector<int64_t>* out_reshape, Buffer& out) {
+                              const std::vector<int64_t>* out_perm, const std::vector<int64_t>* out_reshape, Buffer& out,
+                              std::vector<std::unique_ptr<Buffer>>* pool = nullptr) {
+    try {
+        return matmul_view_direct(a, a_chain, b, b_chain, out_perm, out_reshape, out);
+    } catch (const Error&) {
+        if (!pool) throw;
+    }
+    TensorView am = a_chain.arr.empty() ? a : materialise_chain(a, a_chain, nullptr, *pool);
+    TensorView bm = b_chain.arr.empty() ? b : materialise_chain(b, b_chain, nullptr, *pool);
+    const bool post = out_perm || out_reshape;
+    pool->push_back(std::make_unique<Buffer>());
+    TensorView res = kernels::matmul(am, bm, post ? *pool->back() : out);
+    if (out_perm) res = kernels::transpose(res, *out_perm, out);
+    if (out_reshape) res = kernels::reshape(res, *out_reshape);
+    return res;
+}
+
+inline TensorView matmul_view_direct(const TensorView& a, const Json& a_chain, const TensorView& b, const Json& b_chain,
+                                     const std::vector<int64_t>* out_perm, const std::vector<int64_t>* out_reshape, Buffer& out) {
     const ViewGeom ga = walk_chain(a.shape, a_chain), gb = walk_chain(b.shape, b_chain);
     const size_t r = ga.shape.size();
     if (r != gb.shape.size() || r < 2 || r > 4) throw Error("matmul_view: operand views must have equal rank 2..4");
@@ -562,6 +622,7 @@ class Runner {
     std::unordered_map<std::string, std::pair<TV, std::shared_ptr<std::vector<char>>>> weights_;
     std::unordered_map<std::string, Val> env_;
     size_t calls_ = 0, stmt_ = 0;
+    std::vector<std::unique_ptr<Buffer>> fallback_pool_;  // intermediates of fused forms that ran as their node sequence
     Buffer attn_tmp0_, attn_tmp1_;  // scores / probabilities of an attention_view statement that runs as the three-call sequence
 
     std::string wkey(const Json& w) const { return v2_ ? weight_key(w) : std::to_string(w.arr[1].as_int()); }
@@ -936,13 +997,13 @@ class Runner {
             }
             return set(st, 0, K::transpose(x, perm, o));
         }
-        if (fn == "view_copy") return set(st, 0, view_copy(tensor(a[0]), a[1].at("chain"), o));
+        if (fn == "view_copy") return set(st, 0, view_copy(tensor(a[0]), a[1].at("chain"), o, &fallback_pool_));
         if (fn == "matmul_view") {
             std::vector<int64_t> perm, resh;
             if (!is_none(a[4])) perm = ints(a[4]);
             if (!is_none(a[5])) resh = ints(a[5]);
             return set(st, 0, matmul_view(tensor(a[0]), a[1].at("chain"), tensor(a[2]), a[3].at("chain"), is_none(a[4]) ? nullptr : &perm,
-                                          is_none(a[5]) ? nullptr : &resh, o));
+                                          is_none(a[5]) ? nullptr : &resh, o, &fallback_pool_));
         }
         if (fn == "attention_view") {
             std::vector<int64_t> perm, resh;

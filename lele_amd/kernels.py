@@ -791,11 +791,38 @@ def _walk_chain(shape, chain):
     return shape, strides, offset
 
 
+def _materialise_chain(x, chain, out=None, ctx=None):
+    """the chain run as the operators it stands for -- slice, reshape (of a contiguous tensor: always a view), transpose -- with
+    real copies: the fallback when the chain is not one strided view of its source (a Reshape that would need a copy mid-chain)"""
+    ctx = _ctx(ctx)
+    cur = x
+    steps = list(chain)
+    for i, step in enumerate(steps):
+        last = i == len(steps) - 1
+        if step[0] == "slice":
+            _, axis, start, length = step
+            cur = slice(cur, [start], [start + length], [axis], [1], out=out if last else ctx.buf(), ctx=ctx)
+        elif step[0] == "reshape":
+            cur = reshape(cur, list(step[1]))
+        elif step[0] == "transpose":
+            cur = transpose(cur, list(step[1]), out=out if last else ctx.buf(), ctx=ctx)
+        else:
+            raise _lib.LeleError("view: unknown step %r" % (step[0],))
+    return cur
+
+
 def view_copy(input, chain, out=None, ctx=None):
     """One strided copy for a chain of views of `input`: ["slice", axis, start, length], ["reshape", dims] (0 copies the
     dimension, one -1 is inferred: shape.rs:2-13), ["transpose", perm].  Equal, bit for bit, to running slice / reshape /
-    transpose one after the other (they are exact copies); emitted by lele_amd.compiler for Split -> Reshape -> Transpose."""
-    shape, strides, offset = _walk_chain(_shape_of(input), chain)
+    transpose one after the other (they are exact copies); emitted by lele_amd.compiler for Split -> Reshape -> Transpose.
+    A chain that is not ONE strided view of its source (shapes are not known when the plan is compiled) runs step by step."""
+    try:
+        shape, strides, offset = _walk_chain(_shape_of(input), chain)
+    except _lib.LeleError:
+        res = _materialise_chain(input, chain, out, ctx)
+        if out is not None and (not isinstance(unwrap(res), _lib.DevTensor) or unwrap(res).buf is not out):
+            res = _strided(res, list(_shape_of(res)), _row_major_strides(list(_shape_of(res))), 0, None, out, ctx)
+        return res
     return _strided(input, shape, strides, offset, None, out, ctx)
 
 
@@ -807,10 +834,27 @@ class _MatView(C.Structure):
 def matmul_view(a, a_chain, b, b_chain, out_perm=None, out_reshape=None, out=None, ctx=None):
     """matmul(view(a), view(b)) with the views never materialised and, optionally, the product stored as
     transpose(result, out_perm) [then reshaped]: bit-identical to view_copy + matmul + transpose (same kernels, same tiles)."""
-    ash, ast, aoff = _walk_chain(_shape_of(a), a_chain or [])
-    bsh, bst, boff = _walk_chain(_shape_of(b), b_chain or [])
-    if len(ash) != len(bsh) or not 2 <= len(ash) <= 4 or ash[:-2] != bsh[:-2]:
-        raise _lib.LeleError("matmul_view: operand views %s x %s must have equal batch dimensions and rank 2..4" % (ash, bsh))
+    try:
+        ash, ast, aoff = _walk_chain(_shape_of(a), a_chain or [])
+        bsh, bst, boff = _walk_chain(_shape_of(b), b_chain or [])
+        direct = len(ash) == len(bsh) and 2 <= len(ash) <= 4 and ash[:-2] == bsh[:-2] and \
+            (ast[-1] == 1 or ast[-2] == 1) and (bst[-1] == 1 or bst[-2] == 1) and \
+            (out_perm is None or out_perm[-1] % len(out_perm) == len(out_perm) - 1)
+    except _lib.LeleError:
+        direct = False
+    if not direct:
+        # geometries the strided GEMM does not take (a view that needs a copy, a rank-2 run-time B against a batched A, operands
+        # without a unit stride, a store that is not row-contiguous): the node sequence this op stands for -- materialise the
+        # views, `matmul` (which broadcasts an un-batched B, gemm.rs:131), transpose / reshape the product
+        ctx = _ctx(ctx)
+        am = _materialise_chain(a, a_chain or [], ctx=ctx) if a_chain else a
+        bm = _materialise_chain(b, b_chain or [], ctx=ctx) if b_chain else b
+        res = matmul(am, bm, out=None if (out_perm or out_reshape is not None) else out, ctx=ctx)
+        if out_perm:
+            res = transpose(res, list(out_perm), out=out, ctx=ctx)
+        if out_reshape is not None:
+            res = reshape(res, list(out_reshape))
+        return res
     if ash[-1] != bsh[-2]:
         raise _lib.LeleError("MatMul K dim mismatch: %d vs %d" % (ash[-1], bsh[-2]))
     m, k, n = ash[-2], ash[-1], bsh[-1]

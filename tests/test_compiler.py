@@ -376,8 +376,8 @@ def test_extra_fused_kernels_are_bit_identical_to_their_sequences(ctx):
         chain = [["slice", 2, start, 512], ["reshape", [0, 0, 4, 128]], ["transpose", perm]]
         assert np.array_equal(K.view_copy(qkv, chain, ctx=ctx).numpy(), qkv[:, :, start:start + 512].reshape(3, 41, 4, 128).transpose(perm))
     assert np.array_equal(K.view_copy(qkv, [["slice", -1, 100, 7]], ctx=ctx).numpy(), qkv[..., 100:107])
-    with pytest.raises(Exception, match="needs a copy"):
-        K.view_copy(qkv, [["transpose", [0, 2, 1]], ["reshape", [-1]]], ctx=ctx)
+    # a chain that is not ONE strided view (the reshape after the transpose needs a copy) runs step by step: same values
+    assert np.array_equal(K.view_copy(qkv, [["transpose", [0, 2, 1]], ["reshape", [-1]]], ctx=ctx).numpy(), qkv.transpose(0, 2, 1).reshape(-1))
     # matmul on views == copy the views out, matmul, transpose the result: same kernels and tiles, hence the same bits
     for b_, t_ in ((3, 41), (1, 504), (32, 171), (2, 7)):
         qkv = rng.standard_normal((b_, t_, 1536)).astype(np.float32)
@@ -396,9 +396,9 @@ def test_extra_fused_kernels_are_bit_identical_to_their_sequences(ctx):
         assert av.shape == (b_, t_, 512) and np.array_equal(av.numpy(), av_seq.numpy()), (b_, t_)
     a2, b2 = rng.standard_normal((37, 20)).astype(np.float32), rng.standard_normal((50, 20)).astype(np.float32)
     assert np.array_equal(K.matmul_view(a2, [], b2, [["transpose", [1, 0]]], ctx=ctx).numpy(), K.gemm(a2, b2, None, 1.0, 0.0, False, True, ctx=ctx).numpy())
-    with pytest.raises(Exception, match="contiguous along"):
-        K.matmul_view(rng.standard_normal((4, 6, 8, 10)).astype(np.float32), [["transpose", [0, 3, 1, 2]]],
-                      rng.standard_normal((4, 10, 8, 5)).astype(np.float32), [], ctx=ctx)
+    # an operand view with no unit stride among its last two dimensions: the views are copied out and `matmul` runs (the sequence)
+    a4, b4 = rng.standard_normal((4, 6, 8, 10)).astype(np.float32), rng.standard_normal((4, 10, 8, 5)).astype(np.float32)
+    assert close(K.matmul_view(a4, [["transpose", [0, 3, 1, 2]]], b4, [], ctx=ctx).numpy(), a4.transpose(0, 3, 1, 2) @ b4)
 
 
 @pytest.mark.gpu
@@ -677,3 +677,58 @@ def test_silero_tool_model_compiles_to_the_expected_chain():
     assert all(s.get("may_alias") for s in plan["statements"] if s["fn"] == "transpose")
     full, blob2 = compile_model(data, "silero_shaped")
     assert [s["op"] for s in full["statements"]] == ["host", "if"] and len(blob2) > 1.7 * len(blob)
+
+
+@pytest.mark.gpu
+def test_extra_fusions_fall_back_where_shapes_rule_the_fused_form_out(ctx):
+    """The extra fusions are chosen when the plan is compiled, without shape knowledge: where the run-time shapes rule a
+    fused form out, it must run as the node sequence it stands for -- same results as extra_fusions=False, no error.
+      (a) a residual that broadcasts OUTWARD after a quantised linear, and an Add -> Add whose last operand enlarges the sum;
+      (b) a MatMul of a Reshape -> Transpose view against a rank-2 run-time tensor;
+      (c) a Split -> Reshape -> Transpose chain whose Reshape is not expressible in strides (it merges a sliced dimension)."""
+    from lele_amd.tensor import TensorView
+    rng = np.random.default_rng(11)
+    i64 = lambda *v: np.array(v, np.int64)  # noqa: E731
+
+    def both(model, inputs):
+        outs = {}
+        for extra in (False, True):
+            plan, blob = compile_model(model, extra_fusions=extra)
+            _, res = run_plan(ctx, plan, blob, {k: TensorView(ctx.buf().upload(v)) for k, v in inputs.items()})
+            outs[extra] = [r.numpy() for r in res]
+            outs[extra, "fns"] = fns(plan)
+        for a, b in zip(outs[False], outs[True]):
+            assert a.shape == b.shape and np.array_equal(a, b)
+        return outs
+
+    # (a) quantised linear [1, T, N] + residual [3, T, N]; then (x + y) + z with z [2, 3, T, N]
+    k, n, t = 32, 24, 5
+    w = np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.uint8)
+    g = pb.Graph([], [pb.ValueInfo("x", pb.FLOAT, [1, t, k]), pb.ValueInfo("r", pb.FLOAT, [3, t, n]), pb.ValueInfo("z", pb.FLOAT, [2, 3, t, n])],
+                 [pb.ValueInfo("y", pb.FLOAT, None)],
+                 [pb.Tensor("w", w), pb.Tensor("ws", (np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32)), pb.Tensor("wz", np.array(128, np.uint8)),
+                  pb.Tensor("b", (rng.standard_normal(n) * 0.02).astype(np.float32))])
+    g.node += [pb.Node("DynamicQuantizeLinear", ["x"], ["q", "s", "zp"]), pb.Node("Mul", ["s", "ws"], ["cs"]),
+               pb.Node("MatMulInteger", ["q", "w", "zp", "wz"], ["mm"]), pb.Node("Cast", ["mm"], ["mmf"], to=1), pb.Node("Mul", ["mmf", "cs"], ["dq"]),
+               pb.Node("Add", ["dq", "b"], ["lin"]), pb.Node("Add", ["lin", "r"], ["s1"]), pb.Node("Add", ["s1", "r"], ["s2"]), pb.Node("Add", ["s2", "z"], ["y"])]
+    o = both(pb.Model(g, opset=17).serialize(), {"x": rng.standard_normal((1, t, k)).astype(np.float32), "r": rng.standard_normal((3, t, n)).astype(np.float32),
+                                                  "z": rng.standard_normal((2, 3, t, n)).astype(np.float32)})
+    assert o[True][0].shape == (2, 3, t, n) and "fused_quantized_linear_residual" in o[True, "fns"]
+
+    # (b) [B, T, H, D] -> transpose -> [B, H, T, D] (a view) x run-time [D, 7]
+    g = pb.Graph([], [pb.ValueInfo("x", pb.FLOAT, [2, 6, 32]), pb.ValueInfo("m", pb.FLOAT, [8, 7])], [pb.ValueInfo("y", pb.FLOAT, None)],
+                 [pb.Tensor("hs", i64(0, 0, 4, 8))])
+    g.node += [pb.Node("Reshape", ["x", "hs"], ["xr"]), pb.Node("Transpose", ["xr"], ["xt"], perm=[0, 2, 1, 3]), pb.Node("MatMul", ["xt", "m"], ["y"])]
+    x, m = rng.standard_normal((2, 6, 32)).astype(np.float32), rng.standard_normal((8, 7)).astype(np.float32)
+    o = both(pb.Model(g, opset=17).serialize(), {"x": x, "m": m})
+    assert close(o[True][0], x.reshape(2, 6, 4, 8).transpose(0, 2, 1, 3) @ m)
+
+    # (c) Split along the last axis, then a Reshape that merges the split axis with the one before it, then Transpose
+    g = pb.Graph([], [pb.ValueInfo("x", pb.FLOAT, [2, 6, 12])], [pb.ValueInfo("y", pb.FLOAT, None), pb.ValueInfo("y2", pb.FLOAT, None)],
+                 [pb.Tensor("sp", i64(4, 8)), pb.Tensor("rs", i64(2, 3, 8)), pb.Tensor("rs2", i64(2, 6, 2, 4))])
+    g.node += [pb.Node("Split", ["x", "sp"], ["a", "b"], axis=2), pb.Node("Reshape", ["a", "rs"], ["ar"]), pb.Node("Transpose", ["ar"], ["y"], perm=[0, 2, 1]),
+               pb.Node("Reshape", ["b", "rs2"], ["br"]), pb.Node("Transpose", ["br"], ["y2"], perm=[0, 2, 1, 3])]
+    x = rng.standard_normal((2, 6, 12)).astype(np.float32)
+    o = both(pb.Model(g, opset=17).serialize(), {"x": x})
+    assert np.array_equal(o[True][0], x[:, :, :4].reshape(2, 3, 8).transpose(0, 2, 1))
+    assert np.array_equal(o[True][1], x[:, :, 4:].reshape(2, 6, 2, 4).transpose(0, 2, 1, 3))
