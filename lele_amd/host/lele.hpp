@@ -11,6 +11,7 @@
 #pragma once
 #include "lele_hip.h"
 
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -49,13 +50,41 @@ class Ctx {
         check(rc);
         return g;
     }
-    static Ctx& current() {  // thread-local default, like lele's thread-local scratch and caches
-        static thread_local Ctx ctx(0);
+    static Ctx& current() {  // thread-local default, like lele's thread-local scratch and caches; LELE_HIP_DEVICE picks the GPU
+        static thread_local Ctx ctx(default_device());
         return ctx;
+    }
+    static int default_device() {
+        const char* d = std::getenv("LELE_HIP_DEVICE");
+        return d && *d ? std::atoi(d) : 0;
     }
 
    private:
     LeleCtx* h_ = nullptr;
+};
+
+class Comm {  // this process's membership of an RCCL communicator (one process per GPU), bound to a ctx stream (lele_hip_comm_*)
+   public:
+    Comm(const Ctx& ctx, const std::string& id_file, int rank, int world, int timeout_ms = 120000) : rank_(rank), world_(world) {
+        check(lele_hip_comm_init_file(ctx.raw(), id_file.c_str(), rank, world, timeout_ms, &h_));
+    }
+    ~Comm() {
+        if (h_) lele_hip_comm_destroy(h_);
+    }
+    Comm(const Comm&) = delete;
+    Comm& operator=(const Comm&) = delete;
+    LeleComm* raw() const { return h_; }
+    int rank() const { return rank_; }
+    int world() const { return world_; }
+    void barrier() const { check(lele_hip_comm_barrier(h_)); }
+    int64_t max(int64_t v) const {
+        check(lele_hip_comm_allreduce_max_i64(h_, &v));
+        return v;
+    }
+
+   private:
+    LeleComm* h_ = nullptr;
+    int rank_, world_;
 };
 
 class Graph {  // a captured op sequence; replays on the ctx stream with one hipGraphLaunch

@@ -1,0 +1,66 @@
+"""The exchange step of the sharded recogniser through the C ABI's own RCCL communicator (lele_hip_comm_*).
+
+The GPU box has one device and RCCL refuses two ranks on one device, so what runs here is a 1-rank communicator -- RCCL is
+loaded (dlopen), the unique id travels through a file, the collective is issued on the ctx stream from device memory -- plus the
+native runner's `--ranks 1 --decode` loop.  The N > 1 logic (sharding, packing, ragged shards) is covered with gloo on CPU in
+tests/test_multiprocess.py; N = 2..8 over xGMI is the driver's scaling run of bench.py."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_one_rank_communicator_through_the_c_abi(ctx, tmp_path):
+    from lele_amd import kernels as K
+    from lele_amd._lib import Comm, Weight
+    from lele_amd.sharded import all_gather_ids, all_gather_ids_rccl
+    comm = Comm.from_file(ctx, str(tmp_path / "uid"), 0, 1, timeout_ms=10000)
+    assert (comm.rank, comm.world) == (0, 1)
+    ids = np.arange(24, dtype=np.int32).reshape(4, 6) - 3
+    got = comm.allgather_i32(ctx.buf().upload(ids.reshape(-1)))
+    assert got.shape == (1, 24) and np.array_equal(got.numpy()[0], ids.reshape(-1))
+    assert comm.allreduce_max(41) == 41
+    comm.barrier()
+    # the recogniser's tail: logits -> arg-max -> token filter on the device -> packed rows gathered -> transcripts on the host
+    rng = np.random.default_rng(0)
+    logits = rng.standard_normal((5, 37, 300)).astype(np.float32)
+    skip = np.zeros(300, np.uint8)
+    skip[0] = 1
+    skip[250:] = 1
+    kept, counts = K.token_filter(K.argmax_last(ctx.buf().upload(logits), ctx=ctx), Weight(skip), ctx=ctx)
+    via_rccl = all_gather_ids_rccl(kept, counts, 5, comm, ctx)
+    local = all_gather_ids(kept.numpy(), counts.numpy(), 5)
+    assert len(via_rccl) == 5 and all(np.array_equal(a, b) for a, b in zip(via_rccl, local))
+    am = logits.argmax(-1)
+    for u in range(5):
+        assert np.array_equal(via_rccl[u], np.array([t for t in am[u] if not skip[t]], np.int32))
+    comm.close()
+
+
+def test_native_runner_ranks_and_decode(ctx, tmp_path):
+    """lele_run --ranks 1 --decode: fork, file rendezvous, plan, arg-max on the device, RCCL all-gather, rank 0 prints"""
+    torch = pytest.importorskip("torch")
+    from lele_amd.compiler import compile_model
+    from tests.onnx_util import export
+    from tests.test_compiler import Toy
+    x = torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(3))
+    plan, blob = compile_model(export(Toy(), (x,), opset=13))
+    (tmp_path / "p.json").write_text(json.dumps(plan))
+    (tmp_path / "w.bin").write_bytes(blob)
+    x.numpy().tofile(tmp_path / "x.bin")
+    exe = os.path.join(ROOT, "lele_amd", "lele_run")
+    r = subprocess.run([exe, str(tmp_path / "p.json"), str(tmp_path / "w.bin"), "--input", "x=%s:f32:2,3,16,16" % (tmp_path / "x.bin"), "--out",
+                        str(tmp_path / "o"), "--ranks", "1", "--decode"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    out = np.fromfile(tmp_path / "o0.bin", np.float32).reshape(rec["outputs"][0])
+    assert rec["ranks"] == 1 and rec["gathered_ids"] == [1, int(np.prod(out.shape[:-1]))]
+    # tokenizer.rs:50-61: the LAST of equal maxima wins
+    last_max = out.shape[-1] - 1 - np.flip(out, -1).argmax(-1)
+    assert rec["ids_checksum"] == int(last_max.sum())
