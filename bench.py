@@ -44,6 +44,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 SAMPLE_RATE = 16000
 SECONDS = 30
+VALU_PEAK_TLANE = 78.6  # T lane-ops/s: 256 CUs x 128 lanes x 2.4 GHz
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 I8_PEAK_TOPS = 3944.0   # MI355X_MICROARCH.md: i8 MFMA >= 3944 TOPS measured (16x16x64)
 
@@ -419,7 +420,11 @@ def run_rank(args):
             a = lane_ops / (main_ms * 1e-3)
             roof.update({"bound": "valu", "achieved": round(a / 1e12, 3), "peak": round(valu_peak / 1e12, 3), "unit": "Tlane-op/s",
                          "frac": round(a / valu_peak, 4), "valu_lane_ops_per_launch": lane_ops,
-                         "peak_source": prof.get("valu_peak_source")})
+                         "peak_source": prof.get("valu_peak_source"),
+                         # the data-sheet figure beside it: 256 CUs x 128 f32 lanes per clock at 2.4 GHz (157.3 TFLOP/s of vector FMA
+                         # in MI355X_MICROARCH.md = 78.6 T lane-ops/s; packed f32 issues at half rate, so it adds nothing); the chip
+                         # sustains ~1.7 GHz under a pure VALU load, which is what the measured peak above reflects
+                         "peak_datasheet": VALU_PEAK_TLANE, "frac_datasheet": round(a / 1e12 / VALU_PEAK_TLANE, 4)})
         else:
             roof.update({"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4)})

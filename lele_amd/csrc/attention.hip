@@ -49,16 +49,22 @@ struct AttnArgs {
 constexpr int kDh = 128;   // head dimension (8 chunks of 16)
 constexpr int kSPad = 4;   // LDS row padding (floats)
 
-template <int NT>  // softmax registers per lane: tpad <= 32 * NT
+// NT = softmax registers per lane (tpad <= 32 * NT).  RT = 32-row tiles of queries per workgroup (1 or 2).  With RT = 2 the waves
+// pair up: wave w owns row tile w & 1 throughout; in phase 1 it takes every second key tile of that row tile (three each for the six
+// tiles of a 10 s utterance: balanced, where RT = 1 leaves two of four waves with half the work), in phase 3 two of the four
+// 32-dim output tiles, fed by ONE set of P fragments.  K and V are read half as often.
+template <int NT, int RT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attention_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float s_sp[];  // S, then P: [32][tpad + 4]
+    extern __shared__ __attribute__((aligned(16))) float s_sp[];  // S, then P: [32 * RT][tpad + 4]
     __shared__ float s_mm[4][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hv = lane >> 5, l31 = lane & 31;
     const int pitch = a.tpad + kSPad;
     const int qb = blockIdx.x % a.nqb, bh = blockIdx.x / a.nqb;
     const int bi = bh % a.batch_inner, bo = bh / a.batch_inner;
-    const int i0 = qb * 32;
+    const int i0 = qb * 32 * RT;
+    const int rt = RT == 2 ? (wave & 1) : 0;   // this wave's row tile
+    const int kw = RT == 2 ? (wave >> 1) : wave, kstep = 4 / RT;  // its first key tile and the stride between its key tiles
     const float* qp = a.q + bo * a.q_so + bi * a.q_si;
     const float* kp = a.k + bo * a.k_so + bi * a.k_si;
     const float* vp = a.v + bo * a.v_so + bi * a.v_si;
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     // ---- phase 1: S = Q K^T.  Lane (l31, hv) of a 16-d chunk c owns d = 16c + 8hv + [0, 8): two float4 per chunk
     // K fragments in two register sets of half a head dimension each (4 chunks = 32 registers), requested one set ahead
     float4 ka[8], kb[8];
-    int tq_ = wave, hq = 0;  // (key tile, half) of the next set to request
+    int tq_ = kw, hq = 0;  // (key tile, half) of the next set to request
     auto reqk = [&](float4 (&w)[8]) {
         const int tc = tq_ < ntile ? tq_ : ntile - 1;                 // clamped: a harmless repeated load instead of a branch
         const int key = tc * 32 + l31;
@@ -79,12 +85,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
             w[2 * c + 1] = *reinterpret_cast<const float4*>(src + 16 * c + 4);
         }
         hq ^= 1;
-        if (hq == 0) tq_ += 4;
+        if (hq == 0) tq_ += kstep;
     };
     reqk(ka);
     float4 qf[16];  // this lane's Q row: chunk c -> qf[2c], qf[2c + 1]
     {
-        const int row = i0 + l31;
+        const int row = i0 + 32 * rt + l31;
         const float* src = qp + (int64_t)(row < a.tq ? row : a.tq - 1) * a.q_sr + 8 * hv;  // padded rows re-read the last row; never stored
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
             for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], kk[s], acc, 0, 0, 0);
         }
     };
-    for (int t = wave; t < ntile; t += 4) {
+    for (int t = kw; t < ntile; t += kstep) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -115,19 +121,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         mmk(kb, 1, acc);
         __builtin_amdgcn_sched_barrier(0);
         // C layout of the 32x32 MFMA: column (key) = l31, row = (r & 3) + 8 (r >> 2) + 4 hv
-        float* dst = s_sp + t * 32 + l31;
+        float* dst = s_sp + 32 * rt * pitch + t * 32 + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * hv) * pitch] = acc[r];
     }
     __syncthreads();
 
-    // ---- phase 2: row softmax, eight 32-lane groups x four rows.  P = 0 beyond the last key (those columns then add exact zeros)
+    // ---- phase 2: row softmax, eight 32-lane groups x 4 RT rows.  P = 0 beyond the last key (those columns then add exact zeros)
     {
         const int g = tid >> 5, l = tid & 31;
         const float sc = a.scale ? a.scale[0] : 1.0f;
 #pragma unroll 1
-        for (int rr = 0; rr < 4; ++rr) {
-            float* row = s_sp + (g * 4 + rr) * pitch;
+        for (int rr = 0; rr < 4 * RT; ++rr) {
+            float* row = s_sp + (g * 4 * RT + rr) * pitch;
             float v[NT];
 #pragma unroll
             for (int c = 0; c < NT; ++c) {
@@ -145,56 +151,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     }
     __syncthreads();
 
-    // ---- phase 3: O = P V.  Wave w owns dims [32w, 32w + 32); a set = 32 keys (two 16-key chunks): lane (l31, hv) holds
-    // V[16c + 8hv + s][32w + l31] (16 registers) and reads P[row l31][16c + 8hv .. + 8] from LDS
-    float va[16], vb[16];
+    // ---- phase 3: O = P V.  A wave owns ND = RT output tiles of 32 dims of its row tile; a set = 32 keys (two 16-key chunks):
+    // lane (l31, hv) holds V[16c + 8hv + s][32 d + l31] (16 registers per output tile) and reads P[row l31][16c + 8hv .. + 8] from LDS
+    constexpr int ND = RT;
+    const int dw = RT == 2 ? (wave >> 1) : wave;  // first output tile; the second (RT = 2) is dw + 2
+    float va[ND][16], vb[ND][16];
     int jq = 0;  // first key of the next set to request
-    auto reqv = [&](float (&w)[16]) {
+    auto reqv = [&](float (&w)[ND][16]) {
         const int jc = jq < a.tpad ? jq : a.tpad - 32;
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int key = jc + 16 * c + 8 * hv + s;
-                w[8 * c + s] = vp[(int64_t)(key < a.tk ? key : a.tk - 1) * a.v_sr + 32 * wave + l31];
+                const float* src = vp + (int64_t)(key < a.tk ? key : a.tk - 1) * a.v_sr + 32 * dw + l31;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) w[d][8 * c + s] = src[64 * d];
             }
         jq += 32;
     };
-    const float* prow = s_sp + l31 * pitch + 8 * hv;
-    auto mmv = [&](const float (&w)[16], int j0, f32x16& acc) {
+    const float* prow = s_sp + (32 * rt + l31) * pitch + 8 * hv;
+    f32x16 oacc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.0f;
+    auto mmv = [&](const float (&w)[ND][16], int j0) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const float4 p0 = *reinterpret_cast<const float4*>(prow + j0 + 16 * c), p1 = *reinterpret_cast<const float4*>(prow + j0 + 16 * c + 4);
             const float pa[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
 #pragma unroll
-            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], w[8 * c + s], acc, 0, 0, 0);
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int d = 0; d < ND; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], w[d][8 * c + s], oacc[d], 0, 0, 0);
         }
     };
-    f32x16 oacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[r] = 0.0f;
     reqv(va);
     for (int j0 = 0; j0 < a.tpad; j0 += 64) {
         reqv(vb);
         __builtin_amdgcn_sched_barrier(0);
-        mmv(va, j0, oacc);
+        mmv(va, j0);
         __builtin_amdgcn_sched_barrier(0);
         reqv(va);
         __builtin_amdgcn_sched_barrier(0);
-        mmv(vb, j0 + 32, oacc);
+        mmv(vb, j0 + 32);
         __builtin_amdgcn_sched_barrier(0);
     }
     float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * hv;
-        if (row < a.tq) {
-            const float val = oacc[r];
-            op[(int64_t)row * a.o_sr + 32 * wave + l31] = val;
-            mn = val < mn ? val : mn;
-            mx = val > mx ? val : mx;
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * hv;
+            if (row < a.tq) {
+                const float val = oacc[d][r];
+                op[(int64_t)row * a.o_sr + 32 * (dw + 2 * d) + l31] = val;
+                mn = val < mn ? val : mn;
+                mx = val > mx ? val : mx;
+            }
         }
-    }
     if (a.stat) {  // uniform: one pair per workgroup
         for (int off = 32; off > 0; off >>= 1) {
             const float p = __shfl_xor(mn, off), q = __shfl_xor(mx, off);
@@ -274,7 +290,11 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
                  "attention_view: unsupported geometry (Q / K rows are not 16-byte aligned)");
     a.tq = (int)t_q, a.tk = (int)t_k, a.tpad = (int)((t_k + 63) & ~int64_t(63));
     a.batch_inner = (int)batch_inner;
-    a.nqb = (int)((t_q + 31) / 32);
+    // two row tiles per workgroup when that still leaves at least one workgroup per CU (a batch of utterances); one otherwise
+    const char* rt_env = getenv("LELE_HIP_ATTENTION_RT");
+    const int rt = rt_env && *rt_env ? atoi(rt_env) : (fb * ((t_q + 63) / 64) >= ctx->num_cus ? 2 : 1);
+    const int qrows = rt == 2 ? 64 : 32;
+    a.nqb = (int)((t_q + qrows - 1) / qrows);
     a.scale = (const float*)dsc;
     // result statistics for the dynamic quantisation that reads this tensor next: valid when a slice of the consumer is exactly
     // one outer batch element, i.e. the result is laid out [batch_outer][t_q][batch_inner * dh] (heads merged)
@@ -284,14 +304,22 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
         LELE_TRY(out->reserve_rowstat(nstat));
         if ((size_t)nstat <= out->rowstat_cap) a.stat = out->rowstat;
     }
-    const size_t lds = (size_t)32 * (a.tpad + kSPad) * 4;
+    const size_t lds = (size_t)qrows * (a.tpad + kSPad) * 4;
     const dim3 grid((unsigned)(fb * a.nqb));
+#define LELE_ATTN(NT_, RT_)                                                                                                \
+    do {                                                                                                                 \
+        auto kern = attention_kernel<NT_, RT_>;                                                                           \
+        if (lds > 60 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));               \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, a);                                                   \
+    } while (0)
     if (a.tpad <= 256) {
-        hipLaunchKernelGGL(attention_kernel<8>, grid, dim3(256), lds, ctx->stream, a);
+        if (rt == 2) LELE_ATTN(8, 2);
+        else LELE_ATTN(8, 1);
     } else {
-        if (lds > 60 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(&attention_kernel<16>), (int)lds));
-        hipLaunchKernelGGL(attention_kernel<16>, grid, dim3(256), lds, ctx->stream, a);
+        if (rt == 2) LELE_ATTN(16, 2);
+        else LELE_ATTN(16, 1);
     }
+#undef LELE_ATTN
     LELE_HIP_CHECK(hipGetLastError());
     if (a.stat) {
         out->rowstat_rows = nstat;

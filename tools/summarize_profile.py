@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_<tag>/ (written by tools/profile_frontend.sh on the GPU box) into the tracked files
-under profiles/:  <tag>_frontend_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py`),
-<tag>_frontend_pmc.json (FETCH_SIZE / WRITE_SIZE per kernel, raw and corrected) and frontend_hbm_traffic.json
-(the per-launch HBM bytes bench.py reports as roofline.traffic).
+"""Condense gpurun_out/prof_<tag>/ (written by tools/profile_round.sh on the GPU box) into the tracked files under profiles/:
+
+  <tag>_frontend_kernel_stats.csv     rocprofv3 --kernel-trace --stats of `python bench.py --no-model` (kernel_stats table, verbatim)
+  <tag>_bench_plain.json              the JSON line of an unprofiled default `python bench.py`
+  <tag>_bench_under_rocprof.json      the JSON line of the profiled run (its roofline.kernel_ms must agree with AverageNs above)
+  <tag>_frontend_pmc.json             FETCH_SIZE / WRITE_SIZE / SQ counters of fe_main_kernel, averaged per launch
+  <tag>_valu_rate.json                tools/valu_rate: measured VALU issue cost per wave-instruction (plain and packed f32)
+  <tag>_sensevoice_{c3,c4}_compiled_kernel_stats.csv, <tag>_microbench.json, <tag>_qlinear_variants.json
+  frontend_roofline.json              the constants bench.py copies into its roofline block: HBM bytes per launch (PMC) and the VALU
+                                      work of one launch priced at the measured issue rate
 
 Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md "HBM": FETCH_SIZE / WRITE_SIZE are reported in KiB and were
-collected in separate --pmc passes; on gfx950 FETCH_SIZE counts 128-B read requests at 64 B, so wide coalesced
-streaming reads are doubled; WRITE_SIZE is taken as reported (it matches the kernel's known output bytes)."""
+collected in separate --pmc passes; on gfx950 FETCH_SIZE counts 128-B read requests at 64 B, so wide coalesced streaming reads are
+doubled; WRITE_SIZE is taken as reported (it matches the kernel's known output bytes)."""
 import collections
 import csv
 import json
@@ -17,44 +23,89 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def last_json(path):
+    if not os.path.exists(path):
+        return None
+    lines = [ln for ln in open(path).read().splitlines() if ln.startswith("{")]
+    return json.loads(lines[-1]) if lines else None
+
+
+def counters(path, kernel="fe_main_kernel"):
+    vals = collections.defaultdict(list)
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if kernel in r["Kernel_Name"]:
+                vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in vals.items()}, {k: len(v) for k, v in vals.items()}
+
+
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"), os.path.join(dst, tag + "_frontend_kernel_stats.csv"))
     for name in ("bench_under_rocprof.json", "bench_plain.json"):
-        p = os.path.join(src, name)
+        rec = last_json(os.path.join(src, name))
+        if rec:
+            json.dump(rec, open(os.path.join(dst, tag + "_" + name), "w"))
+    for c in ("c3", "c4"):
+        p = os.path.join(src, "sv", c + "_compiled_kernel_stats.csv")
         if os.path.exists(p):
-            line = [l for l in open(p).read().splitlines() if l.startswith("{")]
-            if line:
-                open(os.path.join(dst, tag + "_" + name), "w").write(line[-1] + "\n")
+            shutil.copy(p, os.path.join(dst, "%s_sensevoice_%s_compiled_kernel_stats.csv" % (tag, c)))
+    for a, b in (("microbench.json", "_microbench.json"), ("qlinear.json", "_qlinear_variants.json"), ("valu_rate.json", "_valu_rate.json")):
+        if os.path.exists(os.path.join(src, a)) and os.path.getsize(os.path.join(src, a)) > 2:
+            shutil.copy(os.path.join(src, a), os.path.join(dst, tag + b))
     pmc = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        vals = collections.defaultdict(list)
-        with open(os.path.join(src, "pmc_" + c, "bench_counter_collection.csv")) as f:
-            for r in csv.DictReader(f):
-                vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-        for k, v in vals.items():
-            short = "fe_main_kernel" if "fe_main_kernel" in k else "fe_frame_sum_kernel" if "fe_frame_sum" in k else None
-            if short:
-                pmc.setdefault(short, {})[c + "_KiB_avg"] = sum(v) / len(v)
-                pmc[short]["launches_" + c] = len(v)
-    for k, d in pmc.items():
-        if "FETCH_SIZE_KiB_avg" not in d or "WRITE_SIZE_KiB_avg" not in d:
-            continue
-        d["read_bytes_corrected"] = int(d["FETCH_SIZE_KiB_avg"] * 1024 * 2)  # gfx950: FETCH_SIZE is half of wide reads
-        d["write_bytes"] = int(d["WRITE_SIZE_KiB_avg"] * 1024)
-        d["hbm_bytes_per_launch"] = d["read_bytes_corrected"] + d["write_bytes"]
-    bench = json.loads(open(os.path.join(dst, tag + "_bench_plain.json")).read())
+        got = counters(os.path.join(src, "pmc_" + c, "bench_counter_collection.csv"))
+        if got:
+            pmc[c + "_KiB_avg"] = got[0].get(c)
+            pmc["launches_" + c] = got[1].get(c)
+    sq = counters(os.path.join(src, "pmc_sq", "bench_counter_collection.csv"))
+    if sq:
+        pmc.update({k: v for k, v in sq[0].items()})
+    if "FETCH_SIZE_KiB_avg" in pmc and "WRITE_SIZE_KiB_avg" in pmc:
+        pmc["read_bytes_corrected"] = int(pmc["FETCH_SIZE_KiB_avg"] * 1024 * 2)  # gfx950: FETCH_SIZE is half of wide reads
+        pmc["write_bytes"] = int(pmc["WRITE_SIZE_KiB_avg"] * 1024)
+        pmc["hbm_bytes_per_launch"] = pmc["read_bytes_corrected"] + pmc["write_bytes"]
+    bench = last_json(os.path.join(src, "bench_plain.json")) or last_json(os.path.join(src, "bench_under_rocprof.json"))
     batch = bench["config"]["batch_per_gpu"]
-    out = {"tag": tag, "batch": batch, "kernels": pmc,
-           "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"]}
-    json.dump(out, open(os.path.join(dst, tag + "_frontend_pmc.json"), "w"), indent=1)
-    json.dump({"batch": batch, "kernel": "fe_main_kernel", "bytes_per_launch": pmc["fe_main_kernel"]["hbm_bytes_per_launch"],
-               "source": "profiles/%s_frontend_pmc.json" % tag},
-              open(os.path.join(dst, "frontend_hbm_traffic.json"), "w"), indent=1)
-    print(json.dumps(out, indent=1))
+    json.dump({"tag": tag, "batch": batch, "kernel": "fe_main_kernel", "counters": pmc,
+               "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"]}, open(os.path.join(dst, tag + "_frontend_pmc.json"), "w"), indent=1)
+    # VALU work of one launch at the measured issue cost.  The ISA of the pass loop (tools/isa_loop.py) holds 519 packed-f32 and 448
+    # plain VALU instructions; SQ_INSTS_VALU counts both as one.  Cost per wave-instruction and SIMD from tools/valu_rate (4 waves
+    # per SIMD, the saturated regime): plain = the mean of v_add / v_mul / the fma+add pair, packed = the mean of the three v_pk ops.
+    roof = {"batch": batch, "kernel": "fe_main_kernel", "source": "profiles/%s_frontend_pmc.json, profiles/%s_valu_rate.json" % (tag, tag)}
+    if "hbm_bytes_per_launch" in pmc:
+        roof["hbm_bytes_per_launch"] = pmc["hbm_bytes_per_launch"]
+    vr = last_json_file(os.path.join(src, "valu_rate.json"))
+    if vr and "SQ_INSTS_VALU" in pmc:
+        plain = sum(vr[k]["wps4"]["ns_per_instr_per_simd"] for k in ("v_add_f32", "v_mul_f32", "v_fma_f32+v_add_f32_pair")) / 3
+        packed = sum(vr[k]["wps4"]["ns_per_instr_per_simd"] for k in ("v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32")) / 3
+        n = pmc["SQ_INSTS_VALU"]
+        n_packed, n_plain = n * 519 / 967.0, n * 448 / 967.0
+        simds = 1024
+        floor_ms = (n_plain * plain + n_packed * packed) / simds * 1e-6
+        lane_ops = n_plain * 64 + n_packed * 128
+        roof.update({"valu_wave_instructions_per_launch": n, "valu_packed_fraction_isa": round(519 / 967.0, 4),
+                     "valu_ns_per_plain_instr_per_simd": round(plain, 4), "valu_ns_per_packed_instr_per_simd": round(packed, 4),
+                     "valu_issue_floor_ms": round(floor_ms, 5), "valu_lane_ops_per_launch": int(lane_ops),
+                     # the rate at which the chip issues this kernel's own mix of plain and packed f32 lane-operations
+                     "valu_peak_lane_ops_per_s": lane_ops / (floor_ms * 1e-3),
+                     "valu_peak_source": "tools/valu_rate on this box: %.2f ns per plain and %.2f ns per packed-f32 wave-instruction and SIMD, "
+                                         "applied to the kernel's instruction mix" % (plain, packed)})
+    json.dump(roof, open(os.path.join(dst, "frontend_roofline.json"), "w"), indent=1)
+    print(json.dumps(roof, indent=1))
+
+
+def last_json_file(path):
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
 
 
 if __name__ == "__main__":
