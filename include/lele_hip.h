@@ -364,6 +364,14 @@ int lele_hip_fused_quantized_linear_residual(LeleCtx* ctx, const LeleTensor* inp
                                              const LeleTensor* weight_scale, const LeleTensor* weight_zero, const LeleTensor* bias,
                                              int apply_relu, const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out,
                                              int64_t* out_shape, int32_t* out_rank);
+/* two quantised linears with a ReLU between them (a transformer layer's feed-forward block):
+ *   fused_quantized_linear[_residual](fused_quantized_linear(input, w1.., apply_relu = 1), w2.., apply_relu2, res1, res2)
+ * (quantization.rs:77-169 twice; res1 / res2 may be NULL).  When the hidden layer is large its f32 tensor is never stored: the first
+ * product runs twice on the matrix cores (once for the range, once quantising straight to the i8 rows the second product reads) */
+int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_int8, const LeleTensor* w1_scale,
+                                 const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8,
+                                 const LeleTensor* w2_scale, const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2,
+                                 const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
 /* softmax(x * scale[0]) over the last axis: `mul` by a one-element tensor followed by `softmax` (norm.rs:8) */
 int lele_hip_softmax_scaled(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, int32_t axis, LeleBuf* out,
                             int64_t* out_shape, int32_t* out_rank);

@@ -762,6 +762,50 @@ class Lowering:
             dead.add(rd[0])
         self.statements[:] = [st for i, st in enumerate(sts) if i not in dead]
 
+    def fold_ffn(self):
+        """fused_quantized_linear(x, W1.., relu) whose result is read once, by the input of a second
+        fused_quantized_linear[_residual]: ONE `fused_ffn_quantized` statement (lele_hip_fused_ffn_quantized: the f32 hidden
+        tensor need not exist).  The run-time form issues the two calls itself when the shapes do not suit the fused route, so
+        the rewrite is always legal.  The merged statement stands where the second linear stood (its residuals exist there)."""
+        sts = self.statements
+        outs = {sanitize(o) for o in self.outputs}
+        readers = {}
+
+        def refs(n, acc):
+            if isinstance(n, dict):
+                for key in ("ref", "ints"):
+                    if isinstance(n.get(key), str):
+                        acc.append(n[key])
+                for v in n.values():
+                    refs(v, acc)
+            elif isinstance(n, list):
+                for v in n:
+                    refs(v, acc)
+            return acc
+        for i, st in enumerate(sts):
+            for r in refs(st.get("args", st.get("in")), []):
+                readers.setdefault(r, []).append(i)
+        dead = set()
+        for i, st in enumerate(sts):
+            if st.get("fn") != "fused_quantized_linear" or st["args"][5] != {"bool": True}:
+                continue
+            hid = st["out"][0]
+            rd = readers.get(hid, [])
+            if len(rd) != 1 or hid in outs or rd[0] <= i:
+                continue
+            second = sts[rd[0]]
+            if second.get("fn") not in ("fused_quantized_linear", "fused_quantized_linear_residual"):
+                continue
+            b = second["args"]
+            if b[0] != {"ref": hid} or refs(b[1:], []).count(hid):
+                continue
+            a = st["args"]
+            res = b[6:8] if second["fn"].endswith("_residual") else [{"none": 1}, {"none": 1}]
+            second["fn"] = "fused_ffn_quantized"
+            second["args"] = [a[0], a[1], a[2], a[3], a[4], b[1], b[2], b[3], b[4], b[5]] + list(res)
+            dead.add(i)
+        self.statements[:] = [st for i, st in enumerate(sts) if i not in dead]
+
     def fold_attention(self):
         """matmul_view(Q view, K^T view) -> softmax_scaled -> matmul_view(P, V view [, out_perm, out_reshape]) with private
         intermediates becomes ONE `attention_view` statement (lele_hip_attention_view: the score / probability tensors stay on
@@ -856,6 +900,7 @@ class Lowering:
             k += 1
         if self.extra_fusions:
             self.fold_linear_residuals()
+            self.fold_ffn()
             self.fold_attention()
 
     def lower_if(self, node):

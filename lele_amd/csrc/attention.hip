@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     const int bi = bh % a.batch_inner, bo = bh / a.batch_inner;
     const int i0 = qb * 32 * RT;
     const int rt = RT == 2 ? (wave & 1) : 0;   // this wave's row tile
-    const int kw = RT == 2 ? (wave >> 1) : wave, kstep = 4 / RT;  // its first key tile and the stride between its key tiles
+    // its first key tile and the stride between its key tiles.  With one row tile the six key tiles of a 10 s utterance leave two
+    // waves (= two SIMDs) with twice the work of the others: the workgroups that share a CU (blockIdx 256 apart) rotate the assignment
+    const int kw = RT == 2 ? (wave >> 1) : ((wave - (int)(blockIdx.x >> 8)) & 3), kstep = 4 / RT;
     const float* qp = a.q + bo * a.q_so + bi * a.q_si;
     const float* kp = a.k + bo * a.k_so + bi * a.k_si;
     const float* vp = a.v + bo * a.v_so + bi * a.v_si;
@@ -290,9 +292,10 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
                  "attention_view: unsupported geometry (Q / K rows are not 16-byte aligned)");
     a.tq = (int)t_q, a.tk = (int)t_k, a.tpad = (int)((t_k + 63) & ~int64_t(63));
     a.batch_inner = (int)batch_inner;
-    // two row tiles per workgroup when that still leaves at least one workgroup per CU (a batch of utterances); one otherwise
+    // two row tiles per workgroup when that still leaves three workgroups per CU (what fits at once); one otherwise (measured:
+    // 32 x 171 rows 47.9 us with one tile against 54.2 us with two; 64 x 171 rows 92.6 against 73.8)
     const char* rt_env = getenv("LELE_HIP_ATTENTION_RT");
-    const int rt = rt_env && *rt_env ? atoi(rt_env) : (fb * ((t_q + 63) / 64) >= ctx->num_cus ? 2 : 1);
+    const int rt = rt_env && *rt_env ? atoi(rt_env) : (fb * ((t_q + 63) / 64) >= 3 * (int64_t)ctx->num_cus ? 2 : 1);
     const int qrows = rt == 2 ? 64 : 32;
     a.nqb = (int)((t_q + qrows - 1) / qrows);
     a.scale = (const float*)dsc;

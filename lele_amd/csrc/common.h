@@ -116,7 +116,7 @@ struct LeleCtx {
 
     // two library-owned result buffers for ops that fall back to an unfused sequence and need somewhere to put the intermediate
     // (add3 / fused_quantized_linear_residual with an operand that broadcasts OUTWARD: the in-place second pass is not possible)
-    LeleBuf* tmp[2] = {nullptr, nullptr};
+    LeleBuf* tmp[3] = {nullptr, nullptr, nullptr};
     int tmp_buf(int i, LeleBuf** out);
 
     int check_deverr(const char* where);

@@ -138,10 +138,17 @@ template <int MODE, bool PREFETCH = false>
 __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x, int64_t rows, int k, int kp, int m,
                                                     QParams* __restrict__ prm, int8_t* __restrict__ aq,
                                                     int* __restrict__ row_sums, const float* __restrict__ partial,
-                                                    int nblk) {
+                                                    int nblk, unsigned* __restrict__ zero_slice = nullptr,
+                                                    int* __restrict__ zero_rows = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    // side job for the fused two-layer form (lele_hip_fused_ffn_quantized): clear the accumulators its GEMM passes add into --
+    // one per slice (the hidden layer's maximum) and one per row (the hidden layer's i8 row sums)
+    if (lane == 0) {
+        if (zero_rows) zero_rows[row] = 0;
+        if (zero_slice && row % m == 0) zero_slice[row / m] = 0u;
+    }
     // PREFETCH (few rows: the launch is latency-bound): the row's elements are requested FIRST (up to 8 x 16 bytes per lane,
     // K <= 2048), so that they travel while the range partials are fetched and reduced below -- two dependent round trips
     // become one.  With many rows the streaming loop is better (more waves in flight per SIMD): +3 % on the batched case.
@@ -329,6 +336,11 @@ struct IgemmEpi {
     const float* res2 = nullptr;
     float* blockstat = nullptr;  // small-problem kernel: one {min, max} pair per workgroup (common.h, LeleBuf::rowstat)
     int flags = 0;               // developer A/B switches (LELE_HIP_IGEMM_FLAGS): 1 = column terms after the K loop, 2 = previous epilogue
+    // the fused two-layer form (igemm_kernel's EM = 1 / 2 passes, see lele_hip_fused_ffn_quantized)
+    unsigned* slice_max = nullptr;  // per slice: bits of max(result) (ReLU results are >= 0: unsigned order = float order)
+    int8_t* q_out = nullptr;        // EM 2: the result quantised with its slice's range, as q - 128, [rows][n]
+    int* q_rowsum = nullptr;        // EM 2: sum over the row of (q - 128), accumulated over column blocks
+    QParams* q_prm = nullptr;       // EM 2: the slices' parameters, published for the next GEMM's epilogue
     // Everything that depends only on the row (slice parameters, row-sum term, output row pointer) or only on the
     // column (column sum, weight scale, bias) is computed once per row / column of a thread's tile, not per element.
     struct RowCtx {
@@ -391,7 +403,13 @@ struct IgemmEpi {
     }
 };
 
-template <int BM, int BN, int WM, int WN, int BKB /* bytes of K per LDS tile: 64 or 128 */, int OCC = 1>
+// EM (epilogue mode) 0: the result as f32.  EM 1 / 2 are the two passes of the fused two-layer form, where the f32 result (the
+// hidden layer of a feed-forward block, 45 MB per configs[3] shard) never exists in HBM -- recomputing the product costs ~5 us of
+// matrix-core time against ~30 us of traffic for writing it and reading it twice:
+//   EM 1: only the per-slice maximum of the (ReLU) result, by atomic max into epi.slice_max;
+//   EM 2: the result again, quantised with the slice's now-known range exactly as qrows_kernel would quantise the stored f32
+//         (SIMD body: rint(fma(v, 1/scale, zp)), saturated), written as i8 with its row sums -- what the next GEMM consumes.
+template <int BM, int BN, int WM, int WN, int BKB /* bytes of K per LDS tile: 64 or 128 */, int OCC = 1, int EM = 0>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC))) void igemm_kernel(const int8_t* __restrict__ a, const int8_t* __restrict__ b,
                                                             int64_t rows, int n, int kp, int64_t b_batch_stride,
                                                             int m_per_batch, IgemmEpi epi) {
@@ -405,11 +423,22 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
     char(*Bs)[BN * PITCH] = reinterpret_cast<char(*)[BN * PITCH]>(igemm_lds + 2 * BM * PITCH);
     __shared__ int s_ca[BM], s_rterm[BM];
     __shared__ float s_ds[BM];
+    __shared__ unsigned s_mx[2];
+    __shared__ QParams s_q[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     unsigned tx, ty, tz;
     gemm::tile_coords(tx, ty, tz);  // XCD-aware order (gemm_core.h)
     const int64_t m0 = (int64_t)ty * BM;
+    // EM 1 / 2 (m >= BM): the tile's rows below `split` belong to slice s0, the rest to slice s0 + 1
+    const int s0 = EM ? (int)(m0 / epi.m) : 0;
+    const int split = EM ? (int)(((int64_t)s0 + 1) * epi.m - m0) : 0;
+    if (EM == 1 && tid < 2) s_mx[tid] = 0u;
+    if (EM == 2 && tid < 2) {
+        const int64_t nslices = epi.rows / epi.m;
+        const int64_t sl = s0 + tid < nslices ? s0 + tid : nslices - 1;
+        s_q[tid] = make_qparams(0.0f, __uint_as_float(epi.slice_max[sl]));
+    }
     // per-row epilogue terms: fetched once per block up front (clamped, unconditional -- their latency hides behind
     // the K loop) instead of per element behind a bounds branch, which serialises one global load per row
     for (int t = tid; t < BM; t += NT) {
@@ -514,6 +543,75 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
 #pragma unroll
         for (int j = 0; j < TNT; ++j) cc[j] = epi.col_ctx(cols[j]);
     }
+    if constexpr (EM == 1) {
+        const int rows_here = (int)(rows - m0 < BM ? rows - m0 : BM);
+        float mx0 = 0.0f, mx1 = 0.0f;  // ReLU: every value is >= 0, NaN becomes 0
+#pragma unroll
+        for (int i = 0; i < TMT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wm * TMT * 32 + i * 32 + 4 * hv + (r & 3) + 8 * (r >> 2);
+                const IgemmEpi::RowCtx rc{s_ca[lr], s_rterm[lr], s_ds[lr], nullptr};
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) {
+                    float v = epi.value24(rc, cc[j], acc[i][j][r]);
+                    v = (lr < rows_here && cols[j] < n) ? v : 0.0f;
+                    if (lr < split) mx0 = fmaxf(mx0, v);
+                    else mx1 = fmaxf(mx1, v);
+                }
+            }
+        for (int off = 32; off > 0; off >>= 1) {
+            mx0 = fmaxf(mx0, __shfl_xor(mx0, off));
+            mx1 = fmaxf(mx1, __shfl_xor(mx1, off));
+        }
+        if (lane == 0) {
+            if (mx0 > 0.0f) atomicMax(&s_mx[0], __float_as_uint(mx0));
+            if (mx1 > 0.0f) atomicMax(&s_mx[1], __float_as_uint(mx1));
+        }
+        __syncthreads();
+        if (tid < 2 && s_mx[tid]) atomicMax(&epi.slice_max[s0 + tid], s_mx[tid]);
+        return;
+    }
+    if constexpr (EM == 2) {
+        static_assert(EM != 2 || BN % 16 == 0, "i8 tile rows are stored in 16-byte chunks");
+        const int rows_here = (int)(rows - m0 < BM ? rows - m0 : BM);
+        constexpr int QP = BN + 16;   // i8 tile [BM][BN] in the K loop's LDS (its last barrier has passed), rows padded
+        char* const qt = igemm_lds;
+#pragma unroll
+        for (int i = 0; i < TMT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = wm * TMT * 32 + i * 32 + 4 * hv + (r & 3) + 8 * (r >> 2);
+                const IgemmEpi::RowCtx rc{s_ca[lr], s_rterm[lr], s_ds[lr], nullptr};
+                const int which = lr < split ? 0 : 1;
+                const float inv = s_q[which].inv_scale, zp = s_q[which].zp;
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) {
+                    const float v = epi.value24(rc, cc[j], acc[i][j][r]);
+                    const unsigned q = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(v, inv, zp)), 0, 0u);
+                    qt[lr * QP + wn * TNT * 32 + j * 32 + l31] = (char)(q ^ 0x80u);
+                }
+            }
+        __syncthreads();
+        constexpr int CH = BN / 16;  // 16-byte chunks per tile row: CH consecutive lanes hold one row
+        static_assert(EM != 2 || (CH == 8 || CH == 4 || CH == 16), "row-sum reduction over CH lanes");
+        for (int c = tid; c < BM * CH; c += NT) {
+            const int row = c / CH, c16 = c % CH;
+            const v4i w = *reinterpret_cast<const v4i*>(qt + row * QP + 16 * c16);
+            unsigned us = __builtin_amdgcn_sad_u8((unsigned)w[0] ^ 0x80808080u, 0u, 0u);
+            us = __builtin_amdgcn_sad_u8((unsigned)w[1] ^ 0x80808080u, 0u, us);
+            us = __builtin_amdgcn_sad_u8((unsigned)w[2] ^ 0x80808080u, 0u, us);
+            us = __builtin_amdgcn_sad_u8((unsigned)w[3] ^ 0x80808080u, 0u, us);
+            int part = (int)us - 128 * 16;  // sum of (q - 128) over the chunk
+            for (int off = CH / 2; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if (row < rows_here) {
+                *reinterpret_cast<v4i*>(epi.q_out + (m0 + row) * (int64_t)n + n0 + 16 * c16) = w;
+                if (c16 == 0) atomicAdd(&epi.q_rowsum[m0 + row], part);
+            }
+        }
+        if (tx == 0 && tid < 2 && (tid == 0 || split < rows_here)) epi.q_prm[s0 + tid] = s_q[tid];
+        return;
+    }
     if (epi.flags & 2) {
     if (epi.res1) {  // residual operands: four rows at a time, their loads issued together before the stores
 #pragma unroll
@@ -607,6 +705,378 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
     else epilogue(std::integral_constant<int, 2>());
 }
 
+
+// ------------------------------------------------------------------------------------------ 3b. i8 GEMM, whole K resident
+// The K = 512 products of a SenseVoice-shaped layer over a batch of utterances (qkv, out projection, first feed-forward layer:
+// 5472 rows) are short -- four 128-byte K steps -- and their cost in igemm_kernel is not the matrix cores (8 % busy) but everything
+// around them: a global-load round trip behind a barrier per K step, a second, mostly empty round of workgroups for the 516 / 688
+// tiles, ~20 vector instructions and one 4-byte store per output value.  This kernel turns the loop inside out:
+//   * one workgroup per CU, persistent: the (column block, 32-row tile) units are dealt out evenly, each workgroup walks its
+//     share in chunks of up to four row tiles of one column block;
+//   * a wave's WEIGHT fragments for the whole K extent (32 columns x 512 B = 64 VGPRs per lane; one workgroup per CU leaves a lane
+//     256 of them) stay in registers while the column block does not change: they come straight from L2, never through LDS;
+//   * the WHOLE K extent of the chunk's A rows (128 x 512 B) sits in LDS, double-buffered: no K loop, ONE barrier per chunk, and
+//     the next chunk's rows (and its per-row epilogue terms) are requested into registers BEFORE the current chunk's MFMA phase;
+//   * a lean epilogue: the accumulators START from the zero-point terms of their (row, column), so what follows the last MFMA is
+//     convert, scale, bias, store; where results are stored the weights are the MFMA's FIRST operand, so that a lane owns one row
+//     and 4 x 4 consecutive columns of it (16-byte stores, one set of row terms per lane); the range-only pass (EM 1) keeps the
+//     usual orientation (a lane owns one column) and works on the i32 totals -- the f32 epilogue is monotone in the total for a
+//     fixed column, so max over rows of f(total) = max(f(max total), f(min total)).
+// Same arithmetic as igemm_kernel (exact i32 products, IgemmEpi's f32 epilogue), same EM modes.
+struct WkArgs {
+    const int8_t* a;  // [rows][512]
+    const int8_t* b;  // [n][512]
+    int64_t rows;
+    int n, nrt, ncb, units;  // 32-row tiles, 128-column blocks, nrt * ncb
+    long long* dbg;          // developer switch LELE_HIP_WHOLEK_STAMPS: 64 cycle-counter stamps per workgroup, or NULL
+    int ablate;              // developer switch LELE_HIP_WHOLEK_ABLATE (timing experiments, results wrong): 1 no products, 2 no row reloads, 4 no stores
+};
+
+template <int EM>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_wholek_kernel(WkArgs g, IgemmEpi epi) {
+    constexpr int KP = 512, PITCH = KP + 16, SLOTS = 8, ABYTES = 128 * PITCH;  // 8 x 16 bytes of A per thread and chunk
+    constexpr bool ROWLANE = EM != 1;   // a lane owns one result row (stores) or one result column (range pass)
+    extern __shared__ __attribute__((aligned(16))) char wk_lds[];
+    char* const qt = wk_lds + 2 * ABYTES;   // EM 2: the chunk's i8 result tile [128][144]
+    __shared__ int2 s_row[2][128];          // per chunk row: {128 - zp_a, row term} -- the accumulators START from them
+    __shared__ float s_ds[2][128];          // per chunk row: the dynamic scale of its slice
+    __shared__ unsigned s_mx[2][2];         // EM 1: chunk j's maxima of slices s0, s0 + 1 in s_mx[j & 1], published after chunk j + 1's barrier
+    __shared__ QParams s_q[2][2];           // EM 2: the hidden layer's quantisation parameters of slices s0, s0 + 1
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3, hv = lane >> 5, l31 = lane & 31;
+    unsigned w = blockIdx.x;
+    const unsigned G = gridDim.x;
+    if ((G & 7u) == 0) w = (w & 7u) * (G >> 3) + (w >> 3);  // an XCD's workgroups share a contiguous range of units (few column blocks)
+    int u = (int)((int64_t)w * g.units / G);
+    const int u1 = (int)((int64_t)(w + 1) * g.units / G);
+    if (u >= u1) return;
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (g.dbg && tid == 0 && nstamp < 64) g.dbg[blockIdx.x * 64 + nstamp++] = (long long)clock64();
+    };
+    stamp();
+    const int n = g.n;
+    const unsigned nu = (unsigned)n, rows_u = (unsigned)g.rows, mu = (unsigned)epi.m;
+    const int nslices = (int)(rows_u / mu);
+    const bool has_ws = epi.wscale != nullptr, has_bias = epi.bias != nullptr;
+
+    v4i ra[SLOTS];
+    int rs_next = 0;
+    QParams q_next = {1.0f, 0.0f, 1.0f, 0};
+    unsigned smax_next = 0u;
+    const unsigned lrow = (unsigned)tid >> 5, lcol = 16u * ((unsigned)tid & 31u);  // this thread's row (of 16) and byte column per slot
+    bool first_load = true;
+    auto load_a = [&](int rt0) {
+        if ((g.ablate & 2) && !first_load) return;
+        first_load = false;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            unsigned r = (unsigned)rt0 * 32u + lrow + 16u * i;
+            r = r < rows_u ? r : rows_u - 1u;
+            ra[i] = *reinterpret_cast<const v4i*>(g.a + (size_t)(r * (unsigned)KP + lcol));
+        }
+        if (tid < 128) {  // the chunk's per-row epilogue terms
+            unsigned r = (unsigned)rt0 * 32u + (unsigned)tid;
+            r = r < rows_u ? r : rows_u - 1u;
+            rs_next = epi.row_sums[r];
+            if (epi.prm) q_next = epi.prm[rows_u == mu ? 0u : r / mu];
+            if (EM == 2 && tid < 2) {
+                const int sl = (int)((unsigned)(rt0 * 32) / mu) + tid;
+                smax_next = epi.slice_max[sl < nslices ? sl : nslices - 1];
+            }
+        }
+    };
+    auto chunk_of = [&](int uu, int& cb, int& rt0, int& cnt) {
+        cb = uu / g.nrt;
+        rt0 = uu - cb * g.nrt;
+        cnt = g.nrt - rt0;
+        cnt = cnt < 4 ? cnt : 4;
+        cnt = cnt < u1 - uu ? cnt : u1 - uu;
+    };
+    int cb, rt0, cnt;
+    chunk_of(u, cb, rt0, cnt);
+    load_a(rt0);
+    if (EM == 1 && tid < 4) (&s_mx[0][0])[tid] = 0u;
+    // weight fragments of the wave's 32 columns: sub-step s, half h -> bf[2 s + h] = bytes [64 s + 32 hv + 16 h, + 16) of weight row l31
+    v4i bf[2 * (KP / 64)];
+    // column terms.  ROWLANE: the lane's 16 columns are col + 8 g + e (g < 4, e < 4), col = 128 cb + 32 wn + 4 hv; else one column
+    constexpr int NC = ROWLANE ? 16 : 1;
+    int colsum[NC];
+    float ws[NC], bias[NC];
+    int col = 0;
+    const unsigned lds_st = lrow * PITCH + lcol;
+    // a new column block: its weights travel coalesced into the LDS buffer `stage` (free at that moment), every wave lifts its
+    // fragments out of it; the column terms come straight from global memory
+    auto new_column_block = [&](char* stage, bool buffer_busy, bool reused_before_barrier) {
+        v4i rb[SLOTS];
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            unsigned c = (unsigned)cb * 128u + lrow + 16u * i;
+            c = c < nu ? c : nu - 1u;
+            rb[i] = *reinterpret_cast<const v4i*>(g.b + (size_t)(c * (unsigned)KP + lcol));
+        }
+        col = cb * 128 + wn * 32 + (ROWLANE ? 4 * hv : l31);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {  // clamped: loads stay unconditional, out-of-range columns are never stored
+            int cidx = col + (ROWLANE ? 8 * (c >> 2) + (c & 3) : 0);
+            cidx = cidx < n ? cidx : n - 1;
+            colsum[c] = epi.col_sums[cidx];
+            ws[c] = has_ws ? (epi.wscale_len <= 1 ? epi.wscale[0] : epi.wscale[cidx]) : 1.0f;
+            bias[c] = has_bias ? epi.bias[cidx] : 0.0f;
+        }
+        if (buffer_busy) __syncthreads();  // slower waves may still read the buffer (the chunk before last)
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) *reinterpret_cast<v4i*>(stage + lds_st + 16 * PITCH * i) = rb[i];
+        __syncthreads();
+        const char* const wsrc = stage + (wn * 32 + l31) * PITCH + 32 * hv;
+#pragma unroll
+        for (int q = 0; q < 2 * (KP / 64); ++q) bf[q] = *reinterpret_cast<const v4i*>(wsrc + 64 * (q >> 1) + 16 * (q & 1));
+        if (reused_before_barrier) __syncthreads();  // the buffer receives the next chunk's rows before the next chunk barrier
+    };
+    auto stage_rows = [&](int buf) {  // the requested chunk: registers -> LDS buffer `buf`, with its per-row epilogue terms
+        char* const dst = wk_lds + buf * ABYTES;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) *reinterpret_cast<v4i*>(dst + lds_st + 16 * PITCH * i) = ra[i];
+        if (tid < 128) {
+            const int zp_a = epi.prm ? q_next.zp_i : epi.zp_a_fixed;
+            const int ca = 128 - zp_a, cbz = 128 - epi.zp_b;
+            s_row[buf][tid] = make_int2(ca, cbz * rs_next + epi.k * ca * cbz);
+            s_ds[buf][tid] = epi.prm ? q_next.scale : 1.0f;
+            if (EM == 2 && tid < 2) s_q[buf][tid] = make_qparams(0.0f, __uint_as_float(smax_next));
+        }
+    };
+    new_column_block(wk_lds + ABYTES, false, false);  // buffer 1 is rewritten only after the first chunk's barrier and products
+    stage_rows(0);
+    stamp();          // [1] the first chunk's rows and the weights have arrived
+    int un = u + cnt;
+    bool more = un < u1;
+    int ncb_ = cb, nrt0 = 0, ncnt = 0;
+    if (more) {
+        chunk_of(un, ncb_, nrt0, ncnt);
+        load_a(nrt0);
+    }
+    int j = 0;        // chunk counter: LDS buffer j & 1
+    int pend_s0 = -1; // EM 1: first slice of the chunk whose maxima wait in s_mx[(j - 1) & 1] (a register: uniform, no LDS round trip)
+    while (true) {
+        const char* const As = wk_lds + (j & 1) * ABYTES;
+        const int r0 = rt0 * 32;                                                               // first row of the chunk
+        const int rows_here = (int)(rows_u - (unsigned)r0 < (unsigned)(cnt * 32) ? rows_u - (unsigned)r0 : (unsigned)(cnt * 32));
+        // this wave's row tiles inside the chunk (a chunk at the end of a column block or of the share may hold fewer than four)
+        const int nti = cnt - 2 * wm < 0 ? 0 : (cnt - 2 * wm > 2 ? 2 : cnt - 2 * wm);
+        const int myr = wm * 64 + l31;  // ROWLANE: the lane's row in tile 0 (+ 32 i)
+        __syncthreads();  // chunk j's rows and row terms are visible; every wave has finished chunk j - 1 (buffer (j + 1) & 1 is free)
+        stamp();          // [2 + 3j]
+        if (EM == 1 && pend_s0 >= 0 && tid < 2) {  // chunk j - 1's maxima are complete (every wave added its own before the barrier)
+            const unsigned v = s_mx[(j - 1) & 1][tid];
+            if (v) atomicMax(&epi.slice_max[pend_s0 + tid], v);
+            s_mx[(j - 1) & 1][tid] = 0u;  // next written by chunk j + 1, after its barrier
+        }
+        // the chunk's rows below `split` belong to slice s0, the rest to slice s0 + 1 (m >= 128 or a single slice)
+        const int s0 = (int)((unsigned)r0 / mu);
+        const int split = rows_u == mu ? 128 : (int)(((unsigned)s0 + 1u) * mu - (unsigned)r0);
+        v16i acc[2];
+        if (ROWLANE) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int2 t = s_row[j & 1][myr + 32 * i];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = t.y + __mul24(t.x, colsum[r]);
+            }
+        } else {
+            const int2* const rowp = s_row[j & 1] + wm * 64 + 4 * hv;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int2 t = rowp[i * 32 + (r & 3) + 8 * (r >> 2)];
+                    acc[i][r] = t.y + __mul24(t.x, colsum[0]);
+                }
+        }
+        const char* const asrc = As + (wm * 64 + l31) * PITCH + 32 * hv;
+        if (nti > 0 && !(g.ablate & 1)) {
+            // A fragments of sub-step s + 1 are read from LDS while sub-step s multiplies (two register sets, order pinned)
+            v4i x0[4], x1[4];
+            auto rd = [&](v4i (&x)[4], int sub) {
+                x[0] = *reinterpret_cast<const v4i*>(asrc + sub * 64), x[1] = *reinterpret_cast<const v4i*>(asrc + sub * 64 + 16);
+                if (nti > 1) x[2] = *reinterpret_cast<const v4i*>(asrc + 32 * PITCH + sub * 64), x[3] = *reinterpret_cast<const v4i*>(asrc + 32 * PITCH + sub * 64 + 16);
+            };
+            auto mm1 = [&](const v4i& fa, const v4i& fb, v16i& c) {
+                c = ROWLANE ? __builtin_amdgcn_mfma_i32_32x32x32_i8(fb, fa, c, 0, 0, 0) : __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, c, 0, 0, 0);
+            };
+            auto mm = [&](const v4i (&x)[4], int sub) {
+                mm1(x[0], bf[2 * sub], acc[0]);
+                if (nti > 1) mm1(x[2], bf[2 * sub], acc[1]);
+                mm1(x[1], bf[2 * sub + 1], acc[0]);
+                if (nti > 1) mm1(x[3], bf[2 * sub + 1], acc[1]);
+            };
+            rd(x0, 0);
+#pragma unroll
+            for (int sub = 0; sub < KP / 64; sub += 2) {
+                rd(x1, sub + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(x0, sub);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sub + 2 < KP / 64) rd(x0, sub + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(x1, sub + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the next chunk's rows: registers -> the other LDS buffer (free since the barrier above), then the chunk after that is
+        // requested -- all BEFORE this chunk's stores, so that waiting for those rows never waits for the stores (loads and stores
+        // retire through one in-order counter)
+        int n2cb = ncb_, n2rt0 = 0, n2cnt = 0;
+        bool more2 = false;
+        if (more) {
+            stage_rows((j + 1) & 1);
+            more2 = un + ncnt < u1;
+            if (more2) {
+                chunk_of(un + ncnt, n2cb, n2rt0, n2cnt);
+                load_a(n2rt0);
+            }
+        }
+        stamp();          // [3 + 3j] products done, next rows staged (wave 0)
+        auto fin = [&](int total, float dsws, float b) {  // == IgemmEpi::value24 once the zero-point terms are inside `total`
+            float vf = (float)total;
+            if (has_ws) vf = vf * dsws;
+            if (has_bias) vf = vf + b;
+            if (epi.relu) vf = vf > 0.0f ? vf : 0.0f;
+            return vf;
+        };
+        if constexpr (EM == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (i < nti) {
+                    const int lr = myr + 32 * i;
+                    const float ds = s_ds[j & 1][lr];
+                    float* const orow = epi.out + (size_t)((unsigned)(r0 + lr) * nu + (unsigned)col);
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        float4 v;
+                        v.x = fin(acc[i][4 * gq + 0], ds * ws[4 * gq + 0], bias[4 * gq + 0]);
+                        v.y = fin(acc[i][4 * gq + 1], ds * ws[4 * gq + 1], bias[4 * gq + 1]);
+                        v.z = fin(acc[i][4 * gq + 2], ds * ws[4 * gq + 2], bias[4 * gq + 2]);
+                        v.w = fin(acc[i][4 * gq + 3], ds * ws[4 * gq + 3], bias[4 * gq + 3]);
+                        // n % 4 == 0: a group is whole or absent.  (Non-temporal stores change nothing here: measured.)
+                        if (lr < rows_here && col + 8 * gq < n && !(g.ablate & 4)) *reinterpret_cast<float4*>(orow + 8 * gq) = v;
+                    }
+                }
+        } else if constexpr (EM == 1) {
+            // range of the ReLU result on i32 totals: the f32 epilogue is monotone in the total for a fixed column
+            const float dsws0 = s_ds[j & 1][0] * ws[0], dsws1 = s_ds[j & 1][split < 127 ? (split > 0 ? split : 0) : 127] * ws[0];
+            const int lane_row = wm * 64 + 4 * hv;
+            int tmax[2] = {INT_MIN, INT_MIN}, tmin[2] = {INT_MAX, INT_MAX};
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (i < nti) {
+                    const int base = wm * 64 + i * 32;
+                    if (base + 32 <= rows_here && (base + 32 <= split || base >= split)) {  // uniform: the whole tile valid, one slice
+                        int lmax = INT_MIN, lmin = INT_MAX;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int total = acc[i][r];
+                            lmax = total > lmax ? total : lmax;
+                            lmin = total < lmin ? total : lmin;
+                        }
+                        const int which = base >= split ? 1 : 0;
+                        tmax[which] = lmax > tmax[which] ? lmax : tmax[which];
+                        tmin[which] = lmin < tmin[which] ? lmin : tmin[which];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int lr = lane_row + i * 32 + (r & 3) + 8 * (r >> 2);
+                            const int total = acc[i][r];
+                            if (lr < rows_here) {
+                                if (lr < split) {
+                                    tmax[0] = total > tmax[0] ? total : tmax[0];
+                                    tmin[0] = total < tmin[0] ? total : tmin[0];
+                                } else {
+                                    tmax[1] = total > tmax[1] ? total : tmax[1];
+                                    tmin[1] = total < tmin[1] ? total : tmin[1];
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float best = 0.0f;
+                if (tmax[p] >= tmin[p]) {
+                    const float a = fin(tmax[p], p ? dsws1 : dsws0, bias[0]), b2 = fin(tmin[p], p ? dsws1 : dsws0, bias[0]);  // ReLU inside: >= 0, no NaN
+                    best = a > b2 ? a : b2;
+                }
+                // wave maximum on the DPP network (values are non-negative floats: their bits order like unsigned integers, 0 is
+                // neutral), then ONE lane goes to the LDS maximum
+                unsigned bits = col < n ? __float_as_uint(best) : 0u;
+                auto step = [&](unsigned x, auto ctrl, auto rowmask) {
+                    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl)::value, decltype(rowmask)::value, 0xf, true);
+                    return o > x ? o : x;
+                };
+                bits = step(bits, std::integral_constant<int, 0xB1>(), std::integral_constant<int, 0xf>());   // quad_perm [1,0,3,2]
+                bits = step(bits, std::integral_constant<int, 0x4E>(), std::integral_constant<int, 0xf>());   // quad_perm [2,3,0,1]
+                bits = step(bits, std::integral_constant<int, 0x141>(), std::integral_constant<int, 0xf>());  // row_half_mirror
+                bits = step(bits, std::integral_constant<int, 0x140>(), std::integral_constant<int, 0xf>());  // row_mirror: every lane = its row's maximum
+                bits = step(bits, std::integral_constant<int, 0x142>(), std::integral_constant<int, 0xa>());  // row_bcast15 into rows 1, 3
+                bits = step(bits, std::integral_constant<int, 0x143>(), std::integral_constant<int, 0xc>());  // row_bcast31 into rows 2, 3: lane 63 = wave maximum
+                if (lane == 63 && bits) atomicMax(&s_mx[j & 1][p], bits);
+            }
+            pend_s0 = s0;
+        } else {
+            constexpr int QP = 128 + 16;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (i < nti) {
+                    const int lr = myr + 32 * i;
+                    const float ds = s_ds[j & 1][lr];
+                    const int which = lr >= split ? 1 : 0;
+                    const float inv = s_q[j & 1][which].inv_scale, zp = s_q[j & 1][which].zp;
+                    char* const qdst = qt + lr * QP + wn * 32 + 4 * hv;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        unsigned pk = 0u;
+                        pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(fin(acc[i][4 * gq + 0], ds * ws[4 * gq + 0], bias[4 * gq + 0]), inv, zp)), 0, pk);
+                        pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(fin(acc[i][4 * gq + 1], ds * ws[4 * gq + 1], bias[4 * gq + 1]), inv, zp)), 1, pk);
+                        pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(fin(acc[i][4 * gq + 2], ds * ws[4 * gq + 2], bias[4 * gq + 2]), inv, zp)), 2, pk);
+                        pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(fin(acc[i][4 * gq + 3], ds * ws[4 * gq + 3], bias[4 * gq + 3]), inv, zp)), 3, pk);
+                        *reinterpret_cast<unsigned*>(qdst + 8 * gq) = pk ^ 0x80808080u;
+                    }
+                }
+            __syncthreads();  // the i8 tile is complete (it is rewritten only after the next chunk's barrier)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {  // 16-byte chunks: exact i32 row sums and the coalesced store
+                const int c = tid + 512 * k2, row = c >> 3, c16 = c & 7;
+                const v4i wq = *reinterpret_cast<const v4i*>(qt + row * QP + 16 * c16);
+                unsigned us = __builtin_amdgcn_sad_u8((unsigned)wq[0] ^ 0x80808080u, 0u, 0u);
+                us = __builtin_amdgcn_sad_u8((unsigned)wq[1] ^ 0x80808080u, 0u, us);
+                us = __builtin_amdgcn_sad_u8((unsigned)wq[2] ^ 0x80808080u, 0u, us);
+                us = __builtin_amdgcn_sad_u8((unsigned)wq[3] ^ 0x80808080u, 0u, us);
+                int part = (int)us - 128 * 16;
+                part += __shfl_xor(part, 4);
+                part += __shfl_xor(part, 2);
+                part += __shfl_xor(part, 1);
+                if (row < rows_here) {
+                    *reinterpret_cast<v4i*>(epi.q_out + (size_t)(((unsigned)(r0 + row)) * nu + (unsigned)(cb * 128 + 16 * c16))) = wq;
+                    if (c16 == 0) atomicAdd(&epi.q_rowsum[r0 + row], part);
+                }
+            }
+            if (cb == 0 && tid < 2 && (tid == 0 || split < rows_here)) epi.q_prm[s0 + tid] = s_q[j & 1][tid];
+        }
+        stamp();          // [4 + 3j] epilogue issued (wave 0)
+        if (!more) break;
+        const int prev_cb = cb;
+        u = un;
+        cb = ncb_, rt0 = nrt0, cnt = ncnt;
+        un = u + cnt, more = more2;
+        ncb_ = n2cb, nrt0 = n2rt0, ncnt = n2cnt;
+        ++j;
+        // buffer (j + 1) & 1 was read by chunk j - 1 and receives chunk j + 1's rows after chunk j's products
+        if (cb != prev_cb) new_column_block(wk_lds + ((j + 1) & 1) * ABYTES, true, false);
+    }
+    if (EM == 1) {  // the last chunk's maxima
+        __syncthreads();
+        if (tid < 2 && s_mx[j & 1][tid]) atomicMax(&epi.slice_max[pend_s0 + tid], s_mx[j & 1][tid]);
+    }
+}
 
 // ------------------------------------------------------------------------------------------ one-pass quantised linear
 // fused_quantized_linear in ONE launch after the range is known (quantization.rs:77-169 -> avx/quantization.rs:225-417):
@@ -1214,6 +1684,9 @@ int launch_range(LeleCtx* ctx, const float* dx, int64_t slices, int64_t slice_le
     return 0;
 }
 
+bool wholek_fits(LeleCtx* ctx, int64_t rows, int n, int kp, int m, int em);
+int launch_igemm_wholek(LeleCtx* ctx, int em, const int8_t* aq, const int8_t* wt, int64_t rows, int n, const IgemmEpi& epi);
+
 int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows, int n, int kp, int64_t b_stride,
                  int m_per_batch, const IgemmEpi& epi_in) {
     if (rows == 0 || n == 0) return 0;
@@ -1242,7 +1715,16 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
     else if (force == 6) IGEMM_LAUNCH(128, 128, 2, 2, 64, 2);
     else if (force == 7) IGEMM_LAUNCH(64, 128, 2, 2, 64, 2);
     else if (force == 8) IGEMM_LAUNCH(256, 128, 4, 2, 128, 2);
+    else if (force == 9) IGEMM_LAUNCH(128, 128, 2, 4, 64, 6);
+    else if (force == 10) IGEMM_LAUNCH(128, 64, 2, 2, 64, 5);
+    else if (force == 11) IGEMM_LAUNCH(64, 128, 2, 2, 64, 5);
+    else if (force == 12) IGEMM_LAUNCH(128, 128, 2, 2, 64, 4);
+    else if (force == 13) IGEMM_LAUNCH(128, 64, 4, 2, 64, 4);
+    else if (force == 14) IGEMM_LAUNCH(128, 64, 4, 2, 128, 4);
     else
+    if (b_stride == 0 && !epi.blockstat && !epi.res1 && b64 >= 2 * (int64_t)ctx->num_cus && wholek_fits(ctx, rows, n, kp, m_per_batch, 0)) {
+        return launch_igemm_wholek(ctx, 0, aq, wt, rows, n, epi);
+    } else
     if (b64 < 2 * (int64_t)ctx->num_cus) {
         // small problem (SenseVoice at M = 504): 32x32 tiles, K split over the four waves, operands straight from L2
         dim3 grid((unsigned)((n + 31) / 32), (unsigned)((rows + 31) / 32));
@@ -1255,10 +1737,63 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
         IGEMM_LAUNCH(128, 128, 2, 4, 128, 1);
     } else if (rows <= 32) {
         IGEMM_LAUNCH(32, 128, 1, 4, 64, 1);
+    } else if (((rows + 127) / 128) * ((n + 63) / 64) >= ctx->num_cus) {
+        // narrow results over many rows (out projection, second feed-forward layer: N = 512 over a batch of utterances): 128 x 64
+        // tiles, eight waves, 128-byte K tiles -- 40.0 us against 45.9 us with 64 x 64 tiles at K = 2048, 16.3 against 16.8 at K = 512
+        IGEMM_LAUNCH(128, 64, 4, 2, 128, 4);
     } else {
         IGEMM_LAUNCH(64, 64, 2, 2, 64, 1);
     }
 #undef IGEMM_LAUNCH
+    LELE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// whole-K kernel: K padded to exactly 512 bytes, enough (column block x row tile) units for every CU, un-batched weights
+bool wholek_fits(LeleCtx* ctx, int64_t rows, int n, int kp, int m, int em) {
+    if (kp != 512 || rows >= (int64_t(1) << 22) || env_int("LELE_HIP_IGEMM_WHOLEK", 1) == 0) return false;  // 32-bit byte offsets into A
+    if (!((env_int("LELE_HIP_IGEMM_WHOLEK_MODES", 7) >> em) & 1)) return false;  // developer switch: bit em enables mode em
+    if (m < 128 && rows != m) return false;  // a chunk of 128 rows touches at most two slices
+    if (n % 4) return false;                 // 16-byte stores
+    if (em && n % 128) return false;
+    const int64_t units = ((rows + 31) / 32) * ((n + 127) / 128);
+    return units >= 2 * (int64_t)ctx->num_cus && (int64_t)rows * n < (int64_t(1) << 32);
+}
+int launch_igemm_wholek(LeleCtx* ctx, int em, const int8_t* aq, const int8_t* wt, int64_t rows, int n, const IgemmEpi& epi) {
+    WkArgs g{aq, wt, rows, n, (int)((rows + 31) / 32), (n + 127) / 128, 0, nullptr, env_int("LELE_HIP_WHOLEK_ABLATE", 0)};
+    g.units = g.nrt * g.ncb;
+    if (const char* e = getenv("LELE_HIP_WHOLEK_STAMPS"))  // a device address (tools/wholek_stamps.py), optionally for one mode only
+        if (env_int("LELE_HIP_WHOLEK_STAMPS_EM", em) == em) g.dbg = (long long*)(uintptr_t)strtoull(e, nullptr, 0);
+    const size_t lds = (size_t)256 * 528 + (em == 2 ? 128 * 144 : 0);  // two A buffers (+ the i8 tile)
+    const dim3 grid((unsigned)std::min<int64_t>(ctx->num_cus, g.units));
+#define LELE_WK(EM_)                                                                                      \
+    do {                                                                                                 \
+        auto kern = igemm_wholek_kernel<EM_>;                                                             \
+        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));                   \
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g, epi);                              \
+    } while (0)
+    if (em == 1) LELE_WK(1);
+    else if (em == 2) LELE_WK(2);
+    else LELE_WK(0);
+#undef LELE_WK
+    LELE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// the two passes of the fused two-layer form over the hidden layer's product (128 x 128 tiles, the big-shape configuration)
+int launch_igemm_hidden(LeleCtx* ctx, int em, const int8_t* aq, const int8_t* wt, int64_t rows, int n, int kp, int m, const IgemmEpi& epi) {
+    if (wholek_fits(ctx, rows, n, kp, m, em)) return launch_igemm_wholek(ctx, em, aq, wt, rows, n, epi);
+    constexpr size_t lds = (size_t)2 * (128 + 128) * (128 + 16);
+    const dim3 grid((n + 127) / 128, (unsigned)((rows + 127) / 128));
+    if (em == 1) {
+        auto kern = igemm_kernel<128, 128, 2, 4, 128, 1, 1>;
+        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, aq, wt, rows, n, kp, (int64_t)0, m, epi);
+    } else {
+        auto kern = igemm_kernel<128, 128, 2, 4, 128, 1, 2>;
+        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, aq, wt, rows, n, kp, (int64_t)0, m, epi);
+    }
     LELE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1293,6 +1828,56 @@ int quant_params_of(LeleCtx* ctx, const float* const* srcs, const int64_t* lens,
 }
 }  // namespace lele
 
+namespace {
+// the producer's {min, max} pairs, if it left any next to this tensor (LayerNorm: one pair per row; the one-launch kernels: a fixed
+// number per slice; a small-problem GEMM: one per workgroup, single slice only): slice s then owns `nblk` consecutive pairs and the
+// separate range pass over the activation is skipped
+void find_partials(LeleCtx* ctx, const LeleTensor* input, int64_t batch, int64_t m, int64_t k, const float** partial, int* nblk) {
+    const int64_t rows = batch * m;
+    *partial = nullptr;
+    *nblk = 0;
+    if (input->mem != LELE_MEM_DEVICE || m > 2048) return;
+    auto it = ctx->buf_of_data.find(input->data);
+    if (it == ctx->buf_of_data.end() || !it->second->rowstat_valid) return;
+    const LeleBuf* src = it->second;
+    if (src->rowstat_kind == 0 && src->rowstat_len == k && src->rowstat_rows == rows) {
+        *partial = src->rowstat;  // one pair per row
+        *nblk = (int)m;
+    } else if (src->rowstat_kind == 2 && src->rowstat_len == k && src->rowstat_m == m && src->rowstat_rows % batch == 0) {
+        *partial = src->rowstat;  // a fixed number of pairs per slice of m rows (qlinear_onepass_kernel, attention_kernel)
+        *nblk = (int)(src->rowstat_rows / batch);
+    } else if (src->rowstat_kind == 1 && batch == 1 && src->rowstat_len == rows * k && src->rowstat_rows <= 4096) {
+        *partial = src->rowstat;  // per-workgroup pairs of the GEMM that produced the tensor: one slice, all pairs
+        *nblk = (int)src->rowstat_rows;
+    }
+}
+
+// weight_zero.data.first() as i32 (quantization.rs:100); fetched on the host: it is a scalar attribute
+int weight_zero_of(LeleCtx* ctx, const LeleTensor* weight_zero, float* wz) {
+    *wz = 0.0f;
+    if (weight_zero && numel(weight_zero) > 0) {
+        if (weight_zero->mem == LELE_MEM_DEVICE) {
+            LELE_HIP_CHECK(hipMemcpyAsync(wz, weight_zero->data, 4, hipMemcpyDeviceToHost, ctx->stream));
+            LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
+            LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        } else {
+            *wz = *(const float*)weight_zero->data;
+        }
+    }
+    return 0;
+}
+
+// weights as i8 [N][Kp] + column sums (cached for declared-immutable weights)
+int packed_weights_of(LeleCtx* ctx, const LeleTensor* weight_int8, int k, int n, int kp, PackedW* pw) {
+    const bool cacheable = weight_int8->mem == LELE_MEM_WEIGHT;  // only declared-immutable weights are cached
+    auto key_w = std::make_tuple((const void*)weight_int8->data, (size_t)numel(weight_int8) * 4, 201);
+    if (cacheable && ctx->weights.count(key_w)) return get_packed_weights(ctx, weight_int8, nullptr, 1, k, n, kp, pw, true);
+    const void* dw = nullptr;
+    LELE_TRY(ctx->dev_ptr(weight_int8, &dw));
+    return get_packed_weights(ctx, weight_int8, (const float*)dw, 1, k, n, kp, pw, cacheable);
+}
+}  // namespace
+
 extern "C" {
 
 static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8, const LeleTensor* weight_scale,
@@ -1319,45 +1904,18 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     LELE_TRY(out->reserve((size_t)rows * n * 4));
     if (rows == 0 || n == 0) return set_shape_v(out_shape, out_rank, shp);
     LELE_TRY(ctx->arena_reset());
-    const void *dx = nullptr, *dw = nullptr, *dws = nullptr, *db = nullptr;
+    const void *dx = nullptr, *dws = nullptr, *db = nullptr;
     LELE_TRY(ctx->dev_ptr(input, &dx));
     LELE_TRY(ctx->dev_ptr(weight_scale, &dws));
     if (blen) LELE_TRY(ctx->dev_ptr(bias, &db));
     const void *dr1 = nullptr, *dr2 = nullptr;
     if (res1) LELE_TRY(ctx->dev_ptr(res1, &dr1));
     if (res2) LELE_TRY(ctx->dev_ptr(res2, &dr2));
-    // weight_zero.data.first() as i32 (quantization.rs:100); fetched on the host: it is a scalar attribute
     float wz = 0.0f;
-    if (weight_zero && numel(weight_zero) > 0) {
-        if (weight_zero->mem == LELE_MEM_DEVICE) {
-            LELE_HIP_CHECK(hipMemcpyAsync(&wz, weight_zero->data, 4, hipMemcpyDeviceToHost, ctx->stream));
-            LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
-            LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        } else {
-            wz = *(const float*)weight_zero->data;
-        }
-    }
-    // the producer's {min, max} pairs, if it left any next to this tensor (LayerNorm: one pair per row; a quantised linear:
-    // one pair per row and column group; a small-problem GEMM: one per workgroup, single slice only): slice s then owns `nblk`
-    // consecutive pairs and the separate range pass over the activation is skipped
+    LELE_TRY(weight_zero_of(ctx, weight_zero, &wz));
     const float* partial = nullptr;
     int nblk = 0;
-    if (input->mem == LELE_MEM_DEVICE && m <= 2048) {
-        auto it = ctx->buf_of_data.find(input->data);
-        if (it != ctx->buf_of_data.end() && it->second->rowstat_valid) {
-            const LeleBuf* src = it->second;
-            if (src->rowstat_kind == 0 && src->rowstat_len == k && src->rowstat_rows == rows) {
-                partial = src->rowstat;  // one pair per row
-                nblk = (int)m;
-            } else if (src->rowstat_kind == 2 && src->rowstat_len == k && src->rowstat_m == m && src->rowstat_rows % batch == 0) {
-                partial = src->rowstat;  // a fixed number of pairs per slice of m rows (qlinear_onepass_kernel)
-                nblk = (int)(src->rowstat_rows / batch);
-            } else if (src->rowstat_kind == 1 && batch == 1 && src->rowstat_len == rows * k && src->rowstat_rows <= 4096) {
-                partial = src->rowstat;  // per-workgroup pairs of the GEMM that produced the tensor: one slice, all pairs
-                nblk = (int)src->rowstat_rows;
-            }
-        }
-    }
+    find_partials(ctx, input, batch, m, k, &partial, &nblk);
     void* prm = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm));
     LELE_TRY(qprof_mark(ctx, 0));
@@ -1440,25 +1998,16 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     // ---- three-kernel chain: rows -> i8 (+ row sums) in HBM, then the tiled i8 GEMM
     const int kp = (int)((k + 15) & ~int64_t(15));
     PackedW pw;
-    {
-        const bool cacheable = weight_int8->mem == LELE_MEM_WEIGHT;  // only declared-immutable weights are cached
-        auto key_w = std::make_tuple((const void*)weight_int8->data, (size_t)numel(weight_int8) * 4, 201);
-        if (cacheable && ctx->weights.count(key_w)) {
-            LELE_TRY(get_packed_weights(ctx, weight_int8, nullptr, 1, (int)k, (int)n, kp, &pw, true));
-        } else {
-            LELE_TRY(ctx->dev_ptr(weight_int8, &dw));
-            LELE_TRY(get_packed_weights(ctx, weight_int8, (const float*)dw, 1, (int)k, (int)n, kp, &pw, cacheable));
-        }
-    }
+    LELE_TRY(packed_weights_of(ctx, weight_int8, (int)k, (int)n, kp, &pw));
     void *aq = nullptr, *rs = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)rows * kp, &aq));
     LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));
     if (rows <= 2048 || (kp <= 2048 && !env_int("LELE_HIP_QROWS_STREAM", 0)))  // the whole row in flight at once (8 x 16 bytes per lane)
         hipLaunchKernelGGL((qrows_kernel<0, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
-                           rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk);
+                           rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk, (unsigned*)nullptr, (int*)nullptr);
     else
         hipLaunchKernelGGL((qrows_kernel<0, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
-                           rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk);
+                           rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk, (unsigned*)nullptr, (int*)nullptr);
     LELE_TRY(qprof_mark(ctx, 2));
     IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, (const int*)rs, pw.col_sums, (const QParams*)prm, 0,
                  (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
@@ -1533,6 +2082,108 @@ int lele_hip_fused_quantized_linear_residual(LeleCtx* ctx, const LeleTensor* inp
         cur = dst;
     }
     return set_shape_v(out_shape, out_rank, std::vector<int64_t>(sh, sh + r));
+}
+
+/* Two quantised linears with a ReLU between them (the feed-forward block of a transformer layer):
+ *     out = fused_quantized_linear[_residual](fused_quantized_linear(input, W1.., relu = 1), W2.., relu2, res1, res2)
+ * bit for bit.  When the hidden layer is large the f32 hidden tensor is never stored: its product runs twice on the matrix cores
+ * (igemm_kernel EM 1: range only; EM 2: quantise with that range, i8 + row sums), then the second GEMM consumes the i8 rows. */
+int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_int8, const LeleTensor* w1_scale,
+                                 const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8,
+                                 const LeleTensor* w2_scale, const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2,
+                                 const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && input && w1_int8 && w1_scale && w2_int8 && w2_scale && out, "fused_ffn_quantized: NULL argument");
+    LELE_REQUIRE(input->rank >= 2 && w1_int8->rank >= 2 && w2_int8->rank >= 2, "fused_ffn_quantized: rank >= 2 required");
+    LELE_REQUIRE(!res2 || res1, "fused_ffn_quantized: res2 without res1");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t m = input->shape[input->rank - 2], k1 = input->shape[input->rank - 1];
+    const int64_t n1 = w1_int8->shape[w1_int8->rank - 1], k2 = w2_int8->shape[w2_int8->rank - 2], n2 = w2_int8->shape[w2_int8->rank - 1];
+    int64_t batch = 1;
+    for (int i = 0; i + 2 < input->rank; ++i) batch *= input->shape[i];
+    const int64_t rows = batch * m;
+    const int64_t ws1_len = numel(w1_scale), b1_len = b1 ? numel(b1) : 0;
+    // the fused route: a hidden layer of whole 128-column tiles (= whole SIMD bodies of its quantiser), slices of at least one tile
+    // of rows, enough tiles to fill the chip, same-shape residuals; everything else runs the two calls it stands for
+    bool fused = env_int("LELE_HIP_FFN_FUSED", 1) != 0 && w1_int8->shape[w1_int8->rank - 2] == k1 && k2 == n1 && n1 % 128 == 0 &&
+                 m >= 128 && rows < (int64_t(1) << 31) && ((rows + 127) / 128) * (n1 / 128) >= 2 * (int64_t)ctx->num_cus &&
+                 ws1_len >= 1 && (ws1_len == 1 || ws1_len >= n1) && (b1_len == 0 || b1_len >= n1) && n2 >= 1;
+    if (fused && res1) {
+        int64_t on = n2 * rows;
+        auto same = [&](const LeleTensor* t) {
+            if (t->dtype != LELE_F32 || numel(t) != on || t->rank > input->rank) return false;
+            for (int d = 0; d < t->rank; ++d)
+                if (t->shape[t->rank - 1 - d] != (d == 0 ? n2 : input->shape[input->rank - 1 - d])) return false;
+            return true;
+        };
+        fused = same(res1) && (!res2 || same(res2));
+    }
+    if (!fused) {
+        LeleBuf* hid = nullptr;
+        LELE_TRY(ctx->tmp_buf(2, &hid));
+        int64_t sh[LELE_MAX_RANK];
+        int32_t r = 0;
+        LELE_TRY(fql_impl(ctx, input, w1_int8, w1_scale, w1_zero, b1, 1, nullptr, nullptr, hid, sh, &r));
+        LeleTensor h{hid->data, sh, r, LELE_F32, LELE_MEM_DEVICE};
+        if (res1) return lele_hip_fused_quantized_linear_residual(ctx, &h, w2_int8, w2_scale, w2_zero, b2, apply_relu2, res1, res2, out, out_shape, out_rank);
+        return fql_impl(ctx, &h, w2_int8, w2_scale, w2_zero, b2, apply_relu2, nullptr, nullptr, out, out_shape, out_rank);
+    }
+    const int64_t ws2_len = numel(w2_scale), b2_len = b2 ? numel(b2) : 0;
+    LELE_REQUIRE(ws2_len >= 1 && (ws2_len == 1 || ws2_len >= n2), "fused_ffn_quantized: weight_scale has %lld entries for N=%lld", (long long)ws2_len, (long long)n2);
+    LELE_REQUIRE(b2_len == 0 || b2_len >= n2, "fused_ffn_quantized: bias has %lld entries for N=%lld", (long long)b2_len, (long long)n2);
+    std::vector<int64_t> shp(input->shape, input->shape + input->rank - 1);
+    shp.push_back(n2);
+    LELE_TRY(out->reserve((size_t)rows * n2 * 4));
+    LELE_TRY(ctx->arena_reset());
+    const void *dx = nullptr, *dws1 = nullptr, *db1 = nullptr, *dws2 = nullptr, *db2 = nullptr, *dr1 = nullptr, *dr2 = nullptr;
+    LELE_TRY(ctx->dev_ptr(input, &dx));
+    LELE_TRY(ctx->dev_ptr(w1_scale, &dws1));
+    LELE_TRY(ctx->dev_ptr(w2_scale, &dws2));
+    if (b1_len) LELE_TRY(ctx->dev_ptr(b1, &db1));
+    if (b2_len) LELE_TRY(ctx->dev_ptr(b2, &db2));
+    if (res1) LELE_TRY(ctx->dev_ptr(res1, &dr1));
+    if (res2) LELE_TRY(ctx->dev_ptr(res2, &dr2));
+    float wz1 = 0.0f, wz2 = 0.0f;
+    LELE_TRY(weight_zero_of(ctx, w1_zero, &wz1));
+    LELE_TRY(weight_zero_of(ctx, w2_zero, &wz2));
+    const float* partial = nullptr;
+    int nblk = 0;
+    find_partials(ctx, input, batch, m, k1, &partial, &nblk);
+    void *prm1 = nullptr, *prm2 = nullptr, *aq1 = nullptr, *rs1 = nullptr, *aq2 = nullptr, *rs2 = nullptr, *hmax = nullptr;
+    LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm1));
+    LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm2));
+    LELE_TRY(qprof_mark(ctx, 0));
+    if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k1, (QParams*)prm1, nullptr, nullptr, &partial, &nblk));
+    LELE_TRY(qprof_mark(ctx, 1));
+    const int kp1 = (int)((k1 + 15) & ~int64_t(15)), kp2 = (int)n1;
+    PackedW pw1, pw2;
+    LELE_TRY(packed_weights_of(ctx, w1_int8, (int)k1, (int)n1, kp1, &pw1));
+    LELE_TRY(packed_weights_of(ctx, w2_int8, (int)k2, (int)n2, kp2, &pw2));
+    LELE_TRY(ctx->arena_alloc((size_t)rows * kp1, &aq1));
+    LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs1));
+    LELE_TRY(ctx->arena_alloc((size_t)rows * kp2, &aq2));
+    LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs2));
+    LELE_TRY(ctx->arena_alloc((size_t)batch * 4, &hmax));
+    // rows -> i8 for the first GEMM; the same launch clears the accumulators of the two hidden-layer passes
+    if (kp1 <= 2048 && !env_int("LELE_HIP_QROWS_STREAM", 0))
+        hipLaunchKernelGGL((qrows_kernel<0, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx, rows,
+                           (int)k1, kp1, (int)m, (QParams*)prm1, (int8_t*)aq1, (int*)rs1, partial, nblk, (unsigned*)hmax, (int*)rs2);
+    else
+        hipLaunchKernelGGL((qrows_kernel<0, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx, rows,
+                           (int)k1, kp1, (int)m, (QParams*)prm1, (int8_t*)aq1, (int*)rs1, partial, nblk, (unsigned*)hmax, (int*)rs2);
+    LELE_TRY(qprof_mark(ctx, 2));
+    IgemmEpi e1{nullptr, rows, n1, (int)m, (int)k1, (const int*)rs1, pw1.col_sums, (const QParams*)prm1, 0, (int)wz1, (const float*)dws1,
+                (int)ws1_len, b1_len ? (const float*)db1 : nullptr, 1};
+    e1.slice_max = (unsigned*)hmax;
+    LELE_TRY(launch_igemm_hidden(ctx, 1, (const int8_t*)aq1, pw1.wt, rows, (int)n1, kp1, (int)m, e1));
+    e1.q_out = (int8_t*)aq2;
+    e1.q_rowsum = (int*)rs2;
+    e1.q_prm = (QParams*)prm2;
+    LELE_TRY(launch_igemm_hidden(ctx, 2, (const int8_t*)aq1, pw1.wt, rows, (int)n1, kp1, (int)m, e1));
+    IgemmEpi e2{(float*)out->data, rows, n2, (int)m, (int)k2, (const int*)rs2, pw2.col_sums, (const QParams*)prm2, 0, (int)wz2,
+                (const float*)dws2, (int)ws2_len, b2_len ? (const float*)db2 : nullptr, apply_relu2, (const float*)dr1, (const float*)dr2};
+    LELE_TRY(launch_igemm(ctx, (const int8_t*)aq2, pw2.wt, rows, (int)n2, kp2, 0, (int)m, e2));
+    LELE_TRY(qprof_mark(ctx, 3));
+    return set_shape_v(out_shape, out_rank, shp);
 }
 
 /* ---- per-stage stopwatch of fused_quantized_linear (bench.py's roofline block for the model path) ------------------- */
@@ -1717,7 +2368,7 @@ int lele_hip_mat_mul_integer_with_scale_bias(LeleCtx* ctx, const LeleTensor* a, 
     LELE_TRY(ctx->arena_alloc((size_t)rows_a * kp, &aq));
     LELE_TRY(ctx->arena_alloc((size_t)rows_a * 4, &rs));
     hipLaunchKernelGGL(qrows_kernel<1>, dim3((unsigned)((rows_a + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)da,
-                       rows_a, (int)k, kp, (int)m, (QParams*)nullptr, (int8_t*)aq, (int*)rs, (const float*)nullptr, 0);
+                       rows_a, (int)k, kp, (int)m, (QParams*)nullptr, (int8_t*)aq, (int*)rs, (const float*)nullptr, 0, (unsigned*)nullptr, (int*)nullptr);
     // one launch per batch slice unless everything is un-batched on the B side (then all rows share the weights)
     const int64_t launches = (batch_b == 1 && batch_a >= 1) ? 1 : fb;
     for (int64_t bi = 0; bi < launches; ++bi) {

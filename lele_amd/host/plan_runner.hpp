@@ -938,6 +938,9 @@ class Runner {
         if (fn == "fused_quantized_linear_residual")
             return set(st, 0, K::fused_quantized_linear_residual(tensor(a[0]), tensor(a[1]), tensor(a[2]), tensor(a[3]), opt(a[4], h0), boolean(a[5]),
                                                                  tensor(a[6]), opt(a[7], h1), o));
+        if (fn == "fused_ffn_quantized")
+            return set(st, 0, K::fused_ffn_quantized(tensor(a[0]), tensor(a[1]), tensor(a[2]), tensor(a[3]), opt(a[4], h0), tensor(a[5]), tensor(a[6]),
+                                                     tensor(a[7]), opt(a[8], h1), boolean(a[9]), opt(a[10], h2), opt(a[11], h3), o));
         if (fn == "mat_mul_integer") return set(st, 0, K::mat_mul_integer(tensor(a[0]), tensor(a[1]), opt(a[2], h0), opt(a[3], h1), o));
         if (fn == "dynamic_quantize_linear") {
             auto r = K::dynamic_quantize_linear(tensor(a[0]), o, slot(st, 1), slot(st, 2));

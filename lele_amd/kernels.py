@@ -958,6 +958,21 @@ def fused_quantized_linear_residual(input, weight_int8, weight_scale, weight_zer
     return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
 
 
+def fused_ffn_quantized(input, w1_int8, w1_scale, w1_zero, b1, w2_int8, w2_scale, w2_zero, b2, apply_relu2=False, res1=None, res2=None,
+                        out=None, ctx=None):
+    """fused_quantized_linear[_residual](fused_quantized_linear(input, w1.., True), w2.., apply_relu2, res1, res2), bit for bit: a
+    transformer layer's feed-forward block whose f32 hidden tensor is never stored when it is large"""
+    ctx = _ctx(ctx)
+    keep = []
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_fused_ffn_quantized(
+        ctx._h, _t(input, keep), _t(w1_int8, keep), _t(w1_scale, keep), _t(w1_zero, keep), _t(b1, keep), _t(w2_int8, keep),
+        _t(w2_scale, keep), _t(w2_zero, keep), _t(b2, keep), C.c_int(int(apply_relu2)), _t(res1, keep), _t(res2, keep), out._h,
+        sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
+
+
 def softmax_scaled(input, scale, axis=-1, out=None, ctx=None):
     """softmax(input * scale[0]): bit-identical to mul(input, scale) followed by softmax"""
     return _op(ctx, _lib.lib().lele_hip_softmax_scaled, [input, scale], [C.c_int32(axis)], out)

@@ -197,6 +197,74 @@ def test_residual_adds_in_the_linear_epilogue_are_bit_identical(ctx):
 
 
 @pytest.mark.gpu
+def test_fused_ffn_never_stores_the_hidden_layer_and_keeps_every_bit(ctx):
+    """lele_hip_fused_ffn_quantized = two fused_quantized_linear calls with a ReLU between them.  Large hidden layers take the
+    recompute route (the first product twice: range, then quantise to i8 + row sums); the result must equal the oracle's
+    composition and the two separate device calls bit for bit -- slices that straddle row tiles, K not a multiple of the tile,
+    odd output widths, with and without residuals, and the shapes that fall back to the two calls."""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    from oracle import pyoracle as O
+    rng = np.random.default_rng(11)
+
+    def lin(k, n):
+        return (Weight(np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32)),
+                Weight((rng.random(n) * 0.01 + 0.002).astype(np.float32)), Weight(np.array([128.0], np.float32)),
+                Weight(rng.standard_normal(n).astype(np.float32) * 0.1))
+    for b, m, k1, n1, n2, relu2 in ((32, 171, 512, 2048, 512, False), (16, 300, 200, 2048, 72, True), (1, 4800, 512, 2048, 512, False),
+                                    (2, 33, 64, 128, 32, False), (1, 504, 512, 2048, 512, False), (40, 129, 96, 2176, 64, False)):
+        x = (rng.standard_normal((b, m, k1)) * rng.uniform(0.3, 3.0, (b, 1, 1))).astype(np.float32)
+        w1, w2 = lin(k1, n1), lin(n1, n2)
+        r1, r2 = rng.standard_normal((b, m, n2)).astype(np.float32), rng.standard_normal((b, m, n2)).astype(np.float32)
+        hid = O.fused_quantized_linear(x, w1[0].arr, w1[1].arr, w1[2].arr, w1[3].arr, True)
+        want = O.fused_quantized_linear(hid, w2[0].arr, w2[1].arr, w2[2].arr, w2[3].arr, relu2)
+        got = K.fused_ffn_quantized(x, *w1, *w2, relu2, ctx=ctx).numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (b, m, k1, n1, n2)
+        # the two calls on the device, and the residual forms
+        h_dev = K.fused_quantized_linear(x, *w1, True, ctx=ctx)
+        assert np.array_equal(h_dev.numpy(), hid)
+        two = K.fused_quantized_linear_residual(h_dev, *w2, relu2, r1, r2, ctx=ctx).numpy()
+        assert np.array_equal(K.fused_ffn_quantized(x, *w1, *w2, relu2, r1, r2, ctx=ctx).numpy(), two), (b, m, k1, n1, n2)
+        one = K.fused_quantized_linear_residual(h_dev, *w2, relu2, r1, ctx=ctx).numpy()
+        assert np.array_equal(K.fused_ffn_quantized(x, *w1, *w2, relu2, r1, ctx=ctx).numpy(), one), (b, m, k1, n1, n2)
+        with _env(LELE_HIP_FFN_FUSED=0):
+            assert np.array_equal(K.fused_ffn_quantized(x, *w1, *w2, relu2, r1, r2, ctx=ctx).numpy(), two)
+    # input statistics left by a LayerNorm (the model's case) are used as before, and a slice of all-negative pre-activations
+    # (hidden layer identically zero: range floor 1e-5) quantises like the stored tensor would
+    x = rng.standard_normal((32, 171, 512)).astype(np.float32)
+    g, be = np.ones(512, np.float32), np.zeros(512, np.float32)
+    xn = K.layer_norm(x, g, be, -1, 1e-5, out=ctx.buf(), ctx=ctx)
+    w1, w2 = lin(512, 2048), lin(2048, 512)
+    w1 = (w1[0], w1[1], w1[2], Weight(np.full(2048, -1e4, np.float32)))     # bias drives every pre-activation below zero
+    hid = O.fused_quantized_linear(xn.numpy(), w1[0].arr, w1[1].arr, w1[2].arr, w1[3].arr, True)
+    assert not hid.any()
+    want = O.fused_quantized_linear(hid, w2[0].arr, w2[1].arr, w2[2].arr, w2[3].arr, False)
+    assert np.array_equal(K.fused_ffn_quantized(xn, *w1, *w2, False, ctx=ctx).numpy(), want)
+
+
+@pytest.mark.gpu
+def test_fused_ffn_is_deterministic_under_repetition(ctx):
+    """the recompute route combines per-workgroup maxima through LDS and global atomics and row sums through integer atomics:
+    300 repetitions of one configs[3]-shard call must give one bit pattern (a race here shows up as one utterance in a few
+    hundred calls quantised with a neighbour's range), equal to the tiled-kernel route's"""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    rng = np.random.default_rng(0)
+
+    def lin(k, n):
+        return (Weight(np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32)),
+                Weight((np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32)), Weight(np.array([128.0], np.float32)),
+                Weight((rng.standard_normal(n) * 0.02).astype(np.float32)))
+    w1, w2 = lin(512, 2048), lin(2048, 512)
+    x = ctx.buf().upload((rng.standard_normal((32, 171, 512)) * rng.uniform(0.3, 3, (32, 1, 1))).astype(np.float32))
+    with _env(LELE_HIP_IGEMM_WHOLEK=0):
+        ref = K.fused_ffn_quantized(x, *w1, *w2, False, ctx=ctx).numpy().copy()
+    ob = ctx.buf()
+    bad = [it for it in range(300) if not np.array_equal(K.fused_ffn_quantized(x, *w1, *w2, False, out=ob, ctx=ctx).numpy(), ref)]
+    assert not bad, "iterations with different bits: %s" % bad[:10]
+
+
+@pytest.mark.gpu
 def test_gemm_block_statistics_feed_the_next_dynamic_quantisation(ctx):
     """The small-problem GEMM kernels publish one {min, max} pair per workgroup; a single-slice quantised linear that reads
     the result next uses them instead of scanning it.  Same bits as the scan (compared with the call on a host copy)."""

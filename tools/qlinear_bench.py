@@ -30,7 +30,7 @@ def main():
     shapes = [("c4 qkv", 32, 171, 512, 1536, False), ("c4 out", 32, 171, 512, 512, False), ("c4 ffn1", 32, 171, 512, 2048, True),
               ("c4 ffn2", 32, 171, 2048, 512, False), ("c3 qkv", 1, 504, 512, 1536, False), ("c3 out", 1, 504, 512, 512, False),
               ("c3 ffn1", 1, 504, 512, 2048, True), ("c3 ffn2", 1, 504, 2048, 512, False)]
-    variants = [("chain", {"LELE_HIP_QLINEAR_ONEPASS": "0"})] + [("chain tile=%d" % t, {"LELE_HIP_IGEMM_TILE": str(t)}) for t in range(1, 9)] + [("onepass", {"LELE_HIP_QLINEAR_ONEPASS": "1"})] + [
+    variants = [("chain", {"LELE_HIP_QLINEAR_ONEPASS": "0"})] + [("chain tile=%d" % t, {"LELE_HIP_IGEMM_TILE": str(t)}) for t in range(1, 15)] + [("onepass", {"LELE_HIP_QLINEAR_ONEPASS": "1"})] + [
         ("onepass rb=%d wgs=%d" % (rb, w), {"LELE_HIP_QLINEAR_ONEPASS": "1", "LELE_HIP_ONEPASS_RB": str(rb), "LELE_HIP_ONEPASS_WGS": str(w)})
         for rb, w in ((1, 192), (1, 384), (2, 384))]
     if args.debug:  # phase ablation of the one-pass kernel (results are wrong by construction)
