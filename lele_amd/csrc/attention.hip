@@ -44,6 +44,8 @@ struct AttnArgs {
     int nqb;           // query blocks per (batch, head)
     const float* scale;
     float* stat;       // [batch_outer][batch_inner * nqb][2] or NULL
+    int ablate;        // developer switch LELE_HIP_ATTN_ABLATE (timing experiments, results wrong): 1 no softmax arithmetic, 2 no exp
+    long long* dbg;    // developer switch LELE_HIP_ATTN_STAMPS: 8 cycle-counter stamps per workgroup (tools/attention_stamps.py), or NULL
 };
 
 constexpr int kDh = 128;   // head dimension (8 chunks of 16)
@@ -72,6 +74,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     const float* vp = a.v + bo * a.v_so + bi * a.v_si;
     float* op = a.o + bo * a.o_so + bi * a.o_si;
     const int ntile = a.tpad / 32;  // key tiles (even: tpad is a multiple of 64)
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 8 + nstamp++] = (long long)clock64();
+    };
+    stamp();
 
     // ---- phase 1: S = Q K^T.  Lane (l31, hv) of a 16-d chunk c owns d = 16c + 8hv + [0, 8): two float4 per chunk
     // K fragments in two register sets of half a head dimension each (4 chunks = 32 registers), requested one set ahead
@@ -127,31 +134,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2) + 4 * hv) * pitch] = acc[r];
     }
+    stamp();  // [1] this wave's score tiles are in LDS
     __syncthreads();
+    stamp();  // [2] every wave's
 
     // ---- phase 2: row softmax, eight 32-lane groups x 4 RT rows.  P = 0 beyond the last key (those columns then add exact zeros)
     {
         const int g = tid >> 5, l = tid & 31;
         const float sc = a.scale ? a.scale[0] : 1.0f;
+        // four rows at a time: their reductions are independent chains of cross-lane operations (each a round trip through the LDS
+        // crossbar), interleaved by the scheduler instead of queued one row after the other
 #pragma unroll 1
-        for (int rr = 0; rr < 4 * RT; ++rr) {
-            float* row = s_sp + (g * 4 * RT + rr) * pitch;
-            float v[NT];
+        for (int r4 = 0; r4 < RT; ++r4) {
+            float v[4][NT];
 #pragma unroll
-            for (int c = 0; c < NT; ++c) {
-                const int j = 32 * c + l;
-                v[c] = row[j < a.tk ? j : a.tk - 1];
-                if (a.scale) v[c] = v[c] * sc;
+            for (int q = 0; q < 4; ++q) {
+                const float* row = s_sp + (g * 4 * RT + 4 * r4 + q) * pitch;
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    const int j = 32 * c + l;
+                    v[q][c] = row[j < a.tk ? j : a.tk - 1];
+                    if (a.scale) v[q][c] = v[q][c] * sc;
+                }
             }
-            softmax_row_reg<NT>(v, a.tk, l);
 #pragma unroll
-            for (int c = 0; c < NT; ++c) {
-                const int j = 32 * c + l;
-                if (j < a.tpad) row[j] = j < a.tk ? v[c] : 0.0f;
+            for (int q = 0; q < 4; ++q)
+                if (!(a.ablate & 1)) softmax_row_reg<NT>(v[q], a.tk, l);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float* row = s_sp + (g * 4 * RT + 4 * r4 + q) * pitch;
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    const int j = 32 * c + l;
+                    if (j < a.tpad) row[j] = j < a.tk ? v[q][c] : 0.0f;
+                }
             }
         }
     }
+    stamp();  // [3] softmax of this group's rows
     __syncthreads();
+    stamp();  // [4]
 
     // ---- phase 3: O = P V.  A wave owns ND = RT output tiles of 32 dims of its row tile; a set = 32 keys (two 16-key chunks):
     // lane (l31, hv) holds V[16c + 8hv + s][32 d + l31] (16 registers per output tile) and reads P[row l31][16c + 8hv .. + 8] from LDS
@@ -200,6 +222,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         mmv(vb, j0 + 32);
         __builtin_amdgcn_sched_barrier(0);
     }
+    stamp();  // [5] P V products done
     float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
 #pragma unroll
     for (int d = 0; d < ND; ++d)
@@ -213,6 +236,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                 mx = val > mx ? val : mx;
             }
         }
+    stamp();  // [6] stores issued
     if (a.stat) {  // uniform: one pair per workgroup
         for (int off = 32; off > 0; off >>= 1) {
             const float p = __shfl_xor(mn, off), q = __shfl_xor(mx, off);
@@ -299,6 +323,10 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
     const int qrows = rt == 2 ? 64 : 32;
     a.nqb = (int)((t_q + qrows - 1) / qrows);
     a.scale = (const float*)dsc;
+    a.dbg = nullptr;
+    a.ablate = 0;
+    if (const char* e = getenv("LELE_HIP_ATTN_ABLATE")) a.ablate = atoi(e);
+    if (const char* e = getenv("LELE_HIP_ATTN_STAMPS")) a.dbg = (long long*)(uintptr_t)strtoull(e, nullptr, 0);
     // result statistics for the dynamic quantisation that reads this tensor next: valid when a slice of the consumer is exactly
     // one outer batch element, i.e. the result is laid out [batch_outer][t_q][batch_inner * dh] (heads merged)
     const int64_t per_slice = (int64_t)a.batch_inner * a.nqb, nstat = batch_outer * per_slice;
@@ -315,13 +343,24 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
         if (lds > 60 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));               \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, a);                                                   \
     } while (0)
-    if (a.tpad <= 256) {
-        if (rt == 2) LELE_ATTN(8, 2);
-        else LELE_ATTN(8, 1);
-    } else {
-        if (rt == 2) LELE_ATTN(16, 2);
-        else LELE_ATTN(16, 1);
+    // softmax registers per lane = key tiles exactly (tpad / 32, even): a 10 s utterance needs 6, not 8 -- the row softmax is a third
+    // of the kernel's instructions (tools/attention_stamps.py) and every surplus register row is exponentials nobody reads
+#define LELE_ATTN_NT(NT_)                   \
+    do {                                    \
+        if (rt == 2) LELE_ATTN(NT_, 2);     \
+        else LELE_ATTN(NT_, 1);             \
+    } while (0)
+    switch (a.tpad / 64) {
+        case 1: LELE_ATTN_NT(2); break;
+        case 2: LELE_ATTN_NT(4); break;
+        case 3: LELE_ATTN_NT(6); break;
+        case 4: LELE_ATTN_NT(8); break;
+        case 5: LELE_ATTN_NT(10); break;
+        case 6: LELE_ATTN_NT(12); break;
+        case 7: LELE_ATTN_NT(14); break;
+        default: LELE_ATTN_NT(16); break;
     }
+#undef LELE_ATTN_NT
 #undef LELE_ATTN
     LELE_HIP_CHECK(hipGetLastError());
     if (a.stat) {

@@ -368,11 +368,8 @@ __global__ void layer_norm_reg_kernel(const float* __restrict__ x, const float* 
         }
     }
     if (rowstat) {
-        for (int off = 16; off > 0; off >>= 1) {
-            const float a = __shfl_xor(mn, off, 32), c2 = __shfl_xor(mx, off, 32);
-            mn = a < mn ? a : mn;
-            mx = c2 > mx ? c2 : mx;
-        }
+        mn = group_allreduce32(mn, [](float cur, float a) { return a < cur ? a : cur; });
+        mx = group_allreduce32(mx, [](float cur, float a) { return a > cur ? a : cur; });
         if (l == 0) {
             rowstat[2 * row] = mn;
             rowstat[2 * row + 1] = mx;
@@ -401,12 +398,15 @@ __global__ void softmax_reg_kernel(const float* __restrict__ x, float* __restric
         if (scaled) v[c] = v[c] * sc;
         if (j < len) m = fmaxf(m, v[c]);
     }
-    for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+    m = group_max32(m);
     const int body = len & ~7;
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
         const int j = 32 * c + l;
-        v[c] = j < body ? exp_poly(v[c] - m) : expf(v[c] - m);  // computed once, reused for the sum and the output
+        // computed once, reused for the sum and the output; register rows entirely inside the 8-wide body skip the libm call
+        // (uniform condition -- a per-lane select would evaluate both functions for every element)
+        if (32 * c + 32 <= body) v[c] = exp_poly(v[c] - m);
+        else v[c] = j < body ? exp_poly(v[c] - m) : expf(v[c] - m);
     }
     float sum, dummy;
     row_sums_reg<NT, false, true>(v, len, l, &sum, &dummy);
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ 
     auto in = [&](int64_t j) { return scaled ? src[j] * sc : src[j]; };
     float m = -3.40282347e+38f;  // f32::MIN seeds; max is order-independent
     for (int64_t j = l; j < len; j += 32) m = fmaxf(m, in(j));
-    for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+    m = group_max32(m);
     const int64_t body = len & ~int64_t(7);
     // exp(x - max): polynomial in the SIMD body, libm in the tail; summed in the AVX accumulator order.  The values
     // are recomputed (deterministically) wherever another lane's element is needed, so no cross-lane memory traffic.

@@ -2,6 +2,7 @@
 // (attention.hip): the 32 lanes of a row play the four 8-wide AVX accumulators of lele's x86 kernels
 // (/root/reference/src/kernels/avx/norm.rs:10-229), so sums are formed in the reference's order and come out bit-identical.
 #pragma once
+#include "lane_ops.h"
 #include "simd_math.h"
 
 namespace lele {
@@ -19,37 +20,50 @@ __device__ __forceinline__ void row_sums_reg(const float (&v)[NT], int n, int l,
             if (PLAIN) s = s + v[c];
             if (SQUARE) q = fmaf_(v[c], v[c], q);
         }
-    float s01 = s + __shfl_down(s, 8, 32), q01 = q + __shfl_down(q, 8, 32);
-    float sv = s01 + __shfl_down(s01, 16, 32), qv = q01 + __shfl_down(q01, 16, 32);
+    // cross-lane moves on the DPP / permlane network (lane_ops.h): the same additions in the same order as the __shfl form, whose
+    // ~15 dependent ds_bpermute round trips per row were the cost of this routine.  Only lanes 0..7 of the group carry the sum from
+    // here on (then lanes 0..3, 0..1, 0), which is where each move's result is defined.
+    float s01 = s + row_down<8>(s), q01 = q + row_down<8>(q);
+    float sv = s01 + swap16(s01), qv = q01 + swap16(q01);
     float last = 0.0f;  // the partially filled register row v[nfull]
 #pragma unroll
     for (int c = 0; c < NT; ++c)
         if (c == nfull) last = v[c];
     const int rem = n - 32 * nfull, nch = rem >> 3;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-        if (r < nch) {
-            const float got = __shfl(last, 8 * r + (l & 7), 32);
-            if (l < 8) {
-                if (PLAIN) sv = sv + got;
-                if (SQUARE) qv = fmaf_(got, got, qv);
-            }
+    // 8-wide remainder chunk r lives in lanes 8r .. 8r + 7; lane l < 8 adds element l of it
+    if (nch > 0 && l < 8) {
+        if (PLAIN) sv = sv + last;
+        if (SQUARE) qv = fmaf_(last, last, qv);
+    }
+    if (nch > 1) {
+        const float got = row_down<8>(last);
+        if (l < 8) {
+            if (PLAIN) sv = sv + got;
+            if (SQUARE) qv = fmaf_(got, got, qv);
         }
-    sv = sv + __shfl_down(sv, 4, 32);
-    qv = qv + __shfl_down(qv, 4, 32);
-    sv = sv + __shfl_down(sv, 2, 32);
-    qv = qv + __shfl_down(qv, 2, 32);
-    sv = sv + __shfl_down(sv, 1, 32);
-    qv = qv + __shfl_down(qv, 1, 32);
+    }
+    if (nch > 2) {
+        const float got = swap16(last);
+        if (l < 8) {
+            if (PLAIN) sv = sv + got;
+            if (SQUARE) qv = fmaf_(got, got, qv);
+        }
+    }
+    sv = sv + row_down<4>(sv);
+    qv = qv + row_down<4>(qv);
+    sv = sv + row_down<2>(sv);
+    qv = qv + row_down<2>(qv);
+    sv = sv + row_down<1>(sv);
+    qv = qv + row_down<1>(qv);
 #pragma unroll
     for (int t = 0; t < 7; ++t)
-        if (t < (rem & 7)) {
-            const float got = __shfl(last, 8 * nch + t, 32);
+        if (t < (rem & 7)) {  // uniform; only lane 0's running sum is read below
+            const float got = group_read(last, 8 * nch + t);
             if (PLAIN) sv = sv + got;
             if (SQUARE) qv = qv + got * got;
         }
-    *out_sum = __shfl(sv, 0, 32);
-    *out_sq = __shfl(qv, 0, 32);
+    *out_sum = group_read(sv, 0);
+    *out_sq = group_read(qv, 0);
 }
 
 // One row of softmax_reg_kernel (eltwise.hip; avx/norm.rs:139-229) on values already in registers: lane l of a 32-lane group
@@ -61,12 +75,15 @@ __device__ __forceinline__ void softmax_row_reg(float (&v)[NT], int len, int l) 
 #pragma unroll
     for (int c = 0; c < NT; ++c)
         if (32 * c + l < len) m = fmaxf(m, v[c]);
-    for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 32));
+    m = group_max32(m);
     const int body = len & ~7;
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
         const int j = 32 * c + l;
-        v[c] = j < body ? exp_poly(v[c] - m) : expf(v[c] - m);
+        // register rows entirely inside the 8-wide body (all but one) skip the libm call: a per-lane select would evaluate both
+        // functions for every element (the condition is uniform: `body` depends on the row length only)
+        if (32 * c + 32 <= body) v[c] = exp_poly(v[c] - m);
+        else v[c] = j < body ? exp_poly(v[c] - m) : expf(v[c] - m);
     }
     float sum, dummy;
     row_sums_reg<NT, false, true>(v, len, l, &sum, &dummy);

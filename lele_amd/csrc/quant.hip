@@ -18,6 +18,7 @@
 // [N, Kpad] (w - 128) with column sums and cached per (pointer, bytes) -- the analogue of B_WEIGHT_CACHE
 // (avx/quantization.rs:12-95).
 #include "common.h"
+#include "lane_ops.h"
 #include "gemm_small.h"
 
 #include <math.h>
@@ -192,11 +193,9 @@ __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x,
             } else {  // up to 1024 pairs (a GEMM's per-workgroup pairs, a LayerNorm's rows) per trip: one round trip, not four
                 for (int i0 = 0; i0 < nblk; i0 += 1024) sweep(i0, std::integral_constant<int, 16>());
             }
-            for (int off = 32; off > 0; off >>= 1) {
-                const float a = __shfl_xor(mn, off), b = __shfl_xor(mx, off);
-                mn = a < mn ? a : mn;
-                mx = b > mx ? b : mx;
-            }
+            // min / max over the wave on the DPP / permlane network (lane_ops.h; order-independent, exact)
+            mn = wave_allreduce64(mn, [](float cur, float a) { return a < cur ? a : cur; });
+            mx = wave_allreduce64(mx, [](float cur, float a) { return a > cur ? a : cur; });
             q = make_qparams(mn, mx);
             if (lane == 0 && row == slice * m) prm[slice] = q;
         } else {
@@ -280,7 +279,7 @@ __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x,
         }
         *reinterpret_cast<int*>(dst + c) = packed;
     }
-    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    sum = wave_sum_i32(sum);
     if (lane == 0) row_sums[row] = sum;
 }
 
