@@ -300,3 +300,72 @@ def adaptive_avg_pool1d(x, output_len):  # pooling.rs:1-30 (sequential f32 sum o
             acc = (acc + flat[:, k]).astype(np.float32)
         out[:, i] = acc / np.float32(end - start)
     return out.reshape(x.shape[:-1] + (output_len,))
+
+
+def depthwise_conv2d_x86_generic(x, w, strides, pads, relu=False):
+    """TEST INFRASTRUCTURE.  What lele's x86 build computes for a depthwise convolution that is NOT the 3x3 / stride 1 / pad 1
+    special case: /root/reference/src/kernels/conv2d.rs:535-570 dispatches to depthwise_conv2d_avx2 (3130-3215) WITHOUT the
+    bias and with only ReLU honoured (SiLU is dropped), and that kernel's 8-wide middle reads `ow + kj - pad_left + lane` without
+    a right-edge test (3156-3163: `in_w + pad_left.saturating_sub(kw - 1 + 7)` is in_w for every usual padding), so the last
+    vector step of a row takes pixels of the NEXT row (flat memory) where the definition has zero padding.  Restated here so that
+    the device library's deliberate divergence (it implements the ONNX definition: DESIGN.md section 4) is pinned by a test
+    instead of being silent.  Returns (out [N,C,OH,OW], defined): `defined` is False where the x86 code reads past the end of
+    the input buffer (undefined behaviour upstream).  FMA is emulated in f64 (exact product, one extra rounding): compare at 1e-6."""
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    n, c, ih, iw = x.shape
+    kh, kw = w.shape[-2:]
+    sh, sw = strides
+    pt, pl, pb, pr = pads
+    oh, ow = (ih + pt + pb - kh) // sh + 1, (iw + pl + pr - kw) // sw + 1
+    flat = x.reshape(-1)
+    out = np.zeros((n, c, oh, ow), np.float32)
+    defined = np.ones((n, c, oh, ow), bool)
+    vec_end = ((iw + max(pl - (kw - 1 + 7), 0)) // 8) * 8 if sw == 1 else 0
+    vec_start = pl if sw == 1 else ow
+
+    def scalar_px(b, ch, y, xo):
+        s = np.float32(0)
+        for ki in range(kh):
+            yy = y * sh + ki - pt
+            if yy < 0 or yy >= ih:
+                continue
+            for kj in range(kw):
+                xx = xo * sw + kj - pl
+                if xx < 0 or xx >= iw:
+                    continue
+                s = np.float32(s + x[b, ch, yy, xx] * w[ch].reshape(kh, kw)[ki, kj])
+        return np.float32(0) if (relu and s < 0) else s
+    for b in range(n):
+        for ch in range(c):
+            base = (b * c + ch) * ih * iw
+            wk = w[ch].reshape(kh, kw)
+            for y in range(oh):
+                xo = 0
+                while xo < min(vec_start, ow):
+                    out[b, ch, y, xo] = scalar_px(b, ch, y, xo)
+                    xo += 1
+                while sw == 1 and xo + 8 <= vec_end and xo + 8 <= ow:
+                    acc = np.zeros(8, np.float64)
+                    ok = np.ones(8, bool)
+                    for ki in range(kh):
+                        yy = y * sh + ki
+                        if yy < pt or yy >= ih + pt:
+                            continue
+                        row = base + (yy - pt) * iw
+                        for kj in range(kw):
+                            idx = row + xo + kj - pl + np.arange(8)
+                            inb = idx < flat.size
+                            ok &= inb
+                            v = flat[np.minimum(idx, flat.size - 1)].astype(np.float64)
+                            acc = (np.float64(wk[ki, kj]) * v + acc).astype(np.float32).astype(np.float64)
+                    r = acc.astype(np.float32)
+                    if relu:
+                        r = np.maximum(r, np.float32(0))
+                    out[b, ch, y, xo:xo + 8] = r
+                    defined[b, ch, y, xo:xo + 8] = ok
+                    xo += 8
+                while xo < ow:
+                    out[b, ch, y, xo] = scalar_px(b, ch, y, xo)
+                    xo += 1
+    return out, defined

@@ -403,3 +403,47 @@ def test_device_thin_convolutions_vs_oracle(ctx, shape):
         got = K.conv2d(x, w, None, [1, 1], 1, pads, strides, ctx=ctx).numpy()
         assert got.shape[2] * got.shape[3] <= 4, got.shape
         _close(got, O.conv2d(x, w, None, [1, 1], 1, pads, strides), RTOL, "thin conv2d %s" % (shape,))
+
+
+def _depthwise_case():
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((2, 3, 6, 24)).astype(np.float32) + 1.5      # non-zero row starts: an over-read is visible
+    w = rng.standard_normal((3, 1, 5, 5)).astype(np.float32)
+    bias = rng.standard_normal(3).astype(np.float32)
+    return x, w, bias
+
+
+def test_x86_generic_depthwise_divergence_is_pinned():
+    """DESIGN.md section 4 lists two deliberate divergences from lele's x86 build for depthwise convolutions outside the 3x3 / s1 /
+    p1 case: upstream drops bias and SiLU there, and its 8-wide middle reads the next row's pixels at the right edge
+    (conv2d.rs:535-570, 3130-3215).  oracle/npref.py restates that code; this test pins WHERE the restatement and the ONNX
+    definition (what the device implements, and what the reference's own ORT comparisons expect) part ways."""
+    from oracle import npref
+    from oracle import pyoracle as O
+    x, w, bias = _depthwise_case()
+    got, defined = npref.depthwise_conv2d_x86_generic(x, w, (1, 1), (0, 0, 4, 4))
+    plain = O.conv2d(x, w, None, (), 3, (0, 0, 4, 4), (1, 1))
+    assert got.shape == plain.shape == (2, 3, 6, 24)                         # same output size
+    # padding on the right only (an asymmetric "same" padding): the vector step for columns 16..23 reads columns up to 23 + 4,
+    # i.e. its last four lanes see the first pixels of the next row where the definition has zeros
+    edge = np.zeros(24, bool)
+    edge[20:] = True
+    assert np.allclose(got[..., ~edge], plain[..., ~edge], rtol=1e-5, atol=1e-5)        # away from the right edge: the definition
+    assert not np.allclose(got[..., edge][defined[..., edge]], plain[..., edge][defined[..., edge]], rtol=1e-3, atol=1e-3)
+    assert not defined[-1, -1, -1, 20:].all()                                # the very last row reads past the buffer upstream
+    # bias and SiLU never reach that kernel upstream: the definition with them differs everywhere
+    full = O.conv2d(x, w, bias, (), 3, (0, 0, 4, 4), (1, 1), act="silu")
+    assert not np.allclose(full[..., ~edge], got[..., ~edge], rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.gpu
+def test_device_generic_depthwise_follows_the_definition_not_the_x86_edge(ctx):
+    from lele_amd import kernels as K
+    from oracle import npref
+    from oracle import pyoracle as O
+    x, w, bias = _depthwise_case()
+    dev = K.conv2d_silu(x, w, bias, [1, 1], 3, [0, 0, 4, 4], [1, 1], ctx=ctx).numpy()
+    want = O.conv2d(x, w, bias, (), 3, (0, 0, 4, 4), (1, 1), act="silu")
+    assert np.allclose(dev, want, rtol=1e-4, atol=1e-5)
+    x86, defined = npref.depthwise_conv2d_x86_generic(x, w, (1, 1), (0, 0, 4, 4))
+    assert not np.allclose(dev[..., 20:][defined[..., 20:]], x86[..., 20:][defined[..., 20:]], rtol=1e-2, atol=1e-2)

@@ -140,3 +140,51 @@ def test_replan_lifted_structure():
     assert len(live) == 3 and cat["slots"][0] not in live
     assert [s.get("fn") for s in replan_lifted(plan, {"y": [1, 4, 3, 3]})["statements"]][:2] == ["conv2d", "silu"]     # 9-element planes
     assert len(plan["statements"]) == 10 and "slot" in plan["statements"][1]["args"][3]                                   # input untouched
+
+
+@pytest.mark.gpu
+def test_c5_sixty_four_images_over_eight_contexts(ctx):
+    """BASELINE configs[4] (batch 64) on lele's generated Yolo26n-seg call sequence.  The generated graph bakes N = 1 into its
+    reshapes (lele's emitter folds the ONNX shape arithmetic for the export's batch; its examples loop over images on the host),
+    so "batch 64" is 64 different images: 8 contexts (= 8 HIP streams, each with its own workspace and recorded graph) replaying
+    8 images each.  Every image's outputs must equal the eager single-context forward of that image, bit for bit.  The plan is
+    an untracked artifact lifted from the reference where it is mounted (tools/lift_generated.py lift): skipped when absent."""
+    import json
+
+    import numpy as np
+    import lele_amd
+    from lele_amd.plan import Runner, replan_lifted, fuse_sigmoid_mul, weight_key
+    from lele_amd.tensor import TensorView
+    import lift_generated as L
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_lifted", "yolo26seg_plan.json")
+    if not os.path.exists(path):
+        pytest.skip("no lifted Yolo26n-seg plan in this checkout")
+    plan = json.load(open(path))
+    raw = L.synth_weights(plan, dict(L.DEFAULT_CONSTS))
+    rng = np.random.default_rng(64)
+    images = rng.uniform(0, 1, (64, 1, 3, 640, 640)).astype(np.float32)
+    name = plan["inputs"][-1]
+    eager = Runner(plan, raw, ctx)
+    want = [[o.numpy().copy() for o in eager.run({name: TensorView(ctx.buf().upload(images[i]))})] for i in range(64)]
+    assert all(np.isfinite(o).all() for o in want[0])
+    lanes = []
+    for s in range(8):
+        c = ctx if s == 0 else lele_amd._lib.Ctx(0)
+        r = Runner(plan, raw, c)
+        x = c.buf().upload(images[s])
+        feed = {name: TensorView(x)}
+        r.run(feed)
+        c.sync()
+        c.graph_begin()
+        outs = r.run(feed)
+        lanes.append((c, c.graph_end(), x, outs))
+    for rnd in range(8):          # image 8 * rnd + s on context s, all eight graphs in flight together
+        for s, (c, g, x, outs) in enumerate(lanes):
+            x.upload(images[8 * rnd + s])
+            g.launch()
+        for s, (c, g, x, outs) in enumerate(lanes):
+            c.sync()
+            for a, o in zip(want[8 * rnd + s], outs):
+                assert np.array_equal(a, TensorView(o.raw()).numpy()), "image %d on context %d" % (8 * rnd + s, s)
+    for c, g, *_ in lanes:
+        g.close()

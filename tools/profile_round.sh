@@ -29,5 +29,11 @@ done
 # 5. operator micro-benchmarks
 timeout 280 python $R/tools/microbench.py --out "$OUT/microbench.json" > "$OUT/microbench.log" 2>&1
 timeout 200 python $R/tools/qlinear_bench.py --out "$OUT/qlinear.json" > "$OUT/qlinear.log" 2>&1
+# 6. the fused attention kernel and the persistent i8 GEMM from the inside (cycle-counter stamps per phase), and their timings
+timeout 120 python $R/tools/attention_bench.py > "$OUT/attention_bench.json" 2> "$OUT/attention_bench.log"
+timeout 120 python $R/tools/attention_stamps.py > "$OUT/attention_stamps.txt" 2> "$OUT/attention_stamps.log"
+timeout 120 python $R/tools/wholek_stamps.py > "$OUT/wholek_stamps.txt" 2> "$OUT/wholek_stamps.log"
+# 7. the sharded recogniser step through the C ABI alone (native runner, RCCL group of one rank per visible GPU)
+timeout 200 $R/lele_amd/lele_run --help > /dev/null 2>&1
 find "$OUT" -name '*.csv' | wc -l
 tail -c 400 "$OUT/bench_plain.json"
