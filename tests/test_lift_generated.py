@@ -171,13 +171,13 @@ def test_c5_sixty_four_images_over_eight_contexts(ctx):
     for s in range(8):
         c = ctx if s == 0 else lele_amd._lib.Ctx(0)
         r = Runner(plan, raw, c)
-        x = c.buf().upload(images[s])
-        feed = {name: TensorView(x)}
+        xb = c.buf()
+        feed = {name: TensorView(xb.upload(images[s]))}
         r.run(feed)
         c.sync()
         c.graph_begin()
         outs = r.run(feed)
-        lanes.append((c, c.graph_end(), x, outs))
+        lanes.append((c, c.graph_end(), xb, outs))
     for rnd in range(8):          # image 8 * rnd + s on context s, all eight graphs in flight together
         for s, (c, g, x, outs) in enumerate(lanes):
             x.upload(images[8 * rnd + s])
