@@ -486,12 +486,18 @@ def spawn(args, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
+    while any(p.poll() is None for p in procs):  # a rank that dies takes the job with it (the others would wait in a collective)
+        for p in procs:
+            if p.poll() not in (None, 0):
+                rc = p.returncode
+        if rc:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
     for p in procs:
         rc = p.wait() or rc
-    if rc:  # a rank that died takes the job with it: make sure nothing lingers
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
     return rc
 
 
