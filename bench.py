@@ -224,11 +224,30 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device):
     skip[VOCAB - 200:] = 1
     skip = lele_amd._lib.Weight(skip)
 
-    comm = None
+    comm, comm_note = None, None
     if world > 1:  # the C ABI's own RCCL communicator; the 128-byte id travels through the already-initialised process group
-        uid = [lele_amd._lib.Comm.unique_id() if rank == 0 else None]
+        uid, err = [None], ""
+        try:
+            if rank == 0:
+                uid = [lele_amd._lib.Comm.unique_id()]
+        except Exception as e:  # noqa: BLE001
+            err = str(e)
         dist.broadcast_object_list(uid, src=0)
-        comm = lele_amd._lib.Comm.from_id(ctx, uid[0], rank, world)
+        if uid[0] is not None:
+            try:
+                comm = lele_amd._lib.Comm.from_id(ctx, uid[0], rank, world)
+                probe = comm.allreduce_max(rank)
+                if probe != world - 1:
+                    raise RuntimeError("communicator probe returned %r" % probe)
+            except Exception as e:  # noqa: BLE001
+                err, comm = str(e), None
+        # every rank must take the same route: agree (MIN over ranks of "mine works"); otherwise the ids travel through the process
+        # group torch already holds, and the line says so -- a scaling measurement is not lost to a transport problem
+        import torch
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            comm, comm_note = None, "torch.distributed all_gather (the C ABI communicator was not usable on every rank: %s)" % (err or "another rank failed")
 
     def build(batch, seconds, seed0):
         n = SAMPLE_RATE * seconds
@@ -268,6 +287,8 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device):
         ids, counts = c4["decode"]()
         if comm is not None:
             return all_gather_ids_rccl(ids, counts, total, comm, ctx, gbufs)
+        if world > 1:
+            return all_gather_ids(ids.numpy(), counts.numpy(), total, dist, device)
         return all_gather_ids(ids.numpy(), counts.numpy(), total)       # single process: just the D2H copy of the ids
 
     for _ in range(2):
@@ -287,7 +308,7 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device):
     rec.update({"c4_utterances": total, "c4_utterances_per_gpu": args.per_gpu, "c4_seconds_per_utterance": 10,
                 "c4_ms_per_step": round(1e3 * wall / args.sv_steps, 3), "rtf_c4": round(wall / args.sv_steps / (total * 10), 8),
                 "audio_s_per_s": round(total * 10 * args.sv_steps / wall, 1), "c4_steps": args.sv_steps,
-                "c4_collective": "rccl all-gather of token ids via lele_hip_comm_allgather_i32" if comm else "none (single process)",
+                "c4_collective": "rccl all-gather of token ids via lele_hip_comm_allgather_i32" if comm else (comm_note or "none (single process)"),
                 "c4_gathered_ok": bool(agree), "c4_tokens": int(c4["logits"].shape[1]),
                 "plan_statements": len(c4["plan"]["statements"]), "plan_calls": sum(fn_count.values()),
                 "logits_finite": bool(np.isfinite(c4["logits"].numpy()[0]).all())})

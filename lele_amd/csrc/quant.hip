@@ -743,11 +743,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ QParams s_q[2][2];           // EM 2: the hidden layer's quantisation parameters of slices s0, s0 + 1
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3, hv = lane >> 5, l31 = lane & 31;
-    unsigned w = blockIdx.x;
+    // Work split.  Workgroup b runs on XCD b mod 8, and every XCD has its own L2: an XCD is given a contiguous range of ROW tiles
+    // (all column blocks of it), so that it pulls its eighth of A and one copy of the weights through the fabric -- 9 MB in total for
+    // the qkv product of a configs[3] shard, where a split by column blocks made every XCD read all of A (23 MB) -- and its 32
+    // workgroups share that range's (column block, row tile) units evenly, column block major.
     const unsigned G = gridDim.x;
-    if ((G & 7u) == 0) w = (w & 7u) * (G >> 3) + (w >> 3);  // an XCD's workgroups share a contiguous range of units (few column blocks)
-    int u = (int)((int64_t)w * g.units / G);
-    const int u1 = (int)((int64_t)(w + 1) * g.units / G);
+    const bool by_xcd = (G & 7u) == 0 && g.nrt >= 8;
+    const int xcd = by_xcd ? (int)(blockIdx.x & 7u) : 0, wg = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int nwg = by_xcd ? (int)(G >> 3) : (int)G;
+    const int rt_lo = by_xcd ? (int)((int64_t)xcd * g.nrt / 8) : 0, rt_hi = by_xcd ? (int)((int64_t)(xcd + 1) * g.nrt / 8) : g.nrt;
+    const int nx = rt_hi - rt_lo, units_x = nx * g.ncb;  // row tiles and units of this XCD's range
+    int u = (int)((int64_t)wg * units_x / nwg);
+    const int u1 = (int)((int64_t)(wg + 1) * units_x / nwg);
     if (u >= u1) return;
     int nstamp = 0;
     auto stamp = [&]() {
@@ -786,9 +793,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     auto chunk_of = [&](int uu, int& cb, int& rt0, int& cnt) {
-        cb = uu / g.nrt;
-        rt0 = uu - cb * g.nrt;
-        cnt = g.nrt - rt0;
+        cb = uu / nx;
+        const int t = uu - cb * nx;
+        rt0 = rt_lo + t;
+        cnt = nx - t;
         cnt = cnt < 4 ? cnt : 4;
         cnt = cnt < u1 - uu ? cnt : u1 - uu;
     };

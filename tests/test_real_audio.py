@@ -1,7 +1,9 @@
 """Real speech (the reference's fixtures/zh.wav, BASELINE configs[0] input): front-end parity on real audio and a
 Silero-shaped streaming chain -- STFT-as-conv1d -> magnitude -> conv blocks -> LSTM with state carried over 175 chunks
 of 512 samples (the loop of examples/silero/src/main.rs:151-228; assumed topology, synthetic weights) -- device vs oracle."""
+import json
 import os
+import time
 
 import numpy as np
 import pytest
@@ -108,11 +110,22 @@ def test_silero_shaped_streaming_chain_matches_oracle(ctx):
     w = _silero_like_weights(np.random.default_rng(11))
     hd = cd = ho = co = np.zeros((1, 1, 128), np.float32)
     worst = 0.0
+    t_oracle = 0.0
     for i in range(175):
         chunk = pcm[i * 512:(i + 1) * 512]
         pd, hd, cd = _chain(Dev, w, chunk, hd, cd)
+        t0 = time.perf_counter()
         po, ho, co = _chain(_OracleOps, w, chunk, ho, co)
+        t_oracle += time.perf_counter() - t0
         hd_n, cd_n = hd.numpy(), cd.numpy()
         worst = max(worst, float(np.abs(pd.numpy() - po).max()), float(np.abs(hd_n - ho).max()), float(np.abs(cd_n - co).max()))
         # keep the two recurrences independent: each carries its own state (no re-synchronisation)
     assert worst <= 1e-4, worst  # 175 dependent steps: the 1e-4 bar holds on the state itself
+    # BASELINE configs[0] as it literally reads -- the streamed VAD chain on one host core: the oracle's time for these 175 chunks
+    # (5.6 s of audio), recorded next to the parity result when a scratch directory for measurements exists
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump({"config": "configs[0]-shaped chain (tests/test_real_audio.py), oracle = C++ restatement of lele's x86 path, 1 thread",
+                   "chunks": 175, "audio_s": 5.6, "oracle_ms_per_chunk": round(1e3 * t_oracle / 175, 4),
+                   "oracle_rtf": round(t_oracle / 5.6, 6), "max_abs_diff_device_vs_oracle": worst},
+                  open(os.path.join(out, "c1_chain_oracle_times.json"), "w"))
