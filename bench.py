@@ -396,6 +396,8 @@ def run_rank(args):
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report n_gpus that is not the number of ranks running"
                          % (args.gpus, world))
+    if rank != 0:   # only rank 0 reports; whatever the libraries of the other ranks print to stdout (RCCL's banner) must not reach the caller
+        silence_stdout()
     if args.dry_run:  # launcher logic only (CPU tests): rendezvous over gloo, the fences and the MAX all-reduce, no GPU work
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -509,10 +511,36 @@ def run_rank(args):
                 cb.update(cpu_baseline_model(encoder_arrays(enc), feats))
             line["cpu_baseline"] = cb
             line["cpu_baseline_all_cores"] = cpu_baseline_frontend_all_cores(n)
-        print(json.dumps(line), flush=True)
+        emit_last_line(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def silence_stdout():
+    """everything the C libraries still hold in their stdio buffers (RCCL prints a version banner to stdout when a communicator
+    is created; it is flushed at exit) goes out NOW, and nothing written to stdout afterwards reaches the caller"""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+    os.close(devnull)
+
+
+def emit_last_line(text):
+    """the bench contract: rank 0 prints ONE JSON line -- make it the LAST thing on stdout"""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+    os.write(1, (text + "\n").encode())
+    silence_stdout()
 
 
 def free_port():

@@ -64,3 +64,29 @@ def test_native_runner_ranks_and_decode(ctx, tmp_path):
     # tokenizer.rs:50-61: the LAST of equal maxima wins
     last_max = out.shape[-1] - 1 - np.flip(out, -1).argmax(-1)
     assert rec["ids_checksum"] == int(last_max.sum())
+
+
+def test_bench_two_ranks_on_one_gpu_end_to_end():
+    """`bench.py --gpus 2` starts its own two ranks.  On a one-GPU box both share the device (LELE_BENCH_SHARE_GPU) and the process
+    group is gloo; RCCL refuses two ranks on one device, so the C ABI communicator cannot come up -- every rank must then agree
+    to move the ids through the process group instead, and the line must say so.  What this pins on real hardware: the N > 1
+    control flow (sharding by rank, fences, MAX over ranks, the transport agreement, the gather and its self-check) and that the
+    JSON line is the LAST line on stdout whatever the collective library prints."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LELE_BENCH_SHARE_GPU="1", LELE_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64",
+                        "--layers", "2", "--per-gpu", "4", "--sv-steps", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    line = json.loads(last)
+    assert line["n_gpus"] == 2 and line["config"]["batch_per_gpu"] == 64
+    sv = line["sensevoice"]
+    assert sv["c4_utterances"] == 8 and sv["c4_gathered_ok"] is True
+    assert "rccl" in sv["c4_collective"] or "torch.distributed" in sv["c4_collective"]
+    assert "rtf_model" not in line and "cpu_baseline" not in line          # N = 1 only
