@@ -96,14 +96,15 @@ class Ctx:
         self.device = device
         self._bufs = []
         self._graphs = []  # weak references: ctx_destroy destroys the graphs recorded on it, their wrappers must not do it again
+        self._comms = []   # likewise the communicators bound to this ctx's stream
 
     def close(self):
         if self._h:
-            for r in self._graphs:
+            for r in self._graphs + self._comms:
                 g = r()
                 if g is not None:
                     g.close()
-            self._graphs = []
+            self._graphs, self._comms = [], []
             for b in self._bufs:
                 b.close()
             lib().lele_hip_ctx_destroy(self._h)
@@ -201,7 +202,9 @@ class Comm:
     `Comm.from_file(ctx, path, rank, world)` is the torch-free rendezvous (rank 0 writes the unique id to `path`)."""
 
     def __init__(self, ctx, h, rank, world):
+        import weakref
         self.ctx, self._h, self.rank, self.world = ctx, h, rank, world
+        ctx._comms.append(weakref.ref(self))   # closed with the ctx (and so before the HIP runtime goes away at interpreter exit)
 
     @staticmethod
     def unique_id():

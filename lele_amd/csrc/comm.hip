@@ -12,6 +12,8 @@
 // through a file (rank 0 writes <path>.tmp and renames it; the others poll), which needs neither MPI nor torch.
 #include "common.h"
 
+#include <algorithm>
+
 #include <dlfcn.h>
 #include <errno.h>
 #include <time.h>
@@ -118,6 +120,7 @@ int lele_hip_comm_init(LeleCtx* ctx, const uint8_t* id128, int rank, int world, 
         delete c;
         return 1;
     }
+    ctx->comms.push_back(c);
     *out = c;
     return 0;
 }
@@ -194,6 +197,8 @@ int lele_hip_comm_barrier(LeleComm* c) {
 
 int lele_hip_comm_destroy(LeleComm* c) {
     if (!c) return 0;
+    auto& live = c->ctx->comms;  // a communicator outlives neither its context nor, at process exit, the HIP runtime: the context
+    live.erase(std::remove(live.begin(), live.end(), c), live.end());  // destroys the ones still registered before its stream
     (void)hipSetDevice(c->ctx->device);
     (void)hipStreamSynchronize(c->ctx->stream);
     if (c->comm) (void)c->api->CommDestroy(c->comm);

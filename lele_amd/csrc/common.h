@@ -107,6 +107,7 @@ struct LeleCtx {
     unsigned* deverr_host = nullptr;
     unsigned* deverr_dev = nullptr;
     std::vector<LeleGraph*> graphs;  // alive graphs recorded on this ctx (destroyed with it)
+    std::vector<struct LeleComm*> comms;  // communicators bound to this ctx's stream (destroyed with it, BEFORE the stream)
     // per-stage stopwatch of the quantised linear (bench.py's roofline block): events recorded between its kernels
     struct QProf {
         bool on = false;

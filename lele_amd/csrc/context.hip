@@ -190,6 +190,7 @@ int lele_hip_ctx_destroy(LeleCtx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     while (!c->graphs.empty()) (void)lele_hip_graph_destroy(c->graphs.back());  // graphs hold raw addresses of this ctx's memory
+    while (!c->comms.empty()) (void)lele_hip_comm_destroy(c->comms.back());     // communicators issue on this ctx's stream
     for (hipEvent_t e : c->qprof.ev) (void)hipEventDestroy(e);
     for (LeleBuf* t : c->tmp)
         if (t) (void)lele_hip_buf_destroy(t);

@@ -23,6 +23,13 @@ def orc():
 @pytest.fixture(scope="session")
 def ctx():
     """A LeleCtx on cuda:0.  GPU tests fail loudly (no skip, no fallback) if the HIP library cannot run."""
+    # Some tests import torch (its exporter), some bring up an RCCL communicator through the C library (dlopen("librccl.so")).
+    # torch ships its own librccl: whichever copy is loaded first must stay the only one in the process (two copies abort the
+    # interpreter at exit), so torch -- when present -- goes first, as it does in bench.py.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     import lele_amd
     return lele_amd.default_ctx(0)
 
