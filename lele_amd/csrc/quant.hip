@@ -1735,8 +1735,12 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
     if (b64 < 2 * (int64_t)ctx->num_cus) {
         // small problem (SenseVoice at M = 504): 32x32 tiles, K split over the four waves, operands straight from L2
         dim3 grid((unsigned)((n + 31) / 32), (unsigned)((rows + 31) / 32));
-        hipLaunchKernelGGL((gemm::igemm_small_kernel<IgemmEpi>), grid, dim3(256), 0, ctx->stream, aq, wt, rows, n, kp, b_stride,
-                           m_per_batch, epi);
+        if (kp <= 512)
+            hipLaunchKernelGGL((gemm::igemm_small_kernel<IgemmEpi, 4>), grid, dim3(256), 0, ctx->stream, aq, wt, rows, n, kp, b_stride,
+                               m_per_batch, epi);
+        else
+            hipLaunchKernelGGL((gemm::igemm_small_kernel<IgemmEpi, 16>), grid, dim3(256), 0, ctx->stream, aq, wt, rows, n, kp, b_stride,
+                               m_per_batch, epi);
     } else if (b128 >= 2 * ctx->num_cus) {
         // 128-byte K tiles (74 KB of LDS, 2 workgroups per CU): half as many barriers and twice the bytes in flight per K step.
         // Measured on the configs[3] shard shapes (profiles/r02_qlinear_variants.json): 29.3 / 30.0 / 41.1 us for qkv / ffn1 / ffn2
