@@ -23,6 +23,7 @@
 // Each workgroup also leaves the {min, max} of what it stored next to the result, one pair per (utterance, head, row block):
 // the output projection's dynamic quantisation needs no range pass (LeleBuf::rowstat kind 2, see quant.hip).
 #include "common.h"
+#include "lane_ops.h"
 #include "norm_core.h"
 
 #include <stdlib.h>
@@ -260,6 +261,189 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     }
 }
 
+// ---- small grids (a single utterance): 16 query rows per workgroup on the 16x16x4 MFMA ----------------------------------------
+// One 30 s utterance has 4 heads x 16 blocks of 32 rows = 64 workgroups: three quarters of the chip idle, and each workgroup's
+// chain of 64-cycle MFMAs is long.  Halving the block (128 workgroups) halves every phase.  The 16x16x4 instruction sums four k
+// values per step, so a dot product is accumulated in another order than in the 32-row kernel and in the batched GEMM -- inside
+// the 1e-4 bar of the f32 GEMM family (the sequence this replaces at this size, the K-split small-problem kernel, is likewise
+// "another order"); softmax is the same routine, bit for bit on equal inputs.
+// Lane l = (r = l & 15, g = l >> 4).  Scores: lane group g owns d in [32 g, 32 g + 32) for BOTH operands (so a step pairs equal
+// d); Q row r in 8 float4 registers, a key tile = 16 keys, fragments requested one tile ahead.  P V: lane group g owns the keys
+// [g tpad / 4, (g + 1) tpad / 4); a wave owns two 16-wide output tiles fed by one set of P fragments.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// NW = waves per workgroup (4; with 8 a wave owns one 16-wide output tile and a 32-lane group one softmax row)
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void attention16_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_sp[];  // S, then P: [16][tpad + 4]
+    __shared__ float s_mm[NW][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int pitch = a.tpad + kSPad;
+    const int qb = blockIdx.x % a.nqb, bh = blockIdx.x / a.nqb;
+    const int bi = bh % a.batch_inner, bo = bh / a.batch_inner;
+    const int i0 = qb * 16;
+    const float* qp = a.q + bo * a.q_so + bi * a.q_si;
+    const float* kp = a.k + bo * a.k_so + bi * a.k_si;
+    const float* vp = a.v + bo * a.v_so + bi * a.v_si;
+    float* op = a.o + bo * a.o_so + bi * a.o_si;
+    const int ntile = a.tpad / 16;
+
+    // ---- phase 1: S = Q K^T
+    float4 ka[8], kb[8];
+    int tnext = wave;
+    auto reqk = [&](float4 (&w)[8]) {
+        const int tc = tnext < ntile ? tnext : ntile - 1;  // clamped: a harmless repeated load instead of a branch
+        const int key = tc * 16 + r16;
+        const float* src = kp + (int64_t)(key < a.tk ? key : a.tk - 1) * a.k_sr + 32 * g;  // padded keys re-read the last key
+#pragma unroll
+        for (int c = 0; c < 8; ++c) w[c] = *reinterpret_cast<const float4*>(src + 4 * c);
+        tnext += NW;
+    };
+    reqk(ka);
+    float4 qf[8];
+    {
+        const int row = i0 + r16;
+        const float* src = qp + (int64_t)(row < a.tq ? row : a.tq - 1) * a.q_sr + 32 * g;  // padded rows re-read the last row; never stored
+#pragma unroll
+        for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const float4*>(src + 4 * c);
+    }
+    auto mmk = [&](const float4 (&w)[8], int t) {
+        f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[c].x, w[c].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[c].y, w[c].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[c].z, w[c].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[c].w, w[c].w, acc, 0, 0, 0);
+        }
+        // C layout of the 16x16 MFMA: column (key) = r16, row = 4 g + register
+        float* dst = s_sp + (4 * g) * pitch + t * 16 + r16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[r * pitch] = acc[r];
+    };
+    for (int t = wave; t < ntile; t += 2 * NW) {  // two tiles per trip: fragments of the next tile travel during the current one
+        reqk(kb);
+        __builtin_amdgcn_sched_barrier(0);
+        mmk(ka, t);
+        __builtin_amdgcn_sched_barrier(0);
+        reqk(ka);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + NW < ntile) mmk(kb, t + NW);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+
+    // ---- phase 2: row softmax, 2 NW 32-lane groups x 16 / (2 NW) rows.  P = 0 beyond the last key (those columns then add exact zeros)
+    {
+        const int gi = tid >> 5, l = tid & 31;
+        const float sc = a.scale ? a.scale[0] : 1.0f;
+        constexpr int RPG = 16 / (2 * NW);  // rows per group
+        float v[RPG][NT];
+#pragma unroll
+        for (int q = 0; q < RPG; ++q) {
+            const float* row = s_sp + (gi * RPG + q) * pitch;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const int j = 32 * c + l;
+                v[q][c] = row[j < a.tk ? j : a.tk - 1];
+                if (a.scale) v[q][c] = v[q][c] * sc;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RPG; ++q) softmax_row_reg<NT>(v[q], a.tk, l);
+#pragma unroll
+        for (int q = 0; q < RPG; ++q) {
+            float* row = s_sp + (gi * RPG + q) * pitch;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const int j = 32 * c + l;
+                if (j < a.tpad) row[j] = j < a.tk ? v[q][c] : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: O = P V.  Wave w owns output dims [32 w, 32 w + 32) as two 16-wide tiles; lane group g sums over its quarter of
+    // the keys: step c of a set pairs P[row r16][g kk + c] with V[g kk + c][32 w + 16 t + r16]
+    const int kk = a.tpad / 4;  // keys per lane group: a multiple of 16
+    const int kbase = g * kk;
+    constexpr int ND = 8 / NW;       // 16-wide output tiles per wave
+    const int d0 = 16 * ND * wave;    // first output dim of this wave
+    float va[ND][16], vb[ND][16];
+    int cq = 0;  // first step of the next set to request
+    auto reqv = [&](float (&w)[ND][16]) {
+        const int cc = cq < kk ? cq : kk - 16;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int key = kbase + cc + u;
+            const float* src = vp + (int64_t)(key < a.tk ? key : a.tk - 1) * a.v_sr + d0 + r16;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) w[d][u] = src[16 * d];
+        }
+        cq += 16;
+    };
+    const float* prow = s_sp + r16 * pitch + kbase;
+    f32x4v oacc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) oacc[d] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+    auto mmv = [&](const float (&w)[ND][16], int c0) {
+#pragma unroll
+        for (int u4 = 0; u4 < 4; ++u4) {
+            const float4 p = *reinterpret_cast<const float4*>(prow + c0 + 4 * u4);
+            const float pa[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int d = 0; d < ND; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[e], w[d][4 * u4 + e], oacc[d], 0, 0, 0);
+        }
+    };
+    reqv(va);
+    for (int c0 = 0; c0 < kk; c0 += 32) {
+        reqv(vb);
+        __builtin_amdgcn_sched_barrier(0);
+        mmv(va, c0);
+        __builtin_amdgcn_sched_barrier(0);
+        reqv(va);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c0 + 16 < kk) mmv(vb, c0 + 16);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = i0 + 4 * g + r;
+        if (row < a.tq) {
+            float* dst = op + (int64_t)row * a.o_sr + d0 + r16;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                const float val = oacc[d][r];
+                dst[16 * d] = val;
+                mn = val < mn ? val : mn;
+                mx = val > mx ? val : mx;
+            }
+        }
+    }
+    if (a.stat) {  // uniform: one pair per workgroup
+        mn = wave_allreduce64(mn, [](float cur, float x) { return x < cur ? x : cur; });
+        mx = wave_allreduce64(mx, [](float cur, float x) { return x > cur ? x : cur; });
+        if (lane == 0) {
+            s_mm[wave][0] = mn;
+            s_mm[wave][1] = mx;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < NW; ++w) {
+                mn = s_mm[w][0] < mn ? s_mm[w][0] : mn;
+                mx = s_mm[w][1] > mx ? s_mm[w][1] : mx;
+            }
+            float* dst = a.stat + ((int64_t)bo * (a.batch_inner * a.nqb) + bi * a.nqb + qb) * 2;
+            dst[0] = mn;
+            dst[1] = mx;
+        }
+    }
+}
+
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -320,7 +504,10 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
     // 32 x 171 rows 47.9 us with one tile against 54.2 us with two; 64 x 171 rows 92.6 against 73.8)
     const char* rt_env = getenv("LELE_HIP_ATTENTION_RT");
     const int rt = rt_env && *rt_env ? atoi(rt_env) : (fb * ((t_q + 63) / 64) >= 3 * (int64_t)ctx->num_cus ? 2 : 1);
-    const int qrows = rt == 2 ? 64 : 32;
+    // small grids (one utterance: 64 blocks of 32 rows for 256 CUs): 16 query rows per workgroup
+    const char* rows_env = getenv("LELE_HIP_ATTENTION_ROWS");
+    const bool rows16 = rows_env && *rows_env ? atoi(rows_env) == 16 : fb * ((t_q + 31) / 32) < (int64_t)ctx->num_cus / 2;
+    const int qrows = rows16 ? 16 : (rt == 2 ? 64 : 32);
     a.nqb = (int)((t_q + qrows - 1) / qrows);
     a.scale = (const float*)dsc;
     a.dbg = nullptr;
@@ -345,10 +532,14 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
     } while (0)
     // softmax registers per lane = key tiles exactly (tpad / 32, even): a 10 s utterance needs 6, not 8 -- the row softmax is a third
     // of the kernel's instructions (tools/attention_stamps.py) and every surplus register row is exponentials nobody reads
-#define LELE_ATTN_NT(NT_)                   \
-    do {                                    \
-        if (rt == 2) LELE_ATTN(NT_, 2);     \
-        else LELE_ATTN(NT_, 1);             \
+#define LELE_ATTN_NT(NT_)                                                                                      \
+    do {                                                                                                       \
+        if (rows16) {                                                                                          \
+            auto kern = attention16_kernel<NT_, 4>; /* eight waves measured no better: 24.5 against 24.1 us */ \
+            if (lds > 60 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)); \
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, a);                                     \
+        } else if (rt == 2) LELE_ATTN(NT_, 2);                                                                 \
+        else LELE_ATTN(NT_, 1);                                                                                \
     } while (0)
     switch (a.tpad / 64) {
         case 1: LELE_ATTN_NT(2); break;

@@ -529,8 +529,8 @@ inline TensorView attention_view(const TensorView& q, const Json& q_chain, const
         for (size_t i = 0; fused && i + 1 < r; ++i) fused = gq.strides[i] % 4 == 0;
         for (size_t i = 0; fused && i < r; ++i) fused = i == r - 2 || gk.strides[i] % 4 == 0;
         if (fused && out_perm) fused = (((*out_perm)[r - 1] + (int64_t)r) % (int64_t)r) == (int64_t)r - 1;
-        if (fused) {  // too few workgroups to fill the chip (a single utterance): the sequence's K-split GEMMs are faster
-            int64_t blocks = (gq.shape[r - 2] + 31) / 32;
+        if (fused) {  // fewer than 96 blocks of 16 query rows: the three-call sequence (the library itself picks 16- or 32-row blocks)
+            int64_t blocks = (gq.shape[r - 2] + 15) / 16;
             for (size_t i = 0; i + 2 < r; ++i) blocks *= gq.shape[i];
             const char* mb = getenv("LELE_HIP_ATTENTION_MIN_BLOCKS");
             fused = blocks >= (mb && *mb ? atoll(mb) : 96);

@@ -902,9 +902,9 @@ def attention_view(q, q_chain, k, k_chain, v, v_chain, scale, out_perm=None, out
              and qsh[:-2] == ksh[:-2] == vsh[:-2] and qsh[-1] == 128 and ksh[-2] == 128 and vsh[-1] == 128 and ksh[-1] == vsh[-2] <= 512
              and qst[-1] == 1 and kst[-2] == 1 and vst[-1] == 1 and all(s % 4 == 0 for s in qst[:-1] + kst[:-2] + kst[-1:]) and qoff % 4 == 0 and koff % 4 == 0
              and (out_perm is None or out_perm[-1] % len(out_perm) == len(out_perm) - 1))
-    # one workgroup per 32 query rows of a head: a single utterance (4 heads x 16 row blocks) leaves three quarters of the chip
-    # idle and the sequence's K-split GEMMs are faster there (measured: 7.35 vs 6.84 ms per 30 s forward)
-    if fused and int(np.prod(qsh[:-2], dtype=np.int64)) * -(-qsh[-2] // 32) < int(os.environ.get("LELE_HIP_ATTENTION_MIN_BLOCKS", "96")):
+    # the library runs one workgroup per 32 query rows of a head, per 16 rows when that would leave most of the chip idle (a single
+    # utterance); grids smaller still (fewer than 96 blocks of 16 rows) run the three-call sequence
+    if fused and int(np.prod(qsh[:-2], dtype=np.int64)) * -(-qsh[-2] // 16) < int(os.environ.get("LELE_HIP_ATTENTION_MIN_BLOCKS", "96")):
         fused = False
     if not fused:
         tmp = getattr(ctx, "_attn_tmp", None)

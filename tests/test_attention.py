@@ -39,7 +39,7 @@ def close(a, b, what, rtol=1e-4):
     assert not bad.any(), "%s: %d of %d elements outside %g (max abs diff %.3g)" % (what, int(bad.sum()), b.size, rtol, float(np.abs(a - b).max()))
 
 
-@pytest.mark.parametrize("rt", [1, 2])   # 32 or 64 query rows per workgroup (the library picks by grid size)
+@pytest.mark.parametrize("rt", [1, 2, 16])   # 32 or 64 query rows per workgroup, or 16 on the 16x16x4 MFMA (the library picks by grid size)
 @pytest.mark.parametrize("b,t", [(32, 171), (1, 504), (2, 33), (3, 64), (1, 512), (2, 100), (5, 1), (1, 8), (2, 65)])
 def test_attention_view_against_oracle_and_sequence(ctx, orc, b, t, rt):
     from lele_amd import kernels as K
@@ -48,7 +48,9 @@ def test_attention_view_against_oracle_and_sequence(ctx, orc, b, t, rt):
     qkv = (rng.standard_normal((b, t, 3 * H * DH)) * 1.5).astype(np.float32)
     scale = Weight(np.array([DH ** -0.5], np.float32))
     qd = ctx.buf().upload(qkv)
-    with _env(LELE_HIP_ATTENTION_MIN_BLOCKS=1, LELE_HIP_ATTENTION_RT=rt):   # the one-launch kernel whatever the grid size
+    env = dict(LELE_HIP_ATTENTION_MIN_BLOCKS=1, LELE_HIP_ATTENTION_RT=1, LELE_HIP_ATTENTION_ROWS=16) if rt == 16 else \
+        dict(LELE_HIP_ATTENTION_MIN_BLOCKS=1, LELE_HIP_ATTENTION_RT=rt, LELE_HIP_ATTENTION_ROWS=32)
+    with _env(**env):   # the one-launch kernel whatever the grid size
         got = K.attention_view(qd, QC, qd, KC, qd, VC, scale, [0, 2, 1, 3], [0, 0, H * DH], ctx=ctx)
     assert got.shape == (b, t, H * DH)
     got = got.numpy()
