@@ -288,6 +288,11 @@ __global__ __launch_bounds__(64 * NW) void attention16_kernel(AttnArgs a) {
     const float* vp = a.v + bo * a.v_so + bi * a.v_si;
     float* op = a.o + bo * a.o_so + bi * a.o_si;
     const int ntile = a.tpad / 16;
+    int nstamp = 0;
+    auto stamp = [&]() {
+        if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 8 + nstamp++] = (long long)clock64();
+    };
+    stamp();
 
     // ---- phase 1: S = Q K^T
     float4 ka[8], kb[8];
@@ -332,7 +337,9 @@ __global__ __launch_bounds__(64 * NW) void attention16_kernel(AttnArgs a) {
         if (t + NW < ntile) mmk(kb, t + NW);
         __builtin_amdgcn_sched_barrier(0);
     }
+    stamp();
     __syncthreads();
+    stamp();
 
     // ---- phase 2: row softmax, 2 NW 32-lane groups x 16 / (2 NW) rows.  P = 0 beyond the last key (those columns then add exact zeros)
     {
@@ -362,7 +369,9 @@ __global__ __launch_bounds__(64 * NW) void attention16_kernel(AttnArgs a) {
             }
         }
     }
+    stamp();
     __syncthreads();
+    stamp();
 
     // ---- phase 3: O = P V.  Wave w owns output dims [32 w, 32 w + 32) as two 16-wide tiles; lane group g sums over its quarter of
     // the keys: step c of a set pairs P[row r16][g kk + c] with V[g kk + c][32 w + 16 t + r16]
@@ -409,6 +418,7 @@ __global__ __launch_bounds__(64 * NW) void attention16_kernel(AttnArgs a) {
         if (c0 + 16 < kk) mmv(vb, c0 + 16);
         __builtin_amdgcn_sched_barrier(0);
     }
+    stamp();
     float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -424,6 +434,7 @@ __global__ __launch_bounds__(64 * NW) void attention16_kernel(AttnArgs a) {
             }
         }
     }
+    stamp();
     if (a.stat) {  // uniform: one pair per workgroup
         mn = wave_allreduce64(mn, [](float cur, float x) { return x < cur ? x : cur; });
         mx = wave_allreduce64(mx, [](float cur, float x) { return x > cur ? x : cur; });

@@ -30,7 +30,8 @@ def main():
         for _ in range(3):
             call()
         ctx.sync()
-        nwg = b * H * ((t + 31) // 32)
+        rows = int(os.environ.get("LELE_HIP_ATTENTION_ROWS", "0")) or (16 if b * H * ((t + 31) // 32) < 128 else 32)
+        nwg = b * H * ((t + rows - 1) // rows)
         dbg = torch.zeros((nwg, 8), dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         os.environ["LELE_HIP_ATTN_STAMPS"] = hex(dbg.data_ptr())
