@@ -212,7 +212,8 @@ def test_fused_ffn_never_stores_the_hidden_layer_and_keeps_every_bit(ctx):
                 Weight((rng.random(n) * 0.01 + 0.002).astype(np.float32)), Weight(np.array([128.0], np.float32)),
                 Weight(rng.standard_normal(n).astype(np.float32) * 0.1))
     for b, m, k1, n1, n2, relu2 in ((32, 171, 512, 2048, 512, False), (16, 300, 200, 2048, 72, True), (1, 4800, 512, 2048, 512, False),
-                                    (2, 33, 64, 128, 32, False), (1, 504, 512, 2048, 512, False), (40, 129, 96, 2176, 64, False)):
+                                    (2, 33, 64, 128, 32, False), (1, 504, 512, 2048, 512, False), (40, 129, 96, 2176, 64, False),
+                                    (70, 128, 500, 1024, 72, False), (5, 2001, 512, 640, 36, True)):
         x = (rng.standard_normal((b, m, k1)) * rng.uniform(0.3, 3.0, (b, 1, 1))).astype(np.float32)
         w1, w2 = lin(k1, n1), lin(n1, n2)
         r1, r2 = rng.standard_normal((b, m, n2)).astype(np.float32), rng.standard_normal((b, m, n2)).astype(np.float32)
@@ -240,6 +241,34 @@ def test_fused_ffn_never_stores_the_hidden_layer_and_keeps_every_bit(ctx):
     assert not hid.any()
     want = O.fused_quantized_linear(hid, w2[0].arr, w2[1].arr, w2[2].arr, w2[3].arr, False)
     assert np.array_equal(K.fused_ffn_quantized(xn, *w1, *w2, False, ctx=ctx).numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,m,k,n,relu,bias,scalar_ws", [
+    (1, 8300, 512, 260, False, True, False),     # one slice, rows not a multiple of 32, a partial last column block (n % 128 = 4)
+    (9, 1000, 500, 384, True, True, False),      # K padded to 512 with zero bytes; slices straddle chunks at every offset
+    (70, 128, 512, 256, False, False, False),    # slices of exactly one chunk of rows; no bias
+    (3, 3333, 512, 1536, False, True, True),     # one weight scale for all columns; 9999 rows
+    (64, 171, 512, 132, True, True, False),      # the configs[3] row structure with a narrow, ragged result
+])
+def test_persistent_whole_k_gemm_bit_exact_on_edge_shapes(ctx, b, m, k, n, relu, bias, scalar_ws):
+    """igemm_wholek_kernel serves every quantised linear with K padded to 512 bytes and enough (row tile, column block) units:
+    bit-exact with the oracle on shapes chosen for its edges -- chunks that end inside a row tile range, column blocks that end
+    inside a 4-column group, slices of every alignment, rows % 32 != 0 -- and identical to the tiled kernel's result"""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    from oracle import pyoracle as O
+    rng = np.random.default_rng(b * 7 + m + n)
+    x = (rng.standard_normal((b, m, k)) * rng.uniform(0.2, 4.0, (b, 1, 1))).astype(np.float32)
+    w = Weight(np.clip(np.round(128 + 40 * rng.standard_normal((k, n))), 0, 255).astype(np.float32))
+    ws = Weight((np.full(1, 0.0071) if scalar_ws else rng.random(n) * 0.01 + 0.002).astype(np.float32))
+    wz = Weight(np.array([121.0], np.float32))          # a weight zero point other than 128: the row-sum term is live
+    bs = Weight(rng.standard_normal(n).astype(np.float32)) if bias else None
+    want = O.fused_quantized_linear(x, w.arr, ws.arr, wz.arr, bs.arr if bias else None, relu)
+    got = K.fused_quantized_linear(x, w, ws, wz, bs, relu, ctx=ctx).numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+    with _env(LELE_HIP_IGEMM_WHOLEK=0):
+        assert np.array_equal(K.fused_quantized_linear(x, w, ws, wz, bs, relu, ctx=ctx).numpy(), want)
 
 
 @pytest.mark.gpu
