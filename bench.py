@@ -349,12 +349,26 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device):
             K.fused_quantized_linear(xn, p.w, p.scale, p.zero, p.bias, True, out=ob, ctx=ctx)
         r_ms, q_ms, g_ms, calls = ctx.quant_profile_read()
         ctx.quant_set_profiling(False)
+        # the op as it runs in the model: 20 calls recorded into a hipGraph, the replays timed with HIP events on the ctx stream (the
+        # per-stage events above put a host-visible boundary between the stages; their sum is the larger, staged figure)
+        ctx.sync()
+        ctx.graph_begin()
+        for _ in range(20):
+            K.fused_quantized_linear(xn, p.w, p.scale, p.zero, p.bias, True, out=ob, ctx=ctx)
+        gq = ctx.graph_end()
+        gq.launch()
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(10):
+            gq.launch()
+        op_ms = ctx.timer_stop() / 200.0
+        gq.close()
         m_rows, kk, nn = (hi - lo) * c4["logits"].shape[1], 512, 2048
         byts = 4 * m_rows * kk + kk * nn + 8 * nn + 4 * m_rows * nn     # f32 in, u8 weights, scale+bias, f32 out
         ops = 2 * m_rows * kk * nn
-        op_ms = r_ms + q_ms + g_ms
         rec["qlinear"] = {"shape": "[%d x %d] x [%d x %d] (ffn1 of one configs[3] shard, input = LayerNorm output)" % (m_rows, kk, kk, nn),
-                          "range_ms": round(r_ms, 5), "quantise_ms": round(q_ms, 5), "gemm_ms": round(g_ms, 5), "op_ms": round(op_ms, 5),
+                          "range_ms": round(r_ms, 5), "quantise_ms": round(q_ms, 5), "gemm_ms": round(g_ms, 5),
+                          "staged_sum_ms": round(r_ms + q_ms + g_ms, 5), "op_ms": round(op_ms, 5),
                           "calls": calls, "algorithmic_bytes": byts, "int_ops": ops,
                           "hbm_gbs": round(byts / (op_ms * 1e-3) / 1e9, 1) if op_ms > 0 else None,
                           "tops": round(ops / (op_ms * 1e-3) / 1e12, 1) if op_ms > 0 else None}
