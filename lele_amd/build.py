@@ -11,11 +11,14 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "_build")
-LIB = os.path.join(HERE, "liblele_hip.so")
+# LELE_HIP_LAB=1 builds the developer's library instead: the same sources with -DLELE_HIP_LAB (in-kernel cycle stamps, ablation
+# switches, experimental kernels), as liblele_hip_lab.so -- never loaded unless LELE_HIP_LAB=1 is set at import (lele_amd/_lib.py)
+LAB = os.environ.get("LELE_HIP_LAB", "0") not in ("", "0")
+OBJ = os.path.join(HERE, "_build_lab" if LAB else "_build")
+LIB = os.path.join(HERE, "liblele_hip_lab.so" if LAB else "liblele_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=" + ARCH, "-Wall",
-         "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-result"]
+         "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-result"] + (["-DLELE_HIP_LAB=1"] if LAB else [])
 
 
 def hipcc():
@@ -61,7 +64,8 @@ def build(force=False, verbose=False):
                 print(out)
     if jobs or force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-ldl"])
-    build_runner(force, run)
+    if not LAB:
+        build_runner(force, run)
     return LIB
 
 

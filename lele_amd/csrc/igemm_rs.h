@@ -1,0 +1,649 @@
+// igemm_rs.h -- register-stationary i8 GEMMs for the quantised linears of a batch of utterances (included by quant.hip).
+//
+// Same arithmetic as igemm_kernel (exact i32 products on v_mfma_i32_32x32x32_i8, IgemmEpi's f32 epilogue:
+// /root/reference/src/kernels/avx/quantization.rs:225-417, 1396-1428), another schedule.  The K = 512 / 2048 products of a
+// SenseVoice-shaped layer over 5472 rows are short and wide; a tiled kernel spends its life in barriers and global -> VGPR -> LDS
+// round trips (round 2: 8-10 % MFMA busy, 17-20 us per launch for 2-6 us of bytes).  Here there is NO LDS staging and NO barrier
+// on the K = 512 path:
+//
+//   * both operands live in HBM in MFMA FRAGMENT ORDER: block (tile, k-step) = 1 KiB, lane l's 16 bytes at offset 16 l hold
+//     row / column 32 tile + (l & 31), k = 32 step + 16 (l >> 5) + [0, 16) -- every operand load of a wave is ONE fully
+//     coalesced 1 KiB dwordx4 instruction straight into the registers the MFMA reads (weights: wpack_frag_kernel, once;
+//     activations: qrows_frag_kernel, which quantises into that order; the hidden layer of a feed-forward block: the epilogue of
+//     the pass that produces it, whose 32 x 32 result tile IS one k-step block of the next product);
+//   * a wave keeps the weight fragments of ITS 32 columns for the whole K extent in 64 VGPRs and streams 32-row activation tiles
+//     past them, double-buffered in registers (the loads of tile t + 1 are in flight during the 16 MFMAs and the stores of tile t);
+//     waves never wait for each other, the eight waves of a workgroup (eight column tiles, same rows) share the activation
+//     tiles through the vector L1;
+//   * the weights are the MFMA's FIRST operand, so a lane owns ONE result row and 4 x 4 consecutive columns of it: 16-byte
+//     stores, one set of row terms per lane; the column terms of the wave's 32 columns sit in a wave-private LDS strip;
+//   * K = 2048 (second feed-forward product): the four waves of a workgroup split K, partial tiles meet in LDS (one barrier per
+//     tile, double-buffered), row sums come from v_dot4 on the fragments the wave loads anyway.
+#pragma once
+
+namespace {
+
+struct RsArgs {
+    const int8_t* af;  // activations, fragment-major [nrt][ks][1024]
+    const int8_t* wf;  // weights, fragment-major [nct][ks][1024]
+    unsigned rows;
+    int n;
+    int nrt, nct;  // 32-row tiles, 32-column tiles
+    int ncb, nrr;  // K = 512: column blocks of 8 tiles and row ranges (grid = ncb * nrr); K split: grid = nct * nrr
+    int8_t* hid;   // EM 2: the result as fragment-major i8 [nrt][n / 32][1024]
+#ifdef LELE_HIP_LAB
+    long long* dbg;  // lab build: [grid][9][32] wall-clock stamps (100 MHz) of every wave (wave 8 = the loader), or NULL
+    int ablate;      // lab build (results wrong): 1 no products, 2 no epilogue, 4 no fragment reads (products on stale registers)
+#endif
+};
+#ifdef LELE_HIP_LAB
+#define RS_STAMP(who) do { if (g.dbg && lane == 0 && nstamp < 32 && wave < 9) g.dbg[((size_t)blockIdx.x * 9 + wave) * 32 + nstamp++] = (long long)wall_clock64(); } while (0)
+#else
+#define RS_STAMP(who) do { } while (0)
+#endif
+
+// ------------------------------------------------------------------------------------------ rows -> fragment-major i8
+// f32 rows [rows][k] -> q - 128 as i8 in fragment order [nrt][kp / 32][1024] (+ exact i32 row sums), quantised with the range
+// of the row's batch slice exactly as qrows_kernel<0> does (SIMD body rint(fma(x, 1/scale, zp)), scalar tail round(x*inv + zp)).
+// A wave owns 256 chunks of 16 elements = 8 rows (kp = 512) or 2 rows (kp = 2048); all its row data is requested before the
+// range partials of its slice(s) are reduced.  Rows beyond `rows` of the last tile and bytes beyond k are written as 0.
+template <int CPR /* 16-element chunks per row: kp / 16 */, int IT /* trips of 64 chunks per wave */>
+__global__ __launch_bounds__(256) void qrows_frag_kernel(const float* __restrict__ x, unsigned rows, int k, int m,
+                                                         QParams* __restrict__ prm, int8_t* __restrict__ af,
+                                                         int* __restrict__ row_sums, const float* __restrict__ partial, int nblk,
+                                                         unsigned* __restrict__ zero_slice) {
+    static_assert((CPR == 32 && IT == 1) || (CPR == 128 && IT == 4), "kp = 512: two rows per wave; kp = 2048: two rows per wave");
+    constexpr int KS = CPR / 2;
+    const int lane = threadIdx.x & 63;
+    const unsigned gw = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const unsigned c0 = gw * (64u * IT);                 // first chunk of this wave (row-major over [rows padded][CPR])
+    const unsigned row_first = c0 / CPR, row_last = (c0 + 64u * IT - 1u) / CPR;
+    const bool vec_ok = (k & 3) == 0 && (((uintptr_t)x & 15) == 0);
+    const int simd_k = k & ~7;
+    float4 v[IT][4];
+    unsigned rowi[IT], ci[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const unsigned ch = c0 + 64u * i + lane;
+        rowi[i] = ch / CPR;
+        ci[i] = ch % CPR;
+        const unsigned r = rowi[i] < rows ? rowi[i] : rows - 1u;
+        const float* src = x + (size_t)r * k + 16u * ci[i];
+        if (vec_ok && (int)(16u * ci[i]) + 16 <= k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = *reinterpret_cast<const float4*>(src + 4 * e);
+        } else {
+            float t[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int kk = (int)(16u * ci[i]) + e;
+                t[e] = x[(size_t)r * k + (kk < k ? kk : k - 1)];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = make_float4(t[4 * e], t[4 * e + 1], t[4 * e + 2], t[4 * e + 3]);
+        }
+    }
+    if (row_first >= rows) {  // a wave of padding rows only
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const size_t blk = (size_t)(rowi[i] >> 5) * KS + (ci[i] >> 1);
+            *reinterpret_cast<v4i*>(af + (blk * 64 + (rowi[i] & 31u) + 32u * (ci[i] & 1u)) * 16) = v4i{0, 0, 0, 0};
+        }
+        return;
+    }
+    const unsigned mu = (unsigned)m;
+    const unsigned last_valid = row_last < rows ? row_last : rows - 1u;
+    const unsigned s_lo = row_first / mu, s_hi = last_valid / mu;
+    unsigned pk[IT][4];
+    int sum[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        sum[i] = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk[i][e] = 0u;
+    }
+    for (unsigned s = s_lo; s <= s_hi; ++s) {  // wave-uniform: the slices this wave's rows belong to (one or two in practice)
+        QParams q;
+        if (partial) {
+            float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+            const float2* pp = reinterpret_cast<const float2*>(partial) + (size_t)s * nblk;
+            for (int i0 = 0; i0 < nblk; i0 += 256) {  // 4 pairs per lane in flight per trip (clamped: a repeated pair changes nothing)
+                float2 w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = i0 + lane + 64 * u;
+                    w[u] = pp[idx < nblk ? idx : nblk - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    mn = w[u].x < mn ? w[u].x : mn;
+                    mx = w[u].y > mx ? w[u].y : mx;
+                }
+            }
+            mn = wave_allreduce64(mn, [](float cur, float a) { return a < cur ? a : cur; });
+            mx = wave_allreduce64(mx, [](float cur, float a) { return a > cur ? a : cur; });
+            q = make_qparams(mn, mx);
+            // the wave that holds the slice's first row publishes its parameters (every row lies in exactly one wave)
+            if (lane == 0 && s * mu >= row_first && s * mu <= row_last) {
+                prm[s] = q;
+                if (zero_slice) zero_slice[s] = 0u;
+            }
+        } else {
+            q = prm[s];
+            if (zero_slice && lane == 0 && s * mu >= row_first && s * mu <= row_last) zero_slice[s] = 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            if (rowi[i] >= rows || rowi[i] / mu != s) continue;
+            const int kb = (int)(16u * ci[i]);
+            if (kb + 16 <= simd_k) {  // the whole chunk inside the SIMD body
+                unsigned us = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned p = 0u;
+                    p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(v[i][e].x, q.inv_scale, q.zp)), 0, p);
+                    p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(v[i][e].y, q.inv_scale, q.zp)), 1, p);
+                    p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(v[i][e].z, q.inv_scale, q.zp)), 2, p);
+                    p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(v[i][e].w, q.inv_scale, q.zp)), 3, p);
+                    us = __builtin_amdgcn_sad_u8(p, 0u, us);
+                    pk[i][e] = p ^ 0x80808080u;
+                }
+                sum[i] = (int)us - 128 * 16;
+            } else {
+                const float xv[16] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w,
+                                      v[i][2].x, v[i][2].y, v[i][2].z, v[i][2].w, v[i][3].x, v[i][3].y, v[i][3].z, v[i][3].w};
+                int sacc = 0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kk = kb + e;
+                    int val = 0;
+                    if (kk < k) {
+                        val = (int)quant_one(xv[e], q, kk < simd_k) - 128;
+                        sacc += val;
+                    }
+                    pk[i][e >> 2] |= (unsigned)(val & 0xff) << (8 * (e & 3));
+                }
+                sum[i] = sacc;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const size_t blk = (size_t)(rowi[i] >> 5) * KS + (ci[i] >> 1);
+        *reinterpret_cast<v4i*>(af + (blk * 64 + (rowi[i] & 31u) + 32u * (ci[i] & 1u)) * 16) =
+            v4i{(int)pk[i][0], (int)pk[i][1], (int)pk[i][2], (int)pk[i][3]};
+    }
+    if (!row_sums) return;
+    auto addi = [](float a, float b) { return __int_as_float(__float_as_int(a) + __float_as_int(b)); };
+    if constexpr (CPR == 32) {  // a row = the 32 chunks of one half wave of one trip
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int tot = __float_as_int(group_allreduce32(__int_as_float(sum[i]), addi));
+            if ((lane & 31) == 0 && rowi[i] < rows) row_sums[rowi[i]] = tot;
+        }
+    } else {  // a row = the 128 chunks of two consecutive trips
+#pragma unroll
+        for (int i = 0; i < IT; i += 2) {
+            const int tot = wave_sum_i32(sum[i] + sum[i + 1]);
+            if (lane == 0 && rowi[i] < rows) row_sums[rowi[i]] = tot;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ shared pieces
+__device__ __forceinline__ unsigned rs_logical_block() {  // workgroup b runs on XCD b % 8: give every XCD a contiguous range
+    const unsigned G = gridDim.x, b = blockIdx.x, xcd = b & 7u, base = G >> 3, rem = G & 7u;
+    return xcd * base + (xcd < rem ? xcd : rem) + (b >> 3);
+}
+
+struct RsRow {  // what the epilogue needs to know about a lane's row of the tile in flight
+    int rowsum;
+    float scale;
+    int zp_i;
+    unsigned slice;
+    unsigned smax;  // EM 2: bits of the hidden layer's maximum over the row's slice
+};
+
+// f32 value of one result element: IgemmEpi::value24 with the row terms in registers
+__device__ __forceinline__ float rs_value(int acc, int rterm, int ca, int colsum, float dsws, float bias, bool has_ws, bool has_bias,
+                                          int relu) {
+    const int total = acc + rterm + __mul24(ca, colsum);
+    float vf = (float)total;  // _mm256_cvtepi32_ps
+    if (has_ws) vf = vf * dsws;
+    if (has_bias) vf = vf + bias;
+    if (relu) vf = vf > 0.0f ? vf : 0.0f;
+    return vf;
+}
+
+// ------------------------------------------------------------------------------------------ K = 512: weights in registers, activations through an LDS ring
+// EM 0: f32 result (+ up to two residual operands, + optional {min, max} per (row tile, column tile) for a single-slice consumer)
+// EM 1: only the per-slice maximum of the ReLU result (atomic max on the bits), EM 2: the result quantised with that range, written
+//       as the fragment-major i8 operand of the next product (see lele_hip_fused_ffn_quantized)
+//
+// Ten waves: eight CONSUMERS, each with the weight fragments of its own 32 columns for the whole K extent in 64 VGPRs, and two
+// LOADERS that do nothing but direct-to-LDS loads (global_load_lds_dwordx4: a fragment block is 1 KiB of consecutive lanes, which
+// is exactly the lane-linear image that instruction writes) of the workgroup's 32-row activation tiles into a ring of RS_NS slots.
+// What the CU's load path delivers is the bound of these products (measured: ~21 TB/s chip-wide = 40 B/clk/CU whether the lines
+// are shared or private, tools/scratch/l2bw.hip), so every activation byte crosses it ONCE per workgroup instead of once per wave,
+// and it is requested up to four tiles ahead of its use.  The loader's vmcnt counter sees only its own 16 loads per tile, so
+// "tile i has landed" is an exact counted wait (the tiles issued after it stay in flight); one s_barrier per tile hands tile i to
+// the consumers and the slot of tile i - 1 back to the loader.  Consumers never touch a counter by hand: their loads (weights
+// once, row terms, residuals) and stores are the compiler's.
+constexpr int RS_NS = 5, RS_AHEAD = 3, RS_TILE = 16 * 1024, RS_SLOT = RS_TILE + 4 * 256;  // a slot: the tile's 16 fragment blocks + its row terms
+constexpr int RS_LDS = RS_NS * RS_SLOT + 3 * 8 * 32 * 4 + 16;        // ring + column strips + EM 1 maxima
+
+// one direct-to-LDS load of 16 bytes per lane: LDS address = lds_dst (wave-uniform byte address) + 16 * lane.  Inline asm: the
+// compiler's own counter bookkeeping must not see it (it would drain the ring at every barrier)
+__device__ __forceinline__ void rs_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void rs_dma4(const void* gsrc, unsigned lds_dst) {  // 4 bytes per lane: LDS address = lds_dst + 4 * lane
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void rs_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+__device__ __forceinline__ void rs_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+template <int EM, int NRES, bool RELU>
+__global__ __launch_bounds__(640) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
+    constexpr int KS = 16;
+    extern __shared__ __attribute__((aligned(16))) char rs_lds[];
+    char* const ring = rs_lds;
+    int* const s_colsum = reinterpret_cast<int*>(rs_lds + RS_NS * RS_SLOT);  // [8][32] each
+    float* const s_ws = reinterpret_cast<float*>(s_colsum + 256);
+    float* const s_bias = s_ws + 256;
+    unsigned* const s_mx = reinterpret_cast<unsigned*>(s_bias + 256);  // [4]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hv = lane >> 5, l31 = lane & 31;
+    const unsigned L = rs_logical_block();
+    const int rr = (int)(L / (unsigned)g.ncb), cb = (int)(L - (unsigned)rr * (unsigned)g.ncb);
+    const int t0 = (int)((unsigned)rr * (unsigned)g.nrt / (unsigned)g.nrr), t1 = (int)((unsigned)(rr + 1) * (unsigned)g.nrt / (unsigned)g.nrr);
+    if (t0 >= t1) return;  // uniform over the workgroup
+    const int nt = t1 - t0;
+    if (EM == 1) {  // the workgroup's slice maxima meet here before they go to memory
+        if (threadIdx.x < 4) s_mx[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    if (wave >= 8) {
+        // ---------------------------------------------------------------- the two loaders
+        // One wave issues a 1 KiB direct-to-LDS load every ~45 ns (measured; MI355X_MICROARCH.md's "ldsdma-fill" row: ~25 GB/s per
+        // CU and loader wave), i.e. 0.8 us per tile -- as long as a consumer's whole tile.  So two waves split a tile's blocks
+        // (wave 8: k-steps 0-7 and the row terms; wave 9: k-steps 8-15), and a tile is ISSUED before the loader waits for an
+        // older one and goes to the barrier: with five slots the slot of tile i + 3 was last read before barrier i - 1.
+        const int half = wave - 8;
+        const unsigned ring_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring;
+        constexpr int NTERM = EM == 2 ? 4 : 3, HS = KS / 2;
+        const unsigned rows = g.rows, mu = (unsigned)epi.m, nslices = rows / mu;
+        auto issue = [&](int i) {
+            const char* src = reinterpret_cast<const char*>(g.af) + (size_t)(t0 + i) * (KS * 1024) + half * (HS * 1024) + lane * 16;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(ring_base + (unsigned)(i % RS_NS) * RS_SLOT);
+#pragma unroll
+            for (int s = 0; s < HS; ++s) rs_dma16(src + s * 1024, dst + (half * HS + s) * 1024);
+            if (half == 0) {
+                // the tile's row terms (both half waves fetch the same 32 rows): row sum, dynamic scale, zero point (, slice maximum)
+                unsigned row = (unsigned)(t0 + i) * 32u + (unsigned)(lane & 31);
+                row = row < rows ? row : rows - 1u;
+                const unsigned sl = rows == mu ? 0u : row / mu;
+                rs_dma4(epi.row_sums + row, dst + RS_TILE);
+                rs_dma4(&epi.prm[sl].scale, dst + RS_TILE + 256);
+                rs_dma4(&epi.prm[sl].zp_i, dst + RS_TILE + 512);
+                if (EM == 2) rs_dma4(epi.slice_max + (sl < nslices ? sl : nslices - 1u), dst + RS_TILE + 768);
+            }
+        };
+        // "tile i has landed": the (up to RS_AHEAD) tiles issued after it may stay in flight -- an exact counted wait, this
+        // wave's vmcnt counter sees nothing but its own PER loads per tile
+        auto wait_for = [&](int younger, auto per_c) {
+            constexpr int PER = decltype(per_c)::value;
+            static_assert(RS_AHEAD == 3 && 3 * PER <= 63, "the wave's vmcnt counter has six bits");
+            if (younger >= 3) rs_wait_vm<3 * PER>();
+            else if (younger == 2) rs_wait_vm<2 * PER>();
+            else if (younger == 1) rs_wait_vm<PER>();
+            else rs_wait_vm<0>();
+        };
+        int nstamp = 0;
+        RS_STAMP(1);
+        const int pre = nt < RS_AHEAD ? nt : RS_AHEAD;
+        for (int i = 0; i < pre; ++i) issue(i);
+        RS_STAMP(1);
+        for (int i = 0; i < nt; ++i) {
+            if (i + RS_AHEAD < nt) issue(i + RS_AHEAD);
+            const int younger = nt - 1 - i < RS_AHEAD ? nt - 1 - i : RS_AHEAD;
+            if (half == 0) wait_for(younger, std::integral_constant<int, HS + NTERM>());
+            else wait_for(younger, std::integral_constant<int, HS>());
+            RS_STAMP(1);   // [2 + 2 i] this wave's part of tile i landed
+            rs_barrier();  // tile i is in LDS for everybody
+            RS_STAMP(1);   // [3 + 2 i] the consumers arrived
+        }
+        if (EM == 1) __syncthreads();
+        return;
+    }
+    // -------------------------------------------------------------------- a consumer
+    const int ct = cb * 8 + wave;
+    if (ct >= g.nct) {  // a partial last column block: the wave only keeps the barriers company
+        for (int i = 0; i < nt; ++i) rs_barrier();
+        if (EM == 1) __syncthreads();
+        return;
+    }
+    int nstamp = 0;
+    RS_STAMP(0);   // [0] entry
+#ifdef LELE_HIP_LAB
+    const long long cyc0 = clock64();
+#endif
+    const int n = g.n;
+    const unsigned rows = g.rows, mu = (unsigned)epi.m;
+    const bool single = rows == mu;
+    v4i bf[KS];
+    {
+        const v4i* wp = reinterpret_cast<const v4i*>(g.wf) + (size_t)ct * KS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bf[s] = wp[s * 64];
+    }
+    // the column terms of the lane's 16 columns (ct * 32 + 8 g + 4 hv + e) stay in registers: 48 of them, and no LDS round trip
+    // in front of every column group of every tile
+    int colsum[16];
+    float wsc[16], biasc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        int c = ct * 32 + 8 * (q >> 2) + 4 * hv + (q & 3);
+        c = c < n ? c : n - 1;  // clamped: loads stay unconditional, out-of-range columns are never stored
+        colsum[q] = epi.col_sums[c];
+        wsc[q] = epi.wscale_len <= 1 ? epi.wscale[0] : epi.wscale[c];
+        biasc[q] = epi.bias ? epi.bias[c] : -0.0f;  // x + (-0.0) == x for every x, the sign of zero included
+    }
+    const int cbz = 128 - epi.zp_b;
+    // results leave through buffer stores: a lane that has nothing to store points beyond the buffer and the hardware drops
+    // it -- no branch in the epilogue, so the next tile's products and this tile's epilogue are ONE basic block to the scheduler
+    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(EM == 0 ? (void*)epi.out : (void*)epi.q_prm,
+                                                            0, EM == 0 ? (int)(rows * (unsigned)n * 4u) : (int)((rows / mu) * 16u), 0x00020000);
+    // EM 1: running maxima of the (up to four) slices the workgroup's row range touches; anything further away goes out at once
+    const unsigned sbase = single ? 0u : ((unsigned)t0 * 32u) / mu;
+    float mx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    // the products of tile i out of its ring slot, and the row terms the loader put behind it (dynamic quantisation is the only
+    // caller: epi.prm is never NULL here)
+    auto products = [&](int i, v16i& acc, RsRow& r) {
+        const char* const slot = ring + (i % RS_NS) * RS_SLOT;
+        const v4i* ap = reinterpret_cast<const v4i*>(slot) + lane;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0;
+#ifdef LELE_HIP_LAB
+        if (g.ablate & 1) {
+        } else if (g.ablate & 4) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[s], bf[(s + 1) & 15], acc, 0, 0, 0);
+        } else
+#endif
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[s], ap[s * 64], acc, 0, 0, 0);
+            if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four fragments read ahead: 16 registers, not 64
+        }
+        r.rowsum = reinterpret_cast<const int*>(slot + RS_TILE)[l31];
+        r.scale = reinterpret_cast<const float*>(slot + RS_TILE + 256)[l31];
+        r.zp_i = reinterpret_cast<const int*>(slot + RS_TILE + 512)[l31];
+        r.smax = EM == 2 ? reinterpret_cast<const unsigned*>(slot + RS_TILE + 768)[l31] : 0u;
+    };
+    auto epilogue = [&](int i, const v16i& acc, const RsRow& r) {
+#ifdef LELE_HIP_LAB
+        if (g.ablate & 2) {
+            if (acc[0] == 0x12345 && r.rowsum == 77) epi.out[0] = 1.0f;
+            return;
+        }
+#endif
+        const int t = t0 + i;
+        const unsigned row = (unsigned)t * 32u + (unsigned)l31;
+        const bool rok = row < rows;
+        const unsigned rowc = rok ? row : rows - 1u;
+        const unsigned obase = rowc * (unsigned)n + (unsigned)(ct * 32 + 4 * hv);  // rows * n < 2^30 (rs_fits)
+        const unsigned slice = (EM == 0 || single) ? 0u : rowc / mu;
+        float4 res1[NRES > 0 ? 4 : 1], res2[NRES > 1 ? 4 : 1];
+        if (NRES > 0) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int c = ct * 32 + 4 * hv + 8 * gq;
+                const unsigned at = c < n ? obase + 8 * gq : rowc * (unsigned)n + (unsigned)(n - 4);
+                res1[gq] = *reinterpret_cast<const float4*>(epi.res1 + at);
+                if (NRES > 1) res2[gq] = *reinterpret_cast<const float4*>(epi.res2 + at);
+            }
+        }
+        const int ca = 128 - r.zp_i;
+        const int rterm = cbz * r.rowsum + epi.k * ca * cbz;
+        const float ds = r.scale;
+        QParams q2;
+        if (EM == 2) q2 = make_qparams(0.0f, __uint_as_float(r.smax));
+        float4 o[4];
+        unsigned d[4];
+        auto val = [&](int a, int cs, float dsws, float b) {  // IgemmEpi::value24 (the weight scale is mandatory on this route)
+#ifdef LELE_HIP_LAB
+            if (g.ablate & 16) return __int_as_float(a);
+#endif
+            const int total = a + rterm + __mul24(ca, cs);
+            float vf = (float)total;  // _mm256_cvtepi32_ps
+            vf = vf * dsws;
+            vf = vf + b;
+            if (RELU) vf = vf > 0.0f ? vf : 0.0f;
+            return vf;
+        };
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            o[gq].x = val(acc[4 * gq + 0], colsum[4 * gq + 0], ds * wsc[4 * gq + 0], biasc[4 * gq + 0]);
+            o[gq].y = val(acc[4 * gq + 1], colsum[4 * gq + 1], ds * wsc[4 * gq + 1], biasc[4 * gq + 1]);
+            o[gq].z = val(acc[4 * gq + 2], colsum[4 * gq + 2], ds * wsc[4 * gq + 2], biasc[4 * gq + 2]);
+            o[gq].w = val(acc[4 * gq + 3], colsum[4 * gq + 3], ds * wsc[4 * gq + 3], biasc[4 * gq + 3]);
+            if (EM == 0) {
+                if (NRES > 0) {
+                    o[gq].x = o[gq].x + res1[gq].x, o[gq].y = o[gq].y + res1[gq].y, o[gq].z = o[gq].z + res1[gq].z, o[gq].w = o[gq].w + res1[gq].w;
+                    if (NRES > 1)
+                        o[gq].x = o[gq].x + res2[gq].x, o[gq].y = o[gq].y + res2[gq].y, o[gq].z = o[gq].z + res2[gq].z, o[gq].w = o[gq].w + res2[gq].w;
+                }
+                const bool cok = ct * 32 + 4 * hv + 8 * gq < n;  // n % 4 == 0: a group of four columns is whole or absent
+                const v4u bits = {__float_as_uint(o[gq].x), __float_as_uint(o[gq].y), __float_as_uint(o[gq].z), __float_as_uint(o[gq].w)};
+#ifdef LELE_HIP_LAB
+                if (g.ablate & 8) {
+                    if (bits[0] == 0x12345u) epi.out[1] = 2.0f;
+                } else
+#endif
+                __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, rok && cok ? (obase + 8u * gq) * 4u : 0xffffffffu, 0, 0);
+            } else if (EM == 2) {
+                unsigned p = 0u;
+                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(o[gq].x, q2.inv_scale, q2.zp)), 0, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(o[gq].y, q2.inv_scale, q2.zp)), 1, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(o[gq].z, q2.inv_scale, q2.zp)), 2, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(o[gq].w, q2.inv_scale, q2.zp)), 3, p);
+                d[gq] = p ^ 0x80808080u;
+            }
+        }
+        if (EM == 2) {
+            // a lane holds columns {0-3, 8-11, 16-19, 24-27} + 4 hv of its row; two half-wave exchanges turn that into the 16
+            // consecutive columns 16 hv + [0, 16): exactly lane (row, hv)'s bytes of the consumer's fragment block (row tile t, k-step ct)
+            const auto r02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
+            const auto r13 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+            const v4i chunk = {(int)r02[0], (int)r02[1], (int)r13[0], (int)r13[1]};
+            *(reinterpret_cast<v4i*>(g.hid) + ((size_t)t * g.nct + ct) * 64 + lane) = chunk;
+            const v4u qb = {__float_as_uint(q2.scale), __float_as_uint(q2.zp), __float_as_uint(q2.inv_scale), (unsigned)q2.zp_i};
+            __builtin_amdgcn_raw_buffer_store_b128(qb, out_rsrc, ct == 0 && hv == 0 && rok && row == slice * mu ? slice * 16u : 0xffffffffu, 0, 0);
+        }
+        if (EM == 1) {  // ReLU results: >= 0, NaN became 0; n % 32 == 0 on the two-pass route: every column of the tile exists
+            float lmax = 0.0f;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) lmax = fmaxf(lmax, fmaxf(fmaxf(o[gq].x, o[gq].y), fmaxf(o[gq].z, o[gq].w)));
+            if (!rok) lmax = 0.0f;
+            const unsigned rel = slice - sbase;
+            mx[0] = rel == 0u ? fmaxf(mx[0], lmax) : mx[0];
+            mx[1] = rel == 1u ? fmaxf(mx[1], lmax) : mx[1];
+            mx[2] = rel == 2u ? fmaxf(mx[2], lmax) : mx[2];
+            mx[3] = rel == 3u ? fmaxf(mx[3], lmax) : mx[3];
+            if (rel > 3u && lmax > 0.0f) atomicMax(&epi.slice_max[slice], __float_as_uint(lmax));
+        }
+        if (EM == 0 && epi.blockstat) {  // one {min, max} pair per (row tile, column tile): LeleBuf::rowstat kind 1
+            float smn = 3.40282347e+38f, smx = -3.40282347e+38f;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                if (rok && ct * 32 + 4 * hv + 8 * gq < n) {
+                    smn = fminf(smn, fminf(fminf(o[gq].x, o[gq].y), fminf(o[gq].z, o[gq].w)));
+                    smx = fmaxf(smx, fmaxf(fmaxf(o[gq].x, o[gq].y), fmaxf(o[gq].z, o[gq].w)));
+                }
+            smn = wave_allreduce64(smn, [](float cur, float x) { return x < cur ? x : cur; });
+            smx = wave_allreduce64(smx, [](float cur, float x) { return x > cur ? x : cur; });
+            if (lane == 0) {
+                float* so = epi.blockstat + ((size_t)t * g.nct + ct) * 2;
+                so[0] = smn;
+                so[1] = smx;
+            }
+        }
+    };
+    // One tile per barrier interval: products, then the epilogue.  (Measured alternatives, all within 5 % of this and fatter in
+    // registers: the next tile's products woven into this tile's epilogue with sched_group_barrier; the two waves of a SIMD in
+    // opposite phase.  The epilogue of a lone wave is dependency-bound, not issue-bound, so neither arrangement buys overlap.)
+    v16i acc;
+    RsRow r;
+    for (int i = 0; i < nt; ++i) {
+        rs_barrier();  // tile i has landed
+        RS_STAMP(0);
+        products(i, acc, r);
+        if (i == 0) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(bf[s]));  // the weights are in: later tiles wait for nothing of the prologue
+        }
+        RS_STAMP(0);
+        epilogue(i, acc, r);
+    }
+    RS_STAMP(0);
+#ifdef LELE_HIP_LAB
+    if (g.dbg && lane == 0) g.dbg[((size_t)blockIdx.x * 9 + wave) * 32 + 31] = clock64() - cyc0;  // shader cycles entry -> end
+#endif
+    if (EM == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = wave_allreduce64(mx[j], [](float cur, float x) { return fmaxf(cur, x); });
+            if (lane == 0 && v > 0.0f) atomicMax(&s_mx[j], __float_as_uint(v));  // non-negative floats order like their bits
+        }
+        __syncthreads();
+        if (threadIdx.x < 4 && s_mx[threadIdx.x]) atomicMax(&epi.slice_max[sbase + threadIdx.x], s_mx[threadIdx.x]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ K = 2048: four waves split K
+// One workgroup = one 32-column tile over a range of row tiles; wave w holds the weight fragments of k-steps [16 w, 16 w + 16)
+// and multiplies the same quarter of every activation tile; the four partial tiles (and the partial row sums: v_dot4 with ones
+// over the fragments in registers) meet in a double-buffered LDS exchange, ONE barrier per tile; wave w then finishes column
+// group w of the tile (4 columns per lane, one 16-byte store).  The activation's row sums never exist in HBM.
+template <int NRES>
+__global__ __launch_bounds__(256, 2) void igemm_rs_ks4_kernel(RsArgs g, IgemmEpi epi) {
+    constexpr int KS = 64, KW = 16;
+    __shared__ v4i s_x[2][4][4][64];  // [buffer][wave][column group][lane]
+    __shared__ int s_rs[2][4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hv = lane >> 5, l31 = lane & 31;
+    const unsigned L = rs_logical_block();
+    const int rr = (int)(L / (unsigned)g.nct), ct = (int)(L - (unsigned)rr * (unsigned)g.nct);
+    const int t0 = (int)((int64_t)rr * g.nrt / g.nrr), t1 = (int)((int64_t)(rr + 1) * g.nrt / g.nrr);
+    if (t0 >= t1) return;  // uniform over the workgroup
+    const int n = g.n;
+    const unsigned rows = g.rows, mu = (unsigned)epi.m;
+    const bool has_ws = epi.wscale != nullptr, has_bias = epi.bias != nullptr, single = rows == mu;
+
+    v4i bf[KW];
+    {
+        const v4i* wp = reinterpret_cast<const v4i*>(g.wf) + ((size_t)ct * KS + wave * KW) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KW; ++s) bf[s] = wp[s * 64];
+    }
+    // the four columns this lane finishes: ct * 32 + 8 wave + 4 hv + e
+    const int col = ct * 32 + 8 * wave + 4 * hv;
+    const bool cok = col < n;  // n % 4 == 0
+    int colsum[4];
+    float ws[4], bias[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = col + e < n ? col + e : n - 1;
+        colsum[e] = epi.col_sums[c];
+        ws[e] = has_ws ? (epi.wscale_len <= 1 ? epi.wscale[0] : epi.wscale[c]) : 1.0f;
+        bias[e] = has_bias ? epi.bias[c] : 0.0f;
+    }
+    const int cbz = 128 - epi.zp_b;
+    struct Row {
+        float scale;
+        int zp_i;
+    };
+    auto load_tile = [&](v4i (&a)[KW], Row& r, int t) {
+        const v4i* ap = reinterpret_cast<const v4i*>(g.af) + ((size_t)t * KS + wave * KW) * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KW; ++s) a[s] = ap[s * 64];
+        unsigned row = (unsigned)t * 32u + (unsigned)l31;
+        row = row < rows ? row : rows - 1u;
+        r.scale = 1.0f;
+        r.zp_i = epi.zp_a_fixed;
+        if (epi.prm) {
+            const unsigned sl = single ? 0u : row / mu;
+            r.scale = epi.prm[sl].scale;
+            r.zp_i = epi.prm[sl].zp_i;
+        }
+    };
+    auto compute = [&](const v4i (&a)[KW], const Row& r, int t, int buf) {
+        const unsigned row = (unsigned)t * 32u + (unsigned)l31;
+        const bool rok = row < rows;
+        const size_t at = (size_t)(rok ? row : rows - 1u) * (unsigned)n + (unsigned)(cok ? col : n - 4);
+        float4 res1, res2;
+        if (NRES > 0) res1 = *reinterpret_cast<const float4*>(epi.res1 + at);
+        if (NRES > 1) res2 = *reinterpret_cast<const float4*>(epi.res2 + at);
+        v16i acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0;
+        int rsp = 0;
+#pragma unroll
+        for (int s = 0; s < KW; ++s) {
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[s], a[s], acc, 0, 0, 0);
+            rsp = __builtin_amdgcn_sdot4(a[s][0], 0x01010101, rsp, false);
+            rsp = __builtin_amdgcn_sdot4(a[s][1], 0x01010101, rsp, false);
+            rsp = __builtin_amdgcn_sdot4(a[s][2], 0x01010101, rsp, false);
+            rsp = __builtin_amdgcn_sdot4(a[s][3], 0x01010101, rsp, false);
+        }
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) s_x[buf][wave][gq][lane] = v4i{acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]};
+        s_rs[buf][wave][lane] = rsp;
+        __syncthreads();  // the only barrier of a tile: buffer `buf` is rewritten two tiles later, after the next tile's barrier
+        v4i tot = s_x[buf][0][wave][lane];
+        int rowsum = s_rs[buf][0][l31] + s_rs[buf][0][l31 + 32];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const v4i p = s_x[buf][w][wave][lane];
+            tot[0] += p[0], tot[1] += p[1], tot[2] += p[2], tot[3] += p[3];
+            rowsum += s_rs[buf][w][l31] + s_rs[buf][w][l31 + 32];
+        }
+        const int ca = 128 - r.zp_i;
+        const int rterm = cbz * rowsum + epi.k * ca * cbz;
+        float4 o;
+        o.x = rs_value(tot[0], rterm, ca, colsum[0], r.scale * ws[0], bias[0], has_ws, has_bias, epi.relu);
+        o.y = rs_value(tot[1], rterm, ca, colsum[1], r.scale * ws[1], bias[1], has_ws, has_bias, epi.relu);
+        o.z = rs_value(tot[2], rterm, ca, colsum[2], r.scale * ws[2], bias[2], has_ws, has_bias, epi.relu);
+        o.w = rs_value(tot[3], rterm, ca, colsum[3], r.scale * ws[3], bias[3], has_ws, has_bias, epi.relu);
+        if (NRES > 0) o.x = o.x + res1.x, o.y = o.y + res1.y, o.z = o.z + res1.z, o.w = o.w + res1.w;
+        if (NRES > 1) o.x = o.x + res2.x, o.y = o.y + res2.y, o.z = o.z + res2.z, o.w = o.w + res2.w;
+        if (rok && cok) *reinterpret_cast<float4*>(epi.out + at) = o;
+    };
+    v4i a0[KW], a1[KW];
+    Row r0, r1;
+    load_tile(a0, r0, t0);
+    int t = t0;
+    while (t + 1 < t1) {  // straight-line pairs, as in igemm_rs_kernel
+        load_tile(a1, r1, t + 1);
+        compute(a0, r0, t, 0);
+        load_tile(a0, r0, t + 2 < t1 ? t + 2 : t1 - 1);
+        compute(a1, r1, t + 1, 1);
+        t += 2;
+    }
+    if (t < t1) compute(a0, r0, t, 0);
+}
+
+}  // namespace

@@ -32,6 +32,7 @@ namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 struct QParams {  // per batch slice
     float scale, zp, inv_scale;
@@ -1085,6 +1086,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+}  // namespace
+#include "igemm_rs.h"
+namespace {
+
 // ------------------------------------------------------------------------------------------ one-pass quantised linear
 // fused_quantized_linear in ONE launch after the range is known (quantization.rs:77-169 -> avx/quantization.rs:225-417):
 // a workgroup owns 32 rows of the activation over ALL of K.  It derives the {scale, zp} of the (one or two) batch slices its
@@ -1809,6 +1814,97 @@ int launch_igemm_hidden(LeleCtx* ctx, int em, const int8_t* aq, const int8_t* wt
     return 0;
 }
 
+// ---- register-stationary route (igemm_rs.h): K padded to exactly 512 or 2048 bytes, enough 32 x 32 tiles to fill the chip
+int rs_kp(int64_t k) {
+    const int64_t kp = (k + 31) & ~int64_t(31);
+    return kp == 512 || kp == 2048 ? (int)kp : 0;
+}
+bool rs_fits(LeleCtx* ctx, int64_t rows, int64_t n, int kp) {
+    if (!kp || env_int("LELE_HIP_IGEMM_RS", 1) == 0) return false;  // documented switch: 0 = the tiled kernels everywhere
+    if (n % 4 || rows * n >= (int64_t(1) << 30)) return false;  // 16-byte stores; 32-bit byte offsets into the result
+    const int64_t units = ((rows + 31) / 32) * ((n + 31) / 32);
+    return units >= (int64_t)env_int("LELE_HIP_IGEMM_RS_MIN", 8 * ctx->num_cus);
+}
+// weights in fragment order + column sums: cached for declared-immutable weights, packed into the arena per call otherwise
+int frag_weights_of(LeleCtx* ctx, const LeleTensor* w, int k, int n, int kp, FragW* out) {
+    const int ks = kp / 32, nt = (n + 31) / 32;
+    if (w->mem == LELE_MEM_WEIGHT) return get_frag_weights(ctx, w, k, n, ks, nt, out);
+    const void* dw = nullptr;
+    LELE_TRY(ctx->dev_ptr(w, &dw));
+    void *dwf = nullptr, *dcs = nullptr;
+    LELE_TRY(ctx->arena_alloc((size_t)nt * ks * 1024, &dwf));
+    LELE_TRY(ctx->arena_alloc((size_t)n * 4, &dcs));
+    const int64_t threads = (int64_t)nt * 32 * ks * 2;
+    hipLaunchKernelGGL(wpack_frag_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)dw, k, n, ks, nt,
+                       (int8_t*)dwf);
+    hipLaunchKernelGGL(wcolsum_kernel, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, (const float*)dw, k, n, (int*)dcs);
+    LELE_HIP_CHECK(hipGetLastError());
+    out->wf = (int8_t*)dwf;
+    out->col_sums = (int*)dcs;
+    return 0;
+}
+// f32 rows -> fragment-major i8 [ceil(rows / 32)][kp / 32][1024] in the arena (+ row sums unless rs == NULL)
+int launch_qrows_frag(LeleCtx* ctx, const float* dx, int64_t rows, int k, int kp, int m, QParams* prm, int8_t* af, int* rs,
+                      const float* partial, int nblk, unsigned* zero_slice) {
+    const int64_t nrt = (rows + 31) / 32;
+    if (kp == 512)  // a wave per two rows: 4 tiles' worth of workgroups per tile
+        hipLaunchKernelGGL((qrows_frag_kernel<32, 1>), dim3((unsigned)(4 * nrt)), dim3(256), 0, ctx->stream, dx, (unsigned)rows, k, m, prm, af, rs,
+                           partial, nblk, zero_slice);
+    else
+        hipLaunchKernelGGL((qrows_frag_kernel<128, 4>), dim3((unsigned)(4 * nrt)), dim3(256), 0, ctx->stream, dx, (unsigned)rows, k, m, prm, af, rs,
+                           partial, nblk, zero_slice);
+    LELE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_rs(LeleCtx* ctx, int em, const int8_t* af, const int8_t* wf, int64_t rows, int n, int8_t* hid, const IgemmEpi& epi) {
+    RsArgs g{af, wf, (unsigned)rows, n, (int)((rows + 31) / 32), (n + 31) / 32, 0, 0, hid};
+#ifdef LELE_HIP_LAB
+    g.dbg = nullptr;
+    g.ablate = env_int("LELE_HIP_RS_ABLATE", 0);
+    if (const char* e = getenv("LELE_HIP_RS_STAMPS"))  // a device address (tools/rs_stamps.py), optionally for one mode only
+        if (env_int("LELE_HIP_RS_STAMPS_EM", em) == em) g.dbg = (long long*)(uintptr_t)strtoull(e, nullptr, 0);
+#endif
+    g.ncb = (g.nct + 7) / 8;
+    g.nrr = std::max(1, std::min(g.nrt, ctx->num_cus / g.ncb));  // one 640-thread workgroup per CU, all resident at once
+    const dim3 grid((unsigned)(g.ncb * g.nrr));
+    const int nres = epi.res1 ? (epi.res2 ? 2 : 1) : 0;
+#define LELE_RS(EM_, NRES_, RELU_)                                                                   \
+    do {                                                                                             \
+        auto kern = igemm_rs_kernel<EM_, NRES_, RELU_>;                                               \
+        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), RS_LDS));                  \
+        hipLaunchKernelGGL(kern, grid, dim3(640), RS_LDS, ctx->stream, g, epi);                       \
+    } while (0)
+    if (em == 1) LELE_RS(1, 0, true);
+    else if (em == 2) LELE_RS(2, 0, true);
+    else if (epi.relu) {
+        if (nres == 0) LELE_RS(0, 0, true);
+        else if (nres == 1) LELE_RS(0, 1, true);
+        else LELE_RS(0, 2, true);
+    } else {
+        if (nres == 0) LELE_RS(0, 0, false);
+        else if (nres == 1) LELE_RS(0, 1, false);
+        else LELE_RS(0, 2, false);
+    }
+#undef LELE_RS
+    LELE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_rs_ks4(LeleCtx* ctx, const int8_t* af, const int8_t* wf, int64_t rows, int n, const IgemmEpi& epi) {
+    RsArgs g{af, wf, (unsigned)rows, n, (int)((rows + 31) / 32), (n + 31) / 32, 0, 0, nullptr};
+#ifdef LELE_HIP_LAB
+    g.dbg = nullptr;
+    g.ablate = 0;
+#endif
+    g.nrr = std::max(1, std::min(g.nrt, 2 * ctx->num_cus / g.nct));  // two 256-thread workgroups per CU
+    const dim3 grid((unsigned)(g.nct * g.nrr));
+    const int nres = epi.res1 ? (epi.res2 ? 2 : 1) : 0;
+    if (nres == 0) hipLaunchKernelGGL(igemm_rs_ks4_kernel<0>, grid, dim3(256), 0, ctx->stream, g, epi);
+    else if (nres == 1) hipLaunchKernelGGL(igemm_rs_ks4_kernel<1>, grid, dim3(256), 0, ctx->stream, g, epi);
+    else hipLaunchKernelGGL(igemm_rs_ks4_kernel<2>, grid, dim3(256), 0, ctx->stream, g, epi);
+    LELE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 namespace lele {
@@ -2006,6 +2102,36 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
         return set_shape_v(out_shape, out_rank, shp);
     }
 
+    // ---- register-stationary route (igemm_rs.h): rows -> i8 in fragment order, then the barrier-free GEMM
+    if (const int kprs = rs_kp(k); rs_fits(ctx, rows, n, kprs)) {
+        FragW fw;
+        LELE_TRY(frag_weights_of(ctx, weight_int8, (int)k, (int)n, kprs, &fw));
+        const int64_t nrt = (rows + 31) / 32;
+        void *af = nullptr, *rs = nullptr;
+        LELE_TRY(ctx->arena_alloc((size_t)nrt * kprs * 32, &af));
+        if (kprs == 512) LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));  // K = 2048: the GEMM sums the rows it loads anyway
+        LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k, kprs, (int)m, (QParams*)prm, (int8_t*)af, (int*)rs, partial, nblk, nullptr));
+        LELE_TRY(qprof_mark(ctx, 2));
+        IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, (const int*)rs, fw.col_sums, (const QParams*)prm, 0,
+                     (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
+                     (const float*)dr2};
+        const int64_t nstat = nrt * ((n + 31) / 32);
+        if (kprs == 512 && batch == 1 && nstat <= 4096) {  // {min, max} per tile for a single-slice consumer (LeleBuf::rowstat kind 1)
+            LELE_TRY(out->reserve_rowstat(nstat));
+            if ((size_t)nstat <= out->rowstat_cap) epi.blockstat = out->rowstat;
+        }
+        if (kprs == 512) LELE_TRY(launch_rs(ctx, 0, (const int8_t*)af, fw.wf, rows, (int)n, nullptr, epi));
+        else LELE_TRY(launch_rs_ks4(ctx, (const int8_t*)af, fw.wf, rows, (int)n, epi));
+        LELE_TRY(qprof_mark(ctx, 3));
+        if (epi.blockstat) {
+            out->rowstat_rows = nstat;
+            out->rowstat_len = rows * n;
+            out->rowstat_kind = 1;
+            out->rowstat_valid = true;
+        }
+        return set_shape_v(out_shape, out_rank, shp);
+    }
+
     // ---- three-kernel chain: rows -> i8 (+ row sums) in HBM, then the tiled i8 GEMM
     const int kp = (int)((k + 15) & ~int64_t(15));
     PackedW pw;
@@ -2115,9 +2241,14 @@ int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const Le
     const int64_t ws1_len = numel(w1_scale), b1_len = b1 ? numel(b1) : 0;
     // the fused route: a hidden layer of whole 128-column tiles (= whole SIMD bodies of its quantiser), slices of at least one tile
     // of rows, enough tiles to fill the chip, same-shape residuals; everything else runs the two calls it stands for
-    bool fused = env_int("LELE_HIP_FFN_FUSED", 1) != 0 && w1_int8->shape[w1_int8->rank - 2] == k1 && k2 == n1 && n1 % 128 == 0 &&
-                 m >= 128 && rows < (int64_t(1) << 31) && ((rows + 127) / 128) * (n1 / 128) >= 2 * (int64_t)ctx->num_cus &&
-                 ws1_len >= 1 && (ws1_len == 1 || ws1_len >= n1) && (b1_len == 0 || b1_len >= n1) && n2 >= 1;
+    const bool args_ok = w1_int8->shape[w1_int8->rank - 2] == k1 && k2 == n1 && rows < (int64_t(1) << 31) && ws1_len >= 1 &&
+                         (ws1_len == 1 || ws1_len >= n1) && (b1_len == 0 || b1_len >= n1) && n2 >= 1;
+    // register-stationary route (igemm_rs.h): K = 512 into a hidden layer of exactly 2048 columns, whose i8 form is written in the
+    // fragment order of the second product and read once
+    const bool rs_route = env_int("LELE_HIP_FFN_FUSED", 1) != 0 && args_ok && rs_kp(k1) == 512 && n1 == 2048 && rs_fits(ctx, rows, n1, 512) &&
+                          rs_fits(ctx, rows, n2, 2048);
+    bool fused = rs_route || (env_int("LELE_HIP_FFN_FUSED", 1) != 0 && args_ok && n1 % 128 == 0 && m >= 128 &&
+                              ((rows + 127) / 128) * (n1 / 128) >= 2 * (int64_t)ctx->num_cus);
     if (fused && res1) {
         int64_t on = n2 * rows;
         auto same = [&](const LeleTensor* t) {
@@ -2165,6 +2296,32 @@ int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const Le
     LELE_TRY(qprof_mark(ctx, 0));
     if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k1, (QParams*)prm1, nullptr, nullptr, &partial, &nblk));
     LELE_TRY(qprof_mark(ctx, 1));
+    if (rs_route) {
+        FragW fw1, fw2;
+        LELE_TRY(frag_weights_of(ctx, w1_int8, (int)k1, (int)n1, 512, &fw1));
+        LELE_TRY(frag_weights_of(ctx, w2_int8, (int)k2, (int)n2, 2048, &fw2));
+        const int64_t nrt = (rows + 31) / 32;
+        void *af1 = nullptr, *hid = nullptr;
+        LELE_TRY(ctx->arena_alloc((size_t)nrt * 512 * 32, &af1));
+        LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs1));
+        LELE_TRY(ctx->arena_alloc((size_t)nrt * 2048 * 32, &hid));
+        LELE_TRY(ctx->arena_alloc((size_t)batch * 4, &hmax));
+        // rows -> i8 for the first product; the same launch clears the per-slice maxima the range pass adds into
+        LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k1, 512, (int)m, (QParams*)prm1, (int8_t*)af1, (int*)rs1, partial, nblk,
+                                   (unsigned*)hmax));
+        LELE_TRY(qprof_mark(ctx, 2));
+        IgemmEpi e1{nullptr, rows, n1, (int)m, (int)k1, (const int*)rs1, fw1.col_sums, (const QParams*)prm1, 0, (int)wz1, (const float*)dws1,
+                    (int)ws1_len, b1_len ? (const float*)db1 : nullptr, 1};
+        e1.slice_max = (unsigned*)hmax;
+        LELE_TRY(launch_rs(ctx, 1, (const int8_t*)af1, fw1.wf, rows, (int)n1, nullptr, e1));   // range of the ReLU result per slice
+        e1.q_prm = (QParams*)prm2;
+        LELE_TRY(launch_rs(ctx, 2, (const int8_t*)af1, fw1.wf, rows, (int)n1, (int8_t*)hid, e1));  // the result again, as the next operand
+        IgemmEpi e2{(float*)out->data, rows, n2, (int)m, (int)k2, nullptr, fw2.col_sums, (const QParams*)prm2, 0, (int)wz2,
+                    (const float*)dws2, (int)ws2_len, b2_len ? (const float*)db2 : nullptr, apply_relu2, (const float*)dr1, (const float*)dr2};
+        LELE_TRY(launch_rs_ks4(ctx, (const int8_t*)hid, fw2.wf, rows, (int)n2, e2));
+        LELE_TRY(qprof_mark(ctx, 3));
+        return set_shape_v(out_shape, out_rank, shp);
+    }
     const int kp1 = (int)((k1 + 15) & ~int64_t(15)), kp2 = (int)n1;
     PackedW pw1, pw2;
     LELE_TRY(packed_weights_of(ctx, w1_int8, (int)k1, (int)n1, kp1, &pw1));
