@@ -268,6 +268,10 @@ int lele_hip_cast(LeleCtx* ctx, const LeleTensor* x, int32_t to_dtype, LeleBuf* 
 int lele_hip_conv2d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,
                     const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
                     const int64_t* strides, size_t nstr, int act, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* reset_conv_stats / print_conv_stats (conv2d.rs:75, 101 -- no-ops upstream; examples/yolo26n-seg/src/main.rs:64,74 calls them):
+ * 2-D convolutions issued on ctx since the last reset, as call count and multiply-accumulate count */
+int lele_hip_conv_stats_reset(LeleCtx* ctx);
+int lele_hip_conv_stats(LeleCtx* ctx, int64_t* calls, int64_t* macs);
 /* conv1d (conv1d.rs:837) / conv1d_fused (conv1d.rs:1464: relu != 0).  x [N,C,L], w [C_out,C_in/g,K], pads [left,right] */
 int lele_hip_conv1d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,
                     const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,

@@ -115,6 +115,9 @@ struct LeleCtx {
         size_t used = 0;
     } qprof;
 
+    // reset_conv_stats / print_conv_stats: 2-D convolutions issued since the last reset
+    int64_t conv_calls = 0, conv_macs = 0;
+
     // two library-owned result buffers for ops that fall back to an unfused sequence and need somewhere to put the intermediate
     // (add3 / fused_quantized_linear_residual with an operand that broadcasts OUTWARD: the in-place second pass is not possible)
     LeleBuf* tmp[3] = {nullptr, nullptr, nullptr};

@@ -738,6 +738,8 @@ int lele_hip_conv2d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, cons
     g.oh = (int)(nh / g.sh + 1);
     g.ow = (int)(nw / g.sw + 1);
     g.K = g.icg * g.kh * g.kw;
+    ctx->conv_calls += 1;  // reset_conv_stats / print_conv_stats (conv2d.rs:75,101)
+    ctx->conv_macs += (int64_t)g.n * g.oc * g.oh * g.ow * g.K;
     g.plane = g.oh * g.ow;
     if (bias) LELE_REQUIRE(numel(bias) >= g.oc, "conv2d: bias has %lld entries for %d channels", (long long)numel(bias), g.oc);
     LELE_TRY(ctx->arena_reset());
@@ -748,6 +750,21 @@ int lele_hip_conv2d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, cons
     LELE_TRY(out->reserve((size_t)g.n * g.oc * g.plane * 4));
     LELE_TRY(run_conv2d(ctx, w, (const float*)dx, (const float*)dwp, (const float*)db, g, act, (float*)out->data));
     return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, (int64_t)g.oh, (int64_t)g.ow});
+}
+
+/* reset_conv_stats / print_conv_stats (conv2d.rs:75,101; examples/yolo26n-seg/src/main.rs:64,74): counters of the 2-D convolutions
+ * issued on this context since the last reset -- calls and multiply-accumulates (host arithmetic at issue: no device cost) */
+int lele_hip_conv_stats_reset(LeleCtx* ctx) {
+    LELE_REQUIRE(ctx, "conv_stats_reset: ctx is NULL");
+    ctx->conv_calls = 0;
+    ctx->conv_macs = 0;
+    return 0;
+}
+int lele_hip_conv_stats(LeleCtx* ctx, int64_t* calls, int64_t* macs) {
+    LELE_REQUIRE(ctx && calls && macs, "conv_stats: NULL argument");
+    *calls = ctx->conv_calls;
+    *macs = ctx->conv_macs;
+    return 0;
 }
 
 int lele_hip_conv1d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,

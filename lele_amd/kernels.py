@@ -553,6 +553,22 @@ def _conv(fn, input, weights, bias, dilations, group, pads, strides, tail, out, 
     return _op(ctx, fn, [input, weights, bias], args + list(tail), out)
 
 
+def reset_conv_stats(ctx=None):  # conv2d.rs:101 (a no-op upstream; here: clears the context's convolution counters)
+    _lib.check(_lib.lib().lele_hip_conv_stats_reset(_ctx(ctx)._h))
+
+
+def conv_stats(ctx=None):
+    """(calls, multiply-accumulates) of the 2-D convolutions issued on the context since the last reset_conv_stats()"""
+    calls, macs = C.c_int64(0), C.c_int64(0)
+    _lib.check(_lib.lib().lele_hip_conv_stats(_ctx(ctx)._h, C.byref(calls), C.byref(macs)))
+    return calls.value, macs.value
+
+
+def print_conv_stats(ctx=None):  # conv2d.rs:75
+    calls, macs = conv_stats(ctx)
+    print("conv stats: %d convolution calls, %.3f GMAC" % (calls, macs * 1e-9))
+
+
 def conv2d(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), out=None, ctx=None):  # conv2d.rs:107
     return _conv(_lib.lib().lele_hip_conv2d, input, weights, bias, dilations, group, pads, strides, [C.c_int(0)], out, ctx)
 

@@ -7,25 +7,44 @@ use std::cell::RefCell;
 use std::collections::HashMap;
 use std::ffi::CStr;
 use std::os::raw::{c_int, c_void};
+use std::rc::Rc;
 
-/// element types of TensorView (src/tensor.rs:14-20); DTYPE is the LeleDType tag
+/// element types of TensorView (src/tensor.rs:14-20); DTYPE is the LeleDType tag.  Every generic `lele::kernels` function of this
+/// crate carries this bound on its element parameters IN ADDITION to upstream's (generated model code only instantiates them
+/// with these five types, so a stricter bound changes nothing for it).
 pub trait ElementOps: Copy + Clone + std::fmt::Debug + Default + 'static {
     const DTYPE: i32;
+    fn as_f32(self) -> f32;
 }
 impl ElementOps for f32 {
     const DTYPE: i32 = ffi::LELE_F32;
+    fn as_f32(self) -> f32 {
+        self
+    }
 }
 impl ElementOps for i64 {
     const DTYPE: i32 = ffi::LELE_I64;
+    fn as_f32(self) -> f32 {
+        self as f32
+    }
 }
 impl ElementOps for i32 {
     const DTYPE: i32 = ffi::LELE_I32;
+    fn as_f32(self) -> f32 {
+        self as f32
+    }
 }
 impl ElementOps for u8 {
     const DTYPE: i32 = ffi::LELE_U8;
+    fn as_f32(self) -> f32 {
+        self as f32
+    }
 }
 impl ElementOps for i8 {
     const DTYPE: i32 = ffi::LELE_I8;
+    fn as_f32(self) -> f32 {
+        self as f32
+    }
 }
 pub trait AsI64 {
     fn as_i64(self) -> i64;
@@ -38,6 +57,21 @@ impl AsI64 for f32 {
 impl AsI64 for i64 {
     fn as_i64(self) -> i64 {
         self
+    }
+}
+impl AsI64 for i32 {
+    fn as_i64(self) -> i64 {
+        self as i64
+    }
+}
+impl AsI64 for u8 {
+    fn as_i64(self) -> i64 {
+        self as i64
+    }
+}
+impl AsI64 for i8 {
+    fn as_i64(self) -> i64 {
+        self as i64
     }
 }
 
@@ -60,7 +94,39 @@ struct Runtime {
     ctx: *mut ffi::LeleCtx,
     slots: HashMap<usize, Slot>,
     scratch: Vec<Slot>,
+    free: Vec<Slot>, // pooled buffers no owned view refers to any more
     prepared: HashMap<(usize, usize), PreparedWeights>,
+}
+
+/// A pooled buffer behind an OWNED result (`TensorView<'static>`: split_owned, lele::features::*).  Views share it through an
+/// `Rc`; when the last one goes the buffer returns to the thread's free list and the next owned result reuses it -- a model that
+/// calls `split_owned` every forward keeps a constant number of device buffers (no per-call allocation, nothing leaked).
+pub struct OwnedSlot(Slot);
+impl OwnedSlot {
+    pub fn slot(&self) -> Slot {
+        self.0
+    }
+}
+impl Drop for OwnedSlot {
+    fn drop(&mut self) {
+        // the thread's runtime may already be gone at thread exit: then the ctx has released the buffer with everything else
+        let _ = RT.try_with(|cell| {
+            if let Ok(mut g) = cell.try_borrow_mut() {
+                if let Some(r) = g.as_mut() {
+                    r.free.push(self.0);
+                }
+            }
+        });
+    }
+}
+pub fn pooled_slot() -> Rc<OwnedSlot> {
+    with_rt(|r| {
+        let s = match r.free.pop() {
+            Some(s) => s,
+            None => new_buf(r),
+        };
+        Rc::new(OwnedSlot(s))
+    })
 }
 thread_local! {
     // one ctx per host thread: lele itself is single-threaded with thread-local caches (conv2d.rs:601-603)
@@ -73,7 +139,7 @@ fn with_rt<R>(f: impl FnOnce(&mut Runtime) -> R) -> R {
             let device = std::env::var("LELE_HIP_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0);
             let mut ctx = std::ptr::null_mut();
             check(unsafe { ffi::lele_hip_ctx_create(device, &mut ctx) });
-            *g = Some(Runtime { ctx, slots: HashMap::new(), scratch: Vec::new(), prepared: HashMap::new() });
+            *g = Some(Runtime { ctx, slots: HashMap::new(), scratch: Vec::new(), free: Vec::new(), prepared: HashMap::new() });
         }
         f(g.as_mut().unwrap())
     })
@@ -138,9 +204,9 @@ impl OptC {
         self.0.as_ref().map(|c| c.ptr()).unwrap_or(std::ptr::null())
     }
 }
-pub fn scalar_opt<U: ElementOps + Into<f64>>(t: Option<&TensorView<U>>) -> (c_int, f32) {
+pub fn scalar_opt<U: ElementOps>(t: Option<&TensorView<U>>) -> (c_int, f32) {
     match t {
-        Some(v) if !v.data.is_empty() => (1, v.data[0].into() as f32),
+        Some(v) if !v.data.is_empty() => (1, v.data[0].as_f32()),
         _ => (0, 0.0),
     }
 }
@@ -378,10 +444,33 @@ pub fn split_into<'a, T: ElementOps>(input: &TensorView<'_, T>, axis: i64, split
     views
 }
 pub fn split_owned<T: ElementOps>(input: &TensorView<'_, T>, axis: i64, splits: &[i64]) -> Vec<TensorView<'static, T>> {
-    // manipulation.rs:1150-1213: owned results -- each part gets a buffer of its own that lives as long as the thread
-    let mut bufs: Vec<Vec<T>> = (0..splits.len()).map(|_| Vec::new()).collect();
-    let leaked: &'static mut [Vec<T>] = Box::leak(std::mem::take(&mut bufs).into_boxed_slice());
-    split_into(input, axis, splits, leaked)
+    // manipulation.rs:1150-1213: owned results -- every part in a pooled buffer that its views keep alive and give back
+    let r = input.shape.len() as i64;
+    let ax = (if axis < 0 { axis + r } else { axis }) as usize;
+    let st = row_major(&input.shape);
+    let c = input.as_c();
+    let mut start = 0i64;
+    let mut views = Vec::with_capacity(splits.len());
+    for &len in splits {
+        let mut dims: Vec<i64> = input.shape.iter().map(|&d| d as i64).collect();
+        dims[ax] = len;
+        let keep = pooled_slot();
+        let mut sh = Shape::new();
+        check(unsafe { ffi::lele_hip_strided_copy(ctx(), c.ptr(), dims.as_ptr(), st.as_ptr(), std::ptr::null(), dims.len() as i32, start * st[ax], keep.slot().raw(), sh.dims(), sh.rank()) });
+        views.push(TensorView::device_owned(keep, sh.vec()));
+        start += len;
+    }
+    views
+}
+/// conv2d.rs:75,101 (`reset_conv_stats` / `print_conv_stats`, called by examples/yolo26n-seg/src/main.rs:64,74; no-ops upstream):
+/// here they front the library's convolution counters (calls and multiply-accumulates issued on this thread's context)
+pub fn reset_conv_stats() {
+    check(unsafe { ffi::lele_hip_conv_stats_reset(ctx()) });
+}
+pub fn print_conv_stats() {
+    let (mut calls, mut macs) = (0i64, 0i64);
+    check(unsafe { ffi::lele_hip_conv_stats(ctx(), &mut calls, &mut macs) });
+    println!("conv stats: {} convolution calls, {:.3} GMAC", calls, macs as f64 * 1e-9);
 }
 pub fn min_max(input: &TensorView<'_, f32>) -> (f32, f32) {
     input.data.iter().fold((f32::MAX, f32::MIN), |(a, b), &v| (a.min(v), b.max(v)))

@@ -7,17 +7,20 @@
 //! copied to the host the first time it is dereferenced (lazy D2H, cached) -- so chains of kernel calls never leave HBM and (c)
 //! keeps working unchanged.
 use crate::ffi;
-use crate::rt::{self, ElementOps, Slot};
+use crate::rt::{self, ElementOps, OwnedSlot, Slot};
 use std::borrow::Cow;
 use std::cell::OnceCell;
 use std::marker::PhantomData;
 use std::ops::Deref;
+use std::rc::Rc;
 
 pub enum Payload<'a, T: Clone> {
     /// host memory (weights.bin slices, user inputs): staged / cached by the library per `mem`
     Host { data: Cow<'a, [T]>, weight: bool },
-    /// a kernel result in the workspace slot `slot`; `host` is filled on first dereference
-    Device { slot: Slot, len: usize, host: OnceCell<Vec<T>>, _borrow: PhantomData<&'a mut Vec<T>> },
+    /// a kernel result in the workspace slot `slot`; `host` is filled on first dereference.  `keep` is None for a slot that
+    /// belongs to the caller's `out` Vec (the borrow `'a` keeps it alive, as upstream) and Some for an OWNED result
+    /// (`split_owned`, `lele::features::*`): the buffer returns to the thread's pool when the last view of it is dropped
+    Device { slot: Slot, len: usize, host: OnceCell<Vec<T>>, keep: Option<Rc<OwnedSlot>>, _borrow: PhantomData<&'a mut Vec<T>> },
 }
 
 impl<'a, T: ElementOps> Deref for Payload<'a, T> {
@@ -68,7 +71,12 @@ impl<'a, T: ElementOps> TensorView<'a, T> {
     /// a kernel result living in `slot` (rt::slot_of(out)); borrows the caller's `out` Vec like upstream's `from_slice(out, ..)`
     pub fn device(slot: Slot, shape: Vec<usize>) -> Self {
         let len = shape.iter().product();
-        Self { data: Payload::Device { slot, len, host: OnceCell::new(), _borrow: PhantomData }, shape: Cow::Owned(shape) }
+        Self { data: Payload::Device { slot, len, host: OnceCell::new(), keep: None, _borrow: PhantomData }, shape: Cow::Owned(shape) }
+    }
+    /// a kernel result in a pooled buffer this view (and every view made from it) keeps alive: upstream's owned `'static` results
+    pub fn device_owned(keep: Rc<OwnedSlot>, shape: Vec<usize>) -> TensorView<'static, T> {
+        let len = shape.iter().product();
+        TensorView { data: Payload::Device { slot: keep.slot(), len, host: OnceCell::new(), keep: Some(keep), _borrow: PhantomData }, shape: Cow::Owned(shape) }
     }
     pub fn dim(&self) -> usize {
         self.shape.len()
@@ -91,8 +99,12 @@ impl<'a, T: ElementOps> TensorView<'a, T> {
     pub fn with_shape(&self, shape: Vec<usize>) -> TensorView<'a, T> {
         assert_eq!(shape.iter().product::<usize>(), self.shape.iter().product::<usize>(), "Reshape: element count mismatch");
         let data = match &self.data {
-            Payload::Host { data, weight } => Payload::Host { data: Cow::Owned(data.to_vec()), weight: *weight },
-            Payload::Device { slot, len, .. } => Payload::Device { slot: *slot, len: *len, host: OnceCell::new(), _borrow: PhantomData },
+            // a borrowed slice outlives the new view (`'a`): same pointer, same `weight` identity -- the library caches packed
+            // weights by (pointer, bytes), so a weight must never be re-labelled onto a temporary copy
+            Payload::Host { data: Cow::Borrowed(b), weight } => Payload::Host { data: Cow::Borrowed(*b), weight: *weight },
+            // owned host data: the view gets its own copy, which is NOT a declared-immutable weight (its address dies with it)
+            Payload::Host { data: Cow::Owned(v), .. } => Payload::Host { data: Cow::Owned(v.clone()), weight: false },
+            Payload::Device { slot, len, keep, .. } => Payload::Device { slot: *slot, len: *len, host: OnceCell::new(), keep: keep.clone(), _borrow: PhantomData },
         };
         TensorView { data, shape: Cow::Owned(shape) }
     }
