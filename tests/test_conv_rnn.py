@@ -205,6 +205,23 @@ def test_oracle_rnn_vs_torch():
 
 # --------------------------------------------------------------------------------------------------- device
 @pytest.mark.gpu
+def test_conv_stats_count_calls_and_macs(ctx):
+    """reset_conv_stats / print_conv_stats (conv2d.rs:75,101; the YOLO example calls them around its timed loop)"""
+    from lele_amd import kernels as K
+    rng = np.random.default_rng(0)
+    x, w = rng.standard_normal((2, 3, 10, 12)).astype(np.float32), rng.standard_normal((5, 3, 3, 3)).astype(np.float32)
+    K.reset_conv_stats(ctx=ctx)
+    assert K.conv_stats(ctx=ctx) == (0, 0)
+    y = K.conv2d(x, w, None, (), 1, (1, 1, 1, 1), (1, 1), ctx=ctx)
+    K.conv2d_silu(x, w, None, (), 1, (0, 0, 0, 0), (2, 2), ctx=ctx)
+    assert y.shape == (2, 5, 10, 12)
+    assert K.conv_stats(ctx=ctx) == (2, 2 * 5 * 10 * 12 * 27 + 2 * 5 * 4 * 5 * 27)
+    K.print_conv_stats(ctx=ctx)
+    K.reset_conv_stats(ctx=ctx)
+    assert K.conv_stats(ctx=ctx) == (0, 0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kat", CONV_KATS, ids=[k[0] for k in CONV_KATS])
 def test_device_conv2d_reference_cases(ctx, kat):
     from lele_amd import kernels as K
