@@ -50,6 +50,7 @@ SECONDS = 30
 VALU_PEAK_TLANE = 78.6  # T lane-ops/s: 256 CUs x 128 lanes x 2.4 GHz
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 I8_PEAK_TOPS = 3944.0   # MI355X_MICROARCH.md: i8 MFMA >= 3944 TOPS measured (16x16x64)
+F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector (= f32-input MFMA) peak
 
 
 def synth_batch(batch, n, seed0):
@@ -269,7 +270,12 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device):
         ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
+            if not args.allow_fallback:  # a scaling number measured on the wrong transport is worse than none
+                raise SystemExit("bench.py: the C ABI's RCCL communicator was not usable on every rank (%s); rerun with --allow-fallback to "
+                                 "measure with torch.distributed's all_gather instead" % (err or "another rank failed"))
             comm, comm_note = None, "torch.distributed all_gather (the C ABI communicator was not usable on every rank: %s)" % (err or "another rank failed")
+        elif comm is not None:  # how many ranks the communicator itself reached (a MAX all-reduce of rank + 1 through the C ABI)
+            rec["rccl_ranks_seen"] = int(comm.allreduce_max(rank + 1))
 
     def build(batch, seconds, seed0):
         n = SAMPLE_RATE * seconds
@@ -471,26 +477,26 @@ def run_rank(args):
                 prof = {}
         # the profile's constants are per launch of prof["batch"] utterances; both scale linearly with the batch
         pscale = args.batch / float(prof["batch"]) if prof.get("batch") else 0.0
+        # the governing roofline of STFT+mel is HBM -- `frac` = algorithmic bytes / kernel time / 8 TB/s.  Beside it:
+        # `compute_frac` = the SURVEY's algorithmic flop count (sparse mel: 0.075 GFLOP per 30 s utterance) / kernel time / the f32
+        # vector peak, and `valu_issue_frac` = issued VALU lane-operations (PMC SQ_INSTS_VALU x the loop's ISA mix) / the measured
+        # issue ceiling: an issue-EFFICIENCY figure (overhead instructions count as work), not a roofline fraction.
+        flop_per_utt = 0.075e9 * (n / float(SAMPLE_RATE * 30))
         roof = {"kernel": "fe_main_kernel", "kernel_ms": round(main_ms, 5), "launches": fe["runs"],
                 "algorithmic_bytes_per_launch": args.batch * fe["bytes_per_utt"],
-                "hbm_achieved": round(achieved, 2), "hbm_peak": HBM_PEAK_GBS, "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": int(prof["hbm_bytes_per_launch"] * pscale) if pscale and prof.get("hbm_bytes_per_launch") else None}
+                "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": int(prof["hbm_bytes_per_launch"] * pscale) if pscale and prof.get("hbm_bytes_per_launch") else None,
+                "compute_frac": round(args.batch * flop_per_utt / (main_ms * 1e-3) / (F32_PEAK_TFLOPS * 1e12), 4) if main_ms > 0 else None,
+                "compute_frac_source": "SURVEY.md 8(d): 0.075 GFLOP per 30 s utterance (FFT 23 040 flop + sparse mel) / kernel time / 157.3 TFLOP/s"}
         lane_ops = int(prof["valu_lane_ops_per_launch"] * pscale) if pscale and prof.get("valu_lane_ops_per_launch") else None
         valu_peak = prof.get("valu_peak_lane_ops_per_s")
         if lane_ops and valu_peak and main_ms > 0:
-            # the governing bound: the bit-exact radix-2 replica needs ~19 VALU lane-ops per algorithmic byte against a ridge of
-            # ~5-10 -> priced against the measured VALU issue ceiling; the HBM fraction stays beside it
             a = lane_ops / (main_ms * 1e-3)
-            roof.update({"bound": "valu", "achieved": round(a / 1e12, 3), "peak": round(valu_peak / 1e12, 3), "unit": "Tlane-op/s",
-                         "frac": round(a / valu_peak, 4), "valu_lane_ops_per_launch": lane_ops,
-                         "peak_source": prof.get("valu_peak_source"),
-                         # the data-sheet figure beside it: 256 CUs x 128 f32 lanes per clock at 2.4 GHz (157.3 TFLOP/s of vector FMA
-                         # in MI355X_MICROARCH.md = 78.6 T lane-ops/s; packed f32 issues at half rate, so it adds nothing); the chip
-                         # sustains ~1.7 GHz under a pure VALU load, which is what the measured peak above reflects
-                         "peak_datasheet": VALU_PEAK_TLANE, "frac_datasheet": round(a / 1e12 / VALU_PEAK_TLANE, 4)})
-        else:
-            roof.update({"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4)})
+            roof.update({"valu_issue_frac": round(a / valu_peak, 4), "valu_lane_ops_per_launch": lane_ops,
+                         "valu_issue_achieved_tlane_ops": round(a / 1e12, 3), "valu_issue_peak_tlane_ops": round(valu_peak / 1e12, 3),
+                         "valu_issue_source": "issued instructions (rocprofv3 SQ_INSTS_VALU x ISA mix, tools/summarize_profile.py) over the "
+                                              "ceiling measured by tools/valu_rate.hip (%s)" % prof.get("valu_peak_source"),
+                         "valu_issue_frac_datasheet": round(a / 1e12 / VALU_PEAK_TLANE, 4)})
         line = {
             "metric": "STFT+mel GB/s (SenseVoice front-end: PCM -> log-mel -> LFR, algorithmic bytes); SenseVoiceSmall-shaped RTF in `sensevoice`",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -602,6 +608,8 @@ def main():
     ap.add_argument("--layers", type=int, default=70)
     ap.add_argument("--no-model", action="store_true", help="front-end leg only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allow-fallback", action="store_true", help="N > 1: if the C ABI's RCCL communicator cannot be set up on every rank, gather the "
+                    "ids with torch.distributed instead of failing (the line then names that transport)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

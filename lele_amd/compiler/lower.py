@@ -810,7 +810,8 @@ class Lowering:
         """matmul_view(Q view, K^T view) -> softmax_scaled -> matmul_view(P, V view [, out_perm, out_reshape]) with private
         intermediates becomes ONE `attention_view` statement (lele_hip_attention_view: the score / probability tensors stay on
         chip).  Shapes are not known here: the run-time form checks the geometry and issues the three calls itself when the
-        kernel does not take it, so the rewrite is always legal."""
+        kernel does not take it -- including chains that are not one strided view of their source, which the three calls
+        materialise exactly as the unfused statements would (kernels.attention_view, plan_runner.hpp attention_view)."""
         sts = self.statements
         outs = {sanitize(o) for o in self.outputs}
         readers = {}
@@ -855,11 +856,13 @@ class Lowering:
             st["fn"] = "attention_view"
             st["args"] = [a[0], a[1], a[2], a[3], b[2], b[3], sm["args"][1], b[4], b[5]]
             st["out"] = list(pv["out"])
+            # everything the fused statement reads beyond the first product's own operands is hoisted to the first product's
+            # position: V and its view chain, the softmax scale, out_perm / out_reshape (run-time `ints` refs included)
             moved_ok = True
-            for r in refs([b[2]], []):
+            for r in refs([b[2], b[3], b[4], b[5], sm["args"][1]], []):
                 if any(r in s2["out"] for s2 in sts[i + 1:rd2[0]]):
                     moved_ok = False
-            if not moved_ok:      # V is produced between the two products: keep the sequence
+            if not moved_ok:      # one of them is produced between the two products: keep the sequence
                 st["fn"], st["args"], st["out"] = "matmul_view", a, [sc]
                 continue
             dead.update((rd[0], rd2[0]))

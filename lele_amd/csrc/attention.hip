@@ -569,6 +569,7 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
         out->rowstat_rows = nstat;
         out->rowstat_len = batch_inner * dh;
         out->rowstat_m = t_q;
+        out->rowstat_batch = batch_outer;
         out->rowstat_kind = 2;
         out->rowstat_valid = true;
     }

@@ -11,6 +11,8 @@
 // unique id is created by rank 0 and handed to the other ranks by whatever launched them -- lele_hip_comm_init_file does that
 // through a file (rank 0 writes <path>.tmp and renames it; the others poll), which needs neither MPI nor torch.
 #include "common.h"
+#include <sys/stat.h>
+#include <time.h>
 
 #include <algorithm>
 
@@ -141,7 +143,10 @@ int lele_hip_comm_init_file(LeleCtx* ctx, const char* path, int rank, int world,
         const int step_ms = 5;
         int waited = 0;
         for (;;) {
-            FILE* f = fopen(path, "rb");
+            // a file left behind by an earlier job would hand out a dead id (and hang ncclCommInitRank): only a file written
+            // within the last minute counts -- rank 0 always (re)writes it, so a fresh one appears or the wait times out
+            struct stat sb;
+            FILE* f = stat(path, &sb) == 0 && time(nullptr) - sb.st_mtime <= 60 ? fopen(path, "rb") : nullptr;
             if (f) {
                 const size_t r = fread(id, 1, sizeof(id), f);
                 fclose(f);

@@ -150,7 +150,7 @@ struct LeleBuf {
     float* rowstat = nullptr;  // [rowstat_rows][2] on the device
     size_t rowstat_cap = 0;    // in rows
     int64_t rowstat_rows = 0, rowstat_len = 0;  // ROWS: pairs = rows, len = row length; WHOLE: pairs = blocks, len = element count
-    int64_t rowstat_m = 0;                      // kind 2: rows per slice
+    int64_t rowstat_m = 0, rowstat_batch = 0;   // kind 2: rows per slice and the number of slices the producer saw
     int rowstat_kind = 0;                       // 0 = one pair per row (LayerNorm); 1 = pairs that together cover the whole tensor;
                                                 // 2 = rowstat_rows / slices pairs per slice of rowstat_m rows of length rowstat_len
     bool rowstat_valid = false;

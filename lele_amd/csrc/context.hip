@@ -304,7 +304,11 @@ int lele_hip_buf_destroy(LeleBuf* b) {
         (void)hipFree(b->data);
         ++b->ctx->generation;
     }
-    if (b->rowstat) (void)hipFree(b->rowstat);
+    if (b->rowstat) {  // a recorded graph may have baked this pointer in (quant.hip reads the pairs): it must not replay either
+        if (!b->data) (void)hipStreamSynchronize(b->ctx->stream);
+        (void)hipFree(b->rowstat);
+        ++b->ctx->generation;
+    }
     delete b;
     return 0;
 }

@@ -1950,7 +1950,7 @@ void find_partials(LeleCtx* ctx, const LeleTensor* input, int64_t batch, int64_t
     if (src->rowstat_kind == 0 && src->rowstat_len == k && src->rowstat_rows == rows) {
         *partial = src->rowstat;  // one pair per row
         *nblk = (int)m;
-    } else if (src->rowstat_kind == 2 && src->rowstat_len == k && src->rowstat_m == m && src->rowstat_rows % batch == 0) {
+    } else if (src->rowstat_kind == 2 && src->rowstat_len == k && src->rowstat_m == m && src->rowstat_batch == batch && src->rowstat_rows % batch == 0) {
         *partial = src->rowstat;  // a fixed number of pairs per slice of m rows (qlinear_onepass_kernel, attention_kernel)
         *nblk = (int)(src->rowstat_rows / batch);
     } else if (src->rowstat_kind == 1 && batch == 1 && src->rowstat_len == rows * k && src->rowstat_rows <= 4096) {
@@ -2096,6 +2096,7 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
             out->rowstat_rows = nstat;
             out->rowstat_len = n;
             out->rowstat_m = m;
+            out->rowstat_batch = batch;
             out->rowstat_kind = 2;
             out->rowstat_valid = true;
         }

@@ -396,20 +396,28 @@ inline ViewGeom walk_chain(const std::vector<int64_t>& src_shape, const Json& ch
     return g;
 }
 
+// Intermediates of fused forms that ran as their node sequence.  The buffers live with the runner and are REUSED by position: a
+// run takes them in the order its fallbacks execute, the next run rewinds and takes the same ones again -- repeated runs of a plan
+// that keeps taking a fallback hold a constant number of device buffers and allocate nothing in the steady state.
+struct FallbackPool {
+    std::vector<std::unique_ptr<Buffer>> bufs;
+    size_t next = 0;
+    Buffer& take() {
+        if (next == bufs.size()) bufs.push_back(std::make_unique<Buffer>());
+        return *bufs[next++];
+    }
+    void rewind() { next = 0; }
+};
+
 // the chain run as the operators it stands for (slice, reshape of a contiguous tensor, transpose) with real copies: the fallback
-// when the chain is not ONE strided view of its source -- shapes are not known when a plan is compiled.  `pool` keeps the
-// intermediate buffers alive with the runner.
-inline TensorView materialise_chain(const TensorView& x, const Json& chain, Buffer* out, std::vector<std::unique_ptr<Buffer>>& pool) {
+// when the chain is not ONE strided view of its source -- shapes are not known when a plan is compiled.
+inline TensorView materialise_chain(const TensorView& x, const Json& chain, Buffer* out, FallbackPool& pool) {
     TensorView cur = x;
     for (size_t i = 0; i < chain.arr.size(); ++i) {
         const Json& step = chain.arr[i];
         const std::string& kind = step.arr.at(0).str;
         const bool last = i + 1 == chain.arr.size();
-        auto dst = [&]() -> Buffer& {
-            if (last && out) return *out;
-            pool.push_back(std::make_unique<Buffer>());
-            return *pool.back();
-        };
+        auto dst = [&]() -> Buffer& { return last && out ? *out : pool.take(); };
         if (kind == "slice") {
             const int64_t axis = step.arr.at(1).as_int(), start = step.arr.at(2).as_int(), len = step.arr.at(3).as_int();
             cur = kernels::slice(cur, {start}, {start + len}, {axis}, {1}, dst());
@@ -428,7 +436,7 @@ inline TensorView materialise_chain(const TensorView& x, const Json& chain, Buff
     return cur;
 }
 
-inline TensorView view_copy(const TensorView& x, const Json& chain, Buffer& out, std::vector<std::unique_ptr<Buffer>>* pool = nullptr) {
+inline TensorView view_copy(const TensorView& x, const Json& chain, Buffer& out, FallbackPool* pool = nullptr) {
     try {
         const ViewGeom g = walk_chain(x.shape, chain);
         return kernels::strided(x, g.shape, g.strides, g.offset, nullptr, out);
@@ -446,7 +454,7 @@ inline TensorView matmul_view_direct(const TensorView& a, const Json& a_chain, c
 // A, ...) run the node sequence the op stands for: materialise the views, `matmul`, transpose / reshape the product.
 inline TensorView matmul_view(const TensorView& a, const Json& a_chain, const TensorView& b, const Json& b_chain,
                               const std::vector<int64_t>* out_perm, const std::vector<int64_t>* out_reshape, Buffer& out,
-                              std::vector<std::unique_ptr<Buffer>>* pool = nullptr) {
+                              FallbackPool* pool = nullptr) {
     try {
         return matmul_view_direct(a, a_chain, b, b_chain, out_perm, out_reshape, out);
     } catch (const Error&) {
@@ -455,8 +463,7 @@ inline TensorView matmul_view(const TensorView& a, const Json& a_chain, const Te
     TensorView am = a_chain.arr.empty() ? a : materialise_chain(a, a_chain, nullptr, *pool);
     TensorView bm = b_chain.arr.empty() ? b : materialise_chain(b, b_chain, nullptr, *pool);
     const bool post = out_perm || out_reshape;
-    pool->push_back(std::make_unique<Buffer>());
-    TensorView res = kernels::matmul(am, bm, post ? *pool->back() : out);
+    TensorView res = kernels::matmul(am, bm, post ? pool->take() : out);
     if (out_perm) res = kernels::transpose(res, *out_perm, out);
     if (out_reshape) res = kernels::reshape(res, *out_reshape);
     return res;
@@ -516,11 +523,18 @@ inline TensorView matmul_view_direct(const TensorView& a, const Json& a_chain, c
 // kernels.py attention_view: softmax(Q K^T * scale) V in one launch when the kernel takes the geometry, else the three calls
 inline TensorView attention_view(const TensorView& q, const Json& q_chain, const TensorView& k, const Json& k_chain, const TensorView& v,
                                  const Json& v_chain, const TensorView& scale, const std::vector<int64_t>* out_perm,
-                                 const std::vector<int64_t>* out_reshape, Buffer& out, Buffer& tmp0, Buffer& tmp1) {
-    const ViewGeom gq = walk_chain(q.shape, q_chain), gk = walk_chain(k.shape, k_chain), gv = walk_chain(v.shape, v_chain);
+                                 const std::vector<int64_t>* out_reshape, Buffer& out, Buffer& tmp0, Buffer& tmp1, FallbackPool* pool = nullptr) {
+    ViewGeom gq, gk, gv;
+    bool is_view = true;
+    try {
+        gq = walk_chain(q.shape, q_chain), gk = walk_chain(k.shape, k_chain), gv = walk_chain(v.shape, v_chain);
+    } catch (const Error&) {  // a chain that is not ONE strided view of its source: the three calls below materialise it, as the
+        if (!pool) throw;     // unfused statements did
+        is_view = false;
+    }
     const size_t r = gq.shape.size();
     const char* off = getenv("LELE_HIP_ATTENTION_FUSED");
-    bool fused = !(off && off[0] == '0') && r == gk.shape.size() && r == gv.shape.size() && r >= 2 && r <= 4;
+    bool fused = is_view && !(off && off[0] == '0') && r == gk.shape.size() && r == gv.shape.size() && r >= 2 && r <= 4;
     if (fused) {
         for (size_t i = 0; i + 2 < r; ++i) fused = fused && gq.shape[i] == gk.shape[i] && gq.shape[i] == gv.shape[i];
         fused = fused && gq.shape[r - 1] == 128 && gk.shape[r - 2] == 128 && gv.shape[r - 1] == 128 && gk.shape[r - 1] == gv.shape[r - 2] &&
@@ -537,11 +551,11 @@ inline TensorView attention_view(const TensorView& q, const Json& q_chain, const
         }
     }
     if (!fused) {
-        TensorView sc = matmul_view(q, q_chain, k, k_chain, nullptr, nullptr, tmp0);
+        TensorView sc = matmul_view(q, q_chain, k, k_chain, nullptr, nullptr, tmp0, pool);
         TensorView pr = kernels::softmax_scaled(sc, scale, -1, tmp1);
         Json none;
         none.kind = Json::Arr;
-        return matmul_view(pr, none, v, v_chain, out_perm, out_reshape, out);
+        return matmul_view(pr, none, v, v_chain, out_perm, out_reshape, out, pool);
     }
     const int64_t tq = gq.shape[r - 2], dh = gq.shape[r - 1], tk = gk.shape[r - 1];
     const int64_t bo = r >= 3 ? gq.shape[0] : 1, bi = r == 4 ? gq.shape[1] : 1;
@@ -606,6 +620,7 @@ class Runner {
         for (const auto& kv : inputs) env_[kv.first] = kv.second;
         calls_ = 0;
         stmt_ = 0;
+        fallback_pool_.rewind();
         exec(plan_.at("statements"));
         std::vector<Val> out;
         for (const Json& o : plan_.at("outputs").arr) out.push_back(env_.at(o.str));
@@ -622,7 +637,7 @@ class Runner {
     std::unordered_map<std::string, std::pair<TV, std::shared_ptr<std::vector<char>>>> weights_;
     std::unordered_map<std::string, Val> env_;
     size_t calls_ = 0, stmt_ = 0;
-    std::vector<std::unique_ptr<Buffer>> fallback_pool_;  // intermediates of fused forms that ran as their node sequence
+    FallbackPool fallback_pool_;  // intermediates of fused forms that ran as their node sequence (rewound at every run)
     Buffer attn_tmp0_, attn_tmp1_;  // scores / probabilities of an attention_view statement that runs as the three-call sequence
 
     std::string wkey(const Json& w) const { return v2_ ? weight_key(w) : std::to_string(w.arr[1].as_int()); }
@@ -1013,7 +1028,7 @@ class Runner {
             if (!is_none(a[7])) perm = ints(a[7]);
             if (!is_none(a[8])) resh = ints(a[8]);
             return set(st, 0, attention_view(tensor(a[0]), a[1].at("chain"), tensor(a[2]), a[3].at("chain"), tensor(a[4]), a[5].at("chain"),
-                                             tensor(a[6]), is_none(a[7]) ? nullptr : &perm, is_none(a[8]) ? nullptr : &resh, o, attn_tmp0_, attn_tmp1_));
+                                             tensor(a[6]), is_none(a[7]) ? nullptr : &perm, is_none(a[8]) ? nullptr : &resh, o, attn_tmp0_, attn_tmp1_, &fallback_pool_));
         }
         if (fn == "concat") {
             std::vector<TV> hold;

@@ -911,10 +911,16 @@ def attention_view(q, q_chain, k, k_chain, v, v_chain, scale, out_perm=None, out
     non-unit inner strides, LELE_HIP_ATTENTION_FUSED=0) run the three-call sequence this op stands for."""
     import os
     ctx = _ctx(ctx)
-    qsh, qst, qoff = _walk_chain(_shape_of(q), q_chain or [])
-    ksh, kst, koff = _walk_chain(_shape_of(k), k_chain or [])
-    vsh, vst, voff = _walk_chain(_shape_of(v), v_chain or [])
-    fused = (os.environ.get("LELE_HIP_ATTENTION_FUSED", "1") != "0" and len(qsh) == len(ksh) == len(vsh) and 2 <= len(qsh) <= 4
+    try:
+        qsh, qst, qoff = _walk_chain(_shape_of(q), q_chain or [])
+        ksh, kst, koff = _walk_chain(_shape_of(k), k_chain or [])
+        vsh, vst, voff = _walk_chain(_shape_of(v), v_chain or [])
+        is_view = True
+    except _lib.LeleError:  # a chain that is not ONE strided view of its source (a Reshape that needs a copy mid-chain): the
+        is_view = False     # three calls this op stands for materialise it, exactly as the unfused statements did
+        qsh = ksh = vsh = qst = kst = vst = [0, 0]
+        qoff = koff = voff = 0
+    fused = (is_view and os.environ.get("LELE_HIP_ATTENTION_FUSED", "1") != "0" and len(qsh) == len(ksh) == len(vsh) and 2 <= len(qsh) <= 4
              and qsh[:-2] == ksh[:-2] == vsh[:-2] and qsh[-1] == 128 and ksh[-2] == 128 and vsh[-1] == 128 and ksh[-1] == vsh[-2] <= 512
              and qst[-1] == 1 and kst[-2] == 1 and vst[-1] == 1 and all(s % 4 == 0 for s in qst[:-1] + kst[:-2] + kst[-1:]) and qoff % 4 == 0 and koff % 4 == 0
              and (out_perm is None or out_perm[-1] % len(out_perm) == len(out_perm) - 1))

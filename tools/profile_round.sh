@@ -4,7 +4,7 @@
 #   then here: python tools/summarize_profile.py <tag>
 # Counters are collected in their own rocprofv3 passes with --kernel-trace only (no sys / hip / hsa trace domains).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -33,7 +33,27 @@ timeout 200 python $R/tools/qlinear_bench.py --out "$OUT/qlinear.json" > "$OUT/q
 timeout 120 python $R/tools/attention_bench.py > "$OUT/attention_bench.json" 2> "$OUT/attention_bench.log"
 timeout 120 python $R/tools/attention_stamps.py > "$OUT/attention_stamps.txt" 2> "$OUT/attention_stamps.log"
 timeout 120 python $R/tools/wholek_stamps.py > "$OUT/wholek_stamps.txt" 2> "$OUT/wholek_stamps.log"
-# 7. the sharded recogniser step through the C ABI alone (native runner, RCCL group of one rank per visible GPU)
-timeout 200 $R/lele_amd/lele_run --help > /dev/null 2>&1
+# 7. the sharded recogniser step through the C ABI alone: the native runner on a 2-layer SenseVoice-shaped plan, one rank per visible
+#    GPU (fork before any HIP call, file rendezvous, RCCL all-gather of the decoded ids through lele_hip_comm_*)
+NGPU=$(python3 -c "import torch; print(max(1, torch.cuda.device_count()))" 2>/dev/null || echo 1)
+( cd $R && timeout 250 python3 - "$OUT" <<'PY'
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import lele_amd
+from lele_amd.compiler import compile_model
+from sensevoice_graph import Encoder, encoder_onnx
+out = sys.argv[1]
+ctx = lele_amd._lib.Ctx(0)
+enc = Encoder(ctx, 2)
+plan, blob = compile_model(encoder_onnx(enc, 8), "sensevoice_shaped")
+json.dump(plan, open(os.path.join(out, "sv2_plan.json"), "w"))
+open(os.path.join(out, "sv2_weights.bin"), "wb").write(blob)
+np.random.default_rng(0).standard_normal((8, 167, 560)).astype(np.float32).tofile(os.path.join(out, "sv2_feats.bin"))
+PY
+) > "$OUT/lele_run_prepare.log" 2>&1
+timeout 200 $R/lele_amd/lele_run "$OUT/sv2_plan.json" "$OUT/sv2_weights.bin" --input feats="$OUT/sv2_feats.bin":f32:8,167,560 --out "$OUT/sv2_out" \
+    --runs 5 --ranks $NGPU --decode > "$OUT/lele_run_ranks.json" 2> "$OUT/lele_run_ranks.log"
+rm -f "$OUT/sv2_weights.bin" "$OUT"/sv2_out*.bin "$OUT/sv2_feats.bin"
 find "$OUT" -name '*.csv' | wc -l
 tail -c 400 "$OUT/bench_plain.json"
