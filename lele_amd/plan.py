@@ -189,6 +189,7 @@ class Runner:
         self.profile = None
         self.stmt_index = 0
         self.shapes = None  # set to {} to record the shape of every tensor value of the next run
+        self.taps = None    # set to {name: None, ...}: host copies of those results are left there by the next run (tests)
 
     def _wkey(self, node):
         return weight_key(node) if self.v2 else node[1]
@@ -357,3 +358,7 @@ class Runner:
                 else:
                     for name, r in zip(st["out"], res):
                         env[name] = r
+                if self.taps:  # test aid: host copies of named results, taken before their workspace slot is reused
+                    for name in st["out"]:
+                        if name in self.taps:
+                            self.taps[name] = env[name].numpy().copy()

@@ -9,6 +9,8 @@ rounding and the activations diverge chaotically layer after layer (SURVEY.md 7,
   * layer 0 and layer 69 of the device run against the ORACLE composed operator by operator (oracle/sensevoice_ref.py), each
     operator fed the device's own input for it ("parity on the same inputs", BASELINE.json): LayerNorm, the four quantised
     linears, softmax and the residual adds bit-exact; the FSMN convolution and the two attention products within 1e-4 relative;
+  * the plan AS IT SHIPS (one-launch attention, fused feed-forward block): layers 0 and 69 tapped from the run, every statement
+    against the oracle on the device's own input of it -- attention_view within 2e-4, everything integer-exact bit for bit;
   * decode on the device (arg-max + token filter) == the oracle's greedy decode of the device's logits;
   * the batch split property on a shallow stack: utterances are independent, so a batch of 32 and two batches of 16 agree.
 """
@@ -26,13 +28,13 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4  # BASELINE.json: "mel and NN ops within 1e-4 relative f32"
 
 
-def close(a, b, what):
-    """|a - b| <= 1e-4 * |b| + 1e-4 * rms(b): relative to the element, with the tensor's own scale as the floor for elements
+def close(a, b, what, rtol=RTOL):
+    """|a - b| <= rtol * |b| + rtol * rms(b): relative to the element, with the tensor's own scale as the floor for elements
     that cancel to ~0 (a sum of K products has an absolute error of ~ulp * K * |terms|, not of its own magnitude)"""
     b = np.asarray(b, np.float32)
-    floor = RTOL * float(np.sqrt(np.mean(np.square(b, dtype=np.float64)))) + 1e-6
-    bad = np.abs(a - b) > RTOL * np.abs(b) + floor
-    assert not bad.any(), "%s: %d of %d elements outside 1e-4 (max abs diff %.3g)" % (what, int(bad.sum()), b.size, float(np.abs(a - b).max()))
+    floor = rtol * float(np.sqrt(np.mean(np.square(b, dtype=np.float64)))) + 1e-6
+    bad = np.abs(a - b) > rtol * np.abs(b) + floor
+    assert not bad.any(), "%s: %d of %d elements outside %g (max abs diff %.3g)" % (what, int(bad.sum()), b.size, rtol, float(np.abs(a - b).max()))
 
 
 def same(a, b, what):
@@ -86,6 +88,46 @@ def check_layer_against_oracle(taps, L, tag):
     same(taps["y"], taps["x1"] + taps["h2"], tag + " final add")
 
 
+def check_shipped_layer_against_oracle(tp, i, L, tag):
+    """One layer of the plan AS IT SHIPS (one-launch attention, FSMN in place, residual adds in the projection's store, the
+    feed-forward block as one call with its hidden layer never stored): every statement's result, tapped from the run, against the
+    oracle composed operator by operator on the device's own input of that statement."""
+    from oracle import pyoracle as O
+    from oracle import sensevoice_ref as R
+    D, H, DH = 512, 4, 128
+    n = lambda s: "l%d_%s" % (i, s)   # noqa: E731
+    x = tp["x0"] if i == 0 else tp["l%d_x2" % (i - 1)]
+    b, t, _ = x.shape
+    same(tp[n("xn")], O.layer_norm(x, L["ln1"][0], L["ln1"][1], -1, 1e-5), tag + " layer_norm 1")
+    qkv = tp[n("qkv")]
+    same(qkv, R.qlinear(tp[n("xn")], L["qkv"]), tag + " qkv linear")
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    vt = np.ascontiguousarray(v.transpose(0, 2, 1))
+    mem = np.ascontiguousarray(O.conv1d(vt, L["fsmn"], None, [1], D, [5, 5], [1]).transpose(0, 2, 1)) + v
+    close(tp[n("mem")], mem, tag + " fsmn memory (depthwise_conv1d_tlc)")
+    # attention_view: softmax(Q K^T * scale) V with the heads merged, against the oracle's composition of the DEVICE's qkv
+    qh = np.ascontiguousarray(q.reshape(b, t, H, DH).transpose(0, 2, 1, 3))
+    kh = np.ascontiguousarray(k.reshape(b, t, H, DH).transpose(0, 2, 3, 1))
+    vh = np.ascontiguousarray(v.reshape(b, t, H, DH).transpose(0, 2, 1, 3))
+    pr = O.softmax(O.matmul(qh, kh) * np.float32(DH ** -0.5), -1)
+    av = np.ascontiguousarray(O.matmul(pr, vh).transpose(0, 2, 1, 3)).reshape(b, t, D)
+    # 2e-4 (tests/test_attention.py's bar) -- on all but a vanishing number of elements: the softmax amplifies the f32 round-off
+    # of a score by the score's own magnitude, and a random-weight layer has query rows whose two largest scores nearly tie, where
+    # ANY two correct evaluations part by more than that (1 of 2.8 M elements of layer 0 at configs[3]).  Those stay within 1 %
+    # of the tensor's scale; where the batched sequence shares the kernel's summation order the run below is bit-identical to it.
+    got = tp[n("avm")]
+    rms = float(np.sqrt(np.mean(np.square(av, dtype=np.float64))))
+    bad = np.abs(got - av) > 2e-4 * np.abs(av) + 2e-4 * rms + 1e-6
+    assert bad.mean() <= 1e-5, "%s attention_view (one launch): %d of %d elements outside 2e-4" % (tag, int(bad.sum()), bad.size)
+    assert float(np.abs(got - av).max()) <= 1e-2 * rms, "%s attention_view: max abs diff %.3g against scale %.3g" % (tag, float(np.abs(got - av).max()), rms)
+    att = R.qlinear(tp[n("avm")], L["out"])
+    x1 = (att + tp[n("mem")]) + x if L["d_in"] == D else att + tp[n("mem")]
+    same(tp[n("x1")], x1, tag + " output projection + residual adds (fused_quantized_linear_residual)")
+    same(tp[n("x1n")], O.layer_norm(tp[n("x1")], L["ln2"][0], L["ln2"][1], -1, 1e-5), tag + " layer_norm 2")
+    h = R.qlinear(tp[n("x1n")], L["ffn1"], True)
+    same(tp[n("x2")], tp[n("x1")] + R.qlinear(h, L["ffn2"]), tag + " feed-forward block + residual (fused_ffn_quantized)")
+
+
 def run_config(ctx, model, batch, seconds, check_layers):
     from lele_amd import kernels as K
     from lele_amd._lib import Weight
@@ -112,8 +154,16 @@ def run_config(ctx, model, batch, seconds, check_layers):
         same(logits.numpy(), hand, "compiled plan vs hand-issued sequence")
     finally:
         del os.environ["LELE_HIP_ATTENTION_FUSED"]
-    hand = runner.run({"feats": feats})[0].numpy()      # from here on: the plan as it ships (attention in one launch)
-    assert np.isfinite(hand).all()
+    # from here on: the plan as it ships (attention in one launch) -- with its first and last layer tapped against the oracle
+    names = ["x0", "l%d_x2" % (check_layers[-1] - 1)] + ["l%d_%s" % (i, s) for i in check_layers for s in ("xn", "qkv", "mem", "avm", "x1", "x1n", "x2")]
+    runner.taps = {nm: None for nm in names}
+    hand = runner.run({"feats": feats})[0].numpy()
+    tp, runner.taps = runner.taps, None
+    assert np.isfinite(hand).all() and all(v is not None for v in tp.values())
+    for i in check_layers:
+        check_shipped_layer_against_oracle(tp, i, arrays["layers"][i], "shipped plan, layer %d" % i)
+    if batch > 1:  # the batched sequence runs the tiled GEMM, whose summation order the one-launch kernel shares: 70 chaotic layers
+        same(hand, logits.numpy(), "shipped plan (one-launch attention) vs the same plan with attention as its three calls")
     ctx.sync()
     ctx.graph_begin()
     logits = runner.run({"feats": feats})[0]
