@@ -49,6 +49,49 @@ struct AttnArgs {
     long long* dbg;    // developer switch LELE_HIP_ATTN_STAMPS: 8 cycle-counter stamps per workgroup (tools/attention_stamps.py), or NULL
 };
 
+// ---- split-bf16 products (the default; LELE_HIP_ATTENTION_EXACT=1 keeps the f32 MFMA of the node sequence) ---------------------
+// The f32-input MFMA runs at the f32 VECTOR rate -- 64 cycles per 32x32x2 -- and, measured here, on the vector pipe's time: making
+// the softmax 10x cheaper did not move the kernel while the products were f32.  A bf16 MFMA does eight times the k extent in
+// half the cycles, so an f32 value is cut into three bf16 pieces of 8 mantissa bits each (hi + mid + lo == x EXACTLY: truncation,
+// then exact remainders) and a product becomes six bf16 MFMAs (hh, hm, mh, hl, lh, mm; the three dropped terms are <= 2^-24
+// of the product: f32-rounding class).  Six 32-cycle instructions per 16 k against eight 64-cycle ones: 2.7x, on the matrix
+// cores proper, with the vector pipe free for the split arithmetic and the softmax.  The result is the exact product's to ~1e-7
+// relative -- inside the 1e-4 bar of the f32 GEMM family like every other summation order -- but not its bits.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Split3 {
+    u32x4 h, m, l;  // eight values each, as bf16 pairs: element e in the low (even e) / high (odd e) half of word e / 2
+};
+__device__ __forceinline__ unsigned top16_pair(float even, float odd) {  // the upper halves of two f32 words side by side: one v_perm_b32
+    return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u);
+}
+__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
+    float r[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        r[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xffff0000u);  // exact: the low 16 mantissa bits
+        q[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xffff0000u);  // exact: the last 8
+    }
+    Split3 s;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        s.h[p] = top16_pair(x[2 * p], x[2 * p + 1]);
+        s.m[p] = top16_pair(r[2 * p], r[2 * p + 1]);
+        s.l[p] = top16_pair(q[2 * p], q[2 * p + 1]);
+    }
+    return s;
+}
+#define LELE_BF(v) __builtin_bit_cast(bf16x8, v)
+// acc += A . B over 16 k (32x32 tile): smallest terms first
+__device__ __forceinline__ void mm6_32(const Split3& a, const Split3& b, f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_BF(a.m), LELE_BF(b.m), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_BF(a.h), LELE_BF(b.l), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_BF(a.l), LELE_BF(b.h), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_BF(a.h), LELE_BF(b.m), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_BF(a.m), LELE_BF(b.h), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_BF(a.h), LELE_BF(b.h), acc, 0, 0, 0);
+}
+
 constexpr int kDh = 128;   // head dimension (8 chunks of 16)
 constexpr int kSPad = 4;   // LDS row padding (floats)
 
@@ -56,7 +99,7 @@ constexpr int kSPad = 4;   // LDS row padding (floats)
 // pair up: wave w owns row tile w & 1 throughout; in phase 1 it takes every second key tile of that row tile (three each for the six
 // tiles of a 10 s utterance: balanced, where RT = 1 leaves two of four waves with half the work), in phase 3 two of the four
 // 32-dim output tiles, fed by ONE set of P fragments.  K and V are read half as often.
-template <int NT, int RT>
+template <int NT, int RT, bool EXACT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attention_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_sp[];  // S, then P: [32 * RT][tpad + 4]
     __shared__ float s_mm[4][2];
@@ -108,14 +151,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
             qf[2 * c + 1] = *reinterpret_cast<const float4*>(src + 16 * c + 4);
         }
     }
+    // split-bf16 route: the query row's three pieces are made once (96 registers), the keys' per chunk as they arrive
+    Split3 qs[EXACT ? 1 : 8];
+    if constexpr (!EXACT) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float qa[8] = {qf[2 * c].x, qf[2 * c].y, qf[2 * c].z, qf[2 * c].w, qf[2 * c + 1].x, qf[2 * c + 1].y, qf[2 * c + 1].z, qf[2 * c + 1].w};
+            qs[c] = split3(qa);
+        }
+    }
     auto mmk = [&](const float4 (&w)[8], int half, f32x16& acc) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float4 q0 = qf[2 * (4 * half + c)], q1 = qf[2 * (4 * half + c) + 1];
-            const float qa[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
             const float kk[8] = {w[2 * c].x, w[2 * c].y, w[2 * c].z, w[2 * c].w, w[2 * c + 1].x, w[2 * c + 1].y, w[2 * c + 1].z, w[2 * c + 1].w};
+            if constexpr (EXACT) {
+                const float4 q0 = qf[2 * (4 * half + c)], q1 = qf[2 * (4 * half + c) + 1];
+                const float qa[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
-            for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], kk[s], acc, 0, 0, 0);
+                for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], kk[s], acc, 0, 0, 0);
+            } else {
+                mm6_32(qs[4 * half + c], split3(kk), acc);
+            }
         }
     };
     for (int t = kw; t < ntile; t += kstep) {
@@ -159,8 +215,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (!(a.ablate & 1)) softmax_row_reg<NT>(v[q], a.tk, l);
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (EXACT) softmax_row_reg<NT>(v[q], a.tk, l);
+                else softmax_row_fast<NT>(v[q], a.tk, l);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float* row = s_sp + (g * 4 * RT + 4 * r4 + q) * pitch;
@@ -206,10 +264,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
         for (int c = 0; c < 2; ++c) {
             const float4 p0 = *reinterpret_cast<const float4*>(prow + j0 + 16 * c), p1 = *reinterpret_cast<const float4*>(prow + j0 + 16 * c + 4);
             const float pa[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+            if constexpr (EXACT) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
+                for (int s = 0; s < 8; ++s)
 #pragma unroll
-                for (int d = 0; d < ND; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], w[d][8 * c + s], oacc[d], 0, 0, 0);
+                    for (int d = 0; d < ND; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[s], w[d][8 * c + s], oacc[d], 0, 0, 0);
+            } else {
+                const Split3 ps = split3(pa);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    const float vv[8] = {w[d][8 * c], w[d][8 * c + 1], w[d][8 * c + 2], w[d][8 * c + 3], w[d][8 * c + 4], w[d][8 * c + 5], w[d][8 * c + 6], w[d][8 * c + 7]};
+                    mm6_32(ps, split3(vv), oacc[d]);
+                }
+            }
         }
     };
     reqv(va);
@@ -273,7 +340,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // NW = waves per workgroup (4; with 8 a wave owns one 16-wide output tile and a 32-lane group one softmax row)
-template <int NT, int NW>
+// acc += A . B over 32 k (16x16 tile: lane group g supplies k-slice g of the instruction's 32, eight values per lane)
+__device__ __forceinline__ void mm6_16(const Split3& a, const Split3& b, f32x4v& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(LELE_BF(a.m), LELE_BF(b.m), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(LELE_BF(a.h), LELE_BF(b.l), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(LELE_BF(a.l), LELE_BF(b.h), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(LELE_BF(a.h), LELE_BF(b.m), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(LELE_BF(a.m), LELE_BF(b.h), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(LELE_BF(a.h), LELE_BF(b.h), acc, 0, 0, 0);
+}
+
+template <int NT, int NW, bool EXACT>
 __global__ __launch_bounds__(64 * NW) void attention16_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float s_sp[];  // S, then P: [16][tpad + 4]
     __shared__ float s_mm[NW][2];
@@ -313,14 +390,32 @@ __global__ __launch_bounds__(64 * NW) void attention16_kernel(AttnArgs a) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) qf[c] = *reinterpret_cast<const float4*>(src + 4 * c);
     }
+    // split-bf16 route: instruction c of four pairs, in lane group g, the dims 32 g + 8 c + [0, 8) of both operands (any assignment
+    // of k to (instruction, lane group, position) is a valid order as long as Q and K share it)
+    Split3 qs[EXACT ? 1 : 4];
+    if constexpr (!EXACT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float qa[8] = {qf[2 * c].x, qf[2 * c].y, qf[2 * c].z, qf[2 * c].w, qf[2 * c + 1].x, qf[2 * c + 1].y, qf[2 * c + 1].z, qf[2 * c + 1].w};
+            qs[c] = split3(qa);
+        }
+    }
     auto mmk = [&](const float4 (&w)[8], int t) {
         f32x4v acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (EXACT) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[c].x, w[c].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[c].y, w[c].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[c].z, w[c].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[c].w, w[c].w, acc, 0, 0, 0);
+            for (int c = 0; c < 8; ++c) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[c].x, w[c].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[c].y, w[c].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[c].z, w[c].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[c].w, w[c].w, acc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float kk[8] = {w[2 * c].x, w[2 * c].y, w[2 * c].z, w[2 * c].w, w[2 * c + 1].x, w[2 * c + 1].y, w[2 * c + 1].z, w[2 * c + 1].w};
+                mm6_16(qs[c], split3(kk), acc);
+            }
         }
         // C layout of the 16x16 MFMA: column (key) = r16, row = 4 g + register
         float* dst = s_sp + (4 * g) * pitch + t * 16 + r16;
@@ -358,7 +453,10 @@ __global__ __launch_bounds__(64 * NW) void attention16_kernel(AttnArgs a) {
             }
         }
 #pragma unroll
-        for (int q = 0; q < RPG; ++q) softmax_row_reg<NT>(v[q], a.tk, l);
+        for (int q = 0; q < RPG; ++q) {
+            if constexpr (EXACT) softmax_row_reg<NT>(v[q], a.tk, l);
+            else softmax_row_fast<NT>(v[q], a.tk, l);
+        }
 #pragma unroll
         for (int q = 0; q < RPG; ++q) {
             float* row = s_sp + (gi * RPG + q) * pitch;
@@ -397,14 +495,28 @@ __global__ __launch_bounds__(64 * NW) void attention16_kernel(AttnArgs a) {
 #pragma unroll
     for (int d = 0; d < ND; ++d) oacc[d] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
     auto mmv = [&](const float (&w)[ND][16], int c0) {
+        if constexpr (EXACT) {
 #pragma unroll
-        for (int u4 = 0; u4 < 4; ++u4) {
-            const float4 p = *reinterpret_cast<const float4*>(prow + c0 + 4 * u4);
-            const float pa[4] = {p.x, p.y, p.z, p.w};
+            for (int u4 = 0; u4 < 4; ++u4) {
+                const float4 p = *reinterpret_cast<const float4*>(prow + c0 + 4 * u4);
+                const float pa[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int d = 0; d < ND; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[e], w[d][4 * u4 + e], oacc[d], 0, 0, 0);
+                    for (int d = 0; d < ND; ++d) oacc[d] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[e], w[d][4 * u4 + e], oacc[d], 0, 0, 0);
+            }
+        } else {  // the lane group's 16 keys of the set as two instructions of 8
+#pragma unroll
+            for (int u8 = 0; u8 < 2; ++u8) {
+                const float4 p0 = *reinterpret_cast<const float4*>(prow + c0 + 8 * u8), p1 = *reinterpret_cast<const float4*>(prow + c0 + 8 * u8 + 4);
+                const float pa[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+                const Split3 ps = split3(pa);
+#pragma unroll
+                for (int d = 0; d < ND; ++d) {
+                    const float vv[8] = {w[d][8 * u8], w[d][8 * u8 + 1], w[d][8 * u8 + 2], w[d][8 * u8 + 3], w[d][8 * u8 + 4], w[d][8 * u8 + 5], w[d][8 * u8 + 6], w[d][8 * u8 + 7]};
+                    mm6_16(ps, split3(vv), oacc[d]);
+                }
+            }
         }
     };
     reqv(va);
@@ -449,6 +561,175 @@ __global__ __launch_bounds__(64 * NW) void attention16_kernel(AttnArgs a) {
                 mx = s_mm[w][1] > mx ? s_mm[w][1] : mx;
             }
             float* dst = a.stat + ((int64_t)bo * (a.batch_inner * a.nqb) + bi * a.nqb + qb) * 2;
+            dst[0] = mn;
+            dst[1] = mx;
+        }
+    }
+}
+
+// ---- large grids (a batch of utterances): one pass over the keys, nothing but registers between the two products ----------------
+// The kernels above put S in LDS between three barrier-separated phases and let every lane fetch its key row with a 6 KB lane
+// stride; with the products on split-bf16 their life is those loads (stamps: 20 k of 41 k cycles in the score phase for 2.3 k of
+// MFMA).  This one is organised around what the matrix cores want:
+//   * S^T = K Q^T and O^T = V^T P^T, so that the lane index is the QUERY in every accumulator (C layout: lane = column): a lane
+//     owns query i for 16 keys of the tile (S^T), then supplies exactly those 16 probabilities as the B operand of the second
+//     product (its k order is ours to choose: V's fragments are read in the same key order), and owns query i for 64 output
+//     dimensions (O^T).  The row maximum / sum of a query live in ONE lane pair: no LDS round trip, no 32-lane butterflies, and
+//     the running rescale of the online softmax is one multiplier per lane;
+//   * a workgroup = three compute waves (three 32-row blocks of one head) + one loader wave that streams the head's K and V
+//     tiles into an LDS ring with direct-to-LDS loads (K rows XOR-swizzled at the source so that the fragment reads are
+//     conflict-free), each tile fetched ONCE per workgroup with fully coalesced 1 KiB requests; one s_barrier per key tile;
+//   * softmax is the online form (running maximum m, running sum l, O rescaled by exp(m_old - m_new) per tile), on v_exp_f32.
+// Same values as the node sequence to ~1e-6 relative (tests/test_attention.py holds it to the oracle at 2e-4 like the other
+// kernels), not its bits: LELE_HIP_ATTENTION_EXACT=1 keeps the replica above.
+constexpr int FA_NS = 3, FA_TILE = 32 * 512, FA_SLOT = 2 * FA_TILE;  // ring slots of {K tile, V tile}: 32 keys x 128 dims x 4 B each
+
+__device__ __forceinline__ void fa_dma16(const void* gsrc, unsigned lds_dst) {  // LDS address = lds_dst (wave-uniform) + 16 * lane
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attention_flash_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char fa_lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hv = lane >> 5, l31 = lane & 31;
+    const int qb = blockIdx.x % a.nqb, bh = blockIdx.x / a.nqb;
+    const int bi = bh % a.batch_inner, bo = bh / a.batch_inner;
+    const float* kp = a.k + bo * a.k_so + bi * a.k_si;
+    const float* vp = a.v + bo * a.v_so + bi * a.v_si;
+    const int nkt = (a.tk + 31) / 32;
+    auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
+    if (wave == 3) {
+        // ------------------------------------------------------------ the loader: 32 direct-to-LDS loads per key tile
+        const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)fa_lds;
+        auto issue = [&](int t) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)(t % FA_NS) * FA_SLOT);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {  // LDS rows 2q, 2q + 1 of the tile: lane l -> row 2q + (l >> 5), 16-byte unit l & 31
+                const int row = 2 * q + hv;
+                int key = 32 * t + row;
+                key = key < a.tk ? key : a.tk - 1;  // keys beyond the last re-read it: masked in the softmax
+                // K: unit p of LDS row `row` holds unit p ^ row of the key's 512 bytes (the fragment read of lane `row` undoes it)
+                fa_dma16(kp + (int64_t)key * a.k_sr + 4 * (l31 ^ row), dst + 1024 * q);
+                fa_dma16(vp + (int64_t)key * a.v_sr + 4 * l31, dst + FA_TILE + 1024 * q);
+            }
+        };
+        issue(0);
+        if (nkt > 1) issue(1);
+        for (int t = 0; t < nkt; ++t) {
+            // this wave's counter sees only its own 32 loads per tile: tile t has landed when at most the next tile's are in flight
+            if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            barrier();  // tile t is in LDS for everybody; every compute wave has finished with tile t - 1
+            if (t + 2 < nkt) issue(t + 2);  // into the slot tile t - 1 occupied
+        }
+        return;
+    }
+    // ---------------------------------------------------------------- a compute wave: 32 query rows of the head
+    const int i0 = (qb * 3 + wave) * 32;
+    const bool live = i0 < a.tq;  // a row block past the last query only keeps the barriers company
+    const int row = i0 + l31;
+    const bool rok = row < a.tq;
+    const float sc = a.scale ? a.scale[0] : 1.0f;
+    constexpr float L2E = 1.44269504088896341f;
+    Split3 qs[8];
+    if (live) {
+        const float* src = a.q + bo * a.q_so + bi * a.q_si + (int64_t)(rok ? row : a.tq - 1) * a.q_sr + 8 * hv;  // padded rows re-read the last; never stored
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 q0 = *reinterpret_cast<const float4*>(src + 16 * c), q1 = *reinterpret_cast<const float4*>(src + 16 * c + 4);
+            const float qa[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            qs[c] = split3(qa);
+        }
+    }
+    f32x16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.0f;
+    float m_run = -3.40282347e+38f, l_run = 0.0f;
+    for (int t = 0; t < nkt; ++t) {
+        barrier();  // tile t has landed
+        if (!live) continue;
+        const char* const kt = fa_lds + (t % FA_NS) * FA_SLOT;
+        const float* const vt = reinterpret_cast<const float*>(kt + FA_TILE);
+        // S^T tile: A = K (lane = key l31, k-slice hv), B = Q (lane = query l31, k-slice hv)
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const char* krow = kt + l31 * 512;
+            const float4 k0 = *reinterpret_cast<const float4*>(krow + 16 * ((4 * c + 2 * hv) ^ l31));
+            const float4 k1 = *reinterpret_cast<const float4*>(krow + 16 * ((4 * c + 2 * hv + 1) ^ l31));
+            const float kk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+            mm6_32(split3(kk), qs[c], st);
+        }
+        // online softmax: this lane holds query l31's scores for the keys 32 t + (r & 3) + 8 (r >> 2) + 4 hv; its partner lane the rest
+        float mt = -3.40282347e+38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hv;
+            st[r] = key < a.tk ? st[r] * sc : -3.40282347e+38f;
+            mt = fmaxf(mt, st[r]);
+        }
+        mt = fmaxf(mt, swap32(mt));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);  // 0 on the first tile (m_run = -FLT_MAX)
+        float p[16], lsum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hv;
+            p[r] = key < a.tk ? __builtin_amdgcn_exp2f((st[r] - m_new) * L2E) : 0.0f;
+            lsum += p[r];
+        }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        // O^T += V^T P^T: B = P (lane = query, its 8 probabilities of chunk c2 in register order), A = V^T (lane = output dim, the
+        // same 8 keys in the same order: rows 16 c2 + 4 hv + {0..3} and 16 c2 + 8 + 4 hv + {0..3} of the tile)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            const float pa[8] = {p[8 * c2], p[8 * c2 + 1], p[8 * c2 + 2], p[8 * c2 + 3], p[8 * c2 + 4], p[8 * c2 + 5], p[8 * c2 + 6], p[8 * c2 + 7]};
+            const Split3 ps = split3(pa);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                float vv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[e] = vt[(16 * c2 + 4 * hv + (e & 3) + 8 * (e >> 2)) * 128 + 32 * d + l31];
+                mm6_32(split3(vv), ps, o[d]);
+            }
+        }
+    }
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+    if (live) {
+        const float lfull = l_run + swap32(l_run);
+        const float inv = 1.0f / lfull;
+        float* orow = a.o + bo * a.o_so + bi * a.o_si + (int64_t)(rok ? row : a.tq - 1) * a.o_sr;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float4 w;
+                w.x = o[d][4 * g4] * inv, w.y = o[d][4 * g4 + 1] * inv, w.z = o[d][4 * g4 + 2] * inv, w.w = o[d][4 * g4 + 3] * inv;
+                if (rok) {
+                    *reinterpret_cast<float4*>(orow + 32 * d + 8 * g4 + 4 * hv) = w;
+                    mn = fminf(mn, fminf(fminf(w.x, w.y), fminf(w.z, w.w)));
+                    mx = fmaxf(mx, fmaxf(fmaxf(w.x, w.y), fmaxf(w.z, w.w)));
+                }
+            }
+    }
+    if (a.stat) {  // one {min, max} pair per compute wave (neutral for an idle one): 3 nqb pairs per (utterance, head)
+        mn = wave_allreduce64(mn, [](float cur, float x) { return x < cur ? x : cur; });
+        mx = wave_allreduce64(mx, [](float cur, float x) { return x > cur ? x : cur; });
+        if (lane == 0) {
+            float* dst = a.stat + (((int64_t)bo * a.batch_inner + bi) * (a.nqb * 3) + qb * 3 + wave) * 2;
             dst[0] = mn;
             dst[1] = mx;
         }
@@ -513,12 +794,20 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
     a.batch_inner = (int)batch_inner;
     // two row tiles per workgroup when that still leaves three workgroups per CU (what fits at once); one otherwise (measured:
     // 32 x 171 rows 47.9 us with one tile against 54.2 us with two; 64 x 171 rows 92.6 against 73.8)
+    // LELE_HIP_ATTENTION_EXACT=1: f32 MFMA products in the tiled GEMM's k order and the reference's row softmax -- the bits of the node
+    // sequence (where that runs the tiled GEMM); default: split-bf16 products and the chip's exponential (same values to ~1e-6)
+    const char* ex_env = getenv("LELE_HIP_ATTENTION_EXACT");
+    const bool exact = ex_env && *ex_env && atoi(ex_env) != 0;
     const char* rt_env = getenv("LELE_HIP_ATTENTION_RT");
     const int rt = rt_env && *rt_env ? atoi(rt_env) : (fb * ((t_q + 63) / 64) >= 3 * (int64_t)ctx->num_cus ? 2 : 1);
     // small grids (one utterance: 64 blocks of 32 rows for 256 CUs): 16 query rows per workgroup
     const char* rows_env = getenv("LELE_HIP_ATTENTION_ROWS");
     const bool rows16 = rows_env && *rows_env ? atoi(rows_env) == 16 : fb * ((t_q + 31) / 32) < (int64_t)ctx->num_cus / 2;
-    const int qrows = rows16 ? 16 : (rt == 2 ? 64 : 32);
+    // one pass over the keys with a loader wave (attention_flash_kernel): a batch of heads that gives every CU a workgroup of
+    // three 32-row blocks; 16-byte aligned V rows for its direct-to-LDS loads
+    const bool flash = !exact && !rows16 && fb * ((t_q + 95) / 96) >= (int64_t)ctx->num_cus / 2 && ok16(a.v, a.v_so, a.v_si, a.v_sr) && a.o_sr % 4 == 0 &&
+                       aligned16(a.o) && a.o_so % 4 == 0 && a.o_si % 4 == 0 && !(rt_env && *rt_env) && !(rows_env && *rows_env);
+    const int qrows = flash ? 96 : (rows16 ? 16 : (rt == 2 ? 64 : 32));
     a.nqb = (int)((t_q + qrows - 1) / qrows);
     a.scale = (const float*)dsc;
     a.dbg = nullptr;
@@ -527,7 +816,7 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
     if (const char* e = getenv("LELE_HIP_ATTN_STAMPS")) a.dbg = (long long*)(uintptr_t)strtoull(e, nullptr, 0);
     // result statistics for the dynamic quantisation that reads this tensor next: valid when a slice of the consumer is exactly
     // one outer batch element, i.e. the result is laid out [batch_outer][t_q][batch_inner * dh] (heads merged)
-    const int64_t per_slice = (int64_t)a.batch_inner * a.nqb, nstat = batch_outer * per_slice;
+    const int64_t per_slice = (int64_t)a.batch_inner * a.nqb * (flash ? 3 : 1), nstat = batch_outer * per_slice;
     const bool merged = ov->stride_row == batch_inner * dh && ov->stride_inner == dh && ov->stride_outer == t_q * batch_inner * dh && ov->offset == 0;
     if (merged && nstat <= (int64_t(1) << 22)) {
         LELE_TRY(out->reserve_rowstat(nstat));
@@ -535,23 +824,33 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
     }
     const size_t lds = (size_t)qrows * (a.tpad + kSPad) * 4;
     const dim3 grid((unsigned)(fb * a.nqb));
-#define LELE_ATTN(NT_, RT_)                                                                                                \
+#define LELE_ATTN1(KERN_)                                                                                                  \
     do {                                                                                                                 \
-        auto kern = attention_kernel<NT_, RT_>;                                                                           \
+        auto kern = KERN_;                                                                                               \
         if (lds > 60 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));               \
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, a);                                                   \
+    } while (0)
+#define LELE_ATTN(NT_, RT_)                                              \
+    do {                                                               \
+        if (exact) LELE_ATTN1((attention_kernel<NT_, RT_, true>));      \
+        else LELE_ATTN1((attention_kernel<NT_, RT_, false>));           \
     } while (0)
     // softmax registers per lane = key tiles exactly (tpad / 32, even): a 10 s utterance needs 6, not 8 -- the row softmax is a third
     // of the kernel's instructions (tools/attention_stamps.py) and every surplus register row is exponentials nobody reads
 #define LELE_ATTN_NT(NT_)                                                                                      \
     do {                                                                                                       \
-        if (rows16) {                                                                                          \
-            auto kern = attention16_kernel<NT_, 4>; /* eight waves measured no better: 24.5 against 24.1 us */ \
-            if (lds > 60 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)); \
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, a);                                     \
+        if (rows16) { /* eight waves measured no better: 24.5 against 24.1 us */                               \
+            if (exact) LELE_ATTN1((attention16_kernel<NT_, 4, true>));                                         \
+            else LELE_ATTN1((attention16_kernel<NT_, 4, false>));                                              \
         } else if (rt == 2) LELE_ATTN(NT_, 2);                                                                 \
         else LELE_ATTN(NT_, 1);                                                                                \
     } while (0)
+    if (flash) {
+        auto kern = attention_flash_kernel;
+        constexpr int flds = FA_NS * FA_SLOT;
+        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), flds));
+        hipLaunchKernelGGL(kern, grid, dim3(256), flds, ctx->stream, a);
+    } else
     switch (a.tpad / 64) {
         case 1: LELE_ATTN_NT(2); break;
         case 2: LELE_ATTN_NT(4); break;
@@ -564,6 +863,7 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
     }
 #undef LELE_ATTN_NT
 #undef LELE_ATTN
+#undef LELE_ATTN1
     LELE_HIP_CHECK(hipGetLastError());
     if (a.stat) {
         out->rowstat_rows = nstat;

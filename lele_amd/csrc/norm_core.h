@@ -92,4 +92,30 @@ __device__ __forceinline__ void softmax_row_reg(float (&v)[NT], int len, int l) 
     for (int c = 0; c < NT; ++c) v[c] = v[c] * inv_sum;
 }
 
+// The same row as softmax_row_reg with the chip's own exponential and tree reductions: exp(x) = v_exp_f32(x * log2 e), the sum over
+// the 32-lane group on the DPP / permlane network, one reciprocal.  ~60 vector instructions per row of 171 against ~670 for the
+// replica of lele's polynomial / libm-tail / 4 x 8-accumulator routine (which cost the one-launch attention kernel 36 % of its
+// life).  Not the reference's bits: the probabilities agree with avx/norm.rs:139-229 to ~1e-6 relative (v_exp_f32 is good to
+// 1 ulp; the argument's rounding costs |x| * 6e-8, and a term of size |x| carries exp(-|x|) of the row's weight).  Used only
+// INSIDE lele_hip_attention_view, whose products already differ from the node sequence by summation order; the stand-alone
+// softmax operator stays bit-exact.
+template <int NT>
+__device__ __forceinline__ void softmax_row_fast(float (&v)[NT], int len, int l) {
+    float m = -3.40282347e+38f;
+#pragma unroll
+    for (int c = 0; c < NT; ++c)
+        if (32 * c + l < len) m = fmaxf(m, v[c]);
+    m = group_max32(m);
+    float sum = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+        v[c] = 32 * c + l < len ? __builtin_amdgcn_exp2f((v[c] - m) * 1.44269504088896341f) : 0.0f;
+        sum += v[c];
+    }
+    sum = group_allreduce32(sum, [](float a, float b) { return a + b; });
+    const float inv_sum = 1.0f / sum;
+#pragma unroll
+    for (int c = 0; c < NT; ++c) v[c] = v[c] * inv_sum;
+}
+
 }  // namespace lele

@@ -69,6 +69,37 @@ def test_attention_view_against_oracle_and_sequence(ctx, orc, b, t, rt):
     close(seq, o, "the sequence vs oracle composition", rtol=2e-4)
 
 
+@pytest.mark.parametrize("b,t", [(32, 171), (40, 33), (33, 100), (130, 1), (16, 512), (35, 65), (40, 8), (32, 96), (32, 97)])
+def test_one_pass_attention_of_a_batch_against_the_oracle(ctx, orc, b, t):
+    """grids of >= 128 workgroups take attention_flash_kernel (loader wave + LDS ring, S^T / O^T in registers, online softmax,
+    split-bf16 products): against the oracle's operator composition at the same 2e-4 as the other forms, and against the
+    LELE_HIP_ATTENTION_EXACT=1 replica (f32 MFMA, the reference's row softmax) -- edge cases: one key, keys not a multiple of 32,
+    exactly / one more than a workgroup's 96 query rows, 512 keys (the maximum), row blocks with nothing to do"""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    rng = np.random.default_rng(b * 77 + t)
+    qkv = (rng.standard_normal((b, t, 3 * H * DH)) * 1.5).astype(np.float32)
+    scale = Weight(np.array([DH ** -0.5], np.float32))
+    qd = ctx.buf().upload(qkv)
+    got = K.attention_view(qd, QC, qd, KC, qd, VC, scale, [0, 2, 1, 3], [0, 0, H * DH], ctx=ctx).numpy()
+    q = np.ascontiguousarray(qkv[..., :512].reshape(b, t, H, DH).transpose(0, 2, 1, 3))
+    kT = np.ascontiguousarray(qkv[..., 512:1024].reshape(b, t, H, DH).transpose(0, 2, 3, 1))
+    v = np.ascontiguousarray(qkv[..., 1024:].reshape(b, t, H, DH).transpose(0, 2, 1, 3))
+    p = orc.softmax(orc.matmul(q, kT) * np.float32(DH ** -0.5), -1)
+    o = np.ascontiguousarray(orc.matmul(p, v).transpose(0, 2, 1, 3)).reshape(b, t, H * DH)
+    close(got, o, "one-pass attention vs oracle composition", rtol=2e-4)
+    with _env(LELE_HIP_ATTENTION_EXACT=1):
+        ex = K.attention_view(qd, QC, qd, KC, qd, VC, scale, [0, 2, 1, 3], [0, 0, H * DH], ctx=ctx).numpy()
+    close(got, ex, "one-pass attention vs the f32 replica kernel")
+    close(ex, o, "replica vs oracle composition", rtol=2e-4)
+    # no scale operand: plain softmax(Q K^T) V
+    got1 = K.attention_view(qd, QC, qd, KC, qd, VC, None, [0, 2, 1, 3], [0, 0, H * DH], ctx=ctx).numpy()
+    p1 = orc.softmax(orc.matmul(q, kT), -1)
+    o1 = np.ascontiguousarray(orc.matmul(p1, v).transpose(0, 2, 1, 3)).reshape(b, t, H * DH)
+    bad = np.abs(got1 - o1) > 2e-4 * np.abs(o1) + 2e-4 * float(np.sqrt(np.mean(np.square(o1, dtype=np.float64)))) + 1e-7
+    assert bad.mean() <= 1e-5 and np.abs(got1 - o1).max() <= 1e-2   # unscaled scores of |s| ~ 30: near-ties amplify f32 round-off (see test_fullsize_graph)
+
+
 def test_attention_statistics_feed_the_output_projection(ctx, orc):
     """the kernel leaves {min, max} per (utterance, head, row block) next to its result; the quantised output projection that
     reads it derives its per-utterance range from them -- same bits as the projection of a host copy (own range pass)"""

@@ -33,7 +33,9 @@ def main():
         dst = ctx.buf()
         flops = 2 * 2 * b * H * t * t * DH
         row = {}
-        for label, env in (("fused rt=1", {"LELE_HIP_ATTENTION_RT": "1", "LELE_HIP_ATTENTION_MIN_BLOCKS": "1", "LELE_HIP_ATTENTION_ROWS": "32"}),
+        for label, env in (("default (one pass over the keys for a batch)", {"LELE_HIP_ATTENTION_MIN_BLOCKS": "1"}),
+                           ("replica (LELE_HIP_ATTENTION_EXACT=1)", {"LELE_HIP_ATTENTION_MIN_BLOCKS": "1", "LELE_HIP_ATTENTION_EXACT": "1"}),
+                           ("fused rt=1", {"LELE_HIP_ATTENTION_RT": "1", "LELE_HIP_ATTENTION_MIN_BLOCKS": "1", "LELE_HIP_ATTENTION_ROWS": "32"}),
                            ("fused rt=2", {"LELE_HIP_ATTENTION_RT": "2", "LELE_HIP_ATTENTION_MIN_BLOCKS": "1", "LELE_HIP_ATTENTION_ROWS": "32"}),
                            ("fused 16 rows", {"LELE_HIP_ATTENTION_RT": "1", "LELE_HIP_ATTENTION_MIN_BLOCKS": "1", "LELE_HIP_ATTENTION_ROWS": "16"}),
                            ("sequence", {"LELE_HIP_ATTENTION_FUSED": "0"})):
