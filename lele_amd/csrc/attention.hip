@@ -569,79 +569,144 @@ __global__ __launch_bounds__(64 * NW) void attention16_kernel(AttnArgs a) {
 
 // ---- large grids (a batch of utterances): one pass over the keys, nothing but registers between the two products ----------------
 // The kernels above put S in LDS between three barrier-separated phases and let every lane fetch its key row with a 6 KB lane
-// stride; with the products on split-bf16 their life is those loads (stamps: 20 k of 41 k cycles in the score phase for 2.3 k of
-// MFMA).  This one is organised around what the matrix cores want:
+// stride; with the products on split-bf16 their life is those loads and the operand splits (stamps: 20 k of 41 k cycles in the
+// score phase for 2.3 k of MFMA).  This one is organised around what the matrix cores want:
 //   * S^T = K Q^T and O^T = V^T P^T, so that the lane index is the QUERY in every accumulator (C layout: lane = column): a lane
 //     owns query i for 16 keys of the tile (S^T), then supplies exactly those 16 probabilities as the B operand of the second
-//     product (its k order is ours to choose: V's fragments are read in the same key order), and owns query i for 64 output
+//     product (its k order is ours to choose: V's fragments are built in the same key order), and owns query i for 64 output
 //     dimensions (O^T).  The row maximum / sum of a query live in ONE lane pair: no LDS round trip, no 32-lane butterflies, and
 //     the running rescale of the online softmax is one multiplier per lane;
-//   * a workgroup = three compute waves (three 32-row blocks of one head) + one loader wave that streams the head's K and V
-//     tiles into an LDS ring with direct-to-LDS loads (K rows XOR-swizzled at the source so that the fragment reads are
-//     conflict-free), each tile fetched ONCE per workgroup with fully coalesced 1 KiB requests; one s_barrier per key tile;
+//   * a workgroup = four compute waves (four 32-row blocks of one head) + four PRODUCER waves, one of each per SIMD.  The
+//     producers fetch the head's K and V tiles (32 keys) from global memory into registers one tile ahead, split every value
+//     into its three bf16 pieces ONCE per workgroup, and store the pieces in LDS in MFMA fragment order (1 KiB = the 16 bytes
+//     of each of the 64 lanes): a compute wave's operand is three conflict-free ds_read_b128, and its instruction stream is
+//     MFMA + softmax only -- the splits issue on the same SIMD's VALU from the other wave while the matrix core runs;
+//   * two LDS stages of {K pieces, V pieces} (48 KiB each), one s_barrier per key tile;
 //   * softmax is the online form (running maximum m, running sum l, O rescaled by exp(m_old - m_new) per tile), on v_exp_f32.
 // Same values as the node sequence to ~1e-6 relative (tests/test_attention.py holds it to the oracle at 2e-4 like the other
 // kernels), not its bits: LELE_HIP_ATTENTION_EXACT=1 keeps the replica above.
-constexpr int FA_NS = 3, FA_TILE = 32 * 512, FA_SLOT = 2 * FA_TILE;  // ring slots of {K tile, V tile}: 32 keys x 128 dims x 4 B each
+constexpr int FA_PART = 8 * 3 * 1024, FA_STAGE = 2 * FA_PART, FA_LDS = 2 * FA_STAGE;  // 8 fragments x 3 pieces x 1 KiB, K then V
+constexpr int FA_ROWS = 128;                                                          // query rows of a workgroup
 
-__device__ __forceinline__ void fa_dma16(const void* gsrc, unsigned lds_dst) {  // LDS address = lds_dst (wave-uniform) + 16 * lane
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_dst)
-                 : "memory");
-}
+#ifdef LELE_HIP_LAB
+#define FA_STAMP(n_) \
+    if (a.dbg && lane == 0) a.dbg[((size_t)blockIdx.x * 8 + wave) * 64 + (n_)] = (long long)clock64()
+#else
+#define FA_STAMP(n_)
+#endif
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attention_flash_kernel(AttnArgs a) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_flash_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char fa_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hv = lane >> 5, l31 = lane & 31;
-    const int qb = blockIdx.x % a.nqb, bh = blockIdx.x / a.nqb;
+    // workgroup b runs on XCD b % 8 (each with its own L2): the nqb workgroups of a head are 8 apart in b, so the second one's K / V
+    // come out of the L2 the first one filled (heads in groups of 8; a ragged last group keeps the plain order)
+    int qb = blockIdx.x % a.nqb, bh = blockIdx.x / a.nqb;
+    {
+        const int per = 8 * a.nqb, grp = blockIdx.x / per, heads = (int)(gridDim.x / a.nqb);
+        if ((grp + 1) * 8 <= heads) {
+            const int in = blockIdx.x - grp * per;
+            bh = grp * 8 + (in & 7);
+            qb = in >> 3;
+        }
+    }
     const int bi = bh % a.batch_inner, bo = bh / a.batch_inner;
-    const float* kp = a.k + bo * a.k_so + bi * a.k_si;
-    const float* vp = a.v + bo * a.v_so + bi * a.v_si;
     const int nkt = (a.tk + 31) / 32;
     auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
-    if (wave == 3) {
-        // ------------------------------------------------------------ the loader: 32 direct-to-LDS loads per key tile
-        const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)fa_lds;
-        auto issue = [&](int t) {
-            const unsigned dst = __builtin_amdgcn_readfirstlane(base + (unsigned)(t % FA_NS) * FA_SLOT);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {  // LDS rows 2q, 2q + 1 of the tile: lane l -> row 2q + (l >> 5), 16-byte unit l & 31
-                const int row = 2 * q + hv;
-                int key = 32 * t + row;
+    if (wave >= 4) {
+        // ------------------------------------------------------------ a producer: four of a tile's sixteen operand fragments
+        const int pw = wave - 4;          // 0, 1: K chunks 4 pw .. 4 pw + 3;  2, 3: V^T fragments of key half c2 = pw - 2
+        const bool is_k = pw < 2;
+        const float* kp = a.k + bo * a.k_so + bi * a.k_si + 8 * hv + 64 * pw;  // K: lane = key l31, dims 16 c + 8 hv + [0, 8)
+        const float* vp = a.v + bo * a.v_so + bi * a.v_si + l31;               // V^T: lane = dim 32 d + l31, keys 16 c2 + 4 hv + {0..3, 8..11}
+        const int c2 = pw - 2;
+        char* const part = fa_lds + (is_k ? pw * 4 : 8 + c2 * 4) * 3072 + lane * 16;
+        float r0[4][8], r1[4][8], r2[4][8];  // three tiles of this wave's fragments: one being split, two in flight
+        auto fetch = [&](float (&r)[4][8], int t) {
+            t = t < nkt ? t : nkt - 1;  // past the end: the last tile again (never stored anywhere a compute wave reads)
+            if (is_k) {
+                int key = 32 * t + l31;
                 key = key < a.tk ? key : a.tk - 1;  // keys beyond the last re-read it: masked in the softmax
-                // K: unit p of LDS row `row` holds unit p ^ row of the key's 512 bytes (the fragment read of lane `row` undoes it)
-                fa_dma16(kp + (int64_t)key * a.k_sr + 4 * (l31 ^ row), dst + 1024 * q);
-                fa_dma16(vp + (int64_t)key * a.v_sr + 4 * l31, dst + FA_TILE + 1024 * q);
+                const float* src = kp + (int64_t)key * a.k_sr;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float4 k0 = *reinterpret_cast<const float4*>(src + 16 * c), k1 = *reinterpret_cast<const float4*>(src + 16 * c + 4);
+                    r[c][0] = k0.x, r[c][1] = k0.y, r[c][2] = k0.z, r[c][3] = k0.w, r[c][4] = k1.x, r[c][5] = k1.y, r[c][6] = k1.z, r[c][7] = k1.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    int key = 32 * t + 16 * c2 + 4 * hv + (e & 3) + 8 * (e >> 2);
+                    key = key < a.tk ? key : a.tk - 1;
+                    const float* src = vp + (int64_t)key * a.v_sr;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) r[d][e] = src[32 * d];
+                }
             }
         };
-        issue(0);
-        if (nkt > 1) issue(1);
-        for (int t = 0; t < nkt; ++t) {
-            // this wave's counter sees only its own 32 loads per tile: tile t has landed when at most the next tile's are in flight
-            if (t + 1 < nkt) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            barrier();  // tile t is in LDS for everybody; every compute wave has finished with tile t - 1
-            if (t + 2 < nkt) issue(t + 2);  // into the slot tile t - 1 occupied
+        auto put = [&](const float (&r)[4][8], int stage) {
+#ifdef LELE_HIP_LAB
+            if (a.ablate & 4) return;
+#endif
+            char* dst = part + stage * FA_STAGE;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const Split3 sp = split3(r[f]);
+                *reinterpret_cast<u32x4*>(dst + f * 3072) = sp.h;
+                *reinterpret_cast<u32x4*>(dst + f * 3072 + 1024) = sp.m;
+                *reinterpret_cast<u32x4*>(dst + f * 3072 + 2048) = sp.l;
+            }
+        };
+        FA_STAMP(0);
+        // tile 0 alone first: every workgroup of the grid starts at once, and what they ask for in their first microsecond is
+        // served at HBM speed -- Q and the first tile are all the first product needs (stamps: with three tiles requested up
+        // front the first operand reached LDS 14 k cycles into a 50 k cycle kernel)
+        fetch(r0, 0);
+        FA_STAMP(1);
+        put(r0, 0);
+        fetch(r1, 1);
+        fetch(r2, 2);
+        FA_STAMP(2);
+        barrier();  // stage 0 holds tile 0
+        FA_STAMP(3);
+        // tile t (compute waves on stage t & 1): refill the registers tile t came from with tile t + 3, split tile t + 1 into
+        // the other stage (its loads were issued two tiles ago).  Past the end the clamped tile lands where nobody reads.
+#define LELE_FA_STEP(FREE_, NEXT_, STAGE_) \
+    {                                      \
+        fetch(FREE_, t + 3);               \
+        FA_STAMP(4 + 3 * t);               \
+        put(NEXT_, STAGE_);                \
+        FA_STAMP(5 + 3 * t);               \
+        barrier();                         \
+        FA_STAMP(6 + 3 * t);               \
+        if (++t >= nkt) break;             \
+    }
+        for (int t = 0;;) {
+            LELE_FA_STEP(r0, r1, 1)
+            LELE_FA_STEP(r1, r2, 0)
+            LELE_FA_STEP(r2, r0, 1)
+            LELE_FA_STEP(r0, r1, 0)
+            LELE_FA_STEP(r1, r2, 1)
+            LELE_FA_STEP(r2, r0, 0)
         }
+#undef LELE_FA_STEP
         return;
     }
     // ---------------------------------------------------------------- a compute wave: 32 query rows of the head
-    const int i0 = (qb * 3 + wave) * 32;
+    const int i0 = (qb * 4 + wave) * 32;
     const bool live = i0 < a.tq;  // a row block past the last query only keeps the barriers company
     const int row = i0 + l31;
     const bool rok = row < a.tq;
-    const float sc = a.scale ? a.scale[0] : 1.0f;
-    constexpr float L2E = 1.44269504088896341f;
+    // the scores in the exponent's own unit: Q carries scale * log2(e) into the product (one rounding of q instead of one of s)
+    const float sc = (a.scale ? a.scale[0] : 1.0f) * 1.44269504088896341f;
     Split3 qs[8];
+    FA_STAMP(0);
     if (live) {
         const float* src = a.q + bo * a.q_so + bi * a.q_si + (int64_t)(rok ? row : a.tq - 1) * a.q_sr + 8 * hv;  // padded rows re-read the last; never stored
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float4 q0 = *reinterpret_cast<const float4*>(src + 16 * c), q1 = *reinterpret_cast<const float4*>(src + 16 * c + 4);
-            const float qa[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+            const float qa[8] = {q0.x * sc, q0.y * sc, q0.z * sc, q0.w * sc, q1.x * sc, q1.y * sc, q1.z * sc, q1.w * sc};
             qs[c] = split3(qa);
         }
     }
@@ -650,86 +715,131 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int d = 0; d < 4; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.0f;
+    // m_run: the exponent offset in use (log2 units).  It follows the running maximum only when that has grown by more than 8
+    // since the last move: probabilities then reach 2^8 at most -- harmless in f32 and in the bf16 pieces -- and the rescale of
+    // O and l, 66 multiplies a lane, happens on the first tile and then hardly ever instead of on every tile.  The final
+    // division by l makes the offset's value immaterial.
     float m_run = -3.40282347e+38f, l_run = 0.0f;
+    auto frag = [&](const char* p) {
+        Split3 f;
+        f.h = *reinterpret_cast<const u32x4*>(p);
+        f.m = *reinterpret_cast<const u32x4*>(p + 1024);
+        f.l = *reinterpret_cast<const u32x4*>(p + 2048);
+        return f;
+    };
+    FA_STAMP(1);
+    barrier();  // tile 0 is in stage 0
+    FA_STAMP(2);
     for (int t = 0; t < nkt; ++t) {
-        barrier();  // tile t has landed
-        if (!live) continue;
-        const char* const kt = fa_lds + (t % FA_NS) * FA_SLOT;
-        const float* const vt = reinterpret_cast<const float*>(kt + FA_TILE);
-        // S^T tile: A = K (lane = key l31, k-slice hv), B = Q (lane = query l31, k-slice hv)
-        f32x16 st;
+        if (live) {
+            const char* const kt = fa_lds + (t & 1) * FA_STAGE + lane * 16;
+            const char* const vt = kt + FA_PART;
+            // S^T tile: A = K (lane = key l31, k-slice hv), B = Q (lane = query l31, k-slice hv)
+            // Two accumulators, alternating by chunk: an instruction between two MFMAs on the SAME accumulator stalls the matrix
+            // core for ~43 cycles (the dependent pair must be adjacent), between different ones it costs its issue slot -- and
+            // every chunk boundary carries the next fragment's three LDS reads, issued BEFORE the six products of the current
+            // one (left to itself the scheduler sinks them to just above their first use).
+            f32x16 st, st2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+            for (int r = 0; r < 16; ++r) st[r] = 0.0f, st2[r] = 0.0f;
+            Split3 kf = frag(kt);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);  // (the groups below are matched in order: these three are chunk 0's)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const char* krow = kt + l31 * 512;
-            const float4 k0 = *reinterpret_cast<const float4*>(krow + 16 * ((4 * c + 2 * hv) ^ l31));
-            const float4 k1 = *reinterpret_cast<const float4*>(krow + 16 * ((4 * c + 2 * hv + 1) ^ l31));
-            const float kk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
-            mm6_32(split3(kk), qs[c], st);
-        }
-        // online softmax: this lane holds query l31's scores for the keys 32 t + (r & 3) + 8 (r >> 2) + 4 hv; its partner lane the rest
-        float mt = -3.40282347e+38f;
+            for (int c = 0; c < 8; ++c) {
+                Split3 kn = kf;
+                if (c < 7) kn = frag(kt + (c + 1) * 3072);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                if (c & 1) mm6_32(kf, qs[c], st2);
+                else mm6_32(kf, qs[c], st);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                kf = kn;
+            }
+            Split3 vf = frag(vt);  // the first V^T fragment travels during the softmax
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hv;
-            st[r] = key < a.tk ? st[r] * sc : -3.40282347e+38f;
-            mt = fmaxf(mt, st[r]);
-        }
-        mt = fmaxf(mt, swap32(mt));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * L2E);  // 0 on the first tile (m_run = -FLT_MAX)
-        float p[16], lsum = 0.0f;
+            for (int r = 0; r < 16; ++r) st[r] += st2[r];
+            // online softmax: this lane holds query l31's scores for the keys 32 t + (r & 3) + 8 (r >> 2) + 4 hv; its partner lane the rest
+            if (32 * t + 32 > a.tk) {  // only the last tile can hold keys that do not exist
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hv;
-            p[r] = key < a.tk ? __builtin_amdgcn_exp2f((st[r] - m_new) * L2E) : 0.0f;
-            lsum += p[r];
-        }
-        l_run = l_run * alpha + lsum;
-        m_run = m_new;
+                for (int r = 0; r < 16; ++r) st[r] = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hv < a.tk ? st[r] : -3.40282347e+38f;
+            }
+            float mt = st[0];
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+            for (int r = 1; r < 16; ++r) mt = fmaxf(mt, st[r]);
+            mt = fmaxf(mt, swap32(mt));
+            FA_STAMP(3 + 4 * t);  // the scores are out of the matrix core
+            if (__builtin_amdgcn_ballot_w64(mt > m_run + 8.0f) != 0) {  // wave-uniform: some query's maximum outgrew its offset
+                const float m_new = mt > m_run + 8.0f ? mt : m_run;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 0 on the first tile (m_run = -FLT_MAX), 1 for a lane that stays
+                l_run *= alpha;
+                m_run = m_new;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-        // O^T += V^T P^T: B = P (lane = query, its 8 probabilities of chunk c2 in register order), A = V^T (lane = output dim, the
-        // same 8 keys in the same order: rows 16 c2 + 4 hv + {0..3} and 16 c2 + 8 + 4 hv + {0..3} of the tile)
+                for (int d = 0; d < 4; ++d)
 #pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            const float pa[8] = {p[8 * c2], p[8 * c2 + 1], p[8 * c2 + 2], p[8 * c2 + 3], p[8 * c2 + 4], p[8 * c2 + 5], p[8 * c2 + 6], p[8 * c2 + 7]};
-            const Split3 ps = split3(pa);
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            }
+            float p[16], lsum = 0.0f;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                float vv[8];
+            for (int r = 0; r < 16; ++r) {
+                p[r] = __builtin_amdgcn_exp2f(st[r] - m_run);  // a masked key: exp2(-FLT_MAX - m) = 0
+                lsum += p[r];
+            }
+            l_run += lsum;
+            FA_STAMP(4 + 4 * t);
+            // O^T += V^T P^T: B = P (lane = query, its 8 probabilities of key half c2 in register order), A = V^T (lane = output
+            // dim, the same 8 keys in the same order: rows 16 c2 + 4 hv + {0..3} and 16 c2 + 8 + 4 hv + {0..3} of the tile)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) vv[e] = vt[(16 * c2 + 4 * hv + (e & 3) + 8 * (e >> 2)) * 128 + 32 * d + l31];
-                mm6_32(split3(vv), ps, o[d]);
+            for (int c2 = 0; c2 < 2; ++c2) {
+                const float pa[8] = {p[8 * c2], p[8 * c2 + 1], p[8 * c2 + 2], p[8 * c2 + 3], p[8 * c2 + 4], p[8 * c2 + 5], p[8 * c2 + 6], p[8 * c2 + 7]};
+                const Split3 ps = split3(pa);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    Split3 vn = vf;
+                    if (c2 * 4 + d < 7) vn = frag(vt + (c2 * 4 + d + 1) * 3072);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    mm6_32(vf, ps, o[d]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    vf = vn;
+                }
             }
         }
+        FA_STAMP(5 + 4 * t);
+        barrier();  // done with this stage; the next tile is in the other one
+        FA_STAMP(6 + 4 * t);
     }
+    // every wave of the workgroup is past the last barrier: the stages are free.  O^T leaves through LDS so that the stores are
+    // whole 512-byte rows (a lane owns a QUERY: stored directly, every instruction would touch 32 rows with 16 bytes each)
     float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
     if (live) {
         const float lfull = l_run + swap32(l_run);
         const float inv = 1.0f / lfull;
-        float* orow = a.o + bo * a.o_so + bi * a.o_si + (int64_t)(rok ? row : a.tq - 1) * a.o_sr;
+        constexpr int kRowB = 512 + 16;  // padded row: the 16-byte column writes of 32 rows spread over the banks
+        char* const mine = fa_lds + wave * (32 * kRowB);
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 float4 w;
                 w.x = o[d][4 * g4] * inv, w.y = o[d][4 * g4 + 1] * inv, w.z = o[d][4 * g4 + 2] * inv, w.w = o[d][4 * g4 + 3] * inv;
+                *reinterpret_cast<float4*>(mine + l31 * kRowB + (32 * d + 8 * g4 + 4 * hv) * 4) = w;
                 if (rok) {
-                    *reinterpret_cast<float4*>(orow + 32 * d + 8 * g4 + 4 * hv) = w;
                     mn = fminf(mn, fminf(fminf(w.x, w.y), fminf(w.z, w.w)));
                     mx = fmaxf(mx, fmaxf(fmaxf(w.x, w.y), fmaxf(w.z, w.w)));
                 }
             }
+        float* obase = a.o + bo * a.o_so + bi * a.o_si + 4 * l31;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {  // rows 2 q + hv of the block: this wave wrote them itself (same-wave LDS order holds)
+            const int r = 2 * q + hv;
+            const float4 w = *reinterpret_cast<const float4*>(mine + r * kRowB + l31 * 16);
+            if (i0 + r < a.tq) *reinterpret_cast<float4*>(obase + (int64_t)(i0 + r) * a.o_sr) = w;
+        }
     }
-    if (a.stat) {  // one {min, max} pair per compute wave (neutral for an idle one): 3 nqb pairs per (utterance, head)
+    FA_STAMP(63);
+    if (a.stat) {  // one {min, max} pair per compute wave (neutral for an idle one): 4 nqb pairs per (utterance, head)
         mn = wave_allreduce64(mn, [](float cur, float x) { return x < cur ? x : cur; });
         mx = wave_allreduce64(mx, [](float cur, float x) { return x > cur ? x : cur; });
         if (lane == 0) {
-            float* dst = a.stat + (((int64_t)bo * a.batch_inner + bi) * (a.nqb * 3) + qb * 3 + wave) * 2;
+            float* dst = a.stat + (((int64_t)bo * a.batch_inner + bi) * (a.nqb * 4) + qb * 4 + wave) * 2;
             dst[0] = mn;
             dst[1] = mx;
         }
@@ -803,11 +913,11 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
     // small grids (one utterance: 64 blocks of 32 rows for 256 CUs): 16 query rows per workgroup
     const char* rows_env = getenv("LELE_HIP_ATTENTION_ROWS");
     const bool rows16 = rows_env && *rows_env ? atoi(rows_env) == 16 : fb * ((t_q + 31) / 32) < (int64_t)ctx->num_cus / 2;
-    // one pass over the keys with a loader wave (attention_flash_kernel): a batch of heads that gives every CU a workgroup of
-    // three 32-row blocks; 16-byte aligned V rows for its direct-to-LDS loads
-    const bool flash = !exact && !rows16 && fb * ((t_q + 95) / 96) >= (int64_t)ctx->num_cus / 2 && ok16(a.v, a.v_so, a.v_si, a.v_sr) && a.o_sr % 4 == 0 &&
+    // one pass over the keys with producer waves (attention_flash_kernel): a batch of heads that gives at least half of the CUs a
+    // workgroup of four 32-row blocks
+    const bool flash = !exact && !rows16 && fb * ((t_q + FA_ROWS - 1) / FA_ROWS) >= (int64_t)ctx->num_cus / 2 && a.o_sr % 4 == 0 &&
                        aligned16(a.o) && a.o_so % 4 == 0 && a.o_si % 4 == 0 && !(rt_env && *rt_env) && !(rows_env && *rows_env);
-    const int qrows = flash ? 96 : (rows16 ? 16 : (rt == 2 ? 64 : 32));
+    const int qrows = flash ? FA_ROWS : (rows16 ? 16 : (rt == 2 ? 64 : 32));
     a.nqb = (int)((t_q + qrows - 1) / qrows);
     a.scale = (const float*)dsc;
     a.dbg = nullptr;
@@ -816,7 +926,7 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
     if (const char* e = getenv("LELE_HIP_ATTN_STAMPS")) a.dbg = (long long*)(uintptr_t)strtoull(e, nullptr, 0);
     // result statistics for the dynamic quantisation that reads this tensor next: valid when a slice of the consumer is exactly
     // one outer batch element, i.e. the result is laid out [batch_outer][t_q][batch_inner * dh] (heads merged)
-    const int64_t per_slice = (int64_t)a.batch_inner * a.nqb * (flash ? 3 : 1), nstat = batch_outer * per_slice;
+    const int64_t per_slice = (int64_t)a.batch_inner * a.nqb * (flash ? 4 : 1), nstat = batch_outer * per_slice;
     const bool merged = ov->stride_row == batch_inner * dh && ov->stride_inner == dh && ov->stride_outer == t_q * batch_inner * dh && ov->offset == 0;
     if (merged && nstat <= (int64_t(1) << 22)) {
         LELE_TRY(out->reserve_rowstat(nstat));
@@ -847,9 +957,8 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
     } while (0)
     if (flash) {
         auto kern = attention_flash_kernel;
-        constexpr int flds = FA_NS * FA_SLOT;
-        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), flds));
-        hipLaunchKernelGGL(kern, grid, dim3(256), flds, ctx->stream, a);
+        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), FA_LDS));
+        hipLaunchKernelGGL(kern, grid, dim3(512), FA_LDS, ctx->stream, a);
     } else
     switch (a.tpad / 64) {
         case 1: LELE_ATTN_NT(2); break;
