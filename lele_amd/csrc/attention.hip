@@ -45,8 +45,10 @@ struct AttnArgs {
     int nqb;           // query blocks per (batch, head)
     const float* scale;
     float* stat;       // [batch_outer][batch_inner * nqb][2] or NULL
-    int ablate;        // developer switch LELE_HIP_ATTN_ABLATE (timing experiments, results wrong): 1 no softmax arithmetic, 2 no exp
-    long long* dbg;    // developer switch LELE_HIP_ATTN_STAMPS: 8 cycle-counter stamps per workgroup (tools/attention_stamps.py), or NULL
+#ifdef LELE_HIP_LAB
+    int ablate;        // lab switch LELE_HIP_ATTN_ABLATE (timing experiments, results wrong): skip parts of the batch kernel
+    long long* dbg;    // lab switch LELE_HIP_ATTN_STAMPS: cycle-counter stamps (tools/attention_stamps.py), or NULL
+#endif
 };
 
 // ---- split-bf16 products (the default; LELE_HIP_ATTENTION_EXACT=1 keeps the f32 MFMA of the node sequence) ---------------------
@@ -120,7 +122,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     const int ntile = a.tpad / 32;  // key tiles (even: tpad is a multiple of 64)
     int nstamp = 0;
     auto stamp = [&]() {
+#ifdef LELE_HIP_LAB
         if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 8 + nstamp++] = (long long)clock64();
+#endif
     };
     stamp();
 
@@ -367,7 +371,9 @@ __global__ __launch_bounds__(64 * NW) void attention16_kernel(AttnArgs a) {
     const int ntile = a.tpad / 16;
     int nstamp = 0;
     auto stamp = [&]() {
+#ifdef LELE_HIP_LAB
         if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 8 + nstamp++] = (long long)clock64();
+#endif
     };
     stamp();
 
@@ -908,10 +914,10 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
     // sequence (where that runs the tiled GEMM); default: split-bf16 products and the chip's exponential (same values to ~1e-6)
     const char* ex_env = getenv("LELE_HIP_ATTENTION_EXACT");
     const bool exact = ex_env && *ex_env && atoi(ex_env) != 0;
-    const char* rt_env = getenv("LELE_HIP_ATTENTION_RT");
+    const char* rt_env = lab_env("LELE_HIP_ATTENTION_RT");
     const int rt = rt_env && *rt_env ? atoi(rt_env) : (fb * ((t_q + 63) / 64) >= 3 * (int64_t)ctx->num_cus ? 2 : 1);
     // small grids (one utterance: 64 blocks of 32 rows for 256 CUs): 16 query rows per workgroup
-    const char* rows_env = getenv("LELE_HIP_ATTENTION_ROWS");
+    const char* rows_env = lab_env("LELE_HIP_ATTENTION_ROWS");
     const bool rows16 = rows_env && *rows_env ? atoi(rows_env) == 16 : fb * ((t_q + 31) / 32) < (int64_t)ctx->num_cus / 2;
     // one pass over the keys with producer waves (attention_flash_kernel): a batch of heads that gives at least half of the CUs a
     // workgroup of four 32-row blocks
@@ -920,10 +926,10 @@ int lele_hip_attention_view(LeleCtx* ctx, const LeleTensor* q, const LeleMatView
     const int qrows = flash ? FA_ROWS : (rows16 ? 16 : (rt == 2 ? 64 : 32));
     a.nqb = (int)((t_q + qrows - 1) / qrows);
     a.scale = (const float*)dsc;
-    a.dbg = nullptr;
-    a.ablate = 0;
-    if (const char* e = getenv("LELE_HIP_ATTN_ABLATE")) a.ablate = atoi(e);
-    if (const char* e = getenv("LELE_HIP_ATTN_STAMPS")) a.dbg = (long long*)(uintptr_t)strtoull(e, nullptr, 0);
+#ifdef LELE_HIP_LAB
+    if (const char* e = lab_env("LELE_HIP_ATTN_ABLATE")) a.ablate = atoi(e);
+    if (const char* e = lab_env("LELE_HIP_ATTN_STAMPS")) a.dbg = (long long*)(uintptr_t)strtoull(e, nullptr, 0);
+#endif
     // result statistics for the dynamic quantisation that reads this tensor next: valid when a slice of the consumer is exactly
     // one outer batch element, i.e. the result is laid out [batch_outer][t_q][batch_inner * dh] (heads merged)
     const int64_t per_slice = (int64_t)a.batch_inner * a.nqb * (flash ? 4 : 1), nstat = batch_outer * per_slice;

@@ -1,6 +1,7 @@
 // common.h -- internals shared by the translation units of liblele_hip.so (context, buffers, staging).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -138,6 +139,15 @@ struct LeleGraph {
 };
 
 #define LELE_DEVERR_GATHER_INDEX 1u
+
+// Developer switches (kernel variants for A/B timing, stamps, ablations) exist in the LAB build only
+// (LELE_HIP_LAB=1 python -m lele_amd.build -> liblele_hip_lab.so); in the product library lab_env() is NULL for every name.
+// The product's own run-time switches are the five documented in INTEGRATION.md ("Run-time switches").
+#ifdef LELE_HIP_LAB
+inline const char* lab_env(const char* name) { return getenv(name); }
+#else
+inline const char* lab_env(const char*) { return nullptr; }
+#endif
 
 struct LeleBuf {
     LeleCtx* ctx = nullptr;

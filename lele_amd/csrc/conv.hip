@@ -505,7 +505,7 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
         const int64_t ihw = (int64_t)g.ih * g.iw, plane_floats = ihw + g.plane + 8, planes = (int64_t)g.n * g.oc;
         int64_t pb = (16 * 1024 - 8) / plane_floats;
         while (pb > 1 && (planes + pb - 1) / pb < 4 * (int64_t)ctx->num_cus) pb = (pb + 1) / 2;
-        const bool lds_ok = row_ok && pb >= 1 && (g.kw == 3 || g.kw == 5 || g.kw == 7 || g.kw == 11) && !getenv("LELE_HIP_DW_NO_LDS");
+        const bool lds_ok = row_ok && pb >= 1 && (g.kw == 3 || g.kw == 5 || g.kw == 7 || g.kw == 11) && !lab_env("LELE_HIP_DW_NO_LDS");
         if (lds_ok) {
             const size_t lds = (size_t)((((pb * ihw + 3) & ~int64_t(3)) + pb * g.plane) * 4);
             const dim3 lgrid((unsigned)((planes + pb - 1) / pb));
@@ -894,7 +894,7 @@ int lele_hip_conv_transpose(LeleCtx* ctx, const LeleTensor* x, const LeleTensor*
     const int64_t total = (int64_t)g.n * g.oc * oh * ow;
     LELE_TRY(out->reserve((size_t)total * 4));
     if (total == 0) return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, oh, ow});
-    if (getenv("LELE_HIP_CONVT_GATHER")) {  // reference gather kernel, kept for A/B checks
+    if (lab_env("LELE_HIP_CONVT_GATHER")) {  // reference gather kernel, kept for A/B checks
         hipLaunchKernelGGL(conv_transpose_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx,
                            (const float*)dwp, (const float*)db, (float*)out->data, g);
         LELE_HIP_CHECK(hipGetLastError());

@@ -647,7 +647,7 @@ int lele_hip_frontend_create(LeleCtx* ctx, const LeleFeatureConfig* cfg, LeleFro
         for (int pm = 0; pm < 16; ++pm)
             if (start_pad[rd * 16 + pm] + kStdMelLen[rd] - 1 > 256) fe->std_mel = false;
     }
-    if (getenv("LELE_HIP_FE_GENERIC_MEL")) fe->std_mel = false;
+    if (lab_env("LELE_HIP_FE_GENERIC_MEL")) fe->std_mel = false;
     int rc = 0;
     rc |= upload(fe, twr, &d.tw_re);
     rc |= upload(fe, twi, &d.tw_im);
@@ -660,9 +660,9 @@ int lele_hip_frontend_create(LeleCtx* ctx, const LeleFeatureConfig* cfg, LeleFro
         lele_hip_frontend_destroy(fe);
         return rc;
     }
-    const char* env = getenv("LELE_HIP_FE_DPP");
+    const char* env = lab_env("LELE_HIP_FE_DPP");
     fe->dpp_mode = env ? atoi(env) : 1;  // 1: DPP row_ror (default), 0: __shfl (ds_bpermute)
-    const char* envf = getenv("LELE_HIP_FE_FUSED");
+    const char* envf = lab_env("LELE_HIP_FE_FUSED");
     fe->fused = envf ? atoi(envf) != 0 : true;
     *out = fe;
     return 0;

@@ -46,7 +46,7 @@ int mm_shape(const LeleTensor* a, const LeleTensor* b, MmShape* s, const char* w
 // the small-problem kernel publishes one {min, max} pair per workgroup next to the result (LeleBuf::rowstat, kind 1)
 float* stat_target(LeleCtx* ctx, LeleBuf* out, int64_t m, int64_t n, int64_t k, int64_t batch, int64_t* count) {
     *count = gemm::small_kernel_blocks((int)m, (int)n, (int)k, (int)batch, ctx->num_cus);
-    if (*count <= 0 || *count > 4096 || getenv("LELE_HIP_GEMM_FORCE")) return nullptr;
+    if (*count <= 0 || *count > 4096 || lab_env("LELE_HIP_GEMM_FORCE")) return nullptr;
     if (m <= 4 || n <= 4) return nullptr;  // matrix-vector shapes go to gemm_f32_thin_kernel, which publishes nothing
     if (out->reserve_rowstat(*count) != 0 || (size_t)*count > out->rowstat_cap) return nullptr;
     return out->rowstat;

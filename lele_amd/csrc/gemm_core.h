@@ -492,7 +492,7 @@ template <class AL, class BL, class EPI>
 inline void launch(hipStream_t st, const AL& al, const BL& bl, const EPI& epi, int M, int N, int K, int batch,
                    int num_cus) {
     if (M <= 0 || N <= 0 || batch <= 0) return;
-    static const int force = getenv("LELE_HIP_GEMM_FORCE") ? atoi(getenv("LELE_HIP_GEMM_FORCE")) : -1;  // A/B experiments
+    static const int force = lab_env("LELE_HIP_GEMM_FORCE") ? atoi(lab_env("LELE_HIP_GEMM_FORCE")) : -1;  // A/B experiments
     if (force >= 0) {
         switch (force) {
             case 0: launch_tile<128, 128, 2, 4, 16, 4>(st, al, bl, epi, M, N, K, batch); return;

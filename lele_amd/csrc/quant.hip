@@ -706,402 +706,11 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
 }
 
 
-// ------------------------------------------------------------------------------------------ 3b. i8 GEMM, whole K resident
-// The K = 512 products of a SenseVoice-shaped layer over a batch of utterances (qkv, out projection, first feed-forward layer:
-// 5472 rows) are short -- four 128-byte K steps -- and their cost in igemm_kernel is not the matrix cores (8 % busy) but everything
-// around them: a global-load round trip behind a barrier per K step, a second, mostly empty round of workgroups for the 516 / 688
-// tiles, ~20 vector instructions and one 4-byte store per output value.  This kernel turns the loop inside out:
-//   * one workgroup per CU, persistent: the (column block, 32-row tile) units are dealt out evenly, each workgroup walks its
-//     share in chunks of up to four row tiles of one column block;
-//   * a wave's WEIGHT fragments for the whole K extent (32 columns x 512 B = 64 VGPRs per lane; one workgroup per CU leaves a lane
-//     256 of them) stay in registers while the column block does not change: they come straight from L2, never through LDS;
-//   * the WHOLE K extent of the chunk's A rows (128 x 512 B) sits in LDS, double-buffered: no K loop, ONE barrier per chunk, and
-//     the next chunk's rows (and its per-row epilogue terms) are requested into registers BEFORE the current chunk's MFMA phase;
-//   * a lean epilogue: the accumulators START from the zero-point terms of their (row, column), so what follows the last MFMA is
-//     convert, scale, bias, store; where results are stored the weights are the MFMA's FIRST operand, so that a lane owns one row
-//     and 4 x 4 consecutive columns of it (16-byte stores, one set of row terms per lane); the range-only pass (EM 1) keeps the
-//     usual orientation (a lane owns one column) and works on the i32 totals -- the f32 epilogue is monotone in the total for a
-//     fixed column, so max over rows of f(total) = max(f(max total), f(min total)).
-// Same arithmetic as igemm_kernel (exact i32 products, IgemmEpi's f32 epilogue), same EM modes.
-struct WkArgs {
-    const int8_t* a;  // [rows][512]
-    const int8_t* b;  // [n][512]
-    int64_t rows;
-    int n, nrt, ncb, units;  // 32-row tiles, 128-column blocks, nrt * ncb
-    long long* dbg;          // developer switch LELE_HIP_WHOLEK_STAMPS: 64 cycle-counter stamps per workgroup, or NULL
-    int ablate;              // developer switch LELE_HIP_WHOLEK_ABLATE (timing experiments, results wrong): 1 no products, 2 no row reloads, 4 no stores
-};
-
-template <int EM>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_wholek_kernel(WkArgs g, IgemmEpi epi) {
-    constexpr int KP = 512, PITCH = KP + 16, SLOTS = 8, ABYTES = 128 * PITCH;  // 8 x 16 bytes of A per thread and chunk
-    constexpr bool ROWLANE = EM != 1;   // a lane owns one result row (stores) or one result column (range pass)
-    extern __shared__ __attribute__((aligned(16))) char wk_lds[];
-    char* const qt = wk_lds + 2 * ABYTES;   // EM 2: the chunk's i8 result tile [128][144]
-    __shared__ int2 s_row[2][128];          // per chunk row: {128 - zp_a, row term} -- the accumulators START from them
-    __shared__ float s_ds[2][128];          // per chunk row: the dynamic scale of its slice
-    __shared__ unsigned s_mx[2][2];         // EM 1: chunk j's maxima of slices s0, s0 + 1 in s_mx[j & 1], published after chunk j + 1's barrier
-    __shared__ QParams s_q[2][2];           // EM 2: the hidden layer's quantisation parameters of slices s0, s0 + 1
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3, hv = lane >> 5, l31 = lane & 31;
-    // Work split.  Workgroup b runs on XCD b mod 8, and every XCD has its own L2: an XCD is given a contiguous range of ROW tiles
-    // (all column blocks of it), so that it pulls its eighth of A and one copy of the weights through the fabric -- 9 MB in total for
-    // the qkv product of a configs[3] shard, where a split by column blocks made every XCD read all of A (23 MB) -- and its 32
-    // workgroups share that range's (column block, row tile) units evenly, column block major.
-    const unsigned G = gridDim.x;
-    const bool by_xcd = (G & 7u) == 0 && g.nrt >= 8;
-    const int xcd = by_xcd ? (int)(blockIdx.x & 7u) : 0, wg = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int nwg = by_xcd ? (int)(G >> 3) : (int)G;
-    const int rt_lo = by_xcd ? (int)((int64_t)xcd * g.nrt / 8) : 0, rt_hi = by_xcd ? (int)((int64_t)(xcd + 1) * g.nrt / 8) : g.nrt;
-    const int nx = rt_hi - rt_lo, units_x = nx * g.ncb;  // row tiles and units of this XCD's range
-    int u = (int)((int64_t)wg * units_x / nwg);
-    const int u1 = (int)((int64_t)(wg + 1) * units_x / nwg);
-    if (u >= u1) return;
-    int nstamp = 0;
-    auto stamp = [&]() {
-        if (g.dbg && tid == 0 && nstamp < 64) g.dbg[blockIdx.x * 64 + nstamp++] = (long long)clock64();
-    };
-    stamp();
-    const int n = g.n;
-    const unsigned nu = (unsigned)n, rows_u = (unsigned)g.rows, mu = (unsigned)epi.m;
-    const int nslices = (int)(rows_u / mu);
-    const bool has_ws = epi.wscale != nullptr, has_bias = epi.bias != nullptr;
-
-    v4i ra[SLOTS];
-    int rs_next = 0;
-    QParams q_next = {1.0f, 0.0f, 1.0f, 0};
-    unsigned smax_next = 0u;
-    const unsigned lrow = (unsigned)tid >> 5, lcol = 16u * ((unsigned)tid & 31u);  // this thread's row (of 16) and byte column per slot
-    bool first_load = true;
-    auto load_a = [&](int rt0) {
-        if ((g.ablate & 2) && !first_load) return;
-        first_load = false;
-#pragma unroll
-        for (int i = 0; i < SLOTS; ++i) {
-            unsigned r = (unsigned)rt0 * 32u + lrow + 16u * i;
-            r = r < rows_u ? r : rows_u - 1u;
-            ra[i] = *reinterpret_cast<const v4i*>(g.a + (size_t)(r * (unsigned)KP + lcol));
-        }
-        if (tid < 128) {  // the chunk's per-row epilogue terms
-            unsigned r = (unsigned)rt0 * 32u + (unsigned)tid;
-            r = r < rows_u ? r : rows_u - 1u;
-            rs_next = epi.row_sums[r];
-            if (epi.prm) q_next = epi.prm[rows_u == mu ? 0u : r / mu];
-            if (EM == 2 && tid < 2) {
-                const int sl = (int)((unsigned)(rt0 * 32) / mu) + tid;
-                smax_next = epi.slice_max[sl < nslices ? sl : nslices - 1];
-            }
-        }
-    };
-    auto chunk_of = [&](int uu, int& cb, int& rt0, int& cnt) {
-        cb = uu / nx;
-        const int t = uu - cb * nx;
-        rt0 = rt_lo + t;
-        cnt = nx - t;
-        cnt = cnt < 4 ? cnt : 4;
-        cnt = cnt < u1 - uu ? cnt : u1 - uu;
-    };
-    int cb, rt0, cnt;
-    chunk_of(u, cb, rt0, cnt);
-    load_a(rt0);
-    if (EM == 1 && tid < 4) (&s_mx[0][0])[tid] = 0u;
-    // weight fragments of the wave's 32 columns: sub-step s, half h -> bf[2 s + h] = bytes [64 s + 32 hv + 16 h, + 16) of weight row l31
-    v4i bf[2 * (KP / 64)];
-    // column terms.  ROWLANE: the lane's 16 columns are col + 8 g + e (g < 4, e < 4), col = 128 cb + 32 wn + 4 hv; else one column
-    constexpr int NC = ROWLANE ? 16 : 1;
-    int colsum[NC];
-    float ws[NC], bias[NC];
-    int col = 0;
-    const unsigned lds_st = lrow * PITCH + lcol;
-    // a new column block: its weights travel coalesced into the LDS buffer `stage` (free at that moment), every wave lifts its
-    // fragments out of it; the column terms come straight from global memory
-    auto new_column_block = [&](char* stage, bool buffer_busy, bool reused_before_barrier) {
-        v4i rb[SLOTS];
-#pragma unroll
-        for (int i = 0; i < SLOTS; ++i) {
-            unsigned c = (unsigned)cb * 128u + lrow + 16u * i;
-            c = c < nu ? c : nu - 1u;
-            rb[i] = *reinterpret_cast<const v4i*>(g.b + (size_t)(c * (unsigned)KP + lcol));
-        }
-        col = cb * 128 + wn * 32 + (ROWLANE ? 4 * hv : l31);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {  // clamped: loads stay unconditional, out-of-range columns are never stored
-            int cidx = col + (ROWLANE ? 8 * (c >> 2) + (c & 3) : 0);
-            cidx = cidx < n ? cidx : n - 1;
-            colsum[c] = epi.col_sums[cidx];
-            ws[c] = has_ws ? (epi.wscale_len <= 1 ? epi.wscale[0] : epi.wscale[cidx]) : 1.0f;
-            bias[c] = has_bias ? epi.bias[cidx] : 0.0f;
-        }
-        if (buffer_busy) __syncthreads();  // slower waves may still read the buffer (the chunk before last)
-#pragma unroll
-        for (int i = 0; i < SLOTS; ++i) *reinterpret_cast<v4i*>(stage + lds_st + 16 * PITCH * i) = rb[i];
-        __syncthreads();
-        const char* const wsrc = stage + (wn * 32 + l31) * PITCH + 32 * hv;
-#pragma unroll
-        for (int q = 0; q < 2 * (KP / 64); ++q) bf[q] = *reinterpret_cast<const v4i*>(wsrc + 64 * (q >> 1) + 16 * (q & 1));
-        if (reused_before_barrier) __syncthreads();  // the buffer receives the next chunk's rows before the next chunk barrier
-    };
-    auto stage_rows = [&](int buf) {  // the requested chunk: registers -> LDS buffer `buf`, with its per-row epilogue terms
-        char* const dst = wk_lds + buf * ABYTES;
-#pragma unroll
-        for (int i = 0; i < SLOTS; ++i) *reinterpret_cast<v4i*>(dst + lds_st + 16 * PITCH * i) = ra[i];
-        if (tid < 128) {
-            const int zp_a = epi.prm ? q_next.zp_i : epi.zp_a_fixed;
-            const int ca = 128 - zp_a, cbz = 128 - epi.zp_b;
-            s_row[buf][tid] = make_int2(ca, cbz * rs_next + epi.k * ca * cbz);
-            s_ds[buf][tid] = epi.prm ? q_next.scale : 1.0f;
-            if (EM == 2 && tid < 2) s_q[buf][tid] = make_qparams(0.0f, __uint_as_float(smax_next));
-        }
-    };
-    new_column_block(wk_lds + ABYTES, false, false);  // buffer 1 is rewritten only after the first chunk's barrier and products
-    stage_rows(0);
-    stamp();          // [1] the first chunk's rows and the weights have arrived
-    int un = u + cnt;
-    bool more = un < u1;
-    int ncb_ = cb, nrt0 = 0, ncnt = 0;
-    if (more) {
-        chunk_of(un, ncb_, nrt0, ncnt);
-        load_a(nrt0);
-    }
-    int j = 0;        // chunk counter: LDS buffer j & 1
-    int pend_s0 = -1; // EM 1: first slice of the chunk whose maxima wait in s_mx[(j - 1) & 1] (a register: uniform, no LDS round trip)
-    while (true) {
-        const char* const As = wk_lds + (j & 1) * ABYTES;
-        const int r0 = rt0 * 32;                                                               // first row of the chunk
-        const int rows_here = (int)(rows_u - (unsigned)r0 < (unsigned)(cnt * 32) ? rows_u - (unsigned)r0 : (unsigned)(cnt * 32));
-        // this wave's row tiles inside the chunk (a chunk at the end of a column block or of the share may hold fewer than four)
-        const int nti = cnt - 2 * wm < 0 ? 0 : (cnt - 2 * wm > 2 ? 2 : cnt - 2 * wm);
-        const int myr = wm * 64 + l31;  // ROWLANE: the lane's row in tile 0 (+ 32 i)
-        __syncthreads();  // chunk j's rows and row terms are visible; every wave has finished chunk j - 1 (buffer (j + 1) & 1 is free)
-        stamp();          // [2 + 3j]
-        if (EM == 1 && pend_s0 >= 0 && tid < 2) {  // chunk j - 1's maxima are complete (every wave added its own before the barrier)
-            const unsigned v = s_mx[(j - 1) & 1][tid];
-            if (v) atomicMax(&epi.slice_max[pend_s0 + tid], v);
-            s_mx[(j - 1) & 1][tid] = 0u;  // next written by chunk j + 1, after its barrier
-        }
-        // the chunk's rows below `split` belong to slice s0, the rest to slice s0 + 1 (m >= 128 or a single slice)
-        const int s0 = (int)((unsigned)r0 / mu);
-        const int split = rows_u == mu ? 128 : (int)(((unsigned)s0 + 1u) * mu - (unsigned)r0);
-        v16i acc[2];
-        if (ROWLANE) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int2 t = s_row[j & 1][myr + 32 * i];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = t.y + __mul24(t.x, colsum[r]);
-            }
-        } else {
-            const int2* const rowp = s_row[j & 1] + wm * 64 + 4 * hv;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int2 t = rowp[i * 32 + (r & 3) + 8 * (r >> 2)];
-                    acc[i][r] = t.y + __mul24(t.x, colsum[0]);
-                }
-        }
-        const char* const asrc = As + (wm * 64 + l31) * PITCH + 32 * hv;
-        if (nti > 0 && !(g.ablate & 1)) {
-            // A fragments of sub-step s + 1 are read from LDS while sub-step s multiplies (two register sets, order pinned)
-            v4i x0[4], x1[4];
-            auto rd = [&](v4i (&x)[4], int sub) {
-                x[0] = *reinterpret_cast<const v4i*>(asrc + sub * 64), x[1] = *reinterpret_cast<const v4i*>(asrc + sub * 64 + 16);
-                if (nti > 1) x[2] = *reinterpret_cast<const v4i*>(asrc + 32 * PITCH + sub * 64), x[3] = *reinterpret_cast<const v4i*>(asrc + 32 * PITCH + sub * 64 + 16);
-            };
-            auto mm1 = [&](const v4i& fa, const v4i& fb, v16i& c) {
-                c = ROWLANE ? __builtin_amdgcn_mfma_i32_32x32x32_i8(fb, fa, c, 0, 0, 0) : __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, c, 0, 0, 0);
-            };
-            auto mm = [&](const v4i (&x)[4], int sub) {
-                mm1(x[0], bf[2 * sub], acc[0]);
-                if (nti > 1) mm1(x[2], bf[2 * sub], acc[1]);
-                mm1(x[1], bf[2 * sub + 1], acc[0]);
-                if (nti > 1) mm1(x[3], bf[2 * sub + 1], acc[1]);
-            };
-            rd(x0, 0);
-#pragma unroll
-            for (int sub = 0; sub < KP / 64; sub += 2) {
-                rd(x1, sub + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(x0, sub);
-                __builtin_amdgcn_sched_barrier(0);
-                if (sub + 2 < KP / 64) rd(x0, sub + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(x1, sub + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // the next chunk's rows: registers -> the other LDS buffer (free since the barrier above), then the chunk after that is
-        // requested -- all BEFORE this chunk's stores, so that waiting for those rows never waits for the stores (loads and stores
-        // retire through one in-order counter)
-        int n2cb = ncb_, n2rt0 = 0, n2cnt = 0;
-        bool more2 = false;
-        if (more) {
-            stage_rows((j + 1) & 1);
-            more2 = un + ncnt < u1;
-            if (more2) {
-                chunk_of(un + ncnt, n2cb, n2rt0, n2cnt);
-                load_a(n2rt0);
-            }
-        }
-        stamp();          // [3 + 3j] products done, next rows staged (wave 0)
-        auto fin = [&](int total, float dsws, float b) {  // == IgemmEpi::value24 once the zero-point terms are inside `total`
-            float vf = (float)total;
-            if (has_ws) vf = vf * dsws;
-            if (has_bias) vf = vf + b;
-            if (epi.relu) vf = vf > 0.0f ? vf : 0.0f;
-            return vf;
-        };
-        if constexpr (EM == 0) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                if (i < nti) {
-                    const int lr = myr + 32 * i;
-                    const float ds = s_ds[j & 1][lr];
-                    float* const orow = epi.out + (size_t)((unsigned)(r0 + lr) * nu + (unsigned)col);
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        float4 v;
-                        v.x = fin(acc[i][4 * gq + 0], ds * ws[4 * gq + 0], bias[4 * gq + 0]);
-                        v.y = fin(acc[i][4 * gq + 1], ds * ws[4 * gq + 1], bias[4 * gq + 1]);
-                        v.z = fin(acc[i][4 * gq + 2], ds * ws[4 * gq + 2], bias[4 * gq + 2]);
-                        v.w = fin(acc[i][4 * gq + 3], ds * ws[4 * gq + 3], bias[4 * gq + 3]);
-                        // n % 4 == 0: a group is whole or absent.  (Non-temporal stores change nothing here: measured.)
-                        if (lr < rows_here && col + 8 * gq < n && !(g.ablate & 4)) *reinterpret_cast<float4*>(orow + 8 * gq) = v;
-                    }
-                }
-        } else if constexpr (EM == 1) {
-            // range of the ReLU result on i32 totals: the f32 epilogue is monotone in the total for a fixed column
-            const float dsws0 = s_ds[j & 1][0] * ws[0], dsws1 = s_ds[j & 1][split < 127 ? (split > 0 ? split : 0) : 127] * ws[0];
-            const int lane_row = wm * 64 + 4 * hv;
-            int tmax[2] = {INT_MIN, INT_MIN}, tmin[2] = {INT_MAX, INT_MAX};
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                if (i < nti) {
-                    const int base = wm * 64 + i * 32;
-                    if (base + 32 <= rows_here && (base + 32 <= split || base >= split)) {  // uniform: the whole tile valid, one slice
-                        int lmax = INT_MIN, lmin = INT_MAX;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int total = acc[i][r];
-                            lmax = total > lmax ? total : lmax;
-                            lmin = total < lmin ? total : lmin;
-                        }
-                        const int which = base >= split ? 1 : 0;
-                        tmax[which] = lmax > tmax[which] ? lmax : tmax[which];
-                        tmin[which] = lmin < tmin[which] ? lmin : tmin[which];
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int lr = lane_row + i * 32 + (r & 3) + 8 * (r >> 2);
-                            const int total = acc[i][r];
-                            if (lr < rows_here) {
-                                if (lr < split) {
-                                    tmax[0] = total > tmax[0] ? total : tmax[0];
-                                    tmin[0] = total < tmin[0] ? total : tmin[0];
-                                } else {
-                                    tmax[1] = total > tmax[1] ? total : tmax[1];
-                                    tmin[1] = total < tmin[1] ? total : tmin[1];
-                                }
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                float best = 0.0f;
-                if (tmax[p] >= tmin[p]) {
-                    const float a = fin(tmax[p], p ? dsws1 : dsws0, bias[0]), b2 = fin(tmin[p], p ? dsws1 : dsws0, bias[0]);  // ReLU inside: >= 0, no NaN
-                    best = a > b2 ? a : b2;
-                }
-                // wave maximum on the DPP network (values are non-negative floats: their bits order like unsigned integers, 0 is
-                // neutral), then ONE lane goes to the LDS maximum
-                unsigned bits = col < n ? __float_as_uint(best) : 0u;
-                auto step = [&](unsigned x, auto ctrl, auto rowmask) {
-                    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl)::value, decltype(rowmask)::value, 0xf, true);
-                    return o > x ? o : x;
-                };
-                bits = step(bits, std::integral_constant<int, 0xB1>(), std::integral_constant<int, 0xf>());   // quad_perm [1,0,3,2]
-                bits = step(bits, std::integral_constant<int, 0x4E>(), std::integral_constant<int, 0xf>());   // quad_perm [2,3,0,1]
-                bits = step(bits, std::integral_constant<int, 0x141>(), std::integral_constant<int, 0xf>());  // row_half_mirror
-                bits = step(bits, std::integral_constant<int, 0x140>(), std::integral_constant<int, 0xf>());  // row_mirror: every lane = its row's maximum
-                bits = step(bits, std::integral_constant<int, 0x142>(), std::integral_constant<int, 0xa>());  // row_bcast15 into rows 1, 3
-                bits = step(bits, std::integral_constant<int, 0x143>(), std::integral_constant<int, 0xc>());  // row_bcast31 into rows 2, 3: lane 63 = wave maximum
-                if (lane == 63 && bits) atomicMax(&s_mx[j & 1][p], bits);
-            }
-            pend_s0 = s0;
-        } else {
-            constexpr int QP = 128 + 16;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                if (i < nti) {
-                    const int lr = myr + 32 * i;
-                    const float ds = s_ds[j & 1][lr];
-                    const int which = lr >= split ? 1 : 0;
-                    const float inv = s_q[j & 1][which].inv_scale, zp = s_q[j & 1][which].zp;
-                    char* const qdst = qt + lr * QP + wn * 32 + 4 * hv;
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        unsigned pk = 0u;
-                        pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(fin(acc[i][4 * gq + 0], ds * ws[4 * gq + 0], bias[4 * gq + 0]), inv, zp)), 0, pk);
-                        pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(fin(acc[i][4 * gq + 1], ds * ws[4 * gq + 1], bias[4 * gq + 1]), inv, zp)), 1, pk);
-                        pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(fin(acc[i][4 * gq + 2], ds * ws[4 * gq + 2], bias[4 * gq + 2]), inv, zp)), 2, pk);
-                        pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(fin(acc[i][4 * gq + 3], ds * ws[4 * gq + 3], bias[4 * gq + 3]), inv, zp)), 3, pk);
-                        *reinterpret_cast<unsigned*>(qdst + 8 * gq) = pk ^ 0x80808080u;
-                    }
-                }
-            __syncthreads();  // the i8 tile is complete (it is rewritten only after the next chunk's barrier)
-#pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {  // 16-byte chunks: exact i32 row sums and the coalesced store
-                const int c = tid + 512 * k2, row = c >> 3, c16 = c & 7;
-                const v4i wq = *reinterpret_cast<const v4i*>(qt + row * QP + 16 * c16);
-                unsigned us = __builtin_amdgcn_sad_u8((unsigned)wq[0] ^ 0x80808080u, 0u, 0u);
-                us = __builtin_amdgcn_sad_u8((unsigned)wq[1] ^ 0x80808080u, 0u, us);
-                us = __builtin_amdgcn_sad_u8((unsigned)wq[2] ^ 0x80808080u, 0u, us);
-                us = __builtin_amdgcn_sad_u8((unsigned)wq[3] ^ 0x80808080u, 0u, us);
-                int part = (int)us - 128 * 16;
-                part += __shfl_xor(part, 4);
-                part += __shfl_xor(part, 2);
-                part += __shfl_xor(part, 1);
-                if (row < rows_here) {
-                    *reinterpret_cast<v4i*>(epi.q_out + (size_t)(((unsigned)(r0 + row)) * nu + (unsigned)(cb * 128 + 16 * c16))) = wq;
-                    if (c16 == 0) atomicAdd(&epi.q_rowsum[r0 + row], part);
-                }
-            }
-            if (cb == 0 && tid < 2 && (tid == 0 || split < rows_here)) epi.q_prm[s0 + tid] = s_q[j & 1][tid];
-        }
-        stamp();          // [4 + 3j] epilogue issued (wave 0)
-        if (!more) break;
-        const int prev_cb = cb;
-        u = un;
-        cb = ncb_, rt0 = nrt0, cnt = ncnt;
-        un = u + cnt, more = more2;
-        ncb_ = n2cb, nrt0 = n2rt0, ncnt = n2cnt;
-        ++j;
-        // buffer (j + 1) & 1 was read by chunk j - 1 and receives chunk j + 1's rows after chunk j's products
-        if (cb != prev_cb) new_column_block(wk_lds + ((j + 1) & 1) * ABYTES, true, false);
-    }
-    if (EM == 1) {  // the last chunk's maxima
-        __syncthreads();
-        if (tid < 2 && s_mx[j & 1][tid]) atomicMax(&epi.slice_max[pend_s0 + tid], s_mx[j & 1][tid]);
-    }
-}
-
 }  // namespace
 #include "igemm_rs.h"
 namespace {
 
-// ------------------------------------------------------------------------------------------ one-pass quantised linear
-// fused_quantized_linear in ONE launch after the range is known (quantization.rs:77-169 -> avx/quantization.rs:225-417):
-// a workgroup owns 32 rows of the activation over ALL of K.  It derives the {scale, zp} of the (one or two) batch slices its
-// rows belong to from the producer's {min, max} pairs, reads its f32 rows from HBM ONCE, quantises them on the way into LDS
-// (rint(fma(x, 1/scale, zp)) body / round(x*inv + zp) tail, exactly as qrows_kernel) while accumulating the exact i32 row
-// sums, and then walks its share of the output columns with v_mfma_i32_32x32x32_i8: A fragments from LDS, W fragments
-// straight from L2 in a FRAGMENT-MAJOR layout (one contiguous 1 KiB block per 32 columns x 32 k: lane l's 16 bytes at
-// offset 16*l), so neither the i8 activation nor its row sums ever exist in HBM and qrows_kernel disappears.  The epilogue
-// is IgemmEpi's (zero-point algebra, (float)acc * (dyn_scale*w_scale[j]), + bias, ReLU, residual adds) and additionally
-// publishes {min, max} of every output row per column group, so that a quantised linear reading THIS result needs no range
-// pass either (ffn1 -> ffn2).  Bit-exact with the three-kernel chain (tests/test_quant.py runs both).
-
+// ------------------------------------------------------------------------------------------ fragment-major weights (igemm_rs.h)
 // weights [K][N] (u8 values as f32) -> fragment-major i8: block (ct, ks) = columns [32ct, +32) x k [32ks, +32), lane l of the
 // block holds column 32ct + (l & 31), k = 32ks + 16(l >> 5) + [0, 16).  One thread per (column, 16-k chunk).
 __global__ void wpack_frag_kernel(const float* __restrict__ w, int k, int n, int ks, int nt, int8_t* __restrict__ wf) {
@@ -1135,446 +744,6 @@ __global__ void wcolsum_kernel(const float* __restrict__ w, int k, int n, int* _
         sum += (r < 0.0f ? 0 : (r > 255.0f ? 255 : (int)r)) - 128;
     }
     col_sums[j] = sum;
-}
-
-struct OnepassArgs {
-    const float* x;
-    int64_t rows;
-    int k, kp;  // kp = K rounded up to 512
-    int m;      // rows per batch slice
-    const float* partial;  // {min, max} pairs, nblk per slice, slice-major
-    int nblk;
-    const int8_t* wf;
-    int n, nt, ks;   // nt = 32-column tiles, ks = 32-k steps
-    int tpw;         // column tiles per workgroup
-    int nsplit;      // column groups per row block
-    int row_blocks;
-    float* stat_out; // [slices][stat_per_slice][2] or NULL: {min, max} of the result per (slice, row block, column group)
-    int stat_per_slice;
-    int dbg;         // developer switch (LELE_HIP_ONEPASS_DEBUG): 1 = skip the quantisation, 2 = skip the MFMA loop, 4 = skip the epilogue
-};
-
-// min / max of a slice's `nblk` pairs, by ONE wave (every wave of a block repeats it: cheaper than a barrier pair, and the
-// loads of several slices can be in flight together).  lane = 0..63.
-struct MinMax {
-    float mn, mx;
-};
-template <int NU>
-__device__ __forceinline__ void pairs_issue(const float2* pp, int nblk, int lane, float2 (&v)[NU]) {
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int idx = lane + 64 * u;
-        v[u] = pp[idx < nblk ? idx : nblk - 1];  // clamped: a repeated pair changes nothing
-    }
-}
-template <int NU>
-__device__ __forceinline__ MinMax pairs_reduce(const float2* pp, int nblk, int lane, const float2 (&v)[NU]) {
-    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        mn = v[u].x < mn ? v[u].x : mn;
-        mx = v[u].y > mx ? v[u].y : mx;
-    }
-    for (int i = 64 * NU + lane; i < nblk; i += 64) {  // long lists (a LayerNorm's rows of a long utterance)
-        const float2 w = pp[i];
-        mn = w.x < mn ? w.x : mn;
-        mx = w.y > mx ? w.y : mx;
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const float p = __shfl_xor(mn, off), q = __shfl_xor(mx, off);
-        mn = p < mn ? p : mn;
-        mx = q > mx ? q : mx;
-    }
-    return MinMax{mn, mx};
-}
-
-// KSPLIT = false: the waves of a block take column tiles two at a time, all of K each; a block owns RB x 32 rows, so every
-//   weight fragment feeds RB MFMAs and every activation fragment two (bytes per MFMA and lane: 16 / RB from L2, 8 from LDS).
-// KSPLIT = true (few tiles per block: one utterance): the four waves split K, one tile at a time, partial tiles meet in LDS.
-// SETK = k-steps (32 k each) per register set of weight fragments; sets alternate between two register files so that the loads
-// of set i+1 are in flight while the MFMAs of set i issue.  The host guarantees (k-steps per wave) % (2 * SETK) == 0.
-// Grid: 1-D, XCD-aware -- workgroup L runs on XCD L % 8 (MI355X_MICROARCH.md); the column groups of one row block get the
-// same L % 8 and consecutive L / 8, so that the second and later reads of the block's f32 rows hit that XCD's L2.
-template <bool KSPLIT, int SETK, int RB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KSPLIT || RB == 1 ? 3 : 2))) void qlinear_onepass_kernel(OnepassArgs a, IgemmEpi epi) {
-    constexpr int BM = 32 * RB;
-    constexpr int NTW = KSPLIT ? 1 : 2;  // tiles a wave works on at a time
-    static_assert(!KSPLIT || RB == 1, "K-split mode works on one row block");
-    extern __shared__ __attribute__((aligned(16))) char op_lds[];  // A' tile: [BM][kp + 16] bytes
-    __shared__ int4 s_row[BM];  // per row: {128 - zp_a, (128 - zp_b) * rowsum + K * ca * cb, bits of the dynamic scale, 0}
-    __shared__ float s_stat[4][4];
-    __shared__ int s_red[KSPLIT ? 4 * 16 * 64 : 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hv = lane >> 5, l31 = lane & 31;
-    const int pitch = a.kp + 16;
-    // (row block, column group) of this workgroup
-    int rblk, grp;
-    {
-        const unsigned L = blockIdx.x, xcd = L & 7u, j = L >> 3;
-        const unsigned full = (unsigned)a.row_blocks >> 3, rem = (unsigned)a.row_blocks & 7u;
-        // XCD x owns row blocks x, x + 8, ... (full or full + 1 of them); its workgroups j enumerate (block, group) pairs
-        const unsigned mine = full + (xcd < rem ? 1u : 0u);
-        const unsigned rb_local = j / (unsigned)a.nsplit;
-        if (rb_local >= mine) return;  // padding workgroups of the rounded-up grid (uniform: before any barrier)
-        rblk = (int)(rb_local * 8u + xcd);
-        grp = (int)(j - rb_local * (unsigned)a.nsplit);
-    }
-    const int64_t m0 = (int64_t)rblk * BM;
-    const int rows_here = (int)(a.rows - m0 < BM ? a.rows - m0 : BM);
-    const int t_lo = grp * a.tpw, t_hi = t_lo + a.tpw < a.nt ? t_lo + a.tpw : a.nt;  // this block's column tiles (>= 1)
-    const v4i* wfv = reinterpret_cast<const v4i*>(a.wf) + lane;  // block (t, s) of the weights: wfv[(t * ks + s) * 64]
-    const int per = a.ks / 4;                                      // K-split: k-steps per wave
-    const int ks0 = KSPLIT ? wave * per : 0, ks1 = KSPLIT ? ks0 + per : a.ks;
-    // work units of the block: tiles (K-split: all four waves on every tile) or tile pairs (taken round-robin by the waves).  The
-    // order is ROTATED by the row block: at any moment the row blocks then write different column ranges.  Left in lockstep, every
-    // block stores the same few 256-byte column strips at the same time, i.e. the whole chip queues on the same L2 / HBM channels
-    // (the row stride N*4 is a multiple of the channel interleave) -- measured 25 us instead of 6 for the 45 MB of ffn1.
-    const int ntile = t_hi - t_lo;
-    const int nunit = KSPLIT ? ntile : (ntile + 1) / 2, ustep = KSPLIT ? 1 : 4, u_first = KSPLIT ? 0 : wave;
-    const int urot = (rblk * 5 + grp) % nunit;
-    auto unit_tile = [&](int u) {
-        const int uu = u + urot;
-        return t_lo + (KSPLIT ? 1 : 2) * (uu < nunit ? uu : uu - nunit);
-    };
-
-    // ---- weight fragments: two register files, requested one set ahead.  (uq, sq) = position of the next set to request; past
-    // the wave's last set the position is clamped (a harmless repeated load instead of a branch, so that the hardware's
-    // outstanding-load counter is exact on every path).  The first set does not depend on the activation: it is requested now
-    // and travels during phases 0 and 1.
-    v4i w_a[NTW][SETK], w_b[NTW][SETK];
-    int uq = u_first, sq = ks0;
-    auto req = [&](v4i (&w)[NTW][SETK]) {
-        const int tc = unit_tile(uq < nunit ? uq : nunit - 1);
-        const v4i* p0 = wfv + ((int64_t)tc * a.ks + sq) * 64;
-        const v4i* p1 = (NTW == 2 && tc + 1 < t_hi) ? p0 + (int64_t)a.ks * 64 : p0;
-#pragma unroll
-        for (int u = 0; u < SETK; ++u) {
-            w[0][u] = p0[u * 64];
-            if (NTW == 2) w[1][u] = p1[u * 64];
-        }
-        sq += SETK;
-        if (sq >= ks1) {
-            sq = ks0;
-            uq += ustep;
-        }
-    };
-    req(w_a);
-
-    // ---- phase 0 (loads): the {min, max} pairs of the (at most two, when m >= BM) slices this block's rows belong to
-    const int64_t sl_lo = m0 / a.m;
-    const int nsl = (int)((m0 + rows_here - 1) / a.m - sl_lo) + 1;
-    const float2* pp0 = reinterpret_cast<const float2*>(a.partial) + sl_lo * (int64_t)a.nblk;
-    const float2* pp1 = pp0 + (nsl > 1 ? a.nblk : 0);
-    float2 pv0[4], pv1[4];
-    pairs_issue(pp0, a.nblk, lane, pv0);
-    pairs_issue(pp1, a.nblk, lane, pv1);
-
-    // ---- phase 1a: this thread's first activation loads.  8 lanes per row read 128-byte chunks (32 floats); row r starts at
-    // chunk 2r and wraps, so that the 32 rows of a pass touch 32 different 128-byte columns at a time: with every row on the
-    // same column the row stride (K*4, a multiple of the channel interleave) sends the whole pass to one or two L2 channels
-    const int qrow = tid >> 3, sub = tid & 7;  // row inside a 32-row pass
-    const bool vec4 = (a.k & 3) == 0 && (((uintptr_t)a.x & 15) == 0);
-    const int nreal = (a.k + 31) / 32;          // chunks that hold data; [nreal * 32, kp) is zero padding
-    const int crot = (2 * qrow) % nreal;
-    constexpr int U = 8;
-    float4 pre[U];
-    auto chunk_of = [&](int it) {  // it-th chunk this thread's row visits (it < nreal)
-        const int c = it + crot;
-        return c < nreal ? c : c - nreal;
-    };
-    auto fetch = [&](const float* xr, int it) -> float4 {
-        const int c = chunk_of(it < nreal ? it : nreal - 1) * 32 + sub * 4;
-        if (vec4) return *reinterpret_cast<const float4*>(xr + (c + 3 < a.k ? c : a.k - 4));  // clamped: never past the row
-        float4 v;
-        v.x = xr[c < a.k ? c : a.k - 1];
-        v.y = xr[c + 1 < a.k ? c + 1 : a.k - 1];
-        v.z = xr[c + 2 < a.k ? c + 2 : a.k - 1];
-        v.w = xr[c + 3 < a.k ? c + 3 : a.k - 1];
-        return v;
-    };
-    auto row_ptr = [&](int rb) {  // rows past the end re-read the last row; their results are never stored
-        const int64_t g = m0 + rb * 32 + qrow;
-        return a.x + (g < a.rows ? g : a.rows - 1) * (int64_t)a.k;
-    };
-    {
-        const float* xr = row_ptr(0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) pre[u] = fetch(xr, u);
-    }
-
-    // ---- phase 0 (reduce): {scale, zp} per slice, in registers of every wave -- no LDS, no barrier
-    const QParams q0 = [&] {
-        const MinMax r = pairs_reduce(pp0, a.nblk, lane, pv0);
-        return make_qparams(r.mn, r.mx);
-    }();
-    const QParams q1 = [&] {
-        const MinMax r = pairs_reduce(pp1, a.nblk, lane, pv1);
-        return make_qparams(r.mn, r.mx);
-    }();
-    const int bnd = (int)((sl_lo + 1) * a.m - m0);  // local rows below bnd are slice sl_lo, the next a.m rows slice sl_lo + 1
-
-    // ---- phase 1b: quantise the rows into LDS, exact row sums on the way.  Whole 32-column chunks inside the SIMD body
-    // (k & ~7) take four instructions per element: fma, round-to-nearest-even, v_cvt_pk_u8_f32 (saturates to [0, 255] = the
-    // clamp, and packs), and per four elements one xor 0x80808080 (q - 128 as i8) and one v_sad_u8 (sum of the four q).
-#pragma unroll 1
-    for (int rb = 0; rb < RB; ++rb) {
-        const int lrow = rb * 32 + qrow;
-        QParams q = lrow < bnd ? q0 : q1;
-        if (nsl > 2 && lrow >= bnd + a.m) {  // more than two slices in a block (m < BM): rare, the slow way
-            const int64_t sl = (m0 + lrow) / a.m;
-            const float2* pps = reinterpret_cast<const float2*>(a.partial) + (m0 + lrow < a.rows ? sl : sl_lo) * (int64_t)a.nblk;
-            float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
-            for (int i = 0; i < a.nblk; ++i) {
-                const float2 w = pps[i];
-                mn = w.x < mn ? w.x : mn;
-                mx = w.y > mx ? w.y : mx;
-            }
-            q = make_qparams(mn, mx);
-        }
-        const int simd_k = a.k & ~7;
-        const int nfull = simd_k / 32;  // chunks with every column below simd_k
-        unsigned usum = 0;              // sum of q over the fast chunks
-        int ssum = 0;                   // sum of (q - 128) over the ragged chunk
-        char* dst = op_lds + lrow * pitch + sub * 4;
-        const float* xr = row_ptr(rb);
-        const float* xr_next = row_ptr(rb + 1 < RB ? rb + 1 : rb);
-        for (int c = nreal * 32 + sub * 4; c < a.kp; c += 32) *reinterpret_cast<int*>(op_lds + lrow * pitch + c) = 0;  // zero padding
-        for (int it0 = 0; it0 < nreal; it0 += U) {
-            float4 cur[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) cur[u] = pre[u];
-            if (it0 + U < nreal) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) pre[u] = fetch(xr, it0 + U + u);
-            } else if (rb + 1 < RB) {  // the next 32 rows' first chunks
-#pragma unroll
-                for (int u = 0; u < U; ++u) pre[u] = fetch(xr_next, u);
-            }
-            if (a.dbg & 1) continue;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (it0 + u >= nreal) continue;  // uniform
-                const int ch = chunk_of(it0 + u);
-                if (ch < nfull) {  // all lanes of a row agree; rows differ only around the (at most one) ragged chunk
-                    unsigned pk = 0;
-                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(cur[u].x, q.inv_scale, q.zp)), 0, pk);
-                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(cur[u].y, q.inv_scale, q.zp)), 1, pk);
-                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(cur[u].z, q.inv_scale, q.zp)), 2, pk);
-                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(cur[u].w, q.inv_scale, q.zp)), 3, pk);
-                    usum = __builtin_amdgcn_sad_u8(pk, 0u, usum);
-                    *reinterpret_cast<unsigned*>(dst + ch * 32) = pk ^ 0x80808080u;
-                } else {  // the chunk that holds the scalar tail (k % 8 columns) and / or the end of the row
-                    const int c = ch * 32 + sub * 4;
-                    const float xv[4] = {cur[u].x, cur[u].y, cur[u].z, cur[u].w};
-                    int packed = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int kk = c + e;
-                        int v = 0;
-                        if (kk < a.k) {
-                            v = (int)quant_one(xv[e], q, kk < simd_k) - 128;
-                            ssum += v;
-                        }
-                        packed |= (v & 0xff) << (8 * e);
-                    }
-                    *reinterpret_cast<int*>(dst + ch * 32) = packed;
-                }
-            }
-        }
-        int sum = (int)usum - 128 * 4 * nfull + ssum;  // every lane of a row did nfull fast chunks of 4 elements (nfull <= nreal)
-        sum += __shfl_xor(sum, 1);
-        sum += __shfl_xor(sum, 2);
-        sum += __shfl_xor(sum, 4);
-        if (sub == 0) {
-            const int ca = 128 - q.zp_i, cb = 128 - epi.zp_b;
-            s_row[lrow] = make_int4(ca, cb * sum + a.k * ca * cb, __builtin_bit_cast(int, q.scale), 0);
-        }
-    }
-    __syncthreads();
-
-    // ---- phase 2: columns
-    const char* arow = op_lds + l31 * pitch + 16 * hv;
-    // {min, max} of what this block stores, separately for the two slices its rows may belong to
-    float mnA = 3.40282347e+38f, mxA = -3.40282347e+38f, mnB = 3.40282347e+38f, mxB = -3.40282347e+38f;
-    // rows r0..r0+NR-1 (accumulator registers) of row block rb of tile t: epilogue + statistics.  cc = the tile's column terms,
-    // requested before the tile's MFMAs so that they have arrived by now.  NRES (compile time) = number of residual operands:
-    // the body is straight-line code -- loads from clamped coordinates, then predicated stores -- because a branch per row makes
-    // the compiler fall back to "wait for every outstanding memory operation" at the joins, i.e. each group of stores waits for
-    // the previous one to reach memory (measured: 25 us of the 45 us of ffn1).
-    auto finish = [&](int t, int rb, const IgemmEpi::ColCtx& cc, auto get_acc, int r0, auto nr_c, auto nres_c) {
-        constexpr int NR = decltype(nr_c)::value, NRES = decltype(nres_c)::value;
-        const int col = t * 32 + l31;
-        const bool cin = col < a.n;
-        const int colc = cin ? col : a.n - 1;
-        // the rows a lane finishes are the same for every tile: left alone, the compiler hoists their 2 x 16 x RB output pointers
-        // and LDS terms out of the tile loop (160 VGPRs for two row blocks -> spills); an opaque copy keeps them per tile
-        int rbase = rb * 32 + 4 * hv;
-        asm volatile("" : "+v"(rbase));
-        // addresses: one uniform 64-bit base per block + a 32-bit element offset per lane (row r of the register file sits
-        // (r & 3) + 8 (r >> 2) rows below rbase: a compile-time multiple of N, computed on the scalar unit) -- per-row 64-bit
-        // multiplies made the epilogue the longest phase of the kernel
-        float* const obase = epi.out + m0 * (int64_t)a.n;
-        const float* const r1base = NRES > 0 ? epi.res1 + m0 * (int64_t)a.n : nullptr;
-        const float* const r2base = NRES > 1 ? epi.res2 + m0 * (int64_t)a.n : nullptr;
-        const unsigned nu = (unsigned)a.n;
-        const unsigned off0 = (unsigned)rbase * nu + (unsigned)col;
-        // residual operands of ALL the rows first: loads and stores retire through one in-order counter, so a load issued after a
-        // store cannot be waited for without waiting for the store -- one such wait per tile instead of one per group of rows
-        float r1[NRES > 0 ? NR : 1], r2[NRES > 1 ? NR : 1];
-        if (NRES > 0) {
-            const int last = rows_here - 1;
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const int r = r0 + i;
-                const int lr = rbase + (r & 3) + 8 * (r >> 2);
-                const unsigned at = (unsigned)(lr < last ? lr : last) * nu + (unsigned)colc;
-                r1[i] = r1base[at];
-                if (NRES > 1) r2[i] = r2base[at];
-            }
-        }
-        const float nan = __builtin_nanf("");
-#pragma unroll
-        for (int g4 = 0; g4 < NR; g4 += 4) {
-            int4 rowt[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = r0 + g4 + q;
-                rowt[q] = s_row[rbase + (r & 3) + 8 * (r >> 2)];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = r0 + g4 + q;
-                const int kr = (r & 3) + 8 * (r >> 2);  // compile time when r0 is (normal mode)
-                const int lr = rbase + kr;
-                const IgemmEpi::RowCtx rc{rowt[q].x, rowt[q].y, __builtin_bit_cast(float, rowt[q].z), nullptr};
-                float v = epi.value24(rc, cc, get_acc(g4 + q));
-                if (NRES > 0) v = v + r1[g4 + q];
-                if (NRES > 1) v = v + r2[g4 + q];
-                const bool ok = cin && lr < rows_here;
-                if (ok) obase[off0 + (unsigned)kr * nu] = v;
-                // statistics: v_min / v_max ignore a NaN operand, so "not this slice / not stored" is one select per slice
-                const float vA = (ok && lr < bnd) ? v : nan, vB = (ok && lr >= bnd) ? v : nan;
-                mnA = __builtin_fminf(mnA, vA);
-                mxA = __builtin_fmaxf(mxA, vA);
-                mnB = __builtin_fminf(mnB, vB);
-                mxB = __builtin_fmaxf(mxB, vB);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: hoisting all 16 rows' LDS terms costs 40 VGPRs
-        }
-    };
-    // SETK k-steps of MFMAs out of one register set: the A fragments come from LDS (short latency), the W fragments were
-    // requested one set ahead, so the wait before the first MFMA leaves the NEXT set's loads in flight
-    auto mm = [&](const v4i (&w)[NTW][SETK], int s, v16i (&acc)[RB][NTW]) {
-#pragma unroll
-        for (int u = 0; u < SETK; ++u) {
-            v4i fa[RB];
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) fa[rb] = *reinterpret_cast<const v4i*>(arow + rb * 32 * pitch + (s + u) * 32);
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                for (int j = 0; j < NTW; ++j) acc[rb][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[rb], w[j][u], acc[rb][j], 0, 0, 0);
-        }
-    };
-    for (int un = u_first; un < nunit; un += ustep) {
-        const int t = unit_tile(un);
-        v16i acc[RB][NTW];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int j = 0; j < NTW; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[rb][j][r] = 0;
-        // the tiles' column terms (column sum, weight scale, bias): requested now, used after the MFMAs
-        IgemmEpi::ColCtx cc[NTW];
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) cc[j] = epi.col_ctx((t + j) * 32 + l31);
-        __builtin_amdgcn_sched_barrier(0);  // pinned HERE: sunk to their use after the MFMAs they would be the youngest loads, and
-                                            // waiting for them would wait for every store of the previous tile as well
-        // sets alternate a, b; the request after this tile's last set is the NEXT tile's first one, so it travels while the
-        // results are stored
-        for (int s = ks0; s < ((a.dbg & 2) ? ks0 : ks1); s += 2 * SETK) {
-            // the scheduling barriers pin "request the next set, THEN issue this set's MFMAs": left alone, the scheduler sinks the
-            // loads next to their uses and waits for each one with the matrix pipe idle
-            req(w_b);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(w_a, s, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            req(w_a);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(w_b, s + SETK, acc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (a.dbg & 4) continue;
-        // one uniform branch per tile on the number of residual operands; inside, everything is straight-line
-        auto finish_all = [&](auto nres_c) {
-            if (!KSPLIT) {
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    finish(t, rb, cc[0], [&](int i) { return acc[rb][0][i]; }, 0, std::integral_constant<int, 16>(), nres_c);
-                    if (t + 1 < t_hi)
-                        finish(t + 1, rb, cc[NTW - 1], [&](int i) { return acc[rb][NTW - 1][i]; }, 0, std::integral_constant<int, 16>(), nres_c);
-                }
-            } else {
-                // the four waves split K: partial tiles meet in LDS (exact: i32), each wave finishes four accumulator rows
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s_red[(wave * 16 + r) * 64 + lane] = acc[0][0][r];
-                __syncthreads();
-                finish(t, 0, cc[0], [&](int i) {
-                    const int r = 4 * wave + i;
-                    return (s_red[(0 * 16 + r) * 64 + lane] + s_red[(1 * 16 + r) * 64 + lane]) +
-                           (s_red[(2 * 16 + r) * 64 + lane] + s_red[(3 * 16 + r) * 64 + lane]);
-                }, 4 * wave, std::integral_constant<int, 4>(), nres_c);
-                __syncthreads();
-            }
-        };
-        if (!epi.res1) finish_all(std::integral_constant<int, 0>());
-        else if (!epi.res2) finish_all(std::integral_constant<int, 1>());
-        else finish_all(std::integral_constant<int, 2>());
-    }
-    if (a.stat_out) {  // uniform.  Slot layout: [slice][block of the slice][column group], a.stat_per_slice pairs per slice
-        for (int off = 32; off > 0; off >>= 1) {
-            const float p0 = __shfl_xor(mnA, off), p1 = __shfl_xor(mxA, off), p2 = __shfl_xor(mnB, off), p3 = __shfl_xor(mxB, off);
-            mnA = p0 < mnA ? p0 : mnA;
-            mxA = p1 > mxA ? p1 : mxA;
-            mnB = p2 < mnB ? p2 : mnB;
-            mxB = p3 > mxB ? p3 : mxB;
-        }
-        if (lane == 0) {
-            s_stat[wave][0] = mnA;
-            s_stat[wave][1] = mxA;
-            s_stat[wave][2] = mnB;
-            s_stat[wave][3] = mxB;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < 4; ++w) {
-                mnA = s_stat[w][0] < mnA ? s_stat[w][0] : mnA;
-                mxA = s_stat[w][1] > mxA ? s_stat[w][1] : mxA;
-                mnB = s_stat[w][2] < mnB ? s_stat[w][2] : mnB;
-                mxB = s_stat[w][3] > mxB ? s_stat[w][3] : mxB;
-            }
-            const int64_t fbA = (sl_lo * a.m) / BM;  // first block of slice sl_lo
-            float* oa = a.stat_out + ((sl_lo * a.stat_per_slice) + ((int64_t)rblk - fbA) * a.nsplit + grp) * 2;
-            oa[0] = mnA;
-            oa[1] = mxA;
-            if (bnd < rows_here) {  // this block also holds the first rows of the next slice: it is that slice's block 0
-                float* ob = a.stat_out + (((sl_lo + 1) * a.stat_per_slice) + grp) * 2;
-                ob[0] = mnB;
-                ob[1] = mxB;
-            }
-        }
-        // the block holding the LAST row of slice sl_lo fills the slice's unused slots with the neutral pair
-        if (grp == 0 && bnd <= rows_here) {
-            const int64_t fbA = (sl_lo * a.m) / BM;
-            const int used = (int)((int64_t)rblk - fbA + 1) * a.nsplit;
-            float* base = a.stat_out + sl_lo * a.stat_per_slice * 2;
-            for (int i = used + tid; i < a.stat_per_slice; i += 256) {
-                base[2 * i] = 3.40282347e+38f;
-                base[2 * i + 1] = -3.40282347e+38f;
-            }
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------ host helpers
@@ -1654,6 +823,15 @@ int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
 }
+// developer switches exist in the lab build only (LELE_HIP_LAB=1 python -m lele_amd.build); the product reads the documented ones
+int lab_int(const char* name, int dflt) {
+#ifdef LELE_HIP_LAB
+    return env_int(name, dflt);
+#else
+    (void)name;
+    return dflt;
+#endif
+}
 
 // stage stopwatch of the quantised linear (lele_hip_quant_set_profiling): stage = 0 start, 1 after the range pass, 2 after the
 // row quantisation, 3 after the GEMM
@@ -1696,14 +874,11 @@ int launch_range(LeleCtx* ctx, const float* dx, int64_t slices, int64_t slice_le
     return 0;
 }
 
-bool wholek_fits(LeleCtx* ctx, int64_t rows, int n, int kp, int m, int em);
-int launch_igemm_wholek(LeleCtx* ctx, int em, const int8_t* aq, const int8_t* wt, int64_t rows, int n, const IgemmEpi& epi);
-
 int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows, int n, int kp, int64_t b_stride,
                  int m_per_batch, const IgemmEpi& epi_in) {
     if (rows == 0 || n == 0) return 0;
     IgemmEpi epi = epi_in;
-    epi.flags = env_int("LELE_HIP_IGEMM_FLAGS", 0);
+    epi.flags = lab_int("LELE_HIP_IGEMM_FLAGS", 0);
     LELE_REQUIRE(rows < (int64_t(1) << 31), "quantized GEMM: more than 2^31 rows");
     const int64_t b128 = ((rows + 127) / 128) * ((n + 127) / 128);
     // batched B needs every block to stay inside one batch slice: tiles never straddle slices when BM divides m,
@@ -1718,7 +893,8 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
                            m_per_batch, epi);                                                                             \
     } while (0)
     const int64_t b64 = ((rows + 63) / 64) * ((n + 63) / 64);
-    const int force = env_int("LELE_HIP_IGEMM_TILE", 0);  // developer override for tile-shape experiments (tools/qlinear_bench.py)
+#ifdef LELE_HIP_LAB
+    const int force = lab_int("LELE_HIP_IGEMM_TILE", 0);  // developer override for tile-shape experiments (tools/qlinear_bench.py)
     if (force == 1) IGEMM_LAUNCH(128, 128, 2, 4, 64, 4);
     else if (force == 2) IGEMM_LAUNCH(128, 128, 2, 4, 128, 1);
     else if (force == 3) IGEMM_LAUNCH(256, 128, 4, 2, 64, 2);
@@ -1734,9 +910,7 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
     else if (force == 13) IGEMM_LAUNCH(128, 64, 4, 2, 64, 4);
     else if (force == 14) IGEMM_LAUNCH(128, 64, 4, 2, 128, 4);
     else
-    if (b_stride == 0 && !epi.blockstat && !epi.res1 && b64 >= 2 * (int64_t)ctx->num_cus && wholek_fits(ctx, rows, n, kp, m_per_batch, 0)) {
-        return launch_igemm_wholek(ctx, 0, aq, wt, rows, n, epi);
-    } else
+#endif
     if (b64 < 2 * (int64_t)ctx->num_cus) {
         // small problem (SenseVoice at M = 504): 32x32 tiles, K split over the four waves, operands straight from L2
         dim3 grid((unsigned)((n + 31) / 32), (unsigned)((rows + 31) / 32));
@@ -1765,40 +939,8 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
     return 0;
 }
 
-// whole-K kernel: K padded to exactly 512 bytes, enough (column block x row tile) units for every CU, un-batched weights
-bool wholek_fits(LeleCtx* ctx, int64_t rows, int n, int kp, int m, int em) {
-    if (kp != 512 || rows >= (int64_t(1) << 22) || env_int("LELE_HIP_IGEMM_WHOLEK", 1) == 0) return false;  // 32-bit byte offsets into A
-    if (!((env_int("LELE_HIP_IGEMM_WHOLEK_MODES", 7) >> em) & 1)) return false;  // developer switch: bit em enables mode em
-    if (m < 128 && rows != m) return false;  // a chunk of 128 rows touches at most two slices
-    if (n % 4) return false;                 // 16-byte stores
-    if (em && n % 128) return false;
-    const int64_t units = ((rows + 31) / 32) * ((n + 127) / 128);
-    return units >= 2 * (int64_t)ctx->num_cus && (int64_t)rows * n < (int64_t(1) << 32);
-}
-int launch_igemm_wholek(LeleCtx* ctx, int em, const int8_t* aq, const int8_t* wt, int64_t rows, int n, const IgemmEpi& epi) {
-    WkArgs g{aq, wt, rows, n, (int)((rows + 31) / 32), (n + 127) / 128, 0, nullptr, env_int("LELE_HIP_WHOLEK_ABLATE", 0)};
-    g.units = g.nrt * g.ncb;
-    if (const char* e = getenv("LELE_HIP_WHOLEK_STAMPS"))  // a device address (tools/wholek_stamps.py), optionally for one mode only
-        if (env_int("LELE_HIP_WHOLEK_STAMPS_EM", em) == em) g.dbg = (long long*)(uintptr_t)strtoull(e, nullptr, 0);
-    const size_t lds = (size_t)256 * 528 + (em == 2 ? 128 * 144 : 0);  // two A buffers (+ the i8 tile)
-    const dim3 grid((unsigned)std::min<int64_t>(ctx->num_cus, g.units));
-#define LELE_WK(EM_)                                                                                      \
-    do {                                                                                                 \
-        auto kern = igemm_wholek_kernel<EM_>;                                                             \
-        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));                   \
-        hipLaunchKernelGGL(kern, grid, dim3(512), lds, ctx->stream, g, epi);                              \
-    } while (0)
-    if (em == 1) LELE_WK(1);
-    else if (em == 2) LELE_WK(2);
-    else LELE_WK(0);
-#undef LELE_WK
-    LELE_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
 // the two passes of the fused two-layer form over the hidden layer's product (128 x 128 tiles, the big-shape configuration)
 int launch_igemm_hidden(LeleCtx* ctx, int em, const int8_t* aq, const int8_t* wt, int64_t rows, int n, int kp, int m, const IgemmEpi& epi) {
-    if (wholek_fits(ctx, rows, n, kp, m, em)) return launch_igemm_wholek(ctx, em, aq, wt, rows, n, epi);
     constexpr size_t lds = (size_t)2 * (128 + 128) * (128 + 16);
     const dim3 grid((n + 127) / 128, (unsigned)((rows + 127) / 128));
     if (em == 1) {
@@ -1823,7 +965,7 @@ bool rs_fits(LeleCtx* ctx, int64_t rows, int64_t n, int kp) {
     if (!kp || env_int("LELE_HIP_IGEMM_RS", 1) == 0) return false;  // documented switch: 0 = the tiled kernels everywhere
     if (n % 4 || rows * n >= (int64_t(1) << 30)) return false;  // 16-byte stores; 32-bit byte offsets into the result
     const int64_t units = ((rows + 31) / 32) * ((n + 31) / 32);
-    return units >= (int64_t)env_int("LELE_HIP_IGEMM_RS_MIN", 8 * ctx->num_cus);
+    return units >= (int64_t)lab_int("LELE_HIP_IGEMM_RS_MIN", 8 * ctx->num_cus);
 }
 // weights in fragment order + column sums: cached for declared-immutable weights, packed into the arena per call otherwise
 int frag_weights_of(LeleCtx* ctx, const LeleTensor* w, int k, int n, int kp, FragW* out) {
@@ -1860,9 +1002,9 @@ int launch_rs(LeleCtx* ctx, int em, const int8_t* af, const int8_t* wf, int64_t 
     RsArgs g{af, wf, (unsigned)rows, n, (int)((rows + 31) / 32), (n + 31) / 32, 0, 0, hid};
 #ifdef LELE_HIP_LAB
     g.dbg = nullptr;
-    g.ablate = env_int("LELE_HIP_RS_ABLATE", 0);
-    if (const char* e = getenv("LELE_HIP_RS_STAMPS"))  // a device address (tools/rs_stamps.py), optionally for one mode only
-        if (env_int("LELE_HIP_RS_STAMPS_EM", em) == em) g.dbg = (long long*)(uintptr_t)strtoull(e, nullptr, 0);
+    g.ablate = lab_int("LELE_HIP_RS_ABLATE", 0);
+    if (const char* e = lab_env("LELE_HIP_RS_STAMPS"))  // a device address (tools/rs_stamps.py), optionally for one mode only
+        if (lab_int("LELE_HIP_RS_STAMPS_EM", em) == em) g.dbg = (long long*)(uintptr_t)strtoull(e, nullptr, 0);
 #endif
     g.ncb = (g.nct + 7) / 8;
     g.nrr = std::max(1, std::min(g.nrt, ctx->num_cus / g.ncb));  // one 640-thread workgroup per CU, all resident at once
@@ -1951,7 +1093,7 @@ void find_partials(LeleCtx* ctx, const LeleTensor* input, int64_t batch, int64_t
         *partial = src->rowstat;  // one pair per row
         *nblk = (int)m;
     } else if (src->rowstat_kind == 2 && src->rowstat_len == k && src->rowstat_m == m && src->rowstat_batch == batch && src->rowstat_rows % batch == 0) {
-        *partial = src->rowstat;  // a fixed number of pairs per slice of m rows (qlinear_onepass_kernel, attention_kernel)
+        *partial = src->rowstat;  // a fixed number of pairs per slice of m rows (igemm_rs_kernel, the attention kernels)
         *nblk = (int)(src->rowstat_rows / batch);
     } else if (src->rowstat_kind == 1 && batch == 1 && src->rowstat_len == rows * k && src->rowstat_rows <= 4096) {
         *partial = src->rowstat;  // per-workgroup pairs of the GEMM that produced the tensor: one slice, all pairs
@@ -2029,80 +1171,6 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
     LELE_TRY(qprof_mark(ctx, 1));
 
-    // ---- one launch: quantise-on-load i8 GEMM (declared-immutable weights, a tile of 32 x K bytes must fit the LDS).  K is
-    // padded to a multiple of 512 (zero activation bytes x zero weight bytes) so that every wave's k-range splits into an even
-    // number of equal register sets: tiny K would be mostly padding and stays on the three-kernel chain
-    const int kp32 = (int)((k + 511) & ~int64_t(511));
-    // two row blocks per workgroup (every weight fragment then feeds two MFMAs) while the tile of 64 x K bytes leaves room for two
-    // workgroups per CU; one row block for long K and for single utterances
-    const int rb_env = env_int("LELE_HIP_ONEPASS_RB", 0);
-    const int RBsel = rb_env ? rb_env : ((kp32 <= 1024 && rows >= 2048 && m >= 64) ? 2 : 1);
-    const int BMsel = 32 * RBsel;
-    const bool onepass = weight_int8->mem == LELE_MEM_WEIGHT && k >= 256 && (size_t)BMsel * (kp32 + 16) <= 140 * 1024 &&
-                         rows < (int64_t(1) << 31) && env_int("LELE_HIP_QLINEAR_ONEPASS", 0) != 0;
-    if (onepass) {
-        const int ks = kp32 / 32, nt = (int)((n + 31) / 32);
-        FragW fw;
-        LELE_TRY(get_frag_weights(ctx, weight_int8, (int)k, (int)n, ks, nt, &fw));
-        const int64_t row_blocks = (rows + BMsel - 1) / BMsel;
-        // enough workgroups to fill the chip (several fit a CU), as few column groups as that allows (every group of a row
-        // block repeats the block's quantisation; their re-reads of the f32 rows hit the XCD's L2, see the kernel's grid note)
-        const int64_t target = env_int("LELE_HIP_ONEPASS_WGS", ctx->num_cus + ctx->num_cus / 2);
-        int nsplit = (int)std::min<int64_t>(nt, std::max<int64_t>(1, (target + row_blocks - 1) / row_blocks));
-        int tpw = (nt + nsplit - 1) / nsplit;
-        bool ksplit = RBsel == 1 && tpw < env_int("LELE_HIP_ONEPASS_KSPLIT_BELOW", 4);
-        if (!ksplit && tpw < 8 && nt >= 8 && RBsel == 1 && rows > 2048) tpw = 8;  // every wave a tile pair
-        nsplit = (nt + tpw - 1) / tpw;
-        IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, nullptr, fw.col_sums, nullptr, 0,
-                     (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
-                     (const float*)dr2};
-        OnepassArgs oa{(const float*)dx, rows, (int)k, kp32, (int)m, partial, nblk, fw.wf, (int)n, nt, ks, tpw, nsplit, (int)row_blocks,
-                       nullptr, 0, env_int("LELE_HIP_ONEPASS_DEBUG", 0)};
-        // statistics for a quantised linear that reads this result next: one pair per (slice, row block, column group); needs
-        // m >= BM (a block then touches at most two slices)
-        const int64_t per_slice = ((m - 1) / BMsel + 2) * nsplit, nstat = batch * per_slice;
-        if (m >= BMsel && per_slice <= 65536 && nstat <= (int64_t(1) << 22)) {
-            LELE_TRY(out->reserve_rowstat(nstat));
-            if ((size_t)nstat <= out->rowstat_cap) {
-                oa.stat_out = out->rowstat;
-                oa.stat_per_slice = (int)per_slice;
-            }
-        }
-        const size_t lds = (size_t)BMsel * (kp32 + 16);
-        // 1-D grid: 8 XCDs x ceil(row_blocks / 8) row blocks x nsplit groups (workgroups beyond an XCD's share exit at once)
-        const dim3 grid((unsigned)(8 * ((row_blocks + 7) / 8) * nsplit));
-        LELE_TRY(qprof_mark(ctx, 2));  // no separate row-quantisation stage: the whole kernel is booked as the GEMM stage
-#define LELE_ONEPASS(KS_, SETK_, RB_)                                                                                     \
-    do {                                                                                                                \
-        auto kern = qlinear_onepass_kernel<KS_, SETK_, RB_>;                                                             \
-        if (lds + ((KS_) ? 16384 : 0) > 60 * 1024) LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)); \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, oa, epi);                                            \
-    } while (0)
-        if (ksplit) {  // k-steps per wave = ks / 4 (a multiple of 4): the largest set size that divides it into an even count
-            const int per = ks / 4;
-            if (per % 16 == 0) LELE_ONEPASS(true, 8, 1);
-            else if (per % 8 == 0) LELE_ONEPASS(true, 4, 1);
-            else LELE_ONEPASS(true, 2, 1);
-        } else if (RBsel == 2) {
-            if (env_int("LELE_HIP_ONEPASS_SETK", 2) == 4) LELE_ONEPASS(false, 4, 2);  // ks is a multiple of 16: an even number of sets
-            else LELE_ONEPASS(false, 2, 2);
-        } else {
-            LELE_ONEPASS(false, 4, 1);
-        }
-#undef LELE_ONEPASS
-        LELE_HIP_CHECK(hipGetLastError());
-        LELE_TRY(qprof_mark(ctx, 3));
-        if (oa.stat_out) {
-            out->rowstat_rows = nstat;
-            out->rowstat_len = n;
-            out->rowstat_m = m;
-            out->rowstat_batch = batch;
-            out->rowstat_kind = 2;
-            out->rowstat_valid = true;
-        }
-        return set_shape_v(out_shape, out_rank, shp);
-    }
-
     // ---- register-stationary route (igemm_rs.h): rows -> i8 in fragment order, then the barrier-free GEMM
     if (const int kprs = rs_kp(k); rs_fits(ctx, rows, n, kprs)) {
         FragW fw;
@@ -2140,7 +1208,7 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     void *aq = nullptr, *rs = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)rows * kp, &aq));
     LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));
-    if (rows <= 2048 || (kp <= 2048 && !env_int("LELE_HIP_QROWS_STREAM", 0)))  // the whole row in flight at once (8 x 16 bytes per lane)
+    if (rows <= 2048 || (kp <= 2048 && !lab_int("LELE_HIP_QROWS_STREAM", 0)))  // the whole row in flight at once (8 x 16 bytes per lane)
         hipLaunchKernelGGL((qrows_kernel<0, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
                            rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk, (unsigned*)nullptr, (int*)nullptr);
     else
@@ -2333,7 +1401,7 @@ int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const Le
     LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs2));
     LELE_TRY(ctx->arena_alloc((size_t)batch * 4, &hmax));
     // rows -> i8 for the first GEMM; the same launch clears the accumulators of the two hidden-layer passes
-    if (kp1 <= 2048 && !env_int("LELE_HIP_QROWS_STREAM", 0))
+    if (kp1 <= 2048 && !lab_int("LELE_HIP_QROWS_STREAM", 0))
         hipLaunchKernelGGL((qrows_kernel<0, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx, rows,
                            (int)k1, kp1, (int)m, (QParams*)prm1, (int8_t*)aq1, (int*)rs1, partial, nblk, (unsigned*)hmax, (int*)rs2);
     else

@@ -39,17 +39,19 @@ def close(a, b, what, rtol=1e-4):
     assert not bad.any(), "%s: %d of %d elements outside %g (max abs diff %.3g)" % (what, int(bad.sum()), b.size, rtol, float(np.abs(a - b).max()))
 
 
-@pytest.mark.parametrize("rt", [1, 2, 16])   # 32 or 64 query rows per workgroup, or 16 on the 16x16x4 MFMA (the library picks by grid size)
-@pytest.mark.parametrize("b,t", [(32, 171), (1, 504), (2, 33), (3, 64), (1, 512), (2, 100), (5, 1), (1, 8), (2, 65)])
-def test_attention_view_against_oracle_and_sequence(ctx, orc, b, t, rt):
+# the library picks the kernel by grid size: 16 query rows per workgroup for one utterance ((1, 504), (2, 33) ...), 32 for a few
+# ((8, 171)), the one-pass batch kernel from half a chip's worth of 128-row blocks ((32, 171)); with LELE_HIP_ATTENTION_EXACT=1 the
+# f32 replicas: 16 / 32 rows, and 64 rows per workgroup for large grids ((64, 171))
+@pytest.mark.parametrize("exact", [0, 1])
+@pytest.mark.parametrize("b,t", [(32, 171), (1, 504), (2, 33), (3, 64), (1, 512), (2, 100), (5, 1), (1, 8), (2, 65), (8, 171), (64, 171)])
+def test_attention_view_against_oracle_and_sequence(ctx, orc, b, t, exact):
     from lele_amd import kernels as K
     from lele_amd._lib import Weight
     rng = np.random.default_rng(b * 1000 + t)
     qkv = (rng.standard_normal((b, t, 3 * H * DH)) * 1.5).astype(np.float32)
     scale = Weight(np.array([DH ** -0.5], np.float32))
     qd = ctx.buf().upload(qkv)
-    env = dict(LELE_HIP_ATTENTION_MIN_BLOCKS=1, LELE_HIP_ATTENTION_RT=1, LELE_HIP_ATTENTION_ROWS=16) if rt == 16 else \
-        dict(LELE_HIP_ATTENTION_MIN_BLOCKS=1, LELE_HIP_ATTENTION_RT=rt, LELE_HIP_ATTENTION_ROWS=32)
+    env = dict(LELE_HIP_ATTENTION_MIN_BLOCKS=1, LELE_HIP_ATTENTION_EXACT=exact)
     with _env(**env):   # the one-launch kernel whatever the grid size
         got = K.attention_view(qd, QC, qd, KC, qd, VC, scale, [0, 2, 1, 3], [0, 0, H * DH], ctx=ctx)
     assert got.shape == (b, t, H * DH)

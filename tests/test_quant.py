@@ -245,16 +245,19 @@ def test_fused_ffn_never_stores_the_hidden_layer_and_keeps_every_bit(ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("b,m,k,n,relu,bias,scalar_ws", [
-    (1, 8300, 512, 260, False, True, False),     # one slice, rows not a multiple of 32, a partial last column block (n % 128 = 4)
-    (9, 1000, 500, 384, True, True, False),      # K padded to 512 with zero bytes; slices straddle chunks at every offset
-    (70, 128, 512, 256, False, False, False),    # slices of exactly one chunk of rows; no bias
+    (1, 8300, 512, 260, False, True, False),     # one slice, rows not a multiple of 32, a partial last column tile (n % 32 = 4)
+    (9, 1000, 500, 384, True, True, False),      # K padded to 512 with zero bytes; slices straddle row tiles at every offset
+    (70, 128, 512, 256, False, False, False),    # slices of exactly four row tiles; no bias
     (3, 3333, 512, 1536, False, True, True),     # one weight scale for all columns; 9999 rows
-    (64, 171, 512, 132, True, True, False),      # the configs[3] row structure with a narrow, ragged result
+    (64, 171, 512, 196, True, True, False),      # the configs[3] row structure with a narrow, ragged result
+    (12, 700, 2040, 260, False, True, False),    # K padded to 2048: the K-split form (four waves a tile), ragged columns
+    (32, 171, 2048, 512, True, True, False),     # configs[3]'s second feed-forward layer
 ])
-def test_persistent_whole_k_gemm_bit_exact_on_edge_shapes(ctx, b, m, k, n, relu, bias, scalar_ws):
-    """igemm_wholek_kernel serves every quantised linear with K padded to 512 bytes and enough (row tile, column block) units:
-    bit-exact with the oracle on shapes chosen for its edges -- chunks that end inside a row tile range, column blocks that end
-    inside a 4-column group, slices of every alignment, rows % 32 != 0 -- and identical to the tiled kernel's result"""
+def test_register_stationary_gemm_bit_exact_on_edge_shapes(ctx, b, m, k, n, relu, bias, scalar_ws):
+    """igemm_rs_kernel / igemm_rs_ks4_kernel serve every quantised linear with K padded to 512 / 2048 bytes and enough 32 x 32
+    tiles to fill the chip: bit-exact with the oracle on shapes chosen for their edges -- row tiles that end inside a slice,
+    column tiles that end inside a 4-column group, slices of every alignment, rows % 32 != 0 -- and identical to the tiled
+    kernels' result (LELE_HIP_IGEMM_RS=0)"""
     from lele_amd import kernels as K
     from lele_amd._lib import Weight
     from oracle import pyoracle as O
@@ -267,7 +270,7 @@ def test_persistent_whole_k_gemm_bit_exact_on_edge_shapes(ctx, b, m, k, n, relu,
     want = O.fused_quantized_linear(x, w.arr, ws.arr, wz.arr, bs.arr if bias else None, relu)
     got = K.fused_quantized_linear(x, w, ws, wz, bs, relu, ctx=ctx).numpy()
     assert got.shape == want.shape and np.array_equal(got, want)
-    with _env(LELE_HIP_IGEMM_WHOLEK=0):
+    with _env(LELE_HIP_IGEMM_RS=0):
         assert np.array_equal(K.fused_quantized_linear(x, w, ws, wz, bs, relu, ctx=ctx).numpy(), want)
 
 
@@ -286,7 +289,7 @@ def test_fused_ffn_is_deterministic_under_repetition(ctx):
                 Weight((rng.standard_normal(n) * 0.02).astype(np.float32)))
     w1, w2 = lin(512, 2048), lin(2048, 512)
     x = ctx.buf().upload((rng.standard_normal((32, 171, 512)) * rng.uniform(0.3, 3, (32, 1, 1))).astype(np.float32))
-    with _env(LELE_HIP_IGEMM_WHOLEK=0):
+    with _env(LELE_HIP_IGEMM_RS=0):
         ref = K.fused_ffn_quantized(x, *w1, *w2, False, ctx=ctx).numpy().copy()
     ob = ctx.buf()
     bad = [it for it in range(300) if not np.array_equal(K.fused_ffn_quantized(x, *w1, *w2, False, out=ob, ctx=ctx).numpy(), ref)]
@@ -357,10 +360,9 @@ class _env:
                                    (5, 32, 96, 64), (2, 64, 128, 33), (1, 504, 512, 25055), (3, 50, 256, 70), (2, 33, 300, 64),
                                    (2, 70, 1001, 96), (1, 9, 4096, 32)])
 @pytest.mark.parametrize("relu", [False, True])
-def test_device_onepass_quantized_linear_bit_exact(ctx, orc, shape, relu):
-    """declared-immutable weights take qlinear_onepass_kernel (quantise-on-load i8 GEMM): bit-exact against the oracle, and
-    against the three-kernel chain, in both of its modes (K split over the waves / column tiles per wave) and for several
-    column-group counts"""
+def test_device_quantized_linear_routes_bit_exact(ctx, orc, shape, relu):
+    """declared-immutable weights, a device-resident activation: whatever route the sizes select (register-stationary kernels,
+    tiled kernels, the small-problem kernel) is bit-exact against the oracle, and so is the tiled chain alone (LELE_HIP_IGEMM_RS=0)"""
     from lele_amd import kernels as Kk
     b, m, k, n = shape
     if relu and n > 4096:
@@ -370,45 +372,36 @@ def test_device_onepass_quantized_linear_bit_exact(ctx, orc, shape, relu):
     w = _qw(rng, k, n)
     ref = orc.fused_quantized_linear(x, w[0].arr, w[1].arr, [128.0], w[3].arr, relu)
     xd = ctx.buf().upload(x)
-    with _env(LELE_HIP_QLINEAR_ONEPASS=1):
-        got = Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx)
-        assert got.shape == ref.shape and np.array_equal(got.numpy(), ref)
-    with _env(LELE_HIP_QLINEAR_ONEPASS=0):  # the default: range pass | row quantisation | tiled i8 GEMM
+    got = Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx)
+    assert got.shape == ref.shape and np.array_equal(got.numpy(), ref)
+    with _env(LELE_HIP_IGEMM_RS=0):  # range pass | row quantisation | tiled i8 GEMM
         assert np.array_equal(Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx).numpy(), ref)
-    for wgs, below, rb, setk in ((1, 0, 1, 4), (64, 0, 2, 4), (100000, 1000, 1, 4), (100000, 0, 1, 4), (700, 4, 2, 2), (300, 4, 1, 4), (1, 4, 2, 4)):
-        with _env(LELE_HIP_QLINEAR_ONEPASS=1, LELE_HIP_ONEPASS_WGS=wgs, LELE_HIP_ONEPASS_KSPLIT_BELOW=below, LELE_HIP_ONEPASS_RB=rb, LELE_HIP_ONEPASS_SETK=setk):
-            assert np.array_equal(Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx).numpy(), ref), (wgs, below, rb, setk)
 
 
 @pytest.mark.gpu
-def test_onepass_statistics_feed_the_next_quantised_linear(ctx, orc):
-    """qlinear_onepass_kernel leaves {min, max} per (slice, row block, column group) next to its result; the quantised linear that
-    reads the result next (ffn1 -> ffn2) derives its per-slice range from them instead of scanning the tensor.  Same bits as the
-    oracle on the same input, for slices that straddle row blocks, every grouping, and after the buffer was rewritten."""
+def test_gemm_statistics_feed_the_next_quantised_linear(ctx, orc):
+    """a quantised linear leaves {min, max} pairs next to its result where its kernel has them; the quantised linear that reads
+    the result next (ffn1 -> ffn2) derives its per-slice range from them instead of scanning the tensor.  Same bits as the oracle
+    on the same input, for slices that straddle row tiles, on either route, and after the buffer was rewritten."""
     from lele_amd import kernels as Kk
     rng = np.random.default_rng(123)
     for b, m, k, h, n in ((32, 171, 512, 2048, 512), (1, 504, 512, 2048, 512), (3, 40, 256, 288, 40), (2, 32, 256, 256, 64), (5, 100, 512, 270, 33),
-                          (4, 31, 256, 256, 32), (3, 40, 64, 96, 40)):
+                          (4, 31, 256, 256, 32), (3, 40, 64, 96, 40), (1, 5472, 512, 512, 512)):
         x = (rng.standard_normal((b, m, k)) * rng.uniform(0.5, 3.0, (b, 1, 1))).astype(np.float32)
         w1, w2 = _qw(rng, k, h), _qw(rng, h, n)
         hid_ref = orc.fused_quantized_linear(x, w1[0].arr, w1[1].arr, [128.0], w1[3].arr, True)
         out_ref = orc.fused_quantized_linear(hid_ref, w2[0].arr, w2[1].arr, [128.0], w2[3].arr, False)
-        for wgs, rb in ((768, 0), (1, 1), (100000, 2), (300, 2), (300, 1)):
-            with _env(LELE_HIP_QLINEAR_ONEPASS=1, LELE_HIP_ONEPASS_WGS=wgs, LELE_HIP_ONEPASS_RB=rb):
+        for rs in (1, 0):
+            with _env(LELE_HIP_IGEMM_RS=rs):
                 hbuf = ctx.buf()
                 hid = Kk.fused_quantized_linear(ctx.buf().upload(x), *w1, True, out=hbuf, ctx=ctx)
                 out = Kk.fused_quantized_linear(hid, *w2, False, ctx=ctx)
-                assert np.array_equal(hid.numpy(), hid_ref), (b, m, wgs)
-                assert np.array_equal(out.numpy(), out_ref), (b, m, wgs)
+                assert np.array_equal(hid.numpy(), hid_ref), (b, m, rs)
+                assert np.array_equal(out.numpy(), out_ref), (b, m, rs)
                 # rewrite the buffer with different data of the same shape: the statistics must not survive
                 y = Kk.mul(hid, np.array([0.5], np.float32), out=hbuf, ctx=ctx)
                 assert np.array_equal(Kk.fused_quantized_linear(y, *w2, False, ctx=ctx).numpy(),
-                                      orc.fused_quantized_linear(hid_ref * np.float32(0.5), w2[0].arr, w2[1].arr, [128.0], w2[3].arr, False)), (b, m, wgs)
-        # the three-kernel chain consumes the same statistics
-        with _env(LELE_HIP_QLINEAR_ONEPASS=1):
-            hid = Kk.fused_quantized_linear(ctx.buf().upload(x), *w1, True, ctx=ctx)
-        with _env(LELE_HIP_QLINEAR_ONEPASS=0):
-            assert np.array_equal(Kk.fused_quantized_linear(hid, *w2, False, ctx=ctx).numpy(), out_ref), (b, m)
+                                      orc.fused_quantized_linear(hid_ref * np.float32(0.5), w2[0].arr, w2[1].arr, [128.0], w2[3].arr, False)), (b, m, rs)
 
 
 @pytest.mark.gpu

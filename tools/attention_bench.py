@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Time lele_hip_attention_view at the SenseVoice-shaped sizes (BASELINE configs[2]: 1 x 504 rows, configs[3]: 32 x 171 rows;
-4 heads of 128) in its one-launch forms (32 / 64 query rows per workgroup) and as the three-call sequence it replaces.
+4 heads of 128) as the library dispatches it, as the f32 replica, and as the three-call sequence it replaces (with the lab
+library also the row-block forms selected by hand).
 Twenty calls are captured into a hipGraph and its replays timed with HIP events.  Output: one JSON object."""
 import argparse
 import json
@@ -33,12 +34,14 @@ def main():
         dst = ctx.buf()
         flops = 2 * 2 * b * H * t * t * DH
         row = {}
-        for label, env in (("default (one pass over the keys for a batch)", {"LELE_HIP_ATTENTION_MIN_BLOCKS": "1"}),
-                           ("replica (LELE_HIP_ATTENTION_EXACT=1)", {"LELE_HIP_ATTENTION_MIN_BLOCKS": "1", "LELE_HIP_ATTENTION_EXACT": "1"}),
-                           ("fused rt=1", {"LELE_HIP_ATTENTION_RT": "1", "LELE_HIP_ATTENTION_MIN_BLOCKS": "1", "LELE_HIP_ATTENTION_ROWS": "32"}),
-                           ("fused rt=2", {"LELE_HIP_ATTENTION_RT": "2", "LELE_HIP_ATTENTION_MIN_BLOCKS": "1", "LELE_HIP_ATTENTION_ROWS": "32"}),
-                           ("fused 16 rows", {"LELE_HIP_ATTENTION_RT": "1", "LELE_HIP_ATTENTION_MIN_BLOCKS": "1", "LELE_HIP_ATTENTION_ROWS": "16"}),
-                           ("sequence", {"LELE_HIP_ATTENTION_FUSED": "0"})):
+        variants = [("default (one pass over the keys for a batch)", {"LELE_HIP_ATTENTION_MIN_BLOCKS": "1"}),
+                    ("replica (LELE_HIP_ATTENTION_EXACT=1)", {"LELE_HIP_ATTENTION_MIN_BLOCKS": "1", "LELE_HIP_ATTENTION_EXACT": "1"}),
+                    ("sequence", {"LELE_HIP_ATTENTION_FUSED": "0"})]
+        if os.environ.get("LELE_HIP_LAB") == "1":  # the row-block forms by hand: lab-only switches
+            variants += [("fused rt=1", {"LELE_HIP_ATTENTION_RT": "1", "LELE_HIP_ATTENTION_MIN_BLOCKS": "1", "LELE_HIP_ATTENTION_ROWS": "32"}),
+                         ("fused rt=2", {"LELE_HIP_ATTENTION_RT": "2", "LELE_HIP_ATTENTION_MIN_BLOCKS": "1", "LELE_HIP_ATTENTION_ROWS": "32"}),
+                         ("fused 16 rows", {"LELE_HIP_ATTENTION_RT": "1", "LELE_HIP_ATTENTION_MIN_BLOCKS": "1", "LELE_HIP_ATTENTION_ROWS": "16"})]
+        for label, env in variants:
             if args.only and args.only not in label:
                 continue
             old = {k: os.environ.get(k) for k in env}

@@ -22,9 +22,9 @@ def main():
                 Weight((rng.standard_normal(nn) * 0.02).astype(np.float32)))
     w, w2 = lin(k, n), lin(n, 512)
     x = ctx.buf().upload((rng.standard_normal((b, m, k)) * rng.uniform(0.3, 3, (b, 1, 1))).astype(np.float32))
-    os.environ["LELE_HIP_IGEMM_WHOLEK"] = "0"
+    os.environ["LELE_HIP_IGEMM_RS"] = "0"
     ref = K.fused_ffn_quantized(x, *w, *w2, False, ctx=ctx).numpy().copy()
-    del os.environ["LELE_HIP_IGEMM_WHOLEK"]
+    del os.environ["LELE_HIP_IGEMM_RS"]
     bad = 0
     ob = ctx.buf()
     for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 300):

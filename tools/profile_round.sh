@@ -31,8 +31,13 @@ timeout 280 python $R/tools/microbench.py --out "$OUT/microbench.json" > "$OUT/m
 timeout 200 python $R/tools/qlinear_bench.py --out "$OUT/qlinear.json" > "$OUT/qlinear.log" 2>&1
 # 6. the fused attention kernel and the persistent i8 GEMM from the inside (cycle-counter stamps per phase), and their timings
 timeout 120 python $R/tools/attention_bench.py > "$OUT/attention_bench.json" 2> "$OUT/attention_bench.log"
-timeout 120 python $R/tools/attention_stamps.py > "$OUT/attention_stamps.txt" 2> "$OUT/attention_stamps.log"
-timeout 120 python $R/tools/wholek_stamps.py > "$OUT/wholek_stamps.txt" 2> "$OUT/wholek_stamps.log"
+if [ -f $R/lele_amd/liblele_hip_lab.so ]; then
+  LELE_HIP_LAB=1 timeout 120 python $R/tools/attention_stamps.py > "$OUT/attention_stamps.txt" 2> "$OUT/attention_stamps.log"
+fi
+timeout 120 python $R/tools/rs_bench.py > "$OUT/rs_bench.txt" 2> "$OUT/rs_bench.log"
+if [ -f $R/lele_amd/liblele_hip_lab.so ]; then  # stamps exist in the lab build only
+  LELE_HIP_LAB=1 timeout 120 python $R/tools/rs_stamps.py > "$OUT/rs_stamps.txt" 2> "$OUT/rs_stamps.log"
+fi
 # 7. the sharded recogniser step through the C ABI alone: the native runner on a 2-layer SenseVoice-shaped plan, one rank per visible
 #    GPU (fork before any HIP call, file rendezvous, RCCL all-gather of the decoded ids through lele_hip_comm_*)
 NGPU=$(python3 -c "import torch; print(max(1, torch.cuda.device_count()))" 2>/dev/null || echo 1)

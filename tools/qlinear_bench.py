@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-call time of fused_quantized_linear at the SenseVoice shapes, free of host overhead: 20 calls are recorded into one
-hipGraph and the replay is timed with HIP events on the ctx stream.  Variants are selected through the library's tuning
-environment (read per call): the three-kernel chain vs the one-pass kernel at several workgroup targets.
+hipGraph and the replay is timed with HIP events on the ctx stream.  Variants: the default routing (register-stationary kernels
+where the sizes allow) against the tiled chain (LELE_HIP_IGEMM_RS=0); with the lab library (LELE_HIP_LAB=1) also the tiled
+kernel's tile shapes (LELE_HIP_IGEMM_TILE, a lab-only switch).
 
     gpurun -- 'python tools/qlinear_bench.py --out gpurun_out/qlinear.json'
 """
@@ -19,7 +20,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--calls", type=int, default=20)
-    ap.add_argument("--debug", action="store_true")
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     import lele_amd
@@ -30,13 +30,9 @@ def main():
     shapes = [("c4 qkv", 32, 171, 512, 1536, False), ("c4 out", 32, 171, 512, 512, False), ("c4 ffn1", 32, 171, 512, 2048, True),
               ("c4 ffn2", 32, 171, 2048, 512, False), ("c3 qkv", 1, 504, 512, 1536, False), ("c3 out", 1, 504, 512, 512, False),
               ("c3 ffn1", 1, 504, 512, 2048, True), ("c3 ffn2", 1, 504, 2048, 512, False)]
-    variants = [("chain", {"LELE_HIP_QLINEAR_ONEPASS": "0"})] + [("chain tile=%d" % t, {"LELE_HIP_IGEMM_TILE": str(t)}) for t in range(1, 15)] + [("onepass", {"LELE_HIP_QLINEAR_ONEPASS": "1"})] + [
-        ("onepass rb=%d wgs=%d" % (rb, w), {"LELE_HIP_QLINEAR_ONEPASS": "1", "LELE_HIP_ONEPASS_RB": str(rb), "LELE_HIP_ONEPASS_WGS": str(w)})
-        for rb, w in ((1, 192), (1, 384), (2, 384))]
-    if args.debug:  # phase ablation of the one-pass kernel (results are wrong by construction)
-        variants = [("chain", {"LELE_HIP_QLINEAR_ONEPASS": "0"})] + [
-            ("onepass wgs=%d dbg=%d" % (w, d), {"LELE_HIP_QLINEAR_ONEPASS": "1", "LELE_HIP_ONEPASS_WGS": str(w), "LELE_HIP_ONEPASS_DEBUG": str(d)})
-            for w in (384,) for d in (0, 1, 2, 4, 3, 5, 6, 7)]
+    variants = [("default", {}), ("tiled chain", {"LELE_HIP_IGEMM_RS": "0"})]
+    if os.environ.get("LELE_HIP_LAB") == "1":
+        variants += [("tiled chain tile=%d" % t, {"LELE_HIP_IGEMM_RS": "0", "LELE_HIP_IGEMM_TILE": str(t)}) for t in range(1, 15)]
     res = []
     for name, b, m, k, n, relu in shapes:
         if args.only and args.only not in name:

@@ -57,7 +57,7 @@ def main():
             shutil.copy(p, os.path.join(dst, "%s_sensevoice_%s_compiled_kernel_stats.csv" % (tag, c)))
     for a, b in (("microbench.json", "_microbench.json"), ("qlinear.json", "_qlinear_variants.json"), ("valu_rate.json", "_valu_rate.json"),
                  ("attention_bench.json", "_attention_bench.json"), ("attention_stamps.txt", "_attention_stamps.txt"),
-                 ("wholek_stamps.txt", "_wholek_stamps.txt")):
+                 ("rs_stamps.txt", "_rs_stamps.txt"), ("rs_bench.txt", "_rs_bench.txt")):
         if os.path.exists(os.path.join(src, a)) and os.path.getsize(os.path.join(src, a)) > 2:
             shutil.copy(os.path.join(src, a), os.path.join(dst, tag + b))
     pmc = {}
