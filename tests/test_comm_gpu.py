@@ -69,7 +69,7 @@ def test_native_runner_ranks_and_decode(ctx, tmp_path):
 def test_bench_two_ranks_on_one_gpu_end_to_end():
     """`bench.py --gpus 2` starts its own two ranks.  On a one-GPU box both share the device (LELE_BENCH_SHARE_GPU) and the process
     group is gloo; RCCL refuses two ranks on one device, so the C ABI communicator cannot come up -- every rank must then agree
-    to move the ids through the process group instead, and the line must say so.  What this pins on real hardware: the N > 1
+    to move the ids through the process group instead (bench.py permits that only under --allow-fallback), and the line must say so.  What this pins on real hardware: the N > 1
     control flow (sharding by rank, fences, MAX over ranks, the transport agreement, the gather and its self-check) and that the
     JSON line is the LAST line on stdout whatever the collective library prints."""
     import json
@@ -80,7 +80,7 @@ def test_bench_two_ranks_on_one_gpu_end_to_end():
     env = dict(os.environ, LELE_BENCH_SHARE_GPU="1", LELE_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64",
-                        "--layers", "2", "--per-gpu", "4", "--sv-steps", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                        "--layers", "2", "--per-gpu", "4", "--sv-steps", "2", "--allow-fallback"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
