@@ -291,6 +291,30 @@ __global__ void reduce_kernel(int op, const float* __restrict__ x, float* __rest
     out[o] = acc;
 }
 
+// max / min over a contiguous innermost axis (order-free, so any tree gives the reference's value): 16 lanes per output row read
+// the row coalesced and meet by shuffle -- the one-thread-per-output form above reads it with a row-length lane stride
+__global__ __launch_bounds__(256) void reduce_minmax_last_kernel(int op, const float* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                                 int64_t n) {
+    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int l = threadIdx.x & 15;
+    // the sequential scan keeps the FIRST of equal values (only +0 / -0 can tell): carry the position, earlier wins a tie
+    float acc = op == R_MAX ? -INFINITY : INFINITY;
+    int64_t at = n;
+    if (r < rows) {
+        const float* row = x + r * n;
+        for (int64_t j = l; j < n; j += 16) {
+            const float v = row[j];
+            if (op == R_MAX ? v > acc : v < acc) acc = v, at = j;  // NaN never wins, as in `v > acc ? v : acc`
+        }
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+        const float o = __shfl_xor(acc, off, 16);
+        const int64_t oa = __shfl_xor(at, off, 16);
+        if ((op == R_MAX ? o > acc : o < acc) || (o == acc && oa < at)) acc = o, at = oa;
+    }
+    if (r < rows && l == 0) out[r] = acc;
+}
+
 // ------------------------------------------------------------------------------------------ row statistics
 // 32 lanes play the 4x8 accumulator slots of the AVX2 code: slot l = 8*u + i accumulates elements j = 32c + l.
 // Returns (in every lane of the 32-lane group) hsum( (s0+s1)+(s2+s3) [+ 8-wide remainder chunks] ) + scalar tail.
@@ -706,8 +730,18 @@ int lele_hip_reduce(LeleCtx* ctx, int op, const LeleTensor* x, const int64_t* ax
     LELE_TRY(ctx->dev_ptr(x, &dx));
     LELE_TRY(out->reserve((size_t)on * 4));
     if (on) {
-        hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((on + 63) / 64)), dim3(64), 0, ctx->stream, op,
-                           (const float*)dx, (float*)out->data, on, rd);
+        bool rows_first = (op == R_MAX || op == R_MIN) && rd.rank_red == 1 && rd.red_stride[0] == 1 && rd.red_count >= 16 && on < (int64_t(1) << 34);
+        int64_t expect = rd.red_count;  // the kept dims must be laid out row after row: output o starts at o * red_count
+        for (int d = rd.rank_keep - 1; rows_first && d >= 0; --d) {
+            rows_first = rd.keep_stride[d] == expect;
+            expect *= rd.keep_shape[d];
+        }
+        if (rows_first)
+            hipLaunchKernelGGL(reduce_minmax_last_kernel, dim3((unsigned)((on + 15) / 16)), dim3(256), 0, ctx->stream, op, (const float*)dx,
+                               (float*)out->data, on, rd.red_count);
+        else
+            hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((on + 63) / 64)), dim3(64), 0, ctx->stream, op,
+                               (const float*)dx, (float*)out->data, on, rd);
         LELE_HIP_CHECK(hipGetLastError());
     }
     return set_shape_v(out_shape, out_rank, oshape);

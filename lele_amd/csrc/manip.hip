@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ x, 
         __syncthreads();
         if (threadIdx.x == 0) alive = 0;
         const int64_t cn = n - c0 < 2048 ? n - c0 : 2048;
-        for (int t = threadIdx.x; t < 2048; t += 256) chunk[t] = t < cn ? row[c0 + t] : __builtin_nanf("");
+        const int nq = (int)((cn + 3) >> 2);  // float4 groups that hold anything: a row of 80 scans 20 of them, not 512
+        for (int t = threadIdx.x; t < 4 * nq; t += 256) chunk[t] = t < cn ? row[c0 + t] : __builtin_nanf("");
         __syncthreads();
         if (rank < k) {
             // four candidates per LDS read; slots past cn hold NaN, which never counts.  A chunk that lies entirely
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ x, 
             const float4* c4 = reinterpret_cast<const float4*>(chunk);
             if (before >= 2048) {
 #pragma unroll 8
-                for (int t = 0; t < 512; ++t) {
+                for (int t = 0; t < nq; ++t) {
                     const float4 u = c4[t];
                     if (largest)
                         add += (int)(u.x >= v) + (int)(u.y >= v) + (int)(u.z >= v) + (int)(u.w >= v);
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ x, 
                 }
             } else if (before < 0) {
 #pragma unroll 8
-                for (int t = 0; t < 512; ++t) {
+                for (int t = 0; t < nq; ++t) {
                     const float4 u = c4[t];
                     if (largest)
                         add += (int)(u.x > v) + (int)(u.y > v) + (int)(u.z > v) + (int)(u.w > v);
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ x, 
                         add += (int)(u.x < v) + (int)(u.y < v) + (int)(u.z < v) + (int)(u.w < v);
                 }
             } else {
-                for (int t = 0; t < 512; ++t) {
+                for (int t = 0; t < nq; ++t) {
                     const float4 u = c4[t];
                     const float uu[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll

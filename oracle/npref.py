@@ -94,10 +94,12 @@ def reduce(op, x, axes, keepdims):
     perm = keep + ax
     xt = np.transpose(x, perm).reshape(int(np.prod([x.shape[d] for d in keep], dtype=np.int64)), -1)
     n = xt.shape[1]
-    if op == "max":
-        out = xt.max(axis=1) if n else np.full(xt.shape[0], -np.inf, np.float32)
-    elif op == "min":
-        out = xt.min(axis=1)
+    if op in ("max", "min"):  # math.rs:1745-1756: `if val > *p { *p = val }` from -inf in input order -- NaN never wins, the first of equal values stays
+        out = np.full(xt.shape[0], -np.inf if op == "max" else np.inf, np.float32)
+        with np.errstate(invalid="ignore"):
+            for j in range(n):
+                col = xt[:, j]
+                out = np.where(col > out if op == "max" else col < out, col, out)
     else:
         acc = np.zeros(xt.shape[0], np.float32)
         for j in range(n):  # sequential f32 accumulation in input order

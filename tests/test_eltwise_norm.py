@@ -199,6 +199,18 @@ def test_device_where_clip_reduce_bit_exact(ctx):
                 got = fn(big, axes, kd, ctx=ctx)
                 ref = npref.reduce(op, big, axes, kd)
                 assert got.shape == ref.shape and np.array_equal(got.numpy(), ref), (op, axes, kd)
+    # max / min over a long contiguous last axis take the 16-lanes-per-row kernel: same value as the sequential scan, signed zeros and
+    # NaN included (the first of equal values wins; NaN never does)
+    wide = (rng.standard_normal((5, 37, 80)) * 3).astype(np.float32)
+    wide[0, 0, :] = -0.0
+    wide[0, 0, 17] = 0.0
+    wide[0, 1, :] = 0.0
+    wide[0, 1, 40] = -0.0
+    wide[1, 2, 5] = np.nan
+    wide[1, 3, :] = np.nan
+    for axes, kd in (([-1], False), ([2], True)):
+        got, ref = Kk.reduce_max(wide, axes, kd, ctx=ctx).numpy(), npref.reduce("max", wide, axes, kd)
+        assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     with pytest.raises(lele_amd.LeleError, match="broadcastable"):
         Kk.add(np.zeros((2, 3), np.float32), np.zeros((4,), np.float32), ctx=ctx)
 

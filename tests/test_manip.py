@@ -144,7 +144,7 @@ def test_device_topk_long_rows_with_ties(ctx):
     # rows longer than the 2048-element LDS chunk, heavy ties (stable: the lower index ranks first), both directions
     from lele_amd import kernels as Kk
     rng = np.random.default_rng(7)
-    for n, k in ((5000, 300), (24000, 300), (2049, 2049), (300, 7)):
+    for n, k in ((5000, 300), (24000, 300), (2049, 2049), (300, 7), (80, 1), (81, 5), (3, 3)):
         x = np.round(rng.standard_normal((3, n)) * 3).astype(np.float32)
         for largest in (True, False):
             v, i = Kk.topk(x, k, -1, largest, True, ctx=ctx)

@@ -26,6 +26,10 @@ for C in c3 c4; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/sv" -o ${C}_compiled -- \
       python $R/tools/sensevoice_graph.py --compiled-only --configs $C --runs 8 > "$OUT/sv_${C}.json" 2> "$OUT/sv_${C}.log"
 done
+# 4b. configs[4]: the Yolo26n-seg-shaped network at batch 64 as one compiled graph (per-image check against the batch-1 plan inside)
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/yolo" -o n64 -- \
+    python $R/tools/yolo_graph.py --batch 64 --check 4 --runs 5 --out "$OUT/yolo_n64_under_rocprof.json" > "$OUT/yolo_prof.log" 2>&1
+timeout 300 python $R/tools/yolo_graph.py --batch 64 --check 8 --out "$OUT/yolo_n64.json" > "$OUT/yolo.log" 2>&1
 # 5. operator micro-benchmarks
 timeout 280 python $R/tools/microbench.py --out "$OUT/microbench.json" > "$OUT/microbench.log" 2>&1
 timeout 200 python $R/tools/qlinear_bench.py --out "$OUT/qlinear.json" > "$OUT/qlinear.log" 2>&1

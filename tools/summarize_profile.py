@@ -55,7 +55,10 @@ def main():
         p = os.path.join(src, "sv", c + "_compiled_kernel_stats.csv")
         if os.path.exists(p):
             shutil.copy(p, os.path.join(dst, "%s_sensevoice_%s_compiled_kernel_stats.csv" % (tag, c)))
-    for a, b in (("microbench.json", "_microbench.json"), ("qlinear.json", "_qlinear_variants.json"), ("valu_rate.json", "_valu_rate.json"),
+    p = os.path.join(src, "yolo", "n64_kernel_stats.csv")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, "%s_yolo_shaped_n64_kernel_stats.csv" % tag))
+    for a, b in (("yolo_n64.json", "_yolo_shaped_n64.json"), ("microbench.json", "_microbench.json"), ("qlinear.json", "_qlinear_variants.json"), ("valu_rate.json", "_valu_rate.json"),
                  ("attention_bench.json", "_attention_bench.json"), ("attention_stamps.txt", "_attention_stamps.txt"),
                  ("rs_stamps.txt", "_rs_stamps.txt"), ("rs_bench.txt", "_rs_bench.txt")):
         if os.path.exists(os.path.join(src, a)) and os.path.getsize(os.path.join(src, a)) > 2:
