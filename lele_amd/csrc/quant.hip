@@ -961,12 +961,18 @@ int rs_kp(int64_t k) {
     const int64_t kp = (k + 31) & ~int64_t(31);
     return kp == 512 || kp == 2048 ? (int)kp : 0;
 }
-bool rs_fits(LeleCtx* ctx, int64_t rows, int64_t n, int kp) {
-    if (!kp || env_int("LELE_HIP_IGEMM_RS", 1) == 0) return false;  // documented switch: 0 = the tiled kernels everywhere
-    if (n % 4 || rows * n >= (int64_t(1) << 30)) return false;  // 16-byte stores; 32-bit byte offsets into the result
+// enough 32 x 32 tiles to fill the chip, 16-byte stores, 32-bit byte offsets into the result
+bool rs_enabled(LeleCtx* ctx, int64_t rows, int64_t n) {
+    if (env_int("LELE_HIP_IGEMM_RS", 1) == 0) return false;  // documented switch: 0 = the tiled kernels everywhere
+    if (n % 4 || rows * n >= (int64_t(1) << 30)) return false;
     const int64_t units = ((rows + 31) / 32) * ((n + 31) / 32);
     return units >= (int64_t)lab_int("LELE_HIP_IGEMM_RS_MIN", 8 * ctx->num_cus);
 }
+// the stand-alone linear.  Measured on one configs[3] shard (tools/rs_bench.py, whole op incl. the row quantisation): N = 1536
+// 24.9 us against 28.7 us tiled, N = 2048 27.2 against 29.5 -- but N = 512 23.0 against 18.7 (few column tiles: the
+// weights-in-registers prologue is not amortised), and a stand-alone K = 2048 linear 54.9 against 41.3 (the fused feed-forward
+// block calls the K-split kernel itself, on a hidden layer that is already in fragment order)
+bool rs_fits(LeleCtx* ctx, int64_t rows, int64_t n, int kp) { return kp == 512 && n >= 1024 && rs_enabled(ctx, rows, n); }
 // weights in fragment order + column sums: cached for declared-immutable weights, packed into the arena per call otherwise
 int frag_weights_of(LeleCtx* ctx, const LeleTensor* w, int k, int n, int kp, FragW* out) {
     const int ks = kp / 32, nt = (n + 31) / 32;
@@ -1314,8 +1320,8 @@ int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const Le
                          (ws1_len == 1 || ws1_len >= n1) && (b1_len == 0 || b1_len >= n1) && n2 >= 1;
     // register-stationary route (igemm_rs.h): K = 512 into a hidden layer of exactly 2048 columns, whose i8 form is written in the
     // fragment order of the second product and read once
-    const bool rs_route = env_int("LELE_HIP_FFN_FUSED", 1) != 0 && args_ok && rs_kp(k1) == 512 && n1 == 2048 && rs_fits(ctx, rows, n1, 512) &&
-                          rs_fits(ctx, rows, n2, 2048);
+    const bool rs_route = env_int("LELE_HIP_FFN_FUSED", 1) != 0 && args_ok && rs_kp(k1) == 512 && n1 == 2048 && rs_enabled(ctx, rows, n1) &&
+                          rs_enabled(ctx, rows, n2);
     bool fused = rs_route || (env_int("LELE_HIP_FFN_FUSED", 1) != 0 && args_ok && n1 % 128 == 0 && m >= 128 &&
                               ((rows + 127) / 128) * (n1 / 128) >= 2 * (int64_t)ctx->num_cus);
     if (fused && res1) {

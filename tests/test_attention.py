@@ -43,7 +43,8 @@ def close(a, b, what, rtol=1e-4):
 # ((8, 171)), the one-pass batch kernel from half a chip's worth of 128-row blocks ((32, 171)); with LELE_HIP_ATTENTION_EXACT=1 the
 # f32 replicas: 16 / 32 rows, and 64 rows per workgroup for large grids ((64, 171))
 @pytest.mark.parametrize("exact", [0, 1])
-@pytest.mark.parametrize("b,t", [(32, 171), (1, 504), (2, 33), (3, 64), (1, 512), (2, 100), (5, 1), (1, 8), (2, 65), (8, 171), (64, 171)])
+@pytest.mark.parametrize("b,t", [(32, 171), (1, 504), (2, 33), (3, 64), (1, 512), (2, 100), (5, 1), (1, 8), (2, 65), (8, 171), (64, 171),
+                                 (1, 300), (2, 257), (1, 256), (1, 449)])   # the last four: more single-utterance lengths (key counts off every tile boundary)
 def test_attention_view_against_oracle_and_sequence(ctx, orc, b, t, exact):
     from lele_amd import kernels as K
     from lele_amd._lib import Weight

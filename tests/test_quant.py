@@ -211,7 +211,7 @@ def test_fused_ffn_never_stores_the_hidden_layer_and_keeps_every_bit(ctx):
         return (Weight(np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32)),
                 Weight((rng.random(n) * 0.01 + 0.002).astype(np.float32)), Weight(np.array([128.0], np.float32)),
                 Weight(rng.standard_normal(n).astype(np.float32) * 0.1))
-    for b, m, k1, n1, n2, relu2 in ((32, 171, 512, 2048, 512, False), (16, 300, 200, 2048, 72, True), (1, 4800, 512, 2048, 512, False),
+    for b, m, k1, n1, n2, relu2 in ((32, 171, 512, 2048, 512, False), (16, 300, 200, 2048, 72, True), (1, 4800, 512, 2048, 512, False), (9, 1000, 500, 2048, 260, False),
                                     (2, 33, 64, 128, 32, False), (1, 504, 512, 2048, 512, False), (40, 129, 96, 2176, 64, False),
                                     (70, 128, 500, 1024, 72, False), (5, 2001, 512, 640, 36, True)):
         x = (rng.standard_normal((b, m, k1)) * rng.uniform(0.3, 3.0, (b, 1, 1))).astype(np.float32)
@@ -245,17 +245,18 @@ def test_fused_ffn_never_stores_the_hidden_layer_and_keeps_every_bit(ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("b,m,k,n,relu,bias,scalar_ws", [
-    (1, 8300, 512, 260, False, True, False),     # one slice, rows not a multiple of 32, a partial last column tile (n % 32 = 4)
-    (9, 1000, 500, 384, True, True, False),      # K padded to 512 with zero bytes; slices straddle row tiles at every offset
-    (70, 128, 512, 256, False, False, False),    # slices of exactly four row tiles; no bias
+    (1, 8300, 512, 1028, False, True, False),    # one slice, rows not a multiple of 32, a partial last column tile (n % 32 = 4)
+    (9, 1000, 500, 1536, True, True, False),     # K padded to 512 with zero bytes; slices straddle row tiles at every offset
+    (70, 128, 512, 1024, False, False, False),   # slices of exactly four row tiles; no bias; the narrowest result the route takes
     (3, 3333, 512, 1536, False, True, True),     # one weight scale for all columns; 9999 rows
-    (64, 171, 512, 196, True, True, False),      # the configs[3] row structure with a narrow, ragged result
-    (12, 700, 2040, 260, False, True, False),    # K padded to 2048: the K-split form (four waves a tile), ragged columns
-    (32, 171, 2048, 512, True, True, False),     # configs[3]'s second feed-forward layer
+    (64, 171, 512, 1156, True, True, False),     # the configs[3] row structure with a ragged result
+    (64, 171, 512, 196, True, True, False),      # narrow results and stand-alone K = 2048 stay on the tiled kernels (measured
+    (32, 171, 2048, 512, True, True, False),     # slower on this route): same bits either way
 ])
 def test_register_stationary_gemm_bit_exact_on_edge_shapes(ctx, b, m, k, n, relu, bias, scalar_ws):
-    """igemm_rs_kernel / igemm_rs_ks4_kernel serve every quantised linear with K padded to 512 / 2048 bytes and enough 32 x 32
-    tiles to fill the chip: bit-exact with the oracle on shapes chosen for their edges -- row tiles that end inside a slice,
+    """igemm_rs_kernel serves the quantised linears with K padded to 512 bytes, results at least 1024 wide and enough 32 x 32
+    tiles to fill the chip (the K-split igemm_rs_ks4_kernel runs inside the fused feed-forward block: test_fused_ffn_*):
+    bit-exact with the oracle on shapes chosen for their edges -- row tiles that end inside a slice,
     column tiles that end inside a 4-column group, slices of every alignment, rows % 32 != 0 -- and identical to the tiled
     kernels' result (LELE_HIP_IGEMM_RS=0)"""
     from lele_amd import kernels as K
