@@ -38,6 +38,10 @@ timeout 120 python $R/tools/attention_bench.py > "$OUT/attention_bench.json" 2> 
 if [ -f $R/lele_amd/liblele_hip_lab.so ]; then
   LELE_HIP_LAB=1 timeout 120 python $R/tools/attention_stamps.py > "$OUT/attention_stamps.txt" 2> "$OUT/attention_stamps.log"
 fi
+# 6b. the attention kernels' matrix-core and vector-pipe occupancy in ONE counter pass (kernel-trace only beside it): does the
+#     MFMA of one tile issue under the VALU of another?
+timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv \
+    -d "$OUT/pmc_attn" -o attn -- python $R/tools/attention_bench.py --only default --reps 40 > "$OUT/pmc_attn.json" 2> "$OUT/pmc_attn.log"
 timeout 120 python $R/tools/rs_bench.py > "$OUT/rs_bench.txt" 2> "$OUT/rs_bench.log"
 if [ -f $R/lele_amd/liblele_hip_lab.so ]; then  # stamps exist in the lab build only
   LELE_HIP_LAB=1 timeout 120 python $R/tools/rs_stamps.py > "$OUT/rs_stamps.txt" 2> "$OUT/rs_stamps.log"

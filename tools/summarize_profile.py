@@ -17,6 +17,7 @@ import collections
 import csv
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -63,6 +64,27 @@ def main():
                  ("rs_stamps.txt", "_rs_stamps.txt"), ("rs_bench.txt", "_rs_bench.txt")):
         if os.path.exists(os.path.join(src, a)) and os.path.getsize(os.path.join(src, a)) > 2:
             shutil.copy(os.path.join(src, a), os.path.join(dst, tag + b))
+    # attention kernels: matrix-core busy cycles and VALU-active cycles from ONE pass, per kernel, averaged per launch
+    apath = os.path.join(src, "pmc_attn", "attn_counter_collection.csv")
+    if os.path.exists(apath):
+        per = collections.defaultdict(lambda: collections.defaultdict(list))
+        with open(apath) as f:
+            for r in csv.DictReader(f):
+                m = re.search(r"attention\w*_kernel(<[^>]*>)?", r["Kernel_Name"])
+                if m:
+                    per[m.group(0)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        rep = {}
+        for k, cs in per.items():
+            row = {c: sum(v) / len(v) for c, v in cs.items()}
+            row["launches"] = len(next(iter(cs.values())))
+            if row.get("SQ_BUSY_CYCLES"):
+                # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the SIMDs of every CU; SQ_BUSY_CYCLES per SE: report raw + the ratio
+                row["mfma_busy_over_valu_active"] = round(row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(1.0, row.get("SQ_ACTIVE_INST_VALU", 1.0)), 3)
+            rep[k] = row
+        json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU in one pass over "
+                           "tools/attention_bench.py --only default (32 x 171, 1 x 504, 8 x 171, 64 x 171 rows); averages per launch; SQ_WAVE_CYCLES / "
+                           "SQ_ACTIVE_INST_* are in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles (MI355X_MICROARCH.md)", "kernels": rep},
+                  open(os.path.join(dst, tag + "_attention_pmc.json"), "w"), indent=1)
     pmc = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         got = counters(os.path.join(src, "pmc_" + c, "bench_counter_collection.csv"))
