@@ -11,6 +11,8 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 # 0. VALU issue-rate microbenchmark (the ceiling the front-end's pass loop is priced against)
 $R/tools/valu_rate > "$OUT/valu_rate.json" 2> "$OUT/valu_rate.err"
+# 0b. what the CU-side load path delivers (shared lines, shared lines in different orders, private regions): section 3.3's figure
+[ -x $R/tools/l2bw ] && timeout 60 $R/tools/l2bw > "$OUT/l2bw.txt" 2> "$OUT/l2bw.err"
 # 1. the default bench invocation: plain, and under rocprofv3 --kernel-trace --stats (front-end leg only under the profiler)
 timeout 280 python $R/bench.py > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.log"
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python $R/bench.py --no-model --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"

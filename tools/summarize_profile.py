@@ -61,7 +61,7 @@ def main():
         shutil.copy(p, os.path.join(dst, "%s_yolo_shaped_n64_kernel_stats.csv" % tag))
     for a, b in (("yolo_n64.json", "_yolo_shaped_n64.json"), ("microbench.json", "_microbench.json"), ("qlinear.json", "_qlinear_variants.json"), ("valu_rate.json", "_valu_rate.json"),
                  ("attention_bench.json", "_attention_bench.json"), ("attention_stamps.txt", "_attention_stamps.txt"),
-                 ("rs_stamps.txt", "_rs_stamps.txt"), ("rs_bench.txt", "_rs_bench.txt")):
+                 ("rs_stamps.txt", "_rs_stamps.txt"), ("rs_bench.txt", "_rs_bench.txt"), ("l2bw.txt", "_l2bw.txt")):
         if os.path.exists(os.path.join(src, a)) and os.path.getsize(os.path.join(src, a)) > 2:
             shutil.copy(os.path.join(src, a), os.path.join(dst, tag + b))
     # attention kernels: matrix-core busy cycles and VALU-active cycles from ONE pass, per kernel, averaged per launch
