@@ -52,8 +52,7 @@ struct AttnArgs {
 };
 
 // ---- split-bf16 products (the default; LELE_HIP_ATTENTION_EXACT=1 keeps the f32 MFMA of the node sequence) ---------------------
-// The f32-input MFMA runs at the f32 VECTOR rate -- 64 cycles per 32x32x2 -- and, measured here, on the vector pipe's time: making
-// the softmax 10x cheaper did not move the kernel while the products were f32.  A bf16 MFMA does eight times the k extent in
+// The f32-input MFMA runs at the f32 VECTOR rate -- 64 cycles per 32x32x2.  A bf16 MFMA does eight times the k extent in
 // half the cycles, so an f32 value is cut into three bf16 pieces of 8 mantissa bits each (hi + mid + lo == x EXACTLY: truncation,
 // then exact remainders) and a product becomes six bf16 MFMAs (hh, hm, mh, hl, lh, mm; the three dropped terms are <= 2^-24
 // of the product: f32-rounding class).  Six 32-cycle instructions per 16 k against eight 64-cycle ones: 2.7x, on the matrix
