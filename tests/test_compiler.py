@@ -518,6 +518,28 @@ def if_reference(x, w, flag):
     return None   # the SiLU branch goes through the device's polynomial sigmoid: compared with the unfused device ops instead
 
 
+def test_yolo_shaped_graph_compiles_with_the_batch_in_the_graph():
+    """tools/yolo_graph.py (BASELINE configs[4] as one graph): the Yolo26n-seg-shaped ONNX compiles on the CPU at N = 1 and N = 64
+    to the same call sequence -- every Conv + Sigmoid + Mul folded into conv2d_silu, the attention block into view products, the
+    top-300 tail kept (2 topk, 3 gather_elements) -- with the batch size only in the shapes"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from yolo_graph import yolo_onnx
+    from lele_amd.compiler import compile_model
+    hist = {}
+    for n in (1, 64):
+        data, info = yolo_onnx(n, 64)
+        assert info["convolutions"] == 100
+        plan, blob = compile_model(data, "yolo_n%d" % n)
+        fns = [s.get("fn") for s in plan["statements"]]
+        hist[n] = {f: fns.count(f) for f in set(fns)}
+        assert hist[n]["conv2d_silu"] == 86 and hist[n]["conv2d"] == 13 and hist[n]["conv_transpose"] == 1
+        assert hist[n]["topk"] == 2 and hist[n]["gather_elements"] == 3 and hist[n]["matmul_view"] == 2 and "sigmoid" in hist[n]
+        assert len(blob) > 10_000_000 and "silu" not in hist[n]
+    assert hist[1] == hist[64]
+
+
 def test_if_lowering_structure_and_static_inlining():
     data, _w = if_model()
     m = pb.load(data)
