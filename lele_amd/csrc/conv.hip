@@ -481,6 +481,73 @@ __global__ void convt_fill_phase_kernel(float* __restrict__ out, const float* __
     }
 }
 
+// ---- 3 x 3 convolutions with FEW output channels (OC <= 16, IC <= 64: the stem and the narrow bottlenecks of a Yolo-shaped
+// network) -- HBM-bound by their byte counts, and an order of magnitude off that bound as an implicit GEMM whose 32-row MFMA
+// tile is mostly padding.  Direct form: a workgroup owns 8 x 32 output pixels of one image, stages their input window (all
+// channels, halo included, zeros outside the image) in LDS once, and every thread accumulates ALL output channels of its pixel in
+// registers: per (input channel, tap) one LDS read feeds OCB FMAs whose weights arrive as SCALAR operands (the address is
+// wave-uniform: [ic][tap][OCB] re-laid once and cached like the tap-major weights), so the vector pipe does nothing but FMAs.
+// Sum order: (ic, tap) ascending per output -- a permutation of the exact-product sum like every other kernel of this file.
+template <int OCB, int S>
+__global__ __launch_bounds__(256) void conv3x3_direct_kernel(const float* __restrict__ x, const float* __restrict__ wq /*[IC][9][OCB]*/,
+                                                             const float* __restrict__ bias, float* __restrict__ out, ConvGeom g, int act,
+                                                             int tiles_x, int icc /* channels per LDS pass */) {
+    extern __shared__ __attribute__((aligned(16))) float c3_lds[];
+    constexpr int TH = 8, TW = 32, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PP = PW + 1;  // odd row pitch: no 2-way pattern on S = 2
+    const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
+    const int tile = blockIdx.x, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int img = blockIdx.y;
+    const int oy = tyi * TH + ty, ox = txi * TW + tx;
+    const int iy0 = tyi * TH * S - g.pt, ix0 = txi * TW * S - g.pl;
+    const float* xin = x + (int64_t)img * g.c * g.ih * g.iw;
+    float acc[OCB];
+#pragma unroll
+    for (int o = 0; o < OCB; ++o) acc[o] = 0.0f;
+    for (int c0 = 0; c0 < g.c; c0 += icc) {
+        const int nc = g.c - c0 < icc ? g.c - c0 : icc;
+        if (c0) __syncthreads();
+        for (int i = tid; i < nc * PH * PW; i += 256) {
+            const int ic = i / (PH * PW), r = i - ic * (PH * PW), py = r / PW, px = r - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool in = iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+            const float v = xin[((int64_t)(c0 + ic) * g.ih + (in ? iy : 0)) * g.iw + (in ? ix : 0)];
+            c3_lds[(ic * PH + py) * PP + px] = in ? v : 0.0f;
+        }
+        __syncthreads();
+        for (int ic = 0; ic < nc; ++ic) {
+            const float* p = c3_lds + (ic * PH + ty * S) * PP + tx * S;
+            float xv[9];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) xv[3 * a + b] = p[a * PP + b];
+            const float* wv = wq + (int64_t)(c0 + ic) * 9 * OCB;  // wave-uniform: scalar loads
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int o = 0; o < OCB; ++o) acc[o] = __builtin_fmaf(xv[t], wv[t * OCB + o], acc[o]);
+        }
+    }
+    if (oy >= g.oh || ox >= g.ow) return;
+    const int pos = oy * g.ow + ox;
+    const bool body = pos < (g.plane & ~7);
+    float* o0 = out + (int64_t)img * g.oc * g.plane + pos;
+#pragma unroll
+    for (int o = 0; o < OCB; ++o)
+        if (o < g.oc) {
+            float v = acc[o];
+            if (bias) v = v + bias[o];
+            o0[(int64_t)o * g.plane] = apply_act(v, act, body);
+        }
+}
+__global__ void conv3x3_wperm_kernel(const float* __restrict__ w, float* __restrict__ wq, int oc, int ic, int ocb) {
+    const int total = ic * 9 * ocb;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int o = i % ocb, t = (i / ocb) % 9, c = i / (9 * ocb);
+        wq[i] = o < oc ? w[((int64_t)o * ic + c) * 9 + t] : 0.0f;
+    }
+}
+
 inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 8192)); }
 inline int64_t attr(const int64_t* v, size_t n, size_t i, int64_t dflt) {
     if (n >= 2) return v[i];  // conv2d.rs:208-243: two values, or one value used for both
@@ -530,6 +597,51 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             hipLaunchKernelGGL(depthwise_conv2d_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dx, dw, db, out, g, act,
                                (unsigned)total);
         }
+    } else if (g.group == 1 && g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.sh == g.sw && (g.sh == 1 || g.sh == 2) && g.oc <= 16 &&
+               g.c <= 64 && g.ow >= 16 && g.n <= 65535 &&
+               (int64_t)g.n * ((g.ow + 31) / 32) * ((g.oh + 7) / 8) >= 2 * (int64_t)ctx->num_cus) {
+        // few channels over a batch: the direct kernel (see conv3x3_direct_kernel).  Measured on the Yolo-shaped network at batch 64
+        // against the implicit GEMM: 3 -> 16 stride 2 at 320 x 320: 227 against 579 us, 16 -> 8 at 160 x 160: 88 against 251,
+        // 8 -> 16: ~95 against 180; with 32 output channels the MFMA tile is full and the GEMM wins (16 -> 32 stride 2: 322 against
+        // 596), and one image does not fill the chip with 8 x 32 tiles -- both stay on the GEMM
+        const int ocb = g.oc <= 8 ? 8 : 16;
+        const size_t wbytes = (size_t)g.c * 9 * ocb * 4;
+        void* dwq = nullptr;
+        const bool cacheable = wt->mem == LELE_MEM_WEIGHT;
+        auto key = std::make_tuple((const void*)wt->data, wbytes, 310 + ocb);
+        auto it = cacheable ? ctx->weights.find(key) : ctx->weights.end();
+        if (it != ctx->weights.end()) {
+            dwq = it->second;
+        } else {
+            if (cacheable) {
+                LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
+                LELE_HIP_CHECK(hipMalloc(&dwq, wbytes));
+                ctx->weights[key] = dwq;
+            } else {
+                LELE_TRY(ctx->arena_alloc(wbytes, &dwq));
+            }
+            hipLaunchKernelGGL(conv3x3_wperm_kernel, dim3(grid_for((int64_t)g.c * 9 * ocb)), dim3(256), 0, ctx->stream, dw, (float*)dwq, g.oc, g.c, ocb);
+        }
+        const int s_ = g.sh, ph = 7 * s_ + 3, pp = 31 * s_ + 3 + 1;
+        int icc = g.c;
+        while ((size_t)icc * ph * pp * 4 > 36 * 1024) icc = (icc + 1) / 2;  // the window of `icc` channels per LDS pass: four workgroups a CU
+        const size_t lds = (size_t)icc * ph * pp * 4;
+        const int tiles_x = (g.ow + 31) / 32, tiles_y = (g.oh + 7) / 8;
+        const dim3 dgrid((unsigned)(tiles_x * tiles_y), (unsigned)g.n);
+#define LELE_C3(OCB_, S_)                                                                                            \
+    do {                                                                                                             \
+        auto kern = conv3x3_direct_kernel<OCB_, S_>;                                                                  \
+        if (lds > 60 * 1024) LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds));     \
+        hipLaunchKernelGGL(kern, dgrid, dim3(256), lds, ctx->stream, dx, (const float*)dwq, db, out, g, act, tiles_x, icc); \
+    } while (0)
+        if (s_ == 1) {
+            if (ocb == 8) LELE_C3(8, 1);
+            else LELE_C3(16, 1);
+        } else {
+            if (ocb == 8) LELE_C3(8, 2);
+            else LELE_C3(16, 2);
+        }
+#undef LELE_C3
     } else {
         ConvWLoad al{dw, g, (int)((((uintptr_t)dw & 15) == 0) && g.K % 4 == 0)};
         ConvEpi epi{out, db, g, act};

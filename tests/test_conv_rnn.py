@@ -242,6 +242,12 @@ CONV_SHAPES = [
     (3, 8, 9, 9, 16, 3, 3, 8, [1, 1], [1], [1], "relu"),                       # channel multiplier 2, short attr forms
     (1, 4, 7, 5, 6, 7, 5, 1, [], [], [], None),                                # kernel == input -> 1x1 output
     (1, 96, 12, 12, 200, 3, 3, 1, [1, 1, 1, 1], [1, 1], [1, 1], None),         # OC > 128 tile, K = 864
+    # few output channels over a batch (>= 512 tiles of 8 x 32 pixels): the direct 3 x 3 kernel -- stride 1 / 2, ragged maps,
+    # asymmetric pads, OC not a multiple of 8, more input channels than one LDS pass holds
+    (48, 16, 48, 48, 8, 3, 3, 1, [1, 1, 1, 1], [1, 1], [1, 1], "silu"),
+    (64, 3, 70, 66, 16, 3, 3, 1, [1, 1, 1, 1], [2, 2], [1, 1], "silu"),
+    (90, 8, 37, 45, 13, 3, 3, 1, [0, 2, 1, 0], [1, 1], [1, 1], "relu"),
+    (176, 64, 40, 36, 5, 3, 3, 1, [1, 0, 1, 2], [2, 2], [1, 1], None),
 ]
 
 
