@@ -294,22 +294,39 @@ __global__ void dq_apply_kernel(const float* __restrict__ x, int64_t len, const 
 }
 
 // ------------------------------------------------------------------------------------------ weights -> i8 [N][Kp]
-__global__ void wpack_kernel(const float* __restrict__ w /*[K][N]*/, int k, int n, int kp, int8_t* __restrict__ wt,
-                             int* __restrict__ col_sums) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;  // coalesced over n
-    if (j >= n) return;
-    int sum = 0;
-    for (int kk = 0; kk < kp; ++kk) {
-        int v = 0;
-        if (kk < k) {
-            const float r = rintf(w[(int64_t)kk * n + j]);  // cvtps + saturating packs (transpose_b_from_f32_avx2)
-            const int u = r < 0.0f ? 0 : (r > 255.0f ? 255 : (int)r);
-            v = u - 128;  // == u8 ^ 0x80 read as i8
-            sum += v;
-        }
-        wt[(int64_t)j * kp + kk] = (int8_t)v;
+// grid (64-column groups, 64-byte chunks of kp), 256 threads: a 64 x 64 tile is read coalesced along n (16 rows per thread, all
+// loads in flight), centred, turned in LDS and written as 16-byte pieces of the [N][Kp] rows; column sums by atomicAdd on zeroed
+// sums (a thread per column walking all of k took 240-410 us per matrix: ~100 ms of a SenseVoice-shaped model's first forward)
+__global__ __launch_bounds__(256) void wpack_kernel(const float* __restrict__ w /*[K][N]*/, int k, int n, int kp, int8_t* __restrict__ wt,
+                                                    int* __restrict__ col_sums) {
+    __shared__ __attribute__((aligned(16))) int8_t s_t[64][80];  // [column][k], 16 bytes of padding per row
+    __shared__ int s_part[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const int j = j0 + c, jc = j < n ? j : n - 1;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int kk = k0 + q * 16 + e;
+        v[e] = w[(int64_t)(kk < k ? kk : k - 1) * n + jc];
     }
-    col_sums[j] = sum;
+    int sum = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        int val = 0;
+        if (k0 + q * 16 + e < k) {
+            const float r = rintf(v[e]);  // cvtps + saturating packs (transpose_b_from_f32_avx2)
+            val = (r < 0.0f ? 0 : (r > 255.0f ? 255 : (int)r)) - 128;  // == u8 ^ 0x80 read as i8
+            sum += val;
+        }
+        s_t[c][q * 16 + e] = (int8_t)val;
+    }
+    s_part[q][c] = sum;
+    __syncthreads();
+    if (q == 0 && j < n) atomicAdd(&col_sums[j], s_part[0][c] + s_part[1][c] + s_part[2][c] + s_part[3][c]);
+    const int cc = threadIdx.x >> 2, seg = threadIdx.x & 3;
+    if (j0 + cc < n && k0 + 16 * seg < kp)  // kp is a multiple of 16: a piece is whole or absent
+        *reinterpret_cast<v4i*>(wt + (int64_t)(j0 + cc) * kp + k0 + 16 * seg) = *reinterpret_cast<const v4i*>(&s_t[cc][16 * seg]);
 }
 
 // ------------------------------------------------------------------------------------------ 3. i8 GEMM
@@ -735,15 +752,35 @@ __global__ void wpack_frag_kernel(const float* __restrict__ w, int k, int n, int
     v4i o = {packed[0], packed[1], packed[2], packed[3]};
     *reinterpret_cast<v4i*>(wf + (blk * 64 + lane) * 16) = o;
 }
-__global__ void wcolsum_kernel(const float* __restrict__ w, int k, int n, int* __restrict__ col_sums) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    int sum = 0;
-    for (int kk = 0; kk < k; ++kk) {
-        const float r = rintf(w[(int64_t)kk * n + j]);
-        sum += (r < 0.0f ? 0 : (r > 255.0f ? 255 : (int)r)) - 128;
+// column sums of the centred weights (exact i32): grid (64-column groups, 64-row chunks of k), 256 threads = 4 k-quarters x 64
+// columns, 16 rows each with every load in flight at once; the quarters meet in LDS, the chunks by atomicAdd on zeroed sums
+// (a thread per column walking all of k took 260 us per weight matrix: 54 ms of a SenseVoice-shaped model's first forward)
+__global__ __launch_bounds__(256) void wcolsum_kernel(const float* __restrict__ w, int k, int n, int* __restrict__ col_sums) {
+    __shared__ int s_part[4][64];
+    const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + c, jc = j < n ? j : n - 1;
+    const int k0 = blockIdx.y * 64 + q * 16;
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int kk = k0 + e;
+        v[e] = w[(int64_t)(kk < k ? kk : k - 1) * n + jc];
     }
-    col_sums[j] = sum;
+    int sum = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float r = rintf(v[e]);
+        sum += k0 + e < k ? (r < 0.0f ? 0 : (r > 255.0f ? 255 : (int)r)) - 128 : 0;
+    }
+    s_part[q][c] = sum;
+    __syncthreads();
+    if (q == 0 && j < n) atomicAdd(&col_sums[j], s_part[0][c] + s_part[1][c] + s_part[2][c] + s_part[3][c]);
+}
+int launch_wcolsum(LeleCtx* ctx, const float* dw, int k, int n, int* dcs) {
+    LELE_HIP_CHECK(hipMemsetAsync(dcs, 0, (size_t)n * 4, ctx->stream));
+    hipLaunchKernelGGL(wcolsum_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((k + 63) / 64)), dim3(256), 0, ctx->stream, dw, k, n, dcs);
+    LELE_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------ host helpers
@@ -777,9 +814,10 @@ int get_packed_weights(LeleCtx* ctx, const LeleTensor* w, const float* dw, int64
         LELE_TRY(ctx->arena_alloc((size_t)nbatch * n * kp, &dwt));
         LELE_TRY(ctx->arena_alloc((size_t)nbatch * n * 4, &dcs));
     }
+    LELE_HIP_CHECK(hipMemsetAsync(dcs, 0, (size_t)nbatch * n * 4, ctx->stream));
     for (int64_t b = 0; b < nbatch; ++b)
-        hipLaunchKernelGGL(wpack_kernel, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, dw + b * (int64_t)k * n, k, n,
-                           kp, (int8_t*)dwt + b * (int64_t)n * kp, (int*)dcs + b * n);
+        hipLaunchKernelGGL(wpack_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((kp + 63) / 64)), dim3(256), 0, ctx->stream,
+                           dw + b * (int64_t)k * n, k, n, kp, (int8_t*)dwt + b * (int64_t)n * kp, (int*)dcs + b * n);
     LELE_HIP_CHECK(hipGetLastError());
     out->wt = (int8_t*)dwt;
     out->col_sums = (int*)dcs;
@@ -810,7 +848,7 @@ int get_frag_weights(LeleCtx* ctx, const LeleTensor* w, int k, int n, int ks, in
     const int64_t threads = (int64_t)nt * 32 * ks * 2;
     hipLaunchKernelGGL(wpack_frag_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)dw, k, n, ks,
                        nt, (int8_t*)dwf);
-    hipLaunchKernelGGL(wcolsum_kernel, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, (const float*)dw, k, n, (int*)dcs);
+    LELE_TRY(launch_wcolsum(ctx, (const float*)dw, k, n, (int*)dcs));
     LELE_HIP_CHECK(hipGetLastError());
     ctx->weights[key_w] = dwf;
     ctx->weights[key_s] = dcs;
@@ -985,7 +1023,7 @@ int frag_weights_of(LeleCtx* ctx, const LeleTensor* w, int k, int n, int kp, Fra
     const int64_t threads = (int64_t)nt * 32 * ks * 2;
     hipLaunchKernelGGL(wpack_frag_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)dw, k, n, ks, nt,
                        (int8_t*)dwf);
-    hipLaunchKernelGGL(wcolsum_kernel, dim3((n + 127) / 128), dim3(128), 0, ctx->stream, (const float*)dw, k, n, (int*)dcs);
+    LELE_TRY(launch_wcolsum(ctx, (const float*)dw, k, n, (int*)dcs));
     LELE_HIP_CHECK(hipGetLastError());
     out->wf = (int8_t*)dwf;
     out->col_sums = (int*)dcs;
