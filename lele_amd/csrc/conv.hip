@@ -548,6 +548,242 @@ __global__ void conv3x3_wperm_kernel(const float* __restrict__ w, float* __restr
     }
 }
 
+// ---- 3 x 3, stride 1, IC % 16 == 0, OC % 64 == 0 over a batch: the input window is fetched ONCE -------------------------------
+// As an implicit GEMM the nine taps of a 3 x 3 convolution read the same input window nine times through element-wise gathers,
+// and the f32 MFMA shares the vector pipe with the gathers' address arithmetic: 0.45-0.5 of the f32 MFMA rate at 64-128
+// channels.  Here a workgroup (4 consumer waves) owns 64 output channels x (8 rows x 32 columns) of one image and walks the input channels
+// in chunks of 16: the chunk's window (10 x 34 positions, zeros outside the image) is fetched once, every value cut into its
+// three bf16 pieces on the way into LDS ([position][piece][16 channels]: a B fragment of tap (a, b) is three 16-byte reads at
+// the shifted position), and all nine taps run from it -- 9 x 24 split-bf16 MFMAs per wave between two barriers, the next chunk's
+// window in flight in registers meanwhile.  The weights are pre-split into MFMA fragment order once ([oc tile][chunk][tap][piece]
+// [lane]: one coalesced 1 KiB load per piece, cached like the other re-laid weights).  Six-term products (gemm_core.h's note on
+// split-bf16: exact-product sum to ~1e-7 per term, exact for integer-valued operands), f32 accumulation, ConvEpi's epilogue.
+typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned cu32x2 __attribute__((ext_vector_type(2)));
+typedef float cf32x16 __attribute__((ext_vector_type(16)));
+constexpr int C3M_TH = 8, C3M_TW = 32, C3M_PH = C3M_TH + 2, C3M_PW = C3M_TW + 2, C3M_POS = C3M_PH * C3M_PW, C3M_PITCH = 112;
+constexpr int C3M_STAGE = C3M_POS * C3M_PITCH, C3M_LDS = 2 * C3M_STAGE;
+constexpr int C3M_TASKS = (C3M_POS * 4 + 255) / 256;  // (position, channel quad) staging tasks per thread and chunk
+
+__device__ __forceinline__ unsigned c3m_pair(float even, float odd) { return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u); }
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3x3_mfma_kernel(const float* __restrict__ x,
+                                                                                                  const cu32x4* __restrict__ wfrag,
+                                                                                                  ConvEpi epi, ConvGeom g, int tiles_x) {
+    extern __shared__ __attribute__((aligned(16))) char c3m_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hv = lane >> 5, l31 = lane & 31;
+    const int tile = blockIdx.x, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int ocb = blockIdx.y, img = blockIdx.z;
+    const int hw = g.ih * g.iw, nchunk = g.c / 16;
+    auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
+    if (wave >= 4) {
+        // ------------------------------------------------------------ producers: the window of the next chunk, split, into LDS.
+        // Their own waves because a wave's memory counter is in order: a consumer that had the window's loads in flight could not
+        // wait for its next weight fragment without waiting for the window too (measured: 938 us against 1529 for the GEMM on
+        // 64 -> 64 channels at 160 x 160 x 64 with one kind of wave; the window's HBM latency sat in front of every chunk)
+        const int pt = tid - 256;
+        const int iy0 = tyi * C3M_TH - g.pt, ix0 = txi * C3M_TW - g.pl;
+        const float* xin = x + (int64_t)img * g.c * hw;
+        int t_off[C3M_TASKS], t_lds[C3M_TASKS];  // task t = (position, channel quad); its four channel planes are hw apart
+        bool t_in[C3M_TASKS];
+#pragma unroll
+        for (int i = 0; i < C3M_TASKS; ++i) {
+            const int t = pt + 256 * i, pos = t % C3M_POS, q = t / C3M_POS;  // q < 4 while t < 4 * POS
+            const int py = pos / C3M_PW, px = pos - py * C3M_PW, iy = iy0 + py, ix = ix0 + px;
+            t_in[i] = t < 4 * C3M_POS && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+            t_off[i] = t_in[i] ? (4 * q * hw + iy * g.iw + ix) : 0;
+            t_lds[i] = t < 4 * C3M_POS ? pos * C3M_PITCH + 8 * q : -1;
+        }
+        float4 sa[C3M_TASKS], sb[C3M_TASKS];
+        auto fetch = [&](float4 (&st)[C3M_TASKS], int cc) {
+            const float* base = xin + (int64_t)(cc < nchunk ? cc : nchunk - 1) * 16 * hw;  // past the end: the last chunk again, never parked where it is read
+#pragma unroll
+            for (int i = 0; i < C3M_TASKS; ++i) {
+                const float* p = base + t_off[i];
+                const float e0 = p[0], e1 = p[hw], e2 = p[2 * hw], e3 = p[3 * hw];  // clamped addresses: unconditional
+                st[i] = t_in[i] ? make_float4(e0, e1, e2, e3) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto park = [&](const float4 (&st)[C3M_TASKS], int buf) {
+            char* dst = c3m_lds + buf * C3M_STAGE;
+#pragma unroll
+            for (int i = 0; i < C3M_TASKS; ++i) {
+                if (t_lds[i] < 0) continue;
+                const float v[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
+                float r[4], q[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r[e] = v[e] - __uint_as_float(__float_as_uint(v[e]) & 0xffff0000u);
+                    q[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xffff0000u);
+                }
+                cu32x2 h, m, l;
+                h[0] = c3m_pair(v[0], v[1]), h[1] = c3m_pair(v[2], v[3]);
+                m[0] = c3m_pair(r[0], r[1]), m[1] = c3m_pair(r[2], r[3]);
+                l[0] = c3m_pair(q[0], q[1]), l[1] = c3m_pair(q[2], q[3]);
+                *reinterpret_cast<cu32x2*>(dst + t_lds[i]) = h;
+                *reinterpret_cast<cu32x2*>(dst + t_lds[i] + 32) = m;
+                *reinterpret_cast<cu32x2*>(dst + t_lds[i] + 64) = l;
+            }
+        };
+        fetch(sa, 0);
+        fetch(sb, 1);
+        park(sa, 0);
+        barrier();  // stage 0 holds chunk 0
+        // chunk cc is being multiplied out of stage cc & 1: refill the registers chunk cc + 1 leaves free with chunk cc + 3's
+        // predecessor ... i.e. two chunks in flight, one being parked
+        int cc = 0;
+        for (; cc + 1 < nchunk; cc += 2) {
+            fetch(sa, cc + 2);
+            park(sb, 1);
+            barrier();
+            fetch(sb, cc + 3);
+            park(sa, 0);
+            barrier();
+        }
+        if (cc < nchunk) barrier();  // an odd count's last chunk
+        return;
+    }
+    // ---------------------------------------------------------------- consumers: 32 output channels x 4 rows of the tile each
+    const int wm = wave & 1, wn = wave >> 1;
+    cf32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    // weights of this wave's 32 output channels: [oc tile][chunk][tap][piece][64 lanes]
+    const cu32x4* wbase = wfrag + ((int64_t)(ocb * 2 + wm) * nchunk) * (9 * 3 * 64) + lane;
+    // weight fragments one tap ahead of their products (two register sets; the nine taps of a chunk are unrolled in pairs + one).
+    // Two workgroups share a CU (2 x 76 KB of LDS, <= 128 registers a lane): while one is in its epilogue -- bias, activation, a
+    // turn through LDS, 64 KB of stores -- the other multiplies
+    cu32x4 ar[2][3];
+    const int64_t wlast = (int64_t)nchunk * 9 - 1;  // clamp: the prefetch past the last tap re-reads it
+    auto wload = [&](cu32x4 (&dst)[3], int64_t gt) {
+        const cu32x4* src = wbase + (gt < wlast ? gt : wlast) * (3 * 64);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p] = src[p * 64];
+    };
+    wload(ar[0], 0);
+    barrier();  // chunk 0 is in stage 0
+    // P = which register set holds the chunk's first tap (9 taps a chunk: it alternates from chunk to chunk, hence the pairs below)
+    auto chunk = [&](int cc, auto pc) {
+        constexpr int P = decltype(pc)::value;
+        const char* stage = c3m_lds + (cc & 1) * C3M_STAGE + hv * 16;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int a = tap / 3, b = tap - 3 * a;
+            constexpr int dummy = 0;
+            (void)dummy;
+            cu32x4 (&af)[3] = ar[(P + tap) & 1];
+            wload(ar[(P + tap + 1) & 1], (int64_t)cc * 9 + tap + 1);
+#define LELE_CBF(v) __builtin_bit_cast(cbf16x8, v)
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};  // mm, hl, lh, hm, mh, hh: smallest terms first
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {  // two rows at a time: 24 fragment registers, and consecutive MFMAs never share an accumulator
+                cu32x4 bf[2][3];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const char* src = stage + ((4 * wn + 2 * jp + j + a) * C3M_PW + l31 + b) * C3M_PITCH;
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const cu32x4*>(src + 32 * p);
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[2 * jp + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_CBF(af[PA[t]]), LELE_CBF(bf[j][PB[t]]), acc[2 * jp + j], 0, 0, 0);
+            }
+#undef LELE_CBF
+            __builtin_amdgcn_sched_barrier(0);  // fragments of later taps are not fetched early: they would not fit 128 registers
+        }
+        barrier();  // done with this stage; the next chunk is in the other one
+    };
+    {
+        int cc = 0;
+        for (; cc + 1 < nchunk; cc += 2) {
+            chunk(cc, std::integral_constant<int, 0>());
+            chunk(cc + 1, std::integral_constant<int, 1>());
+        }
+        if (cc < nchunk) chunk(cc, std::integral_constant<int, 0>());
+    }
+    // C layout: column = lane & 31 = the position inside the row, rows (r & 3) + 8 (r >> 2) + 4 hv = output channels.  Stored as
+    // they sit, a lane would issue 64 four-byte stores and the tile's tail is store-ISSUE bound (measured: 730 of 1370 us on
+    // 64 -> 64 channels at 160 x 160 x 64).  Every wave of the workgroup is past the last barrier, so the stages are free: the
+    // wave's 32 channels x 4 rows x 32 columns take a turn through LDS and leave as 16-byte pieces of 128-byte output rows.
+    const int ox = txi * C3M_TW + l31;
+    if (g.ow % 4 == 0) {
+        constexpr int OCP = 4 * 32 + 8;  // floats per output channel: the two half waves (4 channels apart) land on different banks
+        float* mine = reinterpret_cast<float*>(c3m_lds) + wave * (32 * OCP);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int oy = tyi * C3M_TH + 4 * wn + j;
+            const int col = (oy < g.oh ? oy : g.oh - 1) * g.ow + (ox < g.ow ? ox : g.ow - 1);
+            const bool body = col < (g.plane & ~7);
+            // the activation's scalar-tail form (libm) only where some lane is in the last 0-7 positions of the plane: evaluated
+            // per lane behind a select it would run for every element of every tile
+            const bool all_body = __builtin_amdgcn_ballot_w64(!body) == 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ol = (r & 3) + 8 * (r >> 2) + 4 * hv;
+                float v = acc[j][r];
+                if (epi.bias) v = v + epi.bias[ocb * 64 + wm * 32 + ol];
+                mine[ol * OCP + j * 32 + l31] = all_body ? apply_act(v, epi.act, true) : apply_act(v, epi.act, body);
+            }
+        }
+        const int q4 = lane & 7;
+        const int oxq = txi * C3M_TW + 4 * q4;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int rowid = it * 8 + (lane >> 3), ol = rowid >> 2, j = rowid & 3;
+            const int oy = tyi * C3M_TH + 4 * wn + j;
+            const float4 v = *reinterpret_cast<const float4*>(mine + ol * OCP + j * 32 + 4 * q4);
+            if (oy < g.oh && oxq < g.ow)
+                *reinterpret_cast<float4*>(epi.out + ((int64_t)img * g.oc + ocb * 64 + wm * 32 + ol) * g.plane + oy * g.ow + oxq) = v;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int oy = tyi * C3M_TH + 4 * wn + j;
+        if (oy >= g.oh || ox >= g.ow) continue;
+        const int col = oy * g.ow + ox;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oc = ocb * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv;
+            epi.store(img, oc, col, acc[j][r], epi.load(img, oc, col));
+        }
+    }
+}
+// weights [OC][IC][3][3] f32 -> split-bf16 fragments [OC / 32][IC / 16][9 taps][3 pieces][64 lanes] x 16 bytes:
+// lane (l31 = output channel in the tile, hv) holds input channels 16 chunk + 8 hv + [0, 8) of its tap
+__global__ void conv3x3_wfrag_kernel(const float* __restrict__ w, cu32x4* __restrict__ wfrag, int oc, int ic) {
+    const int64_t total = (int64_t)(oc / 32) * (ic / 16) * 9 * 64;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63), tap = (int)((i >> 6) % 9);
+        const int64_t rest = (i >> 6) / 9;
+        const int cc = (int)(rest % (ic / 16)), mt = (int)(rest / (ic / 16));
+        const int o = mt * 32 + (lane & 31), c0 = cc * 16 + 8 * (lane >> 5);
+        float v[8], r[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = w[((int64_t)o * ic + c0 + e) * 9 + tap];
+            r[e] = v[e] - __uint_as_float(__float_as_uint(v[e]) & 0xffff0000u);
+            q[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xffff0000u);
+        }
+        cu32x4 h, m, l;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            h[p] = c3m_pair(v[2 * p], v[2 * p + 1]);
+            m[p] = c3m_pair(r[2 * p], r[2 * p + 1]);
+            l[p] = c3m_pair(q[2 * p], q[2 * p + 1]);
+        }
+        cu32x4* dst = wfrag + (((int64_t)mt * (ic / 16) + cc) * 9 + tap) * (3 * 64) + lane;
+        dst[0] = h;
+        dst[64] = m;
+        dst[128] = l;
+    }
+}
+
 inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 8192)); }
 inline int64_t attr(const int64_t* v, size_t n, size_t i, int64_t dflt) {
     if (n >= 2) return v[i];  // conv2d.rs:208-243: two values, or one value used for both
@@ -597,6 +833,34 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             hipLaunchKernelGGL(depthwise_conv2d_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dx, dw, db, out, g, act,
                                (unsigned)total);
         }
+    } else if (g.group == 1 && g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.sh == 1 && g.sw == 1 && g.c % 16 == 0 && g.oc % 64 == 0 &&
+               g.ow >= 16 && g.n <= 65535 && (int64_t)g.c * g.ih * g.iw < (int64_t(1) << 31) &&
+               (int64_t)g.n * (g.oc / 64) * ((g.ow + 31) / 32) * ((g.oh + 7) / 8) >= (int64_t)ctx->num_cus) {
+        // many channels, stride 1, over a batch: the window-once MFMA kernel (see conv3x3_mfma_kernel)
+        const size_t wbytes = (size_t)(g.oc / 32) * (g.c / 16) * 9 * 3 * 1024;
+        void* dwf = nullptr;
+        const bool cacheable = wt->mem == LELE_MEM_WEIGHT;
+        auto key = std::make_tuple((const void*)wt->data, wbytes, 330);
+        auto it = cacheable ? ctx->weights.find(key) : ctx->weights.end();
+        if (it != ctx->weights.end()) {
+            dwf = it->second;
+        } else {
+            if (cacheable) {
+                LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
+                LELE_HIP_CHECK(hipMalloc(&dwf, wbytes));
+                ctx->weights[key] = dwf;
+            } else {
+                LELE_TRY(ctx->arena_alloc(wbytes, &dwf));
+            }
+            hipLaunchKernelGGL(conv3x3_wfrag_kernel, dim3(grid_for((int64_t)(g.oc / 32) * (g.c / 16) * 9 * 64)), dim3(256), 0, ctx->stream, dw,
+                               (cu32x4*)dwf, g.oc, g.c);
+        }
+        ConvEpi epi{out, db, g, act};
+        const int tiles_x = (g.ow + 31) / 32, tiles_y = (g.oh + 7) / 8;
+        auto kern = conv3x3_mfma_kernel;
+        LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3M_LDS));
+        hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_x * tiles_y), (unsigned)(g.oc / 64), (unsigned)g.n), dim3(512), C3M_LDS, ctx->stream, dx,
+                           (const cu32x4*)dwf, epi, g, tiles_x);
     } else if (g.group == 1 && g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.sh == g.sw && (g.sh == 1 || g.sh == 2) && g.oc <= 16 &&
                g.c <= 64 && g.ow >= 16 && g.n <= 65535 &&
                (int64_t)g.n * ((g.ow + 31) / 32) * ((g.oh + 7) / 8) >= 2 * (int64_t)ctx->num_cus) {

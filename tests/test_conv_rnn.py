@@ -248,6 +248,11 @@ CONV_SHAPES = [
     (64, 3, 70, 66, 16, 3, 3, 1, [1, 1, 1, 1], [2, 2], [1, 1], "silu"),
     (90, 8, 37, 45, 13, 3, 3, 1, [0, 2, 1, 0], [1, 1], [1, 1], "relu"),
     (176, 64, 40, 36, 5, 3, 3, 1, [1, 0, 1, 2], [2, 2], [1, 1], None),
+    # IC % 16 == 0, OC % 64 == 0, stride 1, >= one tile per CU: the window-once split-bf16 MFMA kernel -- 16-byte stores (ow % 4 == 0,
+    # partial tiles in x and y), the scalar store path (ow % 4 != 0), asymmetric pads, one and several channel chunks, odd chunk count
+    (32, 32, 40, 44, 128, 3, 3, 1, [1, 1, 1, 1], [1, 1], [1, 1], "silu"),
+    (40, 16, 30, 37, 64, 3, 3, 1, [1, 0, 1, 2], [1, 1], [1, 1], "relu"),
+    (32, 48, 33, 64, 64, 3, 3, 1, [0, 1, 2, 1], [1, 1], [1, 1], None),
 ]
 
 
