@@ -184,6 +184,17 @@ struct ConvEpi {
         if (bias) v = v + pre;
         out[((int64_t)img * g.oc + o) * g.plane + col] = apply_act(v, act, col < (g.plane & ~7));
     }
+    // the 16-byte store protocol of gemm_core.h: finished values, a row's address, and when rows may be written four columns at a time
+    __device__ __forceinline__ bool vec_ok() const { return (g.plane & 3) == 0 && (((uintptr_t)out) & 15) == 0; }
+    __device__ __forceinline__ float finish(int b, int row, int col, float acc, float pre) const {  // clamped coordinates
+        float v = acc;
+        if (bias) v = v + pre;
+        return apply_act(v, act, col < (g.plane & ~7));
+    }
+    __device__ __forceinline__ float* row_ptr(int b, int row) const {
+        const int img = b / g.group, o = (b % g.group) * g.ocg + row;
+        return out + ((int64_t)img * g.oc + o) * g.plane;
+    }
 };
 
 // depthwise: one thread per output element, taps in (kh, kw) order, FMA chain in f32.  32-bit index arithmetic (the

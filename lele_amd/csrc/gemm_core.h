@@ -162,6 +162,15 @@ struct has_blockstat : std::false_type {};
 template <class E>
 struct has_blockstat<E, std::void_t<decltype(std::declval<E>().blockstat)>> : std::true_type {};
 
+// epilogues that can hand out finished values and take them back four columns at a time (`finish`, `row_ptr`, `vec_ok`): the
+// tiled kernel then turns every 32 x 32 accumulator tile through LDS and stores 16 bytes per lane instead of 4 (a lane owns a
+// COLUMN of the tile; stored as they sit, a tile is 16 four-byte store instructions per lane and the tail of a workgroup is
+// store-issue bound)
+template <class E, class = void>
+struct has_vec_store : std::false_type {};
+template <class E>
+struct has_vec_store<E, std::void_t<decltype(std::declval<E>().vec_ok())>> : std::true_type {};
+
 // min / max of `mn`, `mx` over a 256-thread workgroup -> thread 0 writes the pair (qminmax_kernel's comparisons)
 __device__ __forceinline__ void block_minmax_store(float mn, float mx, float* pair) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -317,6 +326,39 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
         __syncthreads();
     }
     // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if constexpr (has_vec_store<EPI>::value) {
+        if (epi.vec_ok()) {  // uniform.  The operand buffers are free after the K loop's last barrier: 32 x 36 floats per wave
+            static_assert((size_t)2 * (BM + BN) * PITCH >= (size_t)WM * WN * 32 * 36, "the operand buffers hold a tile per wave");
+            float* mine = gemm_lds + wave * (32 * 36);
+#pragma unroll
+            for (int i = 0; i < TMT; ++i)
+#pragma unroll
+                for (int j = 0; j < TNT; ++j) {
+                    const int col = n0 + wn * TNT * 32 + j * 32 + l31;
+                    const int colc = col < N ? col : N - 1;
+                    const int rbase = m0 + wm * TMT * 32 + i * 32 + 4 * hv;
+                    float pre[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        pre[r] = epi.load(batch, row < M ? row : M - 1, colc);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = (r & 3) + 8 * (r >> 2) + 4 * hv;
+                        mine[rl * 36 + l31] = epi.finish(batch, rbase - 4 * hv + rl < M ? rbase - 4 * hv + rl : M - 1, colc, acc[i][j][r], pre[r]);
+                    }
+                    const int c4 = n0 + wn * TNT * 32 + j * 32 + 4 * (lane & 7);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {  // same-wave LDS order holds: no barrier
+                        const int rl = it * 8 + (lane >> 3), row = m0 + wm * TMT * 32 + i * 32 + rl;
+                        const float4 v = *reinterpret_cast<const float4*>(mine + rl * 36 + 4 * (lane & 7));
+                        if (row < M && c4 < N) *reinterpret_cast<float4*>(epi.row_ptr(batch, row) + c4) = v;  // N % 4 == 0: whole or absent
+                    }
+                }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TMT; ++i)
 #pragma unroll
