@@ -573,15 +573,26 @@ typedef __bf16 cbf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned cu32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned cu32x2 __attribute__((ext_vector_type(2)));
 typedef float cf32x16 __attribute__((ext_vector_type(16)));
-constexpr int C3M_TH = 8, C3M_TW = 32, C3M_PH = C3M_TH + 2, C3M_PW = C3M_TW + 2, C3M_POS = C3M_PH * C3M_PW, C3M_PITCH = 112;
-constexpr int C3M_STAGE = C3M_POS * C3M_PITCH, C3M_LDS = 2 * C3M_STAGE;
-constexpr int C3M_TASKS = (C3M_POS * 4 + 255) / 256;  // (position, channel quad) staging tasks per thread and chunk
+constexpr int C3M_TH = 8, C3M_TW = 32, C3M_PITCH = 112;
+template <int KS>
+struct C3M {  // KS = 3 (3 x 3, padding in the geometry) or 1 (1 x 1: the "window" is the tile itself)
+    static constexpr int PH = C3M_TH + KS - 1, PW = C3M_TW + KS - 1, POS = PH * PW, STAGE = POS * C3M_PITCH;
+    static constexpr int EPI = 4 * 32 * (4 * 32 + 8) * 4;  // the epilogue's four wave tiles reuse the stages
+    static constexpr int LDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    static constexpr int TASKS = (POS * 4 + 255) / 256;  // (position, channel quad) staging tasks per thread and chunk
+    static constexpr int TAPS = KS * KS;
+};
 
 __device__ __forceinline__ unsigned c3m_pair(float even, float odd) { return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u); }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3x3_mfma_kernel(const float* __restrict__ x,
-                                                                                                  const cu32x4* __restrict__ wfrag,
-                                                                                                  ConvEpi epi, ConvGeom g, int tiles_x) {
+// OCT = output channels per workgroup: 64 (two 32-channel tiles x two groups of four tile rows) or 32 (one tile x four groups of
+// two rows): narrow layers do not pay for a half-empty block
+template <int KS, int OCT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_window_kernel(const float* __restrict__ x,
+                                                                                                 const cu32x4* __restrict__ wfrag,
+                                                                                                 ConvEpi epi, ConvGeom g, int tiles_x) {
+    typedef C3M<KS> W;
+    constexpr int NJ = OCT == 64 ? 4 : 2, MTB = OCT / 32;  // tile rows per consumer wave, 32-channel tiles per workgroup
     extern __shared__ __attribute__((aligned(16))) char c3m_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hv = lane >> 5, l31 = lane & 31;
     const int tile = blockIdx.x, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
@@ -596,30 +607,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int pt = tid - 256;
         const int iy0 = tyi * C3M_TH - g.pt, ix0 = txi * C3M_TW - g.pl;
         const float* xin = x + (int64_t)img * g.c * hw;
-        int t_off[C3M_TASKS], t_lds[C3M_TASKS];  // task t = (position, channel quad); its four channel planes are hw apart
-        bool t_in[C3M_TASKS];
+        int t_off[W::TASKS], t_lds[W::TASKS];  // task t = (position, channel quad); its four channel planes are hw apart
+        bool t_in[W::TASKS];
 #pragma unroll
-        for (int i = 0; i < C3M_TASKS; ++i) {
-            const int t = pt + 256 * i, pos = t % C3M_POS, q = t / C3M_POS;  // q < 4 while t < 4 * POS
-            const int py = pos / C3M_PW, px = pos - py * C3M_PW, iy = iy0 + py, ix = ix0 + px;
-            t_in[i] = t < 4 * C3M_POS && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+        for (int i = 0; i < W::TASKS; ++i) {
+            const int t = pt + 256 * i, pos = t % W::POS, q = t / W::POS;  // q < 4 while t < 4 * POS
+            const int py = pos / W::PW, px = pos - py * W::PW, iy = iy0 + py, ix = ix0 + px;
+            t_in[i] = t < 4 * W::POS && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
             t_off[i] = t_in[i] ? (4 * q * hw + iy * g.iw + ix) : 0;
-            t_lds[i] = t < 4 * C3M_POS ? pos * C3M_PITCH + 8 * q : -1;
+            t_lds[i] = t < 4 * W::POS ? pos * C3M_PITCH + 8 * q : -1;
         }
-        float4 sa[C3M_TASKS], sb[C3M_TASKS];
-        auto fetch = [&](float4 (&st)[C3M_TASKS], int cc) {
+        float4 sa[W::TASKS], sb[W::TASKS];
+        auto fetch = [&](float4 (&st)[W::TASKS], int cc) {
             const float* base = xin + (int64_t)(cc < nchunk ? cc : nchunk - 1) * 16 * hw;  // past the end: the last chunk again, never parked where it is read
 #pragma unroll
-            for (int i = 0; i < C3M_TASKS; ++i) {
+            for (int i = 0; i < W::TASKS; ++i) {
                 const float* p = base + t_off[i];
                 const float e0 = p[0], e1 = p[hw], e2 = p[2 * hw], e3 = p[3 * hw];  // clamped addresses: unconditional
                 st[i] = t_in[i] ? make_float4(e0, e1, e2, e3) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
-        auto park = [&](const float4 (&st)[C3M_TASKS], int buf) {
-            char* dst = c3m_lds + buf * C3M_STAGE;
+        auto park = [&](const float4 (&st)[W::TASKS], int buf) {
+            char* dst = c3m_lds + buf * W::STAGE;
 #pragma unroll
-            for (int i = 0; i < C3M_TASKS; ++i) {
+            for (int i = 0; i < W::TASKS; ++i) {
                 if (t_lds[i] < 0) continue;
                 const float v[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
                 float r[4], q[4];
@@ -656,19 +667,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         return;
     }
     // ---------------------------------------------------------------- consumers: 32 output channels x 4 rows of the tile each
-    const int wm = wave & 1, wn = wave >> 1;
-    cf32x16 acc[4];
+    const int wm = OCT == 64 ? (wave & 1) : 0, wn = OCT == 64 ? (wave >> 1) : wave;
+    cf32x16 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     // weights of this wave's 32 output channels: [oc tile][chunk][tap][piece][64 lanes]
-    const cu32x4* wbase = wfrag + ((int64_t)(ocb * 2 + wm) * nchunk) * (9 * 3 * 64) + lane;
+    const cu32x4* wbase = wfrag + ((int64_t)(ocb * MTB + wm) * nchunk) * (W::TAPS * 3 * 64) + lane;
     // weight fragments one tap ahead of their products (two register sets; the nine taps of a chunk are unrolled in pairs + one).
     // Two workgroups share a CU (2 x 76 KB of LDS, <= 128 registers a lane): while one is in its epilogue -- bias, activation, a
     // turn through LDS, 64 KB of stores -- the other multiplies
     cu32x4 ar[2][3];
-    const int64_t wlast = (int64_t)nchunk * 9 - 1;  // clamp: the prefetch past the last tap re-reads it
+    const int64_t wlast = (int64_t)nchunk * W::TAPS - 1;  // clamp: the prefetch past the last tap re-reads it
     auto wload = [&](cu32x4 (&dst)[3], int64_t gt) {
         const cu32x4* src = wbase + (gt < wlast ? gt : wlast) * (3 * 64);
 #pragma unroll
@@ -676,25 +687,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     };
     wload(ar[0], 0);
     barrier();  // chunk 0 is in stage 0
-    // P = which register set holds the chunk's first tap (9 taps a chunk: it alternates from chunk to chunk, hence the pairs below)
+    // P = which register set holds the chunk's first tap (an odd number of taps a chunk: it alternates from chunk to chunk, hence
+    // the pairs below)
     auto chunk = [&](int cc, auto pc) {
         constexpr int P = decltype(pc)::value;
-        const char* stage = c3m_lds + (cc & 1) * C3M_STAGE + hv * 16;
+        const char* stage = c3m_lds + (cc & 1) * W::STAGE + hv * 16;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int a = tap / 3, b = tap - 3 * a;
-            constexpr int dummy = 0;
-            (void)dummy;
+        for (int tap = 0; tap < W::TAPS; ++tap) {
+            const int a = tap / KS, b = tap - KS * a;
             cu32x4 (&af)[3] = ar[(P + tap) & 1];
-            wload(ar[(P + tap + 1) & 1], (int64_t)cc * 9 + tap + 1);
+            wload(ar[(P + tap + 1) & 1], (int64_t)cc * W::TAPS + tap + 1);
 #define LELE_CBF(v) __builtin_bit_cast(cbf16x8, v)
             constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};  // mm, hl, lh, hm, mh, hh: smallest terms first
 #pragma unroll
-            for (int jp = 0; jp < 2; ++jp) {  // two rows at a time: 24 fragment registers, and consecutive MFMAs never share an accumulator
+            for (int jp = 0; jp < NJ / 2; ++jp) {  // two rows at a time: 24 fragment registers, and consecutive MFMAs never share an accumulator
                 cu32x4 bf[2][3];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const char* src = stage + ((4 * wn + 2 * jp + j + a) * C3M_PW + l31 + b) * C3M_PITCH;
+                    const char* src = stage + ((NJ * wn + 2 * jp + j + a) * W::PW + l31 + b) * C3M_PITCH;
 #pragma unroll
                     for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const cu32x4*>(src + 32 * p);
                 }
@@ -723,11 +733,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // wave's 32 channels x 4 rows x 32 columns take a turn through LDS and leave as 16-byte pieces of 128-byte output rows.
     const int ox = txi * C3M_TW + l31;
     if (g.ow % 4 == 0) {
-        constexpr int OCP = 4 * 32 + 8;  // floats per output channel: the two half waves (4 channels apart) land on different banks
+        constexpr int OCP = NJ * 32 + 8;  // floats per output channel: the two half waves (4 channels apart) land on different banks
         float* mine = reinterpret_cast<float*>(c3m_lds) + wave * (32 * OCP);
+        static_assert(4 * 32 * OCP * 4 <= W::LDS, "the epilogue tiles fit the stages");
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int oy = tyi * C3M_TH + 4 * wn + j;
+        for (int j = 0; j < NJ; ++j) {
+            const int oy = tyi * C3M_TH + NJ * wn + j;
             const int col = (oy < g.oh ? oy : g.oh - 1) * g.ow + (ox < g.ow ? ox : g.ow - 1);
             const bool body = col < (g.plane & ~7);
             // the activation's scalar-tail form (libm) only where some lane is in the last 0-7 positions of the plane: evaluated
@@ -737,47 +748,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int r = 0; r < 16; ++r) {
                 const int ol = (r & 3) + 8 * (r >> 2) + 4 * hv;
                 float v = acc[j][r];
-                if (epi.bias) v = v + epi.bias[ocb * 64 + wm * 32 + ol];
+                if (epi.bias) v = v + epi.bias[ocb * OCT + wm * 32 + ol < g.oc ? ocb * OCT + wm * 32 + ol : g.oc - 1];
                 mine[ol * OCP + j * 32 + l31] = all_body ? apply_act(v, epi.act, true) : apply_act(v, epi.act, body);
             }
         }
         const int q4 = lane & 7;
         const int oxq = txi * C3M_TW + 4 * q4;
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int rowid = it * 8 + (lane >> 3), ol = rowid >> 2, j = rowid & 3;
-            const int oy = tyi * C3M_TH + 4 * wn + j;
+        for (int it = 0; it < 4 * NJ; ++it) {
+            const int rowid = it * 8 + (lane >> 3), ol = rowid / NJ, j = rowid % NJ;
+            const int oy = tyi * C3M_TH + NJ * wn + j, oc = ocb * OCT + wm * 32 + ol;
             const float4 v = *reinterpret_cast<const float4*>(mine + ol * OCP + j * 32 + 4 * q4);
-            if (oy < g.oh && oxq < g.ow)
-                *reinterpret_cast<float4*>(epi.out + ((int64_t)img * g.oc + ocb * 64 + wm * 32 + ol) * g.plane + oy * g.ow + oxq) = v;
+            if (oy < g.oh && oxq < g.ow && oc < g.oc)
+                *reinterpret_cast<float4*>(epi.out + ((int64_t)img * g.oc + oc) * g.plane + oy * g.ow + oxq) = v;
         }
         return;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int oy = tyi * C3M_TH + 4 * wn + j;
+    for (int j = 0; j < NJ; ++j) {
+        const int oy = tyi * C3M_TH + NJ * wn + j;
         if (oy >= g.oh || ox >= g.ow) continue;
         const int col = oy * g.ow + ox;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int oc = ocb * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv;
-            epi.store(img, oc, col, acc[j][r], epi.load(img, oc, col));
+            const int oc = ocb * OCT + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv;
+            if (oc < g.oc) epi.store(img, oc, col, acc[j][r], epi.load(img, oc, col));
         }
     }
 }
-// weights [OC][IC][3][3] f32 -> split-bf16 fragments [OC / 32][IC / 16][9 taps][3 pieces][64 lanes] x 16 bytes:
-// lane (l31 = output channel in the tile, hv) holds input channels 16 chunk + 8 hv + [0, 8) of its tap
-__global__ void conv3x3_wfrag_kernel(const float* __restrict__ w, cu32x4* __restrict__ wfrag, int oc, int ic) {
-    const int64_t total = (int64_t)(oc / 32) * (ic / 16) * 9 * 64;
+// weights [OC][IC][taps] f32 -> split-bf16 fragments [ceil(OC / 32)][IC / 16][taps][3 pieces][64 lanes] x 16 bytes (zeros for the
+// channels past OC): lane (l31 = output channel in the tile, hv) holds input channels 16 chunk + 8 hv + [0, 8) of its tap
+__global__ void conv_wfrag_kernel(const float* __restrict__ w, cu32x4* __restrict__ wfrag, int oc, int ic, int taps) {
+    const int64_t total = (int64_t)((oc + 31) / 32) * (ic / 16) * taps * 64;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int lane = (int)(i & 63), tap = (int)((i >> 6) % 9);
-        const int64_t rest = (i >> 6) / 9;
+        const int lane = (int)(i & 63), tap = (int)((i >> 6) % taps);
+        const int64_t rest = (i >> 6) / taps;
         const int cc = (int)(rest % (ic / 16)), mt = (int)(rest / (ic / 16));
         const int o = mt * 32 + (lane & 31), c0 = cc * 16 + 8 * (lane >> 5);
         float v[8], r[8], q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            v[e] = w[((int64_t)o * ic + c0 + e) * 9 + tap];
+            v[e] = o < oc ? w[((int64_t)o * ic + c0 + e) * taps + tap] : 0.0f;
             r[e] = v[e] - __uint_as_float(__float_as_uint(v[e]) & 0xffff0000u);
             q[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xffff0000u);
         }
@@ -788,7 +799,7 @@ __global__ void conv3x3_wfrag_kernel(const float* __restrict__ w, cu32x4* __rest
             m[p] = c3m_pair(r[2 * p], r[2 * p + 1]);
             l[p] = c3m_pair(q[2 * p], q[2 * p + 1]);
         }
-        cu32x4* dst = wfrag + (((int64_t)mt * (ic / 16) + cc) * 9 + tap) * (3 * 64) + lane;
+        cu32x4* dst = wfrag + (((int64_t)mt * (ic / 16) + cc) * taps + tap) * (3 * 64) + lane;
         dst[0] = h;
         dst[64] = m;
         dst[128] = l;
@@ -844,14 +855,23 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             hipLaunchKernelGGL(depthwise_conv2d_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dx, dw, db, out, g, act,
                                (unsigned)total);
         }
-    } else if (g.group == 1 && g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.sh == 1 && g.sw == 1 && g.c % 16 == 0 && g.oc % 64 == 0 &&
-               g.ow >= 16 && g.n <= 65535 && (int64_t)g.c * g.ih * g.iw < (int64_t(1) << 31) &&
-               (int64_t)g.n * (g.oc / 64) * ((g.ow + 31) / 32) * ((g.oh + 7) / 8) >= (int64_t)ctx->num_cus) {
-        // many channels, stride 1, over a batch: the window-once MFMA kernel (see conv3x3_mfma_kernel)
-        const size_t wbytes = (size_t)(g.oc / 32) * (g.c / 16) * 9 * 3 * 1024;
+    } else if (g.group == 1 &&
+               ((g.kh == 3 && g.kw == 3) ||
+                // 1 x 1: only where it measured faster than the tiled GEMM on the Yolo-shaped network at batch 64 -- one block of output
+                // channels (every further block fetches and splits the input again: 64 -> 80 at 80 x 80 179 against 153 us), large
+                // planes, >= 48 input channels (48 -> 64 at 160 x 160: 316 against 406 us, 256 -> 64 at 80 x 80: 208 against 277)
+                (g.kh == 1 && g.kw == 1 && g.pt == 0 && g.pl == 0 && g.oh == g.ih && g.ow == g.iw && g.oc <= 64 && g.plane >= 6400 && g.c >= 48)) &&
+               g.dh == 1 && g.dw == 1 && g.sh == 1 && g.sw == 1 && g.c % 16 == 0 && g.oc > 16 && g.ow >= 16 && g.n <= 65535 &&
+               (int64_t)g.c * g.ih * g.iw < (int64_t(1) << 31) &&
+               (int64_t)g.n * ((g.oc + 63) / 64) * ((g.ow + 31) / 32) * ((g.oh + 7) / 8) >= (int64_t)ctx->num_cus) {
+        // stride 1 over a batch, 16-channel chunks: the window-once MFMA kernel (see conv_window_kernel); 32-channel blocks when that
+        // wastes fewer output channels than 64-channel ones
+        const int taps = g.kh * g.kw;
+        const int oct = ((g.oc + 31) / 32) * 32 < ((g.oc + 63) / 64) * 64 ? 32 : 64;
+        const size_t wbytes = (size_t)((g.oc + 31) / 32) * (g.c / 16) * taps * 3 * 1024 + (oct == 64 ? (size_t)(g.c / 16) * taps * 3 * 1024 : 0);
         void* dwf = nullptr;
         const bool cacheable = wt->mem == LELE_MEM_WEIGHT;
-        auto key = std::make_tuple((const void*)wt->data, wbytes, 330);
+        auto key = std::make_tuple((const void*)wt->data, wbytes, 330 + taps);
         auto it = cacheable ? ctx->weights.find(key) : ctx->weights.end();
         if (it != ctx->weights.end()) {
             dwf = it->second;
@@ -863,15 +883,29 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             } else {
                 LELE_TRY(ctx->arena_alloc(wbytes, &dwf));
             }
-            hipLaunchKernelGGL(conv3x3_wfrag_kernel, dim3(grid_for((int64_t)(g.oc / 32) * (g.c / 16) * 9 * 64)), dim3(256), 0, ctx->stream, dw,
-                               (cu32x4*)dwf, g.oc, g.c);
+            // fragments for ceil(OC / 32) tiles, rounded up to whole blocks (the padding tiles are zeros)
+            const int oc_pad = ((g.oc + oct - 1) / oct) * oct;
+            LELE_HIP_CHECK(hipMemsetAsync(dwf, 0, wbytes, ctx->stream));
+            hipLaunchKernelGGL(conv_wfrag_kernel, dim3(grid_for((int64_t)(oc_pad / 32) * (g.c / 16) * taps * 64)), dim3(256), 0, ctx->stream, dw,
+                               (cu32x4*)dwf, g.oc, g.c, taps);
         }
         ConvEpi epi{out, db, g, act};
         const int tiles_x = (g.ow + 31) / 32, tiles_y = (g.oh + 7) / 8;
-        auto kern = conv3x3_mfma_kernel;
-        LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3M_LDS));
-        hipLaunchKernelGGL(kern, dim3((unsigned)(tiles_x * tiles_y), (unsigned)(g.oc / 64), (unsigned)g.n), dim3(512), C3M_LDS, ctx->stream, dx,
-                           (const cu32x4*)dwf, epi, g, tiles_x);
+        const dim3 wgrid((unsigned)(tiles_x * tiles_y), (unsigned)((g.oc + oct - 1) / oct), (unsigned)g.n);
+#define LELE_CW(KS_, OCT_)                                                                                      \
+    do {                                                                                                        \
+        auto kern = conv_window_kernel<KS_, OCT_>;                                                               \
+        LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3M<KS_>::LDS));                \
+        hipLaunchKernelGGL(kern, wgrid, dim3(512), C3M<KS_>::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tiles_x); \
+    } while (0)
+        if (taps == 9) {
+            if (oct == 64) LELE_CW(3, 64);
+            else LELE_CW(3, 32);
+        } else {
+            if (oct == 64) LELE_CW(1, 64);
+            else LELE_CW(1, 32);
+        }
+#undef LELE_CW
     } else if (g.group == 1 && g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.sh == g.sw && (g.sh == 1 || g.sh == 2) && g.oc <= 16 &&
                g.c <= 64 && g.ow >= 16 && g.n <= 65535 &&
                (int64_t)g.n * ((g.ow + 31) / 32) * ((g.oh + 7) / 8) >= 2 * (int64_t)ctx->num_cus) {

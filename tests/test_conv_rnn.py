@@ -253,6 +253,10 @@ CONV_SHAPES = [
     (32, 32, 40, 44, 128, 3, 3, 1, [1, 1, 1, 1], [1, 1], [1, 1], "silu"),
     (40, 16, 30, 37, 64, 3, 3, 1, [1, 0, 1, 2], [1, 1], [1, 1], "relu"),
     (32, 48, 33, 64, 64, 3, 3, 1, [0, 1, 2, 1], [1, 1], [1, 1], None),
+    # the same kernel in its other forms: blocks of 32 output channels with a ragged last block (OC = 80), and 1 x 1 on a large plane
+    (40, 32, 40, 40, 80, 3, 3, 1, [1, 1, 1, 1], [1, 1], [1, 1], "silu"),
+    (32, 48, 80, 80, 64, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "silu"),
+    (32, 64, 80, 84, 24, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], None),
     # 1 x 1 over a batch: several K steps, odd IC, OC off the 32-channel tile, planes that are / are not a multiple of 4 (16-byte /
     # scalar stores of the tiled kernel's epilogue) and of 32
     (96, 48, 40, 40, 64, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "silu"),
