@@ -253,6 +253,9 @@ CONV_SHAPES = [
     (32, 32, 40, 44, 128, 3, 3, 1, [1, 1, 1, 1], [1, 1], [1, 1], "silu"),
     (40, 16, 30, 37, 64, 3, 3, 1, [1, 0, 1, 2], [1, 1], [1, 1], "relu"),
     (32, 48, 33, 64, 64, 3, 3, 1, [0, 1, 2, 1], [1, 1], [1, 1], None),
+    # stride 2 over a batch (the implicit GEMM: a stride-2 form of the window kernel measured no faster), even and odd input sizes
+    (32, 32, 80, 80, 64, 3, 3, 1, [1, 1, 1, 1], [2, 2], [1, 1], "silu"),
+    (40, 16, 41, 77, 96, 3, 3, 1, [0, 1, 1, 0], [2, 2], [1, 1], "relu"),
     # the same kernel in its other forms: blocks of 32 output channels with a ragged last block (OC = 80), and 1 x 1 on a large plane
     (40, 32, 40, 40, 80, 3, 3, 1, [1, 1, 1, 1], [1, 1], [1, 1], "silu"),
     (32, 48, 80, 80, 64, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "silu"),
