@@ -17,6 +17,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 PEAK = {"mfma_f32": 157.3e12, "mfma_i8": 3.944e15, "hbm": 8.0e12}  # MI355X_MICROARCH.md (dense peaks; HBM spec)
+PEAK_BF16 = 2.5e15  # dense bf16 MFMA; a six-term split-bf16 product of f32 operands runs at a sixth of it (conv_window_kernel)
 
 
 def main():
@@ -57,6 +58,8 @@ def main():
             r["GB/s"] = round(nbytes / ms / 1e6, 1)
         if bound in ("mfma_f32", "mfma_i8"):
             r["frac"] = round(flops / (ms * 1e-3) / PEAK[bound], 4)
+            if op.startswith("conv2d"):  # the batched 3 x 3 / 1 x 1 routes multiply in six-term split-bf16: the other peak, too
+                r["frac_of_split_bf16_peak"] = round(flops / (ms * 1e-3) / (PEAK_BF16 / 6.0), 4)
         elif bound == "hbm":
             r["frac"] = round(nbytes / (ms * 1e-3) / PEAK["hbm"], 4)
         if note:
