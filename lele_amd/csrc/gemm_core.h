@@ -154,6 +154,12 @@ struct EpiAffine {
         if (row >= M || col >= N) return;
         out[ooff(b, row) + col] = value(acc, pre);
     }
+    // the 16-byte store protocol (has_vec_store): rows of the result may be written four columns at a time
+    __device__ __forceinline__ bool vec_ok() const {
+        return (N & 3) == 0 && ((ldo ? ldo : (int64_t)N) & 3) == 0 && (bs & 3) == 0 && (bs2 & 3) == 0 && ((uintptr_t)out & 15) == 0;
+    }
+    __device__ __forceinline__ float finish(int b, int row, int col, float acc, float pre) const { return value(acc, pre); }
+    __device__ __forceinline__ float* row_ptr(int b, int row) const { return out + ooff(b, row); }
 };
 
 // epilogues that can publish per-workgroup {min, max} carry a `blockstat` member
