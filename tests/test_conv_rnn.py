@@ -286,6 +286,36 @@ def test_device_conv2d_vs_oracle(ctx, shape):
 
 
 @pytest.mark.gpu
+def test_batched_convolution_kernels_agree_with_single_image_calls(ctx):
+    """Over a batch the 3 x 3 / 1 x 1 convolutions take their own kernels (window-once split-bf16 MFMA, direct small-channel);
+    one image at a time takes the implicit GEMM.  Random geometries -- channels, ragged maps, asymmetric pads, stride 1 / 2, every
+    activation -- must agree image by image within the 1e-4 bar (the two are different summation orders of the same exact products)."""
+    from lele_amd import kernels as K
+    rng = np.random.default_rng(2024)
+    acts = {"silu": K.conv2d_silu, "relu": lambda *a, **k: K.conv2d_fused(*a, relu=True, **k), None: K.conv2d}
+    for trial in range(14):
+        k = int(rng.choice([1, 3, 3]))
+        c = int(rng.choice([3, 8, 16, 32, 48, 64, 96])) if k == 3 else int(rng.choice([48, 64, 96, 128]))
+        oc = int(rng.choice([5, 8, 13, 16, 24, 32, 40, 64, 80, 128])) if k == 3 else int(rng.choice([24, 32, 64]))
+        stride = int(rng.choice([1, 1, 2])) if k == 3 else 1
+        h, w_ = (int(rng.integers(40, 72)), int(rng.integers(40, 100))) if k == 3 else (int(rng.integers(80, 90)), int(rng.integers(80, 96)))
+        pads = [int(v) for v in rng.integers(0, 3, 4)] if k == 3 else [0, 0, 0, 0]
+        oh = (h + pads[0] + pads[2] - k) // stride + 1
+        ow = (w_ + pads[1] + pads[3] - k) // stride + 1
+        tiles = ((ow + 31) // 32) * ((oh + 7) // 8)
+        n = max(2, -(-600 // tiles))  # enough 8 x 32 tiles for the batched kernels' thresholds
+        act = [None, "relu", "silu"][trial % 3]
+        x = rng.standard_normal((n, c, h, w_)).astype(np.float32)
+        w = (rng.standard_normal((oc, c, k, k)) * (2.0 / (c * k * k)) ** 0.5).astype(np.float32)
+        b = rng.standard_normal(oc).astype(np.float32) if trial % 4 else None
+        got = acts[act](x, w, b, [1, 1], 1, pads, [stride, stride], ctx=ctx).numpy()
+        assert got.shape == (n, oc, oh, ow) and np.isfinite(got).all()
+        for i in sorted(set(int(v) for v in rng.integers(0, n, 3))):
+            one = acts[act](x[i:i + 1], w, b, [1, 1], 1, pads, [stride, stride], ctx=ctx).numpy()
+            _close(got[i:i + 1], one, RTOL, "trial %d: [%d,%d,%d,%d] -> %d, k%d s%d pads %s %s, image %d" % (trial, n, c, h, w_, oc, k, stride, pads, act, i))
+
+
+@pytest.mark.gpu
 def test_device_conv1d(ctx):
     from lele_amd import kernels as K
     y = K.conv1d(np.ones((1, 2, 3), np.float32), np.ones((2, 1, 1), np.float32), None, [1], 2, [0, 0], [1], ctx=ctx)
