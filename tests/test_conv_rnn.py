@@ -260,6 +260,7 @@ CONV_SHAPES = [
     (40, 32, 40, 40, 80, 3, 3, 1, [1, 1, 1, 1], [1, 1], [1, 1], "silu"),
     (32, 48, 80, 80, 64, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "silu"),
     (32, 64, 80, 84, 24, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], None),
+    (48, 96, 40, 44, 100, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "silu"),   # 64 < OC <= 128 (the tiled GEMM: an eight-consumer-wave form of the window kernel measured no faster)
     # 1 x 1 over a batch: several K steps, odd IC, OC off the 32-channel tile, planes that are / are not a multiple of 4 (16-byte /
     # scalar stores of the tiled kernel's epilogue) and of 32
     (96, 48, 40, 40, 64, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "silu"),
