@@ -224,7 +224,7 @@ __device__ __forceinline__ float rs_value(int acc, int rterm, int ca, int colsum
 // LOADERS that do nothing but direct-to-LDS loads (global_load_lds_dwordx4: a fragment block is 1 KiB of consecutive lanes, which
 // is exactly the lane-linear image that instruction writes) of the workgroup's 32-row activation tiles into a ring of RS_NS slots.
 // What the CU's load path delivers is the bound of these products (measured: ~21 TB/s chip-wide = 40 B/clk/CU whether the lines
-// are shared or private, tools/scratch/l2bw.hip), so every activation byte crosses it ONCE per workgroup instead of once per wave,
+// are shared or private, tools/l2bw.hip), so every activation byte crosses it ONCE per workgroup instead of once per wave,
 // and it is requested up to four tiles ahead of its use.  The loader's vmcnt counter sees only its own 16 loads per tile, so
 // "tile i has landed" is an exact counted wait (the tiles issued after it stay in flight); one s_barrier per tile hands tile i to
 // the consumers and the slot of tile i - 1 back to the loader.  Consumers never touch a counter by hand: their loads (weights
