@@ -3,22 +3,21 @@
 // Same arithmetic as igemm_kernel (exact i32 products on v_mfma_i32_32x32x32_i8, IgemmEpi's f32 epilogue:
 // /root/reference/src/kernels/avx/quantization.rs:225-417, 1396-1428), another schedule.  The K = 512 / 2048 products of a
 // SenseVoice-shaped layer over 5472 rows are short and wide; a tiled kernel spends its life in barriers and global -> VGPR -> LDS
-// round trips (round 2: 8-10 % MFMA busy, 17-20 us per launch for 2-6 us of bytes).  Here there is NO LDS staging and NO barrier
-// on the K = 512 path:
+// round trips (round 2: 8-10 % MFMA busy, 17-20 us per launch for 2-6 us of bytes).  Here:
 //
 //   * both operands live in HBM in MFMA FRAGMENT ORDER: block (tile, k-step) = 1 KiB, lane l's 16 bytes at offset 16 l hold
 //     row / column 32 tile + (l & 31), k = 32 step + 16 (l >> 5) + [0, 16) -- every operand load of a wave is ONE fully
-//     coalesced 1 KiB dwordx4 instruction straight into the registers the MFMA reads (weights: wpack_frag_kernel, once;
-//     activations: qrows_frag_kernel, which quantises into that order; the hidden layer of a feed-forward block: the epilogue of
-//     the pass that produces it, whose 32 x 32 result tile IS one k-step block of the next product);
-//   * a wave keeps the weight fragments of ITS 32 columns for the whole K extent in 64 VGPRs and streams 32-row activation tiles
-//     past them, double-buffered in registers (the loads of tile t + 1 are in flight during the 16 MFMAs and the stores of tile t);
-//     waves never wait for each other, the eight waves of a workgroup (eight column tiles, same rows) share the activation
-//     tiles through the vector L1;
+//     coalesced 1 KiB request (weights: wpack_frag_kernel, once; activations: qrows_frag_kernel, which quantises into that
+//     order; the hidden layer of a feed-forward block: the epilogue of the pass that produces it, whose 32 x 32 result tile IS
+//     one k-step block of the next product);
+//   * K = 512 (igemm_rs_kernel): a consumer wave keeps the weight fragments of ITS 32 columns for the whole K extent in 64 VGPRs
+//     and multiplies the 32-row activation tiles that two loader waves stream through an LDS ring with direct-to-LDS loads;
+//     one s_barrier per tile; the eight consumers of a workgroup (eight column tiles) share every activation tile;
 //   * the weights are the MFMA's FIRST operand, so a lane owns ONE result row and 4 x 4 consecutive columns of it: 16-byte
-//     stores, one set of row terms per lane; the column terms of the wave's 32 columns sit in a wave-private LDS strip;
-//   * K = 2048 (second feed-forward product): the four waves of a workgroup split K, partial tiles meet in LDS (one barrier per
-//     tile, double-buffered), row sums come from v_dot4 on the fragments the wave loads anyway.
+//     stores, one set of row terms per lane (they travel with the tile through the ring), the column terms in registers;
+//   * K = 2048 (igemm_rs_ks4_kernel, the second feed-forward product): the four waves of a workgroup split K, A fragments
+//     double-buffered in registers, partial tiles meet in LDS (one barrier per tile), row sums come from v_dot4 on the fragments
+//     the wave loads anyway.
 #pragma once
 
 namespace {
