@@ -559,7 +559,7 @@ __global__ void conv3x3_wperm_kernel(const float* __restrict__ w, float* __restr
     }
 }
 
-// ---- 3 x 3, stride 1, IC % 16 == 0, OC % 64 == 0 over a batch: the input window is fetched ONCE -------------------------------
+// ---- 3 x 3 (and large-plane 1 x 1), stride 1, IC % 16 == 0, over a batch: the input window is fetched ONCE -------------------
 // As an implicit GEMM the nine taps of a 3 x 3 convolution read the same input window nine times through element-wise gathers,
 // and the f32 MFMA shares the vector pipe with the gathers' address arithmetic: 0.45-0.5 of the f32 MFMA rate at 64-128
 // channels.  Here a workgroup (4 consumer waves) owns 64 output channels x (8 rows x 32 columns) of one image and walks the input channels
