@@ -47,6 +47,23 @@ typedef struct LeleTensor {
     int32_t mem;   /* LeleMem   */
 } LeleTensor;
 
+/* Channel views.  A Concat along C of NCHW tensors and a Split along C move no value: an operand of the Concat is the window
+ * [c0, c1) of the result, a result of the Split the window [c0, c1) of its operand -- image n of such a window starts
+ * n * pitch elements after image 0 (pitch = C_total * H * W of the enclosing tensor) and is dense inside.  The *_pitched entry
+ * points take operands and / or write results of that form, so that the convolution / addition / pooling / resize that produces a
+ * Concat operand writes it in place and the one that consumes a Split result reads it in place (lele copies: manipulation.rs:108-207,
+ * 1091-1151; the values are the same).  All fields in ELEMENTS; 0 = dense.
+ *   x_pitch, y_pitch : first / second tensor operand (its `data` already points at the window's first element)
+ *   out_offset, out_pitch : the result goes to out's data + out_offset, images out_pitch apart; `out` must ALREADY hold the
+ *                       enclosing tensor (lele_hip_buf_reserve) -- it is not resized, its other contents are untouched.  With
+ *                       out_pitch == 0 the op resizes `out` and writes a dense result, as its plain form does. */
+typedef struct LelePitch {
+    int64_t x_pitch;
+    int64_t y_pitch;
+    int64_t out_offset;
+    int64_t out_pitch;
+} LelePitch;
+
 typedef struct LeleCtx LeleCtx;
 typedef struct LeleBuf LeleBuf;
 typedef struct LeleFrontend LeleFrontend;
@@ -206,6 +223,10 @@ typedef enum {
 } LeleBinaryOp;
 int lele_hip_binary(LeleCtx* ctx, int op, const LeleTensor* a, const LeleTensor* b, LeleBuf* out, int64_t* out_shape,
                     int32_t* out_rank);
+/* the same op on SAME-SHAPE f32 operands that are channel views and / or with a channel-view result (LelePitch above: a residual
+ * add whose operand is a Split result and whose result is a Concat operand; math.rs:414 on copies) */
+int lele_hip_binary_pitched(LeleCtx* ctx, int op, const LeleTensor* a, const LeleTensor* b, const LelePitch* pitch, LeleBuf* out,
+                            int64_t* out_shape, int32_t* out_rank);
 /* where_op, manipulation.rs:1215: out = cond != 0 ? x : y */
 int lele_hip_where(LeleCtx* ctx, const LeleTensor* cond, const LeleTensor* x, const LeleTensor* y, LeleBuf* out,
                    int64_t* out_shape, int32_t* out_rank);
@@ -247,6 +268,14 @@ int lele_hip_resize_nearest(LeleCtx* ctx, const LeleTensor* x, int64_t out_h, in
 int lele_hip_max_pool2d(LeleCtx* ctx, const LeleTensor* x, const int64_t* kernel_shape, size_t nk,
                         const int64_t* strides, size_t ns, const int64_t* pads, size_t np, const int64_t* dilations,
                         size_t nd, int ceil_mode, LeleBuf* out, int64_t* out_shape, int32_t* out_rank); /* conv2d.rs:1051 */
+/* resize_nearest / max_pool2d reading and / or writing channel views, and the plain copy between views (LelePitch above):
+ * what concat (manipulation.rs:108) and split (manipulation.rs:1091) along C are when an operand cannot be produced in place */
+int lele_hip_resize_nearest_pitched(LeleCtx* ctx, const LeleTensor* x, int64_t out_h, int64_t out_w, int asymmetric,
+                                    const LelePitch* pitch, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+int lele_hip_max_pool2d_pitched(LeleCtx* ctx, const LeleTensor* x, const int64_t* kernel_shape, size_t nk, const int64_t* strides,
+                                size_t ns, const int64_t* pads, size_t np, const int64_t* dilations, size_t nd, int ceil_mode,
+                                const LelePitch* pitch, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+int lele_hip_copy_pitched(LeleCtx* ctx, const LeleTensor* x, const LelePitch* pitch, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
 /* adaptive_avg_pool1d, pooling.rs:1-30: x [.., L] -> [.., output_len]; window i = [floor(i*L/O), ceil((i+1)*L/O)) */
 int lele_hip_adaptive_avg_pool1d(LeleCtx* ctx, const LeleTensor* x, int64_t output_len, LeleBuf* out, int64_t* out_shape,
                                  int32_t* out_rank);
@@ -268,6 +297,12 @@ int lele_hip_cast(LeleCtx* ctx, const LeleTensor* x, int32_t to_dtype, LeleBuf* 
 int lele_hip_conv2d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,
                     const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
                     const int64_t* strides, size_t nstr, int act, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* conv2d on channel views (LelePitch above; group == 1): x may be a Split result read in place, the result a Concat operand
+ * written in place.  Same kernels, same arithmetic order as lele_hip_conv2d on dense copies: identical bits. */
+int lele_hip_conv2d_pitched(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,
+                            const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
+                            const int64_t* strides, size_t nstr, int act, const LelePitch* pitch, LeleBuf* out, int64_t* out_shape,
+                            int32_t* out_rank);
 /* reset_conv_stats / print_conv_stats (conv2d.rs:75, 101 -- no-ops upstream; examples/yolo26n-seg/src/main.rs:64,74 calls them):
  * 2-D convolutions issued on ctx since the last reset, as call count and multiply-accumulate count */
 int lele_hip_conv_stats_reset(LeleCtx* ctx);

@@ -28,6 +28,11 @@ class LeleTensor(C.Structure):
                 ("mem", C.c_int32)]
 
 
+class LelePitch(C.Structure):
+    """channel views (include/lele_hip.h): pitches / offset in elements, 0 = dense"""
+    _fields_ = [("x_pitch", C.c_int64), ("y_pitch", C.c_int64), ("out_offset", C.c_int64), ("out_pitch", C.c_int64)]
+
+
 class LeleFeatureConfig(C.Structure):
     _fields_ = [("sample_rate", C.c_int64), ("n_mels", C.c_int64), ("frame_length_ms", C.c_float),
                 ("frame_shift_ms", C.c_float), ("lfr_m", C.c_int64), ("lfr_n", C.c_int64)]
@@ -187,6 +192,10 @@ class Buf:
         """the contents were written behind the library's back (see lele_hip_buf_mark_dirty)"""
         check(lib().lele_hip_buf_mark_dirty(self._h))
 
+    def reserve(self, nbytes):
+        """make room for `nbytes` (lele_hip_buf_reserve): what the owner of an enclosing tensor does before its windows are written"""
+        check(lib().lele_hip_buf_reserve(self._h, C.c_size_t(int(nbytes))))
+
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
         check(lib().lele_hip_buf_from_host(self._h, arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)))
@@ -276,17 +285,32 @@ class Graph:
 
 
 class DevTensor:
-    """A device-resident tensor: (LeleBuf, shape, dtype)."""
+    """A device-resident tensor: (LeleBuf, shape, dtype) -- or a CHANNEL VIEW of one (include/lele_hip.h, LelePitch): the tensor
+    starts `offset` elements into the buffer and image n (index along axis 0) starts n * pitch elements after image 0; inside an
+    image it is dense.  pitch == 0: dense.  Only the *_pitched entry points accept views (as_tensor refuses them elsewhere)."""
 
-    def __init__(self, buf, shape, dtype=np.float32):
+    def __init__(self, buf, shape, dtype=np.float32, offset=0, pitch=0):
         self.buf = buf
         self.shape = tuple(int(s) for s in shape)
         self.dtype = np.dtype(dtype)
+        self.offset, self.pitch = int(offset), int(pitch)
+        if self.pitch and len(self.shape) and int(np.prod(self.shape[1:], dtype=np.int64)) == self.pitch and not self.offset:
+            self.pitch = 0   # the whole tensor: dense
+
+    @property
+    def is_view(self):
+        return bool(self.pitch or self.offset)
 
     def numpy(self):
         if int(np.prod(self.shape)) == 0:
             return np.zeros(self.shape, self.dtype)
-        return self.buf.to_numpy(self.shape, self.dtype)
+        if not self.is_view:
+            return self.buf.to_numpy(self.shape, self.dtype)
+        n = self.shape[0]
+        per = int(np.prod(self.shape[1:], dtype=np.int64))
+        pitch = self.pitch or per
+        flat = self.buf.to_numpy((self.offset + (n - 1) * pitch + per,), self.dtype)
+        return np.stack([flat[self.offset + i * pitch:self.offset + i * pitch + per] for i in range(n)]).reshape(self.shape)
 
 
 class Weight:
@@ -303,17 +327,20 @@ class Weight:
         Weight._alive.append(self.arr)
 
 
-def as_tensor(x, keep, mem=None):
+def as_tensor(x, keep, mem=None, views=False):
     """Build a LeleTensor for x (numpy array -> host memory, DevTensor -> device memory, Weight -> cached weight).
-    `keep` collects the objects that must stay alive for the duration of the call."""
+    `keep` collects the objects that must stay alive for the duration of the call.  views=True: the caller is a *_pitched entry
+    point and hands the pitch over separately; everywhere else a channel view is an error, not a silently dense read."""
     if x is None:
         return None
     if isinstance(x, Weight):
         x, mem = x.arr, MEM_WEIGHT
     if isinstance(x, DevTensor):
+        if x.is_view and not views:
+            raise LeleError("this operator needs a dense tensor, got a channel view (offset %d, pitch %d)" % (x.offset, x.pitch))
         shape = (C.c_int64 * max(1, len(x.shape)))(*x.shape)
         keep.append(shape)
-        t = LeleTensor(C.c_void_p(x.buf.ptr), shape, len(x.shape), _NP2DT[x.dtype], MEM_DEVICE)
+        t = LeleTensor(C.c_void_p(x.buf.ptr + x.offset * x.dtype.itemsize), shape, len(x.shape), _NP2DT[x.dtype], MEM_DEVICE)
         keep.append(t)
         return C.byref(t)
     a = np.asarray(x)

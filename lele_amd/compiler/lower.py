@@ -1008,10 +1008,18 @@ def allocate(statements, outputs):
     reads = []
     for i, st in enumerate(statements):
         r = refs(st.get("args", st.get("in")), [])
+        # channel views (plan.fold_channel_views): a `chview` shares its source's buffer, a statement with a `window` writes into
+        # (and its result shares) the buffer of the enclosing tensor
+        view_src = st.get("src") if st["op"] == "chview" else (st["window"]["of"] if "window" in st else None)
+        if view_src is not None:
+            r = r + [view_src] + list(st.get("after", []))
         reads.append(r)
         for name in r:
             last_use[name] = i
-        if st["op"] == "call" and st.get("bufs", 1) == 0:  # view: shares its first tensor operand's buffer
+        if view_src is not None:
+            for o in st["out"]:
+                owner[o] = owner.get(view_src, view_src)
+        elif st["op"] == "call" and st.get("bufs", 1) == 0:  # view: shares its first tensor operand's buffer
             src = r[0] if r else None
             owner[st["out"][0]] = owner.get(src, src)
         elif st.get("may_alias") and r:                      # may turn out to be a view of its first operand at run time
@@ -1031,7 +1039,7 @@ def allocate(statements, outputs):
     for i, st in enumerate(statements):
         for name in [n for n, _s in active.items() if last_use.get(n, -1) < i]:
             heapq.heappush(free, active.pop(name))
-        if st["op"] not in ("call", "if") or st.get("bufs", 1) == 0:
+        if st["op"] not in ("call", "if", "reserve") or st.get("bufs", 1) == 0:
             continue
         busy = {slot_of[owner.get(r, r)] for j in range(max(0, i - 5), i + 1) for r in reads[j] if owner.get(r, r) in slot_of}
         st["slots"] = []

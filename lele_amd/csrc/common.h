@@ -180,6 +180,27 @@ struct QParamsDev {
 };
 int quant_params_of(LeleCtx* ctx, const float* const* srcs, const int64_t* lens, int nsrc, void* prm_dev);
 
+// Destination of an op that takes a LelePitch (lele_hip.h): dense (out_pitch == 0: the buffer is resized as usual, out_offset must
+// be 0) or a window of a buffer that ALREADY holds the enclosing tensor (the caller reserved it: growing it here would drop what
+// other producers wrote).  `images` chunks of `per_image` elements of `esize` bytes.
+inline int pitched_out(LeleBuf* out, const LelePitch* pv, int64_t images, int64_t per_image, size_t esize, void** dst) {
+    if (pv->out_pitch == 0) {
+        LELE_REQUIRE(pv->out_offset == 0, "pitched op: out_offset without out_pitch");
+        LELE_TRY(out->reserve((size_t)(images * per_image) * esize));
+        *dst = out->data;
+        return 0;
+    }
+    LELE_REQUIRE(pv->out_offset >= 0 && pv->out_pitch >= per_image, "pitched op: out_pitch %lld is smaller than one image (%lld elements)",
+                 (long long)pv->out_pitch, (long long)per_image);
+    const int64_t need = images > 0 ? pv->out_offset + (images - 1) * pv->out_pitch + per_image : 0;
+    LELE_REQUIRE(out->data && (size_t)need * esize <= out->cap,
+                 "pitched op: the destination buffer holds %zu bytes, the window ends at %lld (reserve the enclosing tensor first)", out->cap,
+                 (long long)((size_t)need * esize));
+    out->rowstat_valid = false;  // the buffer is being written: producer-side statistics of an earlier result are stale
+    *dst = (char*)out->data + (size_t)pv->out_offset * esize;
+    return 0;
+}
+
 inline int set_shape(int64_t* out_shape, int32_t* out_rank, std::initializer_list<int64_t> dims) {
     if (out_rank) *out_rank = (int32_t)dims.size();
     if (out_shape) {

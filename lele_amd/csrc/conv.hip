@@ -34,6 +34,9 @@ __device__ __forceinline__ float apply_act(float v, int act, bool body) {
 
 struct ConvGeom {
     int n, c, ih, iw, oc, kh, kw, group, icg, ocg, pt, pl, sh, sw, dh, dw, oh, ow, K, plane;
+    // elements from one image to the next in x / out.  0 = dense (c*ih*iw / oc*plane, filled in by run_conv2d); anything else is a
+    // CHANNEL VIEW of a wider NCHW tensor (lele_hip_conv2d_pitched: a Concat operand written in place, a Split result read in place)
+    long long xbs = 0, obs = 0;
 };
 
 // exact n / d for the small non-negative values of this file via one mulhi (m = floor(2^32/d) + 1 is exact while
@@ -102,7 +105,7 @@ struct ConvXLoad {
         const int rowc = rin ? r : g.plane - 1;
         const int img = b / g.group, grp = b - img * g.group;
         const int oy = d_ow.div(rowc), ox = rowc - oy * g.ow;
-        return Row{x + ((int64_t)img * g.c + grp * g.icg) * g.ih * g.iw, oy * g.sh - g.pt, ox * g.sw - g.pl, rin};
+        return Row{x + (int64_t)img * g.xbs + (int64_t)grp * g.icg * g.ih * g.iw, oy * g.sh - g.pt, ox * g.sw - g.pl, rin};
     }
     __device__ __forceinline__ float4 get4(const Row& r, int k) const {
         const int kc = k < g.K ? k : g.K - 1;
@@ -143,7 +146,7 @@ struct ConvXLoadTap {
         const int rowc = rin ? r : g.plane - 1;
         const int img = b / g.group, grp = b - img * g.group;
         const int oy = d_ow.div(rowc), ox = rowc - oy * g.ow;
-        return Row{x + ((int64_t)img * g.c + grp * g.icg) * g.ih * g.iw, oy * g.sh - g.pt, ox * g.sw - g.pl, rin};
+        return Row{x + (int64_t)img * g.xbs + (int64_t)grp * g.icg * g.ih * g.iw, oy * g.sh - g.pt, ox * g.sw - g.pl, rin};
     }
     __device__ __forceinline__ float4 get4(const Row& r, int k) const {
         const int kc = k < g.K ? k : g.K - 4;  // K % 4 == 0 here, so a chunk is entirely in or out of range
@@ -182,10 +185,10 @@ struct ConvEpi {
         const int img = b / g.group, o = (b % g.group) * g.ocg + row;
         float v = acc;
         if (bias) v = v + pre;
-        out[((int64_t)img * g.oc + o) * g.plane + col] = apply_act(v, act, col < (g.plane & ~7));
+        out[(int64_t)img * g.obs + (int64_t)o * g.plane + col] = apply_act(v, act, col < (g.plane & ~7));
     }
     // the 16-byte store protocol of gemm_core.h: finished values, a row's address, and when rows may be written four columns at a time
-    __device__ __forceinline__ bool vec_ok() const { return (g.plane & 3) == 0 && (((uintptr_t)out) & 15) == 0; }
+    __device__ __forceinline__ bool vec_ok() const { return (g.plane & 3) == 0 && (g.obs & 3) == 0 && (((uintptr_t)out) & 15) == 0; }
     __device__ __forceinline__ float finish(int b, int row, int col, float acc, float pre) const {  // clamped coordinates
         float v = acc;
         if (bias) v = v + pre;
@@ -193,7 +196,7 @@ struct ConvEpi {
     }
     __device__ __forceinline__ float* row_ptr(int b, int row) const {
         const int img = b / g.group, o = (b % g.group) * g.ocg + row;
-        return out + ((int64_t)img * g.oc + o) * g.plane;
+        return out + (int64_t)img * g.obs + (int64_t)o * g.plane;
     }
 };
 
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const float* __rest
     const int img = blockIdx.y;
     const int oy = tyi * TH + ty, ox = txi * TW + tx;
     const int iy0 = tyi * TH * S - g.pt, ix0 = txi * TW * S - g.pl;
-    const float* xin = x + (int64_t)img * g.c * g.ih * g.iw;
+    const float* xin = x + (int64_t)img * g.xbs;
     float acc[OCB];
 #pragma unroll
     for (int o = 0; o < OCB; ++o) acc[o] = 0.0f;
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const float* __rest
     if (oy >= g.oh || ox >= g.ow) return;
     const int pos = oy * g.ow + ox;
     const bool body = pos < (g.plane & ~7);
-    float* o0 = out + (int64_t)img * g.oc * g.plane + pos;
+    float* o0 = out + (int64_t)img * g.obs + pos;
 #pragma unroll
     for (int o = 0; o < OCB; ++o)
         if (o < g.oc) {
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // 64 -> 64 channels at 160 x 160 x 64 with one kind of wave; the window's HBM latency sat in front of every chunk)
         const int pt = tid - 256;
         const int iy0 = tyi * C3M_TH - g.pt, ix0 = txi * C3M_TW - g.pl;
-        const float* xin = x + (int64_t)img * g.c * hw;
+        const float* xin = x + (int64_t)img * g.xbs;
         int t_off[W::TASKS], t_lds[W::TASKS];  // task t = (position, channel quad); its four channel planes are hw apart
         bool t_in[W::TASKS];
 #pragma unroll
@@ -732,7 +735,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // 64 -> 64 channels at 160 x 160 x 64).  Every wave of the workgroup is past the last barrier, so the stages are free: the
     // wave's 32 channels x 4 rows x 32 columns take a turn through LDS and leave as 16-byte pieces of 128-byte output rows.
     const int ox = txi * C3M_TW + l31;
-    if (g.ow % 4 == 0) {
+    if (g.ow % 4 == 0 && epi.vec_ok()) {  // 16-byte stores need the rows AND the destination (a view may start anywhere) aligned
         constexpr int OCP = NJ * 32 + 8;  // floats per output channel: the two half waves (4 channels apart) land on different banks
         float* mine = reinterpret_cast<float*>(c3m_lds) + wave * (32 * OCP);
         static_assert(4 * 32 * OCP * 4 <= W::LDS, "the epilogue tiles fit the stages");
@@ -760,7 +763,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const int oy = tyi * C3M_TH + NJ * wn + j, oc = ocb * OCT + wm * 32 + ol;
             const float4 v = *reinterpret_cast<const float4*>(mine + ol * OCP + j * 32 + 4 * q4);
             if (oy < g.oh && oxq < g.ow && oc < g.oc)
-                *reinterpret_cast<float4*>(epi.out + ((int64_t)img * g.oc + oc) * g.plane + oy * g.ow + oxq) = v;
+                *reinterpret_cast<float4*>(epi.out + (int64_t)img * g.obs + (int64_t)oc * g.plane + oy * g.ow + oxq) = v;
         }
         return;
     }
@@ -816,7 +819,11 @@ inline int64_t attr(const int64_t* v, size_t n, size_t i, int64_t dflt) {
 int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float* dw, const float* db, ConvGeom g, int act,
                float* out) {
     if ((int64_t)g.n * g.oc * g.plane == 0) return 0;
-    if (g.icg == 1 && g.ocg == 1) {
+    const bool pitched = (g.xbs != 0 && g.xbs != (long long)g.c * g.ih * g.iw) || (g.obs != 0 && g.obs != (long long)g.oc * g.plane);
+    if (g.xbs == 0) g.xbs = (long long)g.c * g.ih * g.iw;
+    if (g.obs == 0) g.obs = (long long)g.oc * g.plane;
+    LELE_REQUIRE(!pitched || g.group == 1, "conv2d: channel views (a batch pitch) are supported for group == 1 only");
+    if (g.icg == 1 && g.ocg == 1 && !pitched) {
         const int64_t total = (int64_t)g.n * g.oc * g.plane;
         LELE_REQUIRE(total < (int64_t(1) << 32), "depthwise conv: more than 2^32 output elements");
         const unsigned ngroups = (unsigned)((g.ow + 3) / 4);
@@ -958,7 +965,7 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
         LELE_REQUIRE(img_elems < (int64_t(1) << 31), "conv2d: one image group exceeds 2^31 elements");
         if (g.kh == 1 && g.kw == 1 && g.sh == 1 && g.sw == 1 && g.pt == 0 && g.pl == 0 && g.oh == g.ih && g.ow == g.iw) {
             // pointwise: B[p][k] = x[img][grp*ICg + k][p] is a plain column-major operand; batch b = img*G + grp
-            gemm::LoadKRow bl{dx, img_elems, (int64_t)g.plane, g.plane, g.K};
+            gemm::LoadKRow bl{dx, g.group == 1 ? (int64_t)g.xbs : img_elems, (int64_t)g.plane, g.plane, g.K};
             gemm::launch(ctx->stream, al, bl, epi, g.ocg, g.plane, g.K, g.n * g.group, ctx->num_cus);
         } else if (g.icg % 4 == 0) {
             // tap-major K: weights permuted to [OC][tap][ic] once (cached when the caller declared them immutable)
@@ -1113,9 +1120,10 @@ int centred_weights(LeleCtx* ctx, const LeleTensor* w, float w_zp, const float**
 
 extern "C" {
 
-int lele_hip_conv2d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,
-                    const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
-                    const int64_t* strides, size_t nstr, int act, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+static int conv2d_entry(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,
+                        const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
+                        const int64_t* strides, size_t nstr, int act, const LelePitch* pv, LeleBuf* out, int64_t* out_shape,
+                        int32_t* out_rank) {
     LELE_REQUIRE(ctx && x && w && out, "conv2d: NULL argument");
     LELE_REQUIRE(x->rank == 4, "Conv2d: expected rank-4 input [N,C,H,W], got rank %d", x->rank);        // conv2d.rs:196
     LELE_REQUIRE(w->rank == 4, "Conv2d: expected rank-4 weight [C_out,C_in/g,kH,kW], got rank %d", w->rank);
@@ -1168,9 +1176,34 @@ int lele_hip_conv2d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, cons
     LELE_TRY(ctx->dev_ptr(x, &dx));
     LELE_TRY(ctx->dev_ptr(w, &dwp));
     if (bias) LELE_TRY(ctx->dev_ptr(bias, &db));
-    LELE_TRY(out->reserve((size_t)g.n * g.oc * g.plane * 4));
-    LELE_TRY(run_conv2d(ctx, w, (const float*)dx, (const float*)dwp, (const float*)db, g, act, (float*)out->data));
+    float* dst = nullptr;
+    if (pv) {  // channel views: see LelePitch in lele_hip.h
+        LELE_REQUIRE(pv->y_pitch == 0, "conv2d_pitched: y_pitch must be 0 (one tensor operand)");
+        LELE_REQUIRE(pv->x_pitch == 0 || (x->mem == LELE_MEM_DEVICE && pv->x_pitch >= (int64_t)g.c * g.ih * g.iw),
+                     "conv2d_pitched: x_pitch needs a device tensor and must cover one image");
+        g.xbs = pv->x_pitch;
+        LELE_TRY(lele::pitched_out(out, pv, g.n, (int64_t)g.oc * g.plane, 4, (void**)&dst));
+        g.obs = pv->out_pitch;
+    } else {
+        LELE_TRY(out->reserve((size_t)g.n * g.oc * g.plane * 4));
+        dst = (float*)out->data;
+    }
+    LELE_TRY(run_conv2d(ctx, w, (const float*)dx, (const float*)dwp, (const float*)db, g, act, dst));
     return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, (int64_t)g.oh, (int64_t)g.ow});
+}
+
+int lele_hip_conv2d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,
+                    const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
+                    const int64_t* strides, size_t nstr, int act, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    return conv2d_entry(ctx, x, w, bias, dilations, ndil, group, pads, npads, strides, nstr, act, nullptr, out, out_shape, out_rank);
+}
+
+int lele_hip_conv2d_pitched(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,
+                            const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
+                            const int64_t* strides, size_t nstr, int act, const LelePitch* pitch, LeleBuf* out, int64_t* out_shape,
+                            int32_t* out_rank) {
+    LELE_REQUIRE(pitch, "conv2d_pitched: pitch is NULL");
+    return conv2d_entry(ctx, x, w, bias, dilations, ndil, group, pads, npads, strides, nstr, act, pitch, out, out_shape, out_rank);
 }
 
 /* reset_conv_stats / print_conv_stats (conv2d.rs:75,101; examples/yolo26n-seg/src/main.rs:64,74): counters of the 2-D convolutions

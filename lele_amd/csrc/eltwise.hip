@@ -582,6 +582,29 @@ bool binary_fast_map(const Bcast& bc, const int64_t* stride, const void* ptr, in
     return true;
 }
 
+// Same-shape binary op whose operands and / or result are CHANNEL VIEWS of wider NCHW tensors (LelePitch, lele_hip.h): image n of
+// an operand starts n * pitch elements after image 0 and is dense inside.  binary_apply element by element: the bits of
+// lele_hip_binary on dense copies.  grid (chunks of one image, images).
+__global__ __launch_bounds__(256) void binary_pitched_kernel(int op, const float* __restrict__ a, const float* __restrict__ b,
+                                                             float* __restrict__ out, unsigned per_image, long long pa, long long pb,
+                                                             long long po, int vec) {
+    const float* ai = a + (long long)blockIdx.y * pa;
+    const float* bi = b + (long long)blockIdx.y * pb;
+    float* oi = out + (long long)blockIdx.y * po;
+    const unsigned gtid = blockIdx.x * 256u + threadIdx.x, gstride = gridDim.x * 256u;
+    if (vec) {
+        const unsigned nvec = per_image >> 2;
+        for (unsigned v = gtid; v < nvec; v += gstride) {
+            const float4 x = reinterpret_cast<const float4*>(ai)[v], y = reinterpret_cast<const float4*>(bi)[v];
+            reinterpret_cast<float4*>(oi)[v] = make_float4(binary_apply<float>(op, x.x, y.x), binary_apply<float>(op, x.y, y.y),
+                                                           binary_apply<float>(op, x.z, y.z), binary_apply<float>(op, x.w, y.w));
+        }
+        for (unsigned i = 4 * nvec + gtid; i < per_image; i += gstride) oi[i] = binary_apply<float>(op, ai[i], bi[i]);
+    } else {
+        for (unsigned i = gtid; i < per_image; i += gstride) oi[i] = binary_apply<float>(op, ai[i], bi[i]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -645,6 +668,37 @@ int lele_hip_binary(LeleCtx* ctx, int op, const LeleTensor* a, const LeleTensor*
         LELE_HIP_CHECK(hipGetLastError());
     }
     return set_shape_v(out_shape, out_rank, oshape);
+}
+
+int lele_hip_binary_pitched(LeleCtx* ctx, int op, const LeleTensor* a, const LeleTensor* b, const LelePitch* pitch, LeleBuf* out,
+                            int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && a && b && out && pitch, "binary_pitched: NULL argument");
+    LELE_REQUIRE(op >= 0 && op <= B_OR, "binary: unknown op %d", op);
+    LELE_REQUIRE(a->dtype == LELE_F32 && b->dtype == LELE_F32, "binary_pitched: f32 operands required");
+    LELE_REQUIRE(a->rank == b->rank && a->rank >= 2, "binary_pitched: operands of the same shape (rank >= 2) required");
+    for (int i = 0; i < a->rank; ++i) LELE_REQUIRE(a->shape[i] == b->shape[i], "binary_pitched: operands of the same shape required");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t images = a->shape[0], per = images ? numel(a) / images : 0;
+    LELE_REQUIRE(per < (int64_t(1) << 32) && images <= 65535, "binary_pitched: image too large for the 32-bit kernel");
+    LELE_REQUIRE((pitch->x_pitch == 0 || (a->mem == LELE_MEM_DEVICE && pitch->x_pitch >= per)) &&
+                 (pitch->y_pitch == 0 || (b->mem == LELE_MEM_DEVICE && pitch->y_pitch >= per)),
+                 "binary_pitched: a pitch needs a device tensor and must cover one image");
+    LELE_TRY(ctx->arena_reset());
+    const void *da = nullptr, *db = nullptr;
+    LELE_TRY(ctx->dev_ptr(a, &da));
+    LELE_TRY(ctx->dev_ptr(b, &db));
+    float* dst = nullptr;
+    LELE_TRY(lele::pitched_out(out, pitch, images, per, 4, (void**)&dst));
+    if (images * per) {
+        const long long pa = pitch->x_pitch ? pitch->x_pitch : per, pb = pitch->y_pitch ? pitch->y_pitch : per,
+                        po = pitch->out_pitch ? pitch->out_pitch : per;
+        const int vec = ((((uintptr_t)da) | ((uintptr_t)db) | ((uintptr_t)dst)) & 15) == 0 && pa % 4 == 0 && pb % 4 == 0 && po % 4 == 0;
+        const unsigned chunks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((per + 2047) / 2048, 4096));
+        hipLaunchKernelGGL(binary_pitched_kernel, dim3(chunks, (unsigned)images), dim3(256), 0, ctx->stream, op, (const float*)da,
+                           (const float*)db, dst, (unsigned)per, pa, pb, po, vec);
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(a->shape, a->shape + a->rank));
 }
 
 int lele_hip_where(LeleCtx* ctx, const LeleTensor* cond, const LeleTensor* x, const LeleTensor* y, LeleBuf* out,

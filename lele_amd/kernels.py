@@ -40,6 +40,44 @@ def _call(fn, tensors, extra=(), out=None, ctx=None, dtype=np.float32):
     return _op(ctx, fn, tensors, list(extra), out, dtype)
 
 
+def _pitch(x):
+    x = unwrap(x)
+    return x.pitch if isinstance(x, _lib.DevTensor) else 0
+
+
+def _is_view(x):
+    x = unwrap(x)
+    return isinstance(x, _lib.DevTensor) and x.is_view
+
+
+def _op_pitched(ctx, fn, tensors, extra, out, out_window, dtype=np.float32, prefix=()):
+    """a *_pitched entry point (include/lele_hip.h, LelePitch): fn(ctx, *prefix, *tensors, *extra, pitch, out, out_shape, out_rank).
+    The first two tensors may be channel views; out_window = (offset, pitch) in elements writes the result into a window of `out`
+    (which must already hold the enclosing tensor) and returns the view of it."""
+    ctx = _ctx(ctx)
+    keep = []
+    args = [ctx._h] + list(prefix)
+    for t in tensors:
+        args.append(_lib.as_tensor(unwrap(t), keep, views=True))
+    for t in tensors[2:]:
+        if _is_view(t):
+            raise _lib.LeleError("only the first two tensor operands may be channel views")
+    pv = _lib.LelePitch(_pitch(tensors[0]) if tensors else 0, _pitch(tensors[1]) if len(tensors) > 1 else 0,
+                        int(out_window[0]) if out_window else 0, int(out_window[1]) if out_window else 0)
+    args.extend(extra)
+    out = out or ctx.buf()
+    sh = _lib.OutShape()
+    args.extend([C.byref(pv), out._h, sh.shape, C.byref(sh.rank)])
+    _lib.check(fn(*args))
+    return TensorView(_lib.DevTensor(out, sh.get(), dtype, pv.out_offset, pv.out_pitch))
+
+
+def copy_view(input, out=None, out_window=None, ctx=None):
+    """copy a tensor or channel view into `out` (dense) or into a window of it: Concat / Split along C when an operand cannot be
+    produced or consumed in place (manipulation.rs:108-207, 1091-1151)"""
+    return _op_pitched(ctx, _lib.lib().lele_hip_copy_pitched, [input], [], out, out_window, _dtype_of(input))
+
+
 def matmul(a, b, out=None, ctx=None):  # gemm.rs:112
     return _call(_lib.lib().lele_hip_matmul, [a, b], (), out, ctx)
 
@@ -207,7 +245,9 @@ def _make_unary(name, op):
 
 
 def _make_binary(name, op):
-    def fn(a, b, out=None, ctx=None):
+    def fn(a, b, out=None, ctx=None, out_window=None):
+        if out_window or _is_view(a) or _is_view(b):   # channel views: same-shape f32 operands only (the library checks)
+            return _op_pitched(ctx, _lib.lib().lele_hip_binary_pitched, [a, b], [], out, out_window, prefix=[C.c_int(op)])
         dt = np.int64 if (np.asarray(unwrap(a)).dtype == np.int64 if not isinstance(unwrap(a), _lib.DevTensor)
                           else unwrap(a).dtype == np.int64) else np.float32
         return _op(ctx, _lib.lib().lele_hip_binary, [a, b], [], out, dt, prefix=[C.c_int(op)])
@@ -455,7 +495,7 @@ def gather_elements(input, indices, axis, out=None, ctx=None):  # conv2d.rs:1438
     return _op(ctx, _lib.lib().lele_hip_gather_elements, [input, indices], [C.c_int64(axis)], out)
 
 
-def resize_nearest(input, scales=None, sizes=None, coordinate_transform_mode="asymmetric", out=None, ctx=None):
+def resize_nearest(input, scales=None, sizes=None, coordinate_transform_mode="asymmetric", out=None, ctx=None, out_window=None):
     """conv2d.rs:1261-1382"""
     shape = _shape_of(input)
     if len(shape) != 4:
@@ -472,8 +512,10 @@ def resize_nearest(input, scales=None, sizes=None, coordinate_transform_mode="as
         oh, ow = int(shape[2] * sh_), int(shape[3] * sw_)  # (in_h as f64 * sh as f64) as u64
     else:
         raise _lib.LeleError("Resize: either scales or sizes must be provided")
-    return _op(ctx, _lib.lib().lele_hip_resize_nearest, [input],
-               [C.c_int64(oh), C.c_int64(ow), C.c_int(int(coordinate_transform_mode == "asymmetric"))], out)
+    extra = [C.c_int64(oh), C.c_int64(ow), C.c_int(int(coordinate_transform_mode == "asymmetric"))]
+    if out_window or _is_view(input):
+        return _op_pitched(ctx, _lib.lib().lele_hip_resize_nearest_pitched, [input], extra, out, out_window)
+    return _op(ctx, _lib.lib().lele_hip_resize_nearest, [input], extra, out)
 
 
 def adaptive_avg_pool1d(input, output_len, out=None, ctx=None):  # pooling.rs:1
@@ -482,13 +524,15 @@ def adaptive_avg_pool1d(input, output_len, out=None, ctx=None):  # pooling.rs:1
     return _op(ctx, _lib.lib().lele_hip_adaptive_avg_pool1d, [input], [C.c_int64(int(output_len))], out)
 
 
-def max_pool2d(input, kernel_shape, strides=(), pads=(), dilations=(), ceil_mode=False, out=None, ctx=None):
+def max_pool2d(input, kernel_shape, strides=(), pads=(), dilations=(), ceil_mode=False, out=None, ctx=None, out_window=None):
     """conv2d.rs:1051-1254"""
     keep = []
     args = []
     for v in (kernel_shape, strides, pads, dilations):
         a, n = _lib.i64_array(list(v), keep)
         args += [a, n]
+    if out_window or _is_view(input):
+        return _op_pitched(ctx, _lib.lib().lele_hip_max_pool2d_pitched, [input], args + [C.c_int(int(ceil_mode))], out, out_window)
     return _op(ctx, _lib.lib().lele_hip_max_pool2d, [input], args + [C.c_int(int(ceil_mode))], out)
 
 
@@ -542,7 +586,7 @@ def cast_to_i64(input, out=None, ctx=None):  # utils.rs:84-101
     return _op(ctx, _lib.lib().lele_hip_cast, [input], [C.c_int32(_lib.I64)], out, np.int64)
 
 # ------------------------------------------------------------------------------------------------- conv / rnn
-def _conv(fn, input, weights, bias, dilations, group, pads, strides, tail, out, ctx):
+def _conv(fn, input, weights, bias, dilations, group, pads, strides, tail, out, ctx, out_window=None):
     keep = []
     args = []
     d, n = _lib.i64_array(list(dilations), keep)
@@ -550,6 +594,10 @@ def _conv(fn, input, weights, bias, dilations, group, pads, strides, tail, out, 
     for v in (pads, strides):
         a, n = _lib.i64_array(list(v), keep)
         args += [a, n]
+    if out_window or _is_view(input):
+        if fn is not _lib.lib().lele_hip_conv2d:
+            raise _lib.LeleError("channel views are supported by conv2d / conv2d_fused / conv2d_silu only")
+        return _op_pitched(ctx, _lib.lib().lele_hip_conv2d_pitched, [input, weights, bias], args + list(tail), out, out_window)
     return _op(ctx, fn, [input, weights, bias], args + list(tail), out)
 
 
@@ -569,18 +617,18 @@ def print_conv_stats(ctx=None):  # conv2d.rs:75
     print("conv stats: %d convolution calls, %.3f GMAC" % (calls, macs * 1e-9))
 
 
-def conv2d(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), out=None, ctx=None):  # conv2d.rs:107
-    return _conv(_lib.lib().lele_hip_conv2d, input, weights, bias, dilations, group, pads, strides, [C.c_int(0)], out, ctx)
+def conv2d(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), out=None, ctx=None, out_window=None):  # conv2d.rs:107
+    return _conv(_lib.lib().lele_hip_conv2d, input, weights, bias, dilations, group, pads, strides, [C.c_int(0)], out, ctx, out_window)
 
 
-def conv2d_fused(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), relu=False, out=None, ctx=None):
+def conv2d_fused(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), relu=False, out=None, ctx=None, out_window=None):
     """conv2d.rs:155"""
     return _conv(_lib.lib().lele_hip_conv2d, input, weights, bias, dilations, group, pads, strides,
-                 [C.c_int(1 if relu else 0)], out, ctx)
+                 [C.c_int(1 if relu else 0)], out, ctx, out_window)
 
 
-def conv2d_silu(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), out=None, ctx=None):  # conv2d.rs:124
-    return _conv(_lib.lib().lele_hip_conv2d, input, weights, bias, dilations, group, pads, strides, [C.c_int(2)], out, ctx)
+def conv2d_silu(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), out=None, ctx=None, out_window=None):  # conv2d.rs:124
+    return _conv(_lib.lib().lele_hip_conv2d, input, weights, bias, dilations, group, pads, strides, [C.c_int(2)], out, ctx, out_window)
 
 
 def conv1d(input, weights, bias=None, dilations=(), group=1, pads=(), strides=(), out=None, ctx=None):  # conv1d.rs:837

@@ -175,12 +175,229 @@ def replan_lifted(plan, shapes):
             "slots": slots, "statements": out, "weights": weights}
 
 
+# ---------------------------------------------------------------------------------------------------------- channel views
+# Concat / Split along C of NCHW tensors as VIEWS of one buffer (include/lele_hip.h, LelePitch).  lele copies (manipulation.rs:108-207,
+# 1091-1151); the values are the same, so a plan folded here gives the bits of the plan it came from.  Shapes are needed: the pass
+# runs on a plan whose value shapes were recorded by one eager run (Runner.shapes) -- the shapes a hipGraph capture freezes anyway.
+_CONVS = ("conv2d", "conv2d_silu", "conv2d_fused")
+_VIEW_WRITERS = _CONVS + ("add", "sub", "mul", "div", "max_pool2d", "resize_nearest")
+_F32_FNS = set(_VIEW_WRITERS) | {"conv_transpose", "silu", "sigmoid", "relu", "tanh", "exp", "sqrt", "softmax", "softmax_scaled", "layer_norm",
+                                 "batch_norm", "matmul", "matmul_fused_add", "gemm", "add3", "depthwise_conv1d_tlc"}
+
+
+def _refs(n, acc):
+    if isinstance(n, dict):
+        for key in ("ref", "ints"):
+            if isinstance(n.get(key), str):
+                acc.append(n[key])
+        if isinstance(n.get("refs"), list):
+            acc += n["refs"]
+        for v in n.values():
+            _refs(v, acc)
+    elif isinstance(n, list):
+        for v in n:
+            _refs(v, acc)
+    return acc
+
+
+def _concat_operands(st):
+    a0 = st["args"][0]
+    if "refs" in a0:
+        return list(a0["refs"])
+    if "list" in a0 and all(isinstance(v, dict) and "ref" in v for v in a0["list"]):
+        return [v["ref"] for v in a0["list"]]
+    return None
+
+
+def _lit_int(node):
+    return node["int"] if isinstance(node, dict) and "int" in node else None
+
+
+def fold_channel_views(plan, shapes):
+    """Returns a format-3 plan in which, wherever every party can work on a channel view,
+      * a Split along C of a rank-4 tensor is a set of views of its operand (no kernel),
+      * the producers of a Concat's operands write straight into the Concat's buffer (a `reserve` statement sizes it before the
+        first of them runs; operands that cannot be produced in place are copied in by `copy_view`) and the Concat itself is a view,
+      * the results of a Split that are, complete and in order, operands of a Concat are handled as ONE operand (the Split's input).
+    `shapes`: value name -> shape, recorded by an eager run of `plan` (Runner.shapes).  Anything the pass cannot prove stays as it is."""
+    from .compiler.lower import allocate
+    import copy
+    sts = copy.deepcopy(plan["statements"])
+    nst = len(sts)
+    prod, multi = {}, set()
+    for i, st in enumerate(sts):
+        for o in st.get("out", []):
+            if o in prod:
+                multi.add(o)
+            prod[o] = i
+    readers = {}
+    for i, st in enumerate(sts):
+        names = _refs(st.get("args", st.get("in")), [])
+        if st["op"] == "if":   # whatever a branch reads counts as a reader that cannot take a view
+            names += _refs([st.get("then"), st.get("else"), st.get("cond")], [])
+        for pos, r in enumerate(names):
+            readers.setdefault(r, []).append(i)
+    outputs = set(plan["outputs"])
+
+    def rank4(name):
+        s_ = shapes.get(name)
+        return s_ is not None and len(s_) == 4 and all(int(d) > 0 for d in s_)
+
+    f32_memo = {}
+
+    def is_f32(name, depth=0):
+        if name in f32_memo:
+            return f32_memo[name]
+        ok = False
+        if name in prod and name not in multi and depth < 64:
+            st = sts[prod[name]]
+            fn = st.get("fn")
+            if fn in _F32_FNS:
+                ok = True
+            elif fn == "split":
+                ok = is_f32(st["args"][0].get("ref"), depth + 1)
+            elif fn == "concat":
+                ops = _concat_operands(st)
+                ok = bool(ops) and all(is_f32(o, depth + 1) for o in ops)
+        elif name in plan["inputs"]:
+            info = {d["name"]: d for d in plan.get("input_info", [])}
+            ok = info.get(name, {}).get("dtype", "f32") == "f32"
+        f32_memo[name] = ok
+        return ok
+
+    def axis1(st, pos, name):
+        ax = _lit_int(st["args"][pos])
+        return ax is not None and rank4(name) and (ax == 1 or ax == -3)
+
+    cand_concat = {}   # statement index -> operand names
+    for i, st in enumerate(sts):
+        if st["op"] == "call" and st.get("fn") == "concat" and len(st["out"]) == 1:
+            ops = _concat_operands(st)
+            r = st["out"][0]
+            if ops and r not in multi and axis1(st, 1, r) and all(rank4(o) and o not in multi and is_f32(o) for o in ops) \
+                    and all(list(shapes[o][:1]) + list(shapes[o][2:]) == list(shapes[r][:1]) + list(shapes[r][2:]) for o in ops) \
+                    and sum(int(shapes[o][1]) for o in ops) == int(shapes[r][1]) and len(set(ops)) == len(ops):
+                cand_concat[i] = ops
+    view_split = {}    # statement index -> True, decided in reverse program order (a split may read another split's view)
+
+    def reader_ok(si, name):
+        """can statement si read `name` as a channel view?"""
+        st = sts[si]
+        if st["op"] != "call":
+            return False
+        fn, args = st.get("fn"), st.get("args", [])
+        where = [k for k, a in enumerate(args) if isinstance(a, dict) and a.get("ref") == name]
+        if fn in _CONVS:
+            return where == [0] and _lit_int(args[4]) == 1
+        if fn in ("add", "sub", "mul", "div"):
+            other = [a.get("ref") for a in args[:2] if isinstance(a, dict)]
+            return len(args) >= 2 and all(k in (0, 1) for k in where) and all(o is not None and shapes.get(o) == shapes.get(name) for o in other) \
+                and rank4(name) and is_f32(name)
+        if fn in ("max_pool2d", "resize_nearest"):
+            return where == [0]
+        if fn == "concat":
+            return si in cand_concat
+        if fn == "split":
+            return view_split.get(si, False)
+        return False
+
+    for i in range(nst - 1, -1, -1):
+        st = sts[i]
+        if st["op"] == "call" and st.get("fn") == "split" and "ref" in st["args"][0]:
+            x = st["args"][0]["ref"]
+            sizes = st["args"][2].get("list") if isinstance(st["args"][2], dict) else None
+            if sizes is None or any(_lit_int(v) is None for v in sizes) or not axis1(st, 1, x) or not is_f32(x) or x in multi:
+                continue
+            if any(o in multi or o in outputs for o in st["out"]):
+                continue
+            if sum(_lit_int(v) for v in sizes) != int(shapes[x][1]) or len(sizes) != len(st["out"]):
+                continue
+            view_split[i] = all(reader_ok(si, o) for o in st["out"] for si in readers.get(o, []))
+    view_split = {i: v for i, v in view_split.items() if v}
+
+    # ---- concat operands: merge complete, ordered runs of one view-split's results into that split's input; pick the in-place ones
+    windowed = {}       # producing statement index -> (concat buffer name, channel offset)
+    reserve_at = {}     # statement index before which a `reserve` goes -> [(buffer name, shape)]
+    concat_plan = {}    # concat statement index -> (buffer name, [(operand, c0, in_place)])
+    for ic in sorted(cand_concat):
+        ops = cand_concat[ic]
+        r = sts[ic]["out"][0]
+        merged, k = [], 0
+        while k < len(ops):
+            o = ops[k]
+            pi = prod.get(o)
+            if pi is not None and pi in view_split and sts[pi]["out"][0] == o and sts[pi]["out"] == ops[k:k + len(sts[pi]["out"])]:
+                merged.append(sts[pi]["args"][0]["ref"])
+                k += len(sts[pi]["out"])
+            else:
+                merged.append(o)
+                k += 1
+        buf = r + "__cat"
+        entries, c0, first = [], 0, None
+        for o in merged:
+            pi = prod.get(o)
+            ok = pi is not None and pi < ic and pi not in windowed and o not in multi and o not in outputs and sts[pi]["op"] == "call" \
+                and len(sts[pi]["out"]) == 1 and sts[pi].get("fn") in _VIEW_WRITERS and "window" not in sts[pi]
+            if ok:
+                pst = sts[pi]
+                if pst["fn"] in _CONVS:
+                    ok = _lit_int(pst["args"][4]) == 1
+                elif pst["fn"] in ("add", "sub", "mul", "div"):
+                    ab = [a.get("ref") if isinstance(a, dict) else None for a in pst["args"][:2]]
+                    ok = all(n is not None and shapes.get(n) == shapes.get(o) for n in ab)
+            if ok:   # everybody else who reads the operand must cope with a view
+                ok = all(si == ic or reader_ok(si, o) for si in readers.get(o, []))
+            if ok:
+                windowed[pi] = (buf, c0)
+                first = pi if first is None else min(first, pi)
+            entries.append((o, c0, bool(ok)))
+            c0 += int(shapes[o][1])
+        if first is None and not any(prod.get(o) in windowed or prod.get(o) in view_split for o, _c, _p in entries):
+            continue                      # nothing can be produced in place and every operand is dense: the concat stays ONE copy kernel
+        concat_plan[ic] = (buf, entries)  # (an operand that is a view elsewhere is copied in by copy_view, which reads views)
+        reserve_at.setdefault(ic if first is None else first, []).append((buf, [int(d) for d in shapes[r]]))
+
+    out = []
+    for i, st in enumerate(sts):
+        for buf, shp in reserve_at.get(i, []):
+            out.append({"op": "reserve", "out": [buf], "shape": shp, "bufs": 1})
+        if i in windowed:
+            buf, c0 = windowed[i]
+            st = dict(st, window={"of": buf, "c0": c0}, bufs=0)
+            st.pop("slots", None)
+            out.append(st)
+        elif i in view_split:
+            x, c0 = st["args"][0]["ref"], 0
+            for o, v in zip(st["out"], st["args"][2]["list"]):
+                out.append({"op": "chview", "out": [o], "src": x, "c0": c0, "c1": c0 + v["int"]})
+                c0 += v["int"]
+        elif i in concat_plan:
+            buf, entries = concat_plan[i]
+            for o, c0, in_place in entries:
+                if not in_place:
+                    out.append({"op": "call", "out": [st["out"][0] + "__in%d" % c0], "fn": "copy_view", "args": [{"ref": o}],
+                                "window": {"of": buf, "c0": c0}, "bufs": 0})
+            # the in-place operands are read here so that liveness keeps the buffer (and them) until the concat's place in the order
+            out.append({"op": "chview", "out": [st["out"][0]], "src": buf, "c0": 0, "c1": int(shapes[st["out"][0]][1]),
+                        "after": [o for o, _c, _p in entries]})
+        else:
+            st = dict(st)
+            st.pop("slots", None)
+            out.append(st)
+    slots = allocate(out, list(plan["outputs"]))
+    new = dict(plan)
+    new.update({"format": "lele_amd.plan/3", "statements": out, "slots": slots,
+                "folded": {"concats_in_place": len(concat_plan), "splits_as_views": len(view_split),
+                           "operands_in_place": len(windowed), "operands_copied": sum(1 for _b, e in concat_plan.values() for x in e if not x[2])}})
+    return new
+
+
 class Runner:
     def __init__(self, plan, weights, ctx):
         from . import kernels as K
         from ._lib import Weight
         self.plan, self.K, self.ctx = plan, K, ctx
-        self.v2 = plan.get("format") == "lele_amd.plan/2"   # compiled plans key weights by (offset, kind, shape); lifted ones by offset
+        self.v2 = plan.get("format") in ("lele_amd.plan/2", "lele_amd.plan/3")   # /3: /2 + channel views (fold_channel_views); compiled plans key weights by (offset, kind, shape); lifted ones by offset
         self.raw = {(k if self.v2 else int(k)): v for k, v in weights.items()}
         self.W = {k: (Weight(a) if a.dtype != np.int64 else a) for k, a in self.raw.items()}
         self.ws = {s: ctx.buf() for s in plan["slots"]}
@@ -329,6 +546,14 @@ class Runner:
                 lst.pop()
             elif op == "alias":
                 env[st["out"][0]] = env[st["src"]]
+            elif op == "reserve":   # the buffer of a Concat whose operands are written in place (fold_channel_views)
+                from .tensor import TensorView
+                from ._lib import DevTensor
+                buf = self.ws[st["slots"][0]]
+                buf.reserve(4 * int(np.prod(st["shape"], dtype=np.int64)))
+                env[st["out"][0]] = TensorView(DevTensor(buf, st["shape"], np.float32))
+            elif op == "chview":    # channels [c0, c1) of a device tensor, no copy
+                env[st["out"][0]] = env[st["src"]].channels(st["c0"], st["c1"])
             elif op == "host":
                 self.host(st, env)
             else:
@@ -346,7 +571,13 @@ class Runner:
                 self.calls += 1
                 try:
                     t0 = time.perf_counter() if self.profile is not None else 0.0
-                    res = self.call(f, fn, pos, bufs, key=st["out"][0] + str(self.stmt_index), may_alias=bool(st.get("may_alias")))
+                    if "window" in st:   # the result is a channel window of an already reserved tensor (fold_channel_views)
+                        whole = env[st["window"]["of"]]
+                        d = whole.raw()
+                        inner = int(np.prod(d.shape[2:], dtype=np.int64))
+                        res = f(*pos, out=d.buf, out_window=(d.offset + st["window"]["c0"] * inner, d.pitch or d.shape[1] * inner), ctx=ctx)
+                    else:
+                        res = self.call(f, fn, pos, bufs, key=st["out"][0] + str(self.stmt_index), may_alias=bool(st.get("may_alias")))
                     if self.profile is not None:
                         ctx.sync()
                         self.profile[fn] = self.profile.get(fn, 0.0) + time.perf_counter() - t0

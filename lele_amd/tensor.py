@@ -13,7 +13,9 @@ from . import _lib
 class TensorView:
     def __init__(self, data, shape=None):
         if isinstance(data, _lib.DevTensor):
-            self._dev = data if shape is None else _lib.DevTensor(data.buf, shape, data.dtype)
+            if shape is not None and data.is_view and tuple(int(d) for d in shape) != tuple(data.shape):
+                raise _lib.LeleError("reshape of a channel view (offset %d, pitch %d): copy it out first" % (data.offset, data.pitch))
+            self._dev = data if shape is None or data.is_view else _lib.DevTensor(data.buf, shape, data.dtype)
             self._host = None
             self.shape = tuple(self._dev.shape)
         else:
@@ -59,6 +61,24 @@ class TensorView:
     @property
     def is_device(self):
         return self._dev is not None
+
+    @property
+    def pitch(self):
+        """elements from one image to the next when this is a channel view of a wider NCHW tensor (0: dense)"""
+        return self._dev.pitch if self._dev is not None else 0
+
+    @property
+    def is_view(self):
+        return self._dev is not None and self._dev.is_view
+
+    def channels(self, c0, c1):
+        """the channel window [c0, c1) of a device tensor [N, C, ...] as a view (no copy): a Split result / Concat operand"""
+        d = self._dev
+        if d is None or len(d.shape) < 2:
+            raise _lib.LeleError("channels(): a device tensor of rank >= 2 is required")
+        inner = int(np.prod(d.shape[2:], dtype=np.int64))
+        pitch = d.pitch or d.shape[1] * inner
+        return TensorView(_lib.DevTensor(d.buf, (d.shape[0], c1 - c0) + tuple(d.shape[2:]), d.dtype, d.offset + c0 * inner, pitch))
 
     def numpy(self):
         if self._host is None:

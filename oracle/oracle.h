@@ -97,6 +97,10 @@ void orc_gru(const float* x, int64_t seq_len, int64_t input_size, int64_t hidden
 void orc_conv2d(const float* x, const float* w, const float* bias, int64_t n, int64_t c, int64_t ih, int64_t iw,
                 int64_t oc, int64_t kh, int64_t kw, int64_t group, int64_t pt, int64_t pl, int64_t pb, int64_t pr,
                 int64_t sh, int64_t sw, int64_t dh, int64_t dw, int act, float* out);
+/* the same convolution the way lele's x86 build computes it: im2col + GEMM + bias / activation pass (conv_fast.cpp) */
+void orc_conv2d_im2col(const float* x, const float* w, const float* bias, int64_t n, int64_t c, int64_t ih, int64_t iw,
+                       int64_t oc, int64_t kh, int64_t kw, int64_t group, int64_t pt, int64_t pl, int64_t pb, int64_t pr,
+                       int64_t sh, int64_t sw, int64_t dh, int64_t dw, int act, float* out);
 void orc_conv_transpose2d(const float* x, const float* w, const float* bias, int64_t n, int64_t c, int64_t ih,
                           int64_t iw, int64_t oc, int64_t kh, int64_t kw, int64_t pt, int64_t pl, int64_t pb, int64_t pr,
                           int64_t sh, int64_t sw, int64_t dh, int64_t dw, float* out);

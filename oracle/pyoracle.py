@@ -16,11 +16,16 @@ c_f32p = C.POINTER(C.c_float)
 c_i64p = C.POINTER(C.c_int64)
 
 
+SANITIZE = os.environ.get("ORACLE_SANITIZE", "0") not in ("", "0")   # the ASan / UBSan build (needs libasan preloaded: see
+                                                                      # tests/test_oracle_sanitized.py, which sets that up)
+
+
 def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+    name = "liboracle_asan.so" if SANITIZE else "liboracle.so"
+    so = os.path.join(_HERE, name)
     srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h"))]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", name])
     return so
 
 
@@ -372,6 +377,24 @@ def conv2d(x, w, bias=None, dilations=(), group=1, pads=(), strides=(), act=None
     lib().orc_conv2d(_p(x), _p(w), _p(b) if b is not None else None, i64(n), i64(c), i64(ih), i64(iw), i64(oc), i64(kh),
                      i64(kw), i64(group), i64(pt), i64(pl), i64(pb), i64(pr), i64(sh), i64(sw), i64(dh), i64(dw),
                      C.c_int(ACT[act]), _p(out))
+    return out
+
+
+def conv2d_im2col(x, w, bias=None, dilations=(), group=1, pads=(), strides=(), act=None):
+    """conv2d as lele's x86 build runs it (conv_fast.cpp: im2col + k-ordered f32 FMA GEMM + bias / activation pass)"""
+    x, w = _f32(x), _f32(w)
+    n, c, ih, iw = x.shape
+    oc, _, kh, kw = w.shape
+    dh, dw = _attr2(dilations, 1)
+    sh, sw = _attr2(strides, 1)
+    pt, pl, pb, pr = _pads4(pads)
+    oh = (ih + pt + pb - dh * (kh - 1) - 1) // sh + 1
+    ow = (iw + pl + pr - dw * (kw - 1) - 1) // sw + 1
+    out = np.empty((n, oc, oh, ow), np.float32)
+    b = _f32(bias) if bias is not None else None
+    lib().orc_conv2d_im2col(_p(x), _p(w), _p(b) if b is not None else None, i64(n), i64(c), i64(ih), i64(iw), i64(oc), i64(kh),
+                            i64(kw), i64(group), i64(pt), i64(pl), i64(pb), i64(pr), i64(sh), i64(sw), i64(dh), i64(dw),
+                            C.c_int(ACT[act]), _p(out))
     return out
 
 
