@@ -7,7 +7,10 @@ One process per GPU.  With --gpus N > 1 and no WORLD_SIZE in the environment the
 LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set per child); under `python -m torch.distributed.run` it
 takes the launcher's environment.  It refuses to run when the world size differs from --gpus.  Rank 0 prints ONE JSON line.
 
-Two legs per run, both on synthetic 16 kHz audio that is resident in HBM before anything is timed:
+Three legs per run, all on synthetic inputs that are resident in HBM before anything is timed (1 and 2: 16 kHz audio; 3 -- `yolo` --
+BASELINE configs[4]: a Yolo26n-seg-shaped network, batch 64 of 640 x 640 images per GPU as one hipGraph, 3 warm-up + 10 timed
+forwards as examples/yolo26n-seg/src/benchmark.rs:29-56, priced against the f32 MFMA peak, two images checked against the batch-1
+plan, the oracle's convolution route on one host core beside it):
 
  1. STFT+mel (BASELINE configs[1], the line's `metric` / `value`): a "step" = one pass of SenseVoiceFrontend (PCM -> log-mel ->
     LFR) over `--batch` 30 s utterances per GPU (default 2048 = 17 hours of audio, 6.2 GB of PCM and features resident in
@@ -239,7 +242,13 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device):
     from sensevoice_graph import VOCAB, Encoder, encoder_arrays, encoder_onnx
 
     rec = {"topology": "ASSUMED (SURVEY.md 8a): 70 SAN-M layers, d=512, 4x128 heads, FFN 2048, FSMN k=11, int8 linears, CTC 25055; "
-                       "synthetic weights (8d)", "layers": args.layers}
+                       "synthetic weights (8d)", "layers": args.layers,
+           # parity bars of what runs here (tests/): everything quantised is bit-exact against the oracle; the fused attention kernel
+           # (split-bf16 products, v_exp_f32) is held to 2e-4 element-relative against the oracle's three-operator composition, and at
+           # full size to <= 1e-5 of the elements beyond that, none beyond 1e-2 of the rms (tests/test_attention.py,
+           # tests/test_fullsize_graph.py); LELE_HIP_ATTENTION_EXACT=1 selects the bit-exact replica of the three calls
+           "parity": {"quantised_linears": "bit-exact", "attention_bar": 2e-4, "attention_outliers_allowed": 1e-5,
+                      "attention_outlier_ceiling_of_rms": 1e-2, "other_f32": 1e-4}}
     fe, cmvn = SenseVoiceFrontend(ctx=ctx), Cmvn(ctx=ctx)
     enc = Encoder(ctx, args.layers)
     skip = np.zeros(VOCAB, np.uint8)          # blank + a block of <|...|> specials, as tokenizer.rs:38-48 marks them
@@ -409,6 +418,122 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device):
     return rec
 
 
+def yolo_conv_layers(plan, shapes):
+    """the 2-D convolutions of a compiled plan with their run-time shapes: (fn, x shape, w shape, dilations, group, pads, strides)"""
+    def ints(node):
+        return [int(v["int"]) for v in node.get("list", [])]
+    layers = []
+    for st in plan["statements"]:
+        if st.get("op") == "call" and st.get("fn") in ("conv2d", "conv2d_silu", "conv2d_fused") and "ref" in st["args"][0]:
+            a = st["args"]
+            layers.append((st["fn"], shapes[a[0]["ref"]], a[1]["weight"][3], ints(a[3]), int(a[4]["int"]), ints(a[5]), ints(a[6])))
+    return layers
+
+
+def cpu_baseline_yolo(layers):
+    """lele's Conv2d route on ONE host core for ONE image: the oracle's im2col + GEMM + bias / activation pass (oracle/conv_fast.cpp,
+    conv2d.rs:597-760; the product is the oracle's own AVX2-FMA kernel where lele calls faer) over every convolution of the network,
+    on random operands of the layers' shapes."""
+    from oracle import pyoracle as O
+    O.lib()
+    rng = np.random.default_rng(7)
+    t_all, macs = 0.0, 0
+    for fn, xs, ws, dil, group, pads, strides in layers:
+        x = rng.standard_normal([1] + list(xs[1:])).astype(np.float32)
+        w = rng.standard_normal(ws).astype(np.float32)
+        b = rng.standard_normal(ws[0]).astype(np.float32)
+        t0 = time.perf_counter()
+        y = O.conv2d_im2col(x, w, b, dil, group, pads, strides, "silu" if fn == "conv2d_silu" else None)
+        t_all += time.perf_counter() - t0
+        macs += y.size * ws[1] * ws[2] * ws[3]
+    return {"value": round(1.0 / t_all, 3), "unit": "images/s", "cores": 1, "kind": "port", "ms_per_image": round(1e3 * t_all, 1),
+            "gflops": round(2 * macs / t_all / 1e9, 2),
+            "sample": "the %d convolutions of ONE 640 x 640 image (%.2f GFLOP) in %.2f s: oracle/conv_fast.cpp (im2col + the oracle's own "
+                      "AVX2-FMA GEMM where lele calls faer + bias / SiLU pass), 1 thread" % (len(layers), 2 * macs / 1e9, t_all)}
+
+
+def yolo_leg(args, ctx, rank, world, fence, dist, device):
+    """BASELINE configs[4]: the Yolo26n-seg-SHAPED network of tools/yolo_graph.py (lele's generated file bakes N = 1 into its reshapes and
+    the ONNX it came from is not in the tree: same family, 100 convolutions, 9.74 GFLOP an image against the reference graph's 118 / 9.13;
+    synthetic weights), batch `--yolo-batch` per GPU, compiled by lele_amd.compiler, Concat / Split along C folded into channel views,
+    replayed as ONE hipGraph.  Protocol of examples/yolo26n-seg/src/benchmark.rs:29-56: 3 warm-up forwards, then 10 timed ones."""
+    from lele_amd.compiler import compile_model
+    from lele_amd.plan import Runner, fold_channel_views, load_weights_bin
+    from lele_amd.tensor import TensorView
+    from yolo_graph import yolo_onnx
+    nb, size = args.yolo_batch, 640
+    data, info = yolo_onnx(nb, size)
+    plan, blob = compile_model(data, "yolo26n_seg_shaped_n%d" % nb)
+    weights = load_weights_bin(plan, blob)
+    images = np.random.default_rng(1000 + rank).uniform(0, 1, (nb, 3, size, size)).astype(np.float32)   # SURVEY.md 8(d): uniform[0, 1)
+    feed = {"images": TensorView(ctx.buf().upload(images))}
+    r0 = Runner(plan, weights, ctx)
+    r0.shapes = {}
+    base = [o.numpy().copy() for o in r0.run(feed)]
+    rec = {"model": "Yolo26n-seg-SHAPED (tools/yolo_graph.py; the reference's generated graph bakes N = 1 into its reshapes), synthetic weights",
+           "batch_per_gpu": nb, "input": [nb, 3, size, size], **info, "plan_calls": r0.calls}
+    layers = yolo_conv_layers(plan, r0.shapes) if rank == 0 else None
+    runner, note = r0, None
+    try:
+        folded = fold_channel_views(plan, r0.shapes)
+        r1 = Runner(folded, weights, ctx)
+        got = [o.numpy() for o in r1.run(feed)]
+        if not all(np.array_equal(a, b) for a, b in zip(base, got)):
+            raise RuntimeError("the folded plan's outputs differ from the plan's")
+        for b_ in r0.ws.values():
+            b_.close()
+        runner = r1
+        rec.update({"channel_views": folded["folded"], "plan_calls": r1.calls, "folded_equals_unfolded_bitwise": True})
+    except Exception as e:  # noqa: BLE001  -- the leg is still measured, on the unfolded plan, and says so
+        note = "channel views NOT used: %s" % e
+        rec["channel_views"] = note
+    ctx.sync()
+    ctx.graph_begin()
+    outs = runner.run(feed)
+    graph = ctx.graph_end()
+    for _ in range(3):
+        graph.launch()
+    fence()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.yolo_runs):
+        graph.launch()
+    ev_ms = ctx.timer_stop() / args.yolo_runs
+    fence()
+    wall = max_over_ranks(time.perf_counter() - t0, dist, device)
+    ms = 1e3 * wall / args.yolo_runs
+    flop = info["gflop_per_image"] * 1e9 * nb
+    rec.update({"runs": args.yolo_runs, "warmup": 3, "ms_per_forward": round(ms, 3), "ms_per_forward_hip_events_rank0": round(ev_ms, 3),
+                "images_per_s": round(world * nb * args.yolo_runs / wall, 1), "tflops_f32_per_gpu": round(flop / (ev_ms * 1e-3) / 1e12, 2),
+                "roofline": {"bound": "mfma", "achieved": round(flop / (ev_ms * 1e-3) / 1e12, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(flop / (ev_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
+                             "note": "convolution + attention multiply-adds of the whole forward (%.3f GFLOP an image) over the graph's HIP-event time, "
+                                     "against the f32-input MFMA peak; the split-bf16 kernels (3 x 3 stride 1, some 1 x 1) run on the bf16 "
+                                     "matrix cores, whose six-term form peaks at 937 TFLOP/s of f32-equivalent work" % info["gflop_per_image"]},
+                "graph_equals_eager_bitwise": bool(all(np.array_equal(a, o.numpy()) for a, o in zip(base, outs))),
+                "finite": bool(all(np.isfinite(a).all() for a in base))})
+    if rank == 0:
+        # two images of the batch against the batch-1 plan of the same network (same seed -> same weights): the prototype map value for
+        # value, the detections' scores in order (two anchors whose scores differ in the last bits may swap places between tilings)
+        d1, _ = yolo_onnx(1, size)
+        p1, b1 = compile_model(d1, "yolo26n_seg_shaped_n1")
+        one = Runner(p1, load_weights_bin(p1, b1), ctx)
+        x1 = ctx.buf()
+        worst = 0.0
+
+        def bars(a, b):
+            den = 1e-4 * np.maximum(np.abs(a), float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))) + 1e-7
+            return float((np.abs(a - b) / den).max()) if a.size else 0.0
+        for i in (0, nb - 1):
+            o1 = [o.numpy() for o in one.run({"images": TensorView(x1.upload(images[i:i + 1]))})]
+            for a, b in zip(o1, base):
+                worst = max(worst, bars(a[..., 4], b[i:i + 1][..., 4]) if a.ndim == 3 else bars(a, b[i:i + 1]))
+        rec.update({"images_checked_against_the_batch_1_plan": 2, "max_error_in_units_of_1e-4": round(worst, 4), "per_image_check_ok": bool(worst <= 1.0)})
+        rec["_layers"] = layers
+    graph.close()
+    return rec
+
+
 def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -457,8 +582,11 @@ def run_rank(args):
     # half a millisecond each -- then run at settled clocks even when the caller asks for few steps (a cold 20-step run reads
     # 0.55-0.57 ms per step where the steady state is 0.48).
     sv = None
+    yo = None
     if not args.no_model:
         sv = sensevoice_leg(args, ctx, rank, world, fence, dist, device)
+    if not args.no_yolo:
+        yo = yolo_leg(args, ctx, rank, world, fence, dist, device)
     fe = frontend_leg(args, ctx, rank, world, fence, dist, device)
 
     if rank == 0:
@@ -524,7 +652,15 @@ def run_rank(args):
                              "model_achieved": q["hbm_gbs"], "model_peak": HBM_PEAK_GBS, "model_unit": "GB/s",
                              "model_frac": round(q["hbm_gbs"] / HBM_PEAK_GBS, 4), "model_tops": q["tops"],
                              "model_mfma_frac": round(q["tops"] / I8_PEAK_TOPS, 4)})
+        layers = None
+        if yo is not None:
+            layers = yo.pop("_layers", None)
+            line["yolo"] = yo
+            for k in ("ms_per_forward", "images_per_s"):
+                line["yolo_" + k] = yo[k]
         if world == 1 and not args.no_cpu_baseline:  # reported baseline: rank 0 at N=1 only
+            if layers:
+                line["yolo"]["cpu_baseline"] = cpu_baseline_yolo(layers)
             cb = cpu_baseline_frontend(n)
             if enc is not None and feats is not None:
                 from sensevoice_graph import encoder_arrays
@@ -606,7 +742,10 @@ def main():
     ap.add_argument("--per-gpu", type=int, default=32, help="recogniser leg: 10 s utterances per GPU per step (configs[3]: 256 / 8)")
     ap.add_argument("--sv-steps", type=int, default=10, help="recogniser leg: timed steady-state steps (lele's harness uses 10)")
     ap.add_argument("--layers", type=int, default=70)
-    ap.add_argument("--no-model", action="store_true", help="front-end leg only")
+    ap.add_argument("--no-model", action="store_true", help="skip the SenseVoice-shaped recogniser legs")
+    ap.add_argument("--no-yolo", action="store_true", help="skip the configs[4] leg")
+    ap.add_argument("--yolo-batch", type=int, default=64, help="configs[4]: 640 x 640 images per GPU per forward")
+    ap.add_argument("--yolo-runs", type=int, default=10, help="configs[4]: timed forwards after 3 warm-up ones (examples/yolo26n-seg/src/benchmark.rs:29-56)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--allow-fallback", action="store_true", help="N > 1: if the C ABI's RCCL communicator cannot be set up on every rank, gather the "
                     "ids with torch.distributed instead of failing (the line then names that transport)")
