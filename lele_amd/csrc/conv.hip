@@ -473,6 +473,50 @@ struct ConvTEpi {
         out[(((int64_t)b * oc + row) * oh + (py + sh * j)) * ow + (px + sw * i)] = v;
     }
 };
+// conv_transpose whose kernel equals its stride (no padding, no dilation): every output has exactly ONE tap, so the whole operator
+// is one GEMM [OC*kh*kw, C] x [C, ih*iw] per image whose row (oc, a, b) and column (y, x) land at out[oc][sh*y + a][sw*x + b]
+// (conv2d.rs:3060-3126 computes the same products and scatters them through col2im).  The k2 / s2 up-sampling of a segmentation
+// head's prototype branch is this case; as four per-phase GEMMs its stores were 4-byte writes at an 8-byte stride.
+struct ConvTKsEpi {
+    float* out;
+    const float* bias;
+    FastDiv d_iw, d_taps, d_kw;
+    int oc, oh, ow, kh, kw, iw, plane, taps;  // plane = ih * iw (GEMM columns), taps = kh * kw
+    __device__ __forceinline__ float load(int b, int row, int col) const { return bias ? bias[d_taps.div(row)] : 0.0f; }
+    __device__ __forceinline__ void store(int b, int row, int col, float acc, float pre) const {
+        if (row >= oc * taps || col >= plane) return;
+        const int o = d_taps.div(row), t = row - o * taps, a = d_kw.div(t), bb = t - a * kw;
+        const int y = d_iw.div(col), x = col - y * iw;
+        float v = acc;
+        if (bias) v = v + pre;
+        out[(((int64_t)b * oc + o) * oh + (kh * y + a)) * ow + (kw * x + bb)] = v;
+    }
+    // kernel 2 x 2: the four rows a lane holds for one column are the four outputs of one (oc, y, x): two 8-byte stores, adjacent
+    // lanes adjacent in memory
+    __device__ __forceinline__ bool quad_ok() const { return kh == 2 && kw == 2 && (((uintptr_t)out) & 7) == 0; }
+    __device__ __forceinline__ void store_quad(int b, int row0, int col, const float* acc, const float* pre) const {
+        if (row0 >= oc * 4 || col >= plane) return;
+        const int o = row0 >> 2;
+        const int y = d_iw.div(col), x = col - y * iw;
+        float* p = out + (((int64_t)b * oc + o) * oh + 2 * y) * ow + 2 * x;
+        float2 r0 = make_float2(acc[0], acc[1]), r1 = make_float2(acc[2], acc[3]);
+        if (bias) {
+            r0.x = r0.x + pre[0], r0.y = r0.y + pre[1];
+            r1.x = r1.x + pre[2], r1.y = r1.y + pre[3];
+        }
+        *reinterpret_cast<float2*>(p) = r0;
+        *reinterpret_cast<float2*>(p + ow) = r1;
+    }
+};
+// w [C][OC][kh][kw] -> [OC*kh*kw][C]
+__global__ void convt_wks_kernel(const float* __restrict__ w, float* __restrict__ wt, int c, int oc, int taps) {
+    const int64_t total = (int64_t)c * oc * taps;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % c);
+        const int64_t row = i / c;  // (o, tap)
+        wt[i] = w[(int64_t)ci * oc * taps + row];
+    }
+}
 __global__ void convt_wphase_kernel(const float* __restrict__ w, float* __restrict__ wt, int c, int oc, int kh, int kw,
                                     int a0, int sa, int na, int b0, int sb, int nb, int tap_major) {
     const int ntap = na * nb;
@@ -1351,6 +1395,40 @@ int lele_hip_conv_transpose(LeleCtx* ctx, const LeleTensor* x, const LeleTensor*
     if (lab_env("LELE_HIP_CONVT_GATHER")) {  // reference gather kernel, kept for A/B checks
         hipLaunchKernelGGL(conv_transpose_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx,
                            (const float*)dwp, (const float*)db, (float*)out->data, g);
+        LELE_HIP_CHECK(hipGetLastError());
+        return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, oh, ow});
+    }
+    if (g.kh == g.sh && g.kw == g.sw && g.dh == 1 && g.dw == 1 && g.pt == 0 && g.pl == 0 && pb == 0 && pr == 0 &&
+        (int64_t)g.oc * g.kh * g.kw < (int64_t(1) << 31) && !lab_env("LELE_HIP_CONVT_PHASES")) {
+        // kernel == stride: one GEMM with a scattering epilogue (see ConvTKsEpi)
+        const int taps = g.kh * g.kw, mrows = g.oc * taps, plane_in = g.ih * g.iw;
+        const size_t wb = (size_t)g.c * mrows * 4;
+        void* dwk = nullptr;
+        const bool cache_k = w->mem == LELE_MEM_WEIGHT;
+        auto kkey = std::make_tuple((const void*)w->data, wb, 450);
+        auto kit = cache_k ? ctx->weights.find(kkey) : ctx->weights.end();
+        if (kit != ctx->weights.end()) {
+            dwk = kit->second;
+        } else {
+            if (cache_k) {
+                LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
+                LELE_HIP_CHECK(hipMalloc(&dwk, std::max<size_t>(wb, 16)));
+                ctx->weights[kkey] = dwk;
+            } else {
+                LELE_TRY(ctx->arena_alloc(std::max<size_t>(wb, 16), &dwk));
+            }
+            hipLaunchKernelGGL(convt_wks_kernel, dim3(grid_for((int64_t)g.c * mrows)), dim3(256), 0, ctx->stream, (const float*)dwp, (float*)dwk,
+                               g.c, g.oc, taps);
+        }
+        ConvGeom q{};
+        q.group = 1;
+        q.ocg = mrows;
+        q.K = g.c;
+        ConvWLoad al{(const float*)dwk, q, (int)(g.c % 4 == 0)};
+        gemm::LoadKRow bl{(const float*)dx, (int64_t)g.c * plane_in, (int64_t)plane_in, plane_in, g.c};
+        ConvTKsEpi epi{(float*)out->data, (const float*)db, make_fastdiv(g.iw, plane_in), make_fastdiv(taps, mrows), make_fastdiv(g.kw, taps),
+                       g.oc, g.oh, g.ow, g.kh, g.kw, g.iw, plane_in, taps};
+        gemm::launch(ctx->stream, al, bl, epi, mrows, plane_in, g.c, g.n, ctx->num_cus);
         LELE_HIP_CHECK(hipGetLastError());
         return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, oh, ow});
     }

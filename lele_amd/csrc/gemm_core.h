@@ -172,6 +172,12 @@ struct has_blockstat<E, std::void_t<decltype(std::declval<E>().blockstat)>> : st
 // tiled kernel then turns every 32 x 32 accumulator tile through LDS and stores 16 bytes per lane instead of 4 (a lane owns a
 // COLUMN of the tile; stored as they sit, a tile is 16 four-byte store instructions per lane and the tail of a workgroup is
 // store-issue bound)
+// epilogues that take the FOUR consecutive rows a lane holds for one column in one call (`store_quad`, `quad_ok`): a transposed
+// convolution with kernel = stride = 2 turns them into two 8-byte stores of horizontally adjacent outputs (conv.hip, ConvTKsEpi)
+template <class E, class = void>
+struct has_quad_store : std::false_type {};
+template <class E>
+struct has_quad_store<E, std::void_t<decltype(std::declval<E>().quad_ok())>> : std::true_type {};
 template <class E, class = void>
 struct has_vec_store : std::false_type {};
 template <class E>
@@ -378,6 +384,16 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 pre[r] = epi.load(batch, row < M ? row : M - 1, colc);
             }
+            if constexpr (has_quad_store<EPI>::value) {
+                if (epi.quad_ok()) {  // uniform
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float a4[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        epi.store_quad(batch, rbase + 8 * q, col, a4, pre + 4 * q);
+                    }
+                    continue;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) epi.store(batch, rbase + (r & 3) + 8 * (r >> 2), col, acc[i][j][r], pre[r]);
         }
@@ -435,10 +451,19 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(AL al, BL bl, EPI e
         pre[q] = epi.load(batch, orow < M ? orow : M - 1, colc);
         tot[q] = (red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane]);
     }
+    bool quad_done = false;
+    if constexpr (has_quad_store<EPI>::value) {
+        if (epi.quad_ok()) {  // uniform: rows m0 + 8 wave + 4 hv + [0, 4) of column col
+            epi.store_quad(batch, m0 + 8 * wave + 4 * hv, col, tot, pre);
+            quad_done = true;
+        }
+    }
+    if (!quad_done) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int r = 4 * wave + q;
-        epi.store(batch, m0 + (r & 3) + 8 * (r >> 2) + 4 * hv, col, tot[q], pre[q]);
+        for (int q = 0; q < 4; ++q) {
+            const int r = 4 * wave + q;
+            epi.store(batch, m0 + (r & 3) + 8 * (r >> 2) + 4 * hv, col, tot[q], pre[q]);
+        }
     }
     if constexpr (has_blockstat<EPI>::value) {
         if (epi.blockstat) {  // uniform

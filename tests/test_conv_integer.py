@@ -7,6 +7,15 @@ from oracle import npref
 from oracle import pyoracle as O
 
 
+
+def _close(got, want, tol=1e-4):
+    """element by element: |got - want| <= tol * |want| + tol * rms(want) (the form of tests/test_conv_rnn.py::_close)"""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape
+    floor = tol * float(np.sqrt(np.mean(np.square(want)))) + 1e-7
+    bad = np.abs(got - want) > tol * np.abs(want) + floor
+    assert not bad.any(), "%d of %d elements outside %g (max abs diff %.3e)" % (int(bad.sum()), want.size, tol, float(np.abs(got - want).max()))
+
 def _u8(rng, shape):
     return rng.integers(0, 256, shape).astype(np.float32)
 
@@ -43,7 +52,7 @@ def test_device_conv_integer_family(ctx):
             got = K.conv_integer(x, Weight(w), zx, zw, [1, 1], g, [p, p, p, p], [st, st], ctx=ctx).numpy()
             want = O.conv2d(x - np.float32(xz or 0), w - np.float32(wz or 0), None, [1, 1], g, [p, p, p, p], [st, st])
             assert got.shape == want.shape
-            assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+            _close(got, want)
     # from_f32: dynamic quantisation of the activations inside the op
     xf = (rng.standard_normal((2, 8, 10, 10)) * 3).astype(np.float32)
     w = _u8(rng, (12, 8, 3, 3))
@@ -52,7 +61,7 @@ def test_device_conv_integer_family(ctx):
     s, z = npref.dql_params([xf])
     assert sc.numpy()[0] == s
     want = O.conv2d(npref.dql_quantize(xf, s, z) - z, w - np.float32(128), None, [1, 1], 1, [1, 1, 1, 1], [1, 1])
-    assert np.abs(out.numpy() - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    _close(out.numpy(), want)
     # multi: joint range over the sources, channel concatenation, 1x1
     a = (rng.standard_normal((1, 5, 7, 7)) * 2).astype(np.float32)
     b = (rng.standard_normal((1, 3, 7, 7)) * 6 + 1).astype(np.float32)
@@ -62,7 +71,7 @@ def test_device_conv_integer_family(ctx):
     assert sc.numpy()[0] == s
     q = np.concatenate([npref.dql_quantize(a, s, z), npref.dql_quantize(b, s, z)], 1)
     want = O.conv2d(q - z, w1 - np.float32(128), None, [1, 1], 1, [0, 0, 0, 0], [1, 1])
-    assert np.abs(out.numpy() - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    _close(out.numpy(), want)
     # fused_scale_bias(_silu): host float scale, and the device scale of conv_integer_from_f32 times a weight scale
     bias = rng.standard_normal(4).astype(np.float32)
     got = K.fused_scale_bias(out, sc, bias, scale_mul=0.02, ctx=ctx).numpy()

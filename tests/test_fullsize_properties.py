@@ -44,6 +44,7 @@ def test_matmul_4096_identity_and_power_of_two_scaling(ctx):
 
 def test_conv2d_c5_shapes_batch_independent_and_scale_exact(ctx):
     from lele_amd import kernels as K
+    from parity import close_f32
     rng = np.random.default_rng(1)
     # (N, C, H, OC, k, stride): Yolo26n-seg stem and one 3x3 body convolution at batch 64 (BASELINE configs[4])
     for n, c, h, oc, k, st in ((64, 3, 640, 16, 3, 2), (64, 64, 160, 64, 3, 1)):
@@ -60,7 +61,7 @@ def test_conv2d_c5_shapes_batch_independent_and_scale_exact(ctx):
         assert np.array_equal(half, full[n // 2:])
         for i in (0, n - 1):
             one = K.conv2d(x[i:i + 1], w, b, [1, 1], 1, [p, p, p, p], [st, st], ctx=ctx).numpy()
-            assert np.abs(one[0] - full[i]).max() <= 1e-4 * max(1.0, np.abs(full[i]).max())
+            close_f32(one[0], full[i], 1e-4, "one image against its place in the batch")
         # exact scaling (no bias, no activation): conv(2x) == 2 conv(x)
         y1 = K.conv2d(x[:2], w, None, [1, 1], 1, [p, p, p, p], [st, st], ctx=ctx).numpy()
         y2 = K.conv2d(x[:2] * np.float32(2.0), w, None, [1, 1], 1, [p, p, p, p], [st, st], ctx=ctx).numpy()
@@ -71,6 +72,38 @@ def test_conv2d_c5_shapes_batch_independent_and_scale_exact(ctx):
             win = x[i, :, yy * st - p:yy * st - p + k, xx * st - p:xx * st - p + k].astype(np.float64)
             ref = (win * w[o].astype(np.float64)).sum() + b[o]
             assert abs(full[i, o, yy, xx] - ref) <= 1e-4 * max(1.0, abs(ref))
+
+
+def test_c5_heaviest_layers_against_the_oracle_at_full_size(ctx):
+    """BASELINE configs[4] at its true sizes: the five heaviest layer shapes of Yolo26n-seg (64 -> 64 3 x 3 at 160 x 160,
+    the 3 -> 16 stride-2 stem at 640 x 640, 128 -> 128 1 x 1 at 80 x 80, 256 -> 256 3 x 3 at 20 x 20, the 64 -> 64 k2 / s2 transposed
+    convolution at 80 x 80) issued as ONE batch-64 call each; the first and the last image of the result against the oracle (lele's
+    im2col + GEMM route with bias and SiLU, oracle/conv_fast.cpp; the transposed convolution against the float64 loop) at the 1e-4
+    bar -- the kernels a batch picks (window-once split-bf16, direct, tiled 16-byte-store GEMM, the one-GEMM transposed form) are
+    not the ones a single image picks."""
+    from lele_amd import kernels as K
+    from oracle import pyoracle as O
+    from parity import close_f32
+    rng = np.random.default_rng(5)
+    n = 64
+    for (c, h, oc, k, st, act) in ((64, 160, 64, 3, 1, "silu"), (3, 640, 16, 3, 2, "silu"), (128, 80, 128, 1, 1, "silu"), (256, 20, 256, 3, 1, "silu"),
+                                   (16, 320, 32, 3, 2, "silu"), (64, 80, 64, 3, 2, None), (48, 160, 64, 1, 1, "silu")):
+        x = rng.standard_normal((n, c, h, h)).astype(np.float32)
+        w = (rng.standard_normal((oc, c, k, k)) * np.sqrt(2.0 / (c * k * k))).astype(np.float32)
+        b = (rng.standard_normal(oc) * 0.1).astype(np.float32)
+        p = k // 2
+        fn = K.conv2d_silu if act else K.conv2d
+        got = fn(ctx.buf().upload(x), w, b, [1, 1], 1, [p] * 4, [st, st], ctx=ctx).numpy()
+        for i in (0, n - 1):
+            want = O.conv2d_im2col(x[i:i + 1], w, b, [1, 1], 1, [p] * 4, [st, st], act)
+            close_f32(got[i:i + 1], want, 1e-4, "conv %d -> %d k%d s%d at %d, image %d of %d" % (c, oc, k, st, h, i, n))
+    x = rng.standard_normal((n, 64, 80, 80)).astype(np.float32)
+    w = (rng.standard_normal((64, 64, 2, 2)) * np.sqrt(1.0 / 64)).astype(np.float32)
+    b = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    got = K.conv_transpose(ctx.buf().upload(x), w, b, [1, 1], 1, [0, 0, 0, 0], [2, 2], ctx=ctx).numpy()
+    assert got.shape == (n, 64, 160, 160)
+    for i in (0, n - 1):
+        close_f32(got[i:i + 1], O.conv_transpose(x[i:i + 1], w, b, [1, 1], 1, [0, 0, 0, 0], [2, 2]), 1e-4, "conv_transpose k2 s2, image %d" % i)
 
 
 def test_quantized_linear_c4_shape_slices_are_independent(ctx):

@@ -15,13 +15,8 @@ SEED = int(os.environ.get("LELE_FUZZ_SEED", "0"))
 
 
 def _close(got, want, what):
-    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
-    assert got.shape == want.shape, (what, got.shape, want.shape)
-    if want.size == 0:
-        return
-    scale = max(1.0, float(np.abs(want).max()))
-    err = float(np.abs(got - want).max())
-    assert err <= RTOL * scale, "%s: max abs err %.3e (scale %.3e)" % (what, err, scale)
+    from parity import close_f32
+    close_f32(got, want, RTOL, what)
 
 
 def test_fuzz_matmul_gemm(ctx):

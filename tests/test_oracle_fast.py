@@ -56,3 +56,23 @@ def test_sgemm_kordered_fast_equals_plain(plain_flag, m, k, n):
     assert np.array_equal(fast, plain)
     ref = O.matmul(a, b)  # f64-accumulated
     assert np.allclose(fast, ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("geom", [(2, 16, 20, 24, 24, 3, 1, 1, [1, 1, 1, 1]), (1, 8, 17, 19, 12, 3, 2, 1, [1, 1, 1, 1]), (2, 12, 9, 9, 8, 1, 1, 1, [0, 0, 0, 0]),
+                                  (1, 8, 16, 16, 8, 3, 1, 8, [1, 1, 1, 1]), (1, 12, 15, 15, 6, 3, 1, 2, [1, 2, 0, 1]), (1, 4, 12, 12, 6, 3, 1, 1, [0, 0, 2, 2]),
+                                  (1, 6, 11, 13, 5, 5, 2, 1, [2, 2, 2, 2]), (1, 3, 33, 31, 16, 3, 2, 1, [1, 1, 1, 1])])
+def test_conv2d_im2col_route_equals_the_float64_loop(geom):
+    """oracle/conv_fast.cpp (lele's im2col + GEMM + bias / activation route, conv2d.rs:597-760, 892-1046) against orc_conv2d's
+    float64-accumulated direct loop: f32 round-off apart, including a bias of exactly 0.0 (whose pass the reference skips) and
+    every activation"""
+    from parity import close_f32
+    n, c, h, w_, oc, k, s, g, pads = geom
+    rng = np.random.default_rng(sum(geom[:8]))
+    x = rng.standard_normal((n, c, h, w_)).astype(np.float32)
+    w = rng.standard_normal((oc, c // g, k, k)).astype(np.float32)
+    b = rng.standard_normal(oc).astype(np.float32)
+    b[0] = 0.0
+    for act in (None, "relu", "silu"):
+        for bias in (b, None):
+            close_f32(O.conv2d_im2col(x, w, bias, [1, 1], g, pads, [s, s], act), O.conv2d(x, w, bias, [1, 1], g, pads, [s, s], act), 2e-6, str(geom))
+    close_f32(O.conv2d_im2col(x, w, b, [2, 1], g, pads, [s, s], None), O.conv2d(x, w, b, [2, 1], g, pads, [s, s], None), 2e-6, "dilated " + str(geom))
