@@ -404,6 +404,7 @@ class Runner:
         self.extra = {}
         self.calls = 0
         self.profile = None
+        self.stmt_times = None   # set to []: (statement index, fn, first result, device ms) of every kernel statement of the next run
         self.stmt_index = 0
         self.shapes = None  # set to {} to record the shape of every tensor value of the next run
         self.taps = None    # set to {name: None, ...}: host copies of those results are left there by the next run (tests)
@@ -570,6 +571,8 @@ class Runner:
                 f = getattr(K, fn)
                 self.calls += 1
                 try:
+                    if self.stmt_times is not None:   # per-statement device time: HIP events on the ctx stream (lele_hip_timer_*)
+                        ctx.timer_start()
                     t0 = time.perf_counter() if self.profile is not None else 0.0
                     if "window" in st:   # the result is a channel window of an already reserved tensor (fold_channel_views)
                         whole = env[st["window"]["of"]]
@@ -578,6 +581,8 @@ class Runner:
                         res = f(*pos, out=d.buf, out_window=(d.offset + st["window"]["c0"] * inner, d.pitch or d.shape[1] * inner), ctx=ctx)
                     else:
                         res = self.call(f, fn, pos, bufs, key=st["out"][0] + str(self.stmt_index), may_alias=bool(st.get("may_alias")))
+                    if self.stmt_times is not None:
+                        self.stmt_times.append((self.stmt_index, fn, st["out"][0], ctx.timer_stop()))
                     if self.profile is not None:
                         ctx.sync()
                         self.profile[fn] = self.profile.get(fn, 0.0) + time.perf_counter() - t0

@@ -211,6 +211,9 @@ def main():
     ap.add_argument("--runs", type=int, default=10)
     ap.add_argument("--check", type=int, default=-1, help="images of the batch compared with the batch-1 plan (default: all)")
     ap.add_argument("--compile-only", action="store_true")
+    ap.add_argument("--no-fold", action="store_true", help="keep Concat / Split along C as copy kernels (default: channel views, plan.fold_channel_views)")
+    ap.add_argument("--no-batch1", action="store_true", help="skip the batch-1 plan (check and timing): a clean kernel trace of the batch-N graph")
+    ap.add_argument("--table", default=None, help="write a per-statement table (device ms by HIP events, GFLOP, MB, the statement's own bound) here")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     from lele_amd.compiler import compile_model
@@ -233,15 +236,70 @@ def main():
     big = Runner(plan, load_weights(plan, blob), ctx)
     xb = ctx.buf().upload(images)
     feed = {"images": TensorView(xb)}
+    big.shapes = {}
     outs = [o.numpy().copy() for o in big.run(feed)]
     rec["finite"] = bool(all(np.isfinite(o).all() for o in outs))
     rec["outputs"] = [list(o.shape) for o in outs]
+    shapes = big.shapes
+    if not args.no_fold:   # Concat / Split along C as views of one buffer: the same bits, fewer kernels
+        from lele_amd.plan import fold_channel_views
+        folded = fold_channel_views(plan, shapes)
+        fr = Runner(folded, load_weights(folded, blob), ctx)
+        same = all(np.array_equal(a, o.numpy()) for a, o in zip(outs, fr.run(feed)))
+        rec.update({"channel_views": folded["folded"], "folded_equals_unfolded_bitwise": bool(same), "kernel_calls_folded": fr.calls})
+        if same:
+            for b_ in big.ws.values():
+                b_.close()
+            big = fr
+    if args.table:
+        big.stmt_times = []
+        big.run(feed)
+        big.stmt_times = []
+        big.run(feed)
+        rows = []
+        byname = {}
+        for st in big.plan["statements"]:
+            for o in st.get("out", []):
+                byname[o] = st
+        for idx, fn, o, ms in big.stmt_times:
+            st = byname[o]
+            osh = shapes.get(o, [])
+            nbytes = 4 * int(np.prod(osh)) if osh else 0
+            gflop = 0.0
+            geo = ""
+            for a in st.get("args", []):
+                if isinstance(a, dict) and "ref" in a and a["ref"] in shapes:
+                    nbytes += 4 * int(np.prod(shapes[a["ref"]]))
+                elif isinstance(a, dict) and "list" in a:
+                    nbytes += sum(4 * int(np.prod(shapes[v["ref"]])) for v in a["list"] if isinstance(v, dict) and v.get("ref") in shapes)
+            if fn.startswith("conv") and len(osh) == 4:
+                w = st["args"][1]["weight"][3]
+                xs = shapes[st["args"][0]["ref"]]
+                if fn == "conv_transpose":
+                    gflop = 2.0 * xs[0] * xs[2] * xs[3] * w[0] * w[1] * w[2] * w[3] / 1e9
+                else:
+                    gflop = 2.0 * int(np.prod(osh)) * w[1] * w[2] * w[3] / 1e9
+                geo = "%d->%d k%d s%s g%s @%dx%d" % (xs[1], osh[1], w[2], st["args"][6]["list"][0]["int"] if len(st["args"]) > 6 and st["args"][6].get("list") else "?",
+                                                  st["args"][4].get("int", "?") if len(st["args"]) > 4 else "?", osh[2], osh[3])
+            t_mfma, t_hbm = gflop / 157.3, nbytes / 6.0e9   # ms at the f32 MFMA peak (157.3 GFLOP per ms) / at 6 TB/s
+            rows.append({"stmt": idx, "fn": fn, "out": o, "shape": osh, "geometry": geo, "ms": round(ms, 4), "gflop": round(gflop, 3), "mbytes": round(nbytes / 1e6, 2),
+                         "bound_ms": round(max(t_mfma, t_hbm), 4), "bound": "mfma" if t_mfma > t_hbm else "hbm", "frac": round(max(t_mfma, t_hbm) / ms, 3) if ms > 0 else None})
+        rows.sort(key=lambda r: -r["ms"])
+        tot = sum(r["ms"] for r in rows)
+        os.makedirs(os.path.dirname(os.path.abspath(args.table)), exist_ok=True)
+        json.dump({"total_ms_eager_events": round(tot, 3), "sum_of_bounds_ms": round(sum(r["bound_ms"] for r in rows), 3), "rows": rows}, open(args.table, "w"), indent=0)
+        for r in rows[:40]:
+            print("%7.3f ms  %-16s %-28s %8.2f GFLOP %8.1f MB  bound %-4s %6.3f ms  frac %s" % (r["ms"], r["fn"], r["geometry"] or str(r["shape"]), r["gflop"], r["mbytes"],
+                                                                                             r["bound"], r["bound_ms"], r["frac"]), file=sys.stderr)
+        print("eager total %.3f ms, sum of bounds %.3f ms" % (tot, sum(r["bound_ms"] for r in rows)), file=sys.stderr)
     # the batch-1 plan of the same network (same seed -> same weights), image by image
     d1, _ = yolo_onnx(1, args.size)
     p1, b1 = compile_model(d1, "yolo26n_seg_shaped_n1")
     one = Runner(p1, load_weights(p1, b1), ctx)
     x1 = ctx.buf()
     ncheck = args.batch if args.check < 0 else min(args.check, args.batch)
+    if args.no_batch1:
+        ncheck = 0
     # the prototype map is a convolution stack: value for value.  The detections pass through two top-k selections: the scores of
     # the 300 selected anchors are compared in order, the rows only where both forwards selected the same anchor (two anchors
     # whose scores differ in the last bits may swap places between the two kernels' summation orders)
@@ -281,19 +339,20 @@ def main():
     rec.update({"graph_ms_per_forward": round(ms, 3), "images_per_s": round(args.batch / ms * 1e3, 1), "tflops_f32": round(flop / ms / 1e9, 2),
                 "f32_mfma_peak_tflops": 157.3, "fraction_of_the_f32_mfma_peak": round(flop / ms / 1e9 / 157.3, 3),
                 "floor_ms_at_the_f32_mfma_peak": round(flop / 157.3e12 * 1e3, 3)})
-    feed1 = {"images": TensorView(x1.upload(images[:1]))}
-    ctx.sync()
-    ctx.graph_begin()
-    one.run(feed1)
-    g1 = ctx.graph_end()
-    g1.launch()
-    ctx.sync()
-    ctx.timer_start()
-    for _ in range(args.runs):
+    if not args.no_batch1:
+        feed1 = {"images": TensorView(x1.upload(images[:1]))}
+        ctx.sync()
+        ctx.graph_begin()
+        one.run(feed1)
+        g1 = ctx.graph_end()
         g1.launch()
-    ms1 = ctx.timer_stop() / args.runs
-    g1.close()
-    rec.update({"batch_1_graph_ms_per_forward": round(ms1, 3), "batch_1_images_per_s": round(1e3 / ms1, 1)})
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(args.runs):
+            g1.launch()
+        ms1 = ctx.timer_stop() / args.runs
+        g1.close()
+        rec.update({"batch_1_graph_ms_per_forward": round(ms1, 3), "batch_1_images_per_s": round(1e3 / ms1, 1)})
     print(json.dumps(rec))
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
