@@ -180,19 +180,28 @@ struct ConvEpi {
     __device__ __forceinline__ float load(int b, int row, int col) const {  // clamped coordinates, unconditional
         return bias ? bias[(b % g.group) * g.ocg + row] : 0.0f;
     }
+    // the activation of one value: the SiLU's scalar-tail form (libm exp, a division) only when some active lane sits in the last
+    // 0-7 positions of its plane -- evaluated per lane behind a select, both forms ran for every element of every tile
+    __device__ __forceinline__ float activate(float v, int col) const {
+        if (act == LELE_ACT_NONE) return v;
+        if (act == LELE_ACT_RELU) return v > 0.0f ? v : 0.0f;
+        const bool body = col < (g.plane & ~7);
+        if (__builtin_amdgcn_ballot_w64(!body) == 0) return apply_act(v, LELE_ACT_SILU, true);
+        return apply_act(v, LELE_ACT_SILU, body);
+    }
     __device__ __forceinline__ void store(int b, int row, int col, float acc, float pre) const {
         if (row >= g.ocg || col >= g.plane) return;
         const int img = b / g.group, o = (b % g.group) * g.ocg + row;
         float v = acc;
         if (bias) v = v + pre;
-        out[(int64_t)img * g.obs + (int64_t)o * g.plane + col] = apply_act(v, act, col < (g.plane & ~7));
+        out[(int64_t)img * g.obs + (int64_t)o * g.plane + col] = activate(v, col);
     }
     // the 16-byte store protocol of gemm_core.h: finished values, a row's address, and when rows may be written four columns at a time
     __device__ __forceinline__ bool vec_ok() const { return (g.plane & 3) == 0 && (g.obs & 3) == 0 && (((uintptr_t)out) & 15) == 0; }
     __device__ __forceinline__ float finish(int b, int row, int col, float acc, float pre) const {  // clamped coordinates
         float v = acc;
         if (bias) v = v + pre;
-        return apply_act(v, act, col < (g.plane & ~7));
+        return activate(v, col);
     }
     __device__ __forceinline__ float* row_ptr(int b, int row) const {
         const int img = b / g.group, o = (b % g.group) * g.ocg + row;
@@ -632,6 +641,83 @@ struct C3M {  // KS = 3 (3 x 3, padding in the geometry) or 1 (1 x 1: the "windo
 
 __device__ __forceinline__ unsigned c3m_pair(float even, float odd) { return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u); }
 
+// Epilogue of the window-once kernels: a consumer wave holds NJ accumulator tiles (32 output channels x 32 columns of NJ tile rows).
+// C layout: column = lane & 31 = the position inside the row, rows (r & 3) + 8 (r >> 2) + 4 hv = output channels.  Stored as they
+// sit, a lane would issue 16 NJ four-byte stores and the tile's tail is store-ISSUE bound (measured: 730 of 1370 us on 64 -> 64
+// channels at 160 x 160 x 64): every wave is past the last barrier, so the stage is free and the wave's tile takes a turn through
+// LDS and leaves as 16-byte pieces of 128-byte output rows.  The 16 bias values a lane needs are fetched ONCE, together, before
+// anything else, and the activation is chosen once per wave: written per element (a load behind `if (bias)` and a switch on the
+// activation for each of the 16 NJ values) the compiler emitted 64 load -> wait -> polynomial chains one after the other, ~19 k
+// cycles of a tile whose products take 28 k.
+template <int NJ, int OCT, int TH>
+__device__ __forceinline__ void c3m_epilogue(const cf32x16 (&acc)[NJ], const ConvEpi& epi, const ConvGeom& g, char* lds, int wave, int lane,
+                                             int wm, int wn, int ocb, int img, int tyi, int txi) {
+    const int hv = lane >> 5, l31 = lane & 31;
+    const int ocw = ocb * OCT + wm * 32;  // first output channel of this wave's tile
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bv[r] = 0.0f;
+    if (epi.bias) {  // uniform
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = ocw + (r & 3) + 8 * (r >> 2) + 4 * hv;
+            bv[r] = epi.bias[o < g.oc ? o : g.oc - 1];
+        }
+    }
+    const int ox = txi * C3M_TW + l31;
+    if (g.ow % 4 == 0 && epi.vec_ok()) {  // 16-byte stores need the rows AND the destination (a view may start anywhere) aligned
+        constexpr int OCP = NJ * 32 + 8;  // floats per output channel: the two half waves (4 channels apart) land on different banks
+        float* mine = reinterpret_cast<float*>(lds) + wave * (32 * OCP);
+        bool body[NJ], every = true;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int oy = tyi * TH + NJ * wn + j;
+            const int col = (oy < g.oh ? oy : g.oh - 1) * g.ow + (ox < g.ow ? ox : g.ow - 1);
+            body[j] = col < (g.plane & ~7);
+            every = every && body[j];
+        }
+        // the activation's scalar-tail form (libm) only where some lane is in the last 0-7 positions of the plane
+        const bool all_body = __builtin_amdgcn_ballot_w64(!every) == 0;
+        auto put = [&](auto fn) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ol = (r & 3) + 8 * (r >> 2) + 4 * hv;
+                    float v = acc[j][r];
+                    if (epi.bias) v = v + bv[r];
+                    mine[ol * OCP + j * 32 + l31] = fn(v, body[j]);
+                }
+        };
+        if (epi.act == LELE_ACT_NONE) put([](float v, bool) { return v; });
+        else if (epi.act == LELE_ACT_RELU) put([](float v, bool) { return v > 0.0f ? v : 0.0f; });
+        else if (all_body) put([](float v, bool) { return apply_act(v, LELE_ACT_SILU, true); });
+        else put([](float v, bool b) { return apply_act(v, LELE_ACT_SILU, b); });
+        const int q4 = lane & 7;
+        const int oxq = txi * C3M_TW + 4 * q4;
+#pragma unroll
+        for (int it = 0; it < 4 * NJ; ++it) {
+            const int rowid = it * 8 + (lane >> 3), ol = rowid / NJ, j = rowid % NJ;
+            const int oy = tyi * TH + NJ * wn + j, oc = ocw + ol;
+            const float4 v = *reinterpret_cast<const float4*>(mine + ol * OCP + j * 32 + 4 * q4);
+            if (oy < g.oh && oxq < g.ow && oc < g.oc)
+                *reinterpret_cast<float4*>(epi.out + (int64_t)img * g.obs + (int64_t)oc * g.plane + oy * g.ow + oxq) = v;
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int oy = tyi * TH + NJ * wn + j;
+        if (oy >= g.oh || ox >= g.ow) continue;
+        const int col = oy * g.ow + ox;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oc = ocw + (r & 3) + 8 * (r >> 2) + 4 * hv;
+            if (oc < g.oc) epi.store(img, oc, col, acc[j][r], bv[r]);
+        }
+    }
+}
+
 // OCT = output channels per workgroup: 64 (two 32-channel tiles x two groups of four tile rows) or 32 (one tile x four groups of
 // two rows): narrow layers do not pay for a half-empty block
 template <int KS, int OCT>
@@ -774,54 +860,161 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         if (cc < nchunk) chunk(cc, std::integral_constant<int, 0>());
     }
-    // C layout: column = lane & 31 = the position inside the row, rows (r & 3) + 8 (r >> 2) + 4 hv = output channels.  Stored as
-    // they sit, a lane would issue 64 four-byte stores and the tile's tail is store-ISSUE bound (measured: 730 of 1370 us on
-    // 64 -> 64 channels at 160 x 160 x 64).  Every wave of the workgroup is past the last barrier, so the stages are free: the
-    // wave's 32 channels x 4 rows x 32 columns take a turn through LDS and leave as 16-byte pieces of 128-byte output rows.
-    const int ox = txi * C3M_TW + l31;
-    if (g.ow % 4 == 0 && epi.vec_ok()) {  // 16-byte stores need the rows AND the destination (a view may start anywhere) aligned
-        constexpr int OCP = NJ * 32 + 8;  // floats per output channel: the two half waves (4 channels apart) land on different banks
-        float* mine = reinterpret_cast<float*>(c3m_lds) + wave * (32 * OCP);
-        static_assert(4 * 32 * OCP * 4 <= W::LDS, "the epilogue tiles fit the stages");
+    static_assert(4 * 32 * (NJ * 32 + 8) * 4 <= W::LDS, "the epilogue tiles fit the stages");
+    c3m_epilogue<NJ, OCT, C3M_TH>(acc, epi, g, c3m_lds, wave, lane, wm, wn, ocb, img, tyi, txi);
+}
+// ---- the same for STRIDE 2 (3 x 3): a workgroup owns 64 output channels x (4 rows x 32 columns) of one image.  The window of a
+// stride-2 tile is 9 x 65 input positions; stored as it lies, tap (a, b) of output column l would read position 2 l + b -- a
+// 224-byte lane stride, two lanes per bank.  The producers therefore store the window DE-INTERLEAVED into its four phases
+// (row parity, column parity): position (py, px) goes to plane 2 (py & 1) + (px & 1), slot (py >> 1, px >> 1), and tap (a, b) of
+// output (j, l) reads plane 2 (a & 1) + (b & 1) at slot (j + (a >> 1), l + (b >> 1)) -- consecutive lanes, consecutive slots, the
+// conflict-free 112-byte pitch of the stride-1 kernel.  660 slots x 112 bytes = 74 KB: ONE stage per workgroup and two workgroups
+// per CU (the stride-1 kernel's measurement: occupancy, not a second stage, is what hides a workgroup's staging and epilogue) --
+// the producers keep the next chunk in registers, park it when the consumers are done with the stage, and the other workgroup of
+// the CU multiplies meanwhile.  Same weight fragments, same six-term products, same epilogue as conv_window_kernel<3, 64>.
+struct C3S2 {
+    static constexpr int TH = 4, TW = 32, PH = 2 * (TH - 1) + 3, PW = 2 * (TW - 1) + 3;   // 9 x 65 input positions
+    static constexpr int SY = (PH + 1) / 2, SX = (PW + 1) / 2, PLANE = SY * SX, POS = 4 * PLANE;   // 5 x 33 slots per phase plane
+    static constexpr int STAGE = POS * C3M_PITCH;
+    static constexpr int EPI = 4 * 32 * (2 * 32 + 8) * 4;
+    static constexpr int LDS = STAGE > EPI ? STAGE : EPI;
+    static constexpr int TASKS = (POS * 4 + 255) / 256;
+};
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_window_s2_kernel(const float* __restrict__ x,
+                                                                                                    const cu32x4* __restrict__ wfrag,
+                                                                                                    ConvEpi epi, ConvGeom g, int tiles_x) {
+    typedef C3S2 W;
+    constexpr int NJ = 2, OCT = 64, MTB = 2, TAPS = 9;
+    extern __shared__ __attribute__((aligned(16))) char c3m_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hv = lane >> 5, l31 = lane & 31;
+    const int tile = blockIdx.x, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int ocb = blockIdx.y, img = blockIdx.z;
+    const int hw = g.ih * g.iw, nchunk = g.c / 16;
+    auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
+    if (wave >= 4) {
+        // ------------------------------------------------------------ producers: one chunk in registers, parked when the stage is free.
+        // Eleven (slot, channel quad) tasks a thread: the loads go through a buffer resource over the chunk's 16 channel planes -- one
+        // 32-bit byte offset per task in a VGPR, one resource per channel of the quad, and an offset beyond the resource's size for
+        // a position outside the image (the load then returns zeros by itself): written with pointers and a select, the eleven
+        // 64-bit addresses and masks did not fit beside the data and the compiler spilled 31 registers.
+        const int pt = tid - 256;
+        const int iy0 = tyi * W::TH * 2 - g.pt, ix0 = txi * W::TW * 2 - g.pl;
+        const float* xin = x + (int64_t)img * g.xbs;
+        unsigned t_off[W::TASKS];
+        int t_lds[W::TASKS];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int oy = tyi * C3M_TH + NJ * wn + j;
-            const int col = (oy < g.oh ? oy : g.oh - 1) * g.ow + (ox < g.ow ? ox : g.ow - 1);
-            const bool body = col < (g.plane & ~7);
-            // the activation's scalar-tail form (libm) only where some lane is in the last 0-7 positions of the plane: evaluated
-            // per lane behind a select it would run for every element of every tile
-            const bool all_body = __builtin_amdgcn_ballot_w64(!body) == 0;
+        for (int i = 0; i < W::TASKS; ++i) {
+            const int t = pt + 256 * i, slot = t % W::POS, q = t / W::POS;  // q < 4 while t < 4 * POS
+            const int ph = slot / W::PLANE, r = slot - ph * W::PLANE, sy = r / W::SX, sx = r - sy * W::SX;
+            const int py = 2 * sy + (ph >> 1), px = 2 * sx + (ph & 1), iy = iy0 + py, ix = ix0 + px;
+            const bool in = t < 4 * W::POS && py < W::PH && px < W::PW && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+            t_off[i] = in ? (unsigned)(4 * q * hw + iy * g.iw + ix) * 4u : 0xfffffff0u;   // past num_records: reads as 0
+            t_lds[i] = t < 4 * W::POS ? slot * C3M_PITCH + 8 * q : -1;
+        }
+        float4 st[W::TASKS];
+        auto fetch = [&](int cc) {
+            // one resource per channel of a quad (bases one plane apart, 13 planes long: quad 3's last position is its end), so that
+            // the range test sees nothing but the lane's own offset
+            const float* cb = xin + (int64_t)cc * 16 * hw;
+            const int extent = (int)(13u * (unsigned)hw * 4u);
+            const auto r0 = __builtin_amdgcn_make_buffer_rsrc((void*)cb, (short)0, extent, 0x00020000);
+            const auto r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(cb + hw), (short)0, extent, 0x00020000);
+            const auto r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(cb + 2 * hw), (short)0, extent, 0x00020000);
+            const auto r3 = __builtin_amdgcn_make_buffer_rsrc((void*)(cb + 3 * hw), (short)0, extent, 0x00020000);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ol = (r & 3) + 8 * (r >> 2) + 4 * hv;
-                float v = acc[j][r];
-                if (epi.bias) v = v + epi.bias[ocb * OCT + wm * 32 + ol < g.oc ? ocb * OCT + wm * 32 + ol : g.oc - 1];
-                mine[ol * OCP + j * 32 + l31] = all_body ? apply_act(v, epi.act, true) : apply_act(v, epi.act, body);
+            for (int i = 0; i < W::TASKS; ++i) {
+                st[i].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, (int)t_off[i], 0, 0));
+                st[i].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, (int)t_off[i], 0, 0));
+                st[i].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2, (int)t_off[i], 0, 0));
+                st[i].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r3, (int)t_off[i], 0, 0));
             }
-        }
-        const int q4 = lane & 7;
-        const int oxq = txi * C3M_TW + 4 * q4;
+        };
+        auto park = [&] {
 #pragma unroll
-        for (int it = 0; it < 4 * NJ; ++it) {
-            const int rowid = it * 8 + (lane >> 3), ol = rowid / NJ, j = rowid % NJ;
-            const int oy = tyi * C3M_TH + NJ * wn + j, oc = ocb * OCT + wm * 32 + ol;
-            const float4 v = *reinterpret_cast<const float4*>(mine + ol * OCP + j * 32 + 4 * q4);
-            if (oy < g.oh && oxq < g.ow && oc < g.oc)
-                *reinterpret_cast<float4*>(epi.out + (int64_t)img * g.obs + (int64_t)oc * g.plane + oy * g.ow + oxq) = v;
+            for (int i = 0; i < W::TASKS; ++i) {
+                if (t_lds[i] < 0) continue;
+                const float v[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
+                float r[4], q[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r[e] = v[e] - __uint_as_float(__float_as_uint(v[e]) & 0xffff0000u);
+                    q[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xffff0000u);
+                }
+                cu32x2 h, m, l;
+                h[0] = c3m_pair(v[0], v[1]), h[1] = c3m_pair(v[2], v[3]);
+                m[0] = c3m_pair(r[0], r[1]), m[1] = c3m_pair(r[2], r[3]);
+                l[0] = c3m_pair(q[0], q[1]), l[1] = c3m_pair(q[2], q[3]);
+                *reinterpret_cast<cu32x2*>(c3m_lds + t_lds[i]) = h;
+                *reinterpret_cast<cu32x2*>(c3m_lds + t_lds[i] + 32) = m;
+                *reinterpret_cast<cu32x2*>(c3m_lds + t_lds[i] + 64) = l;
+            }
+        };
+        fetch(0);
+        for (int cc = 0; cc < nchunk; ++cc) {
+            if (cc) barrier();  // the consumers are done with chunk cc - 1: the stage is free
+            park();
+            barrier();          // the stage holds chunk cc
+            if (cc + 1 < nchunk) fetch(cc + 1);
         }
+        barrier();  // the consumers' last "done" (they reuse the stage for their epilogue)
         return;
     }
+    // ---------------------------------------------------------------- consumers: 32 output channels x 2 rows of the tile each
+    const int wm = wave & 1, wn = wave >> 1;
+    cf32x16 acc[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int oy = tyi * C3M_TH + NJ * wn + j;
-        if (oy >= g.oh || ox >= g.ow) continue;
-        const int col = oy * g.ow + ox;
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int oc = ocb * OCT + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv;
-            if (oc < g.oc) epi.store(img, oc, col, acc[j][r], epi.load(img, oc, col));
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    const cu32x4* wbase = wfrag + ((int64_t)(ocb * MTB + wm) * nchunk) * (TAPS * 3 * 64) + lane;
+    cu32x4 ar[2][3];
+    const int64_t wlast = (int64_t)nchunk * TAPS - 1;
+    auto wload = [&](cu32x4 (&dst)[3], int64_t gt) {
+        const cu32x4* src = wbase + (gt < wlast ? gt : wlast) * (3 * 64);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p] = src[p * 64];
+    };
+    wload(ar[0], 0);
+    auto chunk = [&](int cc, auto pc) {
+        constexpr int P = decltype(pc)::value;
+        if (cc) barrier();  // done with chunk cc - 1
+        barrier();          // chunk cc is in the stage
+        const char* stage = c3m_lds + hv * 16;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int a = tap / 3, b = tap - 3 * a;
+            cu32x4 (&af)[3] = ar[(P + tap) & 1];
+            wload(ar[(P + tap + 1) & 1], (int64_t)cc * TAPS + tap + 1);
+#define LELE_CBF(v) __builtin_bit_cast(cbf16x8, v)
+            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};  // mm, hl, lh, hm, mh, hh: smallest terms first
+            cu32x4 bf[2][3];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int slot = (2 * (a & 1) + (b & 1)) * W::PLANE + (NJ * wn + j + (a >> 1)) * W::SX + l31 + (b >> 1);
+                const char* src = stage + slot * C3M_PITCH;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const cu32x4*>(src + 32 * p);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_CBF(af[PA[t]]), LELE_CBF(bf[j][PB[t]]), acc[j], 0, 0, 0);
+#undef LELE_CBF
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    {
+        int cc = 0;
+        for (; cc + 1 < nchunk; cc += 2) {
+            chunk(cc, std::integral_constant<int, 0>());
+            chunk(cc + 1, std::integral_constant<int, 1>());
+        }
+        if (cc < nchunk) chunk(cc, std::integral_constant<int, 0>());
     }
+    barrier();  // every consumer is done with the last chunk: the stage is free for the epilogue
+    static_assert(4 * 32 * (NJ * 32 + 8) * 4 <= W::LDS, "the epilogue tiles fit the stage");
+    c3m_epilogue<NJ, OCT, W::TH>(acc, epi, g, c3m_lds, wave, lane, wm, wn, ocb, img, tyi, txi);
 }
 // weights [OC][IC][taps] f32 -> split-bf16 fragments [ceil(OC / 32)][IC / 16][taps][3 pieces][64 lanes] x 16 bytes (zeros for the
 // channels past OC): lane (l31 = output channel in the tile, hv) holds input channels 16 chunk + 8 hv + [0, 8) of its tap
@@ -957,6 +1150,37 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             else LELE_CW(1, 32);
         }
 #undef LELE_CW
+    } else if (g.group == 1 && g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.sh == 2 && g.sw == 2 && g.c % 16 == 0 && g.oc >= 48 &&
+               ((g.oc + 63) / 64) * 64 - g.oc <= 16 && g.ow >= 16 && g.n <= 65535 && (int64_t)g.c * g.ih * g.iw < (int64_t(1) << 31) &&
+               (int64_t)g.n * ((g.oc + 63) / 64) * ((g.ow + 31) / 32) * ((g.oh + 3) / 4) >= 2 * (int64_t)ctx->num_cus &&
+               !lab_env("LELE_HIP_CONV_NO_S2_WINDOW")) {
+        // stride 2 over a batch: the de-interleaved window kernel (see conv_window_s2_kernel); weights as for the stride-1 kernel
+        const size_t wbytes = (size_t)((g.oc + 31) / 32) * (g.c / 16) * 9 * 3 * 1024 + (size_t)(g.c / 16) * 9 * 3 * 1024;
+        void* dwf = nullptr;
+        const bool cacheable = wt->mem == LELE_MEM_WEIGHT;
+        auto key = std::make_tuple((const void*)wt->data, wbytes, 330 + 9);
+        auto it = cacheable ? ctx->weights.find(key) : ctx->weights.end();
+        if (it != ctx->weights.end()) {
+            dwf = it->second;
+        } else {
+            if (cacheable) {
+                LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
+                LELE_HIP_CHECK(hipMalloc(&dwf, wbytes));
+                ctx->weights[key] = dwf;
+            } else {
+                LELE_TRY(ctx->arena_alloc(wbytes, &dwf));
+            }
+            const int oc_pad = ((g.oc + 63) / 64) * 64;
+            LELE_HIP_CHECK(hipMemsetAsync(dwf, 0, wbytes, ctx->stream));
+            hipLaunchKernelGGL(conv_wfrag_kernel, dim3(grid_for((int64_t)(oc_pad / 32) * (g.c / 16) * 9 * 64)), dim3(256), 0, ctx->stream, dw,
+                               (cu32x4*)dwf, g.oc, g.c, 9);
+        }
+        ConvEpi epi{out, db, g, act};
+        const int tiles_x = (g.ow + 31) / 32, tiles_y = (g.oh + 3) / 4;
+        const dim3 wgrid((unsigned)(tiles_x * tiles_y), (unsigned)((g.oc + 63) / 64), (unsigned)g.n);
+        auto kern = conv_window_s2_kernel;
+        LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3S2::LDS));
+        hipLaunchKernelGGL(kern, wgrid, dim3(512), C3S2::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tiles_x);
     } else if (g.group == 1 && g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.sh == g.sw && (g.sh == 1 || g.sh == 2) && g.oc <= 16 &&
                g.c <= 64 && g.ow >= 16 && g.n <= 65535 &&
                (int64_t)g.n * ((g.ow + 31) / 32) * ((g.oh + 7) / 8) >= 2 * (int64_t)ctx->num_cus) {

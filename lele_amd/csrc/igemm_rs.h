@@ -50,7 +50,7 @@ template <int CPR /* 16-element chunks per row: kp / 16 */, int IT /* trips of 6
 __global__ __launch_bounds__(256) void qrows_frag_kernel(const float* __restrict__ x, unsigned rows, int k, int m,
                                                          QParams* __restrict__ prm, int8_t* __restrict__ af,
                                                          int* __restrict__ row_sums, const float* __restrict__ partial, int nblk,
-                                                         unsigned* __restrict__ zero_slice) {
+                                                         unsigned* __restrict__ zero_slice, LnApply ln) {
     static_assert((CPR == 32 && IT == 1) || (CPR == 128 && IT == 4), "kp = 512: two rows per wave; kp = 2048: two rows per wave");
     constexpr int KS = CPR / 2;
     const int lane = threadIdx.x & 63;
@@ -80,6 +80,17 @@ __global__ __launch_bounds__(256) void qrows_frag_kernel(const float* __restrict
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[i][e] = make_float4(t[4 * e], t[4 * e + 1], t[4 * e + 2], t[4 * e + 3]);
+        }
+    }
+    if (ln.g) {  // uniform: x is the operand of a LayerNorm whose result is quantised here (see LnApply)
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const unsigned r = rowi[i] < rows ? rowi[i] : rows - 1u;
+            float xv[16] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w,
+                            v[i][2].x, v[i][2].y, v[i][2].z, v[i][2].w, v[i][3].x, v[i][3].y, v[i][3].z, v[i][3].w};
+            ln_apply16(ln, r, (int)(16u * ci[i]), k, xv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = make_float4(xv[4 * e], xv[4 * e + 1], xv[4 * e + 2], xv[4 * e + 3]);
         }
     }
     if (row_first >= rows) {  // a wave of padding rows only

@@ -208,6 +208,24 @@ __global__ void resize_nearest_kernel(const float* __restrict__ x, float* __rest
     }
 }
 
+// the x2 asymmetric case (the up-sampling of a detection neck: out[2y + a][2x + b] = in[y][x]; with h_scale = w_scale = 0.5 the
+// reference's floor(o * 0.5) is o >> 1 exactly): a thread reads FOUR consecutive inputs (16 bytes) and writes two rows of eight
+// outputs (2 x 2 x 16 bytes), whole rows of a wave contiguous on both sides.  The general kernel above writes 4 bytes per thread
+// from an input index it derives with two divisions: 0.17 of the HBM rate on [64, 128, 80, 80].
+__global__ __launch_bounds__(256) void resize_x2_kernel(const float* __restrict__ x, float* __restrict__ out, unsigned quads_per_image,
+                                                        int in_w4 /* in_w / 4 */, int in_h, long long xbs, long long obs) {
+    const unsigned q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= quads_per_image) return;
+    const unsigned row = q / (unsigned)in_w4, xq = q - row * (unsigned)in_w4;   // row = channel * in_h + y
+    const float4 v = *reinterpret_cast<const float4*>(x + (long long)blockIdx.y * xbs + (long long)row * (4 * in_w4) + 4 * xq);
+    float* o = out + (long long)blockIdx.y * obs + (long long)row * 2 * (8 * in_w4) + 8 * xq;
+    const float4 lo = make_float4(v.x, v.x, v.y, v.y), hi = make_float4(v.z, v.z, v.w, v.w);
+    reinterpret_cast<float4*>(o)[0] = lo;
+    reinterpret_cast<float4*>(o)[1] = hi;
+    reinterpret_cast<float4*>(o + 8 * in_w4)[0] = lo;
+    reinterpret_cast<float4*>(o + 8 * in_w4)[1] = hi;
+}
+
 // max_pool2d (conv2d.rs:1051-1254): padded cells are skipped (== -inf)
 struct PoolDesc {
     int in_h, in_w, out_h, out_w, kh, kw, sh, sw, pt, pl, dh, dw;
@@ -866,7 +884,14 @@ static int resize_nearest_entry(LeleCtx* ctx, const LeleTensor* x, int64_t out_h
         LELE_TRY(out->reserve((size_t)total * 4));
         dst = (float*)out->data;
     }
-    if (total) {
+    const long long xbs_ = pv && pv->x_pitch ? pv->x_pitch : in_img, obs_ = pv && pv->out_pitch ? pv->out_pitch : out_img;
+    if (total && asymmetric && out_h == 2 * x->shape[2] && out_w == 2 * x->shape[3] && x->shape[3] % 4 == 0 && x->shape[0] <= 65535 &&
+        in_img / 4 < (int64_t(1) << 32) && ((((uintptr_t)dx) | ((uintptr_t)dst)) & 15) == 0 && xbs_ % 4 == 0 && obs_ % 4 == 0) {
+        const unsigned quads = (unsigned)(in_img / 4);
+        hipLaunchKernelGGL(resize_x2_kernel, dim3((quads + 255u) / 256u, (unsigned)x->shape[0]), dim3(256), 0, ctx->stream, (const float*)dx, dst,
+                           quads, (int)(x->shape[3] / 4), (int)x->shape[2], xbs_, obs_);
+        LELE_HIP_CHECK(hipGetLastError());
+    } else if (total) {
         hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx, dst, planes,
                            (int)x->shape[2], (int)x->shape[3], (int)out_h, (int)out_w, asymmetric, (int)x->shape[1],
                            (long long)(pv && pv->x_pitch ? pv->x_pitch : in_img), (long long)(pv && pv->out_pitch ? pv->out_pitch : out_img));

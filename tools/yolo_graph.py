@@ -256,12 +256,13 @@ def main():
         big.run(feed)
         big.stmt_times = []
         big.run(feed)
+        stmt_times, big.stmt_times = big.stmt_times, None   # off again: the stopwatch cannot run inside a graph capture
         rows = []
         byname = {}
         for st in big.plan["statements"]:
             for o in st.get("out", []):
                 byname[o] = st
-        for idx, fn, o, ms in big.stmt_times:
+        for idx, fn, o, ms in stmt_times:
             st = byname[o]
             osh = shapes.get(o, [])
             nbytes = 4 * int(np.prod(osh)) if osh else 0
