@@ -9,5 +9,5 @@ tail -30 $O/tests.log
 tail -3 $O/yolo.log; head -60 $O/yolo_table.txt
 ( timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "rc=$?" >> $O/bench.err )
 tail -c 2500 $O/bench.json; tail -3 $O/bench.err
-bash tools/kstats_sv.sh r4b_c4 32 10 > $O/kstats_c4.txt 2>&1
+bash tools/kstats_sv.sh c4 r4b_c4 > $O/kstats_c4.txt 2>&1
 head -30 $O/kstats_c4.txt
