@@ -1726,6 +1726,7 @@ int lele_hip_conv_transpose(LeleCtx* ctx, const LeleTensor* x, const LeleTensor*
             q.ow = ni;
             q.K = kp;
             q.plane = nj * ni;
+            q.xbs = (long long)g.c * g.ih * g.iw;  // the loaders address images through it (run_conv2d fills it in; this path builds its own)
             ConvWLoad al{wph, q, (int)((((uintptr_t)wph & 15) == 0) && kp % 4 == 0)};
             ConvTEpi epi{(float*)out->data, (const float*)db, make_fastdiv(ni, q.plane), g.oc, g.oh, g.ow, py, px, g.sh, g.sw, ni,
                          q.plane};

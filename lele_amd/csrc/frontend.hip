@@ -149,23 +149,31 @@ constexpr int kStdMelOff[6] = {0, 3, 7, 13, 23, 40};
 // FUSED: the block first stages its run of PCM (64 frames = 10 480 samples, read from HBM once) into an LDS tile that
 // aliases the exchange region, wave 0 computes the 64 exact sequential frame sums from it (as fe_frame_sum_kernel
 // does), and the per-pass sample loads below then hit L2 -- no separate sum kernel, no second HBM read of the PCM.
-template <int MODE, bool STDMEL, bool FUSED>
-__global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ pcm, int64_t utt_stride,
-                                                      int64_t num_frames, int64_t t_lfr,
-                                                      const float* __restrict__ means, FeDev tb,
-                                                      float* __restrict__ out, float* __restrict__ logmel_out,
-                                                      int aligned16) {
-    constexpr int kXFloats = FUSED ? (kSumRows * kSumPitch > 4 * kWaveLdsFloats ? kSumRows * kSumPitch : 4 * kWaveLdsFloats)
+// PASSES: frames per workgroup = 16 * PASSES (a wave takes 4 frames a pass).  LOWREG (the four-waves-per-SIMD form, fe_main_w4_kernel):
+// the 25 window coefficients of a lane are re-read from the (L1-resident) table every pass instead of living in registers, and the
+// next pass's samples are requested only once the 32 complex points of phase A have left for the exchange -- the two arrays that
+// kept the kernel at 168 registers a lane (three waves per SIMD); with PASSES = 3 the PCM tile of a run fits the exchange region
+// it aliases (50 hop rows, 32.8 KB) and four workgroups share a CU.  Same arithmetic in the same order: the same bits.
+template <int MODE, bool STDMEL, bool FUSED, int PASSES, bool LOWREG>
+__device__ __forceinline__ void fe_main_body(const float* __restrict__ pcm, int64_t utt_stride,
+                                             int64_t num_frames, int64_t t_lfr,
+                                             const float* __restrict__ means, const FeDev& tb,
+                                             float* __restrict__ out, float* __restrict__ logmel_out,
+                                             int aligned16, float* s_melw) {
+    constexpr int FR = 16 * PASSES;           // frames per workgroup
+    constexpr int kRows = FR + 2;             // hop rows of the run (400 = 2.5 hops)
+    constexpr int kXFloats = FUSED ? (kRows * kSumPitch > 4 * kWaveLdsFloats ? kRows * kSumPitch : 4 * kWaveLdsFloats)
                                    : 4 * kWaveLdsFloats;
-    __shared__ float2 s_tw[512];
+    __shared__ float2 s_tw[LOWREG ? 480 : 512];   // LOWREG: only the entries phase B reads (stages 6..9: 31 .. 510)
     __shared__ __attribute__((aligned(16))) float s_x[kXFloats];
     __shared__ float s_mean[64];
-    __shared__ int s_mstart[16 * kMaxMelRounds];
+    __shared__ int s_mstart[16 * (STDMEL ? 5 : kMaxMelRounds)];
     __shared__ int s_moff[kMaxMelRounds + 1];
-    extern __shared__ float s_melw[];  // [mel_steps][16]
+    constexpr int kTwBase = LOWREG ? 31 : 0;
 
-    for (int i = threadIdx.x; i < 511; i += 256) s_tw[i] = tb.tw[i];
-    for (int i = threadIdx.x; i < tb.mel_steps * 16; i += 256) s_melw[i] = tb.melw[i];
+    for (int i = threadIdx.x; i < 511 - kTwBase; i += 256) s_tw[i] = tb.tw[i + kTwBase];
+    if (!STDMEL)
+        for (int i = threadIdx.x; i < tb.mel_steps * 16; i += 256) s_melw[i] = tb.melw[i];
     if (threadIdx.x < tb.mel_rounds * 16) s_mstart[threadIdx.x] = tb.mel_start[threadIdx.x];
     if (threadIdx.x <= tb.mel_rounds) s_moff[threadIdx.x] = tb.mel_step_off[threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -174,9 +182,9 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
         // stage the run [64*blockIdx.x*hop, +66 hops) as [hop row][offset] (x32768, exact) -- same layout and bank
         // argument as fe_frame_sum_kernel, 256 threads, all loads of a thread issued before the first use
         const float* ubase = pcm + (int64_t)blockIdx.y * utt_stride;
-        const int64_t s0 = (int64_t)blockIdx.x * 64 * fe::kHop;
+        const int64_t s0 = (int64_t)blockIdx.x * FR * fe::kHop;
         constexpr int kVecPerRow = fe::kHop / 4;
-        constexpr int kVecs = kSumRows * kVecPerRow;
+        constexpr int kVecs = kRows * kVecPerRow;
         constexpr int kIters = (kVecs + 255) / 256;
         float4 st[kIters];
 #pragma unroll
@@ -217,17 +225,19 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
     float* out_u = out ? out + (int64_t)blockIdx.y * t_lfr * d_out : nullptr;
     float* lm_u = logmel_out ? logmel_out + (int64_t)blockIdx.y * num_frames * tb.n_mels : nullptr;
 
-    // Hann window coefficients of this lane's samples n = p + 16 q (features/window.rs), kept in registers
+    // Hann window coefficients of this lane's samples n = p + 16 q (features/window.rs), kept in registers (LOWREG: re-read per pass)
     float win[fe::kQ];
+    if (!LOWREG) {
 #pragma unroll
-    for (int q = 0; q < fe::kQ; ++q) win[q] = tb.window[p + 16 * q];
+        for (int q = 0; q < fe::kQ; ++q) win[q] = tb.window[p + 16 * q];
+    }
 
     // raw PCM of the next pass is fetched while the current pass computes (software prefetch): the loads are
     // unconditional (clamped to frame 0 for the tail) so that all 25 are in flight together.
     float xr[fe::kQ];
     float mean_next = 0.0f;
     auto issue_loads = [&](int pass) {
-        const int64_t f = (int64_t)blockIdx.x * 64 + wave * 16 + pass * 4 + g;
+        const int64_t f = (int64_t)blockIdx.x * FR + wave * (4 * PASSES) + pass * 4 + g;
         const int64_t fc = f < num_frames ? f : 0;
         const float* src = base + fc * fe::kHop + p;
         if (!FUSED) mean_next = mean_u[fc];
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
     issue_loads(0);
     if (FUSED) {
         constexpr int kVecPerRow = fe::kHop / 4;
-        if (wave == 0) {  // raw_frame.iter().sum() (pipeline.rs:115): one lane per frame, 400 adds in index order
+        if (wave == 0 && lane < FR) {  // raw_frame.iter().sum() (pipeline.rs:115): one lane per frame, 400 adds in index order
             float sum = 0.0f;
 #pragma unroll
             for (int seg = 0; seg < 3; ++seg) {
@@ -257,16 +267,22 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
     }
     __syncthreads();  // tables (and, when FUSED, the means) are in LDS; the PCM tile may now be overwritten
 
-    for (int pass = 0; pass < 4; ++pass) {
-        const int64_t f = (int64_t)blockIdx.x * 64 + wave * 16 + pass * 4 + g;
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int64_t f = (int64_t)blockIdx.x * FR + wave * (4 * PASSES) + pass * 4 + g;
         const bool valid = f < num_frames;
-        const float mean = FUSED ? s_mean[wave * 16 + pass * 4 + g] : mean_next;
+        const float mean = FUSED ? s_mean[wave * (4 * PASSES) + pass * 4 + g] : mean_next;
+        if (LOWREG) {  // the compiler must not hoist these loads out of the pass loop (that is the register form again)
+            int off = 0;
+            asm volatile("" : "+v"(off));
+#pragma unroll
+            for (int q = 0; q < fe::kQ; ++q) win[q] = tb.window[p + 16 * q + off];
+        }
 
         // 1./2. scale and mean subtraction (pipeline.rs:90-137): fl(x*32768) is exact, one rounding on the sub
         float v[fe::kQ];
 #pragma unroll
         for (int q = 0; q < fe::kQ; ++q) v[q] = fe::fsub(fe::fmul(xr[q], 32768.0f), mean);
-        if (pass + 1 < 4) issue_loads(pass + 1);
+        if (!LOWREG && pass + 1 < PASSES) issue_loads(pass + 1);
         // 3. pre-emphasis (pipeline.rs:140-142): y[n] = v[n] - 0.97*v[n-1] for n >= 1; v[n-1] lives in lane p-1
         //    (same q) or, for p == 0, in lane 15 at q-1.  4. window (pipeline.rs:145-166).
         float xin[fe::kRegs];
@@ -298,6 +314,7 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
                 const int slot = fe::xchg_slot(h, cc);
                 *reinterpret_cast<float2*>(xf + 2 * slot) = make_float2(a[rho * 16 + cc].x, a[rho * 16 + cc].y);
             }
+            if (LOWREG && rho == 1 && pass + 1 < PASSES) issue_loads(pass + 1);  // phase A's points are on their way out: room for the samples
             __builtin_amdgcn_wave_barrier();
             fe::cf bq[16];
 #pragma unroll
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
             __builtin_amdgcn_wave_barrier();
             // stages 6..9 with per-lane twiddles from LDS
             float re256 = 0.0f;
-            fe::phase_b(bq, p, rho, [&](int i) { const float2 w = s_tw[i]; return fe::cmk(w.x, w.y); }, &re256);
+            fe::phase_b(bq, p, rho, [&](int i) { const float2 w = s_tw[i - kTwBase]; return fe::cmk(w.x, w.y); }, &re256);
             if (rho == 0) p256 = re256;  // position 256 (used by lane p == 0)
             // 6. power spectrum (pipeline.rs:165-169); bins 0 and 256 have im forced to 0 (kernels/fft.rs:256-261)
 #pragma unroll
@@ -396,6 +413,20 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
     }
 }
 
+template <int MODE, bool STDMEL, bool FUSED>
+__global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ pcm, int64_t utt_stride, int64_t num_frames, int64_t t_lfr,
+                                                      const float* __restrict__ means, FeDev tb, float* __restrict__ out,
+                                                      float* __restrict__ logmel_out, int aligned16) {
+    extern __shared__ float s_melw[];  // [mel_steps][16] (the table-driven mel loop only)
+    fe_main_body<MODE, STDMEL, FUSED, 4, false>(pcm, utt_stride, num_frames, t_lfr, means, tb, out, logmel_out, aligned16, s_melw);
+}
+// four waves per SIMD (<= 128 registers a lane), 48 frames per workgroup, four workgroups per CU: see fe_main_body
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fe_main_w4_kernel(
+    const float* __restrict__ pcm, int64_t utt_stride, int64_t num_frames, int64_t t_lfr, const float* __restrict__ means, FeDev tb,
+    float* __restrict__ out, float* __restrict__ logmel_out, int aligned16) {
+    fe_main_body<1, true, true, 3, true>(pcm, utt_stride, num_frames, t_lfr, means, tb, out, logmel_out, aligned16, nullptr);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Generic path: any FeatureConfig the reference accepts (other sample rates / frame lengths / n_fft = 1024).
 // The same operations in the same order as pipeline.rs:84-187, spread over four simple kernels + the generic
@@ -466,6 +497,7 @@ struct LeleFrontend {
     bool std_mel = false;  // mel bank has the default round structure (fully unrolled kernel variant)
     int dpp_mode = 0;  // 0: __shfl, 1: DPP row_ror (selected after a self-test)
     bool fused = true;  // frame sums computed inside fe_main_kernel (LELE_HIP_FE_FUSED=0 selects the two-kernel form)
+    bool w4 = false;    // fe_main_w4_kernel (four waves per SIMD, 48 frames per workgroup) instead of fe_main_kernel: LELE_HIP_FE_W4
     // generic path tables (configs other than 400/160/512)
     const float* g_window = nullptr;
     const int* g_mstart = nullptr;
@@ -664,6 +696,8 @@ int lele_hip_frontend_create(LeleCtx* ctx, const LeleFeatureConfig* cfg, LeleFro
     fe->dpp_mode = env ? atoi(env) : 1;  // 1: DPP row_ror (default), 0: __shfl (ds_bpermute)
     const char* envf = lab_env("LELE_HIP_FE_FUSED");
     fe->fused = envf ? atoi(envf) != 0 : true;
+    const char* envw = getenv("LELE_HIP_FE_W4");
+    fe->w4 = envw ? atoi(envw) != 0 : false;
     *out = fe;
     return 0;
 }
@@ -741,7 +775,8 @@ static int fe_run(LeleFrontend* fe, const LeleTensor* pcm, int64_t batch, int64_
         return 0;
     }
     const int aligned16 = ((uintptr_t)dpcm % 16 == 0) && (pcm_len % 4 == 0);
-    dim3 grid((unsigned)((nf + 63) / 64), (unsigned)batch);
+    const bool w4 = fe->w4 && fe->fused && fe->std_mel && fe->dpp_mode == 1;
+    dim3 grid((unsigned)(w4 ? (nf + 47) / 48 : (nf + 63) / 64), (unsigned)batch);
     hipEvent_t* ev = nullptr;
     if (fe->profiling) {
         if (fe->events_used + 3 > fe->events.size()) {
@@ -772,7 +807,10 @@ static int fe_run(LeleFrontend* fe, const LeleTensor* pcm, int64_t batch, int64_
         else                  \
             FE_LAUNCH(MODE, STD, false); \
     } while (0)
-    if (fe->dpp_mode == 1) {
+    if (w4) {
+        hipLaunchKernelGGL(fe_main_w4_kernel, grid, dim3(256), 0, ctx->stream, (const float*)dpcm, pcm_len, nf, t_lfr, (const float*)dmean,
+                           fe->dev, o, lm, aligned16);
+    } else if (fe->dpp_mode == 1) {
         if (fe->std_mel) FE_LAUNCH2(1, true); else FE_LAUNCH2(1, false);
     } else {
         if (fe->std_mel) FE_LAUNCH2(0, true); else FE_LAUNCH2(0, false);

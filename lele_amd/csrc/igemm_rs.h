@@ -200,6 +200,120 @@ __global__ __launch_bounds__(256) void qrows_frag_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------ LayerNorm -> fragment-major i8, ONE kernel
+// layer_norm (last axis) -> per-slice dynamic range -> rows quantised into fragment order, for batches of short slices (one
+// utterance of a SenseVoice shard: 171 rows of 512): ONE workgroup of 1024 threads owns a whole slice and keeps it in REGISTERS --
+// 16 waves x 64 lanes x 96 values -- between the normalisation and the quantisation, so that the slice's range, which every row's
+// quantisation waits for, is a workgroup-local reduction (one __syncthreads) instead of a kernel boundary.  Neither the normalised
+// tensor nor row statistics ever reach memory: x is read once, the i8 fragments written once.  (The two-kernel form -- a statistics
+// pass + qrows_frag_kernel with LnApply -- measured 6.7 + 11.3 us per [5472 x 512] against 7.1 + 10.5 for LayerNorm + the plain
+// quantiser: at this size a kernel costs its launch, first touch and drain whatever it moves, so only a kernel LESS helps.)
+// Lane l of a 32-lane group holds elements 32 c + l of its row, the layout of layer_norm_reg_kernel, whose arithmetic this repeats
+// statement for statement (row_sums_reg: lele's 4 x 8 accumulator order; fma inside the row's 8-wide body); the quantiser is
+// qrows_frag_kernel's.  A pass = 32 rows (two per wave); their bytes take a turn through LDS so that wave w writes the k-step-w
+// blocks of the pass as 16-byte pieces (row pitch 528 bytes: the 32 rows of a read fall on all 64 banks once).
+// grid = slices, block = 1024, k <= 512 (kp = 512), m <= 32 NP.
+template <int NP>
+__global__ __launch_bounds__(1024) void ln_qfrag_slice_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                              float eps, int k, int m, unsigned rows_total, QParams* __restrict__ prm,
+                                                              int8_t* __restrict__ af, int* __restrict__ row_sums, unsigned* __restrict__ zero_slice) {
+    constexpr int NT = 16, KS = 16, PITCH = 528;
+    __shared__ float s_g[512], s_b[512];
+    __shared__ float s_mn[32], s_mx[32];
+    __shared__ __attribute__((aligned(16))) unsigned char s_q[32 * PITCH];
+    const int tid = threadIdx.x, l = tid & 31, grp = tid >> 5, lane = tid & 63, wave = tid >> 6;
+    const unsigned s = blockIdx.x, row0 = s * (unsigned)m;
+    for (int i = tid; i < 512; i += 1024) {
+        s_g[i] = g[i < k ? i : k - 1];
+        s_b[i] = b[i < k ? i : k - 1];
+    }
+    float v[NP][NT];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int r = 32 * p + grp, rc = r < m ? r : m - 1;  // rows beyond the slice repeat its last row: same statistics, nothing stored
+        const float* in = x + (size_t)(row0 + (unsigned)rc) * k;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const int j = 32 * c + l;
+            v[p][c] = in[j < k ? j : k - 1];
+        }
+    }
+    __syncthreads();
+    const float inv_n = 1.0f / (float)k;
+    const int body = k & ~7;
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        float sum, sumsq;
+        lele::row_sums_reg<NT, true, true>(v[p], k, l, &sum, &sumsq);
+        const float mean = sum * inv_n;
+        const float var = sumsq * inv_n - mean * mean;
+        const float inv_std = 1.0f / sqrtf(var + eps);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const int j = 32 * c + l;
+            if (j < k) {
+                const float t = (v[p][c] - mean) * inv_std;
+                const float o = j < body ? __builtin_fmaf(t, s_g[j], s_b[j]) : t * s_g[j] + s_b[j];
+                v[p][c] = o;
+                mn = o < mn ? o : mn;
+                mx = o > mx ? o : mx;
+            }
+        }
+    }
+    mn = group_allreduce32(mn, [](float cur, float a) { return a < cur ? a : cur; });
+    mx = group_allreduce32(mx, [](float cur, float a) { return a > cur ? a : cur; });
+    if (l == 0) {
+        s_mn[grp] = mn;
+        s_mx[grp] = mx;
+    }
+    __syncthreads();
+    mn = group_allreduce32(s_mn[l], [](float cur, float a) { return a < cur ? a : cur; });
+    mx = group_allreduce32(s_mx[l], [](float cur, float a) { return a > cur ? a : cur; });
+    const QParams q = make_qparams(mn, mx);
+    if (tid == 0) {
+        prm[s] = q;
+        if (zero_slice) zero_slice[s] = 0u;
+    }
+    const int simd_k = k & ~7;
+    auto addi = [](float a, float c) { return __int_as_float(__float_as_int(a) + __float_as_int(c)); };
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (32 * p >= m) break;  // uniform
+        const int r = 32 * p + grp;
+        int sacc = 0;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const int j = 32 * c + l;
+            int val = 0;
+            if (j < k) {
+                val = (int)quant_one(v[p][c], q, j < simd_k) - 128;
+                sacc += val;
+            }
+            s_q[grp * PITCH + j] = (unsigned char)(val & 0xff);
+        }
+        const int tot = __float_as_int(group_allreduce32(__int_as_float(sacc), addi));
+        if (l == 0 && r < m && row_sums) row_sums[row0 + (unsigned)r] = tot;
+        __syncthreads();
+        {   // wave w writes k-step w of the pass: lane L = (row of the pass, half of the step)
+            const int rr = lane & 31, half = lane >> 5;
+            if (32 * p + rr < m) {
+                const unsigned grow = row0 + (unsigned)(32 * p + rr);
+                const v4i piece = *reinterpret_cast<const v4i*>(s_q + rr * PITCH + (2 * wave + half) * 16);
+                *reinterpret_cast<v4i*>(af + (((size_t)(grow >> 5) * KS + wave) * 64 + (grow & 31u) + 32u * half) * 16) = piece;
+            }
+        }
+        __syncthreads();
+    }
+    // the rows that pad the last tile of the tensor are zeros (the GEMM multiplies whole tiles)
+    if (s == gridDim.x - 1 && (rows_total & 31u)) {
+        const int rr = lane & 31, half = lane >> 5;
+        const unsigned grow = (rows_total & ~31u) + (unsigned)rr;
+        if (grow >= rows_total)
+            *reinterpret_cast<v4i*>(af + (((size_t)(grow >> 5) * KS + wave) * 64 + (grow & 31u) + 32u * half) * 16) = v4i{0, 0, 0, 0};
+    }
+}
+
 // ------------------------------------------------------------------------------------------ shared pieces
 __device__ __forceinline__ unsigned rs_logical_block() {  // workgroup b runs on XCD b % 8: give every XCD a contiguous range
     const unsigned G = gridDim.x, b = blockIdx.x, xcd = b & 7u, base = G >> 3, rem = G & 7u;

@@ -19,6 +19,7 @@
 // (avx/quantization.rs:12-95).
 #include "common.h"
 #include "lane_ops.h"
+#include "norm_core.h"
 #include "gemm_small.h"
 
 #include <math.h>
@@ -1118,6 +1119,23 @@ int launch_qrows_frag(LeleCtx* ctx, const float* dx, int64_t rows, int k, int kp
     LELE_HIP_CHECK(hipGetLastError());
     return 0;
 }
+// LayerNorm + range + quantise-to-fragments in one kernel (ln_qfrag_slice_kernel): slices short enough to live in one workgroup's
+// registers, enough of them to be worth a chip, K = 512 fragments
+bool ln_slice_fits(LeleCtx* ctx, int64_t batch, int64_t m, int64_t k) {
+    return k >= 8 && k <= 512 && m >= 1 && m <= 192 && batch >= 8 && batch * m < (int64_t(1) << 31) && env_int("LELE_HIP_LN_SLICE", 1) != 0;
+}
+int launch_ln_qfrag_slice(LeleCtx* ctx, const float* dx, const float* dg, const float* db, float eps, int64_t batch, int m, int k, QParams* prm,
+                          int8_t* af, int* rs, unsigned* zero_slice) {
+    const unsigned rows = (unsigned)(batch * m);
+#define LELE_LNQ(NP_) \
+    hipLaunchKernelGGL((ln_qfrag_slice_kernel<NP_>), dim3((unsigned)batch), dim3(1024), 0, ctx->stream, dx, dg, db, eps, k, m, rows, prm, af, rs, zero_slice)
+    if (m <= 64) LELE_LNQ(2);
+    else if (m <= 128) LELE_LNQ(4);
+    else LELE_LNQ(6);
+#undef LELE_LNQ
+    LELE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
 int launch_rs(LeleCtx* ctx, int em, const int8_t* af, const int8_t* wf, int64_t rows, int n, int8_t* hid, const IgemmEpi& epi) {
     RsArgs g{af, wf, (unsigned)rows, n, (int)((rows + 31) / 32), (n + 31) / 32, 0, 0, hid};
 #ifdef LELE_HIP_LAB
@@ -1317,16 +1335,18 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     const float* partial = nullptr;
     int nblk = 0;
     LnApply ln{nullptr, nullptr, nullptr};
-    if (lnf) {  // the operand's OWN statistics (if its producer left any) describe x, not LayerNorm(x)
+    // LayerNorm in front, register-stationary route, short slices: ONE kernel from x to the i8 fragments (ln_qfrag_slice_kernel)
+    const bool ln_slice = lnf && rs_fits(ctx, rows, n, rs_kp(k)) && ln_slice_fits(ctx, batch, m, k);
+    if (lnf && !ln_slice) {  // the operand's OWN statistics (if its producer left any) describe x, not LayerNorm(x)
         LELE_TRY(ln_prepare(ctx, lnf, (const float*)dx, rows, k, &partial, &ln));
         nblk = (int)m;
-    } else {
+    } else if (!lnf) {
         find_partials(ctx, input, batch, m, k, &partial, &nblk);
     }
     void* prm = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm));
     LELE_TRY(qprof_mark(ctx, 0));
-    if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
+    if (!partial && !ln_slice) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
     LELE_TRY(qprof_mark(ctx, 1));
 
     // ---- register-stationary route (igemm_rs.h): rows -> i8 in fragment order, then the barrier-free GEMM
@@ -1337,7 +1357,15 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
         void *af = nullptr, *rs = nullptr;
         LELE_TRY(ctx->arena_alloc((size_t)nrt * kprs * 32, &af));
         if (kprs == 512) LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));  // K = 2048: the GEMM sums the rows it loads anyway
-        LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k, kprs, (int)m, (QParams*)prm, (int8_t*)af, (int*)rs, partial, nblk, nullptr, ln));
+        if (ln_slice) {
+            const void *dg = nullptr, *dbt = nullptr;
+            LELE_TRY(ctx->dev_ptr(lnf->scale, &dg));
+            LELE_TRY(ctx->dev_ptr(lnf->bias, &dbt));
+            LELE_TRY(launch_ln_qfrag_slice(ctx, (const float*)dx, (const float*)dg, (const float*)dbt, lnf->eps, batch, (int)m, (int)k, (QParams*)prm,
+                                           (int8_t*)af, (int*)rs, nullptr));
+        } else {
+            LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k, kprs, (int)m, (QParams*)prm, (int8_t*)af, (int*)rs, partial, nblk, nullptr, ln));
+        }
         LELE_TRY(qprof_mark(ctx, 2));
         IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, (const int*)rs, fw.col_sums, (const QParams*)prm, 0,
                      (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
@@ -1517,17 +1545,18 @@ static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_
     const float* partial = nullptr;
     int nblk = 0;
     LnApply ln{nullptr, nullptr, nullptr};
-    if (lnf) {
+    const bool ln_slice = lnf && rs_route && ln_slice_fits(ctx, batch, m, k1);
+    if (lnf && !ln_slice) {
         LELE_TRY(ln_prepare(ctx, lnf, (const float*)dx, rows, k1, &partial, &ln));
         nblk = (int)m;
-    } else {
+    } else if (!lnf) {
         find_partials(ctx, input, batch, m, k1, &partial, &nblk);
     }
     void *prm1 = nullptr, *prm2 = nullptr, *aq1 = nullptr, *rs1 = nullptr, *aq2 = nullptr, *rs2 = nullptr, *hmax = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm1));
     LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm2));
     LELE_TRY(qprof_mark(ctx, 0));
-    if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k1, (QParams*)prm1, nullptr, nullptr, &partial, &nblk));
+    if (!partial && !ln_slice) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k1, (QParams*)prm1, nullptr, nullptr, &partial, &nblk));
     LELE_TRY(qprof_mark(ctx, 1));
     if (rs_route) {
         FragW fw1, fw2;
@@ -1540,8 +1569,16 @@ static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_
         LELE_TRY(ctx->arena_alloc((size_t)nrt * 2048 * 32, &hid));
         LELE_TRY(ctx->arena_alloc((size_t)batch * 4, &hmax));
         // rows -> i8 for the first product; the same launch clears the per-slice maxima the range pass adds into
-        LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k1, 512, (int)m, (QParams*)prm1, (int8_t*)af1, (int*)rs1, partial, nblk,
-                                   (unsigned*)hmax, ln));
+        if (ln_slice) {
+            const void *dg = nullptr, *dbt = nullptr;
+            LELE_TRY(ctx->dev_ptr(lnf->scale, &dg));
+            LELE_TRY(ctx->dev_ptr(lnf->bias, &dbt));
+            LELE_TRY(launch_ln_qfrag_slice(ctx, (const float*)dx, (const float*)dg, (const float*)dbt, lnf->eps, batch, (int)m, (int)k1, (QParams*)prm1,
+                                           (int8_t*)af1, (int*)rs1, (unsigned*)hmax));
+        } else {
+            LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k1, 512, (int)m, (QParams*)prm1, (int8_t*)af1, (int*)rs1, partial, nblk,
+                                       (unsigned*)hmax, ln));
+        }
         LELE_TRY(qprof_mark(ctx, 2));
         IgemmEpi e1{nullptr, rows, n1, (int)m, (int)k1, (const int*)rs1, fw1.col_sums, (const QParams*)prm1, 0, (int)wz1, (const float*)dws1,
                     (int)ws1_len, b1_len ? (const float*)db1 : nullptr, 1};
