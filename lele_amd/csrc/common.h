@@ -121,8 +121,9 @@ struct LeleCtx {
 
     // two library-owned result buffers for ops that fall back to an unfused sequence and need somewhere to put the intermediate
     // (add3 / fused_quantized_linear_residual with an operand that broadcasts OUTWARD: the in-place second pass is not possible)
-    LeleBuf* tmp[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [3]: row statistics of a LayerNorm folded into its consumer
-                                                                      // (quant.hip), [4]: its output where the fold does not apply
+    LeleBuf* tmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [3]: row statistics of a LayerNorm folded into its
+                                                                               // consumer (quant.hip), [4]: its output where the fold does
+                                                                               // not apply, [5]: per-slice rendezvous records (igemm_rs.h)
     int tmp_buf(int i, LeleBuf** out);
 
     int check_deverr(const char* where);
@@ -140,6 +141,7 @@ struct LeleGraph {
 };
 
 #define LELE_DEVERR_GATHER_INDEX 1u
+#define LELE_DEVERR_GROUP_TIMEOUT 2u  // a workgroup gave up waiting for the other workgroups of its slice (ln_qfrag_group_kernel)
 
 // Developer switches (kernel variants for A/B timing, stamps, ablations) exist in the LAB build only
 // (LELE_HIP_LAB=1 python -m lele_amd.build -> liblele_hip_lab.so); in the product library lab_env() is NULL for every name.

@@ -880,11 +880,13 @@ struct C3S2 {
     static constexpr int LDS = STAGE > EPI ? STAGE : EPI;
     static constexpr int TASKS = (POS * 4 + 255) / 256;
 };
+// OCT = 64: two 32-channel tiles x two pairs of tile rows; OCT = 32: one tile x four single rows (narrow layers)
+template <int OCT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_window_s2_kernel(const float* __restrict__ x,
                                                                                                     const cu32x4* __restrict__ wfrag,
                                                                                                     ConvEpi epi, ConvGeom g, int tiles_x) {
     typedef C3S2 W;
-    constexpr int NJ = 2, OCT = 64, MTB = 2, TAPS = 9;
+    constexpr int NJ = OCT == 64 ? 2 : 1, MTB = OCT / 32, TAPS = 9;
     extern __shared__ __attribute__((aligned(16))) char c3m_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hv = lane >> 5, l31 = lane & 31;
     const int tile = blockIdx.x, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
@@ -959,8 +961,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         barrier();  // the consumers' last "done" (they reuse the stage for their epilogue)
         return;
     }
-    // ---------------------------------------------------------------- consumers: 32 output channels x 2 rows of the tile each
-    const int wm = wave & 1, wn = wave >> 1;
+    // ---------------------------------------------------------------- consumers: 32 output channels x NJ rows of the tile each
+    const int wm = OCT == 64 ? (wave & 1) : 0, wn = OCT == 64 ? (wave >> 1) : wave;
     cf32x16 acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -987,9 +989,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             wload(ar[(P + tap + 1) & 1], (int64_t)cc * TAPS + tap + 1);
 #define LELE_CBF(v) __builtin_bit_cast(cbf16x8, v)
             constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};  // mm, hl, lh, hm, mh, hh: smallest terms first
-            cu32x4 bf[2][3];
+            cu32x4 bf[NJ][3];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const int slot = (2 * (a & 1) + (b & 1)) * W::PLANE + (NJ * wn + j + (a >> 1)) * W::SX + l31 + (b >> 1);
                 const char* src = stage + slot * C3M_PITCH;
 #pragma unroll
@@ -998,7 +1000,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int t = 0; t < 6; ++t)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_CBF(af[PA[t]]), LELE_CBF(bf[j][PB[t]]), acc[j], 0, 0, 0);
 #undef LELE_CBF
             __builtin_amdgcn_sched_barrier(0);
@@ -1053,6 +1055,15 @@ inline int64_t attr(const int64_t* v, size_t n, size_t i, int64_t dflt) {
     return dflt;
 }
 
+// where the window-once kernel takes a 1 x 1 convolution (see the dispatch below); LELE_HIP_CONV_W1_* override for measurements
+inline int conv_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+inline int w1_max_oc() { static const int v = conv_env("LELE_HIP_CONV_W1_MAXOC", 64); return v; }
+inline int w1_min_plane() { static const int v = conv_env("LELE_HIP_CONV_W1_MINPLANE", 6400); return v; }
+inline int w1_min_c() { static const int v = conv_env("LELE_HIP_CONV_W1_MINC", 48); return v; }
+
 int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float* dw, const float* db, ConvGeom g, int act,
                float* out) {
     if ((int64_t)g.n * g.oc * g.plane == 0) return 0;
@@ -1104,7 +1115,8 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
                 // 1 x 1: only where it measured faster than the tiled GEMM on the Yolo-shaped network at batch 64 -- one block of output
                 // channels (every further block fetches and splits the input again: 64 -> 80 at 80 x 80 179 against 153 us), large
                 // planes, >= 48 input channels (48 -> 64 at 160 x 160: 316 against 406 us, 256 -> 64 at 80 x 80: 208 against 277)
-                (g.kh == 1 && g.kw == 1 && g.pt == 0 && g.pl == 0 && g.oh == g.ih && g.ow == g.iw && g.oc <= 64 && g.plane >= 6400 && g.c >= 48)) &&
+                (g.kh == 1 && g.kw == 1 && g.pt == 0 && g.pl == 0 && g.oh == g.ih && g.ow == g.iw && g.oc <= w1_max_oc() && g.plane >= w1_min_plane() &&
+                 g.c >= w1_min_c())) &&
                g.dh == 1 && g.dw == 1 && g.sh == 1 && g.sw == 1 && g.c % 16 == 0 && g.oc > 16 && g.ow >= 16 && g.n <= 65535 &&
                (int64_t)g.c * g.ih * g.iw < (int64_t(1) << 31) &&
                (int64_t)g.n * ((g.oc + 63) / 64) * ((g.ow + 31) / 32) * ((g.oh + 7) / 8) >= (int64_t)ctx->num_cus) {
@@ -1150,12 +1162,14 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             else LELE_CW(1, 32);
         }
 #undef LELE_CW
-    } else if (g.group == 1 && g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.sh == 2 && g.sw == 2 && g.c % 16 == 0 && g.oc >= 48 &&
-               ((g.oc + 63) / 64) * 64 - g.oc <= 16 && g.ow >= 16 && g.n <= 65535 && (int64_t)g.c * g.ih * g.iw < (int64_t(1) << 31) &&
+    } else if (g.group == 1 && g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.sh == 2 && g.sw == 2 && g.c % 16 == 0 && g.oc > 16 &&
+               g.ow >= 16 && g.n <= 65535 && (int64_t)g.c * g.ih * g.iw < (int64_t(1) << 31) &&
                (int64_t)g.n * ((g.oc + 63) / 64) * ((g.ow + 31) / 32) * ((g.oh + 3) / 4) >= 2 * (int64_t)ctx->num_cus &&
                !lab_env("LELE_HIP_CONV_NO_S2_WINDOW")) {
-        // stride 2 over a batch: the de-interleaved window kernel (see conv_window_s2_kernel); weights as for the stride-1 kernel
-        const size_t wbytes = (size_t)((g.oc + 31) / 32) * (g.c / 16) * 9 * 3 * 1024 + (size_t)(g.c / 16) * 9 * 3 * 1024;
+        // stride 2 over a batch: the de-interleaved window kernel (see conv_window_s2_kernel); weights as for the stride-1 kernel,
+        // blocks of 32 output channels when that wastes fewer of them than blocks of 64
+        const int oct = ((g.oc + 31) / 32) * 32 < ((g.oc + 63) / 64) * 64 ? 32 : 64;
+        const size_t wbytes = (size_t)((g.oc + 31) / 32) * (g.c / 16) * 9 * 3 * 1024 + (oct == 64 ? (size_t)(g.c / 16) * 9 * 3 * 1024 : 0);
         void* dwf = nullptr;
         const bool cacheable = wt->mem == LELE_MEM_WEIGHT;
         auto key = std::make_tuple((const void*)wt->data, wbytes, 330 + 9);
@@ -1170,17 +1184,23 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             } else {
                 LELE_TRY(ctx->arena_alloc(wbytes, &dwf));
             }
-            const int oc_pad = ((g.oc + 63) / 64) * 64;
+            const int oc_pad = ((g.oc + oct - 1) / oct) * oct;
             LELE_HIP_CHECK(hipMemsetAsync(dwf, 0, wbytes, ctx->stream));
             hipLaunchKernelGGL(conv_wfrag_kernel, dim3(grid_for((int64_t)(oc_pad / 32) * (g.c / 16) * 9 * 64)), dim3(256), 0, ctx->stream, dw,
                                (cu32x4*)dwf, g.oc, g.c, 9);
         }
         ConvEpi epi{out, db, g, act};
         const int tiles_x = (g.ow + 31) / 32, tiles_y = (g.oh + 3) / 4;
-        const dim3 wgrid((unsigned)(tiles_x * tiles_y), (unsigned)((g.oc + 63) / 64), (unsigned)g.n);
-        auto kern = conv_window_s2_kernel;
-        LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3S2::LDS));
-        hipLaunchKernelGGL(kern, wgrid, dim3(512), C3S2::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tiles_x);
+        const dim3 wgrid((unsigned)(tiles_x * tiles_y), (unsigned)((g.oc + oct - 1) / oct), (unsigned)g.n);
+        if (oct == 64) {
+            auto kern = conv_window_s2_kernel<64>;
+            LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3S2::LDS));
+            hipLaunchKernelGGL(kern, wgrid, dim3(512), C3S2::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tiles_x);
+        } else {
+            auto kern = conv_window_s2_kernel<32>;
+            LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3S2::LDS));
+            hipLaunchKernelGGL(kern, wgrid, dim3(512), C3S2::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tiles_x);
+        }
     } else if (g.group == 1 && g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.sh == g.sw && (g.sh == 1 || g.sh == 2) && g.oc <= 16 &&
                g.c <= 64 && g.ow >= 16 && g.n <= 65535 &&
                (int64_t)g.n * ((g.ow + 31) / 32) * ((g.oh + 7) / 8) >= 2 * (int64_t)ctx->num_cus) {

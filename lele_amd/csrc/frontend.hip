@@ -149,11 +149,12 @@ constexpr int kStdMelOff[6] = {0, 3, 7, 13, 23, 40};
 // FUSED: the block first stages its run of PCM (64 frames = 10 480 samples, read from HBM once) into an LDS tile that
 // aliases the exchange region, wave 0 computes the 64 exact sequential frame sums from it (as fe_frame_sum_kernel
 // does), and the per-pass sample loads below then hit L2 -- no separate sum kernel, no second HBM read of the PCM.
-// PASSES: frames per workgroup = 16 * PASSES (a wave takes 4 frames a pass).  LOWREG (the four-waves-per-SIMD form, fe_main_w4_kernel):
-// the 25 window coefficients of a lane are re-read from the (L1-resident) table every pass instead of living in registers, and the
-// next pass's samples are requested only once the 32 complex points of phase A have left for the exchange -- the two arrays that
-// kept the kernel at 168 registers a lane (three waves per SIMD); with PASSES = 3 the PCM tile of a run fits the exchange region
-// it aliases (50 hop rows, 32.8 KB) and four workgroups share a CU.  Same arithmetic in the same order: the same bits.
+// PASSES: frames per workgroup = 16 * PASSES (a wave takes 4 frames a pass).  LOWREG: the 25 window coefficients of a lane are
+// re-read from the (L1-resident) table every pass instead of living in registers, and the next pass's samples are requested only
+// once the 32 complex points of phase A have left for the exchange.  Built in round 4 to reach four waves per SIMD (<= 128
+// registers, PASSES = 3 so that four workgroups' LDS fits a CU): the compiler still spilled 48 registers at that budget and the
+// kernel ran at 7.41 ms per 2048 x 30 s against 3.80 ms (bit-identical results) -- the product instantiates <4, false> only; see
+// docs/experiments.md.
 template <int MODE, bool STDMEL, bool FUSED, int PASSES, bool LOWREG>
 __device__ __forceinline__ void fe_main_body(const float* __restrict__ pcm, int64_t utt_stride,
                                              int64_t num_frames, int64_t t_lfr,
@@ -420,13 +421,6 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
     extern __shared__ float s_melw[];  // [mel_steps][16] (the table-driven mel loop only)
     fe_main_body<MODE, STDMEL, FUSED, 4, false>(pcm, utt_stride, num_frames, t_lfr, means, tb, out, logmel_out, aligned16, s_melw);
 }
-// four waves per SIMD (<= 128 registers a lane), 48 frames per workgroup, four workgroups per CU: see fe_main_body
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fe_main_w4_kernel(
-    const float* __restrict__ pcm, int64_t utt_stride, int64_t num_frames, int64_t t_lfr, const float* __restrict__ means, FeDev tb,
-    float* __restrict__ out, float* __restrict__ logmel_out, int aligned16) {
-    fe_main_body<1, true, true, 3, true>(pcm, utt_stride, num_frames, t_lfr, means, tb, out, logmel_out, aligned16, nullptr);
-}
-
 // ------------------------------------------------------------------------------------------------------
 // Generic path: any FeatureConfig the reference accepts (other sample rates / frame lengths / n_fft = 1024).
 // The same operations in the same order as pipeline.rs:84-187, spread over four simple kernels + the generic
@@ -497,7 +491,6 @@ struct LeleFrontend {
     bool std_mel = false;  // mel bank has the default round structure (fully unrolled kernel variant)
     int dpp_mode = 0;  // 0: __shfl, 1: DPP row_ror (selected after a self-test)
     bool fused = true;  // frame sums computed inside fe_main_kernel (LELE_HIP_FE_FUSED=0 selects the two-kernel form)
-    bool w4 = false;    // fe_main_w4_kernel (four waves per SIMD, 48 frames per workgroup) instead of fe_main_kernel: LELE_HIP_FE_W4
     // generic path tables (configs other than 400/160/512)
     const float* g_window = nullptr;
     const int* g_mstart = nullptr;
@@ -696,8 +689,6 @@ int lele_hip_frontend_create(LeleCtx* ctx, const LeleFeatureConfig* cfg, LeleFro
     fe->dpp_mode = env ? atoi(env) : 1;  // 1: DPP row_ror (default), 0: __shfl (ds_bpermute)
     const char* envf = lab_env("LELE_HIP_FE_FUSED");
     fe->fused = envf ? atoi(envf) != 0 : true;
-    const char* envw = getenv("LELE_HIP_FE_W4");
-    fe->w4 = envw ? atoi(envw) != 0 : false;
     *out = fe;
     return 0;
 }
@@ -775,8 +766,7 @@ static int fe_run(LeleFrontend* fe, const LeleTensor* pcm, int64_t batch, int64_
         return 0;
     }
     const int aligned16 = ((uintptr_t)dpcm % 16 == 0) && (pcm_len % 4 == 0);
-    const bool w4 = fe->w4 && fe->fused && fe->std_mel && fe->dpp_mode == 1;
-    dim3 grid((unsigned)(w4 ? (nf + 47) / 48 : (nf + 63) / 64), (unsigned)batch);
+    dim3 grid((unsigned)((nf + 63) / 64), (unsigned)batch);
     hipEvent_t* ev = nullptr;
     if (fe->profiling) {
         if (fe->events_used + 3 > fe->events.size()) {
@@ -807,10 +797,7 @@ static int fe_run(LeleFrontend* fe, const LeleTensor* pcm, int64_t batch, int64_
         else                  \
             FE_LAUNCH(MODE, STD, false); \
     } while (0)
-    if (w4) {
-        hipLaunchKernelGGL(fe_main_w4_kernel, grid, dim3(256), 0, ctx->stream, (const float*)dpcm, pcm_len, nf, t_lfr, (const float*)dmean,
-                           fe->dev, o, lm, aligned16);
-    } else if (fe->dpp_mode == 1) {
+    if (fe->dpp_mode == 1) {
         if (fe->std_mel) FE_LAUNCH2(1, true); else FE_LAUNCH2(1, false);
     } else {
         if (fe->std_mel) FE_LAUNCH2(0, true); else FE_LAUNCH2(0, false);

@@ -202,35 +202,57 @@ __global__ __launch_bounds__(256) void qrows_frag_kernel(const float* __restrict
 
 // ------------------------------------------------------------------------------------------ LayerNorm -> fragment-major i8, ONE kernel
 // layer_norm (last axis) -> per-slice dynamic range -> rows quantised into fragment order, for batches of short slices (one
-// utterance of a SenseVoice shard: 171 rows of 512): ONE workgroup of 1024 threads owns a whole slice and keeps it in REGISTERS --
-// 16 waves x 64 lanes x 96 values -- between the normalisation and the quantisation, so that the slice's range, which every row's
-// quantisation waits for, is a workgroup-local reduction (one __syncthreads) instead of a kernel boundary.  Neither the normalised
-// tensor nor row statistics ever reach memory: x is read once, the i8 fragments written once.  (The two-kernel form -- a statistics
-// pass + qrows_frag_kernel with LnApply -- measured 6.7 + 11.3 us per [5472 x 512] against 7.1 + 10.5 for LayerNorm + the plain
-// quantiser: at this size a kernel costs its launch, first touch and drain whatever it moves, so only a kernel LESS helps.)
-// Lane l of a 32-lane group holds elements 32 c + l of its row, the layout of layer_norm_reg_kernel, whose arithmetic this repeats
-// statement for statement (row_sums_reg: lele's 4 x 8 accumulator order; fma inside the row's 8-wide body); the quantiser is
-// qrows_frag_kernel's.  A pass = 32 rows (two per wave); their bytes take a turn through LDS so that wave w writes the k-step-w
-// blocks of the pass as 16-byte pieces (row pitch 528 bytes: the 32 rows of a read fall on all 64 banks once).
-// grid = slices, block = 1024, k <= 512 (kp = 512), m <= 32 NP.
-template <int NP>
-__global__ __launch_bounds__(1024) void ln_qfrag_slice_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                                                              float eps, int k, int m, unsigned rows_total, QParams* __restrict__ prm,
-                                                              int8_t* __restrict__ af, int* __restrict__ row_sums, unsigned* __restrict__ zero_slice) {
+// utterance of a SenseVoice shard: 171 rows of 512).  The dynamic quantisation needs the range of the WHOLE slice before its first
+// row can be quantised -- as separate kernels that is a kernel boundary (LayerNorm | quantiser: 7.1 + 10.5 us per [5472 x 512],
+// each of them its launch, first touch and drain rather than its 14 MB), and folding the normalisation into the quantiser did not
+// change the count (statistics pass 6.7 + 11.3 us).  Here the G workgroups that share a slice keep their rows -- normalised -- in
+// REGISTERS, meet at a per-slice record in memory (one atomic min, one atomic max, one arrival counter: a fan-in among G = 8
+// workgroups, not a grid barrier), and quantise from registers: x is read once, the fragments written once, one launch.
+//   * record {min, max (order-preserving integer images of the floats), arrived, departed}: device-scope atomics only, read back with
+//     no-op atomics (a load could be served by the reader's own, non-coherent L2); the last workgroup to depart resets the record, so
+//     the next launch on the stream finds it clean (graph replays included);
+//   * every workgroup of the grid must be resident at once: grid = slices x G <= 2 x CUs (the host checks), 256 threads, ~60 registers;
+//   * the wait is BOUNDED: a workgroup that does not see its slice complete gives up, raises LELE_DEVERR_GROUP_TIMEOUT (reported by
+//     the next sync) and quantises with what it has -- a wrong result that says so instead of a hung device.
+// Lane l of a 32-lane group holds elements 32 c + l of its row: layer_norm_reg_kernel's layout and arithmetic, statement for
+// statement (row_sums_reg: lele's 4 x 8 accumulator order; fma inside the 8-wide body), and qrows_frag_kernel's quantiser.
+struct SliceRec {
+    int mn, mx;
+    unsigned arrived, departed;
+};
+__device__ __forceinline__ int f32_ordered(float f) {  // monotone float -> int (finite values and infinities)
+    const int b = __float_as_int(f);
+    return b >= 0 ? b : (int)(0x80000000u - (unsigned)b);
+}
+__device__ __forceinline__ float ordered_f32(int i) { return __int_as_float(i >= 0 ? i : (int)(0x80000000u - (unsigned)i)); }
+constexpr int kSliceRecMnInit = 0x7f800000;  // the image of +inf (the maximum starts at the image of -inf)
+__global__ void slice_rec_init_kernel(SliceRec* rec, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rec[i] = SliceRec{kSliceRecMnInit, f32_ordered(-INFINITY), 0u, 0u};
+}
+template <int NP /* passes of 8 rows a workgroup holds */>
+__global__ __launch_bounds__(256) void ln_qfrag_group_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                             float eps, int k, int m, int G, int rpg /* rows per workgroup */,
+                                                             unsigned rows_total, SliceRec* __restrict__ rec, QParams* __restrict__ prm,
+                                                             int8_t* __restrict__ af, int* __restrict__ row_sums,
+                                                             unsigned* __restrict__ zero_slice, unsigned* __restrict__ deverr) {
     constexpr int NT = 16, KS = 16, PITCH = 528;
     __shared__ float s_g[512], s_b[512];
-    __shared__ float s_mn[32], s_mx[32];
-    __shared__ __attribute__((aligned(16))) unsigned char s_q[32 * PITCH];
-    const int tid = threadIdx.x, l = tid & 31, grp = tid >> 5, lane = tid & 63, wave = tid >> 6;
-    const unsigned s = blockIdx.x, row0 = s * (unsigned)m;
-    for (int i = tid; i < 512; i += 1024) {
+    __shared__ float s_mn[8], s_mx[8];
+    __shared__ float s_rng[2];
+    __shared__ __attribute__((aligned(16))) unsigned char s_q[8 * PITCH];
+    const int tid = threadIdx.x, l = tid & 31, grp = tid >> 5;
+    const unsigned s = blockIdx.x / (unsigned)G, gi = blockIdx.x - s * (unsigned)G;
+    const int r_lo = (int)gi * rpg, r_hi = r_lo + rpg < m ? r_lo + rpg : m;  // this workgroup's rows of the slice: [r_lo, r_hi), never empty
+    const unsigned row0 = s * (unsigned)m;
+    for (int i = tid; i < 512; i += 256) {
         s_g[i] = g[i < k ? i : k - 1];
         s_b[i] = b[i < k ? i : k - 1];
     }
     float v[NP][NT];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const int r = 32 * p + grp, rc = r < m ? r : m - 1;  // rows beyond the slice repeat its last row: same statistics, nothing stored
+        const int r = r_lo + 8 * p + grp, rc = r < r_hi ? r : r_hi - 1;  // slots beyond the range repeat its last row: same statistics
         const float* in = x + (size_t)(row0 + (unsigned)rc) * k;
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
@@ -268,10 +290,41 @@ __global__ __launch_bounds__(1024) void ln_qfrag_slice_kernel(const float* __res
         s_mx[grp] = mx;
     }
     __syncthreads();
-    mn = group_allreduce32(s_mn[l], [](float cur, float a) { return a < cur ? a : cur; });
-    mx = group_allreduce32(s_mx[l], [](float cur, float a) { return a > cur ? a : cur; });
-    const QParams q = make_qparams(mn, mx);
     if (tid == 0) {
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {
+            mn = s_mn[i] < mn ? s_mn[i] : mn;
+            mx = s_mx[i] > mx ? s_mx[i] : mx;
+        }
+        SliceRec* rc = rec + s;
+        // returning atomics: their values come back only once the operations are done where every XCD sees them
+        const int o1 = __hip_atomic_fetch_min(&rc->mn, f32_ordered(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int o2 = __hip_atomic_fetch_max(&rc->mx, f32_ordered(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(o1), "v"(o2));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned seen = __hip_atomic_fetch_add(&rc->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        int spins = 0;
+        while (seen < (unsigned)G && spins < (1 << 18)) {
+            __builtin_amdgcn_s_sleep(8);
+            seen = __hip_atomic_fetch_add(&rc->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ++spins;
+        }
+        if (seen < (unsigned)G) *deverr = LELE_DEVERR_GROUP_TIMEOUT;
+        const int gmn = __hip_atomic_fetch_min(&rc->mn, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int gmx = __hip_atomic_fetch_max(&rc->mx, (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_rng[0] = ordered_f32(gmn);
+        s_rng[1] = ordered_f32(gmx);
+        // the last one out puts the record back for the next launch
+        if (__hip_atomic_fetch_add(&rc->departed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)G) {
+            __hip_atomic_store(&rc->mn, kSliceRecMnInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&rc->mx, f32_ordered(-INFINITY), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&rc->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&rc->departed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    const QParams q = make_qparams(s_rng[0], s_rng[1]);
+    if (tid == 0 && gi == 0) {
         prm[s] = q;
         if (zero_slice) zero_slice[s] = 0u;
     }
@@ -279,8 +332,8 @@ __global__ __launch_bounds__(1024) void ln_qfrag_slice_kernel(const float* __res
     auto addi = [](float a, float c) { return __int_as_float(__float_as_int(a) + __float_as_int(c)); };
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        if (32 * p >= m) break;  // uniform
-        const int r = 32 * p + grp;
+        if (r_lo + 8 * p >= r_hi) break;  // uniform
+        const int r = r_lo + 8 * p + grp;
         int sacc = 0;
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
@@ -293,24 +346,26 @@ __global__ __launch_bounds__(1024) void ln_qfrag_slice_kernel(const float* __res
             s_q[grp * PITCH + j] = (unsigned char)(val & 0xff);
         }
         const int tot = __float_as_int(group_allreduce32(__int_as_float(sacc), addi));
-        if (l == 0 && r < m && row_sums) row_sums[row0 + (unsigned)r] = tot;
+        if (l == 0 && r < r_hi && row_sums) row_sums[row0 + (unsigned)r] = tot;
         __syncthreads();
-        {   // wave w writes k-step w of the pass: lane L = (row of the pass, half of the step)
-            const int rr = lane & 31, half = lane >> 5;
-            if (32 * p + rr < m) {
-                const unsigned grow = row0 + (unsigned)(32 * p + rr);
-                const v4i piece = *reinterpret_cast<const v4i*>(s_q + rr * PITCH + (2 * wave + half) * 16);
-                *reinterpret_cast<v4i*>(af + (((size_t)(grow >> 5) * KS + wave) * 64 + (grow & 31u) + 32u * half) * 16) = piece;
+        {   // 8 rows x 32 chunks of 16 bytes = 256 pieces: thread t moves piece (row t & 7, chunk t >> 3)
+            const int rr = tid & 7, chunk = tid >> 3;
+            if (r_lo + 8 * p + rr < r_hi) {
+                const unsigned grow = row0 + (unsigned)(r_lo + 8 * p + rr);
+                const v4i piece = *reinterpret_cast<const v4i*>(s_q + rr * PITCH + chunk * 16);
+                *reinterpret_cast<v4i*>(af + (((size_t)(grow >> 5) * KS + (chunk >> 1)) * 64 + (grow & 31u) + 32u * (chunk & 1)) * 16) = piece;
             }
         }
         __syncthreads();
     }
     // the rows that pad the last tile of the tensor are zeros (the GEMM multiplies whole tiles)
-    if (s == gridDim.x - 1 && (rows_total & 31u)) {
-        const int rr = lane & 31, half = lane >> 5;
-        const unsigned grow = (rows_total & ~31u) + (unsigned)rr;
-        if (grow >= rows_total)
-            *reinterpret_cast<v4i*>(af + (((size_t)(grow >> 5) * KS + wave) * 64 + (grow & 31u) + 32u * half) * 16) = v4i{0, 0, 0, 0};
+    if (blockIdx.x == gridDim.x - 1 && (rows_total & 31u)) {
+        for (int t = tid; t < 32 * 32; t += 256) {
+            const int rr = t & 31, chunk = t >> 5;
+            const unsigned grow = (rows_total & ~31u) + (unsigned)rr;
+            if (grow >= rows_total)
+                *reinterpret_cast<v4i*>(af + (((size_t)(grow >> 5) * KS + (chunk >> 1)) * 64 + (grow & 31u) + 32u * (chunk & 1)) * 16) = v4i{0, 0, 0, 0};
+        }
     }
 }
 

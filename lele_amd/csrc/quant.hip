@@ -1119,20 +1119,34 @@ int launch_qrows_frag(LeleCtx* ctx, const float* dx, int64_t rows, int k, int kp
     LELE_HIP_CHECK(hipGetLastError());
     return 0;
 }
-// LayerNorm + range + quantise-to-fragments in one kernel (ln_qfrag_slice_kernel): slices short enough to live in one workgroup's
-// registers, enough of them to be worth a chip, K = 512 fragments
-bool ln_slice_fits(LeleCtx* ctx, int64_t batch, int64_t m, int64_t k) {
-    return k >= 8 && k <= 512 && m >= 1 && m <= 192 && batch >= 8 && batch * m < (int64_t(1) << 31) && env_int("LELE_HIP_LN_SLICE", 1) != 0;
+// LayerNorm + slice range + quantise-to-fragments in ONE kernel (ln_qfrag_group_kernel): G workgroups per slice meet at a record in
+// memory.  Every workgroup of the grid must be resident at once, and a workgroup holds at most 24 rows.
+int ln_group_size(LeleCtx* ctx, int64_t batch, int64_t m, int64_t k) {
+    if (k < 8 || k > 512 || m < 1 || batch < 4 || batch * m >= (int64_t(1) << 31) || env_int("LELE_HIP_LN_GROUP", 1) == 0) return 0;
+    for (int G = 8; G >= 2; G >>= 1)
+        if (batch * G <= 2 * (int64_t)ctx->num_cus && (m + G - 1) / G <= 24) return G;
+    return 0;
 }
-int launch_ln_qfrag_slice(LeleCtx* ctx, const float* dx, const float* dg, const float* db, float eps, int64_t batch, int m, int k, QParams* prm,
-                          int8_t* af, int* rs, unsigned* zero_slice) {
+int launch_ln_qfrag_group(LeleCtx* ctx, int G, const float* dx, const float* dg, const float* db, float eps, int64_t batch, int m, int k,
+                          QParams* prm, int8_t* af, int* rs, unsigned* zero_slice) {
+    LeleBuf* rb = nullptr;
+    LELE_TRY(ctx->tmp_buf(5, &rb));
+    const void* before = rb->data;
+    const size_t had = rb->cap;
+    LELE_TRY(rb->reserve((size_t)batch * sizeof(SliceRec)));
+    if (rb->data != before || had == 0) {  // a fresh allocation: every record in its rest state (the kernels put them back themselves)
+        const int nrec = (int)(rb->cap / sizeof(SliceRec));
+        hipLaunchKernelGGL(slice_rec_init_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, ctx->stream, (SliceRec*)rb->data, nrec);
+    }
     const unsigned rows = (unsigned)(batch * m);
-#define LELE_LNQ(NP_) \
-    hipLaunchKernelGGL((ln_qfrag_slice_kernel<NP_>), dim3((unsigned)batch), dim3(1024), 0, ctx->stream, dx, dg, db, eps, k, m, rows, prm, af, rs, zero_slice)
-    if (m <= 64) LELE_LNQ(2);
-    else if (m <= 128) LELE_LNQ(4);
-    else LELE_LNQ(6);
-#undef LELE_LNQ
+    const int rpg = (m + G - 1) / G;
+#define LELE_LNG(NP_)                                                                                                                  \
+    hipLaunchKernelGGL((ln_qfrag_group_kernel<NP_>), dim3((unsigned)(batch * G)), dim3(256), 0, ctx->stream, dx, dg, db, eps, k, m, G, rpg, rows, \
+                       (SliceRec*)rb->data, prm, af, rs, zero_slice, ctx->deverr_dev)
+    if (rpg <= 8) LELE_LNG(1);
+    else if (rpg <= 16) LELE_LNG(2);
+    else LELE_LNG(3);
+#undef LELE_LNG
     LELE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1335,9 +1349,9 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     const float* partial = nullptr;
     int nblk = 0;
     LnApply ln{nullptr, nullptr, nullptr};
-    // LayerNorm in front, register-stationary route, short slices: ONE kernel from x to the i8 fragments (ln_qfrag_slice_kernel)
-    const bool ln_slice = lnf && rs_fits(ctx, rows, n, rs_kp(k)) && ln_slice_fits(ctx, batch, m, k);
-    if (lnf && !ln_slice) {  // the operand's OWN statistics (if its producer left any) describe x, not LayerNorm(x)
+    // LayerNorm in front, register-stationary route, a batch of short slices: ONE kernel from x to the i8 fragments
+    const int ln_G = lnf && rs_fits(ctx, rows, n, rs_kp(k)) ? ln_group_size(ctx, batch, m, k) : 0;
+    if (lnf && !ln_G) {  // the operand's OWN statistics (if its producer left any) describe x, not LayerNorm(x)
         LELE_TRY(ln_prepare(ctx, lnf, (const float*)dx, rows, k, &partial, &ln));
         nblk = (int)m;
     } else if (!lnf) {
@@ -1346,7 +1360,7 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     void* prm = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm));
     LELE_TRY(qprof_mark(ctx, 0));
-    if (!partial && !ln_slice) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
+    if (!partial && !ln_G) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
     LELE_TRY(qprof_mark(ctx, 1));
 
     // ---- register-stationary route (igemm_rs.h): rows -> i8 in fragment order, then the barrier-free GEMM
@@ -1357,11 +1371,11 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
         void *af = nullptr, *rs = nullptr;
         LELE_TRY(ctx->arena_alloc((size_t)nrt * kprs * 32, &af));
         if (kprs == 512) LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));  // K = 2048: the GEMM sums the rows it loads anyway
-        if (ln_slice) {
+        if (ln_G) {
             const void *dg = nullptr, *dbt = nullptr;
             LELE_TRY(ctx->dev_ptr(lnf->scale, &dg));
             LELE_TRY(ctx->dev_ptr(lnf->bias, &dbt));
-            LELE_TRY(launch_ln_qfrag_slice(ctx, (const float*)dx, (const float*)dg, (const float*)dbt, lnf->eps, batch, (int)m, (int)k, (QParams*)prm,
+            LELE_TRY(launch_ln_qfrag_group(ctx, ln_G, (const float*)dx, (const float*)dg, (const float*)dbt, lnf->eps, batch, (int)m, (int)k, (QParams*)prm,
                                            (int8_t*)af, (int*)rs, nullptr));
         } else {
             LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k, kprs, (int)m, (QParams*)prm, (int8_t*)af, (int*)rs, partial, nblk, nullptr, ln));
@@ -1545,8 +1559,8 @@ static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_
     const float* partial = nullptr;
     int nblk = 0;
     LnApply ln{nullptr, nullptr, nullptr};
-    const bool ln_slice = lnf && rs_route && ln_slice_fits(ctx, batch, m, k1);
-    if (lnf && !ln_slice) {
+    const int ln_G = lnf && rs_route ? ln_group_size(ctx, batch, m, k1) : 0;
+    if (lnf && !ln_G) {
         LELE_TRY(ln_prepare(ctx, lnf, (const float*)dx, rows, k1, &partial, &ln));
         nblk = (int)m;
     } else if (!lnf) {
@@ -1556,7 +1570,7 @@ static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_
     LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm1));
     LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm2));
     LELE_TRY(qprof_mark(ctx, 0));
-    if (!partial && !ln_slice) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k1, (QParams*)prm1, nullptr, nullptr, &partial, &nblk));
+    if (!partial && !ln_G) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k1, (QParams*)prm1, nullptr, nullptr, &partial, &nblk));
     LELE_TRY(qprof_mark(ctx, 1));
     if (rs_route) {
         FragW fw1, fw2;
@@ -1569,12 +1583,12 @@ static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_
         LELE_TRY(ctx->arena_alloc((size_t)nrt * 2048 * 32, &hid));
         LELE_TRY(ctx->arena_alloc((size_t)batch * 4, &hmax));
         // rows -> i8 for the first product; the same launch clears the per-slice maxima the range pass adds into
-        if (ln_slice) {
+        if (ln_G) {
             const void *dg = nullptr, *dbt = nullptr;
             LELE_TRY(ctx->dev_ptr(lnf->scale, &dg));
             LELE_TRY(ctx->dev_ptr(lnf->bias, &dbt));
-            LELE_TRY(launch_ln_qfrag_slice(ctx, (const float*)dx, (const float*)dg, (const float*)dbt, lnf->eps, batch, (int)m, (int)k1, (QParams*)prm1,
-                                           (int8_t*)af1, (int*)rs1, (unsigned*)hmax));
+            LELE_TRY(launch_ln_qfrag_group(ctx, ln_G, (const float*)dx, (const float*)dg, (const float*)dbt, lnf->eps, batch, (int)m, (int)k1,
+                                           (QParams*)prm1, (int8_t*)af1, (int*)rs1, (unsigned*)hmax));
         } else {
             LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k1, 512, (int)m, (QParams*)prm1, (int8_t*)af1, (int*)rs1, partial, nblk,
                                        (unsigned*)hmax, ln));

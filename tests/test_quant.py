@@ -443,10 +443,12 @@ def test_layer_norm_folded_into_the_quantised_linears_is_the_two_calls_bit_for_b
         w = np.clip(np.round(128 + 40 * rng.standard_normal((k, n))), 0, 255).astype(np.float32)
         return (Weight(w), Weight((np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32)), Weight(np.array([128.0], np.float32)),
                 Weight((rng.standard_normal(n) * 0.02).astype(np.float32)))
-    # (32 | 33, 171), (64, 37), (40, 100): enough short slices for the ONE-kernel form (a workgroup keeps a slice in registers: 6, 2 and
-    # 4 passes of 32 rows; 33 x 171 rows leave a ragged last tile, K = 500 a scalar tail in the normalisation and in the quantiser);
-    # the others take the statistics pass + the normalising row quantisers (both GEMM routes)
-    for (b, m, k, n) in ((32, 171, 512, 1536), (33, 171, 512, 1536), (64, 37, 512, 1024), (40, 100, 500, 1024), (1, 504, 512, 2048), (1, 504, 560, 1536),
+    # (32 | 33, 171), (64, 37), (40, 100), (100, 40): batches of short slices take the ONE-kernel form (the G = 8 or 4 workgroups of a
+    # slice keep their rows in registers and meet at a record in memory for the slice's range: 3, 1, 2 and 2 passes of 8 rows;
+    # 33 x 171 rows leave a ragged last tile, K = 500 a scalar tail in the normalisation and in the quantiser); the others take the
+    # statistics pass + the normalising row quantisers (both GEMM routes)
+    for (b, m, k, n) in ((32, 171, 512, 1536), (33, 171, 512, 1536), (64, 37, 512, 1024), (40, 100, 500, 1024), (100, 40, 512, 1024), (1, 504, 512, 2048),
+                         (1, 504, 560, 1536),
                          (3, 37, 512, 1024), (2, 33, 100, 64), (3, 7, 13, 5), (1, 1, 8, 3), (4, 64, 1000, 96)):
         x = (rng.standard_normal((b, m, k)) * (1 + rng.random((b, m, 1)) * 3) + rng.standard_normal((b, 1, 1))).astype(np.float32)
         g = Weight((1 + 0.1 * rng.standard_normal(k)).astype(np.float32))
@@ -457,7 +459,7 @@ def test_layer_norm_folded_into_the_quantised_linears_is_the_two_calls_bit_for_b
             two = K.fused_quantized_linear(K.layer_norm(dx, g, be, -1, 1e-5, ctx=ctx), *w, relu, ctx=ctx).numpy()
             one = K.layer_norm_fused_quantized_linear(dx, g, be, -1, 1e-5, *w, relu, ctx=ctx).numpy()
             assert np.array_equal(one, two), (b, m, k, n, relu)
-        if b * m * k <= 600_000 or (b, m) in ((64, 37), (40, 100)):
+        if b * m * k <= 600_000 or (b, m) in ((64, 37), (40, 100), (100, 40)):
             want = O.fused_quantized_linear(O.layer_norm(x, g.arr, be.arr, -1, 1e-5), w[0].arr, w[1].arr, w[2].arr, w[3].arr, False)
             assert np.array_equal(K.layer_norm_fused_quantized_linear(dx, g, be, -1, 1e-5, *w, False, ctx=ctx).numpy(), want), (b, m, k, n)
         # an axis that is not the last one runs the two calls
@@ -476,6 +478,14 @@ def test_layer_norm_folded_into_the_quantised_linears_is_the_two_calls_bit_for_b
         two = K.fused_ffn_quantized(K.layer_norm(dx, g, be, -1, 1e-5, ctx=ctx), *w1, *w2, False, r1, ctx=ctx).numpy()
         one = K.layer_norm_fused_ffn_quantized(dx, g, be, -1, 1e-5, *w1, *w2, False, r1, ctx=ctx).numpy()
         assert np.array_equal(one, two), (b, m, k1, n1, n2)
+    # the rendezvous records put themselves back: 200 launches back to back, every result the first one's
+    x = (rng.standard_normal((32, 171, 512)) * 2).astype(np.float32)
+    dx, ob = ctx.buf().upload(x), ctx.buf()
+    g, be, w = Weight((1 + 0.1 * rng.standard_normal(512)).astype(np.float32)), Weight((0.1 * rng.standard_normal(512)).astype(np.float32)), lin(512, 1536)
+    ref = K.layer_norm_fused_quantized_linear(dx, g, be, -1, 1e-5, *w, False, out=ob, ctx=ctx).numpy().copy()
+    assert np.array_equal(ref, K.fused_quantized_linear(K.layer_norm(dx, g, be, -1, 1e-5, ctx=ctx), *w, False, ctx=ctx).numpy())
+    bad = [it for it in range(200) if not np.array_equal(K.layer_norm_fused_quantized_linear(dx, g, be, -1, 1e-5, *w, False, out=ob, ctx=ctx).numpy(), ref)]
+    assert not bad, bad[:10]
     # recorded into a graph and replayed (the statistics live in a context buffer sized by the eager run)
     x = (rng.standard_normal((32, 171, 512)) * 2).astype(np.float32)
     dx, ob = ctx.buf().upload(x), ctx.buf()
