@@ -184,6 +184,46 @@ def cpu_baseline_model(enc_arrays, feats, budget_s=14.0):
                             % (len(per), nl, sum(per) + head)}
 
 
+def cpu_baseline_model_all_cores(enc_arrays, feats, budget_s=6.0):
+    """BASELINE.md section 3 `cpu-Nt` for the recogniser: lele runs one forward on one thread (Par::Seq everywhere), so its only route
+    to many cores is one independent instance per core.  One forked worker per granted hardware thread, each running the oracle's
+    layer stack (oracle/sensevoice_ref.py) on its own copy of one 30 s utterance for `budget_s` seconds; throughput = layers finished
+    over all workers, scaled to whole 70-layer forwards (+ the CTC head's share as timed on one core)."""
+    from oracle import sensevoice_ref as R
+    cores, hw = cpu_quota()
+    x0 = np.concatenate([enc_arrays["prompt"], feats], axis=1).astype(np.float32)
+    layers = enc_arrays["layers"]
+    R.layer_forward(x0, layers[0])  # code / tables warm before the fork
+    pipes = []
+    t0 = time.perf_counter()
+    for i in range(cores):
+        r, w = os.pipe()
+        pid = os.fork()
+        if pid == 0:  # child: oracle only, no HIP calls, leaves through _exit
+            os.close(r)
+            cnt, stop = 0, time.perf_counter() + budget_s
+            x = R.layer_forward(x0, layers[0])
+            while time.perf_counter() < stop:
+                x = R.layer_forward(x, layers[1 + cnt % (len(layers) - 1)])
+                cnt += 1
+            os.write(w, str(cnt).encode())
+            os._exit(0)
+        os.close(w)
+        pipes.append((pid, r))
+    total = 0
+    for pid, r in pipes:
+        total += int(os.read(r, 64) or b"0")
+        os.close(r)
+        os.waitpid(pid, 0)
+    el = time.perf_counter() - t0
+    nl = len(layers)
+    fwd_per_s = total / float(nl) / el if el > 0 else 0.0
+    audio = feats.shape[0] * SECONDS
+    return {"model_rtf_all_cores": round(1.0 / (fwd_per_s * audio), 7) if fwd_per_s > 0 else None, "model_all_cores": cores,
+            "model_all_cores_sample": "%d layer forwards of a 30 s utterance by %d single-threaded oracle processes (quota %d of %d hw threads) in %.1f s "
+                                      "= %.2f 70-layer forwards per second (the CTC head, ~3 %% of a forward, not included)" % (total, cores, cores, hw, el, fwd_per_s)}
+
+
 # ----------------------------------------------------------------------------------------------- the two legs
 def frontend_leg(args, ctx, rank, world, fence, dist, device):
     from lele_amd.features import SenseVoiceFrontend
@@ -667,6 +707,8 @@ def run_rank(args):
                 cb.update(cpu_baseline_model(encoder_arrays(enc), feats))
             line["cpu_baseline"] = cb
             line["cpu_baseline_all_cores"] = cpu_baseline_frontend_all_cores(n)
+            if enc is not None and feats is not None:
+                line["cpu_baseline_all_cores"].update(cpu_baseline_model_all_cores(encoder_arrays(enc), feats))
         emit_last_line(json.dumps(line))
     if dist is not None:
         dist.barrier()
