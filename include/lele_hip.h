@@ -411,21 +411,6 @@ int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const Le
                                  const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8,
                                  const LeleTensor* w2_scale, const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2,
                                  const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
-/* layer_norm (norm.rs:226 -> avx/norm.rs:10) followed by fused_quantized_linear / by the feed-forward block above, the normalised
- * tensor private to it: `x` is the LayerNorm's operand, ln_* its scale / bias / axis / epsilon, the rest the consumer's arguments.
- * The normalised tensor is never stored -- a statistics pass leaves {mean, 1 / std, min, max} per row and the linear's row
- * quantiser normalises each value as it loads it, with the operator's own expression: the bits of the two calls.  (Axis not last,
- * rows longer than 1024 or slices longer than 2048 rows: the two calls run.) */
-int lele_hip_layer_norm_fused_quantized_linear(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* ln_scale, const LeleTensor* ln_bias,
-                                               int32_t ln_axis, float ln_eps, const LeleTensor* weight_int8, const LeleTensor* weight_scale,
-                                               const LeleTensor* weight_zero, const LeleTensor* bias, int apply_relu, LeleBuf* out,
-                                               int64_t* out_shape, int32_t* out_rank);
-int lele_hip_layer_norm_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* ln_scale, const LeleTensor* ln_bias,
-                                            int32_t ln_axis, float ln_eps, const LeleTensor* w1_int8, const LeleTensor* w1_scale,
-                                            const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8,
-                                            const LeleTensor* w2_scale, const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2,
-                                            const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out, int64_t* out_shape,
-                                            int32_t* out_rank);
 /* softmax(x * scale[0]) over the last axis: `mul` by a one-element tensor followed by `softmax` (norm.rs:8) */
 int lele_hip_softmax_scaled(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, int32_t axis, LeleBuf* out,
                             int64_t* out_shape, int32_t* out_rank);

@@ -806,56 +806,6 @@ class Lowering:
             dead.add(i)
         self.statements[:] = [st for i, st in enumerate(sts) if i not in dead]
 
-    def fold_layer_norms(self):
-        """layer_norm over the last axis whose result is read once, as the input of a fused_quantized_linear or of a
-        fused_ffn_quantized: ONE statement (`layer_norm_fused_quantized_linear` / `layer_norm_fused_ffn_quantized`) in the consumer's
-        place -- the normalised tensor, written only to be quantised, is never stored.  The run-time forms run the two calls where
-        their fold does not apply, so the rewrite is always legal.  (The LayerNorm's operand stays alive until then: it is the
-        merged statement's first argument.)"""
-        sts = self.statements
-        outs = {sanitize(o) for o in self.outputs}
-        readers = {}
-
-        def refs(n, acc):
-            if isinstance(n, dict):
-                for key in ("ref", "ints"):
-                    if isinstance(n.get(key), str):
-                        acc.append(n[key])
-                for v in n.values():
-                    refs(v, acc)
-            elif isinstance(n, list):
-                for v in n:
-                    refs(v, acc)
-            return acc
-        for i, st in enumerate(sts):
-            names = refs(st.get("args", st.get("in")), [])
-            if st["op"] == "if":
-                names += refs([st.get("then"), st.get("else"), st.get("cond")], [])
-            for r in names:
-                readers.setdefault(r, []).append(i)
-        dead = set()
-        for i, st in enumerate(sts):
-            if st.get("fn") != "layer_norm" or st["args"][3] != {"int": -1}:
-                continue
-            xn = st["out"][0]
-            rd = readers.get(xn, [])
-            if len(rd) != 1 or xn in outs or rd[0] <= i:
-                continue
-            use = sts[rd[0]]
-            if use.get("op") != "call" or use.get("fn") not in ("fused_quantized_linear", "fused_ffn_quantized"):
-                continue
-            b = use["args"]
-            if b[0] != {"ref": xn} or refs(b[1:], []).count(xn):
-                continue
-            # the operand must not be redefined between the two statements (plans are single-assignment; lifted ones may not be)
-            x = st["args"][0].get("ref")
-            if x is None or any(x in s2.get("out", []) for s2 in sts[i + 1:rd[0]]):
-                continue
-            use["fn"] = "layer_norm_" + use["fn"]
-            use["args"] = list(st["args"]) + list(b[1:])
-            dead.add(i)
-        self.statements[:] = [st for i, st in enumerate(sts) if i not in dead]
-
     def fold_attention(self):
         """matmul_view(Q view, K^T view) -> softmax_scaled -> matmul_view(P, V view [, out_perm, out_reshape]) with private
         intermediates becomes ONE `attention_view` statement (lele_hip_attention_view: the score / probability tensors stay on
@@ -954,7 +904,6 @@ class Lowering:
         if self.extra_fusions:
             self.fold_linear_residuals()
             self.fold_ffn()
-            self.fold_layer_norms()
             self.fold_attention()
 
     def lower_if(self, node):

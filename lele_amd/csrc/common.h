@@ -121,9 +121,7 @@ struct LeleCtx {
 
     // two library-owned result buffers for ops that fall back to an unfused sequence and need somewhere to put the intermediate
     // (add3 / fused_quantized_linear_residual with an operand that broadcasts OUTWARD: the in-place second pass is not possible)
-    LeleBuf* tmp[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [3]: row statistics of a LayerNorm folded into its
-                                                                               // consumer (quant.hip), [4]: its output where the fold does
-                                                                               // not apply, [5]: per-slice rendezvous records (igemm_rs.h)
+    LeleBuf* tmp[3] = {nullptr, nullptr, nullptr};
     int tmp_buf(int i, LeleBuf** out);
 
     int check_deverr(const char* where);
@@ -141,7 +139,6 @@ struct LeleGraph {
 };
 
 #define LELE_DEVERR_GATHER_INDEX 1u
-#define LELE_DEVERR_GROUP_TIMEOUT 2u  // a workgroup gave up waiting for the other workgroups of its slice (ln_qfrag_group_kernel)
 
 // Developer switches (kernel variants for A/B timing, stamps, ablations) exist in the LAB build only
 // (LELE_HIP_LAB=1 python -m lele_amd.build -> liblele_hip_lab.so); in the product library lab_env() is NULL for every name.
@@ -175,10 +172,6 @@ namespace lele {
 // features_ops.hip: power spectrum |FFT|^2 of `rows` real rows of length n_fft (a power of two <= 4096), bit-exact with the
 // reference's radix-2 network; out_power is [rows, n_fft/2 + 1]
 int fft_rows_power(LeleCtx* ctx, const float* rows_in, int64_t rows, int64_t n_fft, float* out_power);
-
-// eltwise.hip: LayerNorm's row statistics without its output (see there)
-int launch_ln_stats(LeleCtx* ctx, const float* dx, const float* dg, const float* db, int64_t norm, int64_t outer, float eps, float* stats,
-                    float* rowstat);
 
 // quant.hip: dynamic-quantisation parameters of the joint range of several device arrays (16 bytes on the device)
 struct QParamsDev {

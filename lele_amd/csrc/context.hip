@@ -46,8 +46,7 @@ int LeleCtx::check_deverr(const char* where) {
         *deverr_host = 0;
         LELE_REQUIRE(false, "%s: a kernel reported a data-dependent violation earlier on this stream:%s (the access was clamped; "
                      "lele's bounds-checked indexing panics here, manipulation.rs:626-633)", where,
-                     (bits & LELE_DEVERR_GATHER_INDEX) ? " gather index out of range"
-                     : (bits & LELE_DEVERR_GROUP_TIMEOUT) ? " a workgroup timed out waiting for its slice's range (the result of that op is wrong)" : " unknown");
+                     (bits & LELE_DEVERR_GATHER_INDEX) ? " gather index out of range" : " unknown");
     }
     return 0;
 }

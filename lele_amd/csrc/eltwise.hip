@@ -358,13 +358,12 @@ __device__ __forceinline__ void row_sums(const F& elem, int64_t n, int l, float*
 template <int NT>
 __global__ void layer_norm_reg_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                       const float* __restrict__ b, float* __restrict__ y, int norm, int64_t outer,
-                                      float eps, float* __restrict__ rowstat /* NULL or [outer][2]: min, max of each output row */,
-                                      float* __restrict__ stats = nullptr /* NULL or [outer][2]: mean, 1 / std of each row */) {
+                                      float eps, float* __restrict__ rowstat /* NULL or [outer][2]: min, max of each output row */) {
     const int l = threadIdx.x & 31;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (row >= outer) return;
     const float* in = x + row * norm;
-    float* out = y + row * norm;  // y == NULL: statistics only (the consumer re-applies the normalisation: lele::launch_ln_stats)
+    float* out = y + row * norm;
     float v[NT], gg[NT], bb[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
@@ -387,7 +386,7 @@ __global__ void layer_norm_reg_kernel(const float* __restrict__ x, const float* 
         if (j < norm) {
             const float t = (v[c] - mean) * inv_std;
             const float o = j < body ? fmaf_(t, gg[c], bb[c]) : t * gg[c] + bb[c];
-            if (y) out[j] = o;
+            out[j] = o;
             mn = o < mn ? o : mn;  // the comparisons of qminmax_kernel (quant.hip): min / max are order-independent, exact
             mx = o > mx ? o : mx;
         }
@@ -399,10 +398,6 @@ __global__ void layer_norm_reg_kernel(const float* __restrict__ x, const float* 
             rowstat[2 * row] = mn;
             rowstat[2 * row + 1] = mx;
         }
-    }
-    if (stats && l == 0) {
-        stats[2 * row] = mean;
-        stats[2 * row + 1] = inv_std;
     }
 }
 
@@ -805,30 +800,6 @@ int lele_hip_reduce(LeleCtx* ctx, int op, const LeleTensor* x, const int64_t* ax
     }
     return set_shape_v(out_shape, out_rank, oshape);
 }
-
-}  // extern "C"
-namespace lele {
-// LayerNorm WITHOUT its output: per row {mean, 1 / std} into `stats` and {min, max} of the row the operator would have written
-// into `rowstat` ([outer][2] each) -- what a consumer needs to apply the normalisation to the values as it reads them (quant.hip:
-// layer_norm -> dynamic quantisation, where the normalised tensor would be written only to be read once).  The same kernel as
-// lele_hip_layer_norm minus the stores, so the re-applied values are the operator's bits.  norm <= 1024.
-int launch_ln_stats(LeleCtx* ctx, const float* dx, const float* dg, const float* db, int64_t norm, int64_t outer, float eps, float* stats,
-                    float* rowstat) {
-    LELE_REQUIRE(norm >= 1 && norm <= 1024, "launch_ln_stats: rows of 1..1024 elements");
-    if (outer == 0) return 0;
-    const int rpb = outer >= 4096 ? 8 : (outer >= 1024 ? 4 : 2);
-    const dim3 rgrid((unsigned)((outer + rpb - 1) / rpb)), rblock(32 * rpb);
-    if (norm <= 256)
-        hipLaunchKernelGGL(layer_norm_reg_kernel<8>, rgrid, rblock, 0, ctx->stream, dx, dg, db, (float*)nullptr, (int)norm, outer, eps, rowstat, stats);
-    else if (norm <= 512)
-        hipLaunchKernelGGL(layer_norm_reg_kernel<16>, rgrid, rblock, 0, ctx->stream, dx, dg, db, (float*)nullptr, (int)norm, outer, eps, rowstat, stats);
-    else
-        hipLaunchKernelGGL(layer_norm_reg_kernel<32>, rgrid, rblock, 0, ctx->stream, dx, dg, db, (float*)nullptr, (int)norm, outer, eps, rowstat, stats);
-    LELE_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-}  // namespace lele
-extern "C" {
 
 int lele_hip_layer_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, const LeleTensor* bias,
                         int32_t axis, float epsilon, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {

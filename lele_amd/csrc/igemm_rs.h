@@ -50,7 +50,7 @@ template <int CPR /* 16-element chunks per row: kp / 16 */, int IT /* trips of 6
 __global__ __launch_bounds__(256) void qrows_frag_kernel(const float* __restrict__ x, unsigned rows, int k, int m,
                                                          QParams* __restrict__ prm, int8_t* __restrict__ af,
                                                          int* __restrict__ row_sums, const float* __restrict__ partial, int nblk,
-                                                         unsigned* __restrict__ zero_slice, LnApply ln) {
+                                                         unsigned* __restrict__ zero_slice) {
     static_assert((CPR == 32 && IT == 1) || (CPR == 128 && IT == 4), "kp = 512: two rows per wave; kp = 2048: two rows per wave");
     constexpr int KS = CPR / 2;
     const int lane = threadIdx.x & 63;
@@ -80,17 +80,6 @@ __global__ __launch_bounds__(256) void qrows_frag_kernel(const float* __restrict
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[i][e] = make_float4(t[4 * e], t[4 * e + 1], t[4 * e + 2], t[4 * e + 3]);
-        }
-    }
-    if (ln.g) {  // uniform: x is the operand of a LayerNorm whose result is quantised here (see LnApply)
-#pragma unroll
-        for (int i = 0; i < IT; ++i) {
-            const unsigned r = rowi[i] < rows ? rowi[i] : rows - 1u;
-            float xv[16] = {v[i][0].x, v[i][0].y, v[i][0].z, v[i][0].w, v[i][1].x, v[i][1].y, v[i][1].z, v[i][1].w,
-                            v[i][2].x, v[i][2].y, v[i][2].z, v[i][2].w, v[i][3].x, v[i][3].y, v[i][3].z, v[i][3].w};
-            ln_apply16(ln, r, (int)(16u * ci[i]), k, xv);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[i][e] = make_float4(xv[4 * e], xv[4 * e + 1], xv[4 * e + 2], xv[4 * e + 3]);
         }
     }
     if (row_first >= rows) {  // a wave of padding rows only
@@ -196,175 +185,6 @@ __global__ __launch_bounds__(256) void qrows_frag_kernel(const float* __restrict
         for (int i = 0; i < IT; i += 2) {
             const int tot = wave_sum_i32(sum[i] + sum[i + 1]);
             if (lane == 0 && rowi[i] < rows) row_sums[rowi[i]] = tot;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------ LayerNorm -> fragment-major i8, ONE kernel
-// layer_norm (last axis) -> per-slice dynamic range -> rows quantised into fragment order, for batches of short slices (one
-// utterance of a SenseVoice shard: 171 rows of 512).  The dynamic quantisation needs the range of the WHOLE slice before its first
-// row can be quantised -- as separate kernels that is a kernel boundary (LayerNorm | quantiser: 7.1 + 10.5 us per [5472 x 512],
-// each of them its launch, first touch and drain rather than its 14 MB), and folding the normalisation into the quantiser did not
-// change the count (statistics pass 6.7 + 11.3 us).  Here the G workgroups that share a slice keep their rows -- normalised -- in
-// REGISTERS, meet at a per-slice record in memory (one atomic min, one atomic max, one arrival counter: a fan-in among G = 8
-// workgroups, not a grid barrier), and quantise from registers: x is read once, the fragments written once, one launch.
-//   * record {min, max (order-preserving integer images of the floats), arrived, departed}: device-scope atomics only, read back with
-//     no-op atomics (a load could be served by the reader's own, non-coherent L2); the last workgroup to depart resets the record, so
-//     the next launch on the stream finds it clean (graph replays included);
-//   * every workgroup of the grid must be resident at once: grid = slices x G <= 2 x CUs (the host checks), 256 threads, ~60 registers;
-//   * the wait is BOUNDED: a workgroup that does not see its slice complete gives up, raises LELE_DEVERR_GROUP_TIMEOUT (reported by
-//     the next sync) and quantises with what it has -- a wrong result that says so instead of a hung device.
-// Lane l of a 32-lane group holds elements 32 c + l of its row: layer_norm_reg_kernel's layout and arithmetic, statement for
-// statement (row_sums_reg: lele's 4 x 8 accumulator order; fma inside the 8-wide body), and qrows_frag_kernel's quantiser.
-struct SliceRec {
-    int mn, mx;
-    unsigned arrived, departed;
-};
-__device__ __forceinline__ int f32_ordered(float f) {  // monotone float -> int (finite values and infinities)
-    const int b = __float_as_int(f);
-    return b >= 0 ? b : (int)(0x80000000u - (unsigned)b);
-}
-__device__ __forceinline__ float ordered_f32(int i) { return __int_as_float(i >= 0 ? i : (int)(0x80000000u - (unsigned)i)); }
-constexpr int kSliceRecMnInit = 0x7f800000;  // the image of +inf (the maximum starts at the image of -inf)
-__global__ void slice_rec_init_kernel(SliceRec* rec, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) rec[i] = SliceRec{kSliceRecMnInit, f32_ordered(-INFINITY), 0u, 0u};
-}
-template <int NP /* passes of 8 rows a workgroup holds */>
-__global__ __launch_bounds__(256) void ln_qfrag_group_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
-                                                             float eps, int k, int m, int G, int rpg /* rows per workgroup */,
-                                                             unsigned rows_total, SliceRec* __restrict__ rec, QParams* __restrict__ prm,
-                                                             int8_t* __restrict__ af, int* __restrict__ row_sums,
-                                                             unsigned* __restrict__ zero_slice, unsigned* __restrict__ deverr) {
-    constexpr int NT = 16, KS = 16, PITCH = 528;
-    __shared__ float s_g[512], s_b[512];
-    __shared__ float s_mn[8], s_mx[8];
-    __shared__ float s_rng[2];
-    __shared__ __attribute__((aligned(16))) unsigned char s_q[8 * PITCH];
-    const int tid = threadIdx.x, l = tid & 31, grp = tid >> 5;
-    const unsigned s = blockIdx.x / (unsigned)G, gi = blockIdx.x - s * (unsigned)G;
-    const int r_lo = (int)gi * rpg, r_hi = r_lo + rpg < m ? r_lo + rpg : m;  // this workgroup's rows of the slice: [r_lo, r_hi), never empty
-    const unsigned row0 = s * (unsigned)m;
-    for (int i = tid; i < 512; i += 256) {
-        s_g[i] = g[i < k ? i : k - 1];
-        s_b[i] = b[i < k ? i : k - 1];
-    }
-    float v[NP][NT];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int r = r_lo + 8 * p + grp, rc = r < r_hi ? r : r_hi - 1;  // slots beyond the range repeat its last row: same statistics
-        const float* in = x + (size_t)(row0 + (unsigned)rc) * k;
-#pragma unroll
-        for (int c = 0; c < NT; ++c) {
-            const int j = 32 * c + l;
-            v[p][c] = in[j < k ? j : k - 1];
-        }
-    }
-    __syncthreads();
-    const float inv_n = 1.0f / (float)k;
-    const int body = k & ~7;
-    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        float sum, sumsq;
-        lele::row_sums_reg<NT, true, true>(v[p], k, l, &sum, &sumsq);
-        const float mean = sum * inv_n;
-        const float var = sumsq * inv_n - mean * mean;
-        const float inv_std = 1.0f / sqrtf(var + eps);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) {
-            const int j = 32 * c + l;
-            if (j < k) {
-                const float t = (v[p][c] - mean) * inv_std;
-                const float o = j < body ? __builtin_fmaf(t, s_g[j], s_b[j]) : t * s_g[j] + s_b[j];
-                v[p][c] = o;
-                mn = o < mn ? o : mn;
-                mx = o > mx ? o : mx;
-            }
-        }
-    }
-    mn = group_allreduce32(mn, [](float cur, float a) { return a < cur ? a : cur; });
-    mx = group_allreduce32(mx, [](float cur, float a) { return a > cur ? a : cur; });
-    if (l == 0) {
-        s_mn[grp] = mn;
-        s_mx[grp] = mx;
-    }
-    __syncthreads();
-    if (tid == 0) {
-#pragma unroll
-        for (int i = 1; i < 8; ++i) {
-            mn = s_mn[i] < mn ? s_mn[i] : mn;
-            mx = s_mx[i] > mx ? s_mx[i] : mx;
-        }
-        SliceRec* rc = rec + s;
-        // returning atomics: their values come back only once the operations are done where every XCD sees them
-        const int o1 = __hip_atomic_fetch_min(&rc->mn, f32_ordered(mn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int o2 = __hip_atomic_fetch_max(&rc->mx, f32_ordered(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("" ::"v"(o1), "v"(o2));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned seen = __hip_atomic_fetch_add(&rc->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-        int spins = 0;
-        while (seen < (unsigned)G && spins < (1 << 18)) {
-            __builtin_amdgcn_s_sleep(8);
-            seen = __hip_atomic_fetch_add(&rc->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ++spins;
-        }
-        if (seen < (unsigned)G) *deverr = LELE_DEVERR_GROUP_TIMEOUT;
-        const int gmn = __hip_atomic_fetch_min(&rc->mn, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int gmx = __hip_atomic_fetch_max(&rc->mx, (int)0x80000000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_rng[0] = ordered_f32(gmn);
-        s_rng[1] = ordered_f32(gmx);
-        // the last one out puts the record back for the next launch
-        if (__hip_atomic_fetch_add(&rc->departed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)G) {
-            __hip_atomic_store(&rc->mn, kSliceRecMnInit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&rc->mx, f32_ordered(-INFINITY), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&rc->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&rc->departed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-    const QParams q = make_qparams(s_rng[0], s_rng[1]);
-    if (tid == 0 && gi == 0) {
-        prm[s] = q;
-        if (zero_slice) zero_slice[s] = 0u;
-    }
-    const int simd_k = k & ~7;
-    auto addi = [](float a, float c) { return __int_as_float(__float_as_int(a) + __float_as_int(c)); };
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        if (r_lo + 8 * p >= r_hi) break;  // uniform
-        const int r = r_lo + 8 * p + grp;
-        int sacc = 0;
-#pragma unroll
-        for (int c = 0; c < NT; ++c) {
-            const int j = 32 * c + l;
-            int val = 0;
-            if (j < k) {
-                val = (int)quant_one(v[p][c], q, j < simd_k) - 128;
-                sacc += val;
-            }
-            s_q[grp * PITCH + j] = (unsigned char)(val & 0xff);
-        }
-        const int tot = __float_as_int(group_allreduce32(__int_as_float(sacc), addi));
-        if (l == 0 && r < r_hi && row_sums) row_sums[row0 + (unsigned)r] = tot;
-        __syncthreads();
-        {   // 8 rows x 32 chunks of 16 bytes = 256 pieces: thread t moves piece (row t & 7, chunk t >> 3)
-            const int rr = tid & 7, chunk = tid >> 3;
-            if (r_lo + 8 * p + rr < r_hi) {
-                const unsigned grow = row0 + (unsigned)(r_lo + 8 * p + rr);
-                const v4i piece = *reinterpret_cast<const v4i*>(s_q + rr * PITCH + chunk * 16);
-                *reinterpret_cast<v4i*>(af + (((size_t)(grow >> 5) * KS + (chunk >> 1)) * 64 + (grow & 31u) + 32u * (chunk & 1)) * 16) = piece;
-            }
-        }
-        __syncthreads();
-    }
-    // the rows that pad the last tile of the tensor are zeros (the GEMM multiplies whole tiles)
-    if (blockIdx.x == gridDim.x - 1 && (rows_total & 31u)) {
-        for (int t = tid; t < 32 * 32; t += 256) {
-            const int rr = t & 31, chunk = t >> 5;
-            const unsigned grow = (rows_total & ~31u) + (unsigned)rr;
-            if (grow >= rows_total)
-                *reinterpret_cast<v4i*>(af + (((size_t)(grow >> 5) * KS + (chunk >> 1)) * 64 + (grow & 31u) + 32u * (chunk & 1)) * 16) = v4i{0, 0, 0, 0};
         }
     }
 }

@@ -19,7 +19,6 @@
 // (avx/quantization.rs:12-95).
 #include "common.h"
 #include "lane_ops.h"
-#include "norm_core.h"
 #include "gemm_small.h"
 
 #include <math.h>
@@ -124,65 +123,6 @@ __global__ void qparams_kernel(const float* __restrict__ partial, int nblocks, Q
     }
 }
 
-// A LayerNorm folded into the dynamic quantisation that reads it (lele_hip_layer_norm_fused_quantized_linear / _ffn_quantized):
-// x is the LayerNorm's OPERAND, `stats` holds {mean, 1 / std} per row (lele::launch_ln_stats) and the row quantisers normalise each
-// value as they load it, with the operator's own expression -- (v - mean) * inv_std, then fma(t, g, b) inside the 8-wide body of
-// the row and t * g + b in its scalar tail (eltwise.hip, layer_norm_reg_kernel; avx/norm.rs:10-137) -- so that what is quantised is,
-// bit for bit, what lele_hip_layer_norm would have stored.  g == NULL: off.
-struct LnApply {
-    const float* g;
-    const float* b;
-    const float* stats;
-};
-// 16 consecutive elements k0 .. k0 + 15 of row r (elements at or beyond k are left alone: the callers never use them)
-__device__ __forceinline__ void ln_apply16(const LnApply& ln, unsigned r, int k0, int k, float (&xv)[16]) {
-    const float mean = ln.stats[2 * (size_t)r], inv_std = ln.stats[2 * (size_t)r + 1];
-    const int body = k & ~7;
-    float gg[16], bb[16];
-    if (k0 + 16 <= k && ((((uintptr_t)ln.g) | ((uintptr_t)ln.b)) & 15) == 0 && (k0 & 3) == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float4 g4 = *reinterpret_cast<const float4*>(ln.g + k0 + 4 * e), b4 = *reinterpret_cast<const float4*>(ln.b + k0 + 4 * e);
-            gg[4 * e] = g4.x, gg[4 * e + 1] = g4.y, gg[4 * e + 2] = g4.z, gg[4 * e + 3] = g4.w;
-            bb[4 * e] = b4.x, bb[4 * e + 1] = b4.y, bb[4 * e + 2] = b4.z, bb[4 * e + 3] = b4.w;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int kc = k0 + e < k ? k0 + e : k - 1;
-            gg[e] = ln.g[kc];
-            bb[e] = ln.b[kc];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const float t = (xv[e] - mean) * inv_std;
-        xv[e] = k0 + e < body ? __builtin_fmaf(t, gg[e], bb[e]) : t * gg[e] + bb[e];
-    }
-}
-__device__ __forceinline__ float4 ln_apply4(const LnApply& ln, float mean, float inv_std, int k0, int k, float4 v) {
-    const int body = k & ~7;
-    float x4[4] = {v.x, v.y, v.z, v.w}, gg[4], bb[4];
-    if (k0 + 4 <= k && ((((uintptr_t)ln.g) | ((uintptr_t)ln.b)) & 15) == 0 && (k0 & 3) == 0) {
-        const float4 g4 = *reinterpret_cast<const float4*>(ln.g + k0), b4 = *reinterpret_cast<const float4*>(ln.b + k0);
-        gg[0] = g4.x, gg[1] = g4.y, gg[2] = g4.z, gg[3] = g4.w;
-        bb[0] = b4.x, bb[1] = b4.y, bb[2] = b4.z, bb[3] = b4.w;
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int kc = k0 + e < k ? k0 + e : k - 1;
-            gg[e] = ln.g[kc];
-            bb[e] = ln.b[kc];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float t = (x4[e] - mean) * inv_std;
-        x4[e] = k0 + e < body ? __builtin_fmaf(t, gg[e], bb[e]) : t * gg[e] + bb[e];
-    }
-    return make_float4(x4[0], x4[1], x4[2], x4[3]);
-}
-
 __device__ __forceinline__ float quant_one(float v, const QParams& q, bool simd_body) {
     float r = simd_body ? rintf(__builtin_fmaf(v, q.inv_scale, q.zp))  // _mm256_fmadd_ps + round-to-nearest-even
                         : roundf(v * q.inv_scale + q.zp);               // scalar remainder: two roundings, half away
@@ -201,7 +141,7 @@ __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x,
                                                     QParams* __restrict__ prm, int8_t* __restrict__ aq,
                                                     int* __restrict__ row_sums, const float* __restrict__ partial,
                                                     int nblk, unsigned* __restrict__ zero_slice = nullptr,
-                                                    int* __restrict__ zero_rows = nullptr, LnApply ln = LnApply{nullptr, nullptr, nullptr}) {
+                                                    int* __restrict__ zero_rows = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -263,19 +203,6 @@ __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x,
             q = prm[slice];
         }
     }
-    float ln_mean = 0.0f, ln_inv = 1.0f;
-    if (ln.g) {  // uniform (MODE 0 only): normalise the row's values as they arrive, see LnApply
-        ln_mean = ln.stats[2 * row];
-        ln_inv = ln.stats[2 * row + 1];
-        if (fast) {
-#pragma unroll
-            for (int u = 0; u < MAXC; ++u)
-                if (u < nch) {
-                    const int c = lane * 4 + 256 * u;
-                    if (c < k) pre[u] = ln_apply4(ln, ln_mean, ln_inv, c, k, pre[u]);   // fast: k % 4 == 0, so c < k <=> the chunk is inside
-                }
-        }
-    }
     const float* xr = x + row * k;
     int8_t* dst = aq + row * kp;
     const int simd_k = k & ~7;
@@ -332,10 +259,6 @@ __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x,
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) xv[e] = xr[c + e < k ? c + e : k - 1];
-        }
-        if (ln.g) {
-            const float4 t4 = ln_apply4(ln, ln_mean, ln_inv, c, k, make_float4(xv[0], xv[1], xv[2], xv[3]));
-            xv[0] = t4.x, xv[1] = t4.y, xv[2] = t4.z, xv[3] = t4.w;
         }
         int packed = 0;
 #pragma unroll
@@ -1108,45 +1031,14 @@ int frag_weights_of(LeleCtx* ctx, const LeleTensor* w, int k, int n, int kp, Fra
 }
 // f32 rows -> fragment-major i8 [ceil(rows / 32)][kp / 32][1024] in the arena (+ row sums unless rs == NULL)
 int launch_qrows_frag(LeleCtx* ctx, const float* dx, int64_t rows, int k, int kp, int m, QParams* prm, int8_t* af, int* rs,
-                      const float* partial, int nblk, unsigned* zero_slice, LnApply ln = LnApply{nullptr, nullptr, nullptr}) {
+                      const float* partial, int nblk, unsigned* zero_slice) {
     const int64_t nrt = (rows + 31) / 32;
     if (kp == 512)  // a wave per two rows: 4 tiles' worth of workgroups per tile
         hipLaunchKernelGGL((qrows_frag_kernel<32, 1>), dim3((unsigned)(4 * nrt)), dim3(256), 0, ctx->stream, dx, (unsigned)rows, k, m, prm, af, rs,
-                           partial, nblk, zero_slice, ln);
+                           partial, nblk, zero_slice);
     else
         hipLaunchKernelGGL((qrows_frag_kernel<128, 4>), dim3((unsigned)(4 * nrt)), dim3(256), 0, ctx->stream, dx, (unsigned)rows, k, m, prm, af, rs,
-                           partial, nblk, zero_slice, ln);
-    LELE_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-// LayerNorm + slice range + quantise-to-fragments in ONE kernel (ln_qfrag_group_kernel): G workgroups per slice meet at a record in
-// memory.  Every workgroup of the grid must be resident at once, and a workgroup holds at most 24 rows.
-int ln_group_size(LeleCtx* ctx, int64_t batch, int64_t m, int64_t k) {
-    if (k < 8 || k > 512 || m < 1 || batch < 4 || batch * m >= (int64_t(1) << 31) || env_int("LELE_HIP_LN_GROUP", 1) == 0) return 0;
-    for (int G = 8; G >= 2; G >>= 1)
-        if (batch * G <= 2 * (int64_t)ctx->num_cus && (m + G - 1) / G <= 24) return G;
-    return 0;
-}
-int launch_ln_qfrag_group(LeleCtx* ctx, int G, const float* dx, const float* dg, const float* db, float eps, int64_t batch, int m, int k,
-                          QParams* prm, int8_t* af, int* rs, unsigned* zero_slice) {
-    LeleBuf* rb = nullptr;
-    LELE_TRY(ctx->tmp_buf(5, &rb));
-    const void* before = rb->data;
-    const size_t had = rb->cap;
-    LELE_TRY(rb->reserve((size_t)batch * sizeof(SliceRec)));
-    if (rb->data != before || had == 0) {  // a fresh allocation: every record in its rest state (the kernels put them back themselves)
-        const int nrec = (int)(rb->cap / sizeof(SliceRec));
-        hipLaunchKernelGGL(slice_rec_init_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, ctx->stream, (SliceRec*)rb->data, nrec);
-    }
-    const unsigned rows = (unsigned)(batch * m);
-    const int rpg = (m + G - 1) / G;
-#define LELE_LNG(NP_)                                                                                                                  \
-    hipLaunchKernelGGL((ln_qfrag_group_kernel<NP_>), dim3((unsigned)(batch * G)), dim3(256), 0, ctx->stream, dx, dg, db, eps, k, m, G, rpg, rows, \
-                       (SliceRec*)rb->data, prm, af, rs, zero_slice, ctx->deverr_dev)
-    if (rpg <= 8) LELE_LNG(1);
-    else if (rpg <= 16) LELE_LNG(2);
-    else LELE_LNG(3);
-#undef LELE_LNG
+                           partial, nblk, zero_slice);
     LELE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1279,43 +1171,11 @@ int packed_weights_of(LeleCtx* ctx, const LeleTensor* weight_int8, int k, int n,
 }
 }  // namespace
 
-namespace {
-// A LayerNorm (over the last axis) folded into the quantised linear that reads it: `input` of the op is then the LayerNorm's operand
-struct LnFuse {
-    const LeleTensor* scale;
-    const LeleTensor* bias;
-    float eps;
-};
-bool ln_fusable(const LeleTensor* x, const LeleTensor* scale, const LeleTensor* bias, int32_t axis) {
-    if (!x || !scale || !bias || x->rank < 2 || x->dtype != LELE_F32 || scale->dtype != LELE_F32 || bias->dtype != LELE_F32) return false;
-    const int ax = axis < 0 ? x->rank + axis : axis;
-    const int64_t k = x->shape[x->rank - 1], m = x->shape[x->rank - 2];
-    return ax == x->rank - 1 && k >= 1 && k <= 1024 && m >= 1 && m <= 2048 && numel(scale) >= k && numel(bias) >= k &&
-           env_int("LELE_HIP_LN_FUSED", 1) != 0;
-}
-// statistics of LayerNorm(dx) into the context's buffer: *partial = {min, max} per row (the range pass's input), ln = what the row
-// quantisers need.  After the op's arena_reset (scale / bias may be staged there).
-int ln_prepare(LeleCtx* ctx, const LnFuse* lnf, const float* dx, int64_t rows, int64_t k, const float** partial, LnApply* ln) {
-    const void *dg = nullptr, *db = nullptr;
-    LELE_TRY(ctx->dev_ptr(lnf->scale, &dg));
-    LELE_TRY(ctx->dev_ptr(lnf->bias, &db));
-    LeleBuf* sb = nullptr;
-    LELE_TRY(ctx->tmp_buf(3, &sb));
-    LELE_TRY(sb->reserve((size_t)rows * 16));
-    float* rowstat = (float*)sb->data;
-    float* stats = rowstat + 2 * rows;
-    LELE_TRY(lele::launch_ln_stats(ctx, dx, (const float*)dg, (const float*)db, k, rows, lnf->eps, stats, rowstat));
-    *partial = rowstat;
-    *ln = LnApply{(const float*)dg, (const float*)db, stats};
-    return 0;
-}
-}  // namespace
-
 extern "C" {
 
 static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8, const LeleTensor* weight_scale,
                     const LeleTensor* weight_zero, const LeleTensor* bias, int apply_relu, const LeleTensor* res1,
-                    const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank, const LnFuse* lnf = nullptr) {
+                    const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
     LELE_REQUIRE(ctx && input && weight_int8 && weight_scale && out, "fused_quantized_linear: NULL argument");
     LELE_REQUIRE(input->rank >= 2 && weight_int8->rank >= 2, "fused_quantized_linear: rank >= 2 required");
     LELE_HIP_CHECK(hipSetDevice(ctx->device));
@@ -1348,19 +1208,11 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     LELE_TRY(weight_zero_of(ctx, weight_zero, &wz));
     const float* partial = nullptr;
     int nblk = 0;
-    LnApply ln{nullptr, nullptr, nullptr};
-    // LayerNorm in front, register-stationary route, a batch of short slices: ONE kernel from x to the i8 fragments
-    const int ln_G = lnf && rs_fits(ctx, rows, n, rs_kp(k)) ? ln_group_size(ctx, batch, m, k) : 0;
-    if (lnf && !ln_G) {  // the operand's OWN statistics (if its producer left any) describe x, not LayerNorm(x)
-        LELE_TRY(ln_prepare(ctx, lnf, (const float*)dx, rows, k, &partial, &ln));
-        nblk = (int)m;
-    } else if (!lnf) {
-        find_partials(ctx, input, batch, m, k, &partial, &nblk);
-    }
+    find_partials(ctx, input, batch, m, k, &partial, &nblk);
     void* prm = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm));
     LELE_TRY(qprof_mark(ctx, 0));
-    if (!partial && !ln_G) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
+    if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
     LELE_TRY(qprof_mark(ctx, 1));
 
     // ---- register-stationary route (igemm_rs.h): rows -> i8 in fragment order, then the barrier-free GEMM
@@ -1371,15 +1223,7 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
         void *af = nullptr, *rs = nullptr;
         LELE_TRY(ctx->arena_alloc((size_t)nrt * kprs * 32, &af));
         if (kprs == 512) LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));  // K = 2048: the GEMM sums the rows it loads anyway
-        if (ln_G) {
-            const void *dg = nullptr, *dbt = nullptr;
-            LELE_TRY(ctx->dev_ptr(lnf->scale, &dg));
-            LELE_TRY(ctx->dev_ptr(lnf->bias, &dbt));
-            LELE_TRY(launch_ln_qfrag_group(ctx, ln_G, (const float*)dx, (const float*)dg, (const float*)dbt, lnf->eps, batch, (int)m, (int)k, (QParams*)prm,
-                                           (int8_t*)af, (int*)rs, nullptr));
-        } else {
-            LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k, kprs, (int)m, (QParams*)prm, (int8_t*)af, (int*)rs, partial, nblk, nullptr, ln));
-        }
+        LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k, kprs, (int)m, (QParams*)prm, (int8_t*)af, (int*)rs, partial, nblk, nullptr));
         LELE_TRY(qprof_mark(ctx, 2));
         IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, (const int*)rs, fw.col_sums, (const QParams*)prm, 0,
                      (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
@@ -1410,10 +1254,10 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));
     if (rows <= 2048 || (kp <= 2048 && !lab_int("LELE_HIP_QROWS_STREAM", 0)))  // the whole row in flight at once (8 x 16 bytes per lane)
         hipLaunchKernelGGL((qrows_kernel<0, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
-                           rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk, (unsigned*)nullptr, (int*)nullptr, ln);
+                           rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk, (unsigned*)nullptr, (int*)nullptr);
     else
         hipLaunchKernelGGL((qrows_kernel<0, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx,
-                           rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk, (unsigned*)nullptr, (int*)nullptr, ln);
+                           rows, (int)k, kp, (int)m, (QParams*)prm, (int8_t*)aq, (int*)rs, partial, nblk, (unsigned*)nullptr, (int*)nullptr);
     LELE_TRY(qprof_mark(ctx, 2));
     IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, (const int*)rs, pw.col_sums, (const QParams*)prm, 0,
                  (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
@@ -1494,10 +1338,10 @@ int lele_hip_fused_quantized_linear_residual(LeleCtx* ctx, const LeleTensor* inp
  *     out = fused_quantized_linear[_residual](fused_quantized_linear(input, W1.., relu = 1), W2.., relu2, res1, res2)
  * bit for bit.  When the hidden layer is large the f32 hidden tensor is never stored: its product runs twice on the matrix cores
  * (igemm_kernel EM 1: range only; EM 2: quantise with that range, i8 + row sums), then the second GEMM consumes the i8 rows. */
-static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_int8, const LeleTensor* w1_scale,
-                    const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8,
-                    const LeleTensor* w2_scale, const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2,
-                    const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank, const LnFuse* lnf) {
+int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_int8, const LeleTensor* w1_scale,
+                                 const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8,
+                                 const LeleTensor* w2_scale, const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2,
+                                 const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
     LELE_REQUIRE(ctx && input && w1_int8 && w1_scale && w2_int8 && w2_scale && out, "fused_ffn_quantized: NULL argument");
     LELE_REQUIRE(input->rank >= 2 && w1_int8->rank >= 2 && w2_int8->rank >= 2, "fused_ffn_quantized: rank >= 2 required");
     LELE_REQUIRE(!res2 || res1, "fused_ffn_quantized: res2 without res1");
@@ -1533,7 +1377,7 @@ static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_
         LELE_TRY(ctx->tmp_buf(2, &hid));
         int64_t sh[LELE_MAX_RANK];
         int32_t r = 0;
-        LELE_TRY(fql_impl(ctx, input, w1_int8, w1_scale, w1_zero, b1, 1, nullptr, nullptr, hid, sh, &r, lnf));
+        LELE_TRY(fql_impl(ctx, input, w1_int8, w1_scale, w1_zero, b1, 1, nullptr, nullptr, hid, sh, &r));
         LeleTensor h{hid->data, sh, r, LELE_F32, LELE_MEM_DEVICE};
         if (res1) return lele_hip_fused_quantized_linear_residual(ctx, &h, w2_int8, w2_scale, w2_zero, b2, apply_relu2, res1, res2, out, out_shape, out_rank);
         return fql_impl(ctx, &h, w2_int8, w2_scale, w2_zero, b2, apply_relu2, nullptr, nullptr, out, out_shape, out_rank);
@@ -1558,19 +1402,12 @@ static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_
     LELE_TRY(weight_zero_of(ctx, w2_zero, &wz2));
     const float* partial = nullptr;
     int nblk = 0;
-    LnApply ln{nullptr, nullptr, nullptr};
-    const int ln_G = lnf && rs_route ? ln_group_size(ctx, batch, m, k1) : 0;
-    if (lnf && !ln_G) {
-        LELE_TRY(ln_prepare(ctx, lnf, (const float*)dx, rows, k1, &partial, &ln));
-        nblk = (int)m;
-    } else if (!lnf) {
-        find_partials(ctx, input, batch, m, k1, &partial, &nblk);
-    }
+    find_partials(ctx, input, batch, m, k1, &partial, &nblk);
     void *prm1 = nullptr, *prm2 = nullptr, *aq1 = nullptr, *rs1 = nullptr, *aq2 = nullptr, *rs2 = nullptr, *hmax = nullptr;
     LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm1));
     LELE_TRY(ctx->arena_alloc((size_t)batch * sizeof(QParams), &prm2));
     LELE_TRY(qprof_mark(ctx, 0));
-    if (!partial && !ln_G) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k1, (QParams*)prm1, nullptr, nullptr, &partial, &nblk));
+    if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k1, (QParams*)prm1, nullptr, nullptr, &partial, &nblk));
     LELE_TRY(qprof_mark(ctx, 1));
     if (rs_route) {
         FragW fw1, fw2;
@@ -1583,16 +1420,8 @@ static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_
         LELE_TRY(ctx->arena_alloc((size_t)nrt * 2048 * 32, &hid));
         LELE_TRY(ctx->arena_alloc((size_t)batch * 4, &hmax));
         // rows -> i8 for the first product; the same launch clears the per-slice maxima the range pass adds into
-        if (ln_G) {
-            const void *dg = nullptr, *dbt = nullptr;
-            LELE_TRY(ctx->dev_ptr(lnf->scale, &dg));
-            LELE_TRY(ctx->dev_ptr(lnf->bias, &dbt));
-            LELE_TRY(launch_ln_qfrag_group(ctx, ln_G, (const float*)dx, (const float*)dg, (const float*)dbt, lnf->eps, batch, (int)m, (int)k1,
-                                           (QParams*)prm1, (int8_t*)af1, (int*)rs1, (unsigned*)hmax));
-        } else {
-            LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k1, 512, (int)m, (QParams*)prm1, (int8_t*)af1, (int*)rs1, partial, nblk,
-                                       (unsigned*)hmax, ln));
-        }
+        LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k1, 512, (int)m, (QParams*)prm1, (int8_t*)af1, (int*)rs1, partial, nblk,
+                                   (unsigned*)hmax));
         LELE_TRY(qprof_mark(ctx, 2));
         IgemmEpi e1{nullptr, rows, n1, (int)m, (int)k1, (const int*)rs1, fw1.col_sums, (const QParams*)prm1, 0, (int)wz1, (const float*)dws1,
                     (int)ws1_len, b1_len ? (const float*)db1 : nullptr, 1};
@@ -1618,10 +1447,10 @@ static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_
     // rows -> i8 for the first GEMM; the same launch clears the accumulators of the two hidden-layer passes
     if (kp1 <= 2048 && !lab_int("LELE_HIP_QROWS_STREAM", 0))
         hipLaunchKernelGGL((qrows_kernel<0, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx, rows,
-                           (int)k1, kp1, (int)m, (QParams*)prm1, (int8_t*)aq1, (int*)rs1, partial, nblk, (unsigned*)hmax, (int*)rs2, ln);
+                           (int)k1, kp1, (int)m, (QParams*)prm1, (int8_t*)aq1, (int*)rs1, partial, nblk, (unsigned*)hmax, (int*)rs2);
     else
         hipLaunchKernelGGL((qrows_kernel<0, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, ctx->stream, (const float*)dx, rows,
-                           (int)k1, kp1, (int)m, (QParams*)prm1, (int8_t*)aq1, (int*)rs1, partial, nblk, (unsigned*)hmax, (int*)rs2, ln);
+                           (int)k1, kp1, (int)m, (QParams*)prm1, (int8_t*)aq1, (int*)rs1, partial, nblk, (unsigned*)hmax, (int*)rs2);
     LELE_TRY(qprof_mark(ctx, 2));
     IgemmEpi e1{nullptr, rows, n1, (int)m, (int)k1, (const int*)rs1, pw1.col_sums, (const QParams*)prm1, 0, (int)wz1, (const float*)dws1,
                 (int)ws1_len, b1_len ? (const float*)db1 : nullptr, 1};
@@ -1636,57 +1465,6 @@ static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_
     LELE_TRY(launch_igemm(ctx, (const int8_t*)aq2, pw2.wt, rows, (int)n2, kp2, 0, (int)m, e2));
     LELE_TRY(qprof_mark(ctx, 3));
     return set_shape_v(out_shape, out_rank, shp);
-}
-
-int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_int8, const LeleTensor* w1_scale,
-                                 const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8,
-                                 const LeleTensor* w2_scale, const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2,
-                                 const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
-    return ffn_impl(ctx, input, w1_int8, w1_scale, w1_zero, b1, w2_int8, w2_scale, w2_zero, b2, apply_relu2, res1, res2, out, out_shape, out_rank, nullptr);
-}
-
-/* layer_norm (norm.rs:226) -> fused_quantized_linear (quantization.rs:77) / the feed-forward block above, as ONE call whose
- * normalised tensor is never stored: a statistics pass leaves {mean, 1 / std, min, max} per row, and the row quantiser of the
- * linear normalises each value as it loads it with the operator's own expression (LnApply) -- the bits of the two calls.  Where the
- * fold does not apply (axis not last, rows longer than 1024, slices longer than 2048 rows, LELE_HIP_LN_FUSED=0) the two calls run. */
-static int ln_then(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* ln_scale, const LeleTensor* ln_bias, int32_t ln_axis, float ln_eps,
-                   LeleTensor* xn, int64_t* sh) {
-    LeleBuf* t = nullptr;
-    LELE_TRY(ctx->tmp_buf(4, &t));
-    int32_t r = 0;
-    LELE_TRY(lele_hip_layer_norm(ctx, x, ln_scale, ln_bias, ln_axis, ln_eps, t, sh, &r));
-    *xn = LeleTensor{t->data, sh, r, LELE_F32, LELE_MEM_DEVICE};
-    return 0;
-}
-int lele_hip_layer_norm_fused_quantized_linear(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* ln_scale, const LeleTensor* ln_bias,
-                                               int32_t ln_axis, float ln_eps, const LeleTensor* weight_int8, const LeleTensor* weight_scale,
-                                               const LeleTensor* weight_zero, const LeleTensor* bias, int apply_relu, LeleBuf* out,
-                                               int64_t* out_shape, int32_t* out_rank) {
-    LELE_REQUIRE(ctx && x && ln_scale && ln_bias && weight_int8 && weight_scale && out, "layer_norm_fused_quantized_linear: NULL argument");
-    if (ln_fusable(x, ln_scale, ln_bias, ln_axis)) {
-        const LnFuse lnf{ln_scale, ln_bias, ln_eps};
-        return fql_impl(ctx, x, weight_int8, weight_scale, weight_zero, bias, apply_relu, nullptr, nullptr, out, out_shape, out_rank, &lnf);
-    }
-    LeleTensor xn;
-    int64_t sh[LELE_MAX_RANK];
-    LELE_TRY(ln_then(ctx, x, ln_scale, ln_bias, ln_axis, ln_eps, &xn, sh));
-    return fql_impl(ctx, &xn, weight_int8, weight_scale, weight_zero, bias, apply_relu, nullptr, nullptr, out, out_shape, out_rank);
-}
-int lele_hip_layer_norm_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* ln_scale, const LeleTensor* ln_bias,
-                                            int32_t ln_axis, float ln_eps, const LeleTensor* w1_int8, const LeleTensor* w1_scale,
-                                            const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8,
-                                            const LeleTensor* w2_scale, const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2,
-                                            const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out, int64_t* out_shape,
-                                            int32_t* out_rank) {
-    LELE_REQUIRE(ctx && x && ln_scale && ln_bias && w1_int8 && w1_scale && w2_int8 && w2_scale && out, "layer_norm_fused_ffn_quantized: NULL argument");
-    if (ln_fusable(x, ln_scale, ln_bias, ln_axis)) {
-        const LnFuse lnf{ln_scale, ln_bias, ln_eps};
-        return ffn_impl(ctx, x, w1_int8, w1_scale, w1_zero, b1, w2_int8, w2_scale, w2_zero, b2, apply_relu2, res1, res2, out, out_shape, out_rank, &lnf);
-    }
-    LeleTensor xn;
-    int64_t sh[LELE_MAX_RANK];
-    LELE_TRY(ln_then(ctx, x, ln_scale, ln_bias, ln_axis, ln_eps, &xn, sh));
-    return ffn_impl(ctx, &xn, w1_int8, w1_scale, w1_zero, b1, w2_int8, w2_scale, w2_zero, b2, apply_relu2, res1, res2, out, out_shape, out_rank, nullptr);
 }
 
 /* ---- per-stage stopwatch of fused_quantized_linear (bench.py's roofline block for the model path) ------------------- */

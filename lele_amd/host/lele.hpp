@@ -771,29 +771,6 @@ inline TensorView fused_ffn_quantized(const TensorView& input, const TensorView&
                                        &sh.rank));
     LELE_RET(out, LELE_F32);
 }
-// fused_quantized_linear / fused_ffn_quantized of layer_norm(input, ln_scale, ln_bias, ln_axis, ln_eps): the normalised tensor is never stored
-inline TensorView layer_norm_fused_quantized_linear(const TensorView& input, const TensorView& ln_scale, const TensorView& ln_bias, int64_t ln_axis,
-                                                    float ln_eps, const TensorView& weight_int8, const TensorView& weight_scale,
-                                                    const TensorView& weight_zero, const TensorView* bias, bool apply_relu, Buffer& out) {
-    Shape sh;
-    LeleTensor ti = input.c(), tg = ln_scale.c(), tb = ln_bias.c(), tw = weight_int8.c(), ts = weight_scale.c(), tz = weight_zero.c();
-    Opt ob(bias);
-    check(lele_hip_layer_norm_fused_quantized_linear(ctx(), &ti, &tg, &tb, (int32_t)ln_axis, ln_eps, &tw, &ts, &tz, ob.p, apply_relu, out.raw(), sh.dims,
-                                                     &sh.rank));
-    LELE_RET(out, LELE_F32);
-}
-inline TensorView layer_norm_fused_ffn_quantized(const TensorView& input, const TensorView& ln_scale, const TensorView& ln_bias, int64_t ln_axis, float ln_eps,
-                                                 const TensorView& w1_int8, const TensorView& w1_scale, const TensorView& w1_zero, const TensorView* b1,
-                                                 const TensorView& w2_int8, const TensorView& w2_scale, const TensorView& w2_zero, const TensorView* b2,
-                                                 bool apply_relu2, const TensorView* res1, const TensorView* res2, Buffer& out) {
-    Shape sh;
-    LeleTensor ti = input.c(), tg = ln_scale.c(), tb = ln_bias.c(), tw1 = w1_int8.c(), ts1 = w1_scale.c(), tz1 = w1_zero.c(), tw2 = w2_int8.c(),
-               ts2 = w2_scale.c(), tz2 = w2_zero.c();
-    Opt ob1(b1), ob2(b2), o1(res1), o2(res2);
-    check(lele_hip_layer_norm_fused_ffn_quantized(ctx(), &ti, &tg, &tb, (int32_t)ln_axis, ln_eps, &tw1, &ts1, &tz1, ob1.p, &tw2, &ts2, &tz2, ob2.p,
-                                                  apply_relu2, o1.p, o2.p, out.raw(), sh.dims, &sh.rank));
-    LELE_RET(out, LELE_F32);
-}
 inline TensorView softmax_scaled(const TensorView& x, const TensorView& scale, int64_t axis, Buffer& out) {
     Shape sh;
     LeleTensor tx = x.c(), ts = scale.c();

@@ -956,13 +956,6 @@ class Runner {
         if (fn == "fused_ffn_quantized")
             return set(st, 0, K::fused_ffn_quantized(tensor(a[0]), tensor(a[1]), tensor(a[2]), tensor(a[3]), opt(a[4], h0), tensor(a[5]), tensor(a[6]),
                                                      tensor(a[7]), opt(a[8], h1), boolean(a[9]), opt(a[10], h2), opt(a[11], h3), o));
-        if (fn == "layer_norm_fused_quantized_linear")
-            return set(st, 0, K::layer_norm_fused_quantized_linear(tensor(a[0]), tensor(a[1]), tensor(a[2]), integer(a[3]), number(a[4]), tensor(a[5]),
-                                                                   tensor(a[6]), tensor(a[7]), opt(a[8], h0), boolean(a[9]), o));
-        if (fn == "layer_norm_fused_ffn_quantized")
-            return set(st, 0, K::layer_norm_fused_ffn_quantized(tensor(a[0]), tensor(a[1]), tensor(a[2]), integer(a[3]), number(a[4]), tensor(a[5]),
-                                                                tensor(a[6]), tensor(a[7]), opt(a[8], h0), tensor(a[9]), tensor(a[10]), tensor(a[11]),
-                                                                opt(a[12], h1), boolean(a[13]), opt(a[14], h2), opt(a[15], h3), o));
         if (fn == "mat_mul_integer") return set(st, 0, K::mat_mul_integer(tensor(a[0]), tensor(a[1]), opt(a[2], h0), opt(a[3], h1), o));
         if (fn == "dynamic_quantize_linear") {
             auto r = K::dynamic_quantize_linear(tensor(a[0]), o, slot(st, 1), slot(st, 2));

@@ -1043,34 +1043,6 @@ def fused_ffn_quantized(input, w1_int8, w1_scale, w1_zero, b1, w2_int8, w2_scale
     return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
 
 
-def layer_norm_fused_quantized_linear(input, ln_scale, ln_bias, ln_axis, ln_epsilon, weight_int8, weight_scale, weight_zero, bias,
-                                      apply_relu=False, out=None, ctx=None):
-    """fused_quantized_linear(layer_norm(input, ln_scale, ln_bias, ln_axis, ln_epsilon), weight..) bit for bit; the normalised
-    tensor is never stored (lele_hip_layer_norm_fused_quantized_linear)"""
-    ctx = _ctx(ctx)
-    keep = []
-    out = out or ctx.buf()
-    sh = _lib.OutShape()
-    _lib.check(_lib.lib().lele_hip_layer_norm_fused_quantized_linear(
-        ctx._h, _t(input, keep), _t(ln_scale, keep), _t(ln_bias, keep), C.c_int32(ln_axis), C.c_float(ln_epsilon), _t(weight_int8, keep),
-        _t(weight_scale, keep), _t(weight_zero, keep), _t(bias, keep), C.c_int(int(apply_relu)), out._h, sh.shape, C.byref(sh.rank)))
-    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
-
-
-def layer_norm_fused_ffn_quantized(input, ln_scale, ln_bias, ln_axis, ln_epsilon, w1_int8, w1_scale, w1_zero, b1, w2_int8, w2_scale, w2_zero,
-                                   b2, apply_relu2=False, res1=None, res2=None, out=None, ctx=None):
-    """fused_ffn_quantized(layer_norm(input, ..), w1.., w2.., apply_relu2, res1, res2) bit for bit, the normalised tensor never stored"""
-    ctx = _ctx(ctx)
-    keep = []
-    out = out or ctx.buf()
-    sh = _lib.OutShape()
-    _lib.check(_lib.lib().lele_hip_layer_norm_fused_ffn_quantized(
-        ctx._h, _t(input, keep), _t(ln_scale, keep), _t(ln_bias, keep), C.c_int32(ln_axis), C.c_float(ln_epsilon), _t(w1_int8, keep),
-        _t(w1_scale, keep), _t(w1_zero, keep), _t(b1, keep), _t(w2_int8, keep), _t(w2_scale, keep), _t(w2_zero, keep), _t(b2, keep),
-        C.c_int(int(apply_relu2)), _t(res1, keep), _t(res2, keep), out._h, sh.shape, C.byref(sh.rank)))
-    return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
-
-
 def softmax_scaled(input, scale, axis=-1, out=None, ctx=None):
     """softmax(input * scale[0]): bit-identical to mul(input, scale) followed by softmax"""
     return _op(ctx, _lib.lib().lele_hip_softmax_scaled, [input, scale], [C.c_int32(axis)], out)

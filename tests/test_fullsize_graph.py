@@ -98,10 +98,9 @@ def check_shipped_layer_against_oracle(tp, i, L, tag):
     n = lambda s: "l%d_%s" % (i, s)   # noqa: E731
     x = tp["x0"] if i == 0 else tp["l%d_x2" % (i - 1)]
     b, t, _ = x.shape
-    # the LayerNorms are folded into the linears that read them (layer_norm_fused_quantized_linear / _ffn_quantized: the normalised
-    # tensor is never stored): the oracle's layer_norm of the device's x, then the oracle's linear -- bit for bit
+    same(tp[n("xn")], O.layer_norm(x, L["ln1"][0], L["ln1"][1], -1, 1e-5), tag + " layer_norm 1")
     qkv = tp[n("qkv")]
-    same(qkv, R.qlinear(O.layer_norm(x, L["ln1"][0], L["ln1"][1], -1, 1e-5), L["qkv"]), tag + " layer_norm 1 + qkv linear (one statement)")
+    same(qkv, R.qlinear(tp[n("xn")], L["qkv"]), tag + " qkv linear")
     q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
     vt = np.ascontiguousarray(v.transpose(0, 2, 1))
     mem = np.ascontiguousarray(O.conv1d(vt, L["fsmn"], None, [1], D, [5, 5], [1]).transpose(0, 2, 1)) + v
@@ -124,8 +123,9 @@ def check_shipped_layer_against_oracle(tp, i, L, tag):
     att = R.qlinear(tp[n("avm")], L["out"])
     x1 = (att + tp[n("mem")]) + x if L["d_in"] == D else att + tp[n("mem")]
     same(tp[n("x1")], x1, tag + " output projection + residual adds (fused_quantized_linear_residual)")
-    h = R.qlinear(O.layer_norm(tp[n("x1")], L["ln2"][0], L["ln2"][1], -1, 1e-5), L["ffn1"], True)
-    same(tp[n("x2")], tp[n("x1")] + R.qlinear(h, L["ffn2"]), tag + " layer_norm 2 + feed-forward block + residual (one statement)")
+    same(tp[n("x1n")], O.layer_norm(tp[n("x1")], L["ln2"][0], L["ln2"][1], -1, 1e-5), tag + " layer_norm 2")
+    h = R.qlinear(tp[n("x1n")], L["ffn1"], True)
+    same(tp[n("x2")], tp[n("x1")] + R.qlinear(h, L["ffn2"]), tag + " feed-forward block + residual (fused_ffn_quantized)")
 
 
 def run_config(ctx, model, batch, seconds, check_layers):
@@ -155,7 +155,7 @@ def run_config(ctx, model, batch, seconds, check_layers):
     finally:
         del os.environ["LELE_HIP_ATTENTION_FUSED"]
     # from here on: the plan as it ships (attention in one launch) -- with its first and last layer tapped against the oracle
-    names = ["x0", "l%d_x2" % (check_layers[-1] - 1)] + ["l%d_%s" % (i, s) for i in check_layers for s in ("qkv", "mem", "avm", "x1", "x2")]
+    names = ["x0", "l%d_x2" % (check_layers[-1] - 1)] + ["l%d_%s" % (i, s) for i in check_layers for s in ("xn", "qkv", "mem", "avm", "x1", "x1n", "x2")]
     runner.taps = {nm: None for nm in names}
     hand = runner.run({"feats": feats})[0].numpy()
     tp, runner.taps = runner.taps, None

@@ -426,77 +426,3 @@ def test_prepared_weight_entry_points(ctx, orc):
         assert np.array_equal(Kk.fused_dq_gemm_prepared(x, pw, 128, ws, bias, False, ctx=ctx).numpy(),
                               orc.fused_quantized_linear(x, wu8.astype(np.float32), ws, [128.0], bias, False))
         pw.close()
-
-
-@pytest.mark.gpu
-def test_layer_norm_folded_into_the_quantised_linears_is_the_two_calls_bit_for_bit(ctx):
-    """lele_hip_layer_norm_fused_quantized_linear / _ffn_quantized: a LayerNorm whose result is only ever quantised is not stored -- a
-    statistics pass, then the linear's row quantiser normalises on the fly.  Against the two calls (bit for bit, both GEMM routes,
-    ragged K with a scalar tail, slices that straddle row tiles) and against the oracle's layer_norm -> fused_dq_gemm chain
-    (avx/norm.rs:10-137, avx/quantization.rs:102-417)."""
-    from lele_amd import kernels as K
-    from lele_amd._lib import Weight
-    from oracle import pyoracle as O
-    rng = np.random.default_rng(11)
-
-    def lin(k, n):
-        w = np.clip(np.round(128 + 40 * rng.standard_normal((k, n))), 0, 255).astype(np.float32)
-        return (Weight(w), Weight((np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32)), Weight(np.array([128.0], np.float32)),
-                Weight((rng.standard_normal(n) * 0.02).astype(np.float32)))
-    # (32 | 33, 171), (64, 37), (40, 100), (100, 40): batches of short slices take the ONE-kernel form (the G = 8 or 4 workgroups of a
-    # slice keep their rows in registers and meet at a record in memory for the slice's range: 3, 1, 2 and 2 passes of 8 rows;
-    # 33 x 171 rows leave a ragged last tile, K = 500 a scalar tail in the normalisation and in the quantiser); the others take the
-    # statistics pass + the normalising row quantisers (both GEMM routes)
-    for (b, m, k, n) in ((32, 171, 512, 1536), (33, 171, 512, 1536), (64, 37, 512, 1024), (40, 100, 500, 1024), (100, 40, 512, 1024), (1, 504, 512, 2048),
-                         (1, 504, 560, 1536),
-                         (3, 37, 512, 1024), (2, 33, 100, 64), (3, 7, 13, 5), (1, 1, 8, 3), (4, 64, 1000, 96)):
-        x = (rng.standard_normal((b, m, k)) * (1 + rng.random((b, m, 1)) * 3) + rng.standard_normal((b, 1, 1))).astype(np.float32)
-        g = Weight((1 + 0.1 * rng.standard_normal(k)).astype(np.float32))
-        be = Weight((0.1 * rng.standard_normal(k)).astype(np.float32))
-        w = lin(k, n)
-        dx = ctx.buf().upload(x)
-        for relu in (False, True):
-            two = K.fused_quantized_linear(K.layer_norm(dx, g, be, -1, 1e-5, ctx=ctx), *w, relu, ctx=ctx).numpy()
-            one = K.layer_norm_fused_quantized_linear(dx, g, be, -1, 1e-5, *w, relu, ctx=ctx).numpy()
-            assert np.array_equal(one, two), (b, m, k, n, relu)
-        if b * m * k <= 600_000 or (b, m) in ((64, 37), (40, 100), (100, 40)):
-            want = O.fused_quantized_linear(O.layer_norm(x, g.arr, be.arr, -1, 1e-5), w[0].arr, w[1].arr, w[2].arr, w[3].arr, False)
-            assert np.array_equal(K.layer_norm_fused_quantized_linear(dx, g, be, -1, 1e-5, *w, False, ctx=ctx).numpy(), want), (b, m, k, n)
-        # an axis that is not the last one runs the two calls
-        if k == 13:
-            g2, b2 = Weight(np.ones((7, 13), np.float32)), Weight(np.zeros((7, 13), np.float32))
-            two = K.fused_quantized_linear(K.layer_norm(dx, g2, b2, 1, 1e-5, ctx=ctx), *w, False, ctx=ctx).numpy()
-            assert np.array_equal(K.layer_norm_fused_quantized_linear(dx, g2, b2, 1, 1e-5, *w, False, ctx=ctx).numpy(), two)
-    # the feed-forward block behind a LayerNorm, with its residual (the operand of the LayerNorm, as in a transformer layer)
-    for (b, m, k1, n1, n2) in ((32, 171, 512, 2048, 512), (1, 504, 512, 2048, 512), (2, 130, 512, 256, 512), (2, 9, 24, 40, 24)):
-        x = (rng.standard_normal((b, m, k1)) * 2).astype(np.float32)
-        g = Weight((1 + 0.1 * rng.standard_normal(k1)).astype(np.float32))
-        be = Weight((0.1 * rng.standard_normal(k1)).astype(np.float32))
-        w1, w2 = lin(k1, n1), lin(n1, n2)
-        dx = ctx.buf().upload(x)
-        r1 = dx if n2 == k1 else None
-        two = K.fused_ffn_quantized(K.layer_norm(dx, g, be, -1, 1e-5, ctx=ctx), *w1, *w2, False, r1, ctx=ctx).numpy()
-        one = K.layer_norm_fused_ffn_quantized(dx, g, be, -1, 1e-5, *w1, *w2, False, r1, ctx=ctx).numpy()
-        assert np.array_equal(one, two), (b, m, k1, n1, n2)
-    # the rendezvous records put themselves back: 200 launches back to back, every result the first one's
-    x = (rng.standard_normal((32, 171, 512)) * 2).astype(np.float32)
-    dx, ob = ctx.buf().upload(x), ctx.buf()
-    g, be, w = Weight((1 + 0.1 * rng.standard_normal(512)).astype(np.float32)), Weight((0.1 * rng.standard_normal(512)).astype(np.float32)), lin(512, 1536)
-    ref = K.layer_norm_fused_quantized_linear(dx, g, be, -1, 1e-5, *w, False, out=ob, ctx=ctx).numpy().copy()
-    assert np.array_equal(ref, K.fused_quantized_linear(K.layer_norm(dx, g, be, -1, 1e-5, ctx=ctx), *w, False, ctx=ctx).numpy())
-    bad = [it for it in range(200) if not np.array_equal(K.layer_norm_fused_quantized_linear(dx, g, be, -1, 1e-5, *w, False, out=ob, ctx=ctx).numpy(), ref)]
-    assert not bad, bad[:10]
-    # recorded into a graph and replayed (the statistics live in a context buffer sized by the eager run)
-    x = (rng.standard_normal((32, 171, 512)) * 2).astype(np.float32)
-    dx, ob = ctx.buf().upload(x), ctx.buf()
-    g, be, w = Weight(np.ones(512, np.float32)), Weight(np.zeros(512, np.float32)), lin(512, 1536)
-    ref = K.layer_norm_fused_quantized_linear(dx, g, be, -1, 1e-5, *w, False, out=ob, ctx=ctx).numpy().copy()
-    ctx.sync()
-    ctx.graph_begin()
-    res = K.layer_norm_fused_quantized_linear(dx, g, be, -1, 1e-5, *w, False, out=ob, ctx=ctx)
-    gr = ctx.graph_end()
-    for _ in range(3):
-        gr.launch()
-    ctx.sync()
-    assert np.array_equal(res.numpy(), ref)
-    gr.close()
