@@ -175,6 +175,47 @@ def replan_lifted(plan, shapes):
             "slots": slots, "statements": out, "weights": weights}
 
 
+def rebatch_lifted(plan, n):
+    """A re-planned lifted plan (replan_lifted) whose generated source baked batch 1 into its shape literals, for a batch of `n`.
+    lele's emitter folds the ONNX shape arithmetic for the export's batch (examples/yolo26n-seg/src/yolo26seg.rs: `reshape(x,
+    &[1, 2, 128, 400])`, ...), and its examples loop over images on the host; the data flow itself is batch-agnostic except where
+    the exporter's constant folding used N = 1.  Two rewrites, both checked against the per-image run by whoever calls this
+    (tools/yolo_lifted_batch.py, tests/test_lift_generated.py):
+      * a `reshape` to a literal shape that starts with 1 gets n there (every such reshape in the generated Yolo26n-seg splits or
+        merges trailing axes of an [N, ...] tensor; a reshape whose element count would not match fails loudly at run time);
+      * `gather(flatten(E, 2), idx, 0)` with E [N, K, 1] and idx [N, K] -- the exporter's form of "row idx[n, i] of image n", which
+        flattens the batch away -- becomes `gather_elements(E, unsqueeze(idx, -1), 1)`: the same values at N = 1, per image for N > 1.
+    Returns a new format-2 plan (buffers re-assigned)."""
+    from .compiler.lower import allocate
+    import copy
+    sts = copy.deepcopy(plan["statements"])
+    prod = {}
+    for i, st in enumerate(sts):
+        for o in st.get("out", []):
+            prod[o] = i
+    out, extra = [], 0
+    for st in sts:
+        st = dict(st)
+        st.pop("slots", None)
+        if st.get("op") == "call" and st.get("fn") == "reshape" and isinstance(st["args"][1], dict) and "list" in st["args"][1]:
+            dims = st["args"][1]["list"]
+            if dims and dims[0] == {"int": 1}:
+                st["args"] = [st["args"][0], {"list": [{"int": int(n)}] + list(dims[1:])}] + list(st["args"][2:])
+        elif st.get("op") == "call" and st.get("fn") == "gather" and st["args"][2] == {"int": 0} and "ref" in st["args"][0] and "ref" in st["args"][1]:
+            src = sts[prod[st["args"][0]["ref"]]] if st["args"][0]["ref"] in prod else None
+            if src is not None and src.get("fn") == "flatten" and src["args"][1] == {"int": 2} and "ref" in src["args"][0]:
+                extra += 1
+                ix = "%s__ix%d" % (st["out"][0], extra)
+                out.append({"op": "call", "out": [ix], "fn": "unsqueeze", "args": [st["args"][1], {"list": [{"int": -1}]}], "bufs": 0})
+                st["fn"] = "gather_elements"
+                st["args"] = [src["args"][0], {"ref": ix}, {"int": 1}]
+        out.append(st)
+    slots = allocate(out, list(plan["outputs"]))
+    new = dict(plan)
+    new.update({"statements": out, "slots": slots, "batch": int(n)})
+    return new
+
+
 # ---------------------------------------------------------------------------------------------------------- channel views
 # Concat / Split along C of NCHW tensors as VIEWS of one buffer (include/lele_hip.h, LelePitch).  lele copies (manipulation.rs:108-207,
 # 1091-1151); the values are the same, so a plan folded here gives the bits of the plan it came from.  Shapes are needed: the pass
