@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(const float* __restr
     float* dst = out + (size_t)pl0 * ohw;
     dw_copy_run(src, lin, np * ihw, (((uintptr_t)src) & 15) == 0);
     __syncthreads();
+    const bool direct = (g.ow & 3) == 0 && (((uintptr_t)dst) & 15) == 0 && (ohw & 3u) == 0;   // uniform
     const unsigned per_plane = (unsigned)g.oh * ngroups, items = np * per_plane;
     for (unsigned it = threadIdx.x; it < items; it += 256u) {
         const unsigned p = it / per_plane, r = it - p * per_plane;
@@ -366,17 +367,26 @@ __global__ __launch_bounds__(256) void depthwise_lds_kernel(const float* __restr
             }
         }
         const float bv = bias ? bias[ch] : 0.0f;
-        float* orow = lout + p * ohw + (unsigned)oy * (unsigned)g.ow;
+        float r4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int ox = ox0 + q;
-            if (ox < g.ow) {
-                float v = acc[q];
-                if (bias) v = v + bv;
-                orow[ox] = apply_act(v, act, oy * g.ow + ox < g.body);
-            }
+            float v = acc[q];
+            if (bias) v = v + bv;
+            r4[q] = apply_act(v, act, oy * g.ow + ox0 + q < g.body);
+        }
+        // a thread's four outputs are consecutive in memory and so are the threads of a row: rows a multiple of four wide leave as
+        // 16-byte stores straight from the registers (the second turn through LDS this kernel used to take cost a barrier and half
+        // of its LDS); ragged rows go through LDS as before
+        if (direct) {
+            *reinterpret_cast<float4*>(dst + p * ohw + (unsigned)oy * (unsigned)g.ow + (unsigned)ox0) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        } else {
+            float* orow = lout + p * ohw + (unsigned)oy * (unsigned)g.ow;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (ox0 + q < g.ow) orow[ox0 + q] = r4[q];
         }
     }
+    if (direct) return;
     __syncthreads();
     dw_copy_run(lout, dst, np * ohw, (((uintptr_t)dst) & 15) == 0);
 }
@@ -1084,12 +1094,14 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
     hipLaunchKernelGGL(depthwise_row4_kernel<KW>, rgrid, dim3(256), 0, ctx->stream, dx, dw, db, out, dg, act, (unsigned)threads, ngroups)
         const bool row_ok = g.sw == 1 && g.dw == 1 && g.ow >= 8 && threads < (int64_t(1) << 31);
         // planes per workgroup for the LDS-staged form: input + output planes within 64 KB, enough workgroups to fill the chip
-        const int64_t ihw = (int64_t)g.ih * g.iw, plane_floats = ihw + g.plane + 8, planes = (int64_t)g.n * g.oc;
+        // (rows a multiple of four wide are stored straight from registers: then only the input planes need LDS)
+        const bool dw_direct = (g.ow & 3) == 0 && (g.plane & 3) == 0 && (((uintptr_t)out) & 15) == 0;
+        const int64_t ihw = (int64_t)g.ih * g.iw, plane_floats = ihw + (dw_direct ? 0 : g.plane) + 8, planes = (int64_t)g.n * g.oc;
         int64_t pb = (16 * 1024 - 8) / plane_floats;
         while (pb > 1 && (planes + pb - 1) / pb < 4 * (int64_t)ctx->num_cus) pb = (pb + 1) / 2;
         const bool lds_ok = row_ok && pb >= 1 && (g.kw == 3 || g.kw == 5 || g.kw == 7 || g.kw == 11) && !lab_env("LELE_HIP_DW_NO_LDS");
         if (lds_ok) {
-            const size_t lds = (size_t)((((pb * ihw + 3) & ~int64_t(3)) + pb * g.plane) * 4);
+            const size_t lds = (size_t)((((pb * ihw + 3) & ~int64_t(3)) + (dw_direct ? 0 : pb * g.plane)) * 4);
             const dim3 lgrid((unsigned)((planes + pb - 1) / pb));
 #define LELE_DW_LDS(KW) \
     hipLaunchKernelGGL(depthwise_lds_kernel<KW>, lgrid, dim3(256), lds, ctx->stream, dx, dw, db, out, dg, act, (unsigned)planes, \
@@ -1121,7 +1133,7 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
                  g.c >= w1_min_c())) &&
                g.dh == 1 && g.dw == 1 && g.sh == 1 && g.sw == 1 && g.c % 16 == 0 && g.oc > 16 && g.ow >= 16 && g.n <= 65535 &&
                (int64_t)g.c * g.ih * g.iw < (int64_t(1) << 31) &&
-               (int64_t)g.n * ((g.oc + 63) / 64) * ((g.ow + 31) / 32) * ((g.oh + 7) / 8) >= (int64_t)ctx->num_cus) {
+               (int64_t)g.n * ((g.oc + 63) / 64) * ((g.ow + 31) / 32) * ((g.oh + 7) / 8) >= (int64_t)ctx->num_cus / 2) {
         // stride 1 over a batch, 16-channel chunks: the window-once MFMA kernel (see conv_window_kernel); 32-channel blocks when that
         // wastes fewer output channels than 64-channel ones
         const int taps = g.kh * g.kw;
