@@ -571,6 +571,37 @@ def yolo_leg(args, ctx, rank, world, fence, dist, device):
         rec.update({"images_checked_against_the_batch_1_plan": 2, "max_error_in_units_of_1e-4": round(worst, 4), "per_image_check_ok": bool(worst <= 1.0)})
         rec["_layers"] = layers
     graph.close()
+    # the reference's OWN generated Yolo26n-seg call sequence at the same batch, where the lifted plan is present (an untracked artifact
+    # made from the mounted reference by tools/lift_generated.py; it travels with the working tree, not with a clone): N = 1 only
+    lifted = os.path.join(ROOT, "_lifted", "yolo26seg_plan.json")
+    if rank == 0 and world == 1 and os.path.exists(lifted):
+        try:
+            import yolo_lifted_batch as Y
+            one, big, lfeed, limages, lname, louts, lrec = Y.build(ctx, lifted, nb)
+            worst = 0.0
+            lx1 = ctx.buf()
+            for i in (0, nb - 1):
+                o1 = [o.numpy() for o in one.run({lname: TensorView(lx1.upload(limages[i:i + 1]))})]
+                for a, b in zip(o1, louts):
+                    worst = max(worst, bars(a[..., 4], b[i:i + 1][..., 4]) if a.ndim == 3 else bars(a, b[i:i + 1]))
+            ctx.sync()
+            ctx.graph_begin()
+            big.run(lfeed)
+            lg = ctx.graph_end()
+            for _ in range(3):
+                lg.launch()
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(args.yolo_runs):
+                lg.launch()
+            lms = ctx.timer_stop() / args.yolo_runs
+            lg.close()
+            lrec.update({"ms_per_forward": round(lms, 3), "images_per_s": round(nb / lms * 1e3, 1), "gflop_per_image": 9.127,
+                         "frac_of_the_f32_mfma_peak": round(9.127 * nb / lms / F32_PEAK_TFLOPS, 4),
+                         "max_error_in_units_of_1e-4_vs_the_batch_1_plan": round(worst, 4), "per_image_check_ok": bool(worst <= 1.0)})
+            rec["reference_graph"] = lrec
+        except Exception as e:  # noqa: BLE001
+            rec["reference_graph"] = "failed: %s" % e
     return rec
 
 
