@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--check", type=int, default=4)
     ap.add_argument("--runs", type=int, default=10)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--table", default=None, help="per-statement device times (HIP events) of one eager forward, slowest first")
     args = ap.parse_args()
     if not os.path.exists(args.plan):
         raise SystemExit("no lifted plan at %s (python tools/lift_generated.py lift <reference>/examples/yolo26n-seg/src/yolo26seg.rs -o %s)" % (args.plan, args.plan))
@@ -92,6 +93,23 @@ def main():
                 worst[j] = max(worst[j], bars(a, bi))
     rec.update({"images_checked_against_the_batch_1_plan": idx, "max_error_in_units_of_1e-4_per_output": [round(w, 4) for w in worst],
                 "detection_rows_in_a_different_order": swapped, "bit_identical": bits})
+    if args.table:
+        big.stmt_times = []
+        big.run(feed)
+        big.stmt_times = []
+        big.run(feed)
+        times, big.stmt_times = big.stmt_times, None
+        agg = {}
+        for _i, fn, _o, ms in times:
+            agg[fn] = agg.get(fn, [0, 0.0])
+            agg[fn][0] += 1
+            agg[fn][1] += ms
+        rows = sorted(([fn, c, round(t, 4)] for fn, (c, t) in agg.items()), key=lambda r: -r[2])
+        top = sorted(times, key=lambda r: -r[3])[:40]
+        json.dump({"by_function": rows, "slowest_statements": [[i, fn, o, round(ms, 4)] for i, fn, o, ms in top], "total_ms": round(sum(t[3] for t in times), 3)},
+                  open(args.table, "w"), indent=0)
+        for r in rows[:25]:
+            print("%-28s calls %4d  %8.3f ms" % tuple(r), file=sys.stderr)
     ctx.sync()
     ctx.graph_begin()
     big.run(feed)
