@@ -208,22 +208,28 @@ __global__ void resize_nearest_kernel(const float* __restrict__ x, float* __rest
     }
 }
 
-// the x2 asymmetric case (the up-sampling of a detection neck: out[2y + a][2x + b] = in[y][x]; with h_scale = w_scale = 0.5 the
-// reference's floor(o * 0.5) is o >> 1 exactly): a thread reads FOUR consecutive inputs (16 bytes) and writes two rows of eight
-// outputs (2 x 2 x 16 bytes), whole rows of a wave contiguous on both sides.  The general kernel above writes 4 bytes per thread
-// from an input index it derives with two divisions: 0.17 of the HBM rate on [64, 128, 80, 80].
-__global__ __launch_bounds__(256) void resize_x2_kernel(const float* __restrict__ x, float* __restrict__ out, unsigned quads_per_image,
-                                                        int in_w4 /* in_w / 4 */, int in_h, long long xbs, long long obs) {
+// asymmetric up-sampling by a power of two S (the x2 of a detection neck, the x4 / x8 of a prototype branch):
+// out[S y + a][S x + b] = in[y][x] -- with h_scale = w_scale = 1 / S exactly representable, the reference's floor(o * scale) is
+// o / S exactly.  A thread reads FOUR consecutive inputs (16 bytes) and writes S rows of 4 S outputs as 16-byte stores, whole rows of
+// a wave contiguous on both sides.  The general kernel above writes 4 bytes per thread from an input index it derives with two
+// divisions: 0.17 of the HBM rate on [64, 128, 80, 80].
+template <int S>
+__global__ __launch_bounds__(256) void resize_up_kernel(const float* __restrict__ x, float* __restrict__ out, unsigned quads_per_image,
+                                                        int in_w4 /* in_w / 4 */, long long xbs, long long obs) {
     const unsigned q = blockIdx.x * 256u + threadIdx.x;
     if (q >= quads_per_image) return;
     const unsigned row = q / (unsigned)in_w4, xq = q - row * (unsigned)in_w4;   // row = channel * in_h + y
     const float4 v = *reinterpret_cast<const float4*>(x + (long long)blockIdx.y * xbs + (long long)row * (4 * in_w4) + 4 * xq);
-    float* o = out + (long long)blockIdx.y * obs + (long long)row * 2 * (8 * in_w4) + 8 * xq;
-    const float4 lo = make_float4(v.x, v.x, v.y, v.y), hi = make_float4(v.z, v.z, v.w, v.w);
-    reinterpret_cast<float4*>(o)[0] = lo;
-    reinterpret_cast<float4*>(o)[1] = hi;
-    reinterpret_cast<float4*>(o + 8 * in_w4)[0] = lo;
-    reinterpret_cast<float4*>(o + 8 * in_w4)[1] = hi;
+    const float e[4] = {v.x, v.y, v.z, v.w};
+    const long long out_w = (long long)S * 4 * in_w4;
+    float* o = out + (long long)blockIdx.y * obs + (long long)row * S * out_w + (long long)S * 4 * xq;
+    float4 seg[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) seg[j] = make_float4(e[(4 * j) / S], e[(4 * j + 1) / S], e[(4 * j + 2) / S], e[(4 * j + 3) / S]);
+#pragma unroll
+    for (int a = 0; a < S; ++a)
+#pragma unroll
+        for (int j = 0; j < S; ++j) reinterpret_cast<float4*>(o + a * out_w)[j] = seg[j];
 }
 
 // max_pool2d (conv2d.rs:1051-1254): padded cells are skipped (== -inf)
@@ -477,6 +483,107 @@ __global__ __launch_bounds__(256) void topk_rank_kernel(const float* __restrict_
     if (in && part == 0 && rank < k) {
         values[rowi * k + rank] = v;
         indices[rowi * k + rank] = (float)vi;
+    }
+}
+
+// Long rows, one workgroup per row: RADIX SELECT.  The prefilter above keeps everything at least as good as the k-th best of the
+// first 2048 elements -- ~n k / 2048 survivors, ranked against each other in O(m^2): 0.51 ms for the [64, 24000] -> 300 selection
+// of a Yolo26n-seg tail.  Here the k-th best value itself is found by four 8-bit histogram passes over order-preserving integer
+// images of the values (the histogram bin that holds the k-th element fixes 8 more bits of it each pass), the elements better
+// than it plus the first ties in index order are collected (exactly k of them: the stable sort's "lower index first" among equal
+// values), and only those k are ranked.  Five sweeps of an L2-resident row and k^2 comparisons, no atomics on global memory, a
+// deterministic result: the bits of topk_kernel.  (-0 counts as +0, as `==` does; a NaN ranks below everything.)
+__device__ __forceinline__ unsigned topk_key(float v, int largest) {
+    unsigned u = __float_as_uint(v);
+    if (v != v) return 0u;
+    if (v == 0.0f) u = 0u;
+    const unsigned asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending with the value; >= 1 for every non-NaN
+    return largest ? asc : ~asc + 1u;                                   // "better" = larger key either way (~asc + 1 >= 1 too)
+}
+__global__ __launch_bounds__(256) void topk_select_kernel(const float* __restrict__ x, int64_t n64, int k, int largest,
+                                                          float* __restrict__ values, float* __restrict__ indices) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_need;
+    __shared__ unsigned s_gt[256], s_eq[256];
+    __shared__ unsigned sel_key[1024];
+    __shared__ int sel_idx[1024];
+    __shared__ float sel_val[1024];
+    const int tid = threadIdx.x, n = (int)n64;
+    const float* row = x + (int64_t)blockIdx.x * n64;
+    if (tid == 0) {
+        s_prefix = 0u;
+        s_need = (unsigned)k;
+    }
+    unsigned mask = 0u;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0u;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        for (int i = tid; i < n; i += 256) {
+            const unsigned key = topk_key(row[i], largest);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {  // the bin (from the best downwards) in which the need-th element lies
+            unsigned need = s_need, acc = 0u;
+            int b = 255;
+            for (; b > 0; --b) {
+                if (acc + hist[b] >= need) break;
+                acc += hist[b];
+            }
+            s_need = need - acc;
+            s_prefix = prefix | ((unsigned)b << shift);
+        }
+        mask |= 0xffu << shift;
+        __syncthreads();
+    }
+    const unsigned T = s_prefix, need_eq = s_need;  // the k-th best key; how many elements equal to it belong to the result
+    const int chunk = (n + 255) / 256, i0 = tid * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    unsigned cgt = 0u, ceq = 0u;
+    for (int i = i0; i < i1; ++i) {
+        const unsigned key = topk_key(row[i], largest);
+        cgt += key > T ? 1u : 0u;
+        ceq += key == T ? 1u : 0u;
+    }
+    s_gt[tid] = cgt;
+    s_eq[tid] = ceq;
+    __syncthreads();
+    if (tid == 0) {  // exclusive scans in index order (256 entries)
+        unsigned a = 0u, e = 0u;
+        for (int t = 0; t < 256; ++t) {
+            const unsigned ga = s_gt[t], ea = s_eq[t];
+            s_gt[t] = a;
+            s_eq[t] = e;
+            a += ga;
+            e += ea;
+        }
+    }
+    __syncthreads();
+    const unsigned n_gt = (unsigned)k - need_eq;
+    unsigned pg = s_gt[tid], pe = s_eq[tid];
+    for (int i = i0; i < i1; ++i) {
+        const float v = row[i];
+        const unsigned key = topk_key(v, largest);
+        int slot = -1;
+        if (key > T) slot = (int)pg++;
+        else if (key == T) {
+            if (pe < need_eq) slot = (int)(n_gt + pe);
+            ++pe;
+        }
+        if (slot >= 0) {
+            sel_key[slot] = key;
+            sel_idx[slot] = i;
+            sel_val[slot] = v;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < k; e += 256) {
+        const unsigned key = sel_key[e];
+        const int idx = sel_idx[e];
+        int rank = 0;
+        for (int j = 0; j < k; ++j) rank += (sel_key[j] > key || (sel_key[j] == key && sel_idx[j] < idx)) ? 1 : 0;
+        values[(int64_t)blockIdx.x * k + rank] = sel_val[e];
+        indices[(int64_t)blockIdx.x * k + rank] = (float)idx;  // indices are returned as f32
     }
 }
 
@@ -885,11 +992,17 @@ static int resize_nearest_entry(LeleCtx* ctx, const LeleTensor* x, int64_t out_h
         dst = (float*)out->data;
     }
     const long long xbs_ = pv && pv->x_pitch ? pv->x_pitch : in_img, obs_ = pv && pv->out_pitch ? pv->out_pitch : out_img;
-    if (total && asymmetric && out_h == 2 * x->shape[2] && out_w == 2 * x->shape[3] && x->shape[3] % 4 == 0 && x->shape[0] <= 65535 &&
+    const int64_t up = x->shape[2] > 0 && out_h % x->shape[2] == 0 ? out_h / x->shape[2] : 0;
+    if (total && asymmetric && (up == 2 || up == 4 || up == 8) && out_w == up * x->shape[3] && x->shape[3] % 4 == 0 && x->shape[0] <= 65535 &&
         in_img / 4 < (int64_t(1) << 32) && ((((uintptr_t)dx) | ((uintptr_t)dst)) & 15) == 0 && xbs_ % 4 == 0 && obs_ % 4 == 0) {
         const unsigned quads = (unsigned)(in_img / 4);
-        hipLaunchKernelGGL(resize_x2_kernel, dim3((quads + 255u) / 256u, (unsigned)x->shape[0]), dim3(256), 0, ctx->stream, (const float*)dx, dst,
-                           quads, (int)(x->shape[3] / 4), (int)x->shape[2], xbs_, obs_);
+        const dim3 ugrid((quads + 255u) / 256u, (unsigned)x->shape[0]);
+        if (up == 2)
+            hipLaunchKernelGGL(resize_up_kernel<2>, ugrid, dim3(256), 0, ctx->stream, (const float*)dx, dst, quads, (int)(x->shape[3] / 4), xbs_, obs_);
+        else if (up == 4)
+            hipLaunchKernelGGL(resize_up_kernel<4>, ugrid, dim3(256), 0, ctx->stream, (const float*)dx, dst, quads, (int)(x->shape[3] / 4), xbs_, obs_);
+        else
+            hipLaunchKernelGGL(resize_up_kernel<8>, ugrid, dim3(256), 0, ctx->stream, (const float*)dx, dst, quads, (int)(x->shape[3] / 4), xbs_, obs_);
         LELE_HIP_CHECK(hipGetLastError());
     } else if (total) {
         hipLaunchKernelGGL(resize_nearest_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx, dst, planes,
@@ -1036,7 +1149,10 @@ int lele_hip_topk(LeleCtx* ctx, const LeleTensor* x, int64_t k, int largest, Lel
     LELE_TRY(out_indices->reserve((size_t)rows * kk * 4));
     if (rows * kk) {
         const dim3 tgrid((unsigned)((n + 255) / 256), (unsigned)rows);
-        if (n <= 4096 || kk > 1024 || n >= (int64_t(1) << 31)) {
+        if (n > 1024 && kk <= 1024 && n < (int64_t(1) << 31) && rows < (int64_t(1) << 31)) {  // long rows: radix select, a workgroup per row
+            hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const float*)dx, n, (int)kk, largest,
+                               (float*)out_values->data, (float*)out_indices->data);
+        } else if (n <= 4096 || kk > 1024 || n >= (int64_t(1) << 31)) {
             hipLaunchKernelGGL(topk_kernel, tgrid, dim3(256), 0, ctx->stream, (const float*)dx, n, kk, largest,
                                (float*)out_values->data, (float*)out_indices->data);
         } else {  // prefilter on the first 2048 elements, then rank the survivors only

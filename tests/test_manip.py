@@ -103,7 +103,8 @@ def test_device_pad_gather_resize_pool_topk(ctx):
     gi = rng.integers(-5, 5, (4, 8)).astype(np.float32)
     assert np.array_equal(Kk.gather_elements(emb[:5], gi, 0, ctx=ctx).numpy(), npref.gather_elements(emb[:5], gi, 0))
     f = rng.standard_normal((2, 3, 20, 20)).astype(np.float32)
-    for kw in (dict(scales=[1, 1, 2, 2]), dict(sizes=[2, 3, 33, 17]), dict(scales=[1, 1, 0.5, 1.5])):
+    for kw in (dict(scales=[1, 1, 2, 2]), dict(scales=[1, 1, 4, 4]), dict(scales=[1, 1, 8, 8]), dict(scales=[1, 1, 4, 2]),
+               dict(sizes=[2, 3, 33, 17]), dict(scales=[1, 1, 0.5, 1.5])):
         for mode in ("asymmetric", "half_pixel"):
             got = Kk.resize_nearest(f, coordinate_transform_mode=mode, ctx=ctx, **kw)
             oh, ow = got.shape[2:]
