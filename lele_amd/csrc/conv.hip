@@ -649,6 +649,17 @@ struct C3M {  // KS = 3 (3 x 3, padding in the geometry) or 1 (1 x 1: the "windo
     static constexpr int TAPS = KS * KS;
 };
 
+// The tile of a workgroup of the window-once kernels: `th` rows x `tw` columns of output positions, th * tw <= the positions a workgroup
+// multiplies (256 at stride 1, 128 at stride 2).  The MFMA's 32 columns are 32 CONSECUTIVE POSITIONS OF THE TILE IN ROW-MAJOR ORDER,
+// not 32 columns of one row: position p sits at (p / tw, p % tw), so a 40-wide map is covered by 40 x 6 tiles (0.94 of the products
+// land on outputs) and an 80-wide one by 16 x 16 tiles (1.0) where rows of 32 covered 0.62 and 0.83.  The host picks (tw, th) per
+// layer (pick_win_tile); the window in LDS, the weight fragments and the products are the same for every shape.
+struct WinTile {
+    int tw, th, tiles_x;
+    unsigned inv;  // ceil(2^20 / tw): p / tw == (p * inv) >> 20 for every p < 2^20 / tw
+};
+__device__ __forceinline__ int wt_row(const WinTile& t, int p) { return (int)(((unsigned)p * t.inv) >> 20); }
+
 __device__ __forceinline__ unsigned c3m_pair(float even, float odd) { return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u); }
 
 // Epilogue of the window-once kernels: a consumer wave holds NJ accumulator tiles (32 output channels x 32 columns of NJ tile rows).
@@ -659,9 +670,9 @@ __device__ __forceinline__ unsigned c3m_pair(float even, float odd) { return __b
 // anything else, and the activation is chosen once per wave: written per element (a load behind `if (bias)` and a switch on the
 // activation for each of the 16 NJ values) the compiler emitted 64 load -> wait -> polynomial chains one after the other, ~19 k
 // cycles of a tile whose products take 28 k.
-template <int NJ, int OCT, int TH>
+template <int NJ, int OCT>
 __device__ __forceinline__ void c3m_epilogue(const cf32x16 (&acc)[NJ], const ConvEpi& epi, const ConvGeom& g, char* lds, int wave, int lane,
-                                             int wm, int wn, int ocb, int img, int tyi, int txi) {
+                                             int wm, int wn, int ocb, int img, int ty0, int tx0, const WinTile& wt) {
     const int hv = lane >> 5, l31 = lane & 31;
     const int ocw = ocb * OCT + wm * 32;  // first output channel of this wave's tile
     float bv[16];
@@ -674,16 +685,22 @@ __device__ __forceinline__ void c3m_epilogue(const cf32x16 (&acc)[NJ], const Con
             bv[r] = epi.bias[o < g.oc ? o : g.oc - 1];
         }
     }
-    const int ox = txi * C3M_TW + l31;
-    if (g.ow % 4 == 0 && epi.vec_ok()) {  // 16-byte stores need the rows AND the destination (a view may start anywhere) aligned
+    const int live = wt.tw * wt.th;  // positions of the tile; the rest of the 32 NJ-position strips is padding
+    int oyj[NJ], oxj[NJ];
+    bool inj[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int p = (NJ * wn + j) * 32 + l31, row = wt_row(wt, p);
+        oyj[j] = ty0 + row, oxj[j] = tx0 + p - row * wt.tw;
+        inj[j] = p < live && oyj[j] < g.oh && oxj[j] < g.ow;
+    }
+    if (g.ow % 4 == 0 && wt.tw % 4 == 0 && epi.vec_ok()) {  // 16-byte stores need the rows AND the destination (a view may start anywhere) aligned
         constexpr int OCP = NJ * 32 + 8;  // floats per output channel: the two half waves (4 channels apart) land on different banks
         float* mine = reinterpret_cast<float*>(lds) + wave * (32 * OCP);
         bool body[NJ], every = true;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int oy = tyi * TH + NJ * wn + j;
-            const int col = (oy < g.oh ? oy : g.oh - 1) * g.ow + (ox < g.ow ? ox : g.ow - 1);
-            body[j] = col < (g.plane & ~7);
+            body[j] = !inj[j] || oyj[j] * g.ow + oxj[j] < (g.plane & ~7);  // (a position outside is not stored: either form does)
             every = every && body[j];
         }
         // the activation's scalar-tail form (libm) only where some lane is in the last 0-7 positions of the plane
@@ -703,23 +720,30 @@ __device__ __forceinline__ void c3m_epilogue(const cf32x16 (&acc)[NJ], const Con
         else if (epi.act == LELE_ACT_RELU) put([](float v, bool) { return v > 0.0f ? v : 0.0f; });
         else if (all_body) put([](float v, bool) { return apply_act(v, LELE_ACT_SILU, true); });
         else put([](float v, bool b) { return apply_act(v, LELE_ACT_SILU, b); });
+        // four consecutive positions of a strip are four consecutive columns of one row (tw is a multiple of four)
         const int q4 = lane & 7;
-        const int oxq = txi * C3M_TW + 4 * q4;
+        int colq[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int p = (NJ * wn + j) * 32 + 4 * q4, row = wt_row(wt, p), oy = ty0 + row, oxq = tx0 + p - row * wt.tw;
+            colq[j] = p < live && oy < g.oh && oxq < g.ow ? oy * g.ow + oxq : -1;
+        }
 #pragma unroll
         for (int it = 0; it < 4 * NJ; ++it) {
             const int rowid = it * 8 + (lane >> 3), ol = rowid / NJ, j = rowid % NJ;
-            const int oy = tyi * TH + NJ * wn + j, oc = ocw + ol;
+            const int oc = ocw + ol;
             const float4 v = *reinterpret_cast<const float4*>(mine + ol * OCP + j * 32 + 4 * q4);
-            if (oy < g.oh && oxq < g.ow && oc < g.oc)
-                *reinterpret_cast<float4*>(epi.out + (int64_t)img * g.obs + (int64_t)oc * g.plane + oy * g.ow + oxq) = v;
+            int cq = colq[0];
+#pragma unroll
+            for (int jj = 1; jj < NJ; ++jj) cq = j == jj ? colq[jj] : cq;
+            if (cq >= 0 && oc < g.oc) *reinterpret_cast<float4*>(epi.out + (int64_t)img * g.obs + (int64_t)oc * g.plane + cq) = v;
         }
         return;
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int oy = tyi * TH + NJ * wn + j;
-        if (oy >= g.oh || ox >= g.ow) continue;
-        const int col = oy * g.ow + ox;
+        if (!inj[j]) continue;
+        const int col = oyj[j] * g.ow + oxj[j];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int oc = ocw + (r & 3) + 8 * (r >> 2) + 4 * hv;
@@ -733,14 +757,15 @@ __device__ __forceinline__ void c3m_epilogue(const cf32x16 (&acc)[NJ], const Con
 template <int KS, int OCT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_window_kernel(const float* __restrict__ x,
                                                                                                  const cu32x4* __restrict__ wfrag,
-                                                                                                 ConvEpi epi, ConvGeom g, int tiles_x) {
+                                                                                                 ConvEpi epi, ConvGeom g, WinTile wt) {
     typedef C3M<KS> W;
     constexpr int NJ = OCT == 64 ? 4 : 2, MTB = OCT / 32;  // tile rows per consumer wave, 32-channel tiles per workgroup
     extern __shared__ __attribute__((aligned(16))) char c3m_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hv = lane >> 5, l31 = lane & 31;
-    const int tile = blockIdx.x, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int tile = blockIdx.x, tyi = tile / wt.tiles_x, txi = tile - tyi * wt.tiles_x;
     const int ocb = blockIdx.y, img = blockIdx.z;
     const int hw = g.ih * g.iw, nchunk = g.c / 16;
+    const int pwt = wt.tw + KS - 1, post = (wt.th + KS - 1) * pwt;  // the window of this tile shape: post <= W::POS positions
     auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
     if (wave >= 4) {
         // ------------------------------------------------------------ producers: the window of the next chunk, split, into LDS.
@@ -748,17 +773,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // wait for its next weight fragment without waiting for the window too (measured: 938 us against 1529 for the GEMM on
         // 64 -> 64 channels at 160 x 160 x 64 with one kind of wave; the window's HBM latency sat in front of every chunk)
         const int pt = tid - 256;
-        const int iy0 = tyi * C3M_TH - g.pt, ix0 = txi * C3M_TW - g.pl;
+        const int iy0 = tyi * wt.th - g.pt, ix0 = txi * wt.tw - g.pl;
         const float* xin = x + (int64_t)img * g.xbs;
         int t_off[W::TASKS], t_lds[W::TASKS];  // task t = (position, channel quad); its four channel planes are hw apart
         bool t_in[W::TASKS];
 #pragma unroll
         for (int i = 0; i < W::TASKS; ++i) {
-            const int t = pt + 256 * i, pos = t % W::POS, q = t / W::POS;  // q < 4 while t < 4 * POS
-            const int py = pos / W::PW, px = pos - py * W::PW, iy = iy0 + py, ix = ix0 + px;
-            t_in[i] = t < 4 * W::POS && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+            const int t = pt + 256 * i, q = t / post, pos = t - q * post;  // q < 4 while t < 4 * post
+            const int py = pos / pwt, px = pos - py * pwt, iy = iy0 + py, ix = ix0 + px;
+            t_in[i] = q < 4 && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
             t_off[i] = t_in[i] ? (4 * q * hw + iy * g.iw + ix) : 0;
-            t_lds[i] = t < 4 * W::POS ? pos * C3M_PITCH + 8 * q : -1;
+            t_lds[i] = q < 4 ? pos * C3M_PITCH + 8 * q : -1;
         }
         float4 sa[W::TASKS], sb[W::TASKS];
         auto fetch = [&](float4 (&st)[W::TASKS], int cc) {
@@ -812,10 +837,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // ---------------------------------------------------------------- consumers: 32 output channels x 4 rows of the tile each
     const int wm = OCT == 64 ? (wave & 1) : 0, wn = OCT == 64 ? (wave >> 1) : wave;
     cf32x16 acc[NJ];
+    int sb[NJ];  // where this lane's position of strip j sits in the window (byte offset of its tap (0, 0))
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ; ++j) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        int p = (NJ * wn + j) * 32 + l31;
+        p = p < wt.tw * wt.th ? p : 0;  // padding of the last strip: any position, its products are not stored
+        const int row = wt_row(wt, p);
+        sb[j] = (row * pwt + p - row * wt.tw) * C3M_PITCH + hv * 16;
+    }
     // weights of this wave's 32 output channels: [oc tile][chunk][tap][piece][64 lanes]
     const cu32x4* wbase = wfrag + ((int64_t)(ocb * MTB + wm) * nchunk) * (W::TAPS * 3 * 64) + lane;
     // weight fragments one tap ahead of their products (two register sets; the nine taps of a chunk are unrolled in pairs + one).
@@ -834,10 +865,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // the pairs below)
     auto chunk = [&](int cc, auto pc) {
         constexpr int P = decltype(pc)::value;
-        const char* stage = c3m_lds + (cc & 1) * W::STAGE + hv * 16;
+        const char* stage = c3m_lds + (cc & 1) * W::STAGE;
 #pragma unroll
         for (int tap = 0; tap < W::TAPS; ++tap) {
             const int a = tap / KS, b = tap - KS * a;
+            const char* tapw = stage + (a * pwt + b) * C3M_PITCH;
             cu32x4 (&af)[3] = ar[(P + tap) & 1];
             wload(ar[(P + tap + 1) & 1], (int64_t)cc * W::TAPS + tap + 1);
 #define LELE_CBF(v) __builtin_bit_cast(cbf16x8, v)
@@ -847,7 +879,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 cu32x4 bf[2][3];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const char* src = stage + ((NJ * wn + 2 * jp + j + a) * W::PW + l31 + b) * C3M_PITCH;
+                    const char* src = tapw + sb[2 * jp + j];
 #pragma unroll
                     for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const cu32x4*>(src + 32 * p);
                 }
@@ -871,7 +903,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (cc < nchunk) chunk(cc, std::integral_constant<int, 0>());
     }
     static_assert(4 * 32 * (NJ * 32 + 8) * 4 <= W::LDS, "the epilogue tiles fit the stages");
-    c3m_epilogue<NJ, OCT, C3M_TH>(acc, epi, g, c3m_lds, wave, lane, wm, wn, ocb, img, tyi, txi);
+    c3m_epilogue<NJ, OCT>(acc, epi, g, c3m_lds, wave, lane, wm, wn, ocb, img, tyi * wt.th, txi * wt.tw, wt);
 }
 // ---- the same for STRIDE 2 (3 x 3): a workgroup owns 64 output channels x (4 rows x 32 columns) of one image.  The window of a
 // stride-2 tile is 9 x 65 input positions; stored as it lies, tap (a, b) of output column l would read position 2 l + b -- a
@@ -894,14 +926,15 @@ struct C3S2 {
 template <int OCT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_window_s2_kernel(const float* __restrict__ x,
                                                                                                     const cu32x4* __restrict__ wfrag,
-                                                                                                    ConvEpi epi, ConvGeom g, int tiles_x) {
+                                                                                                    ConvEpi epi, ConvGeom g, WinTile wt) {
     typedef C3S2 W;
     constexpr int NJ = OCT == 64 ? 2 : 1, MTB = OCT / 32, TAPS = 9;
     extern __shared__ __attribute__((aligned(16))) char c3m_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hv = lane >> 5, l31 = lane & 31;
-    const int tile = blockIdx.x, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int tile = blockIdx.x, tyi = tile / wt.tiles_x, txi = tile - tyi * wt.tiles_x;
     const int ocb = blockIdx.y, img = blockIdx.z;
     const int hw = g.ih * g.iw, nchunk = g.c / 16;
+    const int sxt = wt.tw + 1, planet = (wt.th + 1) * sxt, post = 4 * planet;  // slots of a phase plane for this tile shape: post <= W::POS
     auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
     if (wave >= 4) {
         // ------------------------------------------------------------ producers: one chunk in registers, parked when the stage is free.
@@ -910,18 +943,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // a position outside the image (the load then returns zeros by itself): written with pointers and a select, the eleven
         // 64-bit addresses and masks did not fit beside the data and the compiler spilled 31 registers.
         const int pt = tid - 256;
-        const int iy0 = tyi * W::TH * 2 - g.pt, ix0 = txi * W::TW * 2 - g.pl;
+        const int iy0 = tyi * wt.th * 2 - g.pt, ix0 = txi * wt.tw * 2 - g.pl;
         const float* xin = x + (int64_t)img * g.xbs;
         unsigned t_off[W::TASKS];
         int t_lds[W::TASKS];
 #pragma unroll
         for (int i = 0; i < W::TASKS; ++i) {
-            const int t = pt + 256 * i, slot = t % W::POS, q = t / W::POS;  // q < 4 while t < 4 * POS
-            const int ph = slot / W::PLANE, r = slot - ph * W::PLANE, sy = r / W::SX, sx = r - sy * W::SX;
+            const int t = pt + 256 * i, q = t / post, slot = t - q * post;  // q < 4 while t < 4 * post
+            const int ph = slot / planet, r = slot - ph * planet, sy = r / sxt, sx = r - sy * sxt;
             const int py = 2 * sy + (ph >> 1), px = 2 * sx + (ph & 1), iy = iy0 + py, ix = ix0 + px;
-            const bool in = t < 4 * W::POS && py < W::PH && px < W::PW && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+            const bool in = q < 4 && py < 2 * wt.th + 1 && px < 2 * wt.tw + 1 && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
             t_off[i] = in ? (unsigned)(4 * q * hw + iy * g.iw + ix) * 4u : 0xfffffff0u;   // past num_records: reads as 0
-            t_lds[i] = t < 4 * W::POS ? slot * C3M_PITCH + 8 * q : -1;
+            t_lds[i] = q < 4 ? slot * C3M_PITCH + 8 * q : -1;
         }
         float4 st[W::TASKS];
         auto fetch = [&](int cc) {
@@ -974,10 +1007,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // ---------------------------------------------------------------- consumers: 32 output channels x NJ rows of the tile each
     const int wm = OCT == 64 ? (wave & 1) : 0, wn = OCT == 64 ? (wave >> 1) : wave;
     cf32x16 acc[NJ];
+    int sb[NJ];  // this lane's position of strip j: byte offset of its slot (row, column) in a phase plane
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int j = 0; j < NJ; ++j) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        int p = (NJ * wn + j) * 32 + l31;
+        p = p < wt.tw * wt.th ? p : 0;
+        const int row = wt_row(wt, p);
+        sb[j] = (row * sxt + p - row * wt.tw) * C3M_PITCH + hv * 16;
+    }
     const cu32x4* wbase = wfrag + ((int64_t)(ocb * MTB + wm) * nchunk) * (TAPS * 3 * 64) + lane;
     cu32x4 ar[2][3];
     const int64_t wlast = (int64_t)nchunk * TAPS - 1;
@@ -991,10 +1030,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         constexpr int P = decltype(pc)::value;
         if (cc) barrier();  // done with chunk cc - 1
         barrier();          // chunk cc is in the stage
-        const char* stage = c3m_lds + hv * 16;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int a = tap / 3, b = tap - 3 * a;
+            const char* tapw = c3m_lds + ((2 * (a & 1) + (b & 1)) * planet + (a >> 1) * sxt + (b >> 1)) * C3M_PITCH;
             cu32x4 (&af)[3] = ar[(P + tap) & 1];
             wload(ar[(P + tap + 1) & 1], (int64_t)cc * TAPS + tap + 1);
 #define LELE_CBF(v) __builtin_bit_cast(cbf16x8, v)
@@ -1002,8 +1041,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             cu32x4 bf[NJ][3];
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int slot = (2 * (a & 1) + (b & 1)) * W::PLANE + (NJ * wn + j + (a >> 1)) * W::SX + l31 + (b >> 1);
-                const char* src = stage + slot * C3M_PITCH;
+                const char* src = tapw + sb[j];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const cu32x4*>(src + 32 * p);
             }
@@ -1026,7 +1064,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     barrier();  // every consumer is done with the last chunk: the stage is free for the epilogue
     static_assert(4 * 32 * (NJ * 32 + 8) * 4 <= W::LDS, "the epilogue tiles fit the stage");
-    c3m_epilogue<NJ, OCT, W::TH>(acc, epi, g, c3m_lds, wave, lane, wm, wn, ocb, img, tyi, txi);
+    c3m_epilogue<NJ, OCT>(acc, epi, g, c3m_lds, wave, lane, wm, wn, ocb, img, tyi * wt.th, txi * wt.tw, wt);
 }
 // weights [OC][IC][taps] f32 -> split-bf16 fragments [ceil(OC / 32)][IC / 16][taps][3 pieces][64 lanes] x 16 bytes (zeros for the
 // channels past OC): lane (l31 = output channel in the tile, hv) holds input channels 16 chunk + 8 hv + [0, 8) of its tap
@@ -1075,6 +1113,31 @@ inline int conv_env(const char* name, int dflt) {
 inline int w1_max_oc() { static const int v = conv_env("LELE_HIP_CONV_W1_MAXOC", 128); return v; }
 inline int w1_min_plane() { static const int v = conv_env("LELE_HIP_CONV_W1_MINPLANE", 1600); return v; }
 inline int w1_min_c() { static const int v = conv_env("LELE_HIP_CONV_W1_MINC", 32); return v; }
+
+// The tile shape of a window-once launch (see WinTile): the fewest workgroups that cover an ow x oh map with th x tw <= `positions`
+// output positions each, whose window fits `max_slots` LDS slots -- (th + 2)(tw + 2) at stride 1, four phase planes of (th + 1)(tw + 1)
+// at stride 2, th x tw for a 1 x 1.  Widths are multiples of four (16-byte stores); among equal counts the widest tile (longest
+// contiguous runs on both sides).  LELE_HIP_CONV_TILE=tw,th overrides it for measurements.
+inline WinTile pick_win_tile(int ow, int oh, int positions, int ks, int stride, int max_slots) {
+    auto slots = [&](int tw, int th) { return stride == 2 ? 4 * (th + 1) * (tw + 1) : (th + ks - 1) * (tw + ks - 1); };
+    int btw = 0, bth = 0;
+    int64_t best = -1;
+    for (int tw = 4; tw <= positions; tw += 4) {
+        int th = std::min(positions / tw, oh);
+        while (th >= 1 && slots(tw, th) > max_slots) --th;
+        if (th < 1) continue;
+        const int64_t count = (int64_t)((ow + tw - 1) / tw) * ((oh + th - 1) / th);
+        if (best < 0 || count <= best) best = count, btw = tw, bth = th;
+        if (tw >= ow) break;
+    }
+    static const char* forced = getenv("LELE_HIP_CONV_TILE");
+    if (forced && *forced) {
+        int ftw = 0, fth = 0;
+        if (sscanf(forced, "%d,%d", &ftw, &fth) == 2 && ftw >= 4 && ftw % 4 == 0 && fth >= 1 && ftw * fth <= positions && slots(ftw, fth) <= max_slots)
+            btw = ftw, bth = fth;
+    }
+    return WinTile{btw, bth, (ow + btw - 1) / btw, (unsigned)(((1u << 20) + btw - 1) / btw)};
+}
 
 int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float* dw, const float* db, ConvGeom g, int act,
                float* out) {
@@ -1133,7 +1196,7 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
                  g.c >= w1_min_c())) &&
                g.dh == 1 && g.dw == 1 && g.sh == 1 && g.sw == 1 && g.c % 16 == 0 && g.oc > 16 && g.ow >= 16 && g.n <= 65535 &&
                (int64_t)g.c * g.ih * g.iw < (int64_t(1) << 31) &&
-               (int64_t)g.n * ((g.oc + 63) / 64) * ((g.ow + 31) / 32) * ((g.oh + 7) / 8) >= (int64_t)ctx->num_cus / 2) {
+               (int64_t)g.n * ((g.oc + 63) / 64) * (((int64_t)g.plane + 255) / 256) >= (int64_t)ctx->num_cus / 2) {
         // stride 1 over a batch, 16-channel chunks: the window-once MFMA kernel (see conv_window_kernel); 32-channel blocks when that
         // wastes fewer output channels than 64-channel ones
         const int taps = g.kh * g.kw;
@@ -1159,20 +1222,19 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             hipLaunchKernelGGL(conv_wfrag_kernel, dim3(grid_for((int64_t)(oc_pad / 32) * (g.c / 16) * taps * 64)), dim3(256), 0, ctx->stream, dw,
                                (cu32x4*)dwf, g.oc, g.c, taps);
         }
-        // a 1 x 1 convolution has no rows: a plane that is a multiple of 32 positions is handed over as rows of exactly one tile width
-        // (40 x 40 -> 50 x 32: 7 tiles of 8 x 32 at 0.89 occupancy instead of 5 x 2 at 0.62; 80 x 80 -> 200 x 32: 1.0 instead of 0.83)
-        if (taps == 1 && g.plane % 32 == 0) {
-            g.ih = g.oh = g.plane / 32;
-            g.iw = g.ow = 32;
+        // a 1 x 1 convolution has no rows: its plane is ONE row, cut into tiles of 256 positions (only the last one has padding)
+        if (taps == 1) {
+            g.ih = g.oh = 1;
+            g.iw = g.ow = g.plane;
         }
         ConvEpi epi{out, db, g, act};
-        const int tiles_x = (g.ow + 31) / 32, tiles_y = (g.oh + 7) / 8;
-        const dim3 wgrid((unsigned)(tiles_x * tiles_y), (unsigned)((g.oc + oct - 1) / oct), (unsigned)g.n);
+        const WinTile tile = pick_win_tile(g.ow, g.oh, 256, g.kh, 1, taps == 9 ? C3M<3>::POS : C3M<1>::POS);
+        const dim3 wgrid((unsigned)(tile.tiles_x * ((g.oh + tile.th - 1) / tile.th)), (unsigned)((g.oc + oct - 1) / oct), (unsigned)g.n);
 #define LELE_CW(KS_, OCT_)                                                                                      \
     do {                                                                                                        \
         auto kern = conv_window_kernel<KS_, OCT_>;                                                               \
         LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3M<KS_>::LDS));                \
-        hipLaunchKernelGGL(kern, wgrid, dim3(512), C3M<KS_>::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tiles_x); \
+        hipLaunchKernelGGL(kern, wgrid, dim3(512), C3M<KS_>::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tile);    \
     } while (0)
         if (taps == 9) {
             if (oct == 64) LELE_CW(3, 64);
@@ -1184,7 +1246,7 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
 #undef LELE_CW
     } else if (g.group == 1 && g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.sh == 2 && g.sw == 2 && g.c % 16 == 0 && g.oc > 16 &&
                g.ow >= 16 && g.n <= 65535 && (int64_t)g.c * g.ih * g.iw < (int64_t(1) << 31) &&
-               (int64_t)g.n * ((g.oc + 63) / 64) * ((g.ow + 31) / 32) * ((g.oh + 3) / 4) >= 2 * (int64_t)ctx->num_cus &&
+               (int64_t)g.n * ((g.oc + 63) / 64) * (((int64_t)g.plane + 127) / 128) >= 2 * (int64_t)ctx->num_cus &&
                !lab_env("LELE_HIP_CONV_NO_S2_WINDOW")) {
         // stride 2 over a batch: the de-interleaved window kernel (see conv_window_s2_kernel); weights as for the stride-1 kernel,
         // blocks of 32 output channels when that wastes fewer of them than blocks of 64
@@ -1210,16 +1272,16 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
                                (cu32x4*)dwf, g.oc, g.c, 9);
         }
         ConvEpi epi{out, db, g, act};
-        const int tiles_x = (g.ow + 31) / 32, tiles_y = (g.oh + 3) / 4;
-        const dim3 wgrid((unsigned)(tiles_x * tiles_y), (unsigned)((g.oc + oct - 1) / oct), (unsigned)g.n);
+        const WinTile tile = pick_win_tile(g.ow, g.oh, 128, 3, 2, C3S2::POS);
+        const dim3 wgrid((unsigned)(tile.tiles_x * ((g.oh + tile.th - 1) / tile.th)), (unsigned)((g.oc + oct - 1) / oct), (unsigned)g.n);
         if (oct == 64) {
             auto kern = conv_window_s2_kernel<64>;
             LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3S2::LDS));
-            hipLaunchKernelGGL(kern, wgrid, dim3(512), C3S2::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tiles_x);
+            hipLaunchKernelGGL(kern, wgrid, dim3(512), C3S2::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tile);
         } else {
             auto kern = conv_window_s2_kernel<32>;
             LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3S2::LDS));
-            hipLaunchKernelGGL(kern, wgrid, dim3(512), C3S2::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tiles_x);
+            hipLaunchKernelGGL(kern, wgrid, dim3(512), C3S2::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tile);
         }
     } else if (g.group == 1 && g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.sh == g.sw && (g.sh == 1 || g.sh == 2) && g.oc <= 16 &&
                g.c <= 64 && g.ow >= 16 && g.n <= 65535 &&

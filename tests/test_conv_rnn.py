@@ -260,7 +260,7 @@ CONV_SHAPES = [
     (32, 32, 40, 44, 128, 3, 3, 1, [1, 1, 1, 1], [1, 1], [1, 1], "silu"),
     (40, 16, 30, 37, 64, 3, 3, 1, [1, 0, 1, 2], [1, 1], [1, 1], "relu"),
     (32, 48, 33, 64, 64, 3, 3, 1, [0, 1, 2, 1], [1, 1], [1, 1], None),
-    # stride 2 over a batch (the implicit GEMM: a stride-2 form of the window kernel measured no faster), even and odd input sizes
+    # stride 2 over a batch (the de-interleaved window kernel), even and odd input sizes
     (32, 32, 80, 80, 64, 3, 3, 1, [1, 1, 1, 1], [2, 2], [1, 1], "silu"),
     (40, 16, 41, 77, 96, 3, 3, 1, [0, 1, 1, 0], [2, 2], [1, 1], "relu"),
     # the same kernel in its other forms: blocks of 32 output channels with a ragged last block (OC = 80), and 1 x 1 on a large plane
@@ -274,6 +274,15 @@ CONV_SHAPES = [
     (128, 33, 36, 30, 40, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "relu"),
     (168, 16, 27, 29, 96, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], None),
     (64, 130, 48, 40, 200, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "silu"),
+    # the tile shapes the host picks per map (pick_win_tile: row-major strips of 32 positions, not rows of 32): 20 x 12 on a 20-wide
+    # map, 16 x 16 on an 80-wide one, 20 x 6 / 40 x 3 at stride 2, a 1 x 1 plane as one row of 256-position tiles with a ragged last
+    # tile (16-byte stores) and with an odd plane (scalar stores)
+    (64, 32, 20, 20, 64, 3, 3, 1, [1, 1, 1, 1], [1, 1], [1, 1], "silu"),
+    (16, 32, 80, 80, 64, 3, 3, 1, [1, 1, 1, 1], [1, 1], [1, 1], "relu"),
+    (128, 32, 40, 40, 64, 3, 3, 1, [1, 1, 1, 1], [2, 2], [1, 1], "silu"),
+    (48, 16, 80, 80, 32, 3, 3, 1, [1, 1, 1, 1], [2, 2], [1, 1], None),
+    (32, 48, 50, 36, 64, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "silu"),
+    (32, 48, 45, 41, 64, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "relu"),
 ]
 
 
