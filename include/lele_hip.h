@@ -303,6 +303,14 @@ int lele_hip_conv2d_pitched(LeleCtx* ctx, const LeleTensor* x, const LeleTensor*
                             const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
                             const int64_t* strides, size_t nstr, int act, const LelePitch* pitch, LeleBuf* out, int64_t* out_shape,
                             int32_t* out_rank);
+/* conv2d followed by the Add of a residual block, in one call: out = act(conv(x) + bias) + res, res [N,C_out,H_out,W_out] f32.
+ * lele's generated code issues conv2d_silu and then `add` (examples/yolo26n-seg/src/yolo26seg.rs: every bottleneck's
+ * `x + cv2(cv1(x))`); the sum is formed from the same two f32 values, so the bits are those of the two calls.  `pitch` may be NULL;
+ * with it, x / the result may be channel views as for lele_hip_conv2d_pitched and y_pitch is the residual's image pitch (0 = dense). */
+int lele_hip_conv2d_res(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias, const LeleTensor* res,
+                        const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
+                        const int64_t* strides, size_t nstr, int act, const LelePitch* pitch, LeleBuf* out, int64_t* out_shape,
+                        int32_t* out_rank);
 /* reset_conv_stats / print_conv_stats (conv2d.rs:75, 101 -- no-ops upstream; examples/yolo26n-seg/src/main.rs:64,74 calls them):
  * 2-D convolutions issued on ctx since the last reset, as call count and multiply-accumulate count */
 int lele_hip_conv_stats_reset(LeleCtx* ctx);

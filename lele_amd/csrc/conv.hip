@@ -37,6 +37,10 @@ struct ConvGeom {
     // elements from one image to the next in x / out.  0 = dense (c*ih*iw / oc*plane, filled in by run_conv2d); anything else is a
     // CHANNEL VIEW of a wider NCHW tensor (lele_hip_conv2d_pitched: a Concat operand written in place, a Split result read in place)
     long long xbs = 0, obs = 0;
+    // a residual [n, oc, oh, ow] (rbs elements from image to image) added AFTER the activation: out = act(conv + bias) + res, the
+    // bits of the convolution followed by a separate Add (lele_hip_conv2d_res)
+    const float* res = nullptr;
+    long long rbs = 0;
 };
 
 // exact n / d for the small non-negative values of this file via one mulhi (m = floor(2^32/d) + 1 is exact while
@@ -194,10 +198,14 @@ struct ConvEpi {
         const int img = b / g.group, o = (b % g.group) * g.ocg + row;
         float v = acc;
         if (bias) v = v + pre;
-        out[(int64_t)img * g.obs + (int64_t)o * g.plane + col] = activate(v, col);
+        v = activate(v, col);
+        if (g.res) v = v + g.res[(int64_t)img * g.rbs + (int64_t)o * g.plane + col];
+        out[(int64_t)img * g.obs + (int64_t)o * g.plane + col] = v;
     }
     // the 16-byte store protocol of gemm_core.h: finished values, a row's address, and when rows may be written four columns at a time
-    __device__ __forceinline__ bool vec_ok() const { return (g.plane & 3) == 0 && (g.obs & 3) == 0 && (((uintptr_t)out) & 15) == 0; }
+    __device__ __forceinline__ bool vec_ok() const {
+        return (g.plane & 3) == 0 && (g.obs & 3) == 0 && (((uintptr_t)out) & 15) == 0 && (!g.res || ((g.rbs & 3) == 0 && (((uintptr_t)g.res) & 15) == 0));
+    }
     __device__ __forceinline__ float finish(int b, int row, int col, float acc, float pre) const {  // clamped coordinates
         float v = acc;
         if (bias) v = v + pre;
@@ -206,6 +214,11 @@ struct ConvEpi {
     __device__ __forceinline__ float* row_ptr(int b, int row) const {
         const int img = b / g.group, o = (b % g.group) * g.ocg + row;
         return out + (int64_t)img * g.obs + (int64_t)o * g.plane;
+    }
+    // the residual's row beside a row of finished values (gemm_core.h adds it to the 16-byte pieces it stores), or NULL
+    __device__ __forceinline__ const float* res_row_ptr(int b, int row) const {
+        const int img = b / g.group, o = (b % g.group) * g.ocg + row;
+        return g.res ? g.res + (int64_t)img * g.rbs + (int64_t)o * g.plane : nullptr;
     }
 };
 
@@ -736,7 +749,14 @@ __device__ __forceinline__ void c3m_epilogue(const cf32x16 (&acc)[NJ], const Con
             int cq = colq[0];
 #pragma unroll
             for (int jj = 1; jj < NJ; ++jj) cq = j == jj ? colq[jj] : cq;
-            if (cq >= 0 && oc < g.oc) *reinterpret_cast<float4*>(epi.out + (int64_t)img * g.obs + (int64_t)oc * g.plane + cq) = v;
+            if (cq >= 0 && oc < g.oc) {
+                float4 o4 = v;
+                if (g.res) {  // uniform
+                    const float4 r4 = *reinterpret_cast<const float4*>(g.res + (int64_t)img * g.rbs + (int64_t)oc * g.plane + cq);
+                    o4.x = v.x + r4.x, o4.y = v.y + r4.y, o4.z = v.z + r4.z, o4.w = v.w + r4.w;
+                }
+                *reinterpret_cast<float4*>(epi.out + (int64_t)img * g.obs + (int64_t)oc * g.plane + cq) = o4;
+            }
         }
         return;
     }
@@ -1114,24 +1134,42 @@ inline int w1_max_oc() { static const int v = conv_env("LELE_HIP_CONV_W1_MAXOC",
 inline int w1_min_plane() { static const int v = conv_env("LELE_HIP_CONV_W1_MINPLANE", 1600); return v; }
 inline int w1_min_c() { static const int v = conv_env("LELE_HIP_CONV_W1_MINC", 32); return v; }
 
+// out += res, image by image: the residual of lele_hip_conv2d_res behind the two routes that have their own epilogue (depthwise,
+// the direct small-channel kernel); everything else adds it where the finished values are stored
+__global__ __launch_bounds__(256) void conv_residual_kernel(float* __restrict__ out, const float* __restrict__ res, unsigned per_image,
+                                                            long long obs, long long rbs) {
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < per_image; i += gridDim.x * 256u)
+        out[(long long)blockIdx.y * obs + i] = out[(long long)blockIdx.y * obs + i] + res[(long long)blockIdx.y * rbs + i];
+}
+
 // The tile shape of a window-once launch (see WinTile): the fewest workgroups that cover an ow x oh map with th x tw <= `positions`
 // output positions each, whose window fits `max_slots` LDS slots -- (th + 2)(tw + 2) at stride 1, four phase planes of (th + 1)(tw + 1)
 // at stride 2, th x tw for a 1 x 1.  Widths are multiples of four (16-byte stores); among equal counts the widest tile (longest
 // contiguous runs on both sides).  LELE_HIP_CONV_TILE=tw,th overrides it for measurements.
-inline WinTile pick_win_tile(int ow, int oh, int positions, int ks, int stride, int max_slots) {
+inline WinTile pick_win_tile(int ow, int oh, int positions, int ks, int stride, int max_slots, int64_t units, int num_cus) {
+    // `units` = images x blocks of output channels: units x tiles workgroups are launched.  A workgroup multiplies its `positions`
+    // whether they are outputs or padding, so with more workgroups than CUs the fewest tiles win; a launch that does not even give
+    // every CU one workgroup takes as long as ONE of them, and then the smallest window (the most tiles that still fit) is fastest
+    // (256 -> 64 channels at 20 x 20 x 64 images: two 20 x 12 tiles an image 122 us, three 8-row tiles 105)
     auto slots = [&](int tw, int th) { return stride == 2 ? 4 * (th + 1) * (tw + 1) : (th + ks - 1) * (tw + ks - 1); };
     int btw = 0, bth = 0;
-    int64_t best = -1;
+    int64_t best = -1, best_slots = 0;
     for (int tw = 4; tw <= positions; tw += 4) {
         int th = std::min(positions / tw, oh);
         while (th >= 1 && slots(tw, th) > max_slots) --th;
-        if (th < 1) continue;
-        const int64_t count = (int64_t)((ow + tw - 1) / tw) * ((oh + th - 1) / th);
-        if (best < 0 || count <= best) best = count, btw = tw, bth = th;
+        for (; th >= 1; --th) {
+            const int64_t count = (int64_t)((ow + tw - 1) / tw) * ((oh + th - 1) / th);
+            const int64_t cost = std::max<int64_t>(count * units, num_cus), sl = slots(tw, th);
+            if (best < 0 || cost < best || (cost == best && (count * units <= num_cus ? sl <= best_slots : true)))
+                best = cost, best_slots = sl, btw = tw, bth = th;
+            if (count * units > num_cus) break;  // shorter tiles only add workgroups from here
+        }
         if (tw >= ow) break;
     }
     static const char* forced = getenv("LELE_HIP_CONV_TILE");
-    if (forced && *forced) {
+    if (forced && !strcmp(forced, "rows") && ks == 3) {  // the fixed tiles of round 3: 8 (4 at stride 2) rows of 32 columns
+        btw = 32, bth = stride == 2 ? 4 : 8;
+    } else if (forced && *forced && ks == 3) {
         int ftw = 0, fth = 0;
         if (sscanf(forced, "%d,%d", &ftw, &fth) == 2 && ftw >= 4 && ftw % 4 == 0 && fth >= 1 && ftw * fth <= positions && slots(ftw, fth) <= max_slots)
             btw = ftw, bth = fth;
@@ -1187,6 +1225,9 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             hipLaunchKernelGGL(depthwise_conv2d_kernel, dim3(grid_for(total)), dim3(256), 0, ctx->stream, dx, dw, db, out, g, act,
                                (unsigned)total);
         }
+        if (g.res)
+            hipLaunchKernelGGL(conv_residual_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)g.oc * g.plane + 255) / 256, 1024), (unsigned)g.n),
+                               dim3(256), 0, ctx->stream, out, g.res, (unsigned)((int64_t)g.oc * g.plane), g.obs, g.rbs);
     } else if (g.group == 1 &&
                ((g.kh == 3 && g.kw == 3) ||
                 // 1 x 1: only where it measured faster than the tiled GEMM on the Yolo-shaped network at batch 64 -- one block of output
@@ -1228,7 +1269,8 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             g.iw = g.ow = g.plane;
         }
         ConvEpi epi{out, db, g, act};
-        const WinTile tile = pick_win_tile(g.ow, g.oh, 256, g.kh, 1, taps == 9 ? C3M<3>::POS : C3M<1>::POS);
+        const WinTile tile = pick_win_tile(g.ow, g.oh, 256, g.kh, 1, taps == 9 ? C3M<3>::POS : C3M<1>::POS, (int64_t)g.n * ((g.oc + oct - 1) / oct),
+                                           ctx->num_cus);
         const dim3 wgrid((unsigned)(tile.tiles_x * ((g.oh + tile.th - 1) / tile.th)), (unsigned)((g.oc + oct - 1) / oct), (unsigned)g.n);
 #define LELE_CW(KS_, OCT_)                                                                                      \
     do {                                                                                                        \
@@ -1272,7 +1314,7 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
                                (cu32x4*)dwf, g.oc, g.c, 9);
         }
         ConvEpi epi{out, db, g, act};
-        const WinTile tile = pick_win_tile(g.ow, g.oh, 128, 3, 2, C3S2::POS);
+        const WinTile tile = pick_win_tile(g.ow, g.oh, 128, 3, 2, C3S2::POS, (int64_t)g.n * ((g.oc + oct - 1) / oct), ctx->num_cus);
         const dim3 wgrid((unsigned)(tile.tiles_x * ((g.oh + tile.th - 1) / tile.th)), (unsigned)((g.oc + oct - 1) / oct), (unsigned)g.n);
         if (oct == 64) {
             auto kern = conv_window_s2_kernel<64>;
@@ -1328,6 +1370,9 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             else LELE_C3(16, 2);
         }
 #undef LELE_C3
+        if (g.res)
+            hipLaunchKernelGGL(conv_residual_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)g.oc * g.plane + 255) / 256, 1024), (unsigned)g.n),
+                               dim3(256), 0, ctx->stream, out, g.res, (unsigned)((int64_t)g.oc * g.plane), g.obs, g.rbs);
     } else {
         ConvWLoad al{dw, g, (int)((((uintptr_t)dw & 15) == 0) && g.K % 4 == 0)};
         ConvEpi epi{out, db, g, act};
@@ -1493,7 +1538,7 @@ extern "C" {
 static int conv2d_entry(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,
                         const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
                         const int64_t* strides, size_t nstr, int act, const LelePitch* pv, LeleBuf* out, int64_t* out_shape,
-                        int32_t* out_rank) {
+                        int32_t* out_rank, const LeleTensor* res = nullptr) {
     LELE_REQUIRE(ctx && x && w && out, "conv2d: NULL argument");
     LELE_REQUIRE(x->rank == 4, "Conv2d: expected rank-4 input [N,C,H,W], got rank %d", x->rank);        // conv2d.rs:196
     LELE_REQUIRE(w->rank == 4, "Conv2d: expected rank-4 weight [C_out,C_in/g,kH,kW], got rank %d", w->rank);
@@ -1547,8 +1592,21 @@ static int conv2d_entry(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, 
     LELE_TRY(ctx->dev_ptr(w, &dwp));
     if (bias) LELE_TRY(ctx->dev_ptr(bias, &db));
     float* dst = nullptr;
+    if (res) {  // out = act(conv + bias) + res
+        LELE_REQUIRE(res->dtype == LELE_F32 && res->rank == 4 && res->shape[0] == g.n && res->shape[1] == g.oc && res->shape[2] == g.oh &&
+                         res->shape[3] == g.ow, "conv2d_res: the residual must be an f32 tensor of the result's shape [%d,%d,%d,%d]", g.n, g.oc, g.oh, g.ow);
+        LELE_REQUIRE((int64_t)g.oc * g.plane < (int64_t(1) << 32) && g.n <= 65535, "conv2d_res: an image exceeds 2^32 elements or more than 65535 images");
+        const void* dr = nullptr;
+        LELE_TRY(ctx->dev_ptr(res, &dr));
+        g.res = (const float*)dr;
+        g.rbs = (int64_t)g.oc * g.plane;
+        if (pv && pv->y_pitch) {
+            LELE_REQUIRE(res->mem == LELE_MEM_DEVICE && pv->y_pitch >= g.rbs, "conv2d_res: y_pitch needs a device tensor and must cover one image");
+            g.rbs = pv->y_pitch;
+        }
+    }
     if (pv) {  // channel views: see LelePitch in lele_hip.h
-        LELE_REQUIRE(pv->y_pitch == 0, "conv2d_pitched: y_pitch must be 0 (one tensor operand)");
+        LELE_REQUIRE(pv->y_pitch == 0 || res, "conv2d_pitched: y_pitch must be 0 (one tensor operand)");
         LELE_REQUIRE(pv->x_pitch == 0 || (x->mem == LELE_MEM_DEVICE && pv->x_pitch >= (int64_t)g.c * g.ih * g.iw),
                      "conv2d_pitched: x_pitch needs a device tensor and must cover one image");
         g.xbs = pv->x_pitch;
@@ -1560,6 +1618,14 @@ static int conv2d_entry(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, 
     }
     LELE_TRY(run_conv2d(ctx, w, (const float*)dx, (const float*)dwp, (const float*)db, g, act, dst));
     return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, (int64_t)g.oh, (int64_t)g.ow});
+}
+
+int lele_hip_conv2d_res(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias, const LeleTensor* res,
+                        const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
+                        const int64_t* strides, size_t nstr, int act, const LelePitch* pitch, LeleBuf* out, int64_t* out_shape,
+                        int32_t* out_rank) {
+    LELE_REQUIRE(res, "conv2d_res: NULL residual");
+    return conv2d_entry(ctx, x, w, bias, dilations, ndil, group, pads, npads, strides, nstr, act, pitch, out, out_shape, out_rank, res);
 }
 
 int lele_hip_conv2d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,

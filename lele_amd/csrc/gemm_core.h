@@ -178,6 +178,11 @@ template <class E, class = void>
 struct has_quad_store : std::false_type {};
 template <class E>
 struct has_quad_store<E, std::void_t<decltype(std::declval<E>().quad_ok())>> : std::true_type {};
+// epilogues with a residual added to the finished values (`res_row_ptr`: the residual's row beside an output row, or NULL)
+template <class E, class = void>
+struct has_res_row : std::false_type {};
+template <class E>
+struct has_res_row<E, std::void_t<decltype(std::declval<E>().res_row_ptr(0, 0))>> : std::true_type {};
 template <class E, class = void>
 struct has_vec_store : std::false_type {};
 template <class E>
@@ -364,7 +369,14 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {  // same-wave LDS order holds: no barrier
                         const int rl = it * 8 + (lane >> 3), row = m0 + wm * TMT * 32 + i * 32 + rl;
-                        const float4 v = *reinterpret_cast<const float4*>(mine + rl * 36 + 4 * (lane & 7));
+                        float4 v = *reinterpret_cast<const float4*>(mine + rl * 36 + 4 * (lane & 7));
+                        if constexpr (has_res_row<EPI>::value) {
+                            const float* rp = epi.res_row_ptr(batch, row < M ? row : M - 1);
+                            if (rp && row < M && c4 < N) {
+                                const float4 r4 = *reinterpret_cast<const float4*>(rp + c4);
+                                v.x += r4.x, v.y += r4.y, v.z += r4.z, v.w += r4.w;
+                            }
+                        }
                         if (row < M && c4 < N) *reinterpret_cast<float4*>(epi.row_ptr(batch, row) + c4) = v;  // N % 4 == 0: whole or absent
                     }
                 }

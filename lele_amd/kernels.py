@@ -50,7 +50,7 @@ def _is_view(x):
     return isinstance(x, _lib.DevTensor) and x.is_view
 
 
-def _op_pitched(ctx, fn, tensors, extra, out, out_window, dtype=np.float32, prefix=()):
+def _op_pitched(ctx, fn, tensors, extra, out, out_window, dtype=np.float32, prefix=(), pitch_of=(0, 1)):
     """a *_pitched entry point (include/lele_hip.h, LelePitch): fn(ctx, *prefix, *tensors, *extra, pitch, out, out_shape, out_rank).
     The first two tensors may be channel views; out_window = (offset, pitch) in elements writes the result into a window of `out`
     (which must already hold the enclosing tensor) and returns the view of it."""
@@ -59,10 +59,11 @@ def _op_pitched(ctx, fn, tensors, extra, out, out_window, dtype=np.float32, pref
     args = [ctx._h] + list(prefix)
     for t in tensors:
         args.append(_lib.as_tensor(unwrap(t), keep, views=True))
-    for t in tensors[2:]:
-        if _is_view(t):
-            raise _lib.LeleError("only the first two tensor operands may be channel views")
-    pv = _lib.LelePitch(_pitch(tensors[0]) if tensors else 0, _pitch(tensors[1]) if len(tensors) > 1 else 0,
+    for k, t in enumerate(tensors):
+        if k not in pitch_of and _is_view(t):
+            raise _lib.LeleError("only the operands named by x_pitch / y_pitch may be channel views")
+    px, py = (tensors[k] if k < len(tensors) else None for k in pitch_of)
+    pv = _lib.LelePitch(_pitch(px) if px is not None else 0, _pitch(py) if py is not None else 0,
                         int(out_window[0]) if out_window else 0, int(out_window[1]) if out_window else 0)
     args.extend(extra)
     out = out or ctx.buf()
@@ -599,6 +600,21 @@ def _conv(fn, input, weights, bias, dilations, group, pads, strides, tail, out, 
             raise _lib.LeleError("channel views are supported by conv2d / conv2d_fused / conv2d_silu only")
         return _op_pitched(ctx, _lib.lib().lele_hip_conv2d_pitched, [input, weights, bias], args + list(tail), out, out_window)
     return _op(ctx, fn, [input, weights, bias], args + list(tail), out)
+
+
+def conv2d_res(input, weights, bias, res, dilations=(), group=1, pads=(), strides=(), act=0, out=None, ctx=None, out_window=None):
+    """act(conv2d(input) + bias) + res in one call (lele_hip_conv2d_res): a residual block's conv2d / conv2d_silu / conv2d_fused and
+    the `add` behind it (plan.fuse_residual_adds), the same bits.  act: 0 none, 1 ReLU, 2 SiLU.  input, res and the result may be
+    channel views."""
+    keep = []
+    args = []
+    d, n = _lib.i64_array(list(dilations), keep)
+    args += [d, n, C.c_int64(int(group))]
+    for v in (pads, strides):
+        a, n = _lib.i64_array(list(v), keep)
+        args += [a, n]
+    return _op_pitched(ctx, _lib.lib().lele_hip_conv2d_res, [input, weights, bias, res], args + [C.c_int(int(act))], out, out_window,
+                       pitch_of=(0, 3))
 
 
 def reset_conv_stats(ctx=None):  # conv2d.rs:101 (a no-op upstream; here: clears the context's convolution counters)

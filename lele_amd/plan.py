@@ -220,8 +220,68 @@ def rebatch_lifted(plan, n):
 # Concat / Split along C of NCHW tensors as VIEWS of one buffer (include/lele_hip.h, LelePitch).  lele copies (manipulation.rs:108-207,
 # 1091-1151); the values are the same, so a plan folded here gives the bits of the plan it came from.  Shapes are needed: the pass
 # runs on a plan whose value shapes were recorded by one eager run (Runner.shapes) -- the shapes a hipGraph capture freezes anyway.
-_CONVS = ("conv2d", "conv2d_silu", "conv2d_fused")
+_CONVS = ("conv2d", "conv2d_silu", "conv2d_fused", "conv2d_res")
 _VIEW_WRITERS = _CONVS + ("add", "sub", "mul", "div", "max_pool2d", "resize_nearest")
+
+
+def _conv_group(st):
+    """the literal group of a convolution statement (conv2d_res has the residual in front of the attributes), or None"""
+    return _lit_int(st["args"][5 if st["fn"] == "conv2d_res" else 4])
+
+
+def fuse_residual_adds(sts, shapes, outputs, multi):
+    """`c = conv2d*(x, ...)` ... `y = add(c, r)` (either order) -> `y = conv2d_res(x, ..., r, act)` at the convolution's place, when the
+    Add is the convolution's only reader, r has the result's shape (no broadcast) and exists before the convolution.  lele's generated
+    code keeps the two calls (every bottleneck's `x + cv2(cv1(x))`); lele_hip_conv2d_res forms the same sum from the same two f32
+    values.  Returns (statements, number fused)."""
+    prod, readers = {}, {}
+    for i, st in enumerate(sts):
+        for o in st.get("out", []):
+            prod[o] = i
+        names = _refs(st.get("args", st.get("in")), [])
+        if st["op"] == "if":
+            names += _refs([st.get("then"), st.get("else"), st.get("cond")], [])
+        for r in names:
+            readers.setdefault(r, []).append(i)
+    drop, put = set(), {}
+    for i, st in enumerate(sts):
+        if st["op"] != "call" or st.get("fn") != "add" or len(st["out"]) != 1 or st["out"][0] in multi:
+            continue
+        ab = [a.get("ref") if isinstance(a, dict) else None for a in st["args"][:2]]
+        if None in ab or ab[0] == ab[1]:
+            continue
+        for c, r in (ab, ab[::-1]):
+            pi = prod.get(c)
+            if pi is None or pi in put or c in multi or r in multi or c in outputs or readers.get(c) != [i]:
+                continue
+            pst = sts[pi]
+            if pst["op"] != "call" or pst.get("fn") not in ("conv2d", "conv2d_silu", "conv2d_fused") or len(pst["out"]) != 1 or pi >= i:
+                continue
+            sc, sr = shapes.get(c), shapes.get(r)
+            if sc is None or len(sc) != 4 or list(sc) != list(sr or []):
+                continue
+            pr = prod.get(r)
+            if pr is not None and pr >= pi:
+                continue
+            args = [a for a in pst["args"] if not (isinstance(a, dict) and ("slot" in a or "buf" in a))]
+            if len(args) < 7 or not isinstance(args[0], dict) or "ref" not in args[0]:
+                continue
+            if pst["fn"] == "conv2d_fused":
+                relu = args[7].get("bool") if len(args) > 7 and isinstance(args[7], dict) else None
+                if relu is None:
+                    continue
+                act = 1 if relu else 0
+            else:
+                act = 2 if pst["fn"] == "conv2d_silu" else 0
+            new = {k: v for k, v in pst.items() if k not in ("slots", "args", "fn", "out")}
+            new.update({"fn": "conv2d_res", "out": list(st["out"]), "args": args[:3] + [{"ref": r}] + args[3:7] + [{"int": act}]})
+            if "slots" in st:
+                new["slots"] = st["slots"]
+            put[pi] = new
+            drop.add(i)
+            break
+    out = [put.get(i, st) for i, st in enumerate(sts) if i not in drop]
+    return out, len(drop)
 _F32_FNS = set(_VIEW_WRITERS) | {"conv_transpose", "silu", "sigmoid", "relu", "tanh", "exp", "sqrt", "softmax", "softmax_scaled", "layer_norm",
                                  "batch_norm", "matmul", "matmul_fused_add", "gemm", "add3", "depthwise_conv1d_tlc"}
 
@@ -254,8 +314,8 @@ def _lit_int(node):
     return node["int"] if isinstance(node, dict) and "int" in node else None
 
 
-def fold_channel_views(plan, shapes):
-    """Returns a format-3 plan in which, wherever every party can work on a channel view,
+def fold_channel_views(plan, shapes, residuals=True):
+    """Returns a format-3 plan in which (after fuse_residual_adds, unless residuals=False), wherever every party can work on a channel view,
       * a Split along C of a rank-4 tensor is a set of views of its operand (no kernel),
       * the producers of a Concat's operands write straight into the Concat's buffer (a `reserve` statement sizes it before the
         first of them runs; operands that cannot be produced in place are copied in by `copy_view`) and the Concat itself is a view,
@@ -264,12 +324,19 @@ def fold_channel_views(plan, shapes):
     from .compiler.lower import allocate
     import copy
     sts = copy.deepcopy(plan["statements"])
-    nst = len(sts)
     prod, multi = {}, set()
     for i, st in enumerate(sts):
         for o in st.get("out", []):
             if o in prod:
                 multi.add(o)
+            prod[o] = i
+    n_res = 0
+    if residuals:
+        sts, n_res = fuse_residual_adds(sts, shapes, set(plan["outputs"]), multi)
+    nst = len(sts)
+    prod = {}
+    for i, st in enumerate(sts):
+        for o in st.get("out", []):
             prod[o] = i
     readers = {}
     for i, st in enumerate(sts):
@@ -328,8 +395,10 @@ def fold_channel_views(plan, shapes):
             return False
         fn, args = st.get("fn"), st.get("args", [])
         where = [k for k, a in enumerate(args) if isinstance(a, dict) and a.get("ref") == name]
+        if fn == "conv2d_res":   # the input and the residual may be views (x_pitch / y_pitch)
+            return all(k in (0, 3) for k in where) and _conv_group(st) == 1
         if fn in _CONVS:
-            return where == [0] and _lit_int(args[4]) == 1
+            return where == [0] and _conv_group(st) == 1
         if fn in ("add", "sub", "mul", "div"):
             other = [a.get("ref") for a in args[:2] if isinstance(a, dict)]
             return len(args) >= 2 and all(k in (0, 1) for k in where) and all(o is not None and shapes.get(o) == shapes.get(name) for o in other) \
@@ -382,7 +451,7 @@ def fold_channel_views(plan, shapes):
             if ok:
                 pst = sts[pi]
                 if pst["fn"] in _CONVS:
-                    ok = _lit_int(pst["args"][4]) == 1
+                    ok = _conv_group(pst) == 1
                 elif pst["fn"] in ("add", "sub", "mul", "div"):
                     ab = [a.get("ref") if isinstance(a, dict) else None for a in pst["args"][:2]]
                     ok = all(n is not None and shapes.get(n) == shapes.get(o) for n in ab)
@@ -428,7 +497,7 @@ def fold_channel_views(plan, shapes):
     slots = allocate(out, list(plan["outputs"]))
     new = dict(plan)
     new.update({"format": "lele_amd.plan/3", "statements": out, "slots": slots,
-                "folded": {"concats_in_place": len(concat_plan), "splits_as_views": len(view_split),
+                "folded": {"residual_adds_fused": n_res, "concats_in_place": len(concat_plan), "splits_as_views": len(view_split),
                            "operands_in_place": len(windowed), "operands_copied": sum(1 for _b, e in concat_plan.values() for x in e if not x[2])}})
     return new
 

@@ -54,7 +54,7 @@ def _val(x):
 
 class EmuK:
     """the operators of the test plans with the oracle's arithmetic, writing where the library would write"""
-    VIEW_OK = {"conv2d", "conv2d_silu", "conv2d_fused", "add", "mul", "max_pool2d", "resize_nearest", "copy_view"}
+    VIEW_OK = {"conv2d", "conv2d_silu", "conv2d_fused", "conv2d_res", "add", "mul", "max_pool2d", "resize_nearest", "copy_view"}
 
     def __init__(self):
         self.view_reads = 0
@@ -88,6 +88,12 @@ class EmuK:
 
     def conv2d_silu(self, x, w, b, dil, group, pads, strides, out=None, ctx=None, out_window=None):
         return self._conv("conv2d_silu", "silu", x, w, b, dil, group, pads, strides, out, out_window)
+
+    def conv2d_res(self, x, w, b, res, dil, group, pads, strides, act, out=None, ctx=None, out_window=None):
+        self._in("conv2d_res", x, res)
+        y = O.conv2d_im2col(_val(x), _val(w), _val(b), dil, group, pads, strides, {0: None, 1: "relu", 2: "silu"}[act])
+        self.res_calls = getattr(self, "res_calls", 0) + 1
+        return self._put(y + _val(res), out, out_window)
 
     def add(self, a, b, out=None, ctx=None, out_window=None):
         self._in("add", a, b)
@@ -213,12 +219,14 @@ def test_fold_on_emulated_memory():
     info = folded["folded"]
     # C3k2: the split's input goes into the concat in place (one merged operand) + the residual add; SPPF: the 1x1 conv and the three
     # pools; FPN: the resize and p3.  The split feeding the grouped conv / the output stays, as does the concat along H.
-    assert info == {"concats_in_place": 3, "splits_as_views": 1, "operands_in_place": 8, "operands_copied": 0}, info
+    # The bottleneck's `y1 + cv2(cv1(y1))` is ONE conv2d_res call that reads the split result as a view and writes the concat's window.
+    assert info == {"residual_adds_fused": 1, "concats_in_place": 3, "splits_as_views": 1, "operands_in_place": 8, "operands_copied": 0}, info
     fns = [st.get("fn") for st in folded["statements"] if st["op"] == "call"]
-    assert fns.count("concat") == 1 and fns.count("split") == 1
+    assert fns.count("concat") == 1 and fns.count("split") == 1 and fns.count("add") == 0 and fns.count("conv2d_res") == 1
+    assert fold_channel_views(plan, r0.shapes, residuals=False)["folded"]["residual_adds_fused"] == 0
     k = EmuK()
     got, _ = run_plan(folded, weights, ctx, k, feed())
-    assert k.view_reads > 0
+    assert k.view_reads > 0 and k.res_calls == 1
     for a, b in zip(want, got):
         assert a.shape == b.shape and np.array_equal(a, b)
     # twice through the same runner (buffers already sized, as in a replay) and with another batch size's shapes recorded anew
@@ -250,7 +258,101 @@ def test_fold_keeps_what_it_cannot_prove():
     assert all(np.array_equal(p, q) for p, q in zip(want, got))
 
 
+def test_residual_adds_are_fused_only_where_that_is_the_same_program():
+    def build(case):
+        b = PlanBuilder(11)
+        t = b.conv("x", 8, 8, 1)
+        if case == "two readers":            # the convolution's result is read by the Add and by another statement
+            c = b.conv(t, 8, 8, 3)
+            y = b.call("add", [{"ref": t}, {"ref": c}], "add")
+            z = b.call("sigmoid", [{"ref": c}], "sig")
+            return b.finish(["x"], [y, z])
+        if case == "residual later":         # the other operand does not exist yet where the convolution runs
+            c = b.conv(t, 8, 8, 3)
+            u = b.call("sigmoid", [{"ref": t}], "sig")
+            return b.finish(["x"], [b.call("add", [{"ref": c}, {"ref": u}], "add")])
+        if case == "broadcast":              # [N, 8, H, W] + [N, 8, 1, 1]
+            c = b.conv(t, 8, 8, 3)
+            pooled = b.call("max_pool2d", [{"ref": t}, b.ints([6, 8]), b.ints([6, 8]), b.ints([0, 0, 0, 0]), b.ints([1, 1]), {"bool": False}], "pool")
+            return b.finish(["x"], [b.call("add", [{"ref": c}, {"ref": pooled}], "add")])
+        if case == "both orders":            # add(r, conv) and add(conv, r); linear and SiLU; the second feeds the first's residual
+            c1 = b.conv(t, 8, 8, 3, silu=False)
+            y1 = b.call("add", [{"ref": c1}, {"ref": t}], "add")
+            c2 = b.conv(y1, 8, 8, 3)
+            return b.finish(["x"], [b.call("add", [{"ref": y1}, {"ref": c2}], "add")])
+        raise AssertionError(case)
+    x = np.random.default_rng(5).standard_normal((2, 8, 6, 8)).astype(np.float32)
+    for case, fused in (("two readers", 0), ("residual later", 0), ("broadcast", 0), ("both orders", 2)):
+        plan, weights = build(case)
+        ctx = EmuCtx()
+        want, r0 = run_plan(plan, weights, ctx, EmuK(), {"x": EmuK._put(x, ctx.buf(), None)}, record=True)
+        folded = fold_channel_views(plan, r0.shapes)
+        assert folded["folded"]["residual_adds_fused"] == fused, (case, folded["folded"])
+        k = EmuK()
+        got, _ = run_plan(folded, weights, ctx, k, {"x": EmuK._put(x, ctx.buf(), None)})
+        assert getattr(k, "res_calls", 0) == fused and all(np.array_equal(p, q) for p, q in zip(want, got)), case
+        if fused:
+            acts = [st["args"][8]["int"] for st in folded["statements"] if st.get("fn") == "conv2d_res"]
+            assert acts == [0, 2]
+
+
 # --------------------------------------------------------------------------------------------- GPU
+RES_CASES = [
+    # n, c, h, w, oc, k, stride, group, act: every route of run_conv2d once
+    (32, 32, 40, 44, 128, 3, 1, 1, 2),      # window kernel, 16-byte stores
+    (40, 16, 30, 37, 64, 3, 1, 1, 1),       # window kernel, scalar stores (ow % 4 != 0)
+    (32, 32, 80, 80, 64, 3, 2, 1, 2),       # stride-2 window kernel
+    (32, 48, 80, 80, 64, 1, 1, 1, 2),       # 1 x 1 on the window kernel
+    (8, 96, 12, 12, 200, 3, 1, 1, 0),       # tiled GEMM, 16-byte stores
+    (4, 24, 9, 7, 40, 3, 1, 1, 2),          # tiled / small GEMM, scalar stores
+    (64, 130, 20, 20, 200, 1, 1, 1, 2),     # pointwise tiled GEMM
+    (48, 16, 48, 48, 8, 3, 1, 1, 2),        # direct small-channel kernel (+ the separate add)
+    (2, 128, 17, 17, 128, 3, 1, 128, 2),    # depthwise (+ the separate add)
+    (1, 16, 33, 29, 24, 3, 1, 2, 1),        # grouped
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", RES_CASES, ids=[str(i) for i in range(len(RES_CASES))])
+def test_conv2d_res_equals_convolution_then_add(ctx, case):
+    """lele_hip_conv2d_res against the two calls it stands for (lele_hip_conv2d, then the Add): the same bits on every route, dense
+    and with the input, the residual and the result as channel views"""
+    from lele_amd import kernels as K
+    n, c, h, w_, oc, k, s, g, act = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((n, c, h, w_)).astype(np.float32)
+    wt = (rng.standard_normal((oc, c // g, k, k)) * 0.2).astype(np.float32)
+    bias = rng.standard_normal(oc).astype(np.float32)
+    fn = {0: K.conv2d, 1: lambda *a, **kw: K.conv2d_fused(*a, relu=True, **kw), 2: K.conv2d_silu}[act]
+    pads, strides = [k // 2] * 4, [s, s]
+    conv = fn(x, wt, bias, [1, 1], g, pads, strides, ctx=ctx).numpy()
+    res = rng.standard_normal(conv.shape).astype(np.float32)
+    want = K.add(conv, res, ctx=ctx).numpy()
+    got = K.conv2d_res(x, wt, bias, res, [1, 1], g, pads, strides, act, ctx=ctx).numpy()
+    assert np.array_equal(got, want)
+    assert np.array_equal(K.conv2d_res(x, wt, None, res, [1, 1], g, pads, strides, act, ctx=ctx).numpy(),
+                          K.add(fn(x, wt, None, [1, 1], g, pads, strides, ctx=ctx).numpy(), res, ctx=ctx).numpy())
+    with pytest.raises(_lib.LeleError):
+        K.conv2d_res(x, wt, bias, res[:, :, :-1], [1, 1], g, pads, strides, act, ctx=ctx)
+    if g != 1:
+        return
+    # views: x = channels [3, 3 + c) of a wider tensor, res = channels [2, 2 + oc) of another, the result a window of a third
+    oh, ow = conv.shape[2:]
+    wide_x = rng.standard_normal((n, c + 5, h, w_)).astype(np.float32)
+    wide_x[:, 3:3 + c] = x
+    wide_r = rng.standard_normal((n, oc + 4, oh, ow)).astype(np.float32)
+    wide_r[:, 2:2 + oc] = res
+    xv = TensorView(ctx.buf().upload(wide_x)).channels(3, 3 + c)
+    rv = TensorView(ctx.buf().upload(wide_r)).channels(2, 2 + oc)
+    tot = oc + 3
+    big = ctx.buf()
+    big.upload(np.full((n, tot, oh, ow), -3.25, np.float32))
+    out = K.conv2d_res(xv, wt, bias, rv, [1, 1], 1, pads, strides, act, out=big, out_window=(1 * oh * ow, tot * oh * ow), ctx=ctx)
+    assert out.is_view and np.array_equal(out.numpy(), want)
+    whole = big.to_numpy((n, tot, oh, ow))
+    assert np.all(whole[:, :1] == -3.25) and np.all(whole[:, 1 + oc:] == -3.25)
+
+
 @pytest.mark.gpu
 def test_pitched_kernels_vs_oracle(ctx):
     """every *_pitched entry point reading a window of a wider tensor and writing a window of another one, against the oracle on

@@ -280,8 +280,9 @@ def main():
                     gflop = 2.0 * xs[0] * xs[2] * xs[3] * w[0] * w[1] * w[2] * w[3] / 1e9
                 else:
                     gflop = 2.0 * int(np.prod(osh)) * w[1] * w[2] * w[3] / 1e9
-                geo = "%d->%d k%d s%s g%s @%dx%d" % (xs[1], osh[1], w[2], st["args"][6]["list"][0]["int"] if len(st["args"]) > 6 and st["args"][6].get("list") else "?",
-                                                  st["args"][4].get("int", "?") if len(st["args"]) > 4 else "?", osh[2], osh[3])
+                sh_ = 1 if fn == "conv2d_res" else 0   # the residual sits in front of the attributes
+                geo = "%d->%d k%d s%s g%s @%dx%d" % (xs[1], osh[1], w[2], st["args"][6 + sh_]["list"][0]["int"] if len(st["args"]) > 6 + sh_ and st["args"][6 + sh_].get("list") else "?",
+                                                  st["args"][4 + sh_].get("int", "?") if len(st["args"]) > 4 + sh_ else "?", osh[2], osh[3])
             t_mfma, t_hbm = gflop / 157.3, nbytes / 6.0e9   # ms at the f32 MFMA peak (157.3 GFLOP per ms) / at 6 TB/s
             rows.append({"stmt": idx, "fn": fn, "out": o, "shape": osh, "geometry": geo, "ms": round(ms, 4), "gflop": round(gflop, 3), "mbytes": round(nbytes / 1e6, 2),
                          "bound_ms": round(max(t_mfma, t_hbm), 4), "bound": "mfma" if t_mfma > t_hbm else "hbm", "frac": round(max(t_mfma, t_hbm) / ms, 3) if ms > 0 else None})
