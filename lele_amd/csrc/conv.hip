@@ -641,7 +641,7 @@ __global__ void conv3x3_wperm_kernel(const float* __restrict__ w, float* __restr
 // ---- 3 x 3 (and large-plane 1 x 1), stride 1, IC % 16 == 0, over a batch: the input window is fetched ONCE -------------------
 // As an implicit GEMM the nine taps of a 3 x 3 convolution read the same input window nine times through element-wise gathers,
 // and the f32 MFMA shares the vector pipe with the gathers' address arithmetic: 0.45-0.5 of the f32 MFMA rate at 64-128
-// channels.  Here a workgroup (4 consumer waves) owns 64 output channels x (8 rows x 32 columns) of one image and walks the input channels
+// channels.  Here a workgroup (4 consumer waves) owns 64 output channels x 256 positions of one image (WinTile) and walks the input channels
 // in chunks of 16: the chunk's window (10 x 34 positions, zeros outside the image) is fetched once, every value cut into its
 // three bf16 pieces on the way into LDS ([position][piece][16 channels]: a B fragment of tap (a, b) is three 16-byte reads at
 // the shifted position), and all nine taps run from it -- 9 x 24 split-bf16 MFMAs per wave between two barriers, the next chunk's
@@ -656,8 +656,6 @@ constexpr int C3M_TH = 8, C3M_TW = 32, C3M_PITCH = 112;
 template <int KS>
 struct C3M {  // KS = 3 (3 x 3, padding in the geometry) or 1 (1 x 1: the "window" is the tile itself)
     static constexpr int PH = C3M_TH + KS - 1, PW = C3M_TW + KS - 1, POS = PH * PW, STAGE = POS * C3M_PITCH;
-    static constexpr int EPI = 4 * 32 * (4 * 32 + 8) * 4;  // the epilogue's four wave tiles reuse the stages
-    static constexpr int LDS = 2 * STAGE > EPI ? 2 * STAGE : EPI;
     static constexpr int TASKS = (POS * 4 + 255) / 256;  // (position, channel quad) staging tasks per thread and chunk
     static constexpr int TAPS = KS * KS;
 };
@@ -772,47 +770,171 @@ __device__ __forceinline__ void c3m_epilogue(const cf32x16 (&acc)[NJ], const Con
     }
 }
 
-// OCT = output channels per workgroup: 64 (two 32-channel tiles x two groups of four tile rows) or 32 (one tile x four groups of
-// two rows): narrow layers do not pay for a half-empty block
+// ---- the stride-1 kernel: PERSISTENT workgroups of four loader waves and four consumer waves.
+// Loaders ("producers", waves 4-7) and multipliers ("consumers", waves 0-3) are separate waves because a wave's memory counter is in
+// order: a consumer with a window's loads in flight could not wait for its next weight fragment without waiting for the window too
+// (938 us against 1529 for the tiled GEMM on 64 -> 64 channels at 160 x 160 x 64 when the kinds of wave were first separated).  The
+// loaders fetch a chunk's window through buffer resources (a position outside the image is an offset past the resource: it reads as
+// zero), keep two chunks in registers, and park one -- split into its bf16 pieces -- in the LDS stage the consumers have left.
+// The workgroups are persistent because a workgroup that lives for one tile waits for its first window with nothing to overlap,
+// multiplies for 0.3 us a chunk and stores its tile while its loaders have nothing left to fetch: measured with parts knocked out on
+// 64 -> 64 channels 1 x 1 at 80 x 80 x 64 (69 us): no loads 55, no stores 35, neither 22, and 17.5 with no work at all -- loading and
+// storing ADD UP, and launching 1600 short workgroups is a quarter of the time.  So at most two workgroups per CU are launched and
+// each walks through its share of the items (image, tile, group of blocks of output channels), the blocks of an item in turn (the
+// second block's window comes out of the same XCD's L2), as ONE stream of chunks: the loaders run two chunks ahead across item
+// boundaries, so the next item's first windows are in flight while the consumers run the epilogue, and a wave's finished strip takes
+// its turn through the stage the consumers have just left (32 x 32 values at a time: 20 KB for the four waves, inside one stage)
+// while the other stage already holds the next chunk.  Barriers: B_q after chunk q is parked = before it is multiplied, plus E after
+// an epilogue when a later chunk wants the stage the strips went through.  Whole Yolo-shaped forward at batch 64, same box,
+// interleaved runs: 8.70-8.77 ms against 9.01-9.06 with one workgroup per tile.
+template <int NJ, int OCT>
+__device__ __forceinline__ void c3m_epilogue_strips(const cf32x16 (&acc)[NJ], const ConvEpi& epi, const ConvGeom& g, char* region, int wave, int lane,
+                                                    int wm, int wn, int ocb, int img, int ty0, int tx0, const WinTile& wt) {
+    const int hv = lane >> 5, l31 = lane & 31;
+    const int ocw = ocb * OCT + wm * 32;
+    const int live = wt.tw * wt.th;
+    if (g.ow % 4 == 0 && wt.tw % 4 == 0 && epi.vec_ok()) {
+        // A strip (32 channels x 32 positions) goes through LDS AS IT IS and comes back as 16-byte pieces of output rows: a lane then
+        // holds 4 consecutive positions of channel 8 it + (lane >> 3) -- bias, activation and residual are applied to those (the same
+        // operations on the same values as before the turn), so the accumulators die as they are written and a lane needs 4 bias
+        // values, not 16: the epilogue of a 64-channel block fits the 128 registers beside the next block's first weights.
+        constexpr int P = 40;  // floats per output channel of a strip: the half waves (4 channels apart) land 32 banks apart
+        float* mine = reinterpret_cast<float*>(region) + wave * (32 * P);
+        const int q4 = lane & 7, rsub = lane >> 3;
+        float bq[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int o = ocw + it * 8 + rsub;
+            bq[it] = epi.bias ? epi.bias[o < g.oc ? o : g.oc - 1] : 0.0f;
+        }
+        int colq[NJ];
+        bool every = true;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int p = (NJ * wn + j) * 32 + 4 * q4, row = wt_row(wt, p), oy = ty0 + row, oxq = tx0 + p - row * wt.tw;
+            colq[j] = p < live && oy < g.oh && oxq < g.ow ? oy * g.ow + oxq : -1;
+            every = every && colq[j] < (g.plane & ~7);  // four positions from a multiple of four: all on one side of the last multiple of eight
+        }
+        // the activation's scalar-tail form (libm) only where some lane is in the last 0-7 positions of the plane
+        const bool all_body = __builtin_amdgcn_ballot_w64(!every) == 0;
+        float4 rv[NJ][4];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * hv) * P + l31] = acc[j][r];
+#pragma unroll
+            for (int it = 0; it < 4; ++it)  // same-wave LDS order holds: no barrier, and the next strip's writes come after these reads
+                rv[j][it] = *reinterpret_cast<const float4*>(mine + (it * 8 + rsub) * P + 4 * q4);
+        }
+        auto run = [&](auto fn) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const bool body = colq[j] < (g.plane & ~7);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int oc = ocw + it * 8 + rsub;
+                    float4 v = rv[j][it];
+                    if (epi.bias) v.x = v.x + bq[it], v.y = v.y + bq[it], v.z = v.z + bq[it], v.w = v.w + bq[it];
+                    v.x = fn(v.x, body), v.y = fn(v.y, body), v.z = fn(v.z, body), v.w = fn(v.w, body);
+                    if (colq[j] >= 0 && oc < g.oc) {
+                        if (g.res) {  // uniform
+                            const float4 r4 = *reinterpret_cast<const float4*>(g.res + (int64_t)img * g.rbs + (int64_t)oc * g.plane + colq[j]);
+                            v.x = v.x + r4.x, v.y = v.y + r4.y, v.z = v.z + r4.z, v.w = v.w + r4.w;
+                        }
+                        *reinterpret_cast<float4*>(epi.out + (int64_t)img * g.obs + (int64_t)oc * g.plane + colq[j]) = v;
+                    }
+                }
+            }
+        };
+        if (epi.act == LELE_ACT_NONE) run([](float v, bool) { return v; });
+        else if (epi.act == LELE_ACT_RELU) run([](float v, bool) { return v > 0.0f ? v : 0.0f; });
+        else if (all_body) run([](float v, bool) { return apply_act(v, LELE_ACT_SILU, true); });
+        else run([](float v, bool b) { return apply_act(v, LELE_ACT_SILU, b); });
+        return;
+    }
+    float bv[16];  // the scalar path: every value where it sits
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = ocw + (r & 3) + 8 * (r >> 2) + 4 * hv;
+        bv[r] = epi.bias ? epi.bias[o < g.oc ? o : g.oc - 1] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int p = (NJ * wn + j) * 32 + l31, row = wt_row(wt, p), oy = ty0 + row, ox = tx0 + p - row * wt.tw;
+        if (!(p < live && oy < g.oh && ox < g.ow)) continue;
+        const int col = oy * g.ow + ox;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int oc = ocw + (r & 3) + 8 * (r >> 2) + 4 * hv;
+            if (oc < g.oc) epi.store(img, oc, col, acc[j][r], bv[r]);
+        }
+    }
+}
+
 template <int KS, int OCT>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_window_kernel(const float* __restrict__ x,
-                                                                                                 const cu32x4* __restrict__ wfrag,
-                                                                                                 ConvEpi epi, ConvGeom g, WinTile wt) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_window_p_kernel(const float* __restrict__ x,
+                                                                                                   const cu32x4* __restrict__ wfrag,
+                                                                                                   ConvEpi epi, WinTile wt, int ntiles, int nocb,
+                                                                                                   int osplit, int items) {
     typedef C3M<KS> W;
-    constexpr int NJ = OCT == 64 ? 4 : 2, MTB = OCT / 32;  // tile rows per consumer wave, 32-channel tiles per workgroup
+    constexpr int NJ = OCT == 64 ? 4 : 2, MTB = OCT / 32;
+    static_assert(4 * 32 * 40 * 4 <= W::STAGE, "a strip of every consumer wave fits one stage");
+    const ConvGeom& g = epi.g;
     extern __shared__ __attribute__((aligned(16))) char c3m_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hv = lane >> 5, l31 = lane & 31;
-    const int tile = blockIdx.x, tyi = tile / wt.tiles_x, txi = tile - tyi * wt.tiles_x;
-    const int ocb = blockIdx.y, img = blockIdx.z;
     const int hw = g.ih * g.iw, nchunk = g.c / 16;
-    const int pwt = wt.tw + KS - 1, post = (wt.th + KS - 1) * pwt;  // the window of this tile shape: post <= W::POS positions
+    const int pwt = wt.tw + KS - 1, post = (wt.th + KS - 1) * pwt;
+    // An item = (image, tile, group of `nocb` consecutive blocks of output channels); `osplit` groups make up the layer's blocks
+    // (1 when there are enough (image, tile) pairs to go round: the blocks then take turns inside the workgroup and the second one's
+    // window comes out of L2; otherwise every block is an item of its own, so that a small layer still spreads over the chip)
+    const int G = gridDim.x, first = blockIdx.x;          // this workgroup's items: first, first + G, ...
+    const int nseq = ((items - first + G - 1) / G) * nocb;  // (item, block of output channels) pairs, in order
+    const int qtotal = nseq * nchunk;                      // chunks of the whole stream
     auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
     if (wave >= 4) {
-        // ------------------------------------------------------------ producers: the window of the next chunk, split, into LDS.
-        // Their own waves because a wave's memory counter is in order: a consumer that had the window's loads in flight could not
-        // wait for its next weight fragment without waiting for the window too (measured: 938 us against 1529 for the GEMM on
-        // 64 -> 64 channels at 160 x 160 x 64 with one kind of wave; the window's HBM latency sat in front of every chunk)
+        // ------------------------------------------------------------ producers
         const int pt = tid - 256;
-        const int iy0 = tyi * wt.th - g.pt, ix0 = txi * wt.tw - g.pl;
-        const float* xin = x + (int64_t)img * g.xbs;
-        int t_off[W::TASKS], t_lds[W::TASKS];  // task t = (position, channel quad); its four channel planes are hw apart
-        bool t_in[W::TASKS];
+        int t_lds[W::TASKS];
+        unsigned t_pq[W::TASKS], t_off[W::TASKS];  // (quad << 24 | row << 12 | column) of the task inside the window; byte offset for the item at hand
 #pragma unroll
         for (int i = 0; i < W::TASKS; ++i) {
-            const int t = pt + 256 * i, q = t / post, pos = t - q * post;  // q < 4 while t < 4 * post
-            const int py = pos / pwt, px = pos - py * pwt, iy = iy0 + py, ix = ix0 + px;
-            t_in[i] = q < 4 && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
-            t_off[i] = t_in[i] ? (4 * q * hw + iy * g.iw + ix) : 0;
+            const int t = pt + 256 * i, q = t / post, pos = t - q * post, py = pos / pwt, px = pos - py * pwt;
+            t_pq[i] = q < 4 ? ((unsigned)q << 24) | ((unsigned)py << 12) | (unsigned)px : 0xffffffffu;
             t_lds[i] = q < 4 ? pos * C3M_PITCH + 8 * q : -1;
         }
-        float4 sa[W::TASKS], sb[W::TASKS];
-        auto fetch = [&](float4 (&st)[W::TASKS], int cc) {
-            const float* base = xin + (int64_t)(cc < nchunk ? cc : nchunk - 1) * 16 * hw;  // past the end: the last chunk again, never parked where it is read
+        const float* xin = x;
+        int f_item = first - G, f_ocb = nocb - 1, f_cc = nchunk - 1;  // the fetch cursor: one step before the first chunk
+        auto fetch = [&](float4 (&st)[W::TASKS]) {
+            if (++f_cc == nchunk) {
+                f_cc = 0;
+                if (++f_ocb == nocb) {  // the next item: where its window lies
+                    f_ocb = 0;
+                    f_item += G;
+                    const int pair = f_item / osplit;
+                    const int img = pair / ntiles, tile = pair - img * ntiles, tyi = tile / wt.tiles_x, txi = tile - tyi * wt.tiles_x;
+                    const int iy0 = tyi * wt.th - g.pt, ix0 = txi * wt.tw - g.pl;
+                    xin = x + (int64_t)img * g.xbs;
+#pragma unroll
+                    for (int i = 0; i < W::TASKS; ++i) {
+                        const int q = (int)(t_pq[i] >> 24), iy = iy0 + (int)((t_pq[i] >> 12) & 0xfffu), ix = ix0 + (int)(t_pq[i] & 0xfffu);
+                        const bool in = t_pq[i] != 0xffffffffu && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+                        t_off[i] = in ? (unsigned)(4 * q * hw + iy * g.iw + ix) * 4u : 0xfffffff0u;  // past the resource: reads as 0
+                    }
+                }
+            }
+            // one resource per channel of a quad (bases one plane apart, 13 planes long), as in the stride-2 kernel
+            const float* cb = xin + (int64_t)f_cc * 16 * hw;
+            const int extent = (int)(13u * (unsigned)hw * 4u);
+            const auto r0 = __builtin_amdgcn_make_buffer_rsrc((void*)cb, (short)0, extent, 0x00020000);
+            const auto r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(cb + hw), (short)0, extent, 0x00020000);
+            const auto r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(cb + 2 * hw), (short)0, extent, 0x00020000);
+            const auto r3 = __builtin_amdgcn_make_buffer_rsrc((void*)(cb + 3 * hw), (short)0, extent, 0x00020000);
 #pragma unroll
             for (int i = 0; i < W::TASKS; ++i) {
-                const float* p = base + t_off[i];
-                const float e0 = p[0], e1 = p[hw], e2 = p[2 * hw], e3 = p[3 * hw];  // clamped addresses: unconditional
-                st[i] = t_in[i] ? make_float4(e0, e1, e2, e3) : make_float4(0.f, 0.f, 0.f, 0.f);
+                st[i].x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r0, (int)t_off[i], 0, 0));
+                st[i].y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1, (int)t_off[i], 0, 0));
+                st[i].z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2, (int)t_off[i], 0, 0));
+                st[i].w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r3, (int)t_off[i], 0, 0));
             }
         };
         auto park = [&](const float4 (&st)[W::TASKS], int buf) {
@@ -836,66 +958,65 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 *reinterpret_cast<cu32x2*>(dst + t_lds[i] + 64) = l;
             }
         };
-        fetch(sa, 0);
-        fetch(sb, 1);
+        float4 sa[W::TASKS], sb[W::TASKS];
+        fetch(sa);
+        if (qtotal > 1) fetch(sb);
         park(sa, 0);
-        barrier();  // stage 0 holds chunk 0
-        // chunk cc is being multiplied out of stage cc & 1: refill the registers chunk cc + 1 leaves free with chunk cc + 3's
-        // predecessor ... i.e. two chunks in flight, one being parked
-        int cc = 0;
-        for (; cc + 1 < nchunk; cc += 2) {
-            fetch(sa, cc + 2);
+        barrier();  // B_0
+        // `since` = (q - 1) % nchunk for the chunk q about to be parked: 0 means chunk q - 2 ended an item's block, whose epilogue uses
+        // the stage chunk q goes to -- wait for E first
+        int since = 0;
+        for (int q = 1; q < qtotal; q += 2) {
+            if (q + 1 < qtotal) fetch(sa);
+            if (q >= 2 && since == 0) barrier();  // E
             park(sb, 1);
-            barrier();
-            fetch(sb, cc + 3);
+            barrier();  // B_q
+            if (++since == nchunk) since = 0;
+            if (q + 1 >= qtotal) break;
+            if (q + 2 < qtotal) fetch(sb);
+            if (since == 0) barrier();  // E
             park(sa, 0);
-            barrier();
+            barrier();  // B_{q + 1}
+            if (++since == nchunk) since = 0;
         }
-        if (cc < nchunk) barrier();  // an odd count's last chunk
+        barrier();  // B_qtotal: the consumers' last "done"
         return;
     }
-    // ---------------------------------------------------------------- consumers: 32 output channels x 4 rows of the tile each
+    // ---------------------------------------------------------------- consumers
     const int wm = OCT == 64 ? (wave & 1) : 0, wn = OCT == 64 ? (wave >> 1) : wave;
     cf32x16 acc[NJ];
-    int sb[NJ];  // where this lane's position of strip j sits in the window (byte offset of its tap (0, 0))
+    int sb[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
         int p = (NJ * wn + j) * 32 + l31;
-        p = p < wt.tw * wt.th ? p : 0;  // padding of the last strip: any position, its products are not stored
+        p = p < wt.tw * wt.th ? p : 0;
         const int row = wt_row(wt, p);
         sb[j] = (row * pwt + p - row * wt.tw) * C3M_PITCH + hv * 16;
     }
-    // weights of this wave's 32 output channels: [oc tile][chunk][tap][piece][64 lanes]
-    const cu32x4* wbase = wfrag + ((int64_t)(ocb * MTB + wm) * nchunk) * (W::TAPS * 3 * 64) + lane;
-    // weight fragments one tap ahead of their products (two register sets; the nine taps of a chunk are unrolled in pairs + one).
-    // Two workgroups share a CU (2 x 76 KB of LDS, <= 128 registers a lane): while one is in its epilogue -- bias, activation, a
-    // turn through LDS, 64 KB of stores -- the other multiplies
     cu32x4 ar[2][3];
-    const int64_t wlast = (int64_t)nchunk * W::TAPS - 1;  // clamp: the prefetch past the last tap re-reads it
-    auto wload = [&](cu32x4 (&dst)[3], int64_t gt) {
-        const cu32x4* src = wbase + (gt < wlast ? gt : wlast) * (3 * 64);
+    const int wtaps = nchunk * W::TAPS;  // weight fragments of one block of output channels
+    auto wblock = [&](int blk) { return wfrag + ((int64_t)(blk * MTB + wm) * nchunk) * (W::TAPS * 3 * 64) + lane; };
+    const cu32x4* wcur = wblock((first % osplit) * nocb);
+    const cu32x4* wnxt = wcur;
+    auto wload = [&](cu32x4 (&dst)[3], int gt) {  // fragment gt of the current block; one past its end: the next block's first
+        const cu32x4* src = gt < wtaps ? wcur + (int64_t)gt * (3 * 64) : wnxt;
 #pragma unroll
         for (int p = 0; p < 3; ++p) dst[p] = src[p * 64];
     };
-    wload(ar[0], 0);
-    barrier();  // chunk 0 is in stage 0
-    // P = which register set holds the chunk's first tap (an odd number of taps a chunk: it alternates from chunk to chunk, hence
-    // the pairs below)
+    int q = 0;  // chunks done
     auto chunk = [&](int cc, auto pc) {
         constexpr int P = decltype(pc)::value;
-        const char* stage = c3m_lds + (cc & 1) * W::STAGE;
+        const char* stage = c3m_lds + (q & 1) * W::STAGE;
 #pragma unroll
         for (int tap = 0; tap < W::TAPS; ++tap) {
             const int a = tap / KS, b = tap - KS * a;
             const char* tapw = stage + (a * pwt + b) * C3M_PITCH;
             cu32x4 (&af)[3] = ar[(P + tap) & 1];
-            wload(ar[(P + tap + 1) & 1], (int64_t)cc * W::TAPS + tap + 1);
+            wload(ar[(P + tap + 1) & 1], cc * W::TAPS + tap + 1);
 #define LELE_CBF(v) __builtin_bit_cast(cbf16x8, v)
             constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};  // mm, hl, lh, hm, mh, hh: smallest terms first
 #pragma unroll
-            for (int jp = 0; jp < NJ / 2; ++jp) {  // two rows at a time: 24 fragment registers, and consecutive MFMAs never share an accumulator
+            for (int jp = 0; jp < NJ / 2; ++jp) {
                 cu32x4 bf[2][3];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -910,20 +1031,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         acc[2 * jp + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_CBF(af[PA[t]]), LELE_CBF(bf[j][PB[t]]), acc[2 * jp + j], 0, 0, 0);
             }
 #undef LELE_CBF
-            __builtin_amdgcn_sched_barrier(0);  // fragments of later taps are not fetched early: they would not fit 128 registers
+            __builtin_amdgcn_sched_barrier(0);
         }
-        barrier();  // done with this stage; the next chunk is in the other one
     };
-    {
+    int item = first, ocb = 0;
+    wload(ar[0], 0);
+    barrier();  // B_0
+    for (int s = 0; s < nseq; ++s) {
+        const int pair = item / osplit, grp = item - pair * osplit;
+        const int img = pair / ntiles, tile = pair - img * ntiles, tyi = tile / wt.tiles_x, txi = tile - tyi * wt.tiles_x;
+        const int blk = grp * nocb + ocb;  // this pass's block of output channels
+        {
+            const int item_n = ocb + 1 == nocb ? item + G : item;
+            wnxt = wblock((item_n % osplit) * nocb + (ocb + 1 == nocb ? 0 : ocb + 1));  // (past the last item: any block, never multiplied)
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        // nine taps or one: the register sets alternate from chunk to chunk, so chunks go in pairs; a block with an odd count
+        // leaves the next block's first fragment in set 1 and moves it (every block starts from set 0)
         int cc = 0;
         for (; cc + 1 < nchunk; cc += 2) {
             chunk(cc, std::integral_constant<int, 0>());
+            barrier();  // B_{q + 1}: done with this stage, and the next chunk is in the other one
+            ++q;
             chunk(cc + 1, std::integral_constant<int, 1>());
+            barrier();
+            ++q;
         }
-        if (cc < nchunk) chunk(cc, std::integral_constant<int, 0>());
+        if (cc < nchunk) {
+            chunk(cc, std::integral_constant<int, 0>());
+            barrier();
+            ++q;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) ar[0][p] = ar[1][p];
+        }
+        c3m_epilogue_strips<NJ, OCT>(acc, epi, g, c3m_lds + ((q - 1) & 1) * W::STAGE, wave, lane, wm, wn, blk, img, tyi * wt.th, txi * wt.tw, wt);
+        if (q + 1 < qtotal) barrier();  // E: chunk q + 1 may now be parked where the strips went
+        wcur = wnxt;
+        if (++ocb == nocb) ocb = 0, item += G;
     }
-    static_assert(4 * 32 * (NJ * 32 + 8) * 4 <= W::LDS, "the epilogue tiles fit the stages");
-    c3m_epilogue<NJ, OCT>(acc, epi, g, c3m_lds, wave, lane, wm, wn, ocb, img, tyi * wt.th, txi * wt.tw, wt);
 }
 // ---- the same for STRIDE 2 (3 x 3): a workgroup owns 64 output channels x (4 rows x 32 columns) of one image.  The window of a
 // stride-2 tile is 9 x 65 input positions; stored as it lies, tap (a, b) of output column l would read position 2 l + b -- a
@@ -933,7 +1081,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // conflict-free 112-byte pitch of the stride-1 kernel.  660 slots x 112 bytes = 74 KB: ONE stage per workgroup and two workgroups
 // per CU (the stride-1 kernel's measurement: occupancy, not a second stage, is what hides a workgroup's staging and epilogue) --
 // the producers keep the next chunk in registers, park it when the consumers are done with the stage, and the other workgroup of
-// the CU multiplies meanwhile.  Same weight fragments, same six-term products, same epilogue as conv_window_kernel<3, 64>.
+// the CU multiplies meanwhile.  Same weight fragments and six-term products as the stride-1 kernel; one workgroup per tile.
 struct C3S2 {
     static constexpr int TH = 4, TW = 32, PH = 2 * (TH - 1) + 3, PW = 2 * (TW - 1) + 3;   // 9 x 65 input positions
     static constexpr int SY = (PH + 1) / 2, SX = (PW + 1) / 2, PLANE = SY * SX, POS = 4 * PLANE;   // 5 x 33 slots per phase plane
@@ -1238,11 +1386,18 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
                g.dh == 1 && g.dw == 1 && g.sh == 1 && g.sw == 1 && g.c % 16 == 0 && g.oc > 16 && g.ow >= 16 && g.n <= 65535 &&
                (int64_t)g.c * g.ih * g.iw < (int64_t(1) << 31) &&
                (int64_t)g.n * ((g.oc + 63) / 64) * (((int64_t)g.plane + 255) / 256) >= (int64_t)ctx->num_cus / 2) {
-        // stride 1 over a batch, 16-channel chunks: the window-once MFMA kernel (see conv_window_kernel); 32-channel blocks when that
+        // stride 1 over a batch, 16-channel chunks: the window-once MFMA kernel (see conv_window_p_kernel); 32-channel blocks when that
         // wastes fewer output channels than 64-channel ones
         const int taps = g.kh * g.kw;
-        const int oct = ((g.oc + 31) / 32) * 32 < ((g.oc + 63) / 64) * 64 ? 32 : 64;
-        const size_t wbytes = (size_t)((g.oc + 31) / 32) * (g.c / 16) * taps * 3 * 1024 + (oct == 64 ? (size_t)(g.c / 16) * taps * 3 * 1024 : 0);
+        // ... and when 64-channel blocks would not give every CU its two workgroups (256 -> 64 channels at 20 x 20 x 64 images: 115 us
+        // with 256 workgroups of 64 channels, 78 with 512 of 32)
+        int oct = ((g.oc + 31) / 32) * 32 < ((g.oc + 63) / 64) * 64 ? 32 : 64;
+        if (oct == 64) {
+            const int ow_ = taps == 1 ? g.plane : g.ow, oh_ = taps == 1 ? 1 : g.oh;
+            const WinTile t64 = pick_win_tile(ow_, oh_, 256, g.kh, 1, taps == 9 ? C3M<3>::POS : C3M<1>::POS, (int64_t)g.n * ((g.oc + 63) / 64), ctx->num_cus);
+            if ((int64_t)g.n * ((g.oc + 63) / 64) * t64.tiles_x * ((oh_ + t64.th - 1) / t64.th) < 2 * (int64_t)ctx->num_cus) oct = 32;
+        }
+        const size_t wbytes = (size_t)((g.oc + 31) / 32) * (g.c / 16) * taps * 3 * 1024 + (size_t)(g.c / 16) * taps * 3 * 1024;  // (+ one padding tile)
         void* dwf = nullptr;
         const bool cacheable = wt->mem == LELE_MEM_WEIGHT;
         auto key = std::make_tuple((const void*)wt->data, wbytes, 330 + taps);
@@ -1271,12 +1426,18 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
         ConvEpi epi{out, db, g, act};
         const WinTile tile = pick_win_tile(g.ow, g.oh, 256, g.kh, 1, taps == 9 ? C3M<3>::POS : C3M<1>::POS, (int64_t)g.n * ((g.oc + oct - 1) / oct),
                                            ctx->num_cus);
-        const dim3 wgrid((unsigned)(tile.tiles_x * ((g.oh + tile.th - 1) / tile.th)), (unsigned)((g.oc + oct - 1) / oct), (unsigned)g.n);
-#define LELE_CW(KS_, OCT_)                                                                                      \
-    do {                                                                                                        \
-        auto kern = conv_window_kernel<KS_, OCT_>;                                                               \
-        LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3M<KS_>::LDS));                \
-        hipLaunchKernelGGL(kern, wgrid, dim3(512), C3M<KS_>::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tile);    \
+        // at most two workgroups per CU, each walking through its share of the items (see conv_window_p_kernel)
+        const int ntiles = tile.tiles_x * ((g.oh + tile.th - 1) / tile.th), nblocks = (g.oc + oct - 1) / oct;
+        const int osplit = (int64_t)g.n * ntiles >= 2 * (int64_t)ctx->num_cus ? 1 : nblocks, nocb = nblocks / osplit;
+        const int64_t items = (int64_t)g.n * ntiles * osplit;
+        LELE_REQUIRE(items < (int64_t(1) << 31), "conv2d: more than 2^31 tiles");
+        const dim3 pgrid((unsigned)std::min<int64_t>(items, 2 * (int64_t)ctx->num_cus));
+#define LELE_CW(KS_, OCT_)                                                                                                              \
+    do {                                                                                                                                \
+        auto kern = conv_window_p_kernel<KS_, OCT_>;                                                                                     \
+        LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), 2 * C3M<KS_>::STAGE));                                  \
+        hipLaunchKernelGGL(kern, pgrid, dim3(512), 2 * C3M<KS_>::STAGE, ctx->stream, dx, (const cu32x4*)dwf, epi, tile, ntiles, nocb, osplit, \
+                           (int)items);                                                                                                 \
     } while (0)
         if (taps == 9) {
             if (oct == 64) LELE_CW(3, 64);

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--out", default=None)
     ap.add_argument("--compare", nargs=2, default=None)
+    ap.add_argument("--act", default="silu", choices=["silu", "none", "relu"])
+    ap.add_argument("--only", default="", help="substring of the geometry label, e.g. 'k1 ' or '@160'")
     a = ap.parse_args()
     if a.compare:
         A, B = (json.load(open(f)) for f in a.compare)
@@ -49,13 +51,16 @@ def main():
     rng = np.random.default_rng(7)
     rows = []
     for c, oc, k, s, oh in GEOMS:
+        if a.only and a.only not in "%d->%d k%d s%d @%d" % (c, oc, k, s, oh):
+            continue
         ih = oh * s
         xt = ctx.buf().upload((rng.standard_normal((a.batch, c, ih, ih))).astype(np.float32))
         from lele_amd._lib import Weight
         w = Weight((rng.standard_normal((oc, c, k, k)) * 0.1).astype(np.float32))
         b = Weight(rng.standard_normal(oc).astype(np.float32))
         out = ctx.buf()
-        fn = lambda: K.conv2d_silu(xt, w, b, [1, 1], 1, [k // 2] * 4, [s, s], out=out, ctx=ctx)
+        conv = {"silu": K.conv2d_silu, "none": K.conv2d, "relu": lambda *p, **kw: K.conv2d_fused(*p, relu=True, **kw)}[a.act]
+        fn = lambda: conv(xt, w, b, [1, 1], 1, [k // 2] * 4, [s, s], out=out, ctx=ctx)
         for _ in range(3):
             fn()
         ctx.sync()

@@ -17,7 +17,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 PEAK = {"mfma_f32": 157.3e12, "mfma_i8": 3.944e15, "hbm": 8.0e12}  # MI355X_MICROARCH.md (dense peaks; HBM spec)
-PEAK_BF16 = 2.5e15  # dense bf16 MFMA; a six-term split-bf16 product of f32 operands runs at a sixth of it (conv_window_kernel)
+PEAK_BF16 = 2.5e15  # dense bf16 MFMA; a six-term split-bf16 product of f32 operands runs at a sixth of it (conv_window_p_kernel)
 
 
 def main():
