@@ -11,7 +11,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LELE_HIP_LAB=1: the developer's build (python -m lele_amd.build under the same variable), see lele_amd/build.py
-LIB_PATH = os.path.join(_HERE, "liblele_hip_lab.so" if os.environ.get("LELE_HIP_LAB", "0") not in ("", "0") else "liblele_hip.so")
+# LELE_HIP_LIBRARY=<file name in this directory>: another build of the same library (a saved copy: A/B runs inside one gpurun call)
+LIB_PATH = os.path.join(_HERE, os.environ.get("LELE_HIP_LIBRARY") or
+                        ("liblele_hip_lab.so" if os.environ.get("LELE_HIP_LAB", "0") not in ("", "0") else "liblele_hip.so"))
 
 MAX_RANK = 8
 F32, I64, I32, U8, I8 = 0, 1, 2, 3, 4

@@ -28,7 +28,7 @@ namespace {
 
 __device__ __forceinline__ float apply_act(float v, int act, bool body) {
     if (act == LELE_ACT_RELU) return v > 0.0f ? v : 0.0f;
-    if (act == LELE_ACT_SILU) return body ? v * (1.0f / (1.0f + exp_poly(-v))) : v / (1.0f + expf(-v));
+    if (act == LELE_ACT_SILU) return body ? silu_poly(v) : v / (1.0f + expf(-v));
     return v;
 }
 
@@ -958,26 +958,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 *reinterpret_cast<cu32x2*>(dst + t_lds[i] + 64) = l;
             }
         };
-        float4 sa[W::TASKS], sb[W::TASKS];
-        fetch(sa);
-        if (qtotal > 1) fetch(sb);
-        park(sa, 0);
+        // D register sets: the loads of D chunks are in flight (in the network the windows come from HBM, not from the last-level cache
+        // a repeated micro-benchmark reads them from: two chunks of 16 KB a workgroup did not cover the latency)
+        constexpr int D = KS == 1 ? 4 : 3;
+        float4 st[D][W::TASKS];
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < qtotal) fetch(st[d]);
+        park(st[0], 0);
         barrier();  // B_0
         // `since` = (q - 1) % nchunk for the chunk q about to be parked: 0 means chunk q - 2 ended an item's block, whose epilogue uses
         // the stage chunk q goes to -- wait for E first
         int since = 0;
-        for (int q = 1; q < qtotal; q += 2) {
-            if (q + 1 < qtotal) fetch(sa);
-            if (q >= 2 && since == 0) barrier();  // E
-            park(sb, 1);
-            barrier();  // B_q
-            if (++since == nchunk) since = 0;
-            if (q + 1 >= qtotal) break;
-            if (q + 2 < qtotal) fetch(sb);
-            if (since == 0) barrier();  // E
-            park(sa, 0);
-            barrier();  // B_{q + 1}
-            if (++since == nchunk) since = 0;
+        for (int q0 = 1; q0 < qtotal; q0 += D) {
+#pragma unroll
+            for (int u = 0; u < D; ++u) {  // chunk q0 + u sits in set (1 + u) % D; parking chunk q0 + u - 1 freed set u % D
+                const int q = q0 + u;
+                if (q >= qtotal) break;
+                if (q - 1 + D < qtotal) fetch(st[u % D]);
+                if (q >= 2 && since == 0) barrier();  // E
+                park(st[(1 + u) % D], q & 1);
+                barrier();  // B_q
+                if (++since == nchunk) since = 0;
+            }
         }
         barrier();  // B_qtotal: the consumers' last "done"
         return;

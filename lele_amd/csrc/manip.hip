@@ -500,15 +500,26 @@ __device__ __forceinline__ unsigned topk_key(float v, int largest) {
     const unsigned asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending with the value; >= 1 for every non-NaN
     return largest ? asc : ~asc + 1u;                                   // "better" = larger key either way (~asc + 1 >= 1 too)
 }
-__global__ __launch_bounds__(256) void topk_select_kernel(const float* __restrict__ x, int64_t n64, int k, int largest,
-                                                          float* __restrict__ values, float* __restrict__ indices) {
+// (1024 threads a row; the bin search and the index-order scans are wave scans -- written with thread 0 walking the 256 bins and the
+// per-thread counts one LDS read at a time, those serial walks were most of the kernel: 126 us for [64, 24000] -> 300)
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+constexpr int TOPK_TPB = 1024;
+__global__ __launch_bounds__(TOPK_TPB) void topk_select_kernel(const float* __restrict__ x, int64_t n64, int k, int largest,
+                                                              float* __restrict__ values, float* __restrict__ indices) {
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_need;
-    __shared__ unsigned s_gt[256], s_eq[256];
+    __shared__ unsigned w_gt[TOPK_TPB / 64], w_eq[TOPK_TPB / 64];
     __shared__ unsigned sel_key[1024];
     __shared__ int sel_idx[1024];
     __shared__ float sel_val[1024];
-    const int tid = threadIdx.x, n = (int)n64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = (int)n64;
     const float* row = x + (int64_t)blockIdx.x * n64;
     if (tid == 0) {
         s_prefix = 0u;
@@ -516,51 +527,56 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
     }
     unsigned mask = 0u;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        hist[tid] = 0u;
+        if (tid < 256) hist[tid] = 0u;
         __syncthreads();
         const unsigned prefix = s_prefix;
-        for (int i = tid; i < n; i += 256) {
+        for (int i = tid; i < n; i += TOPK_TPB) {
             const unsigned key = topk_key(row[i], largest);
             if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {  // the bin (from the best downwards) in which the need-th element lies
-            unsigned need = s_need, acc = 0u;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (acc + hist[b] >= need) break;
-                acc += hist[b];
+        if (wave == 0) {  // the bin (from the best downwards) in which the need-th element lies: lane l owns bins 4 (63 - l) + [0, 4)
+            const int b0 = 4 * (63 - lane);
+            const unsigned h0 = hist[b0], h1 = hist[b0 + 1], h2 = hist[b0 + 2], h3 = hist[b0 + 3];
+            const unsigned mine = h0 + h1 + h2 + h3, upto = wave_incl_scan(mine, lane);  // elements in this lane's bins and all better ones
+            const unsigned need = s_need, above = upto - mine;
+            // the last lane takes whatever is left (bin 0 included), as the serial walk did
+            if ((above < need && need <= upto) || (lane == 63 && need > upto)) {
+                unsigned acc = above;
+                int b = b0 + 3;
+                const unsigned hb[4] = {h0, h1, h2, h3};
+                for (; b > b0; --b) {
+                    if (acc + hb[b - b0] >= need) break;
+                    acc += hb[b - b0];
+                }
+                s_need = need - acc;
+                s_prefix = prefix | ((unsigned)b << shift);
             }
-            s_need = need - acc;
-            s_prefix = prefix | ((unsigned)b << shift);
         }
         mask |= 0xffu << shift;
         __syncthreads();
     }
     const unsigned T = s_prefix, need_eq = s_need;  // the k-th best key; how many elements equal to it belong to the result
-    const int chunk = (n + 255) / 256, i0 = tid * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    const int chunk = (n + TOPK_TPB - 1) / TOPK_TPB, i0 = tid * chunk < n ? tid * chunk : n, i1 = i0 + chunk < n ? i0 + chunk : n;
     unsigned cgt = 0u, ceq = 0u;
     for (int i = i0; i < i1; ++i) {
         const unsigned key = topk_key(row[i], largest);
         cgt += key > T ? 1u : 0u;
         ceq += key == T ? 1u : 0u;
     }
-    s_gt[tid] = cgt;
-    s_eq[tid] = ceq;
-    __syncthreads();
-    if (tid == 0) {  // exclusive scans in index order (256 entries)
-        unsigned a = 0u, e = 0u;
-        for (int t = 0; t < 256; ++t) {
-            const unsigned ga = s_gt[t], ea = s_eq[t];
-            s_gt[t] = a;
-            s_eq[t] = e;
-            a += ga;
-            e += ea;
-        }
+    // exclusive scans of the two counts in index order (thread t owns elements [t chunk, (t + 1) chunk))
+    const unsigned sg = wave_incl_scan(cgt, lane), se = wave_incl_scan(ceq, lane);
+    if (lane == 63) {
+        w_gt[wave] = sg;
+        w_eq[wave] = se;
     }
     __syncthreads();
+    unsigned pg = sg - cgt, pe = se - ceq;
+    for (int w = 0; w < wave; ++w) {
+        pg += w_gt[w];
+        pe += w_eq[w];
+    }
     const unsigned n_gt = (unsigned)k - need_eq;
-    unsigned pg = s_gt[tid], pe = s_eq[tid];
     for (int i = i0; i < i1; ++i) {
         const float v = row[i];
         const unsigned key = topk_key(v, largest);
@@ -577,7 +593,7 @@ __global__ __launch_bounds__(256) void topk_select_kernel(const float* __restric
         }
     }
     __syncthreads();
-    for (int e = tid; e < k; e += 256) {
+    for (int e = tid; e < k; e += TOPK_TPB) {
         const unsigned key = sel_key[e];
         const int idx = sel_idx[e];
         int rank = 0;
@@ -1150,7 +1166,7 @@ int lele_hip_topk(LeleCtx* ctx, const LeleTensor* x, int64_t k, int largest, Lel
     if (rows * kk) {
         const dim3 tgrid((unsigned)((n + 255) / 256), (unsigned)rows);
         if (n > 1024 && kk <= 1024 && n < (int64_t(1) << 31) && rows < (int64_t(1) << 31)) {  // long rows: radix select, a workgroup per row
-            hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)rows), dim3(256), 0, ctx->stream, (const float*)dx, n, (int)kk, largest,
+            hipLaunchKernelGGL(topk_select_kernel, dim3((unsigned)rows), dim3(TOPK_TPB), 0, ctx->stream, (const float*)dx, n, (int)kk, largest,
                                (float*)out_values->data, (float*)out_indices->data);
         } else if (n <= 4096 || kk > 1024 || n >= (int64_t(1) << 31)) {
             hipLaunchKernelGGL(topk_kernel, tgrid, dim3(256), 0, ctx->stream, (const float*)dx, n, kk, largest,

@@ -27,7 +27,23 @@ __device__ __forceinline__ float exp_poly(float x) {
     const int e = ((int)fx + 127) << 23;  // cvtps_epi32(fx) is exact: fx is integral
     return y * __int_as_float(e);
 }
-__device__ __forceinline__ float sigmoid_poly(float x) { return 1.0f / (1.0f + exp_poly(-x)); }  // avx/math.rs:66-76
+// 1.0f / d, correctly rounded like the _mm256_div_ps it stands for, for the d = 1 + exp(..) of a sigmoid: v_rcp_f32 (1 ulp) and
+// LELE_RECIP_STEPS Newton step (two FMAs) instead of the eleven instructions of the general division (scaling, fix-up), for 1 <= d <= 2^126
+// (quotient and residuals are normal numbers there); anything else (d beyond 2^126: the quotient is subnormal; a NaN) takes the
+// general division.  Equal to it for EVERY d in the range and the sigmoid / SiLU built on it for every f32 input: tools/recip_check.hip
+// checks all of them on the device (profiles/r04_recip_check.json).
+#ifndef LELE_RECIP_STEPS
+#define LELE_RECIP_STEPS 1
+#endif
+__device__ __forceinline__ float recip_ge1(float d) {
+    if (!(d <= 8.507059173023462e37f)) return 1.0f / d;  // 2^126
+    float r = __builtin_amdgcn_rcpf(d);
+#pragma unroll
+    for (int i = 0; i < LELE_RECIP_STEPS; ++i) r = fmaf_(fmaf_(-d, r, 1.0f), r, r);
+    return r;
+}
+__device__ __forceinline__ float sigmoid_poly(float x) { return recip_ge1(1.0f + exp_poly(-x)); }  // avx/math.rs:66-76
+__device__ __forceinline__ float silu_poly(float x) { return x * recip_ge1(1.0f + exp_poly(-x)); }
 __device__ __forceinline__ float tanh_poly(float x) {                                            // avx/math.rs:79-97
     const float e = exp_poly(-x * 2.0f);
     const float r = (1.0f - e) / (1.0f + e);
