@@ -389,7 +389,9 @@ int lele_hip_yolo_seg_postprocess(LeleCtx* ctx, const LeleTensor* logits, const 
  * Nothing is exchanged while computing; at the end ONE all-gather of the decoded token ids (i32) over RCCL / xGMI gives every
  * rank the transcripts of the whole batch.  RCCL is loaded on first use (dlopen): no link-time dependency.
  * The 128-byte unique id is made by rank 0 (comm_unique_id) and handed to the other ranks by the launcher; comm_init_file does
- * that through a file (rank 0 writes it atomically, the others poll for up to timeout_ms). */
+ * that through a file (rank 0 removes what is there and writes [32-byte job token][id] atomically, the others poll for up to
+ * timeout_ms for a file carrying THEIR token).  The token is a digest of the environment variable LELE_JOB_ID (else
+ * TORCHELASTIC_RUN_ID), which the launcher sets to a value unique to the launch: a file of an earlier job is never accepted. */
 typedef struct LeleComm LeleComm;
 int lele_hip_comm_unique_id(uint8_t* id128);
 int lele_hip_comm_init(LeleCtx* ctx, const uint8_t* id128, int rank, int world, LeleComm** out);

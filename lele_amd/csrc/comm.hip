@@ -127,32 +127,57 @@ int lele_hip_comm_init(LeleCtx* ctx, const uint8_t* id128, int rank, int world, 
     return 0;
 }
 
+// The rendezvous file is [32-byte job token][128-byte id].  The token is LELE_JOB_ID (else TORCHELASTIC_RUN_ID, else empty), which
+// whoever launches the ranks sets to something unique per launch (lele_run: its pid and start time): a reader only accepts a file that
+// carries ITS token, so a file left behind by an earlier job is never taken for the current one, however young, and a valid one is
+// never refused, however late the reader arrives (no wall-clock test: clocks on a shared file system differ).  Rank 0 removes the
+// path before it writes.  Without any token in the environment only the size is checked, as much as a launcher that tells its ranks
+// nothing allows.
+static void job_token(uint8_t (&tok)[32]) {
+    memset(tok, 0, sizeof(tok));
+    const char* v = getenv("LELE_JOB_ID");
+    if (!v || !*v) v = getenv("TORCHELASTIC_RUN_ID");
+    if (!v) return;
+    uint64_t h[4] = {0xcbf29ce484222325ull, 0x84222325cbf29ce4ull, 0x9e3779b97f4a7c15ull, 0xc2b2ae3d27d4eb4full};  // four FNV-1a lanes
+    for (size_t i = 0; v[i]; ++i) {
+        const unsigned k = (unsigned)(i & 3);
+        h[k] = (h[k] ^ (uint8_t)v[i]) * 0x100000001b3ull;
+        h[(k + 1) & 3] ^= h[k] >> 29;
+    }
+    memcpy(tok, h, sizeof(tok));
+    tok[0] |= 1;  // never all zeros: "a token was set"
+}
+
 int lele_hip_comm_init_file(LeleCtx* ctx, const char* path, int rank, int world, int timeout_ms, LeleComm** out) {
     LELE_REQUIRE(ctx && path && out, "comm_init_file: NULL argument");
-    uint8_t id[128];
+    uint8_t id[128], tok[32];
+    job_token(tok);
     if (rank == 0) {
+        (void)unlink(path);  // whatever an earlier job left there
         LELE_TRY(lele_hip_comm_unique_id(id));
         const std::string tmp = std::string(path) + ".tmp";
         FILE* f = fopen(tmp.c_str(), "wb");
         LELE_REQUIRE(f, "comm_init_file: cannot write %s (%s)", tmp.c_str(), strerror(errno));
-        const size_t w = fwrite(id, 1, sizeof(id), f);
+        const size_t w = fwrite(tok, 1, sizeof(tok), f) + fwrite(id, 1, sizeof(id), f);
         fclose(f);
-        LELE_REQUIRE(w == sizeof(id), "comm_init_file: short write to %s", tmp.c_str());
+        LELE_REQUIRE(w == sizeof(tok) + sizeof(id), "comm_init_file: short write to %s", tmp.c_str());
         LELE_REQUIRE(rename(tmp.c_str(), path) == 0, "comm_init_file: rename to %s failed (%s)", path, strerror(errno));
     } else {
         const int step_ms = 5;
         int waited = 0;
         for (;;) {
-            // a file left behind by an earlier job would hand out a dead id (and hang ncclCommInitRank): only a file written
-            // within the last minute counts -- rank 0 always (re)writes it, so a fresh one appears or the wait times out
-            struct stat sb;
-            FILE* f = stat(path, &sb) == 0 && time(nullptr) - sb.st_mtime <= 60 ? fopen(path, "rb") : nullptr;
+            FILE* f = fopen(path, "rb");
             if (f) {
-                const size_t r = fread(id, 1, sizeof(id), f);
+                uint8_t got[32 + 128 + 1];
+                const size_t r = fread(got, 1, sizeof(got), f);
                 fclose(f);
-                if (r == sizeof(id)) break;  // the rename makes the file appear complete; a short read means a foreign file
+                // the rename makes the file appear complete: another size is a foreign file, another token another job's
+                if (r == 32 + 128 && memcmp(got, tok, 32) == 0) {
+                    memcpy(id, got + 32, sizeof(id));
+                    break;
+                }
             }
-            LELE_REQUIRE(waited < timeout_ms, "comm_init_file: rank %d waited %d ms for %s", rank, timeout_ms, path);
+            LELE_REQUIRE(waited < timeout_ms, "comm_init_file: rank %d waited %d ms for %s (a file of this job: LELE_JOB_ID)", rank, timeout_ms, path);
             struct timespec ts = {0, step_ms * 1000000L};
             nanosleep(&ts, nullptr);
             waited += step_ms;

@@ -315,6 +315,42 @@ __global__ __launch_bounds__(256) void reduce_minmax_last_kernel(int op, const f
     if (r < rows && l == 0) out[r] = acc;
 }
 
+// The same for FEW LONG rows (a global max over activations is one row): with 16 lanes a row the kernel above would scan a whole
+// tensor from one workgroup.  Stage 1: grid (pieces, rows), a workgroup reduces its piece of a row to (value, position of the first
+// occurrence); stage 2: one wave per row merges the pieces, the earlier position winning a tie -- the sequential scan's value.
+__device__ __forceinline__ void minmax_take(int op, float& acc, int64_t& at, float o, int64_t oa) {
+    if ((op == R_MAX ? o > acc : o < acc) || (o == acc && oa < at)) acc = o, at = oa;
+}
+__global__ __launch_bounds__(256) void reduce_minmax_part_kernel(int op, const float* __restrict__ x, float* __restrict__ pv,
+                                                                 long long* __restrict__ pa, int64_t n, int64_t per) {
+    __shared__ float sv[4];
+    __shared__ long long sa[4];
+    const float* row = x + (int64_t)blockIdx.y * n;
+    const int64_t c0 = (int64_t)blockIdx.x * per, c1 = c0 + per < n ? c0 + per : n;
+    float acc = op == R_MAX ? -INFINITY : INFINITY;
+    int64_t at = n;
+    for (int64_t j = c0 + threadIdx.x; j < c1; j += 256) {
+        const float v = row[j];
+        if (op == R_MAX ? v > acc : v < acc) acc = v, at = j;
+    }
+    for (int off = 32; off > 0; off >>= 1) minmax_take(op, acc, at, __shfl_xor(acc, off), __shfl_xor(at, off));
+    if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = acc, sa[threadIdx.x >> 6] = at;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) minmax_take(op, acc, at, sv[w], (int64_t)sa[w]);
+        pv[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+        pa[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = at;
+    }
+}
+__global__ __launch_bounds__(64) void reduce_minmax_merge_kernel(int op, const float* __restrict__ pv, const long long* __restrict__ pa,
+                                                                 float* __restrict__ out, int pieces, int64_t n) {
+    float acc = op == R_MAX ? -INFINITY : INFINITY;
+    int64_t at = n;
+    for (int p = threadIdx.x; p < pieces; p += 64) minmax_take(op, acc, at, pv[(int64_t)blockIdx.x * pieces + p], (int64_t)pa[(int64_t)blockIdx.x * pieces + p]);
+    for (int off = 32; off > 0; off >>= 1) minmax_take(op, acc, at, __shfl_xor(acc, off), __shfl_xor(at, off));
+    if (threadIdx.x == 0) out[blockIdx.x] = acc;
+}
+
 // ------------------------------------------------------------------------------------------ row statistics
 // 32 lanes play the 4x8 accumulator slots of the AVX2 code: slot l = 8*u + i accumulates elements j = 32c + l.
 // Returns (in every lane of the 32-lane group) hsum( (s0+s1)+(s2+s3) [+ 8-wide remainder chunks] ) + scalar tail.
@@ -790,7 +826,17 @@ int lele_hip_reduce(LeleCtx* ctx, int op, const LeleTensor* x, const int64_t* ax
             rows_first = rd.keep_stride[d] == expect;
             expect *= rd.keep_shape[d];
         }
-        if (rows_first)
+        if (rows_first && on <= 2 * (int64_t)ctx->num_cus && rd.red_count >= 65536 && on <= 65535) {  // few long rows: two stages
+            const int64_t per = std::max<int64_t>(8192, (rd.red_count + 1023) / 1024);
+            const int pieces = (int)((rd.red_count + per - 1) / per);
+            void *pv = nullptr, *pa = nullptr;
+            LELE_TRY(ctx->arena_alloc((size_t)on * pieces * 4, &pv));
+            LELE_TRY(ctx->arena_alloc((size_t)on * pieces * 8, &pa));
+            hipLaunchKernelGGL(reduce_minmax_part_kernel, dim3((unsigned)pieces, (unsigned)on), dim3(256), 0, ctx->stream, op, (const float*)dx,
+                               (float*)pv, (long long*)pa, rd.red_count, per);
+            hipLaunchKernelGGL(reduce_minmax_merge_kernel, dim3((unsigned)on), dim3(64), 0, ctx->stream, op, (const float*)pv, (const long long*)pa,
+                               (float*)out->data, pieces, rd.red_count);
+        } else if (rows_first)
             hipLaunchKernelGGL(reduce_minmax_last_kernel, dim3((unsigned)((on + 15) / 16)), dim3(256), 0, ctx->stream, op, (const float*)dx,
                                (float*)out->data, on, rd.red_count);
         else

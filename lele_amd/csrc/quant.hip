@@ -1011,6 +1011,9 @@ bool rs_enabled(LeleCtx* ctx, int64_t rows, int64_t n) {
 // weights-in-registers prologue is not amortised), and a stand-alone K = 2048 linear 54.9 against 41.3 (the fused feed-forward
 // block calls the K-split kernel itself, on a hidden layer that is already in fragment order)
 bool rs_fits(LeleCtx* ctx, int64_t rows, int64_t n, int kp) { return kp == 512 && n >= 1024 && rs_enabled(ctx, rows, n); }
+// the register-stationary kernels read residuals and write results 16 bytes at a time: a device tensor that does not start on a
+// 16-byte boundary (a view into a larger buffer) takes the tiled route instead (host tensors are staged into the aligned arena)
+bool rs_aligned(const LeleTensor* t) { return !t || t->mem != LELE_MEM_DEVICE || (((uintptr_t)t->data) & 15) == 0; }
 // weights in fragment order + column sums: cached for declared-immutable weights, packed into the arena per call otherwise
 int frag_weights_of(LeleCtx* ctx, const LeleTensor* w, int k, int n, int kp, FragW* out) {
     const int ks = kp / 32, nt = (n + 31) / 32;
@@ -1216,7 +1219,7 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     LELE_TRY(qprof_mark(ctx, 1));
 
     // ---- register-stationary route (igemm_rs.h): rows -> i8 in fragment order, then the barrier-free GEMM
-    if (const int kprs = rs_kp(k); rs_fits(ctx, rows, n, kprs)) {
+    if (const int kprs = rs_kp(k); rs_fits(ctx, rows, n, kprs) && rs_aligned(res1) && rs_aligned(res2) && (((uintptr_t)out->data) & 15) == 0) {
         FragW fw;
         LELE_TRY(frag_weights_of(ctx, weight_int8, (int)k, (int)n, kprs, &fw));
         const int64_t nrt = (rows + 31) / 32;
@@ -1359,7 +1362,7 @@ int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const Le
     // register-stationary route (igemm_rs.h): K = 512 into a hidden layer of exactly 2048 columns, whose i8 form is written in the
     // fragment order of the second product and read once
     const bool rs_route = env_int("LELE_HIP_FFN_FUSED", 1) != 0 && args_ok && rs_kp(k1) == 512 && n1 == 2048 && rs_enabled(ctx, rows, n1) &&
-                          rs_enabled(ctx, rows, n2);
+                          rs_enabled(ctx, rows, n2) && rs_aligned(res1) && rs_aligned(res2);
     bool fused = rs_route || (env_int("LELE_HIP_FFN_FUSED", 1) != 0 && args_ok && n1 % 128 == 0 && m >= 128 &&
                               ((rows + 127) / 128) * (n1 / 128) >= 2 * (int64_t)ctx->num_cus);
     if (fused && res1) {

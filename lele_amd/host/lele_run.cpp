@@ -16,6 +16,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <ctime>
 #include <iostream>
 
 #include "plan_runner.hpp"
@@ -46,6 +47,8 @@ int main(int argc, char** argv) {
         if (ranks >= 1 && !std::getenv("LELE_RANK")) {
             id_file = "/tmp/lele_run_" + std::to_string((long)getpid()) + ".id";
             std::remove(id_file.c_str());
+            // the token the ranks of THIS launch look for in the rendezvous file (lele_hip_comm_init_file)
+            if (!std::getenv("LELE_JOB_ID")) setenv("LELE_JOB_ID", ("lele_run-" + std::to_string((long)getpid()) + "-" + std::to_string((long long)time(nullptr))).c_str(), 1);
             std::vector<pid_t> kids;
             for (int r = 0; r < ranks; ++r) {
                 const pid_t pid = fork();

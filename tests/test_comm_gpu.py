@@ -43,6 +43,26 @@ def test_one_rank_communicator_through_the_c_abi(ctx, tmp_path):
     comm.close()
 
 
+def test_rendezvous_file_of_another_job_is_refused(ctx, tmp_path, monkeypatch):
+    """[32-byte job token][128-byte id]: a reader takes only a file that carries the digest of ITS LELE_JOB_ID -- not what an earlier
+    job left under the same name (whatever its age), not a file of another size -- and rank 0 replaces what it finds"""
+    from lele_amd import _lib
+    from lele_amd._lib import Comm
+    path = tmp_path / "uid"
+    monkeypatch.setenv("LELE_JOB_ID", "job-b")
+    for stale in (b"\0" * 160, b"\1" * 128, b"\7" * 161):
+        path.write_bytes(stale)
+        with pytest.raises(_lib.LeleError, match="waited"):
+            Comm.from_file(ctx, str(path), 1, 2, timeout_ms=40)
+    comm = Comm.from_file(ctx, str(path), 0, 1, timeout_ms=2000)
+    data = path.read_bytes()
+    assert len(data) == 160 and data[:32] != b"\0" * 32 and data != b"\0" * 160
+    comm.close()
+    monkeypatch.setenv("LELE_JOB_ID", "job-c")     # the next job does not take job-b's file either
+    with pytest.raises(_lib.LeleError, match="waited"):
+        Comm.from_file(ctx, str(path), 1, 2, timeout_ms=40)
+
+
 def test_native_runner_ranks_and_decode(ctx, tmp_path):
     """lele_run --ranks 1 --decode: fork, file rendezvous, plan, arg-max on the device, RCCL all-gather, rank 0 prints"""
     torch = pytest.importorskip("torch")

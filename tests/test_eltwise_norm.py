@@ -211,6 +211,20 @@ def test_device_where_clip_reduce_bit_exact(ctx):
     for axes, kd in (([-1], False), ([2], True)):
         got, ref = Kk.reduce_max(wide, axes, kd, ctx=ctx).numpy(), npref.reduce("max", wide, axes, kd)
         assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # few long rows (a global max is ONE row): pieces of a row per workgroup, then a merge -- the first of equal values still wins
+    longrow = (rng.standard_normal((3, 300001)) * 3).astype(np.float32)
+    longrow[0, :] = np.minimum(longrow[0, :], 0.0)
+    longrow[0, 123456] = -0.0
+    longrow[0, 250000] = 0.0                      # max = +/-0: the first zero in scan order decides the sign
+    zeros = np.flatnonzero(longrow[0] == 0.0)
+    longrow[1, 77] = np.nan
+    longrow[2, :] = np.nan
+    for axes, kd in (([-1], False), ([1], True)):
+        got, ref = Kk.reduce_max(longrow, axes, kd, ctx=ctx).numpy(), npref.reduce("max", longrow, axes, kd)
+        assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert np.signbit(Kk.reduce_max(longrow, [-1], False, ctx=ctx).numpy()[0]) == np.signbit(longrow[0, zeros[0]])
+    flat = Kk.reduce_max(longrow[:2].reshape(-1).copy(), [0], False, ctx=ctx).numpy()
+    assert np.array_equal(flat.view(np.uint32), npref.reduce("max", longrow[:2].reshape(-1), [0], False).view(np.uint32))
     with pytest.raises(lele_amd.LeleError, match="broadcastable"):
         Kk.add(np.zeros((2, 3), np.float32), np.zeros((4,), np.float32), ctx=ctx)
 
