@@ -116,6 +116,12 @@ typedef struct LeleFeatureConfig {
 } LeleFeatureConfig;
 
 /* SenseVoiceFrontend::new, pipeline.rs:38-65 (window, twiddle/bit-reverse tables, sparse mel bank, LFR) */
+/* hann_window (window.rs:2-13) and mel_filterbank (mel.rs:7-56; f_max = sample_rate / 2 unless has_f_max) as the library builds
+ * them for its own front-end: host arithmetic into host memory (`size` floats / n_mels * (n_fft / 2 + 1) floats), no ctx. */
+int lele_hip_hann_window(int64_t size, float* out);
+float lele_hip_hz_to_mel_htk(float hz);   /* mel.rs:1-3 */
+float lele_hip_mel_to_hz_htk(float mel);  /* mel.rs:4-6 */
+int lele_hip_mel_filterbank(float sample_rate, int64_t n_fft, int64_t n_mels, float f_min, int32_t has_f_max, float f_max, float* out);
 int lele_hip_frontend_create(LeleCtx* ctx, const LeleFeatureConfig* cfg, LeleFrontend** out);
 int lele_hip_frontend_destroy(LeleFrontend* fe);
 /* rows of the [T, n_mels*lfr_m] result for a pcm of `pcm_len` samples; 0 <=> TensorView::empty() (pipeline.rs:70-73) */

@@ -530,18 +530,14 @@ void host_twiddles(int64_t n, std::vector<float>& re, std::vector<float>& im) { 
 float hz_to_mel(float hz) { return 2595.0f * log10f(1.0f + hz / 700.0f); }       // mel.rs:1-3
 float mel_to_hz(float mel) { return 700.0f * (powf(10.0f, mel / 2595.0f) - 1.0f); }  // mel.rs:4-6
 
-// mel_filterbank + SparseMelBank::new (mel.rs:7-90): per filter (start_bin, weights[])
-void host_sparse_mel(float sr, int64_t n_fft, int64_t n_mels, float f_min, std::vector<int>& start,
-                     std::vector<std::vector<float>>& w) {
-    const float f_max = sr / 2.0f;
+// mel_filterbank (mel.rs:7-56): the dense [n_mels][n_fft / 2 + 1] triangles, HTK mel scale
+void host_dense_mel(float sr, int64_t n_fft, int64_t n_mels, float f_min, float f_max, float* bank) {
     const int64_t n_freqs = n_fft / 2 + 1;
     const float mel_min = hz_to_mel(f_min), mel_max = hz_to_mel(f_max);
     const float mel_step = (mel_max - mel_min) / (float)(n_mels + 1);
-    std::vector<float> hz(n_mels + 2), ff(n_freqs), row(n_freqs);
+    std::vector<float> hz(n_mels + 2), ff(n_freqs);
     for (int64_t i = 0; i < n_mels + 2; ++i) hz[i] = mel_to_hz(mel_min + (float)i * mel_step);
     for (int64_t i = 0; i < n_freqs; ++i) ff[i] = (float)i * sr / (float)n_fft;
-    start.assign(n_mels, 0);
-    w.assign(n_mels, {});
     for (int64_t i = 0; i < n_mels; ++i) {
         const float fl = hz[i], fc = hz[i + 1], fr = hz[i + 2];
         for (int64_t j = 0; j < n_freqs; ++j) {
@@ -551,15 +547,28 @@ void host_sparse_mel(float sr, int64_t n_fft, int64_t n_mels, float f_min, std::
                 val = (f - fl) / (fc - fl);
             else if (f >= fc && f < fr)
                 val = (fr - f) / (fr - fc);
-            row[j] = val;
+            bank[i * n_freqs + j] = val;
         }
+    }
+}
+
+// SparseMelBank::new (mel.rs:58-90) over it: per filter (start_bin, weights[])
+void host_sparse_mel(float sr, int64_t n_fft, int64_t n_mels, float f_min, std::vector<int>& start,
+                     std::vector<std::vector<float>>& w) {
+    const int64_t n_freqs = n_fft / 2 + 1;
+    std::vector<float> bank((size_t)n_mels * n_freqs);
+    host_dense_mel(sr, n_fft, n_mels, f_min, sr / 2.0f, bank.data());
+    start.assign(n_mels, 0);
+    w.assign(n_mels, {});
+    for (int64_t i = 0; i < n_mels; ++i) {
+        const float* row = bank.data() + i * n_freqs;
         int64_t s = 0;
         while (s < n_freqs && row[s] == 0.0f) ++s;
         int64_t e = n_freqs;
         while (e > s && row[e - 1] == 0.0f) --e;
         if (s < e) {
             start[i] = (int)s;
-            w[i].assign(row.begin() + s, row.begin() + e);
+            w[i].assign(row + s, row + e);
         }
     }
 }
@@ -578,6 +587,24 @@ int upload(LeleFrontend* fe, const std::vector<T>& v, const T** out) {
 }  // namespace
 
 extern "C" {
+
+/* The table builders of lele::features as the library computes them itself (window.rs:2-13, mel.rs:7-56): host arithmetic, host
+ * pointers, no ctx.  A binding exposes `hann_window` / `mel_filterbank` through these instead of restating the formulas. */
+int lele_hip_hann_window(int64_t size, float* out) {
+    LELE_REQUIRE(size >= 0 && (out || size == 0), "hann_window: bad argument");
+    std::vector<float> w;
+    host_hann(size, w);
+    if (size) memcpy(out, w.data(), (size_t)size * 4);
+    return 0;
+}
+float lele_hip_hz_to_mel_htk(float hz) { return hz_to_mel(hz); }      /* mel.rs:1-3 */
+float lele_hip_mel_to_hz_htk(float mel) { return mel_to_hz(mel); }    /* mel.rs:4-6 */
+int lele_hip_mel_filterbank(float sample_rate, int64_t n_fft, int64_t n_mels, float f_min, int32_t has_f_max, float f_max, float* out) {
+    LELE_REQUIRE(n_fft >= 0 && n_mels >= 0 && (out || n_mels == 0), "mel_filterbank: bad argument");
+    if (n_mels) host_dense_mel(sample_rate, n_fft, n_mels, f_min, has_f_max ? f_max : sample_rate / 2.0f, out);
+    return 0;
+}
+
 
 int lele_hip_frontend_create(LeleCtx* ctx, const LeleFeatureConfig* cfg, LeleFrontend** out) {
     LELE_REQUIRE(ctx && cfg && out, "frontend_create: NULL argument");

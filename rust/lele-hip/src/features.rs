@@ -1,30 +1,20 @@
-// GENERATED by tools/rust_shim/gen.py from tools/rust_shim/templates/features.rs -- do not edit.
+// Hand-written part of the crate (tools/rust_shim/gen.py generates ffi.rs, kernels.rs and lib.rs beside it and leaves this file alone).
 //! `lele::features::*` (src/features/mod.rs:1-12): the public interface of lele's audio front-end, same names, same signatures,
 //! same receivers -- `SenseVoiceFrontend::new(config)` / `frontend.compute(&audio)` on an immutable binding, `Cmvn::default()`,
 //! `Lfr::new(LfrConfig)`, and the building blocks (`hann_window`, `RealFft`, `SparseMelBank`, ...) lele's own tests call
 //! (tests/verify_features.rs:6-64).  The data-parallel entry points run on the device and return device-resident, reference-counted
 //! results (`TensorView<'static>` whose buffer goes back to the thread's pool when the last view of it is dropped); the small
-//! table builders are host arithmetic, written out with lele's formulas (they define the interface's numbers).
+//! table builders call the library's own (lele_hip_hann_window, lele_hip_mel_filterbank): this file holds no arithmetic of its own.
 use crate::ffi;
 use crate::rt::{self, Shape};
 use crate::tensor::TensorView;
-use std::f32::consts::PI;
 
 // ------------------------------------------------------------------------------------------------ window.rs
-/// window.rs:2-12: symmetric Hann window, 0.5 (1 - cos(2 pi n / (size - 1)))
+/// window.rs:2-12: the symmetric Hann window, as the library builds it for its own front-end (lele_hip_hann_window)
 pub fn hann_window(size: usize) -> Vec<f32> {
-    match size {
-        0 => Vec::new(),
-        1 => vec![1.0],
-        _ => {
-            let last = (size - 1) as f32;
-            let mut w = Vec::with_capacity(size);
-            for n in 0..size {
-                w.push(0.5 * (1.0 - (2.0 * PI * n as f32 / last).cos()));
-            }
-            w
-        }
-    }
+    let mut w = vec![0.0f32; size];
+    rt::check(unsafe { ffi::lele_hip_hann_window(size as i64, w.as_mut_ptr()) });
+    w
 }
 /// window.rs:13-18
 pub fn apply_window(input: &mut [f32], window: &[f32]) {
@@ -37,32 +27,18 @@ pub fn apply_window(input: &mut [f32], window: &[f32]) {
 // ------------------------------------------------------------------------------------------------ mel.rs
 /// mel.rs:1-3
 pub fn hz_to_mel_htk(hz: f32) -> f32 {
-    2595.0 * (1.0 + hz / 700.0).log10()
+    unsafe { ffi::lele_hip_hz_to_mel_htk(hz) }
 }
 /// mel.rs:4-6
 pub fn mel_to_hz_htk(mel: f32) -> f32 {
-    700.0 * (10.0f32.powf(mel / 2595.0) - 1.0)
+    unsafe { ffi::lele_hip_mel_to_hz_htk(mel) }
 }
-/// mel.rs:7-45: dense HTK triangles, row-major [n_mels, n_fft / 2 + 1]
+/// mel.rs:7-45: dense HTK triangles, row-major [n_mels, n_fft / 2 + 1] (lele_hip_mel_filterbank: the table the device front-end uses)
 pub fn mel_filterbank(sample_rate: f32, n_fft: usize, n_mels: usize, f_min: f32, f_max: Option<f32>) -> Vec<f32> {
-    let top = f_max.unwrap_or(sample_rate / 2.0);
-    let bins = n_fft / 2 + 1;
-    let (lo, hi) = (hz_to_mel_htk(f_min), hz_to_mel_htk(top));
-    let step = (hi - lo) / (n_mels + 1) as f32;
-    // the n_mels + 2 band edges in Hz, equally spaced on the mel axis
-    let edges: Vec<f32> = (0..n_mels + 2).map(|i| mel_to_hz_htk(lo + i as f32 * step)).collect();
-    let mut bank = vec![0.0f32; n_mels * bins];
-    for (m, row) in bank.chunks_mut(bins).enumerate() {
-        let (left, centre, right) = (edges[m], edges[m + 1], edges[m + 2]);
-        for (j, w) in row.iter_mut().enumerate() {
-            let f = j as f32 * sample_rate / n_fft as f32;
-            if f > left && f < centre {
-                *w = (f - left) / (centre - left);
-            } else if f >= centre && f < right {
-                *w = (right - f) / (right - centre);
-            }
-        }
-    }
+    let mut bank = vec![0.0f32; n_mels * (n_fft / 2 + 1)];
+    rt::check(unsafe {
+        ffi::lele_hip_mel_filterbank(sample_rate, n_fft as i64, n_mels as i64, f_min, f_max.is_some() as i32, f_max.unwrap_or(0.0), bank.as_mut_ptr())
+    });
     bank
 }
 /// mel.rs:47-104: every filter as (first non-zero bin, its run of weights)
@@ -271,4 +247,25 @@ impl Drop for SenseVoiceFrontend {
     fn drop(&mut self) {
         unsafe { ffi::lele_hip_frontend_destroy(self.h) };
     }
+}
+
+// The paths lele's own sources and tests use (src/features/mod.rs:1-12 declares six submodules and re-exports their contents;
+// tests/verify_features.rs:2 imports `lele::features::fft::Complex`): the same items under the same submodule names.
+pub mod cmvn {
+    pub use super::Cmvn;
+}
+pub mod fft {
+    pub use super::{Complex, RealFft};
+}
+pub mod lfr {
+    pub use super::{Lfr, LfrConfig};
+}
+pub mod mel {
+    pub use super::{apply_mel_bank, hz_to_mel_htk, log_compress, mel_filterbank, mel_to_hz_htk, SparseMelBank};
+}
+pub mod pipeline {
+    pub use super::{FeatureConfig, SenseVoiceFrontend};
+}
+pub mod window {
+    pub use super::{apply_window, hann_window};
 }

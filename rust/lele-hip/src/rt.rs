@@ -1,4 +1,4 @@
-// GENERATED by tools/rust_shim/gen.py from tools/rust_shim/templates/rt.rs -- do not edit.
+// Hand-written part of the crate (tools/rust_shim/gen.py generates ffi.rs, kernels.rs and lib.rs beside it and leaves this file alone).
 //! Runtime glue between lele's host-slice API and the device library: the per-thread context, the `out: &mut Vec<T>` -> LeleBuf
 //! slot registry, error handling (a non-zero status becomes the panic! lele's kernels raise), and the host-side shape arithmetic
 //! of the index operators (computed exactly as the reference does, then handed to ONE strided-copy kernel).
@@ -110,18 +110,17 @@ impl OwnedSlot {
 }
 impl Drop for OwnedSlot {
     fn drop(&mut self) {
-        // the thread's runtime may already be gone at thread exit: then the ctx has released the buffer with everything else
-        let _ = RT.try_with(|cell| {
-            if let Ok(mut g) = cell.try_borrow_mut() {
-                if let Some(r) = g.as_mut() {
-                    r.free.push(self.0);
-                }
-            }
-        });
+        // Not through the runtime: an owned view may be dropped while the runtime is borrowed (inside a kernel wrapper's with_rt
+        // closure, or in a nested drop), and a slot that waited for that borrow would be lost.  The slot goes onto a list of its
+        // own that pooled_slot() drains.  At thread exit the list may already be gone: the ctx then releases the buffer with
+        // everything else.
+        let _ = RETURNED.try_with(|cell| cell.borrow_mut().push(self.0));
     }
 }
 pub fn pooled_slot() -> Rc<OwnedSlot> {
+    let back: Vec<Slot> = RETURNED.with(|cell| std::mem::take(&mut *cell.borrow_mut()));
     with_rt(|r| {
+        r.free.extend(back);
         let s = match r.free.pop() {
             Some(s) => s,
             None => new_buf(r),
@@ -130,6 +129,8 @@ pub fn pooled_slot() -> Rc<OwnedSlot> {
     })
 }
 thread_local! {
+    // buffers whose last owned view has gone, until the next pooled_slot() call moves them to the runtime's free list
+    static RETURNED: RefCell<Vec<Slot>> = RefCell::new(Vec::new());
     // one ctx per host thread: lele itself is single-threaded with thread-local caches (conv2d.rs:601-603)
     static RT: RefCell<Option<Runtime>> = RefCell::new(None);
 }

@@ -1,4 +1,4 @@
-// GENERATED by tools/rust_shim/gen.py from tools/rust_shim/templates/tensor.rs -- do not edit.
+// Hand-written part of the crate (tools/rust_shim/gen.py generates ffi.rs, kernels.rs and lib.rs beside it and leaves this file alone).
 //! `lele::tensor::TensorView` (src/tensor.rs:5-166) with a device-aware payload.
 //!
 //! Upstream: `pub struct TensorView<'a, T = f32> { pub data: Cow<'a, [T]>, pub shape: Cow<'a, [usize]> }`.  Generated model code
