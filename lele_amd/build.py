@@ -14,11 +14,16 @@ CSRC = os.path.join(HERE, "csrc")
 # LELE_HIP_LAB=1 builds the developer's library instead: the same sources with -DLELE_HIP_LAB (in-kernel cycle stamps, ablation
 # switches, experimental kernels), as liblele_hip_lab.so -- never loaded unless LELE_HIP_LAB=1 is set at import (lele_amd/_lib.py)
 LAB = os.environ.get("LELE_HIP_LAB", "0") not in ("", "0")
-OBJ = os.path.join(HERE, "_build_lab" if LAB else "_build")
-LIB = os.path.join(HERE, "liblele_hip_lab.so" if LAB else "liblele_hip.so")
+# LELE_HIP_DEBUG_BOUNDS=1 builds liblele_hip_dbg.so: the same sources with -DLELE_HIP_DEBUG_BOUNDS, in which the loaders and the
+# epilogues ASSERT their coordinates on the device (common.h, LELE_DEV_ASSERT: a violation prints where it happened and traps the
+# kernel).  Loaded with LELE_HIP_LIBRARY=liblele_hip_dbg.so; tests/test_debug_bounds.py runs parity cases on it.
+DBG = os.environ.get("LELE_HIP_DEBUG_BOUNDS", "0") not in ("", "0")
+OBJ = os.path.join(HERE, "_build_dbg" if DBG else "_build_lab" if LAB else "_build")
+LIB = os.path.join(HERE, "liblele_hip_dbg.so" if DBG else "liblele_hip_lab.so" if LAB else "liblele_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=" + ARCH, "-Wall",
-         "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-result"] + (["-DLELE_HIP_LAB=1"] if LAB else [])
+         "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-result"] + (["-DLELE_HIP_LAB=1"] if LAB else []) + \
+        (["-DLELE_HIP_DEBUG_BOUNDS=1"] if DBG else [])
 
 
 def hipcc():
@@ -64,7 +69,7 @@ def build(force=False, verbose=False):
                 print(out)
     if jobs or force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-ldl"])
-    if not LAB:
+    if not LAB and not DBG:
         build_runner(force, run)
     return LIB
 

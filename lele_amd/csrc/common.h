@@ -141,6 +141,25 @@ struct LeleGraph {
 #define LELE_DEVERR_GATHER_INDEX 1u
 
 // Developer switches (kernel variants for A/B timing, stamps, ablations) exist in the LAB build only
+
+// Device-side assertions of the bounds-checking build (LELE_HIP_DEBUG_BOUNDS=1 python -m lele_amd.build -> liblele_hip_dbg.so): the
+// loaders of the GEMM core, the window kernels' LDS offsets and the epilogues' store coordinates state what they assume; a violation
+// prints the condition, the source line and the block / thread, and traps the kernel (the next synchronisation fails).  In the
+// product library the macro is empty.
+#ifdef LELE_HIP_DEBUG_BOUNDS
+#include <stdio.h>
+#define LELE_DEV_ASSERT(cond)                                                                                                      \
+    do {                                                                                                                           \
+        if (!(cond)) {                                                                                                             \
+            printf("lele_hip bounds assertion failed: %s (%s:%d) block (%u, %u, %u) thread %u\n", #cond, __FILE__, __LINE__, blockIdx.x, \
+                   blockIdx.y, blockIdx.z, threadIdx.x);                                                                            \
+            __builtin_trap();                                                                                                      \
+        }                                                                                                                          \
+    } while (0)
+#else
+#define LELE_DEV_ASSERT(cond) ((void)0)
+#endif
+
 // (LELE_HIP_LAB=1 python -m lele_amd.build -> liblele_hip_lab.so); in the product library lab_env() is NULL for every name.
 // The product's own run-time switches are the five documented in INTEGRATION.md ("Run-time switches").
 #ifdef LELE_HIP_LAB

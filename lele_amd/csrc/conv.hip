@@ -130,6 +130,8 @@ struct ConvXLoad {
                 }
             }
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) LELE_DEV_ASSERT(idx[e] >= 0 && idx[e] < g.icg * g.ih * g.iw);  // inside this image group's planes
         const float e0 = r.base[idx[0]], e1 = r.base[idx[1]], e2 = r.base[idx[2]], e3 = r.base[idx[3]];
         return make_float4(ok[0] ? e0 : 0.f, ok[1] ? e1 : 0.f, ok[2] ? e2 : 0.f, ok[3] ? e3 : 0.f);
     }
@@ -162,6 +164,7 @@ struct ConvXLoadTap {
         // (base + ic*hw) is uniform when k is; the lane adds its 32-bit position inside the plane
         const float* q = r.base + (int64_t)ic * hw;
         const unsigned off = ok ? (unsigned)(iy * g.iw + ix) : 0u;
+        LELE_DEV_ASSERT(ic >= 0 && ic + 3 < g.icg && off < (unsigned)hw);  // four channel planes of this image group
         const float e0 = q[off], e1 = (q + hw)[off], e2 = (q + 2 * hw)[off], e3 = (q + 3 * hw)[off];
         return ok ? make_float4(e0, e1, e2, e3) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -199,6 +202,7 @@ struct ConvEpi {
         float v = acc;
         if (bias) v = v + pre;
         v = activate(v, col);
+        LELE_DEV_ASSERT(img >= 0 && img < g.n && o >= 0 && o < g.oc && col >= 0 && col < g.plane);
         if (g.res) v = v + g.res[(int64_t)img * g.rbs + (int64_t)o * g.plane + col];
         out[(int64_t)img * g.obs + (int64_t)o * g.plane + col] = v;
     }
@@ -837,6 +841,7 @@ __device__ __forceinline__ void c3m_epilogue_strips(const cf32x16 (&acc)[NJ], co
                     if (epi.bias) v.x = v.x + bq[it], v.y = v.y + bq[it], v.z = v.z + bq[it], v.w = v.w + bq[it];
                     v.x = fn(v.x, body), v.y = fn(v.y, body), v.z = fn(v.z, body), v.w = fn(v.w, body);
                     if (colq[j] >= 0 && oc < g.oc) {
+                        LELE_DEV_ASSERT(colq[j] + 3 < g.plane && img >= 0 && img < g.n);
                         if (g.res) {  // uniform
                             const float4 r4 = *reinterpret_cast<const float4*>(g.res + (int64_t)img * g.rbs + (int64_t)oc * g.plane + colq[j]);
                             v.x = v.x + r4.x, v.y = v.y + r4.y, v.z = v.z + r4.z, v.w = v.w + r4.w;
@@ -901,6 +906,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const int t = pt + 256 * i, q = t / post, pos = t - q * post, py = pos / pwt, px = pos - py * pwt;
             t_pq[i] = q < 4 ? ((unsigned)q << 24) | ((unsigned)py << 12) | (unsigned)px : 0xffffffffu;
             t_lds[i] = q < 4 ? pos * C3M_PITCH + 8 * q : -1;
+            LELE_DEV_ASSERT(post <= W::POS && py < 4096 && px < 4096 && t_lds[i] + 64 + 8 <= W::STAGE);
         }
         const float* xin = x;
         int f_item = first - G, f_ocb = nocb - 1, f_cc = nchunk - 1;  // the fetch cursor: one step before the first chunk
@@ -995,6 +1001,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         p = p < wt.tw * wt.th ? p : 0;
         const int row = wt_row(wt, p);
         sb[j] = (row * pwt + p - row * wt.tw) * C3M_PITCH + hv * 16;
+        LELE_DEV_ASSERT(sb[j] + ((KS - 1) * pwt + KS - 1) * C3M_PITCH + 64 + 16 <= W::STAGE);  // the last tap's last piece
     }
     cu32x4 ar[2][3];
     const int wtaps = nchunk * W::TAPS;  // weight fragments of one block of output channels

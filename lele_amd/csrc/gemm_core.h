@@ -55,12 +55,15 @@ struct LoadRowK {
         return binner > 1 ? (int64_t)(b / binner) * bs + (int64_t)(b % binner) * bs2 : (int64_t)b * bs;
     }
     __device__ __forceinline__ Row row(int b, int r) const {
+        LELE_DEV_ASSERT(b >= 0 && r >= 0 && rows >= 1 && K >= 1);
         const bool rin = r < rows;
         return Row{p + boff(b) + (int64_t)(rin ? r : rows - 1) * ld, rin};
     }
     __device__ __forceinline__ float4 get4(const Row& r, int k) const {
         float4 v;
+        LELE_DEV_ASSERT(k >= 0);
         if (vec && k + 3 < K) {  // whole chunk in range (always, except in the last K tile)
+            LELE_DEV_ASSERT((((uintptr_t)(r.q + k)) & 15) == 0);
             v = *reinterpret_cast<const float4*>(r.q + k);
         } else {
             const int last = K - 1;
@@ -90,11 +93,13 @@ struct LoadKRow {
         return binner > 1 ? (int64_t)(b / binner) * bs + (int64_t)(b % binner) * bs2 : (int64_t)b * bs;
     }
     __device__ __forceinline__ Row row(int b, int r) const {
+        LELE_DEV_ASSERT(b >= 0 && r >= 0 && rows >= 1 && K >= 1);
         const bool rin = r < rows;
         return Row{p + boff(b), (unsigned)(rin ? r : rows - 1), rin};
     }
     __device__ __forceinline__ float4 get4(const Row& r, int k) const {
         const int last = K - 1;
+        LELE_DEV_ASSERT(k >= 0 && r.off < (unsigned)rows);
         // (base + k*ld) is scalar arithmetic when k is uniform; the lane contributes only its 32-bit row offset
         const float e0 = (r.base + (int64_t)(k + 0 < K ? k + 0 : last) * ld)[r.off];
         const float e1 = (r.base + (int64_t)(k + 1 < K ? k + 1 : last) * ld)[r.off];
@@ -152,6 +157,7 @@ struct EpiAffine {
     }
     __device__ __forceinline__ void store(int b, int row, int col, float acc, float pre) const {
         if (row >= M || col >= N) return;
+        LELE_DEV_ASSERT(b >= 0 && row >= 0 && col >= 0);
         out[ooff(b, row) + col] = value(acc, pre);
     }
     // the 16-byte store protocol (has_vec_store): rows of the result may be written four columns at a time
@@ -377,6 +383,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
                                 v.x += r4.x, v.y += r4.y, v.z += r4.z, v.w += r4.w;
                             }
                         }
+                        LELE_DEV_ASSERT(!(row < M && c4 < N) || (c4 + 3 < N && (((uintptr_t)(epi.row_ptr(batch, row) + c4)) & 15) == 0));
                         if (row < M && c4 < N) *reinterpret_cast<float4*>(epi.row_ptr(batch, row) + c4) = v;  // N % 4 == 0: whole or absent
                     }
                 }
