@@ -1587,23 +1587,215 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
 }
 
 // ---- ConvInteger family (conv2d.rs:1507-2761).  On x86 lele subtracts the zero points in f32 and runs its f32 GEMM
-// (conv2d_with_zero_points, :1507-2000: w - w_zp at :1631-1718, x - x_zp inside im2col_with_zp with padding = 0), so the
-// result is the f32 convolution of the centred operands; here: one centring pass, then the implicit-GEMM convolution.
+// (conv2d_with_zero_points, :1507-2000: w - w_zp at :1631-1718, x - x_zp inside im2col_with_zp), so the result is the f32
+// convolution of the centred operands -- where a PADDED cell is the u8 value 0, i.e. -x_zp once centred (:2025 "pad value is
+// (0 - x_zp)", :2043-2050, :2183-2199), not the zero point.
+// Here (group == 1, integer zero points, u8-coded operands): the codes themselves on the i8 matrix cores.  With x~ the u8 image
+// padded with zeros, a = x~ - 128 and b = w - 128 as i8:
+//     sum (x~ - zx)(w - zw) = sum a b + (128 - zw) sum x~ + (128 - zx) sum w - 16384 K + K zx zw          (K = C kh kw)
+// every term an exact i32; `sum x~` over a window is a 9-tap sum of the per-pixel channel sums T, `sum w` one number per output
+// channel.  The image is re-laid once as u8 [N, H, W, Cp] (Cp = C rounded up to 32; the same pass quantises an f32 source with
+// lele's DynamicQuantizeLinear formula and produces T): 16 consecutive channels of a pixel are then ONE 16-byte load -- a B
+// fragment of v_mfma_i32_32x32x32_i8 straight from L2 through a buffer resource, a position outside the image an offset past the
+// resource (reads 0 = the padded u8 value) -- and u8 -> i8 is a flip of the top bit of every byte.  No LDS, no barrier; the four
+// waves of a workgroup share one block of 32 output channels (its weight fragments stay in L1) and 128 positions each.
+// Everything else (groups, fractional zero points, device-resident weights) centres in f32 as lele does -- on an image padded
+// with zeros FIRST.
+typedef int ci_v4i __attribute__((ext_vector_type(4)));
+typedef int ci_v16i __attribute__((ext_vector_type(16)));
+struct Ci8Prm {          // zero points: host values (conv_integer) or the device record of the dynamic quantisation (from_f32)
+    const lele::QParamsDev* dq;
+    int zx_host, zw;
+};
+// u8 image [N, H, W, Cp] + per-pixel channel sums T [N, H, W] from f32 sources [N, src_c, H*W] landing in channels [ch_off, ..):
+// QUANT: q = clamp(round(x * inv_scale + zp), 0, 255) (conv2d.rs:2388-2394, f32::round = half away from zero); else the value is
+// already a u8 code.  One thread per (image, pixel, 4 channels); T is accumulated with integer atomics (order-free).
+template <bool QUANT>
+__global__ __launch_bounds__(256) void ci8_pack_kernel(const float* __restrict__ src, int64_t n_img, int src_c, int ch_off, int cp, int64_t spatial,
+                                                       const lele::QParamsDev* __restrict__ prm, unsigned* __restrict__ img, int* __restrict__ tsum) {
+    const int quads = (src_c + 3) / 4;
+    const int64_t total = n_img * quads * spatial;
+    float inv_scale = 1.0f, zp = 0.0f;
+    if (QUANT) inv_scale = prm[0].inv_scale, zp = prm[0].zp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i % spatial, r = i / spatial;
+        const int q = (int)(r % quads);
+        const int64_t n = r / quads;
+        unsigned word = 0u;
+        int sum = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * q + e;
+            float v = c < src_c ? src[(n * src_c + c) * spatial + pix] : 0.0f;
+            if (QUANT && c < src_c) {
+                v = roundf(v * inv_scale + zp);
+                v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+            }
+            const unsigned code = (unsigned)(int)v & 255u;
+            word |= code << (8 * e);
+            sum += (int)code;
+        }
+        // ch_off is a multiple of 4 for every source but possibly the last of a multi-source concat: bytes are placed one by one then
+        unsigned char* dst = reinterpret_cast<unsigned char*>(img) + (n * spatial + pix) * cp + ch_off + 4 * q;
+        if ((ch_off & 3) == 0) *reinterpret_cast<unsigned*>(dst) = word;
+        else
+            for (int e = 0; e < 4 && 4 * q + e < src_c; ++e) dst[e] = (unsigned char)(word >> (8 * e));
+        atomicAdd(&tsum[n * spatial + pix], sum);
+    }
+}
+// weights [OC][C][taps] (u8 codes as f32) -> i8 fragments b = w - 128 in MFMA order [oc tile][tap][chunk][64 lanes] x 16 bytes (lane
+// (l31, hv): output channel 32 tile + l31, input channels 32 chunk + 16 hv + [0, 16); zero beyond OC / C) and wsum[oc] = sum w
+__global__ __launch_bounds__(256) void ci8_wfrag_kernel(const float* __restrict__ w, int oc, int c, int taps, int chunks, ci_v4i* __restrict__ frag,
+                                                        int* __restrict__ wsum) {
+    const int64_t total = (int64_t)((oc + 31) / 32) * taps * chunks * 64;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), chunk = (int)((i >> 6) % chunks);
+        const int64_t r = (i >> 6) / chunks;
+        const int tap = (int)(r % taps), tile = (int)(r / taps);
+        const int o = tile * 32 + (lane & 31), c0 = chunk * 32 + 16 * (lane >> 5);
+        ci_v4i v;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            unsigned word = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = c0 + 4 * d + e;
+                const int code = o < oc && ch < c ? (int)w[((int64_t)o * c + ch) * taps + tap] : 128;
+                word |= ((unsigned)(code - 128) & 255u) << (8 * e);
+            }
+            v[d] = (int)word;
+        }
+        frag[i] = v;
+    }
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < oc; o += gridDim.x * 256) {
+        int sum = 0;
+        for (int64_t k = 0; k < (int64_t)c * taps; ++k) sum += (int)w[(int64_t)o * c * taps + k];
+        wsum[o] = sum;
+    }
+}
+// the convolution: 256 threads = four waves; a wave multiplies 32 output channels x NJ strips of 32 positions.  KSPLIT = false: the
+// waves of a workgroup own different positions (4 NJ x 32 a workgroup); KSPLIT = true (small layers: not enough tiles to go round):
+// they share ONE tile, take every fourth (tap, chunk) step each and meet in LDS -- integer sums, any order.  The operands of the next
+// step are requested before the products of this one (two register sets): a step is one L2 round trip otherwise.
+// grid (position blocks, ceil(OC / 32), N).
+template <int NJ, bool KSPLIT>
+__global__ __launch_bounds__(256) void ci8_conv_kernel(const unsigned char* __restrict__ img, const int* __restrict__ tsum, const ci_v4i* __restrict__ frag,
+                                                       const int* __restrict__ wsum, Ci8Prm prm, ConvGeom g, int cp, float* __restrict__ out) {
+    __shared__ int red[KSPLIT ? 3 * NJ * 16 * 64 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, hv = lane >> 5, l31 = lane & 31;
+    const int tile = blockIdx.y, n = blockIdx.z, chunks = cp / 32, taps = g.kh * g.kw, steps = taps * chunks;
+    const int p0 = (KSPLIT ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave) * (32 * NJ);
+    if (!KSPLIT && p0 >= g.plane) return;
+    const unsigned char* base = img + (int64_t)n * g.ih * g.iw * cp;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, (int)((unsigned)g.ih * g.iw * cp), 0x00020000);
+    int iy0[NJ], ix0[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        int p = p0 + 32 * j + l31;
+        p = p < g.plane ? p : g.plane - 1;
+        const int oy = p / g.ow;
+        iy0[j] = oy * g.sh - g.pt;
+        ix0[j] = (p - oy * g.ow) * g.sw - g.pl;
+    }
+    ci_v16i acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0;
+    const ci_v4i* fr = frag + (int64_t)tile * steps * 64 + lane;
+    auto load = [&](int t, ci_v4i& af, ci_v4i (&bf)[NJ]) {  // step t = (tap, chunk of 32 channels)
+        const int tap = t / chunks, ch = t - tap * chunks, a = tap / g.kw, b = tap - a * g.kw;
+        af = fr[(int64_t)t * 64];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int iy = iy0[j] + a * g.dh, ix = ix0[j] + b * g.dw;
+            const bool in = iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+            const unsigned off = in ? (unsigned)(iy * g.iw + ix) * (unsigned)cp + 16u * hv + 32u * ch : 0x80000000u;  // past the resource (< 2^31 bytes): reads 0
+            bf[j] = __builtin_bit_cast(ci_v4i, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0));
+        }
+    };
+    auto mult = [&](const ci_v4i& af, ci_v4i (&bf)[NJ]) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            bf[j] ^= (int)0x80808080u;  // u8 -> i8: x - 128
+            acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[j], acc[j], 0, 0, 0);
+        }
+    };
+    const int stride = KSPLIT ? 4 : 1;
+    ci_v4i a0, a1, b0[NJ], b1[NJ];
+    int t = KSPLIT ? wave : 0;
+    if (t < steps) load(t, a0, b0);
+    while (t < steps) {
+        if (t + stride < steps) load(t + stride, a1, b1);
+        mult(a0, b0);
+        t += stride;
+        if (t >= steps) break;
+        if (t + stride < steps) load(t + stride, a0, b0);
+        mult(a1, b1);
+        t += stride;
+    }
+    if (KSPLIT) {
+        if (wave > 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(((wave - 1) * NJ + j) * 16 + r) * 64 + lane] = acc[j][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][r] += red[((w * NJ + j) * 16 + r) * 64 + lane];
+    }
+    const int zx = prm.dq ? prm.dq[0].zp_i : prm.zx_host, zw = prm.zw, K = g.c * taps;
+    const int konst = K * zx * zw - 16384 * K;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        int sx = 0;  // sum of the u8 codes over this position's window (zeros outside the image): taps of the per-pixel channel sums
+        for (int tap = 0; tap < taps; ++tap) {
+            const int a = tap / g.kw, b = tap - a * g.kw, iy = iy0[j] + a * g.dh, ix = ix0[j] + b * g.dw;
+            if (iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw) sx += tsum[(int64_t)n * g.ih * g.iw + iy * g.iw + ix];
+        }
+        const int p = p0 + 32 * j + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv;
+            if (p < g.plane && o < g.oc)
+                out[((int64_t)n * g.oc + o) * g.plane + p] = (float)(acc[j][r] + (128 - zw) * sx + (128 - zx) * wsum[o] + konst);
+        }
+    }
+}
+// the f32 route's image: x (or its quantised codes) centred, inside a border of -zp cells (the padded u8 value 0)
+__global__ void ci_pad_center_kernel(const float* __restrict__ x, int64_t planes, int ih, int iw, int pt, int pl, int ph, int pw, float zp_host,
+                                     const lele::QParamsDev* __restrict__ dq, float* __restrict__ out) {
+    const float zp = dq ? dq[0].zp : zp_host;
+    const int64_t total = planes * ph * pw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pl_ = i / ((int64_t)ph * pw);
+        const int r = (int)(i - pl_ * ph * pw), y = r / pw - pt, xx = r % pw - pl;
+        const bool in = y >= 0 && y < ih && xx >= 0 && xx < iw;
+        out[i] = (in ? x[(pl_ * ih + y) * iw + xx] : 0.0f) - zp;
+    }
+}
 __global__ void ci_sub_kernel(const float* __restrict__ x, int64_t n, float zp, float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = x[i] - zp;
 }
 // conv_integer_from_f32 (:2246-2418, x86 branch :2388-2394): q = clamp(round(x * inv_scale + zp), 0, 255); the conv sees q - zp.
 // src is [N, src_c, spatial]; it lands in channels [ch_off, ch_off + src_c) of a [N, total_c, spatial] tensor (multi form)
-__global__ void ci_quant_center_kernel(const float* __restrict__ src, int64_t n_img, int64_t src_c, int64_t total_c,
-                                       int64_t ch_off, int64_t spatial, const QParamsDev* __restrict__ prm,
-                                       float* __restrict__ out) {
+// (the codes themselves, q, not q - zp: ci_pad_center_kernel centres them together with the border)
+__global__ void ci_quant_codes_kernel(const float* __restrict__ src, int64_t n_img, int64_t src_c, int64_t total_c,
+                                      int64_t ch_off, int64_t spatial, const QParamsDev* __restrict__ prm,
+                                      float* __restrict__ out) {
     const QParamsDev q = prm[0];
     const int64_t per_img = src_c * spatial, total = n_img * per_img;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t img = i / per_img, r = i - img * per_img;
         float v = roundf(src[i] * q.inv_scale + q.zp);  // f32::round: half away from zero; mul then add, not fused
         v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
-        out[(img * total_c + ch_off) * spatial + r] = v - q.zp;
+        out[(img * total_c + ch_off) * spatial + r] = v;
     }
 }
 __global__ void ci_scale_out_kernel(const QParamsDev* __restrict__ prm, float* __restrict__ scale) { scale[0] = prm[0].scale; }
@@ -1700,6 +1892,119 @@ int centred_weights(LeleCtx* ctx, const LeleTensor* w, float w_zp, const float**
                        (float*)adj);
     *out = (const float*)adj;
     return 0;
+}
+
+inline bool steps_lt8(int steps) { return steps < 8; }  // too few (tap, chunk) steps to share among four waves
+// One ConvInteger: `nsrc` f32 sources [N, c_i, H, W] concatenated along C (u8 codes, or -- dq != NULL -- values to be quantised with
+// the parameters at dq), weights w (u8 codes as f32), zero points zx_host (ignored when dq) and w_zp.  See the section comment.
+int ci_run(LeleCtx* ctx, ConvGeom g, const LeleTensor* w, float w_zp, const float* const* srcs, const int64_t* src_c, int nsrc, const QParamsDev* dq,
+           float zx_host, float* out) {
+    if ((int64_t)g.n * g.oc * g.plane == 0) return 0;
+    const int taps = g.kh * g.kw;
+    const int64_t spatial = (int64_t)g.ih * g.iw, K = (int64_t)g.c * taps;
+    auto code = [](float v) { return v >= 0.0f && v <= 255.0f && v == (float)(int)v; };
+    bool i8 = g.group == 1 && code(w_zp) && (dq || code(zx_host)) && K * 65025 < (int64_t(1) << 31) && w->mem != LELE_MEM_DEVICE &&
+              spatial * (((int64_t)g.c + 31) & ~int64_t(31)) < (int64_t(1) << 31) - 512 && g.n <= 65535 && (g.oc + 31) / 32 <= 65535 &&
+              !lab_env("LELE_HIP_CONV_INTEGER_F32");
+    const int cp = (g.c + 31) & ~31, chunks = cp / 32, tiles = (g.oc + 31) / 32;
+    const size_t fbytes = (size_t)tiles * taps * chunks * 1024, wbytes = fbytes + (size_t)g.oc * 4;
+    const bool cacheable = w->mem == LELE_MEM_WEIGHT;
+    const auto key = std::make_tuple((const void*)w->data, wbytes, 520);
+    const auto key_not = std::make_tuple((const void*)w->data, wbytes, 521);  // verdict "not u8 codes" of an immutable tensor (a 16-byte marker)
+    void* fw = nullptr;
+    if (i8) {  // the weights must be u8 codes: a host array, scanned once per immutable tensor (every call otherwise)
+        auto it = cacheable ? ctx->weights.find(key) : ctx->weights.end();
+        if (it != ctx->weights.end()) {
+            fw = it->second;
+        } else if (cacheable && ctx->weights.count(key_not)) {
+            i8 = false;
+        } else {
+            const float* hw = (const float*)w->data;
+            const int64_t nw = numel(w);
+            for (int64_t i = 0; i < nw && i8; ++i) i8 = code(hw[i]);
+            if (!i8 && cacheable && !ctx->capturing) {
+                void* marker = nullptr;
+                LELE_HIP_CHECK(hipMalloc(&marker, 16));
+                ctx->weights[key_not] = marker;
+            }
+        }
+    }
+    if (i8) {
+        if (!fw) {
+            const void* dw = nullptr;
+            LELE_TRY(ctx->dev_ptr(w, &dw));
+            if (cacheable) {
+                LELE_REQUIRE(!ctx->capturing, "graph capture: this op must run once eagerly first (it allocates or synchronises)");
+                LELE_HIP_CHECK(hipMalloc(&fw, wbytes));
+                ctx->weights[key] = fw;
+            } else {
+                LELE_TRY(ctx->arena_alloc(wbytes, &fw));
+            }
+            hipLaunchKernelGGL(ci8_wfrag_kernel, dim3(grid_for((int64_t)tiles * taps * chunks * 64)), dim3(256), 0, ctx->stream, (const float*)dw, g.oc, g.c,
+                               taps, chunks, (ci_v4i*)fw, (int*)((char*)fw + fbytes));
+        }
+        void *img = nullptr, *ts = nullptr;
+        LELE_TRY(ctx->arena_alloc((size_t)g.n * spatial * cp + 512, &img));
+        LELE_TRY(ctx->arena_alloc((size_t)g.n * spatial * 4, &ts));
+        LELE_HIP_CHECK(hipMemsetAsync(ts, 0, (size_t)g.n * spatial * 4, ctx->stream));
+        int ch_off = 0;
+        for (int i = 0; i < nsrc; ++i) {
+            const int64_t work = (int64_t)g.n * ((src_c[i] + 3) / 4) * spatial;
+            if (work && dq)
+                hipLaunchKernelGGL(ci8_pack_kernel<true>, dim3(grid_for(work)), dim3(256), 0, ctx->stream, srcs[i], (int64_t)g.n, (int)src_c[i], ch_off, cp,
+                                   spatial, dq, (unsigned*)img, (int*)ts);
+            else if (work)
+                hipLaunchKernelGGL(ci8_pack_kernel<false>, dim3(grid_for(work)), dim3(256), 0, ctx->stream, srcs[i], (int64_t)g.n, (int)src_c[i], ch_off, cp,
+                                   spatial, dq, (unsigned*)img, (int*)ts);
+            ch_off += (int)src_c[i];
+        }
+        const Ci8Prm prm{dq, (int)zx_host, (int)w_zp};
+        // the widest wave tile that still gives every CU two workgroups; below that the waves of a workgroup split K instead
+        const int64_t units = (int64_t)g.n * tiles, want = 2 * (int64_t)ctx->num_cus;
+        auto blocks = [&](int nj, bool ks) { return ((int64_t)g.plane + (ks ? 1 : 4) * 32 * nj - 1) / ((ks ? 1 : 4) * 32 * nj); };
+#define LELE_CI8(NJ_, KS_)                                                                                                          \
+    hipLaunchKernelGGL((ci8_conv_kernel<NJ_, KS_>), dim3((unsigned)blocks(NJ_, KS_), (unsigned)tiles, (unsigned)g.n), dim3(256), 0, ctx->stream, \
+                       (const unsigned char*)img, (const int*)ts, (const ci_v4i*)fw, (const int*)((char*)fw + fbytes), prm, g, cp, out)
+        if (units * blocks(4, false) >= want) LELE_CI8(4, false);
+        else if (units * blocks(2, false) >= want) LELE_CI8(2, false);
+        else if (units * blocks(1, false) >= want || steps_lt8(taps * chunks)) LELE_CI8(1, false);
+        else if (units * blocks(2, true) >= want) LELE_CI8(2, true);
+        else LELE_CI8(1, true);
+#undef LELE_CI8
+        LELE_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    // ---- f32: codes -> zero-padded, centred image -> lele's f32 convolution without padding
+    const float* dwc = nullptr;
+    LELE_TRY(centred_weights(ctx, w, w_zp, &dwc));
+    const float* codes = srcs[0];
+    if (dq || nsrc > 1) {
+        void* q = nullptr;
+        LELE_TRY(ctx->arena_alloc((size_t)std::max<int64_t>((int64_t)g.n * g.c * spatial, 1) * 4, &q));
+        int64_t ch_off = 0;
+        for (int i = 0; i < nsrc; ++i) {
+            const int64_t len = (int64_t)g.n * src_c[i] * spatial;
+            LELE_REQUIRE(dq, "conv_integer: several sources need the dynamic quantisation");
+            if (len)
+                hipLaunchKernelGGL(ci_quant_codes_kernel, dim3(grid_for(len)), dim3(256), 0, ctx->stream, srcs[i], (int64_t)g.n, src_c[i], (int64_t)g.c,
+                                   ch_off, spatial, dq, (float*)q);
+            ch_off += src_c[i];
+        }
+        codes = (const float*)q;
+    }
+    const int pb = (g.oh - 1) * g.sh + g.dh * (g.kh - 1) + 1 - g.ih - g.pt, pr = (g.ow - 1) * g.sw + g.dw * (g.kw - 1) + 1 - g.iw - g.pl;
+    const int ph = g.ih + g.pt + std::max(pb, 0), pw = g.iw + g.pl + std::max(pr, 0);  // (rows / columns no window reaches are not needed)
+    void* xc = nullptr;
+    const int64_t planes = (int64_t)g.n * g.c;
+    LELE_TRY(ctx->arena_alloc((size_t)std::max<int64_t>(planes * ph * pw, 1) * 4, &xc));
+    hipLaunchKernelGGL(ci_pad_center_kernel, dim3(grid_for(planes * ph * pw)), dim3(256), 0, ctx->stream, codes, planes, g.ih, g.iw, g.pt, g.pl, ph, pw,
+                       zx_host, dq, (float*)xc);
+    ConvGeom gp = g;
+    gp.ih = ph, gp.iw = pw, gp.pt = gp.pl = 0;
+    LeleTensor wv = *w;
+    wv.mem = LELE_MEM_DEVICE;  // the centred copy is what run_conv2d sees (its own weight cache keys on the pointer below)
+    wv.data = dwc;
+    return run_conv2d(ctx, &wv, (const float*)xc, dwc, nullptr, gp, LELE_ACT_NONE, out);
 }
 
 }  // namespace
@@ -2097,21 +2402,10 @@ int lele_hip_conv_integer(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w
     LELE_TRY(ctx->arena_reset());
     const void* dx = nullptr;
     LELE_TRY(ctx->dev_ptr(x, &dx));
-    const float* dwc = nullptr;
-    LELE_TRY(centred_weights(ctx, w, w_zp, &dwc));
-    const float* xin = (const float*)dx;
-    if (x_zp != 0.0f) {
-        void* xc = nullptr;
-        LELE_TRY(ctx->arena_alloc((size_t)numel(x) * 4, &xc));
-        hipLaunchKernelGGL(ci_sub_kernel, dim3(grid_for(numel(x))), dim3(256), 0, ctx->stream, (const float*)dx, numel(x), x_zp,
-                           (float*)xc);
-        xin = (const float*)xc;
-    }
     LELE_TRY(out->reserve((size_t)g.n * g.oc * g.plane * 4));
-    LeleTensor wv = *w;
-    wv.mem = LELE_MEM_DEVICE;  // the centred copy is what run_conv2d sees (its own weight cache keys on the pointer below)
-    wv.data = dwc;
-    LELE_TRY(run_conv2d(ctx, &wv, xin, dwc, nullptr, g, LELE_ACT_NONE, (float*)out->data));
+    const float* src = (const float*)dx;
+    const int64_t src_c = g.c;
+    LELE_TRY(ci_run(ctx, g, w, w_zp, &src, &src_c, 1, nullptr, x_zp, (float*)out->data));
     return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, (int64_t)g.oh, (int64_t)g.ow});
 }
 
@@ -2146,27 +2440,15 @@ int lele_hip_conv_integer_from_f32(LeleCtx* ctx, const LeleTensor* const* source
         ds[i] = (const float*)d;
         lens[i] = numel(sources[i]);
     }
-    const float* dwc = nullptr;
-    LELE_TRY(centred_weights(ctx, w, w_zp, &dwc));
-    void *prm = nullptr, *xq = nullptr;
+    void* prm = nullptr;
     LELE_TRY(ctx->arena_alloc(sizeof(QParamsDev), &prm));
-    const int64_t spatial = xshape[2] * xshape[3], total = xshape[0] * total_c * spatial;
-    LELE_TRY(ctx->arena_alloc((size_t)std::max<int64_t>(total, 1) * 4, &xq));
     LELE_TRY(out->reserve((size_t)g.n * g.oc * g.plane * 4));
     LELE_TRY(out_scale->reserve(4));
     LELE_TRY(quant_params_of(ctx, ds.data(), lens.data(), (int)nsrc, prm));
-    int64_t ch_off = 0;
-    for (size_t i = 0; i < nsrc; ++i) {
-        if (lens[i])
-            hipLaunchKernelGGL(ci_quant_center_kernel, dim3(grid_for(lens[i])), dim3(256), 0, ctx->stream, ds[i], xshape[0],
-                               sources[i]->shape[1], total_c, ch_off, spatial, (const QParamsDev*)prm, (float*)xq);
-        ch_off += sources[i]->shape[1];
-    }
     hipLaunchKernelGGL(ci_scale_out_kernel, dim3(1), dim3(1), 0, ctx->stream, (const QParamsDev*)prm, (float*)out_scale->data);
-    LeleTensor wv = *w;
-    wv.mem = LELE_MEM_DEVICE;
-    wv.data = dwc;
-    LELE_TRY(run_conv2d(ctx, &wv, (const float*)xq, dwc, nullptr, g, LELE_ACT_NONE, (float*)out->data));
+    std::vector<int64_t> chans(nsrc);
+    for (size_t i = 0; i < nsrc; ++i) chans[i] = sources[i]->shape[1];
+    LELE_TRY(ci_run(ctx, g, w, w_zp, ds.data(), chans.data(), (int)nsrc, (const QParamsDev*)prm, 0.0f, (float*)out->data));
     return set_shape(out_shape, out_rank, {(int64_t)g.n, (int64_t)g.oc, (int64_t)g.oh, (int64_t)g.ow});
 }
 

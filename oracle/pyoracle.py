@@ -380,6 +380,17 @@ def conv2d(x, w, bias=None, dilations=(), group=1, pads=(), strides=(), act=None
     return out
 
 
+def conv_integer(x, w, x_zp=0.0, w_zp=0.0, dilations=(), group=1, pads=(), strides=()):
+    """conv2d_with_zero_points (conv2d.rs:1507-1997) as conv_integer / conv_integer_from_f32 reach it: both operands centred in f32,
+    then lele's f32 convolution.  The PADDING is raw zeros: im2col_with_zp writes `neg_zp = -x_zp` into every padded cell
+    (conv2d.rs:2025, 2043-2050, 2183-2199 -- "pad value is (0 - x_zp)"), i.e. a padded cell stands for the u8 value 0, not for the
+    zero point.  Restated as: pad the u8 image with zeros, centre, convolve without padding."""
+    x, w = _f32(x), _f32(w)
+    pt, pl, pb, pr = _pads4(pads)
+    xp = np.pad(x, ((0, 0), (0, 0), (pt, pb), (pl, pr))) if (pt or pl or pb or pr) else x
+    return conv2d(xp - np.float32(x_zp), w - np.float32(w_zp), None, dilations, group, [0, 0, 0, 0], strides)
+
+
 def conv2d_im2col(x, w, bias=None, dilations=(), group=1, pads=(), strides=(), act=None):
     """conv2d as lele's x86 build runs it (conv_fast.cpp: im2col + k-ordered f32 FMA GEMM + bias / activation pass)"""
     x, w = _f32(x), _f32(w)
