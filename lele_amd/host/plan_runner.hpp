@@ -605,6 +605,10 @@ class Runner {
         // "lele_amd.plan/2": compiled from ONNX (lele_amd.compiler); no format tag: lifted from lele-generated Rust
         // (tools/lift_generated.py) -- weights keyed by byte offset, output buffers named inside the argument lists
         v2_ = plan_.has("format") && plan_.at("format").str == "lele_amd.plan/2";
+        // "lele_amd.plan/3" (plan.fold_channel_views: channel views, windows, conv2d_res) is a shape-specialised form for the batch
+        // graphs of the Python runner; this runner executes the plan it was folded from
+        if (plan_.has("format") && !v2_)
+            throw Error("plan format \"" + plan_.at("format").str + "\" is not supported by the native runner (it runs lele_amd.plan/2 and lifted plans)");
         std::ifstream f(weights_path, std::ios::binary);
         if (!f) throw Error("cannot open " + weights_path);
         blob_.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());

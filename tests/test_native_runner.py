@@ -70,3 +70,15 @@ def test_native_runner_matches_python_runner(ctx, tmp_path):
             assert a.shape == b.shape and np.array_equal(a, b), name
         if name == "toy":
             assert rec["eager_ms"] > 0 and rec["graph_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_native_runner_refuses_a_folded_plan_by_name(ctx, tmp_path):
+    """lele_amd.plan/3 (channel views, windows, conv2d_res: plan.fold_channel_views) is the Python runner's batch form; the native
+    runner says so instead of executing statements it does not know"""
+    plan = {"format": "lele_amd.plan/3", "inputs": [], "outputs": [], "slots": [], "weights": {}, "statements": []}
+    (tmp_path / "p.json").write_text(json.dumps(plan))
+    (tmp_path / "w.bin").write_bytes(b"")
+    r = subprocess.run([RUN, str(tmp_path / "p.json"), str(tmp_path / "w.bin"), "--out", str(tmp_path / "o")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "lele_amd.plan/3" in r.stderr and "not supported by the native runner" in r.stderr
