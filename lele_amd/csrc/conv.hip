@@ -1281,9 +1281,9 @@ inline int64_t attr(const int64_t* v, size_t n, size_t i, int64_t dflt) {
     return dflt;
 }
 
-// where the window-once kernel takes a 1 x 1 convolution (see the dispatch below); LELE_HIP_CONV_W1_* override for measurements
+// where the window-once kernel takes a 1 x 1 convolution (see the dispatch below); LELE_HIP_CONV_W1_* override them in the developer's build
 inline int conv_env(const char* name, int dflt) {
-    const char* v = getenv(name);
+    const char* v = lab_env(name);  // the developer's build only (common.h): the product library has the defaults compiled in
     return v && *v ? atoi(v) : dflt;
 }
 // (measured on the Yolo-shaped network at batch 64, whole forward: <= 64 channels / planes >= 6400 / >= 48 input channels 10.12 ms;
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(256) void conv_residual_kernel(float* __restrict__ 
 // The tile shape of a window-once launch (see WinTile): the fewest workgroups that cover an ow x oh map with th x tw <= `positions`
 // output positions each, whose window fits `max_slots` LDS slots -- (th + 2)(tw + 2) at stride 1, four phase planes of (th + 1)(tw + 1)
 // at stride 2, th x tw for a 1 x 1.  Widths are multiples of four (16-byte stores); among equal counts the widest tile (longest
-// contiguous runs on both sides).  LELE_HIP_CONV_TILE=tw,th overrides it for measurements.
+// contiguous runs on both sides).  In the developer's build LELE_HIP_CONV_TILE=tw,th (or `rows`: round 3's fixed tiles) overrides it.
 inline WinTile pick_win_tile(int ow, int oh, int positions, int ks, int stride, int max_slots, int64_t units, int num_cus) {
     // `units` = images x blocks of output channels: units x tiles workgroups are launched.  A workgroup multiplies its `positions`
     // whether they are outputs or padding, so with more workgroups than CUs the fewest tiles win; a launch that does not even give
@@ -1324,7 +1324,7 @@ inline WinTile pick_win_tile(int ow, int oh, int positions, int ks, int stride, 
         }
         if (tw >= ow) break;
     }
-    static const char* forced = getenv("LELE_HIP_CONV_TILE");
+    static const char* forced = lab_env("LELE_HIP_CONV_TILE");
     if (forced && !strcmp(forced, "rows") && ks == 3) {  // the fixed tiles of round 3: 8 (4 at stride 2) rows of 32 columns
         btw = 32, bth = stride == 2 ? 4 : 8;
     } else if (forced && *forced && ks == 3) {

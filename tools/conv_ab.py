@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Times every distinct convolution geometry of the Yolo-shaped network (tools/yolo_graph.py) at one batch size under the CURRENT
-environment (LELE_HIP_CONV_* switches are read once per process), HIP events around `iters` back-to-back calls.  Run it once per
+environment (the LELE_HIP_CONV_* switches exist in the developer's build, LELE_HIP_LAB=1, and are read once per process), HIP events around `iters` back-to-back calls.  Run it once per
 variant inside ONE gpurun call and compare the files: boxes differ by 10 % from call to call, so A/B across calls says nothing.
 
-    python tools/conv_ab.py --out gpurun_out/a.json;  LELE_HIP_CONV_TILE=rows python tools/conv_ab.py --out gpurun_out/b.json
+    LELE_HIP_LAB=1 python tools/conv_ab.py --out gpurun_out/a.json;  LELE_HIP_LAB=1 LELE_HIP_CONV_TILE=rows python tools/conv_ab.py --out gpurun_out/b.json
     python tools/conv_ab.py --compare gpurun_out/a.json gpurun_out/b.json"""
 import argparse
 import json
