@@ -794,6 +794,10 @@ __device__ __forceinline__ void c3m_epilogue(const cf32x16 (&acc)[NJ], const Con
 template <int NJ, int OCT>
 __device__ __forceinline__ void c3m_epilogue_strips(const cf32x16 (&acc)[NJ], const ConvEpi& epi, const ConvGeom& g, char* region, int wave, int lane,
                                                     int wm, int wn, int ocb, int img, int ty0, int tx0, const WinTile& wt) {
+    // everything below that depends on the lane alone is cheap to compute and expensive to keep: left to itself the compiler hoists it
+    // out of the persistent kernel's item loop, finds no registers for it beside the accumulators and the weight fragments, and reloads
+    // it from scratch memory in every epilogue
+    asm volatile("" : "+v"(lane));
     const int hv = lane >> 5, l31 = lane & 31;
     const int ocw = ocb * OCT + wm * 32;
     const int live = wt.tw * wt.th;
