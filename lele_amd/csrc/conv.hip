@@ -677,103 +677,13 @@ __device__ __forceinline__ int wt_row(const WinTile& t, int p) { return (int)(((
 
 __device__ __forceinline__ unsigned c3m_pair(float even, float odd) { return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u); }
 
-// Epilogue of the window-once kernels: a consumer wave holds NJ accumulator tiles (32 output channels x 32 columns of NJ tile rows).
-// C layout: column = lane & 31 = the position inside the row, rows (r & 3) + 8 (r >> 2) + 4 hv = output channels.  Stored as they
-// sit, a lane would issue 16 NJ four-byte stores and the tile's tail is store-ISSUE bound (measured: 730 of 1370 us on 64 -> 64
-// channels at 160 x 160 x 64): every wave is past the last barrier, so the stage is free and the wave's tile takes a turn through
-// LDS and leaves as 16-byte pieces of 128-byte output rows.  The 16 bias values a lane needs are fetched ONCE, together, before
-// anything else, and the activation is chosen once per wave: written per element (a load behind `if (bias)` and a switch on the
-// activation for each of the 16 NJ values) the compiler emitted 64 load -> wait -> polynomial chains one after the other, ~19 k
-// cycles of a tile whose products take 28 k.
-template <int NJ, int OCT>
-__device__ __forceinline__ void c3m_epilogue(const cf32x16 (&acc)[NJ], const ConvEpi& epi, const ConvGeom& g, char* lds, int wave, int lane,
-                                             int wm, int wn, int ocb, int img, int ty0, int tx0, const WinTile& wt) {
-    const int hv = lane >> 5, l31 = lane & 31;
-    const int ocw = ocb * OCT + wm * 32;  // first output channel of this wave's tile
-    float bv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) bv[r] = 0.0f;
-    if (epi.bias) {  // uniform
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = ocw + (r & 3) + 8 * (r >> 2) + 4 * hv;
-            bv[r] = epi.bias[o < g.oc ? o : g.oc - 1];
-        }
-    }
-    const int live = wt.tw * wt.th;  // positions of the tile; the rest of the 32 NJ-position strips is padding
-    int oyj[NJ], oxj[NJ];
-    bool inj[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int p = (NJ * wn + j) * 32 + l31, row = wt_row(wt, p);
-        oyj[j] = ty0 + row, oxj[j] = tx0 + p - row * wt.tw;
-        inj[j] = p < live && oyj[j] < g.oh && oxj[j] < g.ow;
-    }
-    if (g.ow % 4 == 0 && wt.tw % 4 == 0 && epi.vec_ok()) {  // 16-byte stores need the rows AND the destination (a view may start anywhere) aligned
-        constexpr int OCP = NJ * 32 + 8;  // floats per output channel: the two half waves (4 channels apart) land on different banks
-        float* mine = reinterpret_cast<float*>(lds) + wave * (32 * OCP);
-        bool body[NJ], every = true;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            body[j] = !inj[j] || oyj[j] * g.ow + oxj[j] < (g.plane & ~7);  // (a position outside is not stored: either form does)
-            every = every && body[j];
-        }
-        // the activation's scalar-tail form (libm) only where some lane is in the last 0-7 positions of the plane
-        const bool all_body = __builtin_amdgcn_ballot_w64(!every) == 0;
-        auto put = [&](auto fn) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ol = (r & 3) + 8 * (r >> 2) + 4 * hv;
-                    float v = acc[j][r];
-                    if (epi.bias) v = v + bv[r];
-                    mine[ol * OCP + j * 32 + l31] = fn(v, body[j]);
-                }
-        };
-        if (epi.act == LELE_ACT_NONE) put([](float v, bool) { return v; });
-        else if (epi.act == LELE_ACT_RELU) put([](float v, bool) { return v > 0.0f ? v : 0.0f; });
-        else if (all_body) put([](float v, bool) { return apply_act(v, LELE_ACT_SILU, true); });
-        else put([](float v, bool b) { return apply_act(v, LELE_ACT_SILU, b); });
-        // four consecutive positions of a strip are four consecutive columns of one row (tw is a multiple of four)
-        const int q4 = lane & 7;
-        int colq[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int p = (NJ * wn + j) * 32 + 4 * q4, row = wt_row(wt, p), oy = ty0 + row, oxq = tx0 + p - row * wt.tw;
-            colq[j] = p < live && oy < g.oh && oxq < g.ow ? oy * g.ow + oxq : -1;
-        }
-#pragma unroll
-        for (int it = 0; it < 4 * NJ; ++it) {
-            const int rowid = it * 8 + (lane >> 3), ol = rowid / NJ, j = rowid % NJ;
-            const int oc = ocw + ol;
-            const float4 v = *reinterpret_cast<const float4*>(mine + ol * OCP + j * 32 + 4 * q4);
-            int cq = colq[0];
-#pragma unroll
-            for (int jj = 1; jj < NJ; ++jj) cq = j == jj ? colq[jj] : cq;
-            if (cq >= 0 && oc < g.oc) {
-                float4 o4 = v;
-                if (g.res) {  // uniform
-                    const float4 r4 = *reinterpret_cast<const float4*>(g.res + (int64_t)img * g.rbs + (int64_t)oc * g.plane + cq);
-                    o4.x = v.x + r4.x, o4.y = v.y + r4.y, o4.z = v.z + r4.z, o4.w = v.w + r4.w;
-                }
-                *reinterpret_cast<float4*>(epi.out + (int64_t)img * g.obs + (int64_t)oc * g.plane + cq) = o4;
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        if (!inj[j]) continue;
-        const int col = oyj[j] * g.ow + oxj[j];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int oc = ocw + (r & 3) + 8 * (r >> 2) + 4 * hv;
-            if (oc < g.oc) epi.store(img, oc, col, acc[j][r], bv[r]);
-        }
-    }
-}
-
+// Epilogue of the window-once kernels (c3m_epilogue_strips below): a consumer wave holds NJ accumulator tiles (32 output channels x
+// NJ strips of 32 positions).  C layout: column = lane & 31 = the position inside the strip, rows (r & 3) + 8 (r >> 2) + 4 hv = output
+// channels.  Stored as they sit, a lane would issue 16 NJ four-byte stores and the tile's tail is store-ISSUE bound (measured: 730 of
+// 1370 us on 64 -> 64 channels at 160 x 160 x 64): the strips take a turn through LDS and leave as 16-byte pieces of 128-byte output
+// rows.  Bias values are fetched together before anything else and the activation is chosen once per wave: written per element (a
+// load behind `if (bias)` and a switch on the activation for each value) the compiler emitted 64 load -> wait -> polynomial chains
+// one after the other, ~19 k cycles of a tile whose products take 28 k.
 // ---- the stride-1 kernel: PERSISTENT workgroups of four loader waves and four consumer waves.
 // Loaders ("producers", waves 4-7) and multipliers ("consumers", waves 0-3) are separate waves because a wave's memory counter is in
 // order: a consumer with a window's loads in flight could not wait for its next weight fragment without waiting for the window too
@@ -1095,54 +1005,69 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // conflict-free 112-byte pitch of the stride-1 kernel.  660 slots x 112 bytes = 74 KB: ONE stage per workgroup and two workgroups
 // per CU (the stride-1 kernel's measurement: occupancy, not a second stage, is what hides a workgroup's staging and epilogue) --
 // the producers keep the next chunk in registers, park it when the consumers are done with the stage, and the other workgroup of
-// the CU multiplies meanwhile.  Same weight fragments and six-term products as the stride-1 kernel; one workgroup per tile.
+// the CU multiplies meanwhile.  Same weight fragments and six-term products as the stride-1 kernel.
 struct C3S2 {
     static constexpr int TH = 4, TW = 32, PH = 2 * (TH - 1) + 3, PW = 2 * (TW - 1) + 3;   // 9 x 65 input positions
     static constexpr int SY = (PH + 1) / 2, SX = (PW + 1) / 2, PLANE = SY * SX, POS = 4 * PLANE;   // 5 x 33 slots per phase plane
     static constexpr int STAGE = POS * C3M_PITCH;
-    static constexpr int EPI = 4 * 32 * (2 * 32 + 8) * 4;
-    static constexpr int LDS = STAGE > EPI ? STAGE : EPI;
     static constexpr int TASKS = (POS * 4 + 255) / 256;
 };
-// OCT = 64: two 32-channel tiles x two pairs of tile rows; OCT = 32: one tile x four single rows (narrow layers)
+// OCT = 64: two 32-channel tiles x two pairs of strips; OCT = 32: one tile x four single strips (narrow layers).
+// PERSISTENT like the stride-1 kernel (same items, same schedule): one stream of chunks across items, the loaders a chunk ahead in
+// registers -- the next item's first window is in flight during the epilogue -- and the strips leave through the (single) stage once
+// every multiplier is done with the item's last chunk.  Barriers per chunk: "parked" and "done"; per item two more around the epilogue.
 template <int OCT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_window_s2_kernel(const float* __restrict__ x,
                                                                                                     const cu32x4* __restrict__ wfrag,
-                                                                                                    ConvEpi epi, ConvGeom g, WinTile wt) {
+                                                                                                    ConvEpi epi, WinTile wt, int ntiles, int nocb,
+                                                                                                    int osplit, int items) {
     typedef C3S2 W;
     constexpr int NJ = OCT == 64 ? 2 : 1, MTB = OCT / 32, TAPS = 9;
+    static_assert(4 * 32 * 40 * 4 <= W::STAGE, "a strip of every consumer wave fits the stage");
     extern __shared__ __attribute__((aligned(16))) char c3m_lds[];
+    const ConvGeom& g = epi.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hv = lane >> 5, l31 = lane & 31;
-    const int tile = blockIdx.x, tyi = tile / wt.tiles_x, txi = tile - tyi * wt.tiles_x;
-    const int ocb = blockIdx.y, img = blockIdx.z;
     const int hw = g.ih * g.iw, nchunk = g.c / 16;
     const int sxt = wt.tw + 1, planet = (wt.th + 1) * sxt, post = 4 * planet;  // slots of a phase plane for this tile shape: post <= W::POS
+    const int G = gridDim.x, first = blockIdx.x;
+    const int nseq = ((items - first + G - 1) / G) * nocb, qtotal = nseq * nchunk;
     auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
     if (wave >= 4) {
-        // ------------------------------------------------------------ producers: one chunk in registers, parked when the stage is free.
-        // Eleven (slot, channel quad) tasks a thread: the loads go through a buffer resource over the chunk's 16 channel planes -- one
-        // 32-bit byte offset per task in a VGPR, one resource per channel of the quad, and an offset beyond the resource's size for
-        // a position outside the image (the load then returns zeros by itself): written with pointers and a select, the eleven
-        // 64-bit addresses and masks did not fit beside the data and the compiler spilled 31 registers.
+        // ------------------------------------------------------------ producers: one chunk in registers, parked when the stage is free
         const int pt = tid - 256;
-        const int iy0 = tyi * wt.th * 2 - g.pt, ix0 = txi * wt.tw * 2 - g.pl;
-        const float* xin = x + (int64_t)img * g.xbs;
-        unsigned t_off[W::TASKS];
         int t_lds[W::TASKS];
+        unsigned t_pq[W::TASKS], t_off[W::TASKS];
 #pragma unroll
         for (int i = 0; i < W::TASKS; ++i) {
             const int t = pt + 256 * i, q = t / post, slot = t - q * post;  // q < 4 while t < 4 * post
             const int ph = slot / planet, r = slot - ph * planet, sy = r / sxt, sx = r - sy * sxt;
-            const int py = 2 * sy + (ph >> 1), px = 2 * sx + (ph & 1), iy = iy0 + py, ix = ix0 + px;
-            const bool in = q < 4 && py < 2 * wt.th + 1 && px < 2 * wt.tw + 1 && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
-            t_off[i] = in ? (unsigned)(4 * q * hw + iy * g.iw + ix) * 4u : 0xfffffff0u;   // past num_records: reads as 0
+            const int py = 2 * sy + (ph >> 1), px = 2 * sx + (ph & 1);
+            const bool any = q < 4 && py < 2 * wt.th + 1 && px < 2 * wt.tw + 1;  // (the last row / column of the odd planes does not exist)
+            t_pq[i] = any ? ((unsigned)q << 24) | ((unsigned)py << 12) | (unsigned)px : 0xffffffffu;
             t_lds[i] = q < 4 ? slot * C3M_PITCH + 8 * q : -1;
         }
+        const float* xin = x;
+        int f_item = first - G, f_ocb = nocb - 1, f_cc = nchunk - 1;
         float4 st[W::TASKS];
-        auto fetch = [&](int cc) {
-            // one resource per channel of a quad (bases one plane apart, 13 planes long: quad 3's last position is its end), so that
-            // the range test sees nothing but the lane's own offset
-            const float* cb = xin + (int64_t)cc * 16 * hw;
+        auto fetch = [&] {
+            if (++f_cc == nchunk) {
+                f_cc = 0;
+                if (++f_ocb == nocb) {
+                    f_ocb = 0;
+                    f_item += G;
+                    const int pair = f_item / osplit;
+                    const int img = pair / ntiles, tile = pair - img * ntiles, tyi = tile / wt.tiles_x, txi = tile - tyi * wt.tiles_x;
+                    const int iy0 = tyi * wt.th * 2 - g.pt, ix0 = txi * wt.tw * 2 - g.pl;
+                    xin = x + (int64_t)img * g.xbs;
+#pragma unroll
+                    for (int i = 0; i < W::TASKS; ++i) {
+                        const int q = (int)(t_pq[i] >> 24), iy = iy0 + (int)((t_pq[i] >> 12) & 0xfffu), ix = ix0 + (int)(t_pq[i] & 0xfffu);
+                        const bool in = t_pq[i] != 0xffffffffu && iy >= 0 && iy < g.ih && ix >= 0 && ix < g.iw;
+                        t_off[i] = in ? (unsigned)(4 * q * hw + iy * g.iw + ix) * 4u : 0xfffffff0u;  // past the resource: reads as 0
+                    }
+                }
+            }
+            const float* cb = xin + (int64_t)f_cc * 16 * hw;
             const int extent = (int)(13u * (unsigned)hw * 4u);
             const auto r0 = __builtin_amdgcn_make_buffer_rsrc((void*)cb, (short)0, extent, 0x00020000);
             const auto r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(cb + hw), (short)0, extent, 0x00020000);
@@ -1176,48 +1101,50 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 *reinterpret_cast<cu32x2*>(c3m_lds + t_lds[i] + 64) = l;
             }
         };
-        fetch(0);
-        for (int cc = 0; cc < nchunk; ++cc) {
-            if (cc) barrier();  // the consumers are done with chunk cc - 1: the stage is free
+        fetch();
+        int since = 0;  // chunks of the current block parked so far
+        for (int q = 0; q < qtotal; ++q) {
             park();
-            barrier();          // the stage holds chunk cc
-            if (cc + 1 < nchunk) fetch(cc + 1);
+            barrier();  // chunk q is parked
+            if (q + 1 < qtotal) fetch();
+            barrier();  // the multipliers are done with chunk q
+            if (++since == nchunk) {
+                since = 0;
+                barrier();  // ... and with the block's epilogue, which went through the stage
+            }
         }
-        barrier();  // the consumers' last "done" (they reuse the stage for their epilogue)
         return;
     }
-    // ---------------------------------------------------------------- consumers: 32 output channels x NJ rows of the tile each
+    // ---------------------------------------------------------------- consumers: 32 output channels x NJ strips of the tile each
     const int wm = OCT == 64 ? (wave & 1) : 0, wn = OCT == 64 ? (wave >> 1) : wave;
     cf32x16 acc[NJ];
     int sb[NJ];  // this lane's position of strip j: byte offset of its slot (row, column) in a phase plane
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
         int p = (NJ * wn + j) * 32 + l31;
         p = p < wt.tw * wt.th ? p : 0;
         const int row = wt_row(wt, p);
         sb[j] = (row * sxt + p - row * wt.tw) * C3M_PITCH + hv * 16;
     }
-    const cu32x4* wbase = wfrag + ((int64_t)(ocb * MTB + wm) * nchunk) * (TAPS * 3 * 64) + lane;
     cu32x4 ar[2][3];
-    const int64_t wlast = (int64_t)nchunk * TAPS - 1;
-    auto wload = [&](cu32x4 (&dst)[3], int64_t gt) {
-        const cu32x4* src = wbase + (gt < wlast ? gt : wlast) * (3 * 64);
+    const int wtaps = nchunk * TAPS;
+    auto wblock = [&](int blk) { return wfrag + ((int64_t)(blk * MTB + wm) * nchunk) * (TAPS * 3 * 64) + lane; };
+    const cu32x4* wcur = wblock((first % osplit) * nocb);
+    const cu32x4* wnxt = wcur;
+    auto wload = [&](cu32x4 (&dst)[3], int gt) {
+        const cu32x4* src = gt < wtaps ? wcur + (int64_t)gt * (3 * 64) : wnxt;
 #pragma unroll
         for (int p = 0; p < 3; ++p) dst[p] = src[p * 64];
     };
-    wload(ar[0], 0);
     auto chunk = [&](int cc, auto pc) {
         constexpr int P = decltype(pc)::value;
-        if (cc) barrier();  // done with chunk cc - 1
-        barrier();          // chunk cc is in the stage
+        barrier();  // the chunk is parked
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int a = tap / 3, b = tap - 3 * a;
             const char* tapw = c3m_lds + ((2 * (a & 1) + (b & 1)) * planet + (a >> 1) * sxt + (b >> 1)) * C3M_PITCH;
             cu32x4 (&af)[3] = ar[(P + tap) & 1];
-            wload(ar[(P + tap + 1) & 1], (int64_t)cc * TAPS + tap + 1);
+            wload(ar[(P + tap + 1) & 1], cc * TAPS + tap + 1);
 #define LELE_CBF(v) __builtin_bit_cast(cbf16x8, v)
             constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};  // mm, hl, lh, hm, mh, hh: smallest terms first
             cu32x4 bf[NJ][3];
@@ -1235,18 +1162,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef LELE_CBF
             __builtin_amdgcn_sched_barrier(0);
         }
+        barrier();  // done with the chunk
     };
-    {
+    int item = first, ocb = 0;
+    wload(ar[0], 0);
+    for (int s = 0; s < nseq; ++s) {
+        const int pair = item / osplit, grp = item - pair * osplit;
+        const int img = pair / ntiles, tile = pair - img * ntiles, tyi = tile / wt.tiles_x, txi = tile - tyi * wt.tiles_x;
+        const int blk = grp * nocb + ocb;
+        {
+            const int item_n = ocb + 1 == nocb ? item + G : item;
+            wnxt = wblock((item_n % osplit) * nocb + (ocb + 1 == nocb ? 0 : ocb + 1));
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
         int cc = 0;
         for (; cc + 1 < nchunk; cc += 2) {
             chunk(cc, std::integral_constant<int, 0>());
             chunk(cc + 1, std::integral_constant<int, 1>());
         }
-        if (cc < nchunk) chunk(cc, std::integral_constant<int, 0>());
+        if (cc < nchunk) {
+            chunk(cc, std::integral_constant<int, 0>());
+#pragma unroll
+            for (int p = 0; p < 3; ++p) ar[0][p] = ar[1][p];
+        }
+        c3m_epilogue_strips<NJ, OCT>(acc, epi, g, c3m_lds, wave, lane, wm, wn, blk, img, tyi * wt.th, txi * wt.tw, wt);
+        barrier();  // the strips are out: the stage is the loaders' again
+        wcur = wnxt;
+        if (++ocb == nocb) ocb = 0, item += G;
     }
-    barrier();  // every consumer is done with the last chunk: the stage is free for the epilogue
-    static_assert(4 * 32 * (NJ * 32 + 8) * 4 <= W::LDS, "the epilogue tiles fit the stage");
-    c3m_epilogue<NJ, OCT>(acc, epi, g, c3m_lds, wave, lane, wm, wn, ocb, img, tyi * wt.th, txi * wt.tw, wt);
 }
 // weights [OC][IC][taps] f32 -> split-bf16 fragments [ceil(OC / 32)][IC / 16][taps][3 pieces][64 lanes] x 16 bytes (zeros for the
 // channels past OC): lane (l31 = output channel in the tile, hv) holds input channels 16 chunk + 8 hv + [0, 8) of its tap
@@ -1490,15 +1436,19 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
         }
         ConvEpi epi{out, db, g, act};
         const WinTile tile = pick_win_tile(g.ow, g.oh, 128, 3, 2, C3S2::POS, (int64_t)g.n * ((g.oc + oct - 1) / oct), ctx->num_cus);
-        const dim3 wgrid((unsigned)(tile.tiles_x * ((g.oh + tile.th - 1) / tile.th)), (unsigned)((g.oc + oct - 1) / oct), (unsigned)g.n);
+        const int ntiles = tile.tiles_x * ((g.oh + tile.th - 1) / tile.th), nblocks = (g.oc + oct - 1) / oct;
+        const int osplit = (int64_t)g.n * ntiles >= 2 * (int64_t)ctx->num_cus ? 1 : nblocks, nocb = nblocks / osplit;
+        const int64_t items = (int64_t)g.n * ntiles * osplit;
+        LELE_REQUIRE(items < (int64_t(1) << 31), "conv2d: more than 2^31 tiles");
+        const dim3 pgrid((unsigned)std::min<int64_t>(items, 2 * (int64_t)ctx->num_cus));
         if (oct == 64) {
             auto kern = conv_window_s2_kernel<64>;
-            LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3S2::LDS));
-            hipLaunchKernelGGL(kern, wgrid, dim3(512), C3S2::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tile);
+            LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3S2::STAGE));
+            hipLaunchKernelGGL(kern, pgrid, dim3(512), C3S2::STAGE, ctx->stream, dx, (const cu32x4*)dwf, epi, tile, ntiles, nocb, osplit, (int)items);
         } else {
             auto kern = conv_window_s2_kernel<32>;
-            LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3S2::LDS));
-            hipLaunchKernelGGL(kern, wgrid, dim3(512), C3S2::LDS, ctx->stream, dx, (const cu32x4*)dwf, epi, g, tile);
+            LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3S2::STAGE));
+            hipLaunchKernelGGL(kern, pgrid, dim3(512), C3S2::STAGE, ctx->stream, dx, (const cu32x4*)dwf, epi, tile, ntiles, nocb, osplit, (int)items);
         }
     } else if (g.group == 1 && g.kh == 3 && g.kw == 3 && g.dh == 1 && g.dw == 1 && g.sh == g.sw && (g.sh == 1 || g.sh == 2) && g.oc <= 16 &&
                g.c <= 64 && g.ow >= 16 && g.n <= 65535 &&
