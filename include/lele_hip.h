@@ -282,6 +282,12 @@ int lele_hip_max_pool2d_pitched(LeleCtx* ctx, const LeleTensor* x, const int64_t
                                 size_t ns, const int64_t* pads, size_t np, const int64_t* dilations, size_t nd, int ceil_mode,
                                 const LelePitch* pitch, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
 int lele_hip_copy_pitched(LeleCtx* ctx, const LeleTensor* x, const LelePitch* pitch, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* The transposing copy of a channel view: x [N, C, ...] (image pitch x_pitch) -> [N, P, C] (P = the product of the trailing
+ * dimensions), dense or into the window (out_offset, out_pitch) of an already reserved buffer -- rows [p0, p0 + P) of a wider
+ * [N, P_total, C] tensor are the window p0 * C, P_total * C.  lele's detection tails are Concat(levels, axis = 2) -> Transpose(0, 2, 1)
+ * -> Split(heads, axis = 2) (examples/yolo26n-seg/src/yolo26seg.rs): three passes over the predictions, each a copy; the same
+ * values arrive with one of these calls per (level, head) (lele_amd/plan.py, fold_transposed_splits). */
+int lele_hip_transpose_cp_pitched(LeleCtx* ctx, const LeleTensor* x, const LelePitch* pitch, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
 /* adaptive_avg_pool1d, pooling.rs:1-30: x [.., L] -> [.., output_len]; window i = [floor(i*L/O), ceil((i+1)*L/O)) */
 int lele_hip_adaptive_avg_pool1d(LeleCtx* ctx, const LeleTensor* x, int64_t output_len, LeleBuf* out, int64_t* out_shape,
                                  int32_t* out_rank);

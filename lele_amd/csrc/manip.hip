@@ -486,6 +486,24 @@ __global__ __launch_bounds__(256) void topk_rank_kernel(const float* __restrict_
     }
 }
 
+// out[n][p][c] = x[n][c][p] for one image-pitched operand and result: 32 x 32 tiles through LDS, reads along p, writes along c
+__global__ __launch_bounds__(256) void transpose_cp_kernel(const float* __restrict__ x, float* __restrict__ out, int c, int pos, long long xbs, long long obs) {
+    __shared__ float t[32][33];
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const float* src = x + (long long)blockIdx.z * xbs;
+    float* dst = out + (long long)blockIdx.z * obs;
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) {
+        const int cl = i >> 5, pl = i & 31;
+        if (c0 + cl < c && p0 + pl < pos) t[cl][pl] = src[(long long)(c0 + cl) * pos + p0 + pl];
+    }
+    __syncthreads();
+    const int cw = c - c0 < 32 ? c - c0 : 32;
+    for (int i = threadIdx.x; i < 32 * cw; i += 256) {
+        const int pl = i / cw, cl = i - pl * cw;
+        if (p0 + pl < pos) dst[(long long)(p0 + pl) * c + c0 + cl] = t[cl][pl];
+    }
+}
+
 // Long rows, one workgroup per row: RADIX SELECT.  The prefilter above keeps everything at least as good as the k-th best of the
 // first 2048 elements -- ~n k / 2048 survivors, ranked against each other in O(m^2): 0.51 ms for the [64, 24000] -> 300 selection
 // of a Yolo26n-seg tail.  Here the k-th best value itself is found by four 8-bit histogram passes over order-preserving integer
@@ -1111,6 +1129,32 @@ int lele_hip_max_pool2d_pitched(LeleCtx* ctx, const LeleTensor* x, const int64_t
                                 const LelePitch* pitch, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
     LELE_REQUIRE(pitch, "max_pool2d_pitched: pitch is NULL");
     return max_pool2d_entry(ctx, x, kernel_shape, nk, strides, ns, pads, np, dilations, nd, ceil_mode, pitch, out, out_shape, out_rank);
+}
+
+/* [N, C, P...] -> [N, P, C] of a channel view into a row window: the detection tail's Concat(levels) -> Transpose -> Split(heads)
+ * as one transposing copy per (level, head) -- see lele_hip.h */
+int lele_hip_transpose_cp_pitched(LeleCtx* ctx, const LeleTensor* x, const LelePitch* pitch, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && x && out && pitch, "transpose_cp_pitched: NULL argument");
+    LELE_REQUIRE(x->rank >= 3 && x->dtype == LELE_F32, "transpose_cp_pitched: an f32 tensor [N, C, ...] of rank >= 3 required");
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t images = x->shape[0], c = x->shape[1];
+    int64_t pos = 1;
+    for (int d = 2; d < x->rank; ++d) pos *= x->shape[d];
+    const int64_t per = c * pos;
+    LELE_TRY(check_x_pitch(x, pitch, per, "transpose_cp_pitched"));
+    LELE_TRY(ctx->arena_reset());
+    const void* dx = nullptr;
+    LELE_TRY(ctx->dev_ptr(x, &dx));
+    void* dst = nullptr;
+    LELE_TRY(lele::pitched_out(out, pitch, images, per, 4, &dst));
+    if (images * per) {
+        LELE_REQUIRE(images <= 65535 && (c + 31) / 32 <= 65535 && pos < (int64_t(1) << 31) && c < (int64_t(1) << 31), "transpose_cp_pitched: tensor too large");
+        hipLaunchKernelGGL(transpose_cp_kernel, dim3((unsigned)((pos + 31) / 32), (unsigned)((c + 31) / 32), (unsigned)images), dim3(256), 0, ctx->stream,
+                           (const float*)dx, (float*)dst, (int)c, (int)pos, (long long)(pitch->x_pitch ? pitch->x_pitch : per),
+                           (long long)(pitch->out_pitch ? pitch->out_pitch : per));
+        LELE_HIP_CHECK(hipGetLastError());
+    }
+    return set_shape(out_shape, out_rank, {images, pos, c});
 }
 
 /* Copy between channel views (or a view and a dense tensor): image n of `x` (x_pitch apart, or dense) -> image n of the destination

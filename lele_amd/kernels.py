@@ -79,6 +79,12 @@ def copy_view(input, out=None, out_window=None, ctx=None):
     return _op_pitched(ctx, _lib.lib().lele_hip_copy_pitched, [input], [], out, out_window, _dtype_of(input))
 
 
+def transpose_cp(input, out=None, out_window=None, ctx=None):
+    """[N, C, ...] (a tensor or a channel view) -> [N, P, C], dense or into rows of an already reserved [N, P_total, C] buffer
+    (lele_hip_transpose_cp_pitched): the detection tail's Concat -> Transpose -> Split without the intermediate tensors"""
+    return _op_pitched(ctx, _lib.lib().lele_hip_transpose_cp_pitched, [input], [], out, out_window)
+
+
 def matmul(a, b, out=None, ctx=None):  # gemm.rs:112
     return _call(_lib.lib().lele_hip_matmul, [a, b], (), out, ctx)
 

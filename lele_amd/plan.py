@@ -12,6 +12,7 @@ Argument nodes: {"ref"}, {"weight"}, {"list"}, {"int"|"float"|"bool"|"str"}, {"n
 {"ints": name} (a host integer value as a list), {"first": node} (first element of an integer list),
 {"array": [...], "dtype"} (a literal host tensor), {"chain": [...]} (the view steps of a `view_copy`).
 """
+import os
 import time
 
 import numpy as np
@@ -314,6 +315,94 @@ def _lit_int(node):
     return node["int"] if isinstance(node, dict) and "int" in node else None
 
 
+def fold_transposed_splits(sts, shapes, outputs, multi):
+    """`U = concat([reshape(A_l, [N, C, P_l]) ...], axis = 2)`; `T = transpose(U, [0, 2, 1])`; `H_k = split(T, axis = 2, sizes)` -- the
+    tail of lele's detection heads (yolo26seg.rs: three passes over [N, 116, 8400], each a copy) -> one transposing copy per
+    (level l, head k): channels [c0_k, c1_k) of A_l straight into rows [p_l, p_l + P_l) of H_k (`transpose_cp`, a `window` of a
+    reserved [N, P, c_k] buffer).  The same values in the same places; nothing else reads U, T or the reshapes.  Returns
+    (statements, number of tails rewritten)."""
+    prod, readers = {}, {}
+    for i, st in enumerate(sts):
+        for o in st.get("out", []):
+            prod[o] = i
+        names = _refs(st.get("args", st.get("in")), [])
+        if st["op"] == "if":
+            names += _refs([st.get("then"), st.get("else"), st.get("cond")], [])
+        for r in names:
+            readers.setdefault(r, []).append(i)
+
+    def call(name, fn):
+        i = prod.get(name)
+        return i if i is not None and name not in multi and name not in outputs and sts[i]["op"] == "call" and sts[i].get("fn") == fn \
+            and len(sts[i]["out"]) == 1 else None
+
+    def ints(node):
+        vals = node.get("list") if isinstance(node, dict) else None
+        return None if vals is None or any(_lit_int(v) is None for v in vals) else [_lit_int(v) for v in vals]
+
+    drop, put, count = set(), {}, 0
+    for i, st in enumerate(sts):
+        if st["op"] != "call" or st.get("fn") != "split" or not isinstance(st["args"][0], dict) or "ref" not in st["args"][0]:
+            continue
+        t = st["args"][0]["ref"]
+        sizes = ints(st["args"][2])
+        ts = shapes.get(t)
+        if sizes is None or ts is None or len(ts) != 3 or _lit_int(st["args"][1]) not in (2, -1) or sum(sizes) != int(ts[2]) \
+                or len(sizes) != len(st["out"]) or any(o in multi for o in st["out"]) or readers.get(t) != [i]:
+            continue
+        it = call(t, "transpose")
+        if it is None or ints(sts[it]["args"][1]) != [0, 2, 1] or "ref" not in sts[it]["args"][0]:
+            continue
+        u = sts[it]["args"][0]["ref"]
+        iu = call(u, "concat")
+        if iu is None or readers.get(u) != [it] or _lit_int(sts[iu]["args"][1]) not in (2, -1):
+            continue
+        levels, ok = [], True
+        for lv in _concat_operands(sts[iu]) or [None]:
+            il = call(lv, "reshape") if lv else None
+            if il is None or readers.get(lv) != [iu] or "ref" not in sts[il]["args"][0]:
+                ok = False
+                break
+            a = sts[il]["args"][0]["ref"]
+            sa, sl = shapes.get(a), shapes.get(lv)
+            pa = prod.get(a)
+            f32 = pa is not None and a not in multi and (sts[pa].get("fn") in _F32_FNS or (sts[pa].get("fn") == "concat" and all(
+                prod.get(o) is not None and sts[prod[o]].get("fn") in _F32_FNS for o in (_concat_operands(sts[pa]) or [None]))))
+            if not f32 or sa is None or sl is None or len(sa) != 4 or len(sl) != 3 or list(sl[:2]) != list(sa[:2]) or int(sl[2]) != int(sa[2]) * int(sa[3]) \
+                    or int(sl[1]) != int(ts[2]) or int(sl[0]) != int(ts[0]):
+                ok = False
+                break
+            levels.append((a, int(sl[2]), il))
+        if not ok or not levels or sum(p for _a, p, _i in levels) != int(ts[1]):
+            continue
+        new, after = [], []
+        n = int(ts[0])
+        c0 = 0
+        for k, (o, ck) in enumerate(zip(st["out"], sizes)):
+            buf = o + "__rows"
+            new.append({"op": "reserve", "out": [buf], "shape": [n, int(ts[1]), ck], "bufs": 1})
+            p0 = 0
+            for li, (a, pl, _il) in enumerate(levels):
+                src = "%s__l%d" % (o, li)
+                new.append({"op": "chview", "out": [src], "src": a, "c0": c0, "c1": c0 + ck})
+                piece = "%s__t%d" % (o, li)
+                new.append({"op": "call", "out": [piece], "fn": "transpose_cp", "args": [{"ref": src}], "window": {"of": buf, "c0": p0}, "bufs": 0})
+                after.append(piece)
+                p0 += pl
+            new.append({"op": "chview", "out": [o], "src": buf, "c0": 0, "c1": int(ts[1]), "after": [x for x in after if x.startswith(o + "__t")]})
+            c0 += ck
+        put[i] = new
+        drop |= {it, iu} | {il for _a, _p, il in levels}
+        count += 1
+    out = []
+    for i, st in enumerate(sts):
+        if i in put:
+            out += put[i]
+        elif i not in drop:
+            out.append(st)
+    return out, count
+
+
 def fold_channel_views(plan, shapes, residuals=True):
     """Returns a format-3 plan in which (after fuse_residual_adds, unless residuals=False), wherever every party can work on a channel view,
       * a Split along C of a rank-4 tensor is a set of views of its operand (no kernel),
@@ -330,9 +419,11 @@ def fold_channel_views(plan, shapes, residuals=True):
             if o in prod:
                 multi.add(o)
             prod[o] = i
-    n_res = 0
+    n_res = n_tails = 0
     if residuals:
         sts, n_res = fuse_residual_adds(sts, shapes, set(plan["outputs"]), multi)
+        if os.environ.get("LELE_AMD_FOLD_TAILS", "1") != "0":   # (0: keep Concat -> Transpose -> Split as three passes, for A/B timing)
+            sts, n_tails = fold_transposed_splits(sts, shapes, set(plan["outputs"]), multi)
     nst = len(sts)
     prod = {}
     for i, st in enumerate(sts):
@@ -497,7 +588,7 @@ def fold_channel_views(plan, shapes, residuals=True):
     slots = allocate(out, list(plan["outputs"]))
     new = dict(plan)
     new.update({"format": "lele_amd.plan/3", "statements": out, "slots": slots,
-                "folded": {"residual_adds_fused": n_res, "concats_in_place": len(concat_plan), "splits_as_views": len(view_split),
+                "folded": {"residual_adds_fused": n_res, "transposed_splits_folded": n_tails, "concats_in_place": len(concat_plan), "splits_as_views": len(view_split),
                            "operands_in_place": len(windowed), "operands_copied": sum(1 for _b, e in concat_plan.values() for x in e if not x[2])}})
     return new
 

@@ -54,7 +54,7 @@ def _val(x):
 
 class EmuK:
     """the operators of the test plans with the oracle's arithmetic, writing where the library would write"""
-    VIEW_OK = {"conv2d", "conv2d_silu", "conv2d_fused", "conv2d_res", "add", "mul", "max_pool2d", "resize_nearest", "copy_view"}
+    VIEW_OK = {"conv2d", "conv2d_silu", "conv2d_fused", "conv2d_res", "add", "mul", "max_pool2d", "resize_nearest", "copy_view", "transpose_cp"}
 
     def __init__(self):
         self.view_reads = 0
@@ -115,6 +115,20 @@ class EmuK:
     def copy_view(self, x, out=None, out_window=None, ctx=None):
         self._in("copy_view", x)
         return self._put(_val(x), out, out_window)
+
+    def transpose_cp(self, x, out=None, out_window=None, ctx=None):
+        self._in("transpose_cp", x)
+        v = _val(x)
+        self.tcp_calls = getattr(self, "tcp_calls", 0) + 1
+        return self._put(np.ascontiguousarray(v.reshape(v.shape[0], v.shape[1], -1).transpose(0, 2, 1)), out, out_window)
+
+    def reshape(self, x, shape):
+        from lele_amd import kernels as K
+        return K.reshape(x, shape)
+
+    def transpose(self, x, perm, out=None, ctx=None):
+        self._in("transpose", x)
+        return self._put(np.ascontiguousarray(_val(x).transpose(perm)), out, None)
 
     def concat(self, xs, axis, out=None, ctx=None):
         self._in("concat", *xs)
@@ -220,7 +234,8 @@ def test_fold_on_emulated_memory():
     # C3k2: the split's input goes into the concat in place (one merged operand) + the residual add; SPPF: the 1x1 conv and the three
     # pools; FPN: the resize and p3.  The split feeding the grouped conv / the output stays, as does the concat along H.
     # The bottleneck's `y1 + cv2(cv1(y1))` is ONE conv2d_res call that reads the split result as a view and writes the concat's window.
-    assert info == {"residual_adds_fused": 1, "concats_in_place": 3, "splits_as_views": 1, "operands_in_place": 8, "operands_copied": 0}, info
+    assert info == {"residual_adds_fused": 1, "transposed_splits_folded": 0, "concats_in_place": 3, "splits_as_views": 1, "operands_in_place": 8,
+                    "operands_copied": 0}, info
     fns = [st.get("fn") for st in folded["statements"] if st["op"] == "call"]
     assert fns.count("concat") == 1 and fns.count("split") == 1 and fns.count("add") == 0 and fns.count("conv2d_res") == 1
     assert fold_channel_views(plan, r0.shapes, residuals=False)["folded"]["residual_adds_fused"] == 0
@@ -294,6 +309,49 @@ def test_residual_adds_are_fused_only_where_that_is_the_same_program():
         if fused:
             acts = [st["args"][8]["int"] for st in folded["statements"] if st.get("fn") == "conv2d_res"]
             assert acts == [0, 2]
+
+
+def detection_tail_plan(seed=4):
+    """three levels [N, 10, h, w] (each a Concat along C of a 4-, a 3- and a 3-channel convolution) -> reshape to [N, 10, P_l] ->
+    Concat along positions -> Transpose(0, 2, 1) -> Split into heads of 4 / 3 / 3 -> sigmoid of one head; two heads are outputs"""
+    b = PlanBuilder(seed)
+    levels = []
+    feats = ["x", None, None]
+    feats[1] = b.conv("x", 8, 8, 3, 2)
+    feats[2] = b.conv(feats[1], 8, 8, 3, 2)
+    for f, (h, w) in zip(feats, ((8, 12), (4, 6), (2, 3))):
+        parts = [b.conv(f, 8, c, 1, silu=False) for c in (4, 3, 3)]
+        cat = b.call("concat", [{"list": [{"ref": p} for p in parts]}, {"int": 1}], "cat")
+        levels.append(b.call("reshape", [{"ref": cat}, b.ints([2, 10, h * w])], "lvl"))
+        b.sts[-1]["bufs"] = 0
+    pred = b.call("concat", [{"list": [{"ref": v} for v in levels]}, {"int": 2}], "pred")
+    predt = b.call("transpose", [{"ref": pred}, b.ints([0, 2, 1])], "predt")
+    box, cls, coef = b.call("split", [{"ref": predt}, {"int": 2}, b.ints([4, 3, 3])], "heads", 3)
+    prob = b.call("sigmoid", [{"ref": cls}], "prob")
+    return b.finish(["x"], [box, prob, coef])
+
+
+def test_detection_tail_becomes_transposing_copies():
+    plan, weights = detection_tail_plan()
+    x = np.random.default_rng(8).standard_normal((2, 8, 8, 12)).astype(np.float32)
+    ctx = EmuCtx()
+    want, r0 = run_plan(plan, weights, ctx, EmuK(), {"x": EmuK._put(x, ctx.buf(), None)}, record=True)
+    folded = fold_channel_views(plan, r0.shapes)
+    assert folded["folded"]["transposed_splits_folded"] == 1 and folded["folded"]["concats_in_place"] == 3, folded["folded"]
+    fns = [st.get("fn") for st in folded["statements"] if st["op"] == "call"]
+    assert fns.count("transpose_cp") == 9 and "transpose" not in fns and "split" not in fns and fns.count("concat") == 0
+    k = EmuK()
+    got, _ = run_plan(folded, weights, ctx, k, {"x": EmuK._put(x, ctx.buf(), None)})
+    assert k.tcp_calls == 9 and all(np.array_equal(p, q) for p, q in zip(want, got))
+    # a second reader of the transposed tensor (or of the concatenation) keeps the three passes
+    plan2, w2 = detection_tail_plan()
+    t = [st for st in plan2["statements"] if st.get("fn") == "transpose"][0]["out"][0]
+    plan2["statements"].append({"op": "call", "out": ["extra"], "fn": "sigmoid", "args": [{"ref": t}], "bufs": 1})
+    plan2["outputs"].append("extra")
+    from lele_amd.compiler.lower import allocate
+    plan2["slots"] = allocate(plan2["statements"], plan2["outputs"])
+    _w, r2 = run_plan(plan2, w2, ctx, EmuK(), {"x": EmuK._put(x, ctx.buf(), None)}, record=True)
+    assert fold_channel_views(plan2, r2.shapes)["folded"]["transposed_splits_folded"] == 0
 
 
 # --------------------------------------------------------------------------------------------- GPU
@@ -425,6 +483,30 @@ def test_pitched_kernels_vs_oracle(ctx):
         K.sigmoid(src.channels(0, 4), ctx=ctx)
     with pytest.raises(_lib.LeleError):
         K.conv2d(src.channels(0, 8), np.zeros((8, 1, 3, 3), np.float32), None, [1, 1], 8, [1] * 4, [1, 1], ctx=ctx)
+
+
+@pytest.mark.gpu
+def test_transposing_copy_and_the_detection_tail(ctx):
+    from lele_amd import kernels as K
+    rng = np.random.default_rng(12)
+    wide = rng.standard_normal((3, 116, 7, 9)).astype(np.float32)
+    src = TensorView(ctx.buf().upload(wide))
+    for c0, c1 in ((0, 4), (4, 84), (84, 116), (0, 116)):
+        want = np.ascontiguousarray(wide[:, c0:c1].reshape(3, c1 - c0, 63).transpose(0, 2, 1))
+        assert np.array_equal(K.transpose_cp(src.channels(c0, c1), ctx=ctx).numpy(), want)
+        big = ctx.buf()
+        big.upload(np.full((3, 100, c1 - c0), 2.5, np.float32))
+        got = K.transpose_cp(src.channels(c0, c1), out=big, out_window=(20 * (c1 - c0), 100 * (c1 - c0)), ctx=ctx)
+        whole = big.to_numpy((3, 100, c1 - c0))
+        assert np.array_equal(got.numpy(), want) and np.array_equal(whole[:, 20:83], want) and np.all(whole[:, :20] == 2.5) and np.all(whole[:, 83:] == 2.5)
+    plan, weights = detection_tail_plan()
+    x = rng.standard_normal((2, 8, 8, 12)).astype(np.float32)
+    xb = ctx.buf().upload(x)
+    want, r0 = run_plan(plan, weights, ctx, None, {"x": TensorView(xb)}, record=True)
+    folded = fold_channel_views(plan, r0.shapes)
+    assert folded["folded"]["transposed_splits_folded"] == 1
+    got = [o.numpy().copy() for o in Runner(folded, weights, ctx).run({"x": TensorView(xb)})]
+    assert all(np.array_equal(a, b) for a, b in zip(want, got))
 
 
 @pytest.mark.gpu
