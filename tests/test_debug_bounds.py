@@ -14,9 +14,9 @@ DBG = os.path.join(ROOT, "lele_amd", "liblele_hip_dbg.so")
 
 
 def _dbg_lib():
-    if not os.path.exists(DBG):
-        env = dict(os.environ, LELE_HIP_DEBUG_BOUNDS="1")
-        subprocess.check_call([sys.executable, "-m", "lele_amd.build"], cwd=ROOT, env=env, stdout=subprocess.DEVNULL)
+    # the build is incremental (nothing happens when the library is newer than every source): never test a stale one
+    env = dict(os.environ, LELE_HIP_DEBUG_BOUNDS="1")
+    subprocess.check_call([sys.executable, "-m", "lele_amd.build"], cwd=ROOT, env=env, stdout=subprocess.DEVNULL)
     return DBG
 
 
