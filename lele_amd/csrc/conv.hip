@@ -1236,10 +1236,13 @@ inline int conv_env(const char* name, int dflt) {
     const char* v = lab_env(name);  // the developer's build only (common.h): the product library has the defaults compiled in
     return v && *v ? atoi(v) : dflt;
 }
-// (measured on the Yolo-shaped network at batch 64, whole forward: <= 64 channels / planes >= 6400 / >= 48 input channels 10.12 ms;
-// <= 128 / >= 1600 / >= 32: 9.93; <= 256 / >= 1600: 9.95; <= 256 / >= 400: 9.97)
-inline int w1_max_oc() { static const int v = conv_env("LELE_HIP_CONV_W1_MAXOC", 128); return v; }
-inline int w1_min_plane() { static const int v = conv_env("LELE_HIP_CONV_W1_MINPLANE", 1600); return v; }
+// (measured on the Yolo-shaped network at batch 64, whole forward.  One workgroup per tile, round 4's first half: <= 64 channels /
+// planes >= 6400 / >= 48 input channels 10.12 ms; <= 128 / >= 1600 / >= 32: 9.93; <= 256 / >= 1600: 9.95; <= 256 / >= 400: 9.97 -- every
+// further block of output channels fetched and split the window again.  Persistent workgroups, where the blocks of an item take turns
+// on a window that is in L2: <= 128 / >= 1600 8.69; <= 256 / >= 1600 8.66; <= 128 / >= 400 8.58; <= 256 / >= 400 **8.25-8.38**;
+// <= 512 / >= 400 8.28; <= 256 / >= 100 8.27; >= 16 input channels 8.27)
+inline int w1_max_oc() { static const int v = conv_env("LELE_HIP_CONV_W1_MAXOC", 256); return v; }
+inline int w1_min_plane() { static const int v = conv_env("LELE_HIP_CONV_W1_MINPLANE", 400); return v; }
 inline int w1_min_c() { static const int v = conv_env("LELE_HIP_CONV_W1_MINC", 32); return v; }
 
 // out += res, image by image: the residual of lele_hip_conv2d_res behind the two routes that have their own epilogue (depthwise,
@@ -1338,9 +1341,7 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
                                dim3(256), 0, ctx->stream, out, g.res, (unsigned)((int64_t)g.oc * g.plane), g.obs, g.rbs);
     } else if (g.group == 1 &&
                ((g.kh == 3 && g.kw == 3) ||
-                // 1 x 1: only where it measured faster than the tiled GEMM on the Yolo-shaped network at batch 64 -- one block of output
-                // channels (every further block fetches and splits the input again: 64 -> 80 at 80 x 80 179 against 153 us), large
-                // planes, >= 48 input channels (48 -> 64 at 160 x 160: 316 against 406 us, 256 -> 64 at 80 x 80: 208 against 277)
+                // 1 x 1: where it measured faster than the tiled GEMM on the Yolo-shaped network at batch 64 (w1_max_oc() and friends above)
                 (g.kh == 1 && g.kw == 1 && g.pt == 0 && g.pl == 0 && g.oh == g.ih && g.ow == g.iw && g.oc <= w1_max_oc() && g.plane >= w1_min_plane() &&
                  g.c >= w1_min_c())) &&
                g.dh == 1 && g.dw == 1 && g.sh == 1 && g.sw == 1 && g.c % 16 == 0 && g.oc > 16 && g.ow >= 16 && g.n <= 65535 &&
