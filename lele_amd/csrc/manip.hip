@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void max_pool2d_kernel(const float* __restrict
 // equal values stays: conv2d.rs:1051-1254), and the results leave as one contiguous run.  The one-output-per-thread kernel above
 // reads every input 25 times through the vector cache with a 4-byte lane stride: 0.1 of the HBM rate on [64, 128, 20, 20].
 // grid (ceil(channels / PB), images); dynamic LDS = PB * (plane_in padded to 4 + plane_out padded to 4) floats.
-__global__ __launch_bounds__(256) void max_pool2d_lds_kernel(const float* __restrict__ x, float* __restrict__ out, PoolDesc d, int pb) {
+__global__ __launch_bounds__(256) void max_pool2d_lds_kernel(const float* __restrict__ x, float* __restrict__ out, PoolDesc d, int pb, int separable) {
     extern __shared__ __attribute__((aligned(16))) float mp_lds[];
     const unsigned plane_in = (unsigned)(d.in_h * d.in_w), plane_out = (unsigned)(d.out_h * d.out_w);
     const unsigned c0 = blockIdx.x * (unsigned)pb, np = (unsigned)d.channels - c0 < (unsigned)pb ? (unsigned)d.channels - c0 : (unsigned)pb;
@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void max_pool2d_lds_kernel(const float* __rest
     float* dst = out + (long long)blockIdx.y * d.obs + (long long)c0 * plane_out;
     float* lin = mp_lds;
     float* lout = mp_lds + (((unsigned)pb * plane_in + 3u) & ~3u);
+    float* lrow = separable ? lout + (unsigned)pb * plane_out : nullptr;  // [planes][in_h][out_w]: the row maxima
     {
         const unsigned count = np * plane_in;
         if ((((uintptr_t)src) & 15) == 0) {
@@ -294,6 +295,44 @@ __global__ __launch_bounds__(256) void max_pool2d_lds_kernel(const float* __rest
         }
     }
     __syncthreads();
+    if (lrow) {
+        // SEPARABLE: the maximum of each input row's window first, then the maximum over the window's rows.  The value the (kh, kw)
+        // scan keeps is the first element, in row-major order, that nothing later exceeds: the first row holding a maximal element,
+        // and the first such element in it -- which is what a first-wins row pass followed by a first-wins column pass selects (a
+        // NaN never wins either pass; only +0 / -0 can tell).  kh + kw LDS reads per output instead of kh x kw.
+        const unsigned rows_w = (unsigned)d.in_h * (unsigned)d.out_w;
+        for (unsigned it = threadIdx.x; it < np * rows_w; it += 256u) {
+            const unsigned p = it / rows_w, r = it - p * rows_w;
+            const int y = (int)(r / (unsigned)d.out_w), ow = (int)(r - (unsigned)y * (unsigned)d.out_w);
+            const float* xr = lin + p * plane_in + y * d.in_w;
+            const int iw0 = ow * d.sw - d.pl;
+            float m = -INFINITY;
+#pragma unroll 5
+            for (int b = 0; b < d.kw; ++b) {
+                const int iw = iw0 + b * d.dw;
+                const bool in = iw >= 0 && iw < d.in_w;
+                const float v = xr[in ? iw : 0];
+                m = (in && v > m) ? v : m;
+            }
+            lrow[it] = m;
+        }
+        __syncthreads();
+        for (unsigned it = threadIdx.x; it < np * plane_out; it += 256u) {
+            const unsigned p = it / plane_out, r = it - p * plane_out;
+            const int oh = (int)(r / (unsigned)d.out_w), ow = (int)(r - (unsigned)oh * (unsigned)d.out_w);
+            const float* xc = lrow + p * rows_w + ow;
+            const int ih0 = oh * d.sh - d.pt;
+            float m = -INFINITY;
+#pragma unroll 5
+            for (int a = 0; a < d.kh; ++a) {
+                const int ih = ih0 + a * d.dh;
+                const bool in = ih >= 0 && ih < d.in_h;
+                const float v = xc[(in ? ih : 0) * d.out_w];
+                m = (in && v > m) ? v : m;
+            }
+            lout[it] = m;
+        }
+    } else
     for (unsigned it = threadIdx.x; it < np * plane_out; it += 256u) {
         const unsigned p = it / plane_out, r = it - p * plane_out;
         const int oh = (int)(r / (unsigned)d.out_w), ow = (int)(r - (unsigned)oh * (unsigned)d.out_w);
@@ -1100,16 +1139,18 @@ static int max_pool2d_entry(LeleCtx* ctx, const LeleTensor* x, const int64_t* ke
     if (total) {
         const int64_t in_total = planes * plane_in;
         // whole planes in LDS when (input + output plane) fit 48 KB: as many planes per workgroup as keep >= 4 workgroups per CU
-        const int64_t per_plane = ((plane_in + 3) & ~int64_t(3)) + ((plane_out + 3) & ~int64_t(3));
+        // windows of more than kh + kw + 2 cells go row-wise, then column-wise (kh + kw reads per output): + in_h x out_w floats a plane
+        const bool separable = (int64_t)d.kh * d.kw > (int64_t)d.kh + d.kw + 2;
+        const int64_t per_plane = ((plane_in + 3) & ~int64_t(3)) + ((plane_out + 3) & ~int64_t(3)) + (separable ? (int64_t)d.in_h * d.out_w : 0);
         int64_t ppb = (12 * 1024) / std::max<int64_t>(per_plane, 1);
         ppb = std::min<int64_t>(ppb, d.channels);
         while (ppb > 1 && x->shape[0] * ((d.channels + ppb - 1) / ppb) < 4 * (int64_t)ctx->num_cus) ppb = (ppb + 1) / 2;
         if (ppb >= 1 && x->shape[0] <= 65535 && in_img < (int64_t(1) << 31) && out_img < (int64_t(1) << 31) && plane_in % 4 == 0 &&
             plane_out % 4 == 0) {
             // plane sizes that are multiples of four floats keep every plane 16-byte aligned inside the LDS runs
-            const size_t lds = (size_t)(((ppb * plane_in + 3) & ~int64_t(3)) + ppb * plane_out) * 4;
+            const size_t lds = (size_t)(((ppb * plane_in + 3) & ~int64_t(3)) + ppb * plane_out + (separable ? ppb * d.in_h * d.out_w : 0)) * 4;
             hipLaunchKernelGGL(max_pool2d_lds_kernel, dim3((unsigned)((d.channels + ppb - 1) / ppb), (unsigned)x->shape[0]), dim3(256), lds,
-                               ctx->stream, (const float*)dx, dst, d, (int)ppb);
+                               ctx->stream, (const float*)dx, dst, d, (int)ppb, (int)separable);
         } else if (total < (int64_t(1) << 31) && in_total < (int64_t(1) << 31)) {
             hipLaunchKernelGGL(max_pool2d_kernel<int32_t>, dim3(grid_for(total)), dim3(256), 0, ctx->stream, (const float*)dx, dst, planes, d);
         } else {

@@ -31,7 +31,15 @@ done
 # 4b. configs[4]: the Yolo26n-seg-shaped network at batch 64 as one compiled graph (per-image check against the batch-1 plan inside)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/yolo" -o n64 -- \
     python $R/tools/yolo_graph.py --batch 64 --check 4 --runs 5 --out "$OUT/yolo_n64_under_rocprof.json" > "$OUT/yolo_prof.log" 2>&1
-timeout 300 python $R/tools/yolo_graph.py --batch 64 --check 8 --out "$OUT/yolo_n64.json" > "$OUT/yolo.log" 2>&1
+timeout 300 python $R/tools/yolo_graph.py --batch 64 --check 8 --table "$OUT/yolo_table.json" --out "$OUT/yolo_n64.json" > "$OUT/yolo.log" 2>&1
+# 4c. the reference's own generated Yolo26n-seg graph, re-batched to 64 images as one graph (where the lifted plan exists)
+[ -f $R/_lifted/yolo26seg_plan.json ] && timeout 300 python $R/tools/yolo_lifted_batch.py --batch 64 --table "$OUT/yolo_lifted_table.json" --out "$OUT/yolo_lifted_n64.json" > "$OUT/yolo_lifted.log" 2>&1
+# 4d. ConvInteger: the i8 route against lele's f32 formulation (lab build), and the exhaustive check of the short reciprocal
+if [ -f $R/lele_amd/liblele_hip_lab.so ]; then
+  LELE_HIP_LAB=1 timeout 200 python $R/tools/conv_integer_bench.py > "$OUT/conv_integer_i8.json" 2> "$OUT/conv_integer.log"
+  LELE_HIP_LAB=1 LELE_HIP_CONV_INTEGER_F32=1 timeout 200 python $R/tools/conv_integer_bench.py > "$OUT/conv_integer_f32.json" 2>> "$OUT/conv_integer.log"
+fi
+[ -x $R/tools/recip_check ] && timeout 120 $R/tools/recip_check > "$OUT/recip_check.json" 2> "$OUT/recip_check.err"
 # 5. operator micro-benchmarks
 timeout 280 python $R/tools/microbench.py --out "$OUT/microbench.json" > "$OUT/microbench.log" 2>&1
 timeout 200 python $R/tools/qlinear_bench.py --out "$OUT/qlinear.json" > "$OUT/qlinear.log" 2>&1

@@ -59,7 +59,9 @@ def main():
     p = os.path.join(src, "yolo", "n64_kernel_stats.csv")
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, "%s_yolo_shaped_n64_kernel_stats.csv" % tag))
-    for a, b in (("yolo_n64.json", "_yolo_shaped_n64.json"), ("microbench.json", "_microbench.json"), ("qlinear.json", "_qlinear_variants.json"), ("valu_rate.json", "_valu_rate.json"),
+    for a, b in (("yolo_n64.json", "_yolo_shaped_n64.json"), ("yolo_table.json", "_yolo_shaped_n64_table.json"), ("yolo_lifted_n64.json", "_yolo26seg_lifted_n64.json"),
+                 ("yolo_lifted_table.json", "_yolo26seg_lifted_n64_table.json"), ("conv_integer_i8.json", "_conv_integer_i8.json"),
+                 ("conv_integer_f32.json", "_conv_integer_f32.json"), ("recip_check.json", "_recip_check.json"), ("microbench.json", "_microbench.json"), ("qlinear.json", "_qlinear_variants.json"), ("valu_rate.json", "_valu_rate.json"),
                  ("attention_bench.json", "_attention_bench.json"), ("attention_stamps.txt", "_attention_stamps.txt"),
                  ("rs_stamps.txt", "_rs_stamps.txt"), ("rs_bench.txt", "_rs_bench.txt"), ("l2bw.txt", "_l2bw.txt")):
         if os.path.exists(os.path.join(src, a)) and os.path.getsize(os.path.join(src, a)) > 2:
