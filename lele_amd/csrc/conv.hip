@@ -1310,6 +1310,10 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
         const bool dw_direct = (g.ow & 3) == 0 && (g.plane & 3) == 0 && (((uintptr_t)out) & 15) == 0;
         const int64_t ihw = (int64_t)g.ih * g.iw, plane_floats = ihw + (dw_direct ? 0 : g.plane) + 8, planes = (int64_t)g.n * g.oc;
         int64_t pb = (16 * 1024 - 8) / plane_floats;
+        // ... but no more planes than 16 KB worth (one plane if it is larger): a workgroup copies its planes in and only then computes, so
+        // what overlaps one workgroup's copy with another's arithmetic is the number of workgroups a CU holds (80 x 80 planes over 64
+        // images: two planes a workgroup 119 us, one 84; 40 x 40: five 44 us, two 37.5)
+        if (pb >= 1) pb = std::max<int64_t>(1, std::min<int64_t>(pb, ((int64_t)conv_env("LELE_HIP_DW_LDS_KB", 16) * 256 - 8) / plane_floats));
         while (pb > 1 && (planes + pb - 1) / pb < 4 * (int64_t)ctx->num_cus) pb = (pb + 1) / 2;
         const bool lds_ok = row_ok && pb >= 1 && (g.kw == 3 || g.kw == 5 || g.kw == 7 || g.kw == 11) && !lab_env("LELE_HIP_DW_NO_LDS");
         if (lds_ok) {

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--compare", nargs=2, default=None)
     ap.add_argument("--act", default="silu", choices=["silu", "none", "relu"])
+    ap.add_argument("--dw", action="store_true", help="the depthwise 3 x 3 layers instead (group = channels)")
     ap.add_argument("--only", default="", help="substring of the geometry label, e.g. 'k1 ' or '@160'")
     a = ap.parse_args()
     if a.compare:
@@ -50,17 +51,19 @@ def main():
     ctx = lele_amd._lib.Ctx(0)
     rng = np.random.default_rng(7)
     rows = []
-    for c, oc, k, s, oh in GEOMS:
+    geoms = [(80, 80, 3, 1, 80), (64, 64, 3, 1, 80), (128, 128, 3, 1, 40), (256, 256, 3, 1, 20), (32, 32, 3, 1, 160)] if a.dw else GEOMS
+    for c, oc, k, s, oh in geoms:
         if a.only and a.only not in "%d->%d k%d s%d @%d" % (c, oc, k, s, oh):
             continue
         ih = oh * s
         xt = ctx.buf().upload((rng.standard_normal((a.batch, c, ih, ih))).astype(np.float32))
         from lele_amd._lib import Weight
-        w = Weight((rng.standard_normal((oc, c, k, k)) * 0.1).astype(np.float32))
+        grp = c if a.dw else 1
+        w = Weight((rng.standard_normal((oc, c // grp, k, k)) * 0.1).astype(np.float32))
         b = Weight(rng.standard_normal(oc).astype(np.float32))
         out = ctx.buf()
         conv = {"silu": K.conv2d_silu, "none": K.conv2d, "relu": lambda *p, **kw: K.conv2d_fused(*p, relu=True, **kw)}[a.act]
-        fn = lambda: conv(xt, w, b, [1, 1], 1, [k // 2] * 4, [s, s], out=out, ctx=ctx)
+        fn = lambda: conv(xt, w, b, [1, 1], grp, [k // 2] * 4, [s, s], out=out, ctx=ctx)
         for _ in range(3):
             fn()
         ctx.sync()
@@ -70,7 +73,7 @@ def main():
             for _ in range(a.iters):
                 fn()
             best = min(best, ctx.timer_stop() / a.iters)
-        flop = 2.0 * a.batch * oc * c * k * k * oh * oh
+        flop = 2.0 * a.batch * oc * (c // grp) * k * k * oh * oh
         rows.append({"geom": "%d->%d k%d s%d @%d" % (c, oc, k, s, oh), "us": round(best * 1e3, 1), "tflops": round(flop / best / 1e9, 1)})
         print(rows[-1], flush=True)
     rec = {"batch": a.batch, "env": {k: v for k, v in os.environ.items() if k.startswith("LELE_HIP_")}, "rows": rows,
