@@ -631,7 +631,9 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const float* __rest
         if (o < g.oc) {
             float v = acc[o];
             if (bias) v = v + bias[o];
-            o0[(int64_t)o * g.plane] = apply_act(v, act, body);
+            v = apply_act(v, act, body);
+            if (g.res) v = v + g.res[(int64_t)img * g.rbs + (int64_t)o * g.plane + pos];  // lele_hip_conv2d_res
+            o0[(int64_t)o * g.plane] = v;
         }
 }
 __global__ void conv3x3_wperm_kernel(const float* __restrict__ w, float* __restrict__ wq, int oc, int ic, int ocb) {
@@ -1245,8 +1247,8 @@ inline int w1_max_oc() { static const int v = conv_env("LELE_HIP_CONV_W1_MAXOC",
 inline int w1_min_plane() { static const int v = conv_env("LELE_HIP_CONV_W1_MINPLANE", 400); return v; }
 inline int w1_min_c() { static const int v = conv_env("LELE_HIP_CONV_W1_MINC", 32); return v; }
 
-// out += res, image by image: the residual of lele_hip_conv2d_res behind the two routes that have their own epilogue (depthwise,
-// the direct small-channel kernel); everything else adds it where the finished values are stored
+// out += res, image by image: the residual of lele_hip_conv2d_res behind the depthwise kernels (which have their own epilogues);
+// everything else adds it where the finished values are stored
 __global__ __launch_bounds__(256) void conv_residual_kernel(float* __restrict__ out, const float* __restrict__ res, unsigned per_image,
                                                             long long obs, long long rbs) {
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < per_image; i += gridDim.x * 256u)
@@ -1500,9 +1502,6 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             else LELE_C3(16, 2);
         }
 #undef LELE_C3
-        if (g.res)
-            hipLaunchKernelGGL(conv_residual_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)g.oc * g.plane + 255) / 256, 1024), (unsigned)g.n),
-                               dim3(256), 0, ctx->stream, out, g.res, (unsigned)((int64_t)g.oc * g.plane), g.obs, g.rbs);
     } else {
         ConvWLoad al{dw, g, (int)((((uintptr_t)dw & 15) == 0) && g.K % 4 == 0)};
         ConvEpi epi{out, db, g, act};

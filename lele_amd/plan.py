@@ -355,6 +355,40 @@ def fold_transposed_splits(sts, shapes, outputs, multi):
             continue
         u = sts[it]["args"][0]["ref"]
         iu = call(u, "concat")
+        us = shapes.get(u)
+        if us is not None and len(us) == 3 and readers.get(u) == [it] and u not in multi and \
+                (iu is None or _lit_int(sts[iu]["args"][1]) in (1, -2)):
+            # form B (lele's own Yolo26n-seg tail): U [N, C, P] of any origin -> Transpose -> Split: head k is the transposing copy of
+            # channels [c0_k, c1_k) of U -- or, when U is a Concat along C whose operands are exactly the heads, of operand k itself
+            # (the Concat then has no reader left and goes too)
+            ops = _concat_operands(sts[iu]) if iu is not None else None
+            direct = ops is not None and len(ops) == len(sizes) and all(
+                shapes.get(o) is not None and len(shapes[o]) == 3 and int(shapes[o][1]) == ck and o not in multi for o, ck in zip(ops, sizes))
+            def f32_of(name, depth=0):   # produced by an f32 operator, or a re-arrangement of such values
+                pi = prod.get(name)
+                if pi is None or name in multi or depth > 16 or sts[pi]["op"] != "call":
+                    return False
+                fn = sts[pi].get("fn")
+                if fn in _F32_FNS:
+                    return True
+                if fn in ("reshape", "flatten", "unsqueeze", "squeeze", "identity", "transpose", "concat"):
+                    srcs = _concat_operands(sts[pi]) if fn == "concat" else [sts[pi]["args"][0].get("ref")]
+                    return bool(srcs) and all(o is not None and f32_of(o, depth + 1) for o in srcs)
+                return False
+            if all(f32_of(o) for o in ops) if direct else f32_of(u):
+                new, c0 = [], 0
+                for k, (o, ck) in enumerate(zip(st["out"], sizes)):
+                    if direct:
+                        new.append({"op": "call", "out": [o], "fn": "transpose_cp", "args": [{"ref": ops[k]}], "bufs": 1})
+                    else:
+                        src = "%s__c" % o
+                        new.append({"op": "chview", "out": [src], "src": u, "c0": c0, "c1": c0 + ck})
+                        new.append({"op": "call", "out": [o], "fn": "transpose_cp", "args": [{"ref": src}], "bufs": 1})
+                    c0 += ck
+                put[i] = new
+                drop |= {it} | ({iu} if direct else set())
+                count += 1
+                continue
         if iu is None or readers.get(u) != [it] or _lit_int(sts[iu]["args"][1]) not in (2, -1):
             continue
         levels, ok = [], True

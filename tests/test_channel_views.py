@@ -354,6 +354,35 @@ def test_detection_tail_becomes_transposing_copies():
     assert fold_channel_views(plan2, r2.shapes)["folded"]["transposed_splits_folded"] == 0
 
 
+def rank3_tail_plan(sizes, seed=6):
+    """lele's own Yolo26n-seg tail: rank-3 heads [N, c, P] -> Concat along C -> Transpose(0, 2, 1) -> Split along the last axis"""
+    b = PlanBuilder(seed)
+    heads = []
+    for c, act in ((4, None), (3, "sigmoid"), (3, None)):
+        v = b.call("reshape", [{"ref": b.conv("x", 8, c, 1, silu=False)}, b.ints([2, c, 96])], "flat")
+        b.sts[-1]["bufs"] = 0
+        heads.append(b.call(act, [{"ref": v}], "act") if act else v)
+    u = b.call("concat", [{"list": [{"ref": h} for h in heads]}, {"int": 1}], "pred")
+    t = b.call("transpose", [{"ref": u}, b.ints([0, 2, 1])], "predt")
+    outs = b.call("split", [{"ref": t}, {"int": 2}, b.ints(sizes)], "heads", len(sizes))
+    return b.finish(["x"], list(outs))
+
+
+def test_rank3_tail_transpose_then_split():
+    x = np.random.default_rng(9).standard_normal((2, 8, 8, 12)).astype(np.float32)
+    for sizes, calls, concats in (([4, 3, 3], 3, 0), ([5, 5], 2, 1)):   # heads = the Concat's operands / cut elsewhere
+        plan, weights = rank3_tail_plan(sizes)
+        ctx = EmuCtx()
+        want, r0 = run_plan(plan, weights, ctx, EmuK(), {"x": EmuK._put(x, ctx.buf(), None)}, record=True)
+        folded = fold_channel_views(plan, r0.shapes)
+        fns = [st.get("fn") for st in folded["statements"] if st["op"] == "call"]
+        assert folded["folded"]["transposed_splits_folded"] == 1 and fns.count("transpose_cp") == calls and fns.count("concat") == concats \
+            and "transpose" not in fns and "split" not in fns, (sizes, fns)
+        k = EmuK()
+        got, _ = run_plan(folded, weights, ctx, k, {"x": EmuK._put(x, ctx.buf(), None)})
+        assert k.tcp_calls == calls and all(np.array_equal(p, q) for p, q in zip(want, got))
+
+
 # --------------------------------------------------------------------------------------------- GPU
 RES_CASES = [
     # n, c, h, w, oc, k, stride, group, act: every route of run_conv2d once
@@ -364,7 +393,7 @@ RES_CASES = [
     (8, 96, 12, 12, 200, 3, 1, 1, 0),       # tiled GEMM, 16-byte stores
     (4, 24, 9, 7, 40, 3, 1, 1, 2),          # tiled / small GEMM, scalar stores
     (64, 130, 20, 20, 200, 1, 1, 1, 2),     # pointwise tiled GEMM
-    (48, 16, 48, 48, 8, 3, 1, 1, 2),        # direct small-channel kernel (+ the separate add)
+    (48, 16, 48, 48, 8, 3, 1, 1, 2),        # direct small-channel kernel
     (2, 128, 17, 17, 128, 3, 1, 128, 2),    # depthwise (+ the separate add)
     (1, 16, 33, 29, 24, 3, 1, 2, 1),        # grouped
 ]
