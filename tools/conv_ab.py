@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 GEOMS = [
     (64, 64, 3, 1, 160), (64, 64, 3, 1, 80), (64, 32, 3, 1, 80), (32, 16, 3, 1, 80), (32, 32, 3, 1, 80), (16, 32, 3, 1, 80),
     (128, 64, 3, 1, 40), (64, 64, 3, 1, 40), (128, 32, 3, 1, 40), (64, 32, 3, 1, 40), (32, 64, 3, 1, 40), (32, 32, 3, 1, 40),
-    (256, 64, 3, 1, 20), (256, 32, 3, 1, 20), (64, 64, 3, 1, 20), (128, 128, 3, 1, 20),
+    (256, 64, 3, 1, 20), (256, 32, 3, 1, 20), (64, 64, 3, 1, 20), (128, 128, 3, 1, 20), (32, 16, 3, 1, 80), (64, 16, 3, 1, 40), (32, 8, 3, 1, 80),
     (16, 32, 3, 2, 160), (64, 64, 3, 2, 80), (128, 128, 3, 2, 40), (128, 256, 3, 2, 20), (128, 128, 3, 2, 20), (64, 64, 3, 2, 40),
     (96, 128, 1, 1, 80), (48, 64, 1, 1, 160), (64, 32, 1, 1, 160), (32, 32, 1, 1, 160), (256, 64, 1, 1, 80), (80, 80, 1, 1, 80),
     (64, 80, 1, 1, 80), (96, 64, 1, 1, 80), (64, 64, 1, 1, 80), (384, 128, 1, 1, 40), (192, 128, 1, 1, 40), (128, 80, 1, 1, 40),
