@@ -933,14 +933,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     auto chunk = [&](int cc, auto pc) {
         constexpr int P = decltype(pc)::value;
         const char* stage = c3m_lds + (q & 1) * W::STAGE;
+#define LELE_CBF(v) __builtin_bit_cast(cbf16x8, v)
+        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};  // mm, hl, lh, hm, mh, hh: smallest terms first
+        if constexpr (OCT == 32 && KS == 3) {
+            // 32-channel blocks use 88 registers: room for a second set of B fragments, read a tap ahead of their products
+            cu32x4 bfr[2][2][3];
+            auto loadb = [&](cu32x4 (&bf)[2][3], int tap) {
+                const int a = tap / KS, b = tap - KS * a;
+                const char* tapw = stage + (a * pwt + b) * C3M_PITCH;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const cu32x4*>(tapw + sb[j] + 32 * p);
+            };
+            loadb(bfr[0], 0);
+#pragma unroll
+            for (int tap = 0; tap < W::TAPS; ++tap) {
+                cu32x4 (&af)[3] = ar[(P + tap) & 1];
+                wload(ar[(P + tap + 1) & 1], cc * W::TAPS + tap + 1);
+                if (tap + 1 < W::TAPS) loadb(bfr[(tap + 1) & 1], tap + 1);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_CBF(af[PA[t]]), LELE_CBF(bfr[tap & 1][j][PB[t]]), acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
 #pragma unroll
         for (int tap = 0; tap < W::TAPS; ++tap) {
             const int a = tap / KS, b = tap - KS * a;
             const char* tapw = stage + (a * pwt + b) * C3M_PITCH;
             cu32x4 (&af)[3] = ar[(P + tap) & 1];
             wload(ar[(P + tap + 1) & 1], cc * W::TAPS + tap + 1);
-#define LELE_CBF(v) __builtin_bit_cast(cbf16x8, v)
-            constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};  // mm, hl, lh, hm, mh, hh: smallest terms first
 #pragma unroll
             for (int jp = 0; jp < NJ / 2; ++jp) {
                 cu32x4 bf[2][3];
@@ -956,9 +982,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     for (int j = 0; j < 2; ++j)
                         acc[2 * jp + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_CBF(af[PA[t]]), LELE_CBF(bf[j][PB[t]]), acc[2 * jp + j], 0, 0, 0);
             }
-#undef LELE_CBF
             __builtin_amdgcn_sched_barrier(0);
         }
+#undef LELE_CBF
     };
     int item = first, ocb = 0;
     wload(ar[0], 0);
