@@ -274,6 +274,18 @@ inline TensorView conv2d_silu(const TensorView& x, const TensorView& w, const Te
                               const std::vector<int64_t>& strides, Buffer& out) {
     return conv2d_activation(x, w, bias, dilations, group, pads, strides, LELE_ACT_SILU, out);
 }
+// act(conv2d(x) + bias) + res in one call: a bottleneck's conv2d_silu followed by add (lele_hip_conv2d_res; the same bits).  Dense
+// operands here; channel views (LelePitch) are the batch graph runner's business (lele_amd/plan.py).
+inline TensorView conv2d_res(const TensorView& x, const TensorView& w, const TensorView* bias, const TensorView& res,
+                             const std::vector<int64_t>& dilations, int64_t group, const std::vector<int64_t>& pads,
+                             const std::vector<int64_t>& strides, int act, Buffer& out) {
+    Shape sh;
+    LeleTensor tx = x.c(), tw = w.c(), tr = res.c();
+    Opt ob(bias);
+    check(lele_hip_conv2d_res(ctx(), &tx, &tw, ob.p, &tr, dilations.data(), dilations.size(), group, pads.data(), pads.size(), strides.data(),
+                              strides.size(), act, nullptr, out.raw(), sh.dims, &sh.rank));
+    LELE_RET(out, LELE_F32);
+}
 inline TensorView conv1d_fused(const TensorView& x, const TensorView& w, const TensorView* bias,
                                const std::vector<int64_t>& dilations, int64_t group, const std::vector<int64_t>& pads,
                                const std::vector<int64_t>& strides, bool relu, Buffer& out) {
