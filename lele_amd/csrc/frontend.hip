@@ -279,10 +279,12 @@ __device__ __forceinline__ void fe_main_body(const float* __restrict__ pcm, int6
             for (int q = 0; q < fe::kQ; ++q) win[q] = tb.window[p + 16 * q + off];
         }
 
-        // 1./2. scale and mean subtraction (pipeline.rs:90-137): fl(x*32768) is exact, one rounding on the sub
+        // 1./2. scale and mean subtraction (pipeline.rs:90-137): x * 32768 is exact (a power of two), so the product followed by the
+        // subtraction rounds once -- which is what ONE fused multiply-add does: the same bits in half the instructions
         float v[fe::kQ];
+        const float neg_mean = -mean;
 #pragma unroll
-        for (int q = 0; q < fe::kQ; ++q) v[q] = fe::fsub(fe::fmul(xr[q], 32768.0f), mean);
+        for (int q = 0; q < fe::kQ; ++q) v[q] = __builtin_fmaf(xr[q], 32768.0f, neg_mean);
         if (!LOWREG && pass + 1 < PASSES) issue_loads(pass + 1);
         // 3. pre-emphasis (pipeline.rs:140-142): y[n] = v[n] - 0.97*v[n-1] for n >= 1; v[n-1] lives in lane p-1
         //    (same q) or, for p == 0, in lane 15 at q-1.  4. window (pipeline.rs:145-166).
