@@ -702,7 +702,7 @@ def run_rank(args):
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: STFT+mel+LFR, 30 s synthetic 16 kHz mono, batch %d utterances per GPU per step; "
-                                   "configs[2]/[3] SenseVoice-shaped recogniser in `sensevoice`" % args.batch,
+                                   "configs[2]/[3] SenseVoice-shaped recogniser in `sensevoice`, configs[4] Yolo26n-seg-shaped network at batch 64 per GPU in `yolo`" % args.batch,
                        "samples_per_utterance": n, "frames": fe["nf"], "lfr_rows": fe["t_lfr"], "batch_per_gpu": args.batch,
                        "bytes_per_utterance": fe["bytes_per_utt"], "parallelism": "utterance-sharded x%d" % world},
             "rtf_frontend": round(wall / audio_s, 9),
