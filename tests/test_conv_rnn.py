@@ -367,12 +367,18 @@ def test_device_conv_transpose(ctx):
                                        ((1, 16, 20, 20), (16, 16, 3, 3), [1, 1, 1, 1], [1, 1], [1, 1]),
                                        ((1, 4, 5, 5), (4, 3, 1, 1), [], [2, 2], []),          # stride > kernel: bias-only phases
                                        ((2, 64, 12, 12), (64, 40, 2, 2), [], [2, 2], []),     # the YOLO neck upsampling shape class
-                                       ((1, 5, 6, 7), (5, 6, 3, 5), [0, 2, 1, 0], [2, 3], [3, 2])]:
+                                       ((1, 5, 6, 7), (5, 6, 3, 5), [0, 2, 1, 0], [2, 3], [3, 2]),
+                                       # kernel = stride = 2 over a batch (one GEMM with the scattering quad-store epilogue): ragged tiles, OC not a
+                                       # multiple of 16
+                                       ((80, 16, 40, 40), (16, 12, 2, 2), [], [2, 2], []),
+                                       ((40, 32, 36, 64), (32, 20, 2, 2), [], [2, 2], [])]:
         x = rng.standard_normal(xs).astype(np.float32)
         w = (rng.standard_normal(ws) * 0.2).astype(np.float32)
         b = rng.standard_normal(ws[1]).astype(np.float32)
         got = K.conv_transpose(x, w, b, dil, 1, pads, strides, ctx=ctx).numpy()
         _close(got, O.conv_transpose(x, w, b, dil, 1, pads, strides), RTOL, str((xs, ws)))
+        if xs[0] >= 40:   # ... and without a bias
+            _close(K.conv_transpose(x, w, None, dil, 1, pads, strides, ctx=ctx).numpy(), O.conv_transpose(x, w, None, dil, 1, pads, strides), RTOL, str((xs, ws)))
     with pytest.raises(lele_amd.LeleError, match="group > 1 not supported"):
         K.conv_transpose(np.zeros((1, 4, 3, 3), np.float32), np.zeros((4, 2, 2, 2), np.float32), None, [], 2, [], [], ctx=ctx)
 
