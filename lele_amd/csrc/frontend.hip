@@ -428,25 +428,26 @@ __global__ __launch_bounds__(256) void fe_main_kernel(const float* __restrict__ 
 // The same operations in the same order as pipeline.rs:84-187, spread over four simple kernels + the generic
 // radix-2 FFT of features_ops.hip; nothing is fused, it only has to be bit-exact.
 // ------------------------------------------------------------------------------------------------------
-__global__ void fe_generic_mean_kernel(const float* __restrict__ pcm, int64_t num_frames, int frame_len, int hop,
+// (rows = utterances x frames: row r is frame r % num_frames of utterance r / num_frames, utterances pcm_len samples apart)
+__global__ void fe_generic_mean_kernel(const float* __restrict__ pcm, int64_t rows, int64_t num_frames, int64_t pcm_len, int frame_len, int hop,
                                        float* __restrict__ mean) {
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= num_frames) return;
-    const float* src = pcm + f * hop;
+    if (f >= rows) return;
+    const float* src = pcm + (f / num_frames) * pcm_len + (f % num_frames) * hop;
     float sum = 0.0f;
     for (int j = 0; j < frame_len; ++j) sum = sum + src[j] * 32768.0f;  // raw_frame.iter().sum(), pipeline.rs:115
     mean[f] = sum / (float)frame_len;
 }
 __global__ void fe_generic_frame_kernel(const float* __restrict__ pcm, const float* __restrict__ mean,
-                                        const float* __restrict__ window, int64_t num_frames, int frame_len, int hop,
+                                        const float* __restrict__ window, int64_t rows, int64_t num_frames, int64_t pcm_len, int frame_len, int hop,
                                         int n_fft, float* __restrict__ frames) {
-    const int64_t total = num_frames * n_fft;
+    const int64_t total = rows * n_fft;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t f = i / n_fft;
         const int j = (int)(i - f * n_fft);
         float v = 0.0f;
         if (j < frame_len) {
-            const float* src = pcm + f * hop;
+            const float* src = pcm + (f / num_frames) * pcm_len + (f % num_frames) * hop;
             const float m = mean[f];
             const float cur = fe::fsub(fe::fmul(src[j], 32768.0f), m);
             float y = cur;
@@ -470,8 +471,10 @@ __global__ void fe_generic_mel_kernel(const float* __restrict__ power, int64_t n
     }
 }
 __global__ void fe_generic_lfr_kernel(const float* __restrict__ x, int64_t t, int64_t d, int64_t m, int64_t n,
-                                      int64_t t_lfr, float* __restrict__ out) {  // lfr.rs:18-54
+                                      int64_t t_lfr, float* __restrict__ out) {  // lfr.rs:18-54; grid.y = utterance
     const int64_t d_out = d * m, total = t_lfr * d_out, pad = (m - 1) / 2;
+    x += (int64_t)blockIdx.y * t * d;
+    out += (int64_t)blockIdx.y * total;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = idx / d_out, rem = idx - i * d_out, block = rem / d, k = rem - block * d;
         int64_t raw = i * n + block - pad;
@@ -765,27 +768,35 @@ static int fe_run(LeleFrontend* fe, const LeleTensor* pcm, int64_t batch, int64_
     const size_t out_elems = want_logmel ? (size_t)batch * nf * fe->cfg.n_mels : (size_t)batch * t_lfr * cols;
     LELE_TRY(out->reserve(out_elems * sizeof(float)));
     if (!fe->fast) {
-        // generic path, one utterance at a time (scratch: means [nf], frames [nf, n_fft], power [nf, bins], logmel [nf, mels])
+        // generic path: as many utterances per pass as fit 256 MiB of scratch (means, frames [rows, n_fft], power [rows, bins], logmel
+        // [rows, mels]; rows = utterances x frames) -- five launches a pass (looping over utterances on the host made the launches
+        // the cost: 256 x 30 s at 16 kHz / 20 ms frames 16.1 ms)
         const int64_t bins = fe->n_fft / 2 + 1, nm = fe->cfg.n_mels;
+        const int64_t per_utt = nf * (4 + fe->n_fft * 4 + bins * 4 + nm * 4);
+        const int64_t ub = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(batch, 65535), (int64_t(1) << 28) / std::max<int64_t>(per_utt, 1)));
         void *gm = nullptr, *gf = nullptr, *gp = nullptr, *gl = nullptr;
-        LELE_TRY(ctx->arena_alloc((size_t)nf * 4, &gm));
-        LELE_TRY(ctx->arena_alloc((size_t)nf * fe->n_fft * 4, &gf));
-        LELE_TRY(ctx->arena_alloc((size_t)nf * bins * 4, &gp));
-        if (!want_logmel) LELE_TRY(ctx->arena_alloc((size_t)nf * nm * 4, &gl));
-        auto blocks = [](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096))); };
-        for (int64_t u = 0; u < batch; ++u) {
+        LELE_TRY(ctx->arena_alloc((size_t)ub * nf * 4, &gm));
+        LELE_TRY(ctx->arena_alloc((size_t)ub * nf * fe->n_fft * 4, &gf));
+        LELE_TRY(ctx->arena_alloc((size_t)ub * nf * bins * 4, &gp));
+        if (!want_logmel) LELE_TRY(ctx->arena_alloc((size_t)ub * nf * nm * 4, &gl));
+        auto blocks = [](int64_t n) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 8192))); };
+        for (int64_t u = 0; u < batch; u += ub) {
+            const int64_t nu = std::min<int64_t>(ub, batch - u), rows = nu * nf;
             const float* up = (const float*)dpcm + u * pcm_len;
             float* lm = want_logmel ? (float*)out->data + u * nf * nm : (float*)gl;
-            hipLaunchKernelGGL(fe_generic_mean_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, ctx->stream, up, nf,
+            hipLaunchKernelGGL(fe_generic_mean_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, ctx->stream, up, rows, nf, pcm_len,
                                (int)fe->frame_len, (int)fe->hop_len, (float*)gm);
-            hipLaunchKernelGGL(fe_generic_frame_kernel, blocks(nf * fe->n_fft), dim3(256), 0, ctx->stream, up, (const float*)gm,
-                               fe->g_window, nf, (int)fe->frame_len, (int)fe->hop_len, (int)fe->n_fft, (float*)gf);
-            LELE_TRY(fft_rows_power(ctx, (const float*)gf, nf, fe->n_fft, (float*)gp));
-            hipLaunchKernelGGL(fe_generic_mel_kernel, blocks(nf * nm), dim3(256), 0, ctx->stream, (const float*)gp, nf, (int)bins,
+            hipLaunchKernelGGL(fe_generic_frame_kernel, blocks(rows * fe->n_fft), dim3(256), 0, ctx->stream, up, (const float*)gm,
+                               fe->g_window, rows, nf, pcm_len, (int)fe->frame_len, (int)fe->hop_len, (int)fe->n_fft, (float*)gf);
+            LELE_TRY(fft_rows_power(ctx, (const float*)gf, rows, fe->n_fft, (float*)gp));
+            hipLaunchKernelGGL(fe_generic_mel_kernel, blocks(rows * nm), dim3(256), 0, ctx->stream, (const float*)gp, rows, (int)bins,
                                (int)nm, fe->g_mstart, fe->g_moff, fe->g_mw, lm);
-            if (!want_logmel)
-                hipLaunchKernelGGL(fe_generic_lfr_kernel, blocks(t_lfr * cols), dim3(256), 0, ctx->stream, (const float*)lm, nf, nm,
+            if (!want_logmel) {
+                dim3 lg = blocks(t_lfr * cols);
+                lg.y = (unsigned)nu;
+                hipLaunchKernelGGL(fe_generic_lfr_kernel, lg, dim3(256), 0, ctx->stream, (const float*)lm, nf, nm,
                                    fe->cfg.lfr_m, fe->cfg.lfr_n, t_lfr, (float*)out->data + u * t_lfr * cols);
+            }
         }
         LELE_HIP_CHECK(hipGetLastError());
         if (want_logmel) {

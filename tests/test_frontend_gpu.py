@@ -150,6 +150,20 @@ def test_other_feature_configs_take_the_generic_path(ctx, orc, sr, fl, fs, nm):
     assert f2.compute(x[:10]).shape == ()  # shorter than one frame -> TensorView::empty()
 
 
+def test_generic_path_batches_in_passes(ctx):
+    """the composed path takes as many utterances per pass as fit its scratch budget (256 MiB): 24 x 30 s at 20 ms frames is two passes;
+    every utterance equals its own single-utterance call bit for bit, whichever pass it fell into"""
+    from lele_amd.features import FeatureConfig, SenseVoiceFrontend
+    f2 = SenseVoiceFrontend(FeatureConfig(frame_length_ms=20.0, frame_shift_ms=8.0, n_mels=40), ctx=ctx)
+    rng = np.random.default_rng(3)
+    xs = (rng.standard_normal((24, 16000 * 30)) * 0.05).astype(np.float32)
+    gb = f2.compute_batch(xs).numpy()
+    lb = f2.logmel(xs).numpy()
+    for i in (0, 11, 20, 21, 23):
+        assert np.array_equal(gb[i], f2.compute(xs[i]).numpy()), i
+        assert np.array_equal(lb[i], f2.logmel(xs[i]).numpy()), i
+
+
 def test_unsupported_config_fails_loudly(ctx):
     import lele_amd
     from lele_amd.features import FeatureConfig, SenseVoiceFrontend

@@ -24,7 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--quick", action="store_true")
-    ap.add_argument("--only", default="", help="comma-separated section names: matmul,quant,conv,conv1d,eltwise,c4,rnn,misc")
+    ap.add_argument("--only", default="", help="comma-separated section names: matmul,quant,conv,conv1d,eltwise,c4,rnn,misc,frontend")
     args = ap.parse_args()
     import lele_amd
     from lele_amd import kernels as K
@@ -215,6 +215,22 @@ def main():
         x = dev(f32(500, 560))
         ms = timeit(lambda o: lele_amd.features.Cmvn(ctx=ctx).compute(x, out=o), it)
         record("cmvn", [500, 560], ms, 0, 8.0 * 500 * 560, "hbm", "single utterance: launch-latency dominated")
+
+    # ---- the front-end outside its fused default (pipeline.rs:38-42: n_fft = 1024 when the frame is longer than 512 samples): the
+    # composed path -- frame means, pre-emphasis / window, the generic radix-2 FFT, sparse mel / log, LFR gather -- against the fused
+    # kernel on the same audio length ("bit-exact but unprofiled")
+    if want('misc') or want('frontend'):
+        from lele_amd.features import FeatureConfig, SenseVoiceFrontend
+        for label, cfg, sr in (("fused default 16 kHz / 25 ms / n_fft 512", FeatureConfig(), 16000),
+                               ("composed 32 kHz / 25 ms / n_fft 1024", FeatureConfig(sample_rate=32000), 32000),
+                               ("composed 16 kHz / 20 ms / n_fft 512", FeatureConfig(frame_length_ms=20.0), 16000)):
+            nb_, secs = (64 if args.quick else 256), 30
+            pcm = dev((rng.standard_normal((nb_, sr * secs)) * 0.1).astype(np.float32))
+            fe = SenseVoiceFrontend(cfg, ctx=ctx)
+            ms = timeit(lambda o: fe.compute_batch(pcm, out=o), max(3, it // 4))
+            t_rows = fe.compute_batch(pcm).shape[1]
+            record("frontend", [nb_, sr * secs, label], ms, 0, 4.0 * nb_ * (sr * secs + t_rows * cfg.n_mels * cfg.lfr_m), "hbm",
+                   "algorithmic bytes: PCM read once, LFR written once")
 
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
