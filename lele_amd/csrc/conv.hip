@@ -1289,6 +1289,7 @@ __global__ __launch_bounds__(256) void conv_residual_kernel(float* __restrict__ 
 // output positions each, whose window fits `max_slots` LDS slots -- (th + 2)(tw + 2) at stride 1, four phase planes of (th + 1)(tw + 1)
 // at stride 2, th x tw for a 1 x 1.  Widths are multiples of four (16-byte stores); among equal counts the widest tile (longest
 // contiguous runs on both sides).  In the developer's build LELE_HIP_CONV_TILE=tw,th (or `rows`: round 3's fixed tiles) overrides it.
+inline int narrow_beta() { static const int v = conv_env("LELE_HIP_CONV_TILE_BETA", 4); return v; }
 inline WinTile pick_win_tile(int ow, int oh, int positions, int ks, int stride, int max_slots, int64_t units, int num_cus) {
     // `units` = images x blocks of output channels: units x tiles workgroups are launched.  A workgroup multiplies its `positions`
     // whether they are outputs or padding, so with more workgroups than CUs the fewest tiles win; a launch that does not even give
@@ -1297,12 +1298,16 @@ inline WinTile pick_win_tile(int ow, int oh, int positions, int ks, int stride, 
     auto slots = [&](int tw, int th) { return stride == 2 ? 4 * (th + 1) * (tw + 1) : (th + ks - 1) * (tw + ks - 1); };
     int btw = 0, bth = 0;
     int64_t best = -1, best_slots = 0;
+    // stride 1 only: at stride 2 the four phase planes already make the rows short, and the same weight costs 64 -> 64 at 80 x 80 10 %
+    const int beta = stride == 1 ? narrow_beta() : 0;
     for (int tw = 4; tw <= positions; tw += 4) {
         int th = std::min(positions / tw, oh);
         while (th >= 1 && slots(tw, th) > max_slots) --th;
         for (; th >= 1; --th) {
             const int64_t count = (int64_t)((ow + tw - 1) / tw) * ((oh + th - 1) / th);
-            const int64_t cost = std::max<int64_t>(count * units, num_cus), sl = slots(tw, th);
+            // ... weighted by 1 + 4 / tw: the window's rows are the contiguous runs of the loaders' and the epilogue's memory accesses
+            // (80-wide maps at batch 64: 28 tiles of 40 x 6 against 25 of 16 x 16: -2 ... -13 % on every 3 x 3 layer)
+            const int64_t cost = count * units <= num_cus ? (int64_t)num_cus * 64 : count * units * (tw + beta) * 64 / tw, sl = slots(tw, th);
             if (best < 0 || cost < best || (cost == best && (count * units <= num_cus ? sl <= best_slots : true)))
                 best = cost, best_slots = sl, btw = tw, bth = th;
             if (count * units > num_cus) break;  // shorter tiles only add workgroups from here
