@@ -26,6 +26,12 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=" + 
         (["-DLELE_HIP_DEBUG_BOUNDS=1"] if DBG else [])
 
 
+# Per-file additions.  frontend.hip: the SLP vectoriser pairs the scalar multiplies of the pre-emphasis into v_pk_mul_f32, which cannot
+# take the lane rotation as a DPP operand (25 v_mov_dpp + 25 v_mov a pass come back) -- and a packed f32 instruction issues at
+# half rate on gfx950 anyway; the FFT's packed arithmetic is written as float2 and stays packed.
+FILE_FLAGS = {"frontend.hip": ["-fno-slp-vectorize"]}
+
+
 def hipcc():
     for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -53,7 +59,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(OBJ, s[:-4] + ".o")
         objs.append(obj)
         if force or _newer(src, obj, hdrs):
-            jobs.append([cc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([cc] + FLAGS + FILE_FLAGS.get(s, []) + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -15,6 +15,7 @@
 //                         exchange buffer) -> lane-per-filter sparse mel -> ln -> LFR scatter store.
 // HBM traffic per utterance: PCM read once by each kernel (the second read is an L2/MALL hit for batches
 // below the 256 MiB Infinity Cache) + the LFR output; algorithmic bytes = 4*S + 4*T*560.
+#include <type_traits>
 #include "common.h"
 #include "fe_core.h"
 
@@ -134,7 +135,7 @@ __device__ __forceinline__ float lane_rot_prev(float v, int p) {
     if (MODE == 1) {
         // DPP row_ror:1 -- data moves to the next higher lane, lane 0 receives lane 15
         return __builtin_bit_cast(float,
-                                  __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+                                  __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, true));
     } else {
         return __shfl(v, (p + 15) & 15, 16);
     }
@@ -150,11 +151,10 @@ constexpr int kStdMelOff[6] = {0, 3, 7, 13, 23, 40};
 // aliases the exchange region, wave 0 computes the 64 exact sequential frame sums from it (as fe_frame_sum_kernel
 // does), and the per-pass sample loads below then hit L2 -- no separate sum kernel, no second HBM read of the PCM.
 // PASSES: frames per workgroup = 16 * PASSES (a wave takes 4 frames a pass).  LOWREG: the 25 window coefficients of a lane are
-// re-read from the (L1-resident) table every pass instead of living in registers, and the next pass's samples are requested only
-// once the 32 complex points of phase A have left for the exchange.  Built in round 4 to reach four waves per SIMD (<= 128
-// registers, PASSES = 3 so that four workgroups' LDS fits a CU): the compiler still spilled 48 registers at that budget and the
-// kernel ran at 7.41 ms per 2048 x 30 s against 3.80 ms (bit-identical results) -- the product instantiates <4, false> only; see
-// docs/experiments.md.
+// re-read from the (L1-resident) table every pass instead of living in registers.  Four waves per SIMD (<= 128 registers, PASSES = 3 so
+// that four workgroups' LDS fits a CU) were measured twice in round 4: <3, true> with 48 spilled registers 7.41 ms per 2048 x 30 s, and
+// -- after the pass body lost its copies -- <3, false> at 128 registers without a spill in the loop 3.59 ms against 3.47 ms for
+// <4, false> at three waves (148 registers) in the same call: the product instantiates <4, false> only; docs/experiments.md.
 template <int MODE, bool STDMEL, bool FUSED, int PASSES, bool LOWREG>
 __device__ __forceinline__ void fe_main_body(const float* __restrict__ pcm, int64_t utt_stride,
                                              int64_t num_frames, int64_t t_lfr,
@@ -268,7 +268,11 @@ __device__ __forceinline__ void fe_main_body(const float* __restrict__ pcm, int6
     }
     __syncthreads();  // tables (and, when FUSED, the means) are in LDS; the PCM tile may now be overwritten
 
-    for (int pass = 0; pass < PASSES; ++pass) {
+    // One pass = 4 frames per wave.  The last pass is a second copy of the body WITHOUT the request for the next pass's samples: with
+    // that request behind a branch the compiler sank half of the pre-emphasis below it -- the lane rotation and its multiply ended up
+    // in different blocks (no DPP operand: 25 v_mov_dpp + 25 v_mov a pass) and the 25 samples were copied twice per pass.
+    auto run_pass = [&](int pass, auto load_next_c) {
+        constexpr bool load_next = decltype(load_next_c)::value;
         const int64_t f = (int64_t)blockIdx.x * FR + wave * (4 * PASSES) + pass * 4 + g;
         const bool valid = f < num_frames;
         const float mean = FUSED ? s_mean[wave * (4 * PASSES) + pass * 4 + g] : mean_next;
@@ -285,19 +289,20 @@ __device__ __forceinline__ void fe_main_body(const float* __restrict__ pcm, int6
         const float neg_mean = -mean;
 #pragma unroll
         for (int q = 0; q < fe::kQ; ++q) v[q] = __builtin_fmaf(xr[q], 32768.0f, neg_mean);
-        if (!LOWREG && pass + 1 < PASSES) issue_loads(pass + 1);
         // 3. pre-emphasis (pipeline.rs:140-142): y[n] = v[n] - 0.97*v[n-1] for n >= 1; v[n-1] lives in lane p-1
         //    (same q) or, for p == 0, in lane 15 at q-1.  4. window (pipeline.rs:145-166).
         float xin[fe::kRegs];
 #pragma unroll
         for (int r = 0; r < fe::kRegs; ++r) xin[r] = 0.0f;
-        float rot_prev_q = 0.0f;
+        //    The select happens BEFORE the rotation, on lane 15 (it sends v[q - 1], every other lane v[q]): the rotation then has one
+        //    consumer and becomes that multiply's DPP operand (v_mul_f32_dpp; 0.97 in a register, a DPP instruction takes no literal)
+        float k97;
+        asm("v_mov_b32 %0, 0x3f7851ec" : "=v"(k97));  // 0.97f
 #pragma unroll
         for (int q = 0; q < fe::kQ; ++q) {
-            float rot = lane_rot_prev<MODE>(v[q], p);
-            float prev = (p == 0) ? rot_prev_q : rot;
-            rot_prev_q = rot;
-            float y = fe::fsub(v[q], fe::fmul(0.97f, prev));
+            const float send = (p == 15 && q > 0) ? v[q > 0 ? q - 1 : 0] : v[q];
+            const float prev = lane_rot_prev<MODE>(send, p);
+            float y = fe::fsub(v[q], fe::fmul(k97, prev));
             if (q == 0) y = (p == 0) ? v[0] : y;  // sample 0 is not pre-emphasised
             xin[fe::rev5(q)] = fe::fmul(y, win[q]);
         }
@@ -317,7 +322,7 @@ __device__ __forceinline__ void fe_main_body(const float* __restrict__ pcm, int6
                 const int slot = fe::xchg_slot(h, cc);
                 *reinterpret_cast<float2*>(xf + 2 * slot) = make_float2(a[rho * 16 + cc].x, a[rho * 16 + cc].y);
             }
-            if (LOWREG && rho == 1 && pass + 1 < PASSES) issue_loads(pass + 1);  // phase A's points are on their way out: room for the samples
+            if (rho == 1 && load_next) issue_loads(pass + 1);  // phase A's points are on their way out: room for the next samples
             __builtin_amdgcn_wave_barrier();
             fe::cf bq[16];
 #pragma unroll
@@ -413,7 +418,10 @@ __device__ __forceinline__ void fe_main_body(const float* __restrict__ pcm, int6
             }
         }
         __builtin_amdgcn_wave_barrier();
-    }
+    };
+#pragma unroll 1
+    for (int pass = 0; pass + 1 < PASSES; ++pass) run_pass(pass, std::true_type{});
+    run_pass(PASSES - 1, std::false_type{});
 }
 
 template <int MODE, bool STDMEL, bool FUSED>

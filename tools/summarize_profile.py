@@ -104,8 +104,8 @@ def main():
     batch = bench["config"]["batch_per_gpu"]
     json.dump({"tag": tag, "batch": batch, "kernel": "fe_main_kernel", "counters": pmc,
                "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"]}, open(os.path.join(dst, tag + "_frontend_pmc.json"), "w"), indent=1)
-    # VALU work of one launch at the measured issue cost.  The ISA of the pass loop (tools/isa_loop.py) holds 519 packed-f32 and 448
-    # plain VALU instructions; SQ_INSTS_VALU counts both as one.  Cost per wave-instruction and SIMD from tools/valu_rate (4 waves
+    # VALU work of one launch at the measured issue cost.  The ISA of the pass loop (tools/isa_loop.py) holds 416 packed-f32 and 463
+    # plain VALU instructions (round 4's last form; 519 and 448 before it); SQ_INSTS_VALU counts both as one.  Cost per wave-instruction and SIMD from tools/valu_rate (4 waves
     # per SIMD, the saturated regime): plain = the mean of v_add / v_mul / the fma+add pair, packed = the mean of the three v_pk ops.
     roof = {"batch": batch, "kernel": "fe_main_kernel", "source": "profiles/%s_frontend_pmc.json, profiles/%s_valu_rate.json" % (tag, tag)}
     if "hbm_bytes_per_launch" in pmc:
@@ -115,11 +115,11 @@ def main():
         plain = sum(vr[k]["wps4"]["ns_per_instr_per_simd"] for k in ("v_add_f32", "v_mul_f32", "v_fma_f32+v_add_f32_pair")) / 3
         packed = sum(vr[k]["wps4"]["ns_per_instr_per_simd"] for k in ("v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32")) / 3
         n = pmc["SQ_INSTS_VALU"]
-        n_packed, n_plain = n * 519 / 967.0, n * 448 / 967.0
+        n_packed, n_plain = n * 416 / 879.0, n * 463 / 879.0
         simds = 1024
         floor_ms = (n_plain * plain + n_packed * packed) / simds * 1e-6
         lane_ops = n_plain * 64 + n_packed * 128
-        roof.update({"valu_wave_instructions_per_launch": n, "valu_packed_fraction_isa": round(519 / 967.0, 4),
+        roof.update({"valu_wave_instructions_per_launch": n, "valu_packed_fraction_isa": round(416 / 879.0, 4),
                      "valu_ns_per_plain_instr_per_simd": round(plain, 4), "valu_ns_per_packed_instr_per_simd": round(packed, 4),
                      "valu_issue_floor_ms": round(floor_ms, 5), "valu_lane_ops_per_launch": int(lane_ops),
                      # the rate at which the chip issues this kernel's own mix of plain and packed f32 lane-operations
