@@ -390,7 +390,16 @@ __device__ __forceinline__ void fe_main_body(const float* __restrict__ pcm, int6
                     acc = fe::fadd(acc, fe::fmul(wp[t * 16], pv));
                 }
             }
-            vals[rd] = __logf(fmaxf(acc, 1e-5f));  // v_log_f32 * ln2 (<= 2 ulp), input >= 1e-5
+            // ln(x) = log2(x) * ln2 with ln2 as hi + lo (what __logf expands to: v_log_f32, then the product in extended precision), without
+            // __logf's rescaling of denormal inputs and its infinity test (compare, two selects, ldexp, a subtraction of 0, compare,
+            // select): the input is in [1e-5, f32 max) here, so the bits are the same in 5 instructions instead of 12 (a mel sum that
+            // overflowed to +inf -- samples beyond 1e9 -- gives NaN here and +inf there)
+            {
+                const float l2 = __builtin_amdgcn_logf(fmaxf(acc, 1e-5f));
+                const float hi = __builtin_bit_cast(float, 0x3f317217u), lo = __builtin_bit_cast(float, 0x3377d1cfu);
+                const float r = fe::fmul(l2, hi);
+                vals[rd] = fe::fadd(r, fe::ffma(l2, lo, fe::ffma(l2, hi, -r)));
+            }
         }
         // store: log-mel row (test hook) and/or the LFR scatter; lane p writes mels p, p+16, ... of each target
         if (valid) {
