@@ -122,7 +122,8 @@ __global__ __launch_bounds__(64) void fe_frame_sum_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------------------
 constexpr int kFrameXchgFloats = 2 * 16 * fe::kXchgPitch;  // 544 floats = 2176 B: odd frames start 32 banks later
 constexpr int kWaveLdsFloats = 4 * kFrameXchgFloats;  // 8704 B per wave
-constexpr int kPStride = 258;          // power row stride (words); 4*258 <= kWaveLdsFloats
+constexpr int kPStride = 272;          // power row stride (words); 4*272 <= kWaveLdsFloats.  = 16 mod 32: the two frames of a half-wave write disjoint banks
+                                       // and the lane-per-filter reads collide least (model of the 80-filter bank over all pitches: 186 cycles a pass, 258: 236)
 
 struct TwLds {  // twiddle accessor over the LDS copy (phase B: per-lane indices)
     const float2* t;
