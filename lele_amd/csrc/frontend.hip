@@ -290,6 +290,9 @@ __device__ __forceinline__ void fe_main_body(const float* __restrict__ pcm, int6
         const float neg_mean = -mean;
 #pragma unroll
         for (int q = 0; q < fe::kQ; ++q) v[q] = __builtin_fmaf(xr[q], 32768.0f, neg_mean);
+        // next pass's samples: requested as early as the registers are free -- the workgroup's tile is still in its XCD's L2 then (requested
+        // half a pass later, after phase A: the same time, 9 % more fabric traffic)
+        if (load_next) issue_loads(pass + 1);
         // 3. pre-emphasis (pipeline.rs:140-142): y[n] = v[n] - 0.97*v[n-1] for n >= 1; v[n-1] lives in lane p-1
         //    (same q) or, for p == 0, in lane 15 at q-1.  4. window (pipeline.rs:145-166).
         float xin[fe::kRegs];
@@ -323,7 +326,6 @@ __device__ __forceinline__ void fe_main_body(const float* __restrict__ pcm, int6
                 const int slot = fe::xchg_slot(h, cc);
                 *reinterpret_cast<float2*>(xf + 2 * slot) = make_float2(a[rho * 16 + cc].x, a[rho * 16 + cc].y);
             }
-            if (rho == 1 && load_next) issue_loads(pass + 1);  // phase A's points are on their way out: room for the next samples
             __builtin_amdgcn_wave_barrier();
             fe::cf bq[16];
 #pragma unroll
