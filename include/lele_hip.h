@@ -305,7 +305,10 @@ int lele_hip_cast(LeleCtx* ctx, const LeleTensor* x, int32_t to_dtype, LeleBuf* 
 /* ---- src/kernels/conv2d.rs, conv1d.rs: convolutions (implicit GEMM on the f32 MFMA core) ------------------- */
 /* conv2d (conv2d.rs:107), conv2d_fused (conv2d.rs:420: act = LELE_ACT_RELU), conv2d_silu (conv2d.rs:437:
  * act = LELE_ACT_SILU).  x [N,C,H,W], w [C_out,C_in/g,kH,kW], bias [C_out] or NULL.  dilations / strides hold 0, 1 or 2
- * values (one value is used for both axes), pads holds 0, 2 ([ph, pw]) or 4 ([top, left, bottom, right]) values. */
+ * values (one value is used for both axes), pads holds 0, 2 ([ph, pw]) or 4 ([top, left, bottom, right]) values.
+ * The SiLU of the epilogue is x * rcp(1 + exp2(-x log2 e)) on the transcendental unit: within 1e-5 relative + 1e-7 of the reference's
+ * (avx/math.rs polynomial body, libm tail) -- the sum under it is pinned to 1e-4 only.  LELE_HIP_CONV_SILU_EXACT=1 (read per call)
+ * selects the replica of the reference's form instead. */
 int lele_hip_conv2d(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, const LeleTensor* bias,
                     const int64_t* dilations, size_t ndil, int64_t group, const int64_t* pads, size_t npads,
                     const int64_t* strides, size_t nstr, int act, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);

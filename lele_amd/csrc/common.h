@@ -161,7 +161,7 @@ struct LeleGraph {
 #endif
 
 // (LELE_HIP_LAB=1 python -m lele_amd.build -> liblele_hip_lab.so); in the product library lab_env() is NULL for every name.
-// The product's own run-time switches are the five documented in INTEGRATION.md ("Run-time switches").
+// The product's own run-time switches are the six documented in INTEGRATION.md ("Run-time switches").
 #ifdef LELE_HIP_LAB
 inline const char* lab_env(const char* name) { return getenv(name); }
 #else

@@ -26,9 +26,18 @@ using namespace lele;
 
 namespace {
 
+// SiLU of a convolution's epilogue.  Default: x * rcp(1 + exp2(-x * log2 e)) on the transcendental unit (v_exp_f32, v_rcp_f32: 5
+// instructions; within 1e-5 relative + 1e-7 of the reference's form over the whole f32 range, tests/test_conv_rnn.py) -- the sum it is
+// applied to is itself pinned to 1e-4 only (the summation order of faer is not), and the replica of the reference's epilogue
+// (avx/math.rs: 24 instructions a value: a degree-7 polynomial exp, a Newton-refined reciprocal; libm exp and a division on the last
+// 0-7 positions of a plane) was 10 % of a Yolo-shaped forward at batch 64.  LELE_HIP_CONV_SILU_EXACT=1 selects the replica
+// (kActSiluExact; conv2d_entry).  The stand-alone silu / sigmoid operators and the ConvInteger epilogues are replicas always.
+constexpr int kActSiluExact = 3;
+__device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f)); }
 __device__ __forceinline__ float apply_act(float v, int act, bool body) {
     if (act == LELE_ACT_RELU) return v > 0.0f ? v : 0.0f;
-    if (act == LELE_ACT_SILU) return body ? silu_poly(v) : v / (1.0f + expf(-v));
+    if (act == LELE_ACT_SILU) return silu_fast(v);
+    if (act == kActSiluExact) return body ? silu_poly(v) : v / (1.0f + expf(-v));
     return v;
 }
 
@@ -192,9 +201,10 @@ struct ConvEpi {
     __device__ __forceinline__ float activate(float v, int col) const {
         if (act == LELE_ACT_NONE) return v;
         if (act == LELE_ACT_RELU) return v > 0.0f ? v : 0.0f;
+        if (act == LELE_ACT_SILU) return silu_fast(v);
         const bool body = col < (g.plane & ~7);
-        if (__builtin_amdgcn_ballot_w64(!body) == 0) return apply_act(v, LELE_ACT_SILU, true);
-        return apply_act(v, LELE_ACT_SILU, body);
+        if (__builtin_amdgcn_ballot_w64(!body) == 0) return apply_act(v, kActSiluExact, true);
+        return apply_act(v, kActSiluExact, body);
     }
     __device__ __forceinline__ void store(int b, int row, int col, float acc, float pre) const {
         if (row >= g.ocg || col >= g.plane) return;
@@ -769,8 +779,9 @@ __device__ __forceinline__ void c3m_epilogue_strips(const cf32x16 (&acc)[NJ], co
         };
         if (epi.act == LELE_ACT_NONE) run([](float v, bool) { return v; });
         else if (epi.act == LELE_ACT_RELU) run([](float v, bool) { return v > 0.0f ? v : 0.0f; });
-        else if (all_body) run([](float v, bool) { return apply_act(v, LELE_ACT_SILU, true); });
-        else run([](float v, bool b) { return apply_act(v, LELE_ACT_SILU, b); });
+        else if (epi.act == LELE_ACT_SILU) run([](float v, bool) { return silu_fast(v); });
+        else if (all_body) run([](float v, bool) { return apply_act(v, kActSiluExact, true); });
+        else run([](float v, bool b) { return apply_act(v, kActSiluExact, b); });
         return;
     }
     float bv[16];  // the scalar path: every value where it sits
@@ -2013,6 +2024,10 @@ static int conv2d_entry(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* w, 
     LELE_REQUIRE(w->rank == 4, "Conv2d: expected rank-4 weight [C_out,C_in/g,kH,kW], got rank %d", w->rank);
     LELE_REQUIRE(x->dtype == LELE_F32 && w->dtype == LELE_F32, "conv2d: f32 tensors required");
     LELE_REQUIRE(act >= LELE_ACT_NONE && act <= LELE_ACT_SILU, "conv2d: unknown activation %d", act);
+    if (act == LELE_ACT_SILU) {  // read per call, like the other run-time switches
+        const char* e = getenv("LELE_HIP_CONV_SILU_EXACT");
+        if (e && *e && strcmp(e, "0") != 0) act = kActSiluExact;
+    }
     LELE_REQUIRE(group >= 1, "conv2d: group must be >= 1");
     LELE_HIP_CHECK(hipSetDevice(ctx->device));
     ConvGeom g{};

@@ -303,6 +303,37 @@ def test_device_conv2d_vs_oracle(ctx, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,c,hw", [(2, 32, 40), (64, 32, 20), (64, 8, 24), (1, 16, 17)], ids=["tiled", "window", "narrow", "ragged"])
+def test_conv_epilogue_silu_default_and_exact_forms(ctx, monkeypatch, n, c, hw):
+    """The convolution epilogue's SiLU alone: a 1 x 1 convolution with identity weights hands every input value to the activation
+    unchanged (x * 1 + zeros is exact on every route, split-bf16 included).  Default form (v_exp_f32 / v_rcp_f32): within 1e-5
+    relative + 1e-7 of the reference's (polynomial body, libm tail) over the whole range, the tails of the range included.
+    LELE_HIP_CONV_SILU_EXACT=1: the replica, bit for bit where the reference's vector form applies."""
+    from lele_amd import kernels as K
+    rng = np.random.default_rng(n * 1000 + c)
+    count = n * c * hw * hw
+    vals = np.concatenate([np.linspace(-110.0, 110.0, count // 4), rng.standard_normal(count // 4) * 3.0,
+                           rng.standard_normal(count // 4) * 30.0,
+                           np.sign(rng.standard_normal(count - 3 * (count // 4))) * np.exp(rng.uniform(-60.0, 4.0, count - 3 * (count // 4)))])   # (below 2^-110 a value's third bf16 piece is denormal)
+    x = rng.permutation(vals).astype(np.float32).reshape(n, c, hw, hw)
+    w = np.eye(c, dtype=np.float32).reshape(c, c, 1, 1)
+    want = O.conv2d(x, w, None, (), 1, (0, 0, 0, 0), (1, 1), "silu")
+    monkeypatch.delenv("LELE_HIP_CONV_SILU_EXACT", raising=False)
+    got = K.conv2d_silu(x, w, None, (), 1, (0, 0, 0, 0), (1, 1), ctx=ctx).numpy()
+    err = np.abs(got.astype(np.float64) - want)
+    assert np.all(err <= 1e-5 * np.abs(want) + 1e-7), (float(err.max()), float((err / (np.abs(want) + 1e-30)).max()))
+    monkeypatch.setenv("LELE_HIP_CONV_SILU_EXACT", "1")
+    exact = K.conv2d_silu(x, w, None, (), 1, (0, 0, 0, 0), (1, 1), ctx=ctx).numpy()
+    body = (hw * hw) & ~7   # the last 0-7 positions of a plane take the reference's scalar form: libm's expf, the device's own there
+    ef, wf = exact.reshape(n, c, -1), want.reshape(n, c, -1)
+    assert np.array_equal(ef[..., :body], wf[..., :body])
+    assert np.all(np.abs(ef[..., body:].astype(np.float64) - wf[..., body:]) <= 4e-7 * np.abs(wf[..., body:]) + 1e-30)
+    bias = rng.standard_normal(c).astype(np.float32)   # and with a bias / through the 3 x 3 routes the replica stays inside the usual bar
+    w3 = (rng.standard_normal((c, c, 3, 3)) * 0.2).astype(np.float32)
+    _close(K.conv2d_silu(x, w3, bias, (), 1, (1, 1, 1, 1), (1, 1), ctx=ctx).numpy(), O.conv2d(x, w3, bias, (), 1, (1, 1, 1, 1), (1, 1), "silu"), RTOL, "exact 3x3")
+
+
+@pytest.mark.gpu
 def test_batched_convolution_kernels_agree_with_single_image_calls(ctx):
     """Over a batch the 3 x 3 / 1 x 1 convolutions take their own kernels (window-once split-bf16 MFMA, direct small-channel);
     one image at a time takes the implicit GEMM.  Random geometries -- channels, ragged maps, asymmetric pads, stride 1 / 2, every

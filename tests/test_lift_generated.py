@@ -190,11 +190,20 @@ def test_c5_generated_graph_at_batch_64_as_one_graph(ctx):
             bi = b[i:i + 1]
             if a.ndim == 3:   # detections: two top-k selections upstream -- the scores in order, the rows where both picked the same anchor
                 close_f32(bi[..., 4], a[..., 4], 1e-4, "scores of image %d" % i)
-                # a row is the SAME (anchor, class) pick in both forwards when box and class agree; near-tied scores may order two
-                # picks differently between the two tilings (the second top-k runs over 300 x 80 candidates)
-                same = (np.abs(a[0, :, :4] - bi[0, :, :4]).max(axis=1) <= 1e-5 * (1 + np.abs(a[0, :, :4]).max(axis=1))) & (a[0, :, 5] == bi[0, :, 5])
-                assert same.sum() >= 280, int(same.sum())
-                close_f32(bi[0][same], a[0][same], 1e-4, "detections of image %d" % i)
+                # a row is the SAME (anchor, class) pick in both forwards when box and class agree; near-tied scores may ORDER picks
+                # differently between the two tilings (the second top-k runs over 300 x 80 candidates; with synthetic weights the
+                # scores are nearly tied), so rows are matched as a set: every pick of one forward has its partner in the other,
+                # save a few at the cut-off rank
+                ka, kb = a[0], bi[0]
+                partner, free = np.full(300, -1), np.ones(300, bool)
+                for r in range(300):
+                    cand = np.nonzero(free & (kb[:, 5] == ka[r, 5]) & (np.abs(kb[:, :4] - ka[r, :4]).max(axis=1) <= 1e-5 * (1 + np.abs(ka[r, :4]).max())))[0]
+                    if cand.size:
+                        partner[r] = cand[np.argmin(np.abs(kb[cand, 4] - ka[r, 4]))]
+                        free[partner[r]] = False
+                hit = partner >= 0
+                assert hit.sum() >= 294, int(hit.sum())
+                close_f32(kb[partner[hit]], ka[hit], 1e-4, "detections of image %d" % i)
             else:
                 close_f32(bi, a, 1e-4, "prototype map of image %d" % i)
     ctx.sync()
