@@ -809,7 +809,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                                                                    ConvEpi epi, WinTile wt, int ntiles, int nocb,
                                                                                                    int osplit, int items) {
     typedef C3M<KS> W;
-    constexpr int NJ = OCT == 64 ? 4 : 2, MTB = OCT / 32;
+    // OCT = 128: the four multiplying waves take a block of 32 output channels each over a tile of 128 positions (the window is fetched
+    // and split once for 128 output channels; 64- and 32-channel blocks of a 256-position tile fetch it once per block)
+    constexpr int NJ = OCT == 32 ? 2 : 4, MTB = OCT / 32;
     static_assert(4 * 32 * 40 * 4 <= W::STAGE, "a strip of every consumer wave fits one stage");
     const ConvGeom& g = epi.g;
     extern __shared__ __attribute__((aligned(16))) char c3m_lds[];
@@ -919,7 +921,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         return;
     }
     // ---------------------------------------------------------------- consumers
-    const int wm = OCT == 64 ? (wave & 1) : 0, wn = OCT == 64 ? (wave >> 1) : wave;
+    const int wm = OCT == 128 ? wave : OCT == 64 ? (wave & 1) : 0, wn = OCT == 128 ? 0 : OCT == 64 ? (wave >> 1) : wave;
     cf32x16 acc[NJ];
     int sb[NJ];
 #pragma unroll
@@ -1410,7 +1412,16 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             const WinTile t64 = pick_win_tile(ow_, oh_, 256, g.kh, 1, taps == 9 ? C3M<3>::POS : C3M<1>::POS, (int64_t)g.n * ((g.oc + 63) / 64), ctx->num_cus);
             if ((int64_t)g.n * ((g.oc + 63) / 64) * t64.tiles_x * ((oh_ + t64.th - 1) / t64.th) < 2 * (int64_t)ctx->num_cus) oct = 32;
         }
-        const size_t wbytes = (size_t)((g.oc + 31) / 32) * (g.c / 16) * taps * 3 * 1024 + (size_t)(g.c / 16) * taps * 3 * 1024;  // (+ one padding tile)
+        // 1 x 1 with more than one block of output channels: blocks of 128 over tiles of 128 positions, so that the window is fetched and
+        // split once per 128 channels (where the tiles still go round the chip twice, and no more than a quarter of the block is padding).
+        // Same call, batch 64: 96 -> 128 at 80 x 80 148 -> 139 us, 384 -> 128 at 40 x 40 92 -> 82, 512 / 384 / 256 / 128 -> 256 at 20 x 20
+        // -10 ... -11 %; 80 output channels (48 of 128 padding) +4 ... +7 %: those keep their 64- / 32-channel blocks
+        if (taps == 1 && (g.oc + oct - 1) / oct >= 2 && ((g.oc + 127) / 128) * 128 * 4 <= g.oc * 5 && conv_env("LELE_HIP_CONV_OCT128", 1) != 0 &&
+            (int64_t)g.n * ((g.oc + 127) / 128) * (((int64_t)g.plane + 127) / 128) >= 2 * (int64_t)ctx->num_cus)
+            oct = 128;
+        const int positions = oct == 128 ? 128 : 256;
+        const size_t wbytes = oct == 128 ? (size_t)(((g.oc + 127) / 128) * 4) * (g.c / 16) * taps * 3 * 1024  // whole blocks: the padding tiles are zeros
+                                         : (size_t)((g.oc + 31) / 32) * (g.c / 16) * taps * 3 * 1024 + (size_t)(g.c / 16) * taps * 3 * 1024;  // (+ one padding tile)
         void* dwf = nullptr;
         const bool cacheable = wt->mem == LELE_MEM_WEIGHT;
         auto key = std::make_tuple((const void*)wt->data, wbytes, 330 + taps);
@@ -1437,7 +1448,7 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             g.iw = g.ow = g.plane;
         }
         ConvEpi epi{out, db, g, act};
-        const WinTile tile = pick_win_tile(g.ow, g.oh, 256, g.kh, 1, taps == 9 ? C3M<3>::POS : C3M<1>::POS, (int64_t)g.n * ((g.oc + oct - 1) / oct),
+        const WinTile tile = pick_win_tile(g.ow, g.oh, positions, g.kh, 1, taps == 9 ? C3M<3>::POS : C3M<1>::POS, (int64_t)g.n * ((g.oc + oct - 1) / oct),
                                            ctx->num_cus);
         // at most two workgroups per CU, each walking through its share of the items (see conv_window_p_kernel)
         const int ntiles = tile.tiles_x * ((g.oh + tile.th - 1) / tile.th), nblocks = (g.oc + oct - 1) / oct;
@@ -1456,7 +1467,8 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             if (oct == 64) LELE_CW(3, 64);
             else LELE_CW(3, 32);
         } else {
-            if (oct == 64) LELE_CW(1, 64);
+            if (oct == 128) LELE_CW(1, 128);
+            else if (oct == 64) LELE_CW(1, 64);
             else LELE_CW(1, 32);
         }
 #undef LELE_CW

@@ -390,6 +390,7 @@ RES_CASES = [
     (40, 16, 30, 37, 64, 3, 1, 1, 1),       # window kernel, scalar stores (ow % 4 != 0)
     (32, 32, 80, 80, 64, 3, 2, 1, 2),       # stride-2 window kernel
     (32, 48, 80, 80, 64, 1, 1, 1, 2),       # 1 x 1 on the window kernel
+    (64, 32, 40, 40, 128, 1, 1, 1, 2),      # 1 x 1 on the window kernel, 128-channel blocks
     (8, 96, 12, 12, 200, 3, 1, 1, 0),       # tiled GEMM, 16-byte stores
     (4, 24, 9, 7, 40, 3, 1, 1, 2),          # tiled / small GEMM, scalar stores
     (64, 130, 20, 20, 200, 1, 1, 1, 2),     # pointwise tiled GEMM

@@ -283,6 +283,11 @@ CONV_SHAPES = [
     (48, 16, 80, 80, 32, 3, 3, 1, [1, 1, 1, 1], [2, 2], [1, 1], None),
     (32, 48, 50, 36, 64, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "silu"),
     (32, 48, 45, 41, 64, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "relu"),
+    # 1 x 1 with two or more blocks of output channels: 128-channel blocks over tiles of 128 positions (four waves x 32 channels):
+    # whole blocks, a padded last block (250 of 256), a ragged last tile, an odd plane (scalar stores)
+    (64, 32, 40, 40, 128, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "silu"),
+    (64, 48, 36, 30, 250, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "relu"),
+    (72, 16, 27, 29, 128, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], None),
 ]
 
 
