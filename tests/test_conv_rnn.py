@@ -288,6 +288,9 @@ CONV_SHAPES = [
     (64, 32, 40, 40, 128, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "silu"),
     (64, 48, 36, 30, 250, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], "relu"),
     (72, 16, 27, 29, 128, 1, 1, 1, [0, 0, 0, 0], [1, 1], [1, 1], None),
+    # stride 2 (3 x 3) with two and four blocks of output channels, 250 of 256 on a ragged map
+    (128, 32, 40, 40, 128, 3, 3, 1, [1, 1, 1, 1], [2, 2], [1, 1], "silu"),
+    (96, 16, 50, 46, 250, 3, 3, 1, [1, 1, 1, 1], [2, 2], [1, 1], "relu"),
 ]
 
 
