@@ -96,7 +96,8 @@ def replan_lifted(plan, shapes):
     """A plan lifted from lele-generated Rust, re-planned: buffers re-assigned by this library's liveness allocator
     (lele_amd.compiler.lower.allocate) instead of lele's, which makes statement-level fusions safe that move a result into
     another statement -- here `conv2d` followed by a private `silu` (itself from fuse_sigmoid_mul) -> `conv2d_silu`, wherever
-    the plane size is a multiple of 8 (then the convolution's SiLU epilogue and the separate kernel are the same bits).
+    the plane size is a multiple of 8 (then the REPLICA form of the convolution's SiLU epilogue, LELE_HIP_CONV_SILU_EXACT=1, and the
+    separate kernel are the same bits; the default epilogue is within 1e-5 of them).
     `split_owned` + `swap_remove` become one `split` with named outputs.  Returns a format-2 plan (runs in both runners)."""
     from .compiler.lower import allocate
     src = plan["statements"]

@@ -320,8 +320,23 @@ def main():
         re = replan_lifted(plan, shapes)
         raw2 = {weight_key([k, int(off), ln, shp]): r.raw[int(off)] for off, (k, ln, shp) in plan["weights"].items()}
         r3 = Runner(re, raw2, ctx)
-        if not all(np.array_equal(a, b.numpy()) for a, b in zip(reference_outputs, r3.run(inp))):
+        # conv2d + silu -> conv2d_silu is the same bits with the REPLICA of the reference's SiLU in the convolution's epilogue
+        # (LELE_HIP_CONV_SILU_EXACT=1, read per call): both plans run under it for this check; the default epilogue (v_exp_f32 /
+        # v_rcp_f32) is within 1e-5 of it, and what follows compares like with like (the re-planned graph against itself)
+        had = os.environ.get("LELE_HIP_CONV_SILU_EXACT")
+        os.environ["LELE_HIP_CONV_SILU_EXACT"] = "1"
+        try:
+            before = [o.numpy().copy() for o in r.run(inp)]
+            same = all(np.array_equal(a, b.numpy()) for a, b in zip(before, r3.run(inp)))
+        finally:
+            if had is None:
+                del os.environ["LELE_HIP_CONV_SILU_EXACT"]
+            else:
+                os.environ["LELE_HIP_CONV_SILU_EXACT"] = had
+        if not same:
             raise SystemExit("replan_lifted changed the outputs: refusing to use the re-planned graph")
+        r3.calls = 0
+        reference_outputs = [o.numpy().copy() for o in r3.run(inp)]
         plan, r, calls_replanned = re, r3, r3.calls
     out_shapes = [list(o.shape) for o in outs]
     finite = all(bool(np.isfinite(o.numpy()).all()) for o in outs)
