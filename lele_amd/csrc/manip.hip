@@ -674,6 +674,14 @@ __global__ void cast_kernel(const S* __restrict__ in, D* __restrict__ out, int64
         out[i] = (D)in[i];
 }
 
+// f32 -> u8 with Rust's `as u8` (src/tensor.rs:92-97, TensorView::reinterpret_as_u8): truncation toward zero, saturating, NaN -> 0
+__global__ void cast_f32_u8_kernel(const float* __restrict__ in, uint8_t* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = in[i];
+        out[i] = (v != v) ? (uint8_t)0 : (uint8_t)fminf(fmaxf(truncf(v), 0.0f), 255.0f);
+    }
+}
+
 inline int grid_for(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 8192)); }
 
 struct Word16 {
@@ -1345,6 +1353,10 @@ int lele_hip_cast(LeleCtx* ctx, const LeleTensor* x, int32_t to_dtype, LeleBuf* 
         else if (x->dtype == LELE_I64 && to_dtype == LELE_I64) LELE_CAST(int64_t, int64_t);
         else if (x->dtype == LELE_U8 && to_dtype == LELE_F32) LELE_CAST(uint8_t, float);
         else if (x->dtype == LELE_I8 && to_dtype == LELE_F32) LELE_CAST(int8_t, float);
+        else if (x->dtype == LELE_U8 && to_dtype == LELE_I64) LELE_CAST(uint8_t, int64_t);
+        else if (x->dtype == LELE_I8 && to_dtype == LELE_I64) LELE_CAST(int8_t, int64_t);
+        else if (x->dtype == LELE_F32 && to_dtype == LELE_U8)
+            hipLaunchKernelGGL(cast_f32_u8_kernel, g, b, 0, ctx->stream, (const float*)dx, (uint8_t*)out->data, n);
         else {
             set_error("cast: unsupported conversion %d -> %d", x->dtype, to_dtype);
             return 2;

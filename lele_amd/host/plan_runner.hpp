@@ -691,10 +691,15 @@ class Runner {
         else if (kind == "weight_f64") as_f32(len / 8, [&](size_t k) { double v; std::memcpy(&v, p + 8 * k, 8); return (float)v; });
         else if (kind == "weight_i32" || kind == "weight_i32_f32") as_f32(len / 4, [&](size_t k) { int32_t v; std::memcpy(&v, p + 4 * k, 4); return (float)v; });
         else if (kind == "weight_i64_f32") as_f32(len / 8, [&](size_t k) { int64_t v; std::memcpy(&v, p + 8 * k, 8); return (float)v; });
-        else if (kind == "weight_i64" || kind == "weight_i32_i64") {
-            if (kind == "weight_i32_i64") throw Error("weights view kind weight_i32_i64 is not handled");
+        else if (kind == "weight_i64") {
             store->assign(p, p + len);
             weights_[key] = {TV::weight(reinterpret_cast<const int64_t*>(store->data()), shape), store};
+        } else if (kind == "weight_i32_i64") {  // src/compiler/mod.rs:1162 / tensor.rs:237: little-endian i32 words widened to i64
+            const size_t n = len / 4;
+            store->resize(n * 8);
+            int64_t* d = reinterpret_cast<int64_t*>(store->data());
+            for (size_t k = 0; k < n; ++k) { int32_t v; std::memcpy(&v, p + 4 * k, 4); d[k] = (int64_t)v; }
+            weights_[key] = {TV::weight(d, shape), store};
         } else throw Error("weights view kind '" + kind + "' is not handled");
     }
 

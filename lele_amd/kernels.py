@@ -592,6 +592,10 @@ def cast_to_f32(input, out=None, ctx=None):  # utils.rs:66-83
 def cast_to_i64(input, out=None, ctx=None):  # utils.rs:84-101
     return _op(ctx, _lib.lib().lele_hip_cast, [input], [C.c_int32(_lib.I64)], out, np.int64)
 
+
+def reinterpret_as_u8(input, out=None, ctx=None):  # tensor.rs:88-98: f32-carried u8 codes -> u8 (Rust's saturating `as u8`)
+    return _op(ctx, _lib.lib().lele_hip_cast, [input], [C.c_int32(_lib.U8)], out, np.uint8)
+
 # ------------------------------------------------------------------------------------------------- conv / rnn
 def _conv(fn, input, weights, bias, dilations, group, pads, strides, tail, out, ctx, out_window=None):
     keep = []

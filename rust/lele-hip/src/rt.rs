@@ -477,11 +477,22 @@ pub fn print_conv_stats() {
 pub fn min_max(input: &TensorView<'_, f32>) -> (f32, f32) {
     input.data.iter().fold((f32::MAX, f32::MIN), |(a, b), &v| (a.min(v), b.max(v)))
 }
-pub fn cast_to_i64<'a>(flags: TensorView<'a, f32>, out: &'a mut Vec<i64>) -> TensorView<'a, i64> {
+/// the f32 0 / 1 flags a comparison left in `flags` (a scratch slot), as the i64 tensor lele's `*_i64` comparisons return
+pub fn flags_to_i64<'a>(flags: Slot, shape: Vec<usize>, out: &'a mut Vec<i64>) -> TensorView<'a, i64> {
+    cast_into(&TensorView::<f32>::device(flags, shape), out)
+}
+fn cast_into<'b, T: ElementOps, D: ElementOps>(input: &TensorView<'_, T>, out: &'b mut Vec<D>) -> TensorView<'b, D> {
     let slot = slot_of(out);
     let mut sh = Shape::new();
-    check(unsafe { ffi::lele_hip_cast(ctx(), flags.as_c().ptr(), ffi::LELE_I64, slot.raw(), sh.dims(), sh.rank()) });
+    check(unsafe { ffi::lele_hip_cast(ctx(), input.as_c().ptr(), D::DTYPE, slot.raw(), sh.dims(), sh.rank()) });
     TensorView::device(slot, sh.vec())
+}
+/// utils.rs:71-97: ONNX Cast to f32 / to i64 (`lele::kernels::utils::cast_to_f32` / `cast_to_i64`), one device pass, the result in `out`'s slot
+pub fn cast_to_f32<'a, 'b, T: ElementOps>(input: &TensorView<'a, T>, out: &'b mut Vec<f32>) -> TensorView<'b, f32> {
+    cast_into(input, out)
+}
+pub fn cast_to_i64<'a, 'b, T: ElementOps>(input: &TensorView<'a, T>, out: &'b mut Vec<i64>) -> TensorView<'b, i64> {
+    cast_into(input, out)
 }
 pub fn constant_of_shape<'a, 'b, T: ElementOps + AsI64, V: ElementOps>(input: &TensorView<'a, T>, value: V, out: &'b mut Vec<V>) -> TensorView<'b, V> {
     let dims: Vec<i64> = input.data.iter().map(|v| v.as_i64()).collect(); // a shape tensor: a host read

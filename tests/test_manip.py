@@ -138,6 +138,13 @@ def test_device_range_fill_cast(ctx):
     x = np.array([1.7, -2.2, 3.0], np.float32)
     assert np.array_equal(Kk.cast_to_i64(x, ctx=ctx).numpy(), x.astype(np.int64))
     assert np.array_equal(Kk.cast_to_f32(np.array([5, -6], np.int64), ctx=ctx).numpy(), [5.0, -6.0])
+    # TensorView::reinterpret_as_u8 (src/tensor.rs:92-97): Rust's `x as u8` = truncate toward zero, saturate, NaN -> 0
+    codes = np.array([0.0, 1.0, 254.9, 255.0, 256.0, 1e9, -0.9, -3.0, 127.5, np.nan, np.inf, -np.inf], np.float32)
+    want = np.array([0, 1, 254, 255, 255, 255, 0, 0, 127, 0, 255, 0], np.uint8)
+    assert np.array_equal(Kk.reinterpret_as_u8(codes, ctx=ctx).numpy(), want)
+    u = np.arange(256, dtype=np.uint8)
+    assert np.array_equal(Kk.cast_to_i64(u, ctx=ctx).numpy(), u.astype(np.int64))
+    assert np.array_equal(Kk.cast_to_i64(u.view(np.int8), ctx=ctx).numpy(), u.view(np.int8).astype(np.int64))
 
 
 @pytest.mark.gpu

@@ -77,8 +77,11 @@ def main():
         uniq.append(s)
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "signatures.json")
     feats = features_interface()
-    json.dump({"source": "miuda-ai/lele src/kernels + src/features (declarations only)", "functions": uniq, "features": feats}, open(out, "w"), indent=1)
-    print(len(uniq), "signatures ->", out, "; exported:", sum(1 for s in uniq if s["exported"]), "; features items:", len(feats))
+    tens = tensor_interface()
+    json.dump({"source": "miuda-ai/lele src/kernels + src/features + src/tensor.rs (declarations only)", "functions": uniq, "features": feats, "tensor": tens},
+              open(out, "w"), indent=1)
+    print(len(uniq), "signatures ->", out, "; exported:", sum(1 for s in uniq if s["exported"]), "; features items:", len(feats), "; tensor items:", len(tens))
+    write_api_tokens()
 
 
 def features_interface():
@@ -119,6 +122,100 @@ def features_interface():
             items.append({"kind": "struct", "name": m.group(1), "generics": m.group(2) or "", "pub_fields": fields,
                           "at": "%s:%d" % (rel, text.count("\n", 0, m.start()) + 1)})
     return items
+
+
+def tensor_interface():
+    """`lele::tensor` (src/tensor.rs): every public item's DECLARATION -- methods (with the impl block's self type, `unsafe`, generics,
+    parameters, return type), type aliases, traits with their method declarations, trait impls (trait, generics, for-type), re-exports"""
+    rel = "src/tensor.rs"
+    text = open(os.path.join(REF, rel)).read()
+    line = lambda pos: text.count("\n", 0, pos) + 1   # noqa: E731
+    items = []
+    for m in re.finditer(r"(?m)^pub use ([^;]+);", text):
+        items.append({"kind": "use", "path": re.sub(r"\s+", " ", m.group(1)), "at": "%s:%d" % (rel, line(m.start()))})
+    for m in re.finditer(r"(?m)^pub type (\w+)(<[^>]*>)?\s*=\s*([^;]+);", text):
+        items.append({"kind": "type", "name": m.group(1), "generics": m.group(2) or "", "target": re.sub(r"\s+", " ", m.group(3)), "at": "%s:%d" % (rel, line(m.start()))})
+    blocks = []   # (start, end, header text)
+    for m in re.finditer(r"(?m)^(impl|pub trait)\b([^{]*)\{", text):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"{": 1, "}": -1}.get(text[i], 0)
+            i += 1
+        blocks.append((m.start(), i, m.group(1), re.sub(r"\s+", " ", m.group(2)).strip()))
+    for s0, e0, kw, head in blocks:
+        if kw == "pub trait":
+            name = re.match(r"(\w+)", head).group(1)
+            items.append({"kind": "trait", "name": name, "header": head.split(" where")[0].strip(), "at": "%s:%d" % (rel, line(s0))})
+        else:
+            mm = re.match(r"(<.*?>)?\s*(?:(\w+)(<[^>]*>)?\s+for\s+)?(.+?)(?:\s+where\b.*)?$", head)
+            if mm.group(2):
+                items.append({"kind": "impl", "trait": mm.group(2) + (mm.group(3) or ""), "generics": mm.group(1) or "", "for": mm.group(4).strip(),
+                              "at": "%s:%d" % (rel, line(s0))})
+    for m in re.finditer(r"(?m)^\s*(pub )?(unsafe )?fn (\w+)\s*(<[^>(]*>)?\s*\(", text):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(text[i], 0)
+            i += 1
+        params = split_params(re.sub(r"\s+", " ", text[m.end():i - 1]))
+        j = min(x for x in (text.find("{", i), text.find(";", i)) if x >= 0)
+        ret = re.sub(r"\s+", " ", text[i:j].split("where")[0]).strip()
+        ret = ret[2:].strip() if ret.startswith("->") else ""
+        blk = next(((kw, head) for s0, e0, kw, head in blocks if s0 <= m.start() < e0), None)
+        if blk is None or (not m.group(1) and blk[0] != "pub trait"):
+            continue   # private helpers; trait-impl bodies are covered by the "impl" items
+        owner = blk[1].split(" where")[0].strip()
+        items.append({"kind": "fn", "owner": owner, "name": m.group(3), "unsafe": bool(m.group(2)), "generics": m.group(4) or "",
+                      "params": [p for p in params if p], "ret": ret, "at": "%s:%d" % (rel, line(m.start()))})
+    return items
+
+
+def write_api_tokens():
+    """Every `TensorView::<ident>` / `lele::<path>` token, `.method(` called on a view and trait name that (a) the reference's one
+    generated model source and (b) the text its compiler emits (src/compiler/**: the helper block mod.rs:1135-1233, the per-operator
+    emitters, snippets) and (c) the example applications contain -- the full surface a drop-in `lele` crate has to resolve.  Stored under
+    "api_tokens" of tests/golden/generated_kernel_names.json next to the kernel-name lists (names only: data for tests/test_rust_shim.py)."""
+    pat = re.compile(r"(?:lele::)?(?:tensor::)?TensorView(?:F32|I8|U8|I32|I64|F16|BF16)?::(?:<[^>]*>::)?[a-z_0-9]+|lele::[a-zA-Z_0-9]+(?:::[a-zA-Z_0-9]+)*|\bIntoLogits\b|\binto_logits\b"
+                     r"|TensorView(?:F32|I8|U8|I32|I64|F16|BF16)\b")
+    groups = {"yolo26seg": ["examples/yolo26n-seg/src/yolo26seg.rs"], "emitter": [], "apps": []}
+    for root, _d, files in os.walk(os.path.join(REF, "src", "compiler")):
+        groups["emitter"] += [os.path.relpath(os.path.join(root, f), REF) for f in files if f.endswith(".rs")]
+    for root, _d, files in os.walk(os.path.join(REF, "examples")):
+        for f in files:
+            rp = os.path.relpath(os.path.join(root, f), REF)
+            if f.endswith(".rs") and rp not in groups["yolo26seg"] and "/target/" not in rp:
+                groups["apps"].append(rp)
+    out = {}
+    for g, paths in groups.items():
+        toks = set()
+        for rp in sorted(paths):
+            txt = open(os.path.join(REF, rp)).read()
+            txt = re.sub(r"(?m)^\s*//.*$", "", txt)
+            found = pat.findall(txt)
+            for m in re.finditer(r"\buse (lele::[a-z_:]+)::\{([^}]*)\}", txt):   # `use lele::features::{A, B}` -> lele::features::A, ..
+                found += ["%s::%s" % (m.group(1), n.strip()) for n in m.group(2).split(",") if n.strip()]
+            for t in found:
+                t = re.sub(r"::<[^>]*>", "", t)
+                if t.startswith("TensorView::"):
+                    t = "lele::tensor::" + t
+                elif t.startswith("tensor::TensorView::"):
+                    t = "lele::" + t
+                elif re.match(r"TensorView[A-Z0-9]+$", t) or t in ("IntoLogits",):
+                    t = "lele::tensor::" + t
+                elif t == "into_logits":
+                    t = "lele::tensor::IntoLogits::into_logits"
+                if t.rstrip(":") in ("lele", "lele::kernels", "lele::tensor", "lele::features", "lele::compiler", "lele::model"):
+                    continue
+                if t.startswith("lele::compiler") or t.startswith("lele::model"):
+                    continue   # the ONNX compiler itself (feature "compiler"): out of scope, never referenced by generated sources
+                toks.add(t)
+        out[g] = sorted(toks)
+    gp = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "generated_kernel_names.json")
+    d = json.load(open(gp))
+    d["api_tokens"] = out
+    d["api_tokens_note"] = ("every lele::<path> / TensorView::<fn> / IntoLogits token in (yolo26seg) the reference's generated model source, (emitter) the text "
+                            "src/compiler/** emits, (apps) examples/**.rs -- tools/rust_shim/extract_signatures.py; tests/test_rust_shim.py resolves each in rust/lele-hip")
+    json.dump(d, open(gp, "w"), indent=1)
+    print("api tokens:", {k: len(v) for k, v in out.items()}, "->", gp)
 
 
 if __name__ == "__main__":
