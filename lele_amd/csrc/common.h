@@ -234,4 +234,27 @@ inline int set_shape_v(int64_t* out_shape, int32_t* out_rank, const std::vector<
         for (size_t i = 0; i < dims.size(); ++i) out_shape[i] = dims[i];
     return 0;
 }
+
+#ifdef __HIPCC__
+// f32 -> three bf16 pieces, two values at a time: a = h.lo + m.lo + l.lo and b = h.hi + m.hi + l.hi EXACTLY (element 0 in the low half
+// of each word, the layout of a bf16 MFMA operand pair).  Every piece is ROUNDED TO NEAREST (v_cvt_pk_bf16_f32), the remainders are
+// exact f32 subtractions: |a - h| <= 2^-9 |a| has at most 16 significant bits, |a - h - m| at most 8, so l is exact.
+// Why not truncation (a mask and a subtraction, the same instruction count): with truncated pieces m and l carry the SIGN OF THE VALUE,
+// so in a split-bf16 product every one of the six kept terms and the three dropped ones (m l, l m, l l) has the sign of a * b -- the
+// dropped terms and the matrix core's alignment truncation (a product is cut 2 bits below the accumulator's ulp TOWARDS ZERO:
+// tools/mfma_round.hip) then shrink every product the same way, and a sum of K products comes out ~1e-7 (K = 576) too small in
+// magnitude.  One layer hides that below f32 round-off; a 100-layer SiLU network does not -- a scale error is the one perturbation that
+// adds up coherently through depth: the lifted Yolo26n-seg graph ended 3.3e-5 low (profiles/r05_graph_error_growth.json), ten times
+// the spread of an f32 chain.  With rounded pieces m and l take either sign, five of the six terms and all dropped ones become
+// zero-mean noise, and what is left of the bias is the hh term's alone.
+__device__ __forceinline__ void split3_bf16_pair(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+    typedef __bf16 lele_bf2 __attribute__((ext_vector_type(2)));
+    typedef float lele_f2 __attribute__((ext_vector_type(2)));
+    auto pack = [](float x, float y) { return __builtin_bit_cast(unsigned, __builtin_convertvector(lele_f2{x, y}, lele_bf2)); };
+    h = pack(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+    m = pack(ra, rb);
+    l = pack(ra - __uint_as_float(m << 16), rb - __uint_as_float(m & 0xffff0000u));
+}
+#endif
 }  // namespace lele

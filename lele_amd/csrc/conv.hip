@@ -26,14 +26,21 @@ using namespace lele;
 
 namespace {
 
-// SiLU of a convolution's epilogue.  Default: x * rcp(1 + exp2(-x * log2 e)) on the transcendental unit (v_exp_f32, v_rcp_f32: 5
-// instructions; within 1e-5 relative + 1e-7 of the reference's form over the whole f32 range, tests/test_conv_rnn.py) -- the sum it is
+// SiLU of a convolution's epilogue.  Default: x * r with r = 1 / (1 + exp2(-x * log2 e)) from the transcendental unit (v_exp_f32,
+// v_rcp_f32) and ONE Newton step on the reciprocal (two FMAs: v_rcp_f32 alone leaves a result that is 8e-9 low on average -- nothing
+// for one layer, but a bias is what a deep network adds up coherently: profiles/r05_graph_error_growth.json): 7 instructions; within
+// 1e-5 relative + 1e-7 of the reference's form over the whole f32 range (tests/test_conv_rnn.py), mean error 2e-9 -- the sum it is
 // applied to is itself pinned to 1e-4 only (the summation order of faer is not), and the replica of the reference's epilogue
 // (avx/math.rs: 24 instructions a value: a degree-7 polynomial exp, a Newton-refined reciprocal; libm exp and a division on the last
 // 0-7 positions of a plane) was 10 % of a Yolo-shaped forward at batch 64.  LELE_HIP_CONV_SILU_EXACT=1 selects the replica
 // (kActSiluExact; conv2d_entry).  The stand-alone silu / sigmoid operators and the ConvInteger epilogues are replicas always.
 constexpr int kActSiluExact = 3;
-__device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f)); }
+__device__ __forceinline__ float silu_fast(float v) {
+    const float d = 1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f);
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);  // d = inf (x < -88): r = 0, fma(-inf, 0, 1) = NaN -> guarded below
+    return d < 3.0e38f ? v * r : 0.0f * v;                   // x * 0 keeps the sign of zero / NaN of the plain form
+}
 __device__ __forceinline__ float apply_act(float v, int act, bool body) {
     if (act == LELE_ACT_RELU) return v > 0.0f ? v : 0.0f;
     if (act == LELE_ACT_SILU) return silu_fast(v);
@@ -687,7 +694,6 @@ struct WinTile {
 };
 __device__ __forceinline__ int wt_row(const WinTile& t, int p) { return (int)(((unsigned)p * t.inv) >> 20); }
 
-__device__ __forceinline__ unsigned c3m_pair(float even, float odd) { return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u); }
 
 // Epilogue of the window-once kernels (c3m_epilogue_strips below): a consumer wave holds NJ accumulator tiles (32 output channels x
 // NJ strips of 32 positions).  C layout: column = lane & 31 = the position inside the strip, rows (r & 3) + 8 (r >> 2) + 4 hv = output
@@ -877,17 +883,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int i = 0; i < W::TASKS; ++i) {
                 if (t_lds[i] < 0) continue;
-                const float v[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
-                float r[4], q[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    r[e] = v[e] - __uint_as_float(__float_as_uint(v[e]) & 0xffff0000u);
-                    q[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xffff0000u);
-                }
-                cu32x2 h, m, l;
-                h[0] = c3m_pair(v[0], v[1]), h[1] = c3m_pair(v[2], v[3]);
-                m[0] = c3m_pair(r[0], r[1]), m[1] = c3m_pair(r[2], r[3]);
-                l[0] = c3m_pair(q[0], q[1]), l[1] = c3m_pair(q[2], q[3]);
+                unsigned h0, m0, l0, h1, m1, l1;  // three bf16 pieces a value, rounded to nearest (common.h split3_bf16_pair)
+                split3_bf16_pair(st[i].x, st[i].y, h0, m0, l0);
+                split3_bf16_pair(st[i].z, st[i].w, h1, m1, l1);
+                const cu32x2 h = {h0, h1}, m = {m0, m1}, l = {l0, l1};
                 *reinterpret_cast<cu32x2*>(dst + t_lds[i]) = h;
                 *reinterpret_cast<cu32x2*>(dst + t_lds[i] + 32) = m;
                 *reinterpret_cast<cu32x2*>(dst + t_lds[i] + 64) = l;
@@ -1126,17 +1125,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int i = 0; i < W::TASKS; ++i) {
                 if (t_lds[i] < 0) continue;
-                const float v[4] = {st[i].x, st[i].y, st[i].z, st[i].w};
-                float r[4], q[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    r[e] = v[e] - __uint_as_float(__float_as_uint(v[e]) & 0xffff0000u);
-                    q[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xffff0000u);
-                }
-                cu32x2 h, m, l;
-                h[0] = c3m_pair(v[0], v[1]), h[1] = c3m_pair(v[2], v[3]);
-                m[0] = c3m_pair(r[0], r[1]), m[1] = c3m_pair(r[2], r[3]);
-                l[0] = c3m_pair(q[0], q[1]), l[1] = c3m_pair(q[2], q[3]);
+                unsigned h0, m0, l0, h1, m1, l1;  // three bf16 pieces a value, rounded to nearest (common.h split3_bf16_pair)
+                split3_bf16_pair(st[i].x, st[i].y, h0, m0, l0);
+                split3_bf16_pair(st[i].z, st[i].w, h1, m1, l1);
+                const cu32x2 h = {h0, h1}, m = {m0, m1}, l = {l0, l1};
                 *reinterpret_cast<cu32x2*>(c3m_lds + t_lds[i]) = h;
                 *reinterpret_cast<cu32x2*>(c3m_lds + t_lds[i] + 32) = m;
                 *reinterpret_cast<cu32x2*>(c3m_lds + t_lds[i] + 64) = l;
@@ -1244,19 +1236,15 @@ __global__ void conv_wfrag_kernel(const float* __restrict__ w, cu32x4* __restric
         const int64_t rest = (i >> 6) / taps;
         const int cc = (int)(rest % (ic / 16)), mt = (int)(rest / (ic / 16));
         const int o = mt * 32 + (lane & 31), c0 = cc * 16 + 8 * (lane >> 5);
-        float v[8], r[8], q[8];
+        float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v[e] = o < oc ? w[((int64_t)o * ic + c0 + e) * taps + tap] : 0.0f;
-            r[e] = v[e] - __uint_as_float(__float_as_uint(v[e]) & 0xffff0000u);
-            q[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xffff0000u);
-        }
+        for (int e = 0; e < 8; ++e) v[e] = o < oc ? w[((int64_t)o * ic + c0 + e) * taps + tap] : 0.0f;
         cu32x4 h, m, l;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            h[p] = c3m_pair(v[2 * p], v[2 * p + 1]);
-            m[p] = c3m_pair(r[2 * p], r[2 * p + 1]);
-            l[p] = c3m_pair(q[2 * p], q[2 * p + 1]);
+            unsigned hp, mp, lp;
+            split3_bf16_pair(v[2 * p], v[2 * p + 1], hp, mp, lp);
+            h[p] = hp, m[p] = mp, l[p] = lp;
         }
         cu32x4* dst = wfrag + (((int64_t)mt * (ic / 16) + cc) * taps + tap) * (3 * 64) + lane;
         dst[0] = h;
