@@ -272,7 +272,47 @@ def frontend_leg(args, ctx, rank, world, fence, dist, device):
             "sum_ms": sum_ms, "runs": runs}
 
 
-def sensevoice_leg(args, ctx, rank, world, fence, dist, device):
+def open_comm(args, ctx, rank, world, dist, device):
+    """N > 1: the C ABI's own RCCL communicator (the 128-byte id travels through the already-initialised process group), shared by the
+    recogniser's id gather and the Yolo leg's detection gather.  -> (comm or None, note when torch.distributed stands in, ranks the
+    communicator itself reached)"""
+    import lele_amd
+    if world <= 1:
+        return None, None, None
+    comm, comm_note, seen = None, None, None
+    uid, err = [None], ""
+    try:
+        if rank == 0:
+            uid = [lele_amd._lib.Comm.unique_id()]
+    except Exception as e:  # noqa: BLE001
+        err = str(e)
+    dist.broadcast_object_list(uid, src=0)
+    if uid[0] is not None:
+        try:
+            comm = lele_amd._lib.Comm.from_id(ctx, uid[0], rank, world)
+            probe = comm.allreduce_max(rank)
+            if probe != world - 1:
+                raise RuntimeError("communicator probe returned %r" % probe)
+        except Exception as e:  # noqa: BLE001
+            err, comm = str(e), None
+    # every rank must take the same route: agree (MIN over ranks of "mine works"); otherwise the results travel through the process
+    # group torch already holds, and the line says so -- a scaling measurement is not lost to a transport problem
+    import torch
+    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if not args.allow_fallback:  # a scaling number measured on the wrong transport is worse than none
+            raise SystemExit("bench.py: the C ABI's RCCL communicator was not usable on every rank (%s); rerun with --allow-fallback to "
+                             "measure with torch.distributed's all_gather instead" % (err or "another rank failed"))
+        if comm is not None:
+            comm.close()
+        comm, comm_note = None, "torch.distributed all_gather (the C ABI communicator was not usable on every rank: %s)" % (err or "another rank failed")
+    elif comm is not None:  # how many ranks the communicator itself reached (a MAX all-reduce of rank + 1 through the C ABI)
+        seen = int(comm.allreduce_max(rank + 1))
+    return comm, comm_note, seen
+
+
+def sensevoice_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_note=None, ranks_seen=None):
     import lele_amd
     from lele_amd import kernels as K
     from lele_amd.compiler import compile_model
@@ -296,35 +336,8 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device):
     skip[VOCAB - 200:] = 1
     skip = lele_amd._lib.Weight(skip)
 
-    comm, comm_note = None, None
-    if world > 1:  # the C ABI's own RCCL communicator; the 128-byte id travels through the already-initialised process group
-        uid, err = [None], ""
-        try:
-            if rank == 0:
-                uid = [lele_amd._lib.Comm.unique_id()]
-        except Exception as e:  # noqa: BLE001
-            err = str(e)
-        dist.broadcast_object_list(uid, src=0)
-        if uid[0] is not None:
-            try:
-                comm = lele_amd._lib.Comm.from_id(ctx, uid[0], rank, world)
-                probe = comm.allreduce_max(rank)
-                if probe != world - 1:
-                    raise RuntimeError("communicator probe returned %r" % probe)
-            except Exception as e:  # noqa: BLE001
-                err, comm = str(e), None
-        # every rank must take the same route: agree (MIN over ranks of "mine works"); otherwise the ids travel through the process
-        # group torch already holds, and the line says so -- a scaling measurement is not lost to a transport problem
-        import torch
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=device)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            if not args.allow_fallback:  # a scaling number measured on the wrong transport is worse than none
-                raise SystemExit("bench.py: the C ABI's RCCL communicator was not usable on every rank (%s); rerun with --allow-fallback to "
-                                 "measure with torch.distributed's all_gather instead" % (err or "another rank failed"))
-            comm, comm_note = None, "torch.distributed all_gather (the C ABI communicator was not usable on every rank: %s)" % (err or "another rank failed")
-        elif comm is not None:  # how many ranks the communicator itself reached (a MAX all-reduce of rank + 1 through the C ABI)
-            rec["rccl_ranks_seen"] = int(comm.allreduce_max(rank + 1))
+    if ranks_seen is not None:
+        rec["rccl_ranks_seen"] = ranks_seen
 
     def build(batch, seconds, seed0):
         n = SAMPLE_RATE * seconds
@@ -453,8 +466,6 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device):
                     "rtf_target": 0.001})
         rec["_c3_feats"] = c3["feats"].numpy()
         rec["_enc"] = enc
-    if comm is not None:
-        comm.close()
     return rec
 
 
@@ -492,16 +503,80 @@ def cpu_baseline_yolo(layers):
                       "AVX2-FMA GEMM where lele calls faer + bias / SiLU pass), 1 thread" % (len(layers), 2 * macs / 1e9, t_all)}
 
 
-def yolo_leg(args, ctx, rank, world, fence, dist, device):
-    """BASELINE configs[4]: the Yolo26n-seg-SHAPED network of tools/yolo_graph.py (lele's generated file bakes N = 1 into its reshapes and
-    the ONNX it came from is not in the tree: same family, 100 convolutions, 9.74 GFLOP an image against the reference graph's 118 / 9.13;
-    synthetic weights), batch `--yolo-batch` per GPU, compiled by lele_amd.compiler, Concat / Split along C folded into channel views,
-    replayed as ONE hipGraph.  Protocol of examples/yolo26n-seg/src/benchmark.rs:29-56: 3 warm-up forwards, then 10 timed ones."""
+def cpu_baseline_yolo_graph(lifted):
+    """configs[4]'s CPU baseline on the reference's own graph: ONE forward of the lifted Yolo26n-seg call sequence, statement by
+    statement on the oracle (oracle/plan_ref.py: im2col + the oracle's AVX2-FMA GEMM where lele calls faer, AVX2 epilogues, the index
+    operators in numpy), one thread -- lele's execution model (Par::Seq, one image a call)."""
+    import lift_generated as L
+    from oracle import plan_ref
+    plan = json.load(open(lifted))
+    raw = L.synth_weights(plan, dict(L.DEFAULT_CONSTS))
+    x = np.random.default_rng(1000).uniform(0, 1, (1, 3, 640, 640)).astype(np.float32)
+    ref = plan_ref.PlanRef(plan, raw)
+    ref.run({plan["inputs"][-1]: x})
+    t0 = time.perf_counter()
+    runs = 3
+    for _ in range(runs):
+        ref.run({plan["inputs"][-1]: x})
+    dt = (time.perf_counter() - t0) / runs
+    return {"value": round(1.0 / dt, 3), "unit": "images/s", "cores": 1, "kind": "port", "ms_per_image": round(1e3 * dt, 1),
+            "gflops": round(9.127 / dt, 2),
+            "sample": "%d whole forwards of ONE 640 x 640 image through the reference's generated graph (%d kernel statements, 9.127 GFLOP) in %.1f s: "
+                      "oracle/plan_ref.py over oracle/conv_fast.cpp (im2col + the oracle's own AVX2-FMA GEMM where lele calls faer), 1 thread"
+                      % (runs, ref.calls, runs * dt)}
+
+
+def yolo_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_note=None, ranks_seen=None):
+    """BASELINE configs[4], batch `--yolo-batch` per GPU, one hipGraph a forward.  Two networks:
+      * the reference's OWN generated Yolo26n-seg call sequence (examples/yolo26n-seg/src/yolo26seg.rs: 118 convolutions, 9.127 GFLOP an
+        image), lifted into a plan (tools/lift_generated.py -> _lifted/yolo26seg_plan.json: an untracked artefact that travels with the
+        working tree, not with a clone), its batch-1 shape literals re-batched, Concat / Split along C folded into channel views --
+        the HEADLINE of this leg whenever the artefact is present;
+      * the Yolo26n-seg-SHAPED network of tools/yolo_graph.py (same family, 100 convolutions, 9.736 GFLOP an image; compiled from ONNX by
+        lele_amd.compiler) beside it -- the headline only in a checkout without the lifted plan.
+    Synthetic weights.  Protocol of examples/yolo26n-seg/src/benchmark.rs:29-56: 3 warm-up forwards, then 10 timed ones.
+    After the timed forwards: section 8(e)'s one exchange -- post-processing per image on the device (image.rs:127-265,
+    lele_hip_yolo_seg_postprocess), then an all-gather of the fixed-width detection rows and their counts (RCCL through the C ABI)."""
+    from lele_amd import kernels as K
     from lele_amd.compiler import compile_model
     from lele_amd.plan import Runner, fold_channel_views, load_weights_bin
+    from lele_amd.sharded import all_gather_detections, all_gather_detections_rccl
     from lele_amd.tensor import TensorView
     from yolo_graph import yolo_onnx
     nb, size = args.yolo_batch, 640
+
+    def bars(a, b):
+        den = 1e-4 * np.maximum(np.abs(a), float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))) + 1e-7
+        return float((np.abs(a - b) / den).max()) if a.size else 0.0
+
+    def timed(runner, feed, gflop_per_image):
+        """capture, 3 warm-up replays, `--yolo-runs` timed ones between fences; MAX over ranks of the wall time"""
+        ctx.sync()
+        ctx.graph_begin()
+        outs = runner.run(feed)
+        graph = ctx.graph_end()
+        for _ in range(3):
+            graph.launch()
+        fence()
+        t0 = time.perf_counter()
+        ctx.timer_start()
+        for _ in range(args.yolo_runs):
+            graph.launch()
+        ev_ms = ctx.timer_stop() / args.yolo_runs
+        fence()
+        wall = max_over_ranks(time.perf_counter() - t0, dist, device)
+        ms = 1e3 * wall / args.yolo_runs
+        tf = gflop_per_image * nb / ev_ms           # GFLOP / ms = TFLOP/s
+        return graph, outs, {"runs": args.yolo_runs, "warmup": 3, "ms_per_forward": round(ms, 3), "ms_per_forward_hip_events_rank0": round(ev_ms, 3),
+                             "images_per_s": round(world * nb * args.yolo_runs / wall, 1), "gflop_per_image": gflop_per_image,
+                             "tflops_f32_per_gpu": round(tf, 2),
+                             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / F32_PEAK_TFLOPS, 4),
+                                          "note": "convolution + attention multiply-adds of the whole forward (%.3f GFLOP an image) over the graph's HIP-event time, "
+                                                  "against the f32-input MFMA peak SURVEY.md 8(d) names for configs[4].  The split-bf16 kernels (3 x 3 stride 1, "
+                                                  "some 1 x 1) run on the bf16 matrix cores: six bf16 MFMAs a product, i.e. a ceiling of 2500 / 6 = 417 TFLOP/s "
+                                                  "of f32-equivalent work for those layers" % gflop_per_image}}
+
+    # ---- the look-alike (always available)
     data, info = yolo_onnx(nb, size)
     plan, blob = compile_model(data, "yolo26n_seg_shaped_n%d" % nb)
     weights = load_weights_bin(plan, blob)
@@ -510,10 +585,10 @@ def yolo_leg(args, ctx, rank, world, fence, dist, device):
     r0 = Runner(plan, weights, ctx)
     r0.shapes = {}
     base = [o.numpy().copy() for o in r0.run(feed)]
-    rec = {"model": "Yolo26n-seg-SHAPED (tools/yolo_graph.py; the reference's generated graph bakes N = 1 into its reshapes), synthetic weights",
-           "batch_per_gpu": nb, "input": [nb, 3, size, size], **info, "plan_calls": r0.calls}
+    look = {"model": "Yolo26n-seg-SHAPED (tools/yolo_graph.py), synthetic weights", "batch_per_gpu": nb, "input": [nb, 3, size, size], **info,
+            "plan_calls": r0.calls}
     layers = yolo_conv_layers(plan, r0.shapes) if rank == 0 else None
-    runner, note = r0, None
+    runner = r0
     try:
         folded = fold_channel_views(plan, r0.shapes)
         r1 = Runner(folded, weights, ctx)
@@ -523,89 +598,101 @@ def yolo_leg(args, ctx, rank, world, fence, dist, device):
         for b_ in r0.ws.values():
             b_.close()
         runner = r1
-        rec.update({"channel_views": folded["folded"], "plan_calls": r1.calls, "folded_equals_unfolded_bitwise": True})
+        look.update({"channel_views": folded["folded"], "plan_calls": r1.calls, "folded_equals_unfolded_bitwise": True})
     except Exception as e:  # noqa: BLE001  -- the leg is still measured, on the unfolded plan, and says so
-        note = "channel views NOT used: %s" % e
-        rec["channel_views"] = note
-    ctx.sync()
-    ctx.graph_begin()
-    outs = runner.run(feed)
-    graph = ctx.graph_end()
-    for _ in range(3):
-        graph.launch()
-    fence()
-    t0 = time.perf_counter()
-    ctx.timer_start()
-    for _ in range(args.yolo_runs):
-        graph.launch()
-    ev_ms = ctx.timer_stop() / args.yolo_runs
-    fence()
-    wall = max_over_ranks(time.perf_counter() - t0, dist, device)
-    ms = 1e3 * wall / args.yolo_runs
-    flop = info["gflop_per_image"] * 1e9 * nb
-    rec.update({"runs": args.yolo_runs, "warmup": 3, "ms_per_forward": round(ms, 3), "ms_per_forward_hip_events_rank0": round(ev_ms, 3),
-                "images_per_s": round(world * nb * args.yolo_runs / wall, 1), "tflops_f32_per_gpu": round(flop / (ev_ms * 1e-3) / 1e12, 2),
-                "roofline": {"bound": "mfma", "achieved": round(flop / (ev_ms * 1e-3) / 1e12, 2), "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(flop / (ev_ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS, 4),
-                             "note": "convolution + attention multiply-adds of the whole forward (%.3f GFLOP an image) over the graph's HIP-event time, "
-                                     "against the f32-input MFMA peak; the split-bf16 kernels (3 x 3 stride 1, some 1 x 1) run on the bf16 "
-                                     "matrix cores, whose six-term form peaks at 937 TFLOP/s of f32-equivalent work" % info["gflop_per_image"]},
-                "graph_equals_eager_bitwise": bool(all(np.array_equal(a, o.numpy()) for a, o in zip(base, outs))),
-                "finite": bool(all(np.isfinite(a).all() for a in base)),
-                # parity of what runs here (tests/): convolutions 1e-4 against the oracle (|err| <= 1e-4 max(|want|, rms) + 1e-7); their SiLU
-                # epilogue is the v_exp_f32 / v_rcp_f32 form (<= 1e-5 relative + 1e-7 from the reference's polynomial) unless
-                # LELE_HIP_CONV_SILU_EXACT=1 selects the replica
-                "parity": {"conv_bar": 1e-4, "conv_epilogue_silu": "replica" if os.environ.get("LELE_HIP_CONV_SILU_EXACT", "0") not in ("", "0") else "v_exp_f32/v_rcp_f32 form, <= 1e-5 relative + 1e-7 of the reference's"}})
+        look["channel_views"] = "channel views NOT used: %s" % e
+    graph, outs, t = timed(runner, feed, info["gflop_per_image"])
+    look.update(t)
+    look.update({"graph_equals_eager_bitwise": bool(all(np.array_equal(a, o.numpy()) for a, o in zip(base, outs))),
+                 "finite": bool(all(np.isfinite(a).all() for a in base))})
     if rank == 0:
         # two images of the batch against the batch-1 plan of the same network (same seed -> same weights): the prototype map value for
-        # value, the detections' scores in order (two anchors whose scores differ in the last bits may swap places between tilings)
+        # value, the detections' scores in order.  (Against the CPU ORACLE's forward: tests/test_graph_oracle.py.)
         d1, _ = yolo_onnx(1, size)
         p1, b1 = compile_model(d1, "yolo26n_seg_shaped_n1")
         one = Runner(p1, load_weights_bin(p1, b1), ctx)
         x1 = ctx.buf()
         worst = 0.0
-
-        def bars(a, b):
-            den = 1e-4 * np.maximum(np.abs(a), float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))) + 1e-7
-            return float((np.abs(a - b) / den).max()) if a.size else 0.0
         for i in (0, nb - 1):
             o1 = [o.numpy() for o in one.run({"images": TensorView(x1.upload(images[i:i + 1]))})]
             for a, b in zip(o1, base):
                 worst = max(worst, bars(a[..., 4], b[i:i + 1][..., 4]) if a.ndim == 3 else bars(a, b[i:i + 1]))
-        rec.update({"images_checked_against_the_batch_1_plan": 2, "max_error_in_units_of_1e-4": round(worst, 4), "per_image_check_ok": bool(worst <= 1.0)})
-        rec["_layers"] = layers
+        look.update({"images_checked_against_the_batch_1_plan": 2, "max_error_in_units_of_1e-4": round(worst, 4), "per_image_check_ok": bool(worst <= 1.0)})
     graph.close()
-    # the reference's OWN generated Yolo26n-seg call sequence at the same batch, where the lifted plan is present (an untracked artifact
-    # made from the mounted reference by tools/lift_generated.py; it travels with the working tree, not with a clone): N = 1 only
+    head, head_outs, head_name = look, outs, "look-alike"
+
+    # ---- the reference's own generated graph, where the lifted plan is present (every rank runs it on its own images)
     lifted = os.path.join(ROOT, "_lifted", "yolo26seg_plan.json")
-    if rank == 0 and world == 1 and os.path.exists(lifted):
+    ref = None
+    if os.path.exists(lifted):
         try:
             import yolo_lifted_batch as Y
-            one, big, lfeed, limages, lname, louts, lrec = Y.build(ctx, lifted, nb)
+            one, big, lfeed, limages, lname, louts, ref = Y.build(ctx, lifted, nb, seed=1000 + rank)
             worst = 0.0
-            lx1 = ctx.buf()
-            for i in (0, nb - 1):
-                o1 = [o.numpy() for o in one.run({lname: TensorView(lx1.upload(limages[i:i + 1]))})]
-                for a, b in zip(o1, louts):
-                    worst = max(worst, bars(a[..., 4], b[i:i + 1][..., 4]) if a.ndim == 3 else bars(a, b[i:i + 1]))
-            ctx.sync()
-            ctx.graph_begin()
-            big.run(lfeed)
-            lg = ctx.graph_end()
-            for _ in range(3):
-                lg.launch()
-            ctx.sync()
-            ctx.timer_start()
-            for _ in range(args.yolo_runs):
-                lg.launch()
-            lms = ctx.timer_stop() / args.yolo_runs
-            lg.close()
-            lrec.update({"ms_per_forward": round(lms, 3), "images_per_s": round(nb / lms * 1e3, 1), "gflop_per_image": 9.127,
-                         "frac_of_the_f32_mfma_peak": round(9.127 * nb / lms / F32_PEAK_TFLOPS, 4),
-                         "max_error_in_units_of_1e-4_vs_the_batch_1_plan": round(worst, 4), "per_image_check_ok": bool(worst <= 1.0)})
-            rec["reference_graph"] = lrec
+            if rank == 0:
+                lx1 = ctx.buf()
+                for i in (0, nb - 1):
+                    o1 = [o.numpy() for o in one.run({lname: TensorView(lx1.upload(limages[i:i + 1]))})]
+                    for a, b in zip(o1, louts):
+                        worst = max(worst, bars(a[..., 4], b[i:i + 1][..., 4]) if a.ndim == 3 else bars(a, b[i:i + 1]))
+            lgraph, lres, t = timed(big, lfeed, 9.127)
+            ref.update(t)
+            ref.update({"graph_equals_eager_bitwise": bool(all(np.array_equal(a, o.numpy()) for a, o in zip(louts, lres))),
+                        "max_error_in_units_of_1e-4_vs_the_batch_1_plan": round(worst, 4), "per_image_check_ok": bool(worst <= 1.0)})
+            lgraph.close()
+            head, head_outs, head_name = ref, lres, "reference"
         except Exception as e:  # noqa: BLE001
-            rec["reference_graph"] = "failed: %s" % e
+            ref = {"failed": str(e)}
+    rec = dict(head)
+    rec["graph"] = ("the reference's own generated Yolo26n-seg call sequence (examples/yolo26n-seg/src/yolo26seg.rs, lifted and re-batched)"
+                    if head_name == "reference" else
+                    "Yolo26n-seg-SHAPED look-alike (no _lifted/yolo26seg_plan.json in this checkout: tools/lift_generated.py lift makes it where the reference is mounted)")
+    if head_name == "reference":
+        rec["lookalike"] = {k: look[k] for k in ("model", "convolutions", "gflop_per_image", "plan_calls", "ms_per_forward", "ms_per_forward_hip_events_rank0",
+                                                 "images_per_s", "tflops_f32_per_gpu", "roofline", "max_error_in_units_of_1e-4", "per_image_check_ok",
+                                                 "graph_equals_eager_bitwise") if k in look}
+    elif ref is not None:
+        rec["reference_graph"] = ref
+    # parity of what runs here (tests/): convolutions 1e-4 against the oracle; whole graphs at batch 64 against the oracle's forward
+    # (tests/test_graph_oracle.py: prototype map, pre-top-k tensors, detections row by row)
+    rec["parity"] = {"conv_bar": 1e-4, "graph_bar": 1e-4,
+                     "conv_epilogue_silu": "replica" if os.environ.get("LELE_HIP_CONV_SILU_EXACT", "0") not in ("", "0")
+                     else "v_exp_f32 / v_rcp_f32 + one Newton step, <= 1e-5 relative + 1e-7 of the reference's"}
+
+    # ---- section 8(e), "C5": collect the batch's outputs.  Per image on the device: score / box filter and mask (image.rs:127-265);
+    # what crosses a link is [300, 38] rows + a count per image.  One step = post-processing + both all-gathers + the read-back.
+    total = world * nb
+    gbufs = [ctx.buf() for _ in range(4)]
+    pbufs = [ctx.buf() for _ in range(3)]
+
+    def collect():
+        dets, counts, _mask = K.yolo_seg_postprocess(head_outs[0], head_outs[1], size, size, 0.25, 80, out_dets=pbufs[0], out_count=pbufs[1],
+                                                     out_mask=pbufs[2], ctx=ctx)
+        if comm is not None:
+            return all_gather_detections_rccl(dets, counts, total, comm, ctx, gbufs)
+        if dist is not None:
+            return all_gather_detections(dets.numpy(), counts.numpy(), total, dist, device)
+        return all_gather_detections(dets.numpy(), counts.numpy(), total)
+    everything = collect()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        everything = collect()
+    fence()
+    gather_ms = 1e3 * max_over_ranks(time.perf_counter() - t0, dist, device) / 3
+    mine = everything[rank * nb:(rank + 1) * nb]
+    local = all_gather_detections(*[a.numpy() for a in K.yolo_seg_postprocess(head_outs[0], head_outs[1], size, size, 0.25, 80, ctx=ctx)[:2]], nb)
+    rec["gather"] = {"what": "per-image detections after lele_hip_yolo_seg_postprocess (threshold 0.25): f32 [images, 300, 38] rows + i32 counts",
+                     "collective": ("rccl all-gather via lele_hip_comm_allgather + lele_hip_comm_allgather_i32" if comm is not None
+                                    else (comm_note or "none (single process)")),
+                     "images": len(everything), "images_expected": total, "bytes_per_rank": nb * (300 * 38 * 4 + 4),
+                     "postprocess_gather_readback_ms": round(gather_ms, 3),
+                     "kept_detections_per_rank": [int(sum(d.shape[0] for d in everything[r * nb:(r + 1) * nb])) for r in range(world)],
+                     "own_block_equals_local_postprocess": bool(len(mine) == len(local) and all(np.array_equal(a, b) for a, b in zip(mine, local)))}
+    if ranks_seen is not None:
+        rec["gather"]["rccl_ranks_seen"] = ranks_seen
+    if rank == 0:
+        rec["_layers"] = layers
     return rec
 
 
@@ -658,10 +745,13 @@ def run_rank(args):
     # 0.55-0.57 ms per step where the steady state is 0.48).
     sv = None
     yo = None
+    comm, comm_note, ranks_seen = open_comm(args, ctx, rank, world, dist, device)
     if not args.no_model:
-        sv = sensevoice_leg(args, ctx, rank, world, fence, dist, device)
+        sv = sensevoice_leg(args, ctx, rank, world, fence, dist, device, comm, comm_note, ranks_seen)
     if not args.no_yolo:
-        yo = yolo_leg(args, ctx, rank, world, fence, dist, device)
+        yo = yolo_leg(args, ctx, rank, world, fence, dist, device, comm, comm_note, ranks_seen)
+    if comm is not None:
+        comm.close()
     fe = frontend_leg(args, ctx, rank, world, fence, dist, device)
 
     if rank == 0:
@@ -700,13 +790,15 @@ def run_rank(args):
                          "valu_issue_source": "issued instructions (rocprofv3 SQ_INSTS_VALU x ISA mix, tools/summarize_profile.py) over the "
                                               "ceiling measured by tools/valu_rate.hip (%s)" % prof.get("valu_peak_source"),
                          "valu_issue_frac_datasheet": round(a / 1e12 / VALU_PEAK_TLANE, 4)})
+        yolo_workload = "not run" if yo is None else ("the reference's own generated graph, lifted and re-batched; the look-alike beside it"
+                                                     if "lookalike" in yo else "the Yolo26n-seg-shaped look-alike: no lifted plan in this checkout")
         line = {
             "metric": "STFT+mel GB/s (SenseVoice front-end: PCM -> log-mel -> LFR, algorithmic bytes); SenseVoiceSmall-shaped RTF in `sensevoice`",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: STFT+mel+LFR, 30 s synthetic 16 kHz mono, batch %d utterances per GPU per step; "
-                                   "configs[2]/[3] SenseVoice-shaped recogniser in `sensevoice`, configs[4] Yolo26n-seg-shaped network at batch 64 per GPU in `yolo`" % args.batch,
+                                   "configs[2]/[3] SenseVoice-shaped recogniser in `sensevoice`, configs[4] Yolo26n-seg at batch 64 per GPU in `yolo` (%s)" % (args.batch, yolo_workload),
                        "samples_per_utterance": n, "frames": fe["nf"], "lfr_rows": fe["t_lfr"], "batch_per_gpu": args.batch,
                        "bytes_per_utterance": fe["bytes_per_utt"], "parallelism": "utterance-sharded x%d" % world},
             "rtf_frontend": round(wall / audio_s, 9),
@@ -734,7 +826,12 @@ def run_rank(args):
             for k in ("ms_per_forward", "images_per_s"):
                 line["yolo_" + k] = yo[k]
         if world == 1 and not args.no_cpu_baseline:  # reported baseline: rank 0 at N=1 only
-            if layers:
+            lifted = os.path.join(ROOT, "_lifted", "yolo26seg_plan.json")
+            if yo is not None and "lookalike" in yo and os.path.exists(lifted):
+                line["yolo"]["cpu_baseline"] = cpu_baseline_yolo_graph(lifted)
+                if layers:
+                    line["yolo"]["lookalike"]["cpu_baseline"] = cpu_baseline_yolo(layers)
+            elif layers:
                 line["yolo"]["cpu_baseline"] = cpu_baseline_yolo(layers)
             cb = cpu_baseline_frontend(n)
             if enc is not None and feats is not None:

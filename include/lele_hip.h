@@ -390,11 +390,12 @@ int lele_hip_token_filter(LeleCtx* ctx, const LeleTensor* ids, const LeleTensor*
  * rgb: U8 [H, W, 3] -> out f32 [1, 3, target, target] */
 int lele_hip_image_preprocess(LeleCtx* ctx, const LeleTensor* rgb, int32_t target, LeleBuf* out, int64_t* out_shape,
                               int32_t* out_rank);
-/* image.rs:127-265 (postprocess_segmentation).  logits: f32 [1, 300, 38] = box(4, 640-space) + score + class id + 32 mask
- * coefficients; mask_features: f32 [1, 32, Hm, Wm].  out_dets: f32 [300, 38], the first *out_count rows are the kept
- * detections in query order (box rescaled and clamped to the image, class id clamped to num_classes - 1);
- * out_count: i32 [1]; out_mask: U8 [img_height, img_width] (255 where a detection's mask covers the pixel).
- * The count stays on the device: the call is graph-capturable. */
+/* image.rs:127-265 (postprocess_segmentation), per image of a batch.  logits: f32 [N, 300, 38] = box(4, 640-space) + score + class id
+ * + 32 mask coefficients; mask_features: f32 [N, 32, Hm, Wm].  out_dets: f32 [N, 300, 38], the first out_count[n] rows of image n are
+ * its kept detections in query order (box rescaled and clamped to the image, class id clamped to num_classes - 1), the rows behind
+ * them zeros (fixed width: what the ranks of a sharded batch exchange, SURVEY.md 8e "C5");
+ * out_count: i32 [N]; out_mask: U8 [N, img_height, img_width] (255 where a detection's mask covers the pixel).
+ * The counts stay on the device: the call is graph-capturable. */
 int lele_hip_yolo_seg_postprocess(LeleCtx* ctx, const LeleTensor* logits, const LeleTensor* mask_features, int32_t img_width,
                                   int32_t img_height, float threshold, int32_t num_classes, LeleBuf* out_dets,
                                   LeleBuf* out_count, LeleBuf* out_mask);
@@ -415,6 +416,10 @@ int lele_hip_comm_rank(const LeleComm* comm, int* rank, int* world);
 /* send: DEVICE i32 tensor of the same element count on every rank -> out [world, count] in rank order, on the ctx stream
  * (graph-capturable; the result is ordered after everything queued before it, e.g. lele_hip_token_filter) */
 int lele_hip_comm_allgather_i32(LeleComm* comm, const LeleTensor* send, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* the same for a DEVICE tensor of any element type (configs[4]: every rank's fixed-width detection rows, f32 [images, 300, 38], and their
+ * i32 counts -- the (logits, mask_features) pair of examples/yolo26n-seg/src/yolo26seg.rs:706-716 after lele_hip_yolo_seg_postprocess):
+ * out [world, ...send's shape] in rank order, moved as bytes */
+int lele_hip_comm_allgather(LeleComm* comm, const LeleTensor* send, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
 /* MAX over ranks of a host scalar, in place (row width of ragged shards, a wall time in ns); synchronises the ctx stream */
 int lele_hip_comm_allreduce_max_i64(LeleComm* comm, int64_t* value);
 int lele_hip_comm_barrier(LeleComm* comm); /* every rank's ctx stream has drained when any rank returns */

@@ -245,6 +245,15 @@ class Comm:
         check(lib().lele_hip_comm_allgather_i32(self._h, as_tensor(send, keep), out._h, sh.shape, C.byref(sh.rank)))
         return DevTensor(out, sh.get(), np.int32)
 
+    def allgather(self, send, out=None):
+        """send: device-resident tensor of any element type (same shape on every rank) -> DevTensor [world, ...shape]"""
+        keep = []
+        out = out or self.ctx.buf()
+        sh = OutShape()
+        t = as_tensor(send, keep)
+        check(lib().lele_hip_comm_allgather(self._h, t, out._h, sh.shape, C.byref(sh.rank)))
+        return DevTensor(out, sh.get(), send.dtype)
+
     def allreduce_max(self, value):
         v = C.c_int64(int(value))
         check(lib().lele_hip_comm_allreduce_max_i64(self._h, C.byref(v)))

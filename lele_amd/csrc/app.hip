@@ -120,10 +120,13 @@ __global__ void image_preprocess_kernel(const uint8_t* __restrict__ rgb, int h, 
 
 constexpr int kQueries = 300, kLogitLen = 38, kMaskDim = 32;  // image.rs:135-136,151
 
-// image.rs:159-203: one workgroup; kept queries are written in query order
-__global__ __launch_bounds__(320) void yolo_dets_kernel(const float* __restrict__ logits, float img_w, float img_h, float threshold,
-                                                        int num_classes, float* __restrict__ dets, int32_t* __restrict__ count) {
+// image.rs:159-203: one workgroup an image (blockIdx.x); kept queries are written in query order, the rows behind them are zeros
+__global__ __launch_bounds__(320) void yolo_dets_kernel(const float* __restrict__ logits_all, float img_w, float img_h, float threshold,
+                                                        int num_classes, float* __restrict__ dets_all, int32_t* __restrict__ count_all) {
     __shared__ int wave_cnt[5];
+    const float* logits = logits_all + (int64_t)blockIdx.x * kQueries * kLogitLen;
+    float* dets = dets_all + (int64_t)blockIdx.x * kQueries * kLogitLen;
+    int32_t* count = count_all + blockIdx.x;
     const int i = threadIdx.x, lane = i & 63, wave = i >> 6;
     const float* q = logits + (int64_t)(i < kQueries ? i : 0) * kLogitLen;
     const float score = q[4];
@@ -149,13 +152,21 @@ __global__ __launch_bounds__(320) void yolo_dets_kernel(const float* __restrict_
         d[5] = (float)cid;
         for (int j = 0; j < kMaskDim; ++j) d[6 + j] = q[6 + j];
     }
-    if (i == 0) *count = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3] + wave_cnt[4];
+    const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3] + wave_cnt[4];
+    if (i == 0) *count = total;
+    // rows [total, 300): zeros (upstream returns a Vec of `total` detections; a fixed-width buffer that travels between ranks must not
+    // carry whatever the allocation held).  The kept rows lie below `total`, written by other threads: disjoint.
+    for (int r = total + i; r < kQueries; r += blockDim.x)
+        for (int j = 0; j < kLogitLen; ++j) dets[(int64_t)r * kLogitLen + j] = 0.0f;
 }
 
 // image.rs:213-262: one thread per image pixel; a pixel is set when ANY kept detection covers it (order-free)
-__global__ void yolo_mask_kernel(const float* __restrict__ dets, const int32_t* __restrict__ count, const float* __restrict__ feat,
-                                 int mask_h, int mask_w, int img_w, int img_h, uint8_t* __restrict__ mask_img) {
-    const int total = img_w * img_h, n = *count;
+__global__ void yolo_mask_kernel(const float* __restrict__ dets_all, const int32_t* __restrict__ count_all, const float* __restrict__ feat_all,
+                                 int mask_h, int mask_w, int img_w, int img_h, uint8_t* __restrict__ mask_all) {
+    const int total = img_w * img_h, n = count_all[blockIdx.y];   // blockIdx.y = the image
+    const float* dets = dets_all + (int64_t)blockIdx.y * kQueries * kLogitLen;
+    const float* feat = feat_all + (int64_t)blockIdx.y * kMaskDim * mask_h * mask_w;
+    uint8_t* mask_img = mask_all + (int64_t)blockIdx.y * total;
     const float scale_x = (float)mask_w / (float)img_w, scale_y = (float)mask_h / (float)img_h;
     const int plane = mask_h * mask_w;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -274,12 +285,16 @@ int lele_hip_yolo_seg_postprocess(LeleCtx* ctx, const LeleTensor* logits, const 
                                   int32_t img_height, float threshold, int32_t num_classes, LeleBuf* out_dets,
                                   LeleBuf* out_count, LeleBuf* out_mask) {
     LELE_REQUIRE(ctx && logits && mask_features && out_dets && out_count && out_mask, "yolo_seg_postprocess: NULL argument");
-    LELE_REQUIRE(logits->dtype == LELE_F32 && numel(logits) == (int64_t)kQueries * kLogitLen,
-                 "yolo_seg_postprocess: logits must hold 300 x 38 f32 values");
+    const int64_t per = (int64_t)kQueries * kLogitLen;
+    LELE_REQUIRE(logits->dtype == LELE_F32 && numel(logits) > 0 && numel(logits) % per == 0,
+                 "yolo_seg_postprocess: logits must hold N x 300 x 38 f32 values");
+    const int64_t images = numel(logits) / per;   // upstream: one image a call (image.rs:127); a batch is the same routine per image
     LELE_REQUIRE(mask_features->dtype == LELE_F32, "yolo_seg_postprocess: f32 mask features required");
     LELE_REQUIRE(img_width > 0 && img_height > 0 && (int64_t)img_width * img_height < (int64_t(1) << 31) && num_classes > 0,
                  "yolo_seg_postprocess: bad image size or class count");
-    const int64_t mask_hw = numel(mask_features) / kMaskDim;                 // image.rs:142-145
+    LELE_REQUIRE(numel(mask_features) % (images * kMaskDim) == 0 && images < 65536, "yolo_seg_postprocess: mask features do not match %lld images",
+                 (long long)images);
+    const int64_t mask_hw = numel(mask_features) / (images * kMaskDim);      // image.rs:142-145
     const int mask_h = (int)sqrtf((float)mask_hw), mask_w = mask_h;
     LELE_REQUIRE(mask_h > 0, "yolo_seg_postprocess: empty mask features");
     LELE_HIP_CHECK(hipSetDevice(ctx->device));
@@ -287,13 +302,13 @@ int lele_hip_yolo_seg_postprocess(LeleCtx* ctx, const LeleTensor* logits, const 
     const void *dl = nullptr, *df = nullptr;
     LELE_TRY(ctx->dev_ptr(logits, &dl));
     LELE_TRY(ctx->dev_ptr(mask_features, &df));
-    LELE_TRY(out_dets->reserve((size_t)kQueries * kLogitLen * 4));
-    LELE_TRY(out_count->reserve(4));
-    LELE_TRY(out_mask->reserve((size_t)img_width * img_height));
-    hipLaunchKernelGGL(yolo_dets_kernel, dim3(1), dim3(320), 0, ctx->stream, (const float*)dl, (float)img_width, (float)img_height,
+    LELE_TRY(out_dets->reserve((size_t)(images * per) * 4));
+    LELE_TRY(out_count->reserve((size_t)images * 4));
+    LELE_TRY(out_mask->reserve((size_t)images * img_width * img_height));
+    hipLaunchKernelGGL(yolo_dets_kernel, dim3((unsigned)images), dim3(320), 0, ctx->stream, (const float*)dl, (float)img_width, (float)img_height,
                        threshold, num_classes, (float*)out_dets->data, (int32_t*)out_count->data);
     const int total = img_width * img_height;
-    hipLaunchKernelGGL(yolo_mask_kernel, dim3(std::min((total + 255) / 256, 16384)), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(yolo_mask_kernel, dim3(std::min((total + 255) / 256, 16384), (unsigned)images), dim3(256), 0, ctx->stream,
                        (const float*)out_dets->data, (const int32_t*)out_count->data, (const float*)df, mask_h, mask_w, img_width,
                        img_height, (uint8_t*)out_mask->data);
     LELE_HIP_CHECK(hipGetLastError());

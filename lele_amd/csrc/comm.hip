@@ -30,7 +30,7 @@ struct UniqueId {
 };
 typedef void* Comm;
 // rccl.h:52 ncclSuccess = 0; :448-450 ncclMax = 2; :459-463 ncclInt32 = 2, ncclInt64 = 4
-constexpr int kInt32 = 2, kInt64 = 4, kMax = 2;
+constexpr int kUint8 = 1, kInt32 = 2, kInt64 = 4, kMax = 2;  // ncclDataType_t / ncclRedOp_t values
 
 struct Rccl {
     void* handle = nullptr;
@@ -204,6 +204,21 @@ int lele_hip_comm_allgather_i32(LeleComm* c, const LeleTensor* send, LeleBuf* ou
     LELE_TRY(out->reserve((size_t)c->world * count * 4));
     if (count) LELE_RCCL_CHECK(c->api, c->api->AllGather(send->data, out->data, (size_t)count, kInt32, c->comm, ctx->stream));
     return set_shape(out_shape, out_rank, {(int64_t)c->world, count});
+}
+
+/* any element type: `bytes` of device memory from every rank, [world, ...shape] in rank order, on the ctx stream */
+int lele_hip_comm_allgather(LeleComm* c, const LeleTensor* send, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(c && send && out, "comm_allgather: NULL argument");
+    LELE_REQUIRE(send->mem == LELE_MEM_DEVICE, "comm_allgather: the send tensor must be device memory");
+    LELE_REQUIRE(send->rank + 1 <= LELE_MAX_RANK, "comm_allgather: rank %d leaves no room for the rank axis", send->rank);
+    LeleCtx* ctx = c->ctx;
+    LELE_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)numel(send) * dtype_size(send->dtype);
+    LELE_TRY(out->reserve((size_t)c->world * bytes));
+    if (bytes) LELE_RCCL_CHECK(c->api, c->api->AllGather(send->data, out->data, bytes, kUint8, c->comm, ctx->stream));
+    std::vector<int64_t> shape{(int64_t)c->world};
+    shape.insert(shape.end(), send->shape, send->shape + send->rank);
+    return set_shape_v(out_shape, out_rank, shape);
 }
 
 /* MAX over ranks of a host scalar (row widths of ragged shards; the bench's wall time in ns): one tiny all-reduce + sync */

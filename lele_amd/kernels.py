@@ -808,16 +808,19 @@ def image_preprocess(rgb, target=640, out=None, ctx=None):
 
 def yolo_seg_postprocess(logits, mask_features, img_width, img_height, threshold, num_classes=80, out_dets=None, out_count=None,
                          out_mask=None, ctx=None):
-    """image.rs:127-265 -> (dets f32 [300, 38] of which the first `count` rows are valid, count i32 [1], mask u8 [H, W])"""
+    """image.rs:127-265, per image of a batch -> (dets f32 [N, 300, 38] of which the first count[n] rows of image n are valid and the
+    rest zeros, count i32 [N], mask u8 [N, H, W]); a single image ([1, 300, 38] / [300, 38]) gives [300, 38], [1], [H, W] as before"""
     ctx = _ctx(ctx)
     keep = []
     od, oc, om = out_dets or ctx.buf(), out_count or ctx.buf(), out_mask or ctx.buf()
+    n = int(np.prod(unwrap(logits).shape, dtype=np.int64)) // (300 * 38)
     _lib.check(_lib.lib().lele_hip_yolo_seg_postprocess(ctx._h, _lib.as_tensor(unwrap(logits), keep),
                                                         _lib.as_tensor(unwrap(mask_features), keep), C.c_int32(int(img_width)),
                                                         C.c_int32(int(img_height)), C.c_float(float(threshold)),
                                                         C.c_int32(int(num_classes)), od._h, oc._h, om._h))
-    return (TensorView(_lib.DevTensor(od, [300, 38], np.float32)), TensorView(_lib.DevTensor(oc, [1], np.int32)),
-            TensorView(_lib.DevTensor(om, [int(img_height), int(img_width)], np.uint8)))
+    lead = [n] if n != 1 else []
+    return (TensorView(_lib.DevTensor(od, lead + [300, 38], np.float32)), TensorView(_lib.DevTensor(oc, [n], np.int32)),
+            TensorView(_lib.DevTensor(om, lead + [int(img_height), int(img_width)], np.uint8)))
 
 
 def _reshape_strides(shape, strides, new):

@@ -182,3 +182,23 @@ def test_device_yolo_postprocess_matches_oracle(ctx):
         assert (got_mask != want_mask).mean() <= 1e-5, (seed, (got_mask != want_mask).sum())
     dets, count, mask = K.yolo_seg_postprocess(logits, feat, 64, 64, 1.5, 80, ctx=ctx)   # nothing passes
     assert int(count.numpy()[0]) == 0 and not mask.numpy().any()
+
+
+@pytest.mark.gpu
+def test_device_yolo_postprocess_over_a_batch_is_the_per_image_routine(ctx):
+    """[N, 300, 38] + [N, 32, Hm, Wm] in one call == image.rs:127-265 image by image (the oracle), and the rows behind an image's kept
+    detections are zeros: the fixed-width block the ranks of a sharded batch exchange ("C5")"""
+    from lele_amd import kernels as K
+    from oracle import pyoracle as O
+    rng = np.random.default_rng(11)
+    pairs = [_seg_inputs(rng, n_keep=4 + 5 * i, hm=40) for i in range(5)]
+    logits = np.concatenate([p[0].reshape(1, 300, 38) for p in pairs])
+    feat = np.concatenate([p[1].reshape(1, 32, 40, 40) for p in pairs])
+    dets, count, mask = K.yolo_seg_postprocess(logits, feat, 96, 72, 0.5, 80, ctx=ctx)
+    d, c, m = dets.numpy(), count.numpy(), mask.numpy()
+    assert d.shape == (5, 300, 38) and c.shape == (5,) and m.shape == (5, 72, 96)
+    for i, (lg, ft) in enumerate(pairs):
+        want_dets, want_mask = O.yolo_seg_postprocess(lg, ft, 96, 72, 0.5)
+        assert c[i] == want_dets.shape[0] and np.array_equal(d[i, :c[i]], want_dets) and not d[i, c[i]:].any(), i
+        assert (m[i] != want_mask).mean() <= 1e-4, i
+    assert len(set(c.tolist())) > 1          # the images really keep different numbers of rows

@@ -43,6 +43,34 @@ def test_one_rank_communicator_through_the_c_abi(ctx, tmp_path):
     comm.close()
 
 
+def test_gather_of_detection_rows_through_the_c_abi(ctx, tmp_path):
+    """configs[4]'s exchange: post-processing on the device per image, then the fixed-width rows and their counts gathered with
+    lele_hip_comm_allgather (any element type, moved as bytes) + lele_hip_comm_allgather_i32 -- a 1-rank communicator here (see the
+    module docstring); the packing / ragged-shard logic at world 2 is tests/test_multiprocess.py's gloo test"""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Comm
+    from lele_amd.sharded import all_gather_detections, all_gather_detections_rccl
+    from oracle import pyoracle as O
+    from tests.test_app_steps import _seg_inputs
+    comm = Comm.from_file(ctx, str(tmp_path / "uid"), 0, 1, timeout_ms=10000)
+    x = np.arange(2 * 3 * 5, dtype=np.float32).reshape(2, 3, 5) / 7
+    got = comm.allgather(ctx.buf().upload(x))
+    assert got.shape == (1, 2, 3, 5) and got.dtype == np.float32 and np.array_equal(got.numpy()[0], x)
+    u = np.arange(11, dtype=np.uint8)
+    assert np.array_equal(comm.allgather(ctx.buf().upload(u)).numpy(), u[None])
+    rng = np.random.default_rng(21)
+    pairs = [_seg_inputs(rng, hm=32) for _ in range(3)]
+    logits = np.concatenate([p[0].reshape(1, 300, 38) for p in pairs])
+    feat = np.concatenate([p[1].reshape(1, 32, 32, 32) for p in pairs])
+    dets, count, _mask = K.yolo_seg_postprocess(logits, feat, 64, 64, 0.5, 80, ctx=ctx)
+    via_rccl = all_gather_detections_rccl(dets, count, 3, comm, ctx)
+    local = all_gather_detections(dets.numpy(), count.numpy(), 3)
+    assert len(via_rccl) == 3 and all(np.array_equal(a, b) for a, b in zip(via_rccl, local))
+    for i, (lg, ft) in enumerate(pairs):
+        assert np.array_equal(via_rccl[i], O.yolo_seg_postprocess(lg, ft, 64, 64, 0.5)[0])
+    comm.close()
+
+
 def test_rendezvous_file_of_another_job_is_refused(ctx, tmp_path, monkeypatch):
     """[32-byte job token][128-byte id]: a reader takes only a file that carries the digest of ITS LELE_JOB_ID -- not what an earlier
     job left under the same name (whatever its age), not a file of another size -- and rank 0 replaces what it finds"""
@@ -110,3 +138,6 @@ def test_bench_two_ranks_on_one_gpu_end_to_end():
     assert sv["c4_utterances"] == 8 and sv["c4_gathered_ok"] is True
     assert "rccl" in sv["c4_collective"] or "torch.distributed" in sv["c4_collective"]
     assert "rtf_model" not in line and "cpu_baseline" not in line          # N = 1 only
+    g = line["yolo"]["gather"]                                             # configs[4]: every image's detections reached every rank
+    assert g["images"] == g["images_expected"] == 2 * 64 and g["own_block_equals_local_postprocess"] is True
+    assert "rccl" in g["collective"] or "torch.distributed" in g["collective"]

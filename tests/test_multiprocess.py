@@ -138,6 +138,61 @@ def test_all_gather_of_decoded_ids_two_ranks_gloo(tmp_path):
         assert json.loads(out.strip().splitlines()[-1])["ids"] == want
 
 
+DET_WORKER = '''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["LELE_ROOT"])
+import torch.distributed as dist
+from lele_amd.sharded import all_gather_detections, shard_range
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+total = 5
+lo, hi = shard_range(total, rank, world)
+dets = np.stack([np.random.default_rng(300 + i).standard_normal((300, 38)).astype(np.float32) for i in range(lo, hi)])
+counts = np.array([(7 * i + 3) % 301 for i in range(lo, hi)], np.int32)   # what yolo_seg_postprocess leaves: `count` kept rows per image
+everything = all_gather_detections(dets, counts, total, dist)
+print(json.dumps({"rank": rank, "counts": [int(d.shape[0]) for d in everything], "sums": [float(d.astype(np.float64).sum()) for d in everything]}))
+dist.destroy_process_group()
+'''
+
+
+def test_all_gather_of_detections_two_ranks_gloo(tmp_path):
+    """configs[4]'s only exchange (section 8e, "C5"): every rank ends up with the kept detections of every image of the batch, in global
+    image order -- 5 images over 2 ranks (a ragged last shard), fixed-width rows, the garbage behind an image's kept rows never sent"""
+    port = _free_port()
+    script = tmp_path / "det_worker.py"
+    script.write_text(DET_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LELE_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    want_counts = [(7 * i + 3) % 301 for i in range(5)]
+    want_sums = [float(np.random.default_rng(300 + i).standard_normal((300, 38)).astype(np.float32)[:want_counts[i]].astype(np.float64).sum()) for i in range(5)]
+    for out, _err in outs:
+        rec = json.loads(out.strip().splitlines()[-1])
+        assert rec["counts"] == want_counts and np.allclose(rec["sums"], want_sums, rtol=0, atol=1e-9)
+
+
+def test_pack_detections_round_trip_and_refusals():
+    import pytest
+    from lele_amd.sharded import all_gather_detections, pack_detections, unpack_detections
+    dets = np.random.default_rng(1).standard_normal((2, 300, 38)).astype(np.float32)
+    counts = np.array([300, 0], np.int32)
+    packed = pack_detections(dets, counts, 3)
+    assert packed.shape == (3, 1 + 300 * 38) and packed[:, 0].tolist() == [300.0, 0.0, -1.0] and not packed[1:, 1:].any()
+    got = unpack_detections(packed)
+    assert len(got) == 2 and np.array_equal(got[0], dets[0]) and got[1].shape == (0, 38)
+    assert [g.shape[0] for g in all_gather_detections(dets, counts, 2)] == [300, 0]
+    with pytest.raises(ValueError):
+        pack_detections(dets, counts, 1)
+    with pytest.raises(ValueError):
+        pack_detections(dets, np.array([301, 0], np.int32), 3)
+    with pytest.raises(ValueError):
+        all_gather_detections(dets, counts, 3)
+
+
 def test_pack_ids_rejects_what_does_not_fit():
     import pytest
     from lele_amd.sharded import all_gather_ids, pack_ids, unpack_ids
