@@ -466,6 +466,51 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_
                     "rtf_target": 0.001})
         rec["_c3_feats"] = c3["feats"].numpy()
         rec["_enc"] = enc
+        # the same two figures with the attention on its bit-exact replica path (LELE_HIP_ATTENTION_EXACT=1: f32 MFMA in the tiled GEMM's
+        # k order + the reference's row softmax = the bits of the three-call sequence): graphs re-recorded under the switch
+        old = os.environ.get("LELE_HIP_ATTENTION_EXACT")
+        os.environ["LELE_HIP_ATTENTION_EXACT"] = "1"
+        try:
+            c3x = build(1, 30, 0)
+            tx = []
+            for _ in range(runs):
+                ctx.sync()
+                t0 = time.perf_counter()
+                c3x["graph"].launch()
+                ctx.sync()
+                tx.append(time.perf_counter() - t0)
+            c4x = build(hi - lo, 10, lo)
+
+            def step_c4x():
+                c4x["features"]()
+                c4x["graph"].launch()
+                ids, counts = c4x["decode"]()
+                return all_gather_ids(ids.numpy(), counts.numpy(), total)
+            for _ in range(2):
+                ex_ids = step_c4x()
+            ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.sv_steps):
+                ex_ids = step_c4x()
+            ctx.sync()
+            wx = time.perf_counter() - t0
+            la, lb = c4["logits"].numpy().astype(np.float64), c4x["logits"].numpy().astype(np.float64)
+            lrms = float(np.sqrt(np.mean(la * la)))
+            tok = [(int((a[:min(len(a), len(b))] == b[:min(len(a), len(b))]).sum()), max(len(a), len(b))) for a, b in zip(ex_ids, everything)]
+            rec.update({"rtf_model_exact": round(float(np.mean(tx)) / 30.0, 7), "c3_model_ms_exact": round(1e3 * float(np.mean(tx)), 3),
+                        "rtf_c4_exact": round(wx / args.sv_steps / (total * 10), 8), "c4_ms_per_step_exact": round(1e3 * wx / args.sv_steps, 3),
+                        "exact_vs_default_logits_max_abs_diff_over_rms": round(float(np.abs(la - lb).max()) / lrms, 6),
+                        "exact_vs_default_logits_rms_diff_over_rms": round(float(np.sqrt(np.mean((la - lb) ** 2))) / lrms, 6),
+                        "exact_vs_default_equal_token_positions": round(sum(t[0] for t in tok) / max(1, sum(t[1] for t in tok)), 4),
+                        "exact_note": "LELE_HIP_ATTENTION_EXACT=1: attention = the bits of matmul -> softmax -> matmul.  The two paths' logits differ by "
+                                      "the figures beside this note (70 layers of per-utterance DYNAMIC u8 quantisation turn a last-bit difference "
+                                      "into flipped codes); with synthetic weights the 25055 logits of a frame are near-ties, so the arg-max ids "
+                                      "of the two paths agree only where a frame happens to have a clear winner"})
+        finally:
+            if old is None:
+                os.environ.pop("LELE_HIP_ATTENTION_EXACT", None)
+            else:
+                os.environ["LELE_HIP_ATTENTION_EXACT"] = old
     return rec
 
 
@@ -808,7 +853,7 @@ def run_rank(args):
         if sv is not None:
             feats, enc = sv.pop("_c3_feats", None), sv.pop("_enc", None)
             line["sensevoice"] = sv
-            for k in ("rtf_model", "rtf_e2e", "rtf_c4", "audio_s_per_s"):
+            for k in ("rtf_model", "rtf_e2e", "rtf_c4", "audio_s_per_s", "rtf_model_exact", "rtf_c4_exact"):
                 if k in sv:
                     line[k] = sv[k]
             q = sv.get("qlinear")

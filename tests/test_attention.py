@@ -1,8 +1,15 @@
 """lele_hip_attention_view: softmax(Q K^T * scale) V in one launch (emitted by lele_amd.compiler in place of
-matmul_view -> softmax_scaled -> matmul_view).  Checked (a) operator by operator against the oracle on the device's own
-intermediates' definition -- Q K^T and P V within 1e-4 of the f64-accumulated products, softmax through the oracle's
-restatement of avx/norm.rs:139-229 -- and (b) against the three-call sequence it replaces, which it must equal within the
-same bar (bit for bit where both take the tiled GEMM's k order)."""
+matmul_view -> softmax_scaled -> matmul_view).  Two kinds of check:
+
+(a) the FINAL output against the oracle's three-operator composition (matmul -> softmax -> matmul, each inside 1e-4 of the reference
+    by its own test) at 2e-4, and against the three-call sequence the kernel replaces at 1e-4
+    (test_attention_view_against_oracle_and_sequence, test_one_pass_attention_of_a_batch_against_the_oracle);
+(b) OPERATOR BY OPERATOR at the north_star bar of 1e-4, through the fused kernel itself -- it has no taps, so the operands are chosen
+    to make it hand an intermediate back (test_fused_attention_operator_by_operator):
+      * V = one-hot rows (a 128-key chunk at a time): O IS the probability matrix P, exactly -- P against
+        orc.softmax(orc.matmul(q, kT) * scale): the score product and the softmax;
+      * K^T = 2^k I: the scores ARE 2^k Q, exactly -- P read back the same way against orc.softmax of that: the softmax stage alone;
+      * Q = 0: P is uniform -- O = mean over the keys of V against the f64 mean: the P V product alone."""
 import os
 
 import numpy as np
@@ -133,3 +140,62 @@ def test_attention_view_other_geometries_run_the_sequence(ctx, orc):
     got = K.attention_view(q, [], kT, [], v, [], None, ctx=ctx).numpy()
     o = orc.matmul(orc.softmax(orc.matmul(q, kT), -1), v)
     close(got, o, "sequence fallback", rtol=2e-4)
+
+
+def _views(b, t, q, k, v):
+    """separate [b, t, 512] buffers for Q, K, V as the views the compiler hands the kernel"""
+    qc = [["reshape", [0, 0, H, DH]], ["transpose", [0, 2, 1, 3]]]
+    kc = [["reshape", [0, 0, H, DH]], ["transpose", [0, 2, 3, 1]]]
+    return (q, qc, k, kc, v, qc)
+
+
+@pytest.mark.parametrize("exact", [0, 1])
+@pytest.mark.parametrize("b,t", [(32, 171), (1, 504), (64, 171), (16, 512), (8, 171)])
+def test_fused_attention_operator_by_operator(ctx, orc, b, t, exact):
+    """see the module docstring, (b).  (32, 171) / (64, 171) / (16, 512): attention_flash_kernel (with EXACT: the 64- / 32-row f32
+    replicas); (1, 504): attention16_kernel; (8, 171): attention_kernel.  Every comparison at 1e-4."""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    rng = np.random.default_rng(b * 31 + t)
+    scale_v = np.float32(DH ** -0.5)
+    scale = Weight(np.array([scale_v], np.float32))
+    q = (rng.standard_normal((b, t, H * DH)) * 1.5).astype(np.float32)
+    k = (rng.standard_normal((b, t, H * DH)) * 1.5).astype(np.float32)
+    v = (rng.standard_normal((b, t, H * DH)) * 1.5).astype(np.float32)
+    qh = np.ascontiguousarray(q.reshape(b, t, H, DH).transpose(0, 2, 1, 3))
+    kT = np.ascontiguousarray(k.reshape(b, t, H, DH).transpose(0, 2, 3, 1))
+    vh = np.ascontiguousarray(v.reshape(b, t, H, DH).transpose(0, 2, 1, 3))
+    qd, kd = ctx.buf().upload(q), ctx.buf().upload(k)
+
+    def run(qb, kb, vb):
+        with _env(LELE_HIP_ATTENTION_MIN_BLOCKS=1, LELE_HIP_ATTENTION_EXACT=exact):
+            return K.attention_view(*_views(b, t, qb, kb, vb), scale, None, None, ctx=ctx).numpy()      # [b, H, t, DH]
+
+    def read_p(qb, kb):
+        """the kernel's probability matrix [b, H, t, t], read back 128 keys at a time through one-hot value rows"""
+        p = np.zeros((b, H, t, t), np.float32)
+        for c0 in range(0, t, DH):
+            n = min(DH, t - c0)
+            one_hot = np.zeros((b, t, H, DH), np.float32)
+            one_hot[:, c0 + np.arange(n), :, np.arange(n)] = 1.0        # value row of key c0 + d = e_d, in every head
+            o = run(qb, kb, ctx.buf().upload(one_hot.reshape(b, t, H * DH)))
+            p[..., c0:c0 + n] = o[..., :n]
+            assert not o[..., n:].any() or n == DH
+        return p
+    # 1. score product + softmax
+    p_dev = read_p(qd, kd)
+    p_ref = orc.softmax(orc.matmul(qh, kT) * scale_v, -1)
+    close(p_dev, p_ref, "P = softmax(Q K^T s) read back through one-hot V")
+    assert np.abs(p_dev.sum(-1) - 1).max() < 1e-5
+    # 2. the softmax stage alone: K^T = 4 I (its first 128 keys; the others zero) -> scores = 4 Q exactly (0 beyond key 128)
+    k_id = np.zeros((b, t, H, DH), np.float32)
+    n = min(DH, t)
+    k_id[:, np.arange(n), :, np.arange(n)] = 4.0
+    s_exact = np.zeros((b, H, t, t), np.float32)
+    s_exact[..., :n] = 4.0 * qh[..., :n]
+    p_dev2 = read_p(qd, ctx.buf().upload(k_id.reshape(b, t, H * DH)))
+    close(p_dev2, orc.softmax(s_exact * scale_v, -1), "softmax of exactly known scores")
+    # 3. the P V product alone: Q = 0 -> P = 1 / t everywhere -> O = mean over keys of V
+    o3 = run(ctx.buf().upload(np.zeros_like(q)), kd, ctx.buf().upload(v))
+    want = np.broadcast_to(vh.astype(np.float64).mean(axis=2, keepdims=True), vh.shape)
+    close(o3, want.astype(np.float32), "uniform P times V against the f64 mean")
