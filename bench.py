@@ -621,6 +621,29 @@ def yolo_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_note=N
                                                   "some 1 x 1) run on the bf16 matrix cores: six bf16 MFMAs a product, i.e. a ceiling of 2500 / 6 = 417 TFLOP/s "
                                                   "of f32-equivalent work for those layers" % gflop_per_image}}
 
+    def as_dag(runner, feed, want):
+        """the plan with its independent branches on lanes (lele_amd/lanes.py): per-statement device times of one eager pass (trains of 8
+        launches), list scheduling over 3 lanes where a fork buys at least 40 us (a fork / join pair costs a hipGraph ~8 us:
+        profiles/r05_dag_bench.json), buffers re-assigned under happens-before.  Used only when its outputs equal `want` bit for bit."""
+        from lele_amd.lanes import schedule
+        try:
+            runner.stmt_times, runner.stmt_repeat = [], 8
+            runner.run(feed)
+            times = {o: ms for _i, _fn, o, ms in runner.stmt_times}
+            runner.stmt_times, runner.stmt_repeat = None, 1
+            dag = schedule(runner.plan, times, lanes=3, min_gain_ms=0.04)
+            if dag is None or dag["dag"]["lanes"] < 2:
+                return runner, {"used": False, "why": "no branch worth a fork"}
+            r2 = Runner(dag, runner.raw, ctx)
+            got = [o.numpy() for o in r2.run(feed)]
+            if not all(np.array_equal(a, b) for a, b in zip(want, got)):
+                return runner, {"used": False, "why": "the DAG plan's outputs differ from the sequential plan's"}
+            return r2, dict(dag["dag"], used=True, min_gain_ms=0.04)
+        except Exception as e:  # noqa: BLE001
+            runner.stmt_times, runner.stmt_repeat = None, 1
+            ctx.lane_set(0)
+            return runner, {"used": False, "why": "failed: %s" % e}
+
     # ---- the look-alike (always available)
     data, info = yolo_onnx(nb, size)
     plan, blob = compile_model(data, "yolo26n_seg_shaped_n%d" % nb)
@@ -646,6 +669,11 @@ def yolo_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_note=N
         look.update({"channel_views": folded["folded"], "plan_calls": r1.calls, "folded_equals_unfolded_bitwise": True})
     except Exception as e:  # noqa: BLE001  -- the leg is still measured, on the unfolded plan, and says so
         look["channel_views"] = "channel views NOT used: %s" % e
+    if not args.no_dag:
+        graph, _o, t_lin = timed(runner, feed, info["gflop_per_image"])
+        graph.close()
+        runner, look["dag"] = as_dag(runner, feed, base)
+        look["dag"]["linear_graph_ms"] = t_lin["ms_per_forward_hip_events_rank0"]
     graph, outs, t = timed(runner, feed, info["gflop_per_image"])
     look.update(t)
     look.update({"graph_equals_eager_bitwise": bool(all(np.array_equal(a, o.numpy()) for a, o in zip(base, outs))),
@@ -680,6 +708,11 @@ def yolo_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_note=N
                     o1 = [o.numpy() for o in one.run({lname: TensorView(lx1.upload(limages[i:i + 1]))})]
                     for a, b in zip(o1, louts):
                         worst = max(worst, bars(a[..., 4], b[i:i + 1][..., 4]) if a.ndim == 3 else bars(a, b[i:i + 1]))
+            if not args.no_dag:
+                lgraph, _o, t_lin = timed(big, lfeed, 9.127)
+                lgraph.close()
+                big, ref["dag"] = as_dag(big, lfeed, louts)
+                ref["dag"]["linear_graph_ms"] = t_lin["ms_per_forward_hip_events_rank0"]
             lgraph, lres, t = timed(big, lfeed, 9.127)
             ref.update(t)
             ref.update({"graph_equals_eager_bitwise": bool(all(np.array_equal(a, o.numpy()) for a, o in zip(louts, lres))),
@@ -693,7 +726,7 @@ def yolo_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_note=N
                     if head_name == "reference" else
                     "Yolo26n-seg-SHAPED look-alike (no _lifted/yolo26seg_plan.json in this checkout: tools/lift_generated.py lift makes it where the reference is mounted)")
     if head_name == "reference":
-        rec["lookalike"] = {k: look[k] for k in ("model", "convolutions", "gflop_per_image", "plan_calls", "ms_per_forward", "ms_per_forward_hip_events_rank0",
+        rec["lookalike"] = {k: look[k] for k in ("model", "convolutions", "gflop_per_image", "plan_calls", "dag", "ms_per_forward", "ms_per_forward_hip_events_rank0",
                                                  "images_per_s", "tflops_f32_per_gpu", "roofline", "max_error_in_units_of_1e-4", "per_image_check_ok",
                                                  "graph_equals_eager_bitwise") if k in look}
     elif ref is not None:
@@ -963,6 +996,7 @@ def main():
     ap.add_argument("--layers", type=int, default=70)
     ap.add_argument("--no-model", action="store_true", help="skip the SenseVoice-shaped recogniser legs")
     ap.add_argument("--no-yolo", action="store_true", help="skip the configs[4] leg")
+    ap.add_argument("--no-dag", action="store_true", help="configs[4]: record the plans as linear graphs (default: independent branches on lanes, lele_amd/lanes.py)")
     ap.add_argument("--yolo-batch", type=int, default=64, help="configs[4]: 640 x 640 images per GPU per forward")
     ap.add_argument("--yolo-runs", type=int, default=10, help="configs[4]: timed forwards after 3 warm-up ones (examples/yolo26n-seg/src/benchmark.rs:29-56)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

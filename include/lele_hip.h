@@ -87,6 +87,21 @@ int lele_hip_graph_end(LeleCtx* ctx, LeleGraph** out);
 int lele_hip_graph_abort(LeleCtx* ctx);
 int lele_hip_graph_launch(LeleGraph* graph);
 int lele_hip_graph_destroy(LeleGraph* graph);
+/* Lanes: a ctx owns up to 4 HIP streams.  lele's generated forward() is a SEQUENCE, but the graph behind it is not: the FSMN memory
+ * block of a SenseVoice layer does not depend on the attention beside it, the three detection heads of Yolo26n-seg not on each other
+ * (examples/yolo26n-seg/src/yolo26seg.rs:509-627).  A plan runner that knows the dependencies issues independent branches on
+ * different lanes; recorded between graph_begin and graph_end they become parallel branches of ONE hipGraph (while capturing, a lane
+ * is a chain of graph nodes and an event the set of nodes it stands for: node-to-node edges on the one capturing stream).
+ *   lane_set    : ops issued from now on go to `lane` (0 = the ctx stream of lele_hip_ctx_stream).  A lane has its own stream,
+ *                 staging arena, scratch block and temporary buffers; it is created on first use (not while capturing: run the
+ *                 sequence once eagerly with its lanes, as for every other allocation).  Results are ordered between lanes ONLY by
+ *                 record / wait: the caller orders every cross-lane read-after-write, write-after-read and write-after-write.
+ *   lane_record : event := everything issued on the current lane so far.
+ *   lane_wait   : the current lane continues only after that point.
+ * lele_hip_sync drains every lane; buf_to_host / graph_launch / the communicator use the CURRENT lane (call them on lane 0). */
+int lele_hip_lane_set(LeleCtx* ctx, int lane);
+int lele_hip_lane_record(LeleCtx* ctx, int event);
+int lele_hip_lane_wait(LeleCtx* ctx, int event);
 /* stream-ordered stopwatch (HIP events on the ctx stream) used by bench.py */
 int lele_hip_timer_start(LeleCtx* ctx);
 int lele_hip_timer_stop(LeleCtx* ctx, float* elapsed_ms);

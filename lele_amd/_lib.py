@@ -150,6 +150,27 @@ class Ctx:
         self._graphs.append(weakref.ref(g))
         return g
 
+    # lanes (include/lele_hip.h, lele_hip_lane_*): extra streams of this context for plans run as a DAG (lele_amd/lanes.py)
+    cur_lane = 0
+    _next_event = 0
+
+    def lane_set(self, lane):
+        if lane != self.cur_lane:
+            check(lib().lele_hip_lane_set(self._h, C.c_int(int(lane))))
+            self.cur_lane = int(lane)
+
+    def lane_record(self, event):
+        check(lib().lele_hip_lane_record(self._h, C.c_int(int(event))))
+
+    def lane_wait(self, event):
+        check(lib().lele_hip_lane_wait(self._h, C.c_int(int(event))))
+
+    def lane_events(self, n):
+        """reserve `n` event ids for one plan; returns the first"""
+        base = self._next_event
+        self._next_event += int(n)
+        return base
+
     def quant_set_profiling(self, on):
         """per-stage stopwatch of fused_quantized_linear (eager calls only), see include/lele_hip.h"""
         check(lib().lele_hip_quant_set_profiling(self._h, C.c_int(int(on))))

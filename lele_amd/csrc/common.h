@@ -124,6 +124,34 @@ struct LeleCtx {
     LeleBuf* tmp[3] = {nullptr, nullptr, nullptr};
     int tmp_buf(int i, LeleBuf** out);
 
+    // ---- lanes: extra streams of this context, for plans whose independent branches should overlap (lele_hip_lane_*).
+    // The fields above (stream, arena*, scratch*, tmp) are always those of the CURRENT lane -- every op of the library keeps using
+    // them unchanged; switching lanes swaps them with the parked state of the target lane.  Each lane has its own stream, staging
+    // arena, scratch block and temporary buffers, so two ops in flight on different lanes never share library-owned memory.
+    struct LaneState {
+        hipStream_t stream = nullptr;
+        char* arena = nullptr;
+        size_t arena_cap = 0, arena_used = 0;
+        std::vector<void*> arena_overflow;
+        void* scratch = nullptr;
+        size_t scratch_cap = 0;
+        LeleBuf* tmp[3] = {nullptr, nullptr, nullptr};
+    };
+    static constexpr int kMaxLanes = 4;
+    int lane = 0;                       // the current lane
+    std::vector<LaneState> parked;      // parked[l] = state of lane l while it is not current (entry of the current lane: unused)
+    hipStream_t lane_stream[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};  // every lane's OWN stream ([0] = the ctx stream)
+    std::vector<hipEvent_t> lane_events;  // lele_hip_lane_record / _wait, eager mode
+    // While a graph is being captured there is only ONE stream (lane 0's): a capture that spreads over several streams is recorded by
+    // the runtime as "parallel capture streams" of each other, and ending such a capture recursed without end once a third stream had
+    // joined an earlier one (hip::Stream::EndCapture, ROCm 7.0).  Instead the DAG is built on the capturing stream itself: the dependency
+    // set of the NEXT recorded node is replaced by the tail of the lane that issues it (hipStreamUpdateCaptureDependencies), an event
+    // is the set of nodes it stands for, a wait adds them.  Plain node-to-node edges, no event nodes, no extra streams.
+    std::vector<hipGraphNode_t> lane_tail[kMaxLanes];
+    std::vector<std::vector<hipGraphNode_t>> event_nodes;
+    int capture_deps_get(std::vector<hipGraphNode_t>* out);
+    int sync_all();                     // drain every lane's stream
+
     int check_deverr(const char* where);
     int arena_reset();
     int arena_alloc(size_t bytes, void** out);

@@ -30,6 +30,23 @@ int LeleCtx::arena_reset() {
     return 0;
 }
 
+int LeleCtx::sync_all() {
+    LELE_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int l = 0; l < kMaxLanes; ++l)
+        if (lane_stream[l] && lane_stream[l] != stream) LELE_HIP_CHECK(hipStreamSynchronize(lane_stream[l]));
+    return 0;
+}
+
+int LeleCtx::capture_deps_get(std::vector<hipGraphNode_t>* out) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    const hipGraphNode_t* deps = nullptr;
+    size_t n = 0;
+    LELE_HIP_CHECK(hipStreamGetCaptureInfo_v2(stream, &st, nullptr, nullptr, &deps, &n));
+    LELE_REQUIRE(st == hipStreamCaptureStatusActive, "lanes: the capture is no longer active (an op invalidated it)");
+    out->assign(deps, deps + n);
+    return 0;
+}
+
 int LeleCtx::tmp_buf(int i, LeleBuf** out) {
     if (!tmp[i]) {
         LELE_REQUIRE(!capturing, "graph capture: this op needs a temporary buffer; run the sequence once before capturing it");
@@ -123,7 +140,7 @@ int LeleBuf::reserve(size_t n) {
     rowstat_valid = false;  // the buffer is about to be written
     if (n > cap) {
         LELE_REQUIRE(!ctx->capturing, "graph capture: an output buffer would grow; run the sequence once before capturing it");
-        LELE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        LELE_TRY(ctx->sync_all());
         if (data) {
             ctx->buf_of_data.erase(data);
             (void)hipFree(data);
@@ -174,6 +191,7 @@ int lele_hip_ctx_create(int device, LeleCtx** out) {
     LELE_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     c->num_cus = prop.multiProcessorCount;
     LELE_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->lane_stream[0] = c->stream;
     LELE_HIP_CHECK(hipEventCreate(&c->ev0));
     LELE_HIP_CHECK(hipEventCreate(&c->ev1));
     c->arena_cap = size_t(64) << 20;
@@ -192,8 +210,22 @@ int lele_hip_ctx_destroy(LeleCtx* c) {
     while (!c->graphs.empty()) (void)lele_hip_graph_destroy(c->graphs.back());  // graphs hold raw addresses of this ctx's memory
     while (!c->comms.empty()) (void)lele_hip_comm_destroy(c->comms.back());     // communicators issue on this ctx's stream
     for (hipEvent_t e : c->qprof.ev) (void)hipEventDestroy(e);
+    if (c->lane != 0) (void)lele_hip_lane_set(c, 0);
     for (LeleBuf* t : c->tmp)
         if (t) (void)lele_hip_buf_destroy(t);
+    for (size_t l = 1; l < c->parked.size(); ++l) {
+        LeleCtx::LaneState& s = c->parked[l];
+        if (!c->lane_stream[l]) continue;
+        (void)hipStreamSynchronize(c->lane_stream[l]);
+        for (LeleBuf* t : s.tmp)
+            if (t) (void)lele_hip_buf_destroy(t);
+        for (void* p : s.arena_overflow) (void)hipFree(p);
+        if (s.arena) (void)hipFree(s.arena);
+        if (s.scratch) (void)hipFree(s.scratch);
+        (void)hipStreamDestroy(c->lane_stream[l]);
+    }
+    for (hipEvent_t e : c->lane_events)
+        if (e) (void)hipEventDestroy(e);
     if (c->deverr_host) (void)hipHostFree(c->deverr_host);
     for (void* p : c->arena_overflow) (void)hipFree(p);
     for (auto& kv : c->weights) (void)hipFree(kv.second);
@@ -210,7 +242,7 @@ int lele_hip_ctx_destroy(LeleCtx* c) {
 int lele_hip_sync(LeleCtx* c) {
     LELE_REQUIRE(c, "sync: ctx is NULL");
     LELE_REQUIRE(!c->capturing, "sync: not allowed while a graph is being captured");
-    LELE_HIP_CHECK(hipStreamSynchronize(c->stream));
+    LELE_TRY(c->sync_all());
     return c->check_deverr("sync");
 }
 
@@ -220,15 +252,26 @@ void* lele_hip_ctx_stream(LeleCtx* c) { return c ? (void*)c->stream : nullptr; }
 int lele_hip_graph_begin(LeleCtx* c) {
     LELE_REQUIRE(c, "graph_begin: ctx is NULL");
     LELE_REQUIRE(!c->capturing, "graph_begin: a capture is already in progress");
+    LELE_REQUIRE(c->lane == 0, "graph_begin: lane %d is current; a capture starts (and ends) on lane 0", c->lane);
     LELE_HIP_CHECK(hipSetDevice(c->device));
+    LELE_TRY(c->sync_all());
     LELE_TRY(c->arena_reset());  // frees any overflow blocks now, while synchronising is still legal
     LELE_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     c->capturing = true;
+    for (auto& t : c->lane_tail) t.clear();
+    c->event_nodes.clear();
     return 0;
 }
 int lele_hip_graph_end(LeleCtx* c, LeleGraph** out) {
     LELE_REQUIRE(c && out, "graph_end: NULL argument");
     LELE_REQUIRE(c->capturing, "graph_end: no capture in progress");
+    LELE_REQUIRE(c->lane == 0, "graph_end: lane %d is current; switch back to lane 0 (lele_hip_lane_set) before ending the capture", c->lane);
+    {   // the end of the graph = the end of every lane: whatever follows the launch on the stream is ordered after all of them anyway
+        // (a graph launch completes when its last node does), the explicit join only keeps the capture's dependency set whole
+        std::vector<hipGraphNode_t> all;
+        for (int l = 1; l < LeleCtx::kMaxLanes; ++l) all.insert(all.end(), c->lane_tail[l].begin(), c->lane_tail[l].end());
+        if (!all.empty()) LELE_HIP_CHECK(hipStreamUpdateCaptureDependencies(c->stream, all.data(), all.size(), hipStreamAddCaptureDependencies));
+    }
     c->capturing = false;
     hipGraph_t g = nullptr;
     LELE_HIP_CHECK(hipStreamEndCapture(c->stream, &g));
@@ -275,6 +318,66 @@ int lele_hip_graph_destroy(LeleGraph* g) {
             break;
         }
     delete g;
+    return 0;
+}
+
+/* ---- lanes ------------------------------------------------------------------------------------------------------------ */
+int lele_hip_lane_set(LeleCtx* c, int lane) {
+    LELE_REQUIRE(c, "lane_set: ctx is NULL");
+    LELE_REQUIRE(lane >= 0 && lane < LeleCtx::kMaxLanes, "lane_set: lane %d outside [0, %d)", lane, LeleCtx::kMaxLanes);
+    if (lane == c->lane) return 0;
+    LELE_HIP_CHECK(hipSetDevice(c->device));
+    if (c->parked.size() < (size_t)LeleCtx::kMaxLanes) c->parked.resize(LeleCtx::kMaxLanes);
+    LeleCtx::LaneState& dst = c->parked[lane];
+    if (!c->lane_stream[lane]) {  // first use: its own stream and staging arena
+        LELE_REQUIRE(!c->capturing, "graph capture: lane %d does not exist yet; run the sequence once (with its lanes) before capturing it", lane);
+        LELE_HIP_CHECK(hipStreamCreateWithFlags(&c->lane_stream[lane], hipStreamNonBlocking));
+        dst.arena_cap = c->arena_cap;
+        LELE_HIP_CHECK(hipMalloc((void**)&dst.arena, dst.arena_cap));
+    }
+    if (c->capturing) LELE_TRY(c->capture_deps_get(&c->lane_tail[c->lane]));  // where the lane we leave stands
+    LeleCtx::LaneState& cur = c->parked[c->lane];  // park the current lane's memory
+    cur.arena = c->arena, cur.arena_cap = c->arena_cap, cur.arena_used = c->arena_used;
+    cur.arena_overflow.swap(c->arena_overflow);
+    cur.scratch = c->scratch, cur.scratch_cap = c->scratch_cap;
+    for (int i = 0; i < 3; ++i) cur.tmp[i] = c->tmp[i];
+    c->arena = dst.arena, c->arena_cap = dst.arena_cap, c->arena_used = dst.arena_used;
+    c->arena_overflow.clear();
+    c->arena_overflow.swap(dst.arena_overflow);
+    c->scratch = dst.scratch, c->scratch_cap = dst.scratch_cap;
+    for (int i = 0; i < 3; ++i) c->tmp[i] = dst.tmp[i];
+    c->lane = lane;
+    if (c->capturing) {  // one stream records everything: the next node hangs off THIS lane's tail (nothing yet: a root of the graph)
+        std::vector<hipGraphNode_t>& t = c->lane_tail[lane];
+        LELE_HIP_CHECK(hipStreamUpdateCaptureDependencies(c->stream, t.empty() ? nullptr : t.data(), t.size(), hipStreamSetCaptureDependencies));
+    } else {
+        c->stream = c->lane_stream[lane];
+    }
+    return 0;
+}
+int lele_hip_lane_record(LeleCtx* c, int event) {
+    LELE_REQUIRE(c && event >= 0 && event < (1 << 16), "lane_record: bad argument");
+    LELE_HIP_CHECK(hipSetDevice(c->device));
+    if (c->capturing) {
+        if (c->event_nodes.size() <= (size_t)event) c->event_nodes.resize((size_t)event + 1);
+        return c->capture_deps_get(&c->event_nodes[event]);
+    }
+    if (c->lane_events.size() <= (size_t)event) c->lane_events.resize((size_t)event + 1, nullptr);
+    if (!c->lane_events[event]) LELE_HIP_CHECK(hipEventCreateWithFlags(&c->lane_events[event], hipEventDisableTiming));
+    LELE_HIP_CHECK(hipEventRecord(c->lane_events[event], c->stream));
+    return 0;
+}
+int lele_hip_lane_wait(LeleCtx* c, int event) {
+    LELE_REQUIRE(c && event >= 0, "lane_wait: bad argument");
+    LELE_HIP_CHECK(hipSetDevice(c->device));
+    if (c->capturing) {
+        LELE_REQUIRE((size_t)event < c->event_nodes.size(), "lane_wait: event %d was not recorded in this capture", event);
+        std::vector<hipGraphNode_t>& nodes = c->event_nodes[event];
+        if (!nodes.empty()) LELE_HIP_CHECK(hipStreamUpdateCaptureDependencies(c->stream, nodes.data(), nodes.size(), hipStreamAddCaptureDependencies));
+        return 0;
+    }
+    LELE_REQUIRE((size_t)event < c->lane_events.size() && c->lane_events[event], "lane_wait: event %d was never recorded", event);
+    LELE_HIP_CHECK(hipStreamWaitEvent(c->stream, c->lane_events[event], 0));
     return 0;
 }
 

@@ -1006,9 +1006,12 @@ def attention_view(q, q_chain, k, k_chain, v, v_chain, scale, out_perm=None, out
     if fused and int(np.prod(qsh[:-2], dtype=np.int64)) * -(-qsh[-2] // 16) < int(os.environ.get("LELE_HIP_ATTENTION_MIN_BLOCKS", "96")):
         fused = False
     if not fused:
-        tmp = getattr(ctx, "_attn_tmp", None)
-        if tmp is None:  # scores / probabilities of the sequence: two buffers kept with the ctx
-            tmp = ctx._attn_tmp = (ctx.buf(), ctx.buf())
+        pool = getattr(ctx, "_attn_tmp", None)
+        if pool is None:
+            pool = ctx._attn_tmp = {}
+        tmp = pool.get(ctx.cur_lane)
+        if tmp is None:  # scores / probabilities of the sequence: two buffers kept with the ctx, per lane (two lanes may run one each)
+            tmp = pool[ctx.cur_lane] = (ctx.buf(), ctx.buf())
         sc = matmul_view(q, q_chain, k, k_chain, out=tmp[0], ctx=ctx)
         pr = softmax_scaled(sc, scale, -1, out=tmp[1], ctx=ctx) if scale is not None else softmax(sc, -1, out=tmp[1], ctx=ctx)
         return matmul_view(pr, [], v, v_chain, out_perm, out_reshape, out=out, ctx=ctx)

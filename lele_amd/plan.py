@@ -641,9 +641,12 @@ class Runner:
         self.calls = 0
         self.profile = None
         self.stmt_times = None   # set to []: (statement index, fn, first result, device ms) of every kernel statement of the next run
+        self.stmt_repeat = 1     # with stmt_times: issue every statement this many times back to back and report the mean -- a single
+        #                          eager launch of a 10 us kernel reads as 30 us (launch latency), a train of 8 as its duration
         self.stmt_index = 0
         self.shapes = None  # set to {} to record the shape of every tensor value of the next run
         self.taps = None    # set to {name: None, ...}: host copies of those results are left there by the next run (tests)
+        self.event_base = ctx.lane_events(plan["dag"]["events"]) if "dag" in plan else 0   # a DAG plan (lele_amd.lanes.schedule)
 
     def _wkey(self, node):
         return weight_key(node) if self.v2 else node[1]
@@ -736,7 +739,11 @@ class Runner:
     def run(self, inputs):
         env = dict(inputs)
         self.stmt_index = 0
-        self.exec(self.plan["statements"], env)
+        try:
+            self.exec(self.plan["statements"], env)
+        finally:
+            if getattr(self.ctx, "cur_lane", 0) != 0:      # a failed statement on a side lane: the context goes back to lane 0 whatever happened
+                self.ctx.lane_set(0)
         if self.shapes is not None:
             for name, v in env.items():
                 if hasattr(v, "shape"):
@@ -768,8 +775,16 @@ class Runner:
         for st in statements:
             self.stmt_index += 1
             op = st["op"]
+            if "lane" in st:     # a DAG plan: this statement's stream, and the points of other lanes it has to wait for
+                ctx.lane_set(st["lane"])
+                for e in st.get("wait", ()):
+                    ctx.lane_wait(self.event_base + e)
             if op == "if":
                 self.if_(st, env)
+            elif op == "join":   # back on lane 0, after the last statement of every side lane
+                ctx.lane_set(0)
+                for e in st.get("wait", ()):
+                    ctx.lane_wait(self.event_base + e)
             elif op == "ints":
                 env[st["out"][0]] = st["value"]
             elif op == "newbuf":
@@ -817,8 +832,11 @@ class Runner:
                         res = f(*pos, out=d.buf, out_window=(d.offset + st["window"]["c0"] * inner, d.pitch or d.shape[1] * inner), ctx=ctx)
                     else:
                         res = self.call(f, fn, pos, bufs, key=st["out"][0] + str(self.stmt_index), may_alias=bool(st.get("may_alias")))
+                        if self.stmt_times is not None:
+                            for _ in range(self.stmt_repeat - 1):   # pure functions of their operands: the same result again
+                                self.call(f, fn, pos, bufs, key=st["out"][0] + str(self.stmt_index), may_alias=bool(st.get("may_alias")))
                     if self.stmt_times is not None:
-                        self.stmt_times.append((self.stmt_index, fn, st["out"][0], ctx.timer_stop()))
+                        self.stmt_times.append((self.stmt_index, fn, st["out"][0], ctx.timer_stop() / (self.stmt_repeat if "window" not in st else 1)))
                     if self.profile is not None:
                         ctx.sync()
                         self.profile[fn] = self.profile.get(fn, 0.0) + time.perf_counter() - t0
@@ -834,3 +852,5 @@ class Runner:
                     for name in st["out"]:
                         if name in self.taps:
                             self.taps[name] = env[name].numpy().copy()
+            if "record" in st:
+                ctx.lane_record(self.event_base + st["record"])

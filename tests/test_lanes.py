@@ -1,0 +1,176 @@
+"""Plans as DAGs (lele_amd/lanes.py + lele_hip_lane_*): independent branches on different HIP streams of one context, recorded as ONE
+hipGraph with parallel branches.  The contract: the SAME kernels with the same arguments -- so a DAG plan's outputs equal the sequential
+plan's bit for bit, eagerly and replayed, for the measured schedule and for adversarial ones (random per-statement costs and no
+hysteresis make the scheduler hop lanes at every opportunity: every cross-lane read-after-write has to carry an event, and every
+re-used workspace slot has to be free by happens-before, not by luck of timing)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _toy_dag_plan():
+    """x -> a = relu(x); two independent branches b = sigmoid(a), c = exp(a); d = add(b, c)"""
+    st = [{"op": "call", "out": ["a"], "fn": "relu", "args": [{"ref": "x"}], "bufs": 1},
+          {"op": "call", "out": ["b"], "fn": "sigmoid", "args": [{"ref": "a"}], "bufs": 1},
+          {"op": "call", "out": ["c"], "fn": "exp", "args": [{"ref": "a"}], "bufs": 1},
+          {"op": "call", "out": ["c2"], "fn": "reshape", "args": [{"ref": "c"}, {"list": [{"int": -1}]}], "bufs": 0},
+          {"op": "call", "out": ["b2"], "fn": "reshape", "args": [{"ref": "b"}, {"list": [{"int": -1}]}], "bufs": 0},
+          {"op": "call", "out": ["d"], "fn": "add", "args": [{"ref": "b2"}, {"ref": "c2"}], "bufs": 1},
+          {"op": "call", "out": ["e"], "fn": "sigmoid", "args": [{"ref": "d"}], "bufs": 1}]
+    return {"source": "toy", "format": "lele_amd.plan/2", "inputs": ["x"], "outputs": ["e"], "slots": ["buf_0", "buf_1", "buf_2"], "statements": st, "weights": {}}
+
+
+def test_scheduler_orders_every_cross_lane_edge_and_frees_slots_by_happens_before():
+    """no GPU: the structure of a scheduled plan"""
+    from lele_amd.lanes import schedule
+    plan = _toy_dag_plan()
+    dag = schedule(plan, {"a": 0.01, "b": 0.05, "c": 0.05, "d": 0.01, "e": 0.01}, lanes=2)
+    sts = {st["out"][0]: st for st in dag["statements"] if st["out"]}
+    assert dag["dag"]["lanes"] == 2 and sts["b"]["lane"] != sts["c"]["lane"]          # the two branches overlap
+    side = sts["b"] if sts["b"]["lane"] != sts["a"]["lane"] else sts["c"]
+    assert side["wait"] == [sts["a"]["record"]]                                        # fork: waits for a
+    assert sts["d"]["lane"] in (0, 1) and set(sts["d"].get("wait", [])) == {side["record"]} if sts["d"]["lane"] != side["lane"] else True
+    assert dag["statements"][-1]["op"] == "join"
+    # b and c are alive together: they can never share a slot; e may not take the slot of a value its lane has not seen die
+    assert sts["b"]["slots"] != sts["c"]["slots"] and sts["a"]["slots"] != sts["b"]["slots"] and sts["a"]["slots"] != sts["c"]["slots"]
+    assert dag["dag"]["modelled_makespan_ms"] < dag["dag"]["modelled_sequential_ms"]
+    # constructs the pass does not order are refused, not guessed at
+    assert schedule(dict(plan, statements=plan["statements"] + [{"op": "if", "out": []}])) is None
+    one = schedule(plan, {}, lanes=1)
+    assert one["dag"]["lanes"] == 1 and all(st.get("lane", 0) == 0 for st in one["statements"])
+
+
+def _graph_outputs(ctx, runner, feed, replays=3):
+    ctx.sync()
+    ctx.graph_begin()
+    res = runner.run(feed)
+    g = ctx.graph_end()
+    for _ in range(replays):
+        g.launch()
+    ctx.sync()
+    out = [o.numpy().copy() for o in res]
+    g.close()
+    return out
+
+
+@pytest.mark.gpu
+def test_lanes_through_the_c_abi(ctx):
+    """two lanes by hand: b on lane 1 after an event of lane 0, joined back; eager and recorded"""
+    from lele_amd import kernels as K
+    x = np.random.default_rng(0).standard_normal((64, 1024)).astype(np.float32)
+    xd = ctx.buf().upload(x)
+    bufs = [ctx.buf() for _ in range(4)]
+    base = ctx.lane_events(2)
+
+    def run():
+        a = K.relu(xd, out=bufs[0], ctx=ctx)
+        ctx.lane_record(base)
+        ctx.lane_set(1)
+        ctx.lane_wait(base)
+        b = K.sigmoid(a, out=bufs[1], ctx=ctx)
+        ctx.lane_record(base + 1)
+        ctx.lane_set(0)
+        c = K.exp(a, out=bufs[2], ctx=ctx)
+        ctx.lane_wait(base + 1)
+        return K.add(b, c, out=bufs[3], ctx=ctx)
+    want = K.add(K.sigmoid(K.relu(x, ctx=ctx), ctx=ctx), K.exp(K.relu(x, ctx=ctx), ctx=ctx), ctx=ctx).numpy()
+    got = run().numpy()
+    assert np.array_equal(got, want)
+    ctx.sync()
+    ctx.graph_begin()
+    res = run()
+    g = ctx.graph_end()
+    for _ in range(3):
+        g.launch()
+    ctx.sync()
+    assert np.array_equal(res.numpy(), want)
+    g.close()
+    from lele_amd import _lib
+    ctx.lane_set(1)
+    with pytest.raises(_lib.LeleError, match="lane 1 is current"):
+        ctx.graph_begin()
+    ctx.lane_set(0)
+
+
+def _check_dag(ctx, plan, weights, feed, times=None, **kw):
+    from lele_amd.lanes import schedule
+    from lele_amd.plan import Runner
+    seq = Runner(plan, weights, ctx)
+    want = [o.numpy().copy() for o in seq.run(feed)]
+    dag_plan = schedule(plan, times, **kw)
+    assert dag_plan is not None
+    r = Runner(dag_plan, weights, ctx)
+    got = [o.numpy().copy() for o in r.run(feed)]
+    assert all(np.array_equal(a, b) for a, b in zip(got, want)), "eager DAG run differs from the sequential plan"
+    for k in range(2):
+        again = _graph_outputs(ctx, r, feed)
+        assert all(np.array_equal(a, b) for a, b in zip(again, want)), "recorded DAG differs from the sequential plan (round %d)" % k
+    return dag_plan
+
+
+@pytest.mark.gpu
+def test_dag_plans_equal_sequential_plans_bit_for_bit(ctx):
+    from yolo_graph import yolo_onnx
+    from lele_amd.compiler import compile_model
+    from lele_amd.plan import Runner, fold_channel_views, load_weights_bin
+    from lele_amd.tensor import TensorView
+    nb = 4
+    plan, blob = compile_model(yolo_onnx(nb)[0], "yolo_n%d" % nb)
+    w = load_weights_bin(plan, blob)
+    images = np.random.default_rng(5).uniform(0, 1, (nb, 3, 640, 640)).astype(np.float32)
+    feed = {"images": TensorView(ctx.buf().upload(images))}
+    r0 = Runner(plan, w, ctx)
+    r0.shapes = {}
+    r0.stmt_times = []
+    r0.run(feed)
+    r0.stmt_times = []
+    r0.run(feed)
+    times = {o: ms for _i, _fn, o, ms in r0.stmt_times}
+    r0.stmt_times = None
+    dag = _check_dag(ctx, plan, w, feed, times, lanes=3)
+    assert dag["dag"]["lanes"] >= 2 and dag["dag"]["modelled_makespan_ms"] < dag["dag"]["modelled_sequential_ms"]
+    # adversarial schedules: random costs, no hysteresis -> lane hops wherever two statements are independent
+    rng = np.random.default_rng(9)
+    for trial in range(3):
+        rnd = {k: float(rng.uniform(0.001, 0.2)) for k in times}
+        d = _check_dag(ctx, plan, w, feed, rnd, lanes=4, min_gain_ms=-1.0)
+        assert d["dag"]["events"] > dag["dag"]["events"]
+    # the batch form (channel views, windows written in place): format 3
+    folded = fold_channel_views(plan, r0.shapes)
+    d3 = _check_dag(ctx, folded, w, feed, times, lanes=3)
+    assert d3["dag"]["lanes"] >= 2
+    for trial in range(2):
+        rnd = {k: float(rng.uniform(0.001, 0.2)) for k in times}
+        _check_dag(ctx, folded, w, feed, rnd, lanes=4, min_gain_ms=-1.0)
+
+
+@pytest.mark.gpu
+def test_sensevoice_shaped_dag_plan(ctx):
+    """a 3-layer SenseVoice-shaped encoder: the FSMN memory block of a layer runs beside its attention"""
+    from lele_amd.compiler import compile_model
+    from lele_amd.plan import Runner, load_weights_bin
+    from lele_amd.tensor import TensorView
+    from sensevoice_graph import Encoder, encoder_onnx
+    enc = Encoder(ctx, 3)
+    for b, t in ((4, 171), (1, 504)):
+        plan, blob = compile_model(encoder_onnx(enc, b), "sv")
+        w = load_weights_bin(plan, blob)
+        x = np.random.default_rng(t).standard_normal((b, t, 560)).astype(np.float32)
+        feed = {"feats": TensorView(ctx.buf().upload(x))}
+        r0 = Runner(plan, w, ctx)
+        r0.run(feed)
+        r0.stmt_times = []
+        r0.run(feed)
+        times = {o: ms for _i, _fn, o, ms in r0.stmt_times}
+        r0.stmt_times = None
+        dag = _check_dag(ctx, plan, w, feed, times, lanes=2)
+        fsmn = [st for st in dag["statements"] if st.get("fn") == "depthwise_conv1d_tlc"]
+        attn = [st for st in dag["statements"] if st.get("fn") == "attention_view"]
+        assert fsmn and attn and any(f["lane"] != a["lane"] for f, a in zip(fsmn, attn)), dag["dag"]
+        rng = np.random.default_rng(1)
+        _check_dag(ctx, plan, w, feed, {k: float(rng.uniform(0.001, 0.1)) for k in times}, lanes=4, min_gain_ms=-1.0)

@@ -214,6 +214,8 @@ def synth_weights(plan, consts, seed=1234):
                 a = rng.standard_normal(n) / np.sqrt(max(1, int(np.prod(shape[1:]))))
             else:
                 a = rng.standard_normal(n) * 0.02
+                if list(shape) == [4]:   # the bias of a box-distance head (left, top, right, bottom): positive, as trained distances are --
+                    a = np.abs(a) + 0.5  # with zero-mean noise every synthetic box of a level is empty at once and nothing survives the filter
             if off in consts:
                 a = np.asarray(consts[off], np.float64).reshape(-1)
             out[off] = a.astype(np.float32).reshape(shape)
@@ -241,8 +243,24 @@ def write_weights_bin(plan, weights, path):
     open(path, "wb").write(bytes(blob))
 
 
-# YOLO26n-seg integer constants read from weights.bin (inferred from the graph: see --help); offset -> value
+def _yolo_anchor_grid(size=640, strides=(8, 16, 32)):
+    """the detection tail's two geometry constants: anchor points [1, 2, A] = the cell centres (x + 0.5, y + 0.5) of the 80 x 80, 40 x 40 and
+    20 x 20 maps in cell units, and the stride of each anchor [1, A] (A = 8400): boxes = (anchor -/+ distances) * stride"""
+    pts, st = [], []
+    for s_ in strides:
+        n = size // s_
+        ys, xs = np.meshgrid(np.arange(n, dtype=np.float32) + 0.5, np.arange(n, dtype=np.float32) + 0.5, indexing="ij")
+        pts.append(np.stack([xs.reshape(-1), ys.reshape(-1)], 0))
+        st.append(np.full(n * n, float(s_), np.float32))
+    return np.concatenate(pts, 1)[None], np.concatenate(st)[None]
+
+
+_ANCHORS, _STRIDES = _yolo_anchor_grid()
+
+# YOLO26n-seg constants read from weights.bin (inferred from the graph: see --help); offset -> value
 DEFAULT_CONSTS = {
+    10644560: _ANCHORS,              # anchor points [1, 2, 8400]: `sub(anchors, lt)` / `add(anchors, rb)` (noise here would make every box empty)
+    10951184: _STRIDES,              # stride per anchor [1, 8400]: `mul(xyxy, strides)`
     5445328: [1.0, 1.0, 2.0, 2.0],   # Resize scales (x2 nearest upsampling in the neck)
     7762768: [1, 64, 80, 80],        # proto Resize target size (features brought to the 80x80 level before fusion)
     10993152: [300],                 # TopK k (max detections)
