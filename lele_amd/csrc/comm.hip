@@ -165,8 +165,17 @@ int lele_hip_comm_init_file(LeleCtx* ctx, const char* path, int rank, int world,
     } else {
         const int step_ms = 5;
         int waited = 0;
+        // No token in the environment (a caller that launches ranks itself and sets neither LELE_JOB_ID nor TORCHELASTIC_RUN_ID): the
+        // all-zero token cannot tell this job's file from one an earlier token-less job left under the same name, and a reader that
+        // gets there before rank 0's unlink would take a dead id and hang in ncclCommInitRank.  Then -- and only then -- the file must
+        // also be YOUNGER than this reader's own arrival (minus a slack for clock granularity): rank 0 always writes after it starts.
+        bool tokenless = true;
+        for (uint8_t b : tok) tokenless = tokenless && b == 0;
+        const time_t arrived = time(nullptr);
         for (;;) {
-            FILE* f = fopen(path, "rb");
+            struct stat sb;
+            const bool fresh = !tokenless || (stat(path, &sb) == 0 && sb.st_mtime + 2 >= arrived);
+            FILE* f = fresh ? fopen(path, "rb") : nullptr;
             if (f) {
                 uint8_t got[32 + 128 + 1];
                 const size_t r = fread(got, 1, sizeof(got), f);

@@ -177,7 +177,7 @@ def replan_lifted(plan, shapes):
             "slots": slots, "statements": out, "weights": weights}
 
 
-def rebatch_lifted(plan, n):
+def rebatch_lifted(plan, n, shapes=None):
     """A re-planned lifted plan (replan_lifted) whose generated source baked batch 1 into its shape literals, for a batch of `n`.
     lele's emitter folds the ONNX shape arithmetic for the export's batch (examples/yolo26n-seg/src/yolo26seg.rs: `reshape(x,
     &[1, 2, 128, 400])`, ...), and its examples loop over images on the host; the data flow itself is batch-agnostic except where
@@ -187,10 +187,16 @@ def rebatch_lifted(plan, n):
         merges trailing axes of an [N, ...] tensor; a reshape whose element count would not match fails loudly at run time);
       * `gather(flatten(E, 2), idx, 0)` with E [N, K, 1] and idx [N, K] -- the exporter's form of "row idx[n, i] of image n", which
         flattens the batch away -- becomes `gather_elements(E, unsqueeze(idx, -1), 1)`: the same values at N = 1, per image for N > 1.
+    `shapes` (value name -> shape of the BATCH-1 run, Runner.shapes): when given, a statement is rewritten only where the shapes prove
+    the pattern -- the reshape's operand has leading dimension 1 and the literal's element count is the operand's (a constant
+    reshaped to [1, C, 1, 1] is left alone: its operand is not batched); E is [1, K, 1] and idx [1, K] for the gather.
     Returns a new format-2 plan (buffers re-assigned)."""
     from .compiler.lower import allocate
     import copy
     sts = copy.deepcopy(plan["statements"])
+
+    def numel(shp):
+        return int(np.prod(shp, dtype=np.int64)) if shp is not None else None
     prod = {}
     for i, st in enumerate(sts):
         for o in st.get("out", []):
@@ -201,11 +207,21 @@ def rebatch_lifted(plan, n):
         st.pop("slots", None)
         if st.get("op") == "call" and st.get("fn") == "reshape" and isinstance(st["args"][1], dict) and "list" in st["args"][1]:
             dims = st["args"][1]["list"]
-            if dims and dims[0] == {"int": 1}:
+            ok = bool(dims) and dims[0] == {"int": 1}
+            if ok and shapes is not None:
+                src = shapes.get(st["args"][0].get("ref")) if isinstance(st["args"][0], dict) else None
+                lit = [d.get("int") for d in dims]
+                ok = src is not None and len(src) >= 1 and int(src[0]) == 1 and st["args"][0].get("ref") not in plan["weights"] and \
+                    (any(v in (-1, 0) for v in lit) or numel(lit) == numel(src))
+            if ok:
                 st["args"] = [st["args"][0], {"list": [{"int": int(n)}] + list(dims[1:])}] + list(st["args"][2:])
         elif st.get("op") == "call" and st.get("fn") == "gather" and st["args"][2] == {"int": 0} and "ref" in st["args"][0] and "ref" in st["args"][1]:
             src = sts[prod[st["args"][0]["ref"]]] if st["args"][0]["ref"] in prod else None
-            if src is not None and src.get("fn") == "flatten" and src["args"][1] == {"int": 2} and "ref" in src["args"][0]:
+            ok = src is not None and src.get("fn") == "flatten" and src["args"][1] == {"int": 2} and "ref" in src["args"][0]
+            if ok and shapes is not None:
+                e, ix = shapes.get(src["args"][0]["ref"]), shapes.get(st["args"][1]["ref"])
+                ok = e is not None and ix is not None and len(e) == 3 and int(e[0]) == 1 and int(e[2]) == 1 and list(ix) == [1, int(e[1])]
+            if ok:
                 extra += 1
                 ix = "%s__ix%d" % (st["out"][0], extra)
                 out.append({"op": "call", "out": [ix], "fn": "unsqueeze", "args": [st["args"][1], {"list": [{"int": -1}]}], "bufs": 0})
@@ -588,8 +604,12 @@ def fold_channel_views(plan, shapes, residuals=True):
                 first = pi if first is None else min(first, pi)
             entries.append((o, c0, bool(ok)))
             c0 += int(shapes[o][1])
-        if first is None and not any(prod.get(o) in windowed or prod.get(o) in view_split for o, _c, _p in entries):
+        if first is None and not any(prod.get(o) in windowed or prod.get(o) in view_split for o, _c, _p in entries) \
+                and not any(prod.get(o) in view_split for o in ops):
             continue                      # nothing can be produced in place and every operand is dense: the concat stays ONE copy kernel
+        # (the second test looks at the Concat's OWN operands: results of a Split that became views -- because this Concat counted as
+        # a reader that copes with views -- must not be left to a plain `concat`, which takes dense tensors only, even when merging them
+        # back into the Split's input made every ENTRY dense: y = relu(x); a, b = split(y); z = concat([a, b]))
         concat_plan[ic] = (buf, entries)  # (an operand that is a view elsewhere is copied in by copy_view, which reads views)
         reserve_at.setdefault(ic if first is None else first, []).append((buf, [int(d) for d in shapes[r]]))
 

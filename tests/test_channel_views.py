@@ -593,3 +593,27 @@ def test_yolo_shaped_graph_folded_equals_unfolded(ctx):
     assert r1.calls < r0.calls
     for a, b in zip(want, got):
         assert np.array_equal(a, b)
+
+
+def test_a_concat_of_a_view_splits_results_is_never_left_as_a_plain_concat():
+    """y = relu(x); a, b = split(y); z = concat([a, b]).  The Split's results become channel views because the Concat counts
+    as a reader that copes with views; merging them back into y made every entry of the Concat dense and nothing could be written in
+    place, so the Concat used to be dropped from the plan of in-place Concats -- and a plain `concat` was left reading views, which
+    fails at run time.  No GPU: the structure of the folded plan."""
+    from lele_amd.plan import fold_channel_views
+    L = lambda *v: {"list": [{"int": int(i)} for i in v]}   # noqa: E731
+    st = [{"op": "call", "out": ["y"], "fn": "relu", "args": [{"ref": "x"}], "bufs": 1},
+          {"op": "call", "out": ["a", "b"], "fn": "split", "args": [{"ref": "y"}, {"int": 1}, L(3, 5)], "bufs": 2},
+          {"op": "call", "out": ["z"], "fn": "concat", "args": [{"list": [{"ref": "a"}, {"ref": "b"}]}, {"int": 1}], "bufs": 1},
+          {"op": "call", "out": ["w"], "fn": "relu", "args": [{"ref": "z"}], "bufs": 1}]
+    plan = {"source": "t", "format": "lele_amd.plan/2", "inputs": ["x"], "outputs": ["w"], "slots": [], "statements": st, "weights": {}}
+    shapes = {"x": [2, 8, 4, 4], "y": [2, 8, 4, 4], "a": [2, 3, 4, 4], "b": [2, 5, 4, 4], "z": [2, 8, 4, 4], "w": [2, 8, 4, 4]}
+    out = fold_channel_views(plan, shapes)["statements"]
+    views = {o for s_ in out if s_["op"] == "chview" for o in s_["out"]}
+    for s_ in out:
+        if s_["op"] == "call" and s_.get("fn") == "concat":
+            ops = [v["ref"] for v in s_["args"][0]["list"]]
+            assert not (set(ops) & views), "a plain concat reads channel views: %s" % ops
+    if {"a", "b"} <= views:      # the Split became views: then z is a view of a reserved buffer y was copied into
+        assert any(s_["op"] == "reserve" for s_ in out) and any(s_.get("fn") == "copy_view" for s_ in out)
+        assert "z" in views

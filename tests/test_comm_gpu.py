@@ -89,6 +89,14 @@ def test_rendezvous_file_of_another_job_is_refused(ctx, tmp_path, monkeypatch):
     monkeypatch.setenv("LELE_JOB_ID", "job-c")     # the next job does not take job-b's file either
     with pytest.raises(_lib.LeleError, match="waited"):
         Comm.from_file(ctx, str(path), 1, 2, timeout_ms=40)
+    # no token at all: a well-formed file of an EARLIER token-less job must not be taken either -- it is older than the reader
+    monkeypatch.delenv("LELE_JOB_ID")
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    path.write_bytes(b"\0" * 32 + b"\5" * 128)
+    old = os.stat(path).st_mtime - 60
+    os.utime(path, (old, old))
+    with pytest.raises(_lib.LeleError, match="waited"):
+        Comm.from_file(ctx, str(path), 1, 2, timeout_ms=40)
 
 
 def test_native_runner_ranks_and_decode(ctx, tmp_path):

@@ -234,7 +234,7 @@ def test_c5_reference_generated_graph_batch_64_against_the_oracle_forward(ctx):
     r1.run({name: TensorView(ctx.buf().upload(images[:1]))})
     p2 = replan_lifted(fuse_sigmoid_mul(plan, r1.shapes), r1.shapes)
     w2 = {k: raw[int(k.split(":")[0])] for k in p2["weights"]}
-    pn = rebatch_lifted(p2, n)
+    pn = rebatch_lifted(p2, n, r1.shapes)
     big = Runner(pn, w2, ctx)
     big.taps = {k: None for k in srcs + [first]}
     big.shapes = {}

@@ -165,6 +165,14 @@ def test_rebatch_lifted_rewrites_only_the_batch_literals():
     ge = re["statements"][5]
     assert ge["args"] == [{"ref": "e"}, {"ref": re["statements"][4]["out"][0]}, {"int": 1}] and re["statements"][4]["args"][0] == {"ref": "sel"}
     assert re["statements"][6]["args"][2] == {"int": 1} and len(plan["statements"]) == 6             # axis-1 gather and the input plan untouched
+    # with the batch-1 shapes at hand a statement is rewritten only where they prove the pattern
+    shapes = {"images": [1, 8, 6], "idx": [1, 5], "e": [1, 5, 1], "f": [1, 5], "sel": [1, 5], "r": [1, 2, 24], "k": [4, 12]}
+    same = rebatch_lifted(plan, 64, shapes)
+    assert [s_["fn"] for s_ in same["statements"]] == fns and same["statements"][0]["args"][1] == {"list": [{"int": 64}, {"int": 2}, {"int": -1}]}
+    wrong_e = rebatch_lifted(plan, 64, dict(shapes, e=[1, 5, 3]))                  # E's last dimension is not 1: the gather stays a gather
+    assert [s_["fn"] for s_ in wrong_e["statements"]] == ["reshape", "reshape", "unsqueeze", "flatten", "gather", "gather"]
+    const = rebatch_lifted(plan, 64, dict(shapes, images=[3, 8, 2]))               # the reshape's operand is not [1, ...]: left alone
+    assert const["statements"][0]["args"][1] == {"list": [{"int": 1}, {"int": 2}, {"int": -1}]}
 
 
 @pytest.mark.gpu

@@ -54,7 +54,7 @@ def main():
     r1.run({name: TensorView(ctx.buf().upload(images[:1]))})
     p2 = replan_lifted(fuse_sigmoid_mul(plan, r1.shapes), r1.shapes)
     w2 = {k: raw[int(k.split(":")[0])] for k in p2["weights"]}
-    pn = rebatch_lifted(p2, n) if n > 1 else p2
+    pn = rebatch_lifted(p2, n, r1.shapes) if n > 1 else p2
     # the oracle runs the RE-PLANNED batch-1 plan (same statement names as the device's batch-N plan)
     ref = plan_ref.PlanRef(p2, w2)
     ref.taps = {o: None for st in p2["statements"] for o in st.get("out", [])}

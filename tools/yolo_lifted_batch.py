@@ -37,7 +37,7 @@ def build(ctx, path, batch, seed=64):
     p2 = replan_lifted(fuse_sigmoid_mul(plan, shapes1), shapes1)
     w2 = {k: raw[int(k.split(":")[0])] for k in p2["weights"]}
     one = Runner(p2, w2, ctx)
-    pn = rebatch_lifted(p2, batch)
+    pn = rebatch_lifted(p2, batch, shapes1)
     big = Runner(pn, w2, ctx)
     big.shapes = {}
     xb = ctx.buf().upload(images)
