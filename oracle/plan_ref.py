@@ -227,6 +227,17 @@ class PlanRef:
         if fn == "topk":
             assert int(p[2]) in (-1, np.ndim(p[0]) - 1), "topk: last axis only (conv2d.rs:1394)"
             return list(npref.topk(f32(p[0]), int(p[1]), bool(p[3])))
+        if fn == "lstm":          # rnn.rs:67: (Y [T, 1, 1, H], H_n [1, 1, H], C_n [1, 1, H]); sequence_lens unused upstream
+            return list(O.lstm(p[0], p[1], p[2], p[3], p[5], p[6]))
+        if fn == "gru":
+            assert bool(p[5]) if len(p) > 5 else True, "gru: the oracle restates the linear_before_reset = 1 formula (rnn.rs:246, ref_gru_step)"
+            return list(O.gru(p[0], p[1], p[2], p[3], p[4]))
+        if fn == "halves_pow_add_sqrt":   # sqrt(pow(x[lo], e_lo) + pow(x[hi], e_hi)) along `axis`: slice, pow, add, sqrt (lele_amd/kernels.py)
+            x, axis = f32(p[0]), int(p[1])
+            lo = npref.slice_(x, [int(p[2][0])], [int(p[2][1])], [axis], [1])
+            hi = npref.slice_(x, [int(p[3][0])], [int(p[3][1])], [axis], [1])
+            s_ = npref.binary("add", npref.binary("pow", lo, f32(p[4])), npref.binary("pow", hi, f32(p[5])))
+            return np.sqrt(s_.astype(np.float32))
         if fn == "where_op":
             return npref.where_op(p[0], p[1], p[2])
         if fn == "clip":
