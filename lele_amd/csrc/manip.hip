@@ -587,9 +587,23 @@ __global__ __launch_bounds__(TOPK_TPB) void topk_select_kernel(const float* __re
         if (tid < 256) hist[tid] = 0u;
         __syncthreads();
         const unsigned prefix = s_prefix;
-        for (int i = tid; i < n; i += TOPK_TPB) {
-            const unsigned key = topk_key(row[i], largest);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        for (int i0 = 0; i0 < n; i0 += TOPK_TPB) {  // (uniform trip count: the wave votes below need every lane)
+            const int i = i0 + tid;
+            const unsigned key = i < n ? topk_key(row[i], largest) : 0u;
+            const bool act = i < n && (key & mask) == prefix;
+            const unsigned bin = (key >> shift) & 255u;
+            // Scores of one detection head sit close together: in the first passes (almost) every element of a wave falls into the SAME
+            // bin, and 64 LDS atomics on one address serialise (the whole selection was 76 us for [64, 24000] -> 300 on such rows).  When
+            // the live lanes of a wave agree on the bin, one of them adds the count.
+            const unsigned long long live = __ballot(act);
+            if (live) {
+                const unsigned first = (unsigned)__shfl((int)bin, (int)__builtin_ctzll(live));
+                if (__ballot(act && bin != first) == 0ull) {
+                    if (lane == (int)__builtin_ctzll(live)) atomicAdd(&hist[first], (unsigned)__popcll(live));
+                } else if (act) {
+                    atomicAdd(&hist[bin], 1u);
+                }
+            }
         }
         __syncthreads();
         if (wave == 0) {  // the bin (from the best downwards) in which the need-th element lies: lane l owns bins 4 (63 - l) + [0, 4)
