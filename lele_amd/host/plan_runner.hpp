@@ -782,10 +782,30 @@ class Runner {
     static float number(const Json& n) { return (float)(n.has("float") ? n.at("float").as_num() : n.at("int").as_num()); }
     static bool boolean(const Json& n) { return n.at("bool").b; }
 
+    int event_base_ = 0;  // DAG plans: this runner's first event id (one runner per plan per context here: 0)
+
     void exec(const Json& statements) {
         for (const Json& st : statements.arr) {
             ++stmt_;
             const std::string& op = st.at("op").str;
+            // a DAG plan (lele_amd/lanes.py): the statement's lane, the points of other lanes it waits for, the event it leaves behind
+            if (st.has("lane")) {
+                check(lele_hip_lane_set(detail::ctx(), (int)st.at("lane").as_int()));
+                if (st.has("wait"))
+                    for (const Json& e : st.at("wait").arr) check(lele_hip_lane_wait(detail::ctx(), event_base_ + (int)e.as_int()));
+            }
+            if (op == "join") {  // back on lane 0, after the last statement of every side lane
+                check(lele_hip_lane_set(detail::ctx(), 0));
+                for (const Json& e : st.at("wait").arr) check(lele_hip_lane_wait(detail::ctx(), event_base_ + (int)e.as_int()));
+                continue;
+            }
+            struct Record {  // runs when the statement is done, whatever path it took
+                const Json& st;
+                int base;
+                ~Record() {
+                    if (st.has("record")) (void)lele_hip_lane_record(detail::ctx(), base + (int)st.at("record").as_int());
+                }
+            } record{st, event_base_};
             if (op == "host") host_stmt(st);
             else if (op == "if") if_stmt(st);
             else if (op == "call") call_stmt(st);

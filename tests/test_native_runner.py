@@ -82,3 +82,26 @@ def test_native_runner_refuses_a_folded_plan_by_name(ctx, tmp_path):
     r = subprocess.run([RUN, str(tmp_path / "p.json"), str(tmp_path / "w.bin"), "--out", str(tmp_path / "o")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=120)
     assert r.returncode != 0 and "lele_amd.plan/3" in r.stderr and "not supported by the native runner" in r.stderr
+
+
+@pytest.mark.gpu
+def test_native_runner_runs_a_dag_plan(ctx, tmp_path):
+    """a plan scheduled onto lanes (lele_amd/lanes.py: "lane" / "wait" / "record" on its statements, a final "join") through lele_run:
+    the same bits as the Python runner's sequential plan, eagerly and as a recorded graph with parallel branches"""
+    from lele_amd.compiler import compile_model
+    from lele_amd.lanes import schedule
+    from lele_amd.plan import Runner, load_weights_bin
+    from lele_amd.tensor import TensorView
+    from tests.onnx_util import export
+    from tests.test_compiler import Vision
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, 32, 32, generator=g)
+    plan, blob = compile_model(export(Vision().eval(), (x,), opset=13, output_names=("y", "m")), "vision")
+    rng = np.random.default_rng(3)
+    times = {st["out"][0]: float(rng.uniform(0.001, 0.1)) for st in plan["statements"] if st.get("out")}
+    dag = schedule(plan, times, lanes=3, min_gain_ms=-1.0)        # hop lanes wherever two statements are independent
+    assert dag is not None and dag["dag"]["lanes"] >= 2 and dag["dag"]["events"] >= 1
+    want = [o.numpy() for o in Runner(plan, load_weights_bin(plan, blob), ctx).run({"x": TensorView(ctx.buf().upload(x.numpy()))})]
+    rec, got = _native(tmp_path, dag, blob, {"x": x.numpy()}, extra=("--runs", "3", "--graph"))
+    assert len(got) == len(want) and all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(got, want))
+    assert rec["graph_ms"] > 0

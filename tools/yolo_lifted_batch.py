@@ -94,22 +94,54 @@ def main():
     rec.update({"images_checked_against_the_batch_1_plan": idx, "max_error_in_units_of_1e-4_per_output": [round(w, 4) for w in worst],
                 "detection_rows_in_a_different_order": swapped, "bit_identical": bits})
     if args.table:
-        big.stmt_times = []
+        big.shapes = {}
         big.run(feed)
-        big.stmt_times = []
+        shapes = big.shapes
+        big.stmt_times, big.stmt_repeat = [], 8     # trains of 8 launches: a single eager launch of a 10 us kernel reads as 30 us
         big.run(feed)
-        times, big.stmt_times = big.stmt_times, None
+        times, big.stmt_times, big.stmt_repeat = big.stmt_times, None, 1
+        byname = {}
+        for st in big.plan["statements"]:
+            for o in st.get("out", []):
+                byname[o] = st
+        rows = []
+        for idx, fn, o, ms in times:
+            st = byname[o]
+            osh = shapes.get(o, [])
+            nbytes = 4 * int(np.prod(osh)) if osh else 0
+            gflop, geo = 0.0, ""
+            for a in st.get("args", []):
+                if isinstance(a, dict) and "ref" in a and a["ref"] in shapes:
+                    nbytes += 4 * int(np.prod(shapes[a["ref"]]))
+            if fn.startswith("conv") and len(osh) == 4 and isinstance(st["args"][1], dict) and "weight" in st["args"][1]:
+                w = st["args"][1]["weight"][3]
+                xs = shapes.get(st["args"][0].get("ref"), [0, 0, 0, 0])
+                if fn == "conv_transpose":
+                    gflop = 2.0 * xs[0] * xs[2] * xs[3] * w[0] * w[1] * w[2] * w[3] / 1e9
+                else:
+                    gflop = 2.0 * int(np.prod(osh)) * w[1] * w[2] * w[3] / 1e9
+                sh_ = 1 if fn == "conv2d_res" else 0
+                stride = st["args"][6 + sh_]["list"][0]["int"] if len(st["args"]) > 6 + sh_ and st["args"][6 + sh_].get("list") else "?"
+                group = st["args"][4 + sh_].get("int", "?") if len(st["args"]) > 4 + sh_ else "?"
+                geo = "%d->%d k%d s%s g%s @%dx%d" % (xs[1] if len(xs) > 1 else 0, osh[1], w[2], stride, group, osh[2], osh[3])
+            t_mfma, t_hbm = gflop / 157.3, nbytes / 6.0e9
+            rows.append({"stmt": idx, "fn": fn, "out": o, "shape": osh, "geometry": geo, "ms": round(ms, 4), "gflop": round(gflop, 3), "mbytes": round(nbytes / 1e6, 2),
+                         "bound_ms": round(max(t_mfma, t_hbm), 4), "bound": "mfma" if t_mfma > t_hbm else "hbm", "frac": round(max(t_mfma, t_hbm) / ms, 3) if ms > 0 else None})
         agg = {}
-        for _i, fn, _o, ms in times:
-            agg[fn] = agg.get(fn, [0, 0.0])
-            agg[fn][0] += 1
-            agg[fn][1] += ms
-        rows = sorted(([fn, c, round(t, 4)] for fn, (c, t) in agg.items()), key=lambda r: -r[2])
-        top = sorted(times, key=lambda r: -r[3])[:40]
-        json.dump({"by_function": rows, "slowest_statements": [[i, fn, o, round(ms, 4)] for i, fn, o, ms in top], "total_ms": round(sum(t[3] for t in times), 3)},
+        for r in rows:
+            a = agg.setdefault(r["fn"], [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += r["ms"]
+            a[2] += r["bound_ms"]
+        rows.sort(key=lambda r: -(r["ms"] - r["bound_ms"]))
+        json.dump({"what": "per-statement device time (HIP events, trains of 8 launches) of the reference's generated Yolo26n-seg graph at batch %d against "
+                           "max(f32 MFMA at 157.3 TFLOP/s, HBM at 6 TB/s) of the statement's own geometry; rows by absolute gap" % args.batch,
+                   "total_ms": round(sum(r["ms"] for r in rows), 3), "sum_of_bounds_ms": round(sum(r["bound_ms"] for r in rows), 3),
+                   "by_function": sorted(([fn, c, round(t, 4), round(b, 4)] for fn, (c, t, b) in agg.items()), key=lambda r: -r[2]), "rows": rows},
                   open(args.table, "w"), indent=0)
-        for r in rows[:25]:
-            print("%-28s calls %4d  %8.3f ms" % tuple(r), file=sys.stderr)
+        for r in rows[:30]:
+            print("%7.3f ms  %-16s %-30s %8.2f GFLOP %8.1f MB  bound %-4s %6.3f ms  frac %s" % (r["ms"], r["fn"], r["geometry"] or str(r["shape"]), r["gflop"], r["mbytes"],
+                                                                                             r["bound"], r["bound_ms"], r["frac"]), file=sys.stderr)
     ctx.sync()
     ctx.graph_begin()
     big.run(feed)
