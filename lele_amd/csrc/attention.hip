@@ -53,8 +53,8 @@ struct AttnArgs {
 
 // ---- split-bf16 products (the default; LELE_HIP_ATTENTION_EXACT=1 keeps the f32 MFMA of the node sequence) ---------------------
 // The f32-input MFMA runs at the f32 VECTOR rate -- 64 cycles per 32x32x2.  A bf16 MFMA does eight times the k extent in
-// half the cycles, so an f32 value is cut into three bf16 pieces of 8 mantissa bits each (hi + mid + lo == x EXACTLY: each piece
-// rounded to nearest, exact remainders -- common.h split3_bf16_pair says why not truncation) and a product becomes six bf16 MFMAs (hh, hm, mh, hl, lh, mm; the three dropped terms are <= 2^-24
+// half the cycles, so an f32 value is cut into three bf16 pieces of 8 mantissa bits each (hi + mid + lo == x EXACTLY: truncation,
+// then exact remainders) and a product becomes six bf16 MFMAs (hh, hm, mh, hl, lh, mm; the three dropped terms are <= 2^-24
 // of the product: f32-rounding class).  Six 32-cycle instructions per 16 k against eight 64-cycle ones: 2.7x, on the matrix
 // cores proper, with the vector pipe free for the split arithmetic and the softmax.  The result is the exact product's to ~1e-7
 // relative -- inside the 1e-4 bar of the f32 GEMM family like every other summation order -- but not its bits.
@@ -63,13 +63,27 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct Split3 {
     u32x4 h, m, l;  // eight values each, as bf16 pairs: element e in the low (even e) / high (odd e) half of word e / 2
 };
-__device__ __forceinline__ Split3 split3(const float (&x)[8]) {  // pieces rounded to nearest: common.h split3_bf16_pair
+__device__ __forceinline__ unsigned top16_pair(float even, float odd) {  // the upper halves of two f32 words side by side: one v_perm_b32
+    return __builtin_amdgcn_perm(__float_as_uint(odd), __float_as_uint(even), 0x07060302u);
+}
+// Pieces by TRUNCATION here (mask, exact remainder), not rounded as the convolutions' are (common.h split3_bf16_pair): truncated pieces
+// make every product ~1e-7 short in magnitude -- a bias that a 118-layer f32 convolution chain adds up coherently, and
+// that means nothing where the result is re-quantised to 8 bits by the next linear, as every attention output of these models is.
+// Measured: with rounded pieces (v_cvt_pk_bf16_f32 issues slower than v_and / v_perm) attention_flash_kernel 25.3 -> 27.5 us per
+// configs[3] layer-shard, because here the MULTIPLYING waves split P themselves; the convolutions' loader waves split off the critical path.
+__device__ __forceinline__ Split3 split3(const float (&x)[8]) {
+    float r[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        r[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xffff0000u);  // exact: the low 16 mantissa bits
+        q[e] = r[e] - __uint_as_float(__float_as_uint(r[e]) & 0xffff0000u);  // exact: the last 8
+    }
     Split3 s;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        unsigned h, m, l;
-        split3_bf16_pair(x[2 * p], x[2 * p + 1], h, m, l);
-        s.h[p] = h, s.m[p] = m, s.l[p] = l;
+        s.h[p] = top16_pair(x[2 * p], x[2 * p + 1]);
+        s.m[p] = top16_pair(r[2 * p], r[2 * p + 1]);
+        s.l[p] = top16_pair(q[2 * p], q[2 * p + 1]);
     }
     return s;
 }

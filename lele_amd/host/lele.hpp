@@ -50,6 +50,11 @@ class Ctx {
         check(rc);
         return g;
     }
+    // lanes (include/lele_hip.h, lele_hip_lane_*): independent branches of a plan on other streams of this context -- parallel branches
+    // of one recorded graph; every cross-lane dependency is the caller's to order with record / wait
+    void lane_set(int lane) const { check(lele_hip_lane_set(h_, lane)); }
+    void lane_record(int event) const { check(lele_hip_lane_record(h_, event)); }
+    void lane_wait(int event) const { check(lele_hip_lane_wait(h_, event)); }
     static Ctx& current() {  // thread-local default, like lele's thread-local scratch and caches; LELE_HIP_DEVICE picks the GPU
         static thread_local Ctx ctx(default_device());
         return ctx;
@@ -706,15 +711,20 @@ inline TensorView image_preprocess(const TensorView& rgb, int target, Buffer& ou
     LELE_RET(out, LELE_F32);
 }
 struct SegOutputs {
-    TensorView dets, count, mask;  // f32 [300, 38] (first `count` rows valid), i32 [1], u8 [H, W]
+    // one image: f32 [300, 38] (first `count` rows valid, zeros behind them), i32 [1], u8 [H, W]; a batch of N: [N, 300, 38], [N], [N, H, W]
+    TensorView dets, count, mask;
 };
 inline SegOutputs yolo_seg_postprocess(const TensorView& logits, const TensorView& mask_features, int img_width, int img_height,
                                        float threshold, int num_classes, Buffer& dets, Buffer& count, Buffer& mask) {  // image.rs:127-265
     LeleTensor tl = logits.c(), tm = mask_features.c();
     check(lele_hip_yolo_seg_postprocess(ctx(), &tl, &tm, img_width, img_height, threshold, num_classes, dets.raw(), count.raw(),
                                         mask.raw()));
-    return {TensorView::from_device(dets, {300, 38}, LELE_F32), TensorView::from_device(count, {1}, LELE_I32),
-            TensorView::from_device(mask, {img_height, img_width}, LELE_U8)};
+    const int64_t n = logits.size() / (300 * 38);
+    if (n == 1)
+        return {TensorView::from_device(dets, {300, 38}, LELE_F32), TensorView::from_device(count, {1}, LELE_I32),
+                TensorView::from_device(mask, {img_height, img_width}, LELE_U8)};
+    return {TensorView::from_device(dets, {n, 300, 38}, LELE_F32), TensorView::from_device(count, {n}, LELE_I32),
+            TensorView::from_device(mask, {n, img_height, img_width}, LELE_U8)};
 }
 // examples/silero/src/main.rs:151-228: speech segments (sample indices) from per-chunk probabilities; host-only
 struct VadConfig {  // main.rs:18-28
