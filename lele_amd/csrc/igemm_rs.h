@@ -30,6 +30,7 @@ struct RsArgs {
     int nrt, nct;  // 32-row tiles, 32-column tiles
     int ncb, nrr;  // K = 512: column blocks of 8 tiles and row ranges (grid = ncb * nrr); K split: grid = nct * nrr
     int8_t* hid;   // EM 2: the result as fragment-major i8 [nrt][n / 32][1024]
+    const float* x;  // FQ kernels: the f32 activation [rows][512] itself (af is unused): the loaders quantise it into the ring
 #ifdef LELE_HIP_LAB
     long long* dbg;  // lab build: [grid][9][32] wall-clock stamps (100 MHz) of every wave (wave 8 = the loader), or NULL
     int ablate;      // lab build (results wrong): 1 no products, 2 no epilogue, 4 no fragment reads (products on stale registers)
@@ -253,7 +254,13 @@ __device__ __forceinline__ void rs_wait_vm() {
 }
 __device__ __forceinline__ void rs_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-template <int EM, int NRES, bool RELU>
+// FQ ("fused quantise"): the two loader waves read the f32 ROWS, quantise them with the slice's parameters (prm[] is complete before the
+// launch: qparams_kernel) exactly as qrows_frag_kernel does -- rint(fma(x, 1/scale, zp)) saturated to u8, minus 128 -- and write the
+// codes into the ring in fragment order themselves.  The separate quantising pass (10.7 us per call on a configs[3] shard: an 11 MB
+// read and a 2.8 MB write between two kernels of 14 us) and the fragment-major copy of the activation in HBM disappear; each row tile
+// is quantised once per column block (6-8 times over the grid), out of L2.  A loader lane owns 4 consecutive k of one row per load:
+// 16 rows x 64 bytes per wave instruction on the global side, 64 different LDS banks on the ds_write_b32 side.
+template <int EM, int NRES, bool RELU, bool FQ = false>
 __global__ __launch_bounds__(640) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
     constexpr int KS = 16;
     extern __shared__ __attribute__((aligned(16))) char rs_lds[];
@@ -273,7 +280,65 @@ __global__ __launch_bounds__(640) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
         if (threadIdx.x < 4) s_mx[threadIdx.x] = 0u;
         __syncthreads();
     }
-    if (wave >= 8) {
+    if (FQ && wave >= 8) {
+        // ---------------------------------------------------------------- the two loaders, quantising: wave 8 + half owns k in [256 half, 256 half + 256)
+        const int half = wave - 8, q4 = lane & 3, rsub = lane >> 2;  // a phase = 16 rows of the tile, 4 lanes a row, 16 chunks of 16 k
+        const unsigned rows = g.rows, mu = (unsigned)epi.m, nslices = rows / mu;
+        auto load = [&](int i, int u, float4 (&dst)[16], float4& q, unsigned& sm) {
+            unsigned row = (unsigned)(t0 + i) * 32u + 16u * (unsigned)u + (unsigned)rsub;
+            row = row < rows ? row : rows - 1u;  // rows beyond the end repeat the last one: multiplied, never stored
+            const float* src = g.x + (size_t)row * 512u + 256u * (unsigned)half + 4u * (unsigned)q4;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) dst[c] = *reinterpret_cast<const float4*>(src + 16 * c);
+            const unsigned sl = rows == mu ? 0u : row / mu;
+            q = *reinterpret_cast<const float4*>(&epi.prm[sl]);  // {scale, zp, 1 / scale, (int) zp}
+            if (EM == 2) sm = epi.slice_max[sl < nslices ? sl : nslices - 1u];
+        };
+        auto put = [&](int i, int u, const float4 (&src)[16], const float4& q, unsigned sm) {
+            char* const slot = ring + (i % RS_NS) * RS_SLOT;
+            const float inv_scale = q.z, zp = q.y;
+            unsigned us = 0u;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                unsigned p = 0u;
+                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(src[c].x, inv_scale, zp)), 0, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(src[c].y, inv_scale, zp)), 1, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(src[c].z, inv_scale, zp)), 2, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(src[c].w, inv_scale, zp)), 3, p);
+                us = __builtin_amdgcn_sad_u8(p, 0u, us);
+                // k-step 8 half + c / 2 of the tile; inside its 1 KiB block lane (row, (c & 1)) holds k = 16 (c & 1) + [0, 16)
+                *reinterpret_cast<unsigned*>(slot + (8 * half + (c >> 1)) * 1024 + ((16 * u + rsub) + 32 * (c & 1)) * 16 + 4 * q4) = p ^ 0x80808080u;
+            }
+            us += (unsigned)__shfl_xor((int)us, 1);  // the row's four lanes: its 256 codes of this half
+            us += (unsigned)__shfl_xor((int)us, 2);
+            if (q4 == 0) {
+                const int r = 16 * u + rsub;
+                reinterpret_cast<int*>(slot + RS_TILE)[32 * half + r] = (int)us - 128 * 256;  // the two halves' sums side by side
+                if (half == 0) {
+                    reinterpret_cast<float*>(slot + RS_TILE + 256)[r] = q.x;
+                    reinterpret_cast<int*>(slot + RS_TILE + 512)[r] = __float_as_int(q.w);
+                    if (EM == 2) reinterpret_cast<unsigned*>(slot + RS_TILE + 768)[r] = sm;
+                }
+            }
+        };
+        // Tile i's rows are REQUESTED, then the barrier that hands tile i - 1 over is taken (the loader gets there long before the
+        // consumers: the loads land while it waits), then tile i is quantised into its slot.  Nothing stays in flight over the loop's
+        // back-edge -- the compiler drains the wave's loads there whatever the source says.
+        for (int i = 0; i < nt; ++i) {
+            float4 R0[16], R1[16], Q0, Q1;
+            unsigned S0 = 0u, S1 = 0u;
+            load(i, 0, R0, Q0, S0);
+            load(i, 1, R1, Q1, S1);
+            if (i > 0) rs_barrier();  // tile i - 1 is in LDS for everybody
+            put(i, 0, R0, Q0, S0);
+            put(i, 1, R1, Q1, S1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the codes are in LDS before anybody is told so
+        }
+        rs_barrier();  // the last tile
+        if (EM == 1) __syncthreads();
+        return;
+    }
+    if (!FQ && wave >= 8) {
         // ---------------------------------------------------------------- the two loaders
         // One wave issues a 1 KiB direct-to-LDS load every ~45 ns (measured; MI355X_MICROARCH.md's "ldsdma-fill" row: ~25 GB/s per
         // CU and loader wave), i.e. 0.8 us per tile -- as long as a consumer's whole tile.  So two waves split a tile's blocks
@@ -388,6 +453,7 @@ __global__ __launch_bounds__(640) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four fragments read ahead: 16 registers, not 64
         }
         r.rowsum = reinterpret_cast<const int*>(slot + RS_TILE)[l31];
+        if (FQ) r.rowsum += reinterpret_cast<const int*>(slot + RS_TILE)[32 + l31];  // the quantising loaders leave one sum per half of k
         r.scale = reinterpret_cast<const float*>(slot + RS_TILE + 256)[l31];
         r.zp_i = reinterpret_cast<const int*>(slot + RS_TILE + 512)[l31];
         r.smax = EM == 2 ? reinterpret_cast<const unsigned*>(slot + RS_TILE + 768)[l31] : 0u;

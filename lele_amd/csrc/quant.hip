@@ -102,7 +102,7 @@ __device__ __forceinline__ QParams make_qparams(float mn, float mx) {
 }
 
 __global__ void qparams_kernel(const float* __restrict__ partial, int nblocks, QParams* __restrict__ prm,
-                               float* __restrict__ scale_out, float* __restrict__ zp_out) {
+                               float* __restrict__ scale_out, float* __restrict__ zp_out, unsigned* __restrict__ zero_slice = nullptr) {
     const int s = blockIdx.x;
     float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
     for (int i = threadIdx.x; i < nblocks; i += 64) {
@@ -120,6 +120,7 @@ __global__ void qparams_kernel(const float* __restrict__ partial, int nblocks, Q
         prm[s] = q;
         if (scale_out) scale_out[s] = q.scale;
         if (zp_out) zp_out[s] = q.zp;
+        if (zero_slice) zero_slice[s] = 0u;  // the per-slice maxima a feed-forward block's range pass adds into
     }
 }
 
@@ -1010,6 +1011,9 @@ bool rs_enabled(LeleCtx* ctx, int64_t rows, int64_t n) {
 // 24.9 us against 28.7 us tiled, N = 2048 27.2 against 29.5 -- but N = 512 23.0 against 18.7 (few column tiles: the
 // weights-in-registers prologue is not amortised), and a stand-alone K = 2048 linear 54.9 against 41.3 (the fused feed-forward
 // block calls the K-split kernel itself, on a hidden layer that is already in fragment order)
+// the quantising loaders (igemm_rs.h, FQ): whole 512-element rows read as float4s.  LELE_HIP_IGEMM_RS_FQ=0 (lab build) keeps the
+// separate qrows_frag_kernel pass for A/B timing; both give the same bits.
+bool rs_fq(int64_t k, const void* dx) { return k == 512 && (((uintptr_t)dx) & 15) == 0 && lab_int("LELE_HIP_IGEMM_RS_FQ", 1) != 0; }
 bool rs_fits(LeleCtx* ctx, int64_t rows, int64_t n, int kp) { return kp == 512 && n >= 1024 && rs_enabled(ctx, rows, n); }
 // the register-stationary kernels read residuals and write results 16 bytes at a time: a device tensor that does not start on a
 // 16-byte boundary (a view into a larger buffer) takes the tiled route instead (host tensors are staged into the aligned arena)
@@ -1045,8 +1049,9 @@ int launch_qrows_frag(LeleCtx* ctx, const float* dx, int64_t rows, int k, int kp
     LELE_HIP_CHECK(hipGetLastError());
     return 0;
 }
-int launch_rs(LeleCtx* ctx, int em, const int8_t* af, const int8_t* wf, int64_t rows, int n, int8_t* hid, const IgemmEpi& epi) {
-    RsArgs g{af, wf, (unsigned)rows, n, (int)((rows + 31) / 32), (n + 31) / 32, 0, 0, hid};
+int launch_rs(LeleCtx* ctx, int em, const int8_t* af, const int8_t* wf, int64_t rows, int n, int8_t* hid, const IgemmEpi& epi,
+              const float* x_f32 = nullptr) {
+    RsArgs g{af, wf, (unsigned)rows, n, (int)((rows + 31) / 32), (n + 31) / 32, 0, 0, hid, x_f32};
 #ifdef LELE_HIP_LAB
     g.dbg = nullptr;
     g.ablate = lab_int("LELE_HIP_RS_ABLATE", 0);
@@ -1059,9 +1064,15 @@ int launch_rs(LeleCtx* ctx, int em, const int8_t* af, const int8_t* wf, int64_t 
     const int nres = epi.res1 ? (epi.res2 ? 2 : 1) : 0;
 #define LELE_RS(EM_, NRES_, RELU_)                                                                   \
     do {                                                                                             \
-        auto kern = igemm_rs_kernel<EM_, NRES_, RELU_>;                                               \
-        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), RS_LDS));                  \
-        hipLaunchKernelGGL(kern, grid, dim3(640), RS_LDS, ctx->stream, g, epi);                       \
+        if (x_f32) {                                                                                 \
+            auto kern = igemm_rs_kernel<EM_, NRES_, RELU_, true>;                                     \
+            LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), RS_LDS));              \
+            hipLaunchKernelGGL(kern, grid, dim3(640), RS_LDS, ctx->stream, g, epi);                   \
+        } else {                                                                                     \
+            auto kern = igemm_rs_kernel<EM_, NRES_, RELU_>;                                           \
+            LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), RS_LDS));              \
+            hipLaunchKernelGGL(kern, grid, dim3(640), RS_LDS, ctx->stream, g, epi);                   \
+        }                                                                                            \
     } while (0)
     if (em == 1) LELE_RS(1, 0, true);
     else if (em == 2) LELE_RS(2, 0, true);
@@ -1224,9 +1235,17 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
         LELE_TRY(frag_weights_of(ctx, weight_int8, (int)k, (int)n, kprs, &fw));
         const int64_t nrt = (rows + 31) / 32;
         void *af = nullptr, *rs = nullptr;
-        LELE_TRY(ctx->arena_alloc((size_t)nrt * kprs * 32, &af));
-        if (kprs == 512) LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));  // K = 2048: the GEMM sums the rows it loads anyway
-        LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k, kprs, (int)m, (QParams*)prm, (int8_t*)af, (int*)rs, partial, nblk, nullptr));
+        // K = 512 exactly, 16-byte aligned rows: the GEMM's loader waves quantise the f32 rows themselves (igemm_rs.h, FQ); what is
+        // left of the quantising pass is the slices' parameters (one wave a slice)
+        const bool fq = rs_fq(k, dx);
+        if (fq) {
+            hipLaunchKernelGGL(qparams_kernel, dim3((unsigned)batch), dim3(64), 0, ctx->stream, partial, nblk, (QParams*)prm, (float*)nullptr,
+                               (float*)nullptr, (unsigned*)nullptr);
+        } else {
+            LELE_TRY(ctx->arena_alloc((size_t)nrt * kprs * 32, &af));
+            if (kprs == 512) LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));  // K = 2048: the GEMM sums the rows it loads anyway
+            LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k, kprs, (int)m, (QParams*)prm, (int8_t*)af, (int*)rs, partial, nblk, nullptr));
+        }
         LELE_TRY(qprof_mark(ctx, 2));
         IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, (const int*)rs, fw.col_sums, (const QParams*)prm, 0,
                      (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
@@ -1236,7 +1255,7 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
             LELE_TRY(out->reserve_rowstat(nstat));
             if ((size_t)nstat <= out->rowstat_cap) epi.blockstat = out->rowstat;
         }
-        if (kprs == 512) LELE_TRY(launch_rs(ctx, 0, (const int8_t*)af, fw.wf, rows, (int)n, nullptr, epi));
+        if (kprs == 512) LELE_TRY(launch_rs(ctx, 0, (const int8_t*)af, fw.wf, rows, (int)n, nullptr, epi, fq ? (const float*)dx : nullptr));
         else LELE_TRY(launch_rs_ks4(ctx, (const int8_t*)af, fw.wf, rows, (int)n, epi));
         LELE_TRY(qprof_mark(ctx, 3));
         if (epi.blockstat) {
@@ -1418,20 +1437,26 @@ int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const Le
         LELE_TRY(frag_weights_of(ctx, w2_int8, (int)k2, (int)n2, 2048, &fw2));
         const int64_t nrt = (rows + 31) / 32;
         void *af1 = nullptr, *hid = nullptr;
-        LELE_TRY(ctx->arena_alloc((size_t)nrt * 512 * 32, &af1));
-        LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs1));
+        const bool fq = rs_fq(k1, dx);  // both passes of the first product quantise the f32 rows in their loader waves
         LELE_TRY(ctx->arena_alloc((size_t)nrt * 2048 * 32, &hid));
         LELE_TRY(ctx->arena_alloc((size_t)batch * 4, &hmax));
-        // rows -> i8 for the first product; the same launch clears the per-slice maxima the range pass adds into
-        LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k1, 512, (int)m, (QParams*)prm1, (int8_t*)af1, (int*)rs1, partial, nblk,
-                                   (unsigned*)hmax));
+        if (fq) {  // the slices' parameters; the same launch clears the per-slice maxima the range pass adds into
+            hipLaunchKernelGGL(qparams_kernel, dim3((unsigned)batch), dim3(64), 0, ctx->stream, partial, nblk, (QParams*)prm1, (float*)nullptr,
+                               (float*)nullptr, (unsigned*)hmax);
+        } else {
+            LELE_TRY(ctx->arena_alloc((size_t)nrt * 512 * 32, &af1));
+            LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs1));
+            // rows -> i8 for the first product; the same launch clears the per-slice maxima the range pass adds into
+            LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k1, 512, (int)m, (QParams*)prm1, (int8_t*)af1, (int*)rs1, partial, nblk,
+                                       (unsigned*)hmax));
+        }
         LELE_TRY(qprof_mark(ctx, 2));
         IgemmEpi e1{nullptr, rows, n1, (int)m, (int)k1, (const int*)rs1, fw1.col_sums, (const QParams*)prm1, 0, (int)wz1, (const float*)dws1,
                     (int)ws1_len, b1_len ? (const float*)db1 : nullptr, 1};
         e1.slice_max = (unsigned*)hmax;
-        LELE_TRY(launch_rs(ctx, 1, (const int8_t*)af1, fw1.wf, rows, (int)n1, nullptr, e1));   // range of the ReLU result per slice
+        LELE_TRY(launch_rs(ctx, 1, (const int8_t*)af1, fw1.wf, rows, (int)n1, nullptr, e1, fq ? (const float*)dx : nullptr));   // range of the ReLU result per slice
         e1.q_prm = (QParams*)prm2;
-        LELE_TRY(launch_rs(ctx, 2, (const int8_t*)af1, fw1.wf, rows, (int)n1, (int8_t*)hid, e1));  // the result again, as the next operand
+        LELE_TRY(launch_rs(ctx, 2, (const int8_t*)af1, fw1.wf, rows, (int)n1, (int8_t*)hid, e1, fq ? (const float*)dx : nullptr));  // the result again, as the next operand
         IgemmEpi e2{(float*)out->data, rows, n2, (int)m, (int)k2, nullptr, fw2.col_sums, (const QParams*)prm2, 0, (int)wz2,
                     (const float*)dws2, (int)ws2_len, b2_len ? (const float*)db2 : nullptr, apply_relu2, (const float*)dr1, (const float*)dr2};
         LELE_TRY(launch_rs_ks4(ctx, (const int8_t*)hid, fw2.wf, rows, (int)n2, e2));
