@@ -141,10 +141,10 @@ __global__ __launch_bounds__(256) void qrows_frag_kernel(const float* __restrict
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     unsigned p = 0u;
-                    p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(v[i][e].x, q.inv_scale, q.zp)), 0, p);
-                    p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(v[i][e].y, q.inv_scale, q.zp)), 1, p);
-                    p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(v[i][e].z, q.inv_scale, q.zp)), 2, p);
-                    p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(v[i][e].w, q.inv_scale, q.zp)), 3, p);
+                    p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v[i][e].x, q.inv_scale, q.zp), 0, p);
+                    p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v[i][e].y, q.inv_scale, q.zp), 1, p);
+                    p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v[i][e].z, q.inv_scale, q.zp), 2, p);
+                    p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v[i][e].w, q.inv_scale, q.zp), 3, p);
                     us = __builtin_amdgcn_sad_u8(p, 0u, us);
                     pk[i][e] = p ^ 0x80808080u;
                 }
@@ -202,6 +202,7 @@ struct RsRow {  // what the epilogue needs to know about a lane's row of the til
     int zp_i;
     unsigned slice;
     unsigned smax;  // EM 2: bits of the hidden layer's maximum over the row's slice
+    float q2_scale, q2_zp, q2_inv;  // EM 2 behind quantising loaders: the hidden layer's parameters, ready-made
 };
 
 // f32 value of one result element: IgemmEpi::value24 with the row terms in registers
@@ -211,7 +212,7 @@ __device__ __forceinline__ float rs_value(int acc, int rterm, int ca, int colsum
     float vf = (float)total;  // _mm256_cvtepi32_ps
     if (has_ws) vf = vf * dsws;
     if (has_bias) vf = vf + bias;
-    if (relu) vf = vf > 0.0f ? vf : 0.0f;
+    if (relu) vf = relu0(vf);
     return vf;
 }
 
@@ -220,7 +221,7 @@ __device__ __forceinline__ float rs_value(int acc, int rterm, int ca, int colsum
 // EM 1: only the per-slice maximum of the ReLU result (atomic max on the bits), EM 2: the result quantised with that range, written
 //       as the fragment-major i8 operand of the next product (see lele_hip_fused_ffn_quantized)
 //
-// Ten waves: eight CONSUMERS, each with the weight fragments of its own 32 columns for the whole K extent in 64 VGPRs, and two
+// Ten waves (twelve with quantising loaders, FQ): eight CONSUMERS, each with the weight fragments of its own 32 columns for the whole K extent in 64 VGPRs, and two
 // LOADERS that do nothing but direct-to-LDS loads (global_load_lds_dwordx4: a fragment block is 1 KiB of consecutive lanes, which
 // is exactly the lane-linear image that instruction writes) of the workgroup's 32-row activation tiles into a ring of RS_NS slots.
 // What the CU's load path delivers is the bound of these products (measured: ~21 TB/s chip-wide = 40 B/clk/CU whether the lines
@@ -254,14 +255,14 @@ __device__ __forceinline__ void rs_wait_vm() {
 }
 __device__ __forceinline__ void rs_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-// FQ ("fused quantise"): the two loader waves read the f32 ROWS, quantise them with the slice's parameters (prm[] is complete before the
+// FQ ("fused quantise"): FOUR loader waves read the f32 ROWS, quantise them with the slice's parameters (prm[] is complete before the
 // launch: qparams_kernel) exactly as qrows_frag_kernel does -- rint(fma(x, 1/scale, zp)) saturated to u8, minus 128 -- and write the
 // codes into the ring in fragment order themselves.  The separate quantising pass (10.7 us per call on a configs[3] shard: an 11 MB
 // read and a 2.8 MB write between two kernels of 14 us) and the fragment-major copy of the activation in HBM disappear; each row tile
 // is quantised once per column block (6-8 times over the grid), out of L2.  A loader lane owns 4 consecutive k of one row per load:
 // 16 rows x 64 bytes per wave instruction on the global side, 64 different LDS banks on the ds_write_b32 side.
 template <int EM, int NRES, bool RELU, bool FQ = false>
-__global__ __launch_bounds__(640) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
+__global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
     constexpr int KS = 16;
     extern __shared__ __attribute__((aligned(16))) char rs_lds[];
     char* const ring = rs_lds;
@@ -281,10 +282,12 @@ __global__ __launch_bounds__(640) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
         __syncthreads();
     }
     if (FQ && wave >= 8) {
-        // ---------------------------------------------------------------- the two loaders, quantising: wave 8 + half owns k in [256 half, 256 half + 256)
-        const int half = wave - 8, q4 = lane & 3, rsub = lane >> 2;  // a phase = 16 rows of the tile, 4 lanes a row, 16 chunks of 16 k
+        // ---------------------------------------------------------------- the four loaders, quantising
+        // wave 8 + j owns rows [16 u, 16 u + 16) of every tile (u = j / 2) and k in [256 half, 256 half + 256) (half = j % 2): 4 lanes a
+        // row, 16 float4s a lane and tile = 64 registers, so TWO tiles fit in flight.
+        const int half = (wave - 8) & 1, u = (wave - 8) >> 1, q4 = lane & 3, rsub = lane >> 2;
         const unsigned rows = g.rows, mu = (unsigned)epi.m, nslices = rows / mu;
-        auto load = [&](int i, int u, float4 (&dst)[16], float4& q, unsigned& sm) {
+        auto load = [&](int i, float4 (&dst)[16], float4& q, unsigned& sm) {
             unsigned row = (unsigned)(t0 + i) * 32u + 16u * (unsigned)u + (unsigned)rsub;
             row = row < rows ? row : rows - 1u;  // rows beyond the end repeat the last one: multiplied, never stored
             const float* src = g.x + (size_t)row * 512u + 256u * (unsigned)half + 4u * (unsigned)q4;
@@ -294,17 +297,18 @@ __global__ __launch_bounds__(640) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
             q = *reinterpret_cast<const float4*>(&epi.prm[sl]);  // {scale, zp, 1 / scale, (int) zp}
             if (EM == 2) sm = epi.slice_max[sl < nslices ? sl : nslices - 1u];
         };
-        auto put = [&](int i, int u, const float4 (&src)[16], const float4& q, unsigned sm) {
+        auto put = [&](int i, const float4 (&src)[16], const float4& q, unsigned sm) {
             char* const slot = ring + (i % RS_NS) * RS_SLOT;
-            const float inv_scale = q.z, zp = q.y;
+            const v2f inv2 = {q.z, q.z}, zp2 = {q.y, q.y};  // two codes an instruction (v_pk_fma_f32: the same fused multiply-add per element)
             unsigned us = 0u;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
+                const v2f c0 = __builtin_elementwise_fma(v2f{src[c].x, src[c].y}, inv2, zp2), c1 = __builtin_elementwise_fma(v2f{src[c].z, src[c].w}, inv2, zp2);
                 unsigned p = 0u;
-                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(src[c].x, inv_scale, zp)), 0, p);
-                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(src[c].y, inv_scale, zp)), 1, p);
-                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(src[c].z, inv_scale, zp)), 2, p);
-                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(src[c].w, inv_scale, zp)), 3, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(c0.x, 0, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(c0.y, 1, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(c1.x, 2, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(c1.y, 3, p);
                 us = __builtin_amdgcn_sad_u8(p, 0u, us);
                 // k-step 8 half + c / 2 of the tile; inside its 1 KiB block lane (row, (c & 1)) holds k = 16 (c & 1) + [0, 16)
                 *reinterpret_cast<unsigned*>(slot + (8 * half + (c >> 1)) * 1024 + ((16 * u + rsub) + 32 * (c & 1)) * 16 + 4 * q4) = p ^ 0x80808080u;
@@ -317,24 +321,34 @@ __global__ __launch_bounds__(640) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
                 if (half == 0) {
                     reinterpret_cast<float*>(slot + RS_TILE + 256)[r] = q.x;
                     reinterpret_cast<int*>(slot + RS_TILE + 512)[r] = __float_as_int(q.w);
-                    if (EM == 2) reinterpret_cast<unsigned*>(slot + RS_TILE + 768)[r] = sm;
+                    if (EM == 2) {
+                        // the hidden layer's parameters of the row's slice: derived HERE, once a row, not by each of the eight consumers
+                        // (make_qparams is two divisions and a rounding: a third of a consumer's epilogue otherwise)
+                        const QParams q2 = make_qparams(0.0f, __uint_as_float(sm));
+                        reinterpret_cast<float*>(slot + RS_TILE + 256)[32 + r] = q2.scale;
+                        reinterpret_cast<float*>(slot + RS_TILE + 512)[32 + r] = q2.zp;
+                        reinterpret_cast<float*>(slot + RS_TILE + 768)[32 + r] = q2.inv_scale;
+                    }
                 }
             }
-        };
-        // Tile i's rows are REQUESTED, then the barrier that hands tile i - 1 over is taken (the loader gets there long before the
-        // consumers: the loads land while it waits), then tile i is quantised into its slot.  Nothing stays in flight over the loop's
-        // back-edge -- the compiler drains the wave's loads there whatever the source says.
-        for (int i = 0; i < nt; ++i) {
-            float4 R0[16], R1[16], Q0, Q1;
-            unsigned S0 = 0u, S1 = 0u;
-            load(i, 0, R0, Q0, S0);
-            load(i, 1, R1, Q1, S1);
-            if (i > 0) rs_barrier();  // tile i - 1 is in LDS for everybody
-            put(i, 0, R0, Q0, S0);
-            put(i, 1, R1, Q1, S1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the codes are in LDS before anybody is told so
+        };
+        // Even tiles travel through RA, odd ones through RB (two named sets: nothing is copied, the compiler's counted waits stay exact).
+        // A tile's rows are requested two barriers before it is handed over; barrier number i (counted from 0) hands over tile i.
+        float4 RA[16], RB[16], QA, QB;
+        unsigned SA = 0u, SB = 0u;
+        // (Loads are unconditional -- beyond the range the last tile is read again and dropped: a load under a branch makes its
+        // registers a merge of two values, and the copy the compiler then needs waits for the load on the spot.)
+        load(0, RA, QA, SA);
+        for (int i = 0; i < nt; i += 2) {
+            load(i + 1 < nt ? i + 1 : nt - 1, RB, QB, SB);
+            if (i > 0) rs_barrier();  // tile i - 1
+            put(i, RA, QA, SA);
+            load(i + 2 < nt ? i + 2 : nt - 1, RA, QA, SA);
+            rs_barrier();  // tile i
+            if (i + 1 < nt) put(i + 1, RB, QB, SB);
         }
-        rs_barrier();  // the last tile
+        if ((nt & 1) == 0) rs_barrier();  // an odd tile was the last one
         if (EM == 1) __syncthreads();
         return;
     }
@@ -415,14 +429,14 @@ __global__ __launch_bounds__(640) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
     // the column terms of the lane's 16 columns (ct * 32 + 8 g + 4 hv + e) stay in registers: 48 of them, and no LDS round trip
     // in front of every column group of every tile
     int colsum[16];
-    float wsc[16], biasc[16];
+    v2f wsc[8], biasc[8];  // pairs of neighbouring columns: the epilogue's f32 arithmetic runs two elements an instruction (v_pk_*_f32)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         int c = ct * 32 + 8 * (q >> 2) + 4 * hv + (q & 3);
         c = c < n ? c : n - 1;  // clamped: loads stay unconditional, out-of-range columns are never stored
         colsum[q] = epi.col_sums[c];
-        wsc[q] = epi.wscale_len <= 1 ? epi.wscale[0] : epi.wscale[c];
-        biasc[q] = epi.bias ? epi.bias[c] : -0.0f;  // x + (-0.0) == x for every x, the sign of zero included
+        wsc[q >> 1][q & 1] = epi.wscale_len <= 1 ? epi.wscale[0] : epi.wscale[c];
+        biasc[q >> 1][q & 1] = epi.bias ? epi.bias[c] : -0.0f;  // x + (-0.0) == x for every x, the sign of zero included
     }
     const int cbz = 128 - epi.zp_b;
     // results leave through buffer stores: a lane that has nothing to store points beyond the buffer and the hardware drops
@@ -438,8 +452,25 @@ __global__ __launch_bounds__(640) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
     auto products = [&](int i, v16i& acc, RsRow& r) {
         const char* const slot = ring + (i % RS_NS) * RS_SLOT;
         const v4i* ap = reinterpret_cast<const v4i*>(slot) + lane;
+        r.rowsum = reinterpret_cast<const int*>(slot + RS_TILE)[l31];
+        if (FQ) r.rowsum += reinterpret_cast<const int*>(slot + RS_TILE)[32 + l31];  // the quantising loaders leave one sum per half of k
+        r.scale = reinterpret_cast<const float*>(slot + RS_TILE + 256)[l31];
+        r.zp_i = reinterpret_cast<const int*>(slot + RS_TILE + 512)[l31];
+        r.smax = EM == 2 ? reinterpret_cast<const unsigned*>(slot + RS_TILE + 768)[l31] : 0u;
+        if (EM == 2 && FQ) {
+            r.q2_scale = reinterpret_cast<const float*>(slot + RS_TILE + 256)[32 + l31];
+            r.q2_zp = reinterpret_cast<const float*>(slot + RS_TILE + 512)[32 + l31];
+            r.q2_inv = reinterpret_cast<const float*>(slot + RS_TILE + 768)[32 + l31];
+        }
+        // the accumulators START from the terms that do not depend on the products -- (128 - zp_b) rowsum + K (128 - zp_a)(128 - zp_b)
+        // + (128 - zp_a) colsum: i32 additions in another order, the same total, and 16 vector instructions a tile fewer than adding them
+        // behind the matrix core
+        {
+            const int ca = 128 - r.zp_i;
+            const int rterm = cbz * r.rowsum + epi.k * ca * cbz;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0;
+            for (int q = 0; q < 16; ++q) acc[q] = __mul24(ca, colsum[q]) + rterm;
+        }
 #ifdef LELE_HIP_LAB
         if (g.ablate & 1) {
         } else if (g.ablate & 4) {
@@ -452,11 +483,6 @@ __global__ __launch_bounds__(640) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[s], ap[s * 64], acc, 0, 0, 0);
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four fragments read ahead: 16 registers, not 64
         }
-        r.rowsum = reinterpret_cast<const int*>(slot + RS_TILE)[l31];
-        if (FQ) r.rowsum += reinterpret_cast<const int*>(slot + RS_TILE)[32 + l31];  // the quantising loaders leave one sum per half of k
-        r.scale = reinterpret_cast<const float*>(slot + RS_TILE + 256)[l31];
-        r.zp_i = reinterpret_cast<const int*>(slot + RS_TILE + 512)[l31];
-        r.smax = EM == 2 ? reinterpret_cast<const unsigned*>(slot + RS_TILE + 768)[l31] : 0u;
     };
     auto epilogue = [&](int i, const v16i& acc, const RsRow& r) {
 #ifdef LELE_HIP_LAB
@@ -481,30 +507,32 @@ __global__ __launch_bounds__(640) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
                 if (NRES > 1) res2[gq] = *reinterpret_cast<const float4*>(epi.res2 + at);
             }
         }
-        const int ca = 128 - r.zp_i;
-        const int rterm = cbz * r.rowsum + epi.k * ca * cbz;
         const float ds = r.scale;
         QParams q2;
-        if (EM == 2) q2 = make_qparams(0.0f, __uint_as_float(r.smax));
+        if (EM == 2) {
+            if (FQ) q2 = QParams{r.q2_scale, r.q2_zp, r.q2_inv, (int)r.q2_zp};
+            else q2 = make_qparams(0.0f, __uint_as_float(r.smax));
+        }
         float4 o[4];
         unsigned d[4];
-        auto val = [&](int a, int cs, float dsws, float b) {  // IgemmEpi::value24 (the weight scale is mandatory on this route)
+        // IgemmEpi::value24 on two neighbouring columns at a time (the weight scale is mandatory on this route): _mm256_cvtepi32_ps,
+        // x (dynamic scale x weight scale), + bias, ReLU -- each its own rounding, as the reference's separate instructions
+        auto val2 = [&](int t0, int t1, v2f dsws, v2f b) {
 #ifdef LELE_HIP_LAB
-            if (g.ablate & 16) return __int_as_float(a);
+            if (g.ablate & 16) return v2f{__int_as_float(t0), __int_as_float(t1)};
 #endif
-            const int total = a + rterm + __mul24(ca, cs);
-            float vf = (float)total;  // _mm256_cvtepi32_ps
+            v2f vf = {(float)t0, (float)t1};
             vf = vf * dsws;
             vf = vf + b;
-            if (RELU) vf = vf > 0.0f ? vf : 0.0f;
+            if (RELU) vf = v2f{relu0(vf.x), relu0(vf.y)};
             return vf;
         };
+        const v2f ds2 = {ds, ds};
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            o[gq].x = val(acc[4 * gq + 0], colsum[4 * gq + 0], ds * wsc[4 * gq + 0], biasc[4 * gq + 0]);
-            o[gq].y = val(acc[4 * gq + 1], colsum[4 * gq + 1], ds * wsc[4 * gq + 1], biasc[4 * gq + 1]);
-            o[gq].z = val(acc[4 * gq + 2], colsum[4 * gq + 2], ds * wsc[4 * gq + 2], biasc[4 * gq + 2]);
-            o[gq].w = val(acc[4 * gq + 3], colsum[4 * gq + 3], ds * wsc[4 * gq + 3], biasc[4 * gq + 3]);
+            const v2f lo = val2(acc[4 * gq + 0], acc[4 * gq + 1], ds2 * wsc[2 * gq], biasc[2 * gq]);
+            const v2f hi = val2(acc[4 * gq + 2], acc[4 * gq + 3], ds2 * wsc[2 * gq + 1], biasc[2 * gq + 1]);
+            o[gq].x = lo.x, o[gq].y = lo.y, o[gq].z = hi.x, o[gq].w = hi.y;
             if (EM == 0) {
                 if (NRES > 0) {
                     o[gq].x = o[gq].x + res1[gq].x, o[gq].y = o[gq].y + res1[gq].y, o[gq].z = o[gq].z + res1[gq].z, o[gq].w = o[gq].w + res1[gq].w;
@@ -520,11 +548,13 @@ __global__ __launch_bounds__(640) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
 #endif
                 __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, rok && cok ? (obase + 8u * gq) * 4u : 0xffffffffu, 0, 0);
             } else if (EM == 2) {
+                const v2f inv2 = {q2.inv_scale, q2.inv_scale}, zp2 = {q2.zp, q2.zp};
+                const v2f c0 = __builtin_elementwise_fma(lo, inv2, zp2), c1 = __builtin_elementwise_fma(hi, inv2, zp2);
                 unsigned p = 0u;
-                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(o[gq].x, q2.inv_scale, q2.zp)), 0, p);
-                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(o[gq].y, q2.inv_scale, q2.zp)), 1, p);
-                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(o[gq].z, q2.inv_scale, q2.zp)), 2, p);
-                p = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(o[gq].w, q2.inv_scale, q2.zp)), 3, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(c0.x, 0, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(c0.y, 1, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(c1.x, 2, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(c1.y, 3, p);
                 d[gq] = p ^ 0x80808080u;
             }
         }
@@ -709,6 +739,242 @@ __global__ __launch_bounds__(256, 2) void igemm_rs_ks4_kernel(RsArgs g, IgemmEpi
         t += 2;
     }
     if (t < t1) compute(a0, r0, t, 0);
+}
+
+// ------------------------------------------------------------------------------------------ K = 512, N <= 512: activations stationary
+// The projection behind the attention (5472 x 512 x 512 on a configs[3] shard) has too few column tiles for weights-in-registers (a
+// workgroup would multiply one or two row tiles with 128 KB of weights) and, as a tiled kernel, paid a separate quantising pass over
+// the rows (9 us) in front of 12 us of GEMM.  Here a workgroup owns ONE 32-row tile and ALL columns: its eight waves request the
+// weight fragments of their two column tiles (fragment order: 32 fully coalesced 1 KiB loads a wave, 128 registers), quantise the tile's
+// f32 rows meanwhile -- once, into LDS, with the slices' parameters reduced from the producer's {min, max} partials on the spot --
+// and then run straight through: 16 fragment reads, 32 products, epilogue.  No loop, one barrier, no intermediate in HBM.
+struct AsArgs {
+    const float* x;        // f32 rows [rows][512]
+    const int8_t* wf;      // weights, fragment-major [nct][16][1024]
+    unsigned rows;
+    int n, nct;
+    const float* partial;  // [slices][nblk] {min, max} pairs
+    int nblk;
+    QParams* prm;          // published per slice (the wave that holds the slice's first row)
+};
+
+template <int NRES, bool RELU>
+__global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
+    constexpr int KS = 16;
+    __shared__ __attribute__((aligned(16))) char s_tile[KS * 1024];
+    __shared__ int s_rowsum[4][32];
+    __shared__ float s_scale[32];
+    __shared__ int s_zp[32];
+    __shared__ __attribute__((aligned(16))) int s_colsum[512];
+    __shared__ __attribute__((aligned(16))) float s_ws[512];
+    __shared__ __attribute__((aligned(16))) float s_bias[512];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hv = lane >> 5, l31 = lane & 31;
+    const int t = blockIdx.x, n = g.n;
+    const unsigned rows = g.rows, mu = (unsigned)epi.m;
+    // Everything below is requested in the order it is needed (a wave's loads complete in order as far as its counter can tell): the
+    // range partials of the first two slices, the rows, the column terms -- and only then the 32 KiB of weights, which travel while
+    // the parameters are reduced and the rows quantised.
+    // ---- 1. the rows: wave (u, kq) takes rows [16 u, 16 u + 16) and k in [128 kq, 128 kq + 128): 4 lanes a row, 8 chunks of 16 k
+    const int u = wave >> 2, kq = wave & 3, q4 = lane & 3, rsub = lane >> 2;
+    const unsigned row_q = (unsigned)t * 32u + 16u * (unsigned)u + (unsigned)rsub;
+    const unsigned rowc_q = row_q < rows ? row_q : rows - 1u;
+    const unsigned first = (unsigned)t * 32u + 16u * (unsigned)u;
+    const unsigned last = first + 15u < rows ? first + 15u : rows - 1u;
+    const unsigned s_lo = (first < rows ? first : rows - 1u) / mu, s_hi = last / mu;
+    float2 pw[2][4];  // the first 256 {min, max} pairs of slices s_lo and s_lo + 1 (clamped: a repeated pair changes nothing)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const unsigned sl = s_lo + (unsigned)a < s_hi ? s_lo + (unsigned)a : s_hi;
+        const float2* pp = reinterpret_cast<const float2*>(g.partial) + (size_t)sl * g.nblk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = lane + 64 * j;
+            pw[a][j] = pp[idx < g.nblk ? idx : g.nblk - 1];
+        }
+    }
+    float4 xv[8];
+    {
+        const float* src = g.x + (size_t)rowc_q * 512u + 128u * (unsigned)kq + 4u * (unsigned)q4;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xv[c] = *reinterpret_cast<const float4*>(src + 16 * c);
+    }
+    // the column terms of the whole tile row: one column a thread (no branch around a load: a missing bias reads the scale and drops it)
+    const int ccol = (int)threadIdx.x < n ? (int)threadIdx.x : n - 1;
+    const int csum = epi.col_sums[ccol];
+    const float wsv = epi.wscale[epi.wscale_len <= 1 ? 0 : ccol];
+    const float bv = (epi.bias ? epi.bias : epi.wscale)[epi.bias ? ccol : 0];
+    __builtin_amdgcn_sched_barrier(0);  // ... and the compiler keeps that order
+    // ---- 2. the weights of column tiles 2 wave and 2 wave + 1 (a tile beyond the last one repeats it: multiplied, never stored)
+    const int ct0 = 2 * wave, ct1 = 2 * wave + 1;
+    v4i bf0[KS], bf1[KS];
+    {
+        const v4i* w0 = reinterpret_cast<const v4i*>(g.wf) + (size_t)(ct0 < g.nct ? ct0 : g.nct - 1) * KS * 64 + lane;
+        const v4i* w1 = reinterpret_cast<const v4i*>(g.wf) + (size_t)(ct1 < g.nct ? ct1 : g.nct - 1) * KS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bf0[s] = w0[s * 64];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bf1[s] = w1[s * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    s_colsum[threadIdx.x] = csum;
+    s_ws[threadIdx.x] = wsv;
+    s_bias[threadIdx.x] = epi.bias ? bv : -0.0f;  // x + (-0.0) == x for every x, the sign of zero included
+    // ---- 3. the parameters of the slices this wave's rows belong to (wave-uniform loop: one or two in practice), as qrows_kernel<0>
+    QParams q = {1.0f, 0.0f, 1.0f, 0};
+    {
+        const unsigned mine = rowc_q / mu;
+        for (unsigned sl = s_lo; sl <= s_hi; ++sl) {
+            float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+            const float2* pp = reinterpret_cast<const float2*>(g.partial) + (size_t)sl * g.nblk;
+            int i0 = 0;
+            if (sl - s_lo < 2u) {  // requested before anything else
+                const int a = (int)(sl - s_lo);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float2 w = a == 0 ? pw[0][j] : pw[1][j];
+                    mn = w.x < mn ? w.x : mn;
+                    mx = w.y > mx ? w.y : mx;
+                }
+                i0 = 256;
+            }
+            for (; i0 < g.nblk; i0 += 256) {  // more than 256 pairs a slice, a third slice in 16 rows: fetched now
+                float2 w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int idx = i0 + lane + 64 * j;
+                    w[j] = pp[idx < g.nblk ? idx : g.nblk - 1];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mn = w[j].x < mn ? w[j].x : mn;
+                    mx = w[j].y > mx ? w[j].y : mx;
+                }
+            }
+            mn = wave_allreduce64(mn, [](float cur, float a) { return a < cur ? a : cur; });
+            mx = wave_allreduce64(mx, [](float cur, float a) { return a > cur ? a : cur; });
+            const QParams qs = make_qparams(mn, mx);
+            if (mine == sl) q = qs;
+            if (kq == 0 && q4 == 0 && row_q < rows && row_q == sl * mu) g.prm[sl] = qs;  // the slice's first row publishes
+        }
+    }
+    // ---- 4. quantise into fragment order: rint(fma(x, 1 / scale, zp)) saturated to u8, minus 128 (K = 512: every element is in the
+    //         reference's SIMD body)
+    {
+        const v2f inv2 = {q.inv_scale, q.inv_scale}, zp2 = {q.zp, q.zp};
+        unsigned us = 0u;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const v2f c0 = __builtin_elementwise_fma(v2f{xv[c].x, xv[c].y}, inv2, zp2), c1 = __builtin_elementwise_fma(v2f{xv[c].z, xv[c].w}, inv2, zp2);
+            unsigned p = 0u;
+            p = __builtin_amdgcn_cvt_pk_u8_f32(c0.x, 0, p);
+            p = __builtin_amdgcn_cvt_pk_u8_f32(c0.y, 1, p);
+            p = __builtin_amdgcn_cvt_pk_u8_f32(c1.x, 2, p);
+            p = __builtin_amdgcn_cvt_pk_u8_f32(c1.y, 3, p);
+            us = __builtin_amdgcn_sad_u8(p, 0u, us);
+            // k-step 4 kq + c / 2; inside its 1 KiB block lane (row, c & 1) holds k = 16 (c & 1) + [0, 16)
+            *reinterpret_cast<unsigned*>(s_tile + (4 * kq + (c >> 1)) * 1024 + ((16 * u + rsub) + 32 * (c & 1)) * 16 + 4 * q4) = p ^ 0x80808080u;
+        }
+        us += (unsigned)__shfl_xor((int)us, 1);  // the row's four lanes: its 128 codes of this quarter of k
+        us += (unsigned)__shfl_xor((int)us, 2);
+        if (q4 == 0) {
+            s_rowsum[kq][16 * u + rsub] = (int)us - 128 * 128;
+            if (kq == 0) {
+                s_scale[16 * u + rsub] = q.scale;
+                s_zp[16 * u + rsub] = q.zp_i;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 5. products: the tile's 16 fragments against both column tiles
+    // (the accumulators start from the row / column terms, as in igemm_rs_kernel)
+    const unsigned row = (unsigned)t * 32u + (unsigned)l31;
+    const bool rok = row < rows;
+    const unsigned rowc = rok ? row : rows - 1u;
+    const float ds = s_scale[l31];
+    v16i acc0, acc1;
+    {
+        const int rowsum = s_rowsum[0][l31] + s_rowsum[1][l31] + s_rowsum[2][l31] + s_rowsum[3][l31];
+        const int ca = 128 - s_zp[l31], cbz = 128 - epi.zp_b;
+        const int rterm = cbz * rowsum + epi.k * ca * cbz;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const v4i c0 = *reinterpret_cast<const v4i*>(&s_colsum[(ct0 * 32 + 4 * hv + 8 * gq) & 511]);
+            const v4i c1 = *reinterpret_cast<const v4i*>(&s_colsum[(ct1 * 32 + 4 * hv + 8 * gq) & 511]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc0[4 * gq + e] = __mul24(ca, c0[e]) + rterm, acc1[4 * gq + e] = __mul24(ca, c1[e]) + rterm;
+        }
+    }
+    // the residual operands of both tiles: requested before the products (the rows' registers are free again), used behind them
+    float4 ra1[NRES > 0 ? 4 : 1], ra2[NRES > 1 ? 4 : 1], rb1[NRES > 0 ? 4 : 1], rb2[NRES > 1 ? 4 : 1];
+    if (NRES > 0) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int c0 = ct0 * 32 + 4 * hv + 8 * gq, c1 = ct1 * 32 + 4 * hv + 8 * gq;
+            const unsigned at0 = rowc * (unsigned)n + (unsigned)(c0 < n ? c0 : n - 4), at1 = rowc * (unsigned)n + (unsigned)(c1 < n ? c1 : n - 4);
+            ra1[gq] = *reinterpret_cast<const float4*>(epi.res1 + at0);
+            rb1[gq] = *reinterpret_cast<const float4*>(epi.res1 + at1);
+            if (NRES > 1) {
+                ra2[gq] = *reinterpret_cast<const float4*>(epi.res2 + at0);
+                rb2[gq] = *reinterpret_cast<const float4*>(epi.res2 + at1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+        const v4i* ap = reinterpret_cast<const v4i*>(s_tile) + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const v4i a = ap[s * 64];
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf0[s], a, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf1[s], a, acc1, 0, 0, 0);
+        }
+    }
+    // ---- 6. epilogue (IgemmEpi::value24 with the row terms from LDS), a lane = one row x {4 x 4 columns} of each tile
+    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)epi.out, 0, (int)(rows * (unsigned)n * 4u), 0x00020000);
+    const v2f ds2 = {ds, ds};
+    auto finish = [&](const v16i& acc, int ct, const float4 (&res1)[NRES > 0 ? 4 : 1], const float4 (&res2)[NRES > 1 ? 4 : 1]) {
+        const unsigned obase = rowc * (unsigned)n + (unsigned)(ct * 32 + 4 * hv);  // rows * n < 2^30
+        float smn = 3.40282347e+38f, smx = -3.40282347e+38f;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int cl = (ct * 32 + 4 * hv + 8 * gq) & 511;
+            const float4 ws = *reinterpret_cast<const float4*>(&s_ws[cl]);
+            const float4 bs = *reinterpret_cast<const float4*>(&s_bias[cl]);
+            auto val2 = [&](int t0, int t1, v2f w, v2f b) {
+                v2f vf = {(float)t0, (float)t1};  // _mm256_cvtepi32_ps
+                vf = vf * (ds2 * w);
+                vf = vf + b;
+                if (RELU) vf = v2f{relu0(vf.x), relu0(vf.y)};
+                return vf;
+            };
+            const v2f lo = val2(acc[4 * gq + 0], acc[4 * gq + 1], v2f{ws.x, ws.y}, v2f{bs.x, bs.y});
+            const v2f hi = val2(acc[4 * gq + 2], acc[4 * gq + 3], v2f{ws.z, ws.w}, v2f{bs.z, bs.w});
+            float4 o = make_float4(lo.x, lo.y, hi.x, hi.y);
+            if (NRES > 0) {
+                o.x = o.x + res1[gq].x, o.y = o.y + res1[gq].y, o.z = o.z + res1[gq].z, o.w = o.w + res1[gq].w;
+                if (NRES > 1) o.x = o.x + res2[gq].x, o.y = o.y + res2[gq].y, o.z = o.z + res2[gq].z, o.w = o.w + res2[gq].w;
+            }
+            const bool cok = ct * 32 + 4 * hv + 8 * gq < n;  // n % 4 == 0: a group of four columns is whole or absent
+            const v4u bits = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, rok && cok ? (obase + 8u * gq) * 4u : 0xffffffffu, 0, 0);
+            if (rok && cok) {
+                smn = fminf(smn, fminf(fminf(o.x, o.y), fminf(o.z, o.w)));
+                smx = fmaxf(smx, fmaxf(fmaxf(o.x, o.y), fmaxf(o.z, o.w)));
+            }
+        }
+        if (epi.blockstat && ct < g.nct) {  // one {min, max} pair per (row tile, column tile): LeleBuf::rowstat kind 1
+            smn = wave_allreduce64(smn, [](float cur, float x) { return x < cur ? x : cur; });
+            smx = wave_allreduce64(smx, [](float cur, float x) { return x > cur ? x : cur; });
+            if (lane == 0) {
+                float* so = epi.blockstat + ((size_t)t * g.nct + ct) * 2;
+                so[0] = smn;
+                so[1] = smx;
+            }
+        }
+    };
+    finish(acc0, ct0, ra1, ra2);
+    finish(acc1, ct1, rb1, rb2);
 }
 
 }  // namespace

@@ -33,6 +33,7 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct QParams {  // per batch slice
     float scale, zp, inv_scale;
@@ -83,6 +84,12 @@ __global__ __launch_bounds__(256) void qminmax_kernel(const float* __restrict__ 
         o[1] = mx;
     }
 }
+
+// Two instructions that do on their own what the reference spells out in several (probed on gfx950: profiles/r05_cvt_pk_u8_probe.txt):
+//   * v_cvt_pk_u8_f32 rounds to nearest EVEN and saturates to [0, 255] (0.5 -> 0, 1.5 -> 2, 2.5 -> 2, 254.5 -> 254, 255.5 and
+//     +inf -> 255, negative values and NaN -> 0): _mm256_round_ps(.., NEAREST) + the clamp + the pack in one -- no rintf in front;
+//   * v_max_f32(x, +0) returns +0 for x = -0, for negative x and for NaN: `if x > 0 { x } else { 0 }` (ReLU) bit for bit.
+__device__ __forceinline__ float relu0(float v) { return __builtin_fmaxf(v, 0.0f); }
 
 // avx/quantization.rs:134-140: range -> {scale, zero point, 1/scale}
 __device__ __forceinline__ QParams make_qparams(float mn, float mx) {
@@ -217,13 +224,13 @@ __global__ __launch_bounds__(256) void qrows_kernel(const float* __restrict__ x,
             if (u < nch) {
                 const int c = lane * 4 + 256 * u;
                 if (MODE == 0 && c + 3 < simd_k) {
-                    // four elements inside the SIMD body: fma, round-to-nearest-even, v_cvt_pk_u8_f32 (saturates to [0, 255] = the
+                    // four elements inside the SIMD body: fma, v_cvt_pk_u8_f32 (rounds to nearest even, saturates to [0, 255] = the
                     // clamp, and packs); per four elements one xor 0x80808080 (q - 128 as i8) and one v_sad_u8 (their sum)
                     unsigned pk = 0;
-                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(pre[u].x, q.inv_scale, q.zp)), 0, pk);
-                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(pre[u].y, q.inv_scale, q.zp)), 1, pk);
-                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(pre[u].z, q.inv_scale, q.zp)), 2, pk);
-                    pk = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(pre[u].w, q.inv_scale, q.zp)), 3, pk);
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(pre[u].x, q.inv_scale, q.zp), 0, pk);
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(pre[u].y, q.inv_scale, q.zp), 1, pk);
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(pre[u].z, q.inv_scale, q.zp), 2, pk);
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(pre[u].w, q.inv_scale, q.zp), 3, pk);
                     usum = __builtin_amdgcn_sad_u8(pk, 0u, usum);
                     nfast += 4;
                     *reinterpret_cast<unsigned*>(dst + c) = pk ^ 0x80808080u;
@@ -396,7 +403,7 @@ struct IgemmEpi {
         // combined_scale[j] = dyn_scale * weight_scale[j], then one mul (dyn_scale is 1.0 when there is no dynamic range)
         if (wscale) vf = vf * (r.dyn_scale * c.ws);
         if (bias) vf = vf + c.bias;
-        if (relu) vf = vf > 0.0f ? vf : 0.0f;
+        if (relu) vf = relu0(vf);
         return vf;
     }
     // the same value with the zero-point product on the 24-bit multiplier (full rate): |128 - zp_a| <= 128 and a column sum of
@@ -406,7 +413,7 @@ struct IgemmEpi {
         float vf = (float)total;
         if (wscale) vf = vf * (r.dyn_scale * c.ws);
         if (bias) vf = vf + c.bias;
-        if (relu) vf = vf > 0.0f ? vf : 0.0f;
+        if (relu) vf = relu0(vf);
         return vf;
     }
     __device__ __forceinline__ void store(const RowCtx& r, const ColCtx& c, int col, int acc) const { r.orow[col] = value(r, c, acc); }
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
 #pragma unroll
                 for (int j = 0; j < TNT; ++j) {
                     const float v = epi.value24(rc, cc[j], acc[i][j][r]);
-                    const unsigned q = __builtin_amdgcn_cvt_pk_u8_f32(rintf(__builtin_fmaf(v, inv, zp)), 0, 0u);
+                    const unsigned q = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(v, inv, zp), 0, 0u);
                     qt[lr * QP + wn * TNT * 32 + j * 32 + l31] = (char)(q ^ 0x80u);
                 }
             }
@@ -1014,7 +1021,7 @@ bool rs_enabled(LeleCtx* ctx, int64_t rows, int64_t n) {
 // the quantising loaders (igemm_rs.h, FQ): whole 512-element rows read as float4s.  LELE_HIP_IGEMM_RS_FQ=0 (lab build) keeps the
 // separate qrows_frag_kernel pass for A/B timing; both give the same bits.
 bool rs_fq(int64_t k, const void* dx) { return k == 512 && (((uintptr_t)dx) & 15) == 0 && lab_int("LELE_HIP_IGEMM_RS_FQ", 1) != 0; }
-bool rs_fits(LeleCtx* ctx, int64_t rows, int64_t n, int kp) { return kp == 512 && n >= 1024 && rs_enabled(ctx, rows, n); }
+bool rs_fits(LeleCtx* ctx, int64_t rows, int64_t n, int kp) { return kp == 512 && n >= lab_int("LELE_HIP_IGEMM_RS_MIN_N", 1024) && rs_enabled(ctx, rows, n); }
 // the register-stationary kernels read residuals and write results 16 bytes at a time: a device tensor that does not start on a
 // 16-byte boundary (a view into a larger buffer) takes the tiled route instead (host tensors are staged into the aligned arena)
 bool rs_aligned(const LeleTensor* t) { return !t || t->mem != LELE_MEM_DEVICE || (((uintptr_t)t->data) & 15) == 0; }
@@ -1067,7 +1074,7 @@ int launch_rs(LeleCtx* ctx, int em, const int8_t* af, const int8_t* wf, int64_t 
         if (x_f32) {                                                                                 \
             auto kern = igemm_rs_kernel<EM_, NRES_, RELU_, true>;                                     \
             LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), RS_LDS));              \
-            hipLaunchKernelGGL(kern, grid, dim3(640), RS_LDS, ctx->stream, g, epi);                   \
+            hipLaunchKernelGGL(kern, grid, dim3(768), RS_LDS, ctx->stream, g, epi);                   \
         } else {                                                                                     \
             auto kern = igemm_rs_kernel<EM_, NRES_, RELU_>;                                           \
             LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), RS_LDS));              \
@@ -1086,6 +1093,31 @@ int launch_rs(LeleCtx* ctx, int em, const int8_t* af, const int8_t* wf, int64_t 
         else LELE_RS(0, 2, false);
     }
 #undef LELE_RS
+    LELE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+// K = 512, N <= 512: one workgroup a row tile, all columns (igemm_as_kernel)
+bool as_fits(LeleCtx* ctx, int64_t rows, int64_t n, int64_t k, const void* dx) {
+    if (env_int("LELE_HIP_IGEMM_RS", 1) == 0 || lab_int("LELE_HIP_IGEMM_AS", 1) == 0) return false;
+    return k == 512 && n <= 512 && n % 4 == 0 && n >= 4 && rows * n < (int64_t(1) << 30) && (((uintptr_t)dx) & 15) == 0 &&
+           rows >= (int64_t)lab_int("LELE_HIP_IGEMM_AS_MIN_ROWS", 1024);
+}
+int launch_as(LeleCtx* ctx, const float* x, const int8_t* wf, int64_t rows, int n, const float* partial, int nblk, QParams* prm,
+              const IgemmEpi& epi) {
+    AsArgs g{x, wf, (unsigned)rows, n, (n + 31) / 32, partial, nblk, prm};
+    const dim3 grid((unsigned)((rows + 31) / 32));
+    const int nres = epi.res1 ? (epi.res2 ? 2 : 1) : 0;
+#define LELE_AS(NRES_, RELU_) hipLaunchKernelGGL((igemm_as_kernel<NRES_, RELU_>), grid, dim3(512), 0, ctx->stream, g, epi)
+    if (epi.relu) {
+        if (nres == 0) LELE_AS(0, true);
+        else if (nres == 1) LELE_AS(1, true);
+        else LELE_AS(2, true);
+    } else {
+        if (nres == 0) LELE_AS(0, false);
+        else if (nres == 1) LELE_AS(1, false);
+        else LELE_AS(2, false);
+    }
+#undef LELE_AS
     LELE_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1257,6 +1289,30 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
         }
         if (kprs == 512) LELE_TRY(launch_rs(ctx, 0, (const int8_t*)af, fw.wf, rows, (int)n, nullptr, epi, fq ? (const float*)dx : nullptr));
         else LELE_TRY(launch_rs_ks4(ctx, (const int8_t*)af, fw.wf, rows, (int)n, epi));
+        LELE_TRY(qprof_mark(ctx, 3));
+        if (epi.blockstat) {
+            out->rowstat_rows = nstat;
+            out->rowstat_len = rows * n;
+            out->rowstat_kind = 1;
+            out->rowstat_valid = true;
+        }
+        return set_shape_v(out_shape, out_rank, shp);
+    }
+
+    // ---- activations stationary (igemm_rs.h): few column tiles, K = 512 -- quantise and multiply in one kernel
+    if (as_fits(ctx, rows, n, k, dx) && rs_aligned(res1) && rs_aligned(res2) && (((uintptr_t)out->data) & 15) == 0) {
+        FragW fw;
+        LELE_TRY(frag_weights_of(ctx, weight_int8, (int)k, (int)n, 512, &fw));
+        LELE_TRY(qprof_mark(ctx, 2));
+        IgemmEpi epi{(float*)out->data, rows, n, (int)m, (int)k, nullptr, fw.col_sums, (const QParams*)prm, 0,
+                     (int)wz, (const float*)dws, (int)ws_len, blen ? (const float*)db : nullptr, apply_relu, (const float*)dr1,
+                     (const float*)dr2};
+        const int64_t nstat = ((rows + 31) / 32) * ((n + 31) / 32);
+        if (batch == 1 && nstat <= 4096) {
+            LELE_TRY(out->reserve_rowstat(nstat));
+            if ((size_t)nstat <= out->rowstat_cap) epi.blockstat = out->rowstat;
+        }
+        LELE_TRY(launch_as(ctx, (const float*)dx, fw.wf, rows, (int)n, partial, nblk, (QParams*)prm, epi));
         LELE_TRY(qprof_mark(ctx, 3));
         if (epi.blockstat) {
             out->rowstat_rows = nstat;

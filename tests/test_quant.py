@@ -276,6 +276,44 @@ def test_register_stationary_gemm_bit_exact_on_edge_shapes(ctx, b, m, k, n, relu
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,m,n,relu,bias,scalar_ws", [
+    (1, 5472, 512, False, True, False),     # the projection behind the attention on a configs[3] shard, as one slice
+    (32, 171, 512, False, True, False),     # ... and with its 32 slices (a row tile holds rows of two of them)
+    (150, 7, 100, True, True, False),       # slices shorter than a wave's 16 rows: up to four parameter sets a wave; n % 32 = 4
+    (3, 347, 36, False, False, True),       # 1041 rows (a last tile of 17), two column tiles of which one is partial, no bias
+    (33, 64, 260, True, True, False),       # slices of exactly two row tiles; nine column tiles: the last wave has one
+    (1, 1025, 4, False, True, True),        # the narrowest result; one row in the last tile
+])
+def test_activation_stationary_gemm_bit_exact_on_edge_shapes(ctx, b, m, n, relu, bias, scalar_ws):
+    """igemm_as_kernel (K = 512 exactly, results at most 512 wide, 1024 rows or more): rows quantised inside the GEMM with the
+    slices' parameters reduced from the {min, max} partials on the spot -- same bits as the oracle and as the tiled route
+    (LELE_HIP_IGEMM_RS=0), with and without the residual operands of the epilogue, and the parameters it publishes / the block
+    statistics it leaves serve a following quantised linear"""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    from oracle import pyoracle as O
+    rng = np.random.default_rng(b * 11 + m + n)
+    k = 512
+    x = (rng.standard_normal((b, m, k)) * rng.uniform(0.2, 4.0, (b, 1, 1))).astype(np.float32)
+    w = Weight(np.clip(np.round(128 + 40 * rng.standard_normal((k, n))), 0, 255).astype(np.float32))
+    ws = Weight((np.full(1, 0.0071) if scalar_ws else rng.random(n) * 0.01 + 0.002).astype(np.float32))
+    wz = Weight(np.array([121.0], np.float32))
+    bs = Weight(rng.standard_normal(n).astype(np.float32)) if bias else None
+    want = O.fused_quantized_linear(x, w.arr, ws.arr, wz.arr, bs.arr if bias else None, relu)
+    lin = K.fused_quantized_linear(x, w, ws, wz, bs, relu, ctx=ctx)
+    assert lin.shape == want.shape and np.array_equal(lin.numpy(), want)
+    r1, r2 = rng.standard_normal(want.shape).astype(np.float32), rng.standard_normal(want.shape).astype(np.float32)
+    assert np.array_equal(K.fused_quantized_linear_residual(x, w, ws, wz, bs, relu, r1, ctx=ctx).numpy(), want + r1)
+    assert np.array_equal(K.fused_quantized_linear_residual(x, w, ws, wz, bs, relu, r1, r2, ctx=ctx).numpy(), (want + r1) + r2)
+    with _env(LELE_HIP_IGEMM_RS=0):
+        assert np.array_equal(K.fused_quantized_linear(x, w, ws, wz, bs, relu, ctx=ctx).numpy(), want)
+    if n % 4 == 0 and n >= 16:  # the result feeds another quantised linear: its range comes from what this kernel left (or a scan)
+        w2 = _qw(rng, n, 24)
+        assert np.array_equal(K.fused_quantized_linear(lin, *w2, False, ctx=ctx).numpy(),
+                              O.fused_quantized_linear(want, w2[0].arr, w2[1].arr, [128.0], w2[3].arr, False))
+
+
+@pytest.mark.gpu
 def test_fused_ffn_is_deterministic_under_repetition(ctx):
     """the recompute route combines per-workgroup maxima through LDS and global atomics and row sums through integer atomics:
     300 repetitions of one configs[3]-shard call must give one bit pattern (a race here shows up as one utterance in a few
