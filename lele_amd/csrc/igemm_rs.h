@@ -31,6 +31,11 @@ struct RsArgs {
     int ncb, nrr;  // K = 512: column blocks of 8 tiles and row ranges (grid = ncb * nrr); K split: grid = nct * nrr
     int8_t* hid;   // EM 2: the result as fragment-major i8 [nrt][n / 32][1024]
     const float* x;  // FQ kernels: the f32 activation [rows][512] itself (af is unused): the loaders quantise it into the ring
+    // FQ kernels derive the slices' parameters themselves (no parameter kernel in front):
+    const float* partial;  // {min, max} pairs of the activation, [slices][nblk]
+    int nblk;
+    unsigned* hpart;       // fused feed-forward block: [grid][4] bits of the hidden layer's maxima per workgroup (its first four slices) --
+                           // EM 1 writes them (plain stores: nothing to clear beforehand), EM 2 reduces the ones that concern its rows
 #ifdef LELE_HIP_LAB
     long long* dbg;  // lab build: [grid][9][32] wall-clock stamps (100 MHz) of every wave (wave 8 = the loader), or NULL
     int ablate;      // lab build (results wrong): 1 no products, 2 no epilogue, 4 no fragment reads (products on stale registers)
@@ -196,6 +201,29 @@ __device__ __forceinline__ unsigned rs_logical_block() {  // workgroup b runs on
     return xcd * base + (xcd < rem ? xcd : rem) + (b >> 3);
 }
 
+// {scale, zp, 1 / scale, (int) zp} of slice `sl` from the producer's {min, max} pairs -- what qparams_kernel / qrows_kernel<0> compute,
+// by one wave (min / max are order-independent: the same parameters whoever reduces)
+__device__ __forceinline__ QParams slice_params(const float* __restrict__ partial, int nblk, unsigned sl, int lane) {
+    float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+    const float2* pp = reinterpret_cast<const float2*>(partial) + (size_t)sl * nblk;
+    for (int i0 = 0; i0 < nblk; i0 += 256) {  // 4 pairs per lane in flight per trip (clamped: a repeated pair changes nothing)
+        float2 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = i0 + lane + 64 * j;
+            w[j] = pp[idx < nblk ? idx : nblk - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mn = w[j].x < mn ? w[j].x : mn;
+            mx = w[j].y > mx ? w[j].y : mx;
+        }
+    }
+    mn = wave_allreduce64(mn, [](float cur, float a) { return a < cur ? a : cur; });
+    mx = wave_allreduce64(mx, [](float cur, float a) { return a > cur ? a : cur; });
+    return make_qparams(mn, mx);
+}
+
 struct RsRow {  // what the epilogue needs to know about a lane's row of the tile in flight
     int rowsum;
     float scale;
@@ -231,7 +259,8 @@ __device__ __forceinline__ float rs_value(int acc, int rterm, int ca, int colsum
 // the consumers and the slot of tile i - 1 back to the loader.  Consumers never touch a counter by hand: their loads (weights
 // once, row terms, residuals) and stores are the compiler's.
 constexpr int RS_NS = 5, RS_AHEAD = 3, RS_TILE = 16 * 1024, RS_SLOT = RS_TILE + 4 * 256;  // a slot: the tile's 16 fragment blocks + its row terms
-constexpr int RS_LDS = RS_NS * RS_SLOT + 3 * 8 * 32 * 4 + 16;        // ring + column strips + EM 1 maxima
+constexpr int RS_MAXSL = 16;                                          // FQ: slices a workgroup's row range may touch (launch_rs checks)
+constexpr int RS_LDS = RS_NS * RS_SLOT + 3 * 8 * 32 * 4 + 16 + 2 * RS_MAXSL * 16;  // ring + column strips + EM 1 maxima + FQ parameter tables
 
 // one direct-to-LDS load of 16 bytes per lane: LDS address = lds_dst (wave-uniform byte address) + 16 * lane.  Inline asm: the
 // compiler's own counter bookkeeping must not see it (it would drain the ring at every barrier)
@@ -270,6 +299,8 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
     float* const s_ws = reinterpret_cast<float*>(s_colsum + 256);
     float* const s_bias = s_ws + 256;
     unsigned* const s_mx = reinterpret_cast<unsigned*>(s_bias + 256);  // [4]
+    float4* const s_prm = reinterpret_cast<float4*>(s_mx + 4);           // FQ: [RS_MAXSL] {scale, zp, 1 / scale, (int) zp} of the input's slices
+    float4* const s_q2 = s_prm + RS_MAXSL;                                // FQ, EM 2: [RS_MAXSL] {scale, zp, 1 / scale, bits of the maximum} of the hidden layer's
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hv = lane >> 5, l31 = lane & 31;
     const unsigned L = rs_logical_block();
@@ -286,29 +317,32 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
         // wave 8 + j owns rows [16 u, 16 u + 16) of every tile (u = j / 2) and k in [256 half, 256 half + 256) (half = j % 2): 4 lanes a
         // row, 16 float4s a lane and tile = 64 registers, so TWO tiles fit in flight.
         const int half = (wave - 8) & 1, u = (wave - 8) >> 1, q4 = lane & 3, rsub = lane >> 2;
-        const unsigned rows = g.rows, mu = (unsigned)epi.m, nslices = rows / mu;
-        auto load = [&](int i, float4 (&dst)[16], float4& q, unsigned& sm) {
+        const unsigned rows = g.rows, mu = (unsigned)epi.m;
+        const bool single = rows == mu;
+        const unsigned row_end = (unsigned)t1 * 32u < rows ? (unsigned)t1 * 32u : rows;
+        const unsigned s_lo = single ? 0u : ((unsigned)t0 * 32u) / mu, s_hi = single ? 0u : (row_end - 1u) / mu;  // at most RS_MAXSL slices
+        auto load = [&](int i, float4 (&dst)[16]) {
             unsigned row = (unsigned)(t0 + i) * 32u + 16u * (unsigned)u + (unsigned)rsub;
             row = row < rows ? row : rows - 1u;  // rows beyond the end repeat the last one: multiplied, never stored
             const float* src = g.x + (size_t)row * 512u + 256u * (unsigned)half + 4u * (unsigned)q4;
 #pragma unroll
             for (int c = 0; c < 16; ++c) dst[c] = *reinterpret_cast<const float4*>(src + 16 * c);
-            const unsigned sl = rows == mu ? 0u : row / mu;
-            q = *reinterpret_cast<const float4*>(&epi.prm[sl]);  // {scale, zp, 1 / scale, (int) zp}
-            if (EM == 2) sm = epi.slice_max[sl < nslices ? sl : nslices - 1u];
         };
-        auto put = [&](int i, const float4 (&src)[16], const float4& q, unsigned sm) {
+        auto put = [&](int i, const float4 (&src)[16]) {
             char* const slot = ring + (i % RS_NS) * RS_SLOT;
-            const v2f inv2 = {q.z, q.z}, zp2 = {q.y, q.y};  // two codes an instruction (v_pk_fma_f32: the same fused multiply-add per element)
+            unsigned row = (unsigned)(t0 + i) * 32u + 16u * (unsigned)u + (unsigned)rsub;
+            row = row < rows ? row : rows - 1u;
+            const unsigned rel = single ? 0u : row / mu - s_lo;
+            const float4 q = s_prm[rel];  // {scale, zp, 1 / scale, (int) zp}
+            const float inv_scale = q.z, zp = q.y;
             unsigned us = 0u;
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
-                const v2f c0 = __builtin_elementwise_fma(v2f{src[c].x, src[c].y}, inv2, zp2), c1 = __builtin_elementwise_fma(v2f{src[c].z, src[c].w}, inv2, zp2);
                 unsigned p = 0u;
-                p = __builtin_amdgcn_cvt_pk_u8_f32(c0.x, 0, p);
-                p = __builtin_amdgcn_cvt_pk_u8_f32(c0.y, 1, p);
-                p = __builtin_amdgcn_cvt_pk_u8_f32(c1.x, 2, p);
-                p = __builtin_amdgcn_cvt_pk_u8_f32(c1.y, 3, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(src[c].x, inv_scale, zp), 0, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(src[c].y, inv_scale, zp), 1, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(src[c].z, inv_scale, zp), 2, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(src[c].w, inv_scale, zp), 3, p);
                 us = __builtin_amdgcn_sad_u8(p, 0u, us);
                 // k-step 8 half + c / 2 of the tile; inside its 1 KiB block lane (row, (c & 1)) holds k = 16 (c & 1) + [0, 16)
                 *reinterpret_cast<unsigned*>(slot + (8 * half + (c >> 1)) * 1024 + ((16 * u + rsub) + 32 * (c & 1)) * 16 + 4 * q4) = p ^ 0x80808080u;
@@ -321,13 +355,12 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
                 if (half == 0) {
                     reinterpret_cast<float*>(slot + RS_TILE + 256)[r] = q.x;
                     reinterpret_cast<int*>(slot + RS_TILE + 512)[r] = __float_as_int(q.w);
-                    if (EM == 2) {
-                        // the hidden layer's parameters of the row's slice: derived HERE, once a row, not by each of the eight consumers
-                        // (make_qparams is two divisions and a rounding: a third of a consumer's epilogue otherwise)
-                        const QParams q2 = make_qparams(0.0f, __uint_as_float(sm));
-                        reinterpret_cast<float*>(slot + RS_TILE + 256)[32 + r] = q2.scale;
-                        reinterpret_cast<float*>(slot + RS_TILE + 512)[32 + r] = q2.zp;
-                        reinterpret_cast<float*>(slot + RS_TILE + 768)[32 + r] = q2.inv_scale;
+                    if (EM == 2) {  // the hidden layer's parameters of the row's slice, ready-made for the eight consumers
+                        const float4 q2 = s_q2[rel];
+                        reinterpret_cast<float*>(slot + RS_TILE + 768)[r] = q2.w;
+                        reinterpret_cast<float*>(slot + RS_TILE + 256)[32 + r] = q2.x;
+                        reinterpret_cast<float*>(slot + RS_TILE + 512)[32 + r] = q2.y;
+                        reinterpret_cast<float*>(slot + RS_TILE + 768)[32 + r] = q2.z;
                     }
                 }
             }
@@ -335,18 +368,50 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
         };
         // Even tiles travel through RA, odd ones through RB (two named sets: nothing is copied, the compiler's counted waits stay exact).
         // A tile's rows are requested two barriers before it is handed over; barrier number i (counted from 0) hands over tile i.
-        float4 RA[16], RB[16], QA, QB;
-        unsigned SA = 0u, SB = 0u;
         // (Loads are unconditional -- beyond the range the last tile is read again and dropped: a load under a branch makes its
         // registers a merge of two values, and the copy the compiler then needs waits for the load on the spot.)
-        load(0, RA, QA, SA);
+        float4 RA[16], RB[16];
+        load(0, RA);
+        // The parameters of the slices the workgroup's rows belong to, while the first rows travel: loader j takes slices s_lo + j,
+        // s_lo + j + 4, ... -- the input's from the producer's {min, max} pairs; EM 2: the hidden layer's from the maxima the range pass's
+        // workgroups left (every workgroup whose row range meets the slice, all its column blocks).
+        for (unsigned sl = s_lo + (unsigned)(wave - 8); sl <= s_hi; sl += 4u) {
+            const QParams qs = slice_params(g.partial, g.nblk, sl, lane);
+            if (lane == 0) s_prm[sl - s_lo] = make_float4(qs.scale, qs.zp, qs.inv_scale, __int_as_float(qs.zp_i));
+            if (EM == 2) {
+                const unsigned nrt = (unsigned)g.nrt, nrr = (unsigned)g.nrr, ncb = (unsigned)g.ncb;
+                const unsigned r_first = sl * mu, r_last = (sl + 1u) * mu < rows ? (sl + 1u) * mu - 1u : rows - 1u;
+                auto range_of = [&](unsigned tile) {  // the row range whose tiles [rr nrt / nrr, (rr + 1) nrt / nrr) hold `tile`
+                    unsigned r = tile * nrr / nrt;
+                    while (r + 1u < nrr && (r + 1u) * nrt / nrr <= tile) ++r;
+                    while (r > 0u && r * nrt / nrr > tile) --r;
+                    return r;
+                };
+                const unsigned ra = single ? 0u : range_of(r_first >> 5), rb = single ? nrr - 1u : range_of(r_last >> 5);
+                const unsigned total = (rb - ra + 1u) * ncb;
+                float mxh = 0.0f;  // ReLU results: >= 0, never NaN -- their bits order like the values
+                for (unsigned e0 = 0; e0 < total; e0 += 64u) {
+                    const unsigned e = e0 + (unsigned)lane;
+                    if (e < total) {
+                        const unsigned r = ra + e / ncb, c = e - (e / ncb) * ncb;
+                        const unsigned sb = single ? 0u : ((r * nrt / nrr) * 32u) / mu;  // that workgroup's first slice
+                        mxh = fmaxf(mxh, __uint_as_float(g.hpart[(size_t)(r * ncb + c) * 4u + (sl - sb)]));
+                    }
+                }
+                mxh = wave_allreduce64(mxh, [](float cur, float a) { return fmaxf(cur, a); });
+                const QParams q2 = make_qparams(0.0f, mxh);
+                if (lane == 0) s_q2[sl - s_lo] = make_float4(q2.scale, q2.zp, q2.inv_scale, mxh);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        rs_barrier();  // the tables are complete (the consumers take this barrier too)
         for (int i = 0; i < nt; i += 2) {
-            load(i + 1 < nt ? i + 1 : nt - 1, RB, QB, SB);
+            load(i + 1 < nt ? i + 1 : nt - 1, RB);
             if (i > 0) rs_barrier();  // tile i - 1
-            put(i, RA, QA, SA);
-            load(i + 2 < nt ? i + 2 : nt - 1, RA, QA, SA);
+            put(i, RA);
+            load(i + 2 < nt ? i + 2 : nt - 1, RA);
             rs_barrier();  // tile i
-            if (i + 1 < nt) put(i + 1, RB, QB, SB);
+            if (i + 1 < nt) put(i + 1, RB);
         }
         if ((nt & 1) == 0) rs_barrier();  // an odd tile was the last one
         if (EM == 1) __syncthreads();
@@ -408,6 +473,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
     // -------------------------------------------------------------------- a consumer
     const int ct = cb * 8 + wave;
     if (ct >= g.nct) {  // a partial last column block: the wave only keeps the barriers company
+        if (FQ) rs_barrier();
         for (int i = 0; i < nt; ++i) rs_barrier();
         if (EM == 1) __syncthreads();
         return;
@@ -429,14 +495,14 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
     // the column terms of the lane's 16 columns (ct * 32 + 8 g + 4 hv + e) stay in registers: 48 of them, and no LDS round trip
     // in front of every column group of every tile
     int colsum[16];
-    v2f wsc[8], biasc[8];  // pairs of neighbouring columns: the epilogue's f32 arithmetic runs two elements an instruction (v_pk_*_f32)
+    float wsc[16], biasc[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         int c = ct * 32 + 8 * (q >> 2) + 4 * hv + (q & 3);
         c = c < n ? c : n - 1;  // clamped: loads stay unconditional, out-of-range columns are never stored
         colsum[q] = epi.col_sums[c];
-        wsc[q >> 1][q & 1] = epi.wscale_len <= 1 ? epi.wscale[0] : epi.wscale[c];
-        biasc[q >> 1][q & 1] = epi.bias ? epi.bias[c] : -0.0f;  // x + (-0.0) == x for every x, the sign of zero included
+        wsc[q] = epi.wscale_len <= 1 ? epi.wscale[0] : epi.wscale[c];
+        biasc[q] = epi.bias ? epi.bias[c] : -0.0f;  // x + (-0.0) == x for every x, the sign of zero included
     }
     const int cbz = 128 - epi.zp_b;
     // results leave through buffer stores: a lane that has nothing to store points beyond the buffer and the hardware drops
@@ -515,24 +581,26 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
         }
         float4 o[4];
         unsigned d[4];
-        // IgemmEpi::value24 on two neighbouring columns at a time (the weight scale is mandatory on this route): _mm256_cvtepi32_ps,
-        // x (dynamic scale x weight scale), + bias, ReLU -- each its own rounding, as the reference's separate instructions
-        auto val2 = [&](int t0, int t1, v2f dsws, v2f b) {
+        // IgemmEpi::value24 (the weight scale is mandatory on this route): _mm256_cvtepi32_ps, x (dynamic scale x weight scale), + bias,
+        // ReLU -- each its own rounding.  Scalar f32 instructions on purpose (and -fno-slp-vectorize for this file): v_pk_mul_f32 /
+        // v_pk_add_f32 beside the matrix core cost more than the two instructions they replace (MI355X_MICROARCH.md, measured here:
+        // the packed epilogue made the range and quantise passes 1.3 us slower)
+        auto val = [&](int total, float dsws, float b) {
 #ifdef LELE_HIP_LAB
-            if (g.ablate & 16) return v2f{__int_as_float(t0), __int_as_float(t1)};
+            if (g.ablate & 16) return __int_as_float(total);
 #endif
-            v2f vf = {(float)t0, (float)t1};
+            float vf = (float)total;
             vf = vf * dsws;
             vf = vf + b;
-            if (RELU) vf = v2f{relu0(vf.x), relu0(vf.y)};
+            if (RELU) vf = relu0(vf);
             return vf;
         };
-        const v2f ds2 = {ds, ds};
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            const v2f lo = val2(acc[4 * gq + 0], acc[4 * gq + 1], ds2 * wsc[2 * gq], biasc[2 * gq]);
-            const v2f hi = val2(acc[4 * gq + 2], acc[4 * gq + 3], ds2 * wsc[2 * gq + 1], biasc[2 * gq + 1]);
-            o[gq].x = lo.x, o[gq].y = lo.y, o[gq].z = hi.x, o[gq].w = hi.y;
+            o[gq].x = val(acc[4 * gq + 0], ds * wsc[4 * gq + 0], biasc[4 * gq + 0]);
+            o[gq].y = val(acc[4 * gq + 1], ds * wsc[4 * gq + 1], biasc[4 * gq + 1]);
+            o[gq].z = val(acc[4 * gq + 2], ds * wsc[4 * gq + 2], biasc[4 * gq + 2]);
+            o[gq].w = val(acc[4 * gq + 3], ds * wsc[4 * gq + 3], biasc[4 * gq + 3]);
             if (EM == 0) {
                 if (NRES > 0) {
                     o[gq].x = o[gq].x + res1[gq].x, o[gq].y = o[gq].y + res1[gq].y, o[gq].z = o[gq].z + res1[gq].z, o[gq].w = o[gq].w + res1[gq].w;
@@ -548,13 +616,11 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
 #endif
                 __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, rok && cok ? (obase + 8u * gq) * 4u : 0xffffffffu, 0, 0);
             } else if (EM == 2) {
-                const v2f inv2 = {q2.inv_scale, q2.inv_scale}, zp2 = {q2.zp, q2.zp};
-                const v2f c0 = __builtin_elementwise_fma(lo, inv2, zp2), c1 = __builtin_elementwise_fma(hi, inv2, zp2);
                 unsigned p = 0u;
-                p = __builtin_amdgcn_cvt_pk_u8_f32(c0.x, 0, p);
-                p = __builtin_amdgcn_cvt_pk_u8_f32(c0.y, 1, p);
-                p = __builtin_amdgcn_cvt_pk_u8_f32(c1.x, 2, p);
-                p = __builtin_amdgcn_cvt_pk_u8_f32(c1.y, 3, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(o[gq].x, q2.inv_scale, q2.zp), 0, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(o[gq].y, q2.inv_scale, q2.zp), 1, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(o[gq].z, q2.inv_scale, q2.zp), 2, p);
+                p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(o[gq].w, q2.inv_scale, q2.zp), 3, p);
                 d[gq] = p ^ 0x80808080u;
             }
         }
@@ -578,7 +644,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
             mx[1] = rel == 1u ? fmaxf(mx[1], lmax) : mx[1];
             mx[2] = rel == 2u ? fmaxf(mx[2], lmax) : mx[2];
             mx[3] = rel == 3u ? fmaxf(mx[3], lmax) : mx[3];
-            if (rel > 3u && lmax > 0.0f) atomicMax(&epi.slice_max[slice], __float_as_uint(lmax));
+            if (!FQ && rel > 3u && lmax > 0.0f) atomicMax(&epi.slice_max[slice], __float_as_uint(lmax));  // (FQ: launch_rs admits four slices a workgroup)
         }
         if (EM == 0 && epi.blockstat) {  // one {min, max} pair per (row tile, column tile): LeleBuf::rowstat kind 1
             float smn = 3.40282347e+38f, smx = -3.40282347e+38f;
@@ -602,6 +668,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
     // opposite phase.  The epilogue of a lone wave is dependency-bound, not issue-bound, so neither arrangement buys overlap.)
     v16i acc;
     RsRow r;
+    if (FQ) rs_barrier();  // the loaders' parameter tables (nothing of the consumers' depends on them: it only keeps the count)
     for (int i = 0; i < nt; ++i) {
         rs_barrier();  // tile i has landed
         RS_STAMP(0);
@@ -624,7 +691,11 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
             if (lane == 0 && v > 0.0f) atomicMax(&s_mx[j], __float_as_uint(v));  // non-negative floats order like their bits
         }
         __syncthreads();
-        if (threadIdx.x < 4 && s_mx[threadIdx.x]) atomicMax(&epi.slice_max[sbase + threadIdx.x], s_mx[threadIdx.x]);
+        if (FQ) {
+            if (threadIdx.x < 4) g.hpart[(size_t)L * 4u + threadIdx.x] = s_mx[threadIdx.x];  // slices sbase .. sbase + 3 of this workgroup
+        } else if (threadIdx.x < 4 && s_mx[threadIdx.x]) {
+            atomicMax(&epi.slice_max[sbase + threadIdx.x], s_mx[threadIdx.x]);
+        }
     }
 }
 
@@ -861,16 +932,14 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
     // ---- 4. quantise into fragment order: rint(fma(x, 1 / scale, zp)) saturated to u8, minus 128 (K = 512: every element is in the
     //         reference's SIMD body)
     {
-        const v2f inv2 = {q.inv_scale, q.inv_scale}, zp2 = {q.zp, q.zp};
         unsigned us = 0u;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const v2f c0 = __builtin_elementwise_fma(v2f{xv[c].x, xv[c].y}, inv2, zp2), c1 = __builtin_elementwise_fma(v2f{xv[c].z, xv[c].w}, inv2, zp2);
             unsigned p = 0u;
-            p = __builtin_amdgcn_cvt_pk_u8_f32(c0.x, 0, p);
-            p = __builtin_amdgcn_cvt_pk_u8_f32(c0.y, 1, p);
-            p = __builtin_amdgcn_cvt_pk_u8_f32(c1.x, 2, p);
-            p = __builtin_amdgcn_cvt_pk_u8_f32(c1.y, 3, p);
+            p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(xv[c].x, q.inv_scale, q.zp), 0, p);
+            p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(xv[c].y, q.inv_scale, q.zp), 1, p);
+            p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(xv[c].z, q.inv_scale, q.zp), 2, p);
+            p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(xv[c].w, q.inv_scale, q.zp), 3, p);
             us = __builtin_amdgcn_sad_u8(p, 0u, us);
             // k-step 4 kq + c / 2; inside its 1 KiB block lane (row, c & 1) holds k = 16 (c & 1) + [0, 16)
             *reinterpret_cast<unsigned*>(s_tile + (4 * kq + (c >> 1)) * 1024 + ((16 * u + rsub) + 32 * (c & 1)) * 16 + 4 * q4) = p ^ 0x80808080u;
@@ -932,7 +1001,6 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
     }
     // ---- 6. epilogue (IgemmEpi::value24 with the row terms from LDS), a lane = one row x {4 x 4 columns} of each tile
     const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)epi.out, 0, (int)(rows * (unsigned)n * 4u), 0x00020000);
-    const v2f ds2 = {ds, ds};
     auto finish = [&](const v16i& acc, int ct, const float4 (&res1)[NRES > 0 ? 4 : 1], const float4 (&res2)[NRES > 1 ? 4 : 1]) {
         const unsigned obase = rowc * (unsigned)n + (unsigned)(ct * 32 + 4 * hv);  // rows * n < 2^30
         float smn = 3.40282347e+38f, smx = -3.40282347e+38f;
@@ -941,16 +1009,18 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
             const int cl = (ct * 32 + 4 * hv + 8 * gq) & 511;
             const float4 ws = *reinterpret_cast<const float4*>(&s_ws[cl]);
             const float4 bs = *reinterpret_cast<const float4*>(&s_bias[cl]);
-            auto val2 = [&](int t0, int t1, v2f w, v2f b) {
-                v2f vf = {(float)t0, (float)t1};  // _mm256_cvtepi32_ps
-                vf = vf * (ds2 * w);
+            auto val = [&](int total, float w, float b) {
+                float vf = (float)total;  // _mm256_cvtepi32_ps
+                vf = vf * (ds * w);
                 vf = vf + b;
-                if (RELU) vf = v2f{relu0(vf.x), relu0(vf.y)};
+                if (RELU) vf = relu0(vf);
                 return vf;
             };
-            const v2f lo = val2(acc[4 * gq + 0], acc[4 * gq + 1], v2f{ws.x, ws.y}, v2f{bs.x, bs.y});
-            const v2f hi = val2(acc[4 * gq + 2], acc[4 * gq + 3], v2f{ws.z, ws.w}, v2f{bs.z, bs.w});
-            float4 o = make_float4(lo.x, lo.y, hi.x, hi.y);
+            float4 o;
+            o.x = val(acc[4 * gq + 0], ws.x, bs.x);
+            o.y = val(acc[4 * gq + 1], ws.y, bs.y);
+            o.z = val(acc[4 * gq + 2], ws.z, bs.z);
+            o.w = val(acc[4 * gq + 3], ws.w, bs.w);
             if (NRES > 0) {
                 o.x = o.x + res1[gq].x, o.y = o.y + res1[gq].y, o.z = o.z + res1[gq].z, o.w = o.w + res1[gq].w;
                 if (NRES > 1) o.x = o.x + res2[gq].x, o.y = o.y + res2[gq].y, o.z = o.z + res2[gq].z, o.w = o.w + res2[gq].w;

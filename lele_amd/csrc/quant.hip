@@ -1056,17 +1056,37 @@ int launch_qrows_frag(LeleCtx* ctx, const float* dx, int64_t rows, int k, int kp
     LELE_HIP_CHECK(hipGetLastError());
     return 0;
 }
+// the grid of igemm_rs_kernel: column blocks of 8 tiles x row ranges, one 640 / 768-thread workgroup per CU, all resident at once
+void rs_grid(LeleCtx* ctx, int64_t rows, int64_t n, int* ncb, int* nrr) {
+    const int nrt = (int)((rows + 31) / 32), nct = (int)((n + 31) / 32);
+    *ncb = (nct + 7) / 8;
+    *nrr = std::max(1, std::min(nrt, ctx->num_cus / *ncb));
+}
+// the most slices of m rows a workgroup's row range can touch (FQ: the loaders keep their parameters in a table of RS_MAXSL entries;
+// the fused feed-forward block's range pass keeps four maxima a workgroup)
+int64_t rs_max_slices(LeleCtx* ctx, int64_t rows, int64_t n, int64_t m) {
+    int ncb, nrr;
+    rs_grid(ctx, rows, n, &ncb, &nrr);
+    const int64_t nrt = (rows + 31) / 32, tiles = (nrt + nrr - 1) / nrr;
+    return rows == m ? 1 : (tiles * 32 + m - 2) / m + 1;
+}
+struct RsFq {  // what the quantising loaders need besides the epilogue's arguments
+    const float* x = nullptr;
+    const float* partial = nullptr;
+    int nblk = 0;
+    unsigned* hpart = nullptr;
+};
 int launch_rs(LeleCtx* ctx, int em, const int8_t* af, const int8_t* wf, int64_t rows, int n, int8_t* hid, const IgemmEpi& epi,
-              const float* x_f32 = nullptr) {
-    RsArgs g{af, wf, (unsigned)rows, n, (int)((rows + 31) / 32), (n + 31) / 32, 0, 0, hid, x_f32};
+              const RsFq& fq = RsFq()) {
+    const float* x_f32 = fq.x;
+    RsArgs g{af, wf, (unsigned)rows, n, (int)((rows + 31) / 32), (n + 31) / 32, 0, 0, hid, x_f32, fq.partial, fq.nblk, fq.hpart};
 #ifdef LELE_HIP_LAB
     g.dbg = nullptr;
     g.ablate = lab_int("LELE_HIP_RS_ABLATE", 0);
     if (const char* e = lab_env("LELE_HIP_RS_STAMPS"))  // a device address (tools/rs_stamps.py), optionally for one mode only
         if (lab_int("LELE_HIP_RS_STAMPS_EM", em) == em) g.dbg = (long long*)(uintptr_t)strtoull(e, nullptr, 0);
 #endif
-    g.ncb = (g.nct + 7) / 8;
-    g.nrr = std::max(1, std::min(g.nrt, ctx->num_cus / g.ncb));  // one 640-thread workgroup per CU, all resident at once
+    rs_grid(ctx, rows, n, &g.ncb, &g.nrr);
     const dim3 grid((unsigned)(g.ncb * g.nrr));
     const int nres = epi.res1 ? (epi.res2 ? 2 : 1) : 0;
 #define LELE_RS(EM_, NRES_, RELU_)                                                                   \
@@ -1267,13 +1287,10 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
         LELE_TRY(frag_weights_of(ctx, weight_int8, (int)k, (int)n, kprs, &fw));
         const int64_t nrt = (rows + 31) / 32;
         void *af = nullptr, *rs = nullptr;
-        // K = 512 exactly, 16-byte aligned rows: the GEMM's loader waves quantise the f32 rows themselves (igemm_rs.h, FQ); what is
-        // left of the quantising pass is the slices' parameters (one wave a slice)
-        const bool fq = rs_fq(k, dx);
-        if (fq) {
-            hipLaunchKernelGGL(qparams_kernel, dim3((unsigned)batch), dim3(64), 0, ctx->stream, partial, nblk, (QParams*)prm, (float*)nullptr,
-                               (float*)nullptr, (unsigned*)nullptr);
-        } else {
+        // K = 512 exactly, 16-byte aligned rows: the GEMM's loader waves quantise the f32 rows themselves (igemm_rs.h, FQ) with
+        // parameters they reduce from the {min, max} partials at the start of the kernel: nothing is launched in front of it
+        const bool fq = rs_fq(k, dx) && rs_max_slices(ctx, rows, n, m) <= RS_MAXSL;
+        if (!fq) {
             LELE_TRY(ctx->arena_alloc((size_t)nrt * kprs * 32, &af));
             if (kprs == 512) LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs));  // K = 2048: the GEMM sums the rows it loads anyway
             LELE_TRY(launch_qrows_frag(ctx, (const float*)dx, rows, (int)k, kprs, (int)m, (QParams*)prm, (int8_t*)af, (int*)rs, partial, nblk, nullptr));
@@ -1287,7 +1304,9 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
             LELE_TRY(out->reserve_rowstat(nstat));
             if ((size_t)nstat <= out->rowstat_cap) epi.blockstat = out->rowstat;
         }
-        if (kprs == 512) LELE_TRY(launch_rs(ctx, 0, (const int8_t*)af, fw.wf, rows, (int)n, nullptr, epi, fq ? (const float*)dx : nullptr));
+        RsFq fqa;
+        if (fq) fqa.x = (const float*)dx, fqa.partial = partial, fqa.nblk = nblk;
+        if (kprs == 512) LELE_TRY(launch_rs(ctx, 0, (const int8_t*)af, fw.wf, rows, (int)n, nullptr, epi, fqa));
         else LELE_TRY(launch_rs_ks4(ctx, (const int8_t*)af, fw.wf, rows, (int)n, epi));
         LELE_TRY(qprof_mark(ctx, 3));
         if (epi.blockstat) {
@@ -1493,12 +1512,18 @@ int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const Le
         LELE_TRY(frag_weights_of(ctx, w2_int8, (int)k2, (int)n2, 2048, &fw2));
         const int64_t nrt = (rows + 31) / 32;
         void *af1 = nullptr, *hid = nullptr;
-        const bool fq = rs_fq(k1, dx);  // both passes of the first product quantise the f32 rows in their loader waves
+        // both passes of the first product quantise the f32 rows in their loader waves, with parameters reduced inside the kernels; the
+        // range pass leaves four maxima a workgroup (plain stores: nothing to clear) which the quantise pass's loaders reduce
+        const bool fq = rs_fq(k1, dx) && rs_max_slices(ctx, rows, n1, m) <= 4;
         LELE_TRY(ctx->arena_alloc((size_t)nrt * 2048 * 32, &hid));
         LELE_TRY(ctx->arena_alloc((size_t)batch * 4, &hmax));
-        if (fq) {  // the slices' parameters; the same launch clears the per-slice maxima the range pass adds into
-            hipLaunchKernelGGL(qparams_kernel, dim3((unsigned)batch), dim3(64), 0, ctx->stream, partial, nblk, (QParams*)prm1, (float*)nullptr,
-                               (float*)nullptr, (unsigned*)hmax);
+        RsFq fqa;
+        if (fq) {
+            int ncb = 0, nrr = 0;
+            rs_grid(ctx, rows, n1, &ncb, &nrr);
+            void* hpart = nullptr;
+            LELE_TRY(ctx->arena_alloc((size_t)ncb * nrr * 16, &hpart));
+            fqa.x = (const float*)dx, fqa.partial = partial, fqa.nblk = nblk, fqa.hpart = (unsigned*)hpart;
         } else {
             LELE_TRY(ctx->arena_alloc((size_t)nrt * 512 * 32, &af1));
             LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs1));
@@ -1510,9 +1535,9 @@ int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const Le
         IgemmEpi e1{nullptr, rows, n1, (int)m, (int)k1, (const int*)rs1, fw1.col_sums, (const QParams*)prm1, 0, (int)wz1, (const float*)dws1,
                     (int)ws1_len, b1_len ? (const float*)db1 : nullptr, 1};
         e1.slice_max = (unsigned*)hmax;
-        LELE_TRY(launch_rs(ctx, 1, (const int8_t*)af1, fw1.wf, rows, (int)n1, nullptr, e1, fq ? (const float*)dx : nullptr));   // range of the ReLU result per slice
+        LELE_TRY(launch_rs(ctx, 1, (const int8_t*)af1, fw1.wf, rows, (int)n1, nullptr, e1, fqa));   // range of the ReLU result per slice
         e1.q_prm = (QParams*)prm2;
-        LELE_TRY(launch_rs(ctx, 2, (const int8_t*)af1, fw1.wf, rows, (int)n1, (int8_t*)hid, e1, fq ? (const float*)dx : nullptr));  // the result again, as the next operand
+        LELE_TRY(launch_rs(ctx, 2, (const int8_t*)af1, fw1.wf, rows, (int)n1, (int8_t*)hid, e1, fqa));  // the result again, as the next operand
         IgemmEpi e2{(float*)out->data, rows, n2, (int)m, (int)k2, nullptr, fw2.col_sums, (const QParams*)prm2, 0, (int)wz2,
                     (const float*)dws2, (int)ws2_len, b2_len ? (const float*)db2 : nullptr, apply_relu2, (const float*)dr1, (const float*)dr2};
         LELE_TRY(launch_rs_ks4(ctx, (const int8_t*)hid, fw2.wf, rows, (int)n2, e2));
