@@ -152,8 +152,13 @@ def test_device_topk_long_rows_with_ties(ctx):
     # rows longer than the 2048-element LDS chunk, heavy ties (stable: the lower index ranks first), both directions
     from lele_amd import kernels as Kk
     rng = np.random.default_rng(7)
-    for n, k in ((5000, 300), (24000, 300), (2049, 2049), (300, 7), (80, 1), (81, 5), (3, 3)):
+    # (8400 / 24000: the Yolo26n-seg tail; 28672 is the longest row whose keys are staged in LDS, 28673 the first that is swept from L2)
+    for n, k in ((5000, 300), (24000, 300), (8400, 300), (28672, 300), (28673, 301), (40000, 1024), (2049, 2049), (300, 7), (80, 1), (81, 5), (3, 3)):
         x = np.round(rng.standard_normal((3, n)) * 3).astype(np.float32)
+        if n >= 5000:  # signed zeros tie with each other, a NaN ranks below everything
+            x[0, ::7] = -0.0
+            x[0, 3::11] = 0.0
+            x[1, 5::13] = np.nan
         for largest in (True, False):
             v, i = Kk.topk(x, k, -1, largest, True, ctx=ctx)
             rv, ri = npref.topk(x, k, largest)

@@ -241,6 +241,21 @@ def test_fused_ffn_never_stores_the_hidden_layer_and_keeps_every_bit(ctx):
     assert not hid.any()
     want = O.fused_quantized_linear(hid, w2[0].arr, w2[1].arr, w2[2].arr, w2[3].arr, False)
     assert np.array_equal(K.fused_ffn_quantized(xn, *w1, *w2, False, ctx=ctx).numpy(), want)
+    # weight scales of either sign, and zeros of either sign (the range pass of the tiled route evaluates its epilogue only at the
+    # extreme i32 totals of a column: the maximum for a scale >= 0, the minimum below)
+    for b, m in ((32, 171), (1, 4800), (9, 1000)):
+        x = (rng.standard_normal((b, m, 512)) * rng.uniform(0.3, 3.0, (b, 1, 1))).astype(np.float32)
+        w1, w2 = lin(512, 2048), lin(2048, 512)
+        sc = w1[1].arr.copy()
+        sc[::3] *= -1
+        sc[5::97] = 0.0
+        sc[7::101] = -0.0
+        w1 = (w1[0], Weight(sc), w1[2], w1[3])
+        hid = O.fused_quantized_linear(x, w1[0].arr, sc, w1[2].arr, w1[3].arr, True)
+        want = O.fused_quantized_linear(hid, w2[0].arr, w2[1].arr, w2[2].arr, w2[3].arr, False)
+        for rs in (1, 0):
+            with _env(LELE_HIP_IGEMM_RS=rs):
+                assert np.array_equal(K.fused_ffn_quantized(x, *w1, *w2, False, ctx=ctx).numpy(), want), (b, m, rs)
 
 
 @pytest.mark.gpu
