@@ -1007,12 +1007,14 @@ int rs_kp(int64_t k) {
     const int64_t kp = (k + 31) & ~int64_t(31);
     return kp == 512 || kp == 2048 ? (int)kp : 0;
 }
-// enough 32 x 32 tiles to fill the chip, 16-byte stores, 32-bit byte offsets into the result
+// enough 32 x 32 tiles, 16-byte stores, 32-bit byte offsets into the result.  (Round 3 asked for 8 tiles per CU: below that the
+// quantising pass + small-problem GEMM were faster.  With the rows quantised inside the kernel the route needs no pass in front, and
+// one 30 s utterance -- 16 row tiles x 48-64 column tiles -- gains 7 % per forward on it: 2 tiles per CU.)
 bool rs_enabled(LeleCtx* ctx, int64_t rows, int64_t n) {
     if (env_int("LELE_HIP_IGEMM_RS", 1) == 0) return false;  // documented switch: 0 = the tiled kernels everywhere
     if (n % 4 || rows * n >= (int64_t(1) << 30)) return false;
     const int64_t units = ((rows + 31) / 32) * ((n + 31) / 32);
-    return units >= (int64_t)lab_int("LELE_HIP_IGEMM_RS_MIN", 8 * ctx->num_cus);
+    return units >= (int64_t)lab_int("LELE_HIP_IGEMM_RS_MIN", 2 * ctx->num_cus);
 }
 // the stand-alone linear.  Measured on one configs[3] shard (tools/rs_bench.py, whole op incl. the row quantisation): N = 1536
 // 24.9 us against 28.7 us tiled, N = 2048 27.2 against 29.5 -- but N = 512 23.0 against 18.7 (few column tiles: the
