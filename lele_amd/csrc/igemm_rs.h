@@ -827,9 +827,12 @@ struct AsArgs {
     const float* partial;  // [slices][nblk] {min, max} pairs
     int nblk;
     QParams* prm;          // published per slice (the wave that holds the slice's first row)
+    int tpw;               // !TWO: column tiles per workgroup (8 or 4: grid.y = ceil(nct / tpw)); wave w multiplies tile blockIdx.y tpw + w
 };
 
-template <int NRES, bool RELU>
+// TWO = false (few row tiles: one utterance): a workgroup takes only `tpw` column tiles, one a wave, and the grid's second dimension
+// the rest -- the row tile is quantised once per column group (out of L2), in exchange for four times the workgroups.
+template <int NRES, bool RELU, bool TWO = true>
 __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
     constexpr int KS = 16;
     __shared__ __attribute__((aligned(16))) char s_tile[KS * 1024];
@@ -877,15 +880,18 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
     const float bv = (epi.bias ? epi.bias : epi.wscale)[epi.bias ? ccol : 0];
     __builtin_amdgcn_sched_barrier(0);  // ... and the compiler keeps that order
     // ---- 2. the weights of column tiles 2 wave and 2 wave + 1 (a tile beyond the last one repeats it: multiplied, never stored)
-    const int ct0 = 2 * wave, ct1 = 2 * wave + 1;
-    v4i bf0[KS], bf1[KS];
+    const int ct0 = TWO ? 2 * wave : (int)blockIdx.y * g.tpw + wave, ct1 = 2 * wave + 1;
+    const bool live0 = (TWO || wave < g.tpw) && ct0 < g.nct;  // (a wave without a tile still loads -- clamped -- and quantises; it leaves after the barrier)
+    v4i bf0[KS], bf1[TWO ? KS : 1];
     {
         const v4i* w0 = reinterpret_cast<const v4i*>(g.wf) + (size_t)(ct0 < g.nct ? ct0 : g.nct - 1) * KS * 64 + lane;
-        const v4i* w1 = reinterpret_cast<const v4i*>(g.wf) + (size_t)(ct1 < g.nct ? ct1 : g.nct - 1) * KS * 64 + lane;
 #pragma unroll
         for (int s = 0; s < KS; ++s) bf0[s] = w0[s * 64];
+        if constexpr (TWO) {
+            const v4i* w1 = reinterpret_cast<const v4i*>(g.wf) + (size_t)(ct1 < g.nct ? ct1 : g.nct - 1) * KS * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) bf1[s] = w1[s * 64];
+            for (int s = 0; s < KS; ++s) bf1[s] = w1[s * 64];
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     s_colsum[threadIdx.x] = csum;
@@ -926,7 +932,7 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
             mx = wave_allreduce64(mx, [](float cur, float a) { return a > cur ? a : cur; });
             const QParams qs = make_qparams(mn, mx);
             if (mine == sl) q = qs;
-            if (kq == 0 && q4 == 0 && row_q < rows && row_q == sl * mu) g.prm[sl] = qs;  // the slice's first row publishes
+            if (kq == 0 && q4 == 0 && row_q < rows && row_q == sl * mu && blockIdx.y == 0) g.prm[sl] = qs;  // the slice's first row publishes
         }
     }
     // ---- 4. quantise into fragment order: rint(fma(x, 1 / scale, zp)) saturated to u8, minus 128 (K = 512: every element is in the
@@ -957,6 +963,7 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
     __syncthreads();
     // ---- 5. products: the tile's 16 fragments against both column tiles
     // (the accumulators start from the row / column terms, as in igemm_rs_kernel)
+    if (!TWO && !live0) return;  // after the only barrier
     const unsigned row = (unsigned)t * 32u + (unsigned)l31;
     const bool rok = row < rows;
     const unsigned rowc = rok ? row : rows - 1u;
@@ -969,9 +976,13 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const v4i c0 = *reinterpret_cast<const v4i*>(&s_colsum[(ct0 * 32 + 4 * hv + 8 * gq) & 511]);
-            const v4i c1 = *reinterpret_cast<const v4i*>(&s_colsum[(ct1 * 32 + 4 * hv + 8 * gq) & 511]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc0[4 * gq + e] = __mul24(ca, c0[e]) + rterm, acc1[4 * gq + e] = __mul24(ca, c1[e]) + rterm;
+            for (int e = 0; e < 4; ++e) acc0[4 * gq + e] = __mul24(ca, c0[e]) + rterm;
+            if constexpr (TWO) {
+                const v4i c1 = *reinterpret_cast<const v4i*>(&s_colsum[(ct1 * 32 + 4 * hv + 8 * gq) & 511]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1[4 * gq + e] = __mul24(ca, c1[e]) + rterm;
+            }
         }
     }
     // the residual operands of both tiles: requested before the products (the rows' registers are free again), used behind them
@@ -982,10 +993,10 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
             const int c0 = ct0 * 32 + 4 * hv + 8 * gq, c1 = ct1 * 32 + 4 * hv + 8 * gq;
             const unsigned at0 = rowc * (unsigned)n + (unsigned)(c0 < n ? c0 : n - 4), at1 = rowc * (unsigned)n + (unsigned)(c1 < n ? c1 : n - 4);
             ra1[gq] = *reinterpret_cast<const float4*>(epi.res1 + at0);
-            rb1[gq] = *reinterpret_cast<const float4*>(epi.res1 + at1);
+            if (TWO) rb1[gq] = *reinterpret_cast<const float4*>(epi.res1 + at1);
             if (NRES > 1) {
                 ra2[gq] = *reinterpret_cast<const float4*>(epi.res2 + at0);
-                rb2[gq] = *reinterpret_cast<const float4*>(epi.res2 + at1);
+                if (TWO) rb2[gq] = *reinterpret_cast<const float4*>(epi.res2 + at1);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -996,7 +1007,7 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
         for (int s = 0; s < KS; ++s) {
             const v4i a = ap[s * 64];
             acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf0[s], a, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf1[s], a, acc1, 0, 0, 0);
+            if constexpr (TWO) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf1[s], a, acc1, 0, 0, 0);
         }
     }
     // ---- 6. epilogue (IgemmEpi::value24 with the row terms from LDS), a lane = one row x {4 x 4 columns} of each tile
@@ -1044,7 +1055,7 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
         }
     };
     finish(acc0, ct0, ra1, ra2);
-    finish(acc1, ct1, rb1, rb2);
+    if constexpr (TWO) finish(acc1, ct1, rb1, rb2);
 }
 
 }  // namespace

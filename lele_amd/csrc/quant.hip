@@ -1122,14 +1122,23 @@ int launch_rs(LeleCtx* ctx, int em, const int8_t* af, const int8_t* wf, int64_t 
 bool as_fits(LeleCtx* ctx, int64_t rows, int64_t n, int64_t k, const void* dx) {
     if (env_int("LELE_HIP_IGEMM_RS", 1) == 0 || lab_int("LELE_HIP_IGEMM_AS", 1) == 0) return false;
     return k == 512 && n <= 512 && n % 4 == 0 && n >= 4 && rows * n < (int64_t(1) << 30) && (((uintptr_t)dx) & 15) == 0 &&
-           rows >= (int64_t)lab_int("LELE_HIP_IGEMM_AS_MIN_ROWS", 1024);
+           rows >= (int64_t)lab_int("LELE_HIP_IGEMM_AS_MIN_ROWS", 256);
 }
 int launch_as(LeleCtx* ctx, const float* x, const int8_t* wf, int64_t rows, int n, const float* partial, int nblk, QParams* prm,
               const IgemmEpi& epi) {
-    AsArgs g{x, wf, (unsigned)rows, n, (n + 31) / 32, partial, nblk, prm};
-    const dim3 grid((unsigned)((rows + 31) / 32));
+    AsArgs g{x, wf, (unsigned)rows, n, (n + 31) / 32, partial, nblk, prm, 16};
+    const int64_t nrt = (rows + 31) / 32;
+    // a batch: one workgroup a row tile, all (up to 16) column tiles, two a wave; few row tiles (one utterance: 16): 8 or 4 column
+    // tiles a workgroup, one a wave, so that the grid still covers a good part of the chip
+    const bool two = nrt * 3 >= (int64_t)ctx->num_cus || g.nct <= 4 || lab_int("LELE_HIP_IGEMM_AS_TPW", 0) == 16;
+    if (!two) g.tpw = lab_int("LELE_HIP_IGEMM_AS_TPW", nrt * 6 >= (int64_t)ctx->num_cus ? 8 : 4);
+    const dim3 grid((unsigned)nrt, two ? 1u : (unsigned)((g.nct + g.tpw - 1) / g.tpw));
     const int nres = epi.res1 ? (epi.res2 ? 2 : 1) : 0;
-#define LELE_AS(NRES_, RELU_) hipLaunchKernelGGL((igemm_as_kernel<NRES_, RELU_>), grid, dim3(512), 0, ctx->stream, g, epi)
+#define LELE_AS(NRES_, RELU_)                                                                                     \
+    do {                                                                                                          \
+        if (two) hipLaunchKernelGGL((igemm_as_kernel<NRES_, RELU_, true>), grid, dim3(512), 0, ctx->stream, g, epi);   \
+        else hipLaunchKernelGGL((igemm_as_kernel<NRES_, RELU_, false>), grid, dim3(512), 0, ctx->stream, g, epi);     \
+    } while (0)
     if (epi.relu) {
         if (nres == 0) LELE_AS(0, true);
         else if (nres == 1) LELE_AS(1, true);

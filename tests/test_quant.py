@@ -298,9 +298,12 @@ def test_register_stationary_gemm_bit_exact_on_edge_shapes(ctx, b, m, k, n, relu
     (3, 347, 36, False, False, True),       # 1041 rows (a last tile of 17), two column tiles of which one is partial, no bias
     (33, 64, 260, True, True, False),       # slices of exactly two row tiles; nine column tiles: the last wave has one
     (1, 1025, 4, False, True, True),        # the narrowest result; one row in the last tile
+    (1, 504, 512, False, True, False),      # one 30 s utterance: 16 row tiles -> four column tiles a workgroup, one a wave, grid 16 x 4
+    (2, 300, 384, True, True, False),       # 19 row tiles, 12 column tiles in three groups of four; slices end inside a tile
+    (1, 1600, 500, False, False, True),     # 50 row tiles -> eight column tiles a workgroup; the second group has a partial last tile
 ])
 def test_activation_stationary_gemm_bit_exact_on_edge_shapes(ctx, b, m, n, relu, bias, scalar_ws):
-    """igemm_as_kernel (K = 512 exactly, results at most 512 wide, 1024 rows or more): rows quantised inside the GEMM with the
+    """igemm_as_kernel (K = 512 exactly, results at most 512 wide, 256 rows or more): rows quantised inside the GEMM with the
     slices' parameters reduced from the {min, max} partials on the spot -- same bits as the oracle and as the tiled route
     (LELE_HIP_IGEMM_RS=0), with and without the residual operands of the epilogue, and the parameters it publishes / the block
     statistics it leaves serve a following quantised linear"""
