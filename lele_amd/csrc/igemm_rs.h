@@ -11,13 +11,17 @@
 //     order; the hidden layer of a feed-forward block: the epilogue of the pass that produces it, whose 32 x 32 result tile IS
 //     one k-step block of the next product);
 //   * K = 512 (igemm_rs_kernel): a consumer wave keeps the weight fragments of ITS 32 columns for the whole K extent in 64 VGPRs
-//     and multiplies the 32-row activation tiles that two loader waves stream through an LDS ring with direct-to-LDS loads;
-//     one s_barrier per tile; the eight consumers of a workgroup (eight column tiles) share every activation tile;
+//     and multiplies the 32-row activation tiles that loader waves put into an LDS ring -- FOUR waves that read the f32 rows, derive
+//     the slices' quantisation parameters and quantise on the way (FQ: K = 512 exactly, 16-byte aligned rows; nothing is launched in
+//     front of the kernel), or two waves streaming ready-made i8 fragments with direct-to-LDS loads (K padded to 512, odd
+//     alignments); one s_barrier per tile; the eight consumers of a workgroup (eight column tiles) share every activation tile;
 //   * the weights are the MFMA's FIRST operand, so a lane owns ONE result row and 4 x 4 consecutive columns of it: 16-byte
 //     stores, one set of row terms per lane (they travel with the tile through the ring), the column terms in registers;
 //   * K = 2048 (igemm_rs_ks4_kernel, the second feed-forward product): the four waves of a workgroup split K, A fragments
 //     double-buffered in registers, partial tiles meet in LDS (one barrier per tile), row sums come from v_dot4 on the fragments
-//     the wave loads anyway.
+//     the wave loads anyway;
+//   * K = 512, at most 512 columns (igemm_as_kernel, the projection behind the attention): the other way round -- a workgroup keeps
+//     ONE 32-row tile, quantised once into LDS, and its waves bring the weight fragments of all (or 4 / 8 of the) column tiles.
 #pragma once
 
 namespace {
@@ -284,9 +288,10 @@ __device__ __forceinline__ void rs_wait_vm() {
 }
 __device__ __forceinline__ void rs_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
-// FQ ("fused quantise"): FOUR loader waves read the f32 ROWS, quantise them with the slice's parameters (prm[] is complete before the
-// launch: qparams_kernel) exactly as qrows_frag_kernel does -- rint(fma(x, 1/scale, zp)) saturated to u8, minus 128 -- and write the
-// codes into the ring in fragment order themselves.  The separate quantising pass (10.7 us per call on a configs[3] shard: an 11 MB
+// FQ ("fused quantise"): FOUR loader waves read the f32 ROWS, reduce the parameters of the slices their workgroup's rows belong to from
+// the producer's {min, max} pairs (slice_params: what qparams_kernel / qrows_kernel<0> compute), quantise exactly as qrows_frag_kernel
+// does -- rint(fma(x, 1/scale, zp)) saturated to u8 (one v_cvt_pk_u8_f32), minus 128 -- and write the codes into the ring in fragment
+// order themselves.  The separate quantising pass (10.7 us per call on a configs[3] shard: an 11 MB
 // read and a 2.8 MB write between two kernels of 14 us) and the fragment-major copy of the activation in HBM disappear; each row tile
 // is quantised once per column block (6-8 times over the grid), out of L2.  A loader lane owns 4 consecutive k of one row per load:
 // 16 rows x 64 bytes per wave instruction on the global side, 64 different LDS banks on the ds_write_b32 side.
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
         return;
     }
     if (!FQ && wave >= 8) {
-        // ---------------------------------------------------------------- the two loaders
+        // ---------------------------------------------------------------- the two loaders of ready-made fragments
         // One wave issues a 1 KiB direct-to-LDS load every ~45 ns (measured; MI355X_MICROARCH.md's "ldsdma-fill" row: ~25 GB/s per
         // CU and loader wave), i.e. 0.8 us per tile -- as long as a consumer's whole tile.  So two waves split a tile's blocks
         // (wave 8: k-steps 0-7 and the row terms; wave 9: k-steps 8-15), and a tile is ISSUED before the loader waits for an
