@@ -438,6 +438,9 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_
                           "range_ms": round(r_ms, 5), "quantise_ms": round(q_ms, 5), "gemm_ms": round(g_ms, 5),
                           "staged_sum_ms": round(r_ms + q_ms + g_ms, 5), "op_ms": round(op_ms, 5),
                           "calls": calls, "algorithmic_bytes": byts, "int_ops": ops,
+                          "stages": "range = the {min, max} pairs come with the LayerNorm output: nothing is launched; quantise = nothing is launched either "
+                                    "since round 5 (the GEMM's loader waves reduce the parameters and quantise the f32 rows: igemm_rs.h, FQ) -- "
+                                    "both intervals are the cost of the two HIP events around them; gemm = igemm_rs_kernel",
                           "hbm_gbs": round(byts / (op_ms * 1e-3) / 1e9, 1) if op_ms > 0 else None,
                           "tops": round(ops / (op_ms * 1e-3) / 1e12, 1) if op_ms > 0 else None}
 
