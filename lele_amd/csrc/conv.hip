@@ -2210,20 +2210,30 @@ int lele_hip_depthwise_conv1d_tlc(LeleCtx* ctx, const LeleTensor* x, int64_t x_o
     LELE_TRY(ctx->dev_ptr(w, &dwp));
     if (bias) LELE_TRY(ctx->dev_ptr(bias, &db));
     LELE_TRY(out->reserve((size_t)(bsz * t_out * c) * 4));
-    constexpr int TT = 8;
-    const int64_t tiles = (t_out + TT - 1) / TT, total = bsz * tiles * c;
+    // time steps per thread: 8 (a window of 18 loads for 8 results); a grid that would not give every CU a workgroup that way -- one
+    // utterance -- takes 4 (3.4 against 4.2 us at [504, 512]; at [32 x 171, 512]: 4 -> 12.4, 8 -> 10.2, 16 -> 10.0 us)
+    const char* tt_env = lab_env("LELE_HIP_TLC_TT");
+    const int tt = tt_env && *tt_env ? atoi(tt_env) : (bsz * ((t_out + 7) / 8) * c < 256 * (int64_t)ctx->num_cus ? 4 : 8);
+    const int64_t tiles = (t_out + tt - 1) / tt, total = bsz * tiles * c;
     LELE_REQUIRE(total < (int64_t(1) << 31) && pitch < (int64_t(1) << 31), "depthwise_conv1d_tlc: tensor too large");
     if (bsz && c) {
         const dim3 grid((unsigned)((total + 255) / 256));
-#define LELE_TLC(KW)                                                                                                            \
-    hipLaunchKernelGGL((dwconv1d_tlc_kernel<KW, TT>), grid, dim3(256), 0, ctx->stream, (const float*)dx + x_offset, (const float*)dwp, \
+#define LELE_TLC2(KW, TT_)                                                                                                      \
+    hipLaunchKernelGGL((dwconv1d_tlc_kernel<KW, TT_>), grid, dim3(256), 0, ctx->stream, (const float*)dx + x_offset, (const float*)dwp, \
                        (const float*)db, (float*)out->data, (int)t_in, (int)t_out, (int)c, (int)pitch, (int)pad_left, relu, add_input,  \
                        (unsigned)tiles, (unsigned)total)
+#define LELE_TLC(KW)                      \
+    do {                                  \
+        if (tt == 16) LELE_TLC2(KW, 16);  \
+        else if (tt <= 4) LELE_TLC2(KW, 4); \
+        else LELE_TLC2(KW, 8);            \
+    } while (0)
         if (k == 3) LELE_TLC(3);
         else if (k == 5) LELE_TLC(5);
         else if (k == 7) LELE_TLC(7);
         else LELE_TLC(11);
 #undef LELE_TLC
+#undef LELE_TLC2
         LELE_HIP_CHECK(hipGetLastError());
     }
     return set_shape(out_shape, out_rank, {bsz, t_out, c});
