@@ -43,7 +43,8 @@ for k, cs in sorted(per.items()):
 json.dump({"note": "rocprofv3 --pmc over tools/sensevoice_graph.py --compiled-only --configs c4 --layers 10 --runs 3 (32 x 10 s utterances, eager); three "
                    "passes: {SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT}, "
                    "FETCH_SIZE, WRITE_SIZE; averages per launch; FETCH_SIZE / WRITE_SIZE in KiB as reported, read_MB_corrected = FETCH_SIZE x 2 "
-                   "(gfx950 counts a 128-byte read request as 64); SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles",
+                   "(gfx950 counts a 128-byte read request as 64) -- an UPPER bound where a kernel's requests really are 64 bytes (the quantising loaders "
+                   "and igemm_as_kernel read a row as 64-byte pieces: their f32 rows appear twice); taken before the FSMN kernel's XCD-contiguous block order; SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles",
            "kernels": out}, open(os.path.join(ROOT, "profiles", "r05_sensevoice_c4_pmc.json"), "w"), indent=1)
 for k, row in out.items():
     print(k, {c: row[c] for c in ("launches", "read_MB_corrected", "write_MB", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT") if c in row})
