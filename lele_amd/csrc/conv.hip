@@ -611,8 +611,11 @@ __global__ __launch_bounds__(256) void conv3x3_direct_kernel(const float* __rest
     extern __shared__ __attribute__((aligned(16))) float c3_lds[];
     constexpr int TH = 8, TW = 32, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, PP = PW + 1;  // odd row pitch: no 2-way pattern on S = 2
     const int tid = threadIdx.x, ty = tid >> 5, tx = tid & 31;
-    const int tile = blockIdx.x, tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-    const int img = blockIdx.y;
+    // (tile, image) from an XCD-contiguous relabelling of the launch order, as in win_items(): neighbouring tiles share an L2
+    const unsigned G = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x, xcd = lin & 7u, gbase = G >> 3, grem = G & 7u;
+    const unsigned logical = xcd * gbase + (xcd < grem ? xcd : grem) + (lin >> 3);
+    const int tile = (int)(logical % gridDim.x), tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    const int img = (int)(logical / gridDim.x);
     const int oy = tyi * TH + ty, ox = txi * TW + tx;
     const int iy0 = tyi * TH * S - g.pt, ix0 = txi * TW * S - g.pl;
     const float* xin = x + (int64_t)img * g.xbs;
@@ -814,6 +817,28 @@ __device__ __forceinline__ void c3m_epilogue_strips(const cf32x16 (&acc)[NJ], co
     }
 }
 
+// Which items a persistent workgroup takes.  Workgroup b runs on XCD b % 8, and every XCD has its own L2: handed out round robin
+// (b, b + G, ...), the tiles next to each other in an image -- whose windows share halo rows and, more to the point, the 128-byte lines
+// their ragged row ends lie in -- are multiplied on eight different XCDs, and each fetches those lines again (counters on the
+// reference graph at batch 64: the 3 x 3 layers read 2.4 x and the stride-2 layers 1.6-2.5 x their input from the fabric).  So every
+// XCD gets one CONTIGUOUS share of the items and its workgroups walk it side by side: first = lo + (b / 8), step = the XCD's
+// workgroup count.  (Grids of fewer than eight workgroups keep the plain order.)  Returns the number of items of this workgroup.
+__device__ __forceinline__ int win_items(int items, int* first, int* step) {
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    if (G < 8) {
+        *first = b;
+        *step = G;
+        return (items - b + G - 1) / G;
+    }
+    // XCD x holds gx = ceil((G - x) / 8) workgroups, cum of them sit on the XCDs before it; its range is that share of the items (the
+    // grid never exceeds the item count, so every workgroup finds at least one)
+    const int xcd = b & 7, j = b >> 3, gx = (G + 7 - xcd) >> 3, cum = xcd * (G >> 3) + (xcd < (G & 7) ? xcd : (G & 7));
+    const int lo = (int)((int64_t)items * cum / G), hi = (int)((int64_t)items * (cum + gx) / G);
+    *first = lo + j;
+    *step = gx;
+    return lo + j < hi ? (hi - (lo + j) + gx - 1) / gx : 0;
+}
+
 template <int KS, int OCT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_window_p_kernel(const float* __restrict__ x,
                                                                                                    const cu32x4* __restrict__ wfrag,
@@ -832,9 +857,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // An item = (image, tile, group of `nocb` consecutive blocks of output channels); `osplit` groups make up the layer's blocks
     // (1 when there are enough (image, tile) pairs to go round: the blocks then take turns inside the workgroup and the second one's
     // window comes out of L2; otherwise every block is an item of its own, so that a small layer still spreads over the chip)
-    const int G = gridDim.x, first = blockIdx.x;          // this workgroup's items: first, first + G, ...
-    const int nseq = ((items - first + G - 1) / G) * nocb;  // (item, block of output channels) pairs, in order
-    const int qtotal = nseq * nchunk;                      // chunks of the whole stream
+    // this workgroup's items: first, first + G, ... below the end of its range (win_items: every XCD a contiguous range of items)
+    int first, G;
+    const int nitem = win_items(items, &first, &G);
+    const int nseq = nitem * nocb;    // (item, block of output channels) pairs, in order
+    const int qtotal = nseq * nchunk;  // chunks of the whole stream
     auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
     if (wave >= 4) {
         // ------------------------------------------------------------ producers
@@ -1074,8 +1101,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hv = lane >> 5, l31 = lane & 31;
     const int hw = g.ih * g.iw, nchunk = g.c / 16;
     const int sxt = wt.tw + 1, planet = (wt.th + 1) * sxt, post = 4 * planet;  // slots of a phase plane for this tile shape: post <= W::POS
-    const int G = gridDim.x, first = blockIdx.x;
-    const int nseq = ((items - first + G - 1) / G) * nocb, qtotal = nseq * nchunk;
+    int first, G;
+    const int nitem = win_items(items, &first, &G);
+    const int nseq = nitem * nocb, qtotal = nseq * nchunk;
     auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
     if (wave >= 4) {
         // ------------------------------------------------------------ producers: one chunk in registers, parked when the stage is free
