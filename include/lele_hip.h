@@ -422,11 +422,15 @@ int lele_hip_yolo_seg_postprocess(LeleCtx* ctx, const LeleTensor* logits, const 
  * The 128-byte unique id is made by rank 0 (comm_unique_id) and handed to the other ranks by the launcher; comm_init_file does
  * that through a file (rank 0 removes what is there and writes [32-byte job token][id] atomically, the others poll for up to
  * timeout_ms for a file carrying THEIR token).  The token is a digest of the environment variable LELE_JOB_ID (else
- * TORCHELASTIC_RUN_ID), which the launcher sets to a value unique to the launch: a file of an earlier job is never accepted. */
+ * TORCHELASTIC_RUN_ID), which the launcher sets to a value unique to the launch: a file of an earlier job is never accepted.
+ * Without a token the file carries an 8-byte beat that rank 0 keeps incrementing while it waits for the others (and removes the
+ * file once all have joined): a reader accepts an id only after it has seen two different beats -- proof that the writer is alive,
+ * whatever the ages and clocks involved.  comm_read_id_file is the reader's half on its own (no device, no RCCL). */
 typedef struct LeleComm LeleComm;
 int lele_hip_comm_unique_id(uint8_t* id128);
 int lele_hip_comm_init(LeleCtx* ctx, const uint8_t* id128, int rank, int world, LeleComm** out);
 int lele_hip_comm_init_file(LeleCtx* ctx, const char* path, int rank, int world, int timeout_ms, LeleComm** out);
+int lele_hip_comm_read_id_file(const char* path, int timeout_ms, uint8_t* id128);
 int lele_hip_comm_rank(const LeleComm* comm, int* rank, int* world);
 /* send: DEVICE i32 tensor of the same element count on every rank -> out [world, count] in rank order, on the ctx stream
  * (graph-capturable; the result is ordered after everything queued before it, e.g. lele_hip_token_filter) */

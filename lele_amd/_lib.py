@@ -143,7 +143,7 @@ class Ctx:
         h = C.c_void_p()
         rc = lib().lele_hip_graph_end(self._h, C.byref(h))
         if rc != 0:
-            lib().lele_hip_graph_abort(self._h)
+            self.graph_abort()
         check(rc)
         g = Graph(self, h)
         import weakref
@@ -165,11 +165,39 @@ class Ctx:
     def lane_wait(self, event):
         check(lib().lele_hip_lane_wait(self._h, C.c_int(int(event))))
 
+    LANE_EVENT_IDS = 1 << 16   # lele_hip_lane_record's id space (csrc/context.hip)
+
     def lane_events(self, n):
-        """reserve `n` event ids for one plan; returns the first"""
+        """reserve `n` consecutive event ids for one plan; returns the first.  Ranges come back through lane_events_release (a Runner
+        does that when it is closed or collected) and are re-used first-fit, so a process that re-plans for ever does not run out."""
+        n = int(n)
+        free = self.__dict__.setdefault("_free_events", [])
+        for i, (base, size) in enumerate(free):
+            if size >= n:
+                if size == n:
+                    free.pop(i)
+                else:
+                    free[i] = (base + n, size - n)
+                return base
         base = self._next_event
-        self._next_event += int(n)
+        if base + n > self.LANE_EVENT_IDS:
+            raise LeleError("lane events exhausted: %d ids in use, %d more asked for (of %d); close the Runners of plans no longer run"
+                            % (base, n, self.LANE_EVENT_IDS))
+        self._next_event += n
         return base
+
+    def lane_events_release(self, base, n):
+        if n > 0:
+            free = self.__dict__.setdefault("_free_events", [])
+            free.append((int(base), int(n)))
+            free.sort()
+            merged = []
+            for b, sz in free:   # coalesce neighbours
+                if merged and merged[-1][0] + merged[-1][1] == b:
+                    merged[-1] = (merged[-1][0], merged[-1][1] + sz)
+                else:
+                    merged.append((b, sz))
+            self._free_events = merged
 
     def quant_set_profiling(self, on):
         """per-stage stopwatch of fused_quantized_linear (eager calls only), see include/lele_hip.h"""
@@ -183,6 +211,7 @@ class Ctx:
 
     def graph_abort(self):
         lib().lele_hip_graph_abort(self._h)
+        self.cur_lane = 0   # the library is back on lane 0 whatever lane the failed statement ran on
 
     def buf(self):
         b = Buf(self)

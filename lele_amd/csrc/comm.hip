@@ -15,6 +15,9 @@
 #include <time.h>
 
 #include <algorithm>
+#include <atomic>
+#include <string>
+#include <thread>
 
 #include <dlfcn.h>
 #include <errno.h>
@@ -131,8 +134,15 @@ int lele_hip_comm_init(LeleCtx* ctx, const uint8_t* id128, int rank, int world, 
 // whoever launches the ranks sets to something unique per launch (lele_run: its pid and start time): a reader only accepts a file that
 // carries ITS token, so a file left behind by an earlier job is never taken for the current one, however young, and a valid one is
 // never refused, however late the reader arrives (no wall-clock test: clocks on a shared file system differ).  Rank 0 removes the
-// path before it writes.  Without any token in the environment only the size is checked, as much as a launcher that tells its ranks
-// nothing allows.
+// path before it writes.
+//
+// Without any token in the environment (a launcher that tells its ranks nothing) the all-zero token cannot tell this job's file from
+// one an earlier token-less job left under the same name, and a reader that took a dead id would hang in ncclCommInitRank.  No
+// clock can decide that either (a reader may arrive many seconds after rank 0 wrote; st_mtime is the file server's clock),
+// so the file proves that its writer is ALIVE instead: a token-less file is [32 zero bytes][128-byte id][8-byte beat], rank 0 rewrites
+// it with the beat incremented every 20 ms for as long as it sits in ncclCommInitRank (that call returns only once every rank has
+// joined, i.e. has read the file) and removes it afterwards; a reader accepts an id once it has seen it under two different beats.
+// A file nobody keeps beating -- what a dead job left, whatever its age -- is never accepted, a live one always within two beats.
 static void job_token(uint8_t (&tok)[32]) {
     memset(tok, 0, sizeof(tok));
     const char* v = getenv("LELE_JOB_ID");
@@ -148,51 +158,97 @@ static void job_token(uint8_t (&tok)[32]) {
     tok[0] |= 1;  // never all zeros: "a token was set"
 }
 
+static bool token_is_empty(const uint8_t (&tok)[32]) {
+    for (uint8_t b : tok)
+        if (b) return false;
+    return true;
+}
+
+// [token][id] (+ [beat] when the token is empty), complete when it appears: written beside the path and renamed over it
+static int write_id_file(const char* path, const uint8_t (&tok)[32], const uint8_t (&id)[128], uint64_t beat) {
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    LELE_REQUIRE(f, "comm_init_file: cannot write %s (%s)", tmp.c_str(), strerror(errno));
+    size_t w = fwrite(tok, 1, sizeof(tok), f) + fwrite(id, 1, sizeof(id), f), want = sizeof(tok) + sizeof(id);
+    if (token_is_empty(tok)) {
+        w += fwrite(&beat, 1, sizeof(beat), f);
+        want += sizeof(beat);
+    }
+    fclose(f);
+    LELE_REQUIRE(w == want, "comm_init_file: short write to %s", tmp.c_str());
+    LELE_REQUIRE(rename(tmp.c_str(), path) == 0, "comm_init_file: rename to %s failed (%s)", path, strerror(errno));
+    return 0;
+}
+
+/* the reader's half of lele_hip_comm_init_file: wait (at most timeout_ms) for a rendezvous file of THIS job under `path` and
+ * hand out its 128-byte id.  No device, no RCCL: callable (and tested) on a host without a GPU. */
+int lele_hip_comm_read_id_file(const char* path, int timeout_ms, uint8_t* id128) {
+    LELE_REQUIRE(path && id128, "comm_read_id_file: NULL argument");
+    uint8_t tok[32];
+    job_token(tok);
+    const bool tokenless = token_is_empty(tok);
+    const size_t want = 32 + 128 + (tokenless ? 8 : 0);
+    const int step_ms = 5;
+    int waited = 0;
+    bool have_beat = false;
+    uint64_t first_beat = 0;
+    for (;;) {
+        FILE* f = fopen(path, "rb");
+        if (f) {
+            uint8_t got[32 + 128 + 8 + 1];
+            const size_t r = fread(got, 1, sizeof(got), f);
+            fclose(f);
+            // the rename makes the file appear complete: another size is a foreign file, another token another job's
+            if (r == want && memcmp(got, tok, 32) == 0) {
+                uint64_t beat = 0;
+                memcpy(&beat, got + 160, tokenless ? 8 : 0);
+                if (!tokenless || (have_beat && beat != first_beat)) {
+                    memcpy(id128, got + 32, 128);
+                    return 0;
+                }
+                if (!have_beat) first_beat = beat, have_beat = true;
+            }
+        }
+        LELE_REQUIRE(waited < timeout_ms,
+                     "comm_init_file: waited %d ms for %s (a file of this job: set LELE_JOB_ID per launch; without a token the file "
+                     "must be kept alive by a running rank 0)", timeout_ms, path);
+        struct timespec ts = {0, step_ms * 1000000L};
+        nanosleep(&ts, nullptr);
+        waited += step_ms;
+    }
+}
+
 int lele_hip_comm_init_file(LeleCtx* ctx, const char* path, int rank, int world, int timeout_ms, LeleComm** out) {
     LELE_REQUIRE(ctx && path && out, "comm_init_file: NULL argument");
     uint8_t id[128], tok[32];
     job_token(tok);
-    if (rank == 0) {
-        (void)unlink(path);  // whatever an earlier job left there
-        LELE_TRY(lele_hip_comm_unique_id(id));
-        const std::string tmp = std::string(path) + ".tmp";
-        FILE* f = fopen(tmp.c_str(), "wb");
-        LELE_REQUIRE(f, "comm_init_file: cannot write %s (%s)", tmp.c_str(), strerror(errno));
-        const size_t w = fwrite(tok, 1, sizeof(tok), f) + fwrite(id, 1, sizeof(id), f);
-        fclose(f);
-        LELE_REQUIRE(w == sizeof(tok) + sizeof(id), "comm_init_file: short write to %s", tmp.c_str());
-        LELE_REQUIRE(rename(tmp.c_str(), path) == 0, "comm_init_file: rename to %s failed (%s)", path, strerror(errno));
-    } else {
-        const int step_ms = 5;
-        int waited = 0;
-        // No token in the environment (a caller that launches ranks itself and sets neither LELE_JOB_ID nor TORCHELASTIC_RUN_ID): the
-        // all-zero token cannot tell this job's file from one an earlier token-less job left under the same name, and a reader that
-        // gets there before rank 0's unlink would take a dead id and hang in ncclCommInitRank.  Then -- and only then -- the file must
-        // also be YOUNGER than this reader's own arrival (minus a slack for clock granularity): rank 0 always writes after it starts.
-        bool tokenless = true;
-        for (uint8_t b : tok) tokenless = tokenless && b == 0;
-        const time_t arrived = time(nullptr);
-        for (;;) {
-            struct stat sb;
-            const bool fresh = !tokenless || (stat(path, &sb) == 0 && sb.st_mtime + 2 >= arrived);
-            FILE* f = fresh ? fopen(path, "rb") : nullptr;
-            if (f) {
-                uint8_t got[32 + 128 + 1];
-                const size_t r = fread(got, 1, sizeof(got), f);
-                fclose(f);
-                // the rename makes the file appear complete: another size is a foreign file, another token another job's
-                if (r == 32 + 128 && memcmp(got, tok, 32) == 0) {
-                    memcpy(id, got + 32, sizeof(id));
-                    break;
-                }
-            }
-            LELE_REQUIRE(waited < timeout_ms, "comm_init_file: rank %d waited %d ms for %s (a file of this job: LELE_JOB_ID)", rank, timeout_ms, path);
-            struct timespec ts = {0, step_ms * 1000000L};
-            nanosleep(&ts, nullptr);
-            waited += step_ms;
-        }
+    if (rank != 0) {
+        LELE_TRY(lele_hip_comm_read_id_file(path, timeout_ms, id));
+        return lele_hip_comm_init(ctx, id, rank, world, out);
     }
-    return lele_hip_comm_init(ctx, id, rank, world, out);
+    (void)unlink(path);  // whatever an earlier job left there
+    LELE_TRY(lele_hip_comm_unique_id(id));
+    LELE_TRY(write_id_file(path, tok, id, 1));
+    if (!token_is_empty(tok) || world == 1) return lele_hip_comm_init(ctx, id, rank, world, out);
+    // token-less, other ranks to come: keep the file beating while this thread sits in ncclCommInitRank (which returns when all joined)
+    std::atomic<bool> stop{false};
+    std::thread beat([&] {
+        for (uint64_t b = 2; !stop.load(std::memory_order_acquire); ++b) {
+            struct timespec ts = {0, 20 * 1000000L};
+            nanosleep(&ts, nullptr);
+            uint8_t t0[32] = {0};
+            FILE* f = fopen((std::string(path) + ".tmp").c_str(), "wb");  // errors here only delay the readers: they time out and say so
+            if (!f) continue;
+            const bool ok = fwrite(t0, 1, 32, f) + fwrite(id, 1, 128, f) + fwrite(&b, 1, 8, f) == 168;
+            fclose(f);
+            if (ok) (void)rename((std::string(path) + ".tmp").c_str(), path);
+        }
+    });
+    const int rc = lele_hip_comm_init(ctx, id, rank, world, out);
+    stop.store(true, std::memory_order_release);
+    beat.join();
+    (void)unlink(path);  // every rank has read it (or the group failed): nothing token-less is left behind for a later job to find
+    return rc;
 }
 
 int lele_hip_comm_rank(const LeleComm* c, int* rank, int* world) {

@@ -151,6 +151,7 @@ struct LeleCtx {
     std::vector<std::vector<hipGraphNode_t>> event_nodes;
     int capture_deps_get(std::vector<hipGraphNode_t>* out);
     int sync_all();                     // drain every lane's stream
+    void swap_lane_memory(int to);      // park the current lane's arena / scratch / temporaries, take lane `to`'s
 
     int check_deverr(const char* where);
     int arena_reset();

@@ -30,6 +30,23 @@ int LeleCtx::arena_reset() {
     return 0;
 }
 
+/* park the current lane's arena / scratch / temporaries and take lane `to`'s (streams and capture state are the caller's business) */
+void LeleCtx::swap_lane_memory(int to) {
+    if (parked.size() < (size_t)kMaxLanes) parked.resize(kMaxLanes);
+    LaneState& cur = parked[lane];
+    LaneState& dst = parked[to];
+    cur.arena = arena, cur.arena_cap = arena_cap, cur.arena_used = arena_used;
+    cur.arena_overflow.swap(arena_overflow);
+    cur.scratch = scratch, cur.scratch_cap = scratch_cap;
+    for (int i = 0; i < 3; ++i) cur.tmp[i] = tmp[i];
+    arena = dst.arena, arena_cap = dst.arena_cap, arena_used = dst.arena_used;
+    arena_overflow.clear();
+    arena_overflow.swap(dst.arena_overflow);
+    scratch = dst.scratch, scratch_cap = dst.scratch_cap;
+    for (int i = 0; i < 3; ++i) tmp[i] = dst.tmp[i];
+    lane = to;
+}
+
 int LeleCtx::sync_all() {
     LELE_HIP_CHECK(hipStreamSynchronize(stream));
     for (int l = 0; l < kMaxLanes; ++l)
@@ -256,6 +273,12 @@ int lele_hip_graph_begin(LeleCtx* c) {
     LELE_HIP_CHECK(hipSetDevice(c->device));
     LELE_TRY(c->sync_all());
     LELE_TRY(c->arena_reset());  // frees any overflow blocks now, while synchronising is still legal
+    for (auto& ps : c->parked) {  // ... and every parked lane's (all streams are drained): its first captured op could not free them
+        for (void* p : ps.arena_overflow) (void)hipFree(p);
+        if (!ps.arena_overflow.empty()) ++c->generation;
+        ps.arena_overflow.clear();
+        ps.arena_used = 0;
+    }
     LELE_HIP_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     c->capturing = true;
     for (auto& t : c->lane_tail) t.clear();
@@ -293,9 +316,12 @@ int lele_hip_graph_abort(LeleCtx* c) {  // leave capture mode after a failed op,
     if (!c->capturing) return 0;
     c->capturing = false;
     hipGraph_t g = nullptr;
-    (void)hipStreamEndCapture(c->stream, &g);
+    (void)hipStreamEndCapture(c->stream, &g);   // c->stream is lane 0's stream for the whole capture (lane_set does not switch it)
     if (g) (void)hipGraphDestroy(g);
     (void)hipGetLastError();
+    if (c->lane != 0) c->swap_lane_memory(0);   // the failed op may have run on a side lane: lane 0's arena / scratch / temporaries back
+    for (auto& t : c->lane_tail) t.clear();
+    c->event_nodes.clear();
     return 0;
 }
 int lele_hip_graph_launch(LeleGraph* g) {
@@ -335,22 +361,19 @@ int lele_hip_lane_set(LeleCtx* c, int lane) {
         dst.arena_cap = c->arena_cap;
         LELE_HIP_CHECK(hipMalloc((void**)&dst.arena, dst.arena_cap));
     }
-    if (c->capturing) LELE_TRY(c->capture_deps_get(&c->lane_tail[c->lane]));  // where the lane we leave stands
-    LeleCtx::LaneState& cur = c->parked[c->lane];  // park the current lane's memory
-    cur.arena = c->arena, cur.arena_cap = c->arena_cap, cur.arena_used = c->arena_used;
-    cur.arena_overflow.swap(c->arena_overflow);
-    cur.scratch = c->scratch, cur.scratch_cap = c->scratch_cap;
-    for (int i = 0; i < 3; ++i) cur.tmp[i] = c->tmp[i];
-    c->arena = dst.arena, c->arena_cap = dst.arena_cap, c->arena_used = dst.arena_used;
-    c->arena_overflow.clear();
-    c->arena_overflow.swap(dst.arena_overflow);
-    c->scratch = dst.scratch, c->scratch_cap = dst.scratch_cap;
-    for (int i = 0; i < 3; ++i) c->tmp[i] = dst.tmp[i];
-    c->lane = lane;
-    if (c->capturing) {  // one stream records everything: the next node hangs off THIS lane's tail (nothing yet: a root of the graph)
+    // where the lane we leave stands -- unless an op has invalidated the capture: then there is nothing to remember, and the switch must
+    // still succeed so that a caller's clean-up (`finally: lane_set(0)`, lele_hip_graph_abort) does not mask the original error
+    bool live = c->capturing;
+    if (live) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c->stream, &st) != hipSuccess || st != hipStreamCaptureStatusActive) live = false, (void)hipGetLastError();
+    }
+    if (live) LELE_TRY(c->capture_deps_get(&c->lane_tail[c->lane]));
+    c->swap_lane_memory(lane);
+    if (live) {  // one stream records everything: the next node hangs off THIS lane's tail (nothing yet: a root of the graph)
         std::vector<hipGraphNode_t>& t = c->lane_tail[lane];
         LELE_HIP_CHECK(hipStreamUpdateCaptureDependencies(c->stream, t.empty() ? nullptr : t.data(), t.size(), hipStreamSetCaptureDependencies));
-    } else {
+    } else if (!c->capturing) {
         c->stream = c->lane_stream[lane];
     }
     return 0;

@@ -120,11 +120,17 @@ def schedule(plan, times=None, lanes=3, min_gain_ms=0.004, default_ms=0.006):
                 st["_alias_of"] = root.get(src, src)
     # readers through a may_alias result also read the source's buffer
     alias_of = {o: st["_alias_of"] for st in sts if "_alias_of" in st for o in st["out"]}
+
+    def alias_chain(rt):     # a transpose of a transpose that may both be views: every buffer the value may live in
+        seen = []
+        while rt in alias_of and alias_of[rt] not in seen and alias_of[rt] != rt:
+            rt = alias_of[rt]
+            seen.append(rt)
+        return seen
     for i in range(n):
         if device[i]:
             for rt in list(touched[i]):
-                if rt in alias_of:
-                    touched[i].add(alias_of[rt])
+                touched[i].update(alias_chain(rt))
     # ---- 2. list scheduling
     def cost(i):
         o = sts[i]["out"][0] if sts[i].get("out") else None
@@ -197,6 +203,8 @@ def schedule(plan, times=None, lanes=3, min_gain_ms=0.004, default_ms=0.006):
             accesses.setdefault(rt, []).append((lane_of[i], seq[i]))
             last_touch[rt] = i
     pinned = {root.get(o, o) for o in outputs} | {root.get(x, x) for x in plan["inputs"]}
+    for rt in list(pinned):    # an output that may be a view of its operand at run time keeps the operand's buffer alive too
+        pinned.update(alias_chain(rt))
     slot_value = {}    # slot id -> root name it holds
     n_slots = 0
     recent = []        # roots read by the last few device statements (the sequential allocator's guard, kept)
@@ -262,6 +270,19 @@ def schedule(plan, times=None, lanes=3, min_gain_ms=0.004, default_ms=0.006):
             sts[t]["record"] = event_of[t]
         tails.append(event_of[t])
     sts.append({"op": "join", "out": [], "wait": tails})
+    # ... and the FIRST statement of every side lane waits for a point on lane 0 taken before anything of this run was issued.  Without
+    # it a statement that reads only plan inputs or weights (no producer inside the run: no wait of its own) could, run eagerly,
+    # (1) read a device input the caller produced on lane 0's stream before it is ready and (2) on a back-to-back second run
+    # overwrite a re-used slot that lane 0's tail of the PREVIOUS run still reads -- the final join orders lane 0 after the side
+    # lanes, not the reverse.  In a recorded graph the event stands for no node: nothing is added there.
+    if len(used) > 1 or (used and used[0] != 0):
+        start = len(event_of)
+        event_of["start"] = start
+        sts.insert(0, {"op": "join", "out": [], "wait": [], "record": start})
+        for l in used:
+            if l != 0:
+                f = min(i for i in range(n) if device[i] and lane_of[i] == l)
+                sts[f + 1]["wait"] = [start] + list(sts[f + 1].get("wait", []))
     new = dict(plan)
     new["statements"] = sts
     new["slots"] = ["buf_%d" % s for s in range(n_slots)]

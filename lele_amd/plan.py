@@ -210,7 +210,9 @@ def rebatch_lifted(plan, n, shapes=None):
             ok = bool(dims) and dims[0] == {"int": 1}
             if ok and shapes is not None:
                 src = shapes.get(st["args"][0].get("ref")) if isinstance(st["args"][0], dict) else None
-                lit = [d.get("int") for d in dims]
+                lit = [d.get("int") if isinstance(d, dict) else None for d in dims]
+                if any(not isinstance(v, int) for v in lit):     # a {"ref": ...} or float dimension: pattern not proven, leave it alone
+                    src = None
                 ok = src is not None and len(src) >= 1 and int(src[0]) == 1 and st["args"][0].get("ref") not in plan["weights"] and \
                     (any(v in (-1, 0) for v in lit) or numel(lit) == numel(src))
             if ok:
@@ -666,7 +668,20 @@ class Runner:
         self.stmt_index = 0
         self.shapes = None  # set to {} to record the shape of every tensor value of the next run
         self.taps = None    # set to {name: None, ...}: host copies of those results are left there by the next run (tests)
-        self.event_base = ctx.lane_events(plan["dag"]["events"]) if "dag" in plan else 0   # a DAG plan (lele_amd.lanes.schedule)
+        self.n_events = int(plan["dag"]["events"]) if "dag" in plan else 0                   # a DAG plan (lele_amd.lanes.schedule)
+        self.event_base = ctx.lane_events(self.n_events) if self.n_events else 0
+
+    def close(self):
+        """hand the plan's event ids back to the context (they are a finite space: 65536 per context)"""
+        if getattr(self, "n_events", 0):
+            self.ctx.lane_events_release(self.event_base, self.n_events)
+            self.n_events = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _wkey(self, node):
         return weight_key(node) if self.v2 else node[1]

@@ -89,14 +89,21 @@ def test_rendezvous_file_of_another_job_is_refused(ctx, tmp_path, monkeypatch):
     monkeypatch.setenv("LELE_JOB_ID", "job-c")     # the next job does not take job-b's file either
     with pytest.raises(_lib.LeleError, match="waited"):
         Comm.from_file(ctx, str(path), 1, 2, timeout_ms=40)
-    # no token at all: a well-formed file of an EARLIER token-less job must not be taken either -- it is older than the reader
+    # no token at all: a well-formed file that nobody keeps BEATING (what a dead token-less job left) is refused whatever its age --
+    # a minute old or written this instant (no wall-clock test; tests/test_multiprocess.py has the live handshake)
     monkeypatch.delenv("LELE_JOB_ID")
     monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
-    path.write_bytes(b"\0" * 32 + b"\5" * 128)
-    old = os.stat(path).st_mtime - 60
-    os.utime(path, (old, old))
-    with pytest.raises(_lib.LeleError, match="waited"):
-        Comm.from_file(ctx, str(path), 1, 2, timeout_ms=40)
+    for stale in (b"\0" * 32 + b"\5" * 128, b"\0" * 32 + b"\5" * 128 + b"\3" + b"\0" * 7):
+        path.write_bytes(stale)
+        with pytest.raises(_lib.LeleError, match="waited"):
+            Comm.from_file(ctx, str(path), 1, 2, timeout_ms=40)
+        old = os.stat(path).st_mtime - 60
+        os.utime(path, (old, old))
+        with pytest.raises(_lib.LeleError, match="waited"):
+            Comm.from_file(ctx, str(path), 1, 2, timeout_ms=40)
+    comm = Comm.from_file(ctx, str(path), 0, 1, timeout_ms=2000)   # a token-less rank 0 alone: [zero token][id][beat]
+    assert len(path.read_bytes()) == 168
+    comm.close()
 
 
 def test_native_runner_ranks_and_decode(ctx, tmp_path):

@@ -33,7 +33,9 @@ def test_scheduler_orders_every_cross_lane_edge_and_frees_slots_by_happens_befor
     sts = {st["out"][0]: st for st in dag["statements"] if st["out"]}
     assert dag["dag"]["lanes"] == 2 and sts["b"]["lane"] != sts["c"]["lane"]          # the two branches overlap
     side = sts["b"] if sts["b"]["lane"] != sts["a"]["lane"] else sts["c"]
-    assert side["wait"] == [sts["a"]["record"]]                                        # fork: waits for a
+    start = dag["statements"][0]
+    assert start["op"] == "join" and start["wait"] == [] and "record" in start        # the run's starting point on lane 0
+    assert side["wait"] == [start["record"], sts["a"]["record"]]                       # fork: waits for the start and for a
     assert sts["d"]["lane"] in (0, 1) and set(sts["d"].get("wait", [])) == {side["record"]} if sts["d"]["lane"] != side["lane"] else True
     assert dag["statements"][-1]["op"] == "join"
     # b and c are alive together: they can never share a slot; e may not take the slot of a value its lane has not seen die
@@ -47,7 +49,7 @@ def test_scheduler_orders_every_cross_lane_edge_and_frees_slots_by_happens_befor
 
 def _random_plan(rng, n):
     """a random SSA plan: unary / binary statements over earlier values, views of earlier values, a two-result split now and then"""
-    st, vals = [], ["x"]
+    st, vals = [], ["x", "y"]     # two inputs: statements that read only inputs have no producer inside the run (ADVICE r5)
     for i in range(n):
         kind = rng.choice(["unary", "binary", "view", "split"], p=[0.35, 0.4, 0.15, 0.1])
         a = vals[int(rng.integers(max(0, len(vals) - 6), len(vals)))]
@@ -63,14 +65,16 @@ def _random_plan(rng, n):
             vals.append("w%d" % i)
         vals.append("v%d" % i)
     outs = [vals[-1], vals[len(vals) // 2]]
-    return {"source": "random", "format": "lele_amd.plan/2", "inputs": ["x"], "outputs": outs, "slots": [], "statements": st, "weights": {}}
+    return {"source": "random", "format": "lele_amd.plan/2", "inputs": ["x", "y"], "outputs": outs, "slots": [], "statements": st, "weights": {}}
 
 
 def test_random_plans_every_hazard_is_ordered_by_happens_before():
     """An INDEPENDENT check of the scheduler (no GPU): rebuild happens-before from what the emitted plan says -- program order on each lane
     plus record -> wait edges, transitively closed -- and verify (a) every read of a value is ordered after its producer, (b) two
     values share a workspace slot only if EVERY access of the earlier one (its writer and all readers, through views) happens-before
-    the writer of the later one, (c) the final join waits for the tail of every side lane, (d) outputs never lose their slot.
+    the writer of the later one, (c) the final join waits for the tail of every side lane, (d) outputs never lose their slot,
+    (e) EVERY statement of a side lane -- also one that reads only plan inputs -- is ordered after the run's starting point on lane 0,
+    so that with the final join of the previous run nothing of run k + 1 can overtake anything of run k.
     200 random plans, random costs, 2-4 lanes, with and without hysteresis."""
     from lele_amd.lanes import schedule
     rng = np.random.default_rng(2026)
@@ -80,6 +84,9 @@ def test_random_plans_every_hazard_is_ordered_by_happens_before():
         times = {st["out"][0]: float(rng.uniform(0.001, 0.1)) for st in plan["statements"]}
         dag = schedule(plan, times, lanes=int(rng.integers(2, 5)), min_gain_ms=float(rng.choice([-1.0, 0.004, 0.03])))
         sts = dag["statements"]
+        for st in sts:
+            if st["op"] == "join":
+                st["lane"] = 0          # the start / the final join are points on lane 0
         dev = [i for i, st in enumerate(sts) if "lane" in st]
         n = len(sts)
         hb = np.zeros((n, n), bool)
@@ -96,7 +103,12 @@ def test_random_plans_every_hazard_is_ordered_by_happens_before():
         for k in dev:                                   # transitive closure (plan order is a topological order)
             hb[:, k] |= (hb[:, dev] & hb[dev, k][None, :]).any(axis=1)
         # value -> root buffer, producer of every value, accesses of every root
-        root, producer = {"x": "x"}, {}
+        if any(sts[i]["lane"] != 0 for i in dev):                                                                                     # (e)
+            assert sts[0]["op"] == "join" and "record" in sts[0]
+            for i in dev[1:]:
+                assert hb[0, i], "trial %d: statement %d on lane %d is not ordered after the start of the run" % (trial, i, sts[i]["lane"])
+        dev = [i for i in dev if sts[i]["op"] != "join"]
+        root, producer = {"x": "x", "y": "y"}, {}
         for i, st in enumerate(sts):
             if st["op"] != "call":
                 continue
@@ -134,6 +146,7 @@ def test_random_plans_every_hazard_is_ordered_by_happens_before():
         join = sts[-1]
         assert join["op"] == "join"
         for lane, last in last_on_lane.items():
+            last = max(i for i in dev if sts[i]["lane"] == lane) if any(sts[i]["lane"] == lane for i in dev) else last
             if lane != 0:
                 assert sts[last].get("record") in join["wait"], "trial %d: lane %d is not joined" % (trial, lane)                     # (c)
         forks += dag["dag"]["events"]
@@ -190,6 +203,52 @@ def test_lanes_through_the_c_abi(ctx):
     with pytest.raises(_lib.LeleError, match="lane 1 is current"):
         ctx.graph_begin()
     ctx.lane_set(0)
+
+
+@pytest.mark.gpu
+def test_dag_plan_with_two_inputs_back_to_back_eager_runs(ctx):
+    """a statement that reads only plan inputs has no producer inside the run.  Two inputs, the second consumed FIRST on a
+    side lane; the inputs are produced by kernels on lane 0's stream right before the run (no sync), and the plan runs 6 times back
+    to back eagerly without a sync in between, each time on fresh inputs -- every run's outputs must be that run's, and event ids
+    handed back by a closed Runner are reused."""
+    from lele_amd import kernels as K
+    from lele_amd.lanes import schedule
+    from lele_amd.plan import Runner
+    st = [{"op": "call", "out": ["a"], "fn": "exp", "args": [{"ref": "x"}], "bufs": 1},
+          {"op": "call", "out": ["b"], "fn": "sigmoid", "args": [{"ref": "y"}], "bufs": 1},
+          {"op": "call", "out": ["b1"], "fn": "tanh", "args": [{"ref": "b"}], "bufs": 1},
+          {"op": "call", "out": ["a1"], "fn": "relu", "args": [{"ref": "a"}], "bufs": 1},
+          {"op": "call", "out": ["c"], "fn": "add", "args": [{"ref": "a1"}, {"ref": "b1"}], "bufs": 1},
+          {"op": "call", "out": ["d"], "fn": "sigmoid", "args": [{"ref": "c"}], "bufs": 1}]
+    plan = {"source": "toy2", "format": "lele_amd.plan/2", "inputs": ["x", "y"], "outputs": ["d"], "slots": ["buf_0", "buf_1", "buf_2"],
+            "statements": st, "weights": {}}
+    dag = schedule(plan, {"a": 0.05, "b": 0.05, "b1": 0.05, "a1": 0.05, "c": 0.01, "d": 0.01}, lanes=2, min_gain_ms=-1.0)
+    lanes_used = {s_["lane"] for s_ in dag["statements"] if "lane" in s_}
+    assert lanes_used == {0, 1}
+    side_first = next(s_ for s_ in dag["statements"] if s_.get("lane") == 1)
+    assert dag["statements"][0]["record"] in side_first["wait"]
+    before = ctx._next_event
+    r = Runner(dag, {}, ctx)
+    rng = np.random.default_rng(4)
+    base = [rng.standard_normal((1 << 20,)).astype(np.float32) for _ in range(2)]
+    xs, ys = ctx.buf().upload(base[0]), ctx.buf().upload(base[1])
+    xin, yin = ctx.buf(), ctx.buf()
+    outs, keep = [], [ctx.buf() for _ in range(6)]
+    for k in range(6):     # inputs produced on lane 0's stream by kernels (a big reduction chain makes them late), then the plan at once
+        sc = ctx.buf().upload(np.array([1.0 + k], np.float32))
+        xk = K.mul(xs, sc, out=xin, ctx=ctx)
+        yk = K.mul(ys, sc, out=yin, ctx=ctx)
+        d = r.run({"x": xk, "y": yk})[0]
+        outs.append(K.view_copy(d, [], out=keep[k], ctx=ctx))
+    ctx.sync()
+    for k in range(6):
+        x, y = base[0] * np.float32(1.0 + k), base[1] * np.float32(1.0 + k)
+        want = K.sigmoid(K.add(K.relu(K.exp(x, ctx=ctx), ctx=ctx), K.tanh(K.sigmoid(y, ctx=ctx), ctx=ctx), ctx=ctx), ctx=ctx).numpy()
+        assert np.array_equal(outs[k].numpy(), want), "run %d" % k
+    r.close()
+    r2 = Runner(dag, {}, ctx)
+    assert r2.event_base == r.event_base and ctx._next_event == before + dag["dag"]["events"]     # the id range came back
+    r2.close()
 
 
 def _check_dag(ctx, plan, weights, feed, times=None, **kw):

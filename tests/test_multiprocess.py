@@ -228,3 +228,55 @@ def test_bench_spawns_its_own_ranks_and_refuses_a_mismatched_world():
     bad = subprocess.run([sys.executable, bench_py, "--gpus", "4", "--dry-run"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert bad.returncode != 0 and "refusing" in bad.stderr
+
+
+def test_tokenless_rendezvous_file_needs_a_live_writer(tmp_path, monkeypatch):
+    """lele_hip_comm_read_id_file (the reader's half of comm_init_file; no device): without LELE_JOB_ID / TORCHELASTIC_RUN_ID a
+    file is accepted once it has been seen under two different beats -- however long before the reader it was first written
+    (start-up skew of many seconds, file-server clocks) -- and never when nobody keeps it beating."""
+    import ctypes as C
+    import threading
+    import time
+    from lele_amd import _lib
+    fn = _lib.lib().lele_hip_comm_read_id_file
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+    monkeypatch.delenv("LELE_JOB_ID", raising=False)
+    monkeypatch.delenv("TORCHELASTIC_RUN_ID", raising=False)
+    path = tmp_path / "uid"
+    ident = bytes(range(128))
+
+    def write(beat):
+        tmp = tmp_path / "uid.tmp"
+        tmp.write_bytes(b"\0" * 32 + ident + int(beat).to_bytes(8, "little"))
+        os.replace(tmp, path)
+
+    got = C.create_string_buffer(128)
+    write(7)
+    old = os.stat(path).st_mtime - 3600
+    os.utime(path, (old, old))
+    assert fn(str(path).encode(), 60, got) != 0                     # an hour old, no writer: refused
+    write(7)
+    assert fn(str(path).encode(), 60, got) != 0                     # brand new, no writer: refused all the same
+    stop = threading.Event()
+
+    def rank0():
+        beat = 8
+        while not stop.is_set():
+            time.sleep(0.02)
+            write(beat)
+            beat += 1
+
+    write(7)
+    os.utime(path, (old, old))                                       # "written long before the reader arrived"
+    t = threading.Thread(target=rank0)
+    t.start()
+    try:
+        assert fn(str(path).encode(), 5000, got) == 0
+    finally:
+        stop.set()
+        t.join()
+    assert got.raw == ident
+    # with a token the file is [token][id] and only the token counts (age, beats: irrelevant); another job's token is refused
+    monkeypatch.setenv("LELE_JOB_ID", "job-x")
+    assert fn(str(path).encode(), 40, got) != 0

@@ -21,7 +21,12 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--calls", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--compute-bound", action="store_true",
+                    help="VERDICT r5 item 6: one slice of M rows, M in {8192, 32768}, K in {512, 2048, 4096}, N in {2048, 4096}: what "
+                         "the i8 cores reach when K is not 512 (fused op with its dynamic quantisation, and mat_mul_integer alone)")
     args = ap.parse_args()
+    if args.compute_bound:
+        return compute_bound(args)
     import lele_amd
     from lele_amd import kernels as K
     from lele_amd._lib import Weight
@@ -81,6 +86,79 @@ def main():
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         json.dump(res, open(args.out, "w"), indent=1)
+
+
+def _timed(ctx, fn, calls, graph=True):
+    """us per call: `calls` calls recorded into one hipGraph and replayed (no host overhead); eager trains of calls when the op's scratch
+    does not fit the context's staging arena (an op that allocates cannot be captured) -- those calls take >= 100 us each"""
+    fn()
+    ctx.sync()
+    if not graph:
+        ctx.timer_start()
+        for _ in range(5 * calls):
+            fn()
+        return ctx.timer_stop() * 1e3 / (5 * calls)
+    ctx.graph_begin()
+    for _ in range(calls):
+        fn()
+    gr = ctx.graph_end()
+    gr.launch()
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(5):
+        gr.launch()
+    us = ctx.timer_stop() * 1e3 / (5 * calls)
+    gr.close()
+    return us
+
+
+def compute_bound(args):
+    """TOP/s against the 3944 TOP/s dense i8 peak.  `fused` = lele's fused_quantized_linear (range + quantisation + GEMM + f32
+    epilogue: the op a model pays for), default routing and the tiled chain; `mmi` = mat_mul_integer on u8 codes that are already
+    quantised (the GEMM kernel + its packing of the activation, no range pass): the nearest thing to the core alone."""
+    import lele_amd
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    ctx = lele_amd._lib.Ctx(0)
+    rng = np.random.default_rng(0)
+    PEAK = 3944.0
+    res = []
+    for m in (8192, 32768):
+        for k in (512, 2048, 4096):
+            for n in (2048, 4096):
+                x = ctx.buf().upload(rng.standard_normal((1, m, k)).astype(np.float32))
+                wq = np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32)
+                w = (Weight(wq), Weight((np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32)),
+                     Weight(np.array([128.0], np.float32)), Weight((rng.standard_normal(n) * 0.02).astype(np.float32)))
+                ob = ctx.buf()
+                graph = m * k <= 32 << 20     # the quantised activation has to fit the 64 MiB staging arena for the op to be captured
+                row = {"rows": m, "k": k, "n": n, "GOP": round(2 * m * k * n / 1e9, 1), "timed": "graph replay" if graph else "eager train"}
+                ref = None
+                for vname, env in (("fused default", {}), ("fused tiled chain", {"LELE_HIP_IGEMM_RS": "0"})):
+                    old = {kk: os.environ.get(kk) for kk in env}
+                    os.environ.update(env)
+                    try:
+                        got = K.fused_quantized_linear(x, *w, False, out=ob, ctx=ctx).numpy().copy()
+                        if ref is None:
+                            ref = got
+                        us = _timed(ctx, lambda: K.fused_quantized_linear(x, *w, False, out=ob, ctx=ctx), args.calls, graph)
+                    finally:
+                        for kk, v in old.items():
+                            os.environ.pop(kk, None) if v is None else os.environ.__setitem__(kk, v)
+                    tops = 2 * m * k * n / us / 1e6
+                    row[vname] = {"us": round(us, 2), "same_bits": bool(np.array_equal(got, ref)), "tops": round(tops, 1),
+                                  "frac_of_i8_peak": round(tops / PEAK, 4)}
+                a = ctx.buf().upload(rng.integers(0, 256, (1, m, k)).astype(np.float32))
+                azp, bzp = Weight(np.array([128.0], np.float32)), Weight(np.array([127.0], np.float32))
+                wb = Weight(wq)
+                us = _timed(ctx, lambda: K.mat_mul_integer(a, wb, azp, bzp, out=ob, ctx=ctx), args.calls, graph)
+                tops = 2 * m * k * n / us / 1e6
+                row["mmi"] = {"us": round(us, 2), "tops": round(tops, 1), "frac_of_i8_peak": round(tops / PEAK, 4)}
+                print(json.dumps(row), flush=True)
+                res.append(row)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        json.dump({"peak_i8_tops": PEAK, "rows": res}, open(args.out, "w"), indent=1)
 
 
 if __name__ == "__main__":
