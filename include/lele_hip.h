@@ -452,6 +452,26 @@ int lele_hip_fused_quantized_linear_residual(LeleCtx* ctx, const LeleTensor* inp
                                              const LeleTensor* weight_scale, const LeleTensor* weight_zero, const LeleTensor* bias,
                                              int apply_relu, const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out,
                                              int64_t* out_shape, int32_t* out_rank);
+/* the same followed by the LayerNorm over the last axis that reads the sum (src/kernels/norm.rs:226 -> avx/norm.rs:10-133):
+ *   out = fused_quantized_linear[_residual](input, W.., apply_relu, res1, res2);  ln_out = layer_norm(out, ln_scale, ln_bias, -1, epsilon)
+ * bit for bit the two calls (res1 / res2 may be NULL).  With K = 512 and N = 512 over a batch a workgroup of the GEMM holds whole
+ * rows of the result and normalises them in its epilogue: one launch and one read of the sum less per transformer half-layer. */
+int lele_hip_fused_quantized_linear_residual_ln(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8,
+                                                const LeleTensor* weight_scale, const LeleTensor* weight_zero, const LeleTensor* bias,
+                                                int apply_relu, const LeleTensor* res1, const LeleTensor* res2, const LeleTensor* ln_scale,
+                                                const LeleTensor* ln_bias, float epsilon, LeleBuf* out, LeleBuf* ln_out, int64_t* out_shape,
+                                                int32_t* out_rank);
+/* the output half of a SAN-M attention block (SenseVoice's encoder layer; an FSMN memory block beside the attention) as one call:
+ *   mem = depthwise_conv1d_tlc(v_src, x_offset, fsmn_w, fsmn_bias, pad_left, pad_right, relu = 0, add_input = 1)
+ *   out = fused_quantized_linear_residual(input, W.., apply_relu, mem, res2);  ln_out = layer_norm(out, ln_scale, ln_bias, -1, epsilon)
+ * (conv1d.rs:837 between two transposes + an Add, quantization.rs:77, two Adds, norm.rs:226) bit for bit those three calls; res2 and
+ * fsmn_bias may be NULL.  With K = N = 512 over a batch the GEMM's workgroup computes the memory block of its 32 rows from a window of
+ * v staged in LDS and normalises the rows in its epilogue -- three launches become one; other shapes issue the three calls. */
+int lele_hip_sanm_out_block(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8, const LeleTensor* weight_scale,
+                            const LeleTensor* weight_zero, const LeleTensor* bias, int apply_relu, const LeleTensor* v_src,
+                            const LeleTensor* fsmn_w, const LeleTensor* fsmn_bias, int64_t x_offset, int64_t pad_left, int64_t pad_right,
+                            const LeleTensor* res2, const LeleTensor* ln_scale, const LeleTensor* ln_bias, float epsilon, LeleBuf* out,
+                            LeleBuf* ln_out, int64_t* out_shape, int32_t* out_rank);
 /* two quantised linears with a ReLU between them (a transformer layer's feed-forward block):
  *   fused_quantized_linear[_residual](fused_quantized_linear(input, w1.., apply_relu = 1), w2.., apply_relu2, res1, res2)
  * (quantization.rs:77-169 twice; res1 / res2 may be NULL).  When the hidden layer is large its f32 tensor is never stored: the first

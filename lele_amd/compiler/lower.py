@@ -806,6 +806,66 @@ class Lowering:
             dead.add(i)
         self.statements[:] = [st for i, st in enumerate(sts) if i not in dead]
 
+    def fold_ln_epilogue(self):
+        """A projection's sum and the LayerNorm that reads it, as one statement with two results:
+
+            x1 = fused_quantized_linear_residual(..., res1, res2);  x1n = layer_norm(x1, g, b, -1, eps)
+              -> [x1, x1n] = fused_quantized_linear_residual_ln(..., res1, res2, g, b, eps)
+
+        and, where res1 is a `depthwise_conv1d_tlc(.., relu = false, add_input = true)` that nothing else reads (the FSMN memory block
+        of a SAN-M layer), the three of them as `sanm_out_block` (lele_hip_sanm_out_block).  x1 may have other readers (it is the residual
+        stream); the LayerNorm must normalise over the last axis with constant scale and bias.  The run-time forms issue the
+        separate calls themselves wherever the one-launch kernel does not take the shapes, so the rewrite is always legal; both
+        are bit-identical to the sequence (tests/test_quant.py)."""
+        sts = self.statements
+        outs = {sanitize(o) for o in self.outputs}
+        readers = {}
+
+        def refs(n, acc):
+            if isinstance(n, dict):
+                for key in ("ref", "ints"):
+                    if isinstance(n.get(key), str):
+                        acc.append(n[key])
+                for v in n.values():
+                    refs(v, acc)
+            elif isinstance(n, list):
+                for v in n:
+                    refs(v, acc)
+            return acc
+        producer = {}
+        for i, st in enumerate(sts):
+            for o in st.get("out", []):
+                producer[o] = i
+            for r in refs(st.get("args", st.get("in")), []):
+                readers.setdefault(r, []).append(i)
+        dead = set()
+        for i, st in enumerate(sts):
+            if st.get("fn") != "fused_quantized_linear_residual" or i in dead:
+                continue
+            x1 = st["out"][0]
+            lns = [j for j in readers.get(x1, []) if j > i and sts[j].get("fn") == "layer_norm" and sts[j]["args"][0] == {"ref": x1}
+                   and sts[j]["args"][3] == {"int": -1} and all("ref" not in a for a in sts[j]["args"][1:3])]
+            if len(lns) != 1:
+                continue
+            ln = sts[lns[0]]
+            g, b, eps = ln["args"][1], ln["args"][2], ln["args"][4]
+            a = st["args"]          # input, w, scale, zero, bias, relu, res1, res2
+            mem = a[6].get("ref") if isinstance(a[6], dict) else None
+            tlc = sts[producer[mem]] if mem in producer else None
+            if (tlc is not None and tlc.get("fn") == "depthwise_conv1d_tlc" and readers.get(mem, []) == [i] and mem not in outs
+                    and tlc["args"][5] == {"bool": False} and tlc["args"][7] == {"bool": True} and producer[mem] not in dead):
+                t = tlc["args"]     # x, w, bias, pl, pr, relu, x_offset, add_input
+                st["fn"] = "sanm_out_block"
+                st["args"] = a[:6] + [t[0], t[1], t[2], t[6], t[3], t[4], a[7], g, b, eps]
+                dead.add(producer[mem])
+            else:
+                st["fn"] = "fused_quantized_linear_residual_ln"
+                st["args"] = a[:8] + [g, b, eps]
+            st["out"] = [x1, ln["out"][0]]
+            st["bufs"] = 2
+            dead.add(lns[0])
+        self.statements[:] = [st for i, st in enumerate(sts) if i not in dead]
+
     def fold_attention(self):
         """matmul_view(Q view, K^T view) -> softmax_scaled -> matmul_view(P, V view [, out_perm, out_reshape]) with private
         intermediates becomes ONE `attention_view` statement (lele_hip_attention_view: the score / probability tensors stay on
@@ -904,6 +964,7 @@ class Lowering:
         if self.extra_fusions:
             self.fold_linear_residuals()
             self.fold_ffn()
+            self.fold_ln_epilogue()     # after fold_ffn: the feed-forward block's second linear belongs to that fold
             self.fold_attention()
 
     def lower_if(self, node):

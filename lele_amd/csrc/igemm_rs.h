@@ -833,13 +833,42 @@ struct AsArgs {
     int nblk;
     QParams* prm;          // published per slice (the wave that holds the slice's first row)
     int tpw;               // !TWO: column tiles per workgroup (8 or 4: grid.y = ceil(nct / tpw)); wave w multiplies tile blockIdx.y tpw + w
+    // LN (n == 512, TWO): the LayerNorm that follows the projection, in the same launch (lele_hip_fused_quantized_linear_residual_ln)
+    const float* ln_g = nullptr;    // [512] scale
+    const float* ln_b = nullptr;    // [512] bias
+    float ln_eps = 0.0f;
+    float* ln_out = nullptr;        // [rows][512]
+    float* ln_rowstat = nullptr;    // NULL or [rows][2]: {min, max} of every normalised row (LeleBuf::rowstat kind 0)
+    // FS (with LN): res1 is not read but COMPUTED here -- the FSMN memory block depthwise_conv1d_tlc(fs_x, fs_w, fs_b, pl, pr, add_input)
+    // over the workgroup's 32 rows (conv.hip dwconv1d_tlc_kernel: the same FMA chain per output, so the same bits)
+    const float* fs_x = nullptr;    // [rows][fs_pitch], already offset to the first of the 512 channels; epi.m time steps per utterance
+    int fs_pitch = 0;
+    const float* fs_w = nullptr;    // [512][FS]
+    const float* fs_b = nullptr;    // NULL or [512]
+    // (padding FS / 2 on either side: the output is as long as the input)
 };
+constexpr int AS_LN_PITCH = 516;    // words: eight rows x four words of a ds_write_b128 lane group fall on 32 different banks
+constexpr int AS_LN_LDS = 32 * AS_LN_PITCH * 4;
+constexpr int as_fs_lds(int fs) { return (32 + fs - 1) * AS_LN_PITCH * 4; }
 
 // TWO = false (few row tiles: one utterance): a workgroup takes only `tpw` column tiles, one a wave, and the grid's second dimension
 // the rest -- the row tile is quantised once per column group (out of L2), in exchange for four times the workgroups.
-template <int NRES, bool RELU, bool TWO = true>
+// LN = true: the workgroup holds whole rows of the result (32 x 512), so the LayerNorm that reads it runs here as well -- the tile goes
+// through LDS once (a lane of the epilogue owns 32 columns of ONE row, the normalisation wants a row spread over 32 lanes), then every
+// half-wave normalises two rows with the operations of layer_norm_reg_kernel<16> in their order (eltwise.hip; avx/norm.rs:10-133:
+// the same bits), writes them and leaves their {min, max} for the quantiser of the next linear.  One launch, one read of the sum less.
+// FS = the FSMN kernel width (0: none).  The first residual of a SAN-M layer's out projection is the memory block
+// conv_k(v) + v of the SAME rows' v (k = 11 time steps around each row, zero beyond the utterance): a workgroup fetches the 32 + k - 1
+// rows of v it needs straight into the tile region (direct-to-LDS loads, no registers), thread c slides a k-register window down
+// column c and overwrites row r with its result in place (it is the only reader of its column), and the epilogue takes res1 from
+// there -- the 11 MB result of the separate kernel, its launch and its re-read are gone.
+template <int NRES, bool RELU, bool TWO = true, bool LN = false, int FS = 0>
 __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
+    static_assert(!LN || TWO, "the LayerNorm needs whole rows in one workgroup");
+    static_assert(FS == 0 || (LN && NRES >= 1), "the in-kernel FSMN block is res1 of the LayerNorm form");
     constexpr int KS = 16;
+    extern __shared__ __attribute__((aligned(16))) float s_ln[];  // LN: [32][AS_LN_PITCH]
+    __shared__ float s_lng[LN ? 512 : 1], s_lnb[LN ? 512 : 1];
     __shared__ __attribute__((aligned(16))) char s_tile[KS * 1024];
     __shared__ int s_rowsum[4][32];
     __shared__ float s_scale[32];
@@ -878,11 +907,34 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) xv[c] = *reinterpret_cast<const float4*>(src + 16 * c);
     }
+    // FS: the window of v, rows [32 t - pl, 32 t + 31 + FS - 1 - pl] clamped into the tensor (rows of another utterance are fetched and
+    // never used), two 1 KiB direct-to-LDS loads a row, spread over the eight waves.  Issued right behind the rows: loads return in
+    // order, so the wait for the rows in front of the quantiser below covers them and they cost no register.
+    float fw[FS > 0 ? FS : 1], fbv = 0.0f;
+    if constexpr (FS > 0) {
+        const unsigned tile_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)s_ln;
+#pragma unroll
+        for (int k2 = 0; k2 < (2 * (32 + FS - 1) + 7) / 8; ++k2) {
+            const int it = wave + 8 * k2;  // wave-uniform
+            if (it < 2 * (32 + FS - 1)) {
+                const int wr = it >> 1, half = it & 1;
+                int gr = (int)t * 32 - FS / 2 + wr;
+                gr = gr < 0 ? 0 : (gr < (int)rows ? gr : (int)rows - 1);
+                rs_dma16(g.fs_x + (size_t)gr * (unsigned)g.fs_pitch + 256 * half + 4 * lane,
+                         __builtin_amdgcn_readfirstlane(tile_base + (unsigned)(wr * AS_LN_PITCH * 4 + 1024 * half)));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < FS; ++j) fw[j] = g.fs_w[threadIdx.x * FS + j];
+        fbv = (g.fs_b ? g.fs_b : g.fs_w)[threadIdx.x];
+    }
     // the column terms of the whole tile row: one column a thread (no branch around a load: a missing bias reads the scale and drops it)
     const int ccol = (int)threadIdx.x < n ? (int)threadIdx.x : n - 1;
     const int csum = epi.col_sums[ccol];
     const float wsv = epi.wscale[epi.wscale_len <= 1 ? 0 : ccol];
     const float bv = (epi.bias ? epi.bias : epi.wscale)[epi.bias ? ccol : 0];
+    float lgv = 0.0f, lbv = 0.0f;
+    if constexpr (LN) lgv = g.ln_g[threadIdx.x], lbv = g.ln_b[threadIdx.x];  // n == 512 == the workgroup's threads
     __builtin_amdgcn_sched_barrier(0);  // ... and the compiler keeps that order
     // ---- 2. the weights of column tiles 2 wave and 2 wave + 1 (a tile beyond the last one repeats it: multiplied, never stored)
     const int ct0 = TWO ? 2 * wave : (int)blockIdx.y * g.tpw + wave, ct1 = 2 * wave + 1;
@@ -902,6 +954,7 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
     s_colsum[threadIdx.x] = csum;
     s_ws[threadIdx.x] = wsv;
     s_bias[threadIdx.x] = epi.bias ? bv : -0.0f;  // x + (-0.0) == x for every x, the sign of zero included
+    if constexpr (LN) s_lng[threadIdx.x] = lgv, s_lnb[threadIdx.x] = lbv;
     // ---- 3. the parameters of the slices this wave's rows belong to (wave-uniform loop: one or two in practice), as qrows_kernel<0>
     QParams q = {1.0f, 0.0f, 1.0f, 0};
     {
@@ -966,6 +1019,40 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
         }
     }
     __syncthreads();
+    if constexpr (FS > 0) {
+        // ---- 4b. the memory block, column threadIdx.x, rows top to bottom, in place (dwconv1d_tlc_kernel's arithmetic: taps in
+        //          ascending order, taps outside the utterance skipped, FMA chain, bias afterwards, then + v[t])
+        const int ch = (int)threadIdx.x;
+        constexpr int PL = FS / 2;  // symmetric padding (the host checks): v[t] is window entry PL
+        float win[FS];
+#pragma unroll
+        for (int j = 0; j < FS - 1; ++j) win[j] = s_ln[j * AS_LN_PITCH + ch];
+        const int T = (int)mu;
+        int tt = (int)(((unsigned)t * 32u) % mu);  // time step of tile row 0 inside its utterance (uniform)
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            win[FS - 1] = s_ln[(r + FS - 1) * AS_LN_PITCH + ch];
+            float a = 0.0f;
+            if (tt >= PL && tt + (FS - 1 - PL) < T) {  // (uniform) every tap inside the utterance: 161 of 171 rows
+#pragma unroll
+                for (int j = 0; j < FS; ++j) a = fmaf_(win[j], fw[j], a);
+            } else {
+#pragma unroll
+                for (int j = 0; j < FS; ++j) {
+                    const int tq = tt - PL + j;
+                    const float f = fmaf_(win[j], fw[j], a);
+                    a = (tq >= 0 && tq < T) ? f : a;
+                }
+            }
+            if (g.fs_b) a = a + fbv;
+            a = a + win[PL];
+            s_ln[r * AS_LN_PITCH + ch] = a;
+#pragma unroll
+            for (int j = 0; j < FS - 1; ++j) win[j] = win[j + 1];
+            tt = tt + 1 == T ? 0 : tt + 1;
+        }
+        __syncthreads();
+    }
     // ---- 5. products: the tile's 16 fragments against both column tiles
     // (the accumulators start from the row / column terms, as in igemm_rs_kernel)
     if (!TWO && !live0) return;  // after the only barrier
@@ -997,8 +1084,10 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
         for (int gq = 0; gq < 4; ++gq) {
             const int c0 = ct0 * 32 + 4 * hv + 8 * gq, c1 = ct1 * 32 + 4 * hv + 8 * gq;
             const unsigned at0 = rowc * (unsigned)n + (unsigned)(c0 < n ? c0 : n - 4), at1 = rowc * (unsigned)n + (unsigned)(c1 < n ? c1 : n - 4);
-            ra1[gq] = *reinterpret_cast<const float4*>(epi.res1 + at0);
-            if (TWO) rb1[gq] = *reinterpret_cast<const float4*>(epi.res1 + at1);
+            if constexpr (FS == 0) {
+                ra1[gq] = *reinterpret_cast<const float4*>(epi.res1 + at0);
+                if (TWO) rb1[gq] = *reinterpret_cast<const float4*>(epi.res1 + at1);
+            }
             if (NRES > 1) {
                 ra2[gq] = *reinterpret_cast<const float4*>(epi.res2 + at0);
                 if (TWO) rb2[gq] = *reinterpret_cast<const float4*>(epi.res2 + at1);
@@ -1038,12 +1127,16 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
             o.z = val(acc[4 * gq + 2], ws.z, bs.z);
             o.w = val(acc[4 * gq + 3], ws.w, bs.w);
             if (NRES > 0) {
-                o.x = o.x + res1[gq].x, o.y = o.y + res1[gq].y, o.z = o.z + res1[gq].z, o.w = o.w + res1[gq].w;
+                float4 r1;
+                if constexpr (FS > 0) r1 = *reinterpret_cast<const float4*>(&s_ln[l31 * AS_LN_PITCH + ct * 32 + 4 * hv + 8 * gq]);  // the memory block, computed above
+                else r1 = res1[gq];
+                o.x = o.x + r1.x, o.y = o.y + r1.y, o.z = o.z + r1.z, o.w = o.w + r1.w;
                 if (NRES > 1) o.x = o.x + res2[gq].x, o.y = o.y + res2[gq].y, o.z = o.z + res2[gq].z, o.w = o.w + res2[gq].w;
             }
             const bool cok = ct * 32 + 4 * hv + 8 * gq < n;  // n % 4 == 0: a group of four columns is whole or absent
             const v4u bits = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
             __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, rok && cok ? (obase + 8u * gq) * 4u : 0xffffffffu, 0, 0);
+            if constexpr (LN) *reinterpret_cast<float4*>(&s_ln[l31 * AS_LN_PITCH + ct * 32 + 4 * hv + 8 * gq]) = o;
             if (rok && cok) {
                 smn = fminf(smn, fminf(fminf(o.x, o.y), fminf(o.z, o.w)));
                 smx = fmaxf(smx, fmaxf(fmaxf(o.x, o.y), fmaxf(o.z, o.w)));
@@ -1061,6 +1154,42 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
     };
     finish(acc0, ct0, ra1, ra2);
     if constexpr (TWO) finish(acc1, ct1, rb1, rb2);
+    if constexpr (LN) {
+        __syncthreads();
+        constexpr int NT = 16;
+        const float inv_n = 1.0f / 512.0f;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {  // half-wave (wave, hv) normalises tile rows 2 wave + hv and 16 + 2 wave + hv
+            const int r = 2 * wave + hv + 16 * rr;
+            const unsigned grow = (unsigned)t * 32u + (unsigned)r;
+            float v[NT];
+#pragma unroll
+            for (int c = 0; c < NT; ++c) v[c] = s_ln[r * AS_LN_PITCH + 32 * c + l31];
+            float sum, sumsq;
+            row_sums_reg<NT, true, true>(v, 512, l31, &sum, &sumsq);
+            const float mean = sum * inv_n;
+            const float var = sumsq * inv_n - mean * mean;
+            const float inv_std = 1.0f / sqrtf(var + g.ln_eps);
+            float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+            float* orow = g.ln_out + (size_t)(grow < rows ? grow : rows - 1u) * 512u;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                const float tv = (v[c] - mean) * inv_std;
+                const float o = fmaf_(tv, s_lng[32 * c + l31], s_lnb[32 * c + l31]);  // 512 % 8 == 0: every element is in the 8-wide body
+                if (grow < rows) orow[32 * c + l31] = o;
+                mn = o < mn ? o : mn;
+                mx = o > mx ? o : mx;
+            }
+            if (g.ln_rowstat) {
+                mn = group_allreduce32(mn, [](float cur, float a) { return a < cur ? a : cur; });
+                mx = group_allreduce32(mx, [](float cur, float a) { return a > cur ? a : cur; });
+                if (l31 == 0 && grow < rows) {
+                    g.ln_rowstat[2 * (size_t)grow] = mn;
+                    g.ln_rowstat[2 * (size_t)grow + 1] = mx;
+                }
+            }
+        }
+    }
 }
 
 }  // namespace

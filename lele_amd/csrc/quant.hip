@@ -20,6 +20,7 @@
 #include "common.h"
 #include "lane_ops.h"
 #include "gemm_small.h"
+#include "norm_core.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -1124,16 +1125,63 @@ bool as_fits(LeleCtx* ctx, int64_t rows, int64_t n, int64_t k, const void* dx) {
     return k == 512 && n <= 512 && n % 4 == 0 && n >= 4 && rows * n < (int64_t(1) << 30) && (((uintptr_t)dx) & 15) == 0 &&
            rows >= (int64_t)lab_int("LELE_HIP_IGEMM_AS_MIN_ROWS", 256);
 }
+// a batch: one workgroup a row tile, all (up to 16) column tiles, two a wave; few row tiles (one utterance: 16): 8 or 4 column
+// tiles a workgroup, one a wave, so that the grid still covers a good part of the chip
+bool as_two(LeleCtx* ctx, int64_t rows, int n) {
+    const int64_t nrt = (rows + 31) / 32;
+    return nrt * 3 >= (int64_t)ctx->num_cus || (n + 31) / 32 <= 4 || lab_int("LELE_HIP_IGEMM_AS_TPW", 0) == 16;
+}
+struct AsLn {  // the LayerNorm behind the projection, in the same launch (n == 512, whole rows in a workgroup)
+    const float* g = nullptr;
+    const float* b = nullptr;
+    float eps = 0.0f;
+    float* out = nullptr;
+    float* rowstat = nullptr;
+    // + the FSMN memory block as res1, computed in the kernel (k = 11)
+    const float* fs_x = nullptr;
+    int fs_pitch = 0;
+    const float* fs_w = nullptr;
+    const float* fs_b = nullptr;
+    int fs_pl = 0;
+};
 int launch_as(LeleCtx* ctx, const float* x, const int8_t* wf, int64_t rows, int n, const float* partial, int nblk, QParams* prm,
-              const IgemmEpi& epi) {
+              const IgemmEpi& epi, const AsLn* ln = nullptr) {
     AsArgs g{x, wf, (unsigned)rows, n, (n + 31) / 32, partial, nblk, prm, 16};
     const int64_t nrt = (rows + 31) / 32;
-    // a batch: one workgroup a row tile, all (up to 16) column tiles, two a wave; few row tiles (one utterance: 16): 8 or 4 column
-    // tiles a workgroup, one a wave, so that the grid still covers a good part of the chip
-    const bool two = nrt * 3 >= (int64_t)ctx->num_cus || g.nct <= 4 || lab_int("LELE_HIP_IGEMM_AS_TPW", 0) == 16;
+    const bool two = as_two(ctx, rows, n);
     if (!two) g.tpw = lab_int("LELE_HIP_IGEMM_AS_TPW", nrt * 6 >= (int64_t)ctx->num_cus ? 8 : 4);
     const dim3 grid((unsigned)nrt, two ? 1u : (unsigned)((g.nct + g.tpw - 1) / g.tpw));
     const int nres = epi.res1 ? (epi.res2 ? 2 : 1) : 0;
+    if (ln) {
+        LELE_REQUIRE(two && n == 512 && !epi.relu, "launch_as: the LayerNorm epilogue needs whole 512-wide rows in a workgroup");
+        g.ln_g = ln->g, g.ln_b = ln->b, g.ln_eps = ln->eps, g.ln_out = ln->out, g.ln_rowstat = ln->rowstat;
+#define LELE_AS_LN(NRES_)                                                                              \
+    do {                                                                                               \
+        auto kern = igemm_as_kernel<NRES_, false, true, true>;                                          \
+        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), AS_LN_LDS));                 \
+        hipLaunchKernelGGL(kern, grid, dim3(512), AS_LN_LDS, ctx->stream, g, epi);                      \
+    } while (0)
+        if (ln->fs_x) {   // res1 is the memory block of ln->fs_x (epi.res1 is not read), epi.res2 the optional second residual
+            g.fs_x = ln->fs_x, g.fs_pitch = ln->fs_pitch, g.fs_w = ln->fs_w, g.fs_b = ln->fs_b;
+#define LELE_AS_FS(NRES_)                                                                              \
+    do {                                                                                               \
+        auto kern = igemm_as_kernel<NRES_, false, true, true, 11>;                                      \
+        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), as_fs_lds(11)));             \
+        hipLaunchKernelGGL(kern, grid, dim3(512), as_fs_lds(11), ctx->stream, g, epi);                  \
+    } while (0)
+            if (epi.res2) LELE_AS_FS(2);
+            else LELE_AS_FS(1);
+#undef LELE_AS_FS
+            LELE_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+        if (nres == 0) LELE_AS_LN(0);
+        else if (nres == 1) LELE_AS_LN(1);
+        else LELE_AS_LN(2);
+#undef LELE_AS_LN
+        LELE_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
 #define LELE_AS(NRES_, RELU_)                                                                                     \
     do {                                                                                                          \
         if (two) hipLaunchKernelGGL((igemm_as_kernel<NRES_, RELU_, true>), grid, dim3(512), 0, ctx->stream, g, epi);   \
@@ -1250,9 +1298,29 @@ int packed_weights_of(LeleCtx* ctx, const LeleTensor* weight_int8, int k, int n,
 
 extern "C" {
 
+// the LayerNorm epilogue of igemm_as_kernel: whole 512-wide rows in a workgroup, no ReLU, f32 scale / bias of at least 512 values
+static bool as_ln_ok(LeleCtx* ctx, int64_t rows, int64_t n, int apply_relu, const LeleTensor* g, const LeleTensor* b) {
+    return env_int("LELE_HIP_LN_FUSED", 1) != 0 && n == 512 && !apply_relu && as_two(ctx, rows, (int)n) && g->dtype == LELE_F32 &&
+           b->dtype == LELE_F32 && numel(g) >= 512 && numel(b) >= 512;
+}
+// a LayerNorm over the last axis that the caller wants behind the linear: done in the GEMM's launch where a workgroup holds whole
+// rows of the result (`done` says whether it was; the caller runs lele_hip_layer_norm otherwise)
+struct LnReq {
+    const LeleTensor* g;
+    const LeleTensor* b;
+    float eps;
+    LeleBuf* out;
+    bool done = false;
+    // optionally the FSMN memory block as the first residual (lele_hip_sanm_out_block): only honoured together with the LayerNorm,
+    // `done` then covers both
+    const LeleTensor* fs_x = nullptr;   // [B, T, P]
+    const LeleTensor* fs_w = nullptr;   // [512, 1, 11]
+    const LeleTensor* fs_b = nullptr;
+    int64_t fs_pl = 0, fs_off = 0;
+};
 static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8, const LeleTensor* weight_scale,
                     const LeleTensor* weight_zero, const LeleTensor* bias, int apply_relu, const LeleTensor* res1,
-                    const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+                    const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank, LnReq* ln = nullptr) {
     LELE_REQUIRE(ctx && input && weight_int8 && weight_scale && out, "fused_quantized_linear: NULL argument");
     LELE_REQUIRE(input->rank >= 2 && weight_int8->rank >= 2, "fused_quantized_linear: rank >= 2 required");
     LELE_HIP_CHECK(hipSetDevice(ctx->device));
@@ -1292,6 +1360,8 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
     if (!partial) LELE_TRY(launch_range(ctx, (const float*)dx, batch, m * k, (QParams*)prm, nullptr, nullptr, &partial, &nblk));
     LELE_TRY(qprof_mark(ctx, 1));
 
+    LELE_REQUIRE(!(ln && ln->fs_x) || (as_fits(ctx, rows, n, k, dx) && rs_aligned(res2) && (((uintptr_t)out->data) & 15) == 0),
+                 "internal: the memory block was requested on a route that cannot compute it");
     // ---- register-stationary route (igemm_rs.h): rows -> i8 in fragment order, then the barrier-free GEMM
     if (const int kprs = rs_kp(k); rs_fits(ctx, rows, n, kprs) && rs_aligned(res1) && rs_aligned(res2) && (((uintptr_t)out->data) & 15) == 0) {
         FragW fw;
@@ -1342,7 +1412,37 @@ static int fql_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* wei
             LELE_TRY(out->reserve_rowstat(nstat));
             if ((size_t)nstat <= out->rowstat_cap) epi.blockstat = out->rowstat;
         }
-        LELE_TRY(launch_as(ctx, (const float*)dx, fw.wf, rows, (int)n, partial, nblk, (QParams*)prm, epi));
+        AsLn aln;
+        const bool fuse_ln = ln && as_ln_ok(ctx, rows, n, apply_relu, ln->g, ln->b) && ln->out != out;
+        LELE_REQUIRE(!(ln && ln->fs_x) || fuse_ln, "internal: the memory block was requested on a route that cannot compute it");
+        if (fuse_ln && ln->fs_x) {
+            const void *fx = nullptr, *fwp = nullptr, *fbp = nullptr;
+            LELE_TRY(ctx->dev_ptr(ln->fs_x, &fx));
+            LELE_TRY(ctx->dev_ptr(ln->fs_w, &fwp));
+            if (ln->fs_b) LELE_TRY(ctx->dev_ptr(ln->fs_b, &fbp));
+            aln.fs_x = (const float*)fx + ln->fs_off, aln.fs_pitch = (int)ln->fs_x->shape[2], aln.fs_w = (const float*)fwp;
+            aln.fs_b = (const float*)fbp, aln.fs_pl = (int)ln->fs_pl;
+        }
+        if (fuse_ln) {
+            const void *dg = nullptr, *dbeta = nullptr;
+            LELE_TRY(ctx->dev_ptr(ln->g, &dg));
+            LELE_TRY(ctx->dev_ptr(ln->b, &dbeta));
+            LELE_TRY(ln->out->reserve((size_t)rows * n * 4));
+            LELE_TRY(ln->out->reserve_rowstat(rows));
+            aln.g = (const float*)dg, aln.b = (const float*)dbeta, aln.eps = ln->eps, aln.out = (float*)ln->out->data;
+            aln.rowstat = (size_t)rows <= ln->out->rowstat_cap ? ln->out->rowstat : nullptr;
+            epi.out = (float*)out->data;  // (a first reserve of ln->out cannot move `out`: they are different buffers)
+        }
+        LELE_TRY(launch_as(ctx, (const float*)dx, fw.wf, rows, (int)n, partial, nblk, (QParams*)prm, epi, fuse_ln ? &aln : nullptr));
+        if (fuse_ln) {
+            ln->done = true;
+            if (aln.rowstat) {   // as lele_hip_layer_norm leaves them: one {min, max} pair per row
+                ln->out->rowstat_rows = rows;
+                ln->out->rowstat_len = n;
+                ln->out->rowstat_kind = 0;
+                ln->out->rowstat_valid = true;
+            }
+        }
         LELE_TRY(qprof_mark(ctx, 3));
         if (epi.blockstat) {
             out->rowstat_rows = nstat;
@@ -1440,6 +1540,109 @@ int lele_hip_fused_quantized_linear_residual(LeleCtx* ctx, const LeleTensor* inp
         cur = dst;
     }
     return set_shape_v(out_shape, out_rank, std::vector<int64_t>(sh, sh + r));
+}
+
+int lele_hip_layer_norm(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, const LeleTensor* bias, int32_t axis, float epsilon,
+                        LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+
+/* x1 = fused_quantized_linear[_residual](input, W.., relu, res1, res2);  x1n = layer_norm(x1, ln_scale, ln_bias, axis = -1, epsilon)
+ * -- a projection, the Adds behind it and the LayerNorm that reads their sum (norm.rs:226 -> avx/norm.rs:10-133), bit for bit the
+ * two calls.  Where a workgroup of the GEMM holds whole rows of the result (K = 512, N = 512 over a batch: igemm_as_kernel) the
+ * normalisation runs in its epilogue; everywhere else the two calls are issued here.  res1 may be NULL (then res2 must be). */
+int lele_hip_fused_quantized_linear_residual_ln(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8,
+                                                const LeleTensor* weight_scale, const LeleTensor* weight_zero, const LeleTensor* bias,
+                                                int apply_relu, const LeleTensor* res1, const LeleTensor* res2, const LeleTensor* ln_scale,
+                                                const LeleTensor* ln_bias, float epsilon, LeleBuf* out, LeleBuf* ln_out, int64_t* out_shape,
+                                                int32_t* out_rank) {
+    LELE_REQUIRE(ctx && input && weight_int8 && ln_scale && ln_bias && out && ln_out, "fused_quantized_linear_residual_ln: NULL argument");
+    LELE_REQUIRE(out != ln_out, "fused_quantized_linear_residual_ln: the sum and its normalised form need two buffers");
+    LELE_REQUIRE(res1 || !res2, "fused_quantized_linear_residual_ln: res2 without res1");
+    LELE_REQUIRE(input->rank >= 2 && weight_int8->rank >= 2, "fused_quantized_linear: rank >= 2 required");
+    LnReq ln{ln_scale, ln_bias, epsilon, ln_out};
+    int64_t sh[LELE_MAX_RANK];
+    int32_t r = 0;
+    bool direct = true;   // same-shape residuals: the call that may normalise in its epilogue
+    if (res1) {
+        int64_t on = weight_int8->shape[weight_int8->rank - 1];
+        for (int i = 0; i + 1 < input->rank; ++i) on *= input->shape[i];
+        auto same_shape = [&](const LeleTensor* t) {
+            if (t->dtype != LELE_F32 || numel(t) != on || t->rank > input->rank) return false;
+            for (int d = 0; d < t->rank; ++d)
+                if (t->shape[t->rank - 1 - d] != (d == 0 ? weight_int8->shape[weight_int8->rank - 1] : input->shape[input->rank - 1 - d])) return false;
+            return true;
+        };
+        direct = same_shape(res1) && (!res2 || same_shape(res2));
+    }
+    if (direct) LELE_TRY(fql_impl(ctx, input, weight_int8, weight_scale, weight_zero, bias, apply_relu, res1, res2, out, sh, &r, &ln));
+    else LELE_TRY(lele_hip_fused_quantized_linear_residual(ctx, input, weight_int8, weight_scale, weight_zero, bias, apply_relu, res1, res2, out, sh, &r));
+    if (!ln.done) {
+        LeleTensor x1{out->data, sh, r, LELE_F32, LELE_MEM_DEVICE};
+        int64_t sh2[LELE_MAX_RANK];
+        int32_t r2 = 0;
+        LELE_TRY(lele_hip_layer_norm(ctx, &x1, ln_scale, ln_bias, -1, epsilon, ln_out, sh2, &r2));
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(sh, sh + r));
+}
+
+int lele_hip_depthwise_conv1d_tlc(LeleCtx* ctx, const LeleTensor* x, int64_t x_offset, const LeleTensor* w, const LeleTensor* bias,
+                                  int64_t pad_left, int64_t pad_right, int relu, int add_input, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+
+/* The output half of a SAN-M attention block (SenseVoice's encoder layer) as ONE call:
+ *   mem = depthwise_conv1d_tlc(v_src, fsmn_w, fsmn_bias, x_offset, pad_left, pad_right, relu = 0, add_input = 1)     (FSMN memory + v)
+ *   out = fused_quantized_linear_residual(input, W.., apply_relu, mem, res2);  ln_out = layer_norm(out, ln_scale, ln_bias, -1, epsilon)
+ * bit for bit those three calls.  With K = N = 512 over a batch of utterances the GEMM's workgroup (one 32-row tile, all columns)
+ * computes the memory block of its rows from a (32 + k - 1)-row window of v in LDS and normalises its rows in the epilogue:
+ * three launches become one; every other shape issues the three calls. */
+int lele_hip_sanm_out_block(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* weight_int8, const LeleTensor* weight_scale,
+                            const LeleTensor* weight_zero, const LeleTensor* bias, int apply_relu, const LeleTensor* v_src,
+                            const LeleTensor* fsmn_w, const LeleTensor* fsmn_bias, int64_t x_offset, int64_t pad_left, int64_t pad_right,
+                            const LeleTensor* res2, const LeleTensor* ln_scale, const LeleTensor* ln_bias, float epsilon, LeleBuf* out,
+                            LeleBuf* ln_out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && input && weight_int8 && v_src && fsmn_w && ln_scale && ln_bias && out && ln_out, "sanm_out_block: NULL argument");
+    LELE_REQUIRE(out != ln_out, "sanm_out_block: the sum and its normalised form need two buffers");
+    LELE_REQUIRE(input->rank >= 2 && weight_int8->rank >= 2, "fused_quantized_linear: rank >= 2 required");
+    const int64_t m = input->shape[input->rank - 2], k = input->shape[input->rank - 1], n = weight_int8->shape[weight_int8->rank - 1];
+    int64_t batch = 1;
+    for (int i = 0; i + 2 < input->rank; ++i) batch *= input->shape[i];
+    const int64_t rows = batch * m;
+    // the one-launch form: the projection on igemm_as_kernel with whole rows, v_src [B, T, P] with B * T the projection's rows and T its
+    // slice length, 512 channels from a 16-byte aligned offset, k = 11 with the output as long as the input, res2 of the result's shape
+    auto aligned16 = [](const LeleTensor* t) { return t->mem != LELE_MEM_DEVICE || (((uintptr_t)t->data) & 15) == 0; };
+    bool fused = env_int("LELE_HIP_FSMN_FUSED", 1) != 0 && weight_int8->shape[weight_int8->rank - 2] == k && rows > 0 &&
+                 as_fits(ctx, rows, n, k, input->mem == LELE_MEM_DEVICE ? input->data : nullptr) && !rs_fits(ctx, rows, n, rs_kp(k)) &&
+                 as_ln_ok(ctx, rows, n, apply_relu, ln_scale, ln_bias) && v_src->rank == 3 && v_src->dtype == LELE_F32 && fsmn_w->rank == 3 &&
+                 fsmn_w->dtype == LELE_F32 && fsmn_w->shape[0] == 512 && fsmn_w->shape[1] == 1 && fsmn_w->shape[2] == 11 &&
+                 v_src->shape[0] * v_src->shape[1] == rows && v_src->shape[1] == m && m >= 32 && x_offset >= 0 && x_offset % 4 == 0 &&
+                 x_offset + 512 <= v_src->shape[2] && v_src->shape[2] % 4 == 0 && aligned16(v_src) && pad_left == 5 && pad_right == 5 && (!fsmn_bias || (fsmn_bias->dtype == LELE_F32 && numel(fsmn_bias) >= 512)) &&
+                 v_src->shape[2] * rows < (int64_t(1) << 30);
+    if (fused && res2) {
+        fused = res2->dtype == LELE_F32 && numel(res2) == rows * n && res2->rank <= input->rank && aligned16(res2);
+        for (int d = 0; fused && d < res2->rank; ++d)
+            fused = res2->shape[res2->rank - 1 - d] == (d == 0 ? n : input->shape[input->rank - 1 - d]);
+    }
+    int64_t sh[LELE_MAX_RANK];
+    int32_t r = 0;
+    if (fused) {
+        LELE_TRY(out->reserve((size_t)rows * n * 4));
+        fused = (((uintptr_t)out->data) & 15) == 0;
+    }
+    if (fused) {
+        LnReq ln{ln_scale, ln_bias, epsilon, ln_out};
+        ln.fs_x = v_src, ln.fs_w = fsmn_w, ln.fs_b = fsmn_bias, ln.fs_pl = pad_left, ln.fs_off = x_offset;
+        // res1 of the kernel is the memory block it computes; the caller's res2 stays the second residual.  fql_impl's NRES counts
+        // operands: hand it `input` as a stand-in for res1 (never read in this form)
+        LELE_TRY(fql_impl(ctx, input, weight_int8, weight_scale, weight_zero, bias, apply_relu, input, res2, out, sh, &r, &ln));
+        LELE_REQUIRE(ln.done, "internal: sanm_out_block's one-launch form did not run");
+        return set_shape_v(out_shape, out_rank, std::vector<int64_t>(sh, sh + r));
+    }
+    LeleBuf* mem = nullptr;
+    LELE_TRY(ctx->tmp_buf(2, &mem));
+    int64_t msh[LELE_MAX_RANK];
+    int32_t mr = 0;
+    LELE_TRY(lele_hip_depthwise_conv1d_tlc(ctx, v_src, x_offset, fsmn_w, fsmn_bias, pad_left, pad_right, 0, 1, mem, msh, &mr));
+    LeleTensor mt{mem->data, msh, mr, LELE_F32, LELE_MEM_DEVICE};
+    return lele_hip_fused_quantized_linear_residual_ln(ctx, input, weight_int8, weight_scale, weight_zero, bias, apply_relu, &mt, res2, ln_scale,
+                                                       ln_bias, epsilon, out, ln_out, out_shape, out_rank);
 }
 
 /* Two quantised linears with a ReLU between them (the feed-forward block of a transformer layer):

@@ -782,6 +782,34 @@ inline TensorView fused_quantized_linear_residual(const TensorView& input, const
     check(lele_hip_fused_quantized_linear_residual(ctx(), &ti, &tw, &ts, &tz, ob.p, apply_relu, &t1, o2.p, out.raw(), sh.dims, &sh.rank));
     LELE_RET(out, LELE_F32);
 }
+// (x1, layer_norm(x1, ln_scale, ln_bias, -1, epsilon)) with x1 = fused_quantized_linear[_residual](..., res1, res2)
+struct SumAndNorm {
+    TensorView sum, norm;
+};
+inline SumAndNorm fused_quantized_linear_residual_ln(const TensorView& input, const TensorView& weight_int8, const TensorView& weight_scale,
+                                                     const TensorView& weight_zero, const TensorView* bias, bool apply_relu, const TensorView* res1,
+                                                     const TensorView* res2, const TensorView& ln_scale, const TensorView& ln_bias, float epsilon,
+                                                     Buffer& out, Buffer& ln_out) {
+    Shape sh;
+    LeleTensor ti = input.c(), tw = weight_int8.c(), ts = weight_scale.c(), tz = weight_zero.c(), tg = ln_scale.c(), tb = ln_bias.c();
+    Opt ob(bias), o1(res1), o2(res2);
+    check(lele_hip_fused_quantized_linear_residual_ln(ctx(), &ti, &tw, &ts, &tz, ob.p, apply_relu, o1.p, o2.p, &tg, &tb, epsilon, out.raw(),
+                                                      ln_out.raw(), sh.dims, &sh.rank));
+    return {TensorView::from_device(out, sh.vec(), LELE_F32), TensorView::from_device(ln_out, sh.vec(), LELE_F32)};
+}
+// the output half of a SAN-M attention block: FSMN memory block of v_src as the first residual, projection, Adds, LayerNorm
+inline SumAndNorm sanm_out_block(const TensorView& input, const TensorView& weight_int8, const TensorView& weight_scale, const TensorView& weight_zero,
+                                 const TensorView* bias, bool apply_relu, const TensorView& v_src, const TensorView& fsmn_w, const TensorView* fsmn_bias,
+                                 int64_t x_offset, int64_t pad_left, int64_t pad_right, const TensorView* res2, const TensorView& ln_scale,
+                                 const TensorView& ln_bias, float epsilon, Buffer& out, Buffer& ln_out) {
+    Shape sh;
+    LeleTensor ti = input.c(), tw = weight_int8.c(), ts = weight_scale.c(), tz = weight_zero.c(), tv = v_src.c(), tf = fsmn_w.c(), tg = ln_scale.c(),
+               tb = ln_bias.c();
+    Opt ob(bias), ofb(fsmn_bias), o2(res2);
+    check(lele_hip_sanm_out_block(ctx(), &ti, &tw, &ts, &tz, ob.p, apply_relu, &tv, &tf, ofb.p, x_offset, pad_left, pad_right, o2.p, &tg, &tb, epsilon,
+                                  out.raw(), ln_out.raw(), sh.dims, &sh.rank));
+    return {TensorView::from_device(out, sh.vec(), LELE_F32), TensorView::from_device(ln_out, sh.vec(), LELE_F32)};
+}
 // fused_quantized_linear[_residual](fused_quantized_linear(input, w1.., true), w2.., apply_relu2, res1, res2)
 inline TensorView fused_ffn_quantized(const TensorView& input, const TensorView& w1_int8, const TensorView& w1_scale, const TensorView& w1_zero,
                                       const TensorView* b1, const TensorView& w2_int8, const TensorView& w2_scale, const TensorView& w2_zero,

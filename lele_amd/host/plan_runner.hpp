@@ -982,6 +982,19 @@ class Runner {
         if (fn == "fused_quantized_linear_residual")
             return set(st, 0, K::fused_quantized_linear_residual(tensor(a[0]), tensor(a[1]), tensor(a[2]), tensor(a[3]), opt(a[4], h0), boolean(a[5]),
                                                                  tensor(a[6]), opt(a[7], h1), o));
+        if (fn == "fused_quantized_linear_residual_ln") {
+            auto r = K::fused_quantized_linear_residual_ln(tensor(a[0]), tensor(a[1]), tensor(a[2]), tensor(a[3]), opt(a[4], h0), boolean(a[5]), opt(a[6], h1),
+                                                           opt(a[7], h2), tensor(a[8]), tensor(a[9]), number(a[10]), o, slot(st, 1));
+            set(st, 0, r.sum), set(st, 1, r.norm);
+            return;
+        }
+        if (fn == "sanm_out_block") {
+            auto r = K::sanm_out_block(tensor(a[0]), tensor(a[1]), tensor(a[2]), tensor(a[3]), opt(a[4], h0), boolean(a[5]), tensor(a[6]), tensor(a[7]),
+                                       opt(a[8], h1), integer(a[9]), integer(a[10]), integer(a[11]), opt(a[12], h2), tensor(a[13]), tensor(a[14]),
+                                       number(a[15]), o, slot(st, 1));
+            set(st, 0, r.sum), set(st, 1, r.norm);
+            return;
+        }
         if (fn == "fused_ffn_quantized")
             return set(st, 0, K::fused_ffn_quantized(tensor(a[0]), tensor(a[1]), tensor(a[2]), tensor(a[3]), opt(a[4], h0), tensor(a[5]), tensor(a[6]),
                                                      tensor(a[7]), opt(a[8], h1), boolean(a[9]), opt(a[10], h2), opt(a[11], h3), o));

@@ -1060,6 +1060,37 @@ def fused_quantized_linear_residual(input, weight_int8, weight_scale, weight_zer
     return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
 
 
+def fused_quantized_linear_residual_ln(input, weight_int8, weight_scale, weight_zero, bias, apply_relu, res1, res2, ln_scale, ln_bias,
+                                       epsilon, outs=None, ctx=None):
+    """(x1, layer_norm(x1, ln_scale, ln_bias, -1, epsilon)) with x1 = fused_quantized_linear[_residual](...): the projection, the Adds
+    behind it and the LayerNorm that reads their sum as one call (bit for bit the two calls)"""
+    ctx = _ctx(ctx)
+    keep = []
+    outs = list(outs) if outs else [ctx.buf(), ctx.buf()]
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_fused_quantized_linear_residual_ln(
+        ctx._h, _t(input, keep), _t(weight_int8, keep), _t(weight_scale, keep), _t(weight_zero, keep), _t(bias, keep),
+        C.c_int(int(apply_relu)), _t(res1, keep), _t(res2, keep), _t(ln_scale, keep), _t(ln_bias, keep), C.c_float(float(epsilon)),
+        outs[0]._h, outs[1]._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(outs[0], sh.get(), np.float32)), TensorView(_lib.DevTensor(outs[1], sh.get(), np.float32))
+
+
+def sanm_out_block(input, weight_int8, weight_scale, weight_zero, bias, apply_relu, v_src, fsmn_w, fsmn_bias, x_offset, pad_left, pad_right,
+                   res2, ln_scale, ln_bias, epsilon, outs=None, ctx=None):
+    """(x1, layer_norm(x1)) with x1 = fused_quantized_linear_residual(input, W.., relu, depthwise_conv1d_tlc(v_src, fsmn_w, fsmn_bias,
+    pad_left, pad_right, False, x_offset, add_input=True), res2): the output half of a SAN-M attention block as one call"""
+    ctx = _ctx(ctx)
+    keep = []
+    outs = list(outs) if outs else [ctx.buf(), ctx.buf()]
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_sanm_out_block(
+        ctx._h, _t(input, keep), _t(weight_int8, keep), _t(weight_scale, keep), _t(weight_zero, keep), _t(bias, keep),
+        C.c_int(int(apply_relu)), _t(v_src, keep), _t(fsmn_w, keep), _t(fsmn_bias, keep), C.c_int64(int(x_offset)), C.c_int64(int(pad_left)),
+        C.c_int64(int(pad_right)), _t(res2, keep), _t(ln_scale, keep), _t(ln_bias, keep), C.c_float(float(epsilon)), outs[0]._h, outs[1]._h,
+        sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(outs[0], sh.get(), np.float32)), TensorView(_lib.DevTensor(outs[1], sh.get(), np.float32))
+
+
 def fused_ffn_quantized(input, w1_int8, w1_scale, w1_zero, b1, w2_int8, w2_scale, w2_zero, b2, apply_relu2=False, res1=None, res2=None,
                         out=None, ctx=None):
     """fused_quantized_linear[_residual](fused_quantized_linear(input, w1.., True), w2.., apply_relu2, res1, res2), bit for bit: a

@@ -744,7 +744,7 @@ class Runner:
             return list(f(pos[0], pos[1], pos[2], outputs=bufs, ctx=ctx))
         if fn == "topk":
             return f(pos[0], pos[1], pos[2], pos[3], pos[4], out_values=bufs[0], out_indices=bufs[1], ctx=ctx)
-        if fn in ("lstm", "gru", "dynamic_quantize_linear"):
+        if fn in ("lstm", "gru", "dynamic_quantize_linear", "fused_quantized_linear_residual_ln", "sanm_out_block", "fused_ffn_quantized_ln"):
             return f(*pos, outs=bufs, ctx=ctx)
         if fn in ("reshape", "flatten", "unsqueeze", "squeeze", "identity"):
             return f(*pos)

@@ -238,6 +238,41 @@ class PlanRef:
             hi = npref.slice_(x, [int(p[3][0])], [int(p[3][1])], [axis], [1])
             s_ = npref.binary("add", npref.binary("pow", lo, f32(p[4])), npref.binary("pow", hi, f32(p[5])))
             return np.sqrt(s_.astype(np.float32))
+        # ---- the dynamically quantised linears and the fused forms this repository's compiler builds around them (lower.py fold_*):
+        #      each runs as the operator sequence it stands for
+        if fn == "fused_quantized_linear":       # quantization.rs:77
+            return O.fused_quantized_linear(f32(p[0]), p[1], p[2], p[3], p[4], bool(p[5]))
+        if fn in ("fused_quantized_linear_residual", "fused_quantized_linear_residual_ln"):
+            y = npref.binary("add", O.fused_quantized_linear(f32(p[0]), p[1], p[2], p[3], p[4], bool(p[5])), f32(p[6]))
+            if p[7] is not None:
+                y = npref.binary("add", y, f32(p[7]))
+            return y if fn.endswith("residual") else [y, O.layer_norm(y, p[8], p[9], -1, float(p[10]))]
+        if fn == "depthwise_conv1d_tlc":         # Transpose(0,2,1) -> conv1d(group = C) -> Transpose(0,2,1) [-> Add(input)]
+            return self._tlc(f32(p[0]), p[1], p[2], int(p[3]), int(p[4]), bool(p[5]), int(p[6]), bool(p[7]))
+        if fn == "sanm_out_block":               # memory block -> projection + Adds -> LayerNorm
+            mem = self._tlc(f32(p[6]), p[7], p[8], int(p[10]), int(p[11]), False, int(p[9]), True)
+            y = npref.binary("add", O.fused_quantized_linear(f32(p[0]), p[1], p[2], p[3], p[4], bool(p[5])), mem)
+            if p[12] is not None:
+                y = npref.binary("add", y, f32(p[12]))
+            return [y, O.layer_norm(y, p[13], p[14], -1, float(p[15]))]
+        if fn in ("fused_ffn_quantized", "fused_ffn_quantized_ln"):
+            h = O.fused_quantized_linear(f32(p[0]), p[1], p[2], p[3], p[4], True)
+            y = O.fused_quantized_linear(h, p[5], p[6], p[7], p[8], bool(p[9]))
+            for r in p[10:12]:
+                if r is not None:
+                    y = npref.binary("add", y, f32(r))
+            return y if fn.endswith("quantized") else [y, O.layer_norm(y, p[12], p[13], -1, float(p[14]))]
+        if fn == "attention_view":               # matmul_view -> softmax_scaled -> matmul_view (k-ordered f32 sums: the device replica's order)
+            q, k, v = _apply_chain(f32(p[0]), p[1]), _apply_chain(f32(p[2]), p[3]), _apply_chain(f32(p[4]), p[5])
+            sc = O.matmul(q, k, acc32=self.attention_acc32)
+            if p[6] is not None:
+                sc = npref.binary("mul", sc, f32(p[6]))
+            y = O.matmul(O.softmax(sc, -1), v, acc32=self.attention_acc32)
+            if len(p) > 7 and p[7]:
+                y = np.ascontiguousarray(np.transpose(y, list(p[7])))
+            if len(p) > 8 and p[8] is not None:
+                y = y.reshape(_resolve_shape(y.shape, p[8]))
+            return y
         if fn == "where_op":
             return npref.where_op(p[0], p[1], p[2])
         if fn == "clip":
@@ -245,6 +280,16 @@ class PlanRef:
             hi = None if p[2] is None else float(np.asarray(p[2]).reshape(-1)[0])
             return npref.clip(p[0], lo, hi)
         raise NotImplementedError("oracle/plan_ref.py: no restatement bound to plan function %r" % fn)
+
+    attention_acc32 = True   # the two attention products summed k-ordered in f32 (faer's order is unpinned); False: f64
+
+    @staticmethod
+    def _tlc(x, w, bias, pl, pr, relu, x_offset, add_input):
+        c = int(np.shape(w)[0])
+        v = np.ascontiguousarray(x[..., x_offset:x_offset + c])
+        y = O.conv1d(np.ascontiguousarray(v.transpose(0, 2, 1)), w, bias, [1], c, [pl, pr], [1], relu)
+        y = np.ascontiguousarray(y.transpose(0, 2, 1))
+        return npref.binary("add", y, v) if add_input else y
 
     # ------------------------------------------------------------------------------------------------ the statement loop
     def run(self, inputs):

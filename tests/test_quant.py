@@ -482,3 +482,92 @@ def test_prepared_weight_entry_points(ctx, orc):
         assert np.array_equal(Kk.fused_dq_gemm_prepared(x, pw, 128, ws, bias, False, ctx=ctx).numpy(),
                               orc.fused_quantized_linear(x, wu8.astype(np.float32), ws, [128.0], bias, False))
         pw.close()
+
+
+def _ln_params(rng, n=512):
+    from lele_amd._lib import Weight
+    return Weight((1 + 0.1 * rng.standard_normal(n)).astype(np.float32)), Weight((0.1 * rng.standard_normal(n)).astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,m,n,nres", [
+    (32, 171, 512, 2),    # one configs[3] shard: the LayerNorm runs in igemm_as_kernel's epilogue
+    (32, 171, 512, 1), (32, 171, 512, 0),
+    (3, 1000, 512, 2),    # slices that straddle row tiles, a ragged last tile (3000 rows = 93.75 tiles)
+    (86, 32, 512, 1),     # the smallest batch whose row tiles fill the chip: every tile is one slice
+    (8, 171, 512, 2),     # too few row tiles for whole rows per workgroup: the two calls
+    (1, 504, 512, 2),     # one utterance: the two calls
+    (32, 171, 256, 2),    # N != 512: the two calls
+])
+def test_projection_residuals_and_layer_norm_as_one_call(ctx, orc, b, m, n, nres):
+    """lele_hip_fused_quantized_linear_residual_ln == fused_quantized_linear_residual -> layer_norm, bit for bit, on the route that
+    normalises in the GEMM's epilogue and on every route that issues the two calls; the {min, max} pairs left beside the normalised
+    result feed the next quantised linear exactly as the LayerNorm kernel's do; one case against the oracle's own sequence."""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    rng = np.random.default_rng(b * 1000 + m + n + nres)
+    x = (rng.standard_normal((b, m, 512)) * rng.uniform(0.3, 3.0, (b, 1, 1))).astype(np.float32)
+    g0, b0 = _ln_params(rng)
+    xn = K.layer_norm(ctx.buf().upload(x), g0, b0, -1, 1e-5, out=ctx.buf(), ctx=ctx)
+    w, ws, bias = _weights(rng, 512, n)
+    W = (Weight(w), Weight(ws), Weight(np.array([128.0], np.float32)), Weight(bias))
+    r1 = rng.standard_normal((b, m, n)).astype(np.float32) if nres >= 1 else None
+    r2 = rng.standard_normal((b, m, n)).astype(np.float32) if nres >= 2 else None
+    g1, b1 = _ln_params(rng, n)
+    lin = K.fused_quantized_linear_residual(xn, *W, False, r1, r2, ctx=ctx) if nres else K.fused_quantized_linear(xn, *W, False, ctx=ctx)
+    want = lin.numpy().copy(), K.layer_norm(lin, g1, b1, -1, 1e-5, ctx=ctx).numpy().copy()
+    for rep in range(3):      # repeated: a kernel that read LDS before its loads had landed would not repeat itself
+        got = K.fused_quantized_linear_residual_ln(xn, *W, False, r1, r2, g1, b1, 1e-5, ctx=ctx)
+        assert np.array_equal(got[0].numpy(), want[0]) and np.array_equal(got[1].numpy(), want[1]), (b, m, n, nres, rep)
+    w2, ws2, bias2 = _weights(rng, n, 1024)
+    W2 = (Weight(w2), Weight(ws2), Weight(np.array([128.0], np.float32)), Weight(bias2))
+    seq_next = K.fused_quantized_linear(K.layer_norm(lin, g1, b1, -1, 1e-5, ctx=ctx), *W2, True, ctx=ctx).numpy()
+    assert np.array_equal(K.fused_quantized_linear(got[1], *W2, True, ctx=ctx).numpy(), seq_next)
+    if (b, m, nres) == (3, 1000, 2):
+        o_lin = orc.fused_quantized_linear(xn.numpy(), w, ws, [128.0], bias) + r1 + r2
+        assert np.array_equal(want[0], o_lin) and np.array_equal(want[1], orc.layer_norm(o_lin, g1.arr, b1.arr, -1, 1e-5))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,t,res2,fbias,pads,koff", [
+    (32, 171, True, False, (5, 5), 1024),    # configs[3]: one launch (memory block + projection + Adds + LayerNorm)
+    (32, 171, False, True, (5, 5), 1024),    # the first layer's form (no second residual), with an FSMN bias
+    (40, 100, True, False, (5, 5), 0),       # utterances shorter than four tiles: every tile crosses an utterance boundary somewhere
+    (90, 33, True, True, (5, 5), 512),       # utterances barely longer than a tile; a window that spans three utterances
+    (5, 700, True, False, (5, 5), 1024),     # a ragged last tile
+    (32, 171, True, False, (10, 0), 1024),   # causal padding: the three calls
+    (1, 504, True, False, (5, 5), 1024),     # one utterance: the three calls
+])
+def test_sanm_out_block_is_the_three_calls_bit_for_bit(ctx, orc, b, t, res2, fbias, pads, koff):
+    """lele_hip_sanm_out_block == depthwise_conv1d_tlc(add_input) -> fused_quantized_linear_residual -> layer_norm: the FSMN memory
+    block computed inside the projection kernel from a window of v in LDS (taps outside the utterance skipped, the sequence's FMA
+    order), rows normalised in the epilogue.  Three repetitions (the window arrives through direct-to-LDS loads that only a counted
+    wait orders before their first use), one case against the oracle's sequence."""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    rng = np.random.default_rng(b * 100 + t)
+    av = (rng.standard_normal((b, t, 512)) * rng.uniform(0.3, 3.0, (b, 1, 1))).astype(np.float32)
+    qkv = rng.standard_normal((b, t, 1536)).astype(np.float32)
+    qkv_d, av_d = ctx.buf().upload(qkv), ctx.buf().upload(av)
+    w, ws, bias = _weights(rng, 512, 512)
+    W = (Weight(w), Weight(ws), Weight(np.array([128.0], np.float32)), Weight(bias))
+    fw = Weight((rng.standard_normal((512, 1, 11)) / np.sqrt(11)).astype(np.float32))
+    fb = Weight((rng.standard_normal(512) * 0.1).astype(np.float32)) if fbias else None
+    r2 = rng.standard_normal((b, t, 512)).astype(np.float32) if res2 else None
+    g1, b1 = _ln_params(rng)
+    mem = K.depthwise_conv1d_tlc(qkv_d, fw, fb, pads[0], pads[1], False, koff, True, ctx=ctx)
+    lin = K.fused_quantized_linear_residual(av_d, *W, False, mem, r2, ctx=ctx)
+    want = lin.numpy().copy(), K.layer_norm(lin, g1, b1, -1, 1e-5, ctx=ctx).numpy().copy()
+    for rep in range(3):
+        got = K.sanm_out_block(av_d, *W, False, qkv_d, fw, fb, koff, pads[0], pads[1], r2, g1, b1, 1e-5, ctx=ctx)
+        assert np.array_equal(got[0].numpy(), want[0]), (b, t, rep, float(np.abs(got[0].numpy() - want[0]).max()))
+        assert np.array_equal(got[1].numpy(), want[1]), (b, t, rep)
+    if (b, t) == (40, 100):
+        from oracle import plan_ref
+        o = plan_ref.PlanRef({"statements": [], "weights": {}, "outputs": [], "inputs": []}, {}).call(
+            "sanm_out_block", [av, w, ws, np.array([128.0], np.float32), bias, False, qkv, fw.arr, None, koff, 5, 5, r2, g1.arr, b1.arr, 1e-5])
+        # against the oracle's sequence the bar is the convolution's (1e-4: the oracle's conv1d restates lele's dot loops, the device's
+        # depthwise kernels chain FMAs -- tests/test_conv_rnn.py), everything around it is exact
+        from tests.parity import close_f32
+        close_f32(want[0], o[0], 1e-4, "x1")
+        close_f32(want[1], o[1], 1e-4, "layer_norm(x1)")
