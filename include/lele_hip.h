@@ -480,6 +480,15 @@ int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const Le
                                  const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8,
                                  const LeleTensor* w2_scale, const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2,
                                  const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank);
+/* the same followed by the LayerNorm over the last axis that reads the result (the NEXT half-layer's LayerNorm in a transformer stack):
+ *   out = fused_ffn_quantized(...);  ln_out = layer_norm(out, ln_scale, ln_bias, -1, epsilon)
+ * bit for bit the two calls.  With 2048 hidden and 512 output columns over a batch the second product runs one 32-row tile a workgroup
+ * with all columns (weights streamed from L2) and normalises its rows in the epilogue: the LayerNorm launch and one round trip of the sum go. */
+int lele_hip_fused_ffn_quantized_ln(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_int8, const LeleTensor* w1_scale,
+                                    const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8, const LeleTensor* w2_scale,
+                                    const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2, const LeleTensor* res1,
+                                    const LeleTensor* res2, const LeleTensor* ln_scale, const LeleTensor* ln_bias, float epsilon, LeleBuf* out,
+                                    LeleBuf* ln_out, int64_t* out_shape, int32_t* out_rank);
 /* softmax(x * scale[0]) over the last axis: `mul` by a one-element tensor followed by `softmax` (norm.rs:8) */
 int lele_hip_softmax_scaled(LeleCtx* ctx, const LeleTensor* x, const LeleTensor* scale, int32_t axis, LeleBuf* out,
                             int64_t* out_shape, int32_t* out_rank);

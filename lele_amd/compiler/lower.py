@@ -811,6 +811,7 @@ class Lowering:
 
             x1 = fused_quantized_linear_residual(..., res1, res2);  x1n = layer_norm(x1, g, b, -1, eps)
               -> [x1, x1n] = fused_quantized_linear_residual_ln(..., res1, res2, g, b, eps)
+            y = fused_ffn_quantized(...);  yn = layer_norm(y, g, b, -1, eps)   ->   [y, yn] = fused_ffn_quantized_ln(..., g, b, eps)
 
         and, where res1 is a `depthwise_conv1d_tlc(.., relu = false, add_input = true)` that nothing else reads (the FSMN memory block
         of a SAN-M layer), the three of them as `sanm_out_block` (lele_hip_sanm_out_block).  x1 may have other readers (it is the residual
@@ -840,7 +841,7 @@ class Lowering:
                 readers.setdefault(r, []).append(i)
         dead = set()
         for i, st in enumerate(sts):
-            if st.get("fn") != "fused_quantized_linear_residual" or i in dead:
+            if st.get("fn") not in ("fused_quantized_linear_residual", "fused_ffn_quantized") or i in dead:
                 continue
             x1 = st["out"][0]
             lns = [j for j in readers.get(x1, []) if j > i and sts[j].get("fn") == "layer_norm" and sts[j]["args"][0] == {"ref": x1}
@@ -849,6 +850,13 @@ class Lowering:
                 continue
             ln = sts[lns[0]]
             g, b, eps = ln["args"][1], ln["args"][2], ln["args"][4]
+            if st["fn"] == "fused_ffn_quantized":      # the feed-forward block + the NEXT half-layer's LayerNorm
+                st["fn"] = "fused_ffn_quantized_ln"
+                st["args"] = st["args"][:12] + [g, b, eps]
+                st["out"] = [x1, ln["out"][0]]
+                st["bufs"] = 2
+                dead.add(lns[0])
+                continue
             a = st["args"]          # input, w, scale, zero, bias, relu, res1, res2
             mem = a[6].get("ref") if isinstance(a[6], dict) else None
             tlc = sts[producer[mem]] if mem in producer else None
@@ -964,7 +972,8 @@ class Lowering:
         if self.extra_fusions:
             self.fold_linear_residuals()
             self.fold_ffn()
-            self.fold_ln_epilogue()     # after fold_ffn: the feed-forward block's second linear belongs to that fold
+            if getattr(self, "half_layer_folds", True):   # False: round 5's eight statements a layer (the FSMN block a branch of its own: tests/test_lanes.py)
+                self.fold_ln_epilogue()     # after fold_ffn: the feed-forward block's second linear belongs to that fold
             self.fold_attention()
 
     def lower_if(self, node):
@@ -980,6 +989,7 @@ class Lowering:
             if len(g.output) != len(node.output):
                 raise CompileError("If %r: the %s branch has %d outputs, the node %d" % (node.name, key, len(g.output), len(node.output)))
             ch = Lowering(self.model, self.name, self.extra_fusions, graph=g, parent=self)
+            ch.half_layer_folds = getattr(self, "half_layer_folds", True)
             ch.lower_graph(list(g.node))
             results, k = [], []
             for o in g.output:
@@ -1127,10 +1137,12 @@ def allocate(statements, outputs):
     return ["buf_%d" % s for s in range(n_slots)]
 
 
-def compile_model(model, name="model", extra_fusions=True, bind=None):
+def compile_model(model, name="model", extra_fusions=True, bind=None, half_layer_folds=True):
     """ONNX model (bytes, path or onnx_pb.Model) -> (plan dict, weights.bin bytes).  extra_fusions=False keeps to the
     patterns lele's own compiler has (patterns.rs); the extra fused forms are bit-identical to what they replace.
     bind={input: value} fixes graph inputs at compile time (an `If` on them then inlines the taken branch)."""
     if not isinstance(model, pb.Model):
         model = pb.load(model)
-    return Lowering(model, name, extra_fusions, bind=bind).run()
+    low = Lowering(model, name, extra_fusions, bind=bind)
+    low.half_layer_folds = bool(half_layer_folds)
+    return low.run()

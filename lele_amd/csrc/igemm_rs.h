@@ -853,6 +853,46 @@ constexpr int as_fs_lds(int fs) { return (32 + fs - 1) * AS_LN_PITCH * 4; }
 
 // TWO = false (few row tiles: one utterance): a workgroup takes only `tpw` column tiles, one a wave, and the grid's second dimension
 // the rest -- the row tile is quantised once per column group (out of L2), in exchange for four times the workgroups.
+// The LayerNorm phase of the activation-stationary kernels: the workgroup's 32 x 512 result sits in LDS (s_ln, pitch AS_LN_PITCH);
+// half-wave (wave, hv) normalises tile rows 2 wave + hv and 16 + 2 wave + hv with the operations of layer_norm_reg_kernel<16> in
+// their order (eltwise.hip; avx/norm.rs:10-133: the same bits), stores them and leaves {min, max} per row for the next quantiser.
+__device__ __forceinline__ void as_ln_rows(const float* s_ln, const float* s_lng, const float* s_lnb, unsigned t, int wave, int hv, int l31,
+                                           unsigned rows, float eps, float* ln_out, float* ln_rowstat) {
+    constexpr int NT = 16;
+    const float inv_n = 1.0f / 512.0f;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = 2 * wave + hv + 16 * rr;
+        const unsigned grow = t * 32u + (unsigned)r;
+        float v[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) v[c] = s_ln[r * AS_LN_PITCH + 32 * c + l31];
+        float sum, sumsq;
+        row_sums_reg<NT, true, true>(v, 512, l31, &sum, &sumsq);
+        const float mean = sum * inv_n;
+        const float var = sumsq * inv_n - mean * mean;
+        const float inv_std = 1.0f / sqrtf(var + eps);
+        float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
+        float* orow = ln_out + (size_t)(grow < rows ? grow : rows - 1u) * 512u;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const float tv = (v[c] - mean) * inv_std;
+            const float o = fmaf_(tv, s_lng[32 * c + l31], s_lnb[32 * c + l31]);  // 512 % 8 == 0: every element is in the 8-wide body
+            if (grow < rows) orow[32 * c + l31] = o;
+            mn = o < mn ? o : mn;
+            mx = o > mx ? o : mx;
+        }
+        if (ln_rowstat) {
+            mn = group_allreduce32(mn, [](float cur, float a) { return a < cur ? a : cur; });
+            mx = group_allreduce32(mx, [](float cur, float a) { return a > cur ? a : cur; });
+            if (l31 == 0 && grow < rows) {
+                ln_rowstat[2 * (size_t)grow] = mn;
+                ln_rowstat[2 * (size_t)grow + 1] = mx;
+            }
+        }
+    }
+}
+
 // LN = true: the workgroup holds whole rows of the result (32 x 512), so the LayerNorm that reads it runs here as well -- the tile goes
 // through LDS once (a lane of the epilogue owns 32 columns of ONE row, the normalisation wants a row spread over 32 lanes), then every
 // half-wave normalises two rows with the operations of layer_norm_reg_kernel<16> in their order (eltwise.hip; avx/norm.rs:10-133:
@@ -1156,39 +1196,157 @@ __global__ __launch_bounds__(512) void igemm_as_kernel(AsArgs g, IgemmEpi epi) {
     if constexpr (TWO) finish(acc1, ct1, rb1, rb2);
     if constexpr (LN) {
         __syncthreads();
-        constexpr int NT = 16;
-        const float inv_n = 1.0f / 512.0f;
+        as_ln_rows(s_ln, s_lng, s_lnb, (unsigned)t, wave, hv, l31, rows, g.ln_eps, g.ln_out, g.ln_rowstat);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ K = 2048, N = 512: activations stationary, weights streamed
+// The second product of the feed-forward block (5472 x 2048 x 512 on a configs[3] shard) followed by the next layer's LayerNorm.
+// igemm_rs_ks4_kernel gives a workgroup one column tile, so no workgroup ever holds a whole row and the LayerNorm was a launch of
+// its own (7 us + the sum's round trip).  Here a workgroup owns ONE 32-row tile and ALL 512 columns: the tile's 64 fragment blocks
+// (already i8 in fragment order: the quantise pass of the first product wrote them) arrive in LDS by direct-to-LDS loads, every
+// wave streams the weight fragments of its two column tiles through an eight-step register ring (128 KiB a wave, the same 1 MiB
+// for every workgroup: L2 hits), 2 x 64 products, row sums by v_dot4 on the fragments it reads anyway, then the epilogue of
+// igemm_as_kernel -- convert, scale, bias, residuals, 16-byte stores -- and, LN, the LayerNorm phase on the tile in LDS.
+struct AskArgs {
+    const int8_t* af;      // fragment-major [nrt][64][1024]
+    const int8_t* wf;      // fragment-major [16][64][1024]
+    unsigned rows;
+    const float* ln_g = nullptr;
+    const float* ln_b = nullptr;
+    float ln_eps = 0.0f;
+    float* ln_out = nullptr;
+    float* ln_rowstat = nullptr;
+};
+constexpr int ASK_TILE = 64 * 1024;
+constexpr int ASK_LDS = ASK_TILE + AS_LN_LDS;
+template <int NRES, bool LN>
+__global__ __launch_bounds__(512) void igemm_ask_kernel(AskArgs g, IgemmEpi epi) {
+    constexpr int KS = 64, RING = 8;
+    extern __shared__ __attribute__((aligned(16))) char ask_lds[];  // [the tile's fragments: 64 KiB][LN: 32 x AS_LN_PITCH floats]
+    float* s_ln = reinterpret_cast<float*>(ask_lds + ASK_TILE);
+    __shared__ __attribute__((aligned(16))) int s_colsum[512];
+    __shared__ __attribute__((aligned(16))) float s_ws[512];
+    __shared__ __attribute__((aligned(16))) float s_bias[512];
+    __shared__ float s_lng[LN ? 512 : 1], s_lnb[LN ? 512 : 1];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hv = lane >> 5, l31 = lane & 31;
+    const unsigned t = blockIdx.x, rows = g.rows, mu = (unsigned)epi.m;
+    constexpr int n = 512;
+    // ---- 1. the tile: block b of 64 -> wave b % 8 (eight 1 KiB direct-to-LDS loads a wave), issued before every other load: loads
+    //         return in order, so the wait for the column terms below covers them
+    {
+        const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ask_lds;
+        const char* src = reinterpret_cast<const char*>(g.af) + ((size_t)t * KS) * 1024 + lane * 16;
 #pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {  // half-wave (wave, hv) normalises tile rows 2 wave + hv and 16 + 2 wave + hv
-            const int r = 2 * wave + hv + 16 * rr;
-            const unsigned grow = (unsigned)t * 32u + (unsigned)r;
-            float v[NT];
+        for (int j = 0; j < KS / 8; ++j) {
+            const int blk = wave + 8 * j;
+            rs_dma16(src + (size_t)blk * 1024, __builtin_amdgcn_readfirstlane(base + (unsigned)blk * 1024u));
+        }
+    }
+    // ---- 2. column terms (one column a thread), LayerNorm scale / bias, the row's slice parameters
+    const int csum = epi.col_sums[threadIdx.x];
+    const float wsv = epi.wscale[epi.wscale_len <= 1 ? 0 : threadIdx.x];
+    const float bv = (epi.bias ? epi.bias : epi.wscale)[epi.bias ? threadIdx.x : 0];
+    float lgv = 0.0f, lbv = 0.0f;
+    if constexpr (LN) lgv = g.ln_g[threadIdx.x], lbv = g.ln_b[threadIdx.x];
+    const unsigned row = t * 32u + (unsigned)l31;
+    const bool rok = row < rows;
+    const unsigned rowc = rok ? row : rows - 1u;
+    const unsigned sl = rows == mu ? 0u : rowc / mu;
+    const float ds = epi.prm[sl].scale;
+    const int zp_i = epi.prm[sl].zp_i;
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 3. the first RING steps of this wave's weights (column tiles 2 wave and 2 wave + 1)
+    const int ct0 = 2 * wave, ct1 = 2 * wave + 1;
+    const v4i* w0 = reinterpret_cast<const v4i*>(g.wf) + (size_t)ct0 * KS * 64 + lane;
+    const v4i* w1 = reinterpret_cast<const v4i*>(g.wf) + (size_t)ct1 * KS * 64 + lane;
+    // A layer's weights are COLD (70 layers x 1 MiB pass through the caches between two uses) and every workgroup streams the same
+    // megabyte: in lock step each of them would meet memory latency at every refill of the ring.  The k-steps of an exact integer sum
+    // may be taken in any order, so the workgroups of an XCD (block b runs on XCD b % 8) start at eight different offsets: after the
+    // first RING steps every line a workgroup asks for has been fetched by its neighbour already.
+    const int rot = (int)((blockIdx.x >> 3) & 7u) * 8;
+    v4i ra[RING], rb[RING];
 #pragma unroll
-            for (int c = 0; c < NT; ++c) v[c] = s_ln[r * AS_LN_PITCH + 32 * c + l31];
-            float sum, sumsq;
-            row_sums_reg<NT, true, true>(v, 512, l31, &sum, &sumsq);
-            const float mean = sum * inv_n;
-            const float var = sumsq * inv_n - mean * mean;
-            const float inv_std = 1.0f / sqrtf(var + g.ln_eps);
-            float mn = 3.40282347e+38f, mx = -3.40282347e+38f;
-            float* orow = g.ln_out + (size_t)(grow < rows ? grow : rows - 1u) * 512u;
+    for (int s = 0; s < RING; ++s) ra[s] = w0[((s + rot) & (KS - 1)) * 64], rb[s] = w1[((s + rot) & (KS - 1)) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    s_colsum[threadIdx.x] = csum;
+    s_ws[threadIdx.x] = wsv;
+    s_bias[threadIdx.x] = epi.bias ? bv : -0.0f;
+    if constexpr (LN) s_lng[threadIdx.x] = lgv, s_lnb[threadIdx.x] = lbv;
+    // the residual operands: requested before the products, used behind them
+    float4 ra1[NRES > 0 ? 4 : 1], ra2[NRES > 1 ? 4 : 1], rb1[NRES > 0 ? 4 : 1], rb2[NRES > 1 ? 4 : 1];
+    if (NRES > 0) {
 #pragma unroll
-            for (int c = 0; c < NT; ++c) {
-                const float tv = (v[c] - mean) * inv_std;
-                const float o = fmaf_(tv, s_lng[32 * c + l31], s_lnb[32 * c + l31]);  // 512 % 8 == 0: every element is in the 8-wide body
-                if (grow < rows) orow[32 * c + l31] = o;
-                mn = o < mn ? o : mn;
-                mx = o > mx ? o : mx;
-            }
-            if (g.ln_rowstat) {
-                mn = group_allreduce32(mn, [](float cur, float a) { return a < cur ? a : cur; });
-                mx = group_allreduce32(mx, [](float cur, float a) { return a > cur ? a : cur; });
-                if (l31 == 0 && grow < rows) {
-                    g.ln_rowstat[2 * (size_t)grow] = mn;
-                    g.ln_rowstat[2 * (size_t)grow + 1] = mx;
-                }
+        for (int gq = 0; gq < 4; ++gq) {
+            const unsigned at0 = rowc * (unsigned)n + (unsigned)(ct0 * 32 + 4 * hv + 8 * gq), at1 = rowc * (unsigned)n + (unsigned)(ct1 * 32 + 4 * hv + 8 * gq);
+            ra1[gq] = *reinterpret_cast<const float4*>(epi.res1 + at0);
+            rb1[gq] = *reinterpret_cast<const float4*>(epi.res1 + at1);
+            if (NRES > 1) {
+                ra2[gq] = *reinterpret_cast<const float4*>(epi.res2 + at0);
+                rb2[gq] = *reinterpret_cast<const float4*>(epi.res2 + at1);
             }
         }
+    }
+    __syncthreads();  // every wave's part of the tile has landed (its own loads behind it have been waited for above)
+    // ---- 4. 2 x 64 products; the weights of step s + RING are requested as step s's registers fall free
+    v16i acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = 0, acc1[i] = 0;
+    int rsp = 0;
+    {
+        const v4i* ap = reinterpret_cast<const v4i*>(ask_lds) + lane;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const v4i a = ap[((s + rot) & (KS - 1)) * 64];
+            acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(ra[s % RING], a, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(rb[s % RING], a, acc1, 0, 0, 0);
+            rsp = __builtin_amdgcn_sdot4(a[0], 0x01010101, rsp, false);
+            rsp = __builtin_amdgcn_sdot4(a[1], 0x01010101, rsp, false);
+            rsp = __builtin_amdgcn_sdot4(a[2], 0x01010101, rsp, false);
+            rsp = __builtin_amdgcn_sdot4(a[3], 0x01010101, rsp, false);
+            if (s + RING < KS) ra[s % RING] = w0[((s + RING + rot) & (KS - 1)) * 64], rb[s % RING] = w1[((s + RING + rot) & (KS - 1)) * 64];
+        }
+    }
+    // ---- 5. epilogue: IgemmEpi::value24 as igemm_rs_ks4_kernel applies it (row terms added behind the products)
+    const int rowsum = rsp + __shfl_xor(rsp, 32);  // the two k halves of the row
+    const int ca = 128 - zp_i, cbz = 128 - epi.zp_b;
+    const int rterm = cbz * rowsum + epi.k * ca * cbz;
+    const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)epi.out, 0, (int)(rows * (unsigned)n * 4u), 0x00020000);
+    auto finish = [&](const v16i& acc, int ct, const float4 (&res1)[NRES > 0 ? 4 : 1], const float4 (&res2)[NRES > 1 ? 4 : 1]) {
+        const unsigned obase = rowc * (unsigned)n + (unsigned)(ct * 32 + 4 * hv);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int cl = ct * 32 + 4 * hv + 8 * gq;
+            const float4 ws = *reinterpret_cast<const float4*>(&s_ws[cl]);
+            const float4 bs = *reinterpret_cast<const float4*>(&s_bias[cl]);
+            const v4i cs = *reinterpret_cast<const v4i*>(&s_colsum[cl]);
+            auto val = [&](int a, int c, float w, float b) {
+                float vf = (float)(a + rterm + __mul24(ca, c));  // _mm256_cvtepi32_ps
+                vf = vf * (ds * w);
+                vf = vf + b;
+                if (epi.relu) vf = relu0(vf);
+                return vf;
+            };
+            float4 o;
+            o.x = val(acc[4 * gq + 0], cs[0], ws.x, bs.x);
+            o.y = val(acc[4 * gq + 1], cs[1], ws.y, bs.y);
+            o.z = val(acc[4 * gq + 2], cs[2], ws.z, bs.z);
+            o.w = val(acc[4 * gq + 3], cs[3], ws.w, bs.w);
+            if (NRES > 0) {
+                o.x = o.x + res1[gq].x, o.y = o.y + res1[gq].y, o.z = o.z + res1[gq].z, o.w = o.w + res1[gq].w;
+                if (NRES > 1) o.x = o.x + res2[gq].x, o.y = o.y + res2[gq].y, o.z = o.z + res2[gq].z, o.w = o.w + res2[gq].w;
+            }
+            const v4u bits = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, rok ? (obase + 8u * gq) * 4u : 0xffffffffu, 0, 0);
+            if constexpr (LN) *reinterpret_cast<float4*>(&s_ln[l31 * AS_LN_PITCH + cl]) = o;
+        }
+    };
+    finish(acc0, ct0, ra1, ra2);
+    finish(acc1, ct1, rb1, rb2);
+    if constexpr (LN) {
+        __syncthreads();
+        as_ln_rows(s_ln, s_lng, s_lnb, t, wave, hv, l31, rows, g.ln_eps, g.ln_out, g.ln_rowstat);
     }
 }
 

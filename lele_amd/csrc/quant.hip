@@ -1216,6 +1216,36 @@ int launch_rs_ks4(LeleCtx* ctx, const int8_t* af, const int8_t* wf, int64_t rows
     return 0;
 }
 
+// K = 2048, N = 512 over a batch: one workgroup a row tile, all columns, weights streamed (igemm_ask_kernel), optionally + LayerNorm
+bool ask_fits(LeleCtx* ctx, int64_t rows, int64_t n, int64_t k) {
+    return env_int("LELE_HIP_IGEMM_RS", 1) != 0 && env_int("LELE_HIP_IGEMM_ASK", 1) != 0 && k == 2048 && n == 512 && rows * n < (int64_t(1) << 30) &&
+           as_two(ctx, rows, (int)n);
+}
+int launch_ask(LeleCtx* ctx, const int8_t* af, const int8_t* wf, int64_t rows, const IgemmEpi& epi, const AsLn* ln) {
+    AskArgs g{af, wf, (unsigned)rows};
+    if (ln) g.ln_g = ln->g, g.ln_b = ln->b, g.ln_eps = ln->eps, g.ln_out = ln->out, g.ln_rowstat = ln->rowstat;
+    const dim3 grid((unsigned)((rows + 31) / 32));
+    const int nres = epi.res1 ? (epi.res2 ? 2 : 1) : 0;
+#define LELE_ASK(NRES_, LN_)                                                                            \
+    do {                                                                                                \
+        auto kern = igemm_ask_kernel<NRES_, LN_>;                                                        \
+        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), (LN_) ? ASK_LDS : ASK_TILE)); \
+        hipLaunchKernelGGL(kern, grid, dim3(512), (LN_) ? ASK_LDS : ASK_TILE, ctx->stream, g, epi);      \
+    } while (0)
+    if (ln) {
+        if (nres == 0) LELE_ASK(0, true);
+        else if (nres == 1) LELE_ASK(1, true);
+        else LELE_ASK(2, true);
+    } else {
+        if (nres == 0) LELE_ASK(0, false);
+        else if (nres == 1) LELE_ASK(1, false);
+        else LELE_ASK(2, false);
+    }
+#undef LELE_ASK
+    LELE_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 namespace lele {
@@ -1649,10 +1679,10 @@ int lele_hip_sanm_out_block(LeleCtx* ctx, const LeleTensor* input, const LeleTen
  *     out = fused_quantized_linear[_residual](fused_quantized_linear(input, W1.., relu = 1), W2.., relu2, res1, res2)
  * bit for bit.  When the hidden layer is large the f32 hidden tensor is never stored: its product runs twice on the matrix cores
  * (igemm_kernel EM 1: range only; EM 2: quantise with that range, i8 + row sums), then the second GEMM consumes the i8 rows. */
-int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_int8, const LeleTensor* w1_scale,
-                                 const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8,
-                                 const LeleTensor* w2_scale, const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2,
-                                 const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_int8, const LeleTensor* w1_scale,
+                    const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8,
+                    const LeleTensor* w2_scale, const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2,
+                    const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank, LnReq* ln) {
     LELE_REQUIRE(ctx && input && w1_int8 && w1_scale && w2_int8 && w2_scale && out, "fused_ffn_quantized: NULL argument");
     LELE_REQUIRE(input->rank >= 2 && w1_int8->rank >= 2 && w2_int8->rank >= 2, "fused_ffn_quantized: rank >= 2 required");
     LELE_REQUIRE(!res2 || res1, "fused_ffn_quantized: res2 without res1");
@@ -1754,7 +1784,34 @@ int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const Le
         LELE_TRY(launch_rs(ctx, 2, (const int8_t*)af1, fw1.wf, rows, (int)n1, (int8_t*)hid, e1, fqa));  // the result again, as the next operand
         IgemmEpi e2{(float*)out->data, rows, n2, (int)m, (int)k2, nullptr, fw2.col_sums, (const QParams*)prm2, 0, (int)wz2,
                     (const float*)dws2, (int)ws2_len, b2_len ? (const float*)db2 : nullptr, apply_relu2, (const float*)dr1, (const float*)dr2};
-        LELE_TRY(launch_rs_ks4(ctx, (const int8_t*)hid, fw2.wf, rows, (int)n2, e2));
+        // the second product: one column tile a workgroup over a range of row tiles (igemm_rs_ks4_kernel), or -- where the caller wants
+        // the LayerNorm of the result as well -- one row tile a workgroup with all 512 columns and the normalisation in the epilogue
+        const bool fuse_ln = ln && ask_fits(ctx, rows, n2, k2) && as_ln_ok(ctx, rows, n2, apply_relu2, ln->g, ln->b) && ln->out != out &&
+                             (((uintptr_t)out->data) & 15) == 0;
+        if (fuse_ln || (lab_int("LELE_HIP_IGEMM_ASK_ALWAYS", 0) != 0 && ask_fits(ctx, rows, n2, k2) && (((uintptr_t)out->data) & 15) == 0)) {
+            AsLn aln;
+            if (fuse_ln) {
+                const void *dg = nullptr, *dbeta = nullptr;
+                LELE_TRY(ctx->dev_ptr(ln->g, &dg));
+                LELE_TRY(ctx->dev_ptr(ln->b, &dbeta));
+                LELE_TRY(ln->out->reserve((size_t)rows * n2 * 4));
+                LELE_TRY(ln->out->reserve_rowstat(rows));
+                aln.g = (const float*)dg, aln.b = (const float*)dbeta, aln.eps = ln->eps, aln.out = (float*)ln->out->data;
+                aln.rowstat = (size_t)rows <= ln->out->rowstat_cap ? ln->out->rowstat : nullptr;
+            }
+            LELE_TRY(launch_ask(ctx, (const int8_t*)hid, fw2.wf, rows, e2, fuse_ln ? &aln : nullptr));
+            if (fuse_ln) {
+                ln->done = true;
+                if (aln.rowstat) {
+                    ln->out->rowstat_rows = rows;
+                    ln->out->rowstat_len = n2;
+                    ln->out->rowstat_kind = 0;
+                    ln->out->rowstat_valid = true;
+                }
+            }
+        } else {
+            LELE_TRY(launch_rs_ks4(ctx, (const int8_t*)hid, fw2.wf, rows, (int)n2, e2));
+        }
         LELE_TRY(qprof_mark(ctx, 3));
         return set_shape_v(out_shape, out_rank, shp);
     }
@@ -1788,6 +1845,36 @@ int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const Le
     LELE_TRY(launch_igemm(ctx, (const int8_t*)aq2, pw2.wt, rows, (int)n2, kp2, 0, (int)m, e2));
     LELE_TRY(qprof_mark(ctx, 3));
     return set_shape_v(out_shape, out_rank, shp);
+}
+
+int lele_hip_fused_ffn_quantized(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_int8, const LeleTensor* w1_scale,
+                                 const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8,
+                                 const LeleTensor* w2_scale, const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2,
+                                 const LeleTensor* res1, const LeleTensor* res2, LeleBuf* out, int64_t* out_shape, int32_t* out_rank) {
+    return ffn_impl(ctx, input, w1_int8, w1_scale, w1_zero, b1, w2_int8, w2_scale, w2_zero, b2, apply_relu2, res1, res2, out, out_shape, out_rank, nullptr);
+}
+
+/* out = fused_ffn_quantized(...);  ln_out = layer_norm(out, ln_scale, ln_bias, -1, epsilon) -- a transformer layer's feed-forward block,
+ * its residual Add(s) and the LayerNorm of the NEXT half-layer that reads the sum, bit for bit the two calls.  On the register-stationary
+ * route with 512 output columns the second product runs one row tile a workgroup (igemm_ask_kernel) and normalises in its epilogue. */
+int lele_hip_fused_ffn_quantized_ln(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_int8, const LeleTensor* w1_scale,
+                                    const LeleTensor* w1_zero, const LeleTensor* b1, const LeleTensor* w2_int8, const LeleTensor* w2_scale,
+                                    const LeleTensor* w2_zero, const LeleTensor* b2, int apply_relu2, const LeleTensor* res1,
+                                    const LeleTensor* res2, const LeleTensor* ln_scale, const LeleTensor* ln_bias, float epsilon, LeleBuf* out,
+                                    LeleBuf* ln_out, int64_t* out_shape, int32_t* out_rank) {
+    LELE_REQUIRE(ctx && input && ln_scale && ln_bias && out && ln_out, "fused_ffn_quantized_ln: NULL argument");
+    LELE_REQUIRE(out != ln_out, "fused_ffn_quantized_ln: the sum and its normalised form need two buffers");
+    LnReq ln{ln_scale, ln_bias, epsilon, ln_out};
+    int64_t sh[LELE_MAX_RANK];
+    int32_t r = 0;
+    LELE_TRY(ffn_impl(ctx, input, w1_int8, w1_scale, w1_zero, b1, w2_int8, w2_scale, w2_zero, b2, apply_relu2, res1, res2, out, sh, &r, &ln));
+    if (!ln.done) {
+        LeleTensor y{out->data, sh, r, LELE_F32, LELE_MEM_DEVICE};
+        int64_t sh2[LELE_MAX_RANK];
+        int32_t r2 = 0;
+        LELE_TRY(lele_hip_layer_norm(ctx, &y, ln_scale, ln_bias, -1, epsilon, ln_out, sh2, &r2));
+    }
+    return set_shape_v(out_shape, out_rank, std::vector<int64_t>(sh, sh + r));
 }
 
 /* ---- per-stage stopwatch of fused_quantized_linear (bench.py's roofline block for the model path) ------------------- */

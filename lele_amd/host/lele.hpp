@@ -821,6 +821,18 @@ inline TensorView fused_ffn_quantized(const TensorView& input, const TensorView&
                                        &sh.rank));
     LELE_RET(out, LELE_F32);
 }
+inline SumAndNorm fused_ffn_quantized_ln(const TensorView& input, const TensorView& w1_int8, const TensorView& w1_scale, const TensorView& w1_zero,
+                                         const TensorView* b1, const TensorView& w2_int8, const TensorView& w2_scale, const TensorView& w2_zero,
+                                         const TensorView* b2, bool apply_relu2, const TensorView* res1, const TensorView* res2,
+                                         const TensorView& ln_scale, const TensorView& ln_bias, float epsilon, Buffer& out, Buffer& ln_out) {
+    Shape sh;
+    LeleTensor ti = input.c(), tw1 = w1_int8.c(), ts1 = w1_scale.c(), tz1 = w1_zero.c(), tw2 = w2_int8.c(), ts2 = w2_scale.c(), tz2 = w2_zero.c(),
+               tg = ln_scale.c(), tb = ln_bias.c();
+    Opt ob1(b1), ob2(b2), o1(res1), o2(res2);
+    check(lele_hip_fused_ffn_quantized_ln(ctx(), &ti, &tw1, &ts1, &tz1, ob1.p, &tw2, &ts2, &tz2, ob2.p, apply_relu2, o1.p, o2.p, &tg, &tb, epsilon,
+                                          out.raw(), ln_out.raw(), sh.dims, &sh.rank));
+    return {TensorView::from_device(out, sh.vec(), LELE_F32), TensorView::from_device(ln_out, sh.vec(), LELE_F32)};
+}
 inline TensorView softmax_scaled(const TensorView& x, const TensorView& scale, int64_t axis, Buffer& out) {
     Shape sh;
     LeleTensor tx = x.c(), ts = scale.c();

@@ -794,9 +794,11 @@ class Runner {
                 if (st.has("wait"))
                     for (const Json& e : st.at("wait").arr) check(lele_hip_lane_wait(detail::ctx(), event_base_ + (int)e.as_int()));
             }
-            if (op == "join") {  // back on lane 0, after the last statement of every side lane
+            if (op == "join") {  // a point on lane 0: behind the last statement of every side lane (the plan's end), or -- with a `record` and
+                // nothing to wait for -- the run's starting point that every side lane's first statement waits for (lanes.py)
                 check(lele_hip_lane_set(detail::ctx(), 0));
                 for (const Json& e : st.at("wait").arr) check(lele_hip_lane_wait(detail::ctx(), event_base_ + (int)e.as_int()));
+                if (st.has("record")) check(lele_hip_lane_record(detail::ctx(), event_base_ + (int)st.at("record").as_int()));
                 continue;
             }
             struct Record {  // runs when the statement is done, whatever path it took
@@ -998,6 +1000,13 @@ class Runner {
         if (fn == "fused_ffn_quantized")
             return set(st, 0, K::fused_ffn_quantized(tensor(a[0]), tensor(a[1]), tensor(a[2]), tensor(a[3]), opt(a[4], h0), tensor(a[5]), tensor(a[6]),
                                                      tensor(a[7]), opt(a[8], h1), boolean(a[9]), opt(a[10], h2), opt(a[11], h3), o));
+        if (fn == "fused_ffn_quantized_ln") {
+            auto r = K::fused_ffn_quantized_ln(tensor(a[0]), tensor(a[1]), tensor(a[2]), tensor(a[3]), opt(a[4], h0), tensor(a[5]), tensor(a[6]), tensor(a[7]),
+                                               opt(a[8], h1), boolean(a[9]), opt(a[10], h2), opt(a[11], h3), tensor(a[12]), tensor(a[13]), number(a[14]), o,
+                                               slot(st, 1));
+            set(st, 0, r.sum), set(st, 1, r.norm);
+            return;
+        }
         if (fn == "mat_mul_integer") return set(st, 0, K::mat_mul_integer(tensor(a[0]), tensor(a[1]), opt(a[2], h0), opt(a[3], h1), o));
         if (fn == "dynamic_quantize_linear") {
             auto r = K::dynamic_quantize_linear(tensor(a[0]), o, slot(st, 1), slot(st, 2));

@@ -1106,6 +1106,21 @@ def fused_ffn_quantized(input, w1_int8, w1_scale, w1_zero, b1, w2_int8, w2_scale
     return TensorView(_lib.DevTensor(out, sh.get(), np.float32))
 
 
+def fused_ffn_quantized_ln(input, w1_int8, w1_scale, w1_zero, b1, w2_int8, w2_scale, w2_zero, b2, apply_relu2, res1, res2, ln_scale, ln_bias,
+                           epsilon, outs=None, ctx=None):
+    """(y, layer_norm(y, ln_scale, ln_bias, -1, epsilon)) with y = fused_ffn_quantized(...): the feed-forward block, its residual Adds and
+    the next half-layer's LayerNorm as one call (bit for bit the two calls)"""
+    ctx = _ctx(ctx)
+    keep = []
+    outs = list(outs) if outs else [ctx.buf(), ctx.buf()]
+    sh = _lib.OutShape()
+    _lib.check(_lib.lib().lele_hip_fused_ffn_quantized_ln(
+        ctx._h, _t(input, keep), _t(w1_int8, keep), _t(w1_scale, keep), _t(w1_zero, keep), _t(b1, keep), _t(w2_int8, keep),
+        _t(w2_scale, keep), _t(w2_zero, keep), _t(b2, keep), C.c_int(int(apply_relu2)), _t(res1, keep), _t(res2, keep), _t(ln_scale, keep),
+        _t(ln_bias, keep), C.c_float(float(epsilon)), outs[0]._h, outs[1]._h, sh.shape, C.byref(sh.rank)))
+    return TensorView(_lib.DevTensor(outs[0], sh.get(), np.float32)), TensorView(_lib.DevTensor(outs[1], sh.get(), np.float32))
+
+
 def softmax_scaled(input, scale, axis=-1, out=None, ctx=None):
     """softmax(input * scale[0]): bit-identical to mul(input, scale) followed by softmax"""
     return _op(ctx, _lib.lib().lele_hip_softmax_scaled, [input, scale], [C.c_int32(axis)], out)

@@ -88,10 +88,13 @@ def check_layer_against_oracle(taps, L, tag):
     same(taps["y"], taps["x1"] + taps["h2"], tag + " final add")
 
 
-def check_shipped_layer_against_oracle(tp, i, L, tag):
-    """One layer of the plan AS IT SHIPS (one-launch attention, FSMN in place, residual adds in the projection's store, the
-    feed-forward block as one call with its hidden layer never stored): every statement's result, tapped from the run, against the
-    oracle composed operator by operator on the device's own input of that statement."""
+def check_shipped_layer_against_oracle(tp, i, L, tag, ctx):
+    """One layer of the plan AS IT SHIPS (one-launch attention; the FSMN memory block, the output projection, its residual adds and
+    LayerNorm 2 as ONE statement -- sanm_out_block; the feed-forward block with its hidden layer never stored and the next layer's
+    LayerNorm 1 as one statement): every statement's result, tapped from the run, against the oracle composed operator by operator on
+    the device's own input of that statement.  The memory block no longer exists as a tensor of the plan: the device's own
+    depthwise_conv1d_tlc of the tapped qkv stands in for it (tests/test_quant.py holds the block to that operator bit for bit)."""
+    from lele_amd import kernels as K
     from oracle import pyoracle as O
     from oracle import sensevoice_ref as R
     D, H, DH = 512, 4, 128
@@ -104,7 +107,9 @@ def check_shipped_layer_against_oracle(tp, i, L, tag):
     q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
     vt = np.ascontiguousarray(v.transpose(0, 2, 1))
     mem = np.ascontiguousarray(O.conv1d(vt, L["fsmn"], None, [1], D, [5, 5], [1]).transpose(0, 2, 1)) + v
-    close(tp[n("mem")], mem, tag + " fsmn memory (depthwise_conv1d_tlc)")
+    assert n("mem") not in tp
+    dev_mem = K.depthwise_conv1d_tlc(ctx.buf().upload(qkv), L["fsmn"], None, 5, 5, False, 2 * D, True, ctx=ctx).numpy()
+    close(dev_mem, mem, tag + " fsmn memory (depthwise_conv1d_tlc)")
     # attention_view: softmax(Q K^T * scale) V with the heads merged, against the oracle's composition of the DEVICE's qkv
     qh = np.ascontiguousarray(q.reshape(b, t, H, DH).transpose(0, 2, 1, 3))
     kh = np.ascontiguousarray(k.reshape(b, t, H, DH).transpose(0, 2, 3, 1))
@@ -121,8 +126,8 @@ def check_shipped_layer_against_oracle(tp, i, L, tag):
     assert bad.mean() <= 1e-5, "%s attention_view (one launch): %d of %d elements outside 2e-4" % (tag, int(bad.sum()), bad.size)
     assert float(np.abs(got - av).max()) <= 1e-2 * rms, "%s attention_view: max abs diff %.3g against scale %.3g" % (tag, float(np.abs(got - av).max()), rms)
     att = R.qlinear(tp[n("avm")], L["out"])
-    x1 = (att + tp[n("mem")]) + x if L["d_in"] == D else att + tp[n("mem")]
-    same(tp[n("x1")], x1, tag + " output projection + residual adds (fused_quantized_linear_residual)")
+    x1 = (att + dev_mem) + x if L["d_in"] == D else att + dev_mem
+    same(tp[n("x1")], x1, tag + " memory block + output projection + residual adds (sanm_out_block)")
     same(tp[n("x1n")], O.layer_norm(tp[n("x1")], L["ln2"][0], L["ln2"][1], -1, 1e-5), tag + " layer_norm 2")
     h = R.qlinear(tp[n("x1n")], L["ffn1"], True)
     same(tp[n("x2")], tp[n("x1")] + R.qlinear(h, L["ffn2"]), tag + " feed-forward block + residual (fused_ffn_quantized)")
@@ -155,13 +160,15 @@ def run_config(ctx, model, batch, seconds, check_layers):
     finally:
         del os.environ["LELE_HIP_ATTENTION_FUSED"]
     # from here on: the plan as it ships (attention in one launch) -- with its first and last layer tapped against the oracle
-    names = ["x0", "l%d_x2" % (check_layers[-1] - 1)] + ["l%d_%s" % (i, s) for i in check_layers for s in ("xn", "qkv", "mem", "avm", "x1", "x1n", "x2")]
+    names = ["x0", "l%d_x2" % (check_layers[-1] - 1)] + ["l%d_%s" % (i, s) for i in check_layers for s in ("xn", "qkv", "avm", "x1", "x1n", "x2")]
+    fns = [st.get("fn") for st in plan["statements"]]
+    assert fns.count("sanm_out_block") == 70 and fns.count("fused_ffn_quantized_ln") == 70 and fns.count("layer_norm") == 1
     runner.taps = {nm: None for nm in names}
     hand = runner.run({"feats": feats})[0].numpy()
     tp, runner.taps = runner.taps, None
     assert np.isfinite(hand).all() and all(v is not None for v in tp.values())
     for i in check_layers:
-        check_shipped_layer_against_oracle(tp, i, arrays["layers"][i], "shipped plan, layer %d" % i)
+        check_shipped_layer_against_oracle(tp, i, arrays["layers"][i], "shipped plan, layer %d" % i, ctx)
     if batch > 1:
         # the batched sequence runs the tiled GEMM, whose summation order the one-launch kernel shares; with f32 MFMA products and
         # the reference's row softmax inside it (LELE_HIP_ATTENTION_EXACT=1; the default is split-bf16 + v_exp_f32, ~1e-6 apart) the two

@@ -571,3 +571,35 @@ def test_sanm_out_block_is_the_three_calls_bit_for_bit(ctx, orc, b, t, res2, fbi
         from tests.parity import close_f32
         close_f32(want[0], o[0], 1e-4, "x1")
         close_f32(want[1], o[1], 1e-4, "layer_norm(x1)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,m,nres", [(32, 171, 1), (32, 171, 2), (32, 171, 0), (3, 1000, 1), (86, 32, 1), (8, 171, 1), (1, 504, 1)])
+def test_feed_forward_block_and_next_layer_norm_as_one_call(ctx, orc, b, m, nres):
+    """lele_hip_fused_ffn_quantized_ln == fused_ffn_quantized -> layer_norm, bit for bit: on the route whose second product runs one row
+    tile a workgroup with the weights streamed (igemm_ask_kernel) and normalises in the epilogue, and on the routes that issue the two
+    calls; the statistics left beside the normalised result feed the next quantised linear; one case against the oracle's sequence."""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    rng = np.random.default_rng(7 * b + m + nres)
+    x = (rng.standard_normal((b, m, 512)) * rng.uniform(0.3, 3.0, (b, 1, 1))).astype(np.float32)
+    g0, b0 = _ln_params(rng)
+    xn = K.layer_norm(ctx.buf().upload(x), g0, b0, -1, 1e-5, out=ctx.buf(), ctx=ctx)
+    w1, ws1, bias1 = _weights(rng, 512, 2048)
+    w2, ws2, bias2 = _weights(rng, 2048, 512)
+    W1 = (Weight(w1), Weight(ws1), Weight(np.array([128.0], np.float32)), Weight(bias1))
+    W2 = (Weight(w2), Weight(ws2), Weight(np.array([127.0], np.float32)), Weight(bias2))
+    r1 = rng.standard_normal((b, m, 512)).astype(np.float32) if nres >= 1 else None
+    r2 = rng.standard_normal((b, m, 512)).astype(np.float32) if nres >= 2 else None
+    g1, b1 = _ln_params(rng)
+    y = K.fused_ffn_quantized(xn, *W1, *W2, False, r1, r2, ctx=ctx)
+    want = y.numpy().copy(), K.layer_norm(y, g1, b1, -1, 1e-5, ctx=ctx).numpy().copy()
+    for rep in range(3):
+        got = K.fused_ffn_quantized_ln(xn, *W1, *W2, False, r1, r2, g1, b1, 1e-5, ctx=ctx)
+        assert np.array_equal(got[0].numpy(), want[0]) and np.array_equal(got[1].numpy(), want[1]), (b, m, nres, rep)
+    nxt = K.fused_quantized_linear(K.layer_norm(y, g1, b1, -1, 1e-5, ctx=ctx), *W1, True, ctx=ctx).numpy()
+    assert np.array_equal(K.fused_quantized_linear(got[1], *W1, True, ctx=ctx).numpy(), nxt)
+    if (b, m) == (3, 1000):
+        h = orc.fused_quantized_linear(xn.numpy(), w1, ws1, [128.0], bias1, relu=True)
+        o = orc.fused_quantized_linear(h, w2, ws2, [127.0], bias2) + r1
+        assert np.array_equal(want[0], o) and np.array_equal(want[1], orc.layer_norm(o, g1.arr, b1.arr, -1, 1e-5))
