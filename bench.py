@@ -155,7 +155,16 @@ def cpu_baseline_frontend_all_cores(n, budget_s=5.0):
             "rtf": round(el / max(1, total) / (n / SAMPLE_RATE), 7)}
 
 
-def cpu_baseline_model(enc_arrays, feats, budget_s=14.0):
+def logits_agreement(dev, ref):
+    """MAE of the logits and arg-max agreement per frame, as examples/sensevoice/tests/e2e_test.rs:126-189 judges the model (its bar:
+    mae <= 1.0 against ONNX Runtime), plus the MAE relative to the logits' rms"""
+    dev, ref = np.asarray(dev, np.float64), np.asarray(ref, np.float64)
+    rms = float(np.sqrt(np.mean(ref * ref)))
+    return {"frames": int(ref.shape[0] * ref.shape[1]), "argmax_agreement": round(float((dev.argmax(-1) == ref.argmax(-1)).mean()), 4),
+            "mae": round(float(np.abs(dev - ref).mean()), 4), "mae_over_rms": round(float(np.abs(dev - ref).mean()) / rms, 5)}
+
+
+def cpu_baseline_model(enc_arrays, feats, budget_s=14.0, dev_logits=None):
     """lele's execution model for configs[2] on ONE host core: the oracle's restatement of every kernel the generated code
     would call (oracle/sensevoice_ref.py), layer after layer on one 30 s utterance, until ~budget_s of CPU work; the
     remaining layers are extrapolated from the per-layer mean (layers 1..69 are identical in shape), the CTC head is timed
@@ -173,15 +182,20 @@ def cpu_baseline_model(enc_arrays, feats, budget_s=14.0):
             break
     t0 = time.perf_counter()
     xn = O.layer_norm(x, enc_arrays["ln_out"][0], enc_arrays["ln_out"][1], -1, 1e-5)
-    R.qlinear(xn, enc_arrays["ctc"])
+    ref_logits = R.qlinear(xn, enc_arrays["ctc"])
     head = time.perf_counter() - t0
     nl = len(enc_arrays["layers"])
     rest = per[1:] if len(per) > 1 else per
     est = sum(per) + (nl - len(per)) * (sum(rest) / len(rest)) + head
     audio = feats.shape[0] * SECONDS
-    return {"model_rtf": round(est / audio, 6), "model_ms": round(est * 1e3, 1), "model_cores": 1,
-            "model_sample": "%d of %d layers + CTC head of ONE 30 s utterance timed (%.1f s), rest extrapolated per layer; oracle, 1 thread"
-                            % (len(per), nl, sum(per) + head)}
+    out = {"model_rtf": round(est / audio, 6), "model_ms": round(est * 1e3, 1), "model_cores": 1,
+           "model_sample": "%d of %d layers + CTC head of ONE 30 s utterance timed (%.1f s), rest extrapolated per layer; oracle, 1 thread"
+                           % (len(per), nl, sum(per) + head)}
+    if dev_logits and len(per) == nl:   # the oracle ran the whole forward: the checker's logits against the device's (the oracle as CHECKER)
+        out["oracle_agreement"] = {"what": "configs[2] logits, device vs the oracle's forward timed here (e2e_test.rs:126-189: MAE, arg-max per frame; "
+                                           "its MAE bar is 1.0); bars asserted in tests/test_graph_oracle.py",
+                                   **{k: logits_agreement(v, ref_logits) for k, v in dev_logits.items()}}
+    return out
 
 
 def cpu_baseline_model_all_cores(enc_arrays, feats, budget_s=6.0):
@@ -330,7 +344,11 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_
            "parity": {"quantised_linears": "bit-exact", "attention_bar": 2e-4, "attention_outliers_allowed": 1e-5,
                       "attention_outlier_ceiling_of_rms": 1e-2, "other_f32": 1e-4}}
     fe, cmvn = SenseVoiceFrontend(ctx=ctx), Cmvn(ctx=ctx)
-    enc = Encoder(ctx, args.layers)
+    # damped residual branches (tools/sensevoice_graph.py): kernel times do not depend on the values, and the whole forward can then be held
+    # against the oracle's (`oracle_agreement` below; tests/test_graph_oracle.py)
+    enc = Encoder(ctx, args.layers, damped=True)
+    rec["topology"] += "; residual branches damped (DAMP_BRANCH %.3g, DAMP_V %.3g, DAMP_FIRST %.3g)" % tuple(
+        __import__("sensevoice_graph").__dict__[k] for k in ("DAMP_BRANCH", "DAMP_V", "DAMP_FIRST"))
     skip = np.zeros(VOCAB, np.uint8)          # blank + a block of <|...|> specials, as tokenizer.rs:38-48 marks them
     skip[0] = 1
     skip[VOCAB - 200:] = 1
@@ -469,6 +487,7 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_
                     "rtf_target": 0.001})
         rec["_c3_feats"] = c3["feats"].numpy()
         rec["_enc"] = enc
+        rec["_c3_logits"] = {"shipped": c3["logits"].numpy().copy()}
         # the same two figures with the attention on its bit-exact replica path (LELE_HIP_ATTENTION_EXACT=1: f32 MFMA in the tiled GEMM's
         # k order + the reference's row softmax = the bits of the three-call sequence): graphs re-recorded under the switch
         old = os.environ.get("LELE_HIP_ATTENTION_EXACT")
@@ -497,18 +516,14 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_
                 ex_ids = step_c4x()
             ctx.sync()
             wx = time.perf_counter() - t0
-            la, lb = c4["logits"].numpy().astype(np.float64), c4x["logits"].numpy().astype(np.float64)
-            lrms = float(np.sqrt(np.mean(la * la)))
-            tok = [(int((a[:min(len(a), len(b))] == b[:min(len(a), len(b))]).sum()), max(len(a), len(b))) for a, b in zip(ex_ids, everything)]
+            rec["_c3_logits"]["exact"] = c3x["logits"].numpy().copy()
             rec.update({"rtf_model_exact": round(float(np.mean(tx)) / 30.0, 7), "c3_model_ms_exact": round(1e3 * float(np.mean(tx)), 3),
                         "rtf_c4_exact": round(wx / args.sv_steps / (total * 10), 8), "c4_ms_per_step_exact": round(1e3 * wx / args.sv_steps, 3),
-                        "exact_vs_default_logits_max_abs_diff_over_rms": round(float(np.abs(la - lb).max()) / lrms, 6),
-                        "exact_vs_default_logits_rms_diff_over_rms": round(float(np.sqrt(np.mean((la - lb) ** 2))) / lrms, 6),
-                        "exact_vs_default_equal_token_positions": round(sum(t[0] for t in tok) / max(1, sum(t[1] for t in tok)), 4),
-                        "exact_note": "LELE_HIP_ATTENTION_EXACT=1: attention = the bits of matmul -> softmax -> matmul.  The two paths' logits differ by "
-                                      "the figures beside this note (70 layers of per-utterance DYNAMIC u8 quantisation turn a last-bit difference "
-                                      "into flipped codes); with synthetic weights the 25055 logits of a frame are near-ties, so the arg-max ids "
-                                      "of the two paths agree only where a frame happens to have a clear winner"})
+                        "exact_vs_shipped_c4": logits_agreement(c4["logits"].numpy(), c4x["logits"].numpy()),
+                        "exact_note": "LELE_HIP_ATTENTION_EXACT=1: attention = the bits of matmul -> softmax -> matmul.  `exact_vs_shipped_c4`: the two "
+                                      "device paths against each other (1e-6 apart at every attention output, bit-identical elsewhere) -- the "
+                                      "sensitivity of a 70-layer stack of DYNAMIC u8 quantisers to a last-bit difference, i.e. the floor of any "
+                                      "end-to-end comparison; `oracle_agreement` holds each path against the oracle's forward of configs[2]"})
         finally:
             if old is None:
                 os.environ.pop("LELE_HIP_ATTENTION_EXACT", None)
@@ -1012,9 +1027,9 @@ def run_rank(args):
             "rtf_frontend": round(wall / audio_s, 9),
             "roofline": roof,
         }
-        enc = feats = None
+        enc = feats = dev_logits = None
         if sv is not None:
-            feats, enc = sv.pop("_c3_feats", None), sv.pop("_enc", None)
+            feats, enc, dev_logits = sv.pop("_c3_feats", None), sv.pop("_enc", None), sv.pop("_c3_logits", None)
             line["sensevoice"] = sv
             for k in ("rtf_model", "rtf_e2e", "rtf_c4", "audio_s_per_s", "rtf_model_exact", "rtf_c4_exact"):
                 if k in sv:
@@ -1049,7 +1064,9 @@ def run_rank(args):
             cb = cpu_baseline_frontend(n)
             if enc is not None and feats is not None:
                 from sensevoice_graph import encoder_arrays
-                cb.update(cpu_baseline_model(encoder_arrays(enc), feats))
+                cb.update(cpu_baseline_model(encoder_arrays(enc), feats, dev_logits=dev_logits))
+                if "oracle_agreement" in cb:
+                    line["sensevoice"]["oracle_agreement"] = cb.pop("oracle_agreement")
             line["cpu_baseline"] = cb
             line["cpu_baseline_all_cores"] = cpu_baseline_frontend_all_cores(n)
             if enc is not None and feats is not None:

@@ -1,10 +1,7 @@
-#!/bin/bash
-R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out/r6f; mkdir -p $OUT; cd $R
-timeout 1200 python -m pytest tests -m gpu -x -q > $OUT/tests.log 2>&1; echo "tests rc $?"
-tail -5 $OUT/tests.log
-timeout 600 python bench.py --no-yolo > $OUT/bench.json 2> $OUT/bench.log; echo "bench rc $?"
-python - <<'P'
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+for d in "0.02,0.1,2.0" "0.01,0.05,4.0"; do echo "DAMP $d"; LELE_SV_DAMP=$d python -m pytest tests/test_graph_oracle.py -m gpu -x -q -k sensevoice -s > /dev/null 2>&1; python -c "
 import json
-d=json.loads(open("gpurun_out/r6f/bench.json").read().strip().splitlines()[-1])
-sv=d["sensevoice"]; print({k:sv[k] for k in ("c4_ms_per_step","c3_model_ms","rtf_c4","rtf_model","c4_ms_per_step_exact","plan_statements")})
-P
+d=json.load(open('gpurun_out/sensevoice_graph_oracle.json'))
+for k,v in d.items():
+    if k.startswith('configs'): print(k, round(v['argmax_agreement'],4), round(v['mae_over_rms'],5), round(v['worst_gap_at_a_differing_frame_over_rms'],4))
+"; done
