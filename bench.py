@@ -922,9 +922,17 @@ def run_rank(args):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dist.barrier()
         wall = max_over_ranks(0.001 * (rank + 1), dist, "cpu")
+        # what every rank WOULD open and process: its device (LOCAL_RANK, one per rank), its shard of both sharded legs
+        mine = {"rank": rank, "device": local_rank, "utterances": list(shard_range(args.per_gpu * world, rank, world)),
+                "images": [rank * args.yolo_batch, (rank + 1) * args.yolo_batch]}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
         dist.barrier()
         if rank == 0:
-            print(json.dumps({"metric": "dry-run", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "value": wall}), flush=True)
+            print(json.dumps({"metric": "dry-run", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "value": wall,
+                              "ranks_seen": len(seen), "devices": [m["device"] for m in seen],
+                              "one_device_per_rank": len({m["device"] for m in seen}) == world,
+                              "utterance_shards": [m["utterances"] for m in seen], "image_shards": [m["images"] for m in seen]}), flush=True)
         dist.destroy_process_group()
         return
     dist, device = None, "cpu"
