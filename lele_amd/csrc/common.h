@@ -139,6 +139,9 @@ struct LeleCtx {
     };
     static constexpr int kMaxLanes = 4;
     int lane = 0;                       // the current lane
+    bool side_lanes = false;            // a lane other than 0 has been current since the streams were last drained (sync_all)
+    // quant.hip: arrival counters of the one-launch feed-forward form, one block per grid shape (ncb, nrr); cleared at allocation only
+    std::map<std::pair<int, int>, unsigned*> rs_sync;
     std::vector<LaneState> parked;      // parked[l] = state of lane l while it is not current (entry of the current lane: unused)
     hipStream_t lane_stream[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};  // every lane's OWN stream ([0] = the ctx stream)
     std::vector<hipEvent_t> lane_events;  // lele_hip_lane_record / _wait, eager mode
@@ -168,6 +171,7 @@ struct LeleGraph {
 };
 
 #define LELE_DEVERR_GATHER_INDEX 1u
+#define LELE_DEVERR_FFN_SYNC 2u   // igemm_rs_kernel<3>: a workgroup waited RS_SYNC_LIMIT for its neighbours (they were not resident)
 
 // Developer switches (kernel variants for A/B timing, stamps, ablations) exist in the LAB build only
 
@@ -190,7 +194,7 @@ struct LeleGraph {
 #endif
 
 // (LELE_HIP_LAB=1 python -m lele_amd.build -> liblele_hip_lab.so); in the product library lab_env() is NULL for every name.
-// The product's own run-time switches are the six documented in INTEGRATION.md ("Run-time switches").
+// The product's own run-time switches are the seven documented in INTEGRATION.md ("Run-time switches").
 #ifdef LELE_HIP_LAB
 inline const char* lab_env(const char* name) { return getenv(name); }
 #else
@@ -219,6 +223,7 @@ struct LeleBuf {
 namespace lele {
 // features_ops.hip: power spectrum |FFT|^2 of `rows` real rows of length n_fft (a power of two <= 4096), bit-exact with the
 // reference's radix-2 network; out_power is [rows, n_fft/2 + 1]
+int live_contexts(int device);  // context.hip: contexts of this process alive on `device`
 int fft_rows_power(LeleCtx* ctx, const float* rows_in, int64_t rows, int64_t n_fft, float* out_power);
 
 // quant.hip: dynamic-quantisation parameters of the joint range of several device arrays (16 bytes on the device)

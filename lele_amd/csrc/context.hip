@@ -1,6 +1,7 @@
 // context.hip -- LeleCtx / LeleBuf: stream, staging arena, weight cache, timers.
 #include "common.h"
 
+#include <atomic>
 #include <tuple>
 
 namespace lele {
@@ -51,7 +52,15 @@ int LeleCtx::sync_all() {
     LELE_HIP_CHECK(hipStreamSynchronize(stream));
     for (int l = 0; l < kMaxLanes; ++l)
         if (lane_stream[l] && lane_stream[l] != stream) LELE_HIP_CHECK(hipStreamSynchronize(lane_stream[l]));
+    if (lane == 0 && !capturing) side_lanes = false;
     return 0;
+}
+
+namespace {
+std::atomic<int> g_live_ctx[64];
+}
+namespace lele {
+int live_contexts(int device) { return device >= 0 && device < 64 ? g_live_ctx[device].load() : 2; }
 }
 
 int LeleCtx::capture_deps_get(std::vector<hipGraphNode_t>* out) {
@@ -80,7 +89,10 @@ int LeleCtx::check_deverr(const char* where) {
         *deverr_host = 0;
         LELE_REQUIRE(false, "%s: a kernel reported a data-dependent violation earlier on this stream:%s (the access was clamped; "
                      "lele's bounds-checked indexing panics here, manipulation.rs:626-633)", where,
-                     (bits & LELE_DEVERR_GATHER_INDEX) ? " gather index out of range" : " unknown");
+                     (bits & LELE_DEVERR_GATHER_INDEX) ? " gather index out of range"
+                     : (bits & LELE_DEVERR_FFN_SYNC) ? " a workgroup of the one-launch feed-forward block waited 20 ms for its neighbours -- another "
+                                                        "process is using the device; set LELE_HIP_FFN_ONE_LAUNCH=0 (results of that launch are wrong)"
+                                                      : " unknown");
     }
     return 0;
 }
@@ -216,6 +228,7 @@ int lele_hip_ctx_create(int device, LeleCtx** out) {
     LELE_HIP_CHECK(hipHostMalloc((void**)&c->deverr_host, 64, hipHostMallocMapped));
     *c->deverr_host = 0;
     LELE_HIP_CHECK(hipHostGetDevicePointer((void**)&c->deverr_dev, c->deverr_host, 0));
+    if (device >= 0 && device < 64) ++g_live_ctx[device];
     *out = c;
     return 0;
 }
@@ -244,6 +257,8 @@ int lele_hip_ctx_destroy(LeleCtx* c) {
     for (hipEvent_t e : c->lane_events)
         if (e) (void)hipEventDestroy(e);
     if (c->deverr_host) (void)hipHostFree(c->deverr_host);
+    for (auto& kv : c->rs_sync) (void)hipFree(kv.second);
+    if (c->device >= 0 && c->device < 64) --g_live_ctx[c->device];
     for (void* p : c->arena_overflow) (void)hipFree(p);
     for (auto& kv : c->weights) (void)hipFree(kv.second);
     if (c->arena) (void)hipFree(c->arena);
@@ -352,6 +367,7 @@ int lele_hip_lane_set(LeleCtx* c, int lane) {
     LELE_REQUIRE(c, "lane_set: ctx is NULL");
     LELE_REQUIRE(lane >= 0 && lane < LeleCtx::kMaxLanes, "lane_set: lane %d outside [0, %d)", lane, LeleCtx::kMaxLanes);
     if (lane == c->lane) return 0;
+    if (lane != 0) c->side_lanes = true;
     LELE_HIP_CHECK(hipSetDevice(c->device));
     if (c->parked.size() < (size_t)LeleCtx::kMaxLanes) c->parked.resize(LeleCtx::kMaxLanes);
     LeleCtx::LaneState& dst = c->parked[lane];

@@ -40,6 +40,9 @@ struct RsArgs {
     int nblk;
     unsigned* hpart;       // fused feed-forward block: [grid][4] bits of the hidden layer's maxima per workgroup (its first four slices) --
                            // EM 1 writes them (plain stores: nothing to clear beforehand), EM 2 reduces the ones that concern its rows
+    unsigned* sync;        // EM 3 (both passes in one launch): [64] launch counters, one a row range, never cleared (a launch adds ncb to each);
+                           // behind them [grid][4] 8-byte words {launch tag, bits of the maximum}: what hpart is to EM 1 / 2
+    unsigned* deverr;      // EM 3: the context's sticky error word (a wait that ran out of time: LELE_DEVERR_FFN_SYNC)
 #ifdef LELE_HIP_LAB
     long long* dbg;  // lab build: [grid][9][32] wall-clock stamps (100 MHz) of every wave (wave 8 = the loader), or NULL
     int ablate;      // lab build (results wrong): 1 no products, 2 no epilogue, 4 no fragment reads (products on stale registers)
@@ -265,6 +268,9 @@ __device__ __forceinline__ float rs_value(int acc, int rterm, int ca, int colsum
 constexpr int RS_NS = 5, RS_AHEAD = 3, RS_TILE = 16 * 1024, RS_SLOT = RS_TILE + 4 * 256;  // a slot: the tile's 16 fragment blocks + its row terms
 constexpr int RS_MAXSL = 16;                                          // FQ: slices a workgroup's row range may touch (launch_rs checks)
 constexpr int RS_LDS = RS_NS * RS_SLOT + 3 * 8 * 32 * 4 + 16 + 2 * RS_MAXSL * 16;  // ring + column strips + EM 1 maxima + FQ parameter tables
+// EM 3: every tile of the workgroup keeps its slot (nothing is quantised twice): at most RS_NS_BOTH tiles a workgroup
+constexpr int RS_NS_BOTH = 8;
+constexpr int RS_LDS_BOTH = RS_NS_BOTH * RS_SLOT + 3 * 8 * 32 * 4 + 16 + 2 * RS_MAXSL * 16;
 
 // one direct-to-LDS load of 16 bytes per lane: LDS address = lds_dst (wave-uniform byte address) + 16 * lane.  Inline asm: the
 // compiler's own counter bookkeeping must not see it (it would drain the ring at every barrier)
@@ -295,12 +301,32 @@ __device__ __forceinline__ void rs_barrier() { asm volatile("s_barrier" ::: "mem
 // read and a 2.8 MB write between two kernels of 14 us) and the fragment-major copy of the activation in HBM disappear; each row tile
 // is quantised once per column block (6-8 times over the grid), out of L2.  A loader lane owns 4 consecutive k of one row per load:
 // 16 rows x 64 bytes per wave instruction on the global side, 64 different LDS banks on the ds_write_b32 side.
+//
+// EM 3 (FQ only): the feed-forward block's range pass AND its quantise pass in ONE launch.  The two passes are the same products twice;
+// as two kernels each pays the launch, the weights-in-registers prologue and the loaders' quantisation of every row tile (the
+// knock-outs of DESIGN.md 3.3: 11 of a pass's 17 us).  Here every tile of the workgroup keeps its ring slot (RS_NS_BOTH slots: nothing
+// is overwritten), pass 1 runs as EM 1 does, the workgroup publishes its four maxima -- each as ONE 8-byte word {launch tag, bits of
+// the maximum} written at device scope -- and its loaders read the words of the workgroups whose row range shares a slice with
+// theirs (all their ncb column blocks) until they carry this launch's tag: the wait and the fetch are one load.  They reduce the
+// hidden layer's parameters as EM 2's loaders do, and the consumers run the products again straight out of LDS -- no loader, no
+// barrier between tiles -- into EM 2's epilogue.  Same maxima, same parameters, same codes: bit-identical to the two launches.
+// The tag is the launch number: every launch adds exactly ncb to each row range's counter (g.sync[rr], never cleared), so the value
+// a workgroup's own increment returns (asked for at entry, used after the first pass) divided by ncb is the same for every workgroup.
+// Waiting on other workgroups needs them to be RESIDENT: the grid is at most one workgroup per CU (rs_grid), workgroups are
+// dispatched in index order and a workgroup only waits for row ranges next to its own, so the launch is safe alone on the device;
+// the host side (ffn_impl) takes this route only on lane 0 of the only context of the device with no side lane in flight, and a
+// wait that lasts longer than RS_SYNC_LIMIT sets LELE_DEVERR_FFN_SYNC and goes on (the next sync reports it) instead of hanging.
+constexpr long long RS_SYNC_LIMIT = 20 * 1000 * 100;  // 20 ms of the 100 MHz wall clock
 template <int EM, int NRES, bool RELU, bool FQ = false>
 __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
     constexpr int KS = 16;
+    constexpr bool BOTH = EM == 3;
+    constexpr bool RANGE = EM == 1 || BOTH;   // the workgroup gathers the maxima of its slices
+    constexpr int NS = BOTH ? RS_NS_BOTH : RS_NS;
+    static_assert(!BOTH || FQ, "EM 3 is a form of the quantising-loader kernel");
     extern __shared__ __attribute__((aligned(16))) char rs_lds[];
     char* const ring = rs_lds;
-    int* const s_colsum = reinterpret_cast<int*>(rs_lds + RS_NS * RS_SLOT);  // [8][32] each
+    int* const s_colsum = reinterpret_cast<int*>(rs_lds + NS * RS_SLOT);  // [8][32] each
     float* const s_ws = reinterpret_cast<float*>(s_colsum + 256);
     float* const s_bias = s_ws + 256;
     unsigned* const s_mx = reinterpret_cast<unsigned*>(s_bias + 256);  // [4]
@@ -313,7 +339,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
     const int t0 = (int)((unsigned)rr * (unsigned)g.nrt / (unsigned)g.nrr), t1 = (int)((unsigned)(rr + 1) * (unsigned)g.nrt / (unsigned)g.nrr);
     if (t0 >= t1) return;  // uniform over the workgroup
     const int nt = t1 - t0;
-    if (EM == 1) {  // the workgroup's slice maxima meet here before they go to memory
+    if (RANGE) {  // the workgroup's slice maxima meet here before they go to memory
         if (threadIdx.x < 4) s_mx[threadIdx.x] = 0u;
         __syncthreads();
     }
@@ -334,7 +360,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
             for (int c = 0; c < 16; ++c) dst[c] = *reinterpret_cast<const float4*>(src + 16 * c);
         };
         auto put = [&](int i, const float4 (&src)[16]) {
-            char* const slot = ring + (i % RS_NS) * RS_SLOT;
+            char* const slot = ring + (i % NS) * RS_SLOT;
             unsigned row = (unsigned)(t0 + i) * 32u + 16u * (unsigned)u + (unsigned)rsub;
             row = row < rows ? row : rows - 1u;
             const unsigned rel = single ? 0u : row / mu - s_lo;
@@ -380,33 +406,64 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
         // The parameters of the slices the workgroup's rows belong to, while the first rows travel: loader j takes slices s_lo + j,
         // s_lo + j + 4, ... -- the input's from the producer's {min, max} pairs; EM 2: the hidden layer's from the maxima the range pass's
         // workgroups left (every workgroup whose row range meets the slice, all its column blocks).
+        // the hidden layer's parameters of slice sl from the maxima the range pass's workgroups left: every workgroup whose row range
+        // meets the slice, all its column blocks
+        const unsigned nrt_u = (unsigned)g.nrt, nrr_u = (unsigned)g.nrr, ncb_u = (unsigned)g.ncb;
+        auto range_of = [&](unsigned tile) {  // the row range whose tiles [rr nrt / nrr, (rr + 1) nrt / nrr) hold `tile`
+            unsigned r = tile * nrr_u / nrt_u;
+            while (r + 1u < nrr_u && (r + 1u) * nrt_u / nrr_u <= tile) ++r;
+            while (r > 0u && r * nrt_u / nrr_u > tile) --r;
+            return r;
+        };
+        auto ranges_of_slice = [&](unsigned sl, unsigned& ra, unsigned& rb) {
+            const unsigned r_first = sl * mu, r_last = (sl + 1u) * mu < rows ? (sl + 1u) * mu - 1u : rows - 1u;
+            ra = single ? 0u : range_of(r_first >> 5);
+            rb = single ? nrr_u - 1u : range_of(r_last >> 5);
+        };
+        unsigned tag = 0u;  // EM 3: this launch's number + 1 (set before the first use)
+        auto hidden_params = [&](unsigned sl) {
+            unsigned ra, rb;
+            ranges_of_slice(sl, ra, rb);
+            const unsigned total = (rb - ra + 1u) * ncb_u;
+            float mxh = 0.0f;  // ReLU results: >= 0, never NaN -- their bits order like the values
+            for (unsigned e0 = 0; e0 < total; e0 += 64u) {
+                const unsigned e = e0 + (unsigned)lane;
+                const unsigned ec = e < total ? e : total - 1u;
+                const unsigned r = ra + ec / ncb_u, c = ec - (ec / ncb_u) * ncb_u;
+                const unsigned sb = single ? 0u : ((r * nrt_u / nrr_u) * 32u) / mu;  // that workgroup's first slice
+                const size_t at = (size_t)(r * ncb_u + c) * 4u + (sl - sb);
+                if constexpr (BOTH) {
+                    // written by workgroups of THIS launch, possibly on another XCD: {launch tag, maximum} as ONE 8-byte word, read at
+                    // device scope (past this XCD's L2) until the tag is this launch's -- the wait and the fetch are the same load
+                    const unsigned long long* hp = reinterpret_cast<const unsigned long long*>(g.sync + 64) + at;
+                    const long long started = (long long)wall_clock64();
+                    unsigned long long v;
+                    for (;;) {
+                        v = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__all((unsigned)(v >> 32) == tag)) break;
+                        if ((long long)wall_clock64() - started > RS_SYNC_LIMIT) {
+                            if (lane == 0) atomicOr(g.deverr, 2u);  // LELE_DEVERR_FFN_SYNC (the word lives in host memory)
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                    mxh = fmaxf(mxh, __uint_as_float((unsigned)v));
+                } else {
+                    mxh = fmaxf(mxh, __uint_as_float(g.hpart[at]));
+                }
+            }
+            mxh = wave_allreduce64(mxh, [](float cur, float a) { return fmaxf(cur, a); });
+            const QParams q2 = make_qparams(0.0f, mxh);
+            if (lane == 0) s_q2[sl - s_lo] = make_float4(q2.scale, q2.zp, q2.inv_scale, mxh);
+        };
+        // EM 3: the launch number comes from the row range's counter, which every launch advances by ncb: asked for now, needed after the
+        // first pass
+        unsigned ticket = 0u;
+        if (BOTH && wave == 8 && lane == 0) ticket = __hip_atomic_fetch_add(g.sync + rr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (unsigned sl = s_lo + (unsigned)(wave - 8); sl <= s_hi; sl += 4u) {
             const QParams qs = slice_params(g.partial, g.nblk, sl, lane);
             if (lane == 0) s_prm[sl - s_lo] = make_float4(qs.scale, qs.zp, qs.inv_scale, __int_as_float(qs.zp_i));
-            if (EM == 2) {
-                const unsigned nrt = (unsigned)g.nrt, nrr = (unsigned)g.nrr, ncb = (unsigned)g.ncb;
-                const unsigned r_first = sl * mu, r_last = (sl + 1u) * mu < rows ? (sl + 1u) * mu - 1u : rows - 1u;
-                auto range_of = [&](unsigned tile) {  // the row range whose tiles [rr nrt / nrr, (rr + 1) nrt / nrr) hold `tile`
-                    unsigned r = tile * nrr / nrt;
-                    while (r + 1u < nrr && (r + 1u) * nrt / nrr <= tile) ++r;
-                    while (r > 0u && r * nrt / nrr > tile) --r;
-                    return r;
-                };
-                const unsigned ra = single ? 0u : range_of(r_first >> 5), rb = single ? nrr - 1u : range_of(r_last >> 5);
-                const unsigned total = (rb - ra + 1u) * ncb;
-                float mxh = 0.0f;  // ReLU results: >= 0, never NaN -- their bits order like the values
-                for (unsigned e0 = 0; e0 < total; e0 += 64u) {
-                    const unsigned e = e0 + (unsigned)lane;
-                    if (e < total) {
-                        const unsigned r = ra + e / ncb, c = e - (e / ncb) * ncb;
-                        const unsigned sb = single ? 0u : ((r * nrt / nrr) * 32u) / mu;  // that workgroup's first slice
-                        mxh = fmaxf(mxh, __uint_as_float(g.hpart[(size_t)(r * ncb + c) * 4u + (sl - sb)]));
-                    }
-                }
-                mxh = wave_allreduce64(mxh, [](float cur, float a) { return fmaxf(cur, a); });
-                const QParams q2 = make_qparams(0.0f, mxh);
-                if (lane == 0) s_q2[sl - s_lo] = make_float4(q2.scale, q2.zp, q2.inv_scale, mxh);
-            }
+            if (EM == 2) hidden_params(sl);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         rs_barrier();  // the tables are complete (the consumers take this barrier too)
@@ -419,7 +476,26 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
             if (i + 1 < nt) put(i + 1, RB);
         }
         if ((nt & 1) == 0) rs_barrier();  // an odd tile was the last one
-        if (EM == 1) __syncthreads();
+        if (RANGE) __syncthreads();  // the consumers' maxima are in s_mx
+        if (BOTH) {
+            // Publish the workgroup's four maxima, each with the launch's tag in the upper half of ONE 8-byte word, at device scope (the
+            // stores write through this XCD's L2; nothing is flushed or invalidated for them -- a release / acquire pair at device scope
+            // writes back and invalidates the whole L2: measured, the launch 9 us SLOWER than the two it replaces).  The tag every
+            // workgroup of a row range computes is the same (the counter's old value / ncb), and so is the neighbours' (all counters
+            // advance together), so the loaders below wait for exactly the words this launch writes.
+            ticket = (unsigned)__shfl((int)ticket, 0);
+            if (wave == 8) {
+                tag = ticket / ncb_u + 1u;
+                if (lane < 4)   // slices s_lo .. s_lo + 3 of this workgroup
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(g.sync + 64) + (size_t)L * 4u + (unsigned)lane,
+                                       ((unsigned long long)tag << 32) | s_mx[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                reinterpret_cast<unsigned*>(s_q2 + RS_MAXSL - 1)[3] = tag;  // the other loaders take the tag from here
+            }
+            __syncthreads();  // (the consumers run the first tile's products of the second pass meanwhile)
+            tag = reinterpret_cast<const unsigned*>(s_q2 + RS_MAXSL - 1)[3];
+            for (unsigned sl = s_lo + (unsigned)(wave - 8); sl <= s_hi; sl += 4u) hidden_params(sl);
+            __syncthreads();  // the hidden layer's parameters are in s_q2: the consumers run the second pass on their own
+        }
         return;
     }
     if (!FQ && wave >= 8) {
@@ -434,7 +510,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
         const unsigned rows = g.rows, mu = (unsigned)epi.m, nslices = rows / mu;
         auto issue = [&](int i) {
             const char* src = reinterpret_cast<const char*>(g.af) + (size_t)(t0 + i) * (KS * 1024) + half * (HS * 1024) + lane * 16;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(ring_base + (unsigned)(i % RS_NS) * RS_SLOT);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(ring_base + (unsigned)(i % NS) * RS_SLOT);
 #pragma unroll
             for (int s = 0; s < HS; ++s) rs_dma16(src + s * 1024, dst + (half * HS + s) * 1024);
             if (half == 0) {
@@ -480,7 +556,11 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
     if (ct >= g.nct) {  // a partial last column block: the wave only keeps the barriers company
         if (FQ) rs_barrier();
         for (int i = 0; i < nt; ++i) rs_barrier();
-        if (EM == 1) __syncthreads();
+        if (RANGE) __syncthreads();
+        if (BOTH) {
+            __syncthreads();
+            __syncthreads();
+        }
         return;
     }
     int nstamp = 0;
@@ -514,6 +594,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
     // it -- no branch in the epilogue, so the next tile's products and this tile's epilogue are ONE basic block to the scheduler
     const auto out_rsrc = __builtin_amdgcn_make_buffer_rsrc(EM == 0 ? (void*)epi.out : (void*)epi.q_prm,
                                                             0, EM == 0 ? (int)(rows * (unsigned)n * 4u) : (int)((rows / mu) * 16u), 0x00020000);
+    (void)out_rsrc;
     // EM 1: running maxima of the (up to four) slices the workgroup's row range touches; anything further away goes out at once
     const unsigned sbase = single ? 0u : ((unsigned)t0 * 32u) / mu;
     float mx[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -521,7 +602,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
     // the products of tile i out of its ring slot, and the row terms the loader put behind it (dynamic quantisation is the only
     // caller: epi.prm is never NULL here)
     auto products = [&](int i, v16i& acc, RsRow& r) {
-        const char* const slot = ring + (i % RS_NS) * RS_SLOT;
+        const char* const slot = ring + (i % NS) * RS_SLOT;
         const v4i* ap = reinterpret_cast<const v4i*>(slot) + lane;
         r.rowsum = reinterpret_cast<const int*>(slot + RS_TILE)[l31];
         if (FQ) r.rowsum += reinterpret_cast<const int*>(slot + RS_TILE)[32 + l31];  // the quantising loaders leave one sum per half of k
@@ -555,7 +636,8 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
             if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // at most four fragments read ahead: 16 registers, not 64
         }
     };
-    auto epilogue = [&](int i, const v16i& acc, const RsRow& r) {
+    auto epilogue = [&](auto mode_c, int i, const v16i& acc, const RsRow& r) {
+        constexpr int EMODE = decltype(mode_c)::value;  // the epilogue's own mode: EM 3 runs the one of EM 1, then the one of EM 2
 #ifdef LELE_HIP_LAB
         if (g.ablate & 2) {
             if (acc[0] == 0x12345 && r.rowsum == 77) epi.out[0] = 1.0f;
@@ -567,7 +649,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
         const bool rok = row < rows;
         const unsigned rowc = rok ? row : rows - 1u;
         const unsigned obase = rowc * (unsigned)n + (unsigned)(ct * 32 + 4 * hv);  // rows * n < 2^30 (rs_fits)
-        const unsigned slice = (EM == 0 || single) ? 0u : rowc / mu;
+        const unsigned slice = (EMODE == 0 || single) ? 0u : rowc / mu;
         float4 res1[NRES > 0 ? 4 : 1], res2[NRES > 1 ? 4 : 1];
         if (NRES > 0) {
 #pragma unroll
@@ -580,8 +662,11 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
         }
         const float ds = r.scale;
         QParams q2;
-        if (EM == 2) {
-            if (FQ) q2 = QParams{r.q2_scale, r.q2_zp, r.q2_inv, (int)r.q2_zp};
+        if (EMODE == 2) {
+            if (BOTH) {  // the second pass of EM 3: the loaders left the parameters per slice, not per row of a slot
+                const float4 t = s_q2[slice - sbase];
+                q2 = QParams{t.x, t.y, t.z, (int)t.y};
+            } else if (FQ) q2 = QParams{r.q2_scale, r.q2_zp, r.q2_inv, (int)r.q2_zp};
             else q2 = make_qparams(0.0f, __uint_as_float(r.smax));
         }
         float4 o[4];
@@ -606,7 +691,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
             o[gq].y = val(acc[4 * gq + 1], ds * wsc[4 * gq + 1], biasc[4 * gq + 1]);
             o[gq].z = val(acc[4 * gq + 2], ds * wsc[4 * gq + 2], biasc[4 * gq + 2]);
             o[gq].w = val(acc[4 * gq + 3], ds * wsc[4 * gq + 3], biasc[4 * gq + 3]);
-            if (EM == 0) {
+            if (EMODE == 0) {
                 if (NRES > 0) {
                     o[gq].x = o[gq].x + res1[gq].x, o[gq].y = o[gq].y + res1[gq].y, o[gq].z = o[gq].z + res1[gq].z, o[gq].w = o[gq].w + res1[gq].w;
                     if (NRES > 1)
@@ -620,7 +705,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
                 } else
 #endif
                 __builtin_amdgcn_raw_buffer_store_b128(bits, out_rsrc, rok && cok ? (obase + 8u * gq) * 4u : 0xffffffffu, 0, 0);
-            } else if (EM == 2) {
+            } else if (EMODE == 2) {
                 unsigned p = 0u;
                 p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(o[gq].x, q2.inv_scale, q2.zp), 0, p);
                 p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(o[gq].y, q2.inv_scale, q2.zp), 1, p);
@@ -629,7 +714,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
                 d[gq] = p ^ 0x80808080u;
             }
         }
-        if (EM == 2) {
+        if (EMODE == 2) {
             // a lane holds columns {0-3, 8-11, 16-19, 24-27} + 4 hv of its row; two half-wave exchanges turn that into the 16
             // consecutive columns 16 hv + [0, 16): exactly lane (row, hv)'s bytes of the consumer's fragment block (row tile t, k-step ct)
             const auto r02 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);
@@ -639,7 +724,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
             const v4u qb = {__float_as_uint(q2.scale), __float_as_uint(q2.zp), __float_as_uint(q2.inv_scale), (unsigned)q2.zp_i};
             __builtin_amdgcn_raw_buffer_store_b128(qb, out_rsrc, ct == 0 && hv == 0 && rok && row == slice * mu ? slice * 16u : 0xffffffffu, 0, 0);
         }
-        if (EM == 1) {  // ReLU results: >= 0, NaN became 0; n % 32 == 0 on the two-pass route: every column of the tile exists
+        if (EMODE == 1) {  // ReLU results: >= 0, NaN became 0; n % 32 == 0 on the two-pass route: every column of the tile exists
             float lmax = 0.0f;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) lmax = fmaxf(lmax, fmaxf(fmaxf(o[gq].x, o[gq].y), fmaxf(o[gq].z, o[gq].w)));
@@ -651,7 +736,7 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
             mx[3] = rel == 3u ? fmaxf(mx[3], lmax) : mx[3];
             if (!FQ && rel > 3u && lmax > 0.0f) atomicMax(&epi.slice_max[slice], __float_as_uint(lmax));  // (FQ: launch_rs admits four slices a workgroup)
         }
-        if (EM == 0 && epi.blockstat) {  // one {min, max} pair per (row tile, column tile): LeleBuf::rowstat kind 1
+        if (EMODE == 0 && epi.blockstat) {  // one {min, max} pair per (row tile, column tile): LeleBuf::rowstat kind 1
             float smn = 3.40282347e+38f, smx = -3.40282347e+38f;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq)
@@ -683,20 +768,34 @@ __global__ __launch_bounds__(768) void igemm_rs_kernel(RsArgs g, IgemmEpi epi) {
             for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(bf[s]));  // the weights are in: later tiles wait for nothing of the prologue
         }
         RS_STAMP(0);
-        epilogue(i, acc, r);
+        epilogue(std::integral_constant<int, BOTH ? 1 : EM>(), i, acc, r);
     }
     RS_STAMP(0);
 #ifdef LELE_HIP_LAB
     if (g.dbg && lane == 0) g.dbg[((size_t)blockIdx.x * 9 + wave) * 32 + 31] = clock64() - cyc0;  // shader cycles entry -> end
 #endif
-    if (EM == 1) {
+    if (RANGE) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float v = wave_allreduce64(mx[j], [](float cur, float x) { return fmaxf(cur, x); });
             if (lane == 0 && v > 0.0f) atomicMax(&s_mx[j], __float_as_uint(v));  // non-negative floats order like their bits
         }
         __syncthreads();
-        if (FQ) {
+        if (BOTH) {
+            // loader wave 8 publishes the maxima and waits for the neighbours; then the loaders reduce the hidden layer's parameters
+            RS_STAMP(0);  // the workgroup's maxima are complete
+            __syncthreads();
+            products(0, acc, r);  // the second pass: every tile is still in its slot; the first products need no parameter
+            RS_STAMP(0);
+            __syncthreads();
+            RS_STAMP(0);  // the hidden layer's parameters are in LDS
+            for (int i = 0; i < nt; ++i) {
+                if (i > 0) products(i, acc, r);
+                RS_STAMP(0);
+                epilogue(std::integral_constant<int, 2>(), i, acc, r);
+                RS_STAMP(0);
+            }
+        } else if (FQ) {
             if (threadIdx.x < 4) g.hpart[(size_t)L * 4u + threadIdx.x] = s_mx[threadIdx.x];  // slices sbase .. sbase + 3 of this workgroup
         } else if (threadIdx.x < 4 && s_mx[threadIdx.x]) {
             atomicMax(&epi.slice_max[sbase + threadIdx.x], s_mx[threadIdx.x]);

@@ -734,6 +734,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(OCC
 
 }  // namespace
 #include "igemm_rs.h"
+#include "igemm_big.h"
 namespace {
 
 // ------------------------------------------------------------------------------------------ fragment-major weights (igemm_rs.h)
@@ -958,7 +959,15 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
     else if (force == 14) IGEMM_LAUNCH(128, 64, 4, 2, 128, 4);
     else
 #endif
-    if (b64 < 2 * (int64_t)ctx->num_cus) {
+    // compute-bound shapes (igemm_big.h): long K in whole 128-byte steps, at least half a chip of 256 x 256 results, 16-byte rows
+    if (b_stride == 0 && kp % 128 == 0 && kp >= 1024 && n % 4 == 0 && lab_int("LELE_HIP_IGEMM_BIG", 1) != 0 &&
+        ((rows + 255) / 256) * (((int64_t)n + 255) / 256) * 2 >= (int64_t)ctx->num_cus && ((((uintptr_t)epi.out) | ((uintptr_t)epi.res1) | ((uintptr_t)epi.res2)) & 15) == 0 &&
+        !epi.blockstat) {
+        auto kern = igemm_big_kernel;
+        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), BG_LDS));
+        dim3 grid((unsigned)((n + 255) / 256), (unsigned)((rows + 255) / 256));
+        hipLaunchKernelGGL(kern, grid, dim3(256), BG_LDS, ctx->stream, aq, wt, rows, n, kp, epi);
+    } else if (b64 < 2 * (int64_t)ctx->num_cus) {
         // small problem (SenseVoice at M = 504): 32x32 tiles, K split over the four waves, operands straight from L2
         dim3 grid((unsigned)((n + 31) / 32), (unsigned)((rows + 31) / 32));
         if (kp <= 512)
@@ -1078,11 +1087,39 @@ struct RsFq {  // what the quantising loaders need besides the epilogue's argume
     const float* partial = nullptr;
     int nblk = 0;
     unsigned* hpart = nullptr;
+    unsigned* sync = nullptr;  // EM 3: the row ranges' arrival counters (rs_sync_counters)
 };
+// EM 3 (igemm_rs.h: both passes of the feed-forward block's first product in one launch, workgroups waiting for their neighbours):
+// only where every workgroup of the launch is resident and nothing else of this library can be waiting beside it -- lane 0 of the ONLY
+// live context of the device, no side lane in flight, a grid of at most one workgroup per CU, at most RS_NS_BOTH tiles a workgroup --
+// and only with counters that exist already or can be made now (not while capturing).  LELE_HIP_FFN_ONE_LAUNCH=0 keeps the two launches.
+unsigned* rs_sync_counters(LeleCtx* ctx, int64_t rows, int64_t n) {
+    if (env_int("LELE_HIP_FFN_ONE_LAUNCH", 1) == 0) return nullptr;
+    int ncb = 0, nrr = 0;
+    rs_grid(ctx, rows, n, &ncb, &nrr);
+    const int64_t nrt = (rows + 31) / 32, tiles = (nrt + nrr - 1) / nrr;
+    if (tiles > RS_NS_BOTH || nrr > 64 || ncb * nrr > ctx->num_cus || n % 256 != 0) return nullptr;
+    if (ctx->lane != 0 || ctx->side_lanes || lele::live_contexts(ctx->device) != 1) return nullptr;
+    auto it = ctx->rs_sync.find({ncb, nrr});
+    if (it != ctx->rs_sync.end()) return it->second;
+    if (ctx->capturing) return nullptr;
+    void* p = nullptr;
+    // 64 counters, then one 8-byte word {launch tag, maximum} per workgroup and slice (4 a workgroup): cleared once, never again
+    const size_t bytes = 256 + (size_t)ncb * nrr * 32;
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (p) (void)hipFree(p);
+        return nullptr;
+    }
+    ctx->rs_sync[{ncb, nrr}] = (unsigned*)p;
+    return (unsigned*)p;
+}
 int launch_rs(LeleCtx* ctx, int em, const int8_t* af, const int8_t* wf, int64_t rows, int n, int8_t* hid, const IgemmEpi& epi,
               const RsFq& fq = RsFq()) {
     const float* x_f32 = fq.x;
     RsArgs g{af, wf, (unsigned)rows, n, (int)((rows + 31) / 32), (n + 31) / 32, 0, 0, hid, x_f32, fq.partial, fq.nblk, fq.hpart};
+    g.sync = fq.sync;
+    g.deverr = ctx->deverr_dev;
 #ifdef LELE_HIP_LAB
     g.dbg = nullptr;
     g.ablate = lab_int("LELE_HIP_RS_ABLATE", 0);
@@ -1104,7 +1141,12 @@ int launch_rs(LeleCtx* ctx, int em, const int8_t* af, const int8_t* wf, int64_t 
             hipLaunchKernelGGL(kern, grid, dim3(640), RS_LDS, ctx->stream, g, epi);                   \
         }                                                                                            \
     } while (0)
-    if (em == 1) LELE_RS(1, 0, true);
+    if (em == 3) {
+        LELE_REQUIRE(x_f32 && fq.sync && fq.hpart, "launch_rs: the one-launch form needs the quantising loaders and its counters");
+        auto kern = igemm_rs_kernel<3, 0, true, true>;
+        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), RS_LDS_BOTH));
+        hipLaunchKernelGGL(kern, grid, dim3(768), RS_LDS_BOTH, ctx->stream, g, epi);
+    } else if (em == 1) LELE_RS(1, 0, true);
     else if (em == 2) LELE_RS(2, 0, true);
     else if (epi.relu) {
         if (nres == 0) LELE_RS(0, 0, true);
@@ -1768,6 +1810,7 @@ static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_
             void* hpart = nullptr;
             LELE_TRY(ctx->arena_alloc((size_t)ncb * nrr * 16, &hpart));
             fqa.x = (const float*)dx, fqa.partial = partial, fqa.nblk = nblk, fqa.hpart = (unsigned*)hpart;
+            fqa.sync = rs_sync_counters(ctx, rows, n1);
         } else {
             LELE_TRY(ctx->arena_alloc((size_t)nrt * 512 * 32, &af1));
             LELE_TRY(ctx->arena_alloc((size_t)rows * 4, &rs1));
@@ -1776,12 +1819,22 @@ static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_
                                        (unsigned*)hmax));
         }
         LELE_TRY(qprof_mark(ctx, 2));
+        // (tests) LELE_HIP_FFN_ONE_LAUNCH=2: fail instead of falling back to the two launches, so that a test of the one-launch form tests it
+        LELE_REQUIRE(env_int("LELE_HIP_FFN_ONE_LAUNCH", 1) != 2 || fqa.sync,
+                     "fused_ffn_quantized: LELE_HIP_FFN_ONE_LAUNCH=2, but this call cannot take the one-launch form (K = 512 exactly, 16-byte aligned "
+                     "rows, at most 4 slices and %d row tiles a workgroup, lane 0 of the only context of the device, counters made before a capture)",
+                     RS_NS_BOTH);
         IgemmEpi e1{nullptr, rows, n1, (int)m, (int)k1, (const int*)rs1, fw1.col_sums, (const QParams*)prm1, 0, (int)wz1, (const float*)dws1,
                     (int)ws1_len, b1_len ? (const float*)db1 : nullptr, 1};
         e1.slice_max = (unsigned*)hmax;
-        LELE_TRY(launch_rs(ctx, 1, (const int8_t*)af1, fw1.wf, rows, (int)n1, nullptr, e1, fqa));   // range of the ReLU result per slice
-        e1.q_prm = (QParams*)prm2;
-        LELE_TRY(launch_rs(ctx, 2, (const int8_t*)af1, fw1.wf, rows, (int)n1, (int8_t*)hid, e1, fqa));  // the result again, as the next operand
+        if (fqa.sync) {  // both passes in one launch (igemm_rs.h, EM 3)
+            e1.q_prm = (QParams*)prm2;
+            LELE_TRY(launch_rs(ctx, 3, nullptr, fw1.wf, rows, (int)n1, (int8_t*)hid, e1, fqa));
+        } else {
+            LELE_TRY(launch_rs(ctx, 1, (const int8_t*)af1, fw1.wf, rows, (int)n1, nullptr, e1, fqa));   // range of the ReLU result per slice
+            e1.q_prm = (QParams*)prm2;
+            LELE_TRY(launch_rs(ctx, 2, (const int8_t*)af1, fw1.wf, rows, (int)n1, (int8_t*)hid, e1, fqa));  // the result again, as the next operand
+        }
         IgemmEpi e2{(float*)out->data, rows, n2, (int)m, (int)k2, nullptr, fw2.col_sums, (const QParams*)prm2, 0, (int)wz2,
                     (const float*)dws2, (int)ws2_len, b2_len ? (const float*)db2 : nullptr, apply_relu2, (const float*)dr1, (const float*)dr2};
         // the second product: one column tile a workgroup over a range of row tiles (igemm_rs_ks4_kernel), or -- where the caller wants

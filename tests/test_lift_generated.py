@@ -271,3 +271,5 @@ def test_c5_sixty_four_images_over_eight_contexts(ctx):
                 assert np.array_equal(a, TensorView(o.raw()).numpy()), "image %d on context %d" % (8 * rnd + s, s)
     for c, g, *_ in lanes:
         g.close()
+    for c, *_ in lanes[1:]:       # the extra contexts go now, not whenever the collector finds them: some routes of the library ask
+        c.close()                 # whether theirs is the only context of the device (quant.hip, rs_sync_counters)

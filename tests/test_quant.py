@@ -354,6 +354,90 @@ def test_fused_ffn_is_deterministic_under_repetition(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,m", [(32, 171), (1, 504), (1, 4800), (7, 700), (64, 80), (3, 33 * 32)])
+def test_fused_ffn_one_launch_form_is_bit_identical_to_the_two_launches(ctx, b, m):
+    """igemm_rs_kernel<3>: the range pass and the quantise pass of the feed-forward block's first product in ONE launch -- every row tile
+    stays in LDS, a workgroup publishes its maxima, waits for the row ranges that share a slice with its own and runs the products again.
+    LELE_HIP_FFN_ONE_LAUNCH=2 makes the call fail rather than fall back, =0 keeps the two launches: same bits, equal to the oracle's two
+    calls; slices that straddle row tiles and row ranges (171, 700, 80 rows), one slice over the whole grid (504, 4800), slices of whole
+    tiles; eagerly, under repetition (a workgroup that read a neighbour's maximum too early shows up as one utterance in a few hundred
+    calls) and as replays of a recorded graph (the counters are never cleared: every launch continues where the last one stopped)."""
+    import gc
+    from lele_amd import kernels as K
+    from oracle import pyoracle as O
+    gc.collect()          # contexts other tests dropped without closing them are destroyed now
+    rng = np.random.default_rng(b * 13 + m)
+    w1, w2 = _qw(rng, 512, 2048), _qw(rng, 2048, 512)
+    xh = (rng.standard_normal((b, m, 512)) * rng.uniform(0.3, 3.0, (b, 1, 1))).astype(np.float32)
+    x = ctx.buf().upload(xh)
+    hid = O.fused_quantized_linear(xh, w1[0].arr, w1[1].arr, w1[2].arr, w1[3].arr, True)
+    want = O.fused_quantized_linear(hid, w2[0].arr, w2[1].arr, w2[2].arr, w2[3].arr, False)
+    ob = ctx.buf()
+    with _env(LELE_HIP_FFN_ONE_LAUNCH=0):
+        two = K.fused_ffn_quantized(x, *w1, *w2, False, out=ob, ctx=ctx).numpy().copy()
+    assert np.array_equal(two, want)
+    with _env(LELE_HIP_FFN_ONE_LAUNCH=2):
+        one = K.fused_ffn_quantized(x, *w1, *w2, False, out=ob, ctx=ctx).numpy().copy()
+        assert np.array_equal(one, want), (b, m)
+        bad = [it for it in range(100) if not np.array_equal(K.fused_ffn_quantized(x, *w1, *w2, False, out=ob, ctx=ctx).numpy(), want)]
+        assert not bad, "iterations with different bits: %s" % bad[:10]
+        # another input through the same counters, then a recorded graph of six calls replayed (launch numbers keep counting)
+        x2h = (xh * np.float32(0.37) + np.float32(0.01)).astype(np.float32)
+        x2 = ctx.buf().upload(x2h)
+        hid2 = O.fused_quantized_linear(x2h, w1[0].arr, w1[1].arr, w1[2].arr, w1[3].arr, True)
+        want2 = O.fused_quantized_linear(hid2, w2[0].arr, w2[1].arr, w2[2].arr, w2[3].arr, False)
+        ob2 = ctx.buf()
+        assert np.array_equal(K.fused_ffn_quantized(x2, *w1, *w2, False, out=ob2, ctx=ctx).numpy(), want2)
+        ctx.sync()
+        ctx.graph_begin()
+        for _ in range(3):
+            r1 = K.fused_ffn_quantized(x, *w1, *w2, False, out=ob, ctx=ctx)
+            r2 = K.fused_ffn_quantized(x2, *w1, *w2, False, out=ob2, ctx=ctx)
+        g = ctx.graph_end()
+        for _ in range(20):
+            g.launch()
+        assert np.array_equal(r1.numpy(), want) and np.array_equal(r2.numpy(), want2)
+        g.close()
+
+
+@pytest.mark.gpu
+def test_fused_ffn_one_launch_form_is_not_taken_beside_other_work(ctx):
+    """the one-launch form waits for other workgroups, so it must be alone on the device: with a side lane in flight, on a side lane, or
+    with a second context alive the call takes the two launches (LELE_HIP_FFN_ONE_LAUNCH=2 then fails by name) -- and gives the same bits"""
+    import gc
+    import lele_amd
+    from lele_amd import kernels as K
+    from lele_amd._lib import LeleError
+    gc.collect()
+    rng = np.random.default_rng(3)
+    w1, w2 = _qw(rng, 512, 2048), _qw(rng, 2048, 512)
+    x = ctx.buf().upload(rng.standard_normal((32, 171, 512)).astype(np.float32))
+    ob = ctx.buf()
+    with _env(LELE_HIP_FFN_ONE_LAUNCH=2):
+        want = K.fused_ffn_quantized(x, *w1, *w2, False, out=ob, ctx=ctx).numpy().copy()    # (a buffer that grows drains every lane)
+        ctx.sync()
+        ctx.lane_set(1)
+        try:
+            with pytest.raises(LeleError, match="one-launch"):
+                K.fused_ffn_quantized(x, *w1, *w2, False, ctx=ctx)
+        finally:
+            ctx.lane_set(0)
+        with pytest.raises(LeleError, match="one-launch"):     # lane 1 has been used since the streams were last drained
+            K.fused_ffn_quantized(x, *w1, *w2, False, out=ob, ctx=ctx)
+        ctx.sync()
+        assert np.array_equal(K.fused_ffn_quantized(x, *w1, *w2, False, out=ob, ctx=ctx).numpy(), want)
+        other = lele_amd._lib.Ctx(0)
+        try:
+            with pytest.raises(LeleError, match="one-launch"):
+                K.fused_ffn_quantized(x, *w1, *w2, False, ctx=ctx)
+            with _env(LELE_HIP_FFN_ONE_LAUNCH=1):
+                assert np.array_equal(K.fused_ffn_quantized(x, *w1, *w2, False, ctx=ctx).numpy(), want)
+        finally:
+            other.close()
+        assert np.array_equal(K.fused_ffn_quantized(x, *w1, *w2, False, ctx=ctx).numpy(), want)
+
+
+@pytest.mark.gpu
 def test_gemm_block_statistics_feed_the_next_dynamic_quantisation(ctx):
     """The small-problem GEMM kernels publish one {min, max} pair per workgroup; a single-slice quantised linear that reads
     the result next uses them instead of scanning it.  Same bits as the scan (compared with the call on a host copy)."""
@@ -433,6 +517,31 @@ def test_device_quantized_linear_routes_bit_exact(ctx, orc, shape, relu):
     assert got.shape == ref.shape and np.array_equal(got.numpy(), ref)
     with _env(LELE_HIP_IGEMM_RS=0):  # range pass | row quantisation | tiled i8 GEMM
         assert np.array_equal(Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx).numpy(), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,m,k,n,relu", [
+    (1, 2125, 1024, 3844, False),    # 9 x 16 results of 256 x 256 with ragged last rows AND columns; K = 8 steps of 128 bytes
+    (5, 700, 1152, 2048, True),      # slices that straddle the 256-row results; an odd number of K steps
+    (2, 2048, 2048, 2052, False),    # one column block of four columns only
+])
+def test_compute_bound_i8_gemm_bit_exact(ctx, orc, b, m, k, n, relu):
+    """igemm_big_kernel (csrc/igemm_big.h: 256 x 256 results, both operands by direct-to-LDS loads with the 16-byte chunks permuted on
+    the global side) takes the i8 products with K a multiple of 128 >= 1024 and at least half a chip of results: the fused quantised
+    linear (dynamic range per slice, scale + bias + ReLU, residual operands) and mat_mul_integer on it are bit-exact against the oracle"""
+    from lele_amd import kernels as Kk
+    rng = np.random.default_rng(b * 1000 + m + k + n)
+    x = (rng.standard_normal((b, m, k)) * rng.uniform(0.5, 3.0, (b, 1, 1))).astype(np.float32)
+    w = _qw(rng, k, n)
+    ref = orc.fused_quantized_linear(x, w[0].arr, w[1].arr, [128.0], w[3].arr, relu)
+    xd = ctx.buf().upload(x)
+    got = Kk.fused_quantized_linear(xd, *w, relu, ctx=ctx)
+    assert got.shape == ref.shape and np.array_equal(got.numpy(), ref)
+    r1, r2 = rng.standard_normal(ref.shape).astype(np.float32), rng.standard_normal(ref.shape).astype(np.float32)
+    assert np.array_equal(Kk.fused_quantized_linear_residual(xd, *w, relu, r1, r2, ctx=ctx).numpy(), (ref + r1) + r2)
+    a = rng.integers(0, 256, (b * m, k)).astype(np.float32)
+    want = ((a.astype(np.float64) - 131.0) @ (w[0].arr.astype(np.float64) - 127.0)).astype(np.float32)   # exact: |total| < 2^31
+    assert np.array_equal(Kk.mat_mul_integer(a, w[0], [131.0], [127.0], ctx=ctx).numpy(), want)
 
 
 @pytest.mark.gpu

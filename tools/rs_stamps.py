@@ -24,7 +24,7 @@ def main():
                 Weight((np.abs(rng.standard_normal(nn)) * 0.01 + 0.002).astype(np.float32)), Weight(np.array([128.0], np.float32)),
                 Weight((rng.standard_normal(nn) * 0.02).astype(np.float32)))
     for name, n, em in (("qkv (EM 0)", 1536, 0), ("out + 2 residuals (EM 0)", 512, 0), ("ffn hidden, range pass (EM 1)", 2048, 1),
-                        ("ffn hidden, quantise pass (EM 2)", 2048, 2)):
+                        ("ffn hidden, quantise pass (EM 2)", 2048, 2), ("ffn hidden, both passes in one launch (EM 3)", 2048, 3)):
         b, m, k = 32, 171, 512
         x = ctx.buf().upload(rng.standard_normal((b, m, k)).astype(np.float32))
         g, be = Weight(np.ones(k, np.float32)), Weight(np.zeros(k, np.float32))
@@ -38,6 +38,7 @@ def main():
             call = lambda: K.fused_quantized_linear_residual(xn, *w, False, r1, r1, out=ob, ctx=ctx)
         else:
             call = lambda: K.fused_quantized_linear(xn, *w, False, out=ob, ctx=ctx)
+        os.environ["LELE_HIP_FFN_ONE_LAUNCH"] = "2" if em == 3 else "0"
         for _ in range(3):
             call()
         ctx.sync()
