@@ -961,12 +961,23 @@ int launch_igemm(LeleCtx* ctx, const int8_t* aq, const int8_t* wt, int64_t rows,
 #endif
     // compute-bound shapes (igemm_big.h): long K in whole 128-byte steps, at least half a chip of 256 x 256 results, 16-byte rows
     if (b_stride == 0 && kp % 128 == 0 && kp >= 1024 && n % 4 == 0 && lab_int("LELE_HIP_IGEMM_BIG", 1) != 0 &&
+        rows * kp < (int64_t(1) << 32) && (int64_t)n * kp < (int64_t(1) << 32) &&
         ((rows + 255) / 256) * (((int64_t)n + 255) / 256) * 2 >= (int64_t)ctx->num_cus && ((((uintptr_t)epi.out) | ((uintptr_t)epi.res1) | ((uintptr_t)epi.res2)) & 15) == 0 &&
         !epi.blockstat) {
-        auto kern = igemm_big_kernel;
-        LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), BG_LDS));
         dim3 grid((unsigned)((n + 255) / 256), (unsigned)((rows + 255) / 256));
-        hipLaunchKernelGGL(kern, grid, dim3(256), BG_LDS, ctx->stream, aq, wt, rows, n, kp, epi);
+        if (lab_int("LELE_HIP_IGEMM_BIG", 1) == 2) {   // (lab) four waves of 128 x 128
+            auto kern = igemm_big_kernel<2>;
+            LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), BG_LDS));
+            hipLaunchKernelGGL(kern, grid, dim3(256), BG_LDS, ctx->stream, aq, wt, rows, n, kp, epi);
+        } else if (lab_int("LELE_HIP_IGEMM_BIG", 1) == 3) {   // (lab) eight waves of 128 x 64, operands through staging registers
+            auto kern = igemm_big_kernel<4>;
+            LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), BG_LDS));
+            hipLaunchKernelGGL(kern, grid, dim3(512), BG_LDS, ctx->stream, aq, wt, rows, n, kp, epi);
+        } else {
+            auto kern = igemm_big_kernel<4, true>;
+            LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(kern), BG_LDS));
+            hipLaunchKernelGGL(kern, grid, dim3(512), BG_LDS, ctx->stream, aq, wt, rows, n, kp, epi);
+        }
     } else if (b64 < 2 * (int64_t)ctx->num_cus) {
         // small problem (SenseVoice at M = 504): 32x32 tiles, K split over the four waves, operands straight from L2
         dim3 grid((unsigned)((n + 31) / 32), (unsigned)((rows + 31) / 32));

@@ -209,7 +209,22 @@ def test_c5_lookalike_graph_batch_64_against_the_oracle_forward(ctx):
         exact, t = _compare_image(outs, taps, i, ref, rt, srcs, first, "look-alike")
         print("look-alike image %d: %d rows decided and equal row for row, %d rows inside near-ties of the oracle's own scores" % (i, exact, t))
         tied += t
-    assert tied <= 2 * 285     # printed above; every tied row passed the identity / content / rank checks, the others ARE the oracle's rows
+        _rows_record("look-alike image %d" % i, exact, t)
+    assert tied <= MAX_TIED_LOOKALIKE     # every tied row passed the identity / content / rank checks, the others ARE the oracle's rows
+
+
+# Rows of the 300 detections per image that sit inside near-ties of the ORACLE'S OWN scores (so that "the oracle's row at this rank" is
+# not defined to the tolerance), summed over the two images compared.  The bounds are what the builder's runs printed
+# (profiles/r06_graph_oracle_rows.json) plus a margin of 20 rows: a regression that blurs more ranks fails here.
+MAX_TIED_LOOKALIKE, MAX_TIED_GENERATED = 247 + 262 + 20, 244 + 255 + 20
+
+
+def _rows_record(what, decided, tied):
+    path = os.path.join(ROOT, "gpurun_out", "graph_oracle_rows.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    rec = json.load(open(path)) if os.path.exists(path) else {}
+    rec[what] = {"rows_decided_and_equal": int(decided), "rows_inside_near_ties": int(tied)}
+    json.dump(rec, open(path, "w"), indent=1)
 
 
 @pytest.mark.gpu
@@ -251,7 +266,8 @@ def test_c5_reference_generated_graph_batch_64_against_the_oracle_forward(ctx):
         exact, t = _compare_image(outs, taps, i, ref, rt, srcs, first, "generated graph")
         print("generated graph image %d: %d rows decided and equal row for row, %d rows inside near-ties of the oracle's own scores" % (i, exact, t))
         tied += t
-    assert tied <= 2 * 285
+        _rows_record("generated graph image %d" % i, exact, t)
+    assert tied <= MAX_TIED_GENERATED
 
 
 # ------------------------------------------------------------------------------------------------ configs[2] / configs[3]: the whole recogniser

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--compute-bound", action="store_true",
                     help="VERDICT r5 item 6: one slice of M rows, M in {8192, 32768}, K in {512, 2048, 4096}, N in {2048, 4096}: what "
                          "the i8 cores reach when K is not 512 (fused op with its dynamic quantisation, and mat_mul_integer alone)")
+    ap.add_argument("--shapes", default="", help="with --compute-bound: only these MxKxN (comma-separated), e.g. 8192x4096x4096")
     args = ap.parse_args()
     if args.compute_bound:
         return compute_bound(args)
@@ -126,6 +127,8 @@ def compute_bound(args):
     for m in (8192, 32768):
         for k in (512, 2048, 4096):
             for n in (2048, 4096):
+                if args.shapes and "%dx%dx%d" % (m, k, n) not in args.shapes.split(","):
+                    continue
                 x = ctx.buf().upload(rng.standard_normal((1, m, k)).astype(np.float32))
                 wq = np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32)
                 w = (Weight(wq), Weight((np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32)),
