@@ -705,6 +705,33 @@ def cpu_baseline_yolo_graph(lifted):
                       % (runs, ref.calls, runs * dt)}
 
 
+def native_runner_leg(plan, blob, images, want, runs):
+    """the SAME plan (folded: channel views, windows, conv2d_res; lane-scheduled when the DAG was taken) through lele_run, the native host
+    (lele_amd/host: C++ over the C ABI, no Python, no torch): its own process, its own context, one recorded hipGraph replayed `runs` times"""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "lele_amd", "lele_run")
+    if not os.path.exists(exe):
+        return {"ran": False, "why": "lele_amd/lele_run is not built"}
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            json.dump(plan, open(os.path.join(d, "plan.json"), "w"))
+            open(os.path.join(d, "weights.bin"), "wb").write(blob)
+            images.tofile(os.path.join(d, "images.bin"))
+            cmd = [exe, os.path.join(d, "plan.json"), os.path.join(d, "weights.bin"), "--out", os.path.join(d, "out"), "--input",
+                   "images=%s:f32:%s" % (os.path.join(d, "images.bin"), ",".join(map(str, images.shape))), "--runs", str(runs), "--graph"]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            if r.returncode != 0:
+                return {"ran": False, "why": r.stderr[-400:]}
+            rec = json.loads(r.stdout.strip().splitlines()[-1])
+            got = [np.fromfile(os.path.join(d, "out%d.bin" % k), np.float32).reshape(shape) for k, shape in enumerate(rec["outputs"])]
+            return {"ran": True, "plan_format": plan.get("format"), "lanes": plan.get("dag", {}).get("lanes", 1), "kernel_calls": rec["kernel_calls"],
+                    "graph_ms": round(rec["graph_ms"], 3), "eager_ms": round(rec["eager_ms"], 3),
+                    "equals_python_runner_bitwise": bool(len(got) == len(want) and all(np.array_equal(a, b) for a, b in zip(got, want)))}
+    except Exception as e:  # noqa: BLE001
+        return {"ran": False, "why": "failed: %s" % e}
+
+
 def yolo_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_note=None, ranks_seen=None):
     """BASELINE configs[4], batch `--yolo-batch` per GPU, one hipGraph a forward.  Two networks:
       * the reference's OWN generated Yolo26n-seg call sequence (examples/yolo26n-seg/src/yolo26seg.rs: 118 convolutions, 9.127 GFLOP an
@@ -826,6 +853,8 @@ def yolo_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_note=N
                 worst = max(worst, bars(a[..., 4], b[i:i + 1][..., 4]) if a.ndim == 3 else bars(a, b[i:i + 1]))
         look.update({"images_checked_against_the_batch_1_plan": 2, "max_error_in_units_of_1e-4": round(worst, 4), "per_image_check_ok": bool(worst <= 1.0)})
     graph.close()
+    if rank == 0 and world == 1 and not args.no_native:
+        look["native_runner"] = native_runner_leg(runner.plan, blob, images, base, args.yolo_runs)
     head, head_outs, head_name = look, outs, "look-alike"
 
     # ---- the reference's own generated graph, where the lifted plan is present (every rank runs it on its own images)
@@ -862,7 +891,7 @@ def yolo_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_note=N
     if head_name == "reference":
         rec["lookalike"] = {k: look[k] for k in ("model", "convolutions", "gflop_per_image", "plan_calls", "dag", "ms_per_forward", "ms_per_forward_hip_events_rank0",
                                                  "images_per_s", "tflops_f32_per_gpu", "roofline", "max_error_in_units_of_1e-4", "per_image_check_ok",
-                                                 "graph_equals_eager_bitwise") if k in look}
+                                                 "graph_equals_eager_bitwise", "native_runner") if k in look}
     elif ref is not None:
         rec["reference_graph"] = ref
     # parity of what runs here (tests/): convolutions 1e-4 against the oracle; whole graphs at batch 64 against the oracle's forward
@@ -1157,6 +1186,7 @@ def main():
     ap.add_argument("--no-model", action="store_true", help="skip the SenseVoice-shaped recogniser legs")
     ap.add_argument("--no-yolo", action="store_true", help="skip the configs[4] leg")
     ap.add_argument("--no-dag", action="store_true", help="configs[4]: record the plans as linear graphs (default: independent branches on lanes, lele_amd/lanes.py)")
+    ap.add_argument("--no-native", action="store_true", help="configs[4]: skip the replay of the look-alike's plan through the native host (lele_amd/lele_run)")
     ap.add_argument("--yolo-batch", type=int, default=64, help="configs[4]: 640 x 640 images per GPU per forward")
     ap.add_argument("--yolo-runs", type=int, default=10, help="configs[4]: timed forwards after 3 warm-up ones (examples/yolo26n-seg/src/benchmark.rs:29-56)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -117,6 +117,7 @@ class Buffer {
     Buffer& operator=(const Buffer&) = delete;
     LeleBuf* raw() const { return h_; }
     void* data() const { return lele_hip_buf_data(h_); }
+    void reserve(size_t bytes) { check(lele_hip_buf_reserve(h_, bytes)); }   // the enclosing tensor of windowed results (LelePitch)
     void upload(const void* src, size_t bytes) { check(lele_hip_buf_from_host(h_, src, bytes)); }
     void download(void* dst, size_t bytes) const { check(lele_hip_buf_to_host(h_, dst, bytes)); }
 
@@ -165,6 +166,30 @@ class TensorView {
         t.buf_ = &buf;
         return t;
     }
+    // A CHANNEL VIEW of a device tensor (include/lele_hip.h, LelePitch): the tensor starts `offset` elements into the buffer and image n
+    // (index along axis 0) starts n * pitch elements after image 0; inside an image it is dense.  Only the *_pitched entry points (and
+    // conv2d_res) accept views; `pitch` == 0 and `offset` == 0: dense.
+    static TensorView from_device(const Buffer& buf, std::vector<int64_t> shape, int dtype, int64_t offset, int64_t pitch) {
+        TensorView t = from_device(buf, std::move(shape), dtype);
+        int64_t per = 1;
+        for (size_t i = 1; i < t.shape.size(); ++i) per *= t.shape[i];
+        t.offset_ = offset;
+        t.pitch_ = (pitch == per && offset == 0) ? 0 : pitch;   // the whole tensor: dense
+        return t;
+    }
+    bool is_view() const { return pitch_ != 0 || offset_ != 0; }
+    int64_t offset() const { return offset_; }
+    int64_t pitch() const { return pitch_; }
+    const Buffer* buffer() const { return buf_; }
+    TensorView channels(int64_t c0, int64_t c1) const {   // channels [c0, c1) of a rank >= 2 device tensor, no copy
+        if (mem_ != LELE_MEM_DEVICE || !buf_ || shape.size() < 2 || c0 < 0 || c1 > shape[1] || c0 > c1)
+            throw Error("TensorView::channels: a device tensor of rank >= 2 and 0 <= c0 <= c1 <= C expected");
+        int64_t inner = 1;
+        for (size_t i = 2; i < shape.size(); ++i) inner *= shape[i];
+        std::vector<int64_t> s = shape;
+        s[1] = c1 - c0;
+        return from_device(*buf_, std::move(s), dtype_, offset_ + c0 * inner, pitch_ ? pitch_ : shape[1] * inner);
+    }
     int64_t size() const {
         int64_t n = 1;
         for (int64_t d : shape) n *= d;
@@ -174,11 +199,17 @@ class TensorView {
     int dtype() const { return dtype_; }
     bool is_empty() const { return data_ == nullptr; }
     TensorView with_shape(std::vector<int64_t> s) const {  // view ops share the data (shape.rs:2-13)
+        if (is_view()) throw Error("reshape of a channel view: copy it out first (copy_view)");
         TensorView t = *this;
         t.shape = std::move(s);
         return t;
     }
-    LeleTensor c() const { return LeleTensor{data_, shape.data(), (int32_t)shape.size(), dtype_, mem_}; }
+    LeleTensor c() const {
+        const void* d = data_;
+        if (mem_ == LELE_MEM_DEVICE && buf_ && offset_)
+            d = (const char*)buf_->data() + (size_t)offset_ * (dtype_ == LELE_I64 ? 8 : (dtype_ == LELE_U8 || dtype_ == LELE_I8) ? 1 : 4);
+        return LeleTensor{d, shape.data(), (int32_t)shape.size(), dtype_, mem_};
+    }
     template <class T>
     std::vector<T> to_vec() const {  // `.data` in Rust: host copy (D2H for device results)
         if (dtype_of<T>::value != dtype_) throw Error("TensorView::to_vec: dtype mismatch");
@@ -186,6 +217,16 @@ class TensorView {
         if (v.empty()) return v;
         if (mem_ == LELE_MEM_DEVICE) {
             if (!buf_) throw Error("TensorView::to_vec: device view without a buffer");
+            if (is_view()) {   // a channel view: the span that holds it, then image by image
+                const int64_t n = shape[0];
+                int64_t per = 1;
+                for (size_t i = 1; i < shape.size(); ++i) per *= shape[i];
+                const int64_t pitch = pitch_ ? pitch_ : per;
+                std::vector<T> flat((size_t)(offset_ + (n - 1) * pitch + per));
+                buf_->download(flat.data(), flat.size() * sizeof(T));
+                for (int64_t i = 0; i < n; ++i) std::memcpy(v.data() + i * per, flat.data() + offset_ + i * pitch, (size_t)per * sizeof(T));
+                return v;
+            }
             buf_->download(v.data(), v.size() * sizeof(T));
         } else {
             std::memcpy(v.data(), data_, v.size() * sizeof(T));
@@ -199,6 +240,7 @@ class TensorView {
     int dtype_ = LELE_F32;
     int mem_ = LELE_MEM_HOST;
     const Buffer* buf_ = nullptr;
+    int64_t offset_ = 0, pitch_ = 0;   // channel view (elements); both 0: dense
 };
 
 namespace detail {
@@ -619,6 +661,78 @@ inline TensorView resize_nearest(const TensorView& x, int64_t out_h, int64_t out
     LeleTensor tx = x.c();
     check(lele_hip_resize_nearest(ctx(), &tx, out_h, out_w, asymmetric, out.raw(), sh.dims, &sh.rank));
     LELE_RET(out, LELE_F32);
+}
+// ---- channel views (include/lele_hip.h, LelePitch): operands that are views of a wider tensor, results written into a window of an
+// already reserved one.  `Window` = (offset, pitch) in elements of the destination; NULL: a dense result, the buffer is resized.
+struct Window {
+    int64_t offset = 0, pitch = 0;
+};
+namespace pv_detail {
+inline LelePitch pitch_of(const TensorView* x, const TensorView* y, const Window* w) {
+    return LelePitch{x ? x->pitch() : 0, y ? y->pitch() : 0, w ? w->offset : 0, w ? w->pitch : 0};
+}
+inline TensorView windowed(Buffer& out, const Shape& sh, const LelePitch& pv, int dt = LELE_F32) {
+    return TensorView::from_device(out, sh.vec(), dt, pv.out_offset, pv.out_pitch);
+}
+}  // namespace pv_detail
+inline TensorView copy_view(const TensorView& x, Buffer& out, const Window* w = nullptr) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    const LelePitch pv = pv_detail::pitch_of(&x, nullptr, w);
+    check(lele_hip_copy_pitched(ctx(), &tx, &pv, out.raw(), sh.dims, &sh.rank));
+    return pv_detail::windowed(out, sh, pv, x.dtype());
+}
+inline TensorView transpose_cp(const TensorView& x, Buffer& out, const Window* w = nullptr) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    const LelePitch pv = pv_detail::pitch_of(&x, nullptr, w);
+    check(lele_hip_transpose_cp_pitched(ctx(), &tx, &pv, out.raw(), sh.dims, &sh.rank));
+    return pv_detail::windowed(out, sh, pv);
+}
+inline TensorView binary_pitched(int op, const TensorView& a, const TensorView& b, Buffer& out, const Window* w = nullptr) {
+    Shape sh;
+    LeleTensor ta = a.c(), tb = b.c();
+    const LelePitch pv = pv_detail::pitch_of(&a, &b, w);
+    check(lele_hip_binary_pitched(ctx(), op, &ta, &tb, &pv, out.raw(), sh.dims, &sh.rank));
+    return pv_detail::windowed(out, sh, pv);
+}
+inline TensorView resize_nearest_pitched(const TensorView& x, int64_t out_h, int64_t out_w, bool asymmetric, Buffer& out, const Window* w = nullptr) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    const LelePitch pv = pv_detail::pitch_of(&x, nullptr, w);
+    check(lele_hip_resize_nearest_pitched(ctx(), &tx, out_h, out_w, asymmetric, &pv, out.raw(), sh.dims, &sh.rank));
+    return pv_detail::windowed(out, sh, pv);
+}
+inline TensorView max_pool2d_pitched(const TensorView& x, const std::vector<int64_t>& kernel_shape, const std::vector<int64_t>& strides,
+                                     const std::vector<int64_t>& pads, const std::vector<int64_t>& dilations, bool ceil_mode, Buffer& out,
+                                     const Window* w = nullptr) {
+    Shape sh;
+    LeleTensor tx = x.c();
+    const LelePitch pv = pv_detail::pitch_of(&x, nullptr, w);
+    check(lele_hip_max_pool2d_pitched(ctx(), &tx, kernel_shape.data(), kernel_shape.size(), strides.data(), strides.size(), pads.data(), pads.size(),
+                                      dilations.data(), dilations.size(), ceil_mode, &pv, out.raw(), sh.dims, &sh.rank));
+    return pv_detail::windowed(out, sh, pv);
+}
+inline TensorView conv2d_pitched(const TensorView& x, const TensorView& wt, const TensorView* bias, const std::vector<int64_t>& dilations, int64_t group,
+                                 const std::vector<int64_t>& pads, const std::vector<int64_t>& strides, int act, Buffer& out, const Window* w = nullptr) {
+    Shape sh;
+    LeleTensor tx = x.c(), tw = wt.c();
+    Opt ob(bias);
+    const LelePitch pv = pv_detail::pitch_of(&x, nullptr, w);
+    check(lele_hip_conv2d_pitched(ctx(), &tx, &tw, ob.p, dilations.data(), dilations.size(), group, pads.data(), pads.size(), strides.data(), strides.size(),
+                                  act, &pv, out.raw(), sh.dims, &sh.rank));
+    return pv_detail::windowed(out, sh, pv);
+}
+inline TensorView conv2d_res_pitched(const TensorView& x, const TensorView& wt, const TensorView* bias, const TensorView& res,
+                                     const std::vector<int64_t>& dilations, int64_t group, const std::vector<int64_t>& pads,
+                                     const std::vector<int64_t>& strides, int act, Buffer& out, const Window* w = nullptr) {
+    Shape sh;
+    LeleTensor tx = x.c(), tw = wt.c(), tr = res.c();
+    Opt ob(bias);
+    const LelePitch pv = pv_detail::pitch_of(&x, &res, w);
+    check(lele_hip_conv2d_res(ctx(), &tx, &tw, ob.p, &tr, dilations.data(), dilations.size(), group, pads.data(), pads.size(), strides.data(),
+                              strides.size(), act, &pv, out.raw(), sh.dims, &sh.rank));
+    return pv_detail::windowed(out, sh, pv);
 }
 struct TopkOut {
     TensorView values, indices;

@@ -1,4 +1,5 @@
-// plan_runner.hpp -- native execution of a compiled plan (lele_amd.compiler output, format "lele_amd.plan/2").
+// plan_runner.hpp -- native execution of a compiled plan (lele_amd.compiler output, format "lele_amd.plan/2"; "/3" = the same after
+// lele_amd.plan.fold_channel_views: channel views, windows, conv2d_res).
 //
 // The compiled counterpart of lele's generated `forward()`: lele's compiler emits Rust that is then compiled; here the
 // same decisions are data (plan JSON + weights.bin in lele's layout, src/compiler/mod.rs:1381-1505) and this header
@@ -604,11 +605,12 @@ class Runner {
         plan_ = JsonParser(plan_json).parse();
         // "lele_amd.plan/2": compiled from ONNX (lele_amd.compiler); no format tag: lifted from lele-generated Rust
         // (tools/lift_generated.py) -- weights keyed by byte offset, output buffers named inside the argument lists
-        v2_ = plan_.has("format") && plan_.at("format").str == "lele_amd.plan/2";
-        // "lele_amd.plan/3" (plan.fold_channel_views: channel views, windows, conv2d_res) is a shape-specialised form for the batch
-        // graphs of the Python runner; this runner executes the plan it was folded from
+        // "lele_amd.plan/3": /2 after plan.fold_channel_views -- channel views (`chview`), Concat buffers sized up front (`reserve`),
+        // results written into windows of them (`window` on a call), conv2d_res / copy_view / transpose_cp: the shape-specialised batch
+        // form bench.py times.  Same weights keys as /2.
+        v2_ = plan_.has("format") && (plan_.at("format").str == "lele_amd.plan/2" || plan_.at("format").str == "lele_amd.plan/3");
         if (plan_.has("format") && !v2_)
-            throw Error("plan format \"" + plan_.at("format").str + "\" is not supported by the native runner (it runs lele_amd.plan/2 and lifted plans)");
+            throw Error("plan format \"" + plan_.at("format").str + "\" is not supported by the native runner (it runs lele_amd.plan/2, /3 and lifted plans)");
         std::ifstream f(weights_path, std::ios::binary);
         if (!f) throw Error("cannot open " + weights_path);
         blob_.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
@@ -829,6 +831,23 @@ class Runner {
                 env_[st.at("out").arr[0].str] = v;
             } else if (op == "alias") {
                 env_[st.at("out").arr[0].str] = env_.at(st.at("src").str);
+            } else if (op == "reserve") {   // the buffer of a Concat whose operands are written in place (fold_channel_views)
+                Buffer& b = *slots_.at(st.at("slots").arr.at(0).str);
+                std::vector<int64_t> shape;
+                int64_t n = 1;
+                for (const Json& d : st.at("shape").arr) shape.push_back(d.as_int()), n *= d.as_int();
+                b.reserve((size_t)n * 4);
+                Val v;
+                v.kind = Val::Tensor;
+                v.t = TV::from_device(b, shape, LELE_F32);
+                env_[st.at("out").arr[0].str] = v;
+            } else if (op == "chview") {    // channels [c0, c1) of a device tensor, no copy
+                const Val& src = ref(st.at("src").str);
+                if (src.kind != Val::Tensor) throw Error("plan: chview of a value that is not a tensor");
+                Val v;
+                v.kind = Val::Tensor;
+                v.t = src.t.channels(st.at("c0").as_int(), st.at("c1").as_int());
+                env_[st.at("out").arr[0].str] = v;
             } else throw Error("plan: statement kind '" + op + "' is not supported by the native runner");
         }
     }
@@ -959,7 +978,46 @@ class Runner {
             env_[st.at("out").arr[0].str] = v;
             return;
         }
-        Buffer& o = slot(st, 0);
+        // ---- channel views: a result that is a window of an already reserved tensor, and / or operands that are views (plan/3)
+        kernels::Window win, *pw = nullptr;
+        Buffer* wbuf = nullptr;
+        if (st.has("window")) {
+            const Val& whole = ref(st.at("window").at("of").str);
+            if (whole.kind != Val::Tensor || !whole.t.buffer() || whole.t.dim() < 2) throw Error("plan: the window of '" + fn + "' is not inside a device tensor");
+            int64_t inner = 1;
+            for (size_t i = 2; i < whole.t.shape.size(); ++i) inner *= whole.t.shape[i];
+            win.offset = whole.t.offset() + st.at("window").at("c0").as_int() * inner;
+            win.pitch = whole.t.pitch() ? whole.t.pitch() : whole.t.shape[1] * inner;
+            pw = &win;
+            wbuf = const_cast<Buffer*>(whole.t.buffer());
+        }
+        auto dest = [&]() -> Buffer& { return wbuf ? *wbuf : slot(st, 0); };
+        auto viewed = [&](std::initializer_list<size_t> which) {
+            if (pw) return true;
+            for (size_t k : which)
+                if (a[k].has("ref")) {
+                    const Val& v = ref(a[k].at("ref").str);
+                    if (v.kind == Val::Tensor && v.t.is_view()) return true;
+                }
+            return false;
+        };
+        if (fn == "copy_view") return set(st, 0, K::copy_view(tensor(a[0]), dest(), pw));
+        if (fn == "transpose_cp") return set(st, 0, K::transpose_cp(tensor(a[0]), dest(), pw));
+        if (fn == "conv2d_res")
+            return set(st, 0, K::conv2d_res_pitched(tensor(a[0]), tensor(a[1]), opt(a[2], h0), tensor(a[3]), ints(a[4]), integer(a[5]), ints(a[6]), ints(a[7]),
+                                                    (int)integer(a[8]), dest(), pw));
+        if ((fn == "conv2d" || fn == "conv2d_silu" || fn == "conv2d_fused") && viewed({0})) {
+            const int act = fn == "conv2d_silu" ? LELE_ACT_SILU : (fn == "conv2d_fused" && boolean(a[7])) ? LELE_ACT_RELU : LELE_ACT_NONE;
+            return set(st, 0, K::conv2d_pitched(tensor(a[0]), tensor(a[1]), opt(a[2], h0), ints(a[3]), integer(a[4]), ints(a[5]), ints(a[6]), act, dest(), pw));
+        }
+        if ((fn == "add" || fn == "sub" || fn == "mul" || fn == "div") && viewed({0, 1})) {
+            const int bop = fn == "add" ? LELE_B_ADD : fn == "sub" ? LELE_B_SUB : fn == "mul" ? LELE_B_MUL : LELE_B_DIV;
+            return set(st, 0, K::binary_pitched(bop, tensor(a[0]), tensor(a[1]), dest(), pw));
+        }
+        if (fn == "max_pool2d" && viewed({0}))
+            return set(st, 0, K::max_pool2d_pitched(tensor(a[0]), ints(a[1]), ints(a[2]), ints(a[3]), ints(a[4]), boolean(a[5]), dest(), pw));
+        if (pw && fn != "resize_nearest") throw Error("plan: '" + fn + "' cannot write into a window");
+        Buffer& o = dest();
         static const std::map<std::string, int> unary = {{"exp", LELE_U_EXP}, {"sigmoid", LELE_U_SIGMOID}, {"tanh_kernel", LELE_U_TANH}, {"silu", LELE_U_SILU},
             {"erf", LELE_U_ERF}, {"relu", LELE_U_RELU}, {"sqrt", LELE_U_SQRT}, {"log", LELE_U_LOG}, {"sin", LELE_U_SIN}, {"cos", LELE_U_COS}, {"neg", LELE_U_NEG},
             {"reciprocal", LELE_U_RECIPROCAL}, {"softplus", LELE_U_SOFTPLUS}, {"not_", LELE_U_NOT}, {"abs", LELE_U_ABS}, {"floor", LELE_U_FLOOR}, {"ceil", LELE_U_CEIL}};
@@ -1047,6 +1105,7 @@ class Runner {
                 const double shh = sc.size() >= 3 ? (double)sc[2] : 1.0, sww = sc.size() >= 4 ? (double)sc[3] : 1.0;
                 oh = (int64_t)((double)x.shape[2] * shh), ow = (int64_t)((double)x.shape[3] * sww);
             } else throw Error("Resize: either scales or sizes must be provided");
+            if (pw || x.is_view()) return set(st, 0, K::resize_nearest_pitched(x, oh, ow, a[3].at("str").str == "asymmetric", o, pw));
             return set(st, 0, K::resize_nearest(x, oh, ow, a[3].at("str").str == "asymmetric", o));
         }
         if (fn == "transpose") {

@@ -73,15 +73,56 @@ def test_native_runner_matches_python_runner(ctx, tmp_path):
 
 
 @pytest.mark.gpu
-def test_native_runner_refuses_a_folded_plan_by_name(ctx, tmp_path):
-    """lele_amd.plan/3 (channel views, windows, conv2d_res: plan.fold_channel_views) is the Python runner's batch form; the native
-    runner says so instead of executing statements it does not know"""
-    plan = {"format": "lele_amd.plan/3", "inputs": [], "outputs": [], "slots": [], "weights": {}, "statements": []}
-    (tmp_path / "p.json").write_text(json.dumps(plan))
+def test_native_runner_runs_the_folded_batch_plan_bit_for_bit(ctx, tmp_path):
+    """lele_amd.plan/3 (plan.fold_channel_views: channel views, Concat buffers reserved up front, results written into windows of them,
+    conv2d_res, copy_view, transpose_cp) is the form bench.py times -- the 7.7 ms Yolo graph.  lele_run executes it natively: the
+    Yolo26n-seg look-alike at batch 8, folded, through the Python runner and through lele_run (eagerly, as a recorded graph, and
+    scheduled onto lanes as a DAG inside a recorded graph): every output bit for bit, the same number of kernel calls.  A format the
+    runner does not know is still refused by name."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from lele_amd.compiler import compile_model
+    from lele_amd.lanes import schedule
+    from lele_amd.plan import Runner, fold_channel_views, load_weights_bin
+    from lele_amd.tensor import TensorView
+    from yolo_graph import yolo_onnx
+    n = 8
+    plan, blob = compile_model(yolo_onnx(n)[0], "yolo26n_seg_shaped_n%d" % n)
+    w = load_weights_bin(plan, blob)
+    images = np.random.default_rng(8).uniform(0, 1, (n, 3, 640, 640)).astype(np.float32)
+    feed = {"images": TensorView(ctx.buf().upload(images))}
+    r0 = Runner(plan, w, ctx)
+    r0.shapes = {}
+    plain = [o.numpy().copy() for o in r0.run(feed)]
+    folded = fold_channel_views(plan, r0.shapes)
+    assert folded["format"] == "lele_amd.plan/3" and any(st["op"] == "chview" for st in folded["statements"]) \
+        and any("window" in st for st in folded["statements"]) and any(st.get("fn") == "conv2d_res" for st in folded["statements"])
+    r1 = Runner(folded, w, ctx)
+    want = [o.numpy().copy() for o in r1.run(feed)]
+    assert all(np.array_equal(a, b) for a, b in zip(plain, want))
+    d = tmp_path / "folded"
+    d.mkdir()
+    rec, got = _native(d, folded, blob, {"images": images}, extra=("--runs", "3", "--graph"))
+    assert len(got) == len(want) and rec["kernel_calls"] == r1.calls
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert rec["graph_ms"] > 0
+    # ... and as a DAG (lanes), the schedule bench.py records
+    r1.stmt_times = []
+    r1.run(feed)
+    times = {o: ms for _i, _fn, o, ms in r1.stmt_times}
+    dag = schedule(folded, times, lanes=3)
+    if dag is not None:
+        d2 = tmp_path / "dag"
+        d2.mkdir()
+        rec2, got2 = _native(d2, dag, blob, {"images": images}, extra=("--runs", "3", "--graph"))
+        assert all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(got2, want)) and rec2["graph_ms"] > 0
+    bad = {"format": "lele_amd.plan/9", "inputs": [], "outputs": [], "slots": [], "weights": {}, "statements": []}
+    (tmp_path / "p.json").write_text(json.dumps(bad))
     (tmp_path / "w.bin").write_bytes(b"")
     r = subprocess.run([RUN, str(tmp_path / "p.json"), str(tmp_path / "w.bin"), "--out", str(tmp_path / "o")], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=120)
-    assert r.returncode != 0 and "lele_amd.plan/3" in r.stderr and "not supported by the native runner" in r.stderr
+    assert r.returncode != 0 and "lele_amd.plan/9" in r.stderr and "not supported by the native runner" in r.stderr
 
 
 @pytest.mark.gpu
