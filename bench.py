@@ -656,30 +656,40 @@ def configs0_leg(ctx):
 
 
 def cpu_baseline_configs0(dev_probs):
-    """the same chain on the oracle (the C++ restatement of lele's x86 AVX2 path -- NOT the `cfg(not(x86_64 ...))` scalar branches configs[0]
-    names: those are not restated), one thread, all 175 chunks; its probabilities against the device's"""
+    """the same chain on the oracle, one thread, all 175 chunks, in BOTH of its build modes: `scalar` -- the restatement of the
+    `cfg(not(any(x86_64, aarch64, wasm32)))` bodies configs[0] names (oracle/scalar.cpp: one-channel conv1d as running sums, the LSTM's
+    gate stage and the sigmoid through libm) -- and the x86 AVX2 bodies; the probabilities of each against the device's"""
     from oracle import npref
     from oracle import pyoracle as O
     chunks = _zh_wav_chunks()
     w = _silero_chain_weights()
-    h = c = np.zeros((1, 1, 128), np.float32)
-    probs = []
-    t0 = time.perf_counter()
-    for ch in chunks:
-        x = npref.pad(ch.reshape(1, 1, 512), [0, 0, 64, 0, 0, 64], 0.0, "reflect")
-        s = O.conv1d(x, w["stft"], None, [1], 1, [0, 0], [128])
-        re, im = npref.slice_(s, [0], [129], [1], [1]), npref.slice_(s, [129], [258], [1], [1])
-        y = np.sqrt(re * re + im * im)
-        for i, st in enumerate((1, 2, 2, 1)):
-            y = O.conv1d(y, w["c%d" % i], w["b%d" % i], [1], 1, [1, 1], [st], True)
-        feat = npref.reduce("mean", y, [2], False)
-        _yy, h, c = O.lstm(feat.reshape(1, 1, 128), w["lw"], w["lr"], w["lb"], h, c)
-        probs.append(float(O.unary("sigmoid", O.matmul(h.reshape(1, 128), w["out"])).reshape(-1)[0]))
-    dt = time.perf_counter() - t0
-    return {"value": round(1e3 * dt / 175, 4), "unit": "ms per 32 ms chunk", "cores": 1, "kind": "port", "rtf": round(dt / 5.6, 6),
-            "sample": "all 175 chunks of zh.wav through the oracle's restatement of lele's x86 AVX2 kernels in %.2f s (configs[0] names the "
-                      "SCALAR kernels: the cfg(not) branches are not restated, so this is the faster of lele's two CPU paths)" % dt,
-            "max_abs_diff_device_vs_oracle_probability": round(float(np.abs(np.asarray(probs) - np.asarray(dev_probs)).max()), 9)}
+
+    def chain():
+        h = c = np.zeros((1, 1, 128), np.float32)
+        probs = []
+        t0 = time.perf_counter()
+        for ch in chunks:
+            x = npref.pad(ch.reshape(1, 1, 512), [0, 0, 64, 0, 0, 64], 0.0, "reflect")
+            s = O.conv1d(x, w["stft"], None, [1], 1, [0, 0], [128])
+            re, im = npref.slice_(s, [0], [129], [1], [1]), npref.slice_(s, [129], [258], [1], [1])
+            y = np.sqrt(re * re + im * im)
+            for i, st in enumerate((1, 2, 2, 1)):
+                y = O.conv1d(y, w["c%d" % i], w["b%d" % i], [1], 1, [1, 1], [st], True)
+            feat = npref.reduce("mean", y, [2], False)
+            _yy, h, c = O.lstm(feat.reshape(1, 1, 128), w["lw"], w["lr"], w["lb"], h, c)
+            probs.append(float(O.unary("sigmoid", O.matmul(h.reshape(1, 128), w["out"])).reshape(-1)[0]))
+        return time.perf_counter() - t0, np.asarray(probs)
+    with O.scalar():
+        dt_s, p_s = chain()
+    dt_a, p_a = chain()
+    dev = np.asarray(dev_probs)
+    return {"value": round(1e3 * dt_s / 175, 4), "unit": "ms per 32 ms chunk", "cores": 1, "kind": "port", "mode": "scalar", "rtf": round(dt_s / 5.6, 6),
+            "sample": "all 175 chunks of zh.wav through the oracle in its SCALAR mode (the cfg(not(x86_64 ...)) bodies configs[0] names) in %.2f s, "
+                      "and again through its restatement of lele's x86 AVX2 kernels in %.2f s (`avx2_ms_per_chunk`)" % (dt_s, dt_a),
+            "avx2_ms_per_chunk": round(1e3 * dt_a / 175, 4), "avx2_rtf": round(dt_a / 5.6, 6),
+            "max_abs_diff_device_vs_oracle_probability": round(float(np.abs(p_a - dev).max()), 9),
+            "max_abs_diff_device_vs_scalar_oracle_probability": round(float(np.abs(p_s - dev).max()), 9),
+            "max_abs_diff_scalar_vs_avx2_oracle_probability": round(float(np.abs(p_s - p_a).max()), 9)}
 
 
 def cpu_baseline_yolo_graph(lifted):

@@ -27,6 +27,21 @@
 extern "C" {
 #endif
 
+/* ---- build mode (scalar.cpp): 0 = the x86 AVX2 bodies (default), 1 = the cfg(not(any(x86_64, aarch64, wasm32))) bodies for the
+ * operators that have one upstream: softmax, layer_norm, the LSTM / GRU gate stages, the unary activations, one-channel conv1d,
+ * dynamic_quantize_linear.  Process-wide; tests and bench.py's configs[0] baseline set it around their calls. */
+void orc_set_scalar_mode(int on);
+int orc_scalar_mode(void);
+void orc_scalar_softmax_lastdim(const float* input, float* output, int64_t outer, int64_t len);         /* norm.rs:193-216 */
+void orc_scalar_layer_norm(const float* input, const float* gamma, const float* beta, float* output, int64_t norm_size,
+                           int64_t outer_size, float epsilon);                                         /* norm.rs:286-306 */
+void orc_scalar_lstm_gates(const float* gates, int64_t hidden, float* out_c, float* out_h, float* out_y_t); /* rnn.rs:207-221 */
+void orc_scalar_gru_gates(const float* wc, const float* rc, const float* bw, const float* br, int64_t hidden, float* h);
+void orc_scalar_conv1d_single_channel(const float* input, const float* weights, const float* bias, int64_t batch, int64_t input_len,
+                                      int64_t out_channels, int64_t kernel, int64_t stride, int64_t output_len, int relu,
+                                      float* output);                                                  /* conv1d.rs:1578-1615 */
+void orc_scalar_dynamic_quantize_linear(const float* x, int64_t len, float* y, float* scale, float* zp); /* quantization.rs:1751-1796 */
+
 /* ---- src/features + src/kernels/fft.rs ------------------------------------------------ */
 void orc_hann_window(int64_t size, float* out);                     /* features/window.rs:2-13   */
 void orc_precompute_twiddles(int64_t n, float* tw_re, float* tw_im, /* kernels/fft.rs:136-157    */

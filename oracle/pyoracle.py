@@ -42,6 +42,24 @@ def lib():
     return _LIB
 
 
+def scalar_mode():
+    return bool(lib().orc_scalar_mode())
+
+
+class scalar:
+    """with scalar(): the operators that have a cfg(not(any(x86_64, aarch64, wasm32))) body upstream run its restatement (oracle/scalar.cpp):
+    softmax, layer_norm, the LSTM / GRU gate stages, the unary activations (libm), one-channel conv1d, dynamic_quantize_linear"""
+
+    def __enter__(self):
+        self.was = lib().orc_scalar_mode()
+        lib().orc_set_scalar_mode(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_scalar_mode(self.was)
+        return False
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -418,6 +436,15 @@ def conv1d(x, w, bias=None, dilations=(), group=1, pads=(), strides=(), relu=Fal
         x = x[:, None, :]
     d = int(list(dilations)[0]) if len(list(dilations)) else 1
     s = int(list(strides)[0]) if len(list(strides)) else 1
+    if scalar_mode() and x.shape[1] == 1 and group == 1 and pl == 0 and pr == 0 and d == 1:   # conv1d.rs:902, 945-961 -> 1578-1615
+        n, _c, length = x.shape
+        oc, _ci, k = w.shape
+        ol = (length - k) // s + 1
+        out = np.empty((n, oc, ol), np.float32)
+        b = _f32(bias) if bias is not None else None
+        lib().orc_scalar_conv1d_single_channel(_p(x), _p(w), _p(b) if b is not None else None, i64(n), i64(length), i64(oc), i64(k), i64(s),
+                                               i64(ol), C.c_int(1 if relu else 0), _p(out))
+        return out
     y = conv2d(x[:, :, None, :], w[:, :, None, :], bias, [1, d], group, [0, pl, 0, pr], [1, s], "relu" if relu else None)
     return y[:, :, 0, :]
 

@@ -98,6 +98,7 @@ void int_gemm_epilogue(const int32_t* a, const int32_t* b, int64_t m, int64_t k,
 }  // namespace
 
 extern "C" void orc_dynamic_quantize_linear(const float* x, int64_t len, float* y, float* scale, float* zp) {
+    if (orc_scalar_mode() && len > 0) return orc_scalar_dynamic_quantize_linear(x, len, y, scale, zp);
     if (len == 0) {  // avx/quantization.rs:845-851
         *scale = 1.0f;
         *zp = 0.0f;

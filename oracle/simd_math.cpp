@@ -74,7 +74,8 @@ static inline float hsum(__m256 v) {  // avx/math.rs:151-160
 extern "C" void orc_unary_simd(int op, const float* in, float* out, int64_t len) {
     int64_t i = 0;
     const __m256 half = _mm256_set1_ps(0.5f), one = _mm256_set1_ps(1.0f);
-    for (; i + 8 <= len; i += 8) {
+    // scalar mode (math.rs:927-945, 975-, 1028-, ...: the cfg(not) bodies call libm per element): the loop below IS the tail loop
+    for (; !orc_scalar_mode() && i + 8 <= len; i += 8) {
         __m256 x = _mm256_loadu_ps(in + i), r;
         switch (op) {
             case 0: r = exp_ps(x); break;
@@ -120,6 +121,7 @@ extern "C" void orc_unary_simd(int op, const float* in, float* out, int64_t len)
 
 extern "C" void orc_layer_norm(const float* input, const float* scale, const float* bias, float* output,
                                int64_t norm_size, int64_t outer_size, float epsilon) {  // avx/norm.rs:10-133
+    if (orc_scalar_mode()) return orc_scalar_layer_norm(input, scale, bias, output, norm_size, outer_size, epsilon);
     float inv_n = 1.0f / (float)norm_size;
     for (int64_t i = 0; i < outer_size; ++i) {
         const float* in = input + i * norm_size;
@@ -166,6 +168,7 @@ extern "C" void orc_layer_norm(const float* input, const float* scale, const flo
 }
 
 extern "C" void orc_softmax_lastdim(const float* input, float* output, int64_t outer, int64_t len) {  // avx/norm.rs:139-229
+    if (orc_scalar_mode()) return orc_scalar_softmax_lastdim(input, output, outer, len);
     for (int64_t r = 0; r < outer; ++r) {
         const float* src = input + r * len;
         float* dst = output + r * len;
@@ -290,6 +293,10 @@ extern "C" void orc_lstm(const float* x, int64_t seq_len, int64_t input_size, in
             float bw = bias ? bias[g] : 0.0f, br = bias ? bias[G + g] : 0.0f;
             gates[g] = wc + rc + bw + br;  // rnn.rs:152-154 (left-associated f32 adds)
         }
+        if (orc_scalar_mode()) {
+            orc_scalar_lstm_gates(gates, H, out_c, out_h, out_y + t * H);
+            continue;
+        }
         int64_t k = 0;
         for (; k + 8 <= H; k += 8) {  // lstm_gates_avx2, rnn.rs:15-65; gate order i, o, f, c
             __m256 ig = sigmoid_ps(_mm256_loadu_ps(gates + k)), og = sigmoid_ps(_mm256_loadu_ps(gates + H + k));
@@ -331,6 +338,11 @@ extern "C" void orc_gru(const float* x, int64_t seq_len, int64_t input_size, int
         const float* bw = bias;
         const float* br = bias ? bias + G : nullptr;
         auto B = [&](const float* b, int64_t i) { return b ? b[i] : 0.0f; };
+        if (orc_scalar_mode()) {
+            orc_scalar_gru_gates(wc, rc, bw, br, H, out_h);
+            for (int64_t k2 = 0; k2 < H; ++k2) out_y[t * H + k2] = out_h[k2];
+            continue;
+        }
         int64_t k = 0;
         for (; k + 8 <= H; k += 8) {  // gru_gate_fusion_avx2, rnn.rs:359-432
             float tmp[8];
