@@ -380,8 +380,27 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_
         def decode():
             return K.token_filter(K.argmax_last(logits, out=abuf, ctx=ctx), skip, out_ids=ibuf, out_counts=nbuf, ctx=ctx)
 
+        # the whole step as ONE graph: front-end + CMVN, the encoder plan, arg-max + token filter (same kernels, same buffers as the three
+        # pieces above; what stays outside is the exchange of the ids).  Falls back to the pieces if the capture is refused.
+        step_graph, step_out = None, None
+        try:
+            decode()
+            ctx.sync()
+            ctx.graph_begin()
+            f2 = features()
+            runner.run({"feats": f2})
+            step_out = decode()
+            step_graph = ctx.graph_end()
+            step_graph.launch()
+            ctx.sync()
+        except Exception:  # noqa: BLE001
+            try:
+                ctx.graph_abort()
+            except Exception:  # noqa: BLE001
+                pass
+            step_graph = None
         return {"features": features, "graph": graph, "decode": decode, "feats": feats, "logits": logits, "runner": runner,
-                "plan": plan, "audio": batch * seconds}
+                "plan": plan, "audio": batch * seconds, "step_graph": step_graph, "step_out": step_out}
 
     # ---- configs[3] shard: per_gpu x 10 s utterances on every rank, ids gathered over RCCL
     total = args.per_gpu * world
@@ -390,9 +409,13 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_
     gbufs = [ctx.buf() for _ in range(4)]
 
     def step_c4():
-        c4["features"]()                       # same buffers every step: the graph reads the CMVN output buffer
-        c4["graph"].launch()
-        ids, counts = c4["decode"]()
+        if c4["step_graph"] is not None:       # PCM -> features -> encoder -> token ids as one recorded graph
+            c4["step_graph"].launch()
+            ids, counts = c4["step_out"]
+        else:
+            c4["features"]()                   # same buffers every step: the graph reads the CMVN output buffer
+            c4["graph"].launch()
+            ids, counts = c4["decode"]()
         if comm is not None:
             return all_gather_ids_rccl(ids, counts, total, comm, ctx, gbufs)
         if world > 1:
@@ -418,8 +441,32 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_
                 "audio_s_per_s": round(total * 10 * args.sv_steps / wall, 1), "c4_steps": args.sv_steps,
                 "c4_collective": "rccl all-gather of token ids via lele_hip_comm_allgather_i32" if comm else (comm_note or "none (single process)"),
                 "c4_gathered_ok": bool(agree), "c4_tokens": int(c4["logits"].shape[1]),
+                "c4_step_as_one_graph": c4["step_graph"] is not None,
                 "plan_statements": len(c4["plan"]["statements"]), "plan_calls": sum(fn_count.values()),
                 "logits_finite": bool(np.isfinite(c4["logits"].numpy()[0]).all())})
+
+    # ---- section 8(e), "full logits if requested": the raw [T + 4, 25055] tensors of every utterance on every rank (--gather-logits)
+    if args.gather_logits:
+        from lele_amd.sharded import all_gather_logits, all_gather_logits_rccl
+        lbufs = [ctx.buf() for _ in range(2)]
+
+        def gather_logits():
+            if comm is not None:
+                return all_gather_logits_rccl(c4["logits"], total, comm, ctx, lbufs)
+            if world > 1:
+                return all_gather_logits(c4["logits"].numpy(), total, dist, device)
+            return all_gather_logits(c4["logits"].numpy(), total)
+        every = gather_logits()
+        fence()
+        t0 = time.perf_counter()
+        every = gather_logits()
+        fence()
+        lwall = max_over_ranks(time.perf_counter() - t0, dist, device)
+        rec["c4_logits_gather"] = {"what": "f32 logits [utterances, T + 4, 25055] of the whole batch on every rank (SURVEY.md 8(e): 17.1 MB an utterance at "
+                                           "10 s), incl. the read-back to the host", "utterances": int(every.shape[0]), "tokens": int(every.shape[1]),
+                                   "bytes_per_rank": int((hi - lo) * every.shape[1] * every.shape[2] * 4), "ms": round(1e3 * lwall, 3),
+                                   "collective": "rccl all-gather via lele_hip_comm_allgather" if comm else (comm_note or "none (single process)"),
+                                   "own_block_equals_local_logits": bool(np.array_equal(every[lo:hi], c4["logits"].numpy()))}
 
     # ---- the quantised linear (the model's dominant kernel) at the configs[3] shard shape, per-stage HIP events
     if rank == 0:
@@ -1196,6 +1243,7 @@ def main():
     ap.add_argument("--no-model", action="store_true", help="skip the SenseVoice-shaped recogniser legs")
     ap.add_argument("--no-yolo", action="store_true", help="skip the configs[4] leg")
     ap.add_argument("--no-dag", action="store_true", help="configs[4]: record the plans as linear graphs (default: independent branches on lanes, lele_amd/lanes.py)")
+    ap.add_argument("--gather-logits", action="store_true", help="configs[3]: also exchange the FULL logits (SURVEY.md 8(e): 17.1 MB an utterance), timed once")
     ap.add_argument("--no-native", action="store_true", help="configs[4]: skip the replay of the look-alike's plan through the native host (lele_amd/lele_run)")
     ap.add_argument("--yolo-batch", type=int, default=64, help="configs[4]: 640 x 640 images per GPU per forward")
     ap.add_argument("--yolo-runs", type=int, default=10, help="configs[4]: timed forwards after 3 warm-up ones (examples/yolo26n-seg/src/benchmark.rs:29-56)")

@@ -188,3 +188,51 @@ def all_gather_detections_rccl(dets, counts, total, comm, ctx, bufs=None):
     all_c = comm.allgather_i32(c1.raw(), out=b[3]).numpy().reshape(world, rows)
     parts = [[all_d[r, i, :all_c[r, i]].copy() for i in range(rows) if all_c[r, i] >= 0] for r in range(world)]
     return _collect(parts, total, world, "all_gather_detections_rccl")
+
+
+# ------------------------------------------------------------------------------------------------------------ full logits (configs[3], on request)
+# the preferred payload of configs[3] is the decoded token ids (684 B an utterance); "full logits if requested":
+# f32 [T + 4, 25055] = 17.1 MB an utterance, 548 MB per GPU at 32 utterances -- one all-gather of the raw tensor, shards padded to
+# ceil(total / world) utterances with zero rows that the receiver drops.
+def all_gather_logits(logits, total, dist=None, device="cpu"):
+    """logits f32 [n, T, V] of this rank's `shard_range(total, rank, world)` utterances -> [total, T, V] in global order on every rank
+    (`torch.distributed` form: gloo in the CPU tests, nccl = RCCL with device tensors)"""
+    logits = np.asarray(logits, np.float32)
+    if dist is None:
+        if logits.shape[0] != total:
+            raise ValueError("all_gather_logits: %d utterances given, %d expected" % (logits.shape[0], total))
+        return logits
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lo, hi = shard_range(total, rank, world)
+    if logits.shape[0] != hi - lo:
+        raise ValueError("all_gather_logits: rank %d owns %d utterances but was given %d" % (rank, hi - lo, logits.shape[0]))
+    rows = -(-total // world)
+    mine = np.zeros((rows,) + logits.shape[1:], np.float32)
+    mine[:hi - lo] = logits
+    mine = torch.from_numpy(mine).to(device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    return np.concatenate([p.cpu().numpy()[:shard_range(total, r, world)[1] - shard_range(total, r, world)[0]] for r, p in enumerate(parts)], 0)
+
+
+def all_gather_logits_rccl(logits, total, comm, ctx, bufs=None, to_host=True):
+    """The same on the device through the C ABI: logits = device f32 [n, T, V]; ONE `lele_hip_comm_allgather` on the ctx stream (the
+    tensor moves as bytes).  Returns the [total, T, V] host array (one read-back), or with to_host=False the gathered device tensor
+    [world, rows, T, V] (rows = ceil(total / world); padding utterances are zero) for a consumer that stays on the device."""
+    from . import kernels as K
+    rank, world = comm.rank, comm.world
+    lo, hi = shard_range(total, rank, world)
+    n, t, v = (int(d) for d in logits.shape)
+    if n != hi - lo:
+        raise ValueError("all_gather_logits_rccl: rank %d owns %d utterances but was given %d" % (rank, hi - lo, n))
+    b = bufs or [ctx.buf() for _ in range(2)]
+    rows = -(-total // world)
+    x = logits
+    if rows > n:
+        x = K.pad(x, [0, 0, 0, rows - n, 0, 0], np.array([0], np.float32), "constant", out=b[0], ctx=ctx)
+    got = comm.allgather(x.raw(), out=b[1])
+    if not to_host:
+        return got
+    every = got.numpy().reshape(world, rows, t, v)
+    return np.concatenate([every[r, :shard_range(total, r, world)[1] - shard_range(total, r, world)[0]] for r in range(world)], 0)

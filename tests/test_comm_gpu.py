@@ -71,6 +71,21 @@ def test_gather_of_detection_rows_through_the_c_abi(ctx, tmp_path):
     comm.close()
 
 
+def test_gather_of_full_logits_through_the_c_abi(ctx, tmp_path):
+    """section 8(e)'s other payload: the raw logits (17.1 MB an utterance at full size) with ONE lele_hip_comm_allgather -- a 1-rank
+    communicator here; world 2 on this one GPU runs through bench.py --gather-logits (test_bench_two_ranks_on_one_gpu_end_to_end)"""
+    from lele_amd._lib import Comm
+    from lele_amd.sharded import all_gather_logits_rccl
+    comm = Comm.from_file(ctx, str(tmp_path / "uid"), 0, 1, timeout_ms=10000)
+    x = np.random.default_rng(4).standard_normal((3, 175, 2505)).astype(np.float32)
+    from lele_amd.tensor import TensorView
+    got = all_gather_logits_rccl(TensorView(ctx.buf().upload(x)), 3, comm, ctx)
+    assert got.shape == x.shape and np.array_equal(got, x)
+    dev = all_gather_logits_rccl(TensorView(ctx.buf().upload(x)), 3, comm, ctx, to_host=False)
+    assert tuple(dev.shape)[0] == 1 and np.array_equal(dev.numpy().reshape(x.shape), x)
+    comm.close()
+
+
 def test_rendezvous_file_of_another_job_is_refused(ctx, tmp_path, monkeypatch):
     """[32-byte job token][128-byte id]: a reader takes only a file that carries the digest of ITS LELE_JOB_ID -- not what an earlier
     job left under the same name (whatever its age), not a file of another size -- and rank 0 replaces what it finds"""
@@ -143,7 +158,7 @@ def test_bench_two_ranks_on_one_gpu_end_to_end():
     env = dict(os.environ, LELE_BENCH_SHARE_GPU="1", LELE_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "64",
-                        "--layers", "2", "--per-gpu", "4", "--sv-steps", "2", "--allow-fallback"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                        "--layers", "2", "--per-gpu", "4", "--sv-steps", "2", "--allow-fallback", "--gather-logits"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
@@ -152,6 +167,8 @@ def test_bench_two_ranks_on_one_gpu_end_to_end():
     sv = line["sensevoice"]
     assert sv["c4_utterances"] == 8 and sv["c4_gathered_ok"] is True
     assert "rccl" in sv["c4_collective"] or "torch.distributed" in sv["c4_collective"]
+    lg = sv["c4_logits_gather"]                                            # the full-logits payload at world 2 on this one GPU
+    assert lg["utterances"] == 8 and lg["own_block_equals_local_logits"] is True and lg["bytes_per_rank"] == 4 * lg["tokens"] * 25055 * 4
     assert "rtf_model" not in line and "cpu_baseline" not in line          # N = 1 only
     g = line["yolo"]["gather"]                                             # configs[4]: every image's detections reached every rank
     assert g["images"] == g["images_expected"] == 2 * 64 and g["own_block_equals_local_postprocess"] is True

@@ -175,6 +175,41 @@ def test_all_gather_of_detections_two_ranks_gloo(tmp_path):
         assert rec["counts"] == want_counts and np.allclose(rec["sums"], want_sums, rtol=0, atol=1e-9)
 
 
+LOGITS_WORKER = '''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["LELE_ROOT"])
+import torch.distributed as dist
+from lele_amd.sharded import all_gather_logits, shard_range
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+total = 5
+lo, hi = shard_range(total, rank, world)
+mine = np.stack([np.random.default_rng(700 + i).standard_normal((21, 64)).astype(np.float32) for i in range(lo, hi)])
+every = all_gather_logits(mine, total, dist)
+print(json.dumps({"rank": rank, "shape": list(every.shape), "sums": [float(u.astype(np.float64).sum()) for u in every]}))
+dist.destroy_process_group()
+'''
+
+
+def test_all_gather_of_full_logits_two_ranks_gloo(tmp_path):
+    """section 8(e), "full logits if requested": the raw [T, V] tensors of every utterance on every rank, in global order, a ragged
+    last shard (5 utterances over 2 ranks: 3 + 2) padded for the collective and trimmed behind it"""
+    port = _free_port()
+    script = tmp_path / "logits_worker.py"
+    script.write_text(LOGITS_WORKER)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LELE_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    want = [float(np.random.default_rng(700 + i).standard_normal((21, 64)).astype(np.float32).astype(np.float64).sum()) for i in range(5)]
+    for out, _err in outs:
+        rec = json.loads(out.strip().splitlines()[-1])
+        assert rec["shape"] == [5, 21, 64] and rec["sums"] == want
+
+
 def test_pack_detections_round_trip_and_refusals():
     import pytest
     from lele_amd.sharded import all_gather_detections, pack_detections, unpack_detections
