@@ -8,9 +8,8 @@
 //   * a 256 x 256 result a workgroup, EIGHT waves (two a SIMD) of 128 x 64: 8 accumulator tiles = 128 registers a lane; while one of
 //     a SIMD's two waves requests, reads or waits, the other one's MFMAs keep the matrix core busy;
 //   * K in steps of 64 bytes through FOUR 32 KB stages of LDS; the operands go from memory straight into LDS
-//     (global_load_lds_dwordx4: no staging registers, no ds_write), three steps in flight, counted vmcnt waits, ONE raw s_barrier a step
-//     with nothing but lgkmcnt / the counted vmcnt in front of it; the first fragments of the NEXT stage are requested before the
-//     barrier (that stage has been complete since the previous one);
+//     (global_load_lds_dwordx4: no staging registers, no ds_write), two steps requested at a time, ONE raw s_barrier per TWO steps with
+//     nothing but the waits for those pieces and for the LDS reads in front of it;
 //   * LDS rows are 64 bytes (rows four apart would share their banks), so the 16-byte chunks of a row are permuted: position p of row r
 //     holds chunk p ^ ((r >> 2) & 3) -- applied on the GLOBAL side, since the LDS image of a direct load is lane-linear -- and the reader
 //     of chunk g asks for position g ^ ((r >> 2) & 3): for the lane groups of a ds_read_b128 all 64 banks are distinct
@@ -22,9 +21,10 @@
 // accumulator registers, one wave a SIMD) with direct-to-LDS loads, 128-byte steps, two stages, drain + __syncthreads: 180-200 us;
 // the same through staging registers: 219 (the scheduler sinks the 16 loads of a step to its end, in front of the stores that wait for
 // them); loads pinned + fragments double-buffered: 210; four 64-byte stages, early fragment request, raw barrier: 212; one LDS operation
-// per MFMA gap (sched_group_barrier): 193; eight waves of 128 x 64: 182; direct-to-LDS loads again: **169** (1.63 POP/s).  The ceiling is
+// per MFMA gap (sched_group_barrier): 193; eight waves of 128 x 64: 182; direct-to-LDS loads again: 169 (1.63 POP/s); m0 declared clobbered instead of saved / restored around every piece and two K steps a
+// barrier: 169 there, 32768 x 4096 x 2048 301 -> **284-288 us (1.91-1.93 POP/s, 0.48-0.49 of 3944)**.  The ceiling is
 // not 3944: tools/mfma_i8_rate.hip measures 4.17 POP/s for this instruction on constant operands and **3.23 on random bytes** (the chip
-// clocks down: 16.1 -> 20.8 ns per MFMA and SIMD); of that the kernel reaches one half.  What it is short of (PMC, profiles/
+// clocks down: 16.1 -> 20.8 ns per MFMA and SIMD); of that the kernel reaches 0.50-0.60.  What it is short of (PMC, profiles/
 // r06_igemm_big_pmc.txt): the waves spend 27 % of their life in front of the step's barrier / counted waits and 52 % in issue stalls
 // of which the matrix core's own occupancy explains 25 points -- the schedule of the guide's 8-phase template (four phases a K step,
 // two wave groups staggered by a barrier) is what remains to be built on top of this data path.
@@ -45,11 +45,8 @@ constexpr int BG_LDS = BG_NST * BG_STAGE + BG_TABLES;
 // DMA: the operands go from memory straight into LDS (global_load_lds_dwordx4; the 16-byte chunks permuted on the GLOBAL side, since the
 // LDS image of such a load is lane-linear): no staging registers, no ds_write -- three K steps in flight, counted vmcnt waits
 __device__ __forceinline__ void bg_dma16(const void* base, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(base), "s"(lds_dst)
-                 : "memory");
+    // m0 is declared clobbered instead of being saved and restored around every piece (three scalar instructions a piece less)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory", "m0");
 }
 template <int WC, bool DMA = false>
 __global__ __launch_bounds__(128 * WC) void igemm_big_kernel(const int8_t* __restrict__ a, const int8_t* __restrict__ b, int64_t rows, int n, int kp,
@@ -231,11 +228,16 @@ __global__ __launch_bounds__(128 * WC) void igemm_big_kernel(const int8_t* __res
         // At step kt: stage kt is multiplied, the first fragments of stage kt + 1 are requested (complete since the barrier that ended
         // step kt - 1), K step kt + 3 is requested from memory into the stage last read in step kt - 1; before the barrier that ends
         // step kt this wave's pieces of K step kt + 2 have landed (vmcnt: only the pieces of step kt + 3 may still be in flight).
-        auto step_dma = [&](int kt) {
-            const int st = kt & 3;
+        // TWO K steps between barriers (four stages = two pairs of stages used alternately).  At pair b (steps 2 b, 2 b + 1): their stages
+        // have been complete since barrier b - 1 (every piece is waited for -- vmcnt(0) -- in front of a barrier); K steps 2 b + 2 and
+        // 2 b + 3 are requested at the start of the pair into the two stages read in pair b - 1 and waited for at its end: two whole
+        // steps between a request and its wait, half the barriers of the one-step form (which could ask for the next stage's first
+        // fragments before its barrier; here they are asked for right behind it, under the next pair's eight requests).
+        auto pair_dma = [&](int kt) {
+            dma(kt + 2);
             dma(kt + 3);
-            __builtin_amdgcn_s_setprio(1);   // a wave in its products goes before the SIMD's other wave in its requests
-            frags(fa1, fb1, st, roff1);
+            __builtin_amdgcn_s_setprio(1);
+            frags(fa1, fb1, kt & 3, roff1);
             products(fa0, fb0);
 #pragma unroll
             for (int q = 0; q < 4 + TJ; ++q) {
@@ -250,20 +252,29 @@ __global__ __launch_bounds__(128 * WC) void igemm_big_kernel(const int8_t* __res
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            frags(fa1, fb1, (kt + 1) & 3, roff1);
+            products(fa0, fb0);
+#pragma unroll
+            for (int q = 0; q < 4 + TJ; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            products(fa1, fb1);
             __builtin_amdgcn_s_setprio(0);
             __builtin_amdgcn_sched_barrier(0);
-            // (measured alternative: no early fragment request, two whole steps between a K step's request and its wait -- 176 against 169 us)
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(2 * LI) : "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            frags(fa0, fb0, (kt + 2) & 3, roff0);   // the next pair's first fragments: its stages are complete now
         };
         dma(0);
         dma(1);
-        dma(2);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * LI) : "memory");   // K steps 0 and 1 (this wave's pieces; the barrier: everybody's)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         frags(fa0, fb0, 0, roff0);
-        for (int kt = 0; kt < nk; ++kt) step_dma(kt);
+        for (int kt = 0; kt < nk; kt += 2) pair_dma(kt);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
     fetch(sa0, sb0, 0);
