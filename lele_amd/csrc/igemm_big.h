@@ -108,8 +108,13 @@ __global__ __launch_bounds__(128 * WC) void igemm_big_kernel(const int8_t* __res
         }
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)bg_lds;
+    const int krot = (int)((((blockIdx.x + gridDim.x * blockIdx.y) & 7u) * (unsigned)nk_) >> 3);   // per XCD: its workgroups share operands, and lines, in step
     auto dma = [&](int kstep) {   // K step `kstep` into its stage: rows [LR wave, +LR) of A and of B, 16 rows (1 KiB) a piece
-        const unsigned k0 = (unsigned)(kstep < nk_ ? kstep : nk_ - 1) * BG_BK;
+        // the K steps in an order rotated per XCD (exact i32 sums: any order gives the same total): the eight XCDs do not all ask the
+        // memory side for the same lines of A and B at the same moment; the workgroups of one XCD stay in step and share their L2 lines
+        int kk = (kstep < nk_ ? kstep : nk_ - 1) + krot;
+        kk = kk >= nk_ ? kk - nk_ : kk;
+        const unsigned k0 = (unsigned)kk * BG_BK;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(kstep & 3) * BG_STAGE + (unsigned)(LR * wave) * BG_BK);
 #pragma unroll
         for (int j = 0; j < LI; ++j) bg_dma16(a, aoff[j] + k0, dst + j * 16 * BG_BK);
