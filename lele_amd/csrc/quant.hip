@@ -1117,7 +1117,8 @@ unsigned* rs_sync_counters(LeleCtx* ctx, int64_t rows, int64_t n) {
     void* p = nullptr;
     // 64 counters, then one 8-byte word {launch tag, maximum} per workgroup and slice (4 a workgroup): cleared once, never again
     const size_t bytes = 256 + (size_t)ncb * nrr * 32;
-    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {
+    // cleared ON THE CONTEXT'S STREAM: the stream does not synchronise with the null stream, and the first launch follows at once
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemsetAsync(p, 0, bytes, ctx->stream) != hipSuccess) {
         (void)hipGetLastError();
         if (p) (void)hipFree(p);
         return nullptr;
