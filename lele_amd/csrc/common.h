@@ -224,6 +224,7 @@ namespace lele {
 // features_ops.hip: power spectrum |FFT|^2 of `rows` real rows of length n_fft (a power of two <= 4096), bit-exact with the
 // reference's radix-2 network; out_power is [rows, n_fft/2 + 1]
 int live_contexts(int device);  // context.hip: contexts of this process alive on `device`
+int fft_twiddles(LeleCtx* ctx, int64_t n, const float** tw_re, const float** tw_im);  // features_ops.hip: fft.rs:136-157 on the device
 int fft_rows_power(LeleCtx* ctx, const float* rows_in, int64_t rows, int64_t n_fft, float* out_power);
 
 // quant.hip: dynamic-quantisation parameters of the joint range of several device arrays (16 bytes on the device)

@@ -281,6 +281,14 @@ int feature_2d(const LeleTensor* x, int64_t* t, int64_t* d, const char* who) {
 }  // namespace
 
 namespace lele {
+// the per-stage twiddle tables of the radix-2 network (fft.rs:136-157), on the device: [n - 1] values each, stage by stage
+int fft_twiddles(LeleCtx* ctx, int64_t n, const float** tw_re, const float** tw_im) {
+    FftTables t;
+    LELE_TRY(get_fft_tables(ctx, n, &t));
+    *tw_re = t.tw_re;
+    *tw_im = t.tw_im;
+    return 0;
+}
 int fft_rows_power(LeleCtx* ctx, const float* rows_in, int64_t rows, int64_t n_fft, float* out_power) {
     return launch_fft(ctx, rows_in, rows, n_fft, n_fft, n_fft, n_fft, n_fft, nullptr, 1, 1, out_power, nullptr);
 }

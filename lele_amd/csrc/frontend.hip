@@ -455,7 +455,22 @@ __global__ void fe_generic_mean_kernel(const float* __restrict__ pcm, int64_t ro
     if (f >= rows) return;
     const float* src = pcm + (f / num_frames) * pcm_len + (f % num_frames) * hop;
     float sum = 0.0f;
-    for (int j = 0; j < frame_len; ++j) sum = sum + src[j] * 32768.0f;  // raw_frame.iter().sum(), pipeline.rs:115
+    int j = 0;
+    if ((((uintptr_t)src) & 15) == 0) {   // sixteen samples requested (as four 16-byte loads) before their additions, which stay sequential
+        for (; j + 16 <= frame_len; j += 16) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(src + j + 4 * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sum = sum + v[u].x * 32768.0f;
+                sum = sum + v[u].y * 32768.0f;
+                sum = sum + v[u].z * 32768.0f;
+                sum = sum + v[u].w * 32768.0f;
+            }
+        }
+    }
+    for (; j < frame_len; ++j) sum = sum + src[j] * 32768.0f;  // raw_frame.iter().sum(), pipeline.rs:115
     mean[f] = sum / (float)frame_len;
 }
 __global__ void fe_generic_frame_kernel(const float* __restrict__ pcm, const float* __restrict__ mean,
@@ -488,6 +503,129 @@ __global__ void fe_generic_mel_kernel(const float* __restrict__ power, int64_t n
         float acc = 0.0f;
         for (int t = moff[m]; t < moff[m + 1]; ++t) acc = fe::fadd(acc, fe::fmul(mw[t], p[t - moff[m]]));  // mel.rs:92-104
         logmel[i] = __logf(fmaxf(acc, 1e-5f));                                                            // mel.rs:124-128
+    }
+}
+// The composed path's first four kernels as ONE (every FeatureConfig other than 400 / 160 / 512 ran frame means |
+// pre-emphasis + window | radix-2 FFT | sparse mel + log as four launches over [rows, n_fft] and [rows, bins] scratch tensors --
+// 10-20 x the fused default).  A workgroup takes FPB consecutive frames of one utterance: their PCM span goes to LDS once, one lane a
+// frame forms the frame sum in the reference's order (pipeline.rs:115: a sequential f32 sum), all threads write the windowed frames
+// bit-reversed into LDS, run the butterfly network of fft.rs:172-266 stage by stage there (twiddles in LDS), form the power spectrum
+// and the sparse mel sums (mel.rs:92-104) out of LDS and store ln(max(x, 1e-5)).  The SAME operations in the SAME order as the four
+// kernels (the fe:: helpers of fe_core.h): bit-identical log-mel rows; nothing but the log-mel leaves the workgroup.
+#define FE_PAD(i) ((i) + ((i) >> 5))
+__global__ __launch_bounds__(256) void fe_generic_fused_kernel(const float* __restrict__ pcm, int64_t pcm_len, int64_t num_frames, int frame_len,
+                                                               int hop, int n, int log2n, int fpb, const float* __restrict__ window,
+                                                               const float* __restrict__ tw_re_g, const float* __restrict__ tw_im_g, int n_mels,
+                                                               const int* __restrict__ mstart, const int* __restrict__ moff,
+                                                               const float* __restrict__ mw, const float* __restrict__ means,
+                                                               float* __restrict__ logmel) {
+    extern __shared__ float gfl[];
+    const int nb = n / 2 + 1, span = (fpb - 1) * hop + frame_len;
+    // re / im [fpb][n], one pad word per 32 (FE_PAD): the register passes read 2^R points a thread at strides of 1, 8, 64, ...
+    float* re = gfl;
+    float* im = re + FE_PAD(fpb * n) + 1;
+    float* pw = im + FE_PAD(fpb * n) + 1;  // [fpb][nb]
+    float* sp = pw + fpb * nb;             // [span] samples, then [fpb] means
+    float* smean = sp + span;
+    const int tid = threadIdx.x;
+    const int64_t f0 = (int64_t)blockIdx.x * fpb;
+    const int nfr = (int)(num_frames - f0 < fpb ? num_frames - f0 : fpb);
+    const float* src = pcm + (int64_t)blockIdx.y * pcm_len + f0 * hop;
+    const int have = (nfr - 1) * hop + frame_len;   // samples of the frames that exist (every frame lies inside the utterance)
+    for (int i = tid; i < span; i += 256) sp[i] = i < have ? src[i] : 0.0f;
+    __syncthreads();
+    if (means) {   // the frame sums come from fe_generic_mean_kernel (one LANE a frame there: a sequential sum of frame_len samples by one
+        // lane holds a whole workgroup here for 8 k cycles -- measured 1 ms of 6 at 32 kHz)
+        if (tid < nfr) smean[tid] = means[(int64_t)blockIdx.y * num_frames + f0 + tid];
+    } else if (tid < nfr) {   // pipeline.rs:115-116: raw_frame.iter().sum() / frame_len, samples scaled by 32768 first
+        const float* fr = sp + tid * hop;
+        float sum = 0.0f;
+        int j = 0;
+        for (; j + 16 <= frame_len; j += 16) {   // sixteen samples requested before the (dependent) additions: an LDS round trip per
+            float v[16];                         // sample made this loop 38 us of a workgroup's 40
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = fr[j + u];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) sum = sum + v[u] * 32768.0f;
+        }
+        for (; j < frame_len; ++j) sum = sum + fr[j] * 32768.0f;
+        smean[tid] = sum / (float)frame_len;
+    }
+    __syncthreads();
+    for (int i = tid; i < fpb * n; i += 256) {   // fe_generic_frame_kernel's value, at its bit-reversed slot
+        const int f = i >> log2n, j = i & (n - 1);
+        float v = 0.0f;
+        if (j < frame_len && f < nfr) {
+            const float* fr = sp + f * hop;
+            const float m = smean[f];
+            const float cur = fe::fsub(fe::fmul(fr[j], 32768.0f), m);
+            float y = cur;
+            if (j >= 1) y = fe::fsub(cur, fe::fmul(0.97f, fe::fsub(fe::fmul(fr[j - 1], 32768.0f), m)));  // pipeline.rs:140-142
+            v = fe::fmul(y, window[j]);
+        }
+        const int r = (int)(__brev((unsigned)j) >> (32 - log2n));
+        re[FE_PAD(f * n + r)] = v;
+        im[FE_PAD(f * n + r)] = 0.0f;
+    }
+    __syncthreads();
+    // The butterfly network, up to THREE stages per trip through LDS: a thread takes the 2^R points that stages s0 .. s0 + R - 1 combine
+    // among themselves (indices base + j h, h = 2^s0), runs those stages on them in registers -- every butterfly with the twiddle and
+    // the form (scalar below half = 4, fma from there: fft.rs:172-266) it has in the stage-by-stage network, so the same bits -- and
+    // writes them back: 4 barriers for 1024 points instead of 10, 0.4 x the LDS traffic.
+    for (int s0 = 0; s0 < log2n;) {
+        const int R = log2n - s0 >= 3 ? 3 : log2n - s0, h = 1 << s0, gsz = 1 << R, groups = n >> R;
+        for (int idx = tid; idx < fpb * groups; idx += 256) {
+            const int f = idx / groups, g = idx - f * groups;
+            const int lo = g & (h - 1), base = f * n + ((g >> s0) << (s0 + R)) + lo;
+            float xr[8], xi[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < gsz) xr[j] = re[FE_PAD(base + j * h)], xi[j] = im[FE_PAD(base + j * h)];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if (r >= R) break;
+                const int half = h << r, off = half - 1;   // the stage's twiddles start at 1 + 2 + ... + half / 2
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j >= gsz || (j >> r) & 1) continue;
+                    const int k = lo + (j & ((1 << r) - 1)) * h;
+                    const float wr = tw_re_g[off + k], wi = tw_im_g[off + k];   // (L1-resident: a copy in LDS costs occupancy)
+                    if (half >= 4)
+                        fe::bfly_fma(wr, wi, xr[j], xi[j], xr[j + (1 << r)], xi[j + (1 << r)]);
+                    else
+                        fe::bfly_scalar(wr, wi, xr[j], xi[j], xr[j + (1 << r)], xi[j + (1 << r)]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < gsz) re[FE_PAD(base + j * h)] = xr[j], im[FE_PAD(base + j * h)] = xi[j];
+        }
+        s0 += R;
+        __syncthreads();
+    }
+    for (int i = tid; i < fpb * nb; i += 256) {   // fft_frames_kernel mode 1: bins 0 and n / 2 have im forced to 0 (fft.rs:256-261)
+        const int f = i / nb, k = i - f * nb;
+        const float r = re[FE_PAD(f * n + k)];
+        const float q = (k == 0 || k == nb - 1) ? 0.0f : im[FE_PAD(f * n + k)];
+        pw[i] = fe::power(r, q);
+    }
+    __syncthreads();
+    for (int i = tid; i < nfr * n_mels; i += 256) {   // fe_generic_mel_kernel
+        const int f = i / n_mels, m = i - f * n_mels;
+        const float* pp = pw + f * nb + mstart[m];
+        const float* wp = mw + moff[m];
+        const int cnt = moff[m + 1] - moff[m];
+        float acc = 0.0f;
+        int t = 0;
+        for (; t + 8 <= cnt; t += 8) {   // eight weights and eight powers requested before the (sequential) sum: a filter has up to ~60 taps,
+            float w8[8], p8[8];          // and one memory round trip a tap was most of a workgroup's life (62 % of the wave cycles waiting)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w8[u] = wp[t + u], p8[u] = pp[t + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fe::fadd(acc, fe::fmul(w8[u], p8[u]));  // mel.rs:92-104
+        }
+        for (; t < cnt; ++t) acc = fe::fadd(acc, fe::fmul(wp[t], pp[t]));
+        logmel[((int64_t)blockIdx.y * num_frames + f0 + f) * n_mels + m] = __logf(fmaxf(acc, 1e-5f));      // mel.rs:124-128
     }
 }
 __global__ void fe_generic_lfr_kernel(const float* __restrict__ x, int64_t t, int64_t d, int64_t m, int64_t n,
@@ -768,6 +906,11 @@ int lele_hip_frontend_out_rows(const LeleFrontend* fe, int64_t pcm_len, int64_t*
     return 0;
 }
 
+static int ilog2_i(int n) {
+    int l = 0;
+    while ((1 << (l + 1)) <= n) ++l;
+    return l;
+}
 static int fe_run(LeleFrontend* fe, const LeleTensor* pcm, int64_t batch, int64_t pcm_len, LeleBuf* out,
                   bool want_logmel, int64_t* out_shape, int32_t* out_rank) {
     LeleCtx* ctx = fe->ctx;
@@ -792,6 +935,47 @@ static int fe_run(LeleFrontend* fe, const LeleTensor* pcm, int64_t batch, int64_
         // [rows, mels]; rows = utterances x frames) -- five launches a pass (looping over utterances on the host made the launches
         // the cost: 256 x 30 s at 16 kHz / 20 ms frames 16.1 ms)
         const int64_t bins = fe->n_fft / 2 + 1, nm = fe->cfg.n_mels;
+        // the fused form (fe_generic_fused_kernel): frames per workgroup so that their LDS image stays under 64 KB; anything larger
+        // (n_fft > 4096) keeps the four kernels
+        if (fe->fused && fe->n_fft <= 4096 && fe->frame_len <= fe->n_fft && batch <= 65535) {   // (lab: LELE_HIP_FE_FUSED=0 keeps the four kernels)
+            const int n = (int)fe->n_fft;
+            // (the kernel is bound by latency under its barriers, so by occupancy against work per workgroup: 4 frames of 1024 points with
+            // the twiddles in LDS = 55 KB = two workgroups a CU ran 15 ms where the four kernels took 12)
+            int fpb = n <= 512 ? 4 : n <= 1024 ? 2 : 1;   // measured (tools/fe_fpb.sh): n = 512: 3.9 / 2.6 / 2.4 / 3.1 ms for 1 / 2 / 4 / 8; n = 1024: 6.1 / 5.2 / 7.1 / 17.2
+            if (const char* e = lab_env("LELE_HIP_FE_FPB")) fpb = std::max(1, atoi(e));   // (lab) frames per workgroup
+            const size_t padded = (size_t)fpb * n + (((size_t)fpb * n) >> 5) + 1;
+            const size_t lds = (2 * padded + (size_t)fpb * bins + (size_t)(fpb - 1) * fe->hop_len + fe->frame_len + fpb) * 4;
+            if (lds <= 96 * 1024) {
+                const float *twr = nullptr, *twi = nullptr;
+                LELE_TRY(fft_twiddles(ctx, n, &twr, &twi));
+                LELE_HIP_CHECK(ensure_dyn_lds(reinterpret_cast<const void*>(fe_generic_fused_kernel), (int)lds));
+                const int64_t per_utt_lm = nf * nm * 4;
+                const int64_t ubf = want_logmel ? batch : std::max<int64_t>(1, std::min<int64_t>(batch, (int64_t(1) << 28) / std::max<int64_t>(per_utt_lm, 1)));
+                void* glm = nullptr;
+                if (!want_logmel) LELE_TRY(ctx->arena_alloc((size_t)ubf * nf * nm * 4, &glm));
+                for (int64_t u = 0; u < batch; u += ubf) {
+                    const int64_t nu = std::min<int64_t>(ubf, batch - u);
+                    const float* up = (const float*)dpcm + u * pcm_len;
+                    float* lm = want_logmel ? (float*)out->data + u * nf * nm : (float*)glm;
+                    hipLaunchKernelGGL(fe_generic_mean_kernel, dim3((unsigned)((nu * nf + 63) / 64)), dim3(64), 0, ctx->stream, up, nu * nf, nf, pcm_len,
+                                       (int)fe->frame_len, (int)fe->hop_len, (float*)dmean);
+                    hipLaunchKernelGGL(fe_generic_fused_kernel, dim3((unsigned)((nf + fpb - 1) / fpb), (unsigned)nu), dim3(256), lds, ctx->stream, up,
+                                       pcm_len, nf, (int)fe->frame_len, (int)fe->hop_len, n, ilog2_i(n), fpb, fe->g_window, twr, twi, (int)nm,
+                                       fe->g_mstart, fe->g_moff, fe->g_mw, (const float*)dmean, lm);
+                    if (!want_logmel) {
+                        dim3 lg((unsigned)std::max<int64_t>(1, std::min<int64_t>((t_lfr * cols + 255) / 256, 8192)), (unsigned)nu);
+                        hipLaunchKernelGGL(fe_generic_lfr_kernel, lg, dim3(256), 0, ctx->stream, (const float*)lm, nf, nm, fe->cfg.lfr_m,
+                                           fe->cfg.lfr_n, t_lfr, (float*)out->data + u * t_lfr * cols);
+                    }
+                }
+                LELE_HIP_CHECK(hipGetLastError());
+                if (want_logmel) {
+                    if (batch == 1) return set_shape(out_shape, out_rank, {nf, nm});
+                    return set_shape(out_shape, out_rank, {batch, nf, nm});
+                }
+                return 0;
+            }
+        }
         const int64_t per_utt = nf * (4 + fe->n_fft * 4 + bins * 4 + nm * 4);
         const int64_t ub = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(batch, 65535), (int64_t(1) << 28) / std::max<int64_t>(per_utt, 1)));
         void *gm = nullptr, *gf = nullptr, *gp = nullptr, *gl = nullptr;

@@ -150,6 +150,25 @@ def test_other_feature_configs_take_the_generic_path(ctx, orc, sr, fl, fs, nm):
     assert f2.compute(x[:10]).shape == ()  # shorter than one frame -> TensorView::empty()
 
 
+@lab_only
+@pytest.mark.parametrize("sr,fl,fs,nm", [(32000, 25.0, 10.0, 64), (16000, 20.0, 8.0, 40), (8000, 25.0, 10.0, 80), (40000, 25.0, 10.0, 128)])
+def test_generic_fused_kernel_equals_the_four_kernels(ctx, sr, fl, fs, nm):
+    """fe_generic_fused_kernel (frame sums, pre-emphasis + window, the radix-2 network and the sparse mel sums of FPB frames in one
+    workgroup's LDS) against the four launches it replaces (LELE_HIP_FE_FUSED=0, lab library): the same operations in the same order,
+    so every log-mel value and every LFR row bit for bit -- incl. a frame count that is not a multiple of the frames per workgroup"""
+    from lele_amd.features import FeatureConfig, SenseVoiceFrontend
+    cfg = FeatureConfig(sample_rate=sr, n_mels=nm, frame_length_ms=fl, frame_shift_ms=fs)
+    one = SenseVoiceFrontend(cfg, ctx=ctx)
+    os.environ["LELE_HIP_FE_FUSED"] = "0"
+    try:
+        four = SenseVoiceFrontend(cfg, ctx=ctx)
+    finally:
+        del os.environ["LELE_HIP_FE_FUSED"]
+    xs = np.stack([synth_pcm(int(sr * 1.37), s) for s in range(3)])
+    assert np.array_equal(one.logmel(xs).numpy(), four.logmel(xs).numpy())
+    assert np.array_equal(one.compute_batch(xs).numpy(), four.compute_batch(xs).numpy())
+
+
 def test_generic_path_batches_in_passes(ctx):
     """the composed path takes as many utterances per pass as fit its scratch budget (256 MiB): 24 x 30 s at 20 ms frames is two passes;
     every utterance equals its own single-utterance call bit for bit, whichever pass it fell into"""

@@ -222,8 +222,8 @@ def main():
     if want('misc') or want('frontend'):
         from lele_amd.features import FeatureConfig, SenseVoiceFrontend
         for label, cfg, sr in (("fused default 16 kHz / 25 ms / n_fft 512", FeatureConfig(), 16000),
-                               ("composed 32 kHz / 25 ms / n_fft 1024", FeatureConfig(sample_rate=32000), 32000),
-                               ("composed 16 kHz / 20 ms / n_fft 512", FeatureConfig(frame_length_ms=20.0), 16000)):
+                               ("generic 32 kHz / 25 ms / n_fft 1024", FeatureConfig(sample_rate=32000), 32000),
+                               ("generic 16 kHz / 20 ms / n_fft 512", FeatureConfig(frame_length_ms=20.0), 16000)):
             nb_, secs = (64 if args.quick else 256), 30
             pcm = dev((rng.standard_normal((nb_, sr * secs)) * 0.1).astype(np.float32))
             fe = SenseVoiceFrontend(cfg, ctx=ctx)
