@@ -170,8 +170,8 @@ def test_generic_fused_kernel_equals_the_four_kernels(ctx, sr, fl, fs, nm):
 
 
 def test_generic_path_batches_in_passes(ctx):
-    """the composed path takes as many utterances per pass as fit its scratch budget (256 MiB): 24 x 30 s at 20 ms frames is two passes;
-    every utterance equals its own single-utterance call bit for bit, whichever pass it fell into"""
+    """the generic path over a batch (one launch of the fused generic kernel for all utterances; passes only when the log-mel scratch of the
+    batch exceeds 256 MiB): every utterance equals its own single-utterance call bit for bit, whichever workgroup / pass it fell into"""
     from lele_amd.features import FeatureConfig, SenseVoiceFrontend
     f2 = SenseVoiceFrontend(FeatureConfig(frame_length_ms=20.0, frame_shift_ms=8.0, n_mels=40), ctx=ctx)
     rng = np.random.default_rng(3)
