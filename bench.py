@@ -509,6 +509,41 @@ def sensevoice_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_
                           "hbm_gbs": round(byts / (op_ms * 1e-3) / 1e9, 1) if op_ms > 0 else None,
                           "tops": round(ops / (op_ms * 1e-3) / 1e12, 1) if op_ms > 0 else None}
 
+        # the layer's fused feed-forward block as the model runs it: first product (range + quantise in one launch), second product +
+        # residual Add + the next LayerNorm = two launches; 20 calls recorded into a hipGraph, replays timed with HIP events
+        try:
+            L2 = enc.layers[2]
+            x1 = ctx.buf().upload(np.random.default_rng(6).standard_normal((hi - lo, c4["logits"].shape[1], 512)).astype(np.float32))
+            x1n = K.layer_norm(x1, L.ln2[0], L.ln2[1], -1, 1e-5, out=ctx.buf(), ctx=ctx)
+            o2 = [ctx.buf(), ctx.buf()]
+            f1, f2 = L.ffn1, L.ffn2
+
+            def block():
+                return K.fused_ffn_quantized_ln(x1n, f1.w, f1.scale, f1.zero, f1.bias, f2.w, f2.scale, f2.zero, f2.bias, False, x1, None,
+                                                L2.ln1[0], L2.ln1[1], 1e-5, outs=o2, ctx=ctx)
+            for _ in range(3):
+                block()
+            ctx.sync()
+            ctx.graph_begin()
+            for _ in range(20):
+                block()
+            gb = ctx.graph_end()
+            gb.launch()
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(10):
+                gb.launch()
+            blk_ms = ctx.timer_stop() / 200.0
+            gb.close()
+            m_rows = (hi - lo) * c4["logits"].shape[1]
+            bbytes = 4 * m_rows * 512 * 4 + 512 * 2048 * 2 + 8 * (2048 + 512) + 8 * 512   # x1n, x1 in; sum and its LayerNorm out; both weights; scales, biases, LN
+            bops = 2 * 2 * m_rows * 512 * 2048                                             # the two products (the first one's recompute is not counted)
+            rec["ffn_block"] = {"what": "fused_ffn_quantized_ln [%d x 512] -> 2048 -> 512 + residual + LayerNorm: igemm_rs_kernel<3> + igemm_ask_kernel" % m_rows,
+                                "op_ms": round(blk_ms, 5), "algorithmic_bytes": bbytes, "int_ops": bops,
+                                "hbm_gbs": round(bbytes / (blk_ms * 1e-3) / 1e9, 1), "tops": round(bops / (blk_ms * 1e-3) / 1e12, 1)}
+        except Exception as e:  # noqa: BLE001
+            rec["ffn_block"] = {"failed": str(e)}
+
     # ---- configs[2]: one 30 s utterance, lele's own protocol (N = 1 only)
     if world == 1:
         c3 = build(1, 30, 0)
@@ -1136,6 +1171,10 @@ def run_rank(args):
                              "model_achieved": q["hbm_gbs"], "model_peak": HBM_PEAK_GBS, "model_unit": "GB/s",
                              "model_frac": round(q["hbm_gbs"] / HBM_PEAK_GBS, 4), "model_tops": q["tops"],
                              "model_mfma_frac": round(q["tops"] / I8_PEAK_TOPS, 4)})
+            fb = sv.get("ffn_block")
+            if fb and fb.get("op_ms"):   # the fused kernels of round 6 (two launches for the whole feed-forward block of a layer)
+                roof.update({"model_block": fb["what"], "model_block_op_ms": fb["op_ms"], "model_block_frac": round(fb["hbm_gbs"] / HBM_PEAK_GBS, 4),
+                             "model_block_tops": fb["tops"], "model_block_mfma_frac": round(fb["tops"] / I8_PEAK_TOPS, 4)})
         layers = None
         if yo is not None:
             layers = yo.pop("_layers", None)
