@@ -1064,6 +1064,9 @@ def run_rank(args):
         backend = os.environ.get("LELE_BENCH_BACKEND", "nccl")
         if os.environ.get("LELE_BENCH_SHARE_GPU") == "1":
             local_rank = local_rank % max(1, torch.cuda.device_count())
+            # several PROCESSES on one device: the one-launch feed-forward kernel waits for workgroups of its own launch, which another
+            # process's kernels may keep off the CUs -- the two-launch form where ranks share a GPU
+            os.environ.setdefault("LELE_HIP_FFN_ONE_LAUNCH", "0")
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             device = torch.device("cuda", local_rank)
