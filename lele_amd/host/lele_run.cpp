@@ -58,6 +58,7 @@ int main(int argc, char** argv) {
                     setenv("LELE_WORLD", std::to_string(ranks).c_str(), 1);
                     setenv("LELE_COMM_FILE", id_file.c_str(), 1);
                     if (!std::getenv("LELE_RUN_SHARE_GPU")) setenv("LELE_HIP_DEVICE", std::to_string(r).c_str(), 1);
+                    else setenv("LELE_HIP_FFN_ONE_LAUNCH", "0", 0);   // processes sharing a device: no kernel that waits for its own workgroups
                     rank = r;
                     break;
                 }
