@@ -876,7 +876,7 @@ def yolo_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_note=N
 
     def as_dag(runner, feed, want):
         """the plan with its independent branches on lanes (lele_amd/lanes.py): per-statement device times of one eager pass (trains of 8
-        launches), list scheduling over 3 lanes where a fork buys at least 40 us (a fork / join pair costs a hipGraph ~8 us:
+        launches), list scheduling over 4 lanes where a fork buys at least 40 us (a fork / join pair costs a hipGraph ~8 us:
         profiles/r05_dag_bench.json), buffers re-assigned under happens-before.  Used only when its outputs equal `want` bit for bit."""
         from lele_amd.lanes import schedule
         try:
@@ -884,7 +884,7 @@ def yolo_leg(args, ctx, rank, world, fence, dist, device, comm=None, comm_note=N
             runner.run(feed)
             times = {o: ms for _i, _fn, o, ms in runner.stmt_times}
             runner.stmt_times, runner.stmt_repeat = None, 1
-            dag = schedule(runner.plan, times, lanes=3, min_gain_ms=0.04)
+            dag = schedule(runner.plan, times, lanes=4, min_gain_ms=0.04)   # (3 lanes: 7.83 ms, 4: 7.76 on the reference graph, tools/dag_bench.py)
             if dag is None or dag["dag"]["lanes"] < 2:
                 return runner, {"used": False, "why": "no branch worth a fork"}
             r2 = Runner(dag, runner.raw, ctx)
