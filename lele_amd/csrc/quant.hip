@@ -1031,11 +1031,11 @@ int rs_kp(int64_t k) {
 // enough 32 x 32 tiles, 16-byte stores, 32-bit byte offsets into the result.  (Round 3 asked for 8 tiles per CU: below that the
 // quantising pass + small-problem GEMM were faster.  With the rows quantised inside the kernel the route needs no pass in front, and
 // one 30 s utterance -- 16 row tiles x 48-64 column tiles -- gains 7 % per forward on it: 2 tiles per CU.)
-bool rs_enabled(LeleCtx* ctx, int64_t rows, int64_t n) {
+bool rs_enabled(LeleCtx* ctx, int64_t rows, int64_t n, int per_cu = 2) {
     if (env_int("LELE_HIP_IGEMM_RS", 1) == 0) return false;  // documented switch: 0 = the tiled kernels everywhere
     if (n % 4 || rows * n >= (int64_t(1) << 30)) return false;
     const int64_t units = ((rows + 31) / 32) * ((n + 31) / 32);
-    return units >= (int64_t)lab_int("LELE_HIP_IGEMM_RS_MIN", 2 * ctx->num_cus);
+    return units >= (int64_t)lab_int("LELE_HIP_IGEMM_RS_MIN", per_cu * ctx->num_cus);
 }
 // the stand-alone linear.  Measured on one configs[3] shard (tools/rs_bench.py, whole op incl. the row quantisation): N = 1536
 // 24.9 us against 28.7 us tiled, N = 2048 27.2 against 29.5 -- but N = 512 23.0 against 18.7 (few column tiles: the
@@ -1753,8 +1753,10 @@ static int ffn_impl(LeleCtx* ctx, const LeleTensor* input, const LeleTensor* w1_
                          (ws1_len == 1 || ws1_len >= n1) && (b1_len == 0 || b1_len >= n1) && n2 >= 1;
     // register-stationary route (igemm_rs.h): K = 512 into a hidden layer of exactly 2048 columns, whose i8 form is written in the
     // fragment order of the second product and read once
+    // (the second product's threshold is ONE tile per CU: at one 30 s utterance -- 16 x 16 tiles -- the fused block replaces ffn1 with an f32
+    // hidden layer | row quantisation | small-problem GEMM: a configs[2] forward 5.33 -> 5.05 ms, round 6)
     const bool rs_route = env_int("LELE_HIP_FFN_FUSED", 1) != 0 && args_ok && rs_kp(k1) == 512 && n1 == 2048 && rs_enabled(ctx, rows, n1) &&
-                          rs_enabled(ctx, rows, n2) && rs_aligned(res1) && rs_aligned(res2);
+                          rs_enabled(ctx, rows, n2, 1) && rs_aligned(res1) && rs_aligned(res2);
     bool fused = rs_route || (env_int("LELE_HIP_FFN_FUSED", 1) != 0 && args_ok && n1 % 128 == 0 && m >= 128 &&
                               ((rows + 127) / 128) * (n1 / 128) >= 2 * (int64_t)ctx->num_cus);
     if (fused && res1) {
