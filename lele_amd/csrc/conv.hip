@@ -970,6 +970,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const cu32x4* wnxt = wcur;
     auto wload = [&](cu32x4 (&dst)[3], int gt) {  // fragment gt of the current block; one past its end: the next block's first
         const cu32x4* src = gt < wtaps ? wcur + (int64_t)gt * (3 * 64) : wnxt;
+#ifdef LELE_HIP_LAB
+        if (g.dh & 0x100) src = wcur;  // knock-out (LELE_HIP_CONV_KO=1): every fragment is the block's first -- what do the consumers' weight fetches cost?
+#endif
 #pragma unroll
         for (int p = 0; p < 3; ++p) dst[p] = src[p * 64];
     };
@@ -1468,6 +1471,9 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
             g.ih = g.oh = 1;
             g.iw = g.ow = g.plane;
         }
+#ifdef LELE_HIP_LAB
+        g.dh |= conv_env("LELE_HIP_CONV_KO", 0) << 8;  // the window kernels never read the dilation (it is 1 here): lab knock-out flags ride in it
+#endif
         ConvEpi epi{out, db, g, act};
         const WinTile tile = pick_win_tile(g.ow, g.oh, positions, g.kh, 1, taps == 9 ? C3M<3>::POS : C3M<1>::POS, (int64_t)g.n * ((g.oc + oct - 1) / oct),
                                            ctx->num_cus);
@@ -1476,7 +1482,7 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
         const int osplit = (int64_t)g.n * ntiles >= 2 * (int64_t)ctx->num_cus ? 1 : nblocks, nocb = nblocks / osplit;
         const int64_t items = (int64_t)g.n * ntiles * osplit;
         LELE_REQUIRE(items < (int64_t(1) << 31), "conv2d: more than 2^31 tiles");
-        const dim3 pgrid((unsigned)std::min<int64_t>(items, 2 * (int64_t)ctx->num_cus));
+        const dim3 pgrid((unsigned)std::min<int64_t>(items, conv_env("LELE_HIP_CONV_WG_PER_CU", 2) * (int64_t)ctx->num_cus));
 #define LELE_CW(KS_, OCT_)                                                                                                              \
     do {                                                                                                                                \
         auto kern = conv_window_p_kernel<KS_, OCT_>;                                                                                     \
@@ -1526,7 +1532,7 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
         const int osplit = (int64_t)g.n * ntiles >= 2 * (int64_t)ctx->num_cus ? 1 : nblocks, nocb = nblocks / osplit;
         const int64_t items = (int64_t)g.n * ntiles * osplit;
         LELE_REQUIRE(items < (int64_t(1) << 31), "conv2d: more than 2^31 tiles");
-        const dim3 pgrid((unsigned)std::min<int64_t>(items, 2 * (int64_t)ctx->num_cus));
+        const dim3 pgrid((unsigned)std::min<int64_t>(items, conv_env("LELE_HIP_CONV_WG_PER_CU", 2) * (int64_t)ctx->num_cus));
         if (oct == 64) {
             auto kern = conv_window_s2_kernel<64>;
             LELE_HIP_CHECK(lele::ensure_dyn_lds(reinterpret_cast<const void*>(kern), C3S2::STAGE));

@@ -124,11 +124,12 @@ def compute_bound(args):
     rng = np.random.default_rng(0)
     PEAK = 3944.0
     res = []
-    for m in (8192, 32768):
-        for k in (512, 2048, 4096):
-            for n in (2048, 4096):
-                if args.shapes and "%dx%dx%d" % (m, k, n) not in args.shapes.split(","):
-                    continue
+    grid = [(m, k, n) for m in (8192, 32768) for k in (512, 2048, 4096) for n in (2048, 4096)]
+    if args.shapes:   # any MxKxN, not only the grid's
+        grid = [tuple(int(v) for v in s_.split("x")) for s_ in args.shapes.split(",")]
+    for m, k, n in grid:
+        for _once in (0,):
+            for _once2 in (0,):
                 x = ctx.buf().upload(rng.standard_normal((1, m, k)).astype(np.float32))
                 wq = np.clip(np.round(128 + 32 * rng.standard_normal((k, n))), 0, 255).astype(np.float32)
                 w = (Weight(wq), Weight((np.abs(rng.standard_normal(n)) * 0.01 + 0.002).astype(np.float32)),
