@@ -48,6 +48,11 @@ __device__ __forceinline__ float apply_act(float v, int act, bool body) {
     return v;
 }
 
+// Developer's knock-out builds of the window kernels (tools/conv_ko_build.sh: -DLELE_CONV_KO=<bits>, never the product): 2 = next to
+// nothing is stored, 4 = one product instead of six, 8 = the window loads read past their resource (zeros, no memory access).
+#ifndef LELE_CONV_KO
+#define LELE_CONV_KO 0
+#endif
 struct ConvGeom {
     int n, c, ih, iw, oc, kh, kw, group, icg, ocg, pt, pl, sh, sw, dh, dw, oh, ow, K, plane;
     // elements from one image to the next in x / out.  0 = dense (c*ih*iw / oc*plane, filled in by run_conv2d); anything else is a
@@ -780,6 +785,7 @@ __device__ __forceinline__ void c3m_epilogue_strips(const cf32x16 (&acc)[NJ], co
                     float4 v = rv[j][it];
                     if (epi.bias) v.x = v.x + bq[it], v.y = v.y + bq[it], v.z = v.z + bq[it], v.w = v.w + bq[it];
                     v.x = fn(v.x, body), v.y = fn(v.y, body), v.z = fn(v.z, body), v.w = fn(v.w, body);
+                    if ((LELE_CONV_KO & 2) && v.x != 12345.678f) continue;
                     if (colq[j] >= 0 && oc < g.oc) {
                         LELE_DEV_ASSERT(colq[j] + 3 < g.plane && img >= 0 && img < g.n);
                         if (g.res) {  // uniform
@@ -877,7 +883,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         const float* xin = x;
         int f_item = first - G, f_ocb = nocb - 1, f_cc = nchunk - 1;  // the fetch cursor: one step before the first chunk
-        auto fetch = [&](float4 (&st)[W::TASKS]) {
+        auto fetch = [&](float4 (&st)[W::TASKS], bool live) {
             if (++f_cc == nchunk) {
                 f_cc = 0;
                 if (++f_ocb == nocb) {  // the next item: where its window lies
@@ -897,7 +903,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             }
             // one resource per channel of a quad (bases one plane apart, 13 planes long), as in the stride-2 kernel
             const float* cb = xin + (int64_t)f_cc * 16 * hw;
-            const int extent = (int)(13u * (unsigned)hw * 4u);
+            // (`live` false: past the last chunk -- the same loads against an empty resource read zeros without touching memory.  The loads
+            // must not sit under a branch: the compiler's in-order count of the loads in flight is exact only on straight-line code; with
+            // `if (more) fetch()` every park waited for ALL D sets, vmcnt(0), i.e. for the chunk just requested)
+            const int extent = (LELE_CONV_KO & 8) || !live ? 0 : (int)(13u * (unsigned)hw * 4u);
             const auto r0 = __builtin_amdgcn_make_buffer_rsrc((void*)cb, (short)0, extent, 0x00020000);
             const auto r1 = __builtin_amdgcn_make_buffer_rsrc((void*)(cb + hw), (short)0, extent, 0x00020000);
             const auto r2 = __builtin_amdgcn_make_buffer_rsrc((void*)(cb + 2 * hw), (short)0, extent, 0x00020000);
@@ -929,8 +938,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         constexpr int D = KS == 1 ? 4 : 3;
         float4 st[D][W::TASKS];
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-            if (d < qtotal) fetch(st[d]);
+        for (int d = 0; d < D; ++d) fetch(st[d], d < qtotal);
         park(st[0], 0);
         barrier();  // B_0
         // `since` = (q - 1) % nchunk for the chunk q about to be parked: 0 means chunk q - 2 ended an item's block, whose epilogue uses
@@ -941,7 +949,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int u = 0; u < D; ++u) {  // chunk q0 + u sits in set (1 + u) % D; parking chunk q0 + u - 1 freed set u % D
                 const int q = q0 + u;
                 if (q >= qtotal) break;
-                if (q - 1 + D < qtotal) fetch(st[u % D]);
+                fetch(st[u % D], q - 1 + D < qtotal);
                 if (q >= 2 && since == 0) barrier();  // E
                 park(st[(1 + u) % D], q & 1);
                 barrier();  // B_q
@@ -998,9 +1006,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int tap = 0; tap < W::TAPS; ++tap) {
                 cu32x4 (&af)[3] = ar[(P + tap) & 1];
                 wload(ar[(P + tap + 1) & 1], cc * W::TAPS + tap + 1);
+                // the next tap's weights are REQUESTED here: left to itself the scheduler sinks the three loads behind the tap's products, and
+                // the next tap then waits a whole round trip for them
+                __builtin_amdgcn_sched_barrier(0);
                 if (tap + 1 < W::TAPS) loadb(bfr[(tap + 1) & 1], tap + 1);
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = (LELE_CONV_KO & 4) ? 5 : 0; t < 6; ++t)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_CBF(af[PA[t]]), LELE_CBF(bfr[tap & 1][j][PB[t]]), acc[j], 0, 0, 0);
@@ -1014,6 +1025,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const char* tapw = stage + (a * pwt + b) * C3M_PITCH;
             cu32x4 (&af)[3] = ar[(P + tap) & 1];
             wload(ar[(P + tap + 1) & 1], cc * W::TAPS + tap + 1);
+            // the next tap's weights are REQUESTED here: left to itself the scheduler sinks the three loads behind the tap's products, and
+            // the next tap then waits a whole round trip for them
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int jp = 0; jp < NJ / 2; ++jp) {
                 cu32x4 bf[2][3];
@@ -1024,7 +1038,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const cu32x4*>(src + 32 * p);
                 }
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = (LELE_CONV_KO & 4) ? 5 : 0; t < 6; ++t)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[2 * jp + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(LELE_CBF(af[PA[t]]), LELE_CBF(bf[j][PB[t]]), acc[2 * jp + j], 0, 0, 0);
@@ -1214,6 +1228,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const char* tapw = c3m_lds + ((2 * (a & 1) + (b & 1)) * planet + (a >> 1) * sxt + (b >> 1)) * C3M_PITCH;
             cu32x4 (&af)[3] = ar[(P + tap) & 1];
             wload(ar[(P + tap + 1) & 1], cc * TAPS + tap + 1);
+            // the next tap's weights are REQUESTED here: left to itself the scheduler sinks the three loads behind the tap's products, and
+            // the next tap then waits a whole round trip for them
+            __builtin_amdgcn_sched_barrier(0);
 #define LELE_CBF(v) __builtin_bit_cast(cbf16x8, v)
             constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};  // mm, hl, lh, hm, mh, hh: smallest terms first
             cu32x4 bf[NJ][3];
