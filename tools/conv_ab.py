@@ -24,6 +24,8 @@ GEOMS = [
     (64, 80, 1, 1, 80), (96, 64, 1, 1, 80), (64, 64, 1, 1, 80), (384, 128, 1, 1, 40), (192, 128, 1, 1, 40), (128, 80, 1, 1, 40),
     (64, 64, 1, 1, 40), (64, 32, 1, 1, 40), (512, 256, 1, 1, 20), (384, 256, 1, 1, 20), (256, 256, 1, 1, 20), (128, 256, 1, 1, 20),
     (128, 128, 1, 1, 20), (256, 80, 1, 1, 20), (128, 64, 1, 1, 20),
+    # the direct kernel's layers of the reference graph (few channels)
+    (3, 16, 3, 2, 320), (16, 8, 3, 1, 160), (8, 16, 3, 1, 160), (16, 16, 3, 1, 80), (16, 16, 3, 1, 20),
 ]
 
 
