@@ -205,6 +205,9 @@ struct ConvEpi {
     const float* bias;
     ConvGeom g;
     int act;
+#ifdef LELE_HIP_LAB
+    long long* dbg = nullptr;  // lab switch LELE_HIP_CONV_STAMPS (tools/conv_stamps.py): [workgroup][8 waves][64] shader-clock stamps of the window kernel
+#endif
     __device__ __forceinline__ float load(int b, int row, int col) const {  // clamped coordinates, unconditional
         return bias ? bias[(b % g.group) * g.ocg + row] : 0.0f;
     }
@@ -869,6 +872,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int nseq = nitem * nocb;    // (item, block of output channels) pairs, in order
     const int qtotal = nseq * nchunk;  // chunks of the whole stream
     auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
+#ifdef LELE_HIP_LAB
+    long long* const dbg_w = epi.dbg ? epi.dbg + ((size_t)blockIdx.x * 8 + wave) * 64 : nullptr;
+    int dbg_n = 0;
+#define C_STAMP()                                                              \
+    do {                                                                       \
+        if (dbg_w && dbg_n < 64 && lane == 0) dbg_w[dbg_n] = (long long)clock64(); \
+        ++dbg_n;                                                               \
+    } while (0)
+#else
+#define C_STAMP()
+#endif
+    C_STAMP();  // 0: entry
     if (wave >= 4) {
         // ------------------------------------------------------------ producers
         const int pt = tid - 256;
@@ -939,8 +954,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         float4 st[D][W::TASKS];
 #pragma unroll
         for (int d = 0; d < D; ++d) fetch(st[d], d < qtotal);
+        C_STAMP();  // 1: D chunks requested
         park(st[0], 0);
+        C_STAMP();  // 2: chunk 0 parked
         barrier();  // B_0
+        C_STAMP();  // 3
         // `since` = (q - 1) % nchunk for the chunk q about to be parked: 0 means chunk q - 2 ended an item's block, whose epilogue uses
         // the stage chunk q goes to -- wait for E first
         int since = 0;
@@ -950,9 +968,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const int q = q0 + u;
                 if (q >= qtotal) break;
                 fetch(st[u % D], q - 1 + D < qtotal);
+                C_STAMP();  // 4 + 3 (q - 1): requested
                 if (q >= 2 && since == 0) barrier();  // E
                 park(st[(1 + u) % D], q & 1);
+                C_STAMP();  // 5 + 3 (q - 1): chunk q parked
                 barrier();  // B_q
+                C_STAMP();  // 6 + 3 (q - 1)
                 if (++since == nchunk) since = 0;
             }
         }
@@ -1050,6 +1071,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int item = first, ocb = 0;
     wload(ar[0], 0);
     barrier();  // B_0
+    C_STAMP();  // 1: chunk 0 is there
     for (int s = 0; s < nseq; ++s) {
         const int pair = item / osplit, grp = item - pair * osplit;
         const int img = pair / ntiles, tile = pair - img * ntiles, tyi = tile / wt.tiles_x, txi = tile - tyi * wt.tiles_x;
@@ -1067,25 +1089,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         int cc = 0;
         for (; cc + 1 < nchunk; cc += 2) {
             chunk(cc, std::integral_constant<int, 0>());
+            C_STAMP();  // products issued
             barrier();  // B_{q + 1}: done with this stage, and the next chunk is in the other one
+            C_STAMP();
             ++q;
             chunk(cc + 1, std::integral_constant<int, 1>());
+            C_STAMP();
             barrier();
+            C_STAMP();
             ++q;
         }
         if (cc < nchunk) {
             chunk(cc, std::integral_constant<int, 0>());
+            C_STAMP();
             barrier();
+            C_STAMP();
             ++q;
 #pragma unroll
             for (int p = 0; p < 3; ++p) ar[0][p] = ar[1][p];
         }
         c3m_epilogue_strips<NJ, OCT>(acc, epi, g, c3m_lds + ((q - 1) & 1) * W::STAGE, wave, lane, wm, wn, blk, img, tyi * wt.th, txi * wt.tw, wt);
+        C_STAMP();  // strips out
         if (q + 1 < qtotal) barrier();  // E: chunk q + 1 may now be parked where the strips went
+        C_STAMP();
         wcur = wnxt;
         if (++ocb == nocb) ocb = 0, item += G;
     }
 }
+#undef C_STAMP
 // ---- the same for STRIDE 2 (3 x 3): a workgroup owns 64 output channels x (4 rows x 32 columns) of one image.  The window of a
 // stride-2 tile is 9 x 65 input positions; stored as it lies, tap (a, b) of output column l would read position 2 l + b -- a
 // 224-byte lane stride, two lanes per bank.  The producers therefore store the window DE-INTERLEAVED into its four phases
@@ -1492,6 +1523,9 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
         g.dh |= conv_env("LELE_HIP_CONV_KO", 0) << 8;  // the window kernels never read the dilation (it is 1 here): lab knock-out flags ride in it
 #endif
         ConvEpi epi{out, db, g, act};
+#ifdef LELE_HIP_LAB
+        if (const char* e = lab_env("LELE_HIP_CONV_STAMPS")) epi.dbg = (long long*)(uintptr_t)strtoull(e, nullptr, 0);
+#endif
         const WinTile tile = pick_win_tile(g.ow, g.oh, positions, g.kh, 1, taps == 9 ? C3M<3>::POS : C3M<1>::POS, (int64_t)g.n * ((g.oc + oct - 1) / oct),
                                            ctx->num_cus);
         // at most two workgroups per CU, each walking through its share of the items (see conv_window_p_kernel)

@@ -5,7 +5,7 @@
 export LELE_HIP_LAB=1
 for f in "$@"; do
   python tools/conv_ab.py --only "$f" 2>/dev/null | grep geom | sed "s/^/ko=0 /"
-  for ko in 2 4 8 14; do
+  for ko in ${KOS:-2 4 8 14}; do
     LELE_HIP_LIBRARY=liblele_hip_ko$ko.so python tools/conv_ab.py --only "$f" 2>/dev/null | grep geom | sed "s/^/ko=$ko /"
   done
 done
