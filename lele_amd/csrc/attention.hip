@@ -622,7 +622,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const int bi = bh % a.batch_inner, bo = bh / a.batch_inner;
     const int nkt = (a.tk + 31) / 32;
-    auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
+    // (a raw s_barrier: the compiler's own would wait vmcnt(0), i.e. for every load in flight.  What it must wait for is this wave's LDS
+    // traffic -- a parked chunk's ds_writes are only ISSUED when the instruction after them runs, and the barrier hands the stage over)
+    auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     if (wave >= 4) {
         // ------------------------------------------------------------ a producer: four of a tile's sixteen operand fragments
         const int pw = wave - 4;          // 0, 1: K chunks 4 pw .. 4 pw + 3;  2, 3: V^T fragments of key half c2 = pw - 2

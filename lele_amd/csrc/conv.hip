@@ -737,7 +737,23 @@ __device__ __forceinline__ int wt_row(const WinTile& t, int p) { return (int)(((
 // interleaved runs: 8.70-8.77 ms against 9.01-9.06 with one workgroup per tile.
 template <int NJ, int OCT>
 __device__ __forceinline__ void c3m_epilogue_strips(const cf32x16 (&acc)[NJ], const ConvEpi& epi, const ConvGeom& g, char* region, int wave, int lane,
-                                                    int wm, int wn, int ocb, int img, int ty0, int tx0, const WinTile& wt) {
+                                                    int wm, int wn, int ocb, int img, int ty0, int tx0, const WinTile& wt
+#ifdef LELE_HIP_LAB
+                                                    , long long* dbg_w = nullptr, int* dbg_np = nullptr
+#endif
+) {
+#ifdef LELE_HIP_LAB
+#define E_STAMP()                                                                        \
+    do {                                                                                 \
+        if (dbg_np) {                                                                    \
+            if (dbg_w && *dbg_np < 64 && (lane & 63) == 0) dbg_w[*dbg_np] = (long long)clock64(); \
+            ++*dbg_np;                                                                   \
+        }                                                                                \
+    } while (0)
+#else
+#define E_STAMP()
+#endif
+    E_STAMP();  // e0
     // everything below that depends on the lane alone is cheap to compute and expensive to keep: left to itself the compiler hoists it
     // out of the persistent kernel's item loop, finds no registers for it beside the accumulators and the weight fragments, and reloads
     // it from scratch memory in every epilogue
@@ -769,6 +785,7 @@ __device__ __forceinline__ void c3m_epilogue_strips(const cf32x16 (&acc)[NJ], co
         }
         // the activation's scalar-tail form (libm) only where some lane is in the last 0-7 positions of the plane
         const bool all_body = __builtin_amdgcn_ballot_w64(!every) == 0;
+        E_STAMP();  // e1: bias values requested, coordinates known
         float4 rv[NJ][4];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -778,10 +795,23 @@ __device__ __forceinline__ void c3m_epilogue_strips(const cf32x16 (&acc)[NJ], co
             for (int it = 0; it < 4; ++it)  // same-wave LDS order holds: no barrier, and the next strip's writes come after these reads
                 rv[j][it] = *reinterpret_cast<const float4*>(mine + (it * 8 + rsub) * P + 4 * q4);
         }
+        E_STAMP();  // e2: the strips' LDS turn is issued
         auto run = [&](auto fn) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
+                if (j == 1) E_STAMP();  // e3: strip 0 is out (waited for the bias values and the first pieces)
                 const bool body = colq[j] < (g.plane & ~7);
+                // a residual's four pieces of the strip are requested together, ahead of the activation: fetched where they are added, each
+                // piece waited a round trip for its own load (vmcnt(0) sixteen times an item on the 18 bottleneck layers of the network)
+                float4 r4[4];
+                if (g.res) {  // uniform
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int oc = ocw + it * 8 + rsub;
+                        const bool ok = colq[j] >= 0 && oc < g.oc;
+                        r4[it] = *reinterpret_cast<const float4*>(g.res + (int64_t)img * g.rbs + (int64_t)(ok ? oc : 0) * g.plane + (ok ? colq[j] : 0));
+                    }
+                }
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int oc = ocw + it * 8 + rsub;
@@ -791,10 +821,7 @@ __device__ __forceinline__ void c3m_epilogue_strips(const cf32x16 (&acc)[NJ], co
                     if ((LELE_CONV_KO & 2) && v.x != 12345.678f) continue;
                     if (colq[j] >= 0 && oc < g.oc) {
                         LELE_DEV_ASSERT(colq[j] + 3 < g.plane && img >= 0 && img < g.n);
-                        if (g.res) {  // uniform
-                            const float4 r4 = *reinterpret_cast<const float4*>(g.res + (int64_t)img * g.rbs + (int64_t)oc * g.plane + colq[j]);
-                            v.x = v.x + r4.x, v.y = v.y + r4.y, v.z = v.z + r4.z, v.w = v.w + r4.w;
-                        }
+                        if (g.res) v.x = v.x + r4[it].x, v.y = v.y + r4[it].y, v.z = v.z + r4[it].z, v.w = v.w + r4[it].w;  // uniform
                         *reinterpret_cast<float4*>(epi.out + (int64_t)img * g.obs + (int64_t)oc * g.plane + colq[j]) = v;
                     }
                 }
@@ -805,6 +832,7 @@ __device__ __forceinline__ void c3m_epilogue_strips(const cf32x16 (&acc)[NJ], co
         else if (epi.act == LELE_ACT_SILU) run([](float v, bool) { return silu_fast(v); });
         else if (all_body) run([](float v, bool) { return apply_act(v, kActSiluExact, true); });
         else run([](float v, bool b) { return apply_act(v, kActSiluExact, b); });
+        E_STAMP();  // e4: all stores issued
         return;
     }
     float bv[16];  // the scalar path: every value where it sits
@@ -826,6 +854,7 @@ __device__ __forceinline__ void c3m_epilogue_strips(const cf32x16 (&acc)[NJ], co
     }
 }
 
+#undef E_STAMP
 // Which items a persistent workgroup takes.  Workgroup b runs on XCD b % 8, and every XCD has its own L2: handed out round robin
 // (b, b + G, ...), the tiles next to each other in an image -- whose windows share halo rows and, more to the point, the 128-byte lines
 // their ragged row ends lie in -- are multiplied on eight different XCDs, and each fetches those lines again (counters on the
@@ -871,7 +900,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int nitem = win_items(items, &first, &G);
     const int nseq = nitem * nocb;    // (item, block of output channels) pairs, in order
     const int qtotal = nseq * nchunk;  // chunks of the whole stream
-    auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
+    // (a raw s_barrier: the compiler's own would wait vmcnt(0), i.e. for every load in flight.  What it must wait for is this wave's LDS
+    // traffic -- a parked chunk's ds_writes are only ISSUED when the instruction after them runs, and the barrier hands the stage over)
+    auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 #ifdef LELE_HIP_LAB
     long long* const dbg_w = epi.dbg ? epi.dbg + ((size_t)blockIdx.x * 8 + wave) * 64 : nullptr;
     int dbg_n = 0;
@@ -1108,7 +1139,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int p = 0; p < 3; ++p) ar[0][p] = ar[1][p];
         }
+#ifdef LELE_HIP_LAB
+        c3m_epilogue_strips<NJ, OCT>(acc, epi, g, c3m_lds + ((q - 1) & 1) * W::STAGE, wave, lane, wm, wn, blk, img, tyi * wt.th, txi * wt.tw, wt, dbg_w, &dbg_n);
+#else
         c3m_epilogue_strips<NJ, OCT>(acc, epi, g, c3m_lds + ((q - 1) & 1) * W::STAGE, wave, lane, wm, wn, blk, img, tyi * wt.th, txi * wt.tw, wt);
+#endif
         C_STAMP();  // strips out
         if (q + 1 < qtotal) barrier();  // E: chunk q + 1 may now be parked where the strips went
         C_STAMP();
@@ -1152,7 +1187,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     int first, G;
     const int nitem = win_items(items, &first, &G);
     const int nseq = nitem * nocb, qtotal = nseq * nchunk;
-    auto barrier = [] { asm volatile("s_barrier" ::: "memory"); };
+    // (a raw s_barrier: the compiler's own would wait vmcnt(0), i.e. for every load in flight.  What it must wait for is this wave's LDS
+    // traffic -- a parked chunk's ds_writes are only ISSUED when the instruction after them runs, and the barrier hands the stage over)
+    auto barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     if (wave >= 4) {
         // ------------------------------------------------------------ producers: one chunk in registers, parked when the stage is free
         const int pt = tid - 256;

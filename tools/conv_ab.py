@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--act", default="silu", choices=["silu", "none", "relu"])
     ap.add_argument("--dw", action="store_true", help="the depthwise 3 x 3 layers instead (group = channels)")
     ap.add_argument("--only", default="", help="substring of the geometry label, e.g. 'k1 ' or '@160'")
+    ap.add_argument("--res", action="store_true", help="conv2d_res (a residual added behind the activation) on the stride-1 geometries")
     a = ap.parse_args()
     if a.compare:
         A, B = (json.load(open(f)) for f in a.compare)
@@ -66,6 +67,11 @@ def main():
         out = ctx.buf()
         conv = {"silu": K.conv2d_silu, "none": K.conv2d, "relu": lambda *p, **kw: K.conv2d_fused(*p, relu=True, **kw)}[a.act]
         fn = lambda: conv(xt, w, b, [1, 1], grp, [k // 2] * 4, [s, s], out=out, ctx=ctx)
+        if a.res:
+            if s != 1:
+                continue
+            rt = ctx.buf().upload(rng.standard_normal((a.batch, oc, oh, oh)).astype(np.float32))
+            fn = lambda: K.conv2d_res(xt, w, b, rt, [1, 1], grp, [k // 2] * 4, [s, s], act={"silu": 2, "none": 0, "relu": 1}[a.act], out=out, ctx=ctx)
         for _ in range(3):
             fn()
         ctx.sync()

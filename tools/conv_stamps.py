@@ -47,7 +47,7 @@ def main():
         us = ctx.timer_stop() * 1e2
         t = dbg.cpu().numpy().astype(np.float64)
         nchunk = c // 16
-        per_item = 2 * nchunk + 2
+        per_item = 2 * nchunk + 2 + 5   # + e0 .. e4 inside the epilogue
         cons = t[:, 0, :]            # consumer wave 0
         prod = t[:, 4, :]            # loader wave 0
         live = cons[:, 1 + 2 * per_item] > 0
@@ -59,9 +59,11 @@ def main():
             base = 2 + it * per_item
             mult = [cons[:, base + 2 * q] - cons[:, base + 2 * q - 1] for q in range(nchunk)]
             wait = [cons[:, base + 2 * q + 1] - cons[:, base + 2 * q] for q in range(nchunk)]
-            epi = cons[:, base + 2 * nchunk] - cons[:, base + 2 * nchunk - 1]
-            ebar = cons[:, base + 2 * nchunk + 1] - cons[:, base + 2 * nchunk]
-            tot = cons[:, base + 2 * nchunk + 1] - cons[:, base - 1]
+            e = [cons[:, base + 2 * nchunk + k] - cons[:, base + 2 * nchunk + k - 1] for k in range(6)]   # -> e0, e1, e2, e3, e4, out
+            epi = cons[:, base + 2 * nchunk + 5] - cons[:, base + 2 * nchunk - 1]
+            ebar = cons[:, base + 2 * nchunk + 6] - cons[:, base + 2 * nchunk + 5]
+            tot = cons[:, base + 2 * nchunk + 6] - cons[:, base - 1]
+            print("      epilogue: entry %d | bias requested + coordinates %d | LDS turn issued %d | strip 0 out %d | strips 1.. out %d | return %d" % tuple(int(d(x)) for x in e))
             print("    item %d: products issued per chunk %s | barrier waits %s | strips (LDS turn, bias, activation, stores issued) %d | E barrier %d | item total %d"
                   % (it, [int(d(m)) for m in mult], [int(d(w_)) for w_ in wait], d(epi), d(ebar), d(tot)))
         print("  loader wave 0: entry -> D chunks requested %d -> chunk 0 parked %d -> B_0 %d" % (d(prod[:, 1] - prod[:, 0]), d(prod[:, 2] - prod[:, 1]), d(prod[:, 3] - prod[:, 2])))
