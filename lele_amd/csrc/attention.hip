@@ -23,6 +23,7 @@
 // Each workgroup also leaves the {min, max} of what it stored next to the result, one pair per (utterance, head, row block):
 // the output projection's dynamic quantisation needs no range pass (LeleBuf::rowstat kind 2, see quant.hip).
 #include "common.h"
+#include <type_traits>
 #include "lane_ops.h"
 #include "norm_core.h"
 
@@ -633,56 +634,61 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float* vp = a.v + bo * a.v_so + bi * a.v_si + l31;               // V^T: lane = dim 32 d + l31, keys 16 c2 + 4 hv + {0..3, 8..11}
         const int c2 = pw - 2;
         char* const part = fa_lds + (is_k ? pw * 4 : 8 + c2 * 4) * 3072 + lane * 16;
-        float r0[4][8], r1[4][8], r2[4][8];  // three tiles of this wave's fragments: one being split, two in flight
-        auto fetch = [&](float (&r)[4][8], int t) {
-            t = t < nkt ? t : nkt - 1;  // past the end: the last tile again (never stored anywhere a compute wave reads)
-            if (is_k) {
-                int key = 32 * t + l31;
-                key = key < a.tk ? key : a.tk - 1;  // keys beyond the last re-read it: masked in the softmax
-                const float* src = kp + (int64_t)key * a.k_sr;
+        // K producers and V producers run the SAME loop from two instantiations, chosen once: with `if (is_k)` inside fetch() every
+        // request sat under a branch, and behind the merge the compiler's in-order count of loads in flight was gone -- a tile's split
+        // waited vmcnt(0..3), i.e. for the tile requested a moment ago, in four of the six unrolled steps
+        auto produce = [&](auto isk) {
+            constexpr bool IS_K = decltype(isk)::value;
+            float r0[4][8], r1[4][8], r2[4][8];  // three tiles of this wave's fragments: one being split, two in flight
+            auto fetch = [&](float (&r)[4][8], int t) {
+                t = t < nkt ? t : nkt - 1;  // past the end: the last tile again (never stored anywhere a compute wave reads)
+                if constexpr (IS_K) {
+                    int key = 32 * t + l31;
+                    key = key < a.tk ? key : a.tk - 1;  // keys beyond the last re-read it: masked in the softmax
+                    const float* src = kp + (int64_t)key * a.k_sr;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float4 k0 = *reinterpret_cast<const float4*>(src + 16 * c), k1 = *reinterpret_cast<const float4*>(src + 16 * c + 4);
-                    r[c][0] = k0.x, r[c][1] = k0.y, r[c][2] = k0.z, r[c][3] = k0.w, r[c][4] = k1.x, r[c][5] = k1.y, r[c][6] = k1.z, r[c][7] = k1.w;
+                    for (int c = 0; c < 4; ++c) {
+                        const float4 k0 = *reinterpret_cast<const float4*>(src + 16 * c), k1 = *reinterpret_cast<const float4*>(src + 16 * c + 4);
+                        r[c][0] = k0.x, r[c][1] = k0.y, r[c][2] = k0.z, r[c][3] = k0.w, r[c][4] = k1.x, r[c][5] = k1.y, r[c][6] = k1.z, r[c][7] = k1.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        int key = 32 * t + 16 * c2 + 4 * hv + (e & 3) + 8 * (e >> 2);
+                        key = key < a.tk ? key : a.tk - 1;
+                        const float* src = vp + (int64_t)key * a.v_sr;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) r[d][e] = src[32 * d];
+                    }
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    int key = 32 * t + 16 * c2 + 4 * hv + (e & 3) + 8 * (e >> 2);
-                    key = key < a.tk ? key : a.tk - 1;
-                    const float* src = vp + (int64_t)key * a.v_sr;
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) r[d][e] = src[32 * d];
-                }
-            }
-        };
-        auto put = [&](const float (&r)[4][8], int stage) {
+            };
+            auto put = [&](const float (&r)[4][8], int stage) {
 #ifdef LELE_HIP_LAB
-            if (a.ablate & 4) return;
+                if (a.ablate & 4) return;
 #endif
-            char* dst = part + stage * FA_STAGE;
+                char* dst = part + stage * FA_STAGE;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const Split3 sp = split3(r[f]);
-                *reinterpret_cast<u32x4*>(dst + f * 3072) = sp.h;
-                *reinterpret_cast<u32x4*>(dst + f * 3072 + 1024) = sp.m;
-                *reinterpret_cast<u32x4*>(dst + f * 3072 + 2048) = sp.l;
-            }
-        };
-        FA_STAMP(0);
-        // tile 0 alone first: every workgroup of the grid starts at once, and what they ask for in their first microsecond is
-        // served at HBM speed -- Q and the first tile are all the first product needs (stamps: with three tiles requested up
-        // front the first operand reached LDS 14 k cycles into a 50 k cycle kernel)
-        fetch(r0, 0);
-        FA_STAMP(1);
-        put(r0, 0);
-        fetch(r1, 1);
-        fetch(r2, 2);
-        FA_STAMP(2);
-        barrier();  // stage 0 holds tile 0
-        FA_STAMP(3);
-        // tile t (compute waves on stage t & 1): refill the registers tile t came from with tile t + 3, split tile t + 1 into
-        // the other stage (its loads were issued two tiles ago).  Past the end the clamped tile lands where nobody reads.
+                for (int f = 0; f < 4; ++f) {
+                    const Split3 sp = split3(r[f]);
+                    *reinterpret_cast<u32x4*>(dst + f * 3072) = sp.h;
+                    *reinterpret_cast<u32x4*>(dst + f * 3072 + 1024) = sp.m;
+                    *reinterpret_cast<u32x4*>(dst + f * 3072 + 2048) = sp.l;
+                }
+            };
+            FA_STAMP(0);
+            // tile 0 alone first: every workgroup of the grid starts at once, and what they ask for in their first microsecond is
+            // served at HBM speed -- Q and the first tile are all the first product needs (stamps: with three tiles requested up
+            // front the first operand reached LDS 14 k cycles into a 50 k cycle kernel)
+            fetch(r0, 0);
+            FA_STAMP(1);
+            put(r0, 0);
+            fetch(r1, 1);
+            fetch(r2, 2);
+            FA_STAMP(2);
+            barrier();  // stage 0 holds tile 0
+            FA_STAMP(3);
+            // tile t (compute waves on stage t & 1): refill the registers tile t came from with tile t + 3, split tile t + 1 into
+            // the other stage (its loads were issued two tiles ago).  Past the end the clamped tile lands where nobody reads.
 #define LELE_FA_STEP(FREE_, NEXT_, STAGE_) \
     {                                      \
         fetch(FREE_, t + 3);               \
@@ -693,15 +699,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         FA_STAMP(6 + 3 * t);               \
         if (++t >= nkt) break;             \
     }
-        for (int t = 0;;) {
-            LELE_FA_STEP(r0, r1, 1)
-            LELE_FA_STEP(r1, r2, 0)
-            LELE_FA_STEP(r2, r0, 1)
-            LELE_FA_STEP(r0, r1, 0)
-            LELE_FA_STEP(r1, r2, 1)
-            LELE_FA_STEP(r2, r0, 0)
-        }
+            for (int t = 0;;) {
+                LELE_FA_STEP(r0, r1, 1)
+                LELE_FA_STEP(r1, r2, 0)
+                LELE_FA_STEP(r2, r0, 1)
+                LELE_FA_STEP(r0, r1, 0)
+                LELE_FA_STEP(r1, r2, 1)
+                LELE_FA_STEP(r2, r0, 0)
+            }
 #undef LELE_FA_STEP
+        };
+        if (is_k) produce(std::true_type{});
+        else produce(std::false_type{});
         return;
     }
     // ---------------------------------------------------------------- a compute wave: 32 query rows of the head
