@@ -857,21 +857,45 @@ class Runner:
                 f = getattr(K, fn)
                 self.calls += 1
                 try:
-                    if self.stmt_times is not None:   # per-statement device time: HIP events on the ctx stream (lele_hip_timer_*)
-                        ctx.timer_start()
                     t0 = time.perf_counter() if self.profile is not None else 0.0
-                    if "window" in st:   # the result is a channel window of an already reserved tensor (fold_channel_views)
-                        whole = env[st["window"]["of"]]
-                        d = whole.raw()
-                        inner = int(np.prod(d.shape[2:], dtype=np.int64))
-                        res = f(*pos, out=d.buf, out_window=(d.offset + st["window"]["c0"] * inner, d.pitch or d.shape[1] * inner), ctx=ctx)
-                    else:
-                        res = self.call(f, fn, pos, bufs, key=st["out"][0] + str(self.stmt_index), may_alias=bool(st.get("may_alias")))
-                        if self.stmt_times is not None:
-                            for _ in range(self.stmt_repeat - 1):   # pure functions of their operands: the same result again
-                                self.call(f, fn, pos, bufs, key=st["out"][0] + str(self.stmt_index), may_alias=bool(st.get("may_alias")))
+
+                    def issue():
+                        if "window" in st:   # the result is a channel window of an already reserved tensor (fold_channel_views)
+                            whole = env[st["window"]["of"]]
+                            d = whole.raw()
+                            inner = int(np.prod(d.shape[2:], dtype=np.int64))
+                            return f(*pos, out=d.buf, out_window=(d.offset + st["window"]["c0"] * inner, d.pitch or d.shape[1] * inner), ctx=ctx)
+                        return self.call(f, fn, pos, bufs, key=st["out"][0] + str(self.stmt_index), may_alias=bool(st.get("may_alias")))
+
+                    res = issue()
                     if self.stmt_times is not None:
-                        self.stmt_times.append((self.stmt_index, fn, st["out"][0], ctx.timer_stop() / (self.stmt_repeat if "window" not in st else 1)))
+                        # per-statement DEVICE time: the statement (a pure function of its operands: the same result again) recorded
+                        # `stmt_repeat` times into a hipGraph whose replay is timed with HIP events -- a train issued from here reads as
+                        # the host's issue rate for anything shorter than ~40 us (a 20 us convolution as 45), which is what the lane
+                        # scheduler would then plan with.  Statements that cannot be recorded (they allocate or synchronise) keep the train.
+                        ms = None
+                        if self.stmt_repeat > 1:
+                            try:
+                                ctx.sync()
+                                ctx.graph_begin()
+                                for _ in range(self.stmt_repeat):
+                                    issue()
+                                g = ctx.graph_end()
+                                g.launch()
+                                ctx.sync()
+                                ctx.timer_start()
+                                g.launch()
+                                ms = ctx.timer_stop() / self.stmt_repeat
+                                g.close()
+                            except Exception:  # noqa: BLE001
+                                ctx.graph_abort()   # (a no-op outside capture)
+                                ms = None
+                        if ms is None:
+                            ctx.timer_start()
+                            for _ in range(self.stmt_repeat):
+                                issue()
+                            ms = ctx.timer_stop() / self.stmt_repeat
+                        self.stmt_times.append((self.stmt_index, fn, st["out"][0], ms))
                     if self.profile is not None:
                         ctx.sync()
                         self.profile[fn] = self.profile.get(fn, 0.0) + time.perf_counter() - t0
