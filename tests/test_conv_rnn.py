@@ -372,6 +372,34 @@ def test_batched_convolution_kernels_agree_with_single_image_calls(ctx):
 
 
 @pytest.mark.gpu
+def test_window_kernels_are_deterministic_and_the_residual_is_the_conv_plus_add(ctx):
+    """The window kernels hand LDS stages between loader and multiplying waves at raw s_barriers.  Until round 6 nothing waited for a
+    wave's own ds_writes in front of such a barrier: a parked chunk could still be on its way into LDS when the stage changed hands --
+    it showed as one tile 3e-6 off in one run of two (256 -> 64 channels 1 x 1 at 80 x 80 x 64) once the epilogue's timing moved.  Deep
+    1 x 1 layers on large planes, several runs each: conv2d_res must be conv2d_silu followed by add BIT FOR BIT, and a second run of the
+    same call must reproduce the first (both are exact statements about one summation order)."""
+    from lele_amd import kernels as K
+    from lele_amd._lib import Weight
+    rng = np.random.default_rng(6)
+    for n, c, oc, k, hw in ((64, 256, 64, 1, 80), (64, 96, 64, 1, 80), (64, 64, 64, 3, 40), (32, 128, 128, 1, 40)):
+        x = ctx.buf().upload(rng.standard_normal((n, c, hw, hw)).astype(np.float32))
+        r = ctx.buf().upload(rng.standard_normal((n, oc, hw, hw)).astype(np.float32))
+        w = Weight((rng.standard_normal((oc, c, k, k)) * 0.1).astype(np.float32))
+        b = Weight(rng.standard_normal(oc).astype(np.float32))
+        args = ([1, 1], 1, [k // 2] * 4, [1, 1])
+        first = None
+        for rep in range(3):
+            y = K.conv2d_silu(x, w, b, *args, out=ctx.buf(), ctx=ctx)
+            want = K.add(y, r, out=ctx.buf(), ctx=ctx).numpy()
+            got = K.conv2d_res(x, w, b, r, *args, act=2, out=ctx.buf(), ctx=ctx).numpy()
+            assert np.array_equal(want, got), "conv2d_res != conv2d_silu + add: %d -> %d k%d at %d x %d x %d, run %d: %d elements, max |d| %.3g" % (
+                c, oc, k, hw, hw, n, rep, int((want != got).sum()), float(np.abs(want - got).max()))
+            if first is None:
+                first = got
+            assert np.array_equal(first, got), "run %d differs from run 0: %d -> %d k%d" % (rep, c, oc, k)
+
+
+@pytest.mark.gpu
 def test_device_conv1d(ctx):
     from lele_amd import kernels as K
     y = K.conv1d(np.ones((1, 2, 3), np.float32), np.ones((2, 1, 1), np.float32), None, [1], 2, [0, 0], [1], ctx=ctx)
