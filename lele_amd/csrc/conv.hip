@@ -1395,8 +1395,9 @@ inline int w1_max_oc() { static const int v = conv_env("LELE_HIP_CONV_W1_MAXOC",
 inline int w1_min_plane() { static const int v = conv_env("LELE_HIP_CONV_W1_MINPLANE", 400); return v; }
 // <= 16 output channels: the direct kernel multiplies on the vector pipe (C x 9 x OC FMAs a pixel), so from 32 input channels on a
 // half-empty MFMA tile is faster for 9-16 output channels (at batch 64: 32 -> 16 at 80 x 80 85 -> 70 us, 64 -> 16 at 40 x 40 79 -> 32;
-// 32 -> 8 at 80 x 80 stays direct: 62 against 67)
-inline int win_min_c_narrow() { static const int v = conv_env("LELE_HIP_CONV_WIN_NARROW_MINC", 32); return v; }
+// 32 -> 8 at 80 x 80 stays direct: 62 against 67).  Round 6, after the window kernels' loaders and epilogue changed: from 16 input channels on
+// (the 16 -> 16 layers of the reference graph): the graph at batch 64 7.87 -> 7.74 ms linear, three interleaved pairs
+inline int win_min_c_narrow() { static const int v = conv_env("LELE_HIP_CONV_WIN_NARROW_MINC", 16); return v; }
 inline int w1_min_c() { static const int v = conv_env("LELE_HIP_CONV_W1_MINC", 32); return v; }
 
 // out += res, image by image: the residual of lele_hip_conv2d_res behind the depthwise kernels (which have their own epilogues);
