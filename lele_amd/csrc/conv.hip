@@ -1397,6 +1397,8 @@ inline int w1_min_plane() { static const int v = conv_env("LELE_HIP_CONV_W1_MINP
 // half-empty MFMA tile is faster for 9-16 output channels (at batch 64: 32 -> 16 at 80 x 80 85 -> 70 us, 64 -> 16 at 40 x 40 79 -> 32;
 // 32 -> 8 at 80 x 80 stays direct: 62 against 67).  Round 6, after the window kernels' loaders and epilogue changed: from 16 input channels on
 // (the 16 -> 16 layers of the reference graph): the graph at batch 64 7.87 -> 7.74 ms linear, three interleaved pairs
+// and from 5 output channels on (win_min_oc_narrow: 32 -> 8 at 80 x 80 69 -> 51 us, 16 -> 8 at 160 x 160 104 -> 98)
+inline int win_min_oc_narrow() { static const int v = conv_env("LELE_HIP_CONV_WIN_NARROW_MINOC", 4); return v; }
 inline int win_min_c_narrow() { static const int v = conv_env("LELE_HIP_CONV_WIN_NARROW_MINC", 16); return v; }
 inline int w1_min_c() { static const int v = conv_env("LELE_HIP_CONV_W1_MINC", 32); return v; }
 
@@ -1508,7 +1510,7 @@ int run_conv2d(LeleCtx* ctx, const LeleTensor* wt, const float* dx, const float*
                 // 1 x 1: where it measured faster than the tiled GEMM on the Yolo-shaped network at batch 64 (w1_max_oc() and friends above)
                 (g.kh == 1 && g.kw == 1 && g.pt == 0 && g.pl == 0 && g.oh == g.ih && g.ow == g.iw && g.oc <= w1_max_oc() && g.plane >= w1_min_plane() &&
                  g.c >= w1_min_c())) &&
-               g.dh == 1 && g.dw == 1 && g.sh == 1 && g.sw == 1 && g.c % 16 == 0 && (g.oc > 16 || (g.oc > 8 && g.c >= win_min_c_narrow())) && g.ow >= 16 && g.n <= 65535 &&
+               g.dh == 1 && g.dw == 1 && g.sh == 1 && g.sw == 1 && g.c % 16 == 0 && (g.oc > 16 || (g.oc > win_min_oc_narrow() && g.c >= win_min_c_narrow())) && g.ow >= 16 && g.n <= 65535 &&
                (int64_t)g.c * g.ih * g.iw < (int64_t(1) << 31) &&
                (int64_t)g.n * ((g.oc + 63) / 64) * (((int64_t)g.plane + 255) / 256) >= (int64_t)ctx->num_cus / 2) {
         // stride 1 over a batch, 16-channel chunks: the window-once MFMA kernel (see conv_window_p_kernel); 32-channel blocks when that
